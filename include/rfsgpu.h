@@ -1,0 +1,210 @@
+/*
+ * rfsgpu.h -- C ABI of the MI355X-native RB-PHD SLAM update engine.
+ *
+ * This is the drop-in boundary for ONE hot path of kykleung/RFS-SLAM: the per-particle
+ * Gaussian-mixture PHD map update + particle weighting + GM merge/prune that runs inside
+ * rfs::RBPHDFilter<...>::update() (reference include/RBPHDFilter.hpp:444-541), plus the few
+ * map-side pieces either side of it (static landmark predict + birth Gaussians, resample copy).
+ *
+ * The reference has no FFI / plugin registry; the surface a replacement has to sit behind is the
+ * public interface of the RBPHDFilter class template (include/RBPHDFilter.hpp:72-251) and what it
+ * inherits from ParticleFilter (include/ParticleFilter.hpp:72-186).  Every entry point below
+ * names the reference member it replaces.  INTEGRATION.md shows the binding a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - plain C, opaque handle, int status returns (0 = RFSGPU_OK), no exceptions / STL / torch types.
+ *   - all host buffers are caller-owned; the engine owns its device memory (one handle == one GPU,
+ *     one host thread per handle, one process per GPU).
+ *   - everything is fp64; matrices are row-major; d_m = landmark dim, d_z = measurement dim
+ *     (both 2 for RFSGPU_MODEL_RNGBRG_2D).
+ *   - "slot" = particle index 0..n_particles-1.
+ *   - the engine fails loudly: there is NO CPU fallback anywhere behind this ABI.
+ */
+#ifndef RFSGPU_H
+#define RFSGPU_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RFSGPU_ABI_VERSION 1
+
+/* Maximum measurements per update() (one 64-bit association mask per landmark). */
+#define RFSGPU_MAX_Z 64
+/* Maximum evaluation points for the multi-feature particle weight. */
+#define RFSGPU_MAX_EVAL 64
+
+typedef struct rfsgpu_filter rfsgpu_filter;
+
+enum rfsgpu_status {
+  RFSGPU_OK = 0,
+  RFSGPU_ERR_INVALID = 1,     /* bad argument / bad index                                      */
+  RFSGPU_ERR_HIP = 2,         /* a HIP runtime call failed (rfsgpu_last_error has the string)  */
+  RFSGPU_ERR_CAPACITY = 3,    /* a particle's Gaussian mixture outgrew gm_capacity             */
+  RFSGPU_ERR_NO_DEVICE = 4,   /* no gfx950 device visible                                      */
+  RFSGPU_ERR_UNSUPPORTED = 5  /* configuration outside what the device path implements         */
+};
+
+enum rfsgpu_model {
+  RFSGPU_MODEL_RNGBRG_2D = 0  /* MeasurementModel_RngBrg + KalmanFilter_RngBrg + Landmark2d    */
+};
+
+/* Mirrors RBPHDFilter::Config, include/RBPHDFilter.hpp:90-146 (same meaning, same defaults
+ * :370-382 when filled by rfsgpu_default_filter_config). */
+typedef struct rfsgpu_filter_config {
+  double birthGaussianWeight;
+  unsigned int birthGaussianMeasurementCountThreshold;
+  unsigned int birthGaussianMeasurementCheckThreshold;
+  double birthGaussianMeasurementSupportDist;
+  unsigned int birthGaussianCurrentMeasurementCountThreshold;
+  double newGaussianCreateInnovMDThreshold;
+  int importanceWeightingEvalPointCount;          /* -1 => all (reference :737 unsigned compare) */
+  double importanceWeightingEvalPointGuassianWeight;
+  double importanceWeightingMeasurementLikelihoodMDThreshold;
+  double gaussianMergingThreshold;
+  double gaussianMergingCovarianceInflationFactor;
+  double gaussianPruningThreshold;
+  int minUpdatesBeforeResample;
+  int minMeasurementsBeforeResample;
+  int useClusterProcess;                          /* bool in the reference */
+} rfsgpu_filter_config;
+
+/* Mirrors MeasurementModel_RngBrg::Config (include/MeasurementModel_RngBrg.hpp:65-71) plus the
+ * additive noise R set through MeasurementModel::setNoise (src/rbphdslam2dSim.cpp:466-469). */
+typedef struct rfsgpu_rngbrg_config {
+  double R[4];                     /* 2x2 row-major measurement covariance */
+  double probabilityOfDetection;
+  double uniformClutterIntensity;
+  double rangeLimMax;
+  double rangeLimMin;
+  double rangeLimBuffer;
+} rfsgpu_rngbrg_config;
+
+/* Mirrors KalmanFilter_RngBrg::Config (include/KalmanFilter_RngBrg.hpp:55-60). <=0 disables. */
+typedef struct rfsgpu_kf_config {
+  double rangeInnovationThreshold;
+  double bearingInnovationThreshold;
+} rfsgpu_kf_config;
+
+/* Mirrors RBPHDFilter::TimingInfo (include/RBPHDFilter.hpp:152-167), nanoseconds, accumulated.
+ * *_wall come from HIP events around each phase's kernels; *_cpu is the host time spent inside
+ * the corresponding ABI calls (launch + sync). */
+typedef struct rfsgpu_timing {
+  long long predict_wall, predict_cpu;
+  long long mapUpdate_wall, mapUpdate_cpu;
+  long long mapUpdate_kf_wall, mapUpdate_kf_cpu;
+  long long particleWeighting_wall, particleWeighting_cpu;
+  long long mapMerge_wall, mapMerge_cpu;
+  long long mapPrune_wall, mapPrune_cpu;
+  long long particleResample_wall, particleResample_cpu;
+} rfsgpu_timing;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+
+/* ABI version of the loaded library (== RFSGPU_ABI_VERSION). */
+int rfsgpu_abi_version(void);
+
+/* Replaces the RBPHDFilter constructor (include/RBPHDFilter.hpp:350-393): n_particles particles
+ * of weight 1, pose 0, empty maps, default config.  device_id: HIP ordinal.  gm_capacity: per-particle
+ * Gaussian slots (rounded up to a multiple of 64); must cover the transient size right after the
+ * map update (nM + new Gaussians).  Exceeding it sets RFSGPU_ERR_CAPACITY, never corrupts memory. */
+int rfsgpu_create(rfsgpu_filter **out, int model, int n_particles, int device_id, int gm_capacity);
+/* Replaces ~RBPHDFilter (:395-403). */
+void rfsgpu_destroy(rfsgpu_filter *f);
+/* Human-readable text for the last non-OK status on this handle (never NULL). */
+const char *rfsgpu_last_error(const rfsgpu_filter *f);
+
+/* ---- configuration (the three public config structs of the reference) ---------------------- */
+
+void rfsgpu_default_filter_config(rfsgpu_filter_config *cfg);            /* RBPHDFilter.hpp:370-382 */
+int rfsgpu_set_filter_config(rfsgpu_filter *f, const rfsgpu_filter_config *cfg);   /* filter.config.* */
+int rfsgpu_get_filter_config(const rfsgpu_filter *f, rfsgpu_filter_config *cfg);
+int rfsgpu_set_model_rngbrg(rfsgpu_filter *f, const rfsgpu_rngbrg_config *cfg);    /* getMeasurementModel()->config / setNoise */
+int rfsgpu_set_kf_config(rfsgpu_filter *f, const rfsgpu_kf_config *cfg);           /* getKalmanFilter()->config */
+/* getLmkProcessModel()->setNoise(Q) (include/ProcessModel.hpp:195-208); Q is d_m x d_m. */
+int rfsgpu_set_lmk_process_noise(rfsgpu_filter *f, const double *Q);
+
+/* ---- particle state crossing the boundary --------------------------------------------------- */
+
+/* Poses after the host-side ParticleFilter::propagate / setParticlePose
+ * (include/ParticleFilter.hpp:322-341, RBPHDFilter.hpp:1181-1186).  x: 3 doubles per particle
+ * (x, y, theta).  cov: 3x3 pose covariance (enters S, src/MeasurementModel_RngBrg.cpp:102);
+ * cov_stride = 0 -> one shared 3x3 (or cov==NULL -> zero), 9 -> one per particle. */
+int rfsgpu_set_poses(rfsgpu_filter *f, const double *x, const double *cov, int cov_stride);
+int rfsgpu_get_poses(rfsgpu_filter *f, double *x);
+/* Particle::setWeight / getWeight (include/Particle.hpp), n_particles doubles. */
+int rfsgpu_set_weights(rfsgpu_filter *f, const double *w);
+int rfsgpu_get_weights(rfsgpu_filter *f, double *w);
+
+/* ---- map access (getGMSize / getLandmark, RBPHDFilter.hpp:1152-1178) + state injection ------ */
+
+int rfsgpu_gm_size(rfsgpu_filter *f, int slot);                        /* -1 on bad index */
+/* returns RFSGPU_OK, or RFSGPU_ERR_INVALID on a bad index (reference returns false). */
+int rfsgpu_get_landmark(rfsgpu_filter *f, int slot, int m, double *mean, double *cov, double *w);
+/* Replace particle `slot`'s mixture with n Gaussians (GaussianMixture::addGaussian order). */
+int rfsgpu_import_gm(rfsgpu_filter *f, int slot, int n, const double *w, const double *mean, const double *cov);
+/* Copy out up to max_n Gaussians in storage order; *n_out = mixture size.  w_prev may be NULL. */
+int rfsgpu_export_gm(rfsgpu_filter *f, int slot, int max_n, int *n_out, double *w, double *w_prev,
+                     double *mean, double *cov);
+/* All mixture sizes at once (n_particles ints). */
+int rfsgpu_gm_sizes(rfsgpu_filter *f, int *sizes);
+
+/* ---- the hot path --------------------------------------------------------------------------- */
+
+/* Map part of RBPHDFilter::predict (:415-442): if add_birth, addBirthGaussians (:1000-1084) from
+ * the previous update's measurements / unused lists at the CURRENT (pre-propagation) poses, then
+ * StaticProcessModel::staticStep (Sigma += Q) on every Gaussian (:433-439). */
+int rfsgpu_predict_map(rfsgpu_filter *f, int add_birth);
+
+/* The particle-parallel body of RBPHDFilter::update (:444-523): updateMap, importanceWeighting
+ * (unless useClusterProcess), merge, prune.  z: n_z x d_z doubles.  n_z == 0 returns OK without
+ * touching anything (:450-452).  Resampling / normalisation stay with the caller (below). */
+int rfsgpu_update(rfsgpu_filter *f, const double *z, int n_z);
+/* The same four phases one at a time (used by the parity tests and by profiling):          */
+int rfsgpu_update_map(rfsgpu_filter *f, const double *z, int n_z);      /* updateMap       :543-725 */
+int rfsgpu_importance_weighting(rfsgpu_filter *f);                       /* importanceWeighting :728-997 */
+int rfsgpu_merge(rfsgpu_filter *f);                                      /* GaussianMixture::merge  GaussianMixture.hpp:394-475 */
+int rfsgpu_prune(rfsgpu_filter *f);                                      /* GaussianMixture::prune  :477-534 */
+
+/* unused_measurements_[slot] (:709-720) as indices in ascending order; returns count via *n_out. */
+int rfsgpu_get_unused(rfsgpu_filter *f, int slot, int *idx, int max_n, int *n_out);
+/* nLandmarksInFOV_[slot] (:601-613). */
+int rfsgpu_landmarks_in_fov(rfsgpu_filter *f, int slot, int *n_out);
+
+/* ---- weight normalisation / resampling (ParticleFilter.hpp:352-363, 399-492) ---------------- */
+
+/* Device reduction of this shard's {sum w, sum w^2}; out[2] on the host. */
+int rfsgpu_weight_sums(rfsgpu_filter *f, double *out);
+/* Device pointer to the same two doubles (valid after rfsgpu_weight_sums_async) so a multi-GPU
+ * host can all-reduce them in place over RCCL without a host round trip. */
+int rfsgpu_weight_sums_async(rfsgpu_filter *f);
+void *rfsgpu_weight_sums_device_ptr(rfsgpu_filter *f);
+/* w_i /= sum (sum = global sum over all shards).  If sum_dev != NULL the divisor is read on the
+ * device from sum_dev[0] (after an in-place all-reduce) and `sum` is ignored. */
+int rfsgpu_normalize_weights(rfsgpu_filter *f, double sum, const void *sum_dev);
+/* Apply a resampling decision: slot k takes a deep copy of slot src_slot[k]'s map, unused list and
+ * FOV count (Particle::copy -> GaussianMixture copy-ctor); src_slot[k] == k keeps it.  All weights
+ * are reset to 1 (ParticleFilter.hpp:486-489).  Sources must be slots that keep themselves. */
+int rfsgpu_resample_apply(rfsgpu_filter *f, const int *src_slot);
+
+/* ---- timing / misc ---------------------------------------------------------------------------- */
+
+int rfsgpu_get_timing(rfsgpu_filter *f, rfsgpu_timing *t);              /* getTimingInfo :1219-1232 */
+int rfsgpu_reset_timing(rfsgpu_filter *f);
+/* Block until all queued device work of this handle is complete. */
+int rfsgpu_synchronize(rfsgpu_filter *f);
+/* Native HIP stream of this handle (hipStream_t as void*), for callers that enqueue around it. */
+void *rfsgpu_stream(rfsgpu_filter *f);
+/* Duration in ns of the most recent launch of each hot-path kernel, from HIP events on the
+ * engine's stream: [0]=phd_update_map [1]=phd_weight_multifeature [2]=gm_merge [3]=gm_prune. */
+int rfsgpu_last_kernel_ns(rfsgpu_filter *f, long long *ns4);
+
+/* MatPerm::calc (src/MatrixPermanent.cpp:41-112), batched: `batch` row-major n x n matrices in A
+ * (host), permanents to out (host).  n <= 24.  Standalone (no filter handle needed). */
+int rfsgpu_mat_perm(const double *A, int n, int batch, double *out, int device_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RFSGPU_H */

@@ -1,0 +1,1350 @@
+/*
+ * rbphd_oracle.cpp -- CPU restatement of the RB-PHD update hot path of kykleung/RFS-SLAM.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as the
+ * checker / the timed CPU baseline.  The product path (rfs-slam_amd/) never links, imports or calls it.
+ *
+ * PARITY PIN STATUS (see DESIGN.md "Oracle"): the reference needs Eigen3 + Boost, neither of which
+ * exists in this image, and stand-in headers are not allowed, so the reference filter itself is
+ * UNBUILDABLE here.  What IS pinned against the reference:
+ *   - mat_perm            : the reference's own known-answer test (test/MatrixPermanentTest.hpp:55-87),
+ *   - PermutationLexicographic restatement : the reference's own src/PermutationLexicographic.cpp compiled
+ *     from /root/reference into oracle/_ref (oracle/Makefile), compared sequence-for-sequence,
+ *   - Hungarian / Murty k-best scores : the reference's own src/BruteForceAssignment.cpp (its example
+ *     checker for Murty, src/examples/linearAssignment_MurtyAlgorithm.cpp:99-130) compiled into oracle/_ref.
+ * Everything else (updateMap, KF correct, RngBrg model, importanceWeighting, CostMatrixGeneral partition,
+ * merge, prune, resample) is a line-by-line restatement with NO reference-produced golden vectors:
+ * "parity unpinned" for those rows; they are cross-checked only against independent numpy/scipy
+ * formulations in tests/.
+ *
+ * Each function cites the reference file:line it follows (paths relative to /root/reference).
+ * Arithmetic follows the reference's expression order (Eigen fixed-size closed forms written out).
+ */
+#include <algorithm>
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <queue>
+#include <string>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/rfsgpu.h"
+
+namespace orc {
+
+static const double PI = acos(-1); /* include/RandomVec.hpp:55 */
+
+/* ------------------------------------------------------------------------------------------------
+ * 2x2 / 2x3 algebra, written the way Eigen's fixed-size expression templates evaluate it
+ * (coefficient (i,j) = sum over k in ascending order; nested products evaluated into temporaries).
+ * ---------------------------------------------------------------------------------------------- */
+struct M2 { double a[4]; double &operator()(int i, int j) { return a[2 * i + j]; } double operator()(int i, int j) const { return a[2 * i + j]; } };
+struct V2 { double a[2]; };
+
+static inline M2 mul(const M2 &A, const M2 &B) {
+  M2 C;
+  for (int i = 0; i < 2; i++)
+    for (int j = 0; j < 2; j++) C(i, j) = A(i, 0) * B(0, j) + A(i, 1) * B(1, j);
+  return C;
+}
+static inline M2 mulT(const M2 &A, const M2 &B) { /* A * B^T */
+  M2 C;
+  for (int i = 0; i < 2; i++)
+    for (int j = 0; j < 2; j++) C(i, j) = A(i, 0) * B(j, 0) + A(i, 1) * B(j, 1);
+  return C;
+}
+static inline double det2(const M2 &m) { return m(0, 0) * m(1, 1) - m(1, 0) * m(0, 1); } /* Eigen determinant_impl<.,2> */
+static inline M2 inv2(const M2 &m) { /* Eigen compute_inverse_size2_helper */
+  double invdet = 1.0 / det2(m);
+  M2 r;
+  r(0, 0) = m(1, 1) * invdet;
+  r(1, 0) = -m(1, 0) * invdet;
+  r(0, 1) = -m(0, 1) * invdet;
+  r(1, 1) = m(0, 0) * invdet;
+  return r;
+}
+
+/* A Gaussian of the mixture: GaussianMixture<Landmark2d>::Gaussian (include/GaussianMixture.hpp:60-64).
+ * valid == (landmark != NULL). */
+struct Gauss {
+  bool valid;
+  double w, w_prev;
+  double x[2];
+  M2 S;
+};
+
+/* RandomVec<2>::mahalanobisDist2 (include/RandomVec.hpp:387-394): e = to - x; e^T * Sinv * e,
+ * evaluated as (e^T * Sinv) * e. */
+static inline double md2_2(const double x[2], const M2 &Sinv, const double to[2]) {
+  double e0 = to[0] - x[0], e1 = to[1] - x[1];
+  double t0 = e0 * Sinv(0, 0) + e1 * Sinv(1, 0);
+  double t1 = e0 * Sinv(0, 1) + e1 * Sinv(1, 1);
+  return t0 * e0 + t1 * e1;
+}
+/* RandomVec<2>::evalGaussianLikelihood (include/RandomVec.hpp:417-434). */
+static inline double gauss_lik2(const double x[2], const M2 &S, const double at[2], double *md2_out) {
+  double det = det2(S);
+  double factor = sqrt(pow(2 * PI, 2) * det);
+  M2 Sinv = inv2(S);
+  double md2 = md2_2(x, Sinv, at);
+  double l = exp(-0.5 * md2) / factor;
+  if (l != l) l = 0;
+  if (md2_out) *md2_out = md2;
+  return l;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * MeasurementModel_RngBrg  (src/MeasurementModel_RngBrg.cpp)
+ * ---------------------------------------------------------------------------------------------- */
+struct Pose {
+  double x[3];
+  double P[9]; /* 3x3 row-major covariance */
+};
+
+/* measure(): src/MeasurementModel_RngBrg.cpp:70-115.  Returns false outside [rmin, rmax] (:111). */
+static bool rb_measure(const rfsgpu_rngbrg_config &M, const Pose &pose, const double lx[2], const M2 &lS,
+                       double z[2], M2 &S, M2 *Hout) {
+  double dx = lx[0] - pose.x[0], dy = lx[1] - pose.x[1];
+  double range2 = pow(dx, 2) + pow(dy, 2);
+  double range = sqrt(range2);
+  double bearing = atan2(dy, dx) - pose.x[2];
+  while (bearing > PI) bearing -= 2 * PI;
+  while (bearing < -PI) bearing += 2 * PI;
+  z[0] = range;
+  z[1] = bearing;
+  M2 H;
+  H(0, 0) = dx / range;   H(0, 1) = dy / range;
+  H(1, 0) = -dy / range2; H(1, 1) = dx / range2;
+  double Hr[2][3] = {{-dx / range, -dy / range, 0}, {dy / range2, -dx / range2, -1}};
+  /* cov = H_lmk * Sl * H_lmk^T + H_robot * Sp * H_robot^T + R   (:102) */
+  M2 A = mulT(mul(H, lS), H);
+  double T[2][3];
+  for (int i = 0; i < 2; i++)
+    for (int j = 0; j < 3; j++) T[i][j] = Hr[i][0] * pose.P[0 * 3 + j] + Hr[i][1] * pose.P[1 * 3 + j] + Hr[i][2] * pose.P[2 * 3 + j];
+  M2 B;
+  for (int i = 0; i < 2; i++)
+    for (int j = 0; j < 2; j++) B(i, j) = T[i][0] * Hr[j][0] + T[i][1] * Hr[j][1] + T[i][2] * Hr[j][2];
+  for (int k = 0; k < 4; k++) S.a[k] = (A.a[k] + B.a[k]) + M.R[k];
+  if (Hout) *Hout = H;
+  if (range > M.rangeLimMax || range < M.rangeLimMin) return false;
+  return true;
+}
+
+/* inverseMeasure(): src/MeasurementModel_RngBrg.cpp:117-136. */
+static void rb_inverse_measure(const rfsgpu_rngbrg_config &M, const Pose &pose, const double z[2], double lx[2], M2 &lS) {
+  double a = pose.x[2] + z[1];
+  lx[0] = pose.x[0] + z[0] * cos(a);
+  lx[1] = pose.x[1] + z[0] * sin(a);
+  M2 Hinv;
+  Hinv(0, 0) = cos(a); Hinv(0, 1) = -z[0] * sin(a);
+  Hinv(1, 0) = sin(a); Hinv(1, 1) = z[0] * cos(a);
+  M2 R;
+  memcpy(R.a, M.R, sizeof(R.a));
+  lS = mulT(mul(Hinv, R), Hinv);
+}
+
+/* probabilityOfDetection(): src/MeasurementModel_RngBrg.cpp:138-167. */
+static double rb_pd(const rfsgpu_rngbrg_config &M, const Pose &pose, const double lx[2], bool &close) {
+  close = false;
+  double range = sqrt(pow(lx[0] - pose.x[0], 2) + pow(lx[1] - pose.x[1], 2));
+  double Pd;
+  if (range <= M.rangeLimMax && range >= M.rangeLimMin) {
+    Pd = M.probabilityOfDetection;
+    if (range >= (M.rangeLimMax - M.rangeLimBuffer) || range <= (M.rangeLimMin + M.rangeLimBuffer)) close = true;
+  } else {
+    Pd = 0;
+    if (range <= (M.rangeLimMax + M.rangeLimBuffer) && range >= (M.rangeLimMin - M.rangeLimBuffer)) close = true;
+  }
+  return Pd;
+}
+/* clutterIntensity (:169-172) and clutterIntensityIntegral (:175-178). */
+static inline double rb_clutter(const rfsgpu_rngbrg_config &M) { return M.uniformClutterIntensity; }
+static inline double rb_clutter_integral(const rfsgpu_rngbrg_config &M) {
+  double sensingArea = 2 * PI * (M.rangeLimMax - M.rangeLimMin);
+  return M.uniformClutterIntensity * sensingArea;
+}
+
+/* KalmanFilter_RngBrg::calculateInnovation: src/KalmanFilter_RngBrg.cpp:52-65 (range gate BEFORE wrap). */
+static bool rb_innovation(const rfsgpu_kf_config &K, const double z_exp[2], const double z_act[2], double nu[2]) {
+  nu[0] = z_act[0] - z_exp[0];
+  nu[1] = z_act[1] - z_exp[1];
+  if (K.rangeInnovationThreshold > 0 && fabs(nu[0]) > K.rangeInnovationThreshold) return false;
+  while (nu[1] > PI) nu[1] -= 2 * PI;
+  while (nu[1] < -PI) nu[1] += 2 * PI;
+  if (K.bearingInnovationThreshold > 0 && fabs(nu[1]) > K.bearingInnovationThreshold) return false;
+  return true;
+}
+
+/* KalmanFilter::correct, vector overload: include/KalmanFilter.hpp:261-342.
+ * One landmark against all measurements.  lik uses the RAW difference z - z_exp (:317-320), the
+ * updated mean uses the wrapped/gated innovation.
+ * NOTE (:302): `P_updated = (P_updated + P_updated.transpose())/2` aliases in real Eigen release
+ * builds (<= 1 ulp asymmetry left behind); restated here as the intended exact symmetrisation. */
+static bool kf_correct_all(const rfsgpu_rngbrg_config &M, const rfsgpu_kf_config &K, const Pose &pose, const double *Z, int nZ,
+                           const Gauss &lm, std::vector<Gauss> &lmNew, std::vector<double> &lik, std::vector<double> &md2v) {
+  double z_exp[2];
+  M2 S, H;
+  if (!rb_measure(M, pose, lm.x, lm.S, z_exp, S, &H)) {
+    for (int i = 0; i < nZ; i++) { lik[i] = 0; md2v[i] = 0; }
+    return false;
+  }
+  M2 S_inv = inv2(S);
+  const M2 &P = lm.S;
+  M2 Kg = mul(mulT(P, H), S_inv);             /* K = P * H^T * S_inv */
+  M2 KH = mul(Kg, H);
+  M2 IKH;
+  IKH(0, 0) = 1.0 - KH(0, 0); IKH(0, 1) = 0.0 - KH(0, 1);
+  IKH(1, 0) = 0.0 - KH(1, 0); IKH(1, 1) = 1.0 - KH(1, 1);
+  M2 Pu = mul(IKH, P);
+  M2 Ps;
+  for (int i = 0; i < 2; i++)
+    for (int j = 0; j < 2; j++) Ps(i, j) = (Pu(i, j) + Pu(j, i)) / 2;
+  for (int i = 0; i < nZ; i++) {
+    const double *z = Z + 2 * i;
+    double nu[2];
+    if (rb_innovation(K, z_exp, z, nu)) {
+      lmNew[i].valid = true;
+      lmNew[i].x[0] = lm.x[0] + (Kg(0, 0) * nu[0] + Kg(0, 1) * nu[1]);
+      lmNew[i].x[1] = lm.x[1] + (Kg(1, 0) * nu[0] + Kg(1, 1) * nu[1]);
+      lmNew[i].S = Ps;
+      double md2;
+      double zl = gauss_lik2(z_exp, S, z, &md2); /* innov.set(z_exp,S); innov.evalGaussianLikelihood(measurement[i], &md2) */
+      if (zl != zl) zl = 0;
+      lik[i] = zl;
+      md2v[i] = md2;
+    } else {
+      lik[i] = 0;
+      md2v[i] = 0;
+    }
+  }
+  return true;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * PermutationLexicographic  (src/PermutationLexicographic.cpp:38-96), restated literally.
+ * ---------------------------------------------------------------------------------------------- */
+struct PermLex {
+  unsigned nM_, nZ_, nP_, oSize_;
+  bool last_;
+  std::vector<unsigned> o_;
+  PermLex(unsigned nM, unsigned nZ, bool includeClutter) : nM_(nM), nZ_(nZ), nP_(0), last_(false) {
+    if (nM != nZ) includeClutter = true;
+    oSize_ = includeClutter ? nM + nZ : nM;
+    o_.resize(oSize_);
+    for (unsigned i = 0; i < oSize_; i++) o_[i] = (i < nZ) ? i : nZ;
+  }
+  unsigned next(unsigned *permutation) {
+    if (last_) {
+      for (unsigned i = 0; i < oSize_; i++) permutation[i] = 0;
+      return 0;
+    }
+    for (unsigned i = 0; i < oSize_; i++) permutation[i] = o_[i];
+    unsigned u = nM_;
+    unsigned v = oSize_ - 1; /* oSize_ == 0 cannot occur from the filter */
+    while (u < v) { std::swap(o_[u], o_[v]); u++; v--; }
+    last_ = !std::next_permutation(o_.begin(), o_.end());
+    nP_++;
+    return nP_;
+  }
+};
+
+/* ------------------------------------------------------------------------------------------------
+ * HungarianMethod::run<double**>  (include/HungarianMethod.hpp:91-587), maximize = true path,
+ * restated literally incl. the in-place offset add/subtract (:137-148, :244-250) and the
+ * 1e-14 / 1e-12 tolerances (:293, :487, :500, :538).
+ * ---------------------------------------------------------------------------------------------- */
+static long g_hungarian_fail = 0;
+static bool hungarian_run(double **C, int n, int *soln, double *cost) {
+  std::vector<double> lx(n), ly(n), slack(n);
+  std::vector<int> xy(n, -1), yx(n, -1), p(2 * n);
+  std::vector<char> S(n, 0), T(n, 0), NS(n, 0), x_q(n), y_q(n);
+  int x, x_t, y, root = 0;
+  bool pickFreeVertex = true, updateLabel;
+  double offset = 0;
+  for (int xx = 0; xx < n; xx++)
+    for (int yy = 0; yy < n; yy++)
+      if (C[xx][yy] < offset) offset = C[xx][yy];
+  for (int xx = 0; xx < n; xx++)
+    for (int yy = 0; yy < n; yy++) C[xx][yy] -= offset;
+  /* Step 1 (:162-190) */
+  for (int xx = 0; xx < n; xx++) {
+    lx[xx] = 0.0;
+    ly[xx] = 0.0;
+    for (int yy = 0; yy < n; yy++) {
+      if (C[xx][yy] >= lx[xx]) { lx[xx] = C[xx][yy]; xy[xx] = yy; }
+    }
+    int yy = xy[xx];
+    x_t = yx[yy];
+    if (yx[yy] != -1) {
+      if (C[xx][yy] > C[x_t][yy]) { xy[x_t] = -1; yx[yy] = xx; }
+      else { xy[xx] = -1; }
+    } else {
+      yx[yy] = xx;
+    }
+  }
+  while (true) {
+    if (pickFreeVertex) { /* Step 2 (:222-318) */
+      for (x = 0; x < n; x++) S[x] = 0;
+      for (y = 0; y < n; y++) { T[y] = 0; NS[y] = 0; }
+      for (x = 0; x < n; x++) if (xy[x] == -1) break;
+      if (x == n) {
+        if (offset != 0)
+          for (x = 0; x < n; x++)
+            for (y = 0; y < n; y++) C[x][y] = C[x][y] + offset;
+        *cost = 0;
+        for (x = 0; x < n; x++) { soln[x] = xy[x]; *cost += C[x][xy[x]]; }
+        return true;
+      }
+      root = x;
+      S[x] = 1;
+      for (y = 0; y < n; y++) {
+        slack[y] = lx[x] + ly[y] - C[x][y];
+        if (fabs(slack[y]) < 1e-14) { slack[y] = 0; NS[y] = 1; }
+      }
+    }
+    /* Step 3 (:320-390) */
+    updateLabel = true;
+    for (y = 0; y < n; y++) if (NS[y] != T[y]) { updateLabel = false; break; }
+    if (updateLabel) {
+      double a = DBL_MAX;
+      for (y = 0; y < n; y++) if (!T[y]) a = fmin(a, slack[y]);
+      for (x = 0; x < n; x++) if (S[x]) lx[x] -= a;
+      for (y = 0; y < n; y++) if (T[y]) ly[y] += a;
+      for (y = 0; y < n; y++) {
+        if (!T[y]) slack[y] -= a;
+        if (slack[y] == 0) NS[y] = 1;
+      }
+    }
+    /* Step 4 (:392-) */
+    for (y = 0; y < n; y++) if (NS[y] && !T[y]) break;
+    if (y >= n) { g_hungarian_fail++; return false; } /* reference reads yx[n] (UB); treated as failure */
+    x_t = yx[y];
+    if (x_t == -1) {
+      bool augmentingPathFound = false;
+      int target = y + n;
+      std::queue<int> q;
+      q.push(root);
+      for (x = 0; x < n; x++) { x_q[x] = 0; y_q[x] = 0; }
+      x_q[root] = 1;
+      for (x = 0; x < 2 * n; x++) p[x] = -1;
+      int t = q.front();
+      while (!q.empty()) {
+        t = q.front();
+        if (t == target) {
+          while (t != root) {
+            if (t >= n) { x_t = p[t]; xy[x_t] = t - n; yx[t - n] = x_t; }
+            t = p[t];
+          }
+          augmentingPathFound = true;
+          break;
+        }
+        q.pop();
+        if (t < n) {
+          for (y = 0; y < n; y++) {
+            if (fabs(lx[t] + ly[y] - C[t][y]) < 1e-12 && !y_q[y] && xy[t] != y) { y_q[y] = 1; p[y + n] = t; q.push(y + n); }
+          }
+        } else {
+          t -= n;
+          for (x = 0; x < n; x++) {
+            if (fabs(lx[x] + ly[t] - C[x][t]) < 1e-12 && S[x] && !x_q[x] && yx[t] == x) { x_q[x] = 1; p[x] = t + n; q.push(x); }
+          }
+        }
+      }
+      if (!augmentingPathFound) { g_hungarian_fail++; return false; } /* :513-523 ("Cannot find alternating path") */
+      pickFreeVertex = true;
+    } else {
+      S[x_t] = 1;
+      T[y] = 1;
+      for (int y_t = 0; y_t < n; y_t++)
+        if (fabs(lx[x_t] + ly[y_t] - C[x_t][y_t]) < 1e-14) NS[y_t] = 1;
+      for (int yy = 0; yy < n; yy++) {
+        double slack_x_t = lx[x_t] + ly[yy] - C[x_t][yy];
+        if (slack_x_t < slack[yy]) slack[yy] = slack_x_t;
+      }
+      pickFreeVertex = false;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Murty k-best  (src/MurtyAlgorithm.cpp:107-336, include/MurtyAlgorithm.hpp), restated literally:
+ * same node tree, same std::priority_queue (so identical tie behaviour), same dummy-column
+ * duplicate-suppression quirk comparing the REDUCED column index (:256-262).
+ * ---------------------------------------------------------------------------------------------- */
+struct MurtyNode {
+  int id;
+  MurtyNode *parent;
+  std::vector<int> a;
+  double s;
+};
+struct MurtyNodeCompare {
+  bool operator()(const MurtyNode *p1, const MurtyNode *p2) const { return p1->s < p2->s; }
+};
+struct Murty {
+  int k_;
+  int n_;
+  double bigNumber_;
+  double **C_;
+  std::vector<std::vector<double>> Ct_store;
+  std::vector<double *> C_t_;
+  std::vector<std::unique_ptr<MurtyNode>> pool;
+  MurtyNode *root_;
+  std::priority_queue<MurtyNode *, std::vector<MurtyNode *>, MurtyNodeCompare> pq;
+  int realAssign_nC_, realAssign_nR_;
+  Murty(double **C, int n, double bigNum = 10000) : k_(0), n_(n), bigNumber_(bigNum), C_(C), realAssign_nC_(n), realAssign_nR_(n) {
+    Ct_store.assign(n, std::vector<double>(n));
+    C_t_.resize(n);
+    for (int i = 0; i < n; i++) C_t_[i] = Ct_store[i].data();
+    pool.emplace_back(new MurtyNode{0, nullptr, {}, 0});
+    root_ = pool.back().get();
+  }
+  void setRealAssignmentBlock(int nR, int nC) {
+    realAssign_nC_ = nC; realAssign_nR_ = nR;
+    if (realAssign_nC_ > n_) realAssign_nC_ = n_;
+    if (realAssign_nR_ > n_) realAssign_nR_ = n_;
+  }
+  int findNextBest(std::vector<int> &assignment, double &score) {
+    if (k_ == 0) { /* :147-158 */
+      std::vector<int> a(n_);
+      double s;
+      if (!hungarian_run(C_, n_, a.data(), &s)) { assignment.clear(); score = 0; return -1; }
+      root_->a = a; root_->s = s;
+      k_++;
+      pq.push(root_);
+      assignment = a; score = s;
+      return k_;
+    }
+    if (pq.empty()) { assignment.clear(); score = 0; return -1; }
+    MurtyNode *parent = pq.top();
+    int parent_partition = parent->id;
+    pq.pop();
+    const std::vector<int> a_parent = parent->a;
+    int partitionMax = realAssign_nR_;
+    if (realAssign_nR_ == n_) partitionMax = n_ - 1;
+    for (int n = parent_partition; n < partitionMax; n++) { /* :188 */
+      pool.emplace_back(new MurtyNode{n, parent, {}, 0});
+      MurtyNode *p = pool.back().get();
+      std::vector<int> a(n_, 0);
+      std::vector<char> freeCol(n_, 1);
+      double assignmentFixedScore = 0;
+      for (int i = 0; i < parent_partition; i++) { a[i] = a_parent[i]; freeCol[a[i]] = 0; assignmentFixedScore += C_[i][a[i]]; }
+      for (int i = parent_partition; i < n; i++) { a[i] = a_parent[i]; freeCol[a[i]] = 0; assignmentFixedScore += C_[i][a[i]]; }
+      int nFree = n_ - n;
+      std::vector<int> rowRemap(nFree), rowRemapR(n_, -1), colRemap(nFree), colRemapR(n_, -1);
+      int nFreeCols = 0;
+      for (int i = 0; i < nFree; i++) { rowRemap[i] = n + i; rowRemapR[n + i] = i; }
+      for (int j = 0; j < n_; j++) if (freeCol[j]) { colRemap[nFreeCols] = j; colRemapR[j] = nFreeCols; nFreeCols++; }
+      for (int i = 0; i < nFree; i++)
+        for (int j = 0; j < nFree; j++) C_t_[i][j] = C_[rowRemap[i]][colRemap[j]];
+      /* negative constraints (:247-265) */
+      MurtyNode *current = p, *next;
+      do {
+        int currentPart = current->id;
+        next = current->parent;
+        int doNotAssign_i = rowRemapR[currentPart];
+        int doNotAssign_j = colRemapR[next->a[currentPart]];
+        C_t_[doNotAssign_i][doNotAssign_j] = -bigNumber_;
+        if (doNotAssign_j >= realAssign_nC_) {
+          for (int y = 0; y < nFree; y++)
+            if (y >= realAssign_nC_) C_t_[doNotAssign_i][y] = -bigNumber_;
+        }
+        current = next;
+      } while (current != root_ && current->id >= p->id);
+      bool solutionPossible = false;
+      int constraintRow = rowRemapR[p->id];
+      for (int j = 0; j < nFree; j++) if (C_t_[constraintRow][j] != -bigNumber_) { solutionPossible = true; break; }
+      if (solutionPossible) {
+        std::vector<int> aTmp(nFree);
+        double s = 0;
+        if (!hungarian_run(C_t_.data(), nFree, aTmp.data(), &s)) continue; /* reference ignores the failure (UB) */
+        double s_more_accurate = 0;
+        for (int i = 0; i < nFree; i++) {
+          int i_actual = rowRemap[i];
+          int j_actual = colRemap[aTmp[i]];
+          a[i_actual] = j_actual;
+          s_more_accurate += C_[i_actual][a[i_actual]];
+        }
+        s_more_accurate += assignmentFixedScore;
+        p->a = a; p->s = s_more_accurate;
+        pq.push(p);
+      }
+    }
+    if (pq.empty()) { assignment.clear(); score = 0; return -1; }
+    MurtyNode *hi = pq.top();
+    assignment = hi->a; score = hi->s;
+    k_++;
+    return k_;
+  }
+};
+
+/* ------------------------------------------------------------------------------------------------
+ * CostMatrixGeneral  (src/CostMatrix.cpp:12-28, 92-227) restated, incl. the partition-count /
+ * indexing quirk the caller exposes (SURVEY §7 hard part 2).
+ * Component ids = BGL connected_components DFS discovery order over vertices 0..nR+nC-1, i.e.
+ * components numbered by their smallest vertex (rows first, then columns).
+ * ---------------------------------------------------------------------------------------------- */
+struct CostMatrixGeneral {
+  int nR_, nC_;
+  std::vector<std::vector<double>> C_;
+  std::vector<std::vector<unsigned>> components_i, components_j;
+  int combinedZeroPartition_ = -1;
+  int nPartitions_ = 0;
+  int ncc_ = 0;
+  CostMatrixGeneral(int nR, int nC) : nR_(nR), nC_(nC), C_(nR, std::vector<double>(nC, 0.0)) {}
+  int partition() {
+    if (nPartitions_ != 0) return nPartitions_;
+    int V = nR_ + nC_;
+    std::vector<int> cc(V, -1);
+    int ncc = 0;
+    std::vector<int> stack;
+    for (int v0 = 0; v0 < V; v0++) {
+      if (cc[v0] != -1) continue;
+      cc[v0] = ncc;
+      stack.clear();
+      stack.push_back(v0);
+      while (!stack.empty()) {
+        int v = stack.back();
+        stack.pop_back();
+        if (v < nR_) {
+          for (int j = 0; j < nC_; j++)
+            if (C_[v][j] != 0 && cc[nR_ + j] == -1) { cc[nR_ + j] = ncc; stack.push_back(nR_ + j); }
+        } else {
+          int j = v - nR_;
+          for (int i = 0; i < nR_; i++)
+            if (C_[i][j] != 0 && cc[i] == -1) { cc[i] = ncc; stack.push_back(i); }
+        }
+      }
+      ncc++;
+    }
+    ncc_ = ncc;
+    components_i.assign(ncc, {});
+    components_j.assign(ncc, {});
+    for (int i = 0; i < nR_; i++) components_i[cc[i]].push_back(i);
+    for (int j = nR_; j < V; j++) components_j[cc[j]].push_back(j - nR_);
+    combinedZeroPartition_ = -1;
+    int nMerged = 0;
+    for (int n = 0; n < ncc; n++) {
+      if (components_i[n].size() == 0 || components_j[n].size() == 0) {
+        if (combinedZeroPartition_ == -1) combinedZeroPartition_ = n;
+        else if (components_i[n].size() != 0) { components_i[combinedZeroPartition_].push_back(components_i[n][0]); nMerged++; }
+        else { components_j[combinedZeroPartition_].push_back(components_j[n][0]); nMerged++; }
+      }
+    }
+    nPartitions_ = ncc - nMerged;
+    return nPartitions_;
+  }
+  /* getPartitionSize (:160-173) */
+  bool getPartitionSize(int p, unsigned &nRows, unsigned &nCols) {
+    nRows = components_i[p].size();
+    nCols = components_j[p].size();
+    return p != combinedZeroPartition_;
+  }
+  /* getPartition (:175-227): Cp is (nRows [+nCols]) x (nCols [+nRows]); only [0,nRows)x[0,nCols) filled. */
+  bool getPartition(int p, std::vector<std::vector<double>> &Cp, unsigned &nRows, unsigned &nCols,
+                    std::vector<unsigned> &rowIdx, std::vector<unsigned> &colIdx, bool extended) {
+    nRows = components_i[p].size();
+    nCols = components_j[p].size();
+    unsigned nR = extended ? nRows + nCols : nRows;
+    unsigned nC = extended ? nRows + nCols : nCols;
+    Cp.assign(nR, std::vector<double>(nC, 0.0));
+    for (unsigned i = 0; i < nRows; i++)
+      for (unsigned j = 0; j < nCols; j++) Cp[i][j] = C_[components_i[p][i]][components_j[p][j]];
+    rowIdx = components_i[p];
+    colIdx = components_j[p];
+    return p != combinedZeroPartition_;
+  }
+};
+
+/* ------------------------------------------------------------------------------------------------
+ * MatPerm::calc  (src/MatrixPermanent.cpp:41-112): Nijenhuis-Wilf / Gray-code Ryser.
+ * ---------------------------------------------------------------------------------------------- */
+static double mat_perm(const double *A, int n) {
+  std::vector<double> x(n);
+  std::vector<int> g(n, 0);
+  double p = 0, s = -1;
+  for (int i = 0; i < n; i++) {
+    double row_i_sum = 0;
+    for (int j = 0; j < n; j++) row_i_sum += A[i * n + j];
+    x[i] = A[i * n + (n - 1)] - 0.5 * row_i_sum;
+  }
+  p = s;
+  for (int i = 0; i < n; i++) p *= x[i];
+  for (long long k = 2; k <= (long long)pow(2, n - 1); k++) {
+    int j = 0;
+    if (k % 2 == 0) j = 0;
+    else { j = 1; while (g[j - 1] == 0) j++; }
+    s *= -1;
+    double z = 1 - 2 * g[j];
+    g[j] = !g[j];
+    double x_prod = 1;
+    for (int i = 0; i < n; i++) { x[i] += z * A[i * n + j]; x_prod *= x[i]; }
+    p += s * x_prod;
+  }
+  double retval = 2 * p;
+  if (n % 2 != 0) retval *= -1;
+  return retval;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * The filter state + phases
+ * ---------------------------------------------------------------------------------------------- */
+struct Filter {
+  int n;
+  rfsgpu_filter_config cfg;
+  rfsgpu_rngbrg_config model;
+  rfsgpu_kf_config kf;
+  M2 Qlm;
+  std::vector<Pose> pose;
+  std::vector<double> weight;
+  std::vector<std::vector<Gauss>> gm; /* gList_ (may contain holes between merge and prune) */
+  std::vector<int> gm_n;              /* n_ */
+  std::vector<std::vector<unsigned>> unused;
+  std::vector<unsigned> nInFov;
+  std::vector<double> Z; /* measurements_ (2 doubles each) */
+  int nZ = 0;
+  bool stable_sort = false; /* false: std::sort exactly as the reference (GaussianMixture.hpp:523-534);
+                               true : (weight desc, index asc) == what the device path implements */
+  long murty_calls = 0, lonerow_bug_hits = 0;
+  rfsgpu_timing timing;
+  std::string err;
+};
+
+static inline long long now_ns() {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+/* RBPHDFilter::updateMap  (include/RBPHDFilter.hpp:543-725) for one particle. */
+static void update_map_particle(Filter &F, int i) {
+  const int nZ = F.nZ;
+  std::vector<Gauss> &G = F.gm[i];
+  const unsigned nM = F.gm_n[i]; /* getGaussianCount(); storage has no holes at this point */
+  F.unused[i].clear();
+  F.nInFov[i] = 0;
+  if (nM == 0) {
+    for (int z = 0; z < nZ; z++) F.unused[i].push_back(z);
+    return;
+  }
+  std::vector<double> Pd(nM);
+  std::vector<int> closeLim(nM);
+  double w_km_sum = std::numeric_limits<double>::denorm_min();
+  double likelihoodProd = 1;
+  if (F.cfg.useClusterProcess)
+    for (unsigned m = 0; m < nM; m++) w_km_sum += G[m].w;
+  std::vector<double> W((size_t)nM * nZ, 0.0);
+  std::vector<char> Mvalid((size_t)nM * nZ, 0);
+  std::vector<Gauss> Mtab((size_t)nM * nZ);
+  const Pose &pose = F.pose[i];
+  const double thr = F.cfg.newGaussianCreateInnovMDThreshold * F.cfg.newGaussianCreateInnovMDThreshold;
+  std::vector<double> lik(nZ), md2(nZ);
+  std::vector<Gauss> lmNew(nZ);
+  for (unsigned m = 0; m < nM; m++) {
+    bool close;
+    Pd[m] = rb_pd(F.model, pose, G[m].x, close);
+    if (close) { closeLim[m] = 1; Pd[m] = 1; } else closeLim[m] = 0;
+    double w_km = G[m].w;
+    double Pd_times_w_km = Pd[m] * w_km;
+    if (Pd[m] != 0) {
+      F.nInFov[i]++;
+      kf_correct_all(F.model, F.kf, pose, F.Z.data(), nZ, G[m], lmNew, lik, md2);
+      for (int z = 0; z < nZ; z++) {
+        if (lik[z] == 0 || md2[z] > thr) { Mvalid[(size_t)m * nZ + z] = 0; W[(size_t)m * nZ + z] = 0; }
+        else { Mvalid[(size_t)m * nZ + z] = 1; Mtab[(size_t)m * nZ + z] = lmNew[z]; W[(size_t)m * nZ + z] = Pd_times_w_km * lik[z]; }
+      }
+    }
+  }
+  for (int z = 0; z < nZ; z++) {
+    double clutter = rb_clutter(F.model);
+    double sum = clutter;
+    for (unsigned m = 0; m < nM; m++) sum += W[(size_t)m * nZ + z];
+    if (F.cfg.useClusterProcess) likelihoodProd *= sum;
+    for (unsigned m = 0; m < nM; m++) W[(size_t)m * nZ + z] = W[(size_t)m * nZ + z] / sum;
+  }
+  if (F.cfg.useClusterProcess) {
+    double prev = F.weight[i];
+    F.weight[i] = exp(w_km_sum) * likelihoodProd * prev;
+  }
+  /* 3. add new Gaussians in (m,z) row-major order (:675-683); addGaussian => w_prev = 0 */
+  for (unsigned m = 0; m < nM; m++)
+    for (int z = 0; z < nZ; z++)
+      if (Mvalid[(size_t)m * nZ + z] && W[(size_t)m * nZ + z] > 0) {
+        Gauss g = Mtab[(size_t)m * nZ + z];
+        g.valid = true; g.w = W[(size_t)m * nZ + z]; g.w_prev = 0;
+        G.push_back(g);
+        F.gm_n[i]++;
+      }
+  /* 4. missed-detection weights (:686-706); setWeight stores the old weight in w_prev */
+  for (unsigned m = 0; m < nM; m++) {
+    double w_km = G[m].w;
+    double w_k = (1 - Pd[m]) * w_km;
+    if (closeLim[m] == 1 && w_km > F.cfg.birthGaussianWeight) {
+      double weight_sum_m = 0;
+      for (int z = 0; z < nZ; z++) weight_sum_m += W[(size_t)m * nZ + z];
+      double delta_w = Pd[m] * w_km - weight_sum_m;
+      if (delta_w > 0) { w_k += delta_w; if (w_k > 1) w_k = 1; }
+    }
+    G[m].w_prev = G[m].w;
+    G[m].w = w_k;
+  }
+  /* 5. unused measurements (:709-720) */
+  F.unused[i].clear();
+  for (int z = 0; z < nZ; z++) {
+    bool used = false;
+    for (unsigned m = 0; m < nM; m++) if (W[(size_t)m * nZ + z] != 0) { used = true; break; }
+    if (!used) F.unused[i].push_back(z);
+  }
+}
+
+/* GaussianMixture::sortByWeight (include/GaussianMixture.hpp:523-534). */
+static bool weightCompare(const Gauss &a, const Gauss &b) { return a.w > b.w; }
+static void sort_by_weight(Filter &F, std::vector<Gauss> &G) {
+  if (F.stable_sort) std::stable_sort(G.begin(), G.end(), weightCompare);
+  else std::sort(G.begin(), G.end(), weightCompare);
+}
+
+/* RBPHDFilter::rfsMeasurementLikelihood (include/RBPHDFilter.hpp:821-997). */
+static double rfs_measurement_likelihood(Filter &F, int i, const std::vector<unsigned> &evalPtIdx, const std::vector<double> &evalPtPd,
+                                         long *murty_calls, long *lonerow_hits) {
+  const Pose &x = F.pose[i];
+  const int nM = (int)evalPtIdx.size();
+  const int nZ = F.nZ;
+  const double threshold = F.cfg.importanceWeightingMeasurementLikelihoodMDThreshold * F.cfg.importanceWeightingMeasurementLikelihoodMDThreshold;
+  CostMatrixGeneral cm(nM, nZ);
+  M2 zeroCov = {{0, 0, 0, 0}};
+  for (int m = 0; m < nM; m++) {
+    const Gauss &ev = F.gm[i][evalPtIdx[m]];
+    double z_exp[2];
+    M2 S;
+    rb_measure(F.model, x, ev.x, zeroCov, z_exp, S, nullptr); /* return value ignored (:852) */
+    double Pd = evalPtPd[m];
+    for (int n = 0; n < nZ; n++) {
+      double md2;
+      double L = gauss_lik2(z_exp, S, &F.Z[2 * n], &md2) * Pd;
+      if (md2 > threshold) L = 0;
+      cm.C_[m][n] = L;
+    }
+  }
+  int nP = cm.partition();
+  double l = 1;
+  const double BIG_NEG_NUM = -1000;
+  std::vector<double> clutter(nZ);
+  for (int n = 0; n < nZ; n++) clutter[n] = rb_clutter(F.model);
+  for (int p = 0; p < nP; p++) {
+    double partition_likelihood = 0;
+    unsigned nCols, nRows;
+    std::vector<std::vector<double>> Cp;
+    std::vector<unsigned> rowIdx, colIdx;
+    bool isZeroPartition = !cm.getPartitionSize(p, nRows, nCols);
+    bool useMurty = true;
+    if (nRows + nCols <= 8 || isZeroPartition) useMurty = false;
+    isZeroPartition = !cm.getPartition(p, Cp, nRows, nCols, rowIdx, colIdx, useMurty);
+    if (isZeroPartition) {
+      partition_likelihood = 1;
+      for (unsigned r = 0; r < nRows; r++) partition_likelihood *= evalPtPd[rowIdx[r]]; /* sic: Pd, not 1-Pd (:893-896) */
+      for (unsigned c = 0; c < nCols; c++) partition_likelihood *= clutter[colIdx[c]];
+    } else {
+      if (nCols == 0 && nRows == 1 && lonerow_hits) (*lonerow_hits)++;
+      for (unsigned r = 0; r < nRows; r++)
+        for (unsigned c = 0; c < nCols; c++) {
+          if (Cp[r][c] == 0) Cp[r][c] = BIG_NEG_NUM;
+          else { Cp[r][c] = log(Cp[r][c]); if (Cp[r][c] < BIG_NEG_NUM) Cp[r][c] = BIG_NEG_NUM; }
+        }
+      if (useMurty) {
+        for (unsigned r = 0; r < nRows; r++)
+          for (unsigned c = nCols; c < nRows + nCols; c++) Cp[r][c] = (r == c - nCols) ? log(1 - evalPtPd[rowIdx[r]]) : BIG_NEG_NUM;
+        for (unsigned r = nRows; r < nRows + nCols; r++)
+          for (unsigned c = 0; c < nCols; c++) Cp[r][c] = (r - nRows == c) ? log(clutter[colIdx[c]]) : BIG_NEG_NUM;
+        for (unsigned r = nRows; r < nRows + nCols; r++)
+          for (unsigned c = nCols; c < nRows + nCols; c++) Cp[r][c] = 0;
+        std::vector<double *> rows(nRows + nCols);
+        for (unsigned r = 0; r < nRows + nCols; r++) rows[r] = Cp[r].data();
+        Murty murty(rows.data(), nRows + nCols);
+        if (murty_calls) (*murty_calls)++;
+        std::vector<int> a;
+        partition_likelihood = 0;
+        double pll = 0;
+        murty.setRealAssignmentBlock(nRows, nCols);
+        for (int k = 0; k < 200; k++) {
+          int rank = murty.findNextBest(a, pll);
+          if (rank == -1 || pll < BIG_NEG_NUM) break;
+          partition_likelihood += exp(pll);
+        }
+      } else {
+        partition_likelihood = 0;
+        double pll = 0;
+        std::vector<unsigned> o(nRows + nCols);
+        PermLex pl(nRows, nCols, true);
+        unsigned nPerm = pl.next(o.data());
+        while (nPerm != 0) {
+          pll = 0;
+          for (unsigned a = 0; a < nRows; a++) {
+            if (o[a] < nCols) pll += Cp[a][o[a]];
+            else pll += log(1 - evalPtPd[rowIdx[a]]);
+          }
+          for (unsigned a = nRows; a < nRows + nCols; a++)
+            if (o[a] < nCols) pll += log(clutter[colIdx[o[a]]]);
+          partition_likelihood += exp(pll);
+          nPerm = pl.next(o.data());
+        }
+      }
+    }
+    l *= partition_likelihood;
+  }
+  return l / rb_clutter_integral(F.model);
+}
+
+/* RBPHDFilter::importanceWeighting (include/RBPHDFilter.hpp:728-819) for one particle. */
+static void importance_weighting_particle(Filter &F, int idx, long *murty_calls, long *lonerow_hits) {
+  const Pose &x = F.pose[idx];
+  std::vector<Gauss> &G = F.gm[idx];
+  const unsigned nM = F.gm_n[idx];
+  int nEvalPoints = (unsigned)F.cfg.importanceWeightingEvalPointCount > nM ? (int)nM : F.cfg.importanceWeightingEvalPointCount;
+  std::vector<unsigned> evalPointIdx;
+  std::vector<double> evalPointPd;
+  if (nEvalPoints == 0) {
+    F.weight[idx] = std::numeric_limits<double>::denorm_min();
+    return;
+  }
+  sort_by_weight(F, G);
+  for (unsigned m = 0; m < nM; m++) {
+    double w = G[m].w;
+    if (w < F.cfg.importanceWeightingEvalPointGuassianWeight) break;
+    bool close;
+    double Pd = rb_pd(F.model, x, G[m].x, close);
+    if (Pd > 0) { evalPointIdx.push_back(m); evalPointPd.push_back(Pd); }
+    if (nEvalPoints != -1 && evalPointIdx.size() >= (size_t)nEvalPoints) break;
+  }
+  nEvalPoints = (int)evalPointIdx.size();
+  double sumBefore = 0, sumAfter = 0;
+  for (unsigned m = 0; m < nM; m++) { sumBefore += G[m].w_prev; sumAfter += G[m].w; }
+  double prodBefore = 1, prodAfter = 1;
+  for (int e = 0; e < nEvalPoints; e++) {
+    const Gauss &ev = G[evalPointIdx[e]];
+    double ib = std::numeric_limits<double>::denorm_min();
+    double ia = std::numeric_limits<double>::denorm_min();
+    for (unsigned m = 0; m < nM; m++) {
+      double likelihood = gauss_lik2(G[m].x, G[m].S, ev.x, nullptr);
+      ib += G[m].w_prev * likelihood;
+      ia += G[m].w * likelihood;
+    }
+    prodBefore *= ib;
+    prodAfter *= ia;
+  }
+  double measurementLikelihood = rfs_measurement_likelihood(F, idx, evalPointIdx, evalPointPd, murty_calls, lonerow_hits);
+  double overall_weight = measurementLikelihood * prodBefore / prodAfter * exp(sumAfter - sumBefore);
+  double prev_weight = F.weight[idx];
+  F.weight[idx] = overall_weight * prev_weight;
+}
+
+/* GaussianMixture::merge(idx1, idx2)  (include/GaussianMixture.hpp:419-475). */
+static bool merge_pair(std::vector<Gauss> &G, int &n_, unsigned i1, unsigned i2, double t, double f) {
+  if (!G[i1].valid || !G[i2].valid) return false;
+  double w_1 = G[i1].w, w_2 = G[i2].w;
+  double t2 = t * t;
+  double d1 = md2_2(G[i1].x, inv2(G[i1].S), G[i2].x);
+  if (d1 > t2) {
+    double d2 = md2_2(G[i2].x, inv2(G[i2].S), G[i1].x);
+    if (d2 > t2) return false;
+  }
+  double w_m = w_1 + w_2;
+  if (w_m == 0) return false;
+  double x_m[2], d_1[2], d_2[2];
+  for (int k = 0; k < 2; k++) x_m[k] = (G[i1].x[k] * w_1 + G[i2].x[k] * w_2) / w_m;
+  for (int k = 0; k < 2; k++) { d_1[k] = x_m[k] - G[i1].x[k]; d_2[k] = x_m[k] - G[i2].x[k]; }
+  M2 S_m;
+  for (int r = 0; r < 2; r++)
+    for (int c = 0; c < 2; c++) {
+      /* S_m = ( w_1*(S_1 + f*d_1*d_1^T) + w_2*(S_2 + f*d_2*d_2^T) ) / w_m ; (f*d) is formed first */
+      double a = w_1 * (G[i1].S(r, c) + (f * d_1[r]) * d_1[c]);
+      double b = w_2 * (G[i2].S(r, c) + (f * d_2[r]) * d_2[c]);
+      S_m(r, c) = (a + b) / w_m;
+    }
+  G[i1].x[0] = x_m[0]; G[i1].x[1] = x_m[1];
+  G[i1].S = S_m;
+  G[i1].w = w_m;
+  G[i1].w_prev = 0;
+  /* removeGaussian(idx2) (:310-322) */
+  G[i2].valid = false; G[i2].w = 0; G[i2].w_prev = 0;
+  n_--;
+  return true;
+}
+/* GaussianMixture::merge(t, f)  (:394-416). */
+static unsigned merge_particle(Filter &F, int i) {
+  std::vector<Gauss> &G = F.gm[i];
+  unsigned nMerged = 0;
+  unsigned nG = G.size();
+  for (unsigned a = 0; a < nG; a++) {
+    if (!G[a].valid) continue;
+    for (unsigned b = a + 1; b < nG; b++)
+      if (merge_pair(G, F.gm_n[i], a, b, F.cfg.gaussianMergingThreshold, F.cfg.gaussianMergingCovarianceInflationFactor)) nMerged++;
+  }
+  return nMerged;
+}
+/* GaussianMixture::prune(t)  (:477-521), binary search + linear walk restated literally. */
+static unsigned prune_particle(Filter &F, int i) {
+  std::vector<Gauss> &G = F.gm[i];
+  const double t = F.cfg.gaussianPruningThreshold;
+  unsigned nPruned = 0;
+  if (G.size() < 1) return 0;
+  sort_by_weight(F, G);
+  unsigned min_idx = 0, max_idx = G.size() - 1;
+  unsigned idx = (max_idx + min_idx) / 2;
+  unsigned idx_old = idx + 1;
+  double w = G[idx].w;
+  while (idx != idx_old) {
+    if (w <= t) max_idx = idx;
+    else if (w > t) min_idx = idx;
+    idx_old = idx;
+    idx = (max_idx + min_idx) / 2;
+    w = G[idx].w;
+  }
+  while (w >= t) {
+    idx++;
+    if (idx >= G.size()) break;
+    w = G[idx].w;
+  }
+  idx_old = idx;
+  while (idx < G.size()) {
+    if (G[idx].valid) { G[idx].valid = false; G[idx].w = 0; G[idx].w_prev = 0; F.gm_n[i]--; }
+    idx++;
+    nPruned++;
+  }
+  G.resize(G.size() - nPruned);
+  return nPruned;
+}
+
+/* RBPHDFilter::addBirthGaussians (include/RBPHDFilter.hpp:1000-1084), immediate-birth branch:
+ * birthGaussianMeasurementCountThreshold == 1 or nLandmarksInFOV <= birthGaussianCurrentMeasurementCountThreshold.
+ * (The candidate-list branch is outside the device path's current scope; it is refused loudly.) */
+static int add_birth_particle(Filter &F, int i) {
+  while (F.unused[i].size() > 0) {
+    int zi = F.unused[i].back();
+    F.unused[i].pop_back();
+    bool immediate = F.cfg.birthGaussianMeasurementCountThreshold == 1 || F.nInFov[i] <= F.cfg.birthGaussianCurrentMeasurementCountThreshold;
+    if (!immediate) return RFSGPU_ERR_UNSUPPORTED;
+    Gauss g;
+    g.valid = true; g.w = F.cfg.birthGaussianWeight; g.w_prev = 0;
+    rb_inverse_measure(F.model, F.pose[i], &F.Z[2 * zi], g.x, g.S);
+    F.gm[i].push_back(g);
+    F.gm_n[i]++;
+  }
+  return RFSGPU_OK;
+}
+
+} /* namespace orc */
+
+/* ================================================================================================
+ * C API: same shape as include/rfsgpu.h with prefix rfsor_, so one ctypes wrapper drives both.
+ * ============================================================================================== */
+using orc::Filter;
+#define F_(f) (reinterpret_cast<Filter *>(f))
+
+extern "C" {
+
+int rfsor_abi_version(void) { return RFSGPU_ABI_VERSION; }
+
+void rfsor_default_filter_config(rfsgpu_filter_config *c) { /* RBPHDFilter.hpp:370-382 */
+  memset(c, 0, sizeof(*c));
+  c->birthGaussianWeight = 0.25;
+  c->birthGaussianMeasurementCountThreshold = 1;
+  c->birthGaussianMeasurementCheckThreshold = 1;
+  c->birthGaussianMeasurementSupportDist = 1;
+  c->birthGaussianCurrentMeasurementCountThreshold = 1;
+  c->gaussianMergingThreshold = 0.5;
+  c->gaussianMergingCovarianceInflationFactor = 1.5;
+  c->gaussianPruningThreshold = 0.2;
+  c->importanceWeightingEvalPointCount = 8;
+  c->importanceWeightingEvalPointGuassianWeight = 0; /* uninitialised in the reference ctor */
+  c->importanceWeightingMeasurementLikelihoodMDThreshold = 3.0;
+  c->newGaussianCreateInnovMDThreshold = 0.2;
+  c->minUpdatesBeforeResample = 1;
+  c->minMeasurementsBeforeResample = 1;
+  c->useClusterProcess = 0;
+}
+
+int rfsor_create(void **out, int model, int n_particles, int device_id, int gm_capacity) {
+  (void)device_id; (void)gm_capacity;
+  if (!out || n_particles <= 0 || model != RFSGPU_MODEL_RNGBRG_2D) return RFSGPU_ERR_INVALID;
+  Filter *F = new Filter();
+  F->n = n_particles;
+  rfsor_default_filter_config(&F->cfg);
+  /* MeasurementModel_RngBrg defaults, src/MeasurementModel_RngBrg.cpp:35-43 */
+  memset(&F->model, 0, sizeof(F->model));
+  F->model.probabilityOfDetection = 0.95; F->model.uniformClutterIntensity = 0.1;
+  F->model.rangeLimMax = 5; F->model.rangeLimMin = 0.3; F->model.rangeLimBuffer = 0.25;
+  F->kf.rangeInnovationThreshold = -1; F->kf.bearingInnovationThreshold = -1;
+  memset(&F->Qlm, 0, sizeof(F->Qlm));
+  F->pose.assign(n_particles, orc::Pose{});
+  F->weight.assign(n_particles, 1.0);
+  F->gm.assign(n_particles, {});
+  F->gm_n.assign(n_particles, 0);
+  F->unused.assign(n_particles, {});
+  F->nInFov.assign(n_particles, 0);
+  memset(&F->timing, 0, sizeof(F->timing));
+  *out = F;
+  return RFSGPU_OK;
+}
+void rfsor_destroy(void *f) { delete F_(f); }
+const char *rfsor_last_error(const void *f) { return f ? reinterpret_cast<const Filter *>(f)->err.c_str() : "null handle"; }
+
+int rfsor_set_filter_config(void *f, const rfsgpu_filter_config *c) { F_(f)->cfg = *c; return RFSGPU_OK; }
+int rfsor_get_filter_config(const void *f, rfsgpu_filter_config *c) { *c = reinterpret_cast<const Filter *>(f)->cfg; return RFSGPU_OK; }
+int rfsor_set_model_rngbrg(void *f, const rfsgpu_rngbrg_config *c) { F_(f)->model = *c; return RFSGPU_OK; }
+int rfsor_set_kf_config(void *f, const rfsgpu_kf_config *c) { F_(f)->kf = *c; return RFSGPU_OK; }
+int rfsor_set_lmk_process_noise(void *f, const double *Q) { memcpy(F_(f)->Qlm.a, Q, 4 * sizeof(double)); return RFSGPU_OK; }
+
+int rfsor_set_poses(void *f, const double *x, const double *cov, int cov_stride) {
+  Filter *F = F_(f);
+  for (int i = 0; i < F->n; i++) {
+    memcpy(F->pose[i].x, x + 3 * i, 3 * sizeof(double));
+    if (cov) memcpy(F->pose[i].P, cov + (size_t)cov_stride * i, 9 * sizeof(double));
+    else memset(F->pose[i].P, 0, 9 * sizeof(double));
+  }
+  return RFSGPU_OK;
+}
+int rfsor_get_poses(void *f, double *x) {
+  Filter *F = F_(f);
+  for (int i = 0; i < F->n; i++) memcpy(x + 3 * i, F->pose[i].x, 3 * sizeof(double));
+  return RFSGPU_OK;
+}
+int rfsor_set_weights(void *f, const double *w) { Filter *F = F_(f); F->weight.assign(w, w + F->n); return RFSGPU_OK; }
+int rfsor_get_weights(void *f, double *w) { Filter *F = F_(f); memcpy(w, F->weight.data(), F->n * sizeof(double)); return RFSGPU_OK; }
+
+int rfsor_gm_size(void *f, int slot) { Filter *F = F_(f); return (slot >= 0 && slot < F->n) ? F->gm_n[slot] : -1; }
+int rfsor_gm_sizes(void *f, int *sizes) { Filter *F = F_(f); for (int i = 0; i < F->n; i++) sizes[i] = F->gm_n[i]; return RFSGPU_OK; }
+
+int rfsor_import_gm(void *f, int slot, int n, const double *w, const double *mean, const double *cov) {
+  Filter *F = F_(f);
+  if (slot < 0 || slot >= F->n || n < 0) return RFSGPU_ERR_INVALID;
+  F->gm[slot].clear();
+  for (int m = 0; m < n; m++) {
+    orc::Gauss g;
+    g.valid = true; g.w = w[m]; g.w_prev = 0;
+    g.x[0] = mean[2 * m]; g.x[1] = mean[2 * m + 1];
+    memcpy(g.S.a, cov + 4 * m, 4 * sizeof(double));
+    F->gm[slot].push_back(g);
+  }
+  F->gm_n[slot] = n;
+  return RFSGPU_OK;
+}
+/* Exports VALID Gaussians in storage order (holes skipped). */
+int rfsor_export_gm(void *f, int slot, int max_n, int *n_out, double *w, double *w_prev, double *mean, double *cov) {
+  Filter *F = F_(f);
+  if (slot < 0 || slot >= F->n) return RFSGPU_ERR_INVALID;
+  int k = 0;
+  for (const orc::Gauss &g : F->gm[slot]) {
+    if (!g.valid) continue;
+    if (k < max_n) {
+      if (w) w[k] = g.w;
+      if (w_prev) w_prev[k] = g.w_prev;
+      if (mean) { mean[2 * k] = g.x[0]; mean[2 * k + 1] = g.x[1]; }
+      if (cov) memcpy(cov + 4 * k, g.S.a, 4 * sizeof(double));
+    }
+    k++;
+  }
+  if (n_out) *n_out = k;
+  return RFSGPU_OK;
+}
+int rfsor_get_landmark(void *f, int slot, int m, double *mean, double *cov, double *w) {
+  Filter *F = F_(f);
+  if (slot < 0 || slot >= F->n || m < 0 || m >= F->gm_n[slot] || m >= (int)F->gm[slot].size()) return RFSGPU_ERR_INVALID;
+  const orc::Gauss &g = F->gm[slot][m];
+  mean[0] = g.x[0]; mean[1] = g.x[1];
+  memcpy(cov, g.S.a, 4 * sizeof(double));
+  *w = g.w;
+  return RFSGPU_OK;
+}
+
+int rfsor_predict_map(void *f, int add_birth) {
+  Filter *F = F_(f);
+  long long t0 = orc::now_ns();
+  int rc = RFSGPU_OK;
+  for (int i = 0; i < F->n; i++) {
+    if (add_birth) { int r = orc::add_birth_particle(*F, i); if (r != RFSGPU_OK) rc = r; }
+    for (orc::Gauss &g : F->gm[i]) /* staticStep: S += Q (include/ProcessModel.hpp:195-208) */
+      for (int k = 0; k < 4; k++) g.S.a[k] += F->Qlm.a[k];
+  }
+  F->timing.predict_wall += orc::now_ns() - t0;
+  if (rc != RFSGPU_OK) F->err = "birth-candidate list mode not restated";
+  return rc;
+}
+
+int rfsor_update_map(void *f, const double *z, int n_z) {
+  Filter *F = F_(f);
+  if (n_z < 0) return RFSGPU_ERR_INVALID;
+  F->Z.assign(z, z + 2 * (size_t)n_z);
+  F->nZ = n_z;
+  long long t0 = orc::now_ns();
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int i = 0; i < F->n; i++) orc::update_map_particle(*F, i);
+  F->timing.mapUpdate_wall += orc::now_ns() - t0;
+  return RFSGPU_OK;
+}
+int rfsor_importance_weighting(void *f) {
+  Filter *F = F_(f);
+  long long t0 = orc::now_ns();
+  long mc = 0, lr = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : mc, lr)
+  for (int i = 0; i < F->n; i++) orc::importance_weighting_particle(*F, i, &mc, &lr);
+  F->murty_calls += mc; F->lonerow_bug_hits += lr;
+  F->timing.particleWeighting_wall += orc::now_ns() - t0;
+  return RFSGPU_OK;
+}
+int rfsor_merge(void *f) {
+  Filter *F = F_(f);
+  long long t0 = orc::now_ns();
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int i = 0; i < F->n; i++) orc::merge_particle(*F, i);
+  F->timing.mapMerge_wall += orc::now_ns() - t0;
+  return RFSGPU_OK;
+}
+int rfsor_prune(void *f) {
+  Filter *F = F_(f);
+  long long t0 = orc::now_ns();
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int i = 0; i < F->n; i++) orc::prune_particle(*F, i);
+  F->timing.mapPrune_wall += orc::now_ns() - t0;
+  return RFSGPU_OK;
+}
+/* RBPHDFilter::update body (:444-523). */
+int rfsor_update(void *f, const double *z, int n_z) {
+  Filter *F = F_(f);
+  if (n_z == 0) return RFSGPU_OK; /* :450-452 */
+  rfsor_update_map(f, z, n_z);
+  if (!F->cfg.useClusterProcess) rfsor_importance_weighting(f);
+  rfsor_merge(f);
+  rfsor_prune(f);
+  return RFSGPU_OK;
+}
+
+int rfsor_get_unused(void *f, int slot, int *idx, int max_n, int *n_out) {
+  Filter *F = F_(f);
+  if (slot < 0 || slot >= F->n) return RFSGPU_ERR_INVALID;
+  int k = 0;
+  for (unsigned u : F->unused[slot]) { if (k < max_n) idx[k] = (int)u; k++; }
+  if (n_out) *n_out = k;
+  return RFSGPU_OK;
+}
+int rfsor_landmarks_in_fov(void *f, int slot, int *n_out) {
+  Filter *F = F_(f);
+  if (slot < 0 || slot >= F->n) return RFSGPU_ERR_INVALID;
+  *n_out = (int)F->nInFov[slot];
+  return RFSGPU_OK;
+}
+
+/* ParticleFilter::normalizeWeights (include/ParticleFilter.hpp:352-363) split in its two loops. */
+int rfsor_weight_sums(void *f, double *out) {
+  Filter *F = F_(f);
+  double s = 0, s2 = 0;
+  for (int i = 0; i < F->n; i++) { s += F->weight[i]; s2 += F->weight[i] * F->weight[i]; }
+  out[0] = s; out[1] = s2;
+  return RFSGPU_OK;
+}
+int rfsor_normalize_weights(void *f, double sum, const void *sum_dev) {
+  (void)sum_dev;
+  Filter *F = F_(f);
+  for (int i = 0; i < F->n; i++) F->weight[i] = F->weight[i] / sum;
+  return RFSGPU_OK;
+}
+int rfsor_resample_apply(void *f, const int *src) {
+  Filter *F = F_(f);
+  for (int k = 0; k < F->n; k++) if (src[k] < 0 || src[k] >= F->n || src[src[k]] != src[k]) return RFSGPU_ERR_INVALID;
+  for (int k = 0; k < F->n; k++) {
+    if (src[k] != k) {
+      F->gm[k] = F->gm[src[k]]; F->gm_n[k] = F->gm_n[src[k]];
+      F->unused[k] = F->unused[src[k]]; F->nInFov[k] = F->nInFov[src[k]];
+    }
+    F->weight[k] = 1;
+  }
+  return RFSGPU_OK;
+}
+
+/* ParticleFilter::resample (include/ParticleFilter.hpp:399-492) decision + systematic sampling +
+ * slot assignment, given the uniform draw u01 (= the reference's single drand48()).
+ * weights: in = unnormalised, out = normalised.  Returns 1 if resampling fires (src_slot filled),
+ * 0 if not (weights only normalised). */
+int rfsor_resample_decide(double *weights, int n, double effNParticles_t, double u01, int *src_slot) {
+  double sum = 0;
+  for (int i = 0; i < n; i++) sum += weights[i];
+  for (int i = 0; i < n; i++) weights[i] = weights[i] / sum;
+  double s2 = 0;
+  for (int i = 0; i < n; i++) s2 += weights[i] * weights[i];
+  double nEff = 1.0 / s2;
+  double t_percent = effNParticles_t / n;
+  if (nEff > effNParticles_t && nEff / n > t_percent) return 0;
+  unsigned idx = 0;
+  const double sample_interval = 1.0 / double(n);
+  double sample_point = sample_interval * u01;
+  double cumulative_weight = weights[0];
+  std::vector<char> sampled(n, 0);
+  std::vector<unsigned> sampled_idx(n, 0);
+  for (int i = 0; i < n; i++) {
+    while (sample_point > cumulative_weight) {
+      idx++;
+      if ((int)idx >= n) { idx = n - 1; break; } /* guard: reference reads past the end on round-off */
+      cumulative_weight += weights[idx];
+    }
+    sampled_idx[i] = idx;
+    sampled[idx] = 1;
+    sample_point += sample_interval;
+  }
+  for (int i = 0; i < n; i++) src_slot[i] = i;
+  unsigned idx_prev = 0, next_unsampled = 0;
+  for (int i = 0; i < n; i++) {
+    bool firstTime = true;
+    idx = sampled_idx[i];
+    if (i > 0 && idx == idx_prev) firstTime = false;
+    idx_prev = idx;
+    if (firstTime) continue; /* case 1 (idx < n always here since n == nParticles_) */
+    while (next_unsampled < (unsigned)n && sampled[next_unsampled] == 1) next_unsampled++;
+    src_slot[next_unsampled] = (int)idx;
+    next_unsampled++;
+  }
+  return 1;
+}
+
+int rfsor_get_timing(void *f, rfsgpu_timing *t) { *t = F_(f)->timing; return RFSGPU_OK; }
+int rfsor_reset_timing(void *f) { memset(&F_(f)->timing, 0, sizeof(rfsgpu_timing)); return RFSGPU_OK; }
+int rfsor_synchronize(void *f) { (void)f; return RFSGPU_OK; }
+
+int rfsor_mat_perm(const double *A, int n, int batch, double *out, int device_id) {
+  (void)device_id;
+  if (n < 1 || n > 24) return RFSGPU_ERR_INVALID;
+  for (int b = 0; b < batch; b++) out[b] = orc::mat_perm(A + (size_t)b * n * n, n);
+  return RFSGPU_OK;
+}
+
+/* ---- oracle-only controls and probes (not part of the product ABI) ---------------------------- */
+void rfsor_set_stable_sort(void *f, int on) { F_(f)->stable_sort = on != 0; }
+void rfsor_set_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+int rfsor_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+long rfsor_murty_calls(void *f) { return F_(f)->murty_calls; }
+long rfsor_lonerow_bug_hits(void *f) { return F_(f)->lonerow_bug_hits; }
+long rfsor_hungarian_failures(void) { return orc::g_hungarian_fail; }
+
+/* PermutationLexicographic restatement, flattened: writes up to max_perm permutations of length nM+nZ. */
+int rfsor_permlex_all(unsigned nM, unsigned nZ, unsigned *out, int max_perm) {
+  orc::PermLex pl(nM, nZ, true);
+  std::vector<unsigned> o(nM + nZ);
+  int k = 0;
+  while (pl.next(o.data()) != 0) {
+    if (k < max_perm) memcpy(out + (size_t)k * (nM + nZ), o.data(), (nM + nZ) * sizeof(unsigned));
+    k++;
+  }
+  return k;
+}
+/* Hungarian restatement: C row-major n x n (restored in place like the reference). */
+int rfsor_hungarian(double *C, int n, int *soln, double *cost) {
+  std::vector<double *> rows(n);
+  for (int i = 0; i < n; i++) rows[i] = C + (size_t)i * n;
+  return orc::hungarian_run(rows.data(), n, soln, cost) ? 1 : 0;
+}
+/* Murty restatement: up to k best; real-assignment block (nR,nC) (pass n,n for plain k-best).
+ * Returns the number found; scores[k], assignments[k*n]. */
+int rfsor_murty(double *C, int n, int nR, int nC, int kmax, double *scores, int *assignments) {
+  std::vector<double *> rows(n);
+  for (int i = 0; i < n; i++) rows[i] = C + (size_t)i * n;
+  orc::Murty m(rows.data(), n);
+  m.setRealAssignmentBlock(nR, nC);
+  std::vector<int> a;
+  double s;
+  int k = 0;
+  for (; k < kmax; k++) {
+    int rank = m.findNextBest(a, s);
+    if (rank == -1) break;
+    scores[k] = s;
+    if (assignments) memcpy(assignments + (size_t)k * n, a.data(), n * sizeof(int));
+  }
+  return k;
+}
+/* rfsMeasurementLikelihood on an explicit likelihood table (nE x nZ, already gated, incl. Pd):
+ * the partition / enumeration / Murty part only (RBPHDFilter.hpp:865-996) -- for unit tests. */
+double rfsor_partition_likelihood(const double *L, int nE, int nZ, const double *evalPd, double clutter, double clutterIntegral,
+                                  long *murty_calls, long *lonerow_hits) {
+  /* build a throw-away filter whose model reproduces `clutter` and whose table is injected */
+  orc::CostMatrixGeneral cm(nE, nZ);
+  for (int m = 0; m < nE; m++)
+    for (int n = 0; n < nZ; n++) cm.C_[m][n] = L[m * nZ + n];
+  int nP = cm.partition();
+  double l = 1;
+  const double BIG = -1000;
+  for (int p = 0; p < nP; p++) {
+    double pl = 0;
+    unsigned nCols, nRows;
+    std::vector<std::vector<double>> Cp;
+    std::vector<unsigned> rowIdx, colIdx;
+    bool zero = !cm.getPartitionSize(p, nRows, nCols);
+    bool useMurty = !(nRows + nCols <= 8 || zero);
+    zero = !cm.getPartition(p, Cp, nRows, nCols, rowIdx, colIdx, useMurty);
+    if (zero) {
+      pl = 1;
+      for (unsigned r = 0; r < nRows; r++) pl *= evalPd[rowIdx[r]];
+      for (unsigned c = 0; c < nCols; c++) pl *= clutter;
+    } else {
+      if (nCols == 0 && nRows == 1 && lonerow_hits) (*lonerow_hits)++;
+      for (unsigned r = 0; r < nRows; r++)
+        for (unsigned c = 0; c < nCols; c++) {
+          if (Cp[r][c] == 0) Cp[r][c] = BIG;
+          else { Cp[r][c] = log(Cp[r][c]); if (Cp[r][c] < BIG) Cp[r][c] = BIG; }
+        }
+      if (useMurty) {
+        for (unsigned r = 0; r < nRows; r++)
+          for (unsigned c = nCols; c < nRows + nCols; c++) Cp[r][c] = (r == c - nCols) ? log(1 - evalPd[rowIdx[r]]) : BIG;
+        for (unsigned r = nRows; r < nRows + nCols; r++)
+          for (unsigned c = 0; c < nCols; c++) Cp[r][c] = (r - nRows == c) ? log(clutter) : BIG;
+        for (unsigned r = nRows; r < nRows + nCols; r++)
+          for (unsigned c = nCols; c < nRows + nCols; c++) Cp[r][c] = 0;
+        std::vector<double *> rows(nRows + nCols);
+        for (unsigned r = 0; r < nRows + nCols; r++) rows[r] = Cp[r].data();
+        orc::Murty murty(rows.data(), nRows + nCols);
+        if (murty_calls) (*murty_calls)++;
+        murty.setRealAssignmentBlock(nRows, nCols);
+        std::vector<int> a;
+        double pll = 0;
+        for (int k = 0; k < 200; k++) {
+          int rank = murty.findNextBest(a, pll);
+          if (rank == -1 || pll < BIG) break;
+          pl += exp(pll);
+        }
+      } else {
+        std::vector<unsigned> o(nRows + nCols);
+        orc::PermLex perm(nRows, nCols, true);
+        unsigned nPerm = perm.next(o.data());
+        while (nPerm != 0) {
+          double pll = 0;
+          for (unsigned a = 0; a < nRows; a++) {
+            if (o[a] < nCols) pll += Cp[a][o[a]];
+            else pll += log(1 - evalPd[rowIdx[a]]);
+          }
+          for (unsigned a = nRows; a < nRows + nCols; a++)
+            if (o[a] < nCols) pll += log(clutter);
+          pl += exp(pll);
+          nPerm = perm.next(o.data());
+        }
+      }
+    }
+    l *= pl;
+  }
+  return l / clutterIntegral;
+}
+
+} /* extern "C" */

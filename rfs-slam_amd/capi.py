@@ -1,0 +1,309 @@
+"""ctypes binding of the C ABI in include/rfsgpu.h.
+
+The binding is prefix-parametrised (`rfsgpu_` for the product library).  The same class is reused by
+the test-only oracle binding (oracle/binding.py, prefix `rfsor_`) so parity tests drive both sides
+through identical calls.  Nothing here imports or references the oracle.
+
+Mirrors the public surface of rfs::RBPHDFilter (reference include/RBPHDFilter.hpp:72-251): method
+names follow the reference (predict / update / getGMSize / getLandmark / ...), error behaviour too
+(getGMSize -> -1, getLandmark -> None on bad indices, update/predict raise only on engine failure).
+"""
+import ctypes as C
+import numpy as np
+
+OK = 0
+ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_NO_DEVICE, ERR_UNSUPPORTED = 1, 2, 3, 4, 5
+MODEL_RNGBRG_2D = 0
+MAX_Z = 64
+MAX_EVAL = 64
+
+
+class FilterConfig(C.Structure):
+    """RBPHDFilter::Config (include/RBPHDFilter.hpp:90-146)."""
+    _fields_ = [
+        ("birthGaussianWeight", C.c_double),
+        ("birthGaussianMeasurementCountThreshold", C.c_uint),
+        ("birthGaussianMeasurementCheckThreshold", C.c_uint),
+        ("birthGaussianMeasurementSupportDist", C.c_double),
+        ("birthGaussianCurrentMeasurementCountThreshold", C.c_uint),
+        ("newGaussianCreateInnovMDThreshold", C.c_double),
+        ("importanceWeightingEvalPointCount", C.c_int),
+        ("importanceWeightingEvalPointGuassianWeight", C.c_double),
+        ("importanceWeightingMeasurementLikelihoodMDThreshold", C.c_double),
+        ("gaussianMergingThreshold", C.c_double),
+        ("gaussianMergingCovarianceInflationFactor", C.c_double),
+        ("gaussianPruningThreshold", C.c_double),
+        ("minUpdatesBeforeResample", C.c_int),
+        ("minMeasurementsBeforeResample", C.c_int),
+        ("useClusterProcess", C.c_int),
+    ]
+
+
+class RngBrgConfig(C.Structure):
+    """MeasurementModel_RngBrg::Config + R (include/MeasurementModel_RngBrg.hpp:65-71)."""
+    _fields_ = [
+        ("R", C.c_double * 4),
+        ("probabilityOfDetection", C.c_double),
+        ("uniformClutterIntensity", C.c_double),
+        ("rangeLimMax", C.c_double),
+        ("rangeLimMin", C.c_double),
+        ("rangeLimBuffer", C.c_double),
+    ]
+
+
+class KFConfig(C.Structure):
+    """KalmanFilter_RngBrg::Config (include/KalmanFilter_RngBrg.hpp:55-60)."""
+    _fields_ = [("rangeInnovationThreshold", C.c_double), ("bearingInnovationThreshold", C.c_double)]
+
+
+class Timing(C.Structure):
+    """RBPHDFilter::TimingInfo (include/RBPHDFilter.hpp:152-167), ns."""
+    _fields_ = [(n + s, C.c_longlong) for n in
+                ("predict", "mapUpdate", "mapUpdate_kf", "particleWeighting", "mapMerge", "mapPrune", "particleResample")
+                for s in ("_wall", "_cpu")]
+
+
+# every symbol include/rfsgpu.h declares, without prefix (tests check the product .so exports them all)
+ABI_SYMBOLS = [
+    "abi_version", "create", "destroy", "last_error", "default_filter_config", "set_filter_config",
+    "get_filter_config", "set_model_rngbrg", "set_kf_config", "set_lmk_process_noise", "set_poses", "get_poses",
+    "set_weights", "get_weights", "gm_size", "get_landmark", "import_gm", "export_gm", "gm_sizes", "predict_map",
+    "update", "update_map", "importance_weighting", "merge", "prune", "get_unused", "landmarks_in_fov",
+    "weight_sums", "weight_sums_async", "weight_sums_device_ptr", "normalize_weights", "resample_apply",
+    "get_timing", "reset_timing", "synchronize", "stream", "last_kernel_ns", "mat_perm",
+]
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+class EngineError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"rfsgpu status {status}: {msg}")
+        self.status = status
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+class CFilter:
+    """One filter handle behind the C ABI (one GPU / one shard of particles)."""
+
+    def __init__(self, lib, prefix, n_particles, model=MODEL_RNGBRG_2D, device_id=0, gm_capacity=512):
+        self._lib, self._p = lib, prefix
+        self.n = int(n_particles)
+        self.dm = 2
+        self.dz = 2
+        self._h = C.c_void_p()
+        fn = self._fn("create")
+        fn.restype = C.c_int
+        rc = fn(C.byref(self._h), C.c_int(model), C.c_int(self.n), C.c_int(device_id), C.c_int(gm_capacity))
+        if rc != OK:
+            self._h = C.c_void_p()
+            raise EngineError(rc, "create failed (no gfx950 device / bad arguments)")
+
+    # -- plumbing ------------------------------------------------------------------------------
+    def _fn(self, name):
+        return getattr(self._lib, self._p + name)
+
+    def _call(self, name, *args):
+        fn = self._fn(name)
+        fn.restype = C.c_int
+        rc = fn(self._h, *args)
+        if rc != OK:
+            le = self._fn("last_error")
+            le.restype = C.c_char_p
+            raise EngineError(rc, (le(self._h) or b"").decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            d = self._fn("destroy")
+            d.restype = None
+            d(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _ptr(a):
+        return a.ctypes.data_as(C.c_void_p)
+
+    # -- configuration -------------------------------------------------------------------------
+    def default_filter_config(self):
+        cfg = FilterConfig()
+        fn = self._fn("default_filter_config")
+        fn.restype = None
+        fn(C.byref(cfg))
+        return cfg
+
+    def set_filter_config(self, cfg):
+        self._call("set_filter_config", C.byref(cfg))
+
+    def get_filter_config(self):
+        cfg = FilterConfig()
+        self._call("get_filter_config", C.byref(cfg))
+        return cfg
+
+    def set_model_rngbrg(self, R, Pd, c, rmax, rmin, rbuf):
+        m = RngBrgConfig()
+        R = _f64(R, (4,))
+        for k in range(4):
+            m.R[k] = R[k]
+        m.probabilityOfDetection, m.uniformClutterIntensity = Pd, c
+        m.rangeLimMax, m.rangeLimMin, m.rangeLimBuffer = rmax, rmin, rbuf
+        self._call("set_model_rngbrg", C.byref(m))
+
+    def set_kf_config(self, range_thr, bearing_thr):
+        k = KFConfig(range_thr, bearing_thr)
+        self._call("set_kf_config", C.byref(k))
+
+    def set_lmk_process_noise(self, Q):
+        self._call("set_lmk_process_noise", self._ptr(_f64(Q, (self.dm * self.dm,))))
+
+    # -- particle state ------------------------------------------------------------------------
+    def set_poses(self, x, cov=None):
+        x = _f64(x, (self.n, 3))
+        if cov is None:
+            self._call("set_poses", self._ptr(x), C.c_void_p(), C.c_int(0))
+        else:
+            cov = _f64(cov)
+            stride = 0 if cov.size == 9 else 9
+            assert cov.size in (9, 9 * self.n)
+            self._call("set_poses", self._ptr(x), self._ptr(cov), C.c_int(stride))
+
+    def get_poses(self):
+        x = np.empty((self.n, 3))
+        self._call("get_poses", self._ptr(x))
+        return x
+
+    def set_weights(self, w):
+        self._call("set_weights", self._ptr(_f64(w, (self.n,))))
+
+    def get_weights(self):
+        w = np.empty(self.n)
+        self._call("get_weights", self._ptr(w))
+        return w
+
+    # -- map access ----------------------------------------------------------------------------
+    def getGMSize(self, i):
+        fn = self._fn("gm_size")
+        fn.restype = C.c_int
+        return fn(self._h, C.c_int(i))
+
+    def gm_sizes(self):
+        s = np.empty(self.n, dtype=np.int32)
+        self._call("gm_sizes", self._ptr(s))
+        return s
+
+    def getLandmark(self, i, m):
+        mean = np.empty(self.dm)
+        cov = np.empty((self.dm, self.dm))
+        w = C.c_double()
+        fn = self._fn("get_landmark")
+        fn.restype = C.c_int
+        rc = fn(self._h, C.c_int(i), C.c_int(m), self._ptr(mean), self._ptr(cov), C.byref(w))
+        if rc != OK:
+            return None
+        return mean, cov, w.value
+
+    def import_gm(self, i, w, mean, cov):
+        w = _f64(w).reshape(-1)
+        n = w.size
+        mean = _f64(mean, (n, self.dm))
+        cov = _f64(cov, (n, self.dm, self.dm))
+        self._call("import_gm", C.c_int(i), C.c_int(n), self._ptr(w), self._ptr(mean), self._ptr(cov))
+
+    def export_gm(self, i):
+        n = max(self.getGMSize(i), 0)
+        w, wp = np.empty(n), np.empty(n)
+        mean, cov = np.empty((n, self.dm)), np.empty((n, self.dm, self.dm))
+        nout = C.c_int()
+        self._call("export_gm", C.c_int(i), C.c_int(n), C.byref(nout), self._ptr(w), self._ptr(wp), self._ptr(mean), self._ptr(cov))
+        k = min(nout.value, n)
+        return w[:k], wp[:k], mean[:k], cov[:k]
+
+    # -- hot path ------------------------------------------------------------------------------
+    def predict_map(self, add_birth=True):
+        self._call("predict_map", C.c_int(1 if add_birth else 0))
+
+    def _z(self, Z):
+        Z = _f64(Z).reshape(-1, self.dz) if np.size(Z) else np.zeros((0, self.dz))
+        return Z, C.c_int(Z.shape[0])
+
+    def update(self, Z):
+        Z, n = self._z(Z)
+        self._call("update", self._ptr(Z), n)
+
+    def update_map(self, Z):
+        Z, n = self._z(Z)
+        self._call("update_map", self._ptr(Z), n)
+
+    def importance_weighting(self):
+        self._call("importance_weighting")
+
+    def merge(self):
+        self._call("merge")
+
+    def prune(self):
+        self._call("prune")
+
+    def get_unused(self, i):
+        idx = np.empty(MAX_Z, dtype=np.int32)
+        n = C.c_int()
+        self._call("get_unused", C.c_int(i), self._ptr(idx), C.c_int(MAX_Z), C.byref(n))
+        return idx[: n.value].copy()
+
+    def landmarks_in_fov(self, i):
+        n = C.c_int()
+        self._call("landmarks_in_fov", C.c_int(i), C.byref(n))
+        return n.value
+
+    # -- weights / resampling ------------------------------------------------------------------
+    def weight_sums(self):
+        out = np.empty(2)
+        self._call("weight_sums", self._ptr(out))
+        return out
+
+    def normalize_weights(self, total, sum_dev_ptr=None):
+        self._call("normalize_weights", C.c_double(total), C.c_void_p(sum_dev_ptr))
+
+    def resample_apply(self, src_slot):
+        s = np.ascontiguousarray(src_slot, dtype=np.int32)
+        assert s.size == self.n
+        self._call("resample_apply", self._ptr(s))
+
+    # -- timing --------------------------------------------------------------------------------
+    def getTimingInfo(self):
+        t = Timing()
+        self._call("get_timing", C.byref(t))
+        return t
+
+    def reset_timing(self):
+        self._call("reset_timing")
+
+    def synchronize(self):
+        self._call("synchronize")
+
+
+def mat_perm(lib, prefix, A, device_id=0):
+    """MatPerm::calc (src/MatrixPermanent.cpp:41-112), batched: A is (batch, n, n)."""
+    A = _f64(A)
+    if A.ndim == 2:
+        A = A[None]
+    b, n, _ = A.shape
+    out = np.empty(b)
+    fn = getattr(lib, prefix + "mat_perm")
+    fn.restype = C.c_int
+    rc = fn(A.ctypes.data_as(C.c_void_p), C.c_int(n), C.c_int(b), out.ctypes.data_as(C.c_void_p), C.c_int(device_id))
+    if rc != OK:
+        raise EngineError(rc, "mat_perm failed")
+    return out

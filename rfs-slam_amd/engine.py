@@ -1,0 +1,137 @@
+"""Loader for librfsgpu.so + the host-side mirror of rfs::RBPHDFilter for the device path.
+
+`RBPHDFilter` mirrors the reference class's public members for the hot path
+(include/RBPHDFilter.hpp:72-251): predict-side map ops, update(), getGMSize(), getLandmark(),
+getTimingInfo(), public `config`; resampling follows ParticleFilter::resample
+(include/ParticleFilter.hpp:399-492) on the host exactly like the reference (host RNG), and hands
+the copy plan to the device through rfsgpu_resample_apply.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+from . import capi
+from .build import LIB
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree HIP extension.  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise RuntimeError(
+                f"{LIB} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+                "There is no CPU fallback for the device path.")
+        _lib = C.CDLL(LIB)
+        _lib.rfsgpu_abi_version.restype = C.c_int
+    return _lib
+
+
+def mat_perm(A, device_id=0):
+    return capi.mat_perm(load_library(), "rfsgpu_", A, device_id)
+
+
+class RBPHDFilter(capi.CFilter):
+    """Device-resident RB-PHD filter shard (one GPU).  Mirrors rfs::RBPHDFilter for the update path."""
+
+    def __init__(self, n_particles, device_id=0, gm_capacity=512, model=capi.MODEL_RNGBRG_2D):
+        super().__init__(load_library(), "rfsgpu_", n_particles, model=model, device_id=device_id, gm_capacity=gm_capacity)
+        self.config = self.default_filter_config()
+        self.effNParticles_t = n_particles / 4.0  # ParticleFilter.hpp:232
+        self.nUpdatesSinceResample = 0
+        self.nMeasurementsSinceResample = 0
+        self.resampleOccured = False
+
+    # ParticleFilter::setEffectiveParticleCountThreshold (ParticleFilter.hpp:386-391)
+    def setEffectiveParticleCountThreshold(self, t):
+        self.effNParticles_t = float(t)
+
+    def apply_config(self):
+        self.set_filter_config(self.config)
+
+    def last_kernel_ns(self):
+        ns = (C.c_longlong * 4)()
+        self._call("last_kernel_ns", ns)
+        return list(ns)
+
+    def weight_sums_async(self):
+        self._call("weight_sums_async")
+
+    def weight_sums_device_ptr(self):
+        fn = self._fn("weight_sums_device_ptr")
+        fn.restype = C.c_void_p
+        return fn(self._h)
+
+    def stream(self):
+        fn = self._fn("stream")
+        fn.restype = C.c_void_p
+        return fn(self._h)
+
+    # RBPHDFilter::update (RBPHDFilter.hpp:444-541) including the resample-or-normalise tail.
+    def update_and_resample(self, Z, u01_fn=np.random.random):
+        self.apply_config()
+        self.nUpdatesSinceResample += 1
+        Z = np.asarray(Z, dtype=np.float64).reshape(-1, self.dz)
+        if Z.shape[0] == 0:
+            return False
+        self.nMeasurementsSinceResample += Z.shape[0]
+        self.update(Z)
+        self.resampleOccured = False
+        if (self.nUpdatesSinceResample >= self.config.minUpdatesBeforeResample and
+                self.nMeasurementsSinceResample >= self.config.minMeasurementsBeforeResample):
+            self.resampleOccured = self.resample(u01_fn)
+        if self.resampleOccured:
+            self.nUpdatesSinceResample = 0
+            self.nMeasurementsSinceResample = 0
+        else:
+            s = self.weight_sums()
+            self.normalize_weights(s[0])
+        return self.resampleOccured
+
+    # ParticleFilter::resample (ParticleFilter.hpp:399-492): host logic on the N weights.
+    def resample(self, u01_fn=np.random.random):
+        s = self.weight_sums()
+        self.normalize_weights(s[0])
+        w = self.get_weights()
+        n = self.n
+        neff = 1.0 / float(np.sum(w * w))
+        if neff > self.effNParticles_t and neff / n > self.effNParticles_t / n:
+            return False
+        src = systematic_resample_plan(w, float(u01_fn()))
+        self.resample_apply(src)
+        return True
+
+
+def systematic_resample_plan(w, u01):
+    """Systematic sampling + slot assignment of ParticleFilter::resample (ParticleFilter.hpp:419-479).
+    Returns src_slot[k]: which (kept-in-place) particle slot k copies; k itself when it is kept."""
+    n = w.size
+    interval = 1.0 / float(n)
+    sample_point = interval * u01
+    idx = 0
+    cumulative = w[0]
+    sampled = np.zeros(n, dtype=bool)
+    sampled_idx = np.zeros(n, dtype=np.int64)
+    for i in range(n):
+        while sample_point > cumulative and idx < n - 1:
+            idx += 1
+            cumulative += w[idx]
+        sampled_idx[i] = idx
+        sampled[idx] = True
+        sample_point += interval
+    src = np.arange(n, dtype=np.int32)
+    nxt = 0
+    prev = -1
+    for i in range(n):
+        idx = int(sampled_idx[i])
+        first = not (i > 0 and idx == prev)
+        prev = idx
+        if first:
+            continue
+        while nxt < n and sampled[nxt]:
+            nxt += 1
+        src[nxt] = idx
+        nxt += 1
+    return src

@@ -1,0 +1,181 @@
+"""Pins the oracle's combinatorial restatements (CPU only).
+
+ - mat_perm against the reference's own known-answer test (test/MatrixPermanentTest.hpp:55-87)
+ - PermutationLexicographic against the REAL reference class compiled into oracle/_ref (when present)
+   and against the committed golden fixture generated from it (tests/golden/permlex.json)
+ - Hungarian against scipy.optimize.linear_sum_assignment
+ - Murty (plain k-best) against the reference's BruteForceLinearAssignment (oracle/_ref + golden fixture)
+ - Murty with the real-assignment block + lexicographic enumeration against an independent brute force
+"""
+import itertools
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+from scipy.optimize import linear_sum_assignment
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+DERANGEMENTS = {2: 1, 3: 2, 4: 9, 5: 44, 6: 265, 7: 1854, 8: 14833, 9: 133496, 10: 1334961, 11: 14684570, 12: 176214841}
+
+
+def test_mat_perm_known_answers(ob):
+    # reference test: ones - identity, n = 2..12, ASSERT_DOUBLE_EQ (4 ulp)
+    for n, want in DERANGEMENTS.items():
+        A = np.ones((n, n)) - np.eye(n)
+        got = ob.mat_perm(A)[0]
+        assert abs(got - want) <= 4 * np.spacing(float(want)), (n, got, want)
+
+
+def brute_perm(A):
+    n = A.shape[0]
+    return sum(np.prod([A[i, p[i]] for i in range(n)]) for p in itertools.permutations(range(n)))
+
+
+def test_mat_perm_random_vs_bruteforce(ob):
+    rng = np.random.default_rng(0)
+    for n in range(1, 8):
+        A = rng.uniform(-1, 1, (3, n, n))
+        got = ob.mat_perm(A)
+        for b in range(3):
+            assert np.isclose(got[b], brute_perm(A[b]), rtol=1e-10, atol=1e-12)
+
+
+def test_permlex_matches_reference_build(ob):
+    ref = ob.load_ref()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    for nM in range(0, 5):
+        for nZ in range(0, 5):
+            if nM + nZ == 0:
+                continue
+            a = ob.permlex_all(nM, nZ)
+            b = ob.permlex_all(nM, nZ, lib=ref, sym="rfsref_permlex_all")
+            assert a.shape == b.shape and np.array_equal(a, b), (nM, nZ)
+
+
+def test_permlex_matches_golden_fixture(ob):
+    with open(os.path.join(GOLD, "permlex.json")) as fh:
+        gold = json.load(fh)
+    for key, perms in gold.items():
+        nM, nZ = map(int, key.split("x"))
+        a = ob.permlex_all(nM, nZ)
+        assert a.tolist() == perms, key
+
+
+def test_permlex_counts():
+    # sum_k C(r,k) C(c,k) k!  (SURVEY a11): 7 for 2x2, 34 for 3x3, 209 for 4x4
+    from oracle import binding as ob
+    for r, c, want in [(2, 2, 7), (3, 3, 34), (4, 4, 209), (1, 0, 1), (0, 1, 1), (3, 5, 136)]:
+        assert ob.permlex_all(r, c).shape[0] == want
+
+
+def test_hungarian_vs_scipy(ob):
+    rng = np.random.default_rng(1)
+    for n in range(1, 12):
+        for _ in range(5):
+            Cm = rng.uniform(-5, 5, (n, n))
+            ok, soln, cost, Cafter = ob.hungarian(Cm)
+            assert ok
+            r, c = linear_sum_assignment(Cm, maximize=True)
+            assert np.isclose(cost, Cm[r, c].sum(), rtol=1e-12, atol=1e-12)
+            assert sorted(soln.tolist()) == list(range(n))
+            # the in-place offset is restored up to rounding (HungarianMethod.hpp:244-250)
+            assert np.allclose(Cafter, Cm, rtol=0, atol=1e-12)
+
+
+def test_murty_plain_vs_reference_bruteforce(ob):
+    ref = ob.load_ref()
+    if ref is None:
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(2)
+    for n in (2, 3, 4, 5, 6):
+        Cm = rng.uniform(-3, 0, (n, n))
+        want, _ = ob.ref_bruteforce(Cm)
+        k = min(200, math.factorial(n))
+        got, assign = ob.murty(Cm, kmax=k)
+        assert got.size == k
+        assert np.allclose(got, want[:k], rtol=0, atol=1e-9)
+        assert len({tuple(a) for a in assign.tolist()}) == k  # all distinct
+
+
+def test_murty_plain_vs_golden_fixture(ob):
+    with open(os.path.join(GOLD, "bruteforce_ranked.json")) as fh:
+        gold = json.load(fh)
+    for case in gold:
+        Cm = np.array(case["C"])
+        want = np.array(case["scores"])
+        got, _ = ob.murty(Cm, kmax=len(want))
+        assert np.allclose(got, want, rtol=0, atol=1e-9)
+
+
+def enumerate_partial(Lp, pd, clutter):
+    """Independent brute force of sum over partial assignments (rows -> distinct cols or miss)."""
+    r, c = Lp.shape
+    total = 0.0
+    for k in range(0, min(r, c) + 1):
+        for rows in itertools.combinations(range(r), k):
+            for cols in itertools.permutations(range(c), k):
+                t = 1.0
+                for a, b in zip(rows, cols):
+                    t *= Lp[a, b]
+                for a in range(r):
+                    if a not in rows:
+                        t *= 1 - pd[a]
+                t *= clutter ** (c - k)
+                total += t
+    return total
+
+
+def test_partition_likelihood_small_connected(ob):
+    rng = np.random.default_rng(3)
+    for r, c in [(1, 1), (2, 2), (3, 3), (2, 4), (4, 3), (4, 4)]:
+        L = rng.uniform(0.1, 2.0, (r, c))  # fully connected -> a single partition, r+c <= 8 -> lexicographic
+        pd = rng.uniform(0.5, 0.99, r)
+        cl, ci = 1e-2, 0.37
+        got, mc, lr = ob.partition_likelihood(L, pd, cl, ci)
+        want = enumerate_partial(L, pd, cl) / ci
+        assert mc == 0
+        assert np.isclose(got, want, rtol=1e-11)
+
+
+def test_partition_likelihood_murty_matches_enumeration_when_few_terms(ob):
+    # r+c > 8 -> Murty-200; sparse matrix with < 200 significant assignments -> equals the full sum
+    rng = np.random.default_rng(4)
+    r, c = 5, 5
+    L = np.zeros((r, c))
+    for i in range(r):       # a chain so the component is connected but sparse
+        L[i, i] = rng.uniform(0.5, 2)
+        if i + 1 < c:
+            L[i, i + 1] = rng.uniform(0.5, 2)
+    pd = np.full(r, 0.9)
+    cl, ci = 1e-3, 1.0
+    got, mc, lr = ob.partition_likelihood(L, pd, cl, ci)
+    assert mc == 1
+    want = enumerate_partial(L, pd, cl)
+    assert np.isclose(got, want, rtol=1e-9), (got, want)
+
+
+def test_partition_indexing_quirk(ob):
+    """SURVEY §7 hard part 2 probe: rows {0,1} isolated, 2<->col0, 3<->col1.
+    Visited: p0 = zero partition [rows 0,1] -> Pd0*Pd1 ; p1 = lone row 1 as NON-zero -> (1-Pd1) ;
+    p2 = [row2,col0] ; the component [row3,col1] is never visited."""
+    L = np.zeros((4, 2))
+    L[2, 0] = 0.7
+    L[3, 1] = 0.4
+    pd = np.array([0.9, 0.8, 0.95, 0.85])
+    cl, ci = 1e-2, 1.0
+    got, mc, lr = ob.partition_likelihood(L, pd, cl, ci)
+    p2 = L[2, 0] + (1 - pd[2]) * cl
+    want = (pd[0] * pd[1]) * (1 - pd[1]) * p2
+    assert lr == 1
+    assert np.isclose(got, want, rtol=1e-12)
+
+
+def test_partition_no_eval_points(ob):
+    # nE = 0: all measurements clutter -> c^nZ / integral
+    L = np.zeros((0, 3))
+    got, _, _ = ob.partition_likelihood(L, np.zeros(0), 0.5, 2.0)
+    assert np.isclose(got, 0.5 ** 3 / 2.0)
