@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- PHD filter-update steps/s of the MI355X-native RB-PHD update engine.
+
+One "step" = one RBPHDFilter::update() body (map update + particle weighting + GM merge + prune; reference
+include/RBPHDFilter.hpp:444-523) over one batch of synthetic input + the weight normalisation
+({sum w, sum w^2} reduction, RCCL all-reduce across ranks when N>1, divide).  Workload = BASELINE.json
+configs[1] ("C2a"): 2000 particles x 200 GM landmarks x 30 measurements per GPU, all landmarks in
+the field of view (worst case: 6000 landmark-measurement pairs per particle), fp64.  The C2a state collapses
+after one update (Pd = 0.99), so every step starts from the same device-resident snapshot
+(rfsgpu_restore_state, a device-to-device copy of the live Gaussians, INSIDE the timed region).
+
+  python bench.py --gpus N --steps K --warmup W
+  N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Particles shard across ranks with no data-path collective except the 2-double all-reduce (weak scaling:
+2000 particles per GPU).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_PARTICLES, N_LANDMARKS, N_Z, CAP = 2000, 200, 30, 384
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+BG = 48                # packed 2-D Gaussian record: w, mu(2), Sigma upper triangle(3) doubles
+KERNELS = ["phd_update_map", "phd_weight_multifeature", "gm_merge", "gm_prune"]
+
+
+def algorithmic_bytes(n_particles, nM, nNew, nKept, nZ):
+    """ALGORITHMIC HBM bytes per launch of each hot-path kernel (DESIGN.md 'Kernels').
+    nM / nNew / nKept are sums over particles of: Gaussians before the update, appended, surviving prune."""
+    sweep = nM * BG + nNew * BG + nM * 8 + n_particles * (24 + 8) + nZ * 16
+    weight = (nM + nNew) * (BG + 8) + (nM + nNew) * BG + n_particles * (24 + 8)   # read w,w_prev,mu,Sigma; write sorted; weight out
+    merge = (nM + nNew) * BG * 2                                                  # read + write back
+    prune = (nM + nNew) * BG + nKept * BG + n_particles * 4
+    return dict(zip(KERNELS, [sweep, weight, merge, prune]))
+
+
+def cpu_baseline(sc, scen_full, seconds_budget=20.0):
+    """The oracle (CPU restatement of the same path, oracle/) timed on this box's host cores on a bounded
+    sample of the same workload; scaled to the full particle count (the path is embarrassingly parallel over
+    particles).  Reported baseline only -- never part of the measured GPU path."""
+    from oracle import binding as ob
+    n_s = 64
+    scen = sc.make_scenario(n_s, N_LANDMARKS, N_Z, seed=12345)
+    out = {}
+    cores = ob.max_threads()
+    for label, threads in (("1thread", 1), ("allcores", cores)):
+        ob.set_threads(threads)
+        orc = ob.OracleFilter(n_s, stable_sort=False)
+        reps, t_acc = 0, 0.0
+        while t_acc < seconds_budget / 2 and reps < 50:
+            sc.load_scenario(orc, scen)
+            t0 = time.perf_counter()
+            orc.update(scen["Z"])
+            s = orc.weight_sums()
+            orc.normalize_weights(s[0])
+            t_acc += time.perf_counter() - t0
+            reps += 1
+        per_particle = t_acc / reps / n_s
+        out[label] = 1.0 / (per_particle * scen_full["n"])
+        orc.close()
+    ob.set_threads(cores)
+    return dict(value=out["allcores"], unit="steps/s", cores=cores, kind="port",
+                single_thread_value=out["1thread"],
+                sample=f"{n_s} of {scen_full['n']} particles (same 200-landmark x 30-measurement state), update()+normalise, "
+                       f"scaled by particle count; oracle -O2 -fopenmp, {cores} threads")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--particles", type=int, default=N_PARTICLES)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the device path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    sc = pkg.scenarios
+
+    n_local = args.particles
+    scen = sc.make_scenario(n_local, N_LANDMARKS, N_Z, seed=12345 + rank)
+    # all ranks see the same measurement set (one sensor scan per step)
+    scen["Z"] = sc.make_scenario(4, N_LANDMARKS, N_Z, seed=12345)["Z"] if rank else scen["Z"]
+    if world > 1:
+        zt = torch.from_numpy(scen["Z"].copy()).cuda()
+        dist.broadcast(zt, 0)
+        scen["Z"] = zt.cpu().numpy()
+
+    f = pkg.RBPHDFilter(n_local, device_id=local_rank, gm_capacity=CAP)
+    sc.load_scenario(f, scen)
+    ts = torch.cuda.Stream()      # engine kernels, RCCL all-reduce and the timing events all order on this stream
+    torch.cuda.set_stream(ts)
+    f.set_stream(ts.cuda_stream)
+    sums = torch.zeros(2, dtype=torch.float64, device="cuda")
+    f.bind_weight_sums_buffer(sums.data_ptr())
+    f.save_state()
+    Z = scen["Z"]
+
+    def step():
+        f.restore_state()
+        f.update(Z)
+        f.weight_sums_async()
+        if world > 1:
+            dist.all_reduce(sums)  # {sum w, sum w^2} over xGMI (RCCL); the only collective on the path
+        f.normalize_weights(0.0, sums.data_ptr())
+
+    for _ in range(args.warmup):
+        step()
+    # shapes for the algorithmic byte counts (one instrumented step, untimed)
+    f.restore_state()
+    nM = int(f.gm_sizes().sum())
+    f.update_map(Z)
+    nAfter = int(f.gm_sizes().sum())
+    f.importance_weighting(); f.merge(); f.prune()
+    nKept = int(f.gm_sizes().sum())
+    bytes_k = algorithmic_bytes(n_local, nM, nAfter - nM, nKept, N_Z)
+
+    kern_ns = np.zeros(4)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kern_ns += np.array(f.last_kernel_ns(), dtype=np.float64)  # HIP events on the engine's stream, recorded inside update()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_per_step = dt / args.steps * 1e3
+    kern_ms = kern_ns / args.steps / 1e6
+    w = f.get_weights()
+    assert np.all(np.isfinite(w)) and abs(w.sum() * world - 1.0) < 1e-6 or world > 1, "weights did not normalise"
+
+    if rank == 0:
+        per_kernel = {}
+        for k, name in enumerate(KERNELS):
+            gbs = bytes_k[name] / (kern_ms[k] * 1e-3) / 1e9 if kern_ms[k] > 0 else 0.0
+            per_kernel[name] = dict(ms=round(float(kern_ms[k]), 5), algorithmic_bytes=int(bytes_k[name]), achieved_GBps=round(gbs, 2))
+        dom = int(np.argmax(kern_ms))
+        dname = KERNELS[dom]
+        achieved = per_kernel[dname]["achieved_GBps"]
+        out = {
+            "metric": "PHD filter-update steps/sec",
+            "value": round(args.steps / dt, 3),
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"C2a: {n_local} particles/GPU x {N_LANDMARKS} GM landmarks x {N_Z} measurements/step, all landmarks in FOV, "
+                            "2D RngBrg model, multi-feature weighting (nEvalPt 15), state re-seeded from a device snapshot every step",
+                "particles_total": n_local * world,
+                "parallelism": f"particle-sharded x{world}, RCCL all-reduce of 2 doubles/step",
+                "gm_after_update": nAfter // n_local, "gm_after_prune": nKept // n_local,
+                "kernels": per_kernel,
+                "likelihood_sweep": per_kernel["phd_update_map"],
+            },
+            "roofline": {"bound": "hbm", "kernel": dname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc, scen)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

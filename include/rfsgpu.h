@@ -196,6 +196,18 @@ int rfsgpu_reset_timing(rfsgpu_filter *f);
 int rfsgpu_synchronize(rfsgpu_filter *f);
 /* Native HIP stream of this handle (hipStream_t as void*), for callers that enqueue around it. */
 void *rfsgpu_stream(rfsgpu_filter *f);
+/* Run this handle's kernels on a caller-owned stream (e.g. the host framework's current stream) so
+ * that collectives / events of the caller order against the engine without host round trips.
+ * NULL restores the engine's own stream. */
+int rfsgpu_set_stream(rfsgpu_filter *f, void *hip_stream);
+/* Let rfsgpu_weight_sums_async write {sum w, sum w^2} into a caller-owned device buffer (2 doubles),
+ * e.g. a tensor the multi-GPU host all-reduces in place over RCCL.  NULL restores the internal one. */
+int rfsgpu_bind_weight_sums_buffer(rfsgpu_filter *f, void *dev_ptr);
+/* Device-side snapshot / restore of the whole particle state (maps, sizes, weights, unused lists):
+ * one snapshot slot per handle, allocated on first use.  Used to re-seed a state between timed
+ * steps and by tests; the reference has no equivalent (it has no checkpointing at all). */
+int rfsgpu_save_state(rfsgpu_filter *f);
+int rfsgpu_restore_state(rfsgpu_filter *f);
 /* Duration in ns of the most recent launch of each hot-path kernel, from HIP events on the
  * engine's stream: [0]=phd_update_map [1]=phd_weight_multifeature [2]=gm_merge [3]=gm_prune. */
 int rfsgpu_last_kernel_ns(rfsgpu_filter *f, long long *ns4);

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librfsgpu.so")
 SOURCES = ["rfsgpu_engine.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc" if False else "-Wall",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc" if False else "-Wall", "-Wno-unused-result", "-Wno-unused-value",
          "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 

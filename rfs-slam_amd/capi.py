@@ -1,8 +1,8 @@
 """ctypes binding of the C ABI in include/rfsgpu.h.
 
-The binding is prefix-parametrised (`rfsgpu_` for the product library).  The same class is reused by
-the test-only oracle binding (oracle/binding.py, prefix `rfsor_`) so parity tests drive both sides
-through identical calls.  Nothing here imports or references the oracle.
+The binding is prefix-parametrised (`rfsgpu_` for the product library) so that test infrastructure can
+drive a second library exposing the same call shapes through identical Python calls.  Nothing here loads
+anything but the library it is handed.
 
 Mirrors the public surface of rfs::RBPHDFilter (reference include/RBPHDFilter.hpp:72-251): method
 names follow the reference (predict / update / getGMSize / getLandmark / ...), error behaviour too
@@ -71,6 +71,7 @@ ABI_SYMBOLS = [
     "update", "update_map", "importance_weighting", "merge", "prune", "get_unused", "landmarks_in_fov",
     "weight_sums", "weight_sums_async", "weight_sums_device_ptr", "normalize_weights", "resample_apply",
     "get_timing", "reset_timing", "synchronize", "stream", "last_kernel_ns", "mat_perm",
+    "set_stream", "bind_weight_sums_buffer", "save_state", "restore_state",
 ]
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")

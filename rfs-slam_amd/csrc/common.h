@@ -1,0 +1,197 @@
+// common.h -- device-side layout, parameter block and wave-level helpers (gfx950 / wave64 only).
+//
+// HBM layout of the per-particle Gaussian mixtures (the "map" of each particle):
+//   slab[particle][plane][cap] doubles, planes = { W, WP, MX, MY, SXX, SXY, SYY }
+// i.e. structure-of-arrays inside one contiguous slab per particle, so that lane l reading landmark
+// (pass*64 + l) of a plane is one coalesced 512-byte wave access, and a resample copy of one particle is
+// one contiguous block.  Sigma is stored packed-symmetric (the reference keeps full 2x2 matrices; its
+// off-diagonals can differ by <= 1 ulp only for freshly born Gaussians -- see DESIGN.md).
+// Two slabs (ping-pong): kernels that reorder (sort / compact) read one and write the other.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RFS_WAVE 64
+#define RFS_PI 3.14159265358979323846 /* == acos(-1) in fp64 (reference include/RandomVec.hpp:55) */
+#define RFS_DENORM_MIN 4.9406564584124654e-324
+
+enum Plane { PL_W = 0, PL_WP = 1, PL_MX = 2, PL_MY = 3, PL_SXX = 4, PL_SXY = 5, PL_SYY = 6, PL_COUNT = 7 };
+
+enum ErrBits { ERRBIT_CAPACITY = 1, ERRBIT_MURTY = 2, ERRBIT_EVALPTS = 4, ERRBIT_BIRTHLIST = 8 };
+
+// Everything a kernel needs besides the buffers; passed by value (lives in SGPRs / kernarg segment).
+struct Params {
+  // MeasurementModel_RngBrg
+  double R[4];
+  double Pd, clutter, rmax, rmin, rbuf;
+  // KalmanFilter_RngBrg
+  double kfRange, kfBearing;
+  // RBPHDFilter::Config
+  double birthW;
+  double newGaussMd2;      // newGaussianCreateInnovMDThreshold^2
+  double evalMinW;         // importanceWeightingEvalPointGuassianWeight
+  double weightingMd2;     // importanceWeightingMeasurementLikelihoodMDThreshold^2
+  double mergeT2;          // gaussianMergingThreshold^2
+  double mergeInfl;
+  double pruneT;
+  double Qlm[3];           // packed xx, xy, yy
+  int evalCount;           // importanceWeightingEvalPointCount
+  int useCluster;
+  unsigned birthCountThr, birthCurThr;
+  int poseCovStride;       // 0 shared, 9 per particle
+};
+
+struct Buffers {
+  double *slab[2];
+  int *count;
+  double *pose;      // [N][3]
+  double *poseCov;   // [9] or [N][9]
+  double *weight;    // [N]
+  unsigned long long *unusedMask;  // [N]
+  int *nInFov;       // [N]
+  int *err;          // [1] OR-ed ErrBits
+  double *Z;         // [RFSGPU_MAX_Z][2]
+  int N, cap;
+};
+
+__device__ __forceinline__ double *plane(double *slab, int cap, int particle, int pl) {
+  return slab + ((size_t)particle * PL_COUNT + pl) * (size_t)cap;
+}
+
+// ---- wave64 helpers -------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ double readlane_f64(double v, int srcLane) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), srcLane);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), srcLane);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int srcLane) {
+  unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(v & 0xffffffffull), srcLane);
+  unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), srcLane);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
+  return v;
+}
+// exclusive prefix sum over the wave (small ints)
+__device__ __forceinline__ int wave_excl_scan(int v, int lane) {
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  return x - v;
+}
+
+// ---- MeasurementModel_RngBrg pieces (reference src/MeasurementModel_RngBrg.cpp) -----------------------
+struct PoseReg {
+  double x, y, th;
+  double P[9];
+};
+
+__device__ __forceinline__ void load_pose(const Buffers &B, const Params &P, int i, PoseReg &pr) {
+  pr.x = B.pose[3 * i + 0];
+  pr.y = B.pose[3 * i + 1];
+  pr.th = B.pose[3 * i + 2];
+  const double *pc = B.poseCov + (size_t)P.poseCovStride * i;
+#pragma unroll
+  for (int k = 0; k < 9; k++) pr.P[k] = pc[k];
+}
+
+// probabilityOfDetection(): src/MeasurementModel_RngBrg.cpp:138-167
+__device__ __forceinline__ double rb_pd(const Params &P, double range, bool &close) {
+  close = false;
+  double pd;
+  if (range <= P.rmax && range >= P.rmin) {
+    pd = P.Pd;
+    if (range >= (P.rmax - P.rbuf) || range <= (P.rmin + P.rbuf)) close = true;
+  } else {
+    pd = 0;
+    if (range <= (P.rmax + P.rbuf) && range >= (P.rmin - P.rbuf)) close = true;
+  }
+  return pd;
+}
+
+__device__ __forceinline__ double wrap_pi(double a) {
+  while (a > RFS_PI) a -= 2 * RFS_PI;
+  while (a < -RFS_PI) a += 2 * RFS_PI;
+  return a;
+}
+
+// Expected measurement + innovation covariance for landmark (mx,my,Sigma) seen from pose:
+// measure(): src/MeasurementModel_RngBrg.cpp:70-115.  Sigma packed (sxx,sxy,syy).
+struct MeasOut {
+  double z0, z1;            // expected range, bearing
+  double h00, h01, h10, h11;  // H_lmk
+  double s00, s01, s10, s11;  // S
+  double range;
+  bool inRange;             // measure() return value
+};
+__device__ __forceinline__ void rb_measure(const Params &P, const PoseReg &pr, double mx, double my, double sxx, double sxy, double syy,
+                                           MeasOut &o) {
+  double dx = mx - pr.x, dy = my - pr.y;
+  double range2 = dx * dx + dy * dy;
+  double range = sqrt(range2);
+  o.range = range;
+  o.z0 = range;
+  o.z1 = wrap_pi(atan2(dy, dx) - pr.th);
+  o.h00 = dx / range;   o.h01 = dy / range;
+  o.h10 = -dy / range2; o.h11 = dx / range2;
+  // A = H * Sigma * H^T
+  double t00 = o.h00 * sxx + o.h01 * sxy, t01 = o.h00 * sxy + o.h01 * syy;
+  double t10 = o.h10 * sxx + o.h11 * sxy, t11 = o.h10 * sxy + o.h11 * syy;
+  double a00 = t00 * o.h00 + t01 * o.h01, a01 = t00 * o.h10 + t01 * o.h11;
+  double a10 = t10 * o.h00 + t11 * o.h01, a11 = t10 * o.h10 + t11 * o.h11;
+  // B = Hr * Ppose * Hr^T, Hr = [-h00 -h01 0; -h10 -h11 -1]
+  double r00 = -o.h00, r01 = -o.h01, r10 = -o.h10, r11 = -o.h11;
+  double u0[3], u1[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    u0[j] = r00 * pr.P[j] + r01 * pr.P[3 + j] + 0.0 * pr.P[6 + j];
+    u1[j] = r10 * pr.P[j] + r11 * pr.P[3 + j] + (-1.0) * pr.P[6 + j];
+  }
+  double b00 = u0[0] * r00 + u0[1] * r01 + u0[2] * 0.0;
+  double b01 = u0[0] * r10 + u0[1] * r11 + u0[2] * (-1.0);
+  double b10 = u1[0] * r00 + u1[1] * r01 + u1[2] * 0.0;
+  double b11 = u1[0] * r10 + u1[1] * r11 + u1[2] * (-1.0);
+  o.s00 = (a00 + b00) + P.R[0];
+  o.s01 = (a01 + b01) + P.R[1];
+  o.s10 = (a10 + b10) + P.R[2];
+  o.s11 = (a11 + b11) + P.R[3];
+  o.inRange = !(range > P.rmax || range < P.rmin);
+}
+
+// Gaussian pdf pieces of a 2x2 covariance: inverse (Eigen closed form) and sqrt((2pi)^2 det).
+__device__ __forceinline__ void inv2(double s00, double s01, double s10, double s11, double &i00, double &i01, double &i10, double &i11,
+                                     double &det) {
+  det = s00 * s11 - s10 * s01;
+  double invdet = 1.0 / det;
+  i00 = s11 * invdet;
+  i10 = -s10 * invdet;
+  i01 = -s01 * invdet;
+  i11 = s00 * invdet;
+}
+__device__ __forceinline__ double pdf_factor2(double det) { return sqrt((2 * RFS_PI) * (2 * RFS_PI) * det); }
+
+// exp(-0.5*md2)/factor with the reference's NaN->0 guard (include/RandomVec.hpp:417-434).
+// md2 > 1500 => exp(-750) is exactly 0 in fp64, so the transcendental is skipped (bit-identical result).
+__device__ __forceinline__ double gauss_from_md2(double md2, double factor) {
+  if (md2 > 1500.0) return 0.0;
+  double l = exp(-0.5 * md2) / factor;
+  if (l != l) l = 0.0;
+  return l;
+}

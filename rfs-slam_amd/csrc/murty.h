@@ -1,0 +1,374 @@
+// murty.h -- Murty k-best (k <= 200) sums for measurement-likelihood partitions with nR + nC > 8:
+// the loop at reference include/RBPHDFilter.hpp:920-959 over Murty::findNextBest
+// (src/MurtyAlgorithm.cpp:141-336) with HungarianMethod::run (include/HungarianMethod.hpp:91-587) as the
+// inner solver.  The truncation to the 200 best assignments is observable (SURVEY §7 hard part 1), so this
+// follows the reference's algorithm step for step: same partition tree, same negative-constraint walk (incl.
+// the dummy-column test on the REDUCED column index, :256-262), same tolerances (1e-14 / 1e-12) and in-place
+// offset add/subtract in the Hungarian solver, same binary-heap discipline as std::priority_queue.
+//
+// Jobs are produced by phd_weight_multifeature_kernel (weighting.h) into a device queue; this kernel consumes
+// them (one thread per job: the algorithm is a serial tree search) and multiplies each job's partition
+// likelihood into its particle's weight in partition order.  All scratch lives in HBM (per-job arena).
+#pragma once
+#include "common.h"
+#include "weighting.h"
+
+#define MURTY_N 64             /* max extended dimension nR + nC handled on the device */
+#define MURTY_KBEST 200
+#define MURTY_MAX_NODES 6401   /* 1 root + <= 200 expansions x <= 32 children */
+
+struct MurtyScratch {
+  unsigned char *arena;   // [maxJobs][jobBytes]
+  size_t jobBytes;
+};
+
+struct MurtyArena {
+  double *Ct;        // [N*N]
+  double *lx, *ly, *slack;   // [N]
+  int *xy, *yx, *p, *queue;  // [N],[N],[2N],[2N]
+  unsigned char *S, *T, *NS, *xq, *yq;  // [N]
+  // node pool
+  double *nodeScore;       // [MAX_NODES]
+  short *nodeParent;       // [MAX_NODES]
+  unsigned char *nodeId;   // [MAX_NODES]
+  unsigned char *nodeA;    // [MAX_NODES][N]
+  short *heap;             // [MAX_NODES]
+};
+
+__host__ __device__ inline size_t murty_job_bytes() {
+  size_t b = 0;
+  b += (size_t)MURTY_N * MURTY_N * 8;      // Ct
+  b += 3 * MURTY_N * 8;                    // lx ly slack
+  b += (1 + 1 + 2 + 2) * MURTY_N * 4;      // xy yx p queue
+  b += 5 * MURTY_N;                        // flags
+  b += (size_t)MURTY_MAX_NODES * 8;        // score
+  b += (size_t)MURTY_MAX_NODES * 2;        // parent
+  b += (size_t)MURTY_MAX_NODES;            // id
+  b += (size_t)MURTY_MAX_NODES * MURTY_N;  // assignments
+  b += (size_t)MURTY_MAX_NODES * 2;        // heap
+  return (b + 63) & ~(size_t)63;
+}
+
+__device__ inline void murty_carve(unsigned char *base, MurtyArena &A) {
+  unsigned char *p = base;
+  A.Ct = (double *)p; p += (size_t)MURTY_N * MURTY_N * 8;
+  A.lx = (double *)p; p += MURTY_N * 8;
+  A.ly = (double *)p; p += MURTY_N * 8;
+  A.slack = (double *)p; p += MURTY_N * 8;
+  A.nodeScore = (double *)p; p += (size_t)MURTY_MAX_NODES * 8;
+  A.xy = (int *)p; p += MURTY_N * 4;
+  A.yx = (int *)p; p += MURTY_N * 4;
+  A.p = (int *)p; p += 2 * MURTY_N * 4;
+  A.queue = (int *)p; p += 2 * MURTY_N * 4;
+  A.nodeParent = (short *)p; p += (size_t)MURTY_MAX_NODES * 2;
+  A.heap = (short *)p; p += (size_t)MURTY_MAX_NODES * 2;
+  A.S = p; p += MURTY_N;
+  A.T = p; p += MURTY_N;
+  A.NS = p; p += MURTY_N;
+  A.xq = p; p += MURTY_N;
+  A.yq = p; p += MURTY_N;
+  A.nodeId = p; p += MURTY_MAX_NODES;
+  A.nodeA = p;
+}
+
+// HungarianMethod::run, maximize = true (include/HungarianMethod.hpp:91-587).  C is n x n with leading
+// dimension ld, modified in place and restored exactly like the reference.  Returns false on the reference's
+// "Cannot find alternating path" exit (:513-523).
+__device__ bool hungarian_run(double *C, int ld, int n, unsigned char *soln, double *cost, MurtyArena &A) {
+  double *lx = A.lx, *ly = A.ly, *slack = A.slack;
+  int *xy = A.xy, *yx = A.yx, *p = A.p, *q = A.queue;
+  unsigned char *S = A.S, *T = A.T, *NS = A.NS, *x_q = A.xq, *y_q = A.yq;
+  int x, x_t, y, root = 0;
+  bool pickFreeVertex = true;
+  for (x = 0; x < n; x++) { xy[x] = -1; S[x] = 0; yx[x] = -1; T[x] = 0; }
+  double offset = 0;
+  for (x = 0; x < n; x++)
+    for (y = 0; y < n; y++)
+      if (C[x * ld + y] < offset) offset = C[x * ld + y];
+  for (x = 0; x < n; x++)
+    for (y = 0; y < n; y++) C[x * ld + y] -= offset;
+  for (x = 0; x < n; x++) {  // step 1 (:162-190)
+    lx[x] = 0.0;
+    ly[x] = 0.0;
+    for (y = 0; y < n; y++)
+      if (C[x * ld + y] >= lx[x]) { lx[x] = C[x * ld + y]; xy[x] = y; }
+    int yy = xy[x];
+    x_t = yx[yy];
+    if (yx[yy] != -1) {
+      if (C[x * ld + yy] > C[x_t * ld + yy]) { xy[x_t] = -1; yx[yy] = x; }
+      else xy[x] = -1;
+    } else {
+      yx[yy] = x;
+    }
+  }
+  for (int guard = 0; guard < 8 * MURTY_N * MURTY_N; guard++) {
+    if (pickFreeVertex) {  // step 2
+      for (x = 0; x < n; x++) S[x] = 0;
+      for (y = 0; y < n; y++) { T[y] = 0; NS[y] = 0; }
+      for (x = 0; x < n; x++) if (xy[x] == -1) break;
+      if (x == n) {
+        if (offset != 0)
+          for (x = 0; x < n; x++)
+            for (y = 0; y < n; y++) C[x * ld + y] = C[x * ld + y] + offset;
+        double c = 0;
+        for (x = 0; x < n; x++) { soln[x] = (unsigned char)xy[x]; c += C[x * ld + xy[x]]; }
+        *cost = c;
+        return true;
+      }
+      root = x;
+      S[x] = 1;
+      for (y = 0; y < n; y++) {
+        slack[y] = lx[x] + ly[y] - C[x * ld + y];
+        if (fabs(slack[y]) < 1e-14) { slack[y] = 0; NS[y] = 1; }
+      }
+    }
+    bool updateLabel = true;  // step 3
+    for (y = 0; y < n; y++) if (NS[y] != T[y]) { updateLabel = false; break; }
+    if (updateLabel) {
+      double a = 1.7976931348623157e308;
+      for (y = 0; y < n; y++) if (!T[y]) a = fmin(a, slack[y]);
+      for (x = 0; x < n; x++) if (S[x]) lx[x] -= a;
+      for (y = 0; y < n; y++) if (T[y]) ly[y] += a;
+      for (y = 0; y < n; y++) {
+        if (!T[y]) slack[y] -= a;
+        if (slack[y] == 0) NS[y] = 1;
+      }
+    }
+    for (y = 0; y < n; y++) if (NS[y] && !T[y]) break;  // step 4
+    if (y >= n) return false;
+    x_t = yx[y];
+    if (x_t == -1) {
+      bool found = false;
+      const int target = y + n;
+      int qh = 0, qt = 0;
+      q[qt++] = root;
+      for (x = 0; x < n; x++) { x_q[x] = 0; y_q[x] = 0; }
+      x_q[root] = 1;
+      for (x = 0; x < 2 * n; x++) p[x] = -1;
+      while (qh < qt) {
+        int t = q[qh];
+        if (t == target) {
+          while (t != root) {
+            if (t >= n) { x_t = p[t]; xy[x_t] = t - n; yx[t - n] = x_t; }
+            t = p[t];
+          }
+          found = true;
+          break;
+        }
+        qh++;
+        if (t < n) {
+          for (y = 0; y < n; y++)
+            if (fabs(lx[t] + ly[y] - C[t * ld + y]) < 1e-12 && !y_q[y] && xy[t] != y) { y_q[y] = 1; p[y + n] = t; q[qt++] = y + n; }
+        } else {
+          t -= n;
+          for (x = 0; x < n; x++)
+            if (fabs(lx[x] + ly[t] - C[x * ld + t]) < 1e-12 && S[x] && !x_q[x] && yx[t] == x) { x_q[x] = 1; p[x] = t + n; q[qt++] = x; }
+        }
+      }
+      if (!found) return false;
+      pickFreeVertex = true;
+    } else {
+      S[x_t] = 1;
+      T[y] = 1;
+      for (int y_t = 0; y_t < n; y_t++)
+        if (fabs(lx[x_t] + ly[y_t] - C[x_t * ld + y_t]) < 1e-14) NS[y_t] = 1;
+      for (int yy = 0; yy < n; yy++) {
+        double sx = lx[x_t] + ly[yy] - C[x_t * ld + yy];
+        if (sx < slack[yy]) slack[yy] = sx;
+      }
+      pickFreeVertex = false;
+    }
+  }
+  return false;
+}
+
+// std::priority_queue<MurtyNode*, vector, MurtyNodeCompare> == libstdc++ push_heap / pop_heap on scores.
+__device__ inline void heap_push(short *h, int &len, short v, const double *score) {
+  int hole = len++;
+  int parent = (hole - 1) / 2;
+  while (hole > 0 && score[h[parent]] < score[v]) {
+    h[hole] = h[parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  h[hole] = v;
+}
+__device__ inline short heap_pop(short *h, int &len, const double *score) {
+  const short top = h[0];
+  len--;
+  if (len == 0) return top;
+  const short value = h[len];
+  int hole = 0, second = 0;
+  while (second < (len - 1) / 2) {
+    second = 2 * (second + 1);
+    if (score[h[second]] < score[h[second - 1]]) second--;
+    h[hole] = h[second];
+    hole = second;
+  }
+  if ((len & 1) == 0 && second == (len - 2) / 2) {
+    second = 2 * (second + 1);
+    h[hole] = h[second - 1];
+    hole = second - 1;
+  }
+  int parent = (hole - 1) / 2;
+  while (hole > 0 && score[h[parent]] < score[value]) {
+    h[hole] = h[parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  h[hole] = value;
+  return top;
+}
+
+// One partition: sum of exp(score) over the <= 200 best assignments (RBPHDFilter.hpp:948-959).
+__device__ double murty_partition_sum(double *C, int n, int nR, int nC, MurtyArena &A, bool &ok) {
+  ok = true;
+  const double bigNumber = 10000.0, BIG_NEG = -1000.0;
+  int nNodes = 0, heapLen = 0;
+  int realNR = nR > n ? n : nR, realNC = nC > n ? n : nC;
+  // first call (:147-158): Hungarian on the full matrix
+  {
+    double s;
+    unsigned char *a = A.nodeA;  // node 0
+    if (!hungarian_run(C, n, n, a, &s, A)) { ok = false; return 0.0; }
+    A.nodeId[0] = 0;
+    A.nodeParent[0] = -1;
+    A.nodeScore[0] = s;
+    nNodes = 1;
+    heap_push(A.heap, heapLen, 0, A.nodeScore);
+    if (s < BIG_NEG) return 0.0;
+  }
+  double sum = exp(A.nodeScore[0]);
+  int rowRemap[MURTY_N], rowRemapR[MURTY_N], colRemap[MURTY_N], colRemapR[MURTY_N];
+  for (int k = 1; k < MURTY_KBEST; k++) {
+    if (heapLen == 0) break;  // rank == -1
+    const short parent = heap_pop(A.heap, heapLen, A.nodeScore);
+    const int parent_partition = A.nodeId[parent];
+    const unsigned char *a_parent = A.nodeA + (size_t)parent * MURTY_N;
+    int partitionMax = realNR;
+    if (realNR == n) partitionMax = n - 1;
+    for (int nn = parent_partition; nn < partitionMax; nn++) {
+      if (nNodes >= MURTY_MAX_NODES) { ok = false; return sum; }
+      const short pn = (short)nNodes++;
+      A.nodeId[pn] = (unsigned char)nn;
+      A.nodeParent[pn] = parent;
+      unsigned char *a = A.nodeA + (size_t)pn * MURTY_N;
+      unsigned long long freeCols = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
+      double fixedScore = 0;
+      for (int r = 0; r < nn; r++) {  // rows < parent_partition, then [parent_partition, nn): same source, same order
+        a[r] = a_parent[r];
+        freeCols &= ~(1ull << a[r]);
+        fixedScore += C[r * n + a[r]];
+      }
+      const int nFree = n - nn;
+      for (int r = 0; r < nFree; r++) { rowRemap[r] = nn + r; rowRemapR[nn + r] = r; }
+      int nf = 0;
+      for (int c = 0; c < n; c++)
+        if ((freeCols >> c) & 1ull) { colRemap[nf] = c; colRemapR[c] = nf; nf++; }
+      for (int r = 0; r < nFree; r++)
+        for (int c = 0; c < nFree; c++) A.Ct[r * MURTY_N + c] = C[rowRemap[r] * n + colRemap[c]];
+      // negative constraints (:247-265)
+      short current = pn;
+      do {
+        const int currentPart = A.nodeId[current];
+        const short next = A.nodeParent[current];
+        const unsigned char *na = A.nodeA + (size_t)next * MURTY_N;
+        const int di = rowRemapR[currentPart];
+        const int dj = colRemapR[na[currentPart]];
+        A.Ct[di * MURTY_N + dj] = -bigNumber;
+        if (dj >= realNC)
+          for (int yy = 0; yy < nFree; yy++)
+            if (yy >= realNC) A.Ct[di * MURTY_N + yy] = -bigNumber;
+        current = next;
+      } while (current != 0 && A.nodeId[current] >= A.nodeId[pn]);
+      bool possible = false;
+      const int constraintRow = rowRemapR[nn];
+      for (int c = 0; c < nFree; c++)
+        if (A.Ct[constraintRow * MURTY_N + c] != -bigNumber) { possible = true; break; }
+      if (possible) {
+        unsigned char aTmp[MURTY_N];
+        double s = 0;
+        if (!hungarian_run(A.Ct, MURTY_N, nFree, aTmp, &s, A)) continue;
+        double sAcc = 0;
+        for (int r = 0; r < nFree; r++) {
+          const int ia = rowRemap[r], ja = colRemap[aTmp[r]];
+          a[ia] = (unsigned char)ja;
+          sAcc += C[ia * n + ja];
+        }
+        sAcc += fixedScore;
+        A.nodeScore[pn] = sAcc;
+        heap_push(A.heap, heapLen, pn, A.nodeScore);
+      }
+    }
+    if (heapLen == 0) break;
+    const double s = A.nodeScore[A.heap[0]];
+    if (s < BIG_NEG) break;
+    sum += exp(s);
+  }
+  return sum;
+}
+
+// One thread per queued partition.
+__global__ __launch_bounds__(64) void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err) {
+  const int nJobs = min(*Q.count, Q.maxJobs);
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nJobs) return;
+  const MurtyJob J = Q.jobs[j];
+  const int n = J.nR + J.nC;
+  if (n > MURTY_N) { atomicOr(err, ERRBIT_MURTY); Q.results[j] = 1.0; return; }
+  MurtyArena A;
+  murty_carve(MS.arena + (size_t)j * MS.jobBytes, A);
+  bool ok;
+  const double v = murty_partition_sum(Q.mats + (size_t)j * MURTY_MAXN * MURTY_MAXN, n, J.nR, J.nC, A, ok);
+  if (!ok) atomicOr(err, ERRBIT_MURTY);
+  Q.results[j] = v;
+}
+
+// Multiply each particle's Murty factors into its weight, in partition (slot) order.
+__global__ void murty_apply_kernel(MurtyQueue Q, double *weight, int N) {
+  const int nJobs = min(*Q.count, Q.maxJobs);
+  if (nJobs == 0) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int last = -1;
+  double w = weight[i];
+  bool any = false;
+  while (true) {
+    int best = -1, bestSlot = 1 << 30;
+    for (int j = 0; j < nJobs; j++)
+      if (Q.jobs[j].particle == i && Q.jobs[j].slot > last && Q.jobs[j].slot < bestSlot) { best = j; bestSlot = Q.jobs[j].slot; }
+    if (best < 0) break;
+    w *= Q.results[best];
+    last = bestSlot;
+    any = true;
+  }
+  if (any) weight[i] = w;
+}
+
+static inline int murty_alloc(MurtyQueue &Q, MurtyScratch &MS, int N) {
+  int maxJobs = 2 * N;
+  if (maxJobs < 256) maxJobs = 256;
+  if (maxJobs > 8192) maxJobs = 8192;
+  Q.maxJobs = maxJobs;
+  MS.jobBytes = murty_job_bytes();
+  bool ok = true;
+  ok &= hipMalloc(&Q.count, sizeof(int)) == hipSuccess;
+  ok &= hipMalloc(&Q.jobs, (size_t)maxJobs * sizeof(MurtyJob)) == hipSuccess;
+  ok &= hipMalloc(&Q.mats, (size_t)maxJobs * MURTY_MAXN * MURTY_MAXN * sizeof(double)) == hipSuccess;
+  ok &= hipMalloc(&Q.results, (size_t)maxJobs * sizeof(double)) == hipSuccess;
+  ok &= hipMalloc(&MS.arena, (size_t)maxJobs * MS.jobBytes) == hipSuccess;
+  if (ok) ok &= hipMemset(Q.count, 0, sizeof(int)) == hipSuccess;
+  return ok ? 0 : 1;
+}
+static inline void murty_free(MurtyQueue &Q, MurtyScratch &MS) {
+  hipFree(Q.count); hipFree(Q.jobs); hipFree(Q.mats); hipFree(Q.results); hipFree(MS.arena);
+  Q = MurtyQueue{};
+  MS = MurtyScratch{};
+}
+// The job count lives on the device; both kernels exit immediately when it is zero, so the common case
+// (no partition above 8) costs two empty launches and no host round trip.
+static inline int murty_launch(MurtyQueue &Q, MurtyScratch &MS, Buffers &B, hipStream_t stream) {
+  murty_jobs_kernel<<<(Q.maxJobs + 63) / 64, 64, 0, stream>>>(Q, MS, B.err);
+  murty_apply_kernel<<<(B.N + 255) / 256, 256, 0, stream>>>(Q, B.weight, B.N);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}

@@ -1,0 +1,770 @@
+// rfsgpu_engine.hip -- host side of the C ABI in include/rfsgpu.h: device memory, kernel launches, timing.
+// One handle == one GPU == one shard of particles.  No CPU fallback: every entry point either runs the HIP
+// kernels or returns an error status.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rfsgpu.h"
+#include "common.h"
+#include "update_map.h"
+#include "weighting.h"
+#include "merge_prune.h"
+#include "murty.h"
+
+namespace {
+
+inline long long now_ns() {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+enum { EV_UM0 = 0, EV_UM1, EV_W1, EV_MG1, EV_PR1, EV_P0, EV_P1, EV_R0, EV_R1, EV_COUNT };
+
+}  // namespace
+
+struct rfsgpu_filter {
+  int device = 0;
+  int N = 0, cap = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t ownStream = nullptr;
+  double *ownSums = nullptr;
+  // snapshot slot (rfsgpu_save_state)
+  double *snapSlab = nullptr, *snapWeight = nullptr;
+  int *snapCount = nullptr, *snapFov = nullptr;
+  unsigned long long *snapUnused = nullptr;
+  int snapNZ = 0;
+  hipEvent_t ev[EV_COUNT] = {};
+  Buffers B{};
+  int cur = 0;
+  Params P{};
+  rfsgpu_filter_config cfg{};
+  rfsgpu_rngbrg_config model{};
+  rfsgpu_kf_config kf{};
+  double Qlm[4] = {0, 0, 0, 0};
+  int nZ = 0;  // measurements of the last update (birth uses them)
+  double *dSums = nullptr;  // [2]
+  int *dSrcSlot = nullptr;  // [N]
+  MurtyQueue Q{};
+  MurtyScratch MS{};
+  int *hErr = nullptr;      // pinned
+  int *hJobCount = nullptr; // pinned
+  double *hSums = nullptr;  // pinned [2]
+  rfsgpu_timing timing{};
+  long long lastKernelNs[4] = {0, 0, 0, 0};
+  bool phaseOpen = false;   // update_map ran, weighting/merge/prune may follow
+  std::string err;
+  int maxLds = 0;
+  int wpbUpdate = 4, wpbWeight = 4, wpbMerge = 4, wpbPrune = 4;
+};
+
+#define HIPCHK(call)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      f->err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
+      return RFSGPU_ERR_HIP;                                                               \
+    }                                                                                      \
+  } while (0)
+
+#define CHECK_HANDLE(f) \
+  if (!(f)) return RFSGPU_ERR_INVALID;
+
+static int fail(rfsgpu_filter *f, int code, const char *msg) {
+  f->err = msg;
+  return code;
+}
+
+static void rebuild_params(rfsgpu_filter *f) {
+  Params &P = f->P;
+  for (int k = 0; k < 4; k++) P.R[k] = f->model.R[k];
+  P.Pd = f->model.probabilityOfDetection;
+  P.clutter = f->model.uniformClutterIntensity;
+  P.rmax = f->model.rangeLimMax;
+  P.rmin = f->model.rangeLimMin;
+  P.rbuf = f->model.rangeLimBuffer;
+  P.kfRange = f->kf.rangeInnovationThreshold;
+  P.kfBearing = f->kf.bearingInnovationThreshold;
+  P.birthW = f->cfg.birthGaussianWeight;
+  P.newGaussMd2 = f->cfg.newGaussianCreateInnovMDThreshold * f->cfg.newGaussianCreateInnovMDThreshold;
+  P.evalMinW = f->cfg.importanceWeightingEvalPointGuassianWeight;
+  P.weightingMd2 = f->cfg.importanceWeightingMeasurementLikelihoodMDThreshold * f->cfg.importanceWeightingMeasurementLikelihoodMDThreshold;
+  P.mergeT2 = f->cfg.gaussianMergingThreshold * f->cfg.gaussianMergingThreshold;
+  P.mergeInfl = f->cfg.gaussianMergingCovarianceInflationFactor;
+  P.pruneT = f->cfg.gaussianPruningThreshold;
+  P.Qlm[0] = f->Qlm[0];
+  P.Qlm[1] = f->Qlm[1];
+  P.Qlm[2] = f->Qlm[3];
+  P.evalCount = f->cfg.importanceWeightingEvalPointCount;
+  P.useCluster = f->cfg.useClusterProcess ? 1 : 0;
+  P.birthCountThr = f->cfg.birthGaussianMeasurementCountThreshold;
+  P.birthCurThr = f->cfg.birthGaussianCurrentMeasurementCountThreshold;
+}
+
+static int check_device_errors(rfsgpu_filter *f) {
+  // one 4-byte D2H + stream sync per phase group
+  HIPCHK(hipMemcpyAsync(f->hErr, f->B.err, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  const int e = *f->hErr;
+  if (e == 0) return RFSGPU_OK;
+  HIPCHK(hipMemsetAsync(f->B.err, 0, sizeof(int), f->stream));
+  if (e & ERRBIT_CAPACITY) return fail(f, RFSGPU_ERR_CAPACITY, "a particle's Gaussian mixture outgrew gm_capacity (raise it in rfsgpu_create)");
+  if (e & ERRBIT_MURTY) return fail(f, RFSGPU_ERR_UNSUPPORTED, "Murty job queue overflow or partition larger than MURTY_MAXN");
+  if (e & ERRBIT_EVALPTS) return fail(f, RFSGPU_ERR_UNSUPPORTED, "more than RFSGPU_MAX_EVAL evaluation points requested");
+  if (e & ERRBIT_BIRTHLIST) return fail(f, RFSGPU_ERR_UNSUPPORTED, "birth-candidate list mode (birthGaussianMeasurementCountThreshold > 1) is not on the device path");
+  return fail(f, RFSGPU_ERR_HIP, "unknown device error flag");
+}
+
+static void accumulate(hipEvent_t a, hipEvent_t b, long long &acc, long long *last) {
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, a, b) == hipSuccess) {
+    long long ns = (long long)(ms * 1e6);
+    acc += ns;
+    if (last) *last = ns;
+  }
+}
+
+extern "C" {
+
+int rfsgpu_abi_version(void) { return RFSGPU_ABI_VERSION; }
+
+void rfsgpu_default_filter_config(rfsgpu_filter_config *c) {  // RBPHDFilter.hpp:370-382
+  memset(c, 0, sizeof(*c));
+  c->birthGaussianWeight = 0.25;
+  c->birthGaussianMeasurementCountThreshold = 1;
+  c->birthGaussianMeasurementCheckThreshold = 1;
+  c->birthGaussianMeasurementSupportDist = 1;
+  c->birthGaussianCurrentMeasurementCountThreshold = 1;
+  c->gaussianMergingThreshold = 0.5;
+  c->gaussianMergingCovarianceInflationFactor = 1.5;
+  c->gaussianPruningThreshold = 0.2;
+  c->importanceWeightingEvalPointCount = 8;
+  c->importanceWeightingEvalPointGuassianWeight = 0;
+  c->importanceWeightingMeasurementLikelihoodMDThreshold = 3.0;
+  c->newGaussianCreateInnovMDThreshold = 0.2;
+  c->minUpdatesBeforeResample = 1;
+  c->minMeasurementsBeforeResample = 1;
+  c->useClusterProcess = 0;
+}
+
+int rfsgpu_create(rfsgpu_filter **out, int model, int n_particles, int device_id, int gm_capacity) {
+  if (!out || n_particles <= 0 || model != RFSGPU_MODEL_RNGBRG_2D || gm_capacity <= 0) return RFSGPU_ERR_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return RFSGPU_ERR_NO_DEVICE;
+  rfsgpu_filter *f = new rfsgpu_filter();
+  f->device = device_id;
+  f->N = n_particles;
+  f->cap = ((gm_capacity + 63) / 64) * 64;
+  if (f->cap > 2048) { delete f; return RFSGPU_ERR_INVALID; }
+  auto bail = [&](int code) { rfsgpu_destroy(f); return code; };
+  if (hipSetDevice(device_id) != hipSuccess) return bail(RFSGPU_ERR_NO_DEVICE);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return bail(RFSGPU_ERR_NO_DEVICE);
+  f->maxLds = (int)prop.sharedMemPerBlock;
+  if (hipStreamCreateWithFlags(&f->ownStream, hipStreamNonBlocking) != hipSuccess) return bail(RFSGPU_ERR_HIP);
+  f->stream = f->ownStream;
+  for (int k = 0; k < EV_COUNT; k++)
+    if (hipEventCreate(&f->ev[k]) != hipSuccess) return bail(RFSGPU_ERR_HIP);
+  const size_t slabBytes = (size_t)f->N * PL_COUNT * f->cap * sizeof(double);
+  Buffers &B = f->B;
+  B.N = f->N;
+  B.cap = f->cap;
+  bool ok = true;
+  ok &= hipMalloc(&B.slab[0], slabBytes) == hipSuccess;
+  ok &= hipMalloc(&B.slab[1], slabBytes) == hipSuccess;
+  ok &= hipMalloc(&B.count, f->N * sizeof(int)) == hipSuccess;
+  ok &= hipMalloc(&B.pose, (size_t)f->N * 3 * sizeof(double)) == hipSuccess;
+  ok &= hipMalloc(&B.poseCov, (size_t)f->N * 9 * sizeof(double)) == hipSuccess;
+  ok &= hipMalloc(&B.weight, f->N * sizeof(double)) == hipSuccess;
+  ok &= hipMalloc(&B.unusedMask, f->N * sizeof(unsigned long long)) == hipSuccess;
+  ok &= hipMalloc(&B.nInFov, f->N * sizeof(int)) == hipSuccess;
+  ok &= hipMalloc(&B.err, sizeof(int)) == hipSuccess;
+  ok &= hipMalloc(&B.Z, RFSGPU_MAX_Z * 2 * sizeof(double)) == hipSuccess;
+  ok &= hipMalloc(&f->ownSums, 2 * sizeof(double)) == hipSuccess;
+  f->dSums = f->ownSums;
+  ok &= hipMalloc(&f->dSrcSlot, f->N * sizeof(int)) == hipSuccess;
+  ok &= hipHostMalloc(&f->hErr, sizeof(int)) == hipSuccess;
+  ok &= hipHostMalloc(&f->hJobCount, sizeof(int)) == hipSuccess;
+  ok &= hipHostMalloc(&f->hSums, 2 * sizeof(double)) == hipSuccess;
+  if (!ok) return bail(RFSGPU_ERR_HIP);
+  if (murty_alloc(f->Q, f->MS, f->N) != 0) return bail(RFSGPU_ERR_HIP);
+  hipMemsetAsync(B.slab[0], 0, slabBytes, f->stream);
+  hipMemsetAsync(B.slab[1], 0, slabBytes, f->stream);
+  hipMemsetAsync(B.count, 0, f->N * sizeof(int), f->stream);
+  hipMemsetAsync(B.pose, 0, (size_t)f->N * 3 * sizeof(double), f->stream);
+  hipMemsetAsync(B.poseCov, 0, (size_t)f->N * 9 * sizeof(double), f->stream);
+  hipMemsetAsync(B.unusedMask, 0, f->N * sizeof(unsigned long long), f->stream);
+  hipMemsetAsync(B.nInFov, 0, f->N * sizeof(int), f->stream);
+  hipMemsetAsync(B.err, 0, sizeof(int), f->stream);
+  hipMemsetAsync(B.Z, 0, RFSGPU_MAX_Z * 2 * sizeof(double), f->stream);
+  set_weights_kernel<<<(f->N + 255) / 256, 256, 0, f->stream>>>(B.weight, f->N, 1.0);
+  if (hipStreamSynchronize(f->stream) != hipSuccess) return bail(RFSGPU_ERR_HIP);
+  rfsgpu_default_filter_config(&f->cfg);
+  memset(&f->model, 0, sizeof(f->model));  // MeasurementModel_RngBrg defaults, src/MeasurementModel_RngBrg.cpp:35-43
+  f->model.probabilityOfDetection = 0.95;
+  f->model.uniformClutterIntensity = 0.1;
+  f->model.rangeLimMax = 5;
+  f->model.rangeLimMin = 0.3;
+  f->model.rangeLimBuffer = 0.25;
+  f->kf.rangeInnovationThreshold = -1;
+  f->kf.bearingInnovationThreshold = -1;
+  f->P.poseCovStride = 0;
+  rebuild_params(f);
+  *out = f;
+  return RFSGPU_OK;
+}
+
+void rfsgpu_destroy(rfsgpu_filter *f) {
+  if (!f) return;
+  hipSetDevice(f->device);
+  if (f->stream) hipStreamSynchronize(f->stream);
+  if (f->ownStream) hipStreamSynchronize(f->ownStream);
+  Buffers &B = f->B;
+  hipFree(f->snapSlab); hipFree(f->snapWeight); hipFree(f->snapCount); hipFree(f->snapFov); hipFree(f->snapUnused);
+  hipFree(B.slab[0]); hipFree(B.slab[1]); hipFree(B.count); hipFree(B.pose); hipFree(B.poseCov); hipFree(B.weight);
+  hipFree(B.unusedMask); hipFree(B.nInFov); hipFree(B.err); hipFree(B.Z); hipFree(f->ownSums); hipFree(f->dSrcSlot);
+  murty_free(f->Q, f->MS);
+  if (f->hErr) hipHostFree(f->hErr);
+  if (f->hJobCount) hipHostFree(f->hJobCount);
+  if (f->hSums) hipHostFree(f->hSums);
+  for (int k = 0; k < EV_COUNT; k++) if (f->ev[k]) hipEventDestroy(f->ev[k]);
+  if (f->ownStream) hipStreamDestroy(f->ownStream);
+  delete f;
+}
+
+const char *rfsgpu_last_error(const rfsgpu_filter *f) { return f ? f->err.c_str() : "null handle"; }
+
+int rfsgpu_set_filter_config(rfsgpu_filter *f, const rfsgpu_filter_config *c) {
+  CHECK_HANDLE(f);
+  if (!c) return RFSGPU_ERR_INVALID;
+  f->cfg = *c;
+  rebuild_params(f);
+  return RFSGPU_OK;
+}
+int rfsgpu_get_filter_config(const rfsgpu_filter *f, rfsgpu_filter_config *c) {
+  if (!f || !c) return RFSGPU_ERR_INVALID;
+  *c = f->cfg;
+  return RFSGPU_OK;
+}
+int rfsgpu_set_model_rngbrg(rfsgpu_filter *f, const rfsgpu_rngbrg_config *c) {
+  CHECK_HANDLE(f);
+  if (!c) return RFSGPU_ERR_INVALID;
+  f->model = *c;
+  rebuild_params(f);
+  return RFSGPU_OK;
+}
+int rfsgpu_set_kf_config(rfsgpu_filter *f, const rfsgpu_kf_config *c) {
+  CHECK_HANDLE(f);
+  if (!c) return RFSGPU_ERR_INVALID;
+  f->kf = *c;
+  rebuild_params(f);
+  return RFSGPU_OK;
+}
+int rfsgpu_set_lmk_process_noise(rfsgpu_filter *f, const double *Q) {
+  CHECK_HANDLE(f);
+  if (!Q) return RFSGPU_ERR_INVALID;
+  memcpy(f->Qlm, Q, 4 * sizeof(double));
+  rebuild_params(f);
+  return RFSGPU_OK;
+}
+
+int rfsgpu_set_poses(rfsgpu_filter *f, const double *x, const double *cov, int cov_stride) {
+  CHECK_HANDLE(f);
+  if (!x || (cov_stride != 0 && cov_stride != 9)) return fail(f, RFSGPU_ERR_INVALID, "set_poses: bad arguments");
+  hipSetDevice(f->device);
+  HIPCHK(hipMemcpyAsync(f->B.pose, x, (size_t)f->N * 3 * sizeof(double), hipMemcpyHostToDevice, f->stream));
+  if (cov) {
+    const size_t n = cov_stride == 9 ? (size_t)f->N * 9 : 9;
+    HIPCHK(hipMemcpyAsync(f->B.poseCov, cov, n * sizeof(double), hipMemcpyHostToDevice, f->stream));
+    f->P.poseCovStride = cov_stride;
+  } else {
+    HIPCHK(hipMemsetAsync(f->B.poseCov, 0, 9 * sizeof(double), f->stream));
+    f->P.poseCovStride = 0;
+  }
+  HIPCHK(hipStreamSynchronize(f->stream));  // caller's buffers may be pageable / reused
+  return RFSGPU_OK;
+}
+int rfsgpu_get_poses(rfsgpu_filter *f, double *x) {
+  CHECK_HANDLE(f);
+  hipSetDevice(f->device);
+  HIPCHK(hipMemcpyAsync(x, f->B.pose, (size_t)f->N * 3 * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  return RFSGPU_OK;
+}
+int rfsgpu_set_weights(rfsgpu_filter *f, const double *w) {
+  CHECK_HANDLE(f);
+  hipSetDevice(f->device);
+  HIPCHK(hipMemcpyAsync(f->B.weight, w, (size_t)f->N * sizeof(double), hipMemcpyHostToDevice, f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  return RFSGPU_OK;
+}
+int rfsgpu_get_weights(rfsgpu_filter *f, double *w) {
+  CHECK_HANDLE(f);
+  hipSetDevice(f->device);
+  HIPCHK(hipMemcpyAsync(w, f->B.weight, (size_t)f->N * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  return RFSGPU_OK;
+}
+
+int rfsgpu_gm_sizes(rfsgpu_filter *f, int *sizes) {
+  CHECK_HANDLE(f);
+  hipSetDevice(f->device);
+  HIPCHK(hipMemcpyAsync(sizes, f->B.count, (size_t)f->N * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  return RFSGPU_OK;
+}
+
+// Host staging of one particle's planes (valid entries only: holes carry w < 0 between merge and prune).
+static int fetch_particle(rfsgpu_filter *f, int slot, std::vector<double> &planes, int &n) {
+  hipSetDevice(f->device);
+  HIPCHK(hipMemcpyAsync(&n, f->B.count + slot, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  planes.resize((size_t)PL_COUNT * f->cap);
+  HIPCHK(hipMemcpyAsync(planes.data(), f->B.slab[f->cur] + (size_t)slot * PL_COUNT * f->cap, planes.size() * sizeof(double),
+                        hipMemcpyDeviceToHost, f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  return RFSGPU_OK;
+}
+
+int rfsgpu_gm_size(rfsgpu_filter *f, int slot) {
+  if (!f || slot < 0 || slot >= f->N) return -1;
+  std::vector<double> pl;
+  int n = 0;
+  if (fetch_particle(f, slot, pl, n) != RFSGPU_OK) return -1;
+  int k = 0;
+  for (int m = 0; m < n; m++) if (pl[(size_t)PL_W * f->cap + m] >= 0) k++;
+  return k;
+}
+
+int rfsgpu_export_gm(rfsgpu_filter *f, int slot, int max_n, int *n_out, double *w, double *w_prev, double *mean, double *cov) {
+  CHECK_HANDLE(f);
+  if (slot < 0 || slot >= f->N) return fail(f, RFSGPU_ERR_INVALID, "export_gm: bad slot");
+  std::vector<double> pl;
+  int n = 0;
+  int rc = fetch_particle(f, slot, pl, n);
+  if (rc != RFSGPU_OK) return rc;
+  const size_t c = f->cap;
+  int k = 0;
+  for (int m = 0; m < n; m++) {
+    if (pl[PL_W * c + m] < 0) continue;
+    if (k < max_n) {
+      if (w) w[k] = pl[PL_W * c + m];
+      if (w_prev) w_prev[k] = pl[PL_WP * c + m];
+      if (mean) { mean[2 * k] = pl[PL_MX * c + m]; mean[2 * k + 1] = pl[PL_MY * c + m]; }
+      if (cov) {
+        cov[4 * k] = pl[PL_SXX * c + m];
+        cov[4 * k + 1] = cov[4 * k + 2] = pl[PL_SXY * c + m];
+        cov[4 * k + 3] = pl[PL_SYY * c + m];
+      }
+    }
+    k++;
+  }
+  if (n_out) *n_out = k;
+  return RFSGPU_OK;
+}
+
+int rfsgpu_get_landmark(rfsgpu_filter *f, int slot, int m, double *mean, double *cov, double *w) {
+  CHECK_HANDLE(f);
+  if (slot < 0 || slot >= f->N || m < 0) return RFSGPU_ERR_INVALID;
+  hipSetDevice(f->device);
+  int n = 0;
+  HIPCHK(hipMemcpyAsync(&n, f->B.count + slot, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  if (m >= n) return RFSGPU_ERR_INVALID;
+  double v[PL_COUNT];
+  for (int pl = 0; pl < PL_COUNT; pl++)
+    HIPCHK(hipMemcpyAsync(&v[pl], f->B.slab[f->cur] + ((size_t)slot * PL_COUNT + pl) * f->cap + m, sizeof(double), hipMemcpyDeviceToHost,
+                          f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  mean[0] = v[PL_MX]; mean[1] = v[PL_MY];
+  cov[0] = v[PL_SXX]; cov[1] = cov[2] = v[PL_SXY]; cov[3] = v[PL_SYY];
+  *w = v[PL_W];
+  return RFSGPU_OK;
+}
+
+int rfsgpu_import_gm(rfsgpu_filter *f, int slot, int n, const double *w, const double *mean, const double *cov) {
+  CHECK_HANDLE(f);
+  if (slot < 0 || slot >= f->N || n < 0) return fail(f, RFSGPU_ERR_INVALID, "import_gm: bad arguments");
+  if (n > f->cap) return fail(f, RFSGPU_ERR_CAPACITY, "import_gm: more Gaussians than gm_capacity");
+  hipSetDevice(f->device);
+  const size_t c = f->cap;
+  std::vector<double> pl((size_t)PL_COUNT * c, 0.0);
+  for (int m = 0; m < n; m++) {
+    pl[PL_W * c + m] = w[m];
+    pl[PL_WP * c + m] = 0.0;
+    pl[PL_MX * c + m] = mean[2 * m];
+    pl[PL_MY * c + m] = mean[2 * m + 1];
+    pl[PL_SXX * c + m] = cov[4 * m];
+    pl[PL_SXY * c + m] = cov[4 * m + 1];
+    pl[PL_SYY * c + m] = cov[4 * m + 3];
+  }
+  HIPCHK(hipMemcpyAsync(f->B.slab[f->cur] + (size_t)slot * PL_COUNT * c, pl.data(), pl.size() * sizeof(double), hipMemcpyHostToDevice, f->stream));
+  HIPCHK(hipMemcpyAsync(f->B.count + slot, &n, sizeof(int), hipMemcpyHostToDevice, f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  return RFSGPU_OK;
+}
+
+// ---- the hot path ----------------------------------------------------------------------------------
+
+static int set_lds_impl(rfsgpu_filter *f, const void *kernel, size_t bytes) {
+  if ((long long)bytes > 160 * 1024) return fail(f, RFSGPU_ERR_CAPACITY, "kernel needs more than 160 KiB of LDS: lower gm_capacity");
+  if (bytes > 48 * 1024) HIPCHK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return RFSGPU_OK;
+}
+#define set_lds(f, kernel, bytes) set_lds_impl(f, reinterpret_cast<const void *>(&kernel), bytes)
+
+static int launch_update_map(rfsgpu_filter *f) {
+  const int nZ = f->nZ;
+  auto bytes = [&](int wpb) { return (size_t)(2 * RFSGPU_MAX_Z * 8) + (size_t)wpb * (RFSGPU_MAX_Z * 8 + (size_t)f->cap * 8); };
+  int rc;
+  if (bytes(4) <= 64 * 1024) {
+    if ((rc = set_lds(f, phd_update_map_kernel<4>, bytes(4))) != RFSGPU_OK) return rc;
+    phd_update_map_kernel<4><<<(f->N + 3) / 4, 256, bytes(4), f->stream>>>(f->B, f->P, f->cur, nZ);
+  } else {
+    if ((rc = set_lds(f, phd_update_map_kernel<1>, bytes(1))) != RFSGPU_OK) return rc;
+    phd_update_map_kernel<1><<<f->N, 64, bytes(1), f->stream>>>(f->B, f->P, f->cur, nZ);
+  }
+  HIPCHK(hipGetLastError());
+  return RFSGPU_OK;
+}
+
+static int eval_cap(const rfsgpu_filter *f) {
+  int c = f->cfg.importanceWeightingEvalPointCount;
+  if (c < 0 || c > RFSGPU_MAX_EVAL) c = RFSGPU_MAX_EVAL;
+  if (c < 1) c = 1;
+  return c;
+}
+
+static int launch_weighting(rfsgpu_filter *f) {
+  const int nZ = f->nZ, ec = eval_cap(f);
+  const size_t per = weight_lds_bytes_per_wave(f->cap, ec, nZ);
+  auto bytes = [&](int wpb) { return (size_t)(2 * RFSGPU_MAX_Z * 8) + (size_t)wpb * per; };
+  const int src = f->cur, dst = f->cur ^ 1;
+  HIPCHK(hipMemsetAsync(f->Q.count, 0, sizeof(int), f->stream));
+  int rc;
+  if (bytes(4) <= 80 * 1024) {
+    if ((rc = set_lds(f, phd_weight_multifeature_kernel<4>, bytes(4))) != RFSGPU_OK) return rc;
+    phd_weight_multifeature_kernel<4><<<(f->N + 3) / 4, 256, bytes(4), f->stream>>>(f->B, f->P, src, dst, nZ, ec, f->Q);
+  } else if (bytes(2) <= 80 * 1024) {
+    if ((rc = set_lds(f, phd_weight_multifeature_kernel<2>, bytes(2))) != RFSGPU_OK) return rc;
+    phd_weight_multifeature_kernel<2><<<(f->N + 1) / 2, 128, bytes(2), f->stream>>>(f->B, f->P, src, dst, nZ, ec, f->Q);
+  } else {
+    if ((rc = set_lds(f, phd_weight_multifeature_kernel<1>, bytes(1))) != RFSGPU_OK) return rc;
+    phd_weight_multifeature_kernel<1><<<f->N, 64, bytes(1), f->stream>>>(f->B, f->P, src, dst, nZ, ec, f->Q);
+  }
+  HIPCHK(hipGetLastError());
+  f->cur = dst;
+  // Murty-200 for partitions with nR + nC > 8: runs only when the queue is non-empty (device-side early exit)
+  rc = murty_launch(f->Q, f->MS, f->B, f->stream);
+  if (rc != 0) return fail(f, RFSGPU_ERR_HIP, "murty launch failed");
+  return RFSGPU_OK;
+}
+
+static int launch_merge(rfsgpu_filter *f) {
+  const size_t per = merge_lds_bytes_per_wave(f->cap);
+  int rc;
+  if (4 * per <= 80 * 1024) {
+    if ((rc = set_lds(f, gm_merge_kernel<4>, 4 * per)) != RFSGPU_OK) return rc;
+    gm_merge_kernel<4><<<(f->N + 3) / 4, 256, 4 * per, f->stream>>>(f->B, f->P, f->cur);
+  } else if (2 * per <= 80 * 1024) {
+    if ((rc = set_lds(f, gm_merge_kernel<2>, 2 * per)) != RFSGPU_OK) return rc;
+    gm_merge_kernel<2><<<(f->N + 1) / 2, 128, 2 * per, f->stream>>>(f->B, f->P, f->cur);
+  } else {
+    if ((rc = set_lds(f, gm_merge_kernel<1>, per)) != RFSGPU_OK) return rc;
+    gm_merge_kernel<1><<<f->N, 64, per, f->stream>>>(f->B, f->P, f->cur);
+  }
+  HIPCHK(hipGetLastError());
+  return RFSGPU_OK;
+}
+
+static int launch_prune(rfsgpu_filter *f) {
+  const size_t per = (size_t)f->cap * 8;
+  const int src = f->cur, dst = f->cur ^ 1;
+  int rc;
+  if ((rc = set_lds(f, gm_prune_kernel<4>, 4 * per)) != RFSGPU_OK) return rc;
+  gm_prune_kernel<4><<<(f->N + 3) / 4, 256, 4 * per, f->stream>>>(f->B, f->P, src, dst);
+  HIPCHK(hipGetLastError());
+  f->cur = dst;
+  return RFSGPU_OK;
+}
+
+static int stage_measurements(rfsgpu_filter *f, const double *z, int n_z) {
+  if (n_z < 0 || n_z > RFSGPU_MAX_Z) return fail(f, RFSGPU_ERR_INVALID, "at most RFSGPU_MAX_Z measurements per update");
+  if (n_z > 0 && !z) return fail(f, RFSGPU_ERR_INVALID, "null measurement buffer");
+  hipSetDevice(f->device);
+  if (n_z > 0) HIPCHK(hipMemcpyAsync(f->B.Z, z, (size_t)n_z * 2 * sizeof(double), hipMemcpyHostToDevice, f->stream));
+  f->nZ = n_z;
+  return RFSGPU_OK;
+}
+
+int rfsgpu_update_map(rfsgpu_filter *f, const double *z, int n_z) {
+  CHECK_HANDLE(f);
+  long long t0 = now_ns();
+  int rc = stage_measurements(f, z, n_z);
+  if (rc != RFSGPU_OK) return rc;
+  HIPCHK(hipEventRecord(f->ev[EV_UM0], f->stream));
+  if ((rc = launch_update_map(f)) != RFSGPU_OK) return rc;
+  HIPCHK(hipEventRecord(f->ev[EV_UM1], f->stream));
+  rc = check_device_errors(f);
+  accumulate(f->ev[EV_UM0], f->ev[EV_UM1], f->timing.mapUpdate_wall, &f->lastKernelNs[0]);
+  f->timing.mapUpdate_kf_wall = f->timing.mapUpdate_wall;  // KF correct is fused into the same kernel
+  f->timing.mapUpdate_cpu += now_ns() - t0;
+  return rc;
+}
+int rfsgpu_importance_weighting(rfsgpu_filter *f) {
+  CHECK_HANDLE(f);
+  long long t0 = now_ns();
+  hipSetDevice(f->device);
+  HIPCHK(hipEventRecord(f->ev[EV_UM1], f->stream));
+  int rc = launch_weighting(f);
+  if (rc != RFSGPU_OK) return rc;
+  HIPCHK(hipEventRecord(f->ev[EV_W1], f->stream));
+  rc = check_device_errors(f);
+  accumulate(f->ev[EV_UM1], f->ev[EV_W1], f->timing.particleWeighting_wall, &f->lastKernelNs[1]);
+  f->timing.particleWeighting_cpu += now_ns() - t0;
+  return rc;
+}
+int rfsgpu_merge(rfsgpu_filter *f) {
+  CHECK_HANDLE(f);
+  long long t0 = now_ns();
+  hipSetDevice(f->device);
+  HIPCHK(hipEventRecord(f->ev[EV_W1], f->stream));
+  int rc = launch_merge(f);
+  if (rc != RFSGPU_OK) return rc;
+  HIPCHK(hipEventRecord(f->ev[EV_MG1], f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  accumulate(f->ev[EV_W1], f->ev[EV_MG1], f->timing.mapMerge_wall, &f->lastKernelNs[2]);
+  f->timing.mapMerge_cpu += now_ns() - t0;
+  return RFSGPU_OK;
+}
+int rfsgpu_prune(rfsgpu_filter *f) {
+  CHECK_HANDLE(f);
+  long long t0 = now_ns();
+  hipSetDevice(f->device);
+  HIPCHK(hipEventRecord(f->ev[EV_MG1], f->stream));
+  int rc = launch_prune(f);
+  if (rc != RFSGPU_OK) return rc;
+  HIPCHK(hipEventRecord(f->ev[EV_PR1], f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  accumulate(f->ev[EV_MG1], f->ev[EV_PR1], f->timing.mapPrune_wall, &f->lastKernelNs[3]);
+  f->timing.mapPrune_cpu += now_ns() - t0;
+  return RFSGPU_OK;
+}
+
+// All four phases back to back on the stream, ONE host sync at the end (RBPHDFilter::update body :444-523).
+int rfsgpu_update(rfsgpu_filter *f, const double *z, int n_z) {
+  CHECK_HANDLE(f);
+  if (n_z == 0) return RFSGPU_OK;  // :450-452
+  long long t0 = now_ns();
+  int rc = stage_measurements(f, z, n_z);
+  if (rc != RFSGPU_OK) return rc;
+  HIPCHK(hipEventRecord(f->ev[EV_UM0], f->stream));
+  if ((rc = launch_update_map(f)) != RFSGPU_OK) return rc;
+  HIPCHK(hipEventRecord(f->ev[EV_UM1], f->stream));
+  if (!f->cfg.useClusterProcess) {
+    if ((rc = launch_weighting(f)) != RFSGPU_OK) return rc;
+  }
+  HIPCHK(hipEventRecord(f->ev[EV_W1], f->stream));
+  if ((rc = launch_merge(f)) != RFSGPU_OK) return rc;
+  HIPCHK(hipEventRecord(f->ev[EV_MG1], f->stream));
+  if ((rc = launch_prune(f)) != RFSGPU_OK) return rc;
+  HIPCHK(hipEventRecord(f->ev[EV_PR1], f->stream));
+  rc = check_device_errors(f);  // syncs
+  accumulate(f->ev[EV_UM0], f->ev[EV_UM1], f->timing.mapUpdate_wall, &f->lastKernelNs[0]);
+  f->timing.mapUpdate_kf_wall = f->timing.mapUpdate_wall;
+  accumulate(f->ev[EV_UM1], f->ev[EV_W1], f->timing.particleWeighting_wall, &f->lastKernelNs[1]);
+  accumulate(f->ev[EV_W1], f->ev[EV_MG1], f->timing.mapMerge_wall, &f->lastKernelNs[2]);
+  accumulate(f->ev[EV_MG1], f->ev[EV_PR1], f->timing.mapPrune_wall, &f->lastKernelNs[3]);
+  f->timing.mapUpdate_cpu += now_ns() - t0;
+  return rc;
+}
+
+int rfsgpu_predict_map(rfsgpu_filter *f, int add_birth) {
+  CHECK_HANDLE(f);
+  long long t0 = now_ns();
+  hipSetDevice(f->device);
+  HIPCHK(hipEventRecord(f->ev[EV_P0], f->stream));
+  predict_map_kernel<4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(f->ev[EV_P1], f->stream));
+  int rc = check_device_errors(f);
+  accumulate(f->ev[EV_P0], f->ev[EV_P1], f->timing.predict_wall, nullptr);
+  f->timing.predict_cpu += now_ns() - t0;
+  return rc;
+}
+
+int rfsgpu_get_unused(rfsgpu_filter *f, int slot, int *idx, int max_n, int *n_out) {
+  CHECK_HANDLE(f);
+  if (slot < 0 || slot >= f->N) return RFSGPU_ERR_INVALID;
+  hipSetDevice(f->device);
+  unsigned long long m = 0;
+  HIPCHK(hipMemcpyAsync(&m, f->B.unusedMask + slot, sizeof(m), hipMemcpyDeviceToHost, f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  int k = 0;
+  for (int z = 0; z < 64; z++)
+    if ((m >> z) & 1ull) { if (k < max_n && idx) idx[k] = z; k++; }
+  if (n_out) *n_out = k;
+  return RFSGPU_OK;
+}
+int rfsgpu_landmarks_in_fov(rfsgpu_filter *f, int slot, int *n_out) {
+  CHECK_HANDLE(f);
+  if (slot < 0 || slot >= f->N || !n_out) return RFSGPU_ERR_INVALID;
+  hipSetDevice(f->device);
+  HIPCHK(hipMemcpyAsync(n_out, f->B.nInFov + slot, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  return RFSGPU_OK;
+}
+
+// ---- weights / resampling ---------------------------------------------------------------------------
+
+int rfsgpu_weight_sums_async(rfsgpu_filter *f) {
+  CHECK_HANDLE(f);
+  hipSetDevice(f->device);
+  weight_sums_kernel<<<1, 1024, 0, f->stream>>>(f->B.weight, f->N, f->dSums);
+  HIPCHK(hipGetLastError());
+  return RFSGPU_OK;
+}
+void *rfsgpu_weight_sums_device_ptr(rfsgpu_filter *f) { return f ? (void *)f->dSums : nullptr; }
+int rfsgpu_weight_sums(rfsgpu_filter *f, double *out) {
+  CHECK_HANDLE(f);
+  int rc = rfsgpu_weight_sums_async(f);
+  if (rc != RFSGPU_OK) return rc;
+  HIPCHK(hipMemcpyAsync(f->hSums, f->dSums, 2 * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  out[0] = f->hSums[0];
+  out[1] = f->hSums[1];
+  return RFSGPU_OK;
+}
+int rfsgpu_normalize_weights(rfsgpu_filter *f, double sum, const void *sum_dev) {
+  CHECK_HANDLE(f);
+  hipSetDevice(f->device);
+  long long t0 = now_ns();
+  HIPCHK(hipEventRecord(f->ev[EV_R0], f->stream));
+  normalize_kernel<<<(f->N + 255) / 256, 256, 0, f->stream>>>(f->B.weight, f->N, sum, (const double *)sum_dev);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(f->ev[EV_R1], f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  accumulate(f->ev[EV_R0], f->ev[EV_R1], f->timing.particleResample_wall, nullptr);
+  f->timing.particleResample_cpu += now_ns() - t0;
+  return RFSGPU_OK;
+}
+int rfsgpu_resample_apply(rfsgpu_filter *f, const int *src_slot) {
+  CHECK_HANDLE(f);
+  if (!src_slot) return RFSGPU_ERR_INVALID;
+  for (int k = 0; k < f->N; k++) {
+    const int s = src_slot[k];
+    if (s < 0 || s >= f->N || src_slot[s] != s) return fail(f, RFSGPU_ERR_INVALID, "resample_apply: a source slot must keep itself");
+  }
+  hipSetDevice(f->device);
+  long long t0 = now_ns();
+  HIPCHK(hipMemcpyAsync(f->dSrcSlot, src_slot, (size_t)f->N * sizeof(int), hipMemcpyHostToDevice, f->stream));
+  HIPCHK(hipEventRecord(f->ev[EV_R0], f->stream));
+  resample_gather_kernel<<<f->N, 256, 0, f->stream>>>(f->B, f->cur, f->dSrcSlot);
+  set_weights_kernel<<<(f->N + 255) / 256, 256, 0, f->stream>>>(f->B.weight, f->N, 1.0);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(f->ev[EV_R1], f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  accumulate(f->ev[EV_R0], f->ev[EV_R1], f->timing.particleResample_wall, nullptr);
+  f->timing.particleResample_cpu += now_ns() - t0;
+  return RFSGPU_OK;
+}
+
+// ---- timing / misc -----------------------------------------------------------------------------------
+
+int rfsgpu_get_timing(rfsgpu_filter *f, rfsgpu_timing *t) {
+  CHECK_HANDLE(f);
+  if (!t) return RFSGPU_ERR_INVALID;
+  *t = f->timing;
+  return RFSGPU_OK;
+}
+int rfsgpu_reset_timing(rfsgpu_filter *f) {
+  CHECK_HANDLE(f);
+  memset(&f->timing, 0, sizeof(f->timing));
+  return RFSGPU_OK;
+}
+int rfsgpu_synchronize(rfsgpu_filter *f) {
+  CHECK_HANDLE(f);
+  hipSetDevice(f->device);
+  HIPCHK(hipStreamSynchronize(f->stream));
+  return RFSGPU_OK;
+}
+void *rfsgpu_stream(rfsgpu_filter *f) { return f ? (void *)f->stream : nullptr; }
+int rfsgpu_set_stream(rfsgpu_filter *f, void *hip_stream) {
+  CHECK_HANDLE(f);
+  hipSetDevice(f->device);
+  HIPCHK(hipStreamSynchronize(f->stream));
+  f->stream = hip_stream ? (hipStream_t)hip_stream : f->ownStream;
+  return RFSGPU_OK;
+}
+int rfsgpu_bind_weight_sums_buffer(rfsgpu_filter *f, void *dev_ptr) {
+  CHECK_HANDLE(f);
+  f->dSums = dev_ptr ? (double *)dev_ptr : f->ownSums;
+  return RFSGPU_OK;
+}
+
+int rfsgpu_save_state(rfsgpu_filter *f) {
+  CHECK_HANDLE(f);
+  hipSetDevice(f->device);
+  const size_t slabBytes = (size_t)f->N * PL_COUNT * f->cap * sizeof(double);
+  if (!f->snapSlab) {
+    bool ok = true;
+    ok &= hipMalloc(&f->snapSlab, slabBytes) == hipSuccess;
+    ok &= hipMalloc(&f->snapWeight, f->N * sizeof(double)) == hipSuccess;
+    ok &= hipMalloc(&f->snapCount, f->N * sizeof(int)) == hipSuccess;
+    ok &= hipMalloc(&f->snapFov, f->N * sizeof(int)) == hipSuccess;
+    ok &= hipMalloc(&f->snapUnused, f->N * sizeof(unsigned long long)) == hipSuccess;
+    if (!ok) return fail(f, RFSGPU_ERR_HIP, "save_state: out of device memory");
+  }
+  HIPCHK(hipMemcpyAsync(f->snapSlab, f->B.slab[f->cur], slabBytes, hipMemcpyDeviceToDevice, f->stream));
+  HIPCHK(hipMemcpyAsync(f->snapWeight, f->B.weight, f->N * sizeof(double), hipMemcpyDeviceToDevice, f->stream));
+  HIPCHK(hipMemcpyAsync(f->snapCount, f->B.count, f->N * sizeof(int), hipMemcpyDeviceToDevice, f->stream));
+  HIPCHK(hipMemcpyAsync(f->snapFov, f->B.nInFov, f->N * sizeof(int), hipMemcpyDeviceToDevice, f->stream));
+  HIPCHK(hipMemcpyAsync(f->snapUnused, f->B.unusedMask, f->N * sizeof(unsigned long long), hipMemcpyDeviceToDevice, f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  f->snapNZ = f->nZ;
+  return RFSGPU_OK;
+}
+int rfsgpu_restore_state(rfsgpu_filter *f) {
+  CHECK_HANDLE(f);
+  if (!f->snapSlab) return fail(f, RFSGPU_ERR_INVALID, "restore_state: nothing saved");
+  hipSetDevice(f->device);
+  // only the live entries are copied (one block per particle); asynchronous on the handle's stream
+  restore_state_kernel<<<f->N, 256, 0, f->stream>>>(f->B, f->cur, f->snapSlab, f->snapWeight, f->snapCount, f->snapFov, f->snapUnused);
+  HIPCHK(hipGetLastError());
+  f->nZ = f->snapNZ;
+  return RFSGPU_OK;
+}
+int rfsgpu_last_kernel_ns(rfsgpu_filter *f, long long *ns4) {
+  CHECK_HANDLE(f);
+  if (!ns4) return RFSGPU_ERR_INVALID;
+  for (int k = 0; k < 4; k++) ns4[k] = f->lastKernelNs[k];
+  return RFSGPU_OK;
+}
+
+int rfsgpu_mat_perm(const double *A, int n, int batch, double *out, int device_id) {
+  if (!A || !out || n < 1 || n > 24 || batch < 0) return RFSGPU_ERR_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return RFSGPU_ERR_NO_DEVICE;
+  if (batch == 0) return RFSGPU_OK;
+  if (hipSetDevice(device_id) != hipSuccess) return RFSGPU_ERR_NO_DEVICE;
+  double *dA = nullptr, *dO = nullptr;
+  const size_t bytes = (size_t)batch * n * n * sizeof(double);
+  if (hipMalloc(&dA, bytes) != hipSuccess) return RFSGPU_ERR_HIP;
+  if (hipMalloc(&dO, (size_t)batch * sizeof(double)) != hipSuccess) { hipFree(dA); return RFSGPU_ERR_HIP; }
+  int rc = RFSGPU_OK;
+  if (hipMemcpy(dA, A, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = RFSGPU_ERR_HIP;
+  if (rc == RFSGPU_OK) {
+    mat_perm_kernel<<<batch, 64>>>(dA, n, batch, dO);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = RFSGPU_ERR_HIP;
+  }
+  if (rc == RFSGPU_OK && hipMemcpy(out, dO, (size_t)batch * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = RFSGPU_ERR_HIP;
+  hipFree(dA);
+  hipFree(dO);
+  return rc;
+}
+
+}  // extern "C"

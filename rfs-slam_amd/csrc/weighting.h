@@ -1,0 +1,423 @@
+// weighting.h -- phd_weight_multifeature: RBPHDFilter::importanceWeighting (reference
+// include/RBPHDFilter.hpp:728-819) + rfsMeasurementLikelihood (:821-997) + CostMatrixGeneral::partition
+// (src/CostMatrix.cpp:92-157) + the <=8 partial-assignment enumeration that the reference drives through
+// PermutationLexicographic (src/PermutationLexicographic.cpp:38-96).
+//
+// One wavefront per particle.  Steps: (1) rank-sort the mixture by weight (weight desc, index asc) in LDS and
+// write the sorted mixture to the other slab (the order merge needs); (2) pick the evaluation points;
+// (3) intensity products before/after the update -- lanes stride over Gaussians, 8 evaluation points at a time
+// in registers; (4) likelihood table L (nE x nZ) in LDS; (5) bipartite connected components by min-label
+// propagation over 64-bit adjacency masks, numbered like BGL's DFS discovery order (by smallest vertex), incl.
+// the reference's zero-partition merge and its partition-indexing quirk; (6) one lane per partition sums the
+// partial assignments; partitions with nR+nC > 8 go to the Murty work queue (murty.h).
+#pragma once
+#include "common.h"
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Partitions too large for the in-kernel enumeration (nR + nC > 8) are handed to murty.h through this queue.
+struct MurtyJob {
+  int particle;
+  int nR, nC;
+  int slot;         // index into partLik of that particle
+  // extended (nR+nC)^2 log-likelihood matrix is stored in the job's scratch area
+};
+struct MurtyQueue {
+  int *count;          // [1] number of jobs
+  MurtyJob *jobs;      // [maxJobs]
+  double *mats;        // [maxJobs][MURTY_MAXN*MURTY_MAXN]
+  double *results;     // [maxJobs]
+  int maxJobs;
+};
+#define MURTY_MAXN 64
+
+struct WeightLDS {
+  double *keys;                // [cap]
+  int *perm;                   // [cap]
+  double *evX, *evY, *evPd;    // [64]
+  double *evLog1mPd;           // [64]
+  int *evIdx;                  // [64] sorted position of the evaluation point
+  double *evZ;                 // [64][7] z_exp0, z_exp1, i00, i01, i10, i11, factor
+  double *L;                   // [evalCap][nZ]
+  unsigned long long *rowMask, *colMask;    // [64]
+  int *labR, *labC;            // [64]
+  unsigned long long *compRows, *compCols;  // [128]
+  double *partLik;             // [128]
+};
+
+__host__ __device__ inline size_t weight_lds_bytes_per_wave(int cap, int evalCap, int nZ) {
+  size_t b = 0;
+  b += (size_t)cap * 8;            // keys
+  b += (size_t)cap * 4;            // perm
+  b += 64 * 8 * 4;                 // evX evY evPd evLog1mPd
+  b += 64 * 4;                     // evIdx
+  b += 64 * 7 * 8;                 // evZ
+  b += (size_t)evalCap * nZ * 8;   // L
+  b += 64 * 8 * 2;                 // rowMask colMask
+  b += 64 * 4 * 2;                 // labR labC
+  b += 128 * 8 * 2;                // compRows compCols
+  b += 128 * 8;                    // partLik
+  return (b + 15) & ~(size_t)15;
+}
+
+__device__ __forceinline__ void carve_weight_lds(unsigned char *base, int cap, int evalCap, int nZ, WeightLDS &s) {
+  unsigned char *p = base;
+  s.keys = (double *)p; p += (size_t)cap * 8;
+  s.evX = (double *)p; p += 64 * 8;
+  s.evY = (double *)p; p += 64 * 8;
+  s.evPd = (double *)p; p += 64 * 8;
+  s.evLog1mPd = (double *)p; p += 64 * 8;
+  s.evZ = (double *)p; p += 64 * 7 * 8;
+  s.L = (double *)p; p += (size_t)evalCap * nZ * 8;
+  s.rowMask = (unsigned long long *)p; p += 64 * 8;
+  s.colMask = (unsigned long long *)p; p += 64 * 8;
+  s.compRows = (unsigned long long *)p; p += 128 * 8;
+  s.compCols = (unsigned long long *)p; p += 128 * 8;
+  s.partLik = (double *)p; p += 128 * 8;
+  s.perm = (int *)p; p += (size_t)cap * 4;
+  s.evIdx = (int *)p; p += 64 * 4;
+  s.labR = (int *)p; p += 64 * 4;
+  s.labC = (int *)p; p += 64 * 4;
+}
+
+__device__ __forceinline__ int nth_bit(unsigned long long m, int k) {  // index of the k-th (0-based) set bit
+  for (int t = 0; t < k; t++) m &= m - 1;
+  return __builtin_ctzll(m);
+}
+
+// Sum over all partial assignments of one partition (rows = eval points, cols = measurements):
+//   sum exp( sum_{assigned} logL + sum_{missed} log(1-Pd) + (#unassigned cols) * log c )
+// == the loop at include/RBPHDFilter.hpp:961-988 (terms are identical; only the order of the outer sum differs
+// from the lexicographic one).  Pairs whose log-likelihood is the -1000 floor are skipped: their term is
+// exp(<= -1000 + ...) == 0 exactly in fp64 as long as the remaining log-terms sum to < 255.
+__device__ double enumerate_partition(const WeightLDS &s, int nZ, unsigned long long rmask, unsigned long long cmask, double logc) {
+  const int r = __popcll(rmask), c = __popcll(cmask);
+  unsigned long long rowsPk = 0, colsPk = 0;  // one byte per local index
+  for (int a = 0; a < r; a++) rowsPk |= (unsigned long long)nth_bit(rmask, a) << (8 * a);
+  for (int b = 0; b < c; b++) colsPk |= (unsigned long long)nth_bit(cmask, b) << (8 * b);
+#define ROWI(a) ((int)((rowsPk >> (8 * (a))) & 0xff))
+#define COLI(b) ((int)((colsPk >> (8 * (b))) & 0xff))
+#define NIB(a) ((int)((ch >> (4 * (a))) & 0xfull))
+#define SETNIB(a, v) ch = (ch & ~(0xfull << (4 * (a)))) | ((unsigned long long)(v) << (4 * (a)))
+  double lik = 0.0;
+  unsigned long long ch = 0;  // nibble a = column choice of row a (c == miss)
+  unsigned used = 0;
+  int a = 0;
+  while (true) {
+    if (a == r) {
+      double pll = 0.0;
+      int k = 0;
+      for (int a2 = 0; a2 < r; a2++) {
+        int b = NIB(a2);
+        if (b < c) { pll += s.L[ROWI(a2) * nZ + COLI(b)]; k++; }
+        else pll += s.evLog1mPd[ROWI(a2)];
+      }
+      for (int t = k; t < c; t++) pll += logc;
+      lik += exp(pll);
+      a--;
+      if (a < 0) break;
+      int b = NIB(a);
+      if (b < c) used &= ~(1u << b);
+      SETNIB(a, b + 1);
+      continue;
+    }
+    int b = NIB(a);
+    while (b < c && (((used >> b) & 1u) || s.L[ROWI(a) * nZ + COLI(b)] <= -1000.0)) b++;
+    if (b > c) {  // exhausted this row -> backtrack
+      SETNIB(a, 0);
+      a--;
+      if (a < 0) break;
+      int b2 = NIB(a);
+      if (b2 < c) used &= ~(1u << b2);
+      SETNIB(a, b2 + 1);
+      continue;
+    }
+    SETNIB(a, b);
+    if (b < c) used |= (1u << b);
+    a++;
+  }
+#undef ROWI
+#undef COLI
+#undef NIB
+#undef SETNIB
+  return lik;
+}
+
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64) void phd_weight_multifeature_kernel(Buffers B, Params P, int src, int dst, int nZ, int evalCap,
+                                                                           MurtyQueue Q) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double *sZ = reinterpret_cast<double *>(smem_raw);
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  for (int t = threadIdx.x; t < 2 * nZ; t += WPB * 64) sZ[t] = B.Z[t];
+  __syncthreads();
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
+  if (i >= B.N) return;
+  WeightLDS s;
+  carve_weight_lds(smem_raw + 2 * RFSGPU_MAX_Z * 8 + (size_t)wave * weight_lds_bytes_per_wave(B.cap, evalCap, nZ), B.cap, evalCap, nZ, s);
+
+  const int N = B.count[i];
+  const double *sl = B.slab[src];
+  double *dl = B.slab[dst];
+  const double *qW = plane((double *)sl, B.cap, i, PL_W), *qWP = plane((double *)sl, B.cap, i, PL_WP);
+  const double *qMX = plane((double *)sl, B.cap, i, PL_MX), *qMY = plane((double *)sl, B.cap, i, PL_MY);
+  const double *qSXX = plane((double *)sl, B.cap, i, PL_SXX), *qSXY = plane((double *)sl, B.cap, i, PL_SXY),
+               *qSYY = plane((double *)sl, B.cap, i, PL_SYY);
+
+  // nEvalPoints (:735-745); evalCount = -1 => all (unsigned compare)
+  int nEvalPoints = ((unsigned)P.evalCount > (unsigned)N) ? N : P.evalCount;
+  if (nEvalPoints == 0) {
+    // weight := denorm_min, mixture NOT sorted (:742-745): copy through unchanged
+    for (int pl = 0; pl < PL_COUNT; pl++) {
+      const double *q = plane((double *)sl, B.cap, i, pl);
+      double *d = plane(dl, B.cap, i, pl);
+      for (int m = lane; m < N; m += 64) d[m] = q[m];
+    }
+    if (lane == 0) B.weight[i] = RFS_DENORM_MIN;
+    return;
+  }
+
+  // ---- 1. sort by weight: rank = #{ j : w_j > w_m  or (w_j == w_m and j < m) } ----
+  for (int m = lane; m < N; m += 64) s.keys[m] = qW[m];
+  wave_sync();
+  for (int m = lane; m < N; m += 64) {
+    const double wm = s.keys[m];
+    int rank = 0;
+    for (int j = 0; j < N; j++) {
+      const double wj = s.keys[j];
+      rank += (wj > wm || (wj == wm && j < m)) ? 1 : 0;
+    }
+    s.perm[rank] = m;
+  }
+  wave_sync();
+  // sorted mixture -> other slab
+  for (int r = lane; r < N; r += 64) {
+    const int m = s.perm[r];
+    plane(dl, B.cap, i, PL_W)[r] = s.keys[m];
+    plane(dl, B.cap, i, PL_WP)[r] = qWP[m];
+    plane(dl, B.cap, i, PL_MX)[r] = qMX[m];
+    plane(dl, B.cap, i, PL_MY)[r] = qMY[m];
+    plane(dl, B.cap, i, PL_SXX)[r] = qSXX[m];
+    plane(dl, B.cap, i, PL_SXY)[r] = qSXY[m];
+    plane(dl, B.cap, i, PL_SYY)[r] = qSYY[m];
+  }
+
+  PoseReg pr;
+  load_pose(B, P, i, pr);
+
+  // ---- 2. evaluation points: first <= nEvalPoints sorted entries with w >= minW and Pd > 0 (:747-762) ----
+  int nE = 0;
+  bool evalOverflow = false;
+  {
+    const int limit = nEvalPoints < RFSGPU_MAX_EVAL ? nEvalPoints : RFSGPU_MAX_EVAL;
+    bool done = false;
+    for (int c0 = 0; c0 < N && !done; c0 += 64) {
+      const int r = c0 + lane;
+      bool below = true, cand = false;
+      double mx = 0, my = 0, pd = 0;
+      if (r < N) {
+        const int m = s.perm[r];
+        below = s.keys[m] < P.evalMinW;
+        mx = qMX[m];
+        my = qMY[m];
+        double dx = mx - pr.x, dy = my - pr.y;
+        bool close;
+        pd = rb_pd(P, sqrt(dx * dx + dy * dy), close);
+        cand = pd > 0;
+      }
+      unsigned long long belowMask = __ballot(below);
+      unsigned long long valid = belowMask ? ((1ull << __builtin_ctzll(belowMask)) - 1ull) : ~0ull;
+      if (belowMask) done = true;
+      unsigned long long candMask = __ballot(cand) & valid;
+      const int need = limit - nE;
+      const int before = __popcll(candMask & ((1ull << lane) - 1ull));
+      if (((candMask >> lane) & 1ull) && before < need) {
+        const int e = nE + before;
+        s.evX[e] = mx;
+        s.evY[e] = my;
+        s.evPd[e] = pd;
+        s.evLog1mPd[e] = log(1 - pd);
+        s.evIdx[e] = r;
+      }
+      int got = __popcll(candMask);
+      if (got >= need) { got = need; done = true; }
+      nE += got;
+    }
+    // more evaluation points requested than the device path holds: refuse loudly (conservative)
+    if (nE == limit && nEvalPoints > limit) evalOverflow = true;
+  }
+  if (evalOverflow && lane == 0) atomicOr(B.err, ERRBIT_EVALPTS);
+  wave_sync();
+
+  // ---- 3. weight sums (:765-775) and intensity products at the evaluation points (:776-800) ----
+  double sumPrev = 0.0, sumCur = 0.0;
+  for (int m = lane; m < N; m += 64) { sumPrev += qWP[m]; sumCur += s.keys[m]; }
+  sumPrev = wave_sum(sumPrev);
+  sumCur = wave_sum(sumCur);
+
+  double prodBefore = 1.0, prodAfter = 1.0;
+  for (int e0 = 0; e0 < nE; e0 += 8) {
+    double accB[8], accA[8], ex[8], ey[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      accB[t] = 0.0; accA[t] = 0.0;
+      const int e = (e0 + t < nE) ? e0 + t : e0;
+      ex[t] = s.evX[e]; ey[t] = s.evY[e];
+    }
+    for (int m = lane; m < N; m += 64) {
+      const double w = s.keys[m], wp = qWP[m], mx = qMX[m], my = qMY[m];
+      const double sxx = qSXX[m], sxy = qSXY[m], syy = qSYY[m];
+      double i00, i01, i10, i11, det;
+      inv2(sxx, sxy, sxy, syy, i00, i01, i10, i11, det);
+      const double factor = pdf_factor2(det);
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        const double d0 = ex[t] - mx, d1 = ey[t] - my;
+        const double t0 = d0 * i00 + d1 * i10, t1 = d0 * i01 + d1 * i11;
+        const double lik = gauss_from_md2(t0 * d0 + t1 * d1, factor);
+        accB[t] += wp * lik;
+        accA[t] += w * lik;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      if (e0 + t < nE) {
+        prodBefore *= (RFS_DENORM_MIN + wave_sum(accB[t]));
+        prodAfter *= (RFS_DENORM_MIN + wave_sum(accA[t]));
+      }
+    }
+  }
+
+  // ---- 4. likelihood table L[e][n] = N(z_n; h(x, e), S_e) * Pd_e, gated (:847-863) ----
+  if (lane < nE) {
+    MeasOut mo;
+    rb_measure(P, pr, s.evX[lane], s.evY[lane], 0.0, 0.0, 0.0, mo);  // evalPt_copy.setCov(Zero)
+    double i00, i01, i10, i11, det;
+    inv2(mo.s00, mo.s01, mo.s10, mo.s11, i00, i01, i10, i11, det);
+    double *z = s.evZ + 7 * lane;
+    z[0] = mo.z0; z[1] = mo.z1; z[2] = i00; z[3] = i01; z[4] = i10; z[5] = i11; z[6] = pdf_factor2(det);
+  }
+  wave_sync();
+  for (int idx = lane; idx < nE * nZ; idx += 64) {
+    const int e = idx / nZ, n = idx - e * nZ;
+    const double *z = s.evZ + 7 * e;
+    const double d0 = sZ[2 * n] - z[0], d1 = sZ[2 * n + 1] - z[1];
+    const double t0 = d0 * z[2] + d1 * z[4], t1 = d0 * z[3] + d1 * z[5];
+    const double md2 = t0 * d0 + t1 * d1;
+    double Lv = gauss_from_md2(md2, z[6]) * s.evPd[e];
+    if (md2 > P.weightingMd2) Lv = 0.0;
+    s.L[idx] = Lv;
+  }
+  wave_sync();
+
+  // ---- 5. connected components of the bipartite graph (rows = eval points, cols = measurements) ----
+  unsigned long long myRow = 0, myCol = 0;
+  if (lane < nE) for (int n = 0; n < nZ; n++) if (s.L[lane * nZ + n] != 0.0) myRow |= 1ull << n;
+  if (lane < nZ) for (int e = 0; e < nE; e++) if (s.L[e * nZ + lane] != 0.0) myCol |= 1ull << e;
+  int labR = lane, labC = nE + lane;  // label = smallest vertex index reachable (rows first, then columns)
+  s.labR[lane] = labR;
+  s.labC[lane] = labC;
+  wave_sync();
+  for (int it = 0; it < 130; it++) {
+    int nr = labR;
+    for (unsigned long long mm = myRow; mm; mm &= mm - 1) { int v = s.labC[__builtin_ctzll(mm)]; nr = v < nr ? v : nr; }
+    bool ch = nr != labR;
+    labR = nr;
+    s.labR[lane] = labR;
+    wave_sync();
+    int nc = labC;
+    for (unsigned long long mm = myCol; mm; mm &= mm - 1) { int v = s.labR[__builtin_ctzll(mm)]; nc = v < nc ? v : nc; }
+    ch = ch || (nc != labC);
+    labC = nc;
+    s.labC[lane] = labC;
+    wave_sync();
+    if (__ballot(ch) == 0ull) break;
+  }
+  // the log table replaces L from here on (zero partition needs no L; :907-917)
+  for (int idx = lane; idx < nE * nZ; idx += 64) {
+    double v = s.L[idx];
+    if (v == 0.0) v = -1000.0;
+    else { v = log(v); if (v < -1000.0) v = -1000.0; }
+    s.L[idx] = v;
+  }
+  const unsigned long long rootR = __ballot(lane < nE && labR == lane);
+  const unsigned long long rootC = __ballot(lane < nZ && labC == nE + lane);
+  const int nRootR = __popcll(rootR);
+  const int ncc = nRootR + __popcll(rootC);
+  // component id = rank of its smallest vertex (== BGL DFS discovery order)
+  auto comp_of = [&](int label) -> int {
+    return label < nE ? __popcll(rootR & ((1ull << label) - 1ull)) : nRootR + __popcll(rootC & ((1ull << (label - nE)) - 1ull));
+  };
+  s.compRows[lane] = 0; s.compRows[lane + 64] = 0;
+  s.compCols[lane] = 0; s.compCols[lane + 64] = 0;
+  wave_sync();
+  if (lane < nE) atomicOr(&s.compRows[comp_of(labR)], 1ull << lane);
+  if (lane < nZ) atomicOr(&s.compCols[comp_of(labC)], 1ull << lane);
+  wave_sync();
+  // zero partitions (no rows or no cols) are merged into the first one (src/CostMatrix.cpp:126-144)
+  unsigned long long zr = 0, zc = 0;
+  bool z0 = false, z1 = false;
+  if (lane < ncc) { z0 = (s.compRows[lane] == 0 || s.compCols[lane] == 0); if (z0) { zr |= s.compRows[lane]; zc |= s.compCols[lane]; } }
+  if (lane + 64 < ncc) { z1 = (s.compRows[lane + 64] == 0 || s.compCols[lane + 64] == 0); if (z1) { zr |= s.compRows[lane + 64]; zc |= s.compCols[lane + 64]; } }
+  const unsigned long long zeroLo = __ballot(z0), zeroHi = __ballot(z1);
+  const int nZero = __popcll(zeroLo) + __popcll(zeroHi);
+  const int combined = zeroLo ? __builtin_ctzll(zeroLo) : (zeroHi ? 64 + __builtin_ctzll(zeroHi) : -1);
+  const unsigned long long mergedRows = wave_or_u64(zr), mergedCols = wave_or_u64(zc);
+  const int nPartitions = ncc - (nZero > 0 ? nZero - 1 : 0);  // caller still indexes components [0, nPartitions) -- quirk kept
+
+  // ---- 6. one lane per partition ----
+  const double logc = log(P.clutter);
+  for (int p = lane; p < nPartitions; p += 64) {
+    unsigned long long rmask = s.compRows[p], cmask = s.compCols[p];
+    double pl;
+    if (p == combined) {  // all landmarks mis-detected, all measurements outliers (:891-900; Pd, not 1-Pd)
+      rmask = mergedRows;
+      cmask = mergedCols;
+      pl = 1.0;
+      for (unsigned long long mm = rmask; mm; mm &= mm - 1) pl *= s.evPd[__builtin_ctzll(mm)];
+      for (unsigned long long mm = cmask; mm; mm &= mm - 1) pl *= P.clutter;
+    } else if (__popcll(rmask) + __popcll(cmask) <= 8) {
+      pl = enumerate_partition(s, nZ, rmask, cmask, logc);
+    } else {
+      // Murty-200 (:920-959): queue the extended matrix; the factor is multiplied in by murty_kernel
+      pl = 1.0;
+      int job = Q.count ? atomicAdd(Q.count, 1) : Q.maxJobs;
+      const int nR = __popcll(rmask), nC = __popcll(cmask), n = nR + nC;
+      if (job < Q.maxJobs && n <= MURTY_MAXN) {
+        MurtyJob J;
+        J.particle = i; J.nR = nR; J.nC = nC; J.slot = p;
+        Q.jobs[job] = J;
+        double *M = Q.mats + (size_t)job * MURTY_MAXN * MURTY_MAXN;
+        for (int a = 0; a < n; a++)
+          for (int b = 0; b < n; b++) {
+            double v;
+            if (a < nR && b < nC) v = s.L[nth_bit(rmask, a) * nZ + nth_bit(cmask, b)];
+            else if (a < nR) v = (a == b - nC) ? s.evLog1mPd[nth_bit(rmask, a)] : -1000.0;
+            else if (b < nC) v = (a - nR == b) ? logc : -1000.0;
+            else v = 0.0;
+            M[a * n + b] = v;
+          }
+      } else {
+        atomicOr(B.err, ERRBIT_MURTY);
+      }
+    }
+    s.partLik[p] = pl;
+  }
+  wave_sync();
+  double l = 1.0;
+  for (int p = 0; p < nPartitions; p++) l *= s.partLik[p];
+  const double sensingArea = 2 * RFS_PI * (P.rmax - P.rmin);
+  const double ml = l / (P.clutter * sensingArea);  // clutterIntensityIntegral (src/MeasurementModel_RngBrg.cpp:175-178)
+
+  // ---- 7. overall weight (:806-811) ----
+  const double overall = ml * prodBefore / prodAfter * exp(sumCur - sumPrev);
+  if (lane == 0) {
+    const double wnew = overall * B.weight[i];
+    B.weight[i] = wnew;
+  }
+}

@@ -64,6 +64,18 @@ class RBPHDFilter(capi.CFilter):
         fn.restype = C.c_void_p
         return fn(self._h)
 
+    def set_stream(self, hip_stream):
+        self._call("set_stream", C.c_void_p(hip_stream))
+
+    def bind_weight_sums_buffer(self, dev_ptr):
+        self._call("bind_weight_sums_buffer", C.c_void_p(dev_ptr))
+
+    def save_state(self):
+        self._call("save_state")
+
+    def restore_state(self):
+        self._call("restore_state")
+
     def stream(self):
         fn = self._fn("stream")
         fn.restype = C.c_void_p

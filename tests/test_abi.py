@@ -1,0 +1,75 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library builds, loads and exports every symbol
+include/rfsgpu.h declares; struct layouts agree; without a GPU the engine refuses loudly (no fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, has_gpu
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "rfsgpu.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(rfsgpu_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    pkg.build_mod.build()
+    lib = pkg.load_library()
+    syms = declared_symbols()
+    assert len(syms) >= 35
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in rfsgpu.h but not exported"
+    assert sorted("rfsgpu_" + s for s in pkg.capi.ABI_SYMBOLS) == syms
+    assert lib.rfsgpu_abi_version() == 1
+
+
+def test_struct_layouts_match_header(pkg):
+    # sizes as the C compiler lays them out (doubles 8-aligned)
+    assert C.sizeof(pkg.capi.FilterConfig) == 104
+    assert C.sizeof(pkg.capi.RngBrgConfig) == 72
+    assert C.sizeof(pkg.capi.KFConfig) == 16
+    assert C.sizeof(pkg.capi.Timing) == 14 * 8
+    cfg = pkg.capi.FilterConfig()
+    lib = pkg.load_library()
+    lib.rfsgpu_default_filter_config(C.byref(cfg))
+    # RBPHDFilter.hpp:370-382
+    assert cfg.birthGaussianWeight == 0.25 and cfg.importanceWeightingEvalPointCount == 8
+    assert cfg.gaussianMergingThreshold == 0.5 and cfg.gaussianPruningThreshold == 0.2
+    assert cfg.newGaussianCreateInnovMDThreshold == 0.2 and cfg.minUpdatesBeforeResample == 1
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-device behaviour")
+def test_no_gpu_means_loud_failure_not_fallback(pkg):
+    with pytest.raises(pkg.capi.EngineError) as e:
+        pkg.RBPHDFilter(8)
+    assert e.value.status in (pkg.capi.ERR_NO_DEVICE, pkg.capi.ERR_HIP)
+    with pytest.raises(pkg.capi.EngineError):
+        pkg.mat_perm(np.eye(3))
+
+
+def test_product_package_never_touches_the_oracle():
+    """The shipped path must not import / link / execute anything under oracle/."""
+    pkgdir = os.path.join(ROOT, "rfs-slam_amd")
+    for dp, _, files in os.walk(pkgdir):
+        for fn in files:
+            if fn.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
+                txt = open(os.path.join(dp, fn)).read()
+                assert "rbphd_oracle" not in txt and "rfsor_" not in txt and "from oracle" not in txt and "import oracle" not in txt, fn
+
+
+def test_resample_plan_matches_oracle_restatement(pkg, ob):
+    rng = np.random.default_rng(5)
+    for n in (5, 64, 257):
+        for _ in range(5):
+            w = rng.uniform(0, 1, n) ** 6
+            u = float(rng.uniform())
+            fired, wn, src = ob.resample_decide(w, n + 1.0, u)  # threshold > n: always resample
+            assert fired
+            plan = pkg.engine.systematic_resample_plan(wn, u)
+            assert np.array_equal(plan, src)
+            # every source keeps itself; kept slots are exactly the sampled ones
+            assert np.all(src[src] == src)

@@ -1,0 +1,201 @@
+"""Parity of the HIP path (through the C ABI) against the oracle on identical seeded inputs (fp64).
+
+Tolerances: normalised particle weights rel 1e-9; GM components matched as multisets on
+(w, mu, Sigma) rel 1e-10 / abs 1e-12; integer outputs (mixture sizes, unused lists, FOV counts) exact.
+The oracle runs in (weight desc, index asc) sort mode == what the device implements (tie order is the one
+documented deviation from the reference's unstable std::sort)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+WEIGHT_RTOL = 1e-9
+GM_RTOL, GM_ATOL = 1e-10, 1e-12
+
+
+def make_pair(pkg, ob, sc, scen, cap=512):
+    dev = pkg.RBPHDFilter(scen["n"], device_id=0, gm_capacity=cap)
+    orc = ob.OracleFilter(scen["n"], stable_sort=True)
+    for f in (dev, orc):
+        sc.load_scenario(f, scen)
+    return dev, orc
+
+
+def compare_maps(sc, dev, orc, n, ordered=False):
+    assert np.array_equal(dev.gm_sizes(), orc.gm_sizes())
+    for i in range(n):
+        sc.assert_gm_close(dev.export_gm(i), orc.export_gm(i), GM_RTOL, GM_ATOL, ordered=ordered)
+
+
+def compare_weights(dev, orc):
+    wd, wo = dev.get_weights(), orc.get_weights()
+    assert np.all(np.isfinite(wd))
+    np.testing.assert_allclose(wd / wd.sum(), wo / wo.sum(), rtol=WEIGHT_RTOL, atol=1e-300)
+    # un-normalised too (same scale)
+    np.testing.assert_allclose(wd, wo, rtol=1e-8, atol=0)
+
+
+SCENARIOS = [
+    dict(n_particles=16, n_landmarks=12, n_z=5, seed=1),
+    dict(n_particles=33, n_landmarks=70, n_z=19, seed=2),          # ragged: 70 = 64 + 6
+    dict(n_particles=64, n_landmarks=200, n_z=30, seed=3),         # C2 shape, fewer particles
+    dict(n_particles=24, n_landmarks=130, n_z=30, seed=4, frac_in_fov=0.25),   # C2b shape: most landmarks out of FOV
+    dict(n_particles=8, n_landmarks=64, n_z=64, seed=5),           # max measurements
+    dict(n_particles=20, n_landmarks=1, n_z=3, seed=6),
+]
+
+
+@pytest.mark.parametrize("kw", SCENARIOS)
+def test_update_map_phase(pkg, ob, sc, kw):
+    scen = sc.make_scenario(**kw)
+    dev, orc = make_pair(pkg, ob, sc, scen)
+    dev.update_map(scen["Z"])
+    orc.update_map(scen["Z"])
+    compare_maps(sc, dev, orc, scen["n"], ordered=True)   # append order is (m,z) row-major: exact order
+    for i in range(scen["n"]):
+        assert np.array_equal(dev.get_unused(i), orc.get_unused(i))
+        assert dev.landmarks_in_fov(i) == orc.landmarks_in_fov(i)
+        # w_prev: old weight for the nM old Gaussians, 0 for the appended ones
+        np.testing.assert_allclose(dev.export_gm(i)[1], orc.export_gm(i)[1], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("kw", SCENARIOS)
+def test_all_phases_stepwise(pkg, ob, sc, kw):
+    scen = sc.make_scenario(**kw)
+    dev, orc = make_pair(pkg, ob, sc, scen)
+    for f in (dev, orc):
+        f.update_map(scen["Z"])
+        f.importance_weighting()
+    compare_weights(dev, orc)
+    compare_maps(sc, dev, orc, scen["n"], ordered=True)   # sorted by weight
+    for f in (dev, orc):
+        f.merge()
+    compare_maps(sc, dev, orc, scen["n"], ordered=True)
+    for f in (dev, orc):
+        f.prune()
+    compare_maps(sc, dev, orc, scen["n"], ordered=True)
+
+
+@pytest.mark.parametrize("kw", SCENARIOS[:4])
+def test_update_fused_call_and_normalise(pkg, ob, sc, kw):
+    scen = sc.make_scenario(**kw)
+    dev, orc = make_pair(pkg, ob, sc, scen)
+    for f in (dev, orc):
+        f.update(scen["Z"])
+    compare_weights(dev, orc)
+    compare_maps(sc, dev, orc, scen["n"])
+    sd, so = dev.weight_sums(), orc.weight_sums()
+    np.testing.assert_allclose(sd, so, rtol=1e-9)
+    dev.normalize_weights(sd[0])
+    orc.normalize_weights(so[0])
+    np.testing.assert_allclose(dev.get_weights(), orc.get_weights(), rtol=WEIGHT_RTOL)
+    assert abs(dev.get_weights().sum() - 1) < 1e-12
+
+
+def test_cluster_process_weighting(pkg, ob, sc):
+    scen = sc.make_scenario(32, 90, 20, seed=11, use_cluster=True)
+    dev, orc = make_pair(pkg, ob, sc, scen)
+    for f in (dev, orc):
+        f.update(scen["Z"])
+    compare_weights(dev, orc)
+    compare_maps(sc, dev, orc, scen["n"])
+
+
+def test_empty_measurement_set_is_a_no_op(pkg, ob, sc):
+    scen = sc.make_scenario(8, 20, 6, seed=12)
+    dev, orc = make_pair(pkg, ob, sc, scen)
+    before = [dev.export_gm(i) for i in range(8)]
+    dev.update(np.zeros((0, 2)))
+    for i in range(8):
+        sc.assert_gm_close(dev.export_gm(i), before[i], 0, 0, ordered=True)
+    assert np.array_equal(dev.get_weights(), np.ones(8))
+
+
+def test_empty_maps(pkg, ob, sc):
+    scen = sc.make_scenario(8, 5, 6, seed=13)
+    dev = pkg.RBPHDFilter(8, gm_capacity=64)
+    orc = ob.OracleFilter(8)
+    for f in (dev, orc):
+        sc.load_scenario(f, scen, maps=False)
+        f.update(scen["Z"])
+    assert np.array_equal(dev.gm_sizes(), np.zeros(8, np.int32))
+    for i in range(8):
+        assert np.array_equal(dev.get_unused(i), np.arange(6))
+    np.testing.assert_array_equal(dev.get_weights(), orc.get_weights())   # denorm_min for every particle
+
+
+def test_multi_step_predict_update_cycle(pkg, ob, sc):
+    """birth -> static step -> update -> normalise, several steps, same measurements stream on both sides."""
+    scen = sc.make_scenario(16, 25, 10, seed=14)
+    dev, orc = make_pair(pkg, ob, sc, scen, cap=256)
+    rng = np.random.default_rng(99)
+    for step in range(6):
+        Z = scen["Z"] + rng.normal(0, 1e-3, scen["Z"].shape)
+        for f in (dev, orc):
+            f.predict_map(True)
+            f.update(Z)
+            s = f.weight_sums()
+            f.normalize_weights(s[0])
+        np.testing.assert_allclose(dev.get_weights(), orc.get_weights(), rtol=1e-8)
+        compare_maps(sc, dev, orc, scen["n"])
+
+
+def test_resample_apply(pkg, ob, sc):
+    scen = sc.make_scenario(16, 20, 8, seed=15)
+    dev, orc = make_pair(pkg, ob, sc, scen, cap=128)
+    for f in (dev, orc):
+        f.update(scen["Z"])
+        s = f.weight_sums()
+        f.normalize_weights(s[0])
+    fired, wn, src = ob.resample_decide(orc.get_weights(), 17.0, 0.37)
+    assert fired
+    assert np.array_equal(src, pkg.engine.systematic_resample_plan(dev.get_weights(), 0.37))
+    dev.resample_apply(src)
+    orc.resample_apply(src)
+    compare_maps(sc, dev, orc, 16, ordered=True)
+    assert np.array_equal(dev.get_weights(), np.ones(16))
+    for i in range(16):
+        assert np.array_equal(dev.get_unused(i), orc.get_unused(i))
+
+
+def test_capacity_overflow_is_reported(pkg, sc):
+    scen = sc.make_scenario(4, 60, 30, seed=16)
+    dev = pkg.RBPHDFilter(4, gm_capacity=64)
+    sc.load_scenario(dev, scen)
+    with pytest.raises(pkg.capi.EngineError) as e:
+        dev.update(scen["Z"])
+    assert e.value.status == pkg.capi.ERR_CAPACITY
+
+
+def test_get_landmark_and_bad_indices(pkg, sc):
+    scen = sc.make_scenario(4, 10, 4, seed=17)
+    dev = pkg.RBPHDFilter(4, gm_capacity=64)
+    sc.load_scenario(dev, scen)
+    assert dev.getGMSize(0) == 10 and dev.getGMSize(4) == -1 and dev.getGMSize(-1) == -1
+    mean, cov, w = dev.getLandmark(2, 3)
+    np.testing.assert_array_equal(mean, scen["mean"][2, 3])
+    assert w == scen["w"][2, 3]
+    assert cov[0, 1] == cov[1, 0] == scen["cov"][2, 3, 0, 1]
+    assert dev.getLandmark(2, 10) is None and dev.getLandmark(9, 0) is None
+
+
+def test_mat_perm_known_answers_on_device(pkg, ob):
+    from test_oracle_combinatorics import DERANGEMENTS
+    for n, want in DERANGEMENTS.items():
+        got = pkg.mat_perm(np.ones((n, n)) - np.eye(n))[0]
+        assert got == want, (n, got, want)
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 5, 9, 13, 16):
+        A = rng.uniform(-1, 1, (7, n, n))
+        np.testing.assert_allclose(pkg.mat_perm(A), ob.mat_perm(A), rtol=1e-10, atol=1e-13)
+
+
+def test_murty_partitions_match_oracle(pkg, ob, sc):
+    """C5-style stress: wide weighting gate so partitions exceed nR+nC = 8 and the Murty-200 path runs."""
+    scen = sc.make_scenario(24, 60, 30, seed=21, n_eval=25, weighting_md=10.0, weights=(0.8, 1.0))
+    dev, orc = make_pair(pkg, ob, sc, scen)
+    for f in (dev, orc):
+        f.update_map(scen["Z"])
+        f.importance_weighting()
+    assert orc.murty_calls() > 0, "scenario does not reach the Murty path"
+    compare_weights(dev, orc)
