@@ -200,6 +200,19 @@ __global__ __launch_bounds__(256) void resample_gather_kernel(Buffers B, int cur
   }
 }
 
+// Number of valid Gaussians per particle (holes left by gm_merge carry w < 0 until gm_prune drops them).
+__global__ __launch_bounds__(256) void valid_count_kernel(Buffers B, int cur, int *out) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= B.N) return;
+  const int lane = threadIdx.x & 63;
+  const int n = B.count[i];
+  const double *w = plane(B.slab[cur], B.cap, i, PL_W);
+  int c = 0;
+  for (int m = lane; m < n; m += 64) c += (w[m] >= 0.0) ? 1 : 0;
+  c = wave_sum_i(c);
+  if (lane == 0) out[i] = c;
+}
+
 // rfsgpu_restore_state: copy the saved live entries back (one block per particle).
 __global__ __launch_bounds__(256) void restore_state_kernel(Buffers B, int cur, const double *snapSlab, const double *snapWeight,
                                                             const int *snapCount, const int *snapFov, const unsigned long long *snapUnused) {

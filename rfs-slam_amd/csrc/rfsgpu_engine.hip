@@ -313,7 +313,9 @@ int rfsgpu_get_weights(rfsgpu_filter *f, double *w) {
 int rfsgpu_gm_sizes(rfsgpu_filter *f, int *sizes) {
   CHECK_HANDLE(f);
   hipSetDevice(f->device);
-  HIPCHK(hipMemcpyAsync(sizes, f->B.count, (size_t)f->N * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+  valid_count_kernel<<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->cur, f->dSrcSlot);  // dSrcSlot doubles as int scratch
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(sizes, f->dSrcSlot, (size_t)f->N * sizeof(int), hipMemcpyDeviceToHost, f->stream));
   HIPCHK(hipStreamSynchronize(f->stream));
   return RFSGPU_OK;
 }
