@@ -52,7 +52,16 @@ struct Buffers {
   int *err;          // [1] OR-ed ErrBits
   double *Z;         // [RFSGPU_MAX_Z][2]
   int N, cap;
+  long long *dbg;    // section timestamps (only written by -DRFS_PROFILE builds; NULL otherwise)
 };
+
+// Section timing for kernel tuning (tools/kernel_sections.py builds a separate -DRFS_PROFILE library):
+// particle `RFS_PROFILE_PARTICLE`'s lane 0 stamps s_memtime at section boundaries.
+#ifdef RFS_PROFILE
+#define DBG_T(base, k) do { if (B.dbg && i == 7 && lane == 0) B.dbg[(base) + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define DBG_T(base, k) do { } while (0)
+#endif
 
 __device__ __forceinline__ double *plane(double *slab, int cap, int particle, int pl) {
   return slab + ((size_t)particle * PL_COUNT + pl) * (size_t)cap;

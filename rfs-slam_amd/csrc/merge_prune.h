@@ -15,108 +15,211 @@
 #include "common.h"
 #include "weighting.h"  // wave_sync
 
-#define MERGE_LDS_DOUBLES_PER_ENTRY 9
+// LDS per wave and entry: x, y, w, i00, i01, i11, bound (7 doubles) + first-candidate index (u16)
+__host__ __device__ inline size_t merge_lds_bytes_per_wave(int cap) { return (((size_t)cap * (7 * 8 + 2)) + 15) & ~(size_t)15; }
 
-__host__ __device__ inline size_t merge_lds_bytes_per_wave(int cap) { return (size_t)cap * MERGE_LDS_DOUBLES_PER_ENTRY * 8; }
+// Necessary condition for a pair to pass the merge test: md2 = e^T S^-1 e >= |e|^2 / lambda_max(S) >= |e|^2 / tr(S),
+// so d1 <= t^2 or d2 <= t^2 implies |e|^2 <= t^2 * max(tr S_a, tr S_j).  The bound carries a 1e-6 relative
+// margin for rounding in the computed md2 / inverse; a non-PSD or non-finite covariance gets an infinite bound
+// (always fully tested), so the prefilter never changes a decision of the exact test.
+__device__ __forceinline__ double merge_bound(double t2, double xx, double yy, double det) {
+  const double tr = xx + yy;
+  const bool sane = (det > 0.0) && (tr > 0.0) && (tr < 1.7e308);
+  return sane ? t2 * tr * (1.0 + 1e-6) : __builtin_huge_val();
+}
 
-template <int WPB>
-__global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P, int cur) {
+// gm_merge (+ optional fused gm_prune).
+// Phase 1 (parallel): every pair (a, j>a) is tested once against the INITIAL states -- which is exactly what the
+//   reference's sequential scan sees the first time it meets a pair, because a Gaussian only changes while it is the
+//   outer index -- and the lowest passing j of each row is recorded (firstCand).  Lanes hold 64 consecutive j in
+//   registers, a is broadcast from LDS; a cheap distance prefilter rejects almost all pairs before the two
+//   Mahalanobis forms are evaluated.
+// Phase 2 (sequential, rare): rows with a candidate are replayed in order with the exact greedy rule: merge the
+//   lowest passing j, update a, re-test only j' > j against the new state (ballot + ctz), skip absorbed entries.
+// FUSE_PRUNE: survivors (w >= pruneT, not absorbed) are rank-sorted by (weight desc, index asc) and compacted into
+//   the other slab straight from here (GaussianMixture::prune :477-521), saving gm_prune's launch and re-read.
+template <int WPB, bool FUSE_PRUNE>
+__global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P, int cur, int dst) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
   if (i >= B.N) return;
   const int cap = B.cap;
-  double *base = reinterpret_cast<double *>(smem_raw) + (size_t)wave * cap * MERGE_LDS_DOUBLES_PER_ENTRY;
-  double *sMX = base, *sMY = base + cap, *sXX = base + 2 * cap, *sXY = base + 3 * cap, *sYY = base + 4 * cap;
-  double *sW = base + 5 * cap, *sI00 = base + 6 * cap, *sI01 = base + 7 * cap, *sI11 = base + 8 * cap;
+  unsigned char *wbase = smem_raw + (size_t)wave * merge_lds_bytes_per_wave(cap);
+  double *sMX = reinterpret_cast<double *>(wbase), *sMY = sMX + cap, *sW = sMX + 2 * cap;
+  double *sI00 = sMX + 3 * cap, *sI01 = sMX + 4 * cap, *sI11 = sMX + 5 * cap, *sBnd = sMX + 6 * cap;
+  unsigned short *sFirst = reinterpret_cast<unsigned short *>(sMX + 7 * cap);
 
   const int N = B.count[i];
   double *slab = B.slab[cur];
   double *pW = plane(slab, cap, i, PL_W), *pMX = plane(slab, cap, i, PL_MX), *pMY = plane(slab, cap, i, PL_MY);
   double *pSXX = plane(slab, cap, i, PL_SXX), *pSXY = plane(slab, cap, i, PL_SXY), *pSYY = plane(slab, cap, i, PL_SYY);
+  const double t2 = P.mergeT2, f = P.mergeInfl;
 
-  // stage; hole flags live in per-lane registers: bit s of `hole` <=> entry s*64+lane is a hole
+  DBG_T(32, 0);
+  // ---- stage; hole flags live in per-lane registers: bit s of `hole` <=> entry s*64+lane is a hole ----
   unsigned hole = 0;
   for (int m = lane, sidx = 0; m < N; m += 64, sidx++) {
     const double w = pW[m], mx = pMX[m], my = pMY[m], xx = pSXX[m], xy = pSXY[m], yy = pSYY[m];
     double i00, i01, i10, i11, det;
     inv2(xx, xy, xy, yy, i00, i01, i10, i11, det);
-    sMX[m] = mx; sMY[m] = my; sXX[m] = xx; sXY[m] = xy; sYY[m] = yy; sW[m] = w;
+    sMX[m] = mx; sMY[m] = my; sW[m] = w;
     sI00[m] = i00; sI01[m] = i01; sI11[m] = i11;
-    if (w < 0) hole |= 1u << sidx;  // already a hole (merge called twice)
+    sBnd[m] = merge_bound(t2, xx, yy, det);
+    sFirst[m] = 0xffffu;
+    if (w < 0) hole |= 1u << sidx;  // already absorbed (merge called twice)
   }
   wave_sync();
 
-  const double t2 = P.mergeT2, f = P.mergeInfl;
-  bool anyMerge = false;
-  for (int a = 0; a < N; a++) {
-    // is a itself a hole?  owner lane a&63, slot a>>6
-    const unsigned ownerHole = (unsigned)__builtin_amdgcn_readlane((int)hole, a & 63);
-    if ((ownerHole >> (a >> 6)) & 1u) continue;
-    // current state of Gaussian a (wave-uniform)
-    double ax = sMX[a], ay = sMY[a], axx = sXX[a], axy = sXY[a], ayy = sYY[a], aw = sW[a];
-    double a00 = sI00[a], a01 = sI01[a], a11 = sI11[a];
-    bool changed = false;
-    for (int c0 = (a + 1) & ~63; c0 < N; c0 += 64) {
-      const int j = c0 + lane;
-      const int slot = c0 >> 6;
-      bool live = (j > a) && (j < N) && !((hole >> slot) & 1u);
-      double jx = 0, jy = 0, jw = 0, j00 = 0, j01 = 0, j11 = 0;
-      if (live) { jx = sMX[j]; jy = sMY[j]; jw = sW[j]; j00 = sI00[j]; j01 = sI01[j]; j11 = sI11[j]; }
-      int floorLane = 0;  // only lanes >= floorLane are (re-)tested
-      while (true) {
+  DBG_T(32, 1);
+  // ---- phase 1: first passing partner of every row, against initial states ----
+  // j-chunk in registers; a-chunk in registers too, broadcast lane by lane with v_readlane (no LDS latency in
+  // the inner loop); the Mahalanobis forms run only for the rare pairs that survive the distance prefilter.
+  for (int c0 = 0; c0 < N; c0 += 64) {
+    const int j = c0 + lane;
+    const bool jlive = (j < N) && !((hole >> (c0 >> 6)) & 1u);
+    double jx = 0, jy = 0, jw = 0, j00 = 0, j01 = 0, j11 = 0, jb = 0;
+    if (j < N) { jx = sMX[j]; jy = sMY[j]; jw = sW[j]; j00 = sI00[j]; j01 = sI01[j]; j11 = sI11[j]; jb = sBnd[j]; }
+    for (int a0 = 0; a0 <= c0; a0 += 64) {
+      const int am = a0 + lane;
+      double rx = 0, ry = 0, rb = 0;
+      if (am < N) { rx = sMX[am]; ry = sMY[am]; rb = sBnd[am]; }
+      const int tEnd = (N - a0 < 64) ? N - a0 : 64;
+#pragma unroll 8
+      for (int t = 0; t < tEnd; t++) {
+        const int a = a0 + t;
+        const double ax = readlane_f64(rx, t), ay = readlane_f64(ry, t), ab = readlane_f64(rb, t);
+        const double e0 = jx - ax, e1 = jy - ay;
+        const double e2 = e0 * e0 + e1 * e1;
+        const bool cand = jlive && (j > a) && !(e2 > fmax(ab, jb));
+        if (__ballot(cand) == 0ull) continue;
         bool pass = false;
-        if (live && lane >= floorLane) {
-          // d1 = md2 of x_j under (x_a, S_a); d2 = md2 of x_a under (x_j, S_j)   (:434-442)
-          const double e0 = jx - ax, e1 = jy - ay;
+        if (cand) {
+          const double a00 = sI00[a], a01 = sI01[a], a11 = sI11[a], aw = sW[a];
           const double u0 = e0 * a00 + e1 * a01, u1 = e0 * a01 + e1 * a11;
           const double d1 = u0 * e0 + u1 * e1;
           bool far = d1 > t2;
           if (far) {
             const double g0 = -e0, g1 = -e1;
             const double v0 = g0 * j00 + g1 * j01, v1 = g0 * j01 + g1 * j11;
-            const double d2 = v0 * g0 + v1 * g1;
-            far = d2 > t2;
+            far = (v0 * g0 + v1 * g1) > t2;
           }
-          pass = !far && ((aw + jw) != 0.0);
+          pass = !far && ((aw + jw) != 0.0) && !(aw < 0.0);
         }
         const unsigned long long pm = __ballot(pass);
-        if (pm == 0ull) break;
-        const int l = __builtin_ctzll(pm);
-        const int jj = c0 + l;
-        // merge jj into a (:444-471), wave-uniform arithmetic
-        const double w1 = aw, w2 = sW[jj];
-        const double x2 = sMX[jj], y2 = sMY[jj], bxx = sXX[jj], bxy = sXY[jj], byy = sYY[jj];
-        const double wm = w1 + w2;
-        const double xm = (ax * w1 + x2 * w2) / wm, ym = (ay * w1 + y2 * w2) / wm;
-        const double d10 = xm - ax, d11 = ym - ay, d20 = xm - x2, d21 = ym - y2;
-        const double nxx = (w1 * (axx + (f * d10) * d10) + w2 * (bxx + (f * d20) * d20)) / wm;
-        const double nxy = (w1 * (axy + (f * d10) * d11) + w2 * (bxy + (f * d20) * d21)) / wm;
-        const double nyy = (w1 * (ayy + (f * d11) * d11) + w2 * (byy + (f * d21) * d21)) / wm;
-        ax = xm; ay = ym; axx = nxx; axy = nxy; ayy = nyy; aw = wm;
-        double i10, det;
-        inv2(axx, axy, axy, ayy, a00, a01, i10, a11, det);
-        changed = true;
-        if (lane == l) { hole |= 1u << slot; live = false; }
-        floorLane = l + 1;
-        if (floorLane >= 64) break;
+        if (pm != 0ull && sFirst[a] == 0xffffu) sFirst[a] = (unsigned short)(c0 + __builtin_ctzll(pm));  // uniform store
       }
-    }
-    if (changed) {
-      anyMerge = true;
-      // every lane stores the same values (uniform); visible to later reads of this wave
-      sMX[a] = ax; sMY[a] = ay; sXX[a] = axx; sXY[a] = axy; sYY[a] = ayy; sW[a] = aw;
-      sI00[a] = a00; sI01[a] = a01; sI11[a] = a11;
     }
   }
   wave_sync();
-  if (!anyMerge) return;  // nothing changed: the slab is already right
-  for (int m = lane, sidx = 0; m < N; m += 64, sidx++) {
-    const bool h = (hole >> sidx) & 1u;
-    pW[m] = h ? -1.0 : sW[m];
-    if (!h) { pMX[m] = sMX[m]; pMY[m] = sMY[m]; pSXX[m] = sXX[m]; pSXY[m] = sXY[m]; pSYY[m] = sYY[m]; }
+
+  DBG_T(32, 2);
+  // ---- phase 2: replay rows that have a candidate, in order, with the exact greedy rule ----
+  bool anyMerge = false;
+  for (int r0 = 0; r0 < N; r0 += 64) {
+    const int rr = r0 + lane;
+    unsigned long long rows = __ballot(rr < N && sFirst[rr] != 0xffffu);
+    while (rows) {
+      const int a = r0 + __builtin_ctzll(rows);
+      rows &= rows - 1;
+      const unsigned ownerHole = (unsigned)__builtin_amdgcn_readlane((int)hole, a & 63);
+      if ((ownerHole >> (a >> 6)) & 1u) continue;  // a was absorbed by an earlier row
+      const int j0 = sFirst[a];
+      double ax = sMX[a], ay = sMY[a], aw = sW[a], a00 = sI00[a], a01 = sI01[a], a11 = sI11[a];
+      double axx = pSXX[a], axy = pSXY[a], ayy = pSYY[a];
+      bool changed = false;
+      int floorLane = j0 & 63;  // every j < j0 is known to fail against a's initial state
+      for (int c0 = j0 & ~63; c0 < N; c0 += 64) {
+        const int j = c0 + lane;
+        const int slot = c0 >> 6;
+        bool live = (j > a) && (j < N) && !((hole >> slot) & 1u);
+        double jx = 0, jy = 0, jw = 0, j00 = 0, j01 = 0, j11 = 0;
+        if (live) { jx = sMX[j]; jy = sMY[j]; jw = sW[j]; j00 = sI00[j]; j01 = sI01[j]; j11 = sI11[j]; }
+        while (true) {
+          bool pass = false;
+          if (live && lane >= floorLane) {
+            // d1 = md2 of x_j under (x_a, S_a); d2 = md2 of x_a under (x_j, S_j)   (GaussianMixture.hpp:434-442)
+            const double e0 = jx - ax, e1 = jy - ay;
+            const double u0 = e0 * a00 + e1 * a01, u1 = e0 * a01 + e1 * a11;
+            const double d1 = u0 * e0 + u1 * e1;
+            bool far = d1 > t2;
+            if (far) {
+              const double g0 = -e0, g1 = -e1;
+              const double v0 = g0 * j00 + g1 * j01, v1 = g0 * j01 + g1 * j11;
+              far = (v0 * g0 + v1 * g1) > t2;
+            }
+            pass = !far && ((aw + jw) != 0.0);
+          }
+          const unsigned long long pm = __ballot(pass);
+          if (pm == 0ull) break;
+          const int l = __builtin_ctzll(pm);
+          const int jj = c0 + l;
+          // merge jj into a (:444-471), wave-uniform arithmetic
+          const double w1 = aw, w2 = sW[jj];
+          const double x2 = sMX[jj], y2 = sMY[jj], bxx = pSXX[jj], bxy = pSXY[jj], byy = pSYY[jj];
+          const double wm = w1 + w2;
+          const double xm = (ax * w1 + x2 * w2) / wm, ym = (ay * w1 + y2 * w2) / wm;
+          const double d10 = xm - ax, d11 = ym - ay, d20 = xm - x2, d21 = ym - y2;
+          const double nxx = (w1 * (axx + (f * d10) * d10) + w2 * (bxx + (f * d20) * d20)) / wm;
+          const double nxy = (w1 * (axy + (f * d10) * d11) + w2 * (bxy + (f * d20) * d21)) / wm;
+          const double nyy = (w1 * (ayy + (f * d11) * d11) + w2 * (byy + (f * d21) * d21)) / wm;
+          ax = xm; ay = ym; axx = nxx; axy = nxy; ayy = nyy; aw = wm;
+          double i10, det;
+          inv2(axx, axy, axy, ayy, a00, a01, i10, a11, det);
+          changed = true;
+          if (lane == l) { hole |= 1u << slot; live = false; }
+          floorLane = l + 1;
+          if (floorLane >= 64) break;
+        }
+        floorLane = 0;
+      }
+      if (changed) {
+        anyMerge = true;
+        sW[a] = aw;  // uniform store; the other LDS fields of a are never read again (a is behind the scan)
+        if (lane == 0) { pW[a] = aw; pMX[a] = ax; pMY[a] = ay; pSXX[a] = axx; pSXY[a] = axy; pSYY[a] = ayy; }
+      }
+    }
   }
+
+  if (!FUSE_PRUNE) {
+    if (!anyMerge) return;
+    for (int m = lane, sidx = 0; m < N; m += 64, sidx++)
+      if ((hole >> sidx) & 1u) pW[m] = -1.0;
+    return;
+  }
+
+  DBG_T(32, 3);
+  // ---- fused prune: keep w >= t (not absorbed), order (weight desc, index asc), compact into the other slab ----
+  for (int m = lane, sidx = 0; m < N; m += 64, sidx++)
+    if ((hole >> sidx) & 1u) sW[m] = -1.0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // lane 0's in-place updates of merged rows -> visible to the wave
+  wave_sync();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  double *dl = B.slab[dst];
+  const double t = P.pruneT;
+  int kept = 0;
+  for (int m = lane; m < N; m += 64) {
+    const double wm = sW[m];
+    if ((wm >= t) && (wm >= 0.0)) {
+      int rank = 0;
+      for (int j2 = 0; j2 < N; j2++) {
+        const double wj = sW[j2];
+        rank += (wj > wm || (wj == wm && j2 < m)) ? 1 : 0;
+      }
+      plane(dl, cap, i, PL_W)[rank] = wm;
+      plane(dl, cap, i, PL_WP)[rank] = 0.0;
+      plane(dl, cap, i, PL_MX)[rank] = pMX[m];
+      plane(dl, cap, i, PL_MY)[rank] = pMY[m];
+      plane(dl, cap, i, PL_SXX)[rank] = pSXX[m];
+      plane(dl, cap, i, PL_SXY)[rank] = pSXY[m];
+      plane(dl, cap, i, PL_SYY)[rank] = pSYY[m];
+      kept++;
+    }
+  }
+  kept = wave_sum_i(kept);
+  if (lane == 0) B.count[i] = kept;
+  DBG_T(32, 4);
 }
 
 // LDS per wave: keys[cap] doubles

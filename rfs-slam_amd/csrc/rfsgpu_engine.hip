@@ -466,22 +466,31 @@ static int launch_weighting(rfsgpu_filter *f) {
   return RFSGPU_OK;
 }
 
-static int launch_merge(rfsgpu_filter *f) {
+}  // extern "C" (templates need C++ linkage)
+template <bool FUSE>
+static int launch_merge_t(rfsgpu_filter *f) {
   const size_t per = merge_lds_bytes_per_wave(f->cap);
+  const int cur = f->cur, dst = f->cur ^ 1;
   int rc;
-  if (4 * per <= 80 * 1024) {
-    if ((rc = set_lds(f, gm_merge_kernel<4>, 4 * per)) != RFSGPU_OK) return rc;
-    gm_merge_kernel<4><<<(f->N + 3) / 4, 256, 4 * per, f->stream>>>(f->B, f->P, f->cur);
-  } else if (2 * per <= 80 * 1024) {
-    if ((rc = set_lds(f, gm_merge_kernel<2>, 2 * per)) != RFSGPU_OK) return rc;
-    gm_merge_kernel<2><<<(f->N + 1) / 2, 128, 2 * per, f->stream>>>(f->B, f->P, f->cur);
+  // pick the block shape that keeps the most waves resident per CU (160 KiB LDS): 4 waves/block only while
+  // two such blocks still fit, otherwise smaller blocks pack better
+  if (4 * per <= 40 * 1024) {
+    if ((rc = set_lds(f, (gm_merge_kernel<4, FUSE>), 4 * per)) != RFSGPU_OK) return rc;
+    gm_merge_kernel<4, FUSE><<<(f->N + 3) / 4, 256, 4 * per, f->stream>>>(f->B, f->P, cur, dst);
+  } else if (2 * per <= 40 * 1024) {
+    if ((rc = set_lds(f, (gm_merge_kernel<2, FUSE>), 2 * per)) != RFSGPU_OK) return rc;
+    gm_merge_kernel<2, FUSE><<<(f->N + 1) / 2, 128, 2 * per, f->stream>>>(f->B, f->P, cur, dst);
   } else {
-    if ((rc = set_lds(f, gm_merge_kernel<1>, per)) != RFSGPU_OK) return rc;
-    gm_merge_kernel<1><<<f->N, 64, per, f->stream>>>(f->B, f->P, f->cur);
+    if ((rc = set_lds(f, (gm_merge_kernel<1, FUSE>), per)) != RFSGPU_OK) return rc;
+    gm_merge_kernel<1, FUSE><<<f->N, 64, per, f->stream>>>(f->B, f->P, cur, dst);
   }
   HIPCHK(hipGetLastError());
+  if (FUSE) f->cur = dst;
   return RFSGPU_OK;
 }
+extern "C" {
+static int launch_merge(rfsgpu_filter *f) { return launch_merge_t<false>(f); }
+static int launch_merge_prune(rfsgpu_filter *f) { return launch_merge_t<true>(f); }
 
 static int launch_prune(rfsgpu_filter *f) {
   const size_t per = (size_t)f->cap * 8;
@@ -571,9 +580,10 @@ int rfsgpu_update(rfsgpu_filter *f, const double *z, int n_z) {
     if ((rc = launch_weighting(f)) != RFSGPU_OK) return rc;
   }
   HIPCHK(hipEventRecord(f->ev[EV_W1], f->stream));
-  if ((rc = launch_merge(f)) != RFSGPU_OK) return rc;
+  // merge + prune fused in one kernel (the mapPrune bucket stays 0 on this path; rfsgpu_merge / rfsgpu_prune keep
+  // the two-kernel form for phase-by-phase use)
+  if ((rc = launch_merge_prune(f)) != RFSGPU_OK) return rc;
   HIPCHK(hipEventRecord(f->ev[EV_MG1], f->stream));
-  if ((rc = launch_prune(f)) != RFSGPU_OK) return rc;
   HIPCHK(hipEventRecord(f->ev[EV_PR1], f->stream));
   rc = check_device_errors(f);  // syncs
   accumulate(f->ev[EV_UM0], f->ev[EV_UM1], f->timing.mapUpdate_wall, &f->lastKernelNs[0]);
@@ -746,6 +756,20 @@ int rfsgpu_last_kernel_ns(rfsgpu_filter *f, long long *ns4) {
   for (int k = 0; k < 4; k++) ns4[k] = f->lastKernelNs[k];
   return RFSGPU_OK;
 }
+
+#ifdef RFS_PROFILE
+// tuning builds only (not declared in rfsgpu.h): 64 s_memtime stamps of one particle's last kernels
+int rfsgpu_debug_sections(rfsgpu_filter *f, long long *out64) {
+  CHECK_HANDLE(f);
+  hipSetDevice(f->device);
+  if (!f->B.dbg) {
+    HIPCHK(hipMalloc(&f->B.dbg, 64 * sizeof(long long)));
+    HIPCHK(hipMemset(f->B.dbg, 0, 64 * sizeof(long long)));
+  }
+  HIPCHK(hipMemcpy(out64, f->B.dbg, 64 * sizeof(long long), hipMemcpyDeviceToHost));
+  return RFSGPU_OK;
+}
+#endif
 
 int rfsgpu_mat_perm(const double *A, int n, int batch, double *out, int device_id) {
   if (!A || !out || n < 1 || n > 24 || batch < 0) return RFSGPU_ERR_INVALID;

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(WPB * 64) void phd_update_map_kernel(Buffers B, Par
   double *pMX = plane(slab, B.cap, i, PL_MX), *pMY = plane(slab, B.cap, i, PL_MY);
   double *pSXX = plane(slab, B.cap, i, PL_SXX), *pSXY = plane(slab, B.cap, i, PL_SXY), *pSYY = plane(slab, B.cap, i, PL_SYY);
 
+  DBG_T(0, 0);
   PoseReg pr;
   load_pose(B, P, i, pr);
 
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(WPB * 64) void phd_update_map_kernel(Buffers B, Par
     if (act) assoc[m] = mymask;
   }
   __builtin_amdgcn_wave_barrier();
+  DBG_T(0, 1);
 
   // ---------------- pass 2: normalise, append new Gaussians, missed-detection weights ----------------
   int base = nM;
@@ -214,6 +216,7 @@ __global__ __launch_bounds__(WPB * 64) void phd_update_map_kernel(Buffers B, Par
       pW[m] = w_k;
     }
   }
+  DBG_T(0, 2);
   used = wave_or_u64(used);
   if (__ballot(overflow) != 0ull) {
     if (lane == 0) atomicOr(B.err, ERRBIT_CAPACITY);

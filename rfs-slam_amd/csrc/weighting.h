@@ -182,6 +182,7 @@ __global__ __launch_bounds__(WPB * 64) void phd_weight_multifeature_kernel(Buffe
     return;
   }
 
+  DBG_T(16, 0);
   // ---- 1. sort by weight: rank = #{ j : w_j > w_m  or (w_j == w_m and j < m) } ----
   for (int m = lane; m < N; m += 64) s.keys[m] = qW[m];
   wave_sync();
@@ -207,6 +208,7 @@ __global__ __launch_bounds__(WPB * 64) void phd_weight_multifeature_kernel(Buffe
     plane(dl, B.cap, i, PL_SYY)[r] = qSYY[m];
   }
 
+  DBG_T(16, 1);
   PoseReg pr;
   load_pose(B, P, i, pr);
 
@@ -254,6 +256,7 @@ __global__ __launch_bounds__(WPB * 64) void phd_weight_multifeature_kernel(Buffe
   if (evalOverflow && lane == 0) atomicOr(B.err, ERRBIT_EVALPTS);
   wave_sync();
 
+  DBG_T(16, 2);
   // ---- 3. weight sums (:765-775) and intensity products at the evaluation points (:776-800) ----
   double sumPrev = 0.0, sumCur = 0.0;
   for (int m = lane; m < N; m += 64) { sumPrev += qWP[m]; sumCur += s.keys[m]; }
@@ -293,6 +296,7 @@ __global__ __launch_bounds__(WPB * 64) void phd_weight_multifeature_kernel(Buffe
     }
   }
 
+  DBG_T(16, 3);
   // ---- 4. likelihood table L[e][n] = N(z_n; h(x, e), S_e) * Pd_e, gated (:847-863) ----
   if (lane < nE) {
     MeasOut mo;
@@ -315,6 +319,7 @@ __global__ __launch_bounds__(WPB * 64) void phd_weight_multifeature_kernel(Buffe
   }
   wave_sync();
 
+  DBG_T(16, 4);
   // ---- 5. connected components of the bipartite graph (rows = eval points, cols = measurements) ----
   unsigned long long myRow = 0, myCol = 0;
   if (lane < nE) for (int n = 0; n < nZ; n++) if (s.L[lane * nZ + n] != 0.0) myRow |= 1ull << n;
@@ -370,6 +375,7 @@ __global__ __launch_bounds__(WPB * 64) void phd_weight_multifeature_kernel(Buffe
   const unsigned long long mergedRows = wave_or_u64(zr), mergedCols = wave_or_u64(zc);
   const int nPartitions = ncc - (nZero > 0 ? nZero - 1 : 0);  // caller still indexes components [0, nPartitions) -- quirk kept
 
+  DBG_T(16, 5);
   // ---- 6. one lane per partition ----
   const double logc = log(P.clutter);
   for (int p = lane; p < nPartitions; p += 64) {
@@ -414,10 +420,12 @@ __global__ __launch_bounds__(WPB * 64) void phd_weight_multifeature_kernel(Buffe
   const double sensingArea = 2 * RFS_PI * (P.rmax - P.rmin);
   const double ml = l / (P.clutter * sensingArea);  // clutterIntensityIntegral (src/MeasurementModel_RngBrg.cpp:175-178)
 
+  DBG_T(16, 6);
   // ---- 7. overall weight (:806-811) ----
   const double overall = ml * prodBefore / prodAfter * exp(sumCur - sumPrev);
   if (lane == 0) {
     const double wnew = overall * B.weight[i];
     B.weight[i] = wnew;
   }
+  DBG_T(16, 7);
 }

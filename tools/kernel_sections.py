@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Kernel-section timing for tuning (not part of the product): builds a -DRFS_PROFILE copy of the library where
+lane 0 of one particle stamps s_memtime at section boundaries, runs the C2a step, prints cycles per section."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+pkg = load_package()
+prof_lib = os.path.join(ROOT, "tools", "_build", "librfsgpu_prof.so")
+if "--build" in sys.argv:
+    os.makedirs(os.path.dirname(prof_lib), exist_ok=True)
+    bm = pkg.build_mod
+    cmd = [bm.hipcc()] + bm.FLAGS + ["-DRFS_PROFILE", os.path.join(bm.CSRC, "rfsgpu_engine.hip"), "-o", prof_lib]
+    subprocess.check_call(cmd)
+    sys.exit(0)
+lib = C.CDLL(prof_lib)
+pkg.engine._lib = lib
+sc = pkg.scenarios
+n, nm, nz, cap = [int(x) for x in (sys.argv[1:5] + [2000, 200, 30, 384][len(sys.argv[1:5]):])]
+scen = sc.make_scenario(n, nm, nz, seed=12345)
+f = pkg.RBPHDFilter(n, gm_capacity=cap)
+sc.load_scenario(f, scen)
+out = (C.c_longlong * 64)()
+lib.rfsgpu_debug_sections(f._h, out)  # allocates the stamp buffer
+f.save_state()
+for _ in range(3):
+    f.restore_state()
+    f.update(scen["Z"])
+lib.rfsgpu_debug_sections(f._h, out)
+t = np.array(list(out), dtype=np.int64)
+names = {0: ["update_map: pass1", "update_map: pass2"],
+         16: ["weight: sort+write", "weight: eval pts", "weight: intensity", "weight: L table", "weight: components", "weight: partitions", "weight: final"],
+         32: ["merge: stage", "merge: phase1", "merge: phase2", "merge: prune"]}
+for base, ns in names.items():
+    for k, nm_ in enumerate(ns):
+        d = t[base + k + 1] - t[base + k]
+        print(f"{nm_:28s} {d:10d} cycles")
+print("kernel ns (events):", f.last_kernel_ns())
