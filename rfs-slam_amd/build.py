@@ -36,3 +36,20 @@ def build(force=False, verbose=False, extra_flags=()):
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     return LIB
+
+
+SIM = os.path.join(HERE, "host", "rbphdslam2d_sim")
+
+
+def build_host(force=False, verbose=False):
+    """Compile the C++ host driver (plain g++, links the C-ABI library only)."""
+    src = os.path.join(HERE, "host", "rbphdslam2d_sim.cpp")
+    hdr = os.path.join(HERE, "host", "rbphd_filter.hpp")
+    if not force and os.path.exists(SIM) and os.path.getmtime(SIM) > max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(LIB)):
+        return SIM
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "host"), src,
+           "-L" + HERE, "-lrfsgpu", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib", "-o", SIM]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SIM

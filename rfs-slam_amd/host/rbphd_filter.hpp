@@ -1,0 +1,315 @@
+// rbphd_filter.hpp -- C++ host mirror of rfs::RBPHDFilter for the device path (header-only, over the C ABI in
+// include/rfsgpu.h).  Same public surface as the reference class template instantiated by rbphdslam2dSim
+//   RBPHDFilter<MotionModel_Odometry2d, StaticProcessModel<Landmark2d>, MeasurementModel_RngBrg, KalmanFilter_RngBrg>
+// (reference include/RBPHDFilter.hpp:72-251, src/rbphdslam2dSim.cpp:446-491): predict / update / getGMSize /
+// getLandmark / setParticlePose / getKalmanFilter / getLmkProcessModel / getMeasurementModel / getProcessModel /
+// getTimingInfo / public `config`, same argument meaning and error behaviour (void predict/update, getGMSize -> -1,
+// getLandmark -> false on bad indices).  What stays on the host, exactly as in the reference: pose propagation with
+// host RNG (ParticleFilter::propagate, include/ParticleFilter.hpp:322-341), the resampling decision and the
+// systematic draw with drand48() (ParticleFilter::resample :399-492), the resample counters (:526-539).
+// Eigen/Boost are not available in this image, so Pose2d / Landmark2d / Measurement2d are plain structs here;
+// INTEGRATION.md shows the Eigen-typed binding for the reference tree.
+#pragma once
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "rfsgpu.h"
+
+namespace rfs_amd {
+
+struct Pose2d {
+  double x[3] = {0, 0, 0};
+  double P[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // row-major covariance (enters S, MeasurementModel_RngBrg.cpp:102)
+};
+struct Odometry2d {
+  double u[3] = {0, 0, 0};
+  double t = 0;
+};
+struct Measurement2d {
+  double z[2] = {0, 0};
+  double t = 0;
+};
+
+// MotionModel_Odometry2d::step (reference src/ProcessModel_Odometry2D.cpp:40-88) + ProcessModel::sample
+// (include/ProcessModel.hpp:126-150): host-side, RNG-bound, 3 doubles per particle.
+class MotionModel_Odometry2d {
+ public:
+  void setNoise(const double Q[9]) { std::memcpy(Q_, Q, sizeof(Q_)); chol(); }
+  void getNoise(double Q[9]) const { std::memcpy(Q, Q_, sizeof(Q_)); }
+  static void step(Pose2d &s_k, const Pose2d &s_km, const Odometry2d &in) {
+    const double ct = std::cos(s_km.x[2]), st = std::sin(s_km.x[2]);
+    // C_km = [ct st; -st ct]; p_k = p_km + C_km^T * dp
+    const double px = s_km.x[0] + (ct * in.u[0] + (-st) * in.u[1]);
+    const double py = s_km.x[1] + (st * in.u[0] + ct * in.u[1]);
+    const double cd = std::cos(in.u[2]), sd = std::sin(in.u[2]);
+    // C_k = C_d * C_km ; theta = atan2(C_k(0,1), C_k(0,0))
+    const double c00 = cd * ct + sd * (-st), c01 = cd * st + sd * ct;
+    s_k.x[0] = px;
+    s_k.x[1] = py;
+    s_k.x[2] = std::atan2(c01, c00);
+  }
+  template <class RNG>
+  void sample(Pose2d &s_k, const Pose2d &s_km, const Odometry2d &in, bool useModelNoise, RNG &rng) const {
+    Pose2d out = s_km;
+    step(out, s_km, in);
+    bool zeroQ = true;
+    for (double q : Q_) zeroQ = zeroQ && (q == 0);
+    if (useModelNoise && !zeroQ) {
+      std::memcpy(out.P, Q_, sizeof(Q_));  // the sampled pose keeps covariance Q (ProcessModel.hpp:145-149)
+      std::normal_distribution<double> N01(0.0, 1.0);
+      const double n0 = N01(rng), n1 = N01(rng), n2 = N01(rng);
+      out.x[0] += L_[0] * n0;
+      out.x[1] += L_[3] * n0 + L_[4] * n1;
+      out.x[2] += L_[6] * n0 + L_[7] * n1 + L_[8] * n2;
+    }
+    s_k = out;
+  }
+
+ private:
+  double Q_[9] = {0}, L_[9] = {0};
+  void chol() {  // lower Cholesky factor of Q (RandomVec::sample uses Eigen::LLT)
+    std::memset(L_, 0, sizeof(L_));
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j <= i; j++) {
+        double s = Q_[3 * i + j];
+        for (int k = 0; k < j; k++) s -= L_[3 * i + k] * L_[3 * j + k];
+        L_[3 * i + j] = (i == j) ? (s > 0 ? std::sqrt(s) : 0.0) : (L_[3 * j + j] != 0 ? s / L_[3 * j + j] : 0.0);
+      }
+  }
+};
+
+class RBPHDFilter2d {
+ public:
+  // --- nested "model" handles so that driver code reads like the reference's (getXxx()->config.yyy_ = ...) ---
+  struct MeasurementModel {
+    struct Config {
+      double probabilityOfDetection_ = 0.95, uniformClutterIntensity_ = 0.1, rangeLimMax_ = 5, rangeLimMin_ = 0.3, rangeLimBuffer_ = 0.25;
+    } config;
+    double R[4] = {0, 0, 0, 0};
+    void setNoise(const double Rin[4]) { std::memcpy(R, Rin, sizeof(R)); }
+  };
+  struct KalmanFilter {
+    struct Config {
+      double rangeInnovationThreshold_ = -1, bearingInnovationThreshold_ = -1;
+    } config;
+  };
+  struct LmkProcessModel {
+    double Q[4] = {0, 0, 0, 0};
+    void setNoise(const double Qin[4]) { std::memcpy(Q, Qin, sizeof(Q)); }
+  };
+  struct Config {  // RBPHDFilter::Config (RBPHDFilter.hpp:90-146), reference member names
+    double birthGaussianWeight_ = 0.25;
+    unsigned birthGaussianMeasurementCountThreshold_ = 1, birthGaussianMeasurementCheckThreshold_ = 1;
+    double birthGaussianMeasurementSupportDist_ = 1;
+    unsigned birthGaussianCurrentMeasurementCountThreshold_ = 1;
+    double newGaussianCreateInnovMDThreshold_ = 0.2;
+    int importanceWeightingEvalPointCount_ = 8;
+    double importanceWeightingEvalPointGuassianWeight_ = 0;
+    double importanceWeightingMeasurementLikelihoodMDThreshold_ = 3.0;
+    double gaussianMergingThreshold_ = 0.5, gaussianMergingCovarianceInflationFactor_ = 1.5, gaussianPruningThreshold_ = 0.2;
+    int minUpdatesBeforeResample_ = 1, minMeasurementsBeforeResample_ = 1;
+    bool useClusterProcess_ = false;
+  } config;
+  typedef rfsgpu_timing TimingInfo;  // same 14 fields as RBPHDFilter::TimingInfo (:152-167)
+
+  explicit RBPHDFilter2d(int n, int device_id = 0, int gm_capacity = 512) : n_(n), poses_(n), weights_(n, 1.0), rng_(std::rand()) {
+    int rc = rfsgpu_create(&h_, RFSGPU_MODEL_RNGBRG_2D, n, device_id, gm_capacity);
+    if (rc != RFSGPU_OK) throw std::runtime_error("rfsgpu_create failed with status " + std::to_string(rc) + " (no gfx950 device? there is no CPU fallback)");
+    effNParticles_t_ = double(n) / 4.0;  // ParticleFilter.hpp:232
+  }
+  ~RBPHDFilter2d() { rfsgpu_destroy(h_); }
+  RBPHDFilter2d(const RBPHDFilter2d &) = delete;
+  RBPHDFilter2d &operator=(const RBPHDFilter2d &) = delete;
+
+  MotionModel_Odometry2d *getProcessModel() { return &motion_; }
+  LmkProcessModel *getLmkProcessModel() { return &lmk_; }
+  MeasurementModel *getMeasurementModel() { return &meas_; }
+  KalmanFilter *getKalmanFilter() { return &kf_; }
+  int getParticleCount() const { return n_; }
+  void setEffectiveParticleCountThreshold(double t) { effNParticles_t_ = t; }
+  double getEffectiveParticleCountThreshold() const { return effNParticles_t_; }
+  const Pose2d &getParticlePose(int i) const { return poses_[i]; }
+  double getParticleWeight(int i) {
+    pullWeights();
+    return weights_[i];
+  }
+  bool resampleOccured() const { return resampleOccured_; }
+
+  // RBPHDFilter::setParticlePose (:1181-1186)
+  void setParticlePose(int i, const Pose2d &p) {
+    poses_[i] = p;
+    posesDirty_ = true;
+  }
+
+  // RBPHDFilter::predict (:415-442): birth Gaussians at the pre-propagation pose, host propagation, Sigma += Q.
+  void predict(const Odometry2d &u, double /*dT*/, bool useModelNoise = true, bool /*useInputNoise*/ = false, bool birthGaussianCheck = true) {
+    pushConfig();
+    pushPoses();
+    check(rfsgpu_predict_map(h_, birthGaussianCheck ? 1 : 0), "predict_map");
+    for (int i = 0; i < n_; i++) {  // ParticleFilter::propagate
+      Pose2d xk;
+      motion_.sample(xk, poses_[i], u, useModelNoise, rng_);
+      poses_[i] = xk;
+    }
+    posesDirty_ = true;
+  }
+
+  // RBPHDFilter::update (:444-541).  Z is consumed (swapped into the filter and cleared, ParticleFilter.hpp:316-320).
+  void update(std::vector<Measurement2d> &Z) {
+    nUpdatesSinceResample_++;
+    std::vector<Measurement2d> meas;
+    meas.swap(Z);
+    Z.clear();
+    if (meas.empty()) return;  // :450-452
+    nMeasurementsSinceResample_ += (unsigned)meas.size();
+    pushConfig();
+    pushPoses();
+    std::vector<double> z(2 * meas.size());
+    for (size_t k = 0; k < meas.size(); k++) { z[2 * k] = meas[k].z[0]; z[2 * k + 1] = meas[k].z[1]; }
+    check(rfsgpu_update(h_, z.data(), (int)meas.size()), "update");
+    weightsStale_ = true;
+    resampleOccured_ = false;
+    if (nUpdatesSinceResample_ >= (unsigned)config.minUpdatesBeforeResample_ &&
+        nMeasurementsSinceResample_ >= (unsigned)config.minMeasurementsBeforeResample_)
+      resampleOccured_ = resample();
+    if (resampleOccured_) {
+      nUpdatesSinceResample_ = 0;
+      nMeasurementsSinceResample_ = 0;
+    } else {
+      normalizeWeights();
+    }
+  }
+
+  // RBPHDFilter::getGMSize / getLandmark (:1152-1178)
+  int getGMSize(int i) { return rfsgpu_gm_size(h_, i); }
+  bool getLandmark(int i, int m, double u[2], double S[4], double &w) { return rfsgpu_get_landmark(h_, i, m, u, S, &w) == RFSGPU_OK; }
+
+  TimingInfo *getTimingInfo() {
+    rfsgpu_get_timing(h_, &timing_);
+    return &timing_;
+  }
+  rfsgpu_filter *handle() { return h_; }
+
+ private:
+  rfsgpu_filter *h_ = nullptr;
+  int n_;
+  MotionModel_Odometry2d motion_;
+  LmkProcessModel lmk_;
+  MeasurementModel meas_;
+  KalmanFilter kf_;
+  std::vector<Pose2d> poses_;
+  std::vector<double> weights_;
+  std::mt19937 rng_;
+  double effNParticles_t_;
+  unsigned nUpdatesSinceResample_ = 0, nMeasurementsSinceResample_ = 0;
+  bool resampleOccured_ = false, posesDirty_ = true, weightsStale_ = false;
+  TimingInfo timing_{};
+
+  void check(int rc, const char *what) {
+    if (rc != RFSGPU_OK) throw std::runtime_error(std::string(what) + ": " + rfsgpu_last_error(h_));
+  }
+  void pushConfig() {
+    rfsgpu_filter_config c;
+    c.birthGaussianWeight = config.birthGaussianWeight_;
+    c.birthGaussianMeasurementCountThreshold = config.birthGaussianMeasurementCountThreshold_;
+    c.birthGaussianMeasurementCheckThreshold = config.birthGaussianMeasurementCheckThreshold_;
+    c.birthGaussianMeasurementSupportDist = config.birthGaussianMeasurementSupportDist_;
+    c.birthGaussianCurrentMeasurementCountThreshold = config.birthGaussianCurrentMeasurementCountThreshold_;
+    c.newGaussianCreateInnovMDThreshold = config.newGaussianCreateInnovMDThreshold_;
+    c.importanceWeightingEvalPointCount = config.importanceWeightingEvalPointCount_;
+    c.importanceWeightingEvalPointGuassianWeight = config.importanceWeightingEvalPointGuassianWeight_;
+    c.importanceWeightingMeasurementLikelihoodMDThreshold = config.importanceWeightingMeasurementLikelihoodMDThreshold_;
+    c.gaussianMergingThreshold = config.gaussianMergingThreshold_;
+    c.gaussianMergingCovarianceInflationFactor = config.gaussianMergingCovarianceInflationFactor_;
+    c.gaussianPruningThreshold = config.gaussianPruningThreshold_;
+    c.minUpdatesBeforeResample = config.minUpdatesBeforeResample_;
+    c.minMeasurementsBeforeResample = config.minMeasurementsBeforeResample_;
+    c.useClusterProcess = config.useClusterProcess_ ? 1 : 0;
+    check(rfsgpu_set_filter_config(h_, &c), "set_filter_config");
+    rfsgpu_rngbrg_config m;
+    std::memcpy(m.R, meas_.R, sizeof(m.R));
+    m.probabilityOfDetection = meas_.config.probabilityOfDetection_;
+    m.uniformClutterIntensity = meas_.config.uniformClutterIntensity_;
+    m.rangeLimMax = meas_.config.rangeLimMax_;
+    m.rangeLimMin = meas_.config.rangeLimMin_;
+    m.rangeLimBuffer = meas_.config.rangeLimBuffer_;
+    check(rfsgpu_set_model_rngbrg(h_, &m), "set_model_rngbrg");
+    rfsgpu_kf_config k{kf_.config.rangeInnovationThreshold_, kf_.config.bearingInnovationThreshold_};
+    check(rfsgpu_set_kf_config(h_, &k), "set_kf_config");
+    check(rfsgpu_set_lmk_process_noise(h_, lmk_.Q), "set_lmk_process_noise");
+  }
+  void pushPoses() {
+    if (!posesDirty_) return;
+    std::vector<double> x(3 * (size_t)n_), P(9 * (size_t)n_);
+    for (int i = 0; i < n_; i++) {
+      std::memcpy(&x[3 * i], poses_[i].x, 3 * sizeof(double));
+      std::memcpy(&P[9 * i], poses_[i].P, 9 * sizeof(double));
+    }
+    check(rfsgpu_set_poses(h_, x.data(), P.data(), 9), "set_poses");
+    posesDirty_ = false;
+  }
+  void pullWeights() {
+    if (!weightsStale_) return;
+    check(rfsgpu_get_weights(h_, weights_.data()), "get_weights");
+    weightsStale_ = false;
+  }
+  // ParticleFilter::normalizeWeights (ParticleFilter.hpp:352-363): sum on the device, divide on the device.
+  void normalizeWeights() {
+    double s[2];
+    check(rfsgpu_weight_sums(h_, s), "weight_sums");
+    check(rfsgpu_normalize_weights(h_, s[0], nullptr), "normalize_weights");
+    weightsStale_ = true;
+  }
+  // ParticleFilter::resample (ParticleFilter.hpp:399-492).
+  bool resample() {
+    normalizeWeights();
+    pullWeights();
+    double s2 = 0;
+    for (int i = 0; i < n_; i++) s2 += weights_[i] * weights_[i];
+    const double nEff = 1.0 / s2;
+    const double t_percent = effNParticles_t_ / n_;
+    if (nEff > effNParticles_t_ && nEff / n_ > t_percent) return false;
+    const int n = n_;
+    const double u01 = drand48();
+    unsigned idx = 0;
+    const double interval = 1.0 / double(n);
+    double sample_point = interval * u01;
+    double cumulative = weights_[0];
+    std::vector<char> sampled(n, 0);
+    std::vector<unsigned> sampled_idx(n, 0);
+    for (int i = 0; i < n; i++) {
+      while (sample_point > cumulative && (int)idx < n - 1) {
+        idx++;
+        cumulative += weights_[idx];
+      }
+      sampled_idx[i] = idx;
+      sampled[idx] = 1;
+      sample_point += interval;
+    }
+    std::vector<int> src(n);
+    for (int i = 0; i < n; i++) src[i] = i;
+    unsigned idx_prev = 0, next_unsampled = 0;
+    for (int i = 0; i < n; i++) {
+      idx = sampled_idx[i];
+      const bool firstTime = !(i > 0 && idx == idx_prev);
+      idx_prev = idx;
+      if (firstTime) continue;  // case 1: keeps its slot
+      while (next_unsampled < (unsigned)n && sampled[next_unsampled] == 1) next_unsampled++;
+      src[next_unsampled] = (int)idx;
+      poses_[next_unsampled] = poses_[idx];  // Particle::copy copies the pose too
+      next_unsampled++;
+    }
+    check(rfsgpu_resample_apply(h_, src.data()), "resample_apply");
+    posesDirty_ = true;
+    for (int i = 0; i < n; i++) weights_[i] = 1.0;
+    weightsStale_ = false;
+    return true;
+  }
+};
+
+}  // namespace rfs_amd

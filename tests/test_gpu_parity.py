@@ -199,3 +199,20 @@ def test_murty_partitions_match_oracle(pkg, ob, sc):
         f.importance_weighting()
     assert orc.murty_calls() > 0, "scenario does not reach the Murty path"
     compare_weights(dev, orc)
+
+
+def test_cpp_host_driver_end_to_end(pkg):
+    """The C++ host mirror (rfs-slam_amd/host/rbphd_filter.hpp) driving the device path through the C ABI on the
+    shipped C1 configuration (cfg values of the reference's rbphdslam2dSim.xml): the map must converge."""
+    import os
+    import re
+    import subprocess
+    exe = pkg.build_mod.build_host()
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "rbphdslam2dSim_c1.xml")
+    out = subprocess.run([exe, "-c", cfg, "-t", "2", "-s", "2", "-n", "200"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    m = re.search(r"RESULT matched=(\d+) landmarks=(\d+) mean_err=([\d.]+) pose_err=([\d.]+)", out.stdout)
+    assert m, out.stdout[-2000:]
+    matched, total, mean_err, pose_err = int(m.group(1)), int(m.group(2)), float(m.group(3)), float(m.group(4))
+    assert total == 50 and matched >= 40, out.stdout[-800:]
+    assert mean_err < 0.3 and pose_err < 0.6
