@@ -119,14 +119,14 @@ def main():
     f.bind_weight_sums_buffer(sums.data_ptr())
     f.save_state()
     Z = scen["Z"]
+    sh = pkg.sharded.ShardedRBPHDFilter(f, device=torch.device("cuda", local_rank))
 
     def step():
         f.restore_state()
         f.update(Z)
-        f.weight_sums_async()
-        if world > 1:
-            dist.all_reduce(sums)  # {sum w, sum w^2} over xGMI (RCCL); the only collective on the path
-        f.normalize_weights(0.0, sums.data_ptr())
+        # device reduction of {sum w, sum w^2} -> RCCL all-reduce over xGMI (the only collective on the path, N>1)
+        # -> on-device divide; no host round trip for the sums
+        sh.normalize(sums)
 
     for _ in range(args.warmup):
         step()

@@ -147,6 +147,9 @@ int rfsgpu_import_gm(rfsgpu_filter *f, int slot, int n, const double *w, const d
 /* Copy out up to max_n Gaussians in storage order; *n_out = mixture size.  w_prev may be NULL. */
 int rfsgpu_export_gm(rfsgpu_filter *f, int slot, int max_n, int *n_out, double *w, double *w_prev,
                      double *mean, double *cov);
+/* Set particle `slot`'s birth bookkeeping (unused_measurements_[slot] as ascending indices, nLandmarksInFOV_[slot]);
+ * needed when a particle migrates between shards during a multi-GPU resample (RBPHDFilter.hpp:1005-1011). */
+int rfsgpu_import_aux(rfsgpu_filter *f, int slot, const int *unused_idx, int n_unused, int n_in_fov);
 /* All mixture sizes at once (n_particles ints). */
 int rfsgpu_gm_sizes(rfsgpu_filter *f, int *sizes);
 

@@ -1062,6 +1062,14 @@ int rfsor_get_landmark(void *f, int slot, int m, double *mean, double *cov, doub
   return RFSGPU_OK;
 }
 
+int rfsor_import_aux(void *f, int slot, const int *unused_idx, int n_unused, int n_in_fov) {
+  Filter *F = F_(f);
+  if (slot < 0 || slot >= F->n) return RFSGPU_ERR_INVALID;
+  F->unused[slot].assign(unused_idx, unused_idx + n_unused);
+  F->nInFov[slot] = (unsigned)n_in_fov;
+  return RFSGPU_OK;
+}
+
 int rfsor_predict_map(void *f, int add_birth) {
   Filter *F = F_(f);
   long long t0 = orc::now_ns();

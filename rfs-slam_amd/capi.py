@@ -71,7 +71,7 @@ ABI_SYMBOLS = [
     "update", "update_map", "importance_weighting", "merge", "prune", "get_unused", "landmarks_in_fov",
     "weight_sums", "weight_sums_async", "weight_sums_device_ptr", "normalize_weights", "resample_apply",
     "get_timing", "reset_timing", "synchronize", "stream", "last_kernel_ns", "mat_perm",
-    "set_stream", "bind_weight_sums_buffer", "save_state", "restore_state",
+    "set_stream", "bind_weight_sums_buffer", "save_state", "restore_state", "import_aux",
 ]
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -231,6 +231,10 @@ class CFilter:
         self._call("export_gm", C.c_int(i), C.c_int(n), C.byref(nout), self._ptr(w), self._ptr(wp), self._ptr(mean), self._ptr(cov))
         k = min(nout.value, n)
         return w[:k], wp[:k], mean[:k], cov[:k]
+
+    def import_aux(self, i, unused_idx, n_in_fov):
+        u = np.ascontiguousarray(unused_idx, dtype=np.int32)
+        self._call("import_aux", C.c_int(i), self._ptr(u), C.c_int(u.size), C.c_int(int(n_in_fov)))
 
     # -- hot path ------------------------------------------------------------------------------
     def predict_map(self, add_birth=True):

@@ -410,6 +410,21 @@ int rfsgpu_import_gm(rfsgpu_filter *f, int slot, int n, const double *w, const d
   return RFSGPU_OK;
 }
 
+int rfsgpu_import_aux(rfsgpu_filter *f, int slot, const int *unused_idx, int n_unused, int n_in_fov) {
+  CHECK_HANDLE(f);
+  if (slot < 0 || slot >= f->N || n_unused < 0 || (n_unused > 0 && !unused_idx)) return fail(f, RFSGPU_ERR_INVALID, "import_aux: bad arguments");
+  unsigned long long m = 0;
+  for (int k = 0; k < n_unused; k++) {
+    if (unused_idx[k] < 0 || unused_idx[k] >= RFSGPU_MAX_Z) return fail(f, RFSGPU_ERR_INVALID, "import_aux: measurement index out of range");
+    m |= 1ull << unused_idx[k];
+  }
+  hipSetDevice(f->device);
+  HIPCHK(hipMemcpyAsync(f->B.unusedMask + slot, &m, sizeof(m), hipMemcpyHostToDevice, f->stream));
+  HIPCHK(hipMemcpyAsync(f->B.nInFov + slot, &n_in_fov, sizeof(int), hipMemcpyHostToDevice, f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  return RFSGPU_OK;
+}
+
 // ---- the hot path ----------------------------------------------------------------------------------
 
 static int set_lds_impl(rfsgpu_filter *f, const void *kernel, size_t bytes) {
