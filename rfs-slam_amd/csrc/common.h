@@ -95,6 +95,50 @@ __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) 
   for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
   return v;
 }
+// ---- DPP wave reductions (gfx9 row_shr / row_bcast): ~10x cheaper than ds_bpermute-based shuffles ----------
+// Pattern of rocPRIM's warp_reduce_dpp: quad swaps, row_shr:4/8 inside each 16-lane row, then row_bcast:15 / :31
+// across rows; the full-wave result lands in lane 63 and is broadcast with v_readlane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, true);  // bound_ctrl: invalid source lanes read 0
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// Sum over the 64 lanes, result returned in every lane.  Lanes that receive no partner add +0.0.
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v += dpp_f64<0xb1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4e, 0xf>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_f64<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of each row holds the row sum
+  v += dpp_f64<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_f64<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+  return readlane_f64(v, 63);
+}
+__device__ __forceinline__ int wave_sum_i_dpp(int v) {
+  v += dpp_i32<0xb1, 0xf>(v);
+  v += dpp_i32<0x4e, 0xf>(v);
+  v += dpp_i32<0x114, 0xf>(v);
+  v += dpp_i32<0x118, 0xf>(v);
+  v += dpp_i32<0x142, 0xa>(v);
+  v += dpp_i32<0x143, 0xc>(v);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+// min / max of a float over the wave (exact in any order).  Uses shuffles of 32-bit values (one ds_bpermute each).
+__device__ __forceinline__ float wave_min_f32(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
 // exclusive prefix sum over the wave (small ints)
 __device__ __forceinline__ int wave_excl_scan(int v, int lane) {
   int x = v;

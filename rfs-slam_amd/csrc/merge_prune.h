@@ -15,8 +15,12 @@
 #include "common.h"
 #include "weighting.h"  // wave_sync
 
-// LDS per wave and entry: x, y, w, i00, i01, i11, bound (7 doubles) + first-candidate index (u16)
-__host__ __device__ inline size_t merge_lds_bytes_per_wave(int cap) { return (((size_t)cap * (7 * 8 + 2)) + 15) & ~(size_t)15; }
+// LDS per wave: per entry x, y, w, i00, i01, i11, bound (7 doubles) + first-candidate index (u16) + grid-sorted
+// index (u16); plus the 16x16 spatial grid: cell start offsets and scatter cursors (u32 each).
+#define MERGE_GRID 16
+__host__ __device__ inline size_t merge_lds_bytes_per_wave(int cap) {
+  return (((size_t)cap * (7 * 8 + 2 + 2)) + (size_t)(MERGE_GRID * MERGE_GRID + 1) * 4 * 2 + 15) & ~(size_t)15;
+}
 
 // Necessary condition for a pair to pass the merge test: md2 = e^T S^-1 e >= |e|^2 / lambda_max(S) >= |e|^2 / tr(S),
 // so d1 <= t^2 or d2 <= t^2 implies |e|^2 <= t^2 * max(tr S_a, tr S_j).  The bound carries a 1e-6 relative
@@ -49,7 +53,10 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
   unsigned char *wbase = smem_raw + (size_t)wave * merge_lds_bytes_per_wave(cap);
   double *sMX = reinterpret_cast<double *>(wbase), *sMY = sMX + cap, *sW = sMX + 2 * cap;
   double *sI00 = sMX + 3 * cap, *sI01 = sMX + 4 * cap, *sI11 = sMX + 5 * cap, *sBnd = sMX + 6 * cap;
-  unsigned short *sFirst = reinterpret_cast<unsigned short *>(sMX + 7 * cap);
+  unsigned *sCellStart = reinterpret_cast<unsigned *>(sMX + 7 * cap);      // [GRID*GRID + 1]
+  unsigned *sCellCur = sCellStart + (MERGE_GRID * MERGE_GRID + 1);          // [GRID*GRID]
+  unsigned short *sFirst = reinterpret_cast<unsigned short *>(sCellCur + MERGE_GRID * MERGE_GRID + 1);
+  unsigned short *sSorted = sFirst + cap;
 
   const int N = B.count[i];
   double *slab = B.slab[cur];
@@ -74,42 +81,95 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
 
   DBG_T(32, 1);
   // ---- phase 1: first passing partner of every row, against initial states ----
-  // j-chunk in registers; a-chunk in registers too, broadcast lane by lane with v_readlane (no LDS latency in
-  // the inner loop); the Mahalanobis forms run only for the rare pairs that survive the distance prefilter.
-  for (int c0 = 0; c0 < N; c0 += 64) {
-    const int j = c0 + lane;
-    const bool jlive = (j < N) && !((hole >> (c0 >> 6)) & 1u);
-    double jx = 0, jy = 0, jw = 0, j00 = 0, j01 = 0, j11 = 0, jb = 0;
-    if (j < N) { jx = sMX[j]; jy = sMY[j]; jw = sW[j]; j00 = sI00[j]; j01 = sI01[j]; j11 = sI11[j]; jb = sBnd[j]; }
-    for (int a0 = 0; a0 <= c0; a0 += 64) {
-      const int am = a0 + lane;
-      double rx = 0, ry = 0, rb = 0;
-      if (am < N) { rx = sMX[am]; ry = sMY[am]; rb = sBnd[am]; }
-      const int tEnd = (N - a0 < 64) ? N - a0 : 64;
-#pragma unroll 8
-      for (int t = 0; t < tEnd; t++) {
-        const int a = a0 + t;
-        const double ax = readlane_f64(rx, t), ay = readlane_f64(ry, t), ab = readlane_f64(rb, t);
-        const double e0 = jx - ax, e1 = jy - ay;
-        const double e2 = e0 * e0 + e1 * e1;
-        const bool cand = jlive && (j > a) && !(e2 > fmax(ab, jb));
-        if (__ballot(cand) == 0ull) continue;
-        bool pass = false;
-        if (cand) {
-          const double a00 = sI00[a], a01 = sI01[a], a11 = sI11[a], aw = sW[a];
+  // Candidate search through a 16x16 uniform grid over the mixture's bounding box.  The cell edge is >= the largest
+  // prefilter radius (sqrt of the largest bound), so every pair that can pass the prefilter lies in adjacent cells;
+  // an entry only looks at partners with a HIGHER index (it plays `a`, they play `j`), so each lane finds the lowest
+  // passing j of its own rows without atomics.  A non-finite bound makes the cell edge infinite: everything falls
+  // into one cell and the search degrades to all pairs, still exact.
+  {
+    float fxmin = 3.0e38f, fxmax = -3.0e38f, fymin = 3.0e38f, fymax = -3.0e38f, frad = 0.f;
+    for (int m = lane, sidx = 0; m < N; m += 64, sidx++) {
+      if ((hole >> sidx) & 1u) continue;
+      const float fx = (float)sMX[m], fy = (float)sMY[m];
+      fxmin = fminf(fxmin, fx); fxmax = fmaxf(fxmax, fx);
+      fymin = fminf(fymin, fy); fymax = fmaxf(fymax, fy);
+      frad = fmaxf(frad, (float)sqrt(sBnd[m]));
+    }
+    fxmin = wave_min_f32(fxmin); fxmax = wave_max_f32(fxmax);
+    fymin = wave_min_f32(fymin); fymax = wave_max_f32(fymax);
+    frad = wave_max_f32(frad);
+    // float rounding of the box / radius is covered by the 1e-3 relative slack on the cell edge
+    const double x0 = (double)fxmin - 1e-3 * fabs((double)fxmin) - 1e-30, y0 = (double)fymin - 1e-3 * fabs((double)fymin) - 1e-30;
+    const double span = fmax((double)fxmax - x0, (double)fymax - y0);
+    double cell = fmax((double)frad, span / MERGE_GRID) * 1.001 + 1e-300;
+    const bool degenerate = !(cell < 1.0e300) || !(span == span);  // inf / NaN -> a single cell
+    const double invCell = degenerate ? 0.0 : 1.0 / cell;
+    for (int c = lane; c <= MERGE_GRID * MERGE_GRID; c += 64) sCellStart[c] = 0u;
+    wave_sync();
+    auto cell_of = [&](double x, double y, int &cx, int &cy) {
+      int ix = (int)((x - x0) * invCell), iy = (int)((y - y0) * invCell);
+      cx = ix < 0 ? 0 : (ix >= MERGE_GRID ? MERGE_GRID - 1 : ix);
+      cy = iy < 0 ? 0 : (iy >= MERGE_GRID ? MERGE_GRID - 1 : iy);
+      if (degenerate) { cx = 0; cy = 0; }
+    };
+    for (int m = lane, sidx = 0; m < N; m += 64, sidx++) {
+      if ((hole >> sidx) & 1u) continue;
+      int cx, cy;
+      cell_of(sMX[m], sMY[m], cx, cy);
+      atomicAdd(&sCellStart[cy * MERGE_GRID + cx + 1], 1u);  // counts, shifted by one for the exclusive scan
+    }
+    wave_sync();
+    {  // exclusive scan of 256 counts: 4 per lane + wave scan
+      unsigned c0 = sCellStart[4 * lane + 1], c1 = sCellStart[4 * lane + 2], c2 = sCellStart[4 * lane + 3], c3 = sCellStart[4 * lane + 4];
+      const int tot = (int)(c0 + c1 + c2 + c3);
+      const int off = wave_excl_scan(tot, lane);
+      wave_sync();
+      sCellStart[4 * lane + 1] = off + c0;
+      sCellStart[4 * lane + 2] = off + c0 + c1;
+      sCellStart[4 * lane + 3] = off + c0 + c1 + c2;
+      sCellStart[4 * lane + 4] = off + tot;
+      sCellCur[4 * lane + 0] = (lane == 0) ? 0u : (unsigned)off;  // cursor of cell c starts at start[c]
+      sCellCur[4 * lane + 1] = off + c0;
+      sCellCur[4 * lane + 2] = off + c0 + c1;
+      sCellCur[4 * lane + 3] = off + c0 + c1 + c2;
+    }
+    wave_sync();
+    for (int m = lane, sidx = 0; m < N; m += 64, sidx++) {
+      if ((hole >> sidx) & 1u) continue;
+      int cx, cy;
+      cell_of(sMX[m], sMY[m], cx, cy);
+      const unsigned pos = atomicAdd(&sCellCur[cy * MERGE_GRID + cx], 1u);
+      sSorted[pos] = (unsigned short)m;
+    }
+    wave_sync();
+    for (int m = lane, sidx = 0; m < N; m += 64, sidx++) {
+      if ((hole >> sidx) & 1u) continue;
+      const double ax = sMX[m], ay = sMY[m], ab = sBnd[m];
+      const double a00 = sI00[m], a01 = sI01[m], a11 = sI11[m], aw = sW[m];
+      int cx, cy;
+      cell_of(ax, ay, cx, cy);
+      const int cxa = cx > 0 ? cx - 1 : 0, cxb = cx < MERGE_GRID - 1 ? cx + 1 : MERGE_GRID - 1;
+      unsigned best = 0xffffu;
+      for (int ry = (cy > 0 ? cy - 1 : 0); ry <= (cy < MERGE_GRID - 1 ? cy + 1 : MERGE_GRID - 1); ry++) {
+        const unsigned qs = sCellStart[ry * MERGE_GRID + cxa], qe = sCellStart[ry * MERGE_GRID + cxb + 1];
+        for (unsigned q = qs; q < qe; q++) {
+          const unsigned j = sSorted[q];
+          if (j <= (unsigned)m || j >= best) continue;  // partners with a higher index only; keep the lowest passing one
+          const double e0 = sMX[j] - ax, e1 = sMY[j] - ay;
+          const double e2 = e0 * e0 + e1 * e1;
+          if (e2 > fmax(ab, sBnd[j])) continue;
           const double u0 = e0 * a00 + e1 * a01, u1 = e0 * a01 + e1 * a11;
-          const double d1 = u0 * e0 + u1 * e1;
-          bool far = d1 > t2;
+          bool far = (u0 * e0 + u1 * e1) > t2;
           if (far) {
+            const double j00 = sI00[j], j01 = sI01[j], j11 = sI11[j];
             const double g0 = -e0, g1 = -e1;
             const double v0 = g0 * j00 + g1 * j01, v1 = g0 * j01 + g1 * j11;
             far = (v0 * g0 + v1 * g1) > t2;
           }
-          pass = !far && ((aw + jw) != 0.0) && !(aw < 0.0);
+          if (!far && ((aw + sW[j]) != 0.0)) best = j;
         }
-        const unsigned long long pm = __ballot(pass);
-        if (pm != 0ull && sFirst[a] == 0xffffu) sFirst[a] = (unsigned short)(c0 + __builtin_ctzll(pm));  // uniform store
       }
+      sFirst[m] = (unsigned short)best;
     }
   }
   wave_sync();
@@ -198,28 +258,37 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   double *dl = B.slab[dst];
   const double t = P.pruneT;
-  int kept = 0;
-  for (int m = lane; m < N; m += 64) {
-    const double wm = sW[m];
-    if ((wm >= t) && (wm >= 0.0)) {
-      int rank = 0;
-      for (int j2 = 0; j2 < N; j2++) {
-        const double wj = sW[j2];
-        rank += (wj > wm || (wj == wm && j2 < m)) ? 1 : 0;
-      }
-      plane(dl, cap, i, PL_W)[rank] = wm;
-      plane(dl, cap, i, PL_WP)[rank] = 0.0;
-      plane(dl, cap, i, PL_MX)[rank] = pMX[m];
-      plane(dl, cap, i, PL_MY)[rank] = pMY[m];
-      plane(dl, cap, i, PL_SXX)[rank] = pSXX[m];
-      plane(dl, cap, i, PL_SXY)[rank] = pSXY[m];
-      plane(dl, cap, i, PL_SYY)[rank] = pSYY[m];
-      kept++;
-    }
+  // survivors are compacted into sSorted (ascending index) so that ranks only need the survivors' keys
+  int nSurv = 0;
+  for (int c0 = 0; c0 < N; c0 += 64) {
+    const int m = c0 + lane;
+    const double wm = (m < N) ? sW[m] : -1.0;
+    const bool keep = (wm >= t) && (wm >= 0.0);
+    const unsigned long long km = __ballot(keep);
+    if (keep) sSorted[nSurv + __popcll(km & ((1ull << lane) - 1ull))] = (unsigned short)m;
+    nSurv += __popcll(km);
   }
-  kept = wave_sum_i(kept);
-  if (lane == 0) B.count[i] = kept;
+  wave_sync();
+  for (int q = lane; q < nSurv; q += 64) {
+    const int m = sSorted[q];
+    const double wm = sW[m];
+    int rank = 0;
+    for (int q2 = 0; q2 < nSurv; q2++) {
+      const int j2 = sSorted[q2];
+      const double wj = sW[j2];
+      rank += (wj > wm || (wj == wm && j2 < m)) ? 1 : 0;
+    }
+    plane(dl, cap, i, PL_W)[rank] = wm;
+    plane(dl, cap, i, PL_WP)[rank] = 0.0;
+    plane(dl, cap, i, PL_MX)[rank] = pMX[m];
+    plane(dl, cap, i, PL_MY)[rank] = pMY[m];
+    plane(dl, cap, i, PL_SXX)[rank] = pSXX[m];
+    plane(dl, cap, i, PL_SXY)[rank] = pSXY[m];
+    plane(dl, cap, i, PL_SYY)[rank] = pSYY[m];
+  }
+  if (lane == 0) B.count[i] = nSurv;
   DBG_T(32, 4);
+  return;
 }
 
 // LDS per wave: keys[cap] doubles
