@@ -15,29 +15,52 @@
 #include "common.h"
 #include "weighting.h"  // wave_sync
 
-// LDS per wave: per entry x, y, w, i00, i01, i11, bound (7 doubles) + first-candidate index (u16) + grid-sorted
-// index (u16); plus the 16x16 spatial grid: cell start offsets and scatter cursors (u32 each).
+// LDS per wave: per entry x, y, w, bound (4 doubles) + first-candidate index (u16) + grid-sorted index (u16);
+// plus the 16x16 spatial grid: cell start offsets and scatter cursors (u32 each).  Covariances stay in HBM/L2 and
+// their inverses are formed on demand for the few pairs that survive the distance prefilter -- this keeps the
+// footprint at 36 B/entry so that 8+ waves fit a CU and 2000 particles run in a single round.
 #define MERGE_GRID 16
 __host__ __device__ inline size_t merge_lds_bytes_per_wave(int cap) {
-  return (((size_t)cap * (7 * 8 + 2 + 2)) + (size_t)(MERGE_GRID * MERGE_GRID + 1) * 4 * 2 + 15) & ~(size_t)15;
+  return (((size_t)cap * (4 * 8 + 2 + 2)) + (size_t)(MERGE_GRID * MERGE_GRID + 1) * 4 * 2 + 15) & ~(size_t)15;
 }
 
 // Necessary condition for a pair to pass the merge test: md2 = e^T S^-1 e >= |e|^2 / lambda_max(S) >= |e|^2 / tr(S),
 // so d1 <= t^2 or d2 <= t^2 implies |e|^2 <= t^2 * max(tr S_a, tr S_j).  The bound carries a 1e-6 relative
 // margin for rounding in the computed md2 / inverse; a non-PSD or non-finite covariance gets an infinite bound
 // (always fully tested), so the prefilter never changes a decision of the exact test.
-__device__ __forceinline__ double merge_bound(double t2, double xx, double yy, double det) {
+__device__ __forceinline__ double merge_bound(double t2, double xx, double xy, double yy) {
   const double tr = xx + yy;
+  const double det = xx * yy - xy * xy;
   const bool sane = (det > 0.0) && (tr > 0.0) && (tr < 1.7e308);
   return sane ? t2 * tr * (1.0 + 1e-6) : __builtin_huge_val();
 }
 
+// The exact pair test of GaussianMixture::merge (:434-447) for e = x_j - x_a:
+//   d1 = e^T S_a^-1 e ; if d1 > t2: d2 = e^T S_j^-1 e (same value for -e); fail if d2 > t2 ; fail if w_a + w_j == 0.
+// S_j is fetched from the slab only when d1 fails.
+__device__ __forceinline__ bool merge_pair_passes(double e0, double e1, double a00, double a01, double a11, double aw, double jw,
+                                                  const double *pSXX, const double *pSXY, const double *pSYY, int j, double t2) {
+  const double u0 = e0 * a00 + e1 * a01, u1 = e0 * a01 + e1 * a11;
+  bool far = (u0 * e0 + u1 * e1) > t2;
+  if (far) {
+    double j00, j01, j10, j11, det;
+    const double xy = pSXY[j];
+    inv2(pSXX[j], xy, xy, pSYY[j], j00, j01, j10, j11, det);
+    const double g0 = -e0, g1 = -e1;
+    const double v0 = g0 * j00 + g1 * j01, v1 = g0 * j01 + g1 * j11;
+    far = (v0 * g0 + v1 * g1) > t2;
+  }
+  return !far && ((aw + jw) != 0.0);
+}
+
 // gm_merge (+ optional fused gm_prune).
-// Phase 1 (parallel): every pair (a, j>a) is tested once against the INITIAL states -- which is exactly what the
+// Phase 1 (parallel): every pair (a, j>a) is examined once against the INITIAL states -- which is exactly what the
 //   reference's sequential scan sees the first time it meets a pair, because a Gaussian only changes while it is the
-//   outer index -- and the lowest passing j of each row is recorded (firstCand).  Lanes hold 64 consecutive j in
-//   registers, a is broadcast from LDS; a cheap distance prefilter rejects almost all pairs before the two
-//   Mahalanobis forms are evaluated.
+//   outer index -- and the lowest passing j of each row is recorded (firstCand).  Candidates come from a 16x16
+//   uniform grid over the mixture's bounding box whose cell edge is >= the largest prefilter radius, so every pair that
+//   can pass lies in adjacent cells; an entry only looks at partners with a HIGHER index, so each lane finds the
+//   lowest passing j of its own rows without atomics.  A non-finite bound makes the cell edge infinite: everything
+//   falls into one cell and the search degrades to all pairs, still exact.
 // Phase 2 (sequential, rare): rows with a candidate are replayed in order with the exact greedy rule: merge the
 //   lowest passing j, update a, re-test only j' > j against the new state (ballot + ctz), skip absorbed entries.
 // FUSE_PRUNE: survivors (w >= pruneT, not absorbed) are rank-sorted by (weight desc, index asc) and compacted into
@@ -51,10 +74,9 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
   if (i >= B.N) return;
   const int cap = B.cap;
   unsigned char *wbase = smem_raw + (size_t)wave * merge_lds_bytes_per_wave(cap);
-  double *sMX = reinterpret_cast<double *>(wbase), *sMY = sMX + cap, *sW = sMX + 2 * cap;
-  double *sI00 = sMX + 3 * cap, *sI01 = sMX + 4 * cap, *sI11 = sMX + 5 * cap, *sBnd = sMX + 6 * cap;
-  unsigned *sCellStart = reinterpret_cast<unsigned *>(sMX + 7 * cap);      // [GRID*GRID + 1]
-  unsigned *sCellCur = sCellStart + (MERGE_GRID * MERGE_GRID + 1);          // [GRID*GRID]
+  double *sMX = reinterpret_cast<double *>(wbase), *sMY = sMX + cap, *sW = sMX + 2 * cap, *sBnd = sMX + 3 * cap;
+  unsigned *sCellStart = reinterpret_cast<unsigned *>(sMX + 4 * cap);      // [GRID*GRID + 1]
+  unsigned *sCellCur = sCellStart + (MERGE_GRID * MERGE_GRID + 1);          // [GRID*GRID (+1 pad)]
   unsigned short *sFirst = reinterpret_cast<unsigned short *>(sCellCur + MERGE_GRID * MERGE_GRID + 1);
   unsigned short *sSorted = sFirst + cap;
 
@@ -67,110 +89,106 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
   DBG_T(32, 0);
   // ---- stage; hole flags live in per-lane registers: bit s of `hole` <=> entry s*64+lane is a hole ----
   unsigned hole = 0;
+  float fxmin = 3.0e38f, fxmax = -3.0e38f, fymin = 3.0e38f, fymax = -3.0e38f, frad = 0.f;
   for (int m = lane, sidx = 0; m < N; m += 64, sidx++) {
-    const double w = pW[m], mx = pMX[m], my = pMY[m], xx = pSXX[m], xy = pSXY[m], yy = pSYY[m];
-    double i00, i01, i10, i11, det;
-    inv2(xx, xy, xy, yy, i00, i01, i10, i11, det);
-    sMX[m] = mx; sMY[m] = my; sW[m] = w;
-    sI00[m] = i00; sI01[m] = i01; sI11[m] = i11;
-    sBnd[m] = merge_bound(t2, xx, yy, det);
+    const double w = pW[m], mx = pMX[m], my = pMY[m];
+    const double bnd = merge_bound(t2, pSXX[m], pSXY[m], pSYY[m]);
+    sMX[m] = mx; sMY[m] = my; sW[m] = w; sBnd[m] = bnd;
     sFirst[m] = 0xffffu;
-    if (w < 0) hole |= 1u << sidx;  // already absorbed (merge called twice)
+    if (w < 0) { hole |= 1u << sidx; continue; }  // already absorbed (merge called twice)
+    const float fx = (float)mx, fy = (float)my;
+    fxmin = fminf(fxmin, fx); fxmax = fmaxf(fxmax, fx);
+    fymin = fminf(fymin, fy); fymax = fmaxf(fymax, fy);
+    frad = fmaxf(frad, sqrtf((float)bnd) * 1.0001f);
   }
+  for (int c = lane; c <= MERGE_GRID * MERGE_GRID; c += 64) sCellStart[c] = 0u;
   wave_sync();
 
   DBG_T(32, 1);
-  // ---- phase 1: first passing partner of every row, against initial states ----
-  // Candidate search through a 16x16 uniform grid over the mixture's bounding box.  The cell edge is >= the largest
-  // prefilter radius (sqrt of the largest bound), so every pair that can pass the prefilter lies in adjacent cells;
-  // an entry only looks at partners with a HIGHER index (it plays `a`, they play `j`), so each lane finds the lowest
-  // passing j of its own rows without atomics.  A non-finite bound makes the cell edge infinite: everything falls
-  // into one cell and the search degrades to all pairs, still exact.
-  {
-    float fxmin = 3.0e38f, fxmax = -3.0e38f, fymin = 3.0e38f, fymax = -3.0e38f, frad = 0.f;
-    for (int m = lane, sidx = 0; m < N; m += 64, sidx++) {
-      if ((hole >> sidx) & 1u) continue;
-      const float fx = (float)sMX[m], fy = (float)sMY[m];
-      fxmin = fminf(fxmin, fx); fxmax = fmaxf(fxmax, fx);
-      fymin = fminf(fymin, fy); fymax = fmaxf(fymax, fy);
-      frad = fmaxf(frad, (float)sqrt(sBnd[m]));
-    }
-    fxmin = wave_min_f32(fxmin); fxmax = wave_max_f32(fxmax);
-    fymin = wave_min_f32(fymin); fymax = wave_max_f32(fymax);
-    frad = wave_max_f32(frad);
-    // float rounding of the box / radius is covered by the 1e-3 relative slack on the cell edge
-    const double x0 = (double)fxmin - 1e-3 * fabs((double)fxmin) - 1e-30, y0 = (double)fymin - 1e-3 * fabs((double)fymin) - 1e-30;
-    const double span = fmax((double)fxmax - x0, (double)fymax - y0);
-    double cell = fmax((double)frad, span / MERGE_GRID) * 1.001 + 1e-300;
-    const bool degenerate = !(cell < 1.0e300) || !(span == span);  // inf / NaN -> a single cell
-    const double invCell = degenerate ? 0.0 : 1.0 / cell;
-    for (int c = lane; c <= MERGE_GRID * MERGE_GRID; c += 64) sCellStart[c] = 0u;
+  // ---- phase 1: grid build ----
+  fxmin = wave_min_f32(fxmin); fxmax = wave_max_f32(fxmax);
+  fymin = wave_min_f32(fymin); fymax = wave_max_f32(fymax);
+  frad = wave_max_f32(frad);
+  // float rounding of the box / radius is covered by the 1e-3 relative slack on the cell edge; indices are clamped
+  // (clamping is monotone, so adjacency is preserved for out-of-box values)
+  const double x0 = (double)fxmin - 1e-3 * fabs((double)fxmin) - 1e-30, y0 = (double)fymin - 1e-3 * fabs((double)fymin) - 1e-30;
+  const double span = fmax((double)fxmax - x0, (double)fymax - y0);
+  const double cell = fmax((double)frad, span / MERGE_GRID) * 1.001 + 1e-300;
+  const bool degenerate = !(cell < 1.0e300) || !(span == span);  // inf / NaN -> a single cell
+  const double invCell = degenerate ? 0.0 : 1.0 / cell;
+  auto cell_of = [&](double x, double y, int &cx, int &cy) {
+    int ix = (int)((x - x0) * invCell), iy = (int)((y - y0) * invCell);
+    cx = ix < 0 ? 0 : (ix >= MERGE_GRID ? MERGE_GRID - 1 : ix);
+    cy = iy < 0 ? 0 : (iy >= MERGE_GRID ? MERGE_GRID - 1 : iy);
+    if (degenerate) { cx = 0; cy = 0; }
+  };
+  for (int m = lane, sidx = 0; m < N; m += 64, sidx++) {
+    if ((hole >> sidx) & 1u) continue;
+    int cx, cy;
+    cell_of(sMX[m], sMY[m], cx, cy);
+    atomicAdd(&sCellStart[cy * MERGE_GRID + cx + 1], 1u);  // counts, shifted by one for the exclusive scan
+  }
+  wave_sync();
+  {  // exclusive scan of 256 counts: 4 per lane + wave scan
+    const unsigned c0 = sCellStart[4 * lane + 1], c1 = sCellStart[4 * lane + 2], c2 = sCellStart[4 * lane + 3], c3 = sCellStart[4 * lane + 4];
+    const int tot = (int)(c0 + c1 + c2 + c3);
+    const int off = wave_excl_scan(tot, lane);
     wave_sync();
-    auto cell_of = [&](double x, double y, int &cx, int &cy) {
-      int ix = (int)((x - x0) * invCell), iy = (int)((y - y0) * invCell);
-      cx = ix < 0 ? 0 : (ix >= MERGE_GRID ? MERGE_GRID - 1 : ix);
-      cy = iy < 0 ? 0 : (iy >= MERGE_GRID ? MERGE_GRID - 1 : iy);
-      if (degenerate) { cx = 0; cy = 0; }
-    };
-    for (int m = lane, sidx = 0; m < N; m += 64, sidx++) {
-      if ((hole >> sidx) & 1u) continue;
-      int cx, cy;
-      cell_of(sMX[m], sMY[m], cx, cy);
-      atomicAdd(&sCellStart[cy * MERGE_GRID + cx + 1], 1u);  // counts, shifted by one for the exclusive scan
-    }
-    wave_sync();
-    {  // exclusive scan of 256 counts: 4 per lane + wave scan
-      unsigned c0 = sCellStart[4 * lane + 1], c1 = sCellStart[4 * lane + 2], c2 = sCellStart[4 * lane + 3], c3 = sCellStart[4 * lane + 4];
-      const int tot = (int)(c0 + c1 + c2 + c3);
-      const int off = wave_excl_scan(tot, lane);
-      wave_sync();
-      sCellStart[4 * lane + 1] = off + c0;
-      sCellStart[4 * lane + 2] = off + c0 + c1;
-      sCellStart[4 * lane + 3] = off + c0 + c1 + c2;
-      sCellStart[4 * lane + 4] = off + tot;
-      sCellCur[4 * lane + 0] = (lane == 0) ? 0u : (unsigned)off;  // cursor of cell c starts at start[c]
-      sCellCur[4 * lane + 1] = off + c0;
-      sCellCur[4 * lane + 2] = off + c0 + c1;
-      sCellCur[4 * lane + 3] = off + c0 + c1 + c2;
-    }
-    wave_sync();
-    for (int m = lane, sidx = 0; m < N; m += 64, sidx++) {
-      if ((hole >> sidx) & 1u) continue;
-      int cx, cy;
-      cell_of(sMX[m], sMY[m], cx, cy);
-      const unsigned pos = atomicAdd(&sCellCur[cy * MERGE_GRID + cx], 1u);
-      sSorted[pos] = (unsigned short)m;
-    }
-    wave_sync();
-    for (int m = lane, sidx = 0; m < N; m += 64, sidx++) {
-      if ((hole >> sidx) & 1u) continue;
-      const double ax = sMX[m], ay = sMY[m], ab = sBnd[m];
-      const double a00 = sI00[m], a01 = sI01[m], a11 = sI11[m], aw = sW[m];
-      int cx, cy;
-      cell_of(ax, ay, cx, cy);
-      const int cxa = cx > 0 ? cx - 1 : 0, cxb = cx < MERGE_GRID - 1 ? cx + 1 : MERGE_GRID - 1;
-      unsigned best = 0xffffu;
-      for (int ry = (cy > 0 ? cy - 1 : 0); ry <= (cy < MERGE_GRID - 1 ? cy + 1 : MERGE_GRID - 1); ry++) {
-        const unsigned qs = sCellStart[ry * MERGE_GRID + cxa], qe = sCellStart[ry * MERGE_GRID + cxb + 1];
-        for (unsigned q = qs; q < qe; q++) {
-          const unsigned j = sSorted[q];
-          if (j <= (unsigned)m || j >= best) continue;  // partners with a higher index only; keep the lowest passing one
-          const double e0 = sMX[j] - ax, e1 = sMY[j] - ay;
-          const double e2 = e0 * e0 + e1 * e1;
-          if (e2 > fmax(ab, sBnd[j])) continue;
-          const double u0 = e0 * a00 + e1 * a01, u1 = e0 * a01 + e1 * a11;
-          bool far = (u0 * e0 + u1 * e1) > t2;
-          if (far) {
-            const double j00 = sI00[j], j01 = sI01[j], j11 = sI11[j];
-            const double g0 = -e0, g1 = -e1;
-            const double v0 = g0 * j00 + g1 * j01, v1 = g0 * j01 + g1 * j11;
-            far = (v0 * g0 + v1 * g1) > t2;
+    sCellStart[4 * lane + 1] = off + c0;
+    sCellStart[4 * lane + 2] = off + c0 + c1;
+    sCellStart[4 * lane + 3] = off + c0 + c1 + c2;
+    sCellStart[4 * lane + 4] = off + tot;
+    sCellCur[4 * lane + 0] = (unsigned)off;  // cursor of cell c starts at start[c]
+    sCellCur[4 * lane + 1] = off + c0;
+    sCellCur[4 * lane + 2] = off + c0 + c1;
+    sCellCur[4 * lane + 3] = off + c0 + c1 + c2;
+  }
+  wave_sync();
+  for (int m = lane, sidx = 0; m < N; m += 64, sidx++) {
+    if ((hole >> sidx) & 1u) continue;
+    int cx, cy;
+    cell_of(sMX[m], sMY[m], cx, cy);
+    const unsigned pos = atomicAdd(&sCellCur[cy * MERGE_GRID + cx], 1u);
+    sSorted[pos] = (unsigned short)m;
+  }
+  wave_sync();
+  // ---- phase 1: per-row lowest passing partner (initial states) ----
+  for (int m = lane, sidx = 0; m < N; m += 64, sidx++) {
+    if ((hole >> sidx) & 1u) continue;
+    const double ax = sMX[m], ay = sMY[m], ab = sBnd[m], aw = sW[m];
+    double a00 = 0, a01 = 0, a11 = 0;
+    bool haveInv = false;
+    int cx, cy;
+    cell_of(ax, ay, cx, cy);
+    const int cxa = cx > 0 ? cx - 1 : 0, cxb = cx < MERGE_GRID - 1 ? cx + 1 : MERGE_GRID - 1;
+    unsigned best = 0xffffu;
+    for (int ry = (cy > 0 ? cy - 1 : 0); ry <= (cy < MERGE_GRID - 1 ? cy + 1 : MERGE_GRID - 1); ry++) {
+      const unsigned qs = sCellStart[ry * MERGE_GRID + cxa], qe = sCellStart[ry * MERGE_GRID + cxb + 1];
+      for (unsigned q = qs; q < qe; q += 4) {
+        // four candidates per trip: the index loads, then the position/bound loads, are independent LDS reads
+        unsigned jj[4];
+        double jx[4], jy[4], jb[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) jj[k] = sSorted[(q + k < qe) ? q + k : qe - 1];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { jx[k] = sMX[jj[k]]; jy[k] = sMY[jj[k]]; jb[k] = sBnd[jj[k]]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const unsigned j = jj[k];
+          if (q + k >= qe || j <= (unsigned)m || j >= best) continue;  // higher index only; keep the lowest passing one
+          const double e0 = jx[k] - ax, e1 = jy[k] - ay;
+          if ((e0 * e0 + e1 * e1) > fmax(ab, jb[k])) continue;
+          if (!haveInv) {
+            double i10, det;
+            const double xy = pSXY[m];
+            inv2(pSXX[m], xy, xy, pSYY[m], a00, a01, i10, a11, det);
+            haveInv = true;
           }
-          if (!far && ((aw + sW[j]) != 0.0)) best = j;
+          if (merge_pair_passes(e0, e1, a00, a01, a11, aw, sW[j], pSXX, pSXY, pSYY, (int)j, t2)) best = j;
         }
       }
-      sFirst[m] = (unsigned short)best;
     }
+    sFirst[m] = (unsigned short)best;
   }
   wave_sync();
 
@@ -186,36 +204,29 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
       const unsigned ownerHole = (unsigned)__builtin_amdgcn_readlane((int)hole, a & 63);
       if ((ownerHole >> (a >> 6)) & 1u) continue;  // a was absorbed by an earlier row
       const int j0 = sFirst[a];
-      double ax = sMX[a], ay = sMY[a], aw = sW[a], a00 = sI00[a], a01 = sI01[a], a11 = sI11[a];
+      double ax = sMX[a], ay = sMY[a], aw = sW[a], ab = sBnd[a];
       double axx = pSXX[a], axy = pSXY[a], ayy = pSYY[a];
+      double a00, a01, a10, a11, adet;
+      inv2(axx, axy, axy, ayy, a00, a01, a10, a11, adet);
       bool changed = false;
       int floorLane = j0 & 63;  // every j < j0 is known to fail against a's initial state
       for (int c0 = j0 & ~63; c0 < N; c0 += 64) {
         const int j = c0 + lane;
         const int slot = c0 >> 6;
         bool live = (j > a) && (j < N) && !((hole >> slot) & 1u);
-        double jx = 0, jy = 0, jw = 0, j00 = 0, j01 = 0, j11 = 0;
-        if (live) { jx = sMX[j]; jy = sMY[j]; jw = sW[j]; j00 = sI00[j]; j01 = sI01[j]; j11 = sI11[j]; }
+        double jx = 0, jy = 0, jw = 0, jb = 0;
+        if (live) { jx = sMX[j]; jy = sMY[j]; jw = sW[j]; jb = sBnd[j]; }
         while (true) {
           bool pass = false;
           if (live && lane >= floorLane) {
-            // d1 = md2 of x_j under (x_a, S_a); d2 = md2 of x_a under (x_j, S_j)   (GaussianMixture.hpp:434-442)
             const double e0 = jx - ax, e1 = jy - ay;
-            const double u0 = e0 * a00 + e1 * a01, u1 = e0 * a01 + e1 * a11;
-            const double d1 = u0 * e0 + u1 * e1;
-            bool far = d1 > t2;
-            if (far) {
-              const double g0 = -e0, g1 = -e1;
-              const double v0 = g0 * j00 + g1 * j01, v1 = g0 * j01 + g1 * j11;
-              far = (v0 * g0 + v1 * g1) > t2;
-            }
-            pass = !far && ((aw + jw) != 0.0);
+            if (!((e0 * e0 + e1 * e1) > fmax(ab, jb))) pass = merge_pair_passes(e0, e1, a00, a01, a11, aw, jw, pSXX, pSXY, pSYY, j, t2);
           }
           const unsigned long long pm = __ballot(pass);
           if (pm == 0ull) break;
           const int l = __builtin_ctzll(pm);
           const int jj = c0 + l;
-          // merge jj into a (:444-471), wave-uniform arithmetic
+          // merge jj into a (GaussianMixture.hpp:444-471), wave-uniform arithmetic
           const double w1 = aw, w2 = sW[jj];
           const double x2 = sMX[jj], y2 = sMY[jj], bxx = pSXX[jj], bxy = pSXY[jj], byy = pSYY[jj];
           const double wm = w1 + w2;
@@ -225,8 +236,8 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
           const double nxy = (w1 * (axy + (f * d10) * d11) + w2 * (bxy + (f * d20) * d21)) / wm;
           const double nyy = (w1 * (ayy + (f * d11) * d11) + w2 * (byy + (f * d21) * d21)) / wm;
           ax = xm; ay = ym; axx = nxx; axy = nxy; ayy = nyy; aw = wm;
-          double i10, det;
-          inv2(axx, axy, axy, ayy, a00, a01, i10, a11, det);
+          inv2(axx, axy, axy, ayy, a00, a01, a10, a11, adet);
+          ab = merge_bound(t2, axx, axy, ayy);
           changed = true;
           if (lane == l) { hole |= 1u << slot; live = false; }
           floorLane = l + 1;
@@ -288,7 +299,6 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
   }
   if (lane == 0) B.count[i] = nSurv;
   DBG_T(32, 4);
-  return;
 }
 
 // LDS per wave: keys[cap] doubles

@@ -186,14 +186,29 @@ __global__ __launch_bounds__(WPB * 64) void phd_weight_multifeature_kernel(Buffe
   // ---- 1. sort by weight: rank = #{ j : w_j > w_m  or (w_j == w_m and j < m) } ----
   for (int m = lane; m < N; m += 64) s.keys[m] = qW[m];
   wave_sync();
-  for (int m = lane; m < N; m += 64) {
-    const double wm = s.keys[m];
-    int rank = 0;
+  // each lane ranks up to 8 of its entries in ONE pass over the keys (one broadcast LDS read feeds 8 counters)
+  for (int g0 = 0; g0 < N; g0 += 512) {
+    double wm[8];
+    int cnt[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int m = g0 + 64 * k + lane;
+      wm[k] = (m < N) ? s.keys[m] : 0.0;
+      cnt[k] = 0;
+    }
     for (int j = 0; j < N; j++) {
       const double wj = s.keys[j];
-      rank += (wj > wm || (wj == wm && j < m)) ? 1 : 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int m = g0 + 64 * k + lane;
+        cnt[k] += (wj > wm[k] || (wj == wm[k] && j < m)) ? 1 : 0;
+      }
     }
-    s.perm[rank] = m;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int m = g0 + 64 * k + lane;
+      if (m < N) s.perm[cnt[k]] = m;
+    }
   }
   wave_sync();
   // sorted mixture -> other slab
@@ -260,8 +275,8 @@ __global__ __launch_bounds__(WPB * 64) void phd_weight_multifeature_kernel(Buffe
   // ---- 3. weight sums (:765-775) and intensity products at the evaluation points (:776-800) ----
   double sumPrev = 0.0, sumCur = 0.0;
   for (int m = lane; m < N; m += 64) { sumPrev += qWP[m]; sumCur += s.keys[m]; }
-  sumPrev = wave_sum(sumPrev);
-  sumCur = wave_sum(sumCur);
+  sumPrev = wave_sum_dpp(sumPrev);
+  sumCur = wave_sum_dpp(sumCur);
 
   double prodBefore = 1.0, prodAfter = 1.0;
   for (int e0 = 0; e0 < nE; e0 += 8) {
@@ -290,8 +305,8 @@ __global__ __launch_bounds__(WPB * 64) void phd_weight_multifeature_kernel(Buffe
 #pragma unroll
     for (int t = 0; t < 8; t++) {
       if (e0 + t < nE) {
-        prodBefore *= (RFS_DENORM_MIN + wave_sum(accB[t]));
-        prodAfter *= (RFS_DENORM_MIN + wave_sum(accA[t]));
+        prodBefore *= (RFS_DENORM_MIN + wave_sum_dpp(accB[t]));
+        prodAfter *= (RFS_DENORM_MIN + wave_sum_dpp(accA[t]));
       }
     }
   }
