@@ -68,6 +68,13 @@ __device__ __forceinline__ double *plane(double *slab, int cap, int particle, in
 }
 
 // ---- wave64 helpers -------------------------------------------------------------------------------
+// Ordering point for LDS traffic between lanes of ONE wave (wave-synchronous code): formally a wavefront-scope
+// release/acquire pair around a wave barrier; costs no hardware barrier.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 __device__ __forceinline__ double readlane_f64(double v, int srcLane) {
@@ -179,9 +186,13 @@ __device__ __forceinline__ double rb_pd(const Params &P, double range, bool &clo
   return pd;
 }
 
+// while(a > PI) a -= 2PI; while(a < -PI) a += 2PI;  -- the reference's wrap (src/KalmanFilter_RngBrg.cpp:58-61).
+// First iteration branch-free (the common case: both bearings lie in [-pi, pi]); further iterations only if needed.
 __device__ __forceinline__ double wrap_pi(double a) {
-  while (a > RFS_PI) a -= 2 * RFS_PI;
-  while (a < -RFS_PI) a += 2 * RFS_PI;
+  a = (a > RFS_PI) ? a - 2 * RFS_PI : a;
+  if (a > RFS_PI) { do { a -= 2 * RFS_PI; } while (a > RFS_PI); }
+  a = (a < -RFS_PI) ? a + 2 * RFS_PI : a;
+  if (a < -RFS_PI) { do { a += 2 * RFS_PI; } while (a < -RFS_PI); }
   return a;
 }
 

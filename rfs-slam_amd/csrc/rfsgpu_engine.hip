@@ -436,14 +436,14 @@ static int set_lds_impl(rfsgpu_filter *f, const void *kernel, size_t bytes) {
 
 static int launch_update_map(rfsgpu_filter *f) {
   const int nZ = f->nZ;
-  auto bytes = [&](int wpb) { return (size_t)(2 * RFSGPU_MAX_Z * 8) + (size_t)wpb * (RFSGPU_MAX_Z * 8 + (size_t)f->cap * 8); };
+  auto bytes = [&](int wpb) { return (size_t)(2 * RFSGPU_MAX_Z * 8) + (size_t)wpb * update_map_lds_bytes_per_wave(f->cap); };
   int rc;
   if (bytes(4) <= 64 * 1024) {
     if ((rc = set_lds(f, phd_update_map_kernel<4>, bytes(4))) != RFSGPU_OK) return rc;
-    phd_update_map_kernel<4><<<(f->N + 3) / 4, 256, bytes(4), f->stream>>>(f->B, f->P, f->cur, nZ);
+    phd_update_map_kernel<4><<<(f->N + 3) / 4, 256, bytes(4), f->stream>>>(f->B, f->P, f->cur, nZ, f->B.Z);
   } else {
     if ((rc = set_lds(f, phd_update_map_kernel<1>, bytes(1))) != RFSGPU_OK) return rc;
-    phd_update_map_kernel<1><<<f->N, 64, bytes(1), f->stream>>>(f->B, f->P, f->cur, nZ);
+    phd_update_map_kernel<1><<<f->N, 64, bytes(1), f->stream>>>(f->B, f->P, f->cur, nZ, f->B.Z);
   }
   HIPCHK(hipGetLastError());
   return RFSGPU_OK;

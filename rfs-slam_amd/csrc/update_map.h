@@ -73,23 +73,59 @@ __device__ __forceinline__ double pair_weight(const Params &P, const LmKF &k, do
   return pdw * lik;
 }
 
-template <int WPB>
-__global__ __launch_bounds__(WPB * 64) void phd_update_map_kernel(Buffers B, Params P, int cur, int nZ) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  // LDS: Z[2*nZ] | per wave: colsum[64] | per wave: assoc[cap]
-  double *sZ = reinterpret_cast<double *>(smem_raw);
-  double *sCol = sZ + 2 * RFSGPU_MAX_Z;
-  unsigned long long *sAssoc = reinterpret_cast<unsigned long long *>(sCol + WPB * RFSGPU_MAX_Z);
+// LDS per wave: survivor list (value, packed (m,z)) + per-landmark segment (start, count) + final normalisers.
+__host__ __device__ inline size_t update_map_lds_bytes_per_wave(int cap) {
+  return (size_t)cap * (8 + 4 + 4) + RFSGPU_MAX_Z * 8;
+}
 
+// Gates of KalmanFilter_RngBrg::calculateInnovation only (cheap part of pair_weight).
+__device__ __forceinline__ bool pair_gate(const Params &P, const LmKF &k, double z0, double z1) {
+  const double e0 = z0 - k.zx0;
+  if (P.kfRange > 0 && fabs(e0) > P.kfRange) return false;
+  const double w1 = wrap_pi(z1 - k.zx1);
+  if (P.kfBearing > 0 && fabs(w1) > P.kfBearing) return false;
+  return true;
+}
+// Likelihood part for a pair that passed the innovation gates: Pd*w*lik or 0 (KalmanFilter.hpp:317-326, RBPHDFilter.hpp:622-632).
+__device__ __forceinline__ double pair_value(const Params &P, const LmKF &k, double pdw, double z0, double z1) {
+  const double e0 = z0 - k.zx0, e1 = z1 - k.zx1;  // UNWRAPPED difference
+  const double t0 = e0 * k.i00 + e1 * k.i10;
+  const double t1 = e0 * k.i01 + e1 * k.i11;
+  const double md2 = t0 * e0 + t1 * e1;
+  if (md2 > P.newGaussMd2) return 0.0;
+  const double lik = gauss_from_md2(md2, k.factor);
+  if (lik == 0.0) return 0.0;
+  return pdw * lik;
+}
+
+// Structure (one wavefront per particle):
+//  phase 1, per pass of 64 landmarks: KF quantities once per landmark; a cheap sweep over the measurements builds each
+//    landmark's innovation-gate bitmask; only the set bits (a few per landmark) go through the Mahalanobis gate and the
+//    Gaussian; survivors are written into a dense (m,z)-row-major list in LDS through a wave prefix sum -- list position
+//    == output slot of the new Gaussian; lane z then folds this pass's survivors of measurement z into its normaliser
+//    in landmark order, i.e. in the reference's summation order (clutter first, then m ascending).
+//  phase 2, dense over the survivor list (all 64 lanes busy): normalise, recompute the landmark's KF quantities, emit.
+//  phase 3: missed-detection weights (+ near-limit heuristic from the landmark's list segment), unused mask.
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64) void phd_update_map_kernel(Buffers B, Params P, int cur, int nZ, const double *__restrict__ Zg) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  // The measurement set is wave-uniform and read-only: it is read through the scalar cache (s_load into SGPRs, which
+  // VALU instructions take as operands directly) where the index is uniform, and from an LDS copy where lanes index
+  // it independently (phases 1b/2).
+  double *sZ = reinterpret_cast<double *>(smem_raw);  // [2*MAX_Z], block-shared
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
-  for (int t = threadIdx.x; t < 2 * nZ; t += WPB * 64) sZ[t] = B.Z[t];
+  for (int t = threadIdx.x; t < 2 * nZ; t += WPB * 64) sZ[t] = Zg[t];
   __syncthreads();
 
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
   if (i >= B.N) return;
-  double *colsum = sCol + wave * RFSGPU_MAX_Z;
-  unsigned long long *assoc = sAssoc + (size_t)wave * B.cap;
+  const int cap = B.cap;
+  unsigned char *wb = smem_raw + 2 * RFSGPU_MAX_Z * 8 + (size_t)wave * update_map_lds_bytes_per_wave(cap);
+  double *sV = reinterpret_cast<double *>(wb);                 // [cap] survivor values Pd*w*lik
+  double *sCol = sV + cap;                                      // [MAX_Z] final normalisers
+  unsigned *sMZ = reinterpret_cast<unsigned *>(sCol + RFSGPU_MAX_Z);  // [cap] (m << 8) | z
+  unsigned *sSeg = sMZ + cap;                                   // [cap] per landmark: (start << 8) | count
 
   const int nM = B.count[i];
   const unsigned long long zmask = (nZ >= 64) ? ~0ull : ((1ull << nZ) - 1ull);
@@ -101,19 +137,23 @@ __global__ __launch_bounds__(WPB * 64) void phd_update_map_kernel(Buffers B, Par
     return;
   }
   double *slab = B.slab[cur];
-  double *pW = plane(slab, B.cap, i, PL_W), *pWP = plane(slab, B.cap, i, PL_WP);
-  double *pMX = plane(slab, B.cap, i, PL_MX), *pMY = plane(slab, B.cap, i, PL_MY);
-  double *pSXX = plane(slab, B.cap, i, PL_SXX), *pSXY = plane(slab, B.cap, i, PL_SXY), *pSYY = plane(slab, B.cap, i, PL_SYY);
+  double *pW = plane(slab, cap, i, PL_W), *pWP = plane(slab, cap, i, PL_WP);
+  double *pMX = plane(slab, cap, i, PL_MX), *pMY = plane(slab, cap, i, PL_MY);
+  double *pSXX = plane(slab, cap, i, PL_SXX), *pSXY = plane(slab, cap, i, PL_SXY), *pSYY = plane(slab, cap, i, PL_SYY);
 
   DBG_T(0, 0);
   PoseReg pr;
   load_pose(B, P, i, pr);
 
   const int nPass = (nM + 63) >> 6;
+  const int room = cap - nM;  // survivors that still fit as new Gaussians
   int nFov = 0;
-  double wsum = 0.0;  // SC-PHD: sum of prior weights
+  double wsum = 0.0;           // SC-PHD: sum of prior weights
+  double cs = P.clutter;       // lane z: normaliser of measurement z (reference: sum = clutter; sum += W[m][z] ...)
+  int nSurv = 0;
+  bool overflow = false;
 
-  // ---------------- pass 1: gates, association masks, per-measurement normalisers ----------------
+  // ---------------- phase 1 ----------------
   for (int p = 0; p < nPass; p++) {
     const int m = p * 64 + lane;
     const bool act = m < nM;
@@ -129,108 +169,165 @@ __global__ __launch_bounds__(WPB * 64) void phd_update_map_kernel(Buffers B, Par
     const double pdw = pd * w;
     nFov += __popcll(__ballot(fov));
     if (P.useCluster) wsum += act ? w : 0.0;
-    unsigned long long mymask = 0;
-    for (int z = 0; z < nZ; z++) {
-      double nu0, nu1;
-      double v = fov ? pair_weight(P, k, pdw, sZ[2 * z], sZ[2 * z + 1], nu0, nu1) : 0.0;
-      unsigned long long hit = __ballot(v != 0.0);
-      if (v != 0.0) mymask |= (1ull << z);
-      double cs = (p == 0) ? P.clutter : colsum[z];
-      while (hit) {  // reference order: sum = clutter; for m: sum += W[m][z]
-        int l = __builtin_ctzll(hit);
-        hit &= hit - 1;
-        cs += readlane_f64(v, l);
+    if (p == 0) DBG_T(0, 4);
+    // innovation gates for every measurement (cheap), as a bitmask
+    unsigned long long gate = 0;
+    {
+      // Eight measurements per trip: their 16 doubles are fetched with wide scalar loads up front (uniform
+      // addresses), the gate arithmetic is branch-free; the rare bearing difference beyond one wrap is redone exactly.
+      const bool live = fov && k.ok;
+      const bool useR = P.kfRange > 0, useB = P.kfBearing > 0;
+      for (int z0 = 0; z0 < nZ; z0 += 8) {
+        double zr[8], zb[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int zz = (z0 + u < nZ) ? z0 + u : nZ - 1;
+          zr[u] = Zg[2 * zz];
+          zb[u] = Zg[2 * zz + 1];
+        }
+        bool redo = false;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const double e0 = zr[u] - k.zx0;
+          double w1 = zb[u] - k.zx1;
+          w1 = (w1 > RFS_PI) ? w1 - 2 * RFS_PI : w1;
+          w1 = (w1 < -RFS_PI) ? w1 + 2 * RFS_PI : w1;
+          // bitwise (non-short-circuit) logic on purpose: no branches, the 8 chains interleave
+          redo = redo | (w1 > RFS_PI) | (w1 < -RFS_PI);
+          const bool g = !(useR & (fabs(e0) > P.kfRange)) & !(useB & (fabs(w1) > P.kfBearing));
+          gate |= (live & g & (z0 + u < nZ)) ? (1ull << (z0 + u)) : 0ull;
+        }
+        if (__ballot(redo) != 0ull) {  // some bearing difference needs more than one wrap step: exact loop form
+          for (int u = 0; u < 8 && z0 + u < nZ; u++) {
+            const bool g = pair_gate(P, k, zr[u], zb[u]);
+            const unsigned long long bit = 1ull << (z0 + u);
+            gate = (live && g) ? (gate | bit) : (gate & ~bit);
+          }
+        }
       }
-      colsum[z] = cs;  // every lane stores the same value: plain per-thread store->load ordering, no cross-lane hazard
     }
-    if (act) assoc[m] = mymask;
-  }
-  __builtin_amdgcn_wave_barrier();
-  DBG_T(0, 1);
-
-  // ---------------- pass 2: normalise, append new Gaussians, missed-detection weights ----------------
-  int base = nM;
-  unsigned long long used = 0;
-  bool overflow = false;
-  for (int p = 0; p < nPass; p++) {
-    const int m = p * 64 + lane;
-    const bool act = m < nM;
-    double w = 0, mx = 0, my = 0, sxx = 1, sxy = 0, syy = 1;
-    if (act) { w = pW[m]; mx = pMX[m]; my = pMY[m]; sxx = pSXX[m]; sxy = pSXY[m]; syy = pSYY[m]; }
-    LmKF k;
-    double range;
-    lm_precompute(P, pr, mx, my, sxx, sxy, syy, k, range);
-    bool close;
-    double pd = rb_pd(P, range, close);
-    if (close) pd = 1;
-    const double pdw = pd * w;
-    unsigned long long mymask = act ? assoc[m] : 0ull;
-    // loop A: count survivors (normalised weight > 0), row sum, used flags
-    int cnt = 0;
-    double rowsum = 0.0;
-    for (unsigned long long mm = mymask; mm; mm &= mm - 1) {
-      int z = __builtin_ctzll(mm);
-      double nu0, nu1;
-      double v = pair_weight(P, k, pdw, sZ[2 * z], sZ[2 * z + 1], nu0, nu1);
-      double wn = v / colsum[z];
-      rowsum += wn;
-      if (wn != 0.0) used |= (1ull << z);
-      if (wn > 0.0) cnt++;
+    if (p == 0) DBG_T(0, 5);
+    // Mahalanobis gate + likelihood only for the set bits
+    unsigned long long surv = 0;
+    for (unsigned long long g = gate; g; g &= g - 1) {
+      const int z = __builtin_ctzll(g);
+      if (pair_value(P, k, pdw, sZ[2 * z], sZ[2 * z + 1]) != 0.0) surv |= (1ull << z);
     }
+    if (p == 0) DBG_T(0, 6);
+    const int cnt = __popcll(surv);
     const int off = wave_excl_scan(cnt, lane);
-    const int total = __shfl(off + cnt, 63, 64);
-    // loop B: emit in (m, z) row-major order
-    int pos = base + off;
-    for (unsigned long long mm = mymask; mm; mm &= mm - 1) {
-      int z = __builtin_ctzll(mm);
-      double nu0 = 0, nu1 = 0;
-      double v = pair_weight(P, k, pdw, sZ[2 * z], sZ[2 * z + 1], nu0, nu1);
-      double wn = v / colsum[z];
-      if (wn > 0.0) {
-        if (pos < B.cap) {
-          pW[pos] = wn;
-          pWP[pos] = 0.0;  // addGaussian: weight_prev = 0 (GaussianMixture.hpp:267-284)
-          pMX[pos] = mx + (k.k00 * nu0 + k.k01 * nu1);
-          pMY[pos] = my + (k.k10 * nu0 + k.k11 * nu1);
-          pSXX[pos] = k.p00;
-          pSXY[pos] = k.p01;
-          pSYY[pos] = k.p11;
+    const int total = __builtin_amdgcn_readlane(off + cnt, 63);
+    if (act) sSeg[m] = ((unsigned)(nSurv + off) << 8) | (unsigned)cnt;
+    {
+      int pos = nSurv + off;
+      for (unsigned long long g = surv; g; g &= g - 1) {
+        const int z = __builtin_ctzll(g);
+        if (pos < room) {
+          sV[pos] = pair_value(P, k, pdw, sZ[2 * z], sZ[2 * z + 1]);
+          sMZ[pos] = ((unsigned)m << 8) | (unsigned)z;
         } else {
           overflow = true;
         }
         pos++;
       }
     }
-    base += total;
-    // missed detection (:686-706); setWeight keeps the old weight in w_prev
-    if (act) {
-      double w_k = (1 - pd) * w;
-      if (close && w > P.birthW) {
-        double delta_w = pd * w - rowsum;
-        if (delta_w > 0) {
-          w_k += delta_w;
-          if (w_k > 1) w_k = 1;
-        }
+    wave_sync();
+    if (p == 0) DBG_T(0, 7);
+    // lane z folds this pass's survivors of measurement z into its normaliser, in landmark order
+    {
+      const int lo = nSurv, hi = (nSurv + total < room) ? nSurv + total : room;
+      int sIdx = lo;
+      for (; sIdx + 4 <= hi; sIdx += 4) {  // broadcast reads, four in flight; the adds stay in list (= landmark) order
+        const unsigned mz0 = sMZ[sIdx], mz1 = sMZ[sIdx + 1], mz2 = sMZ[sIdx + 2], mz3 = sMZ[sIdx + 3];
+        const double v0 = sV[sIdx], v1 = sV[sIdx + 1], v2 = sV[sIdx + 2], v3 = sV[sIdx + 3];
+        if ((int)(mz0 & 0xffu) == lane) cs += v0;
+        if ((int)(mz1 & 0xffu) == lane) cs += v1;
+        if ((int)(mz2 & 0xffu) == lane) cs += v2;
+        if ((int)(mz3 & 0xffu) == lane) cs += v3;
       }
-      pWP[m] = w;
-      pW[m] = w_k;
+      for (; sIdx < hi; sIdx++) {
+        const unsigned mz = sMZ[sIdx];
+        const double v = sV[sIdx];
+        if ((int)(mz & 0xffu) == lane) cs += v;
+      }
     }
+    nSurv += total;
+    if (p == 0) DBG_T(0, 8);
+  }
+  DBG_T(0, 1);
+  if (__ballot(overflow) != 0ull || nSurv > room) {
+    if (lane == 0) atomicOr(B.err, ERRBIT_CAPACITY);
+    nSurv = room < 0 ? 0 : (nSurv > room ? room : nSurv);
+  }
+  sCol[lane] = cs;
+  wave_sync();
+
+  // ---------------- phase 2: dense over survivors ----------------
+  int outBase = nM;
+  unsigned long long used = 0;
+  for (int s0 = 0; s0 < nSurv; s0 += 64) {
+    const int sIdx = s0 + lane;
+    const bool act = sIdx < nSurv;
+    unsigned mz = 0;
+    double v = 0.0;
+    if (act) { mz = sMZ[sIdx]; v = sV[sIdx]; }
+    const int m = (int)(mz >> 8), z = (int)(mz & 0xffu);
+    const double wn = act ? v / sCol[z] : 0.0;
+    if (act && wn != 0.0) used |= (1ull << z);
+    const bool keep = act && (wn > 0.0);  // :677
+    const unsigned long long km = __ballot(keep);
+    if (keep) {
+      const int pos = outBase + __popcll(km & ((1ull << lane) - 1ull));
+      const double mx = pMX[m], my = pMY[m], sxx = pSXX[m], sxy = pSXY[m], syy = pSYY[m];
+      LmKF k;
+      double range;
+      lm_precompute(P, pr, mx, my, sxx, sxy, syy, k, range);
+      const double nu0 = sZ[2 * z] - k.zx0;
+      const double nu1 = wrap_pi(sZ[2 * z + 1] - k.zx1);
+      pW[pos] = wn;
+      pWP[pos] = 0.0;  // addGaussian: weight_prev = 0 (GaussianMixture.hpp:267-284)
+      pMX[pos] = mx + (k.k00 * nu0 + k.k01 * nu1);
+      pMY[pos] = my + (k.k10 * nu0 + k.k11 * nu1);
+      pSXX[pos] = k.p00;
+      pSXY[pos] = k.p01;
+      pSYY[pos] = k.p11;
+    }
+    outBase += __popcll(km);
+  }
+
+  // ---------------- phase 3: missed-detection weights (:686-706); setWeight keeps the old weight in w_prev ----------------
+  for (int m = lane; m < nM; m += 64) {
+    const double w = pW[m];
+    const double dx = pMX[m] - pr.x, dy = pMY[m] - pr.y;
+    bool close;
+    double pd = rb_pd(P, sqrt(dx * dx + dy * dy), close);
+    if (close) pd = 1;
+    double w_k = (1 - pd) * w;
+    if (close && w > P.birthW) {
+      const unsigned seg = sSeg[m];
+      const int st = (int)(seg >> 8), c = (int)(seg & 0xffu);
+      double rowsum = 0.0;
+      for (int q = st; q < st + c && q < nSurv; q++) rowsum += sV[q] / sCol[sMZ[q] & 0xffu];
+      const double delta_w = pd * w - rowsum;
+      if (delta_w > 0) {
+        w_k += delta_w;
+        if (w_k > 1) w_k = 1;
+      }
+    }
+    pWP[m] = w;
+    pW[m] = w_k;
   }
   DBG_T(0, 2);
   used = wave_or_u64(used);
-  if (__ballot(overflow) != 0ull) {
-    if (lane == 0) atomicOr(B.err, ERRBIT_CAPACITY);
-    if (base > B.cap) base = B.cap;
-  }
   if (lane == 0) {
-    B.count[i] = base;
+    B.count[i] = outBase;
     B.unusedMask[i] = (~used) & zmask;  // :709-720
     B.nInFov[i] = nFov;
   }
   if (P.useCluster) {  // :570-580, :652-668
-    double s = RFS_DENORM_MIN + wave_sum(wsum);
+    const double s = RFS_DENORM_MIN + wave_sum_dpp(wsum);
     double prod = 1.0;
-    for (int z = 0; z < nZ; z++) prod *= colsum[z];
+    for (int z = 0; z < nZ; z++) prod *= readlane_f64(cs, z);
     if (lane == 0) B.weight[i] = exp(s) * prod * B.weight[i];
   }
 }

@@ -13,12 +13,6 @@
 #pragma once
 #include "common.h"
 
-__device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // Partitions too large for the in-kernel enumeration (nR + nC > 8) are handed to murty.h through this queue.
 struct MurtyJob {
   int particle;
@@ -38,12 +32,12 @@ struct MurtyQueue {
 struct WeightLDS {
   double *keys;                // [cap]
   int *perm;                   // [cap]
-  double *evX, *evY, *evPd;    // [64]
-  double *evLog1mPd;           // [64]
-  int *evIdx;                  // [64] sorted position of the evaluation point
-  double *evZ;                 // [64][7] z_exp0, z_exp1, i00, i01, i10, i11, factor
+  float *fkeys;                // [cap + 8]
+  double *evX, *evY, *evPd;    // [evalCap]
+  double *evLog1mPd;           // [evalCap]
+  int *evIdx;                  // [evalCap] sorted position of the evaluation point
+  double *evZ;                 // [evalCap][7] z_exp0, z_exp1, i00, i01, i10, i11, factor
   double *L;                   // [evalCap][nZ]
-  unsigned long long *rowMask, *colMask;    // [64]
   int *labR, *labC;            // [64]
   unsigned long long *compRows, *compCols;  // [128]
   double *partLik;             // [128]
@@ -53,11 +47,11 @@ __host__ __device__ inline size_t weight_lds_bytes_per_wave(int cap, int evalCap
   size_t b = 0;
   b += (size_t)cap * 8;            // keys
   b += (size_t)cap * 4;            // perm
-  b += 64 * 8 * 4;                 // evX evY evPd evLog1mPd
-  b += 64 * 4;                     // evIdx
-  b += 64 * 7 * 8;                 // evZ
+  b += (size_t)(cap + 8) * 4;      // fkeys (float keys for the rank sort, padded to a multiple of 8)
+  b += (size_t)evalCap * 8 * 4;    // evX evY evPd evLog1mPd
+  b += (size_t)evalCap * 4;        // evIdx
+  b += (size_t)evalCap * 7 * 8;    // evZ
   b += (size_t)evalCap * nZ * 8;   // L
-  b += 64 * 8 * 2;                 // rowMask colMask
   b += 64 * 4 * 2;                 // labR labC
   b += 128 * 8 * 2;                // compRows compCols
   b += 128 * 8;                    // partLik
@@ -67,19 +61,18 @@ __host__ __device__ inline size_t weight_lds_bytes_per_wave(int cap, int evalCap
 __device__ __forceinline__ void carve_weight_lds(unsigned char *base, int cap, int evalCap, int nZ, WeightLDS &s) {
   unsigned char *p = base;
   s.keys = (double *)p; p += (size_t)cap * 8;
-  s.evX = (double *)p; p += 64 * 8;
-  s.evY = (double *)p; p += 64 * 8;
-  s.evPd = (double *)p; p += 64 * 8;
-  s.evLog1mPd = (double *)p; p += 64 * 8;
-  s.evZ = (double *)p; p += 64 * 7 * 8;
+  s.evX = (double *)p; p += (size_t)evalCap * 8;
+  s.evY = (double *)p; p += (size_t)evalCap * 8;
+  s.evPd = (double *)p; p += (size_t)evalCap * 8;
+  s.evLog1mPd = (double *)p; p += (size_t)evalCap * 8;
+  s.evZ = (double *)p; p += (size_t)evalCap * 7 * 8;
   s.L = (double *)p; p += (size_t)evalCap * nZ * 8;
-  s.rowMask = (unsigned long long *)p; p += 64 * 8;
-  s.colMask = (unsigned long long *)p; p += 64 * 8;
   s.compRows = (unsigned long long *)p; p += 128 * 8;
   s.compCols = (unsigned long long *)p; p += 128 * 8;
   s.partLik = (double *)p; p += 128 * 8;
   s.perm = (int *)p; p += (size_t)cap * 4;
-  s.evIdx = (int *)p; p += 64 * 4;
+  s.fkeys = (float *)p; p += (size_t)(cap + 8) * 4;
+  s.evIdx = (int *)p; p += (size_t)evalCap * 4;
   s.labR = (int *)p; p += 64 * 4;
   s.labC = (int *)p; p += 64 * 4;
 }
@@ -147,6 +140,34 @@ __device__ double enumerate_partition(const WeightLDS &s, int nZ, unsigned long 
   return lik;
 }
 
+// One sweep over the float keys ranks NS entries per lane (entries g0 + 64*k + lane).
+template <int NS>
+__device__ __forceinline__ void rank_sweep_f32(const float *fkeys, int *perm, int N, int Npad, int g0, int lane) {
+  float fm[NS];
+  int cgt[NS];
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    const int m = g0 + 64 * k + lane;
+    fm[k] = (m < N) ? fkeys[m] : 3.0e38f;
+    cgt[k] = 0;
+  }
+  for (int j = 0; j < Npad; j += 8) {
+    float fj[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) fj[u] = fkeys[j + u];  // wave-uniform: LDS broadcast reads, 8 in flight
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+#pragma unroll
+      for (int k = 0; k < NS; k++) cgt[k] += (fj[u] > fm[k]) ? 1 : 0;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    const int m = g0 + 64 * k + lane;
+    if (m < N) perm[cgt[k]] = m;
+  }
+}
+
 template <int WPB>
 __global__ __launch_bounds__(WPB * 64) void phd_weight_multifeature_kernel(Buffers B, Params P, int src, int dst, int nZ, int evalCap,
                                                                            MurtyQueue Q) {
@@ -184,44 +205,61 @@ __global__ __launch_bounds__(WPB * 64) void phd_weight_multifeature_kernel(Buffe
 
   DBG_T(16, 0);
   // ---- 1. sort by weight: rank = #{ j : w_j > w_m  or (w_j == w_m and j < m) } ----
-  for (int m = lane; m < N; m += 64) s.keys[m] = qW[m];
+  // Rank sort, fp32 first: float conversion is monotone, so when all float keys of the mixture are distinct
+  //   rank = #{ j : (float)w_j > (float)w_m }  exactly (one fp32 compare + add per pair, NS entries per lane in one
+  // sweep over the keys).  A float collision (or a true tie) shows up as a rank that nobody claims; the mixture is then
+  // re-ranked with exact fp64 comparisons, (weight desc, index asc).
+  float *fkeys = s.fkeys;
+  for (int m = lane; m < N; m += 64) { const double w = qW[m]; s.keys[m] = w; s.perm[m] = -1; }
   wave_sync();
-  // each lane ranks up to 8 of its entries in ONE pass over the keys (one broadcast LDS read feeds 8 counters)
+  const int Npad = (N + 7) & ~7;
+  for (int m = lane; m < Npad; m += 64) fkeys[m] = (m < N) ? (float)s.keys[m] : -3.0e38f;  // sentinel never ranks ahead
+  wave_sync();
   for (int g0 = 0; g0 < N; g0 += 512) {
-    double wm[8];
-    int cnt[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int m = g0 + 64 * k + lane;
-      wm[k] = (m < N) ? s.keys[m] : 0.0;
-      cnt[k] = 0;
-    }
-    for (int j = 0; j < N; j++) {
-      const double wj = s.keys[j];
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const int m = g0 + 64 * k + lane;
-        cnt[k] += (wj > wm[k] || (wj == wm[k] && j < m)) ? 1 : 0;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int m = g0 + 64 * k + lane;
-      if (m < N) s.perm[cnt[k]] = m;
+    const int nSlots = (N - g0 + 63) >> 6;
+    switch (nSlots >= 8 ? 8 : nSlots) {
+      case 1: rank_sweep_f32<1>(fkeys, s.perm, N, Npad, g0, lane); break;
+      case 2: rank_sweep_f32<2>(fkeys, s.perm, N, Npad, g0, lane); break;
+      case 3: rank_sweep_f32<3>(fkeys, s.perm, N, Npad, g0, lane); break;
+      case 4: rank_sweep_f32<4>(fkeys, s.perm, N, Npad, g0, lane); break;
+      case 5: rank_sweep_f32<5>(fkeys, s.perm, N, Npad, g0, lane); break;
+      case 6: rank_sweep_f32<6>(fkeys, s.perm, N, Npad, g0, lane); break;
+      case 7: rank_sweep_f32<7>(fkeys, s.perm, N, Npad, g0, lane); break;
+      default: rank_sweep_f32<8>(fkeys, s.perm, N, Npad, g0, lane); break;
     }
   }
   wave_sync();
+  {
+    bool missing = false;
+    for (int r = lane; r < N; r += 64) missing = missing | (s.perm[r] < 0);
+    if (__ballot(missing) != 0ull) {  // rare: exact re-rank of the whole mixture
+      wave_sync();
+      for (int m = lane; m < N; m += 64) {
+        const double wm = s.keys[m];
+        int rank = 0;
+        for (int j = 0; j < N; j++) {
+          const double wj = s.keys[j];
+          rank += ((wj > wm) | ((wj == wm) & (j < m))) ? 1 : 0;
+        }
+        s.perm[rank] = m;
+      }
+      wave_sync();
+    }
+  }
   // sorted mixture -> other slab
   for (int r = lane; r < N; r += 64) {
     const int m = s.perm[r];
-    plane(dl, B.cap, i, PL_W)[r] = s.keys[m];
-    plane(dl, B.cap, i, PL_WP)[r] = qWP[m];
-    plane(dl, B.cap, i, PL_MX)[r] = qMX[m];
-    plane(dl, B.cap, i, PL_MY)[r] = qMY[m];
-    plane(dl, B.cap, i, PL_SXX)[r] = qSXX[m];
-    plane(dl, B.cap, i, PL_SXY)[r] = qSXY[m];
-    plane(dl, B.cap, i, PL_SYY)[r] = qSYY[m];
+    // all gathers first (independent loads in flight together), then the coalesced stores
+    const double v0 = s.keys[m], v1 = qWP[m], v2 = qMX[m], v3 = qMY[m], v4 = qSXX[m], v5 = qSXY[m], v6 = qSYY[m];
+    plane(dl, B.cap, i, PL_W)[r] = v0;
+    plane(dl, B.cap, i, PL_WP)[r] = v1;
+    plane(dl, B.cap, i, PL_MX)[r] = v2;
+    plane(dl, B.cap, i, PL_MY)[r] = v3;
+    plane(dl, B.cap, i, PL_SXX)[r] = v4;
+    plane(dl, B.cap, i, PL_SXY)[r] = v5;
+    plane(dl, B.cap, i, PL_SYY)[r] = v6;
   }
+  DBG_T(16, 8);
 
   DBG_T(16, 1);
   PoseReg pr;

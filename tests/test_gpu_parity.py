@@ -216,3 +216,25 @@ def test_cpp_host_driver_end_to_end(pkg):
     matched, total, mean_err, pose_err = int(m.group(1)), int(m.group(2)), float(m.group(3)), float(m.group(4))
     assert total == 50 and matched >= 40, out.stdout[-800:]
     assert mean_err < 0.3 and pose_err < 0.6
+
+
+def test_tied_weights_take_the_exact_rank_path(pkg, ob, sc):
+    """Equal prior weights (common in real runs: all birth Gaussians share one weight) collide in the fp32 first pass of
+    the device rank sort, which must then fall back to the exact (weight desc, index asc) order everywhere."""
+    scen = sc.make_scenario(16, 90, 14, seed=23)
+    scen["w"][:, ::3] = 0.5                                  # many exact ties
+    scen["w"][:, 1::3] = np.float64(np.float32(0.7)) + 1e-12 * np.arange(30)[None, :]   # distinct in fp64, equal in fp32
+    dev, orc = make_pair(pkg, ob, sc, scen)
+    for f in (dev, orc):
+        f.update_map(scen["Z"])
+        f.importance_weighting()
+    compare_weights(dev, orc)
+    compare_maps(sc, dev, orc, scen["n"], ordered=True)
+    for f in (dev, orc):
+        f.merge()
+        f.prune()
+    compare_maps(sc, dev, orc, scen["n"], ordered=True)
+    dev2, orc2 = make_pair(pkg, ob, sc, scen)
+    for f in (dev2, orc2):
+        f.update(scen["Z"])                                  # fused merge+prune path
+    compare_maps(sc, dev2, orc2, scen["n"], ordered=True)

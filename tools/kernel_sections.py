@@ -42,4 +42,6 @@ for base, ns in names.items():
     for k, nm_ in enumerate(ns):
         d = t[base + k + 1] - t[base + k]
         print(f"{nm_:28s} {d:10d} cycles")
+print("update_map pass0: precompute %d, gates %d, maha+lik %d, scan+write %d, fold %d" % (t[4]-t[0], t[5]-t[4], t[6]-t[5], t[7]-t[6], t[8]-t[7]))
+print("weight: rank sort %d, write %d" % (t[16+8]-t[16], t[17]-t[16+8]))
 print("kernel ns (events):", f.last_kernel_ns())
