@@ -20,8 +20,10 @@
 // their inverses are formed on demand for the few pairs that survive the distance prefilter -- this keeps the
 // footprint at 36 B/entry so that 8+ waves fit a CU and 2000 particles run in a single round.
 #define MERGE_GRID 16
+#define MERGE_PAIR_CAP(cap) (2 * (cap))
 __host__ __device__ inline size_t merge_lds_bytes_per_wave(int cap) {
-  return (((size_t)cap * (4 * 8 + 2 + 2)) + (size_t)(MERGE_GRID * MERGE_GRID + 1) * 4 * 2 + 15) & ~(size_t)15;
+  // entries: 4 doubles + firstCand (u32, atomicMin target) + grid-sorted index (u16); grid: 2 x 257 u32; pair list: u32
+  return (((size_t)cap * (4 * 8 + 4 + 2)) + (size_t)(MERGE_GRID * MERGE_GRID + 1) * 4 * 2 + (size_t)MERGE_PAIR_CAP(cap) * 4 + 16 + 15) & ~(size_t)15;
 }
 
 // Necessary condition for a pair to pass the merge test: md2 = e^T S^-1 e >= |e|^2 / lambda_max(S) >= |e|^2 / tr(S),
@@ -77,8 +79,10 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
   double *sMX = reinterpret_cast<double *>(wbase), *sMY = sMX + cap, *sW = sMX + 2 * cap, *sBnd = sMX + 3 * cap;
   unsigned *sCellStart = reinterpret_cast<unsigned *>(sMX + 4 * cap);      // [GRID*GRID + 1]
   unsigned *sCellCur = sCellStart + (MERGE_GRID * MERGE_GRID + 1);          // [GRID*GRID (+1 pad)]
-  unsigned short *sFirst = reinterpret_cast<unsigned short *>(sCellCur + MERGE_GRID * MERGE_GRID + 1);
-  unsigned short *sSorted = sFirst + cap;
+  unsigned *sFirst = sCellCur + MERGE_GRID * MERGE_GRID + 1;                // [cap] lowest passing partner (0xffff = none)
+  unsigned *sPairs = sFirst + cap;                                          // [PAIR_CAP] (a << 16) | j, prefilter survivors
+  unsigned *sPairCount = sPairs + MERGE_PAIR_CAP(cap);                      // [1] (+3 pad)
+  unsigned short *sSorted = reinterpret_cast<unsigned short *>(sPairCount + 4);
 
   const int N = B.count[i];
   double *slab = B.slab[cur];
@@ -152,20 +156,24 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
     sSorted[pos] = (unsigned short)m;
   }
   wave_sync();
+  DBG_T(32, 8);
   // ---- phase 1: per-row lowest passing partner (initial states) ----
+  // 1a: neighbours from the 3x3 cells, four per trip, branch-free distance prefilter; the few pairs that survive go
+  //     into a dense list in LDS.  1b: the list is processed with all lanes busy (one pair per lane): both covariances
+  //     are fetched together, the exact Mahalanobis test runs, and the row's lowest passing partner is kept with an
+  //     LDS atomicMin.  Splitting the rare expensive test from the scan keeps divergence out of the scan loop.
+  if (lane == 0) *sPairCount = 0u;
+  wave_sync();
+  const int pairCap = MERGE_PAIR_CAP(cap);
   for (int m = lane, sidx = 0; m < N; m += 64, sidx++) {
     if ((hole >> sidx) & 1u) continue;
-    const double ax = sMX[m], ay = sMY[m], ab = sBnd[m], aw = sW[m];
-    double a00 = 0, a01 = 0, a11 = 0;
-    bool haveInv = false;
+    const double ax = sMX[m], ay = sMY[m], ab = sBnd[m];
     int cx, cy;
     cell_of(ax, ay, cx, cy);
     const int cxa = cx > 0 ? cx - 1 : 0, cxb = cx < MERGE_GRID - 1 ? cx + 1 : MERGE_GRID - 1;
-    unsigned best = 0xffffu;
     for (int ry = (cy > 0 ? cy - 1 : 0); ry <= (cy < MERGE_GRID - 1 ? cy + 1 : MERGE_GRID - 1); ry++) {
       const unsigned qs = sCellStart[ry * MERGE_GRID + cxa], qe = sCellStart[ry * MERGE_GRID + cxb + 1];
       for (unsigned q = qs; q < qe; q += 4) {
-        // four candidates per trip: the index loads, then the position/bound loads, are independent LDS reads
         unsigned jj[4];
         double jx[4], jy[4], jb[4];
 #pragma unroll
@@ -174,27 +182,59 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
         for (int k = 0; k < 4; k++) { jx[k] = sMX[jj[k]]; jy[k] = sMY[jj[k]]; jb[k] = sBnd[jj[k]]; }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          const unsigned j = jj[k];
-          if (q + k >= qe || j <= (unsigned)m || j >= best) continue;  // higher index only; keep the lowest passing one
           const double e0 = jx[k] - ax, e1 = jy[k] - ay;
-          if ((e0 * e0 + e1 * e1) > fmax(ab, jb[k])) continue;
-          if (!haveInv) {
-            double i10, det;
-            const double xy = pSXY[m];
-            inv2(pSXX[m], xy, xy, pSYY[m], a00, a01, i10, a11, det);
-            haveInv = true;
+          // higher index only (the entry plays `a`); NaN distances fall through to the exact test like the reference
+          const bool c = (q + k < qe) & (jj[k] > (unsigned)m) & !((e0 * e0 + e1 * e1) > fmax(ab, jb[k]));
+          if (c) {
+            const unsigned pos = atomicAdd(sPairCount, 1u);
+            if (pos < (unsigned)pairCap) {
+              sPairs[pos] = ((unsigned)m << 16) | jj[k];
+            } else {  // list full (pathological density): test in place
+              double a00, a01, a10, a11, det;
+              const double xy = pSXY[m];
+              inv2(pSXX[m], xy, xy, pSYY[m], a00, a01, a10, a11, det);
+              if (merge_pair_passes(e0, e1, a00, a01, a11, sW[m], sW[jj[k]], pSXX, pSXY, pSYY, (int)jj[k], t2)) atomicMin(&sFirst[m], jj[k]);
+            }
           }
-          if (merge_pair_passes(e0, e1, a00, a01, a11, aw, sW[j], pSXX, pSXY, pSYY, (int)j, t2)) best = j;
         }
       }
     }
-    sFirst[m] = (unsigned short)best;
+  }
+  wave_sync();
+  {
+    const int nPairs = (int)min(*sPairCount, (unsigned)pairCap);
+    for (int p0 = 0; p0 < nPairs; p0 += 64) {
+      const int pi = p0 + lane;
+      if (pi < nPairs) {
+        const unsigned pr2 = sPairs[pi];
+        const int a = (int)(pr2 >> 16), j = (int)(pr2 & 0xffffu);
+        // both covariances up front: six independent loads in flight
+        const double axx = pSXX[a], axy = pSXY[a], ayy = pSYY[a];
+        const double jxx = pSXX[j], jxy = pSXY[j], jyy = pSYY[j];
+        const double e0 = sMX[j] - sMX[a], e1 = sMY[j] - sMY[a];
+        double a00, a01, a10, a11, det;
+        inv2(axx, axy, axy, ayy, a00, a01, a10, a11, det);
+        const double u0 = e0 * a00 + e1 * a01, u1 = e0 * a01 + e1 * a11;
+        bool far = (u0 * e0 + u1 * e1) > t2;
+        if (far) {
+          double j00, j01, j10, j11, jdet;
+          inv2(jxx, jxy, jxy, jyy, j00, j01, j10, j11, jdet);
+          const double g0 = -e0, g1 = -e1;
+          const double v0 = g0 * j00 + g1 * j01, v1 = g0 * j01 + g1 * j11;
+          far = (v0 * g0 + v1 * g1) > t2;
+        }
+        if (!far && ((sW[a] + sW[j]) != 0.0)) atomicMin(&sFirst[a], (unsigned)j);
+      }
+    }
   }
   wave_sync();
 
   DBG_T(32, 2);
   // ---- phase 2: replay rows that have a candidate, in order, with the exact greedy rule ----
   bool anyMerge = false;
+#ifdef RFS_PROFILE
+  int dbgRows = 0, dbgMerges = 0, dbgChunks = 0;
+#endif
   for (int r0 = 0; r0 < N; r0 += 64) {
     const int rr = r0 + lane;
     unsigned long long rows = __ballot(rr < N && sFirst[rr] != 0xffffu);
@@ -204,6 +244,9 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
       const unsigned ownerHole = (unsigned)__builtin_amdgcn_readlane((int)hole, a & 63);
       if ((ownerHole >> (a >> 6)) & 1u) continue;  // a was absorbed by an earlier row
       const int j0 = sFirst[a];
+#ifdef RFS_PROFILE
+      dbgRows++;
+#endif
       double ax = sMX[a], ay = sMY[a], aw = sW[a], ab = sBnd[a];
       double axx = pSXX[a], axy = pSXY[a], ayy = pSYY[a];
       double a00, a01, a10, a11, adet;
@@ -213,6 +256,9 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
       for (int c0 = j0 & ~63; c0 < N; c0 += 64) {
         const int j = c0 + lane;
         const int slot = c0 >> 6;
+#ifdef RFS_PROFILE
+        dbgChunks++;
+#endif
         bool live = (j > a) && (j < N) && !((hole >> slot) & 1u);
         double jx = 0, jy = 0, jw = 0, jb = 0;
         if (live) { jx = sMX[j]; jy = sMY[j]; jw = sW[j]; jb = sBnd[j]; }
@@ -239,6 +285,9 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
           inv2(axx, axy, axy, ayy, a00, a01, a10, a11, adet);
           ab = merge_bound(t2, axx, axy, ayy);
           changed = true;
+#ifdef RFS_PROFILE
+          dbgMerges++;
+#endif
           if (lane == l) { hole |= 1u << slot; live = false; }
           floorLane = l + 1;
           if (floorLane >= 64) break;
@@ -253,6 +302,9 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
     }
   }
 
+#ifdef RFS_PROFILE
+  if (B.dbg && i == 7 && lane == 0) { B.dbg[48] = dbgRows; B.dbg[49] = dbgMerges; B.dbg[50] = dbgChunks; B.dbg[51] = N; }
+#endif
   if (!FUSE_PRUNE) {
     if (!anyMerge) return;
     for (int m = lane, sidx = 0; m < N; m += 64, sidx++)
