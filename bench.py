@@ -43,19 +43,19 @@ def algorithmic_bytes(n_particles, nM, nNew, nKept, nZ):
 
 
 def cpu_baseline(sc, scen_full, seconds_budget=20.0):
-    """The oracle (CPU restatement of the same path, oracle/) timed on this box's host cores on a bounded
-    sample of the same workload; scaled to the full particle count (the path is embarrassingly parallel over
-    particles).  Reported baseline only -- never part of the measured GPU path."""
+    """The oracle (CPU restatement of the same path, oracle/, g++ -O2 -fopenmp, OpenMP `parallel for` over particles
+    exactly like the reference) timed on this box's host cores on a bounded sample of the same workload, scaled to the
+    full particle count (the path is embarrassingly parallel over particles).  Reported baseline only -- never part
+    of the measured GPU path."""
     from oracle import binding as ob
-    n_s = 64
-    scen = sc.make_scenario(n_s, N_LANDMARKS, N_Z, seed=12345)
-    out = {}
+    out, info = {}, {}
     cores = ob.max_threads()
-    for label, threads in (("1thread", 1), ("allcores", cores)):
+    for label, threads, n_s in (("1thread", 1, 64), ("allcores", cores, min(scen_full["n"], max(64, 8 * cores)))):
         ob.set_threads(threads)
+        scen = sc.make_scenario(n_s, N_LANDMARKS, N_Z, seed=12345)
         orc = ob.OracleFilter(n_s, stable_sort=False)
         reps, t_acc = 0, 0.0
-        while t_acc < seconds_budget / 2 and reps < 50:
+        while t_acc < seconds_budget / 2 and reps < 30:
             sc.load_scenario(orc, scen)
             t0 = time.perf_counter()
             orc.update(scen["Z"])
@@ -63,14 +63,31 @@ def cpu_baseline(sc, scen_full, seconds_budget=20.0):
             orc.normalize_weights(s[0])
             t_acc += time.perf_counter() - t0
             reps += 1
-        per_particle = t_acc / reps / n_s
-        out[label] = 1.0 / (per_particle * scen_full["n"])
+        out[label] = 1.0 / (t_acc / reps / n_s * scen_full["n"])
+        info[label] = n_s
         orc.close()
     ob.set_threads(cores)
-    return dict(value=out["allcores"], unit="steps/s", cores=cores, kind="port",
-                single_thread_value=out["1thread"],
-                sample=f"{n_s} of {scen_full['n']} particles (same 200-landmark x 30-measurement state), update()+normalise, "
-                       f"scaled by particle count; oracle -O2 -fopenmp, {cores} threads")
+    return dict(value=round(out["allcores"], 4), unit="steps/s", cores=cores, kind="port",
+                single_thread_value=round(out["1thread"], 4),
+                sample=f"update()+normalise on {info['allcores']} of {scen_full['n']} particles with {cores} OpenMP threads "
+                       f"({info['1thread']} particles for the 1-thread figure), same 200-landmark x 30-measurement state, "
+                       "scaled by particle count")
+
+
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC summary (profiles/pmc_latest.json, made by
+    tools/profile_round.sh + tools/pmc_summary.py on this workload): (2*FETCH_SIZE + WRITE_SIZE)*1024."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+    except Exception:
+        return None
+    alias = {"phd_update_map": "phd_update_map_kernel", "phd_weight_multifeature": "phd_weight_multifeature_kernel",
+             "gm_merge": "gm_merge_kernel", "gm_prune": "gm_prune_kernel"}[kernel_name]
+    best = None
+    for k, v in d.items():
+        if k.startswith(alias) and (best is None or v["calls"] > best["calls"]):
+            best = v
+    return int(best["hbm_bytes"]) if best else None
 
 
 def main():
@@ -192,7 +209,8 @@ def main():
                 "likelihood_sweep": per_kernel["phd_update_map"],
             },
             "roofline": {"bound": "hbm", "kernel": dname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None},
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(dname),
+                         "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload)"},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, scen)

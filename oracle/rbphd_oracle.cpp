@@ -632,19 +632,25 @@ static void update_map_particle(Filter &F, int i) {
     for (int z = 0; z < nZ; z++) F.unused[i].push_back(z);
     return;
   }
-  std::vector<double> Pd(nM);
-  std::vector<int> closeLim(nM);
+  /* per-thread scratch that persists across particles, like the reference's per-thread wTables_/mTables_ (:352-393) */
+  static thread_local std::vector<double> Pd, W, lik, md2;
+  static thread_local std::vector<int> closeLim;
+  static thread_local std::vector<char> Mvalid;
+  static thread_local std::vector<Gauss> Mtab, lmNew;
+  Pd.assign(nM, 0.0);
+  closeLim.assign(nM, 0);
   double w_km_sum = std::numeric_limits<double>::denorm_min();
   double likelihoodProd = 1;
   if (F.cfg.useClusterProcess)
     for (unsigned m = 0; m < nM; m++) w_km_sum += G[m].w;
-  std::vector<double> W((size_t)nM * nZ, 0.0);
-  std::vector<char> Mvalid((size_t)nM * nZ, 0);
-  std::vector<Gauss> Mtab((size_t)nM * nZ);
+  W.assign((size_t)nM * nZ, 0.0);
+  Mvalid.assign((size_t)nM * nZ, 0);
+  if (Mtab.size() < (size_t)nM * nZ) Mtab.resize((size_t)nM * nZ);
   const Pose &pose = F.pose[i];
   const double thr = F.cfg.newGaussianCreateInnovMDThreshold * F.cfg.newGaussianCreateInnovMDThreshold;
-  std::vector<double> lik(nZ), md2(nZ);
-  std::vector<Gauss> lmNew(nZ);
+  lik.assign(nZ, 0.0);
+  md2.assign(nZ, 0.0);
+  if (lmNew.size() < (size_t)nZ) lmNew.resize(nZ);
   for (unsigned m = 0; m < nM; m++) {
     bool close;
     Pd[m] = rb_pd(F.model, pose, G[m].x, close);
