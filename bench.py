@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 N_PARTICLES, N_LANDMARKS, N_Z, CAP = 2000, 200, 30, 384
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 BG = 48                # packed 2-D Gaussian record: w, mu(2), Sigma upper triangle(3) doubles
-KERNELS = ["phd_update_map", "phd_weight_multifeature", "gm_merge", "gm_prune"]
+KERNELS = ["phd_update_map", "phd_weight_multifeature", "gm_merge_prune"]   # rfsgpu_update runs merge+prune fused
 
 
 def algorithmic_bytes(n_particles, nM, nNew, nKept, nZ):
@@ -37,9 +37,8 @@ def algorithmic_bytes(n_particles, nM, nNew, nKept, nZ):
     nM / nNew / nKept are sums over particles of: Gaussians before the update, appended, surviving prune."""
     sweep = nM * BG + nNew * BG + nM * 8 + n_particles * (24 + 8) + nZ * 16
     weight = (nM + nNew) * (BG + 8) + (nM + nNew) * BG + n_particles * (24 + 8)   # read w,w_prev,mu,Sigma; write sorted; weight out
-    merge = (nM + nNew) * BG * 2                                                  # read + write back
-    prune = (nM + nNew) * BG + nKept * BG + n_particles * 4
-    return dict(zip(KERNELS, [sweep, weight, merge, prune]))
+    merge_prune = (nM + nNew) * BG + nKept * BG + n_particles * 4                 # read once, write the compacted survivors
+    return dict(zip(KERNELS, [sweep, weight, merge_prune]))
 
 
 def cpu_baseline(sc, scen_full, seconds_budget=20.0):
@@ -82,7 +81,7 @@ def pmc_traffic(kernel_name):
     except Exception:
         return None
     alias = {"phd_update_map": "phd_update_map_kernel", "phd_weight_multifeature": "phd_weight_multifeature_kernel",
-             "gm_merge": "gm_merge_kernel", "gm_prune": "gm_prune_kernel"}[kernel_name]
+             "gm_merge_prune": "gm_merge_kernel"}[kernel_name]
     best = None
     for k, v in d.items():
         if k.startswith(alias) and (best is None or v["calls"] > best["calls"]):
@@ -156,14 +155,14 @@ def main():
     nKept = int(f.gm_sizes().sum())
     bytes_k = algorithmic_bytes(n_local, nM, nAfter - nM, nKept, N_Z)
 
-    kern_ns = np.zeros(4)
+    kern_ns = np.zeros(3)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        kern_ns += np.array(f.last_kernel_ns(), dtype=np.float64)  # HIP events on the engine's stream, recorded inside update()
+        kern_ns += np.array(f.last_kernel_ns()[:3], dtype=np.float64)  # HIP events on the engine's stream, recorded inside update()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

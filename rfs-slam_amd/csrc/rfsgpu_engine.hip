@@ -56,6 +56,8 @@ struct rfsgpu_filter {
   rfsgpu_timing timing{};
   long long lastKernelNs[4] = {0, 0, 0, 0};
   bool phaseOpen = false;   // update_map ran, weighting/merge/prune may follow
+  bool normPending = false; // a normalize_kernel event pair has not been accumulated yet
+  double *hZ = nullptr;     // pinned staging for the measurement set
   std::string err;
   int maxLds = 0;
   int wpbUpdate = 4, wpbWeight = 4, wpbMerge = 4, wpbPrune = 4;
@@ -190,6 +192,7 @@ int rfsgpu_create(rfsgpu_filter **out, int model, int n_particles, int device_id
   ok &= hipHostMalloc(&f->hErr, sizeof(int)) == hipSuccess;
   ok &= hipHostMalloc(&f->hJobCount, sizeof(int)) == hipSuccess;
   ok &= hipHostMalloc(&f->hSums, 2 * sizeof(double)) == hipSuccess;
+  ok &= hipHostMalloc(&f->hZ, RFSGPU_MAX_Z * 2 * sizeof(double)) == hipSuccess;
   if (!ok) return bail(RFSGPU_ERR_HIP);
   if (murty_alloc(f->Q, f->MS, f->N) != 0) return bail(RFSGPU_ERR_HIP);
   hipMemsetAsync(B.slab[0], 0, slabBytes, f->stream);
@@ -231,6 +234,7 @@ void rfsgpu_destroy(rfsgpu_filter *f) {
   if (f->hErr) hipHostFree(f->hErr);
   if (f->hJobCount) hipHostFree(f->hJobCount);
   if (f->hSums) hipHostFree(f->hSums);
+  if (f->hZ) hipHostFree(f->hZ);
   for (int k = 0; k < EV_COUNT; k++) if (f->ev[k]) hipEventDestroy(f->ev[k]);
   if (f->ownStream) hipStreamDestroy(f->ownStream);
   delete f;
@@ -522,7 +526,12 @@ static int stage_measurements(rfsgpu_filter *f, const double *z, int n_z) {
   if (n_z < 0 || n_z > RFSGPU_MAX_Z) return fail(f, RFSGPU_ERR_INVALID, "at most RFSGPU_MAX_Z measurements per update");
   if (n_z > 0 && !z) return fail(f, RFSGPU_ERR_INVALID, "null measurement buffer");
   hipSetDevice(f->device);
-  if (n_z > 0) HIPCHK(hipMemcpyAsync(f->B.Z, z, (size_t)n_z * 2 * sizeof(double), hipMemcpyHostToDevice, f->stream));
+  if (n_z > 0) {
+    // through a pinned staging buffer: the H2D copy is then truly asynchronous.  The previous step's copy has completed
+    // (every update ends with a stream sync) before the buffer is overwritten.
+    memcpy(f->hZ, z, (size_t)n_z * 2 * sizeof(double));
+    HIPCHK(hipMemcpyAsync(f->B.Z, f->hZ, (size_t)n_z * 2 * sizeof(double), hipMemcpyHostToDevice, f->stream));
+  }
   f->nZ = n_z;
   return RFSGPU_OK;
 }
@@ -674,8 +683,9 @@ int rfsgpu_normalize_weights(rfsgpu_filter *f, double sum, const void *sum_dev) 
   normalize_kernel<<<(f->N + 255) / 256, 256, 0, f->stream>>>(f->B.weight, f->N, sum, (const double *)sum_dev);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(f->ev[EV_R1], f->stream));
-  HIPCHK(hipStreamSynchronize(f->stream));
-  accumulate(f->ev[EV_R0], f->ev[EV_R1], f->timing.particleResample_wall, nullptr);
+  // stream-ordered, no host sync: the next call that syncs (or rfsgpu_synchronize) completes it; its event pair is
+  // folded into the Resampling bucket by rfsgpu_get_timing
+  f->normPending = true;
   f->timing.particleResample_cpu += now_ns() - t0;
   return RFSGPU_OK;
 }
@@ -705,6 +715,12 @@ int rfsgpu_resample_apply(rfsgpu_filter *f, const int *src_slot) {
 int rfsgpu_get_timing(rfsgpu_filter *f, rfsgpu_timing *t) {
   CHECK_HANDLE(f);
   if (!t) return RFSGPU_ERR_INVALID;
+  if (f->normPending) {
+    hipSetDevice(f->device);
+    HIPCHK(hipStreamSynchronize(f->stream));
+    accumulate(f->ev[EV_R0], f->ev[EV_R1], f->timing.particleResample_wall, nullptr);
+    f->normPending = false;
+  }
   *t = f->timing;
   return RFSGPU_OK;
 }
