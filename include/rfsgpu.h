@@ -17,7 +17,7 @@
  *   - all host buffers are caller-owned; the engine owns its device memory (one handle == one GPU,
  *     one host thread per handle, one process per GPU).
  *   - everything is fp64; matrices are row-major; d_m = landmark dim, d_z = measurement dim
- *     (both 2 for RFSGPU_MODEL_RNGBRG_2D).
+ *     (both 2 for RFSGPU_MODEL_RNGBRG_2D, both 3 for RFSGPU_MODEL_VICTORIAPARK_3D).
  *   - "slot" = particle index 0..n_particles-1.
  *   - the engine fails loudly: there is NO CPU fallback anywhere behind this ABI.
  */
@@ -47,8 +47,15 @@ enum rfsgpu_status {
 };
 
 enum rfsgpu_model {
-  RFSGPU_MODEL_RNGBRG_2D = 0  /* MeasurementModel_RngBrg + KalmanFilter_RngBrg + Landmark2d    */
+  RFSGPU_MODEL_RNGBRG_2D = 0,       /* MeasurementModel_RngBrg + KalmanFilter_RngBrg + Landmark2d (d_m = d_z = 2)            */
+  RFSGPU_MODEL_VICTORIAPARK_3D = 1  /* MeasurementModel_VictoriaPark + KalmanFilter_VictoriaPark + Landmark3d (d_m = d_z = 3:
+                                       landmark (x, y, diameter), measurement (range, bearing, diameter))                    */
 };
+
+/* Maximum entries of the Victoria Park Pd table / beams of a laser scan / birth candidates per particle. */
+#define RFSGPU_VP_MAX_PD 16
+#define RFSGPU_VP_MAX_SCAN 720
+#define RFSGPU_MAX_CANDIDATES 64
 
 /* Mirrors RBPHDFilter::Config, include/RBPHDFilter.hpp:90-146 (same meaning, same defaults
  * :370-382 when filled by rfsgpu_default_filter_config). */
@@ -80,6 +87,19 @@ typedef struct rfsgpu_rngbrg_config {
   double rangeLimMin;
   double rangeLimBuffer;
 } rfsgpu_rngbrg_config;
+
+/* Mirrors MeasurementModel_VictoriaPark::Config (include/MeasurementModel_VictoriaPark.hpp:150-158) plus the noise set
+ * through setNoise(R, Slb) (src/MeasurementModel_VictoriaPark.cpp:66-73).  Angles in radians. */
+typedef struct rfsgpu_vp_config {
+  double R[9];                       /* 3x3 row-major measurement covariance (range, bearing, diameter) */
+  double Slb;                        /* variance of the lidar beam angle                                 */
+  double PdTable[RFSGPU_VP_MAX_PD];  /* config.probabilityOfDetection_ (Pd by number of visible beams)   */
+  int nPd;
+  double expectedClutterNumber;
+  double rangeLimMax, rangeLimMin;
+  double bearingLimitMax, bearingLimitMin;
+  double bufferZonePd;
+} rfsgpu_vp_config;
 
 /* Mirrors KalmanFilter_RngBrg::Config (include/KalmanFilter_RngBrg.hpp:55-60). <=0 disables. */
 typedef struct rfsgpu_kf_config {
@@ -122,6 +142,11 @@ int rfsgpu_set_filter_config(rfsgpu_filter *f, const rfsgpu_filter_config *cfg);
 int rfsgpu_get_filter_config(const rfsgpu_filter *f, rfsgpu_filter_config *cfg);
 int rfsgpu_set_model_rngbrg(rfsgpu_filter *f, const rfsgpu_rngbrg_config *cfg);    /* getMeasurementModel()->config / setNoise */
 int rfsgpu_set_kf_config(rfsgpu_filter *f, const rfsgpu_kf_config *cfg);           /* getKalmanFilter()->config */
+/* Victoria Park model: getMeasurementModel()->config / setNoise(R, Slb) (src/rbphdslam_VictoriaPark.cpp:371-378). */
+int rfsgpu_set_model_victoriapark(rfsgpu_filter *f, const rfsgpu_vp_config *cfg);
+/* MeasurementModel_VictoriaPark::setLaserScan (src/MeasurementModel_VictoriaPark.cpp:267-281): the raw scan used by the
+ * occlusion-based Pd and by the clutter intensity (expected clutter / field-of-view area); n <= RFSGPU_VP_MAX_SCAN. */
+int rfsgpu_set_laser_scan(rfsgpu_filter *f, const double *scan, int n);
 /* getLmkProcessModel()->setNoise(Q) (include/ProcessModel.hpp:195-208); Q is d_m x d_m. */
 int rfsgpu_set_lmk_process_noise(rfsgpu_filter *f, const double *Q);
 
@@ -150,6 +175,9 @@ int rfsgpu_export_gm(rfsgpu_filter *f, int slot, int max_n, int *n_out, double *
 /* Set particle `slot`'s birth bookkeeping (unused_measurements_[slot] as ascending indices, nLandmarksInFOV_[slot]);
  * needed when a particle migrates between shards during a multi-GPU resample (RBPHDFilter.hpp:1005-1011). */
 int rfsgpu_import_aux(rfsgpu_filter *f, int slot, const int *unused_idx, int n_unused, int n_in_fov);
+/* birthGaussians_[slot] (RBPHDFilter.hpp:253, :173-177): the particle's birth-Gaussian candidates in list order. */
+int rfsgpu_export_birth_candidates(rfsgpu_filter *f, int slot, int max_n, int *n_out, double *mean, double *cov, int *n_support, int *n_checks);
+int rfsgpu_import_birth_candidates(rfsgpu_filter *f, int slot, int n, const double *mean, const double *cov, const int *n_support, const int *n_checks);
 /* All mixture sizes at once (n_particles ints). */
 int rfsgpu_gm_sizes(rfsgpu_filter *f, int *sizes);
 

@@ -53,6 +53,30 @@ class OracleFilter:
         return obj
 
 
+def vp_pd(f, pose, lx, lS):
+    """Oracle probe: MeasurementModel_VictoriaPark::probabilityOfDetection -> (Pd, isCloseToSensingLimit)."""
+    lib = load()
+    lib.rfsor_vp_pd.restype = C.c_double
+    pose, lx, lS = (np.ascontiguousarray(a, dtype=np.float64) for a in (pose, lx, lS))
+    close = C.c_int()
+    v = lib.rfsor_vp_pd(f._h, pose.ctypes.data_as(C.c_void_p), lx.ctypes.data_as(C.c_void_p), lS.ctypes.data_as(C.c_void_p), C.byref(close))
+    return v, bool(close.value)
+
+
+def vp_measure(f, pose, lx, lS):
+    lib = load()
+    pose, lx, lS = (np.ascontiguousarray(a, dtype=np.float64) for a in (pose, lx, lS))
+    z, S, H = np.empty(3), np.empty((3, 3)), np.empty((3, 3))
+    lib.rfsor_vp_measure(f._h, *(a.ctypes.data_as(C.c_void_p) for a in (pose, lx, lS, z, S, H)))
+    return z, S, H
+
+
+def vp_clutter(f):
+    lib = load()
+    lib.rfsor_vp_clutter.restype = C.c_double
+    return lib.rfsor_vp_clutter(f._h)
+
+
 def _long(fn, h):
     fn.restype = C.c_long
     return fn(h)

@@ -13,13 +13,14 @@
  *     from /root/reference into oracle/_ref (oracle/Makefile), compared sequence-for-sequence,
  *   - Hungarian / Murty k-best scores : the reference's own src/BruteForceAssignment.cpp (its example
  *     checker for Murty, src/examples/linearAssignment_MurtyAlgorithm.cpp:99-130) compiled into oracle/_ref.
- * Everything else (updateMap, KF correct, RngBrg model, importanceWeighting, CostMatrixGeneral partition,
- * merge, prune, resample) is a line-by-line restatement with NO reference-produced golden vectors:
- * "parity unpinned" for those rows; they are cross-checked only against independent numpy/scipy
+ * Everything else (updateMap, KF correct, RngBrg / VictoriaPark models, importanceWeighting, CostMatrixGeneral
+ * partition, merge, prune, birth Gaussians, resample) is a line-by-line restatement with NO reference-produced
+ * golden vectors: "parity unpinned" for those rows; they are cross-checked only against independent numpy/scipy
  * formulations in tests/.
  *
  * Each function cites the reference file:line it follows (paths relative to /root/reference).
  * Arithmetic follows the reference's expression order (Eigen fixed-size closed forms written out).
+ * The filter is a template over the measurement model, like the reference's RBPHDFilter<..., MeasurementModel, KF>.
  */
 #include <algorithm>
 #include <cfloat>
@@ -28,6 +29,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <list>
 #include <memory>
 #include <queue>
 #include <string>
@@ -43,27 +45,49 @@ namespace orc {
 static const double PI = acos(-1); /* include/RandomVec.hpp:55 */
 
 /* ------------------------------------------------------------------------------------------------
- * 2x2 / 2x3 algebra, written the way Eigen's fixed-size expression templates evaluate it
+ * Fixed-size algebra, written the way Eigen's fixed-size expression templates evaluate it
  * (coefficient (i,j) = sum over k in ascending order; nested products evaluated into temporaries).
  * ---------------------------------------------------------------------------------------------- */
-struct M2 { double a[4]; double &operator()(int i, int j) { return a[2 * i + j]; } double operator()(int i, int j) const { return a[2 * i + j]; } };
-struct V2 { double a[2]; };
+template <int D>
+struct Mat {
+  double a[D * D];
+  double &operator()(int i, int j) { return a[D * i + j]; }
+  double operator()(int i, int j) const { return a[D * i + j]; }
+};
+template <int D>
+static inline Mat<D> zeroM() {
+  Mat<D> m;
+  for (int k = 0; k < D * D; k++) m.a[k] = 0;
+  return m;
+}
+template <int D>
+static inline Mat<D> mul(const Mat<D> &A, const Mat<D> &B) {
+  Mat<D> C;
+  for (int i = 0; i < D; i++)
+    for (int j = 0; j < D; j++) {
+      double s = A(i, 0) * B(0, j);
+      for (int k = 1; k < D; k++) s += A(i, k) * B(k, j);
+      C(i, j) = s;
+    }
+  return C;
+}
+template <int D>
+static inline Mat<D> mulT(const Mat<D> &A, const Mat<D> &B) { /* A * B^T */
+  Mat<D> C;
+  for (int i = 0; i < D; i++)
+    for (int j = 0; j < D; j++) {
+      double s = A(i, 0) * B(j, 0);
+      for (int k = 1; k < D; k++) s += A(i, k) * B(j, k);
+      C(i, j) = s;
+    }
+  return C;
+}
+typedef Mat<2> M2;
+typedef Mat<3> M3;
 
-static inline M2 mul(const M2 &A, const M2 &B) {
-  M2 C;
-  for (int i = 0; i < 2; i++)
-    for (int j = 0; j < 2; j++) C(i, j) = A(i, 0) * B(0, j) + A(i, 1) * B(1, j);
-  return C;
-}
-static inline M2 mulT(const M2 &A, const M2 &B) { /* A * B^T */
-  M2 C;
-  for (int i = 0; i < 2; i++)
-    for (int j = 0; j < 2; j++) C(i, j) = A(i, 0) * B(j, 0) + A(i, 1) * B(j, 1);
-  return C;
-}
-static inline double det2(const M2 &m) { return m(0, 0) * m(1, 1) - m(1, 0) * m(0, 1); } /* Eigen determinant_impl<.,2> */
-static inline M2 inv2(const M2 &m) { /* Eigen compute_inverse_size2_helper */
-  double invdet = 1.0 / det2(m);
+static inline double det(const M2 &m) { return m(0, 0) * m(1, 1) - m(1, 0) * m(0, 1); } /* Eigen determinant_impl<.,2> */
+static inline M2 inv(const M2 &m) {                                                          /* Eigen compute_inverse_size2_helper */
+  double invdet = 1.0 / det(m);
   M2 r;
   r(0, 0) = m(1, 1) * invdet;
   r(1, 0) = -m(1, 0) * invdet;
@@ -71,47 +95,73 @@ static inline M2 inv2(const M2 &m) { /* Eigen compute_inverse_size2_helper */
   r(1, 1) = m(0, 0) * invdet;
   return r;
 }
+/* Eigen bruteforce_det3_helper / determinant_impl<.,3> */
+static inline double det3h(const M3 &m, int a, int b, int c) { return m(0, a) * (m(1, b) * m(2, c) - m(1, c) * m(2, b)); }
+static inline double det(const M3 &m) { return det3h(m, 0, 1, 2) - det3h(m, 1, 0, 2) + det3h(m, 2, 0, 1); }
+/* Eigen cofactor_3x3 + compute_inverse<.,3> / compute_inverse_size3_helper */
+static inline double cof3(const M3 &m, int i, int j) {
+  int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  return m(i1, j1) * m(i2, j2) - m(i1, j2) * m(i2, j1);
+}
+static inline M3 inv(const M3 &m) {
+  double c0 = cof3(m, 0, 0), c1 = cof3(m, 1, 0), c2 = cof3(m, 2, 0);
+  double d = (c0 * m(0, 0) + c1 * m(1, 0)) + c2 * m(2, 0);
+  double invdet = 1.0 / d;
+  M3 r;
+  r(0, 0) = c0 * invdet; r(0, 1) = c1 * invdet; r(0, 2) = c2 * invdet;
+  r(1, 0) = cof3(m, 0, 1) * invdet; r(1, 1) = cof3(m, 1, 1) * invdet; r(1, 2) = cof3(m, 2, 1) * invdet;
+  r(2, 0) = cof3(m, 0, 2) * invdet; r(2, 1) = cof3(m, 1, 2) * invdet; r(2, 2) = cof3(m, 2, 2) * invdet;
+  return r;
+}
 
-/* A Gaussian of the mixture: GaussianMixture<Landmark2d>::Gaussian (include/GaussianMixture.hpp:60-64).
+/* A Gaussian of the mixture: GaussianMixture<Landmark>::Gaussian (include/GaussianMixture.hpp:60-64).
  * valid == (landmark != NULL). */
-struct Gauss {
+template <int D>
+struct GaussT {
   bool valid;
   double w, w_prev;
-  double x[2];
-  M2 S;
+  double x[D];
+  Mat<D> S;
 };
 
-/* RandomVec<2>::mahalanobisDist2 (include/RandomVec.hpp:387-394): e = to - x; e^T * Sinv * e,
- * evaluated as (e^T * Sinv) * e. */
-static inline double md2_2(const double x[2], const M2 &Sinv, const double to[2]) {
-  double e0 = to[0] - x[0], e1 = to[1] - x[1];
-  double t0 = e0 * Sinv(0, 0) + e1 * Sinv(1, 0);
-  double t1 = e0 * Sinv(0, 1) + e1 * Sinv(1, 1);
-  return t0 * e0 + t1 * e1;
+/* RandomVec<n>::mahalanobisDist2 (include/RandomVec.hpp:387-394): e = to - x; (e^T * Sinv) * e. */
+template <int D>
+static inline double md2(const double *x, const Mat<D> &Sinv, const double *to) {
+  double e[D], t[D];
+  for (int k = 0; k < D; k++) e[k] = to[k] - x[k];
+  for (int j = 0; j < D; j++) {
+    double s = e[0] * Sinv(0, j);
+    for (int i = 1; i < D; i++) s += e[i] * Sinv(i, j);
+    t[j] = s;
+  }
+  double r = t[0] * e[0];
+  for (int j = 1; j < D; j++) r += t[j] * e[j];
+  return r;
 }
-/* RandomVec<2>::evalGaussianLikelihood (include/RandomVec.hpp:417-434). */
-static inline double gauss_lik2(const double x[2], const M2 &S, const double at[2], double *md2_out) {
-  double det = det2(S);
-  double factor = sqrt(pow(2 * PI, 2) * det);
-  M2 Sinv = inv2(S);
-  double md2 = md2_2(x, Sinv, at);
-  double l = exp(-0.5 * md2) / factor;
+/* RandomVec<n>::evalGaussianLikelihood (include/RandomVec.hpp:417-434). */
+template <int D>
+static inline double gauss_lik(const double *x, const Mat<D> &S, const double *at, double *md2_out) {
+  double dt = det(S);
+  double factor = sqrt(pow(2 * PI, D) * dt);
+  Mat<D> Sinv = inv(S);
+  double m = md2<D>(x, Sinv, at);
+  double l = exp(-0.5 * m) / factor;
   if (l != l) l = 0;
-  if (md2_out) *md2_out = md2;
+  if (md2_out) *md2_out = m;
   return l;
 }
 
-/* ------------------------------------------------------------------------------------------------
- * MeasurementModel_RngBrg  (src/MeasurementModel_RngBrg.cpp)
- * ---------------------------------------------------------------------------------------------- */
 struct Pose {
   double x[3];
   double P[9]; /* 3x3 row-major covariance */
 };
 
-/* measure(): src/MeasurementModel_RngBrg.cpp:70-115.  Returns false outside [rmin, rmax] (:111). */
-static bool rb_measure(const rfsgpu_rngbrg_config &M, const Pose &pose, const double lx[2], const M2 &lS,
-                       double z[2], M2 &S, M2 *Hout) {
+/* ------------------------------------------------------------------------------------------------
+ * MeasurementModel_RngBrg  (src/MeasurementModel_RngBrg.cpp) -- free functions on (config, R)
+ * ---------------------------------------------------------------------------------------------- */
+/* measure(): :70-115.  Returns false outside [rmin, rmax] (:111). */
+static bool rb_measure_core(const double R[4], double rmax, double rmin, const Pose &pose, const double lx[2], const M2 &lS, double z[2],
+                            M2 &S, M2 *Hout) {
   double dx = lx[0] - pose.x[0], dy = lx[1] - pose.x[1];
   double range2 = pow(dx, 2) + pow(dy, 2);
   double range = sqrt(range2);
@@ -132,101 +182,200 @@ static bool rb_measure(const rfsgpu_rngbrg_config &M, const Pose &pose, const do
   M2 B;
   for (int i = 0; i < 2; i++)
     for (int j = 0; j < 2; j++) B(i, j) = T[i][0] * Hr[j][0] + T[i][1] * Hr[j][1] + T[i][2] * Hr[j][2];
-  for (int k = 0; k < 4; k++) S.a[k] = (A.a[k] + B.a[k]) + M.R[k];
+  for (int k = 0; k < 4; k++) S.a[k] = (A.a[k] + B.a[k]) + R[k];
   if (Hout) *Hout = H;
-  if (range > M.rangeLimMax || range < M.rangeLimMin) return false;
+  if (range > rmax || range < rmin) return false;
   return true;
 }
-
-/* inverseMeasure(): src/MeasurementModel_RngBrg.cpp:117-136. */
-static void rb_inverse_measure(const rfsgpu_rngbrg_config &M, const Pose &pose, const double z[2], double lx[2], M2 &lS) {
+/* inverseMeasure(): :117-136. */
+static void rb_inverse_measure_core(const double R[4], const Pose &pose, const double z[2], double lx[2], M2 &lS) {
   double a = pose.x[2] + z[1];
   lx[0] = pose.x[0] + z[0] * cos(a);
   lx[1] = pose.x[1] + z[0] * sin(a);
   M2 Hinv;
   Hinv(0, 0) = cos(a); Hinv(0, 1) = -z[0] * sin(a);
   Hinv(1, 0) = sin(a); Hinv(1, 1) = z[0] * cos(a);
-  M2 R;
-  memcpy(R.a, M.R, sizeof(R.a));
-  lS = mulT(mul(Hinv, R), Hinv);
+  M2 Rm;
+  memcpy(Rm.a, R, sizeof(Rm.a));
+  lS = mulT(mul(Hinv, Rm), Hinv);
 }
 
-/* probabilityOfDetection(): src/MeasurementModel_RngBrg.cpp:138-167. */
-static double rb_pd(const rfsgpu_rngbrg_config &M, const Pose &pose, const double lx[2], bool &close) {
-  close = false;
-  double range = sqrt(pow(lx[0] - pose.x[0], 2) + pow(lx[1] - pose.x[1], 2));
-  double Pd;
-  if (range <= M.rangeLimMax && range >= M.rangeLimMin) {
-    Pd = M.probabilityOfDetection;
-    if (range >= (M.rangeLimMax - M.rangeLimBuffer) || range <= (M.rangeLimMin + M.rangeLimBuffer)) close = true;
-  } else {
-    Pd = 0;
-    if (range <= (M.rangeLimMax + M.rangeLimBuffer) && range >= (M.rangeLimMin - M.rangeLimBuffer)) close = true;
+/* ---- model policy: 2-D range-bearing (MeasurementModel_RngBrg + KalmanFilter_RngBrg) ---- */
+struct ModelRB {
+  enum { D = 2 };
+  rfsgpu_rngbrg_config c;
+  rfsgpu_kf_config kf;
+  ModelRB() {
+    memset(&c, 0, sizeof(c)); /* defaults: src/MeasurementModel_RngBrg.cpp:35-43 */
+    c.probabilityOfDetection = 0.95; c.uniformClutterIntensity = 0.1;
+    c.rangeLimMax = 5; c.rangeLimMin = 0.3; c.rangeLimBuffer = 0.25;
+    kf.rangeInnovationThreshold = -1; kf.bearingInnovationThreshold = -1;
   }
-  return Pd;
-}
-/* clutterIntensity (:169-172) and clutterIntensityIntegral (:175-178). */
-static inline double rb_clutter(const rfsgpu_rngbrg_config &M) { return M.uniformClutterIntensity; }
-static inline double rb_clutter_integral(const rfsgpu_rngbrg_config &M) {
-  double sensingArea = 2 * PI * (M.rangeLimMax - M.rangeLimMin);
-  return M.uniformClutterIntensity * sensingArea;
-}
-
-/* KalmanFilter_RngBrg::calculateInnovation: src/KalmanFilter_RngBrg.cpp:52-65 (range gate BEFORE wrap). */
-static bool rb_innovation(const rfsgpu_kf_config &K, const double z_exp[2], const double z_act[2], double nu[2]) {
-  nu[0] = z_act[0] - z_exp[0];
-  nu[1] = z_act[1] - z_exp[1];
-  if (K.rangeInnovationThreshold > 0 && fabs(nu[0]) > K.rangeInnovationThreshold) return false;
-  while (nu[1] > PI) nu[1] -= 2 * PI;
-  while (nu[1] < -PI) nu[1] += 2 * PI;
-  if (K.bearingInnovationThreshold > 0 && fabs(nu[1]) > K.bearingInnovationThreshold) return false;
-  return true;
-}
-
-/* KalmanFilter::correct, vector overload: include/KalmanFilter.hpp:261-342.
- * One landmark against all measurements.  lik uses the RAW difference z - z_exp (:317-320), the
- * updated mean uses the wrapped/gated innovation.
- * NOTE (:302): `P_updated = (P_updated + P_updated.transpose())/2` aliases in real Eigen release
- * builds (<= 1 ulp asymmetry left behind); restated here as the intended exact symmetrisation. */
-static bool kf_correct_all(const rfsgpu_rngbrg_config &M, const rfsgpu_kf_config &K, const Pose &pose, const double *Z, int nZ,
-                           const Gauss &lm, std::vector<Gauss> &lmNew, std::vector<double> &lik, std::vector<double> &md2v) {
-  double z_exp[2];
-  M2 S, H;
-  if (!rb_measure(M, pose, lm.x, lm.S, z_exp, S, &H)) {
-    for (int i = 0; i < nZ; i++) { lik[i] = 0; md2v[i] = 0; }
-    return false;
+  bool measure(const Pose &pose, const double *lx, const M2 &lS, double *z, M2 &S, M2 *H) const {
+    return rb_measure_core(c.R, c.rangeLimMax, c.rangeLimMin, pose, lx, lS, z, S, H);
   }
-  M2 S_inv = inv2(S);
-  const M2 &P = lm.S;
-  M2 Kg = mul(mulT(P, H), S_inv);             /* K = P * H^T * S_inv */
-  M2 KH = mul(Kg, H);
-  M2 IKH;
-  IKH(0, 0) = 1.0 - KH(0, 0); IKH(0, 1) = 0.0 - KH(0, 1);
-  IKH(1, 0) = 0.0 - KH(1, 0); IKH(1, 1) = 1.0 - KH(1, 1);
-  M2 Pu = mul(IKH, P);
-  M2 Ps;
-  for (int i = 0; i < 2; i++)
-    for (int j = 0; j < 2; j++) Ps(i, j) = (Pu(i, j) + Pu(j, i)) / 2;
-  for (int i = 0; i < nZ; i++) {
-    const double *z = Z + 2 * i;
-    double nu[2];
-    if (rb_innovation(K, z_exp, z, nu)) {
-      lmNew[i].valid = true;
-      lmNew[i].x[0] = lm.x[0] + (Kg(0, 0) * nu[0] + Kg(0, 1) * nu[1]);
-      lmNew[i].x[1] = lm.x[1] + (Kg(1, 0) * nu[0] + Kg(1, 1) * nu[1]);
-      lmNew[i].S = Ps;
-      double md2;
-      double zl = gauss_lik2(z_exp, S, z, &md2); /* innov.set(z_exp,S); innov.evalGaussianLikelihood(measurement[i], &md2) */
-      if (zl != zl) zl = 0;
-      lik[i] = zl;
-      md2v[i] = md2;
+  void inverse_measure(const Pose &pose, const double *z, double *lx, M2 &lS) const { rb_inverse_measure_core(c.R, pose, z, lx, lS); }
+  /* probabilityOfDetection(): :138-167. */
+  double pd(const Pose &pose, const double *lx, const M2 &, bool &close) const {
+    close = false;
+    double range = sqrt(pow(lx[0] - pose.x[0], 2) + pow(lx[1] - pose.x[1], 2));
+    double Pd;
+    if (range <= c.rangeLimMax && range >= c.rangeLimMin) {
+      Pd = c.probabilityOfDetection;
+      if (range >= (c.rangeLimMax - c.rangeLimBuffer) || range <= (c.rangeLimMin + c.rangeLimBuffer)) close = true;
     } else {
-      lik[i] = 0;
-      md2v[i] = 0;
+      Pd = 0;
+      if (range <= (c.rangeLimMax + c.rangeLimBuffer) && range >= (c.rangeLimMin - c.rangeLimBuffer)) close = true;
     }
+    return Pd;
   }
-  return true;
-}
+  double clutter() const { return c.uniformClutterIntensity; }                          /* :169-172 */
+  double clutter_integral() const {                                                       /* :175-178 */
+    double sensingArea = 2 * PI * (c.rangeLimMax - c.rangeLimMin);
+    return c.uniformClutterIntensity * sensingArea;
+  }
+  /* KalmanFilter_RngBrg::calculateInnovation: src/KalmanFilter_RngBrg.cpp:52-65 (range gate BEFORE wrap). */
+  bool innovation(const double *z_exp, const double *z_act, double *nu) const {
+    nu[0] = z_act[0] - z_exp[0];
+    nu[1] = z_act[1] - z_exp[1];
+    if (kf.rangeInnovationThreshold > 0 && fabs(nu[0]) > kf.rangeInnovationThreshold) return false;
+    while (nu[1] > PI) nu[1] -= 2 * PI;
+    while (nu[1] < -PI) nu[1] += 2 * PI;
+    if (kf.bearingInnovationThreshold > 0 && fabs(nu[1]) > kf.bearingInnovationThreshold) return false;
+    return true;
+  }
+};
+
+/* ---- model policy: Victoria Park (range, bearing, diameter)  src/MeasurementModel_VictoriaPark.cpp,
+ *      include/KalmanFilter_VictoriaPark.hpp ---- */
+struct ModelVP {
+  enum { D = 3 };
+  rfsgpu_vp_config c;
+  rfsgpu_kf_config kf;
+  std::vector<double> scan;
+  double clutterIntensity_;
+  ModelVP() {
+    memset(&c, 0, sizeof(c));
+    kf.rangeInnovationThreshold = -1; kf.bearingInnovationThreshold = -1;
+    clutterIntensity_ = 0;
+  }
+  /* measure(): :104-151.  Pose rebuilt from its MEAN only (covariance dropped, :112-114), heading - pi/2, 2-D
+   * model on (x,y) -- the embedded rangeBearingModel keeps its default range limits and its return value is
+   * ignored -- diameter passes through, S33 = Sigma33 + R33 + r^2 * Slb, H = blockdiag(H2, 1); always true. */
+  bool measure(const Pose &pose, const double *lx, const M3 &lS, double *z, M3 &S, M3 *H) const {
+    Pose tp;
+    tp.x[0] = pose.x[0]; tp.x[1] = pose.x[1]; tp.x[2] = pose.x[2] - PI / 2;
+    memset(tp.P, 0, sizeof(tp.P));
+    M2 S2l, S2, H2;
+    S2l(0, 0) = lS(0, 0); S2l(0, 1) = lS(0, 1); S2l(1, 0) = lS(1, 0); S2l(1, 1) = lS(1, 1);
+    double R2[4] = {c.R[0], c.R[1], c.R[3], c.R[4]};
+    double z2[2];
+    rb_measure_core(R2, 5, 0.3, tp, lx, S2l, z2, S2, &H2);
+    z[0] = z2[0]; z[1] = z2[1]; z[2] = lx[2];
+    S = zeroM<3>();
+    S(0, 0) = S2(0, 0); S(0, 1) = S2(0, 1); S(1, 0) = S2(1, 0); S(1, 1) = S2(1, 1);
+    S(2, 2) = lS(2, 2) + c.R[8] + pow(z2[0], 2) * c.Slb;
+    if (H) {
+      *H = zeroM<3>();
+      (*H)(0, 0) = H2(0, 0); (*H)(0, 1) = H2(0, 1); (*H)(1, 0) = H2(1, 0); (*H)(1, 1) = H2(1, 1);
+      (*H)(2, 2) = 1;
+    }
+    return true;
+  }
+  /* inverseMeasure(): :75-102. */
+  void inverse_measure(const Pose &pose, const double *z, double *lx, M3 &lS) const {
+    Pose tp;
+    tp.x[0] = pose.x[0]; tp.x[1] = pose.x[1]; tp.x[2] = pose.x[2] - PI / 2;
+    memset(tp.P, 0, sizeof(tp.P));
+    double R2[4] = {c.R[0], c.R[1], c.R[3], c.R[4]};
+    M2 c2;
+    rb_inverse_measure_core(R2, tp, z, lx, c2);
+    lS = zeroM<3>();
+    lS(0, 0) = c2(0, 0); lS(0, 1) = c2(0, 1); lS(1, 0) = c2(1, 0); lS(1, 1) = c2(1, 1);
+    lS(2, 2) = c.R[8];
+    lx[2] = z[2];
+  }
+  /* probabilityOfDetection2(): :202-265 (occlusion count against the raw scan, Pd table). */
+  double pd2(const Pose &pose, const double *lx, const M3 &lS, bool &close) const {
+    close = false;
+    double z[3];
+    M3 S;
+    measure(pose, lx, lS, z, S, nullptr);
+    double dist = z[0], angle = z[1];
+    if (angle > c.bearingLimitMax || angle < c.bearingLimitMin || dist < c.rangeLimMin || dist > c.rangeLimMax) return 0;
+    double modified_radius = z[2] / 2;
+    double gamma = atan(modified_radius / z[0]);
+    int maxNumPoints = (int)floor(2 * gamma * 720.0 / (2 * PI));
+    const int tab = c.nPd;
+    if (tab > maxNumPoints && maxNumPoints >= 0 && c.PdTable[maxNumPoints] == 0) return 0;
+    if (tab > maxNumPoints && maxNumPoints >= 0 && c.PdTable[maxNumPoints] < c.bufferZonePd) close = true;
+    int minb = (int)ceil((angle - gamma) * 720.0 / (2 * PI));
+    int maxb = minb + maxNumPoints;
+    while (minb >= 720) minb -= 720;
+    while (minb < 0) minb += 720;
+    while (maxb >= 720) maxb -= 720;
+    while (maxb < 0) maxb += 720;
+    int numPoints = 0;
+    double minrange = dist - modified_radius - 6 * 0.03;
+    if ((maxb - minb + 720) % 720 > 0) {
+      for (int b = minb; b != maxb; b = (b + 1) % 720) {
+        double s = (b < (int)scan.size()) ? scan[b] : 0.0; /* the reference reads past a 361-entry scan here (UB); 0 counts as visible */
+        if (s > minrange || s == 0) numPoints++;
+      }
+    }
+    if (numPoints >= tab) numPoints = tab - 1;
+    if (c.PdTable[numPoints] == 0) close = false;
+    return c.PdTable[numPoints];
+  }
+  /* probabilityOfDetection(): :153-199 (max over laterally shifted copies; `angle` formed as written). */
+  double pd(const Pose &pose, const double *lx, const M3 &lS, bool &close) const {
+    double z[3];
+    M3 S;
+    measure(pose, lx, lS, z, S, nullptr);
+    double angle = atan2(z[1], z[0]) + pose.x[2]; /* sic (:165-166) */
+    double perp[2] = {-sin(angle), cos(angle)};
+    double r0 = perp[0] * lS(0, 0) + perp[1] * lS(1, 0), r1 = perp[0] * lS(0, 1) + perp[1] * lS(1, 1);
+    double sd = r0 * perp[0] + r1 * perp[1];
+    sd = 3 * sqrt(sd);
+    sd = std::max(sd, 0.2);
+    double mn = DBL_MAX, mx = -DBL_MAX;
+    double l2[3] = {lx[0], lx[1], lx[2]};
+    for (int i = 1; (i - 1) * (2 * lx[2]) < sd; i++) {
+      if (i > 100000) break; /* non-positive diameter: the reference never terminates */
+      double s = i * 2 * lx[2];
+      l2[0] = lx[0] + s * perp[0]; l2[1] = lx[1] + s * perp[1];
+      double p = pd2(pose, l2, lS, close);
+      mn = std::min(mn, p); mx = std::max(mx, p);
+      l2[0] = lx[0] - s * perp[0]; l2[1] = lx[1] - s * perp[1];
+      p = pd2(pose, l2, lS, close);
+      mn = std::min(mn, p); mx = std::max(mx, p);
+    }
+    double p = pd2(pose, lx, lS, close);
+    mn = std::min(mn, p); mx = std::max(mx, p);
+    if (mn == 0 && mx > 0) close = true;
+    return mx;
+  }
+  /* setLaserScan(): :267-281. */
+  void set_scan(const double *s, int n) {
+    scan.assign(s, s + n);
+    double FoVArea = 0;
+    for (int i = 1; i < n; i++) FoVArea += scan[i] * scan[i - 1];
+    FoVArea += scan[0] * scan[n - 1];
+    FoVArea *= sin(PI / 360) / 2;
+    clutterIntensity_ = c.expectedClutterNumber / FoVArea;
+  }
+  double clutter() const { return clutterIntensity_; }
+  double clutter_integral() const { return c.expectedClutterNumber; }
+  /* KalmanFilter_VictoriaPark::calculateInnovation: include/KalmanFilter_VictoriaPark.hpp:56-73 (wrap FIRST). */
+  bool innovation(const double *z_exp, const double *z_act, double *nu) const {
+    for (int k = 0; k < 3; k++) nu[k] = z_act[k] - z_exp[k];
+    while (nu[1] > PI) nu[1] -= 2 * PI;
+    while (nu[1] < -PI) nu[1] += 2 * PI;
+    if (kf.rangeInnovationThreshold > 0 && fabs(nu[0]) > kf.rangeInnovationThreshold) return false;
+    if (kf.bearingInnovationThreshold > 0 && fabs(nu[1]) > kf.bearingInnovationThreshold) return false;
+    return true;
+  }
+};
 
 /* ------------------------------------------------------------------------------------------------
  * PermutationLexicographic  (src/PermutationLexicographic.cpp:38-96), restated literally.
@@ -563,185 +712,13 @@ struct CostMatrixGeneral {
   }
 };
 
-/* ------------------------------------------------------------------------------------------------
- * MatPerm::calc  (src/MatrixPermanent.cpp:41-112): Nijenhuis-Wilf / Gray-code Ryser.
- * ---------------------------------------------------------------------------------------------- */
-static double mat_perm(const double *A, int n) {
-  std::vector<double> x(n);
-  std::vector<int> g(n, 0);
-  double p = 0, s = -1;
-  for (int i = 0; i < n; i++) {
-    double row_i_sum = 0;
-    for (int j = 0; j < n; j++) row_i_sum += A[i * n + j];
-    x[i] = A[i * n + (n - 1)] - 0.5 * row_i_sum;
-  }
-  p = s;
-  for (int i = 0; i < n; i++) p *= x[i];
-  for (long long k = 2; k <= (long long)pow(2, n - 1); k++) {
-    int j = 0;
-    if (k % 2 == 0) j = 0;
-    else { j = 1; while (g[j - 1] == 0) j++; }
-    s *= -1;
-    double z = 1 - 2 * g[j];
-    g[j] = !g[j];
-    double x_prod = 1;
-    for (int i = 0; i < n; i++) { x[i] += z * A[i * n + j]; x_prod *= x[i]; }
-    p += s * x_prod;
-  }
-  double retval = 2 * p;
-  if (n % 2 != 0) retval *= -1;
-  return retval;
-}
-
-/* ------------------------------------------------------------------------------------------------
- * The filter state + phases
- * ---------------------------------------------------------------------------------------------- */
-struct Filter {
-  int n;
-  rfsgpu_filter_config cfg;
-  rfsgpu_rngbrg_config model;
-  rfsgpu_kf_config kf;
-  M2 Qlm;
-  std::vector<Pose> pose;
-  std::vector<double> weight;
-  std::vector<std::vector<Gauss>> gm; /* gList_ (may contain holes between merge and prune) */
-  std::vector<int> gm_n;              /* n_ */
-  std::vector<std::vector<unsigned>> unused;
-  std::vector<unsigned> nInFov;
-  std::vector<double> Z; /* measurements_ (2 doubles each) */
-  int nZ = 0;
-  bool stable_sort = false; /* false: std::sort exactly as the reference (GaussianMixture.hpp:523-534);
-                               true : (weight desc, index asc) == what the device path implements */
-  long murty_calls = 0, lonerow_bug_hits = 0;
-  rfsgpu_timing timing;
-  std::string err;
-};
-
-static inline long long now_ns() {
-  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
-/* RBPHDFilter::updateMap  (include/RBPHDFilter.hpp:543-725) for one particle. */
-static void update_map_particle(Filter &F, int i) {
-  const int nZ = F.nZ;
-  std::vector<Gauss> &G = F.gm[i];
-  const unsigned nM = F.gm_n[i]; /* getGaussianCount(); storage has no holes at this point */
-  F.unused[i].clear();
-  F.nInFov[i] = 0;
-  if (nM == 0) {
-    for (int z = 0; z < nZ; z++) F.unused[i].push_back(z);
-    return;
-  }
-  /* per-thread scratch that persists across particles, like the reference's per-thread wTables_/mTables_ (:352-393) */
-  static thread_local std::vector<double> Pd, W, lik, md2;
-  static thread_local std::vector<int> closeLim;
-  static thread_local std::vector<char> Mvalid;
-  static thread_local std::vector<Gauss> Mtab, lmNew;
-  Pd.assign(nM, 0.0);
-  closeLim.assign(nM, 0);
-  double w_km_sum = std::numeric_limits<double>::denorm_min();
-  double likelihoodProd = 1;
-  if (F.cfg.useClusterProcess)
-    for (unsigned m = 0; m < nM; m++) w_km_sum += G[m].w;
-  W.assign((size_t)nM * nZ, 0.0);
-  Mvalid.assign((size_t)nM * nZ, 0);
-  if (Mtab.size() < (size_t)nM * nZ) Mtab.resize((size_t)nM * nZ);
-  const Pose &pose = F.pose[i];
-  const double thr = F.cfg.newGaussianCreateInnovMDThreshold * F.cfg.newGaussianCreateInnovMDThreshold;
-  lik.assign(nZ, 0.0);
-  md2.assign(nZ, 0.0);
-  if (lmNew.size() < (size_t)nZ) lmNew.resize(nZ);
-  for (unsigned m = 0; m < nM; m++) {
-    bool close;
-    Pd[m] = rb_pd(F.model, pose, G[m].x, close);
-    if (close) { closeLim[m] = 1; Pd[m] = 1; } else closeLim[m] = 0;
-    double w_km = G[m].w;
-    double Pd_times_w_km = Pd[m] * w_km;
-    if (Pd[m] != 0) {
-      F.nInFov[i]++;
-      kf_correct_all(F.model, F.kf, pose, F.Z.data(), nZ, G[m], lmNew, lik, md2);
-      for (int z = 0; z < nZ; z++) {
-        if (lik[z] == 0 || md2[z] > thr) { Mvalid[(size_t)m * nZ + z] = 0; W[(size_t)m * nZ + z] = 0; }
-        else { Mvalid[(size_t)m * nZ + z] = 1; Mtab[(size_t)m * nZ + z] = lmNew[z]; W[(size_t)m * nZ + z] = Pd_times_w_km * lik[z]; }
-      }
-    }
-  }
-  for (int z = 0; z < nZ; z++) {
-    double clutter = rb_clutter(F.model);
-    double sum = clutter;
-    for (unsigned m = 0; m < nM; m++) sum += W[(size_t)m * nZ + z];
-    if (F.cfg.useClusterProcess) likelihoodProd *= sum;
-    for (unsigned m = 0; m < nM; m++) W[(size_t)m * nZ + z] = W[(size_t)m * nZ + z] / sum;
-  }
-  if (F.cfg.useClusterProcess) {
-    double prev = F.weight[i];
-    F.weight[i] = exp(w_km_sum) * likelihoodProd * prev;
-  }
-  /* 3. add new Gaussians in (m,z) row-major order (:675-683); addGaussian => w_prev = 0 */
-  for (unsigned m = 0; m < nM; m++)
-    for (int z = 0; z < nZ; z++)
-      if (Mvalid[(size_t)m * nZ + z] && W[(size_t)m * nZ + z] > 0) {
-        Gauss g = Mtab[(size_t)m * nZ + z];
-        g.valid = true; g.w = W[(size_t)m * nZ + z]; g.w_prev = 0;
-        G.push_back(g);
-        F.gm_n[i]++;
-      }
-  /* 4. missed-detection weights (:686-706); setWeight stores the old weight in w_prev */
-  for (unsigned m = 0; m < nM; m++) {
-    double w_km = G[m].w;
-    double w_k = (1 - Pd[m]) * w_km;
-    if (closeLim[m] == 1 && w_km > F.cfg.birthGaussianWeight) {
-      double weight_sum_m = 0;
-      for (int z = 0; z < nZ; z++) weight_sum_m += W[(size_t)m * nZ + z];
-      double delta_w = Pd[m] * w_km - weight_sum_m;
-      if (delta_w > 0) { w_k += delta_w; if (w_k > 1) w_k = 1; }
-    }
-    G[m].w_prev = G[m].w;
-    G[m].w = w_k;
-  }
-  /* 5. unused measurements (:709-720) */
-  F.unused[i].clear();
-  for (int z = 0; z < nZ; z++) {
-    bool used = false;
-    for (unsigned m = 0; m < nM; m++) if (W[(size_t)m * nZ + z] != 0) { used = true; break; }
-    if (!used) F.unused[i].push_back(z);
-  }
-}
-
-/* GaussianMixture::sortByWeight (include/GaussianMixture.hpp:523-534). */
-static bool weightCompare(const Gauss &a, const Gauss &b) { return a.w > b.w; }
-static void sort_by_weight(Filter &F, std::vector<Gauss> &G) {
-  if (F.stable_sort) std::stable_sort(G.begin(), G.end(), weightCompare);
-  else std::sort(G.begin(), G.end(), weightCompare);
-}
-
-/* RBPHDFilter::rfsMeasurementLikelihood (include/RBPHDFilter.hpp:821-997). */
-static double rfs_measurement_likelihood(Filter &F, int i, const std::vector<unsigned> &evalPtIdx, const std::vector<double> &evalPtPd,
-                                         long *murty_calls, long *lonerow_hits) {
-  const Pose &x = F.pose[i];
-  const int nM = (int)evalPtIdx.size();
-  const int nZ = F.nZ;
-  const double threshold = F.cfg.importanceWeightingMeasurementLikelihoodMDThreshold * F.cfg.importanceWeightingMeasurementLikelihoodMDThreshold;
-  CostMatrixGeneral cm(nM, nZ);
-  M2 zeroCov = {{0, 0, 0, 0}};
-  for (int m = 0; m < nM; m++) {
-    const Gauss &ev = F.gm[i][evalPtIdx[m]];
-    double z_exp[2];
-    M2 S;
-    rb_measure(F.model, x, ev.x, zeroCov, z_exp, S, nullptr); /* return value ignored (:852) */
-    double Pd = evalPtPd[m];
-    for (int n = 0; n < nZ; n++) {
-      double md2;
-      double L = gauss_lik2(z_exp, S, &F.Z[2 * n], &md2) * Pd;
-      if (md2 > threshold) L = 0;
-      cm.C_[m][n] = L;
-    }
-  }
+/* The partition / enumeration / Murty part of rfsMeasurementLikelihood (include/RBPHDFilter.hpp:865-996) on a filled
+ * likelihood table.  Returns prod over partitions (NOT yet divided by the clutter integral). */
+static double partitions_likelihood(CostMatrixGeneral &cm, const std::vector<double> &evalPtPd, const std::vector<double> &clutter,
+                                    long *murty_calls, long *lonerow_hits) {
   int nP = cm.partition();
   double l = 1;
   const double BIG_NEG_NUM = -1000;
-  std::vector<double> clutter(nZ);
-  for (int n = 0; n < nZ; n++) clutter[n] = rb_clutter(F.model);
   for (int p = 0; p < nP; p++) {
     double partition_likelihood = 0;
     unsigned nCols, nRows;
@@ -803,154 +780,581 @@ static double rfs_measurement_likelihood(Filter &F, int i, const std::vector<uns
     }
     l *= partition_likelihood;
   }
-  return l / rb_clutter_integral(F.model);
+  return l;
 }
 
-/* RBPHDFilter::importanceWeighting (include/RBPHDFilter.hpp:728-819) for one particle. */
-static void importance_weighting_particle(Filter &F, int idx, long *murty_calls, long *lonerow_hits) {
-  const Pose &x = F.pose[idx];
-  std::vector<Gauss> &G = F.gm[idx];
-  const unsigned nM = F.gm_n[idx];
-  int nEvalPoints = (unsigned)F.cfg.importanceWeightingEvalPointCount > nM ? (int)nM : F.cfg.importanceWeightingEvalPointCount;
-  std::vector<unsigned> evalPointIdx;
-  std::vector<double> evalPointPd;
-  if (nEvalPoints == 0) {
-    F.weight[idx] = std::numeric_limits<double>::denorm_min();
-    return;
+/* ------------------------------------------------------------------------------------------------
+ * MatPerm::calc  (src/MatrixPermanent.cpp:41-112): Nijenhuis-Wilf / Gray-code Ryser.
+ * ---------------------------------------------------------------------------------------------- */
+static double mat_perm(const double *A, int n) {
+  std::vector<double> x(n);
+  std::vector<int> g(n, 0);
+  double p = 0, s = -1;
+  for (int i = 0; i < n; i++) {
+    double row_i_sum = 0;
+    for (int j = 0; j < n; j++) row_i_sum += A[i * n + j];
+    x[i] = A[i * n + (n - 1)] - 0.5 * row_i_sum;
   }
-  sort_by_weight(F, G);
-  for (unsigned m = 0; m < nM; m++) {
-    double w = G[m].w;
-    if (w < F.cfg.importanceWeightingEvalPointGuassianWeight) break;
-    bool close;
-    double Pd = rb_pd(F.model, x, G[m].x, close);
-    if (Pd > 0) { evalPointIdx.push_back(m); evalPointPd.push_back(Pd); }
-    if (nEvalPoints != -1 && evalPointIdx.size() >= (size_t)nEvalPoints) break;
+  p = s;
+  for (int i = 0; i < n; i++) p *= x[i];
+  for (long long k = 2; k <= (long long)pow(2, n - 1); k++) {
+    int j = 0;
+    if (k % 2 == 0) j = 0;
+    else { j = 1; while (g[j - 1] == 0) j++; }
+    s *= -1;
+    double z = 1 - 2 * g[j];
+    g[j] = !g[j];
+    double x_prod = 1;
+    for (int i = 0; i < n; i++) { x[i] += z * A[i * n + j]; x_prod *= x[i]; }
+    p += s * x_prod;
   }
-  nEvalPoints = (int)evalPointIdx.size();
-  double sumBefore = 0, sumAfter = 0;
-  for (unsigned m = 0; m < nM; m++) { sumBefore += G[m].w_prev; sumAfter += G[m].w; }
-  double prodBefore = 1, prodAfter = 1;
-  for (int e = 0; e < nEvalPoints; e++) {
-    const Gauss &ev = G[evalPointIdx[e]];
-    double ib = std::numeric_limits<double>::denorm_min();
-    double ia = std::numeric_limits<double>::denorm_min();
+  double retval = 2 * p;
+  if (n % 2 != 0) retval *= -1;
+  return retval;
+}
+
+static inline long long now_ns() {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * The filter (model-independent interface + template over the model)
+ * ---------------------------------------------------------------------------------------------- */
+struct FilterBase {
+  int n = 0, dm = 2, dz = 2;
+  rfsgpu_filter_config cfg;
+  std::vector<Pose> pose;
+  std::vector<double> weight;
+  std::vector<std::vector<unsigned>> unused;
+  std::vector<unsigned> nInFov;
+  std::vector<double> Z; /* measurements_ (dz doubles each) */
+  int nZ = 0;
+  bool stable_sort = false; /* false: std::sort exactly as the reference (GaussianMixture.hpp:523-534);
+                               true : (weight desc, index asc) == what the device path implements */
+  long murty_calls = 0, lonerow_bug_hits = 0;
+  rfsgpu_timing timing;
+  std::string err;
+  virtual ~FilterBase() {}
+  virtual int gm_size(int slot) = 0;
+  virtual void import_gm(int slot, int cnt, const double *w, const double *mean, const double *cov) = 0;
+  virtual int export_gm(int slot, int max_n, double *w, double *wp, double *mean, double *cov) = 0;
+  virtual int get_landmark(int slot, int m, double *mean, double *cov, double *w) = 0;
+  virtual int predict_map(int add_birth) = 0;
+  virtual void update_map() = 0;
+  virtual void importance_weighting() = 0;
+  virtual void merge() = 0;
+  virtual void prune() = 0;
+  virtual void copy_particle(int dst, int src) = 0;
+  virtual void set_lmk_noise(const double *Q) = 0;
+  virtual int export_candidates(int slot, int max_n, double *mean, double *cov, int *support, int *checks) = 0;
+  virtual void import_candidates(int slot, int cnt, const double *mean, const double *cov, const int *support, const int *checks) = 0;
+};
+
+template <class M>
+struct FilterT : FilterBase {
+  enum { D = M::D };
+  typedef GaussT<D> Gauss;
+  typedef Mat<D> MatD;
+  struct Candidate { /* RBPHDFilter::BirthGaussianCandidate (:173-177) */
+    double x[D];
+    MatD S;
+    unsigned nSupportingMeasurements, nChecks;
+  };
+  M model;
+  MatD Qlm;
+  std::vector<std::vector<Gauss>> gm; /* gList_ (may contain holes between merge and prune) */
+  std::vector<int> gm_n;              /* n_ */
+  std::vector<std::list<Candidate>> cand; /* birthGaussians_ */
+
+  explicit FilterT(int n_) {
+    n = n_; dm = D; dz = D;
+    Qlm = zeroM<D>();
+    pose.assign(n, Pose{});
+    weight.assign(n, 1.0);
+    gm.assign(n, {});
+    gm_n.assign(n, 0);
+    cand.assign(n, {});
+    unused.assign(n, {});
+    nInFov.assign(n, 0);
+    memset(&timing, 0, sizeof(timing));
+  }
+
+  /* KalmanFilter::correct, vector overload: include/KalmanFilter.hpp:261-342.  One landmark against all measurements.
+   * lik uses the RAW difference z - z_exp (:317-320), the updated mean uses the wrapped/gated innovation.
+   * NOTE (:302): `P_updated = (P_updated + P_updated.transpose())/2` aliases in real Eigen release builds (<= 1 ulp
+   * asymmetry left behind); restated here as the intended exact symmetrisation. */
+  bool kf_correct_all(const Pose &ps, const Gauss &lm, std::vector<Gauss> &lmNew, std::vector<double> &lik, std::vector<double> &md2v) {
+    double z_exp[D];
+    MatD S, H;
+    if (!model.measure(ps, lm.x, lm.S, z_exp, S, &H)) {
+      for (int i = 0; i < nZ; i++) { lik[i] = 0; md2v[i] = 0; }
+      return false;
+    }
+    MatD S_inv = inv(S);
+    const MatD &P = lm.S;
+    MatD Kg = mul(mulT(P, H), S_inv); /* K = P * H^T * S_inv */
+    MatD KH = mul(Kg, H);
+    MatD IKH;
+    for (int i = 0; i < D; i++)
+      for (int j = 0; j < D; j++) IKH(i, j) = (i == j ? 1.0 : 0.0) - KH(i, j);
+    MatD Pu = mul(IKH, P);
+    MatD Ps;
+    for (int i = 0; i < D; i++)
+      for (int j = 0; j < D; j++) Ps(i, j) = (Pu(i, j) + Pu(j, i)) / 2;
+    for (int i = 0; i < nZ; i++) {
+      const double *z = &Z[(size_t)D * i];
+      double nu[D];
+      if (model.innovation(z_exp, z, nu)) {
+        lmNew[i].valid = true;
+        for (int r = 0; r < D; r++) {
+          double s = Kg(r, 0) * nu[0];
+          for (int k = 1; k < D; k++) s += Kg(r, k) * nu[k];
+          lmNew[i].x[r] = lm.x[r] + s;
+        }
+        lmNew[i].S = Ps;
+        double m2;
+        double zl = gauss_lik<D>(z_exp, S, z, &m2); /* innov.set(z_exp,S); innov.evalGaussianLikelihood(measurement[i], &md2) */
+        if (zl != zl) zl = 0;
+        lik[i] = zl;
+        md2v[i] = m2;
+      } else {
+        lik[i] = 0;
+        md2v[i] = 0;
+      }
+    }
+    return true;
+  }
+  /* KalmanFilter::correct, single-measurement overload (:209-259), used by addBirthGaussians. */
+  bool kf_correct_one(const Pose &ps, const double *z, const double *lx, const MatD &lS, double *ox, MatD &oS) {
+    double z_exp[D];
+    MatD S, H;
+    if (!model.measure(ps, lx, lS, z_exp, S, &H)) return false;
+    MatD S_inv = inv(S);
+    double nu[D];
+    if (!model.innovation(z_exp, z, nu)) return false;
+    MatD Kg = mul(mulT(lS, H), S_inv);
+    MatD KH = mul(Kg, H);
+    MatD IKH;
+    for (int i = 0; i < D; i++)
+      for (int j = 0; j < D; j++) IKH(i, j) = (i == j ? 1.0 : 0.0) - KH(i, j);
+    MatD Pu = mul(IKH, lS);
+    double nx[D];
+    for (int r = 0; r < D; r++) {
+      double s = Kg(r, 0) * nu[0];
+      for (int k = 1; k < D; k++) s += Kg(r, k) * nu[k];
+      nx[r] = lx[r] + s;
+    }
+    MatD Ps;
+    for (int i = 0; i < D; i++)
+      for (int j = 0; j < D; j++) Ps(i, j) = (Pu(i, j) + Pu(j, i)) / 2;
+    oS = Ps;
+    for (int r = 0; r < D; r++) ox[r] = nx[r];
+    return true;
+  }
+
+  /* RBPHDFilter::updateMap  (include/RBPHDFilter.hpp:543-725) for one particle. */
+  void update_map_particle(int i) {
+    std::vector<Gauss> &G = gm[i];
+    const unsigned nM = gm_n[i]; /* getGaussianCount(); storage has no holes at this point */
+    unused[i].clear();
+    nInFov[i] = 0;
+    if (nM == 0) {
+      for (int z = 0; z < nZ; z++) unused[i].push_back(z);
+      return;
+    }
+    /* per-thread scratch that persists across particles, like the reference's per-thread wTables_/mTables_ (:352-393) */
+    static thread_local std::vector<double> Pd, W, lik, md2v;
+    static thread_local std::vector<int> closeLim;
+    static thread_local std::vector<char> Mvalid;
+    static thread_local std::vector<Gauss> Mtab, lmNew;
+    Pd.assign(nM, 0.0);
+    closeLim.assign(nM, 0);
+    double w_km_sum = std::numeric_limits<double>::denorm_min();
+    double likelihoodProd = 1;
+    if (cfg.useClusterProcess)
+      for (unsigned m = 0; m < nM; m++) w_km_sum += G[m].w;
+    W.assign((size_t)nM * nZ, 0.0);
+    Mvalid.assign((size_t)nM * nZ, 0);
+    if (Mtab.size() < (size_t)nM * nZ) Mtab.resize((size_t)nM * nZ);
+    const Pose &ps = pose[i];
+    const double thr = cfg.newGaussianCreateInnovMDThreshold * cfg.newGaussianCreateInnovMDThreshold;
+    lik.assign(nZ, 0.0);
+    md2v.assign(nZ, 0.0);
+    if (lmNew.size() < (size_t)nZ) lmNew.resize(nZ);
     for (unsigned m = 0; m < nM; m++) {
-      double likelihood = gauss_lik2(G[m].x, G[m].S, ev.x, nullptr);
-      ib += G[m].w_prev * likelihood;
-      ia += G[m].w * likelihood;
+      bool close;
+      Pd[m] = model.pd(ps, G[m].x, G[m].S, close);
+      if (close) { closeLim[m] = 1; Pd[m] = 1; } else closeLim[m] = 0;
+      double w_km = G[m].w;
+      double Pd_times_w_km = Pd[m] * w_km;
+      if (Pd[m] != 0) {
+        nInFov[i]++;
+        kf_correct_all(ps, G[m], lmNew, lik, md2v);
+        for (int z = 0; z < nZ; z++) {
+          if (lik[z] == 0 || md2v[z] > thr) { Mvalid[(size_t)m * nZ + z] = 0; W[(size_t)m * nZ + z] = 0; }
+          else { Mvalid[(size_t)m * nZ + z] = 1; Mtab[(size_t)m * nZ + z] = lmNew[z]; W[(size_t)m * nZ + z] = Pd_times_w_km * lik[z]; }
+        }
+      }
     }
-    prodBefore *= ib;
-    prodAfter *= ia;
-  }
-  double measurementLikelihood = rfs_measurement_likelihood(F, idx, evalPointIdx, evalPointPd, murty_calls, lonerow_hits);
-  double overall_weight = measurementLikelihood * prodBefore / prodAfter * exp(sumAfter - sumBefore);
-  double prev_weight = F.weight[idx];
-  F.weight[idx] = overall_weight * prev_weight;
-}
-
-/* GaussianMixture::merge(idx1, idx2)  (include/GaussianMixture.hpp:419-475). */
-static bool merge_pair(std::vector<Gauss> &G, int &n_, unsigned i1, unsigned i2, double t, double f) {
-  if (!G[i1].valid || !G[i2].valid) return false;
-  double w_1 = G[i1].w, w_2 = G[i2].w;
-  double t2 = t * t;
-  double d1 = md2_2(G[i1].x, inv2(G[i1].S), G[i2].x);
-  if (d1 > t2) {
-    double d2 = md2_2(G[i2].x, inv2(G[i2].S), G[i1].x);
-    if (d2 > t2) return false;
-  }
-  double w_m = w_1 + w_2;
-  if (w_m == 0) return false;
-  double x_m[2], d_1[2], d_2[2];
-  for (int k = 0; k < 2; k++) x_m[k] = (G[i1].x[k] * w_1 + G[i2].x[k] * w_2) / w_m;
-  for (int k = 0; k < 2; k++) { d_1[k] = x_m[k] - G[i1].x[k]; d_2[k] = x_m[k] - G[i2].x[k]; }
-  M2 S_m;
-  for (int r = 0; r < 2; r++)
-    for (int c = 0; c < 2; c++) {
-      /* S_m = ( w_1*(S_1 + f*d_1*d_1^T) + w_2*(S_2 + f*d_2*d_2^T) ) / w_m ; (f*d) is formed first */
-      double a = w_1 * (G[i1].S(r, c) + (f * d_1[r]) * d_1[c]);
-      double b = w_2 * (G[i2].S(r, c) + (f * d_2[r]) * d_2[c]);
-      S_m(r, c) = (a + b) / w_m;
+    for (int z = 0; z < nZ; z++) {
+      double clutter = model.clutter();
+      double sum = clutter;
+      for (unsigned m = 0; m < nM; m++) sum += W[(size_t)m * nZ + z];
+      if (cfg.useClusterProcess) likelihoodProd *= sum;
+      for (unsigned m = 0; m < nM; m++) W[(size_t)m * nZ + z] = W[(size_t)m * nZ + z] / sum;
     }
-  G[i1].x[0] = x_m[0]; G[i1].x[1] = x_m[1];
-  G[i1].S = S_m;
-  G[i1].w = w_m;
-  G[i1].w_prev = 0;
-  /* removeGaussian(idx2) (:310-322) */
-  G[i2].valid = false; G[i2].w = 0; G[i2].w_prev = 0;
-  n_--;
-  return true;
-}
-/* GaussianMixture::merge(t, f)  (:394-416). */
-static unsigned merge_particle(Filter &F, int i) {
-  std::vector<Gauss> &G = F.gm[i];
-  unsigned nMerged = 0;
-  unsigned nG = G.size();
-  for (unsigned a = 0; a < nG; a++) {
-    if (!G[a].valid) continue;
-    for (unsigned b = a + 1; b < nG; b++)
-      if (merge_pair(G, F.gm_n[i], a, b, F.cfg.gaussianMergingThreshold, F.cfg.gaussianMergingCovarianceInflationFactor)) nMerged++;
+    if (cfg.useClusterProcess) {
+      double prev = weight[i];
+      weight[i] = exp(w_km_sum) * likelihoodProd * prev;
+    }
+    /* 3. add new Gaussians in (m,z) row-major order (:675-683); addGaussian => w_prev = 0 */
+    for (unsigned m = 0; m < nM; m++)
+      for (int z = 0; z < nZ; z++)
+        if (Mvalid[(size_t)m * nZ + z] && W[(size_t)m * nZ + z] > 0) {
+          Gauss g = Mtab[(size_t)m * nZ + z];
+          g.valid = true; g.w = W[(size_t)m * nZ + z]; g.w_prev = 0;
+          G.push_back(g);
+          gm_n[i]++;
+        }
+    /* 4. missed-detection weights (:686-706); setWeight stores the old weight in w_prev */
+    for (unsigned m = 0; m < nM; m++) {
+      double w_km = G[m].w;
+      double w_k = (1 - Pd[m]) * w_km;
+      if (closeLim[m] == 1 && w_km > cfg.birthGaussianWeight) {
+        double weight_sum_m = 0;
+        for (int z = 0; z < nZ; z++) weight_sum_m += W[(size_t)m * nZ + z];
+        double delta_w = Pd[m] * w_km - weight_sum_m;
+        if (delta_w > 0) { w_k += delta_w; if (w_k > 1) w_k = 1; }
+      }
+      G[m].w_prev = G[m].w;
+      G[m].w = w_k;
+    }
+    /* 5. unused measurements (:709-720) */
+    unused[i].clear();
+    for (int z = 0; z < nZ; z++) {
+      bool used = false;
+      for (unsigned m = 0; m < nM; m++) if (W[(size_t)m * nZ + z] != 0) { used = true; break; }
+      if (!used) unused[i].push_back(z);
+    }
   }
-  return nMerged;
-}
-/* GaussianMixture::prune(t)  (:477-521), binary search + linear walk restated literally. */
-static unsigned prune_particle(Filter &F, int i) {
-  std::vector<Gauss> &G = F.gm[i];
-  const double t = F.cfg.gaussianPruningThreshold;
-  unsigned nPruned = 0;
-  if (G.size() < 1) return 0;
-  sort_by_weight(F, G);
-  unsigned min_idx = 0, max_idx = G.size() - 1;
-  unsigned idx = (max_idx + min_idx) / 2;
-  unsigned idx_old = idx + 1;
-  double w = G[idx].w;
-  while (idx != idx_old) {
-    if (w <= t) max_idx = idx;
-    else if (w > t) min_idx = idx;
-    idx_old = idx;
-    idx = (max_idx + min_idx) / 2;
-    w = G[idx].w;
-  }
-  while (w >= t) {
-    idx++;
-    if (idx >= G.size()) break;
-    w = G[idx].w;
-  }
-  idx_old = idx;
-  while (idx < G.size()) {
-    if (G[idx].valid) { G[idx].valid = false; G[idx].w = 0; G[idx].w_prev = 0; F.gm_n[i]--; }
-    idx++;
-    nPruned++;
-  }
-  G.resize(G.size() - nPruned);
-  return nPruned;
-}
 
-/* RBPHDFilter::addBirthGaussians (include/RBPHDFilter.hpp:1000-1084), immediate-birth branch:
- * birthGaussianMeasurementCountThreshold == 1 or nLandmarksInFOV <= birthGaussianCurrentMeasurementCountThreshold.
- * (The candidate-list branch is outside the device path's current scope; it is refused loudly.) */
-static int add_birth_particle(Filter &F, int i) {
-  while (F.unused[i].size() > 0) {
-    int zi = F.unused[i].back();
-    F.unused[i].pop_back();
-    bool immediate = F.cfg.birthGaussianMeasurementCountThreshold == 1 || F.nInFov[i] <= F.cfg.birthGaussianCurrentMeasurementCountThreshold;
-    if (!immediate) return RFSGPU_ERR_UNSUPPORTED;
+  /* GaussianMixture::sortByWeight (include/GaussianMixture.hpp:523-534). */
+  static bool weightCompare(const Gauss &a, const Gauss &b) { return a.w > b.w; }
+  void sort_by_weight(std::vector<Gauss> &G) {
+    if (stable_sort) std::stable_sort(G.begin(), G.end(), weightCompare);
+    else std::sort(G.begin(), G.end(), weightCompare);
+  }
+
+  /* RBPHDFilter::rfsMeasurementLikelihood (include/RBPHDFilter.hpp:821-997). */
+  double rfs_measurement_likelihood(int i, const std::vector<unsigned> &evalPtIdx, const std::vector<double> &evalPtPd, long *mc, long *lr) {
+    const Pose &x = pose[i];
+    const int nE = (int)evalPtIdx.size();
+    const double threshold = cfg.importanceWeightingMeasurementLikelihoodMDThreshold * cfg.importanceWeightingMeasurementLikelihoodMDThreshold;
+    CostMatrixGeneral cm(nE, nZ);
+    MatD zeroCov = zeroM<D>();
+    for (int m = 0; m < nE; m++) {
+      const Gauss &ev = gm[i][evalPtIdx[m]];
+      double z_exp[D];
+      MatD S;
+      model.measure(x, ev.x, zeroCov, z_exp, S, nullptr); /* evalPt_copy.setCov(Zero); return value ignored (:850-852) */
+      double Pd = evalPtPd[m];
+      for (int nn = 0; nn < nZ; nn++) {
+        double m2;
+        double L = gauss_lik<D>(z_exp, S, &Z[(size_t)D * nn], &m2) * Pd;
+        if (m2 > threshold) L = 0;
+        cm.C_[m][nn] = L;
+      }
+    }
+    std::vector<double> clutter(nZ);
+    for (int nn = 0; nn < nZ; nn++) clutter[nn] = model.clutter();
+    double l = partitions_likelihood(cm, evalPtPd, clutter, mc, lr);
+    return l / model.clutter_integral();
+  }
+
+  /* RBPHDFilter::importanceWeighting (include/RBPHDFilter.hpp:728-819) for one particle. */
+  void importance_weighting_particle(int idx, long *mc, long *lr) {
+    const Pose &x = pose[idx];
+    std::vector<Gauss> &G = gm[idx];
+    const unsigned nM = gm_n[idx];
+    int nEvalPoints = (unsigned)cfg.importanceWeightingEvalPointCount > nM ? (int)nM : cfg.importanceWeightingEvalPointCount;
+    std::vector<unsigned> evalPointIdx;
+    std::vector<double> evalPointPd;
+    if (nEvalPoints == 0) {
+      weight[idx] = std::numeric_limits<double>::denorm_min();
+      return;
+    }
+    sort_by_weight(G);
+    for (unsigned m = 0; m < nM; m++) {
+      double w = G[m].w;
+      if (w < cfg.importanceWeightingEvalPointGuassianWeight) break;
+      bool close;
+      double Pd = model.pd(x, G[m].x, G[m].S, close);
+      if (Pd > 0) { evalPointIdx.push_back(m); evalPointPd.push_back(Pd); }
+      if (nEvalPoints != -1 && evalPointIdx.size() >= (size_t)nEvalPoints) break;
+    }
+    nEvalPoints = (int)evalPointIdx.size();
+    double sumBefore = 0, sumAfter = 0;
+    for (unsigned m = 0; m < nM; m++) { sumBefore += G[m].w_prev; sumAfter += G[m].w; }
+    double prodBefore = 1, prodAfter = 1;
+    for (int e = 0; e < nEvalPoints; e++) {
+      const Gauss &ev = G[evalPointIdx[e]];
+      double ib = std::numeric_limits<double>::denorm_min();
+      double ia = std::numeric_limits<double>::denorm_min();
+      for (unsigned m = 0; m < nM; m++) {
+        double likelihood = gauss_lik<D>(G[m].x, G[m].S, ev.x, nullptr);
+        ib += G[m].w_prev * likelihood;
+        ia += G[m].w * likelihood;
+      }
+      prodBefore *= ib;
+      prodAfter *= ia;
+    }
+    double measurementLikelihood = rfs_measurement_likelihood(idx, evalPointIdx, evalPointPd, mc, lr);
+    double overall_weight = measurementLikelihood * prodBefore / prodAfter * exp(sumAfter - sumBefore);
+    double prev_weight = weight[idx];
+    weight[idx] = overall_weight * prev_weight;
+  }
+
+  /* GaussianMixture::merge(idx1, idx2)  (include/GaussianMixture.hpp:419-475). */
+  bool merge_pair(std::vector<Gauss> &G, int &n_, unsigned i1, unsigned i2, double t, double f) {
+    if (!G[i1].valid || !G[i2].valid) return false;
+    double w_1 = G[i1].w, w_2 = G[i2].w;
+    double t2 = t * t;
+    double d1 = md2<D>(G[i1].x, inv(G[i1].S), G[i2].x);
+    if (d1 > t2) {
+      double d2 = md2<D>(G[i2].x, inv(G[i2].S), G[i1].x);
+      if (d2 > t2) return false;
+    }
+    double w_m = w_1 + w_2;
+    if (w_m == 0) return false;
+    double x_m[D], d_1[D], d_2[D];
+    for (int k = 0; k < D; k++) x_m[k] = (G[i1].x[k] * w_1 + G[i2].x[k] * w_2) / w_m;
+    for (int k = 0; k < D; k++) { d_1[k] = x_m[k] - G[i1].x[k]; d_2[k] = x_m[k] - G[i2].x[k]; }
+    MatD S_m;
+    for (int r = 0; r < D; r++)
+      for (int c = 0; c < D; c++) {
+        /* S_m = ( w_1*(S_1 + f*d_1*d_1^T) + w_2*(S_2 + f*d_2*d_2^T) ) / w_m ; (f*d) is formed first */
+        double a = w_1 * (G[i1].S(r, c) + (f * d_1[r]) * d_1[c]);
+        double b = w_2 * (G[i2].S(r, c) + (f * d_2[r]) * d_2[c]);
+        S_m(r, c) = (a + b) / w_m;
+      }
+    for (int k = 0; k < D; k++) G[i1].x[k] = x_m[k];
+    G[i1].S = S_m;
+    G[i1].w = w_m;
+    G[i1].w_prev = 0;
+    G[i2].valid = false; G[i2].w = 0; G[i2].w_prev = 0; /* removeGaussian(idx2) (:310-322) */
+    n_--;
+    return true;
+  }
+  /* GaussianMixture::merge(t, f)  (:394-416). */
+  void merge_particle(int i) {
+    std::vector<Gauss> &G = gm[i];
+    unsigned nG = G.size();
+    for (unsigned a = 0; a < nG; a++) {
+      if (!G[a].valid) continue;
+      for (unsigned b = a + 1; b < nG; b++) merge_pair(G, gm_n[i], a, b, cfg.gaussianMergingThreshold, cfg.gaussianMergingCovarianceInflationFactor);
+    }
+  }
+  /* GaussianMixture::prune(t)  (:477-521), binary search + linear walk restated literally. */
+  void prune_particle(int i) {
+    std::vector<Gauss> &G = gm[i];
+    const double t = cfg.gaussianPruningThreshold;
+    unsigned nPruned = 0;
+    if (G.size() < 1) return;
+    sort_by_weight(G);
+    unsigned min_idx = 0, max_idx = G.size() - 1;
+    unsigned idx = (max_idx + min_idx) / 2;
+    unsigned idx_old = idx + 1;
+    double w = G[idx].w;
+    while (idx != idx_old) {
+      if (w <= t) max_idx = idx;
+      else if (w > t) min_idx = idx;
+      idx_old = idx;
+      idx = (max_idx + min_idx) / 2;
+      w = G[idx].w;
+    }
+    while (w >= t) {
+      idx++;
+      if (idx >= G.size()) break;
+      w = G[idx].w;
+    }
+    while (idx < G.size()) {
+      if (G[idx].valid) { G[idx].valid = false; G[idx].w = 0; G[idx].w_prev = 0; gm_n[i]--; }
+      idx++;
+      nPruned++;
+    }
+    G.resize(G.size() - nPruned);
+  }
+
+  void add_gaussian(int i, const double *x, const MatD &S, double w) { /* GaussianMixture::addGaussian(p, w, true) :267-284 */
     Gauss g;
-    g.valid = true; g.w = F.cfg.birthGaussianWeight; g.w_prev = 0;
-    rb_inverse_measure(F.model, F.pose[i], &F.Z[2 * zi], g.x, g.S);
-    F.gm[i].push_back(g);
-    F.gm_n[i]++;
+    g.valid = true; g.w = w; g.w_prev = 0;
+    for (int k = 0; k < D; k++) g.x[k] = x[k];
+    g.S = S;
+    gm[i].push_back(g);
+    gm_n[i]++;
   }
-  return RFSGPU_OK;
-}
+  /* RBPHDFilter::addBirthGaussians (include/RBPHDFilter.hpp:1000-1084) for one particle (the parent-state copy at
+   * :1005-1011 is done when the resample plan is applied).  The promotion loop (:1062-1080) increments the iterator after
+   * erase() may have returned end(): with libstdc++'s circular std::list, ++end() is begin(), so when the LAST candidate
+   * is erased while others remain the loop wraps and visits the survivors again.  Restated as that behaviour. */
+  void add_birth_particle(int i) {
+    std::list<Candidate> &L = cand[i];
+    while (unused[i].size() > 0) {
+      int zi = unused[i].back();
+      const double *uz = &Z[(size_t)D * zi];
+      unused[i].pop_back();
+      bool isNew = true;
+      for (auto it = L.begin(); it != L.end(); it++) {
+        double z_exp[D];
+        MatD S;
+        model.measure(pose[i], it->x, it->S, z_exp, S, nullptr);
+        double d2 = md2<D>(z_exp, inv(S), uz); /* z_exp.mahalanobisDist2(unused_z) */
+        if (d2 <= cfg.birthGaussianMeasurementSupportDist * cfg.birthGaussianMeasurementSupportDist) {
+          kf_correct_one(pose[i], uz, it->x, it->S, it->x, it->S);
+          (it->nSupportingMeasurements)++;
+          isNew = false;
+          break;
+        }
+      }
+      if (isNew) {
+        Candidate c;
+        c.nSupportingMeasurements = 1;
+        c.nChecks = 0;
+        model.inverse_measure(pose[i], uz, c.x, c.S);
+        if (cfg.birthGaussianMeasurementCountThreshold == 1 || nInFov[i] <= cfg.birthGaussianCurrentMeasurementCountThreshold)
+          add_gaussian(i, c.x, c.S, cfg.birthGaussianWeight);
+        else
+          L.push_back(c);
+      }
+    }
+    auto it = L.begin();
+    while (it != L.end()) {
+      it->nChecks++;
+      while (it->nSupportingMeasurements >= cfg.birthGaussianMeasurementCountThreshold || it->nChecks > cfg.birthGaussianMeasurementCheckThreshold ||
+             nInFov[i] <= cfg.birthGaussianCurrentMeasurementCountThreshold) {
+        if (it->nSupportingMeasurements >= cfg.birthGaussianMeasurementCountThreshold) add_gaussian(i, it->x, it->S, cfg.birthGaussianWeight);
+        else if (nInFov[i] <= cfg.birthGaussianCurrentMeasurementCountThreshold) add_gaussian(i, it->x, it->S, cfg.birthGaussianWeight);
+        it = L.erase(it);
+        if (it != L.end()) it->nChecks++;
+        else break;
+      }
+      if (it == L.end()) it = L.begin(); /* for-loop's it++ on end(): wraps to begin() (== end() when the list is empty) */
+      else ++it;
+    }
+  }
+
+  /* ---- FilterBase ---- */
+  int gm_size(int slot) override { return gm_n[slot]; }
+  void import_gm(int slot, int cnt, const double *w, const double *mean, const double *cov) override {
+    gm[slot].clear();
+    for (int m = 0; m < cnt; m++) {
+      Gauss g;
+      g.valid = true; g.w = w[m]; g.w_prev = 0;
+      for (int k = 0; k < D; k++) g.x[k] = mean[D * m + k];
+      memcpy(g.S.a, cov + (size_t)D * D * m, D * D * sizeof(double));
+      gm[slot].push_back(g);
+    }
+    gm_n[slot] = cnt;
+  }
+  int export_gm(int slot, int max_n, double *w, double *wp, double *mean, double *cov) override {
+    int k = 0;
+    for (const Gauss &g : gm[slot]) {
+      if (!g.valid) continue;
+      if (k < max_n) {
+        if (w) w[k] = g.w;
+        if (wp) wp[k] = g.w_prev;
+        if (mean) for (int d = 0; d < D; d++) mean[D * k + d] = g.x[d];
+        if (cov) memcpy(cov + (size_t)D * D * k, g.S.a, D * D * sizeof(double));
+      }
+      k++;
+    }
+    return k;
+  }
+  int get_landmark(int slot, int m, double *mean, double *cov, double *w) override {
+    if (m < 0 || m >= gm_n[slot] || m >= (int)gm[slot].size()) return RFSGPU_ERR_INVALID;
+    const Gauss &g = gm[slot][m];
+    for (int d = 0; d < D; d++) mean[d] = g.x[d];
+    memcpy(cov, g.S.a, D * D * sizeof(double));
+    *w = g.w;
+    return RFSGPU_OK;
+  }
+  int predict_map(int add_birth) override {
+    long long t0 = now_ns();
+    for (int i = 0; i < n; i++) {
+      if (add_birth) add_birth_particle(i);
+      for (Gauss &g : gm[i]) /* staticStep: S += Q (include/ProcessModel.hpp:195-208) */
+        for (int k = 0; k < D * D; k++) g.S.a[k] += Qlm.a[k];
+    }
+    timing.predict_wall += now_ns() - t0;
+    return RFSGPU_OK;
+  }
+  void update_map() override {
+    long long t0 = now_ns();
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < n; i++) update_map_particle(i);
+    timing.mapUpdate_wall += now_ns() - t0;
+  }
+  void importance_weighting() override {
+    long long t0 = now_ns();
+    long mc = 0, lr = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : mc, lr)
+    for (int i = 0; i < n; i++) importance_weighting_particle(i, &mc, &lr);
+    murty_calls += mc; lonerow_bug_hits += lr;
+    timing.particleWeighting_wall += now_ns() - t0;
+  }
+  void merge() override {
+    long long t0 = now_ns();
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < n; i++) merge_particle(i);
+    timing.mapMerge_wall += now_ns() - t0;
+  }
+  void prune() override {
+    long long t0 = now_ns();
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < n; i++) prune_particle(i);
+    timing.mapPrune_wall += now_ns() - t0;
+  }
+  void copy_particle(int dst, int src) override {
+    gm[dst] = gm[src]; gm_n[dst] = gm_n[src];
+    unused[dst] = unused[src]; nInFov[dst] = nInFov[src];
+    cand[dst] = cand[src]; /* birthGaussians_[i] = birthGaussians_[i_prev] (:1005-1011) */
+  }
+  void set_lmk_noise(const double *Q) override { memcpy(Qlm.a, Q, D * D * sizeof(double)); }
+  int export_candidates(int slot, int max_n, double *mean, double *cov, int *support, int *checks) override {
+    int k = 0;
+    for (const Candidate &c : cand[slot]) {
+      if (k < max_n) {
+        for (int d = 0; d < D; d++) mean[D * k + d] = c.x[d];
+        memcpy(cov + (size_t)D * D * k, c.S.a, D * D * sizeof(double));
+        support[k] = (int)c.nSupportingMeasurements;
+        checks[k] = (int)c.nChecks;
+      }
+      k++;
+    }
+    return k;
+  }
+  void import_candidates(int slot, int cnt, const double *mean, const double *cov, const int *support, const int *checks) override {
+    cand[slot].clear();
+    for (int k = 0; k < cnt; k++) {
+      Candidate c;
+      for (int d = 0; d < D; d++) c.x[d] = mean[D * k + d];
+      memcpy(c.S.a, cov + (size_t)D * D * k, D * D * sizeof(double));
+      c.nSupportingMeasurements = (unsigned)support[k];
+      c.nChecks = (unsigned)checks[k];
+      cand[slot].push_back(c);
+    }
+  }
+};
 
 } /* namespace orc */
 
 /* ================================================================================================
  * C API: same shape as include/rfsgpu.h with prefix rfsor_, so one ctypes wrapper drives both.
  * ============================================================================================== */
-using orc::Filter;
-#define F_(f) (reinterpret_cast<Filter *>(f))
+using orc::FilterBase;
+#define F_(f) (reinterpret_cast<FilterBase *>(f))
+#define FRB_(f) (dynamic_cast<orc::FilterT<orc::ModelRB> *>(F_(f)))
+#define FVP_(f) (dynamic_cast<orc::FilterT<orc::ModelVP> *>(F_(f)))
 
 extern "C" {
 
@@ -977,37 +1381,47 @@ void rfsor_default_filter_config(rfsgpu_filter_config *c) { /* RBPHDFilter.hpp:3
 
 int rfsor_create(void **out, int model, int n_particles, int device_id, int gm_capacity) {
   (void)device_id; (void)gm_capacity;
-  if (!out || n_particles <= 0 || model != RFSGPU_MODEL_RNGBRG_2D) return RFSGPU_ERR_INVALID;
-  Filter *F = new Filter();
-  F->n = n_particles;
+  if (!out || n_particles <= 0) return RFSGPU_ERR_INVALID;
+  FilterBase *F = nullptr;
+  if (model == RFSGPU_MODEL_RNGBRG_2D) F = new orc::FilterT<orc::ModelRB>(n_particles);
+  else if (model == RFSGPU_MODEL_VICTORIAPARK_3D) F = new orc::FilterT<orc::ModelVP>(n_particles);
+  else return RFSGPU_ERR_INVALID;
   rfsor_default_filter_config(&F->cfg);
-  /* MeasurementModel_RngBrg defaults, src/MeasurementModel_RngBrg.cpp:35-43 */
-  memset(&F->model, 0, sizeof(F->model));
-  F->model.probabilityOfDetection = 0.95; F->model.uniformClutterIntensity = 0.1;
-  F->model.rangeLimMax = 5; F->model.rangeLimMin = 0.3; F->model.rangeLimBuffer = 0.25;
-  F->kf.rangeInnovationThreshold = -1; F->kf.bearingInnovationThreshold = -1;
-  memset(&F->Qlm, 0, sizeof(F->Qlm));
-  F->pose.assign(n_particles, orc::Pose{});
-  F->weight.assign(n_particles, 1.0);
-  F->gm.assign(n_particles, {});
-  F->gm_n.assign(n_particles, 0);
-  F->unused.assign(n_particles, {});
-  F->nInFov.assign(n_particles, 0);
-  memset(&F->timing, 0, sizeof(F->timing));
   *out = F;
   return RFSGPU_OK;
 }
 void rfsor_destroy(void *f) { delete F_(f); }
-const char *rfsor_last_error(const void *f) { return f ? reinterpret_cast<const Filter *>(f)->err.c_str() : "null handle"; }
+const char *rfsor_last_error(const void *f) { return f ? reinterpret_cast<const FilterBase *>(f)->err.c_str() : "null handle"; }
 
 int rfsor_set_filter_config(void *f, const rfsgpu_filter_config *c) { F_(f)->cfg = *c; return RFSGPU_OK; }
-int rfsor_get_filter_config(const void *f, rfsgpu_filter_config *c) { *c = reinterpret_cast<const Filter *>(f)->cfg; return RFSGPU_OK; }
-int rfsor_set_model_rngbrg(void *f, const rfsgpu_rngbrg_config *c) { F_(f)->model = *c; return RFSGPU_OK; }
-int rfsor_set_kf_config(void *f, const rfsgpu_kf_config *c) { F_(f)->kf = *c; return RFSGPU_OK; }
-int rfsor_set_lmk_process_noise(void *f, const double *Q) { memcpy(F_(f)->Qlm.a, Q, 4 * sizeof(double)); return RFSGPU_OK; }
+int rfsor_get_filter_config(const void *f, rfsgpu_filter_config *c) { *c = reinterpret_cast<const FilterBase *>(f)->cfg; return RFSGPU_OK; }
+int rfsor_set_model_rngbrg(void *f, const rfsgpu_rngbrg_config *c) {
+  auto *F = FRB_(f);
+  if (!F) return RFSGPU_ERR_INVALID;
+  F->model.c = *c;
+  return RFSGPU_OK;
+}
+int rfsor_set_model_victoriapark(void *f, const rfsgpu_vp_config *c) {
+  auto *F = FVP_(f);
+  if (!F) return RFSGPU_ERR_INVALID;
+  F->model.c = *c;
+  return RFSGPU_OK;
+}
+int rfsor_set_laser_scan(void *f, const double *scan, int n) {
+  auto *F = FVP_(f);
+  if (!F || n <= 0) return RFSGPU_ERR_INVALID;
+  F->model.set_scan(scan, n);
+  return RFSGPU_OK;
+}
+int rfsor_set_kf_config(void *f, const rfsgpu_kf_config *c) {
+  if (auto *F = FRB_(f)) { F->model.kf = *c; return RFSGPU_OK; }
+  if (auto *F = FVP_(f)) { F->model.kf = *c; return RFSGPU_OK; }
+  return RFSGPU_ERR_INVALID;
+}
+int rfsor_set_lmk_process_noise(void *f, const double *Q) { F_(f)->set_lmk_noise(Q); return RFSGPU_OK; }
 
 int rfsor_set_poses(void *f, const double *x, const double *cov, int cov_stride) {
-  Filter *F = F_(f);
+  FilterBase *F = F_(f);
   for (int i = 0; i < F->n; i++) {
     memcpy(F->pose[i].x, x + 3 * i, 3 * sizeof(double));
     if (cov) memcpy(F->pose[i].P, cov + (size_t)cov_stride * i, 9 * sizeof(double));
@@ -1016,130 +1430,82 @@ int rfsor_set_poses(void *f, const double *x, const double *cov, int cov_stride)
   return RFSGPU_OK;
 }
 int rfsor_get_poses(void *f, double *x) {
-  Filter *F = F_(f);
+  FilterBase *F = F_(f);
   for (int i = 0; i < F->n; i++) memcpy(x + 3 * i, F->pose[i].x, 3 * sizeof(double));
   return RFSGPU_OK;
 }
-int rfsor_set_weights(void *f, const double *w) { Filter *F = F_(f); F->weight.assign(w, w + F->n); return RFSGPU_OK; }
-int rfsor_get_weights(void *f, double *w) { Filter *F = F_(f); memcpy(w, F->weight.data(), F->n * sizeof(double)); return RFSGPU_OK; }
+int rfsor_set_weights(void *f, const double *w) { FilterBase *F = F_(f); F->weight.assign(w, w + F->n); return RFSGPU_OK; }
+int rfsor_get_weights(void *f, double *w) { FilterBase *F = F_(f); memcpy(w, F->weight.data(), F->n * sizeof(double)); return RFSGPU_OK; }
 
-int rfsor_gm_size(void *f, int slot) { Filter *F = F_(f); return (slot >= 0 && slot < F->n) ? F->gm_n[slot] : -1; }
-int rfsor_gm_sizes(void *f, int *sizes) { Filter *F = F_(f); for (int i = 0; i < F->n; i++) sizes[i] = F->gm_n[i]; return RFSGPU_OK; }
+int rfsor_gm_size(void *f, int slot) { FilterBase *F = F_(f); return (slot >= 0 && slot < F->n) ? F->gm_size(slot) : -1; }
+int rfsor_gm_sizes(void *f, int *sizes) { FilterBase *F = F_(f); for (int i = 0; i < F->n; i++) sizes[i] = F->gm_size(i); return RFSGPU_OK; }
 
 int rfsor_import_gm(void *f, int slot, int n, const double *w, const double *mean, const double *cov) {
-  Filter *F = F_(f);
+  FilterBase *F = F_(f);
   if (slot < 0 || slot >= F->n || n < 0) return RFSGPU_ERR_INVALID;
-  F->gm[slot].clear();
-  for (int m = 0; m < n; m++) {
-    orc::Gauss g;
-    g.valid = true; g.w = w[m]; g.w_prev = 0;
-    g.x[0] = mean[2 * m]; g.x[1] = mean[2 * m + 1];
-    memcpy(g.S.a, cov + 4 * m, 4 * sizeof(double));
-    F->gm[slot].push_back(g);
-  }
-  F->gm_n[slot] = n;
+  F->import_gm(slot, n, w, mean, cov);
   return RFSGPU_OK;
 }
 /* Exports VALID Gaussians in storage order (holes skipped). */
 int rfsor_export_gm(void *f, int slot, int max_n, int *n_out, double *w, double *w_prev, double *mean, double *cov) {
-  Filter *F = F_(f);
+  FilterBase *F = F_(f);
   if (slot < 0 || slot >= F->n) return RFSGPU_ERR_INVALID;
-  int k = 0;
-  for (const orc::Gauss &g : F->gm[slot]) {
-    if (!g.valid) continue;
-    if (k < max_n) {
-      if (w) w[k] = g.w;
-      if (w_prev) w_prev[k] = g.w_prev;
-      if (mean) { mean[2 * k] = g.x[0]; mean[2 * k + 1] = g.x[1]; }
-      if (cov) memcpy(cov + 4 * k, g.S.a, 4 * sizeof(double));
-    }
-    k++;
-  }
+  int k = F->export_gm(slot, max_n, w, w_prev, mean, cov);
   if (n_out) *n_out = k;
   return RFSGPU_OK;
 }
 int rfsor_get_landmark(void *f, int slot, int m, double *mean, double *cov, double *w) {
-  Filter *F = F_(f);
-  if (slot < 0 || slot >= F->n || m < 0 || m >= F->gm_n[slot] || m >= (int)F->gm[slot].size()) return RFSGPU_ERR_INVALID;
-  const orc::Gauss &g = F->gm[slot][m];
-  mean[0] = g.x[0]; mean[1] = g.x[1];
-  memcpy(cov, g.S.a, 4 * sizeof(double));
-  *w = g.w;
-  return RFSGPU_OK;
+  FilterBase *F = F_(f);
+  if (slot < 0 || slot >= F->n) return RFSGPU_ERR_INVALID;
+  return F->get_landmark(slot, m, mean, cov, w);
 }
-
 int rfsor_import_aux(void *f, int slot, const int *unused_idx, int n_unused, int n_in_fov) {
-  Filter *F = F_(f);
+  FilterBase *F = F_(f);
   if (slot < 0 || slot >= F->n) return RFSGPU_ERR_INVALID;
   F->unused[slot].assign(unused_idx, unused_idx + n_unused);
   F->nInFov[slot] = (unsigned)n_in_fov;
   return RFSGPU_OK;
 }
-
-int rfsor_predict_map(void *f, int add_birth) {
-  Filter *F = F_(f);
-  long long t0 = orc::now_ns();
-  int rc = RFSGPU_OK;
-  for (int i = 0; i < F->n; i++) {
-    if (add_birth) { int r = orc::add_birth_particle(*F, i); if (r != RFSGPU_OK) rc = r; }
-    for (orc::Gauss &g : F->gm[i]) /* staticStep: S += Q (include/ProcessModel.hpp:195-208) */
-      for (int k = 0; k < 4; k++) g.S.a[k] += F->Qlm.a[k];
-  }
-  F->timing.predict_wall += orc::now_ns() - t0;
-  if (rc != RFSGPU_OK) F->err = "birth-candidate list mode not restated";
-  return rc;
+int rfsor_export_birth_candidates(void *f, int slot, int max_n, int *n_out, double *mean, double *cov, int *support, int *checks) {
+  FilterBase *F = F_(f);
+  if (slot < 0 || slot >= F->n) return RFSGPU_ERR_INVALID;
+  int k = F->export_candidates(slot, max_n, mean, cov, support, checks);
+  if (n_out) *n_out = k;
+  return RFSGPU_OK;
 }
+int rfsor_import_birth_candidates(void *f, int slot, int n, const double *mean, const double *cov, const int *support, const int *checks) {
+  FilterBase *F = F_(f);
+  if (slot < 0 || slot >= F->n || n < 0) return RFSGPU_ERR_INVALID;
+  F->import_candidates(slot, n, mean, cov, support, checks);
+  return RFSGPU_OK;
+}
+
+int rfsor_predict_map(void *f, int add_birth) { return F_(f)->predict_map(add_birth); }
 
 int rfsor_update_map(void *f, const double *z, int n_z) {
-  Filter *F = F_(f);
+  FilterBase *F = F_(f);
   if (n_z < 0) return RFSGPU_ERR_INVALID;
-  F->Z.assign(z, z + 2 * (size_t)n_z);
+  F->Z.assign(z, z + (size_t)F->dz * n_z);
   F->nZ = n_z;
-  long long t0 = orc::now_ns();
-#pragma omp parallel for schedule(dynamic, 1)
-  for (int i = 0; i < F->n; i++) orc::update_map_particle(*F, i);
-  F->timing.mapUpdate_wall += orc::now_ns() - t0;
+  F->update_map();
   return RFSGPU_OK;
 }
-int rfsor_importance_weighting(void *f) {
-  Filter *F = F_(f);
-  long long t0 = orc::now_ns();
-  long mc = 0, lr = 0;
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : mc, lr)
-  for (int i = 0; i < F->n; i++) orc::importance_weighting_particle(*F, i, &mc, &lr);
-  F->murty_calls += mc; F->lonerow_bug_hits += lr;
-  F->timing.particleWeighting_wall += orc::now_ns() - t0;
-  return RFSGPU_OK;
-}
-int rfsor_merge(void *f) {
-  Filter *F = F_(f);
-  long long t0 = orc::now_ns();
-#pragma omp parallel for schedule(dynamic, 1)
-  for (int i = 0; i < F->n; i++) orc::merge_particle(*F, i);
-  F->timing.mapMerge_wall += orc::now_ns() - t0;
-  return RFSGPU_OK;
-}
-int rfsor_prune(void *f) {
-  Filter *F = F_(f);
-  long long t0 = orc::now_ns();
-#pragma omp parallel for schedule(dynamic, 1)
-  for (int i = 0; i < F->n; i++) orc::prune_particle(*F, i);
-  F->timing.mapPrune_wall += orc::now_ns() - t0;
-  return RFSGPU_OK;
-}
+int rfsor_importance_weighting(void *f) { F_(f)->importance_weighting(); return RFSGPU_OK; }
+int rfsor_merge(void *f) { F_(f)->merge(); return RFSGPU_OK; }
+int rfsor_prune(void *f) { F_(f)->prune(); return RFSGPU_OK; }
 /* RBPHDFilter::update body (:444-523). */
 int rfsor_update(void *f, const double *z, int n_z) {
-  Filter *F = F_(f);
+  FilterBase *F = F_(f);
   if (n_z == 0) return RFSGPU_OK; /* :450-452 */
   rfsor_update_map(f, z, n_z);
-  if (!F->cfg.useClusterProcess) rfsor_importance_weighting(f);
-  rfsor_merge(f);
-  rfsor_prune(f);
+  if (!F->cfg.useClusterProcess) F->importance_weighting();
+  F->merge();
+  F->prune();
   return RFSGPU_OK;
 }
 
 int rfsor_get_unused(void *f, int slot, int *idx, int max_n, int *n_out) {
-  Filter *F = F_(f);
+  FilterBase *F = F_(f);
   if (slot < 0 || slot >= F->n) return RFSGPU_ERR_INVALID;
   int k = 0;
   for (unsigned u : F->unused[slot]) { if (k < max_n) idx[k] = (int)u; k++; }
@@ -1147,7 +1513,7 @@ int rfsor_get_unused(void *f, int slot, int *idx, int max_n, int *n_out) {
   return RFSGPU_OK;
 }
 int rfsor_landmarks_in_fov(void *f, int slot, int *n_out) {
-  Filter *F = F_(f);
+  FilterBase *F = F_(f);
   if (slot < 0 || slot >= F->n) return RFSGPU_ERR_INVALID;
   *n_out = (int)F->nInFov[slot];
   return RFSGPU_OK;
@@ -1155,7 +1521,7 @@ int rfsor_landmarks_in_fov(void *f, int slot, int *n_out) {
 
 /* ParticleFilter::normalizeWeights (include/ParticleFilter.hpp:352-363) split in its two loops. */
 int rfsor_weight_sums(void *f, double *out) {
-  Filter *F = F_(f);
+  FilterBase *F = F_(f);
   double s = 0, s2 = 0;
   for (int i = 0; i < F->n; i++) { s += F->weight[i]; s2 += F->weight[i] * F->weight[i]; }
   out[0] = s; out[1] = s2;
@@ -1163,18 +1529,15 @@ int rfsor_weight_sums(void *f, double *out) {
 }
 int rfsor_normalize_weights(void *f, double sum, const void *sum_dev) {
   (void)sum_dev;
-  Filter *F = F_(f);
+  FilterBase *F = F_(f);
   for (int i = 0; i < F->n; i++) F->weight[i] = F->weight[i] / sum;
   return RFSGPU_OK;
 }
 int rfsor_resample_apply(void *f, const int *src) {
-  Filter *F = F_(f);
+  FilterBase *F = F_(f);
   for (int k = 0; k < F->n; k++) if (src[k] < 0 || src[k] >= F->n || src[src[k]] != src[k]) return RFSGPU_ERR_INVALID;
   for (int k = 0; k < F->n; k++) {
-    if (src[k] != k) {
-      F->gm[k] = F->gm[src[k]]; F->gm_n[k] = F->gm_n[src[k]];
-      F->unused[k] = F->unused[src[k]]; F->nInFov[k] = F->nInFov[src[k]];
-    }
+    if (src[k] != k) F->copy_particle(k, src[k]);
     F->weight[k] = 1;
   }
   return RFSGPU_OK;
@@ -1255,6 +1618,32 @@ long rfsor_murty_calls(void *f) { return F_(f)->murty_calls; }
 long rfsor_lonerow_bug_hits(void *f) { return F_(f)->lonerow_bug_hits; }
 long rfsor_hungarian_failures(void) { return orc::g_hungarian_fail; }
 
+/* Victoria Park model probes for unit tests: Pd (with near-limit flag) and measure(). */
+double rfsor_vp_pd(void *f, const double *pose3, const double *lx3, const double *lS9, int *close_out) {
+  auto *F = FVP_(f);
+  orc::Pose p;
+  memcpy(p.x, pose3, sizeof(p.x));
+  memset(p.P, 0, sizeof(p.P));
+  orc::M3 S;
+  memcpy(S.a, lS9, sizeof(S.a));
+  bool close;
+  double v = F->model.pd(p, lx3, S, close);
+  if (close_out) *close_out = close ? 1 : 0;
+  return v;
+}
+void rfsor_vp_measure(void *f, const double *pose3, const double *lx3, const double *lS9, double *z3, double *S9, double *H9) {
+  auto *F = FVP_(f);
+  orc::Pose p;
+  memcpy(p.x, pose3, sizeof(p.x));
+  memset(p.P, 0, sizeof(p.P));
+  orc::M3 lS, S, H;
+  memcpy(lS.a, lS9, sizeof(lS.a));
+  F->model.measure(p, lx3, lS, z3, S, &H);
+  memcpy(S9, S.a, sizeof(S.a));
+  memcpy(H9, H.a, sizeof(H.a));
+}
+double rfsor_vp_clutter(void *f) { return FVP_(f)->model.clutter(); }
+
 /* PermutationLexicographic restatement, flattened: writes up to max_perm permutations of length nM+nZ. */
 int rfsor_permlex_all(unsigned nM, unsigned nZ, unsigned *out, int max_perm) {
   orc::PermLex pl(nM, nZ, true);
@@ -1294,71 +1683,11 @@ int rfsor_murty(double *C, int n, int nR, int nC, int kmax, double *scores, int 
  * the partition / enumeration / Murty part only (RBPHDFilter.hpp:865-996) -- for unit tests. */
 double rfsor_partition_likelihood(const double *L, int nE, int nZ, const double *evalPd, double clutter, double clutterIntegral,
                                   long *murty_calls, long *lonerow_hits) {
-  /* build a throw-away filter whose model reproduces `clutter` and whose table is injected */
   orc::CostMatrixGeneral cm(nE, nZ);
   for (int m = 0; m < nE; m++)
     for (int n = 0; n < nZ; n++) cm.C_[m][n] = L[m * nZ + n];
-  int nP = cm.partition();
-  double l = 1;
-  const double BIG = -1000;
-  for (int p = 0; p < nP; p++) {
-    double pl = 0;
-    unsigned nCols, nRows;
-    std::vector<std::vector<double>> Cp;
-    std::vector<unsigned> rowIdx, colIdx;
-    bool zero = !cm.getPartitionSize(p, nRows, nCols);
-    bool useMurty = !(nRows + nCols <= 8 || zero);
-    zero = !cm.getPartition(p, Cp, nRows, nCols, rowIdx, colIdx, useMurty);
-    if (zero) {
-      pl = 1;
-      for (unsigned r = 0; r < nRows; r++) pl *= evalPd[rowIdx[r]];
-      for (unsigned c = 0; c < nCols; c++) pl *= clutter;
-    } else {
-      if (nCols == 0 && nRows == 1 && lonerow_hits) (*lonerow_hits)++;
-      for (unsigned r = 0; r < nRows; r++)
-        for (unsigned c = 0; c < nCols; c++) {
-          if (Cp[r][c] == 0) Cp[r][c] = BIG;
-          else { Cp[r][c] = log(Cp[r][c]); if (Cp[r][c] < BIG) Cp[r][c] = BIG; }
-        }
-      if (useMurty) {
-        for (unsigned r = 0; r < nRows; r++)
-          for (unsigned c = nCols; c < nRows + nCols; c++) Cp[r][c] = (r == c - nCols) ? log(1 - evalPd[rowIdx[r]]) : BIG;
-        for (unsigned r = nRows; r < nRows + nCols; r++)
-          for (unsigned c = 0; c < nCols; c++) Cp[r][c] = (r - nRows == c) ? log(clutter) : BIG;
-        for (unsigned r = nRows; r < nRows + nCols; r++)
-          for (unsigned c = nCols; c < nRows + nCols; c++) Cp[r][c] = 0;
-        std::vector<double *> rows(nRows + nCols);
-        for (unsigned r = 0; r < nRows + nCols; r++) rows[r] = Cp[r].data();
-        orc::Murty murty(rows.data(), nRows + nCols);
-        if (murty_calls) (*murty_calls)++;
-        murty.setRealAssignmentBlock(nRows, nCols);
-        std::vector<int> a;
-        double pll = 0;
-        for (int k = 0; k < 200; k++) {
-          int rank = murty.findNextBest(a, pll);
-          if (rank == -1 || pll < BIG) break;
-          pl += exp(pll);
-        }
-      } else {
-        std::vector<unsigned> o(nRows + nCols);
-        orc::PermLex perm(nRows, nCols, true);
-        unsigned nPerm = perm.next(o.data());
-        while (nPerm != 0) {
-          double pll = 0;
-          for (unsigned a = 0; a < nRows; a++) {
-            if (o[a] < nCols) pll += Cp[a][o[a]];
-            else pll += log(1 - evalPd[rowIdx[a]]);
-          }
-          for (unsigned a = nRows; a < nRows + nCols; a++)
-            if (o[a] < nCols) pll += log(clutter);
-          pl += exp(pll);
-          nPerm = perm.next(o.data());
-        }
-      }
-    }
-    l *= pl;
-  }
-  return l / clutterIntegral;
+  std::vector<double> pd(evalPd, evalPd + nE), cl(nZ, clutter);
+  return orc::partitions_likelihood(cm, pd, cl, murty_calls, lonerow_hits) / clutterIntegral;
 }
 
 } /* extern "C" */

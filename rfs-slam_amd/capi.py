@@ -14,6 +14,9 @@ import numpy as np
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_NO_DEVICE, ERR_UNSUPPORTED = 1, 2, 3, 4, 5
 MODEL_RNGBRG_2D = 0
+MODEL_VICTORIAPARK_3D = 1
+VP_MAX_PD = 16
+MAX_CANDIDATES = 64
 MAX_Z = 64
 MAX_EVAL = 64
 
@@ -51,6 +54,22 @@ class RngBrgConfig(C.Structure):
     ]
 
 
+class VPConfig(C.Structure):
+    """MeasurementModel_VictoriaPark::Config + R, Slb (include/MeasurementModel_VictoriaPark.hpp:150-158)."""
+    _fields_ = [
+        ("R", C.c_double * 9),
+        ("Slb", C.c_double),
+        ("PdTable", C.c_double * VP_MAX_PD),
+        ("nPd", C.c_int),
+        ("expectedClutterNumber", C.c_double),
+        ("rangeLimMax", C.c_double),
+        ("rangeLimMin", C.c_double),
+        ("bearingLimitMax", C.c_double),
+        ("bearingLimitMin", C.c_double),
+        ("bufferZonePd", C.c_double),
+    ]
+
+
 class KFConfig(C.Structure):
     """KalmanFilter_RngBrg::Config (include/KalmanFilter_RngBrg.hpp:55-60)."""
     _fields_ = [("rangeInnovationThreshold", C.c_double), ("bearingInnovationThreshold", C.c_double)]
@@ -72,6 +91,7 @@ ABI_SYMBOLS = [
     "weight_sums", "weight_sums_async", "weight_sums_device_ptr", "normalize_weights", "resample_apply",
     "get_timing", "reset_timing", "synchronize", "stream", "last_kernel_ns", "mat_perm",
     "set_stream", "bind_weight_sums_buffer", "save_state", "restore_state", "import_aux",
+    "set_model_victoriapark", "set_laser_scan", "export_birth_candidates", "import_birth_candidates",
 ]
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -97,8 +117,8 @@ class CFilter:
     def __init__(self, lib, prefix, n_particles, model=MODEL_RNGBRG_2D, device_id=0, gm_capacity=512):
         self._lib, self._p = lib, prefix
         self.n = int(n_particles)
-        self.dm = 2
-        self.dz = 2
+        self.model = model
+        self.dm = self.dz = 3 if model == MODEL_VICTORIAPARK_3D else 2
         self._h = C.c_void_p()
         fn = self._fn("create")
         fn.restype = C.c_int
@@ -162,6 +182,42 @@ class CFilter:
         m.probabilityOfDetection, m.uniformClutterIntensity = Pd, c
         m.rangeLimMax, m.rangeLimMin, m.rangeLimBuffer = rmax, rmin, rbuf
         self._call("set_model_rngbrg", C.byref(m))
+
+    def set_model_victoriapark(self, R, Slb, pd_table, expected_clutter, rmax, rmin, bmax, bmin, buffer_pd):
+        m = VPConfig()
+        R = _f64(R, (9,))
+        for k in range(9):
+            m.R[k] = R[k]
+        m.Slb = Slb
+        pd_table = list(pd_table)
+        assert len(pd_table) <= VP_MAX_PD
+        for k, v in enumerate(pd_table):
+            m.PdTable[k] = v
+        m.nPd = len(pd_table)
+        m.expectedClutterNumber = expected_clutter
+        m.rangeLimMax, m.rangeLimMin, m.bearingLimitMax, m.bearingLimitMin, m.bufferZonePd = rmax, rmin, bmax, bmin, buffer_pd
+        self._call("set_model_victoriapark", C.byref(m))
+
+    def set_laser_scan(self, scan):
+        s = _f64(scan).reshape(-1)
+        self._call("set_laser_scan", self._ptr(s), C.c_int(s.size))
+
+    def export_birth_candidates(self, i):
+        n = MAX_CANDIDATES
+        mean, cov = np.empty((n, self.dm)), np.empty((n, self.dm, self.dm))
+        sup, chk = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32)
+        nout = C.c_int()
+        self._call("export_birth_candidates", C.c_int(i), C.c_int(n), C.byref(nout), self._ptr(mean), self._ptr(cov), self._ptr(sup), self._ptr(chk))
+        k = min(nout.value, n)
+        return mean[:k], cov[:k], sup[:k], chk[:k]
+
+    def import_birth_candidates(self, i, mean, cov, sup, chk):
+        sup = np.ascontiguousarray(sup, dtype=np.int32)
+        k = sup.size
+        mean = _f64(mean, (k, self.dm)) if k else np.zeros((0, self.dm))
+        cov = _f64(cov, (k, self.dm, self.dm)) if k else np.zeros((0, self.dm, self.dm))
+        chk = np.ascontiguousarray(chk, dtype=np.int32)
+        self._call("import_birth_candidates", C.c_int(i), C.c_int(k), self._ptr(mean), self._ptr(cov), self._ptr(sup), self._ptr(chk))
 
     def set_kf_config(self, range_thr, bearing_thr):
         k = KFConfig(range_thr, bearing_thr)

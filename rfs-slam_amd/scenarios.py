@@ -105,7 +105,10 @@ def apply_params(f, P):
 
 def load_scenario(f, scen, maps=True):
     """(Re-)inject a scenario's state into a filter handle."""
-    apply_params(f, scen["params"])
+    if scen.get("model") == "vp":
+        apply_vp_params(f, scen["params"], scen["scan"])
+    else:
+        apply_params(f, scen["params"])
     f.set_poses(scen["poses"], scen["pose_cov"])
     f.set_weights(scen["particle_w"])
     if maps:
@@ -120,6 +123,8 @@ def match_gm(a, b, rtol=1e-10, atol=1e-12):
     assert wa.size == wb.size, f"GM size {wa.size} != {wb.size}"
     if wa.size == 0:
         return 0.0
+    ca = (ca + np.swapaxes(ca, -1, -2)) / 2   # the device stores Sigma packed-symmetric
+    cb = (cb + np.swapaxes(cb, -1, -2)) / 2
     A = np.concatenate([wa[:, None], ma, ca.reshape(wa.size, -1)], 1)
     B = np.concatenate([wb[:, None], mb, cb.reshape(wb.size, -1)], 1)
     ia = np.lexsort(np.round(A, 9).T[::-1])
@@ -145,3 +150,82 @@ def assert_gm_close(a, b, rtol=1e-10, atol=1e-12, ordered=False):
             np.testing.assert_allclose(x, y, rtol=rtol, atol=atol)
     else:
         match_gm(a, b, rtol, atol)
+
+
+# ---- Victoria Park (config 4): parameter values of the reference's cfg/rbphdslam_VictoriaPark_artificialClutter.xml ----
+VP_PARAMS = dict(
+    R=np.diag([0.025, 2.5e-5, 0.002]) * 40.0, Slb=1e-5, pd_table=[0.0, 0.05, 0.35, 0.76, 0.89, 0.90], expected_clutter=6.0,
+    rmax=70.0, rmin=5.0, bmax=np.deg2rad(177.0), bmin=np.deg2rad(6.3025), buffer_pd=0.4,
+    kf_range=7.5, kf_bearing=0.2, new_gaussian_md=3.0, n_eval=15, min_weight=0.75, weighting_md=3.0,
+    merge_thr=1.0, merge_infl=1.5, prune_thr=0.01, birth_w=0.01, use_cluster=0,
+    birth_count_thr=5, birth_check_thr=10, birth_support_dist=2.0, birth_cur_thr=2,
+    Q_lm=np.diag([5e-4, 5e-4, 1e-4]) * 0.025 ** 2, min_updates=2, min_measurements=15,
+)
+
+
+def make_vp_scenario(n_particles, n_landmarks, n_z, seed=4242, scan="const", params=None, weights=(0.3, 1.0), frac_in_fov=0.8):
+    """Victoria-Park-shaped state: landmarks (x, y, trunk diameter) in front of the vehicle, measurements
+    (range, bearing, diameter); the laser scan is the synthetic constant-70 m one of SURVEY §8d (the dataset's LASER.txt is
+    missing) or a ragged one that exercises the occlusion count."""
+    P = dict(VP_PARAMS)
+    if params:
+        P.update(params)
+    rng = np.random.default_rng(seed)
+    n_in = int(round(n_landmarks * frac_in_fov))
+    r = rng.uniform(8.0, 60.0, n_landmarks)
+    b = rng.uniform(np.deg2rad(15), np.deg2rad(165), n_landmarks)
+    out = np.arange(n_landmarks) >= n_in
+    r[out] = rng.uniform(80.0, 120.0, out.sum())          # beyond the range limit
+    d = rng.uniform(0.3, 1.5, n_landmarks)
+    th0 = 0.3                                              # vehicle heading; the sensor frame is heading - pi/2
+    gt = np.stack([r * np.cos(th0 - np.pi / 2 + b), r * np.sin(th0 - np.pi / 2 + b), d], 1)
+    perm = rng.permutation(n_landmarks)
+    gt, r, b, out = gt[perm], r[perm], b[perm], out[perm]
+    poses = np.array([0.0, 0.0, th0]) + rng.normal(0, 1, (n_particles, 3)) * np.array([0.05, 0.05, 0.004])
+    means = gt[None] + rng.normal(0, 1, (n_particles, n_landmarks, 3)) * np.array([0.08, 0.08, 0.03])
+    A = rng.normal(0, 1, (n_particles, n_landmarks, 3, 3)) * np.array([0.25, 0.25, 0.08])[None, None, :, None]
+    covs = A @ np.swapaxes(A, -1, -2) + np.diag([0.01, 0.01, 0.002])
+    w = rng.uniform(weights[0], weights[1], (n_particles, n_landmarks))
+    n_clutter = max(1, n_z // 4) if n_z > 1 else 0
+    n_det = min(n_z - n_clutter, int((~out).sum()))
+    n_clutter = n_z - n_det
+    det = rng.choice(np.nonzero(~out)[0], n_det, replace=False) if n_det > 0 else np.zeros(0, int)
+    Rm = np.asarray(P["R"]) / 40.0
+    Zd = np.stack([r[det] + rng.normal(0, np.sqrt(Rm[0, 0]), n_det), b[det] + rng.normal(0, np.sqrt(Rm[1, 1]), n_det),
+                   gt[det, 2] + rng.normal(0, np.sqrt(Rm[2, 2]), n_det)], 1)
+    Zc = np.stack([rng.uniform(P["rmin"], P["rmax"], n_clutter), rng.uniform(P["bmin"], P["bmax"], n_clutter), np.ones(n_clutter)], 1)
+    Z = np.concatenate([Zd, Zc], 0)
+    Z = Z[rng.permutation(n_z)] if n_z > 0 else Z.reshape(0, 3)
+    if isinstance(scan, str) and scan == "const":
+        scan = np.full(361, 70.0)
+    elif isinstance(scan, str):
+        scan = rng.uniform(20.0, 80.0, 361)
+        scan[rng.integers(0, 361, 20)] = 0.0               # no-return beams count as visible
+    return dict(n=n_particles, nM=n_landmarks, poses=poses, pose_cov=np.zeros((3, 3)), w=w, mean=means, cov=covs, Z=Z,
+                particle_w=np.ones(n_particles), params=P, gt=gt, scan=np.asarray(scan, dtype=np.float64), model="vp")
+
+
+def apply_vp_params(f, P, scan):
+    cfg = f.default_filter_config()
+    cfg.birthGaussianWeight = P["birth_w"]
+    cfg.birthGaussianMeasurementCountThreshold = P["birth_count_thr"]
+    cfg.birthGaussianMeasurementCheckThreshold = P["birth_check_thr"]
+    cfg.birthGaussianMeasurementSupportDist = P["birth_support_dist"]
+    cfg.birthGaussianCurrentMeasurementCountThreshold = P["birth_cur_thr"]
+    cfg.newGaussianCreateInnovMDThreshold = P["new_gaussian_md"]
+    cfg.importanceWeightingEvalPointCount = P["n_eval"]
+    cfg.importanceWeightingEvalPointGuassianWeight = P["min_weight"]
+    cfg.importanceWeightingMeasurementLikelihoodMDThreshold = P["weighting_md"]
+    cfg.gaussianMergingThreshold = P["merge_thr"]
+    cfg.gaussianMergingCovarianceInflationFactor = P["merge_infl"]
+    cfg.gaussianPruningThreshold = P["prune_thr"]
+    cfg.useClusterProcess = P["use_cluster"]
+    cfg.minUpdatesBeforeResample = P["min_updates"]
+    cfg.minMeasurementsBeforeResample = P["min_measurements"]
+    f.set_filter_config(cfg)
+    if hasattr(f, "config"):
+        f.config = cfg
+    f.set_model_victoriapark(P["R"], P["Slb"], P["pd_table"], P["expected_clutter"], P["rmax"], P["rmin"], P["bmax"], P["bmin"], P["buffer_pd"])
+    f.set_kf_config(P["kf_range"], P["kf_bearing"])
+    f.set_lmk_process_noise(P["Q_lm"])
+    f.set_laser_scan(scan)
