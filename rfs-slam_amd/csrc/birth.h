@@ -1,0 +1,233 @@
+// birth.h -- map part of RBPHDFilter::predict for BOTH models, with the complete addBirthGaussians logic
+// (reference include/RBPHDFilter.hpp:1000-1084): unused measurements are consumed back to front; each is matched against
+// the particle's birth candidates (measure() + raw Mahalanobis distance <= SupportDist^2 -> single-measurement KF correct
+// (KalmanFilter.hpp:209-259) + support count), otherwise inverseMeasure() creates a candidate that is born immediately
+// (CountThreshold == 1 or few landmarks in the FOV) or queued; then the promotion / expiry loop (:1062-1080) including the
+// effect of its `it++` on end(): with libstdc++'s circular list that wraps to begin(), so when the LAST candidate is erased
+// while others remain, the survivors are visited again.  Then StaticProcessModel::staticStep, Sigma += Q, on every
+// Gaussian (ProcessModel.hpp:195-208) -- births get Q added where they are created.
+// The candidate logic is a short serial walk per particle: lane 0 of the particle's wave runs it, all lanes do the
+// Sigma += Q sweep.  (The 2-D immediate-birth case keeps its lane-parallel kernel in merge_prune.h.)
+#pragma once
+#include "common.h"
+#include "vp.h"
+
+template <int D>
+struct Cand {
+  double x[3];
+  double S[6];  // packed xx, xy, xd, yy, yd, dd (2-D uses xx, xy, yy = S[0], S[1], S[3])
+};
+
+template <int D>
+__device__ void cand_load(const Buffers &B, int i, int c, Cand<D> &k) {
+  const double *m = B.candMean + ((size_t)i * RFSGPU_MAX_CANDIDATES + c) * 3;
+  const double *s = B.candCov + ((size_t)i * RFSGPU_MAX_CANDIDATES + c) * 6;
+  for (int t = 0; t < 3; t++) k.x[t] = m[t];
+  for (int t = 0; t < 6; t++) k.S[t] = s[t];
+}
+template <int D>
+__device__ void cand_store(const Buffers &B, int i, int c, const Cand<D> &k) {
+  double *m = B.candMean + ((size_t)i * RFSGPU_MAX_CANDIDATES + c) * 3;
+  double *s = B.candCov + ((size_t)i * RFSGPU_MAX_CANDIDATES + c) * 6;
+  for (int t = 0; t < 3; t++) m[t] = k.x[t];
+  for (int t = 0; t < 6; t++) s[t] = k.S[t];
+}
+
+// d2 = z_exp.mahalanobisDist2(z) with z_exp ~ N(h(x, candidate), S)   (:1029-1031)
+template <int D>
+__device__ double cand_support_md2(const Params &P, const PoseReg &pr, const Cand<D> &k, const double *z) {
+  if (D == 2) {
+    MeasOut mo;
+    rb_measure(P, pr, k.x[0], k.x[1], k.S[0], k.S[1], k.S[3], mo);
+    double i00, i01, i10, i11, det;
+    inv2(mo.s00, mo.s01, mo.s10, mo.s11, i00, i01, i10, i11, det);
+    const double e0 = z[0] - mo.z0, e1 = z[1] - mo.z1;
+    const double t0 = e0 * i00 + e1 * i10, t1 = e0 * i01 + e1 * i11;
+    return t0 * e0 + t1 * e1;
+  } else {
+    VPMeas o;
+    vp_measure(P, pr.x, pr.y, pr.th, k.x[0], k.x[1], k.x[2], k.S[0], k.S[1], k.S[3], k.S[5], o);
+    double Si[9];
+    inv3(o.S, Si);
+    return md2_3(Si, z[0] - o.z0, z[1] - o.z1, z[2] - o.z2);
+  }
+}
+
+// kfs_[0].correct(x, z, candidate, candidate)  (KalmanFilter.hpp:209-259): in place; unchanged when measure() or the
+// innovation gate rejects.
+template <int D>
+__device__ void cand_correct(const Params &P, const PoseReg &pr, Cand<D> &k, const double *z) {
+  if (D == 2) {
+    MeasOut mo;
+    rb_measure(P, pr, k.x[0], k.x[1], k.S[0], k.S[1], k.S[3], mo);
+    if (!mo.inRange) return;
+    const double e0 = z[0] - mo.z0;
+    if (P.kfRange > 0 && fabs(e0) > P.kfRange) return;  // KalmanFilter_RngBrg: range gate before the wrap
+    const double w1 = wrap_pi(z[1] - mo.z1);
+    if (P.kfBearing > 0 && fabs(w1) > P.kfBearing) return;
+    double i00, i01, i10, i11, det;
+    inv2(mo.s00, mo.s01, mo.s10, mo.s11, i00, i01, i10, i11, det);
+    const double sxx = k.S[0], sxy = k.S[1], syy = k.S[3];
+    const double t00 = sxx * mo.h00 + sxy * mo.h01, t01 = sxx * mo.h10 + sxy * mo.h11;
+    const double t10 = sxy * mo.h00 + syy * mo.h01, t11 = sxy * mo.h10 + syy * mo.h11;
+    const double k00 = t00 * i00 + t01 * i10, k01 = t00 * i01 + t01 * i11;
+    const double k10 = t10 * i00 + t11 * i10, k11 = t10 * i01 + t11 * i11;
+    const double kh00 = k00 * mo.h00 + k01 * mo.h10, kh01 = k00 * mo.h01 + k01 * mo.h11;
+    const double kh10 = k10 * mo.h00 + k11 * mo.h10, kh11 = k10 * mo.h01 + k11 * mo.h11;
+    const double a00 = 1.0 - kh00, a01 = 0.0 - kh01, a10 = 0.0 - kh10, a11 = 1.0 - kh11;
+    const double q00 = a00 * sxx + a01 * sxy, q01 = a00 * sxy + a01 * syy;
+    const double q10 = a10 * sxx + a11 * sxy, q11 = a10 * sxy + a11 * syy;
+    k.x[0] = k.x[0] + (k00 * e0 + k01 * w1);
+    k.x[1] = k.x[1] + (k10 * e0 + k11 * w1);
+    k.S[0] = (q00 + q00) / 2; k.S[1] = (q01 + q10) / 2; k.S[3] = (q11 + q11) / 2;
+  } else {
+    Ent3 e;
+    e.x = k.x[0]; e.y = k.x[1]; e.d = k.x[2];
+    e.xx = k.S[0]; e.xy = k.S[1]; e.xd = k.S[2]; e.yy = k.S[3]; e.yd = k.S[4]; e.dd = k.S[5];
+    LmKF3 kf;
+    lm_precompute3(P, pr.x, pr.y, pr.th, e, kf);
+    double nu0, nu1;
+    if (!vp_gate(P, kf, z[0], z[1], nu0, nu1)) return;
+    const double nu2 = z[2] - kf.zx2;
+    k.x[0] = e.x + ((kf.K[0] * nu0 + kf.K[1] * nu1) + kf.K[2] * nu2);
+    k.x[1] = e.y + ((kf.K[3] * nu0 + kf.K[4] * nu1) + kf.K[5] * nu2);
+    k.x[2] = e.d + ((kf.K[6] * nu0 + kf.K[7] * nu1) + kf.K[8] * nu2);
+    for (int t = 0; t < 6; t++) k.S[t] = kf.p[t];
+  }
+}
+
+// inverseMeasure(): src/MeasurementModel_RngBrg.cpp:117-136 / src/MeasurementModel_VictoriaPark.cpp:75-102
+template <int D>
+__device__ void cand_inverse(const Params &P, const PoseReg &pr, const double *z, Cand<D> &k) {
+  const double th = (D == 2) ? pr.th : pr.th - RFS_PI / 2;
+  const double a = th + z[1];
+  const double ca = cos(a), sa = sin(a);
+  const double h00 = ca, h01 = -z[0] * sa, h10 = sa, h11 = z[0] * ca;
+  const double t00 = h00 * P.R[0] + h01 * P.R[2], t01 = h00 * P.R[1] + h01 * P.R[3];
+  const double t10 = h10 * P.R[0] + h11 * P.R[2], t11 = h10 * P.R[1] + h11 * P.R[3];
+  for (int t = 0; t < 3; t++) k.x[t] = 0.0;
+  for (int t = 0; t < 6; t++) k.S[t] = 0.0;
+  k.x[0] = pr.x + z[0] * ca;
+  k.x[1] = pr.y + z[0] * sa;
+  k.S[0] = t00 * h00 + t01 * h01;
+  k.S[1] = t00 * h10 + t01 * h11;
+  k.S[3] = t10 * h10 + t11 * h11;
+  if (D == 3) { k.x[2] = z[2]; k.S[5] = P.R9[8]; }
+}
+
+// GaussianMixture::addGaussian(candidate, birthWeight, true) + this predict's Sigma += Q on it.
+template <int D>
+__device__ bool birth_append(const Buffers &B, const Params &P, int cur, int i, int &n, const Cand<D> &k) {
+  if (n >= B.cap) return false;
+  double *slab = B.slab[cur];
+  if (D == 2) {
+    plane(slab, B.cap, i, PL_W)[n] = P.birthW;
+    plane(slab, B.cap, i, PL_WP)[n] = 0.0;
+    plane(slab, B.cap, i, PL_MX)[n] = k.x[0];
+    plane(slab, B.cap, i, PL_MY)[n] = k.x[1];
+    plane(slab, B.cap, i, PL_SXX)[n] = k.S[0] + P.Qlm[0];
+    plane(slab, B.cap, i, PL_SXY)[n] = k.S[1] + P.Qlm[1];
+    plane(slab, B.cap, i, PL_SYY)[n] = k.S[3] + P.Qlm[2];
+  } else {
+    plane3(slab, B.cap, i, P3_W)[n] = P.birthW;
+    plane3(slab, B.cap, i, P3_WP)[n] = 0.0;
+    plane3(slab, B.cap, i, P3_MX)[n] = k.x[0];
+    plane3(slab, B.cap, i, P3_MY)[n] = k.x[1];
+    plane3(slab, B.cap, i, P3_MD)[n] = k.x[2];
+    for (int t = 0; t < 6; t++) plane3(slab, B.cap, i, P3_SXX + t)[n] = k.S[t] + P.Qlm6[t];
+  }
+  n++;
+  return true;
+}
+
+template <int D, int WPB>
+__global__ __launch_bounds__(WPB * 64) void predict_map_general_kernel(Buffers B, Params P, int cur, int addBirth, int nZprev) {
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
+  if (i >= B.N) return;
+  const int cap = B.cap;
+  const int nOld = B.count[i];
+  if (lane == 0 && addBirth) {
+    int n = nOld;
+    int nc = B.candCount[i];
+    const unsigned nfov = (unsigned)B.nInFov[i];
+    PoseReg pr;
+    load_pose(B, P, i, pr);
+    bool fail = false, listFull = false;
+    unsigned long long um = (nZprev > 0) ? B.unusedMask[i] : 0ull;
+    while (um) {  // back to front (:1013-1017)
+      const int zi = 63 - __builtin_clzll(um);
+      um &= ~(1ull << zi);
+      const double *z = B.Z + (size_t)D * zi;
+      bool isNew = true;
+      for (int c = 0; c < nc; c++) {
+        Cand<D> k;
+        cand_load<D>(B, i, c, k);
+        const double d2 = cand_support_md2<D>(P, pr, k, z);
+        if (d2 <= P.birthSupportD2) {
+          cand_correct<D>(P, pr, k, z);
+          cand_store<D>(B, i, c, k);
+          B.candSup[(size_t)i * RFSGPU_MAX_CANDIDATES + c]++;
+          isNew = false;
+          break;
+        }
+      }
+      if (isNew) {
+        Cand<D> k;
+        cand_inverse<D>(P, pr, z, k);
+        if (P.birthCountThr == 1u || nfov <= P.birthCurThr) {
+          if (!birth_append<D>(B, P, cur, i, n, k)) fail = true;
+        } else if (nc < RFSGPU_MAX_CANDIDATES) {
+          cand_store<D>(B, i, nc, k);
+          B.candSup[(size_t)i * RFSGPU_MAX_CANDIDATES + nc] = 1;
+          B.candChk[(size_t)i * RFSGPU_MAX_CANDIDATES + nc] = 0;
+          nc++;
+        } else {
+          listFull = true;
+        }
+      }
+    }
+    B.unusedMask[i] = 0ull;
+    // promotion / expiry (:1062-1080) with the ++end() wrap
+    int *sup = B.candSup + (size_t)i * RFSGPU_MAX_CANDIDATES, *chk = B.candChk + (size_t)i * RFSGPU_MAX_CANDIDATES;
+    int k = 0;
+    while (k < nc) {
+      chk[k]++;
+      bool atEnd = false;
+      while ((unsigned)sup[k] >= P.birthCountThr || (unsigned)chk[k] > P.birthCheckThr || nfov <= P.birthCurThr) {
+        if ((unsigned)sup[k] >= P.birthCountThr || nfov <= P.birthCurThr) {
+          Cand<D> c;
+          cand_load<D>(B, i, k, c);
+          if (!birth_append<D>(B, P, cur, i, n, c)) fail = true;
+        }
+        for (int t = k; t + 1 < nc; t++) {  // erase(it): shift the tail down, list order kept
+          Cand<D> c;
+          cand_load<D>(B, i, t + 1, c);
+          cand_store<D>(B, i, t, c);
+          sup[t] = sup[t + 1];
+          chk[t] = chk[t + 1];
+        }
+        nc--;
+        if (k < nc) chk[k]++;
+        else { atEnd = true; break; }
+      }
+      k = atEnd ? 0 : k + 1;
+    }
+    B.candCount[i] = nc;
+    B.count[i] = n;
+    if (fail) atomicOr(B.err, ERRBIT_CAPACITY);
+    if (listFull) atomicOr(B.err, ERRBIT_BIRTHLIST);
+  }
+  // staticStep on the pre-existing Gaussians
+  double *slab = B.slab[cur];
+  if (D == 2) {
+    double *pSXX = plane(slab, cap, i, PL_SXX), *pSXY = plane(slab, cap, i, PL_SXY), *pSYY = plane(slab, cap, i, PL_SYY);
+    for (int m = lane; m < nOld; m += 64) { pSXX[m] += P.Qlm[0]; pSXY[m] += P.Qlm[1]; pSYY[m] += P.Qlm[2]; }
+  } else {
+    for (int t = 0; t < 6; t++) {
+      double *p = plane3(slab, cap, i, P3_SXX + t);
+      for (int m = lane; m < nOld; m += 64) p[m] += P.Qlm6[t];
+    }
+  }
+}

@@ -37,8 +37,19 @@ struct Params {
   double Qlm[3];           // packed xx, xy, yy
   int evalCount;           // importanceWeightingEvalPointCount
   int useCluster;
-  unsigned birthCountThr, birthCurThr;
+  unsigned birthCountThr, birthCurThr, birthCheckThr;
+  double birthSupportD2;   // birthGaussianMeasurementSupportDist^2
   int poseCovStride;       // 0 shared, 9 per particle
+  // MeasurementModel_VictoriaPark (model 1); R[] above then holds its 2x2 range-bearing block
+  double R9[9];
+  double Slb;
+  double PdTable[16];
+  int nPd;
+  double vpClutter;        // expectedClutterNumber / FoV area of the current scan (setLaserScan)
+  double vpExpClutter;     // clutterIntensityIntegral
+  double bmax, bmin, bufferPd;
+  double Qlm6[6];          // packed xx, xy, xd, yy, yd, dd
+  double twoPiPowD;        // pow(2*pi, d_z) as the host libm rounds it (RandomVec.hpp:419)
 };
 
 struct Buffers {
@@ -50,8 +61,16 @@ struct Buffers {
   unsigned long long *unusedMask;  // [N]
   int *nInFov;       // [N]
   int *err;          // [1] OR-ed ErrBits
-  double *Z;         // [RFSGPU_MAX_Z][2]
+  double *Z;         // [RFSGPU_MAX_Z][d_z]
   int N, cap;
+  int npl;           // planes per particle: 7 (2-D) or 11 (3-D)
+  double *scan;      // [RFSGPU_VP_MAX_SCAN] laser scan (Victoria Park Pd)
+  int nScan;
+  // birth-Gaussian candidates (RBPHDFilter::birthGaussians_), list order == array order
+  double *candMean;  // [N][RFSGPU_MAX_CANDIDATES][3]
+  double *candCov;   // [N][RFSGPU_MAX_CANDIDATES][6] packed symmetric
+  int *candSup, *candChk;  // [N][RFSGPU_MAX_CANDIDATES]
+  int *candCount;    // [N]
   long long *dbg;    // section timestamps (only written by -DRFS_PROFILE builds; NULL otherwise)
 };
 

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(WPB * 64) void gm_prune_kernel(Buffers B, Params P,
   const int N = B.count[i];
   const double *sl = B.slab[src];
   double *dl = B.slab[dst];
-  const double *qW = plane((double *)sl, cap, i, PL_W);
+  const double *qW = sl + ((size_t)i * B.npl + 0) * cap;  // plane 0 is the weight in every layout
   const double t = P.pruneT;
   for (int m = lane; m < N; m += 64) keys[m] = qW[m];
   wave_sync();
@@ -380,7 +380,8 @@ __global__ __launch_bounds__(WPB * 64) void gm_prune_kernel(Buffers B, Params P,
         const double wj = keys[j];
         rank += (wj > wm || (wj == wm && j < m)) ? 1 : 0;  // everything ranked ahead of a survivor also survives
       }
-      for (int pl = 0; pl < PL_COUNT; pl++) plane(dl, cap, i, pl)[rank] = plane((double *)sl, cap, i, pl)[m];
+      for (int pl = 0; pl < B.npl; pl++)
+        (dl + ((size_t)i * B.npl + pl) * cap)[rank] = (sl + ((size_t)i * B.npl + pl) * cap)[m];
       kept++;
     }
   }
@@ -422,15 +423,24 @@ __global__ __launch_bounds__(256) void resample_gather_kernel(Buffers B, int cur
   if (s == k) return;
   const int n = B.count[s];
   double *slab = B.slab[cur];
-  for (int pl = 0; pl < PL_COUNT; pl++) {
-    const double *q = plane(slab, B.cap, s, pl);
-    double *d = plane(slab, B.cap, k, pl);
+  for (int pl = 0; pl < B.npl; pl++) {
+    const double *q = slab + ((size_t)s * B.npl + pl) * (size_t)B.cap;
+    double *d = slab + ((size_t)k * B.npl + pl) * (size_t)B.cap;
     for (int m = threadIdx.x; m < n; m += blockDim.x) d[m] = q[m];
+  }
+  // birth bookkeeping travels with the particle (RBPHDFilter.hpp:1005-1011): unused list, FOV count, candidate list
+  const int nc = B.candCount[s];
+  for (int t = threadIdx.x; t < nc * 3; t += blockDim.x) B.candMean[(size_t)k * RFSGPU_MAX_CANDIDATES * 3 + t] = B.candMean[(size_t)s * RFSGPU_MAX_CANDIDATES * 3 + t];
+  for (int t = threadIdx.x; t < nc * 6; t += blockDim.x) B.candCov[(size_t)k * RFSGPU_MAX_CANDIDATES * 6 + t] = B.candCov[(size_t)s * RFSGPU_MAX_CANDIDATES * 6 + t];
+  for (int t = threadIdx.x; t < nc; t += blockDim.x) {
+    B.candSup[(size_t)k * RFSGPU_MAX_CANDIDATES + t] = B.candSup[(size_t)s * RFSGPU_MAX_CANDIDATES + t];
+    B.candChk[(size_t)k * RFSGPU_MAX_CANDIDATES + t] = B.candChk[(size_t)s * RFSGPU_MAX_CANDIDATES + t];
   }
   if (threadIdx.x == 0) {
     B.count[k] = n;
     B.unusedMask[k] = B.unusedMask[s];
     B.nInFov[k] = B.nInFov[s];
+    B.candCount[k] = nc;
   }
 }
 
@@ -440,7 +450,7 @@ __global__ __launch_bounds__(256) void valid_count_kernel(Buffers B, int cur, in
   if (i >= B.N) return;
   const int lane = threadIdx.x & 63;
   const int n = B.count[i];
-  const double *w = plane(B.slab[cur], B.cap, i, PL_W);
+  const double *w = B.slab[cur] + ((size_t)i * B.npl + 0) * B.cap;
   int c = 0;
   for (int m = lane; m < n; m += 64) c += (w[m] >= 0.0) ? 1 : 0;
   c = wave_sum_i(c);
@@ -452,9 +462,9 @@ __global__ __launch_bounds__(256) void restore_state_kernel(Buffers B, int cur, 
                                                             const int *snapCount, const int *snapFov, const unsigned long long *snapUnused) {
   const int k = blockIdx.x;
   const int n = snapCount[k];
-  for (int pl = 0; pl < PL_COUNT; pl++) {
-    const double *q = snapSlab + ((size_t)k * PL_COUNT + pl) * (size_t)B.cap;
-    double *d = plane(B.slab[cur], B.cap, k, pl);
+  for (int pl = 0; pl < B.npl; pl++) {
+    const double *q = snapSlab + ((size_t)k * B.npl + pl) * (size_t)B.cap;
+    double *d = B.slab[cur] + ((size_t)k * B.npl + pl) * (size_t)B.cap;
     for (int m = threadIdx.x; m < n; m += blockDim.x) d[m] = q[m];
   }
   if (threadIdx.x == 0) {

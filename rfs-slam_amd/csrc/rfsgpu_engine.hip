@@ -15,6 +15,8 @@
 #include "weighting.h"
 #include "merge_prune.h"
 #include "murty.h"
+#include "vp.h"
+#include "birth.h"
 
 namespace {
 
@@ -29,6 +31,10 @@ enum { EV_UM0 = 0, EV_UM1, EV_W1, EV_MG1, EV_PR1, EV_P0, EV_P1, EV_R0, EV_R1, EV
 struct rfsgpu_filter {
   int device = 0;
   int N = 0, cap = 0;
+  int model = RFSGPU_MODEL_RNGBRG_2D;
+  int D = 2;          // d_m == d_z
+  rfsgpu_vp_config vp{};
+  double vpClutter = 0.0;
   hipStream_t stream = nullptr;
   hipStream_t ownStream = nullptr;
   double *ownSums = nullptr;
@@ -42,9 +48,9 @@ struct rfsgpu_filter {
   int cur = 0;
   Params P{};
   rfsgpu_filter_config cfg{};
-  rfsgpu_rngbrg_config model{};
+  rfsgpu_rngbrg_config rb{};
   rfsgpu_kf_config kf{};
-  double Qlm[4] = {0, 0, 0, 0};
+  double Qlm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   int nZ = 0;  // measurements of the last update (birth uses them)
   double *dSums = nullptr;  // [2]
   int *dSrcSlot = nullptr;  // [N]
@@ -82,12 +88,12 @@ static int fail(rfsgpu_filter *f, int code, const char *msg) {
 
 static void rebuild_params(rfsgpu_filter *f) {
   Params &P = f->P;
-  for (int k = 0; k < 4; k++) P.R[k] = f->model.R[k];
-  P.Pd = f->model.probabilityOfDetection;
-  P.clutter = f->model.uniformClutterIntensity;
-  P.rmax = f->model.rangeLimMax;
-  P.rmin = f->model.rangeLimMin;
-  P.rbuf = f->model.rangeLimBuffer;
+  for (int k = 0; k < 4; k++) P.R[k] = f->rb.R[k];
+  P.Pd = f->rb.probabilityOfDetection;
+  P.clutter = f->rb.uniformClutterIntensity;
+  P.rmax = f->rb.rangeLimMax;
+  P.rmin = f->rb.rangeLimMin;
+  P.rbuf = f->rb.rangeLimBuffer;
   P.kfRange = f->kf.rangeInnovationThreshold;
   P.kfBearing = f->kf.bearingInnovationThreshold;
   P.birthW = f->cfg.birthGaussianWeight;
@@ -97,9 +103,28 @@ static void rebuild_params(rfsgpu_filter *f) {
   P.mergeT2 = f->cfg.gaussianMergingThreshold * f->cfg.gaussianMergingThreshold;
   P.mergeInfl = f->cfg.gaussianMergingCovarianceInflationFactor;
   P.pruneT = f->cfg.gaussianPruningThreshold;
-  P.Qlm[0] = f->Qlm[0];
-  P.Qlm[1] = f->Qlm[1];
-  P.Qlm[2] = f->Qlm[3];
+  if (f->D == 2) {
+    P.Qlm[0] = f->Qlm[0];
+    P.Qlm[1] = f->Qlm[1];
+    P.Qlm[2] = f->Qlm[3];
+    P.twoPiPowD = pow(2 * acos(-1), 2);
+  } else {
+    P.Qlm6[0] = f->Qlm[0]; P.Qlm6[1] = f->Qlm[1]; P.Qlm6[2] = f->Qlm[2];
+    P.Qlm6[3] = f->Qlm[4]; P.Qlm6[4] = f->Qlm[5]; P.Qlm6[5] = f->Qlm[8];
+    P.twoPiPowD = pow(2 * acos(-1), 3);
+    for (int k = 0; k < 9; k++) P.R9[k] = f->vp.R[k];
+    P.R[0] = f->vp.R[0]; P.R[1] = f->vp.R[1]; P.R[2] = f->vp.R[3]; P.R[3] = f->vp.R[4];  // 2x2 range-bearing block
+    P.Slb = f->vp.Slb;
+    for (int k = 0; k < RFSGPU_VP_MAX_PD; k++) P.PdTable[k] = f->vp.PdTable[k];
+    P.nPd = f->vp.nPd;
+    P.vpClutter = f->vpClutter;
+    P.vpExpClutter = f->vp.expectedClutterNumber;
+    P.rmax = f->vp.rangeLimMax; P.rmin = f->vp.rangeLimMin;
+    P.bmax = f->vp.bearingLimitMax; P.bmin = f->vp.bearingLimitMin;
+    P.bufferPd = f->vp.bufferZonePd;
+  }
+  P.birthCheckThr = f->cfg.birthGaussianMeasurementCheckThreshold;
+  P.birthSupportD2 = f->cfg.birthGaussianMeasurementSupportDist * f->cfg.birthGaussianMeasurementSupportDist;
   P.evalCount = f->cfg.importanceWeightingEvalPointCount;
   P.useCluster = f->cfg.useClusterProcess ? 1 : 0;
   P.birthCountThr = f->cfg.birthGaussianMeasurementCountThreshold;
@@ -153,13 +178,15 @@ void rfsgpu_default_filter_config(rfsgpu_filter_config *c) {  // RBPHDFilter.hpp
 }
 
 int rfsgpu_create(rfsgpu_filter **out, int model, int n_particles, int device_id, int gm_capacity) {
-  if (!out || n_particles <= 0 || model != RFSGPU_MODEL_RNGBRG_2D || gm_capacity <= 0) return RFSGPU_ERR_INVALID;
+  if (!out || n_particles <= 0 || (model != RFSGPU_MODEL_RNGBRG_2D && model != RFSGPU_MODEL_VICTORIAPARK_3D) || gm_capacity <= 0) return RFSGPU_ERR_INVALID;
   *out = nullptr;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return RFSGPU_ERR_NO_DEVICE;
   rfsgpu_filter *f = new rfsgpu_filter();
   f->device = device_id;
   f->N = n_particles;
+  f->model = model;
+  f->D = (model == RFSGPU_MODEL_VICTORIAPARK_3D) ? 3 : 2;
   f->cap = ((gm_capacity + 63) / 64) * 64;
   if (f->cap > 2048) { delete f; return RFSGPU_ERR_INVALID; }
   auto bail = [&](int code) { rfsgpu_destroy(f); return code; };
@@ -171,10 +198,11 @@ int rfsgpu_create(rfsgpu_filter **out, int model, int n_particles, int device_id
   f->stream = f->ownStream;
   for (int k = 0; k < EV_COUNT; k++)
     if (hipEventCreate(&f->ev[k]) != hipSuccess) return bail(RFSGPU_ERR_HIP);
-  const size_t slabBytes = (size_t)f->N * PL_COUNT * f->cap * sizeof(double);
   Buffers &B = f->B;
   B.N = f->N;
   B.cap = f->cap;
+  B.npl = (f->D == 3) ? (int)P3_COUNT : (int)PL_COUNT;
+  const size_t slabBytes = (size_t)f->N * B.npl * f->cap * sizeof(double);
   bool ok = true;
   ok &= hipMalloc(&B.slab[0], slabBytes) == hipSuccess;
   ok &= hipMalloc(&B.slab[1], slabBytes) == hipSuccess;
@@ -185,14 +213,20 @@ int rfsgpu_create(rfsgpu_filter **out, int model, int n_particles, int device_id
   ok &= hipMalloc(&B.unusedMask, f->N * sizeof(unsigned long long)) == hipSuccess;
   ok &= hipMalloc(&B.nInFov, f->N * sizeof(int)) == hipSuccess;
   ok &= hipMalloc(&B.err, sizeof(int)) == hipSuccess;
-  ok &= hipMalloc(&B.Z, RFSGPU_MAX_Z * 2 * sizeof(double)) == hipSuccess;
+  ok &= hipMalloc(&B.Z, RFSGPU_MAX_Z * 3 * sizeof(double)) == hipSuccess;
+  ok &= hipMalloc(&B.scan, RFSGPU_VP_MAX_SCAN * sizeof(double)) == hipSuccess;
+  ok &= hipMalloc(&B.candMean, (size_t)f->N * RFSGPU_MAX_CANDIDATES * 3 * sizeof(double)) == hipSuccess;
+  ok &= hipMalloc(&B.candCov, (size_t)f->N * RFSGPU_MAX_CANDIDATES * 6 * sizeof(double)) == hipSuccess;
+  ok &= hipMalloc(&B.candSup, (size_t)f->N * RFSGPU_MAX_CANDIDATES * sizeof(int)) == hipSuccess;
+  ok &= hipMalloc(&B.candChk, (size_t)f->N * RFSGPU_MAX_CANDIDATES * sizeof(int)) == hipSuccess;
+  ok &= hipMalloc(&B.candCount, (size_t)f->N * sizeof(int)) == hipSuccess;
   ok &= hipMalloc(&f->ownSums, 2 * sizeof(double)) == hipSuccess;
   f->dSums = f->ownSums;
   ok &= hipMalloc(&f->dSrcSlot, f->N * sizeof(int)) == hipSuccess;
   ok &= hipHostMalloc(&f->hErr, sizeof(int)) == hipSuccess;
   ok &= hipHostMalloc(&f->hJobCount, sizeof(int)) == hipSuccess;
   ok &= hipHostMalloc(&f->hSums, 2 * sizeof(double)) == hipSuccess;
-  ok &= hipHostMalloc(&f->hZ, RFSGPU_MAX_Z * 2 * sizeof(double)) == hipSuccess;
+  ok &= hipHostMalloc(&f->hZ, RFSGPU_MAX_Z * 3 * sizeof(double)) == hipSuccess;
   if (!ok) return bail(RFSGPU_ERR_HIP);
   if (murty_alloc(f->Q, f->MS, f->N) != 0) return bail(RFSGPU_ERR_HIP);
   hipMemsetAsync(B.slab[0], 0, slabBytes, f->stream);
@@ -203,16 +237,20 @@ int rfsgpu_create(rfsgpu_filter **out, int model, int n_particles, int device_id
   hipMemsetAsync(B.unusedMask, 0, f->N * sizeof(unsigned long long), f->stream);
   hipMemsetAsync(B.nInFov, 0, f->N * sizeof(int), f->stream);
   hipMemsetAsync(B.err, 0, sizeof(int), f->stream);
-  hipMemsetAsync(B.Z, 0, RFSGPU_MAX_Z * 2 * sizeof(double), f->stream);
+  hipMemsetAsync(B.Z, 0, RFSGPU_MAX_Z * 3 * sizeof(double), f->stream);
+  hipMemsetAsync(B.scan, 0, RFSGPU_VP_MAX_SCAN * sizeof(double), f->stream);
+  hipMemsetAsync(B.candCount, 0, (size_t)f->N * sizeof(int), f->stream);
+  B.nScan = 0;
   set_weights_kernel<<<(f->N + 255) / 256, 256, 0, f->stream>>>(B.weight, f->N, 1.0);
   if (hipStreamSynchronize(f->stream) != hipSuccess) return bail(RFSGPU_ERR_HIP);
   rfsgpu_default_filter_config(&f->cfg);
-  memset(&f->model, 0, sizeof(f->model));  // MeasurementModel_RngBrg defaults, src/MeasurementModel_RngBrg.cpp:35-43
-  f->model.probabilityOfDetection = 0.95;
-  f->model.uniformClutterIntensity = 0.1;
-  f->model.rangeLimMax = 5;
-  f->model.rangeLimMin = 0.3;
-  f->model.rangeLimBuffer = 0.25;
+  memset(&f->rb, 0, sizeof(f->rb));  // MeasurementModel_RngBrg defaults, src/MeasurementModel_RngBrg.cpp:35-43
+  f->rb.probabilityOfDetection = 0.95;
+  f->rb.uniformClutterIntensity = 0.1;
+  f->rb.rangeLimMax = 5;
+  f->rb.rangeLimMin = 0.3;
+  f->rb.rangeLimBuffer = 0.25;
+  memset(&f->vp, 0, sizeof(f->vp));
   f->kf.rangeInnovationThreshold = -1;
   f->kf.bearingInnovationThreshold = -1;
   f->P.poseCovStride = 0;
@@ -230,6 +268,7 @@ void rfsgpu_destroy(rfsgpu_filter *f) {
   hipFree(f->snapSlab); hipFree(f->snapWeight); hipFree(f->snapCount); hipFree(f->snapFov); hipFree(f->snapUnused);
   hipFree(B.slab[0]); hipFree(B.slab[1]); hipFree(B.count); hipFree(B.pose); hipFree(B.poseCov); hipFree(B.weight);
   hipFree(B.unusedMask); hipFree(B.nInFov); hipFree(B.err); hipFree(B.Z); hipFree(f->ownSums); hipFree(f->dSrcSlot);
+  hipFree(B.scan); hipFree(B.candMean); hipFree(B.candCov); hipFree(B.candSup); hipFree(B.candChk); hipFree(B.candCount);
   murty_free(f->Q, f->MS);
   if (f->hErr) hipHostFree(f->hErr);
   if (f->hJobCount) hipHostFree(f->hJobCount);
@@ -257,7 +296,35 @@ int rfsgpu_get_filter_config(const rfsgpu_filter *f, rfsgpu_filter_config *c) {
 int rfsgpu_set_model_rngbrg(rfsgpu_filter *f, const rfsgpu_rngbrg_config *c) {
   CHECK_HANDLE(f);
   if (!c) return RFSGPU_ERR_INVALID;
-  f->model = *c;
+  if (f->model != RFSGPU_MODEL_RNGBRG_2D) return fail(f, RFSGPU_ERR_INVALID, "set_model_rngbrg on a handle created for another model");
+  f->rb = *c;
+  rebuild_params(f);
+  return RFSGPU_OK;
+}
+int rfsgpu_set_model_victoriapark(rfsgpu_filter *f, const rfsgpu_vp_config *c) {
+  CHECK_HANDLE(f);
+  if (!c) return RFSGPU_ERR_INVALID;
+  if (f->model != RFSGPU_MODEL_VICTORIAPARK_3D) return fail(f, RFSGPU_ERR_INVALID, "set_model_victoriapark on a handle created for another model");
+  if (c->nPd < 1 || c->nPd > RFSGPU_VP_MAX_PD) return fail(f, RFSGPU_ERR_INVALID, "Pd table size out of range");
+  f->vp = *c;
+  rebuild_params(f);
+  return RFSGPU_OK;
+}
+// MeasurementModel_VictoriaPark::setLaserScan (src/MeasurementModel_VictoriaPark.cpp:267-281): the FoV area / clutter
+// intensity are a 361-term host sum; the raw scan goes to the device for the occlusion-based Pd.
+int rfsgpu_set_laser_scan(rfsgpu_filter *f, const double *scan, int n) {
+  CHECK_HANDLE(f);
+  if (f->model != RFSGPU_MODEL_VICTORIAPARK_3D) return fail(f, RFSGPU_ERR_INVALID, "set_laser_scan needs the Victoria Park model");
+  if (!scan || n < 2 || n > RFSGPU_VP_MAX_SCAN) return fail(f, RFSGPU_ERR_INVALID, "laser scan size out of range");
+  double area = 0;
+  for (int k = 1; k < n; k++) area += scan[k] * scan[k - 1];
+  area += scan[0] * scan[n - 1];
+  area *= sin(acos(-1) / 360) / 2;
+  f->vpClutter = f->vp.expectedClutterNumber / area;
+  hipSetDevice(f->device);
+  HIPCHK(hipMemcpyAsync(f->B.scan, scan, (size_t)n * sizeof(double), hipMemcpyHostToDevice, f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  f->B.nScan = n;
   rebuild_params(f);
   return RFSGPU_OK;
 }
@@ -271,7 +338,7 @@ int rfsgpu_set_kf_config(rfsgpu_filter *f, const rfsgpu_kf_config *c) {
 int rfsgpu_set_lmk_process_noise(rfsgpu_filter *f, const double *Q) {
   CHECK_HANDLE(f);
   if (!Q) return RFSGPU_ERR_INVALID;
-  memcpy(f->Qlm, Q, 4 * sizeof(double));
+  memcpy(f->Qlm, Q, (size_t)f->D * f->D * sizeof(double));
   rebuild_params(f);
   return RFSGPU_OK;
 }
@@ -329,11 +396,20 @@ static int fetch_particle(rfsgpu_filter *f, int slot, std::vector<double> &plane
   hipSetDevice(f->device);
   HIPCHK(hipMemcpyAsync(&n, f->B.count + slot, sizeof(int), hipMemcpyDeviceToHost, f->stream));
   HIPCHK(hipStreamSynchronize(f->stream));
-  planes.resize((size_t)PL_COUNT * f->cap);
-  HIPCHK(hipMemcpyAsync(planes.data(), f->B.slab[f->cur] + (size_t)slot * PL_COUNT * f->cap, planes.size() * sizeof(double),
+  planes.resize((size_t)f->B.npl * f->cap);
+  HIPCHK(hipMemcpyAsync(planes.data(), f->B.slab[f->cur] + (size_t)slot * f->B.npl * f->cap, planes.size() * sizeof(double),
                         hipMemcpyDeviceToHost, f->stream));
   HIPCHK(hipStreamSynchronize(f->stream));
   return RFSGPU_OK;
+}
+
+// plane index of mean component d / of covariance entry (r,c) in the slab layout of the handle's model
+static inline int mean_plane(const rfsgpu_filter *f, int d) { return 2 + d; }
+static inline int cov_plane(const rfsgpu_filter *f, int r, int c) {
+  if (r > c) { int t = r; r = c; c = t; }
+  if (f->D == 2) return PL_SXX + (r == 0 ? c : 2);          // xx, xy, yy
+  static const int idx[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};  // xx, xy, xd, yy, yd, dd
+  return P3_SXX + idx[r][c];
 }
 
 int rfsgpu_gm_size(rfsgpu_filter *f, int slot) {
@@ -342,7 +418,7 @@ int rfsgpu_gm_size(rfsgpu_filter *f, int slot) {
   int n = 0;
   if (fetch_particle(f, slot, pl, n) != RFSGPU_OK) return -1;
   int k = 0;
-  for (int m = 0; m < n; m++) if (pl[(size_t)PL_W * f->cap + m] >= 0) k++;
+  for (int m = 0; m < n; m++) if (pl[m] >= 0) k++;  // plane 0 = weight
   return k;
 }
 
@@ -354,18 +430,17 @@ int rfsgpu_export_gm(rfsgpu_filter *f, int slot, int max_n, int *n_out, double *
   int rc = fetch_particle(f, slot, pl, n);
   if (rc != RFSGPU_OK) return rc;
   const size_t c = f->cap;
+  const int D = f->D;
   int k = 0;
   for (int m = 0; m < n; m++) {
-    if (pl[PL_W * c + m] < 0) continue;
+    if (pl[m] < 0) continue;  // hole left by merge
     if (k < max_n) {
-      if (w) w[k] = pl[PL_W * c + m];
-      if (w_prev) w_prev[k] = pl[PL_WP * c + m];
-      if (mean) { mean[2 * k] = pl[PL_MX * c + m]; mean[2 * k + 1] = pl[PL_MY * c + m]; }
-      if (cov) {
-        cov[4 * k] = pl[PL_SXX * c + m];
-        cov[4 * k + 1] = cov[4 * k + 2] = pl[PL_SXY * c + m];
-        cov[4 * k + 3] = pl[PL_SYY * c + m];
-      }
+      if (w) w[k] = pl[m];
+      if (w_prev) w_prev[k] = pl[1 * c + m];
+      if (mean) for (int d = 0; d < D; d++) mean[D * k + d] = pl[(size_t)mean_plane(f, d) * c + m];
+      if (cov)
+        for (int r = 0; r < D; r++)
+          for (int q = 0; q < D; q++) cov[(size_t)D * D * k + D * r + q] = pl[(size_t)cov_plane(f, r, q) * c + m];
     }
     k++;
   }
@@ -381,14 +456,16 @@ int rfsgpu_get_landmark(rfsgpu_filter *f, int slot, int m, double *mean, double 
   HIPCHK(hipMemcpyAsync(&n, f->B.count + slot, sizeof(int), hipMemcpyDeviceToHost, f->stream));
   HIPCHK(hipStreamSynchronize(f->stream));
   if (m >= n) return RFSGPU_ERR_INVALID;
-  double v[PL_COUNT];
-  for (int pl = 0; pl < PL_COUNT; pl++)
-    HIPCHK(hipMemcpyAsync(&v[pl], f->B.slab[f->cur] + ((size_t)slot * PL_COUNT + pl) * f->cap + m, sizeof(double), hipMemcpyDeviceToHost,
+  double v[P3_COUNT];
+  for (int pl = 0; pl < f->B.npl; pl++)
+    HIPCHK(hipMemcpyAsync(&v[pl], f->B.slab[f->cur] + ((size_t)slot * f->B.npl + pl) * f->cap + m, sizeof(double), hipMemcpyDeviceToHost,
                           f->stream));
   HIPCHK(hipStreamSynchronize(f->stream));
-  mean[0] = v[PL_MX]; mean[1] = v[PL_MY];
-  cov[0] = v[PL_SXX]; cov[1] = cov[2] = v[PL_SXY]; cov[3] = v[PL_SYY];
-  *w = v[PL_W];
+  const int D = f->D;
+  for (int d = 0; d < D; d++) mean[d] = v[mean_plane(f, d)];
+  for (int r = 0; r < D; r++)
+    for (int q = 0; q < D; q++) cov[D * r + q] = v[cov_plane(f, r, q)];
+  *w = v[0];
   return RFSGPU_OK;
 }
 
@@ -398,17 +475,16 @@ int rfsgpu_import_gm(rfsgpu_filter *f, int slot, int n, const double *w, const d
   if (n > f->cap) return fail(f, RFSGPU_ERR_CAPACITY, "import_gm: more Gaussians than gm_capacity");
   hipSetDevice(f->device);
   const size_t c = f->cap;
-  std::vector<double> pl((size_t)PL_COUNT * c, 0.0);
+  const int D = f->D;
+  std::vector<double> pl((size_t)f->B.npl * c, 0.0);
   for (int m = 0; m < n; m++) {
-    pl[PL_W * c + m] = w[m];
-    pl[PL_WP * c + m] = 0.0;
-    pl[PL_MX * c + m] = mean[2 * m];
-    pl[PL_MY * c + m] = mean[2 * m + 1];
-    pl[PL_SXX * c + m] = cov[4 * m];
-    pl[PL_SXY * c + m] = cov[4 * m + 1];
-    pl[PL_SYY * c + m] = cov[4 * m + 3];
+    pl[m] = w[m];
+    pl[1 * c + m] = 0.0;
+    for (int d = 0; d < D; d++) pl[(size_t)mean_plane(f, d) * c + m] = mean[D * m + d];
+    for (int r = 0; r < D; r++)
+      for (int q = r; q < D; q++) pl[(size_t)cov_plane(f, r, q) * c + m] = cov[(size_t)D * D * m + D * r + q];  // upper triangle
   }
-  HIPCHK(hipMemcpyAsync(f->B.slab[f->cur] + (size_t)slot * PL_COUNT * c, pl.data(), pl.size() * sizeof(double), hipMemcpyHostToDevice, f->stream));
+  HIPCHK(hipMemcpyAsync(f->B.slab[f->cur] + (size_t)slot * f->B.npl * c, pl.data(), pl.size() * sizeof(double), hipMemcpyHostToDevice, f->stream));
   HIPCHK(hipMemcpyAsync(f->B.count + slot, &n, sizeof(int), hipMemcpyHostToDevice, f->stream));
   HIPCHK(hipStreamSynchronize(f->stream));
   return RFSGPU_OK;
@@ -429,6 +505,55 @@ int rfsgpu_import_aux(rfsgpu_filter *f, int slot, const int *unused_idx, int n_u
   return RFSGPU_OK;
 }
 
+int rfsgpu_export_birth_candidates(rfsgpu_filter *f, int slot, int max_n, int *n_out, double *mean, double *cov, int *n_support, int *n_checks) {
+  CHECK_HANDLE(f);
+  if (slot < 0 || slot >= f->N) return fail(f, RFSGPU_ERR_INVALID, "export_birth_candidates: bad slot");
+  hipSetDevice(f->device);
+  int nc = 0;
+  std::vector<double> m((size_t)RFSGPU_MAX_CANDIDATES * 3), c((size_t)RFSGPU_MAX_CANDIDATES * 6);
+  std::vector<int> su(RFSGPU_MAX_CANDIDATES), ch(RFSGPU_MAX_CANDIDATES);
+  HIPCHK(hipMemcpyAsync(&nc, f->B.candCount + slot, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+  HIPCHK(hipMemcpyAsync(m.data(), f->B.candMean + (size_t)slot * RFSGPU_MAX_CANDIDATES * 3, m.size() * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  HIPCHK(hipMemcpyAsync(c.data(), f->B.candCov + (size_t)slot * RFSGPU_MAX_CANDIDATES * 6, c.size() * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  HIPCHK(hipMemcpyAsync(su.data(), f->B.candSup + (size_t)slot * RFSGPU_MAX_CANDIDATES, su.size() * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+  HIPCHK(hipMemcpyAsync(ch.data(), f->B.candChk + (size_t)slot * RFSGPU_MAX_CANDIDATES, ch.size() * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  const int D = f->D;
+  static const int idx3[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+  for (int k = 0; k < nc && k < max_n; k++) {
+    for (int d = 0; d < D; d++) mean[D * k + d] = m[3 * k + d];
+    for (int r = 0; r < D; r++)
+      for (int q = 0; q < D; q++) cov[(size_t)D * D * k + D * r + q] = c[6 * k + idx3[r][q]];
+    n_support[k] = su[k];
+    n_checks[k] = ch[k];
+  }
+  if (n_out) *n_out = nc;
+  return RFSGPU_OK;
+}
+int rfsgpu_import_birth_candidates(rfsgpu_filter *f, int slot, int n, const double *mean, const double *cov, const int *n_support, const int *n_checks) {
+  CHECK_HANDLE(f);
+  if (slot < 0 || slot >= f->N || n < 0 || n > RFSGPU_MAX_CANDIDATES) return fail(f, RFSGPU_ERR_INVALID, "import_birth_candidates: bad arguments");
+  hipSetDevice(f->device);
+  const int D = f->D;
+  static const int idx3[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+  std::vector<double> m((size_t)RFSGPU_MAX_CANDIDATES * 3, 0.0), c((size_t)RFSGPU_MAX_CANDIDATES * 6, 0.0);
+  std::vector<int> su(RFSGPU_MAX_CANDIDATES, 0), ch(RFSGPU_MAX_CANDIDATES, 0);
+  for (int k = 0; k < n; k++) {
+    for (int d = 0; d < D; d++) m[3 * k + d] = mean[D * k + d];
+    for (int r = 0; r < D; r++)
+      for (int q = r; q < D; q++) c[6 * k + idx3[r][q]] = cov[(size_t)D * D * k + D * r + q];
+    su[k] = n_support[k];
+    ch[k] = n_checks[k];
+  }
+  HIPCHK(hipMemcpyAsync(f->B.candMean + (size_t)slot * RFSGPU_MAX_CANDIDATES * 3, m.data(), m.size() * sizeof(double), hipMemcpyHostToDevice, f->stream));
+  HIPCHK(hipMemcpyAsync(f->B.candCov + (size_t)slot * RFSGPU_MAX_CANDIDATES * 6, c.data(), c.size() * sizeof(double), hipMemcpyHostToDevice, f->stream));
+  HIPCHK(hipMemcpyAsync(f->B.candSup + (size_t)slot * RFSGPU_MAX_CANDIDATES, su.data(), su.size() * sizeof(int), hipMemcpyHostToDevice, f->stream));
+  HIPCHK(hipMemcpyAsync(f->B.candChk + (size_t)slot * RFSGPU_MAX_CANDIDATES, ch.data(), ch.size() * sizeof(int), hipMemcpyHostToDevice, f->stream));
+  HIPCHK(hipMemcpyAsync(f->B.candCount + slot, &n, sizeof(int), hipMemcpyHostToDevice, f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  return RFSGPU_OK;
+}
+
 // ---- the hot path ----------------------------------------------------------------------------------
 
 static int set_lds_impl(rfsgpu_filter *f, const void *kernel, size_t bytes) {
@@ -440,6 +565,15 @@ static int set_lds_impl(rfsgpu_filter *f, const void *kernel, size_t bytes) {
 
 static int launch_update_map(rfsgpu_filter *f) {
   const int nZ = f->nZ;
+  if (f->D == 3) {
+    if (f->B.nScan < 2) return fail(f, RFSGPU_ERR_INVALID, "Victoria Park model: rfsgpu_set_laser_scan must precede the update");
+    const size_t b = (size_t)(3 * RFSGPU_MAX_Z + RFSGPU_VP_MAX_SCAN) * 8 + 2 * vp_update_lds_bytes_per_wave(f->cap);
+    int rc3;
+    if ((rc3 = set_lds(f, vp_update_map_kernel<2>, b)) != RFSGPU_OK) return rc3;
+    vp_update_map_kernel<2><<<(f->N + 1) / 2, 128, b, f->stream>>>(f->B, f->P, f->cur, nZ);
+    HIPCHK(hipGetLastError());
+    return RFSGPU_OK;
+  }
   auto bytes = [&](int wpb) { return (size_t)(2 * RFSGPU_MAX_Z * 8) + (size_t)wpb * update_map_lds_bytes_per_wave(f->cap); };
   int rc;
   if (bytes(4) <= 64 * 1024) {
@@ -467,6 +601,15 @@ static int launch_weighting(rfsgpu_filter *f) {
   const int src = f->cur, dst = f->cur ^ 1;
   HIPCHK(hipMemsetAsync(f->Q.count, 0, sizeof(int), f->stream));
   int rc;
+  if (f->D == 3) {
+    const size_t b = (size_t)(3 * RFSGPU_MAX_Z + RFSGPU_VP_MAX_SCAN) * 8 + 2 * (per + (size_t)ec * 16 * 8);
+    if ((rc = set_lds(f, vp_weighting_kernel<2>, b)) != RFSGPU_OK) return rc;
+    vp_weighting_kernel<2><<<(f->N + 1) / 2, 128, b, f->stream>>>(f->B, f->P, src, dst, nZ, ec, f->Q);
+    HIPCHK(hipGetLastError());
+    f->cur = dst;
+    if (murty_launch(f->Q, f->MS, f->B, f->stream) != 0) return fail(f, RFSGPU_ERR_HIP, "murty launch failed");
+    return RFSGPU_OK;
+  }
   if (bytes(4) <= 80 * 1024) {
     if ((rc = set_lds(f, phd_weight_multifeature_kernel<4>, bytes(4))) != RFSGPU_OK) return rc;
     phd_weight_multifeature_kernel<4><<<(f->N + 3) / 4, 256, bytes(4), f->stream>>>(f->B, f->P, src, dst, nZ, ec, f->Q);
@@ -488,9 +631,17 @@ static int launch_weighting(rfsgpu_filter *f) {
 }  // extern "C" (templates need C++ linkage)
 template <bool FUSE>
 static int launch_merge_t(rfsgpu_filter *f) {
-  const size_t per = merge_lds_bytes_per_wave(f->cap);
   const int cur = f->cur, dst = f->cur ^ 1;
   int rc;
+  if (f->D == 3) {
+    const size_t b = vp_merge_lds_bytes_per_wave(f->cap);
+    if ((rc = set_lds(f, (vp_merge_kernel<1, FUSE>), b)) != RFSGPU_OK) return rc;
+    vp_merge_kernel<1, FUSE><<<f->N, 64, b, f->stream>>>(f->B, f->P, cur, dst);
+    HIPCHK(hipGetLastError());
+    if (FUSE) f->cur = dst;
+    return RFSGPU_OK;
+  }
+  const size_t per = merge_lds_bytes_per_wave(f->cap);
   // pick the block shape that keeps the most waves resident per CU (160 KiB LDS): 4 waves/block only while
   // two such blocks still fit, otherwise smaller blocks pack better
   if (4 * per <= 40 * 1024) {
@@ -529,8 +680,8 @@ static int stage_measurements(rfsgpu_filter *f, const double *z, int n_z) {
   if (n_z > 0) {
     // through a pinned staging buffer: the H2D copy is then truly asynchronous.  The previous step's copy has completed
     // (every update ends with a stream sync) before the buffer is overwritten.
-    memcpy(f->hZ, z, (size_t)n_z * 2 * sizeof(double));
-    HIPCHK(hipMemcpyAsync(f->B.Z, f->hZ, (size_t)n_z * 2 * sizeof(double), hipMemcpyHostToDevice, f->stream));
+    memcpy(f->hZ, z, (size_t)n_z * f->D * sizeof(double));
+    HIPCHK(hipMemcpyAsync(f->B.Z, f->hZ, (size_t)n_z * f->D * sizeof(double), hipMemcpyHostToDevice, f->stream));
   }
   f->nZ = n_z;
   return RFSGPU_OK;
@@ -624,7 +775,12 @@ int rfsgpu_predict_map(rfsgpu_filter *f, int add_birth) {
   long long t0 = now_ns();
   hipSetDevice(f->device);
   HIPCHK(hipEventRecord(f->ev[EV_P0], f->stream));
-  predict_map_kernel<4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
+  if (f->D == 3)
+    predict_map_general_kernel<3, 4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
+  else if (f->cfg.birthGaussianMeasurementCountThreshold != 1u)
+    predict_map_general_kernel<2, 4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
+  else  // CountThreshold == 1: every unused measurement is born at once, no candidate can exist -> lane-parallel kernel
+    predict_map_kernel<4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(f->ev[EV_P1], f->stream));
   int rc = check_device_errors(f);
@@ -752,7 +908,7 @@ int rfsgpu_bind_weight_sums_buffer(rfsgpu_filter *f, void *dev_ptr) {
 int rfsgpu_save_state(rfsgpu_filter *f) {
   CHECK_HANDLE(f);
   hipSetDevice(f->device);
-  const size_t slabBytes = (size_t)f->N * PL_COUNT * f->cap * sizeof(double);
+  const size_t slabBytes = (size_t)f->N * f->B.npl * f->cap * sizeof(double);
   if (!f->snapSlab) {
     bool ok = true;
     ok &= hipMalloc(&f->snapSlab, slabBytes) == hipSuccess;

@@ -140,6 +140,110 @@ __device__ double enumerate_partition(const WeightLDS &s, int nZ, unsigned long 
   return lik;
 }
 
+// Steps 5-6 of the particle weight, model-independent: connected components of the bipartite graph (rows = evaluation
+// points, columns = measurements) of the likelihood table s.L (nE x nZ, already gated, incl. Pd), the reference's
+// zero-partition merge + partition-indexing quirk, one lane per partition for the <= 8 enumeration, Murty jobs for the
+// rest.  Returns the product over the visited partitions (RBPHDFilter.hpp:865-990), before the clutter-integral division.
+__device__ double rfs_partitions_wave(const WeightLDS &s, int nE, int nZ, double clutter, int lane, int particle, MurtyQueue Q, int *err) {
+  // ---- 5. connected components of the bipartite graph (rows = eval points, cols = measurements) ----
+  unsigned long long myRow = 0, myCol = 0;
+  if (lane < nE) for (int n = 0; n < nZ; n++) if (s.L[lane * nZ + n] != 0.0) myRow |= 1ull << n;
+  if (lane < nZ) for (int e = 0; e < nE; e++) if (s.L[e * nZ + lane] != 0.0) myCol |= 1ull << e;
+  int labR = lane, labC = nE + lane;  // label = smallest vertex index reachable (rows first, then columns)
+  s.labR[lane] = labR;
+  s.labC[lane] = labC;
+  wave_sync();
+  for (int it = 0; it < 130; it++) {
+    int nr = labR;
+    for (unsigned long long mm = myRow; mm; mm &= mm - 1) { int v = s.labC[__builtin_ctzll(mm)]; nr = v < nr ? v : nr; }
+    bool ch = nr != labR;
+    labR = nr;
+    s.labR[lane] = labR;
+    wave_sync();
+    int nc = labC;
+    for (unsigned long long mm = myCol; mm; mm &= mm - 1) { int v = s.labR[__builtin_ctzll(mm)]; nc = v < nc ? v : nc; }
+    ch = ch || (nc != labC);
+    labC = nc;
+    s.labC[lane] = labC;
+    wave_sync();
+    if (__ballot(ch) == 0ull) break;
+  }
+  // the log table replaces L from here on (zero partition needs no L; :907-917)
+  for (int idx = lane; idx < nE * nZ; idx += 64) {
+    double v = s.L[idx];
+    if (v == 0.0) v = -1000.0;
+    else { v = log(v); if (v < -1000.0) v = -1000.0; }
+    s.L[idx] = v;
+  }
+  const unsigned long long rootR = __ballot(lane < nE && labR == lane);
+  const unsigned long long rootC = __ballot(lane < nZ && labC == nE + lane);
+  const int nRootR = __popcll(rootR);
+  const int ncc = nRootR + __popcll(rootC);
+  // component id = rank of its smallest vertex (== BGL DFS discovery order)
+  auto comp_of = [&](int label) -> int {
+    return label < nE ? __popcll(rootR & ((1ull << label) - 1ull)) : nRootR + __popcll(rootC & ((1ull << (label - nE)) - 1ull));
+  };
+  s.compRows[lane] = 0; s.compRows[lane + 64] = 0;
+  s.compCols[lane] = 0; s.compCols[lane + 64] = 0;
+  wave_sync();
+  if (lane < nE) atomicOr(&s.compRows[comp_of(labR)], 1ull << lane);
+  if (lane < nZ) atomicOr(&s.compCols[comp_of(labC)], 1ull << lane);
+  wave_sync();
+  // zero partitions (no rows or no cols) are merged into the first one (src/CostMatrix.cpp:126-144)
+  unsigned long long zr = 0, zc = 0;
+  bool z0 = false, z1 = false;
+  if (lane < ncc) { z0 = (s.compRows[lane] == 0 || s.compCols[lane] == 0); if (z0) { zr |= s.compRows[lane]; zc |= s.compCols[lane]; } }
+  if (lane + 64 < ncc) { z1 = (s.compRows[lane + 64] == 0 || s.compCols[lane + 64] == 0); if (z1) { zr |= s.compRows[lane + 64]; zc |= s.compCols[lane + 64]; } }
+  const unsigned long long zeroLo = __ballot(z0), zeroHi = __ballot(z1);
+  const int nZero = __popcll(zeroLo) + __popcll(zeroHi);
+  const int combined = zeroLo ? __builtin_ctzll(zeroLo) : (zeroHi ? 64 + __builtin_ctzll(zeroHi) : -1);
+  const unsigned long long mergedRows = wave_or_u64(zr), mergedCols = wave_or_u64(zc);
+  const int nPartitions = ncc - (nZero > 0 ? nZero - 1 : 0);  // caller still indexes components [0, nPartitions) -- quirk kept
+
+  // ---- 6. one lane per partition ----
+  const double logc = log(clutter);
+  for (int p = lane; p < nPartitions; p += 64) {
+    unsigned long long rmask = s.compRows[p], cmask = s.compCols[p];
+    double pl;
+    if (p == combined) {  // all landmarks mis-detected, all measurements outliers (:891-900; Pd, not 1-Pd)
+      rmask = mergedRows;
+      cmask = mergedCols;
+      pl = 1.0;
+      for (unsigned long long mm = rmask; mm; mm &= mm - 1) pl *= s.evPd[__builtin_ctzll(mm)];
+      for (unsigned long long mm = cmask; mm; mm &= mm - 1) pl *= clutter;
+    } else if (__popcll(rmask) + __popcll(cmask) <= 8) {
+      pl = enumerate_partition(s, nZ, rmask, cmask, logc);
+    } else {
+      // Murty-200 (:920-959): queue the extended matrix; the factor is multiplied in by murty_kernel
+      pl = 1.0;
+      int job = Q.count ? atomicAdd(Q.count, 1) : Q.maxJobs;
+      const int nR = __popcll(rmask), nC = __popcll(cmask), n = nR + nC;
+      if (job < Q.maxJobs && n <= MURTY_MAXN) {
+        MurtyJob J;
+        J.particle = particle; J.nR = nR; J.nC = nC; J.slot = p;
+        Q.jobs[job] = J;
+        double *M = Q.mats + (size_t)job * MURTY_MAXN * MURTY_MAXN;
+        for (int a = 0; a < n; a++)
+          for (int b = 0; b < n; b++) {
+            double v;
+            if (a < nR && b < nC) v = s.L[nth_bit(rmask, a) * nZ + nth_bit(cmask, b)];
+            else if (a < nR) v = (a == b - nC) ? s.evLog1mPd[nth_bit(rmask, a)] : -1000.0;
+            else if (b < nC) v = (a - nR == b) ? logc : -1000.0;
+            else v = 0.0;
+            M[a * n + b] = v;
+          }
+      } else {
+        atomicOr(err, ERRBIT_MURTY);
+      }
+    }
+    s.partLik[p] = pl;
+  }
+  wave_sync();
+  double l = 1.0;
+  for (int p = 0; p < nPartitions; p++) l *= s.partLik[p];
+  return l;
+}
+
 // One sweep over the float keys ranks NS entries per lane (entries g0 + 64*k + lane).
 template <int NS>
 __device__ __forceinline__ void rank_sweep_f32(const float *fkeys, int *perm, int N, int Npad, int g0, int lane) {
@@ -373,103 +477,8 @@ __global__ __launch_bounds__(WPB * 64) void phd_weight_multifeature_kernel(Buffe
   wave_sync();
 
   DBG_T(16, 4);
-  // ---- 5. connected components of the bipartite graph (rows = eval points, cols = measurements) ----
-  unsigned long long myRow = 0, myCol = 0;
-  if (lane < nE) for (int n = 0; n < nZ; n++) if (s.L[lane * nZ + n] != 0.0) myRow |= 1ull << n;
-  if (lane < nZ) for (int e = 0; e < nE; e++) if (s.L[e * nZ + lane] != 0.0) myCol |= 1ull << e;
-  int labR = lane, labC = nE + lane;  // label = smallest vertex index reachable (rows first, then columns)
-  s.labR[lane] = labR;
-  s.labC[lane] = labC;
-  wave_sync();
-  for (int it = 0; it < 130; it++) {
-    int nr = labR;
-    for (unsigned long long mm = myRow; mm; mm &= mm - 1) { int v = s.labC[__builtin_ctzll(mm)]; nr = v < nr ? v : nr; }
-    bool ch = nr != labR;
-    labR = nr;
-    s.labR[lane] = labR;
-    wave_sync();
-    int nc = labC;
-    for (unsigned long long mm = myCol; mm; mm &= mm - 1) { int v = s.labR[__builtin_ctzll(mm)]; nc = v < nc ? v : nc; }
-    ch = ch || (nc != labC);
-    labC = nc;
-    s.labC[lane] = labC;
-    wave_sync();
-    if (__ballot(ch) == 0ull) break;
-  }
-  // the log table replaces L from here on (zero partition needs no L; :907-917)
-  for (int idx = lane; idx < nE * nZ; idx += 64) {
-    double v = s.L[idx];
-    if (v == 0.0) v = -1000.0;
-    else { v = log(v); if (v < -1000.0) v = -1000.0; }
-    s.L[idx] = v;
-  }
-  const unsigned long long rootR = __ballot(lane < nE && labR == lane);
-  const unsigned long long rootC = __ballot(lane < nZ && labC == nE + lane);
-  const int nRootR = __popcll(rootR);
-  const int ncc = nRootR + __popcll(rootC);
-  // component id = rank of its smallest vertex (== BGL DFS discovery order)
-  auto comp_of = [&](int label) -> int {
-    return label < nE ? __popcll(rootR & ((1ull << label) - 1ull)) : nRootR + __popcll(rootC & ((1ull << (label - nE)) - 1ull));
-  };
-  s.compRows[lane] = 0; s.compRows[lane + 64] = 0;
-  s.compCols[lane] = 0; s.compCols[lane + 64] = 0;
-  wave_sync();
-  if (lane < nE) atomicOr(&s.compRows[comp_of(labR)], 1ull << lane);
-  if (lane < nZ) atomicOr(&s.compCols[comp_of(labC)], 1ull << lane);
-  wave_sync();
-  // zero partitions (no rows or no cols) are merged into the first one (src/CostMatrix.cpp:126-144)
-  unsigned long long zr = 0, zc = 0;
-  bool z0 = false, z1 = false;
-  if (lane < ncc) { z0 = (s.compRows[lane] == 0 || s.compCols[lane] == 0); if (z0) { zr |= s.compRows[lane]; zc |= s.compCols[lane]; } }
-  if (lane + 64 < ncc) { z1 = (s.compRows[lane + 64] == 0 || s.compCols[lane + 64] == 0); if (z1) { zr |= s.compRows[lane + 64]; zc |= s.compCols[lane + 64]; } }
-  const unsigned long long zeroLo = __ballot(z0), zeroHi = __ballot(z1);
-  const int nZero = __popcll(zeroLo) + __popcll(zeroHi);
-  const int combined = zeroLo ? __builtin_ctzll(zeroLo) : (zeroHi ? 64 + __builtin_ctzll(zeroHi) : -1);
-  const unsigned long long mergedRows = wave_or_u64(zr), mergedCols = wave_or_u64(zc);
-  const int nPartitions = ncc - (nZero > 0 ? nZero - 1 : 0);  // caller still indexes components [0, nPartitions) -- quirk kept
-
-  DBG_T(16, 5);
-  // ---- 6. one lane per partition ----
-  const double logc = log(P.clutter);
-  for (int p = lane; p < nPartitions; p += 64) {
-    unsigned long long rmask = s.compRows[p], cmask = s.compCols[p];
-    double pl;
-    if (p == combined) {  // all landmarks mis-detected, all measurements outliers (:891-900; Pd, not 1-Pd)
-      rmask = mergedRows;
-      cmask = mergedCols;
-      pl = 1.0;
-      for (unsigned long long mm = rmask; mm; mm &= mm - 1) pl *= s.evPd[__builtin_ctzll(mm)];
-      for (unsigned long long mm = cmask; mm; mm &= mm - 1) pl *= P.clutter;
-    } else if (__popcll(rmask) + __popcll(cmask) <= 8) {
-      pl = enumerate_partition(s, nZ, rmask, cmask, logc);
-    } else {
-      // Murty-200 (:920-959): queue the extended matrix; the factor is multiplied in by murty_kernel
-      pl = 1.0;
-      int job = Q.count ? atomicAdd(Q.count, 1) : Q.maxJobs;
-      const int nR = __popcll(rmask), nC = __popcll(cmask), n = nR + nC;
-      if (job < Q.maxJobs && n <= MURTY_MAXN) {
-        MurtyJob J;
-        J.particle = i; J.nR = nR; J.nC = nC; J.slot = p;
-        Q.jobs[job] = J;
-        double *M = Q.mats + (size_t)job * MURTY_MAXN * MURTY_MAXN;
-        for (int a = 0; a < n; a++)
-          for (int b = 0; b < n; b++) {
-            double v;
-            if (a < nR && b < nC) v = s.L[nth_bit(rmask, a) * nZ + nth_bit(cmask, b)];
-            else if (a < nR) v = (a == b - nC) ? s.evLog1mPd[nth_bit(rmask, a)] : -1000.0;
-            else if (b < nC) v = (a - nR == b) ? logc : -1000.0;
-            else v = 0.0;
-            M[a * n + b] = v;
-          }
-      } else {
-        atomicOr(B.err, ERRBIT_MURTY);
-      }
-    }
-    s.partLik[p] = pl;
-  }
-  wave_sync();
-  double l = 1.0;
-  for (int p = 0; p < nPartitions; p++) l *= s.partLik[p];
+  // ---- 5./6. partition the table, sum the assignments of every partition (shared with the 3-D kernel) ----
+  const double l = rfs_partitions_wave(s, nE, nZ, P.clutter, lane, i, Q, B.err);
   const double sensingArea = 2 * RFS_PI * (P.rmax - P.rmin);
   const double ml = l / (P.clutter * sensingArea);  // clutterIntensityIntegral (src/MeasurementModel_RngBrg.cpp:175-178)
 

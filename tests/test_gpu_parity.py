@@ -238,3 +238,99 @@ def test_tied_weights_take_the_exact_rank_path(pkg, ob, sc):
     for f in (dev2, orc2):
         f.update(scen["Z"])                                  # fused merge+prune path
     compare_maps(sc, dev2, orc2, scen["n"], ordered=True)
+
+
+# ---- Victoria Park model (3-D landmarks, scan-based Pd, birth-candidate lists) -----------------------------------------
+
+def make_vp_pair(pkg, ob, sc, scen, cap=192):
+    dev = pkg.RBPHDFilter(scen["n"], device_id=0, gm_capacity=cap, model=pkg.capi.MODEL_VICTORIAPARK_3D)
+    orc = ob.OracleFilter(scen["n"], stable_sort=True, model=pkg.capi.MODEL_VICTORIAPARK_3D)
+    for f in (dev, orc):
+        sc.load_scenario(f, scen)
+    return dev, orc
+
+
+VP_SCENARIOS = [
+    dict(n_particles=12, n_landmarks=30, n_z=9, seed=41, scan="const"),
+    dict(n_particles=20, n_landmarks=70, n_z=18, seed=42, scan="ragged"),      # ragged: 70 = 64 + 6; occlusion counts vary
+    dict(n_particles=8, n_landmarks=5, n_z=3, seed=43, scan="const"),
+]
+
+
+@pytest.mark.parametrize("kw", VP_SCENARIOS)
+def test_vp_phases_stepwise(pkg, ob, sc, kw):
+    scen = sc.make_vp_scenario(**kw)
+    dev, orc = make_vp_pair(pkg, ob, sc, scen)
+    for f in (dev, orc):
+        f.update_map(scen["Z"])
+    compare_maps(sc, dev, orc, scen["n"], ordered=True)
+    for i in range(scen["n"]):
+        assert np.array_equal(dev.get_unused(i), orc.get_unused(i))
+        assert dev.landmarks_in_fov(i) == orc.landmarks_in_fov(i)
+        np.testing.assert_allclose(dev.export_gm(i)[1], orc.export_gm(i)[1], rtol=0, atol=0)
+    for f in (dev, orc):
+        f.importance_weighting()
+    compare_weights(dev, orc)
+    compare_maps(sc, dev, orc, scen["n"], ordered=True)
+    for f in (dev, orc):
+        f.merge()
+    compare_maps(sc, dev, orc, scen["n"], ordered=True)
+    for f in (dev, orc):
+        f.prune()
+    compare_maps(sc, dev, orc, scen["n"], ordered=True)
+
+
+def test_vp_fused_update_and_birth_candidates_multi_step(pkg, ob, sc):
+    """Victoria Park cycle: predict (birth candidates with the 5/10/2 thresholds of the shipped cfg, scaled down so that
+    promotions happen within the test) -> update, several steps; maps, weights and the candidate lists must agree."""
+    scen = sc.make_vp_scenario(10, 12, 8, seed=44, params=dict(birth_count_thr=3, birth_check_thr=2))
+    dev, orc = make_vp_pair(pkg, ob, sc, scen)
+    rng = np.random.default_rng(3)
+    promoted = 0
+    for step in range(8):
+        Z = scen["Z"] + rng.normal(0, 1, scen["Z"].shape) * np.array([0.05, 0.002, 0.01])
+        for f in (dev, orc):
+            f.predict_map(True)
+            f.update(Z)
+            s = f.weight_sums()
+            f.normalize_weights(s[0])
+        np.testing.assert_allclose(dev.get_weights(), orc.get_weights(), rtol=1e-8)
+        compare_maps(sc, dev, orc, scen["n"])
+        for i in range(scen["n"]):
+            md, cd, sd, kd = dev.export_birth_candidates(i)
+            mo, co, so, ko = orc.export_birth_candidates(i)
+            assert list(sd) == list(so) and list(kd) == list(ko), (step, i)
+            np.testing.assert_allclose(md, mo, rtol=1e-9, atol=1e-10)
+            np.testing.assert_allclose(cd, (co + np.swapaxes(co, -1, -2)) / 2, rtol=1e-8, atol=1e-12)
+            promoted += len(so)
+    assert promoted > 0, "scenario never produced a birth candidate"
+
+
+def test_2d_birth_candidate_list_mode(pkg, ob, sc):
+    """The candidate-list branch of addBirthGaussians with the 2-D model (birthGaussianMeasurementCountThreshold > 1)."""
+    scen = sc.make_scenario(12, 6, 8, seed=45)
+    dev, orc = make_pair(pkg, ob, sc, scen, cap=128)
+    for f in (dev, orc):
+        cfg = f.get_filter_config()
+        cfg.birthGaussianMeasurementCountThreshold = 3
+        cfg.birthGaussianMeasurementCheckThreshold = 2
+        cfg.birthGaussianMeasurementSupportDist = 2.0
+        cfg.birthGaussianCurrentMeasurementCountThreshold = 0
+        f.set_filter_config(cfg)
+    rng = np.random.default_rng(4)
+    seen = 0
+    for step in range(7):
+        Z = scen["Z"] + rng.normal(0, 1e-3, scen["Z"].shape)
+        for f in (dev, orc):
+            f.predict_map(True)
+            f.update(Z)
+            s = f.weight_sums()
+            f.normalize_weights(s[0])
+        compare_maps(sc, dev, orc, scen["n"])
+        for i in range(scen["n"]):
+            md, cd, sd, kd = dev.export_birth_candidates(i)
+            mo, co, so, ko = orc.export_birth_candidates(i)
+            assert list(sd) == list(so) and list(kd) == list(ko), (step, i)
+            np.testing.assert_allclose(md, mo, rtol=1e-9, atol=1e-11)
+            seen += len(so)
+    assert seen > 0
