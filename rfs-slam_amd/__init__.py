@@ -13,4 +13,5 @@ from . import build as build_mod  # noqa: F401
 from . import engine  # noqa: F401
 from . import scenarios  # noqa: F401
 from . import sharded  # noqa: F401
+from . import vp_driver  # noqa: F401
 from .engine import RBPHDFilter, load_library, mat_perm  # noqa: F401

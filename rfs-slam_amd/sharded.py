@@ -108,7 +108,8 @@ class ShardedRBPHDFilter:
             s = int(plan[g])
             if lo <= s < lo + n and not (lo <= g < lo + n):
                 w, _, mean, cov = self.f.export_gm(s - lo)
-                outgoing[int(g)] = (w, mean, cov, self.f.get_unused(s - lo), self.f.landmarks_in_fov(s - lo))
+                outgoing[int(g)] = (w, mean, cov, self.f.get_unused(s - lo), self.f.landmarks_in_fov(s - lo),
+                                    self.f.export_birth_candidates(s - lo))
         if self.world > 1:
             gathered = [None] * self.world
             dist.all_gather_object(gathered, outgoing, group=self.group)
@@ -123,7 +124,8 @@ class ShardedRBPHDFilter:
         self.f.resample_apply(local_src)              # also resets every weight to 1 (ParticleFilter.hpp:486-489)
         # 3. migrated children: import the packed mixtures into the dead slots
         for d in gathered:
-            for g, (w, mean, cov, unused, nfov) in d.items():
+            for g, (w, mean, cov, unused, nfov, cands) in d.items():
                 if lo <= g < lo + n:
                     self.f.import_gm(g - lo, w, mean, cov)
                     self.f.import_aux(g - lo, unused, nfov)
+                    self.f.import_birth_candidates(g - lo, *cands)   # birthGaussians_ travel with the particle (:1005-1011)

@@ -334,3 +334,27 @@ def test_2d_birth_candidate_list_mode(pkg, ob, sc):
             np.testing.assert_allclose(md, mo, rtol=1e-9, atol=1e-11)
             seen += len(so)
     assert seen > 0
+
+
+def test_victoria_park_dataset_extract_device_vs_oracle(pkg, ob, sc):
+    """Config 4 in miniature: the first sensor messages of the Victoria Park dataset (tests/golden/victoria_park_extract.npz,
+    extracted from the reference's data files) through the event-driven host loop -- predict with birth candidates, artificial
+    clutter, scan-based Pd, update, resampling -- on the device and on the oracle with the same host RNG stream."""
+    import os
+    data = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "victoria_park_extract.npz"))
+    n = 32
+    P = dict(sc.VP_PARAMS)
+    runs = []
+    for make in (lambda: pkg.RBPHDFilter(n, gm_capacity=192, model=pkg.capi.MODEL_VICTORIAPARK_3D),
+                 lambda: ob.OracleFilter(n, stable_sort=True, model=pkg.capi.MODEL_VICTORIAPARK_3D)):
+        f = make()
+        sc.apply_vp_params(f, P, np.full(361, 70.0))
+        runs.append(pkg.vp_driver.VictoriaParkRun(f, data, P, seed=5).run(n_messages=900))
+    dev, orc = runs
+    assert dev.n_lidar == orc.n_lidar and dev.n_lidar > 50
+    assert dev.n_resamples == orc.n_resamples
+    np.testing.assert_allclose(dev.f.get_weights(), orc.f.get_weights(), rtol=1e-6)
+    sizes = dev.f.gm_sizes()
+    assert np.array_equal(sizes, orc.f.gm_sizes()) and sizes.max() > 3
+    for i in range(n):
+        sc.assert_gm_close(dev.f.export_gm(i), orc.f.export_gm(i), 1e-7, 1e-9)
