@@ -358,3 +358,58 @@ def test_victoria_park_dataset_extract_device_vs_oracle(pkg, ob, sc):
     assert np.array_equal(sizes, orc.f.gm_sizes()) and sizes.max() > 3
     for i in range(n):
         sc.assert_gm_close(dev.f.export_gm(i), orc.f.export_gm(i), 1e-7, 1e-9)
+
+
+# ---- BASELINE.json full-size configurations: size-independent properties + oracle parity on a particle subset -------------
+
+def _full_size_check(pkg, ob, sc, scen, cap, subset=24, check_murty=False):
+    n = scen["n"]
+    dev = pkg.RBPHDFilter(n, gm_capacity=cap)
+    sc.load_scenario(dev, scen)
+    dev.update_map(scen["Z"])
+    dev.importance_weighting()
+    w_before_merge = np.array([dev.export_gm(i)[0].sum() for i in range(0, n, max(1, n // 50))])
+    dev.merge()
+    w_after_merge = np.array([dev.export_gm(i)[0].sum() for i in range(0, n, max(1, n // 50))])
+    np.testing.assert_allclose(w_after_merge, w_before_merge, rtol=1e-12)      # merging conserves the total mixture weight
+    dev.prune()
+    sizes1 = dev.gm_sizes()
+    dev.prune()
+    assert np.array_equal(dev.gm_sizes(), sizes1)                                # prune is idempotent
+    P = scen["params"]
+    for i in range(0, n, max(1, n // 50)):
+        w = dev.export_gm(i)[0]
+        assert np.all(w >= P["prune_thr"]) and np.all(np.diff(w) <= 0)           # sorted by weight, nothing below threshold
+    wd = dev.get_weights()
+    assert np.all(np.isfinite(wd)) and np.all(wd > 0)
+    # oracle parity on a subset of the particles (same per-particle inputs => same per-particle outputs)
+    idx = np.linspace(0, n - 1, subset).astype(int)
+    sub = dict(scen)
+    sub.update(n=subset, poses=scen["poses"][idx], w=scen["w"][idx], mean=scen["mean"][idx], cov=scen["cov"][idx], particle_w=scen["particle_w"][idx])
+    if np.ndim(scen["pose_cov"]) == 3:
+        sub["pose_cov"] = scen["pose_cov"][idx]
+    orc = ob.OracleFilter(subset, stable_sort=True)
+    sc.load_scenario(orc, sub)
+    orc.update(scen["Z"])
+    if check_murty:
+        assert orc.murty_calls() > 0
+    np.testing.assert_allclose(wd[idx], orc.get_weights(), rtol=1e-8)
+    for k, i in enumerate(idx):
+        sc.assert_gm_close(dev.export_gm(int(i)), orc.export_gm(k), GM_RTOL, GM_ATOL, ordered=True)
+    dev.close()
+
+
+def test_full_size_c2(pkg, ob, sc):
+    """configs[1]: 2000 particles x 200 GM landmarks x 30 measurements."""
+    _full_size_check(pkg, ob, sc, sc.make_scenario(2000, 200, 30, seed=12345), cap=384)
+
+
+def test_full_size_c3_shard(pkg, ob, sc):
+    """configs[2], one GPU's shard: 2500 particles x 500 GM landmarks x 30 measurements (range limit 5 m)."""
+    _full_size_check(pkg, ob, sc, sc.make_scenario(2500, 500, 30, seed=777, rmax=5.0), cap=704)
+
+
+def test_full_size_c5_murty_stress(pkg, ob, sc):
+    """configs[4]: 1000 particles x 50 measurements, 40 evaluation points, 10-sigma weighting gate -> Murty-200 partitions."""
+    scen = sc.make_scenario(1000, 200, 50, seed=555, n_clutter=10, n_eval=40, weighting_md=10.0, weights=(0.8, 1.0))
+    _full_size_check(pkg, ob, sc, scen, cap=448, subset=16, check_murty=True)
