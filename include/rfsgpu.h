@@ -192,6 +192,15 @@ int rfsgpu_predict_map(rfsgpu_filter *f, int add_birth);
  * (unless useClusterProcess), merge, prune.  z: n_z x d_z doubles.  n_z == 0 returns OK without
  * touching anything (:450-452).  Resampling / normalisation stay with the caller (below). */
 int rfsgpu_update(rfsgpu_filter *f, const double *z, int n_z);
+/* Stream-ordered form of rfsgpu_update: enqueues the same kernels and returns without waiting for the GPU.  Device-side
+ * errors (capacity overflow, ...) surface at the next rfsgpu_synchronize() / synchronous call; per-phase HIP-event pairs of
+ * up to RFSGPU_ASYNC_RING outstanding steps are harvested there into TimingInfo and rfsgpu_kernel_time_stats.  A host loop
+ * that does not need the weights every step (no resampling decision pending) pipelines its steps with this. */
+#define RFSGPU_ASYNC_RING 256
+int rfsgpu_update_async(rfsgpu_filter *f, const double *z, int n_z);
+/* Average duration (ns) of each hot-path kernel group over the async steps harvested since the last call / reset:
+ * [0]=phd_update_map [1]=phd_weight_multifeature(+murty) [2]=gm_merge(+prune); *n_steps = steps averaged. */
+int rfsgpu_kernel_time_stats(rfsgpu_filter *f, double *avg_ns3, int *n_steps);
 /* The same four phases one at a time (used by the parity tests and by profiling):          */
 int rfsgpu_update_map(rfsgpu_filter *f, const double *z, int n_z);      /* updateMap       :543-725 */
 int rfsgpu_importance_weighting(rfsgpu_filter *f);                       /* importanceWeighting :728-997 */
@@ -223,7 +232,7 @@ int rfsgpu_resample_apply(rfsgpu_filter *f, const int *src_slot);
 
 int rfsgpu_get_timing(rfsgpu_filter *f, rfsgpu_timing *t);              /* getTimingInfo :1219-1232 */
 int rfsgpu_reset_timing(rfsgpu_filter *f);
-/* Block until all queued device work of this handle is complete. */
+/* Block until all queued device work of this handle is complete; reports a pending device-side error of async steps. */
 int rfsgpu_synchronize(rfsgpu_filter *f);
 /* Native HIP stream of this handle (hipStream_t as void*), for callers that enqueue around it. */
 void *rfsgpu_stream(rfsgpu_filter *f);

@@ -92,6 +92,7 @@ ABI_SYMBOLS = [
     "get_timing", "reset_timing", "synchronize", "stream", "last_kernel_ns", "mat_perm",
     "set_stream", "bind_weight_sums_buffer", "save_state", "restore_state", "import_aux",
     "set_model_victoriapark", "set_laser_scan", "export_birth_candidates", "import_birth_candidates",
+    "update_async", "kernel_time_stats",
 ]
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")

@@ -63,7 +63,15 @@ struct rfsgpu_filter {
   long long lastKernelNs[4] = {0, 0, 0, 0};
   bool phaseOpen = false;   // update_map ran, weighting/merge/prune may follow
   bool normPending = false; // a normalize_kernel event pair has not been accumulated yet
-  double *hZ = nullptr;     // pinned staging for the measurement set
+  double *hZ = nullptr;     // pinned staging ring for the measurement set: ZRING slots
+  hipEvent_t evZ[8] = {};   // slot k's H2D copy finished
+  bool evZPending[8] = {};
+  unsigned zSlot = 0;
+  // async steps: ring of per-phase event sets, harvested at the next sync
+  hipEvent_t ring[RFSGPU_ASYNC_RING][4] = {};
+  int ringCount = 0;        // async steps recorded since the last harvest
+  double statNs[3] = {0, 0, 0};
+  int statSteps = 0;
   std::string err;
   int maxLds = 0;
   int wpbUpdate = 4, wpbWeight = 4, wpbMerge = 4, wpbPrune = 4;
@@ -226,7 +234,10 @@ int rfsgpu_create(rfsgpu_filter **out, int model, int n_particles, int device_id
   ok &= hipHostMalloc(&f->hErr, sizeof(int)) == hipSuccess;
   ok &= hipHostMalloc(&f->hJobCount, sizeof(int)) == hipSuccess;
   ok &= hipHostMalloc(&f->hSums, 2 * sizeof(double)) == hipSuccess;
-  ok &= hipHostMalloc(&f->hZ, RFSGPU_MAX_Z * 3 * sizeof(double)) == hipSuccess;
+  ok &= hipHostMalloc(&f->hZ, (size_t)8 * RFSGPU_MAX_Z * 3 * sizeof(double)) == hipSuccess;
+  for (int k = 0; k < 8; k++) ok &= hipEventCreateWithFlags(&f->evZ[k], hipEventDisableTiming) == hipSuccess;
+  for (int k = 0; k < RFSGPU_ASYNC_RING; k++)
+    for (int e = 0; e < 4; e++) ok &= hipEventCreate(&f->ring[k][e]) == hipSuccess;
   if (!ok) return bail(RFSGPU_ERR_HIP);
   if (murty_alloc(f->Q, f->MS, f->N) != 0) return bail(RFSGPU_ERR_HIP);
   hipMemsetAsync(B.slab[0], 0, slabBytes, f->stream);
@@ -274,6 +285,9 @@ void rfsgpu_destroy(rfsgpu_filter *f) {
   if (f->hJobCount) hipHostFree(f->hJobCount);
   if (f->hSums) hipHostFree(f->hSums);
   if (f->hZ) hipHostFree(f->hZ);
+  for (int k = 0; k < 8; k++) if (f->evZ[k]) hipEventDestroy(f->evZ[k]);
+  for (int k = 0; k < RFSGPU_ASYNC_RING; k++)
+    for (int e = 0; e < 4; e++) if (f->ring[k][e]) hipEventDestroy(f->ring[k][e]);
   for (int k = 0; k < EV_COUNT; k++) if (f->ev[k]) hipEventDestroy(f->ev[k]);
   if (f->ownStream) hipStreamDestroy(f->ownStream);
   delete f;
@@ -678,10 +692,15 @@ static int stage_measurements(rfsgpu_filter *f, const double *z, int n_z) {
   if (n_z > 0 && !z) return fail(f, RFSGPU_ERR_INVALID, "null measurement buffer");
   hipSetDevice(f->device);
   if (n_z > 0) {
-    // through a pinned staging buffer: the H2D copy is then truly asynchronous.  The previous step's copy has completed
-    // (every update ends with a stream sync) before the buffer is overwritten.
-    memcpy(f->hZ, z, (size_t)n_z * f->D * sizeof(double));
-    HIPCHK(hipMemcpyAsync(f->B.Z, f->hZ, (size_t)n_z * f->D * sizeof(double), hipMemcpyHostToDevice, f->stream));
+    // through a ring of pinned staging slots: the H2D copy is truly asynchronous, and a slot is only reused after the
+    // copy that read it has completed (its event), so pipelined async steps never race on the staging memory
+    const unsigned k = f->zSlot++ & 7u;
+    if (f->evZPending[k]) { HIPCHK(hipEventSynchronize(f->evZ[k])); f->evZPending[k] = false; }
+    double *slot = f->hZ + (size_t)k * RFSGPU_MAX_Z * 3;
+    memcpy(slot, z, (size_t)n_z * f->D * sizeof(double));
+    HIPCHK(hipMemcpyAsync(f->B.Z, slot, (size_t)n_z * f->D * sizeof(double), hipMemcpyHostToDevice, f->stream));
+    HIPCHK(hipEventRecord(f->evZ[k], f->stream));
+    f->evZPending[k] = true;
   }
   f->nZ = n_z;
   return RFSGPU_OK;
@@ -768,6 +787,62 @@ int rfsgpu_update(rfsgpu_filter *f, const double *z, int n_z) {
   accumulate(f->ev[EV_MG1], f->ev[EV_PR1], f->timing.mapPrune_wall, &f->lastKernelNs[3]);
   f->timing.mapUpdate_cpu += now_ns() - t0;
   return rc;
+}
+
+// Fold the event pairs of the async steps recorded since the last harvest into TimingInfo / the kernel statistics.
+// Caller has synchronised the stream.
+static void harvest_async(rfsgpu_filter *f) {
+  const int n = f->ringCount < RFSGPU_ASYNC_RING ? f->ringCount : RFSGPU_ASYNC_RING;
+  for (int k = 0; k < n; k++) {
+    hipEvent_t *e = f->ring[k];
+    long long ns[3] = {0, 0, 0};
+    accumulate(e[0], e[1], f->timing.mapUpdate_wall, &ns[0]);
+    accumulate(e[1], e[2], f->timing.particleWeighting_wall, &ns[1]);
+    accumulate(e[2], e[3], f->timing.mapMerge_wall, &ns[2]);
+    for (int q = 0; q < 3; q++) { f->statNs[q] += (double)ns[q]; f->lastKernelNs[q] = ns[q]; }
+    f->statSteps++;
+  }
+  f->timing.mapUpdate_kf_wall = f->timing.mapUpdate_wall;
+  f->ringCount = 0;
+}
+
+int rfsgpu_update_async(rfsgpu_filter *f, const double *z, int n_z) {
+  CHECK_HANDLE(f);
+  if (n_z == 0) return RFSGPU_OK;  // :450-452
+  long long t0 = now_ns();
+  if (f->ringCount >= RFSGPU_ASYNC_RING) {  // ring full: drain (one sync per RFSGPU_ASYNC_RING steps)
+    hipSetDevice(f->device);
+    HIPCHK(hipStreamSynchronize(f->stream));
+    harvest_async(f);
+  }
+  int rc = stage_measurements(f, z, n_z);
+  if (rc != RFSGPU_OK) return rc;
+  hipEvent_t *e = f->ring[f->ringCount];
+  HIPCHK(hipEventRecord(e[0], f->stream));
+  if ((rc = launch_update_map(f)) != RFSGPU_OK) return rc;
+  HIPCHK(hipEventRecord(e[1], f->stream));
+  if (!f->cfg.useClusterProcess) {
+    if ((rc = launch_weighting(f)) != RFSGPU_OK) return rc;
+  }
+  HIPCHK(hipEventRecord(e[2], f->stream));
+  if ((rc = launch_merge_prune(f)) != RFSGPU_OK) return rc;
+  HIPCHK(hipEventRecord(e[3], f->stream));
+  f->ringCount++;
+  f->timing.mapUpdate_cpu += now_ns() - t0;
+  return RFSGPU_OK;
+}
+
+int rfsgpu_kernel_time_stats(rfsgpu_filter *f, double *avg_ns3, int *n_steps) {
+  CHECK_HANDLE(f);
+  if (!avg_ns3 || !n_steps) return RFSGPU_ERR_INVALID;
+  hipSetDevice(f->device);
+  HIPCHK(hipStreamSynchronize(f->stream));
+  harvest_async(f);
+  for (int q = 0; q < 3; q++) avg_ns3[q] = f->statSteps ? f->statNs[q] / f->statSteps : 0.0;
+  *n_steps = f->statSteps;
+  f->statSteps = 0;
+  f->statNs[0] = f->statNs[1] = f->statNs[2] = 0.0;
+  return RFSGPU_OK;
 }
 
 int rfsgpu_predict_map(rfsgpu_filter *f, int add_birth) {
@@ -888,8 +963,9 @@ int rfsgpu_reset_timing(rfsgpu_filter *f) {
 int rfsgpu_synchronize(rfsgpu_filter *f) {
   CHECK_HANDLE(f);
   hipSetDevice(f->device);
-  HIPCHK(hipStreamSynchronize(f->stream));
-  return RFSGPU_OK;
+  const int rc = check_device_errors(f);  // syncs the stream, reports errors of async steps
+  harvest_async(f);
+  return rc;
 }
 void *rfsgpu_stream(rfsgpu_filter *f) { return f ? (void *)f->stream : nullptr; }
 int rfsgpu_set_stream(rfsgpu_filter *f, void *hip_stream) {

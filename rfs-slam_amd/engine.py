@@ -56,6 +56,17 @@ class RBPHDFilter(capi.CFilter):
         self._call("last_kernel_ns", ns)
         return list(ns)
 
+    def update_async(self, Z):
+        """Stream-ordered update: no host sync; errors surface at synchronize()."""
+        Z, n = self._z(Z)
+        self._call("update_async", self._ptr(Z), n)
+
+    def kernel_time_stats(self):
+        avg = (C.c_double * 3)()
+        n = C.c_int()
+        self._call("kernel_time_stats", avg, C.byref(n))
+        return list(avg), n.value
+
     def weight_sums_async(self):
         self._call("weight_sums_async")
 
