@@ -20,7 +20,7 @@
 // their inverses are formed on demand for the few pairs that survive the distance prefilter -- this keeps the
 // footprint at 36 B/entry so that 8+ waves fit a CU and 2000 particles run in a single round.
 #define MERGE_GRID 16
-#define MERGE_PAIR_CAP(cap) (2 * (cap))
+#define MERGE_PAIR_CAP(cap) ((2 * (cap)) > ((cap) + 320) ? (2 * (cap)) : ((cap) + 320))
 __host__ __device__ inline size_t merge_lds_bytes_per_wave(int cap) {
   // entries: 4 doubles + firstCand (u32, atomicMin target) + grid-sorted index (u16); grid: 2 x 257 u32; pair list: u32
   return (((size_t)cap * (4 * 8 + 4 + 2)) + (size_t)(MERGE_GRID * MERGE_GRID + 1) * 4 * 2 + (size_t)MERGE_PAIR_CAP(cap) * 4 + 16 + 15) & ~(size_t)15;
@@ -67,6 +67,7 @@ __device__ __forceinline__ bool merge_pair_passes(double e0, double e1, double a
 //   lowest passing j, update a, re-test only j' > j against the new state (ballot + ctz), skip absorbed entries.
 // FUSE_PRUNE: survivors (w >= pruneT, not absorbed) are rank-sorted by (weight desc, index asc) and compacted into
 //   the other slab straight from here (GaussianMixture::prune :477-521), saving gm_prune's launch and re-read.
+#define MERGE_NB_WORDS 8  // speculative replay: neighbourhood indices kept in registers, 4 per 64-bit word
 template <int WPB, bool FUSE_PRUNE>
 __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P, int cur, int dst) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
     const double bnd = merge_bound(t2, pSXX[m], pSXY[m], pSYY[m]);
     sMX[m] = mx; sMY[m] = my; sW[m] = w; sBnd[m] = bnd;
     sFirst[m] = 0xffffu;
-    if (w < 0) { hole |= 1u << sidx; continue; }  // already absorbed (merge called twice)
+    if (w < 0) { hole |= 1u << sidx; sBnd[m] = -1.0; continue; }  // already absorbed (merge called twice); bound < 0 marks a hole
     const float fx = (float)mx, fy = (float)my;
     fxmin = fminf(fxmin, fx); fxmax = fmaxf(fxmax, fx);
     fymin = fminf(fymin, fy); fymax = fmaxf(fymax, fy);
@@ -230,77 +231,272 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
   wave_sync();
 
   DBG_T(32, 2);
-  // ---- phase 2: replay rows that have a candidate, in order, with the exact greedy rule ----
+  // ---- phase 2: replay the rows that have a candidate, with the exact greedy rule ----
+  // Liveness lives in LDS from here on: sBnd[j] < 0  <=>  j has been absorbed.
+  //
+  // Speculative lane-parallel replay + ordered validation.  Up to 64 candidate rows at a time, one per lane, are
+  // replayed independently against the states every entry had when the round started: the lane walks the partners of
+  // its row in ascending index order (each met once, with the row's state at that moment, found through the grid around
+  // the row's CURRENT position and radius), merging as the reference would.  A row only reads entries with a higher
+  // index, and an entry's mean/covariance change only while it is the outer row, so the sole cross-row hazard is an
+  // entry absorbed by an EARLIER row of the same round.  Rows are therefore validated in ascending order: a row that
+  // was itself absorbed is dropped; a row that absorbed an entry already taken is replayed again, sequentially by the
+  // whole wave (the reference's own scan), with the committed holes visible; everything else commits as computed.
   bool anyMerge = false;
 #ifdef RFS_PROFILE
   int dbgRows = 0, dbgMerges = 0, dbgChunks = 0;
 #endif
-  for (int r0 = 0; r0 < N; r0 += 64) {
-    const int rr = r0 + lane;
-    unsigned long long rows = __ballot(rr < N && sFirst[rr] != 0xffffu);
-    while (rows) {
-      const int a = r0 + __builtin_ctzll(rows);
-      rows &= rows - 1;
-      const unsigned ownerHole = (unsigned)__builtin_amdgcn_readlane((int)hole, a & 63);
-      if ((ownerHole >> (a >> 6)) & 1u) continue;  // a was absorbed by an earlier row
-      const int j0 = sFirst[a];
+  unsigned *sRows = sPairs;                                                           // [<= cap] candidate rows, ascending
+  unsigned short *sSpec = reinterpret_cast<unsigned short *>(sPairs + cap);           // [64][8] absorbed entries per lane
+  int nRowsTotal = 0;
+  for (int c0 = 0; c0 < N; c0 += 64) {
+    const int m = c0 + lane;
+    const bool isRow = (m < N) && (sFirst[m] != 0xffffu);
+    if (m < N) sFirst[m] |= 0xffff0000u;  // upper half: claim slot of the speculative round (none)
+    const unsigned long long rm = __ballot(isRow);
+    if (isRow) sRows[nRowsTotal + __popcll(rm & ((1ull << lane) - 1ull))] = (unsigned)m;
+    nRowsTotal += __popcll(rm);
+  }
+  wave_sync();
+  DBG_T(32, 9);
+
+  // the reference's sequential scan for ONE row, executed by the whole wave (fallback + exactness anchor)
+  auto seq_replay = [&](const int a) {
+    const int j0 = (int)(sFirst[a] & 0xffffu);
+    double ax = sMX[a], ay = sMY[a], aw = sW[a], ab = sBnd[a];
+    double axx = pSXX[a], axy = pSXY[a], ayy = pSYY[a];
+    double a00, a01, a10, a11, adet;
+    inv2(axx, axy, axy, ayy, a00, a01, a10, a11, adet);
+    bool changed = false;
+    int floorLane = j0 & 63;  // every j < j0 is known to fail against a's initial state
+    for (int c0 = j0 & ~63; c0 < N; c0 += 64) {
+      const int j = c0 + lane;
 #ifdef RFS_PROFILE
-      dbgRows++;
+      dbgChunks++;
 #endif
-      double ax = sMX[a], ay = sMY[a], aw = sW[a], ab = sBnd[a];
-      double axx = pSXX[a], axy = pSXY[a], ayy = pSYY[a];
+      double jx = 0, jy = 0, jw = 0, jb = -1.0;
+      if (j > a && j < N) { jx = sMX[j]; jy = sMY[j]; jw = sW[j]; jb = sBnd[j]; }
+      bool live = !(jb < 0.0);
+      while (true) {
+        bool pass = false;
+        if (live && lane >= floorLane) {
+          const double e0 = jx - ax, e1 = jy - ay;
+          if (!((e0 * e0 + e1 * e1) > fmax(ab, jb))) pass = merge_pair_passes(e0, e1, a00, a01, a11, aw, jw, pSXX, pSXY, pSYY, j, t2);
+        }
+        const unsigned long long pm = __ballot(pass);
+        if (pm == 0ull) break;
+        const int l = __builtin_ctzll(pm);
+        const int jj = c0 + l;
+        // merge jj into a (GaussianMixture.hpp:444-471), wave-uniform arithmetic
+        const double w1 = aw, w2 = sW[jj];
+        const double x2 = sMX[jj], y2 = sMY[jj], bxx = pSXX[jj], bxy = pSXY[jj], byy = pSYY[jj];
+        const double wm = w1 + w2;
+        const double xm = (ax * w1 + x2 * w2) / wm, ym = (ay * w1 + y2 * w2) / wm;
+        const double d10 = xm - ax, d11 = ym - ay, d20 = xm - x2, d21 = ym - y2;
+        const double nxx = (w1 * (axx + (f * d10) * d10) + w2 * (bxx + (f * d20) * d20)) / wm;
+        const double nxy = (w1 * (axy + (f * d10) * d11) + w2 * (bxy + (f * d20) * d21)) / wm;
+        const double nyy = (w1 * (ayy + (f * d11) * d11) + w2 * (byy + (f * d21) * d21)) / wm;
+        ax = xm; ay = ym; axx = nxx; axy = nxy; ayy = nyy; aw = wm;
+        inv2(axx, axy, axy, ayy, a00, a01, a10, a11, adet);
+        ab = merge_bound(t2, axx, axy, ayy);
+        changed = true;
+#ifdef RFS_PROFILE
+        dbgMerges++;
+#endif
+        if (lane == l) { sBnd[jj] = -1.0; live = false; }
+        floorLane = l + 1;
+        if (floorLane >= 64) break;
+      }
+      floorLane = 0;
+    }
+    if (changed) {
+      anyMerge = true;
+      sW[a] = aw;  // uniform store; the other LDS fields of a are never read again (a is behind the scan)
+      if (lane == 0) { pW[a] = aw; pMX[a] = ax; pMY[a] = ay; pSXX[a] = axx; pSXY[a] = axy; pSYY[a] = ayy; }
+    }
+    wave_sync();
+  };
+
+  for (int r0 = 0; r0 < nRowsTotal; r0 += 64) {
+    const int cnt = (nRowsTotal - r0 < 64) ? nRowsTotal - r0 : 64;
+    // ---- speculative replay, one row per lane ----
+    const int a = (lane < cnt) ? (int)sRows[r0 + lane] : 0;
+    const bool active = (lane < cnt) && !(sBnd[a] < 0.0);
+    int nAbs = 0;
+    bool ovf = false;
+    double ax = 0, ay = 0, aw = 0, axx = 1, axy = 0, ayy = 1;
+    if (active) {
+      ax = sMX[a]; ay = sMY[a]; aw = sW[a];
+      double ab = sBnd[a];
+      axx = pSXX[a]; axy = pSXY[a]; ayy = pSYY[a];
       double a00, a01, a10, a11, adet;
       inv2(axx, axy, axy, ayy, a00, a01, a10, a11, adet);
-      bool changed = false;
-      int floorLane = j0 & 63;  // every j < j0 is known to fail against a's initial state
-      for (int c0 = j0 & ~63; c0 < N; c0 += 64) {
-        const int j = c0 + lane;
-        const int slot = c0 >> 6;
-#ifdef RFS_PROFILE
-        dbgChunks++;
-#endif
-        bool live = (j > a) && (j < N) && !((hole >> slot) & 1u);
-        double jx = 0, jy = 0, jw = 0, jb = 0;
-        if (live) { jx = sMX[j]; jy = sMY[j]; jw = sW[j]; jb = sBnd[j]; }
-        while (true) {
-          bool pass = false;
-          if (live && lane >= floorLane) {
-            const double e0 = jx - ax, e1 = jy - ay;
-            if (!((e0 * e0 + e1 * e1) > fmax(ab, jb))) pass = merge_pair_passes(e0, e1, a00, a01, a11, aw, jw, pSXX, pSXY, pSYY, j, t2);
+      unsigned cur = (unsigned)a;
+      // The row's neighbourhood (higher indices only) is gathered into registers, up to 32 indices of 16 bits, and
+      // gathered again only if a merge moves the row to another cell or enlarges its reach.
+      unsigned long long nb[MERGE_NB_WORDS];
+      int nNb = 0, gcx = -1, gcy = -1, greach = -1;
+      for (int round = 0; round < cap; round++) {
+        int cx, cy;
+        cell_of(ax, ay, cx, cy);
+        int reach = MERGE_GRID;
+        if (!degenerate && ab < 1.0e300) { const double rr = sqrt(ab) * invCell; reach = (rr < (double)MERGE_GRID) ? (int)rr + 1 : MERGE_GRID; }
+        if (cx != gcx || cy != gcy || reach != greach) {
+          gcx = cx; gcy = cy; greach = reach;
+          nNb = 0;
+#pragma unroll
+          for (int g = 0; g < MERGE_NB_WORDS; g++) nb[g] = 0ull;
+          const int cxa = cx - reach > 0 ? cx - reach : 0, cxb = cx + reach < MERGE_GRID - 1 ? cx + reach : MERGE_GRID - 1;
+          const int cya = cy - reach > 0 ? cy - reach : 0, cyb = cy + reach < MERGE_GRID - 1 ? cy + reach : MERGE_GRID - 1;
+          for (int ry = cya; ry <= cyb && nNb <= 4 * MERGE_NB_WORDS; ry++) {
+            const unsigned qs = sCellStart[ry * MERGE_GRID + cxa], qe = sCellStart[ry * MERGE_GRID + cxb + 1];
+            for (unsigned q = qs; q < qe; q++) {
+              const unsigned j = sSorted[q];
+              if (j <= (unsigned)a) continue;
+              const unsigned long long v = (unsigned long long)j << (16 * (nNb & 3));
+#pragma unroll
+              for (int g = 0; g < MERGE_NB_WORDS; g++)
+                if ((nNb >> 2) == g) nb[g] |= v;
+              nNb++;
+            }
           }
-          const unsigned long long pm = __ballot(pass);
-          if (pm == 0ull) break;
-          const int l = __builtin_ctzll(pm);
-          const int jj = c0 + l;
-          // merge jj into a (GaussianMixture.hpp:444-471), wave-uniform arithmetic
-          const double w1 = aw, w2 = sW[jj];
-          const double x2 = sMX[jj], y2 = sMY[jj], bxx = pSXX[jj], bxy = pSXY[jj], byy = pSYY[jj];
+          if (nNb > 4 * MERGE_NB_WORDS) { ovf = true; break; }  // crowded neighbourhood: leave the row to the sequential scan
+        }
+        // One pass over the neighbourhood with the row's CURRENT state: the (up to) four lowest live partners above
+        // `cur` that pass the distance prefilter, kept sorted by a min/max insertion network.
+        unsigned c0 = 0xffffu, c1 = 0xffffu, c2 = 0xffffu, c3 = 0xffffu;
+        int nPass = 0;
+#pragma unroll
+        for (int g = 0; g < MERGE_NB_WORDS; g++) {
+          if (4 * g >= nNb) break;
+          const unsigned long long word = nb[g];
+          unsigned jj[4];
+          double jx[4], jy[4], jbb[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            jj[k] = (unsigned)((word >> (16 * k)) & 0xffffull);
+            const unsigned js = (4 * g + k < nNb) ? jj[k] : (unsigned)a;
+            jx[k] = sMX[js]; jy[k] = sMY[js]; jbb[k] = sBnd[js];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const double e0 = jx[k] - ax, e1 = jy[k] - ay;
+            const bool c = (4 * g + k < nNb) & (jj[k] > cur) & !(jbb[k] < 0.0) & !((e0 * e0 + e1 * e1) > fmax(ab, jbb[k]));
+            unsigned x = c ? jj[k] : 0xffffu, t;
+            nPass += c ? 1 : 0;
+            t = min(c0, x); x = max(c0, x); c0 = t;
+            t = min(c1, x); x = max(c1, x); c1 = t;
+            t = min(c2, x); x = max(c2, x); c2 = t;
+            c3 = min(c3, x);
+          }
+        }
+        if (nPass == 0) break;
+        // their weights / means / covariances in one batch of independent loads
+        const unsigned cs[4] = {c0, c1, c2, c3};
+        double qw[4], qx[4], qy[4], qxx[4], qxy[4], qyy[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const unsigned js = (cs[k] != 0xffffu) ? cs[k] : (unsigned)a;
+          qw[k] = sW[js]; qx[k] = sMX[js]; qy[k] = sMY[js];
+          qxx[k] = pSXX[js]; qxy[k] = pSXY[js]; qyy[k] = pSYY[js];
+        }
+        bool merged = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (merged || cs[k] == 0xffffu) continue;
+          cur = cs[k];
+          const double e0 = qx[k] - ax, e1 = qy[k] - ay;
+          const double u0 = e0 * a00 + e1 * a01, u1 = e0 * a01 + e1 * a11;
+          bool far = (u0 * e0 + u1 * e1) > t2;
+          if (far) {
+            double j00, j01, j10, j11, jdet;
+            inv2(qxx[k], qxy[k], qxy[k], qyy[k], j00, j01, j10, j11, jdet);
+            const double g0 = -e0, g1 = -e1;
+            const double v0 = g0 * j00 + g1 * j01, v1 = g0 * j01 + g1 * j11;
+            far = (v0 * g0 + v1 * g1) > t2;
+          }
+          if (far || ((aw + qw[k]) == 0.0)) continue;
+          if (nAbs >= 8) { ovf = true; merged = true; continue; }
+          sSpec[lane * 8 + nAbs] = (unsigned short)cs[k];
+          nAbs++;
+          const double w1 = aw, w2 = qw[k];
           const double wm = w1 + w2;
-          const double xm = (ax * w1 + x2 * w2) / wm, ym = (ay * w1 + y2 * w2) / wm;
-          const double d10 = xm - ax, d11 = ym - ay, d20 = xm - x2, d21 = ym - y2;
-          const double nxx = (w1 * (axx + (f * d10) * d10) + w2 * (bxx + (f * d20) * d20)) / wm;
-          const double nxy = (w1 * (axy + (f * d10) * d11) + w2 * (bxy + (f * d20) * d21)) / wm;
-          const double nyy = (w1 * (ayy + (f * d11) * d11) + w2 * (byy + (f * d21) * d21)) / wm;
+          const double xm = (ax * w1 + qx[k] * w2) / wm, ym = (ay * w1 + qy[k] * w2) / wm;
+          const double d10 = xm - ax, d11 = ym - ay, d20 = xm - qx[k], d21 = ym - qy[k];
+          const double nxx = (w1 * (axx + (f * d10) * d10) + w2 * (qxx[k] + (f * d20) * d20)) / wm;
+          const double nxy = (w1 * (axy + (f * d10) * d11) + w2 * (qxy[k] + (f * d20) * d21)) / wm;
+          const double nyy = (w1 * (ayy + (f * d11) * d11) + w2 * (qyy[k] + (f * d21) * d21)) / wm;
           ax = xm; ay = ym; axx = nxx; axy = nxy; ayy = nyy; aw = wm;
           inv2(axx, axy, axy, ayy, a00, a01, a10, a11, adet);
           ab = merge_bound(t2, axx, axy, ayy);
-          changed = true;
-#ifdef RFS_PROFILE
-          dbgMerges++;
-#endif
-          if (lane == l) { hole |= 1u << slot; live = false; }
-          floorLane = l + 1;
-          if (floorLane >= 64) break;
+          merged = true;  // the prefilter of everything above `cur` has to be redone with the new state
         }
-        floorLane = 0;
-      }
-      if (changed) {
-        anyMerge = true;
-        sW[a] = aw;  // uniform store; the other LDS fields of a are never read again (a is behind the scan)
-        if (lane == 0) { pW[a] = aw; pMX[a] = ax; pMY[a] = ay; pSXX[a] = axx; pSXY[a] = axy; pSYY[a] = ayy; }
+        if (ovf) break;
+        if (!merged && nPass <= 4) break;  // every partner that could pass has been met
       }
     }
+    // claims: (lane << 16) in the upper half of sFirst[e] for every entry a lane absorbed (lowest lane wins)
+    for (int k = 0; k < nAbs; k++) {
+      const unsigned e = sSpec[lane * 8 + k];
+      atomicMin(&sFirst[e], ((unsigned)lane << 16) | (sFirst[e] & 0xffffu));
+    }
+    wave_sync();
+    DBG_T(32, 10);
+    // A lane is CLEAN when nobody claimed its row and it holds the claim on everything it absorbed.  The rows before
+    // the first dirty lane cannot be affected by any other row of the round: they commit together.  From the first
+    // dirty lane on, rows are validated one by one in ascending order, and replayed by the whole wave on a conflict.
+    bool dirty = ovf;
+    if (active) {
+      dirty |= (sFirst[a] >> 16) != 0xffffu;
+      for (int k = 0; k < nAbs; k++) dirty |= (sFirst[sSpec[lane * 8 + k]] >> 16) != (unsigned)lane;
+    }
+    const unsigned long long actm = __ballot(active);
+    const unsigned long long dm = __ballot(dirty & active);
+    const int firstDirty = dm ? __builtin_ctzll(dm) : 64;
+    unsigned long long commit = 0;
+    if (active && lane < firstDirty && nAbs > 0) {
+      for (int k = 0; k < nAbs; k++) sBnd[sSpec[lane * 8 + k]] = -1.0;
+    }
+    commit = __ballot(active && lane < firstDirty && nAbs > 0);
+#ifdef RFS_PROFILE
+    dbgRows += __popcll(actm & ((firstDirty < 64) ? ((1ull << firstDirty) - 1ull) : ~0ull));
+#endif
+    wave_sync();
+    for (int l = firstDirty; l < cnt; l++) {
+      if (!((actm >> l) & 1ull)) continue;
+      const int al = __builtin_amdgcn_readlane(a, l);
+      if (sBnd[al] < 0.0) continue;  // absorbed by an earlier row of this round: the row no longer exists
+#ifdef RFS_PROFILE
+      dbgRows++;
+#endif
+      const int nl = __builtin_amdgcn_readlane(nAbs, l);
+      const bool ovl = (__ballot(ovf) >> l) & 1ull;
+      bool taken = false;
+      int mine = 0;
+      if (lane < nl) { mine = sSpec[l * 8 + lane]; taken = sBnd[mine] < 0.0; }
+      if (ovl || __ballot(taken) != 0ull) {
+        seq_replay(al);  // conflict (or more merges than the speculative buffer holds): the reference's scan, exactly
+      } else {
+        if (lane < nl) sBnd[mine] = -1.0;
+        if (nl > 0) commit |= 1ull << l;
+        wave_sync();
+      }
+    }
+    if ((commit >> lane) & 1ull) {  // committed rows publish their merged state
+      anyMerge = true;
+      sW[a] = aw;
+      pW[a] = aw; pMX[a] = ax; pMY[a] = ay; pSXX[a] = axx; pSXY[a] = axy; pSYY[a] = ayy;
+    }
+    anyMerge = __ballot(anyMerge) != 0ull;
+    // claims are per round
+    if (r0 + 64 < nRowsTotal)
+      for (int m = lane; m < N; m += 64) sFirst[m] |= 0xffff0000u;
+    wave_sync();
+    DBG_T(32, 11);
   }
+  // hole flags back into the per-lane registers used by the write-back / prune below
+  for (int m = lane, sidx = 0; m < N; m += 64, sidx++)
+    if (sBnd[m] < 0.0) hole |= 1u << sidx;
 
 #ifdef RFS_PROFILE
   if (B.dbg && i == 7 && lane == 0) { B.dbg[48] = dbgRows; B.dbg[49] = dbgMerges; B.dbg[50] = dbgChunks; B.dbg[51] = N; }

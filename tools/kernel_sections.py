@@ -44,5 +44,6 @@ for base, ns in names.items():
         print(f"{nm_:28s} {d:10d} cycles")
 print("update_map pass0: precompute %d, gates %d, maha+lik %d, scan+write %d, fold %d" % (t[4]-t[0], t[5]-t[4], t[6]-t[5], t[7]-t[6], t[8]-t[7]))
 print("weight: rank sort %d, write %d" % (t[16+8]-t[16], t[17]-t[16+8]))
+print("merge phase2: rows %d, speculative %d, validate %d, tail %d" % (t[41]-t[34], t[42]-t[41], t[43]-t[42], t[35]-t[43]))
 print("merge: grid build %d, candidate scan %d; phase2 rows %d merges %d chunks %d N %d" % (t[40]-t[33], t[34]-t[40], t[48], t[49], t[50], t[51]))
 print("kernel ns (events):", f.last_kernel_ns())
