@@ -78,8 +78,10 @@ struct Buffers {
 // particle `RFS_PROFILE_PARTICLE`'s lane 0 stamps s_memtime at section boundaries.
 #ifdef RFS_PROFILE
 #define DBG_T(base, k) do { if (B.dbg && i == 7 && lane == 0) B.dbg[(base) + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define DBG_TB(base, k) do { if (B.dbg && i == 7 && threadIdx.x == 0) B.dbg[(base) + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define DBG_T(base, k) do { } while (0)
+#define DBG_TB(base, k) do { } while (0)
 #endif
 
 __device__ __forceinline__ double *plane(double *slab, int cap, int particle, int pl) {

@@ -19,11 +19,17 @@
 // plus the 16x16 spatial grid: cell start offsets and scatter cursors (u32 each).  Covariances stay in HBM/L2 and
 // their inverses are formed on demand for the few pairs that survive the distance prefilter -- this keeps the
 // footprint at 36 B/entry so that 8+ waves fit a CU and 2000 particles run in a single round.
-#define MERGE_GRID 16
+#define MERGE_GX 32  // grid cells along x
+#define MERGE_GY 16  // grid cells along y
+#define MERGE_CELLS (MERGE_GX * MERGE_GY)
 #define MERGE_PAIR_CAP(cap) ((2 * (cap)) > ((cap) + 320) ? (2 * (cap)) : ((cap) + 320))
 __host__ __device__ inline size_t merge_lds_bytes_per_wave(int cap) {
   // entries: 4 doubles + firstCand (u32, atomicMin target) + grid-sorted index (u16); grid: 2 x 257 u32; pair list: u32
-  return (((size_t)cap * (4 * 8 + 4 + 2)) + (size_t)(MERGE_GRID * MERGE_GRID + 1) * 4 * 2 + (size_t)MERGE_PAIR_CAP(cap) * 4 + 16 + 15) & ~(size_t)15;
+  return (((size_t)cap * (4 * 8 + 4 + 2)) + (size_t)(MERGE_CELLS + 4) * 4 + (size_t)MERGE_PAIR_CAP(cap) * 4 + 16 + 15) & ~(size_t)15;
+}
+// + cross-wave reduction scratch ([waves][8] floats) when a workgroup of several waves works on one particle
+__host__ __device__ inline size_t merge_lds_bytes_per_block(int cap, int wavesPerParticle) {
+  return merge_lds_bytes_per_wave(cap) + (size_t)wavesPerParticle * 32;
 }
 
 // Necessary condition for a pair to pass the merge test: md2 = e^T S^-1 e >= |e|^2 / lambda_max(S) >= |e|^2 / tr(S),
@@ -68,19 +74,26 @@ __device__ __forceinline__ bool merge_pair_passes(double e0, double e1, double a
 // FUSE_PRUNE: survivors (w >= pruneT, not absorbed) are rank-sorted by (weight desc, index asc) and compacted into
 //   the other slab straight from here (GaussianMixture::prune :477-521), saving gm_prune's launch and re-read.
 #define MERGE_NB_WORDS 8  // speculative replay: neighbourhood indices kept in registers, 4 per 64-bit word
-template <int WPB, bool FUSE_PRUNE>
-__global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P, int cur, int dst) {
+// One workgroup of WPP waves per particle: the entry- and pair-parallel phases (stage, grid, phase 1, prune) are spread
+// over all WPP*64 threads, which is what fills the SIMDs at ~2000 particles; phase 2 is run by wave 0.
+#ifndef MERGE_WAVES_PER_EU
+#define MERGE_WAVES_PER_EU 4  // 128 VGPRs: with 2 waves per particle all ~2000 particles of C2 are resident at once
+#endif
+template <int WPP, bool FUSE_PRUNE>
+__global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(MERGE_WAVES_PER_EU))) void gm_merge_kernel(Buffers B, Params P, int cur, int dst) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  const int wave = threadIdx.x >> 6;
-  const int lane = threadIdx.x & 63;
-  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
-  if (i >= B.N) return;
+  constexpr int NT = WPP * 64;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int i = blockIdx.x;
   const int cap = B.cap;
-  unsigned char *wbase = smem_raw + (size_t)wave * merge_lds_bytes_per_wave(cap);
+  unsigned char *wbase = smem_raw;
+  float *sRed = reinterpret_cast<float *>(smem_raw + merge_lds_bytes_per_wave(cap));  // [WPP][8] cross-wave reduction scratch
+  auto block_sync = [&]() { if (WPP == 1) wave_sync(); else __syncthreads(); };
   double *sMX = reinterpret_cast<double *>(wbase), *sMY = sMX + cap, *sW = sMX + 2 * cap, *sBnd = sMX + 3 * cap;
-  unsigned *sCellStart = reinterpret_cast<unsigned *>(sMX + 4 * cap);      // [GRID*GRID + 1]
-  unsigned *sCellCur = sCellStart + (MERGE_GRID * MERGE_GRID + 1);          // [GRID*GRID (+1 pad)]
-  unsigned *sFirst = sCellCur + MERGE_GRID * MERGE_GRID + 1;                // [cap] lowest passing partner (0xffff = none)
+  unsigned *sCellStart = reinterpret_cast<unsigned *>(sMX + 4 * cap);      // [CELLS + 1]: cell c's entries are sSorted[start[c] .. start[c+1])
+  unsigned *sFirst = sCellStart + MERGE_CELLS + 4;                          // [cap] lowest passing partner (0xffff = none)
   unsigned *sPairs = sFirst + cap;                                          // [PAIR_CAP] (a << 16) | j, prefilter survivors
   unsigned *sPairCount = sPairs + MERGE_PAIR_CAP(cap);                      // [1] (+3 pad)
   unsigned short *sSorted = reinterpret_cast<unsigned short *>(sPairCount + 4);
@@ -91,11 +104,11 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
   double *pSXX = plane(slab, cap, i, PL_SXX), *pSXY = plane(slab, cap, i, PL_SXY), *pSYY = plane(slab, cap, i, PL_SYY);
   const double t2 = P.mergeT2, f = P.mergeInfl;
 
-  DBG_T(32, 0);
+  DBG_TB(32, 0);
   // ---- stage; hole flags live in per-lane registers: bit s of `hole` <=> entry s*64+lane is a hole ----
   unsigned hole = 0;
   float fxmin = 3.0e38f, fxmax = -3.0e38f, fymin = 3.0e38f, fymax = -3.0e38f, frad = 0.f;
-  for (int m = lane, sidx = 0; m < N; m += 64, sidx++) {
+  for (int m = tid, sidx = 0; m < N; m += NT, sidx++) {
     const double w = pW[m], mx = pMX[m], my = pMY[m];
     const double bnd = merge_bound(t2, pSXX[m], pSXY[m], pSYY[m]);
     sMX[m] = mx; sMY[m] = my; sW[m] = w; sBnd[m] = bnd;
@@ -106,74 +119,88 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
     fymin = fminf(fymin, fy); fymax = fmaxf(fymax, fy);
     frad = fmaxf(frad, sqrtf((float)bnd) * 1.0001f);
   }
-  for (int c = lane; c <= MERGE_GRID * MERGE_GRID; c += 64) sCellStart[c] = 0u;
-  wave_sync();
-
-  DBG_T(32, 1);
-  // ---- phase 1: grid build ----
+  for (int c = tid; c <= MERGE_CELLS; c += NT) sCellStart[c] = 0u;
   fxmin = wave_min_f32(fxmin); fxmax = wave_max_f32(fxmax);
   fymin = wave_min_f32(fymin); fymax = wave_max_f32(fymax);
   frad = wave_max_f32(frad);
-  // float rounding of the box / radius is covered by the 1e-3 relative slack on the cell edge; indices are clamped
-  // (clamping is monotone, so adjacency is preserved for out-of-box values)
+  if (WPP > 1 && lane == 0) { float *r = sRed + wave * 8; r[0] = fxmin; r[1] = fxmax; r[2] = fymin; r[3] = fymax; r[4] = frad; }
+  block_sync();
+
+  DBG_TB(32, 1);
+  // ---- phase 1: grid build ----
+  if (WPP > 1) {
+#pragma unroll
+    for (int w2 = 0; w2 < WPP; w2++) {
+      const float *r = sRed + w2 * 8;
+      fxmin = fminf(fxmin, r[0]); fxmax = fmaxf(fxmax, r[1]); fymin = fminf(fymin, r[2]); fymax = fmaxf(fymax, r[3]); frad = fmaxf(frad, r[4]);
+    }
+  }
+  // float rounding of the box / radius is covered by the 1e-3 relative slack on the cell edges; indices are clamped
+  // (clamping is monotone, so adjacency is preserved for out-of-box values).  Cell edges are >= the largest prefilter
+  // radius in both directions, so every pair that can pass lies in adjacent cells.
   const double x0 = (double)fxmin - 1e-3 * fabs((double)fxmin) - 1e-30, y0 = (double)fymin - 1e-3 * fabs((double)fymin) - 1e-30;
-  const double span = fmax((double)fxmax - x0, (double)fymax - y0);
-  const double cell = fmax((double)frad, span / MERGE_GRID) * 1.001 + 1e-300;
-  const bool degenerate = !(cell < 1.0e300) || !(span == span);  // inf / NaN -> a single cell
-  const double invCell = degenerate ? 0.0 : 1.0 / cell;
+  const double spanx = (double)fxmax - x0, spany = (double)fymax - y0;
+  const double cellx = fmax((double)frad, spanx / MERGE_GX) * 1.001 + 1e-300, celly = fmax((double)frad, spany / MERGE_GY) * 1.001 + 1e-300;
+  const bool degenerate = !(cellx < 1.0e300) || !(celly < 1.0e300) || !(spanx == spanx) || !(spany == spany);  // inf / NaN -> a single cell
+  const double invCx = degenerate ? 0.0 : 1.0 / cellx, invCy = degenerate ? 0.0 : 1.0 / celly;
   auto cell_of = [&](double x, double y, int &cx, int &cy) {
-    int ix = (int)((x - x0) * invCell), iy = (int)((y - y0) * invCell);
-    cx = ix < 0 ? 0 : (ix >= MERGE_GRID ? MERGE_GRID - 1 : ix);
-    cy = iy < 0 ? 0 : (iy >= MERGE_GRID ? MERGE_GRID - 1 : iy);
+    int ix = (int)((x - x0) * invCx), iy = (int)((y - y0) * invCy);
+    cx = ix < 0 ? 0 : (ix >= MERGE_GX ? MERGE_GX - 1 : ix);
+    cy = iy < 0 ? 0 : (iy >= MERGE_GY ? MERGE_GY - 1 : iy);
     if (degenerate) { cx = 0; cy = 0; }
   };
-  for (int m = lane, sidx = 0; m < N; m += 64, sidx++) {
+  // cells a Gaussian of squared prefilter radius `ab` can reach from its own cell, per axis
+  auto reach_of = [&](double ab, int &rx, int &ry) {
+    rx = MERGE_GX; ry = MERGE_GY;
+    if (!degenerate && ab < 1.0e300) {
+      const double r = sqrt(ab), qx = r * invCx, qy = r * invCy;
+      rx = (qx < (double)MERGE_GX) ? (int)qx + 1 : MERGE_GX;
+      ry = (qy < (double)MERGE_GY) ? (int)qy + 1 : MERGE_GY;
+    }
+  };
+  for (int m = tid, sidx = 0; m < N; m += NT, sidx++) {
     if ((hole >> sidx) & 1u) continue;
     int cx, cy;
     cell_of(sMX[m], sMY[m], cx, cy);
-    atomicAdd(&sCellStart[cy * MERGE_GRID + cx + 1], 1u);  // counts, shifted by one for the exclusive scan
+    atomicAdd(&sCellStart[cy * MERGE_GX + cx + 1], 1u);  // counts, shifted by one
   }
-  wave_sync();
-  {  // exclusive scan of 256 counts: 4 per lane + wave scan
-    const unsigned c0 = sCellStart[4 * lane + 1], c1 = sCellStart[4 * lane + 2], c2 = sCellStart[4 * lane + 3], c3 = sCellStart[4 * lane + 4];
-    const int tot = (int)(c0 + c1 + c2 + c3);
-    const int off = wave_excl_scan(tot, lane);
+  block_sync();
+  if (wave == 0) {  // start[c + 1] := entries in cells < c (the cursor of cell c); the scatter below advances it to end(c) = start(c + 1)
+    constexpr int PER = MERGE_CELLS / 64;
+    unsigned cnt[PER];
+    int tot = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { cnt[k] = sCellStart[PER * lane + k + 1]; tot += (int)cnt[k]; }
+    int off = wave_excl_scan(tot, lane);
     wave_sync();
-    sCellStart[4 * lane + 1] = off + c0;
-    sCellStart[4 * lane + 2] = off + c0 + c1;
-    sCellStart[4 * lane + 3] = off + c0 + c1 + c2;
-    sCellStart[4 * lane + 4] = off + tot;
-    sCellCur[4 * lane + 0] = (unsigned)off;  // cursor of cell c starts at start[c]
-    sCellCur[4 * lane + 1] = off + c0;
-    sCellCur[4 * lane + 2] = off + c0 + c1;
-    sCellCur[4 * lane + 3] = off + c0 + c1 + c2;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { sCellStart[PER * lane + k + 1] = (unsigned)off; off += (int)cnt[k]; }
   }
-  wave_sync();
-  for (int m = lane, sidx = 0; m < N; m += 64, sidx++) {
+  block_sync();
+  for (int m = tid, sidx = 0; m < N; m += NT, sidx++) {
     if ((hole >> sidx) & 1u) continue;
     int cx, cy;
     cell_of(sMX[m], sMY[m], cx, cy);
-    const unsigned pos = atomicAdd(&sCellCur[cy * MERGE_GRID + cx], 1u);
+    const unsigned pos = atomicAdd(&sCellStart[cy * MERGE_GX + cx + 1], 1u);
     sSorted[pos] = (unsigned short)m;
   }
-  wave_sync();
-  DBG_T(32, 8);
+  if (tid == 0) *sPairCount = 0u;
+  block_sync();
+  DBG_TB(32, 8);
   // ---- phase 1: per-row lowest passing partner (initial states) ----
   // 1a: neighbours from the 3x3 cells, four per trip, branch-free distance prefilter; the few pairs that survive go
   //     into a dense list in LDS.  1b: the list is processed with all lanes busy (one pair per lane): both covariances
   //     are fetched together, the exact Mahalanobis test runs, and the row's lowest passing partner is kept with an
   //     LDS atomicMin.  Splitting the rare expensive test from the scan keeps divergence out of the scan loop.
-  if (lane == 0) *sPairCount = 0u;
-  wave_sync();
   const int pairCap = MERGE_PAIR_CAP(cap);
-  for (int m = lane, sidx = 0; m < N; m += 64, sidx++) {
+  for (int m = tid, sidx = 0; m < N; m += NT, sidx++) {
     if ((hole >> sidx) & 1u) continue;
     const double ax = sMX[m], ay = sMY[m], ab = sBnd[m];
     int cx, cy;
     cell_of(ax, ay, cx, cy);
-    const int cxa = cx > 0 ? cx - 1 : 0, cxb = cx < MERGE_GRID - 1 ? cx + 1 : MERGE_GRID - 1;
-    for (int ry = (cy > 0 ? cy - 1 : 0); ry <= (cy < MERGE_GRID - 1 ? cy + 1 : MERGE_GRID - 1); ry++) {
-      const unsigned qs = sCellStart[ry * MERGE_GRID + cxa], qe = sCellStart[ry * MERGE_GRID + cxb + 1];
+    const int cxa = cx > 0 ? cx - 1 : 0, cxb = cx < MERGE_GX - 1 ? cx + 1 : MERGE_GX - 1;
+    for (int ry = (cy > 0 ? cy - 1 : 0); ry <= (cy < MERGE_GY - 1 ? cy + 1 : MERGE_GY - 1); ry++) {
+      const unsigned qs = sCellStart[ry * MERGE_GX + cxa], qe = sCellStart[ry * MERGE_GX + cxb + 1];
       for (unsigned q = qs; q < qe; q += 4) {
         unsigned jj[4];
         double jx[4], jy[4], jb[4];
@@ -201,11 +228,11 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
       }
     }
   }
-  wave_sync();
+  block_sync();
   {
     const int nPairs = (int)min(*sPairCount, (unsigned)pairCap);
-    for (int p0 = 0; p0 < nPairs; p0 += 64) {
-      const int pi = p0 + lane;
+    for (int p0 = 0; p0 < nPairs; p0 += NT) {
+      const int pi = p0 + tid;
       if (pi < nPairs) {
         const unsigned pr2 = sPairs[pi];
         const int a = (int)(pr2 >> 16), j = (int)(pr2 & 0xffffu);
@@ -228,9 +255,9 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
       }
     }
   }
-  wave_sync();
+  block_sync();
 
-  DBG_T(32, 2);
+  DBG_TB(32, 2);
   // ---- phase 2: replay the rows that have a candidate, with the exact greedy rule ----
   // Liveness lives in LDS from here on: sBnd[j] < 0  <=>  j has been absorbed.
   //
@@ -246,6 +273,7 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
 #ifdef RFS_PROFILE
   int dbgRows = 0, dbgMerges = 0, dbgChunks = 0;
 #endif
+  if (wave == 0) {  // ======== phase 2 is wave 0's; the other waves wait at the barrier below ========
   unsigned *sRows = sPairs;                                                           // [<= cap] candidate rows, ascending
   unsigned short *sSpec = reinterpret_cast<unsigned short *>(sPairs + cap);           // [64][8] absorbed entries per lane
   int nRowsTotal = 0;
@@ -258,7 +286,7 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
     nRowsTotal += __popcll(rm);
   }
   wave_sync();
-  DBG_T(32, 9);
+  DBG_TB(32, 9);
 
   // the reference's sequential scan for ONE row, executed by the whole wave (fallback + exactness anchor)
   auto seq_replay = [&](const int a) {
@@ -335,21 +363,31 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
       // The row's neighbourhood (higher indices only) is gathered into registers, up to 32 indices of 16 bits, and
       // gathered again only if a merge moves the row to another cell or enlarges its reach.
       unsigned long long nb[MERGE_NB_WORDS];
-      int nNb = 0, gcx = -1, gcy = -1, greach = -1;
+      int nNb = 0, gcx = -1, gcy = -1, grx = -1, gry = -1;
+#ifdef RFS_PROFILE
+      int dbgRounds = 0, dbgGather = 0;
+      if (B.dbg && i == 7 && lane == 0) B.dbg[52] = (long long)__builtin_readcyclecounter();
+#endif
       for (int round = 0; round < cap; round++) {
+#ifdef RFS_PROFILE
+        dbgRounds++;
+#endif
         int cx, cy;
         cell_of(ax, ay, cx, cy);
-        int reach = MERGE_GRID;
-        if (!degenerate && ab < 1.0e300) { const double rr = sqrt(ab) * invCell; reach = (rr < (double)MERGE_GRID) ? (int)rr + 1 : MERGE_GRID; }
-        if (cx != gcx || cy != gcy || reach != greach) {
-          gcx = cx; gcy = cy; greach = reach;
+        int rx, ry2;
+        reach_of(ab, rx, ry2);
+        if (cx != gcx || cy != gcy || rx != grx || ry2 != gry) {
+          gcx = cx; gcy = cy; grx = rx; gry = ry2;
           nNb = 0;
+#ifdef RFS_PROFILE
+          dbgGather++;
+#endif
 #pragma unroll
           for (int g = 0; g < MERGE_NB_WORDS; g++) nb[g] = 0ull;
-          const int cxa = cx - reach > 0 ? cx - reach : 0, cxb = cx + reach < MERGE_GRID - 1 ? cx + reach : MERGE_GRID - 1;
-          const int cya = cy - reach > 0 ? cy - reach : 0, cyb = cy + reach < MERGE_GRID - 1 ? cy + reach : MERGE_GRID - 1;
+          const int cxa = cx - rx > 0 ? cx - rx : 0, cxb = cx + rx < MERGE_GX - 1 ? cx + rx : MERGE_GX - 1;
+          const int cya = cy - ry2 > 0 ? cy - ry2 : 0, cyb = cy + ry2 < MERGE_GY - 1 ? cy + ry2 : MERGE_GY - 1;
           for (int ry = cya; ry <= cyb && nNb <= 4 * MERGE_NB_WORDS; ry++) {
-            const unsigned qs = sCellStart[ry * MERGE_GRID + cxa], qe = sCellStart[ry * MERGE_GRID + cxb + 1];
+            const unsigned qs = sCellStart[ry * MERGE_GX + cxa], qe = sCellStart[ry * MERGE_GX + cxb + 1];
             for (unsigned q = qs; q < qe; q++) {
               const unsigned j = sSorted[q];
               if (j <= (unsigned)a) continue;
@@ -364,8 +402,16 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
         }
         // One pass over the neighbourhood with the row's CURRENT state: the (up to) four lowest live partners above
         // `cur` that pass the distance prefilter, kept sorted by a min/max insertion network.
+#ifdef RFS_PROFILE
+        if (B.dbg && i == 7 && lane == 0 && round == 0) B.dbg[53] = (long long)__builtin_readcyclecounter();
+#endif
         unsigned c0 = 0xffffu, c1 = 0xffffu, c2 = 0xffffu, c3 = 0xffffu;
         int nPass = 0;
+        // Smallest slack (distance minus prefilter radius, rounded DOWN in fp32) among the partners that FAIL the
+        // prefilter now: while the row's accumulated shift plus radius growth stays below it, none of them can start
+        // passing, so after a merge the candidates already fetched are still the complete list.
+        float slackMin = 3.0e38f;
+        const double abPass = ab;
 #pragma unroll
         for (int g = 0; g < MERGE_NB_WORDS; g++) {
           if (4 * g >= nNb) break;
@@ -381,7 +427,11 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             const double e0 = jx[k] - ax, e1 = jy[k] - ay;
-            const bool c = (4 * g + k < nNb) & (jj[k] > cur) & !(jbb[k] < 0.0) & !((e0 * e0 + e1 * e1) > fmax(ab, jbb[k]));
+            const double e2 = e0 * e0 + e1 * e1, T = fmax(ab, jbb[k]);
+            const bool cand = (4 * g + k < nNb) & (jj[k] > cur) & !(jbb[k] < 0.0);
+            const bool c = cand & !(e2 > T);
+            const float slack = __builtin_sqrtf((float)e2) * (1.f - 4e-6f) - __builtin_sqrtf((float)T) * (1.f + 4e-6f);
+            slackMin = (cand & !c & !(slack >= slackMin)) ? slack : slackMin;
             unsigned x = c ? jj[k] : 0xffffu, t;
             nPass += c ? 1 : 0;
             t = min(c0, x); x = max(c0, x); c0 = t;
@@ -390,6 +440,9 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
             c3 = min(c3, x);
           }
         }
+#ifdef RFS_PROFILE
+        if (B.dbg && i == 7 && lane == 0 && round == 0) B.dbg[54] = (long long)__builtin_readcyclecounter();
+#endif
         if (nPass == 0) break;
         // their weights / means / covariances in one batch of independent loads
         const unsigned cs[4] = {c0, c1, c2, c3};
@@ -400,7 +453,11 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
           qw[k] = sW[js]; qx[k] = sMX[js]; qy[k] = sMY[js];
           qxx[k] = pSXX[js]; qxy[k] = pSXY[js]; qyy[k] = pSYY[js];
         }
-        bool merged = false;
+#ifdef RFS_PROFILE
+        if (B.dbg && i == 7 && lane == 0 && round == 0) B.dbg[55] = (long long)__builtin_readcyclecounter();
+#endif
+        bool merged = false;  // true: the neighbourhood has to be examined again with the row's new state
+        float shift = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           if (merged || cs[k] == 0xffffu) continue;
@@ -429,11 +486,30 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
           ax = xm; ay = ym; axx = nxx; axy = nxy; ayy = nyy; aw = wm;
           inv2(axx, axy, axy, ayy, a00, a01, a10, a11, adet);
           ab = merge_bound(t2, axx, axy, ayy);
-          merged = true;  // the prefilter of everything above `cur` has to be redone with the new state
+          // Can a partner that failed the prefilter pass it now?  Not while the row stays in its cell with the same
+          // reach (entries outside the gathered cells stay out of range) and moved / grew by less than the slack.
+          shift += __builtin_sqrtf((float)(d10 * d10 + d11 * d11)) * (1.f + 4e-6f) + 1e-30f;
+          const float grow = __builtin_sqrtf((float)ab) * (1.f + 4e-6f) - __builtin_sqrtf((float)abPass) * (1.f - 4e-6f);
+          int ncx, ncy;
+          cell_of(ax, ay, ncx, ncy);
+          int nrx, nry;
+          reach_of(ab, nrx, nry);
+          const bool still = (nPass <= 4) & (ncx == gcx) & (ncy == gcy) & (nrx == grx) & (nry == gry) & (slackMin > shift + fmaxf(grow, 0.f));
+          merged = !still;  // otherwise: carry on with the remaining fetched candidates against the new state
         }
+#ifdef RFS_PROFILE
+        if (B.dbg && i == 7 && lane == 0 && round == 0) B.dbg[56] = (long long)__builtin_readcyclecounter();
+#endif
         if (ovf) break;
         if (!merged && nPass <= 4) break;  // every partner that could pass has been met
       }
+#ifdef RFS_PROFILE
+      {
+        int mr = dbgRounds, mg = dbgGather, mn = nNb;
+        // (only active lanes are here; plain max over them through LDS-free shuffles is overkill: lane 0 reports itself)
+        if (B.dbg && i == 7 && lane == 0) { B.dbg[57] = mr; B.dbg[58] = mg; B.dbg[59] = mn; }
+      }
+#endif
     }
     // claims: (lane << 16) in the upper half of sFirst[e] for every entry a lane absorbed (lowest lane wins)
     for (int k = 0; k < nAbs; k++) {
@@ -441,25 +517,37 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
       atomicMin(&sFirst[e], ((unsigned)lane << 16) | (sFirst[e] & 0xffffu));
     }
     wave_sync();
-    DBG_T(32, 10);
-    // A lane is CLEAN when nobody claimed its row and it holds the claim on everything it absorbed.  The rows before
-    // the first dirty lane cannot be affected by any other row of the round: they commit together.  From the first
-    // dirty lane on, rows are validated one by one in ascending order, and replayed by the whole wave on a conflict.
-    bool dirty = ovf;
+    DBG_TB(32, 10);
+    // Validation.  `conflict`: the lane lost the claim on something it absorbed (or overflowed).  Before the first
+    // conflicting lane every entry has at most one claimer, so a row there is absorbed exactly when its claimer is
+    // itself alive: alive(l) = !claimed(a_l) || !alive(claimer(a_l)), claimer < l -- resolved by iterating to the fixed
+    // point (chain depth, usually 1-2 trips).  Those rows commit together.  From the first conflicting lane on, rows are
+    // validated one by one in ascending order, and replayed by the whole wave when an absorbed entry is gone.
+    bool conflict = ovf;
+    bool claimedRow = false;
+    unsigned claimer = 0;
     if (active) {
-      dirty |= (sFirst[a] >> 16) != 0xffffu;
-      for (int k = 0; k < nAbs; k++) dirty |= (sFirst[sSpec[lane * 8 + k]] >> 16) != (unsigned)lane;
+      claimer = sFirst[a] >> 16;
+      claimedRow = claimer != 0xffffu;
+      claimer &= 63u;
+      for (int k = 0; k < nAbs; k++) conflict |= (sFirst[sSpec[lane * 8 + k]] >> 16) != (unsigned)lane;
     }
     const unsigned long long actm = __ballot(active);
-    const unsigned long long dm = __ballot(dirty & active);
-    const int firstDirty = dm ? __builtin_ctzll(dm) : 64;
-    unsigned long long commit = 0;
-    if (active && lane < firstDirty && nAbs > 0) {
+    const unsigned long long cm = __ballot(conflict & active);
+    const int firstDirty = cm ? __builtin_ctzll(cm) : 64;
+    unsigned long long alivem = __ballot(active & !claimedRow);
+    for (int it = 0; it < 64; it++) {
+      const unsigned long long nm = __ballot(active & (!claimedRow | !((alivem >> claimer) & 1ull)));
+      if (nm == alivem) break;
+      alivem = nm;
+    }
+    const bool commitNow = active && lane < firstDirty && ((alivem >> lane) & 1ull) && nAbs > 0;
+    if (commitNow) {
       for (int k = 0; k < nAbs; k++) sBnd[sSpec[lane * 8 + k]] = -1.0;
     }
-    commit = __ballot(active && lane < firstDirty && nAbs > 0);
+    unsigned long long commit = __ballot(commitNow);
 #ifdef RFS_PROFILE
-    dbgRows += __popcll(actm & ((firstDirty < 64) ? ((1ull << firstDirty) - 1ull) : ~0ull));
+    dbgRows += __popcll(alivem & ((firstDirty < 64) ? ((1ull << firstDirty) - 1ull) : ~0ull));
 #endif
     wave_sync();
     for (int l = firstDirty; l < cnt; l++) {
@@ -492,43 +580,51 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
     if (r0 + 64 < nRowsTotal)
       for (int m = lane; m < N; m += 64) sFirst[m] |= 0xffff0000u;
     wave_sync();
-    DBG_T(32, 11);
+    DBG_TB(32, 11);
   }
-  // hole flags back into the per-lane registers used by the write-back / prune below
-  for (int m = lane, sidx = 0; m < N; m += 64, sidx++)
-    if (sBnd[m] < 0.0) hole |= 1u << sidx;
-
 #ifdef RFS_PROFILE
   if (B.dbg && i == 7 && lane == 0) { B.dbg[48] = dbgRows; B.dbg[49] = dbgMerges; B.dbg[50] = dbgChunks; B.dbg[51] = N; }
 #endif
+  if (lane == 0) sRed[0] = anyMerge ? 1.f : 0.f;
+  }  // ======== end of wave 0's phase 2 ========
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // in-place updates of merged rows (global) -> visible to the workgroup
+  block_sync();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  anyMerge = sRed[0] != 0.f;
+  // hole flags back into the per-thread registers used by the write-back / prune below
+  for (int m = tid, sidx = 0; m < N; m += NT, sidx++)
+    if (sBnd[m] < 0.0) hole |= 1u << sidx;
+
   if (!FUSE_PRUNE) {
     if (!anyMerge) return;
-    for (int m = lane, sidx = 0; m < N; m += 64, sidx++)
+    for (int m = tid, sidx = 0; m < N; m += NT, sidx++)
       if ((hole >> sidx) & 1u) pW[m] = -1.0;
     return;
   }
 
-  DBG_T(32, 3);
+  DBG_TB(32, 3);
   // ---- fused prune: keep w >= t (not absorbed), order (weight desc, index asc), compact into the other slab ----
-  for (int m = lane, sidx = 0; m < N; m += 64, sidx++)
+  for (int m = tid, sidx = 0; m < N; m += NT, sidx++)
     if ((hole >> sidx) & 1u) sW[m] = -1.0;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // lane 0's in-place updates of merged rows -> visible to the wave
-  wave_sync();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  block_sync();
   double *dl = B.slab[dst];
   const double t = P.pruneT;
   // survivors are compacted into sSorted (ascending index) so that ranks only need the survivors' keys
   int nSurv = 0;
-  for (int c0 = 0; c0 < N; c0 += 64) {
-    const int m = c0 + lane;
-    const double wm = (m < N) ? sW[m] : -1.0;
-    const bool keep = (wm >= t) && (wm >= 0.0);
-    const unsigned long long km = __ballot(keep);
-    if (keep) sSorted[nSurv + __popcll(km & ((1ull << lane) - 1ull))] = (unsigned short)m;
-    nSurv += __popcll(km);
+  if (wave == 0) {
+    for (int c0 = 0; c0 < N; c0 += 64) {
+      const int m = c0 + lane;
+      const double wm = (m < N) ? sW[m] : -1.0;
+      const bool keep = (wm >= t) && (wm >= 0.0);
+      const unsigned long long km = __ballot(keep);
+      if (keep) sSorted[nSurv + __popcll(km & ((1ull << lane) - 1ull))] = (unsigned short)m;
+      nSurv += __popcll(km);
+    }
+    if (lane == 0) *sPairCount = (unsigned)nSurv;
   }
-  wave_sync();
-  for (int q = lane; q < nSurv; q += 64) {
+  block_sync();
+  nSurv = (int)*sPairCount;
+  for (int q = tid; q < nSurv; q += NT) {
     const int m = sSorted[q];
     const double wm = sW[m];
     int rank = 0;
@@ -545,8 +641,8 @@ __global__ __launch_bounds__(WPB * 64) void gm_merge_kernel(Buffers B, Params P,
     plane(dl, cap, i, PL_SXY)[rank] = pSXY[m];
     plane(dl, cap, i, PL_SYY)[rank] = pSYY[m];
   }
-  if (lane == 0) B.count[i] = nSurv;
-  DBG_T(32, 4);
+  if (tid == 0) B.count[i] = nSurv;
+  DBG_TB(32, 4);
 }
 
 // LDS per wave: keys[cap] doubles

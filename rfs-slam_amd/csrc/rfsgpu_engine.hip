@@ -643,6 +643,9 @@ static int launch_weighting(rfsgpu_filter *f) {
 }
 
 }  // extern "C" (templates need C++ linkage)
+#ifndef MERGE_WPP
+#define MERGE_WPP 2
+#endif
 template <bool FUSE>
 static int launch_merge_t(rfsgpu_filter *f) {
   const int cur = f->cur, dst = f->cur ^ 1;
@@ -655,19 +658,10 @@ static int launch_merge_t(rfsgpu_filter *f) {
     if (FUSE) f->cur = dst;
     return RFSGPU_OK;
   }
-  const size_t per = merge_lds_bytes_per_wave(f->cap);
-  // pick the block shape that keeps the most waves resident per CU (160 KiB LDS): 4 waves/block only while
-  // two such blocks still fit, otherwise smaller blocks pack better
-  if (4 * per <= 40 * 1024) {
-    if ((rc = set_lds(f, (gm_merge_kernel<4, FUSE>), 4 * per)) != RFSGPU_OK) return rc;
-    gm_merge_kernel<4, FUSE><<<(f->N + 3) / 4, 256, 4 * per, f->stream>>>(f->B, f->P, cur, dst);
-  } else if (2 * per <= 40 * 1024) {
-    if ((rc = set_lds(f, (gm_merge_kernel<2, FUSE>), 2 * per)) != RFSGPU_OK) return rc;
-    gm_merge_kernel<2, FUSE><<<(f->N + 1) / 2, 128, 2 * per, f->stream>>>(f->B, f->P, cur, dst);
-  } else {
-    if ((rc = set_lds(f, (gm_merge_kernel<1, FUSE>), per)) != RFSGPU_OK) return rc;
-    gm_merge_kernel<1, FUSE><<<f->N, 64, per, f->stream>>>(f->B, f->P, cur, dst);
-  }
+  // one workgroup of MERGE_WPP waves per particle
+  const size_t per = merge_lds_bytes_per_block(f->cap, MERGE_WPP);
+  if ((rc = set_lds(f, (gm_merge_kernel<MERGE_WPP, FUSE>), per)) != RFSGPU_OK) return rc;
+  gm_merge_kernel<MERGE_WPP, FUSE><<<f->N, MERGE_WPP * 64, per, f->stream>>>(f->B, f->P, cur, dst);
   HIPCHK(hipGetLastError());
   if (FUSE) f->cur = dst;
   return RFSGPU_OK;

@@ -17,7 +17,7 @@ prof_lib = os.path.join(ROOT, "tools", "_build", "librfsgpu_prof.so")
 if "--build" in sys.argv:
     os.makedirs(os.path.dirname(prof_lib), exist_ok=True)
     bm = pkg.build_mod
-    cmd = [bm.hipcc()] + bm.FLAGS + ["-DRFS_PROFILE", os.path.join(bm.CSRC, "rfsgpu_engine.hip"), "-o", prof_lib]
+    cmd = [bm.hipcc()] + bm.FLAGS + ["-DRFS_PROFILE"] + os.environ.get("KS_FLAGS", "").split() + [os.path.join(bm.CSRC, "rfsgpu_engine.hip"), "-o", prof_lib]
     subprocess.check_call(cmd)
     sys.exit(0)
 lib = C.CDLL(prof_lib)
@@ -45,5 +45,6 @@ for base, ns in names.items():
 print("update_map pass0: precompute %d, gates %d, maha+lik %d, scan+write %d, fold %d" % (t[4]-t[0], t[5]-t[4], t[6]-t[5], t[7]-t[6], t[8]-t[7]))
 print("weight: rank sort %d, write %d" % (t[16+8]-t[16], t[17]-t[16+8]))
 print("merge phase2: rows %d, speculative %d, validate %d, tail %d" % (t[41]-t[34], t[42]-t[41], t[43]-t[42], t[35]-t[43]))
+print("merge spec lane0: setup %d gather %d pass %d loads %d tests %d | rounds %d gathers %d nNb %d" % (t[52]-t[41], t[53]-t[52], t[54]-t[53], t[55]-t[54], t[56]-t[55], t[57], t[58], t[59]))
 print("merge: grid build %d, candidate scan %d; phase2 rows %d merges %d chunks %d N %d" % (t[40]-t[33], t[34]-t[40], t[48], t[49], t[50], t[51]))
 print("kernel ns (events):", f.last_kernel_ns())

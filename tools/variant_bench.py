@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Tuning aid (not part of the product): build variants of the HIP library with extra -D flags and bench each.
+
+  python tools/variant_bench.py --build name1="-DA=1 -DB=2" name2="..."     (here: cross-compiles into tools/_build/)
+  python tools/variant_bench.py --run name1 name2                           (on the GPU box)
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "tools", "_build")
+
+
+def lib_of(name):
+    return os.path.join(OUT, f"librfsgpu_{name}.so")
+
+
+if sys.argv[1] == "--build":
+    import __graft_entry__ as g
+    bm = g.load_package().build_mod
+    os.makedirs(OUT, exist_ok=True)
+    procs = []
+    for spec in sys.argv[2:]:
+        name, flags = spec.split("=", 1)
+        cmd = [bm.hipcc()] + bm.FLAGS + flags.split() + [os.path.join(bm.CSRC, "rfsgpu_engine.hip"), "-o", lib_of(name)]
+        procs.append((name, subprocess.Popen(cmd)))
+    for name, p in procs:
+        print(name, "rc", p.wait())
+else:
+    steps = os.environ.get("VB_STEPS", "200")
+    for name in sys.argv[2:]:
+        code = (f"import sys; sys.path.insert(0, {ROOT!r}); import __graft_entry__ as g; pkg = g.load_package(); "
+                f"pkg.engine.LIB = {lib_of(name)!r}; import bench; "
+                f"sys.argv = ['bench.py', '--steps', '{steps}', '--warmup', '20', '--no-cpu-baseline']; bench.main()")
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
+        try:
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            print(name, d["value"], d["ms_per_step"], {k: v["ms"] for k, v in d["config"]["kernels"].items()}, flush=True)
+        except Exception:
+            print(name, "FAILED", r.stdout[-300:], r.stderr[-600:], flush=True)
