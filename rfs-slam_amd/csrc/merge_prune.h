@@ -22,11 +22,17 @@
 #define MERGE_GX 32  // grid cells along x
 #define MERGE_GY 16  // grid cells along y
 #define MERGE_CELLS (MERGE_GX * MERGE_GY)
-#define MERGE_PAIR_CAP(cap) ((2 * (cap)) > ((cap) + 320) ? (2 * (cap)) : ((cap) + 320))
+#define MERGE_PAIR_CAP(cap) ((cap) > 320 ? (cap) : 320)  // listed partners per particle: ~0.7 per entry on dense maps
+#define MERGE_ROW_SLOTS 8   // prefilter survivors one row can list; a row with more is replayed by the sequential scan
 __host__ __device__ inline size_t merge_lds_bytes_per_wave(int cap) {
-  // entries: 4 doubles + firstCand (u32, atomicMin target) + grid-sorted index (u16); grid: 2 x 257 u32; pair list: u32
-  return (((size_t)cap * (4 * 8 + 4 + 2)) + (size_t)(MERGE_CELLS + 4) * 4 + (size_t)MERGE_PAIR_CAP(cap) * 4 + 16 + 15) & ~(size_t)15;
+  // entries: 4 doubles + row record (u32) + grid-sorted index (u16) + prefilter slack (u16); grid: CELLS+4 u32; pair list: u32
+  return (((size_t)cap * (4 * 8 + 4 + 2 + 2)) + (size_t)(MERGE_CELLS + 4) * 4 + (size_t)MERGE_PAIR_CAP(cap) * 4 + 16 + 15) & ~(size_t)15;
 }
+// Row record (sRec[m]): [31:25] claim of the speculative round (lane, 0x7f = none) | [24] the row has a partner that
+// passes the exact test against the initial states | [23:20] number of listed survivors (15 = not listable) |
+// [19:0] offset of the row's contiguous segment in the pair list.
+#define MERGE_REC_NOCLAIM 0xfe000000u
+#define MERGE_REC_ISROW 0x01000000u
 // + cross-wave reduction scratch ([waves][8] floats) when a workgroup of several waves works on one particle
 __host__ __device__ inline size_t merge_lds_bytes_per_block(int cap, int wavesPerParticle) {
   return merge_lds_bytes_per_wave(cap) + (size_t)wavesPerParticle * 32;
@@ -93,10 +99,11 @@ __global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(MERGE_
   auto block_sync = [&]() { if (WPP == 1) wave_sync(); else __syncthreads(); };
   double *sMX = reinterpret_cast<double *>(wbase), *sMY = sMX + cap, *sW = sMX + 2 * cap, *sBnd = sMX + 3 * cap;
   unsigned *sCellStart = reinterpret_cast<unsigned *>(sMX + 4 * cap);      // [CELLS + 1]: cell c's entries are sSorted[start[c] .. start[c+1])
-  unsigned *sFirst = sCellStart + MERGE_CELLS + 4;                          // [cap] lowest passing partner (0xffff = none)
-  unsigned *sPairs = sFirst + cap;                                          // [PAIR_CAP] (a << 16) | j, prefilter survivors
+  unsigned *sRec = sCellStart + MERGE_CELLS + 4;                            // [cap] row records (see MERGE_REC_*)
+  unsigned *sPairs = sRec + cap;                                            // [PAIR_CAP] (a << 16) | (passes << 15) | (reserve << 14) | j
   unsigned *sPairCount = sPairs + MERGE_PAIR_CAP(cap);                      // [1] (+3 pad)
-  unsigned short *sSorted = reinterpret_cast<unsigned short *>(sPairCount + 4);
+  unsigned short *sSorted = reinterpret_cast<unsigned short *>(sPairCount + 4);  // [cap] grid order; later: candidate rows, prune survivors
+  unsigned short *sSlack = sSorted + cap;                                   // [cap] prefilter slack of the row (upper half of an fp32, rounded down)
 
   const int N = B.count[i];
   double *slab = B.slab[cur];
@@ -105,6 +112,14 @@ __global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(MERGE_
   const double t2 = P.mergeT2, f = P.mergeInfl;
 
   DBG_TB(32, 0);
+#ifdef RFS_PROFILE
+  const long long dbgT0 = (long long)__builtin_readcyclecounter();
+  long long dbgT2 = 0, dbgT3 = 0;
+  int dbgFallbacks = 0, dbgSlackN = 0, dbgUnlistN = 0;
+  unsigned dbgPairs = 0;
+  if (B.dbg && tid == 0) B.dbg[64 + 4 * (size_t)i + 3] = 0;
+  __syncthreads();
+#endif
   // ---- stage; hole flags live in per-lane registers: bit s of `hole` <=> entry s*64+lane is a hole ----
   unsigned hole = 0;
   float fxmin = 3.0e38f, fxmax = -3.0e38f, fymin = 3.0e38f, fymax = -3.0e38f, frad = 0.f;
@@ -112,7 +127,7 @@ __global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(MERGE_
     const double w = pW[m], mx = pMX[m], my = pMY[m];
     const double bnd = merge_bound(t2, pSXX[m], pSXY[m], pSYY[m]);
     sMX[m] = mx; sMY[m] = my; sW[m] = w; sBnd[m] = bnd;
-    sFirst[m] = 0xffffu;
+    sRec[m] = MERGE_REC_NOCLAIM;
     if (w < 0) { hole |= 1u << sidx; sBnd[m] = -1.0; continue; }  // already absorbed (merge called twice); bound < 0 marks a hole
     const float fx = (float)mx, fy = (float)my;
     fxmin = fminf(fxmin, fx); fxmax = fmaxf(fxmax, fx);
@@ -187,18 +202,26 @@ __global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(MERGE_
   if (tid == 0) *sPairCount = 0u;
   block_sync();
   DBG_TB(32, 8);
-  // ---- phase 1: per-row lowest passing partner (initial states) ----
-  // 1a: neighbours from the 3x3 cells, four per trip, branch-free distance prefilter; the few pairs that survive go
-  //     into a dense list in LDS.  1b: the list is processed with all lanes busy (one pair per lane): both covariances
-  //     are fetched together, the exact Mahalanobis test runs, and the row's lowest passing partner is kept with an
-  //     LDS atomicMin.  Splitting the rare expensive test from the scan keeps divergence out of the scan loop.
+  // ---- phase 1: every pair (a, j > a) against the INITIAL states ----
+  // 1a: each entry scans the 3x3 cells around it, four neighbours per trip, with the branch-free distance prefilter.
+  //     Survivors with a higher index are collected in registers and written as ONE contiguous segment of the pair
+  //     list (one atomicAdd per row).  The scan also keeps the row's SLACK: the smallest (distance - prefilter radius)
+  //     among the neighbours that fail, bounded by what separates it from entries outside the 3x3 cells.  While the row
+  //     later moves / grows by less than its slack, no other entry can start passing, so the segment stays the
+  //     complete list of possible partners.
+  // 1b: the list is processed with all lanes busy (one pair per lane): both covariances are fetched together, the
+  //     exact Mahalanobis test runs, and the verdict is kept in the pair's own word (bit 15) and in the row record.
   const int pairCap = MERGE_PAIR_CAP(cap);
+  const float slackOut = (float)(fmin(cellx, celly)) * (1.f - 4e-6f) - frad * (1.f + 4e-6f);
   for (int m = tid, sidx = 0; m < N; m += NT, sidx++) {
     if ((hole >> sidx) & 1u) continue;
     const double ax = sMX[m], ay = sMY[m], ab = sBnd[m];
     int cx, cy;
     cell_of(ax, ay, cx, cy);
     const int cxa = cx > 0 ? cx - 1 : 0, cxb = cx < MERGE_GX - 1 ? cx + 1 : MERGE_GX - 1;
+    unsigned long long buf0 = 0ull, buf1 = 0ull;  // up to 8 survivors, 16 bits each
+    int nP = 0;
+    double farE2 = 1.0e300;   // nearest neighbour that fails the prefilter by a factor >= 2 in distance
     for (int ry = (cy > 0 ? cy - 1 : 0); ry <= (cy < MERGE_GY - 1 ? cy + 1 : MERGE_GY - 1); ry++) {
       const unsigned qs = sCellStart[ry * MERGE_GX + cxa], qe = sCellStart[ry * MERGE_GX + cxb + 1];
       for (unsigned q = qs; q < qe; q += 4) {
@@ -211,22 +234,48 @@ __global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(MERGE_
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const double e0 = jx[k] - ax, e1 = jy[k] - ay;
+          const double e2 = e0 * e0 + e1 * e1, T = fmax(ab, jb[k]);
           // higher index only (the entry plays `a`); NaN distances fall through to the exact test like the reference
-          const bool c = (q + k < qe) & (jj[k] > (unsigned)m) & !((e0 * e0 + e1 * e1) > fmax(ab, jb[k]));
-          if (c) {
-            const unsigned pos = atomicAdd(sPairCount, 1u);
-            if (pos < (unsigned)pairCap) {
-              sPairs[pos] = ((unsigned)m << 16) | jj[k];
-            } else {  // list full (pathological density): test in place
-              double a00, a01, a10, a11, det;
-              const double xy = pSXY[m];
-              inv2(pSXX[m], xy, xy, pSYY[m], a00, a01, a10, a11, det);
-              if (merge_pair_passes(e0, e1, a00, a01, a11, sW[m], sW[jj[k]], pSXX, pSXY, pSYY, (int)jj[k], t2)) atomicMin(&sFirst[m], jj[k]);
-            }
+          const bool cand = (q + k < qe) & (jj[k] > (unsigned)m);
+          const bool c = cand & !(e2 > T);
+          // neighbours within twice the prefilter radius are listed too, as RESERVE partners (bit 14): they cannot pass
+          // now, but may once the row has merged and moved; everything farther bounds the row's slack from below
+          const bool reserve = cand & !c & (e2 < 4.0 * T);
+          const bool farFail = cand & !c & !reserve;
+          farE2 = farFail ? fmin(farE2, e2) : farE2;  // sqrt(e2) - sqrt(T) >= sqrt(e2) / 2 for these
+          if (c | reserve) {
+            const unsigned long long v = (unsigned long long)(jj[k] | (reserve ? 0x4000u : 0u)) << (16 * (nP & 3));
+            if (nP < 4) buf0 |= v; else if (nP < 8) buf1 |= v;
+            nP++;
           }
         }
       }
     }
+    unsigned rec = MERGE_REC_NOCLAIM;
+    if (nP > 0) {
+      unsigned base = 0;
+      bool listed = nP <= MERGE_ROW_SLOTS;
+      if (listed) {
+        base = atomicAdd(sPairCount, (unsigned)nP);
+        listed = base + (unsigned)nP <= (unsigned)pairCap;
+      }
+      if (listed) {
+        for (int k = 0; k < nP; k++) {
+          const unsigned j = (unsigned)(((k < 4 ? buf0 : buf1) >> (16 * (k & 3))) & 0xffffull);  // index | reserve flag
+          sPairs[base + k] = ((unsigned)m << 16) | j;
+        }
+        rec |= ((unsigned)nP << 20) | base;
+      } else {
+        rec |= MERGE_REC_ISROW | (15u << 20);  // too crowded to list: the sequential scan handles this row
+        if (nP <= MERGE_ROW_SLOTS)
+          for (int k = 0; k < nP; k++)
+            if (base + k < (unsigned)pairCap) sPairs[base + k] = 0xffffffffu;  // reserved but unused words: skipped by 1b
+      }
+    }
+    sRec[m] = rec;
+    float slackMin = __builtin_amdgcn_sqrtf((float)farE2) * (0.5f - 4e-6f);
+    slackMin = degenerate ? 0.f : fminf(slackMin, slackOut);
+    sSlack[m] = (slackMin > 0.f) ? (unsigned short)(__float_as_uint(slackMin) >> 16) : (unsigned short)0;
   }
   block_sync();
   {
@@ -235,54 +284,64 @@ __global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(MERGE_
       const int pi = p0 + tid;
       if (pi < nPairs) {
         const unsigned pr2 = sPairs[pi];
-        const int a = (int)(pr2 >> 16), j = (int)(pr2 & 0xffffu);
-        // both covariances up front: six independent loads in flight
-        const double axx = pSXX[a], axy = pSXY[a], ayy = pSYY[a];
-        const double jxx = pSXX[j], jxy = pSXY[j], jyy = pSYY[j];
-        const double e0 = sMX[j] - sMX[a], e1 = sMY[j] - sMY[a];
-        double a00, a01, a10, a11, det;
-        inv2(axx, axy, axy, ayy, a00, a01, a10, a11, det);
-        const double u0 = e0 * a00 + e1 * a01, u1 = e0 * a01 + e1 * a11;
-        bool far = (u0 * e0 + u1 * e1) > t2;
-        if (far) {
-          double j00, j01, j10, j11, jdet;
-          inv2(jxx, jxy, jxy, jyy, j00, j01, j10, j11, jdet);
-          const double g0 = -e0, g1 = -e1;
-          const double v0 = g0 * j00 + g1 * j01, v1 = g0 * j01 + g1 * j11;
-          far = (v0 * g0 + v1 * g1) > t2;
+        const int a = (int)(pr2 >> 16), j = (int)(pr2 & 0x3fffu);
+        if (pr2 != 0xffffffffu && !(pr2 & 0x4000u)) {  // (unused words and reserve partners need no test)
+          // both covariances up front: six independent loads in flight
+          const double axx = pSXX[a], axy = pSXY[a], ayy = pSYY[a];
+          const double jxx = pSXX[j], jxy = pSXY[j], jyy = pSYY[j];
+          const double e0 = sMX[j] - sMX[a], e1 = sMY[j] - sMY[a];
+          double a00, a01, a10, a11, det;
+          inv2(axx, axy, axy, ayy, a00, a01, a10, a11, det);
+          const double u0 = e0 * a00 + e1 * a01, u1 = e0 * a01 + e1 * a11;
+          bool far = (u0 * e0 + u1 * e1) > t2;
+          if (far) {
+            double j00, j01, j10, j11, jdet;
+            inv2(jxx, jxy, jxy, jyy, j00, j01, j10, j11, jdet);
+            const double g0 = -e0, g1 = -e1;
+            const double v0 = g0 * j00 + g1 * j01, v1 = g0 * j01 + g1 * j11;
+            far = (v0 * g0 + v1 * g1) > t2;
+          }
+          if (!far && ((sW[a] + sW[j]) != 0.0)) {
+            sPairs[pi] = pr2 | 0x8000u;
+            atomicOr(&sRec[a], MERGE_REC_ISROW);
+          }
         }
-        if (!far && ((sW[a] + sW[j]) != 0.0)) atomicMin(&sFirst[a], (unsigned)j);
       }
     }
   }
   block_sync();
 
   DBG_TB(32, 2);
+#ifdef RFS_PROFILE
+  dbgT2 = (long long)__builtin_readcyclecounter();
+  dbgPairs = *sPairCount;
+#endif
   // ---- phase 2: replay the rows that have a candidate, with the exact greedy rule ----
   // Liveness lives in LDS from here on: sBnd[j] < 0  <=>  j has been absorbed.
   //
   // Speculative lane-parallel replay + ordered validation.  Up to 64 candidate rows at a time, one per lane, are
-  // replayed independently against the states every entry had when the round started: the lane walks the partners of
-  // its row in ascending index order (each met once, with the row's state at that moment, found through the grid around
-  // the row's CURRENT position and radius), merging as the reference would.  A row only reads entries with a higher
+  // replayed independently against the states every entry had when the round started: the lane walks its row's listed
+  // partners in ascending index order (each met once, with the row's state at that moment), merging as the reference
+  // would; before the row's first merge the verdicts of phase 1b are reused.  A row only reads entries with a higher
   // index, and an entry's mean/covariance change only while it is the outer row, so the sole cross-row hazard is an
   // entry absorbed by an EARLIER row of the same round.  Rows are therefore validated in ascending order: a row that
   // was itself absorbed is dropped; a row that absorbed an entry already taken is replayed again, sequentially by the
   // whole wave (the reference's own scan), with the committed holes visible; everything else commits as computed.
+  // A row that outgrows its slack (unlisted entries might start passing) also goes to the sequential scan.
   bool anyMerge = false;
 #ifdef RFS_PROFILE
   int dbgRows = 0, dbgMerges = 0, dbgChunks = 0;
 #endif
   if (wave == 0) {  // ======== phase 2 is wave 0's; the other waves wait at the barrier below ========
-  unsigned *sRows = sPairs;                                                           // [<= cap] candidate rows, ascending
-  unsigned short *sSpec = reinterpret_cast<unsigned short *>(sPairs + cap);           // [64][8] absorbed entries per lane
+  unsigned short *sRows = sSorted;                                      // [<= cap] candidate rows, ascending (the grid is done)
+  unsigned short *sSpec = reinterpret_cast<unsigned short *>(sCellStart);  // [64][8] absorbed entries per lane
   int nRowsTotal = 0;
   for (int c0 = 0; c0 < N; c0 += 64) {
     const int m = c0 + lane;
-    const bool isRow = (m < N) && (sFirst[m] != 0xffffu);
-    if (m < N) sFirst[m] |= 0xffff0000u;  // upper half: claim slot of the speculative round (none)
+    const bool isRow = (m < N) && (sRec[m] & MERGE_REC_ISROW);
     const unsigned long long rm = __ballot(isRow);
-    if (isRow) sRows[nRowsTotal + __popcll(rm & ((1ull << lane) - 1ull))] = (unsigned)m;
+    wave_sync();  // (sRows aliases sSorted: nothing reads the grid order any more)
+    if (isRow) sRows[nRowsTotal + __popcll(rm & ((1ull << lane) - 1ull))] = (unsigned short)m;
     nRowsTotal += __popcll(rm);
   }
   wave_sync();
@@ -290,13 +349,27 @@ __global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(MERGE_
 
   // the reference's sequential scan for ONE row, executed by the whole wave (fallback + exactness anchor)
   auto seq_replay = [&](const int a) {
-    const int j0 = (int)(sFirst[a] & 0xffffu);
+#ifdef RFS_PROFILE
+    dbgFallbacks++;
+#endif
+    // nothing below the row's lowest listed partner can pass before the first merge, and that merge is at or above it
+    int j0 = a + 1;
+    {
+      const unsigned rec = sRec[a];
+      const int n = (int)((rec >> 20) & 15u);
+      if (n != 15 && n > 0) {
+        const unsigned base = rec & 0xfffffu;
+        unsigned lo = 0x3fffu;
+        for (int k = 0; k < n; k++) lo = min(lo, sPairs[base + k] & 0x3fffu);
+        j0 = (int)lo;
+      }
+    }
     double ax = sMX[a], ay = sMY[a], aw = sW[a], ab = sBnd[a];
     double axx = pSXX[a], axy = pSXY[a], ayy = pSYY[a];
     double a00, a01, a10, a11, adet;
     inv2(axx, axy, axy, ayy, a00, a01, a10, a11, adet);
     bool changed = false;
-    int floorLane = j0 & 63;  // every j < j0 is known to fail against a's initial state
+    int floorLane = j0 & 63;
     for (int c0 = j0 & ~63; c0 < N; c0 += 64) {
       const int j = c0 + lane;
 #ifdef RFS_PROFILE
@@ -352,195 +425,124 @@ __global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(MERGE_
     const bool active = (lane < cnt) && !(sBnd[a] < 0.0);
     int nAbs = 0;
     bool ovf = false;
+    int dbgWhy = 0;  // (profile builds report why rows fell back to the sequential scan)
     double ax = 0, ay = 0, aw = 0, axx = 1, axy = 0, ayy = 1;
     if (active) {
-      ax = sMX[a]; ay = sMY[a]; aw = sW[a];
-      double ab = sBnd[a];
-      axx = pSXX[a]; axy = pSXY[a]; ayy = pSYY[a];
-      double a00, a01, a10, a11, adet;
-      inv2(axx, axy, axy, ayy, a00, a01, a10, a11, adet);
-      unsigned cur = (unsigned)a;
-      // The row's neighbourhood (higher indices only) is gathered into registers, up to 32 indices of 16 bits, and
-      // gathered again only if a merge moves the row to another cell or enlarges its reach.
-      unsigned long long nb[MERGE_NB_WORDS];
-      int nNb = 0, gcx = -1, gcy = -1, grx = -1, gry = -1;
-#ifdef RFS_PROFILE
-      int dbgRounds = 0, dbgGather = 0;
-      if (B.dbg && i == 7 && lane == 0) B.dbg[52] = (long long)__builtin_readcyclecounter();
-#endif
-      for (int round = 0; round < cap; round++) {
-#ifdef RFS_PROFILE
-        dbgRounds++;
-#endif
-        int cx, cy;
-        cell_of(ax, ay, cx, cy);
-        int rx, ry2;
-        reach_of(ab, rx, ry2);
-        if (cx != gcx || cy != gcy || rx != grx || ry2 != gry) {
-          gcx = cx; gcy = cy; grx = rx; gry = ry2;
-          nNb = 0;
-#ifdef RFS_PROFILE
-          dbgGather++;
-#endif
+      const unsigned rec = sRec[a];
+      const int n = (int)((rec >> 20) & 15u);
+      if (n == 15) {
+        ovf = true;  // not listable
+        dbgWhy |= 1;
+      } else {
+        const unsigned base = rec & 0xfffffu;
+        // the row's partners: (passes << 15) | j; absorbed ones are dropped here (liveness is fixed during the round)
+        unsigned it[MERGE_ROW_SLOTS];
 #pragma unroll
-          for (int g = 0; g < MERGE_NB_WORDS; g++) nb[g] = 0ull;
-          const int cxa = cx - rx > 0 ? cx - rx : 0, cxb = cx + rx < MERGE_GX - 1 ? cx + rx : MERGE_GX - 1;
-          const int cya = cy - ry2 > 0 ? cy - ry2 : 0, cyb = cy + ry2 < MERGE_GY - 1 ? cy + ry2 : MERGE_GY - 1;
-          for (int ry = cya; ry <= cyb && nNb <= 4 * MERGE_NB_WORDS; ry++) {
-            const unsigned qs = sCellStart[ry * MERGE_GX + cxa], qe = sCellStart[ry * MERGE_GX + cxb + 1];
-            for (unsigned q = qs; q < qe; q++) {
-              const unsigned j = sSorted[q];
-              if (j <= (unsigned)a) continue;
-              const unsigned long long v = (unsigned long long)j << (16 * (nNb & 3));
+        for (int k = 0; k < MERGE_ROW_SLOTS; k++) it[k] = (k < n) ? (sPairs[base + k] & 0xffffu) : 0xffffffffu;
 #pragma unroll
-              for (int g = 0; g < MERGE_NB_WORDS; g++)
-                if ((nNb >> 2) == g) nb[g] |= v;
-              nNb++;
-            }
-          }
-          if (nNb > 4 * MERGE_NB_WORDS) { ovf = true; break; }  // crowded neighbourhood: leave the row to the sequential scan
-        }
-        // One pass over the neighbourhood with the row's CURRENT state: the (up to) four lowest live partners above
-        // `cur` that pass the distance prefilter, kept sorted by a min/max insertion network.
-#ifdef RFS_PROFILE
-        if (B.dbg && i == 7 && lane == 0 && round == 0) B.dbg[53] = (long long)__builtin_readcyclecounter();
-#endif
-        unsigned c0 = 0xffffu, c1 = 0xffffu, c2 = 0xffffu, c3 = 0xffffu;
-        int nPass = 0;
-        // Smallest slack (distance minus prefilter radius, rounded DOWN in fp32) among the partners that FAIL the
-        // prefilter now: while the row's accumulated shift plus radius growth stays below it, none of them can start
-        // passing, so after a merge the candidates already fetched are still the complete list.
-        float slackMin = 3.0e38f;
-        const double abPass = ab;
-#pragma unroll
-        for (int g = 0; g < MERGE_NB_WORDS; g++) {
-          if (4 * g >= nNb) break;
-          const unsigned long long word = nb[g];
-          unsigned jj[4];
-          double jx[4], jy[4], jbb[4];
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            jj[k] = (unsigned)((word >> (16 * k)) & 0xffffull);
-            const unsigned js = (4 * g + k < nNb) ? jj[k] : (unsigned)a;
-            jx[k] = sMX[js]; jy[k] = sMY[js]; jbb[k] = sBnd[js];
-          }
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const double e0 = jx[k] - ax, e1 = jy[k] - ay;
-            const double e2 = e0 * e0 + e1 * e1, T = fmax(ab, jbb[k]);
-            const bool cand = (4 * g + k < nNb) & (jj[k] > cur) & !(jbb[k] < 0.0);
-            const bool c = cand & !(e2 > T);
-            const float slack = __builtin_sqrtf((float)e2) * (1.f - 4e-6f) - __builtin_sqrtf((float)T) * (1.f + 4e-6f);
-            slackMin = (cand & !c & !(slack >= slackMin)) ? slack : slackMin;
-            unsigned x = c ? jj[k] : 0xffffu, t;
-            nPass += c ? 1 : 0;
-            t = min(c0, x); x = max(c0, x); c0 = t;
-            t = min(c1, x); x = max(c1, x); c1 = t;
-            t = min(c2, x); x = max(c2, x); c2 = t;
-            c3 = min(c3, x);
-          }
-        }
-#ifdef RFS_PROFILE
-        if (B.dbg && i == 7 && lane == 0 && round == 0) B.dbg[54] = (long long)__builtin_readcyclecounter();
-#endif
-        if (nPass == 0) break;
-        // their weights / means / covariances in one batch of independent loads
-        const unsigned cs[4] = {c0, c1, c2, c3};
-        double qw[4], qx[4], qy[4], qxx[4], qxy[4], qyy[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const unsigned js = (cs[k] != 0xffffu) ? cs[k] : (unsigned)a;
-          qw[k] = sW[js]; qx[k] = sMX[js]; qy[k] = sMY[js];
-          qxx[k] = pSXX[js]; qxy[k] = pSXY[js]; qyy[k] = pSYY[js];
-        }
-#ifdef RFS_PROFILE
-        if (B.dbg && i == 7 && lane == 0 && round == 0) B.dbg[55] = (long long)__builtin_readcyclecounter();
-#endif
-        bool merged = false;  // true: the neighbourhood has to be examined again with the row's new state
+        for (int k = 0; k < MERGE_ROW_SLOTS; k++)
+          if (k < n && sBnd[it[k] & 0x3fffu] < 0.0) it[k] = 0xffffffffu;
+        ax = sMX[a]; ay = sMY[a]; aw = sW[a];
+        axx = pSXX[a]; axy = pSXY[a]; ayy = pSYY[a];
+        const float slack = __uint_as_float((unsigned)sSlack[a] << 16);
+        const float rPass = __builtin_amdgcn_sqrtf((float)sBnd[a]) * (1.f - 4e-6f);
         float shift = 0.f;
+        bool changed = false;
+        double a00 = 0, a01 = 0, a11 = 0;
+        unsigned cur = (unsigned)a;
+        for (int step = 0; step < MERGE_ROW_SLOTS; step++) {
+          // lowest listed partner above `cur`
+          unsigned best = 0xffffffffu;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          if (merged || cs[k] == 0xffffu) continue;
-          cur = cs[k];
-          const double e0 = qx[k] - ax, e1 = qy[k] - ay;
-          const double u0 = e0 * a00 + e1 * a01, u1 = e0 * a01 + e1 * a11;
-          bool far = (u0 * e0 + u1 * e1) > t2;
-          if (far) {
-            double j00, j01, j10, j11, jdet;
-            inv2(qxx[k], qxy[k], qxy[k], qyy[k], j00, j01, j10, j11, jdet);
-            const double g0 = -e0, g1 = -e1;
-            const double v0 = g0 * j00 + g1 * j01, v1 = g0 * j01 + g1 * j11;
-            far = (v0 * g0 + v1 * g1) > t2;
+          for (int k = 0; k < MERGE_ROW_SLOTS; k++) {
+            const unsigned j = it[k] & 0x3fffu;
+            const bool c = (it[k] != 0xffffffffu) & (j > cur) & (j < (best & 0x3fffu) || best == 0xffffffffu);
+            best = c ? it[k] : best;
           }
-          if (far || ((aw + qw[k]) == 0.0)) continue;
-          if (nAbs >= 8) { ovf = true; merged = true; continue; }
-          sSpec[lane * 8 + nAbs] = (unsigned short)cs[k];
+          if (best == 0xffffffffu) break;
+          const unsigned j = best & 0x3fffu;
+          cur = j;
+          bool pass = (best & 0x8000u) != 0u;  // verdict of phase 1b: valid while the row is in its initial state
+          if (!changed && !pass) continue;
+          const double jw = sW[j], jx = sMX[j], jy = sMY[j];
+          const double jxx = pSXX[j], jxy = pSXY[j], jyy = pSYY[j];
+          if (changed) {
+            const double e0 = jx - ax, e1 = jy - ay;
+            const double u0 = e0 * a00 + e1 * a01, u1 = e0 * a01 + e1 * a11;
+            bool far = (u0 * e0 + u1 * e1) > t2;
+            if (far) {
+              double j00, j01, j10, j11, jdet;
+              inv2(jxx, jxy, jxy, jyy, j00, j01, j10, j11, jdet);
+              const double g0 = -e0, g1 = -e1;
+              const double v0 = g0 * j00 + g1 * j01, v1 = g0 * j01 + g1 * j11;
+              far = (v0 * g0 + v1 * g1) > t2;
+            }
+            pass = !far && ((aw + jw) != 0.0);
+            if (!pass) continue;
+          }
+          if (nAbs >= 8) { ovf = true; dbgWhy |= 4; break; }
+          sSpec[lane * 8 + nAbs] = (unsigned short)j;
           nAbs++;
-          const double w1 = aw, w2 = qw[k];
+          const double w1 = aw, w2 = jw;
           const double wm = w1 + w2;
-          const double xm = (ax * w1 + qx[k] * w2) / wm, ym = (ay * w1 + qy[k] * w2) / wm;
-          const double d10 = xm - ax, d11 = ym - ay, d20 = xm - qx[k], d21 = ym - qy[k];
-          const double nxx = (w1 * (axx + (f * d10) * d10) + w2 * (qxx[k] + (f * d20) * d20)) / wm;
-          const double nxy = (w1 * (axy + (f * d10) * d11) + w2 * (qxy[k] + (f * d20) * d21)) / wm;
-          const double nyy = (w1 * (ayy + (f * d11) * d11) + w2 * (qyy[k] + (f * d21) * d21)) / wm;
+          const double xm = (ax * w1 + jx * w2) / wm, ym = (ay * w1 + jy * w2) / wm;
+          const double d10 = xm - ax, d11 = ym - ay, d20 = xm - jx, d21 = ym - jy;
+          const double nxx = (w1 * (axx + (f * d10) * d10) + w2 * (jxx + (f * d20) * d20)) / wm;
+          const double nxy = (w1 * (axy + (f * d10) * d11) + w2 * (jxy + (f * d20) * d21)) / wm;
+          const double nyy = (w1 * (ayy + (f * d11) * d11) + w2 * (jyy + (f * d21) * d21)) / wm;
           ax = xm; ay = ym; axx = nxx; axy = nxy; ayy = nyy; aw = wm;
+          changed = true;
+          // Could an entry outside the list pass now?  Not while the row has moved / grown by less than its slack.
+          const double ab = merge_bound(t2, axx, axy, ayy);
+          shift += __builtin_amdgcn_sqrtf((float)(d10 * d10 + d11 * d11)) * (1.f + 4e-6f) + 1e-30f;
+          const float grow = __builtin_amdgcn_sqrtf((float)ab) * (1.f + 4e-6f) - rPass;
+          if (!(slack > shift + fmaxf(grow, 0.f))) { ovf = true; dbgWhy |= 2; break; }
+          double a10, adet;
           inv2(axx, axy, axy, ayy, a00, a01, a10, a11, adet);
-          ab = merge_bound(t2, axx, axy, ayy);
-          // Can a partner that failed the prefilter pass it now?  Not while the row stays in its cell with the same
-          // reach (entries outside the gathered cells stay out of range) and moved / grew by less than the slack.
-          shift += __builtin_sqrtf((float)(d10 * d10 + d11 * d11)) * (1.f + 4e-6f) + 1e-30f;
-          const float grow = __builtin_sqrtf((float)ab) * (1.f + 4e-6f) - __builtin_sqrtf((float)abPass) * (1.f - 4e-6f);
-          int ncx, ncy;
-          cell_of(ax, ay, ncx, ncy);
-          int nrx, nry;
-          reach_of(ab, nrx, nry);
-          const bool still = (nPass <= 4) & (ncx == gcx) & (ncy == gcy) & (nrx == grx) & (nry == gry) & (slackMin > shift + fmaxf(grow, 0.f));
-          merged = !still;  // otherwise: carry on with the remaining fetched candidates against the new state
         }
-#ifdef RFS_PROFILE
-        if (B.dbg && i == 7 && lane == 0 && round == 0) B.dbg[56] = (long long)__builtin_readcyclecounter();
-#endif
-        if (ovf) break;
-        if (!merged && nPass <= 4) break;  // every partner that could pass has been met
       }
-#ifdef RFS_PROFILE
-      {
-        int mr = dbgRounds, mg = dbgGather, mn = nNb;
-        // (only active lanes are here; plain max over them through LDS-free shuffles is overkill: lane 0 reports itself)
-        if (B.dbg && i == 7 && lane == 0) { B.dbg[57] = mr; B.dbg[58] = mg; B.dbg[59] = mn; }
-      }
-#endif
     }
-    // claims: (lane << 16) in the upper half of sFirst[e] for every entry a lane absorbed (lowest lane wins)
+    wave_sync();
+    // claims: the lane in the top bits of the record of every entry a lane absorbed (lowest lane wins)
     for (int k = 0; k < nAbs; k++) {
       const unsigned e = sSpec[lane * 8 + k];
-      atomicMin(&sFirst[e], ((unsigned)lane << 16) | (sFirst[e] & 0xffffu));
+      atomicMin(&sRec[e], ((unsigned)lane << 25) | (sRec[e] & 0x01ffffffu));
     }
     wave_sync();
     DBG_TB(32, 10);
-    // Validation.  `conflict`: the lane lost the claim on something it absorbed (or overflowed).  Before the first
-    // conflicting lane every entry has at most one claimer, so a row there is absorbed exactly when its claimer is
-    // itself alive: alive(l) = !claimed(a_l) || !alive(claimer(a_l)), claimer < l -- resolved by iterating to the fixed
-    // point (chain depth, usually 1-2 trips).  Those rows commit together.  From the first conflicting lane on, rows are
-    // validated one by one in ascending order, and replayed by the whole wave when an absorbed entry is gone.
+    // Validation.  `conflict`: the lane lost the claim on something it absorbed (or could not finish its row).
+    // A row is absorbed exactly when the (lowest) lane claiming it is itself alive: alive(l) = !claimed(a_l) ||
+    // !alive(claimer(a_l)), claimer < l -- resolved by iterating to the fixed point (chain depth, usually 1-2 trips).
+    // Before the first lane that is alive AND in conflict this is exact: an alive lane without conflict holds the
+    // lowest claim on everything it absorbed, and any other claimer of those entries would be alive-and-in-conflict
+    // itself or dead.  Those rows commit together.  From that lane on, rows are validated one by one in ascending
+    // order, and replayed by the whole wave when an absorbed entry is gone.
     bool conflict = ovf;
     bool claimedRow = false;
     unsigned claimer = 0;
     if (active) {
-      claimer = sFirst[a] >> 16;
-      claimedRow = claimer != 0xffffu;
+      claimer = sRec[a] >> 25;
+      claimedRow = claimer != 0x7fu;
       claimer &= 63u;
-      for (int k = 0; k < nAbs; k++) conflict |= (sFirst[sSpec[lane * 8 + k]] >> 16) != (unsigned)lane;
+      for (int k = 0; k < nAbs; k++) conflict |= (sRec[sSpec[lane * 8 + k]] >> 25) != (unsigned)lane;
     }
     const unsigned long long actm = __ballot(active);
-    const unsigned long long cm = __ballot(conflict & active);
-    const int firstDirty = cm ? __builtin_ctzll(cm) : 64;
     unsigned long long alivem = __ballot(active & !claimedRow);
     for (int it = 0; it < 64; it++) {
       const unsigned long long nm = __ballot(active & (!claimedRow | !((alivem >> claimer) & 1ull)));
       if (nm == alivem) break;
       alivem = nm;
     }
+    const unsigned long long cm = __ballot(conflict & active) & alivem;
+#ifdef RFS_PROFILE
+    dbgSlackN += __popcll(__ballot((dbgWhy & 2) != 0));
+    dbgUnlistN += __popcll(__ballot((dbgWhy & 1) != 0));
+    if (B.dbg && i == 7) {
+      const int w1 = __popcll(__ballot(dbgWhy & 1)), w2 = __popcll(__ballot(dbgWhy & 2)), w4 = __popcll(__ballot(dbgWhy & 4)), wc = __popcll(__ballot(conflict & active & !ovf));
+      if (lane == 0) { B.dbg[52] = w1; B.dbg[53] = w2; B.dbg[54] = w4; B.dbg[55] = wc; B.dbg[56] = __popcll(actm); }
+    }
+#endif
+    const int firstDirty = cm ? __builtin_ctzll(cm) : 64;
     const bool commitNow = active && lane < firstDirty && ((alivem >> lane) & 1ull) && nAbs > 0;
     if (commitNow) {
       for (int k = 0; k < nAbs; k++) sBnd[sSpec[lane * 8 + k]] = -1.0;
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(MERGE_
     anyMerge = __ballot(anyMerge) != 0ull;
     // claims are per round
     if (r0 + 64 < nRowsTotal)
-      for (int m = lane; m < N; m += 64) sFirst[m] |= 0xffff0000u;
+      for (int m = lane; m < N; m += 64) sRec[m] |= MERGE_REC_NOCLAIM;
     wave_sync();
     DBG_TB(32, 11);
   }
@@ -586,6 +588,9 @@ __global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(MERGE_
   if (B.dbg && i == 7 && lane == 0) { B.dbg[48] = dbgRows; B.dbg[49] = dbgMerges; B.dbg[50] = dbgChunks; B.dbg[51] = N; }
 #endif
   if (lane == 0) sRed[0] = anyMerge ? 1.f : 0.f;
+#ifdef RFS_PROFILE
+  dbgT3 = (long long)__builtin_readcyclecounter();
+#endif
   }  // ======== end of wave 0's phase 2 ========
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // in-place updates of merged rows (global) -> visible to the workgroup
   block_sync();
@@ -643,6 +648,12 @@ __global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(MERGE_
   }
   if (tid == 0) B.count[i] = nSurv;
   DBG_TB(32, 4);
+#ifdef RFS_PROFILE
+  if (B.dbg && tid == 0) {
+    long long *d = B.dbg + 64 + 4 * (size_t)i;
+    d[0] = (long long)__builtin_readcyclecounter() - dbgT0; d[1] = dbgT3 - dbgT2; d[2] = dbgFallbacks | (dbgSlackN << 8) | (dbgUnlistN << 16); atomicAdd((unsigned long long *)&d[3], (unsigned long long)N | ((unsigned long long)min(dbgPairs, 65535u) << 16));
+  }
+#endif
 }
 
 // LDS per wave: keys[cap] doubles

@@ -1020,10 +1020,18 @@ int rfsgpu_debug_sections(rfsgpu_filter *f, long long *out64) {
   CHECK_HANDLE(f);
   hipSetDevice(f->device);
   if (!f->B.dbg) {
-    HIPCHK(hipMalloc(&f->B.dbg, 64 * sizeof(long long)));
-    HIPCHK(hipMemset(f->B.dbg, 0, 64 * sizeof(long long)));
+    HIPCHK(hipMalloc(&f->B.dbg, (64 + 4 * (size_t)f->N) * sizeof(long long)));
+    HIPCHK(hipMemset(f->B.dbg, 0, (64 + 4 * (size_t)f->N) * sizeof(long long)));
   }
   HIPCHK(hipMemcpy(out64, f->B.dbg, 64 * sizeof(long long), hipMemcpyDeviceToHost));
+  return RFSGPU_OK;
+}
+// four counters per particle written by the last instrumented kernel (see the RFS_PROFILE blocks in the kernels)
+int rfsgpu_debug_per_particle(rfsgpu_filter *f, long long *out4n) {
+  CHECK_HANDLE(f);
+  if (!f->B.dbg) return RFSGPU_ERR_INVALID;
+  hipSetDevice(f->device);
+  HIPCHK(hipMemcpy(out4n, f->B.dbg + 64, 4 * (size_t)f->N * sizeof(long long), hipMemcpyDeviceToHost));
   return RFSGPU_OK;
 }
 #endif

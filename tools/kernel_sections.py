@@ -45,6 +45,20 @@ for base, ns in names.items():
 print("update_map pass0: precompute %d, gates %d, maha+lik %d, scan+write %d, fold %d" % (t[4]-t[0], t[5]-t[4], t[6]-t[5], t[7]-t[6], t[8]-t[7]))
 print("weight: rank sort %d, write %d" % (t[16+8]-t[16], t[17]-t[16+8]))
 print("merge phase2: rows %d, speculative %d, validate %d, tail %d" % (t[41]-t[34], t[42]-t[41], t[43]-t[42], t[35]-t[43]))
-print("merge spec lane0: setup %d gather %d pass %d loads %d tests %d | rounds %d gathers %d nNb %d" % (t[52]-t[41], t[53]-t[52], t[54]-t[53], t[55]-t[54], t[56]-t[55], t[57], t[58], t[59]))
+print("merge fallbacks: unlistable %d, slack %d, >8 merges %d, claim conflicts %d of %d active rows" % (t[52], t[53], t[54], t[55], t[56]))
 print("merge: grid build %d, candidate scan %d; phase2 rows %d merges %d chunks %d N %d" % (t[40]-t[33], t[34]-t[40], t[48], t[49], t[50], t[51]))
 print("kernel ns (events):", f.last_kernel_ns())
+
+import numpy as np
+pp = (C.c_longlong * (4 * n))()
+if lib.rfsgpu_debug_per_particle(f._h, pp) == 0:
+    a = np.frombuffer(pp, dtype=np.int64).reshape(n, 4)
+    tot, p2, fb, nn = a[:, 0], a[:, 1], a[:, 2] & 255, a[:, 3]
+    print("merge per particle: slack-type rows mean %.2f max %d; unlistable rows mean %.2f max %d" % (((a[:, 2] >> 8) & 255).mean(), ((a[:, 2] >> 8) & 255).max(), ((a[:, 2] >> 16) & 255).mean(), ((a[:, 2] >> 16) & 255).max()))
+    q = lambda v: "min %d p50 %d p90 %d p99 %d max %d" % (v.min(), np.percentile(v, 50), np.percentile(v, 90), np.percentile(v, 99), v.max())
+    print("merge per particle: total cycles", q(tot))
+    print("merge per particle: phase-2 cycles", q(p2))
+    print("merge per particle: sequential fallbacks", q(fb), "mean %.2f" % fb.mean())
+    print("merge per particle: N", q(nn & 0xffff))
+    print("merge per particle: listed pairs", q((nn >> 16) & 0xffff))
+    print("merge per particle: near-failing neighbours", q(nn >> 32))
