@@ -427,7 +427,10 @@ __global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(MERGE_
     bool ovf = false;
     int dbgWhy = 0;  // (profile builds report why rows fell back to the sequential scan)
     double ax = 0, ay = 0, aw = 0, axx = 1, axy = 0, ayy = 1;
-    if (active) {
+    // the walk of ONE row over its listed partners, by the calling lane, against the liveness it sees now
+    auto walk = [&]() {
+      nAbs = 0;
+      ovf = false;
       const unsigned rec = sRec[a];
       const int n = (int)((rec >> 20) & 15u);
       if (n == 15) {
@@ -501,7 +504,8 @@ __global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(MERGE_
           inv2(axx, axy, axy, ayy, a00, a01, a10, a11, adet);
         }
       }
-    }
+    };
+    if (active) walk();
     wave_sync();
     // claims: the lane in the top bits of the record of every entry a lane absorbed (lowest lane wins)
     for (int k = 0; k < nAbs; k++) {
@@ -564,8 +568,21 @@ __global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(MERGE_
       bool taken = false;
       int mine = 0;
       if (lane < nl) { mine = sSpec[l * 8 + lane]; taken = sBnd[mine] < 0.0; }
-      if (ovl || __ballot(taken) != 0ull) {
-        seq_replay(al);  // conflict (or more merges than the speculative buffer holds): the reference's scan, exactly
+      if (ovl) {
+        seq_replay(al);  // the row could not be finished from its list: the reference's scan, exactly
+      } else if (__ballot(taken) != 0ull) {
+        // An entry this row absorbed is gone.  Every earlier row is final now, so the row's own walk, redone by its
+        // lane against the present liveness, is final too (unless it outgrows its list: then the full scan).
+        if (lane == l) walk();
+        wave_sync();
+        if ((__ballot(ovf) >> l) & 1ull) {
+          seq_replay(al);
+        } else {
+          const int nl2 = __builtin_amdgcn_readlane(nAbs, l);
+          if (lane < nl2) sBnd[sSpec[l * 8 + lane]] = -1.0;
+          if (nl2 > 0) commit |= 1ull << l;
+          wave_sync();
+        }
       } else {
         if (lane < nl) sBnd[mine] = -1.0;
         if (nl > 0) commit |= 1ull << l;
