@@ -240,6 +240,104 @@ def test_tied_weights_take_the_exact_rank_path(pkg, ob, sc):
     compare_maps(sc, dev2, orc2, scen["n"], ordered=True)
 
 
+def _clustered_mixtures(sc, n_particles, n_gauss, kind, seed):
+    """Mixtures built to hit every path of the device merge: dense clusters (chains of merges, rows that share partners,
+    rows absorbed by earlier rows), coincident means, crowded neighbourhoods (more partners than a row can list),
+    a wide spread of covariance sizes (cells set by the largest radius) and degenerate covariances (infinite bound)."""
+    rng = np.random.default_rng(seed)
+    scen = sc.make_scenario(n_particles, n_gauss, 3, seed=seed)
+    n, M = n_particles, n_gauss
+    mean = np.zeros((n, M, 2))
+    cov = np.zeros((n, M, 2, 2))
+    for i in range(n):
+        if kind == "clusters":          # ~M/6 clusters of ~6, spacing comparable to the merge radius
+            k = max(1, M // 6)
+            c = rng.uniform(-8, 8, (k, 2))
+            a = rng.integers(0, k, M)
+            mean[i] = c[a] + rng.normal(0, 0.04, (M, 2))
+            s = rng.uniform(0.03, 0.09, (M, 2))
+        elif kind == "crowded":         # a few very crowded spots: far more than 8 partners per row
+            k = 3
+            c = rng.uniform(-3, 3, (k, 2))
+            a = rng.integers(0, k, M)
+            mean[i] = c[a] + rng.normal(0, 0.02, (M, 2))
+            s = rng.uniform(0.05, 0.1, (M, 2))
+        elif kind == "coincident":      # exact duplicates and near-duplicates
+            k = max(1, M // 4)
+            c = rng.uniform(-5, 5, (k, 2))
+            a = rng.integers(0, k, M)
+            mean[i] = c[a]
+            mean[i, ::3] += rng.normal(0, 1e-3, (len(mean[i, ::3]), 2))
+            s = rng.uniform(0.02, 0.05, (M, 2))
+        elif kind == "mixed_scales":    # one huge covariance sets the cell size; the rest are tight clusters
+            k = max(1, M // 5)
+            c = rng.uniform(-20, 20, (k, 2))
+            a = rng.integers(0, k, M)
+            mean[i] = c[a] + rng.normal(0, 0.05, (M, 2))
+            s = rng.uniform(0.03, 0.08, (M, 2))
+            s[:: max(1, M // 3)] = rng.uniform(2.0, 4.0, (len(s[:: max(1, M // 3)]), 2))
+        elif kind == "chain":           # a line of equally spaced Gaussians: every merge moves the row toward the next one
+            mean[i, :, 0] = 0.02 * np.arange(M) + rng.normal(0, 1e-3, M)
+            mean[i, :, 1] = rng.normal(0, 1e-3, M)
+            s = np.full((M, 2), 0.05)
+        else:
+            raise ValueError(kind)
+        rho = rng.uniform(-0.5, 0.5, M)
+        cov[i, :, 0, 0] = s[:, 0] ** 2
+        cov[i, :, 1, 1] = s[:, 1] ** 2
+        cov[i, :, 0, 1] = cov[i, :, 1, 0] = rho * s[:, 0] * s[:, 1]
+    scen["mean"], scen["cov"] = mean, cov
+    scen["w"] = rng.uniform(0.005, 1.0, (n, M))
+    return scen
+
+
+@pytest.mark.parametrize("kind,M,cap", [("clusters", 150, 256), ("clusters", 500, 512), ("crowded", 120, 128), ("coincident", 200, 256),
+                                        ("mixed_scales", 180, 192), ("chain", 100, 128), ("chain", 300, 320)])
+def test_merge_stress_against_oracle(pkg, ob, sc, kind, M, cap):
+    """GaussianMixture::merge / prune on adversarial mixtures, two-kernel form (merge, then prune)."""
+    scen = _clustered_mixtures(sc, 12, M, kind, seed=700 + M)
+    dev, orc = make_pair(pkg, ob, sc, scen, cap=cap)
+    for f in (dev, orc):
+        f.merge()
+    compare_maps(sc, dev, orc, scen["n"], ordered=True)
+    assert dev.gm_sizes().max() < M          # the mixtures really merge
+    for f in (dev, orc):
+        f.prune()
+    compare_maps(sc, dev, orc, scen["n"], ordered=True)
+    for f in (dev, orc):                     # merging an already merged + pruned mixture again (holes gone, new order)
+        f.merge()
+    compare_maps(sc, dev, orc, scen["n"], ordered=True)
+
+
+def test_merge_with_degenerate_covariances(pkg, ob, sc):
+    """An indefinite covariance gives an unbounded prefilter radius (its Mahalanobis "distance" can be negative at any
+    range): the grid collapses to one cell and every pair takes the exact test, as in the reference.  (An exactly
+    singular matrix is outside the parity envelope: its determinant is 0 or 1e-21 depending on FMA contraction.)"""
+    scen = _clustered_mixtures(sc, 6, 90, "clusters", seed=77)
+    scen["cov"][:, 5] = [[1e-2, 2e-2], [2e-2, 1e-2]]           # indefinite
+    scen["cov"][:, 40] = [[1e-2, 3e-2], [3e-2, 1e-2]]          # indefinite
+    dev, orc = make_pair(pkg, ob, sc, scen, cap=128)
+    for f in (dev, orc):
+        f.merge()
+        f.prune()
+    assert np.array_equal(dev.gm_sizes(), orc.gm_sizes())
+    for i in range(scen["n"]):
+        a, b = dev.export_gm(i), orc.export_gm(i)
+        fin = np.isfinite(b[0]) & np.isfinite(b[2]).all(1) & np.isfinite(b[3]).all((1, 2))
+        sc.assert_gm_close(tuple(x[fin] for x in a), tuple(x[fin] for x in b), GM_RTOL, GM_ATOL, ordered=True)
+
+
+@pytest.mark.parametrize("kind,M", [("clusters", 150), ("crowded", 100), ("chain", 120)])
+def test_fused_merge_prune_stress_through_update(pkg, ob, sc, kind, M):
+    """Same adversarial maps through rfsgpu_update (fused merge+prune kernel) and update_async."""
+    scen = _clustered_mixtures(sc, 10, M, kind, seed=900 + M)
+    dev, orc = make_pair(pkg, ob, sc, scen, cap=512)
+    for f in (dev, orc):
+        f.update(scen["Z"])
+    compare_weights(dev, orc)
+    compare_maps(sc, dev, orc, scen["n"], ordered=True)
+
+
 # ---- Victoria Park model (3-D landmarks, scan-based Pd, birth-candidate lists) -----------------------------------------
 
 def make_vp_pair(pkg, ob, sc, scen, cap=192):
