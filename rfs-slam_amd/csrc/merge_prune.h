@@ -15,10 +15,10 @@
 #include "common.h"
 #include "weighting.h"  // wave_sync
 
-// LDS per wave: per entry x, y, w, bound (4 doubles) + first-candidate index (u16) + grid-sorted index (u16);
-// plus the 16x16 spatial grid: cell start offsets and scatter cursors (u32 each).  Covariances stay in HBM/L2 and
-// their inverses are formed on demand for the few pairs that survive the distance prefilter -- this keeps the
-// footprint at 36 B/entry so that 8+ waves fit a CU and 2000 particles run in a single round.
+// LDS per particle: per entry x, y, w, bound (4 doubles) + row record (u32) + grid-sorted index (u16) + slack (u16);
+// plus the 32x16 spatial grid (one cursor array, u32) and the list of possible partners (u32 each).  Covariances stay
+// in HBM/L2 and their inverses are formed on demand for the few pairs that survive the distance prefilter -- this
+// keeps the footprint at 40 B/entry so that 8 workgroups fit a CU and 2000 particles run in a single round.
 #define MERGE_GX 32  // grid cells along x
 #define MERGE_GY 16  // grid cells along y
 #define MERGE_CELLS (MERGE_GX * MERGE_GY)
@@ -70,16 +70,16 @@ __device__ __forceinline__ bool merge_pair_passes(double e0, double e1, double a
 // gm_merge (+ optional fused gm_prune).
 // Phase 1 (parallel): every pair (a, j>a) is examined once against the INITIAL states -- which is exactly what the
 //   reference's sequential scan sees the first time it meets a pair, because a Gaussian only changes while it is the
-//   outer index -- and the lowest passing j of each row is recorded (firstCand).  Candidates come from a 16x16
-//   uniform grid over the mixture's bounding box whose cell edge is >= the largest prefilter radius, so every pair that
-//   can pass lies in adjacent cells; an entry only looks at partners with a HIGHER index, so each lane finds the
-//   lowest passing j of its own rows without atomics.  A non-finite bound makes the cell edge infinite: everything
-//   falls into one cell and the search degrades to all pairs, still exact.
-// Phase 2 (sequential, rare): rows with a candidate are replayed in order with the exact greedy rule: merge the
-//   lowest passing j, update a, re-test only j' > j against the new state (ballot + ctz), skip absorbed entries.
+//   outer index.  Candidates come from a 32x16 uniform grid over the mixture's bounding box whose cell edges are >= the
+//   largest prefilter radius, so every pair that can pass lies in adjacent cells; each entry writes the list of its
+//   possible partners (higher indices only) and a slack bound for everything it did not list; the listed pairs are
+//   tested exactly.  A non-finite bound makes the cell edge infinite: everything falls into one cell and the search
+//   degrades to all pairs, still exact.
+// Phase 2: rows with a passing partner are replayed with the exact greedy rule (merge the lowest passing j, update a,
+//   re-test only j' > j against the new state, skip absorbed entries) -- speculatively one row per lane, validated in
+//   ascending row order; see the comments in the kernel.
 // FUSE_PRUNE: survivors (w >= pruneT, not absorbed) are rank-sorted by (weight desc, index asc) and compacted into
 //   the other slab straight from here (GaussianMixture::prune :477-521), saving gm_prune's launch and re-read.
-#define MERGE_NB_WORDS 8  // speculative replay: neighbourhood indices kept in registers, 4 per 64-bit word
 // One workgroup of WPP waves per particle: the entry- and pair-parallel phases (stage, grid, phase 1, prune) are spread
 // over all WPP*64 threads, which is what fills the SIMDs at ~2000 particles; phase 2 is run by wave 0.
 #ifndef MERGE_WAVES_PER_EU
