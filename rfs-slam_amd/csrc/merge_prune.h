@@ -164,15 +164,6 @@ __global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(MERGE_
     cy = iy < 0 ? 0 : (iy >= MERGE_GY ? MERGE_GY - 1 : iy);
     if (degenerate) { cx = 0; cy = 0; }
   };
-  // cells a Gaussian of squared prefilter radius `ab` can reach from its own cell, per axis
-  auto reach_of = [&](double ab, int &rx, int &ry) {
-    rx = MERGE_GX; ry = MERGE_GY;
-    if (!degenerate && ab < 1.0e300) {
-      const double r = sqrt(ab), qx = r * invCx, qy = r * invCy;
-      rx = (qx < (double)MERGE_GX) ? (int)qx + 1 : MERGE_GX;
-      ry = (qy < (double)MERGE_GY) ? (int)qy + 1 : MERGE_GY;
-    }
-  };
   for (int m = tid, sidx = 0; m < N; m += NT, sidx++) {
     if ((hole >> sidx) & 1u) continue;
     int cx, cy;
@@ -425,7 +416,7 @@ __global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(MERGE_
     const bool active = (lane < cnt) && !(sBnd[a] < 0.0);
     int nAbs = 0;
     bool ovf = false;
-    int dbgWhy = 0;  // (profile builds report why rows fell back to the sequential scan)
+    [[maybe_unused]] int dbgWhy = 0;  // (profile builds report why rows fell back to the sequential scan)
     double ax = 0, ay = 0, aw = 0, axx = 1, axy = 0, ayy = 1;
     // the walk of ONE row over its listed partners, by the calling lane, against the liveness it sees now
     auto walk = [&]() {

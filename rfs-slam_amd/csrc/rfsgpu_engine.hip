@@ -608,10 +608,12 @@ static int eval_cap(const rfsgpu_filter *f) {
   return c;
 }
 
+#ifndef WEIGHT_WPP
+#define WEIGHT_WPP 2
+#endif
 static int launch_weighting(rfsgpu_filter *f) {
   const int nZ = f->nZ, ec = eval_cap(f);
   const size_t per = weight_lds_bytes_per_wave(f->cap, ec, nZ);
-  auto bytes = [&](int wpb) { return (size_t)(2 * RFSGPU_MAX_Z * 8) + (size_t)wpb * per; };
   const int src = f->cur, dst = f->cur ^ 1;
   HIPCHK(hipMemsetAsync(f->Q.count, 0, sizeof(int), f->stream));
   int rc;
@@ -624,15 +626,10 @@ static int launch_weighting(rfsgpu_filter *f) {
     if (murty_launch(f->Q, f->MS, f->B, f->stream) != 0) return fail(f, RFSGPU_ERR_HIP, "murty launch failed");
     return RFSGPU_OK;
   }
-  if (bytes(4) <= 80 * 1024) {
-    if ((rc = set_lds(f, phd_weight_multifeature_kernel<4>, bytes(4))) != RFSGPU_OK) return rc;
-    phd_weight_multifeature_kernel<4><<<(f->N + 3) / 4, 256, bytes(4), f->stream>>>(f->B, f->P, src, dst, nZ, ec, f->Q);
-  } else if (bytes(2) <= 80 * 1024) {
-    if ((rc = set_lds(f, phd_weight_multifeature_kernel<2>, bytes(2))) != RFSGPU_OK) return rc;
-    phd_weight_multifeature_kernel<2><<<(f->N + 1) / 2, 128, bytes(2), f->stream>>>(f->B, f->P, src, dst, nZ, ec, f->Q);
-  } else {
-    if ((rc = set_lds(f, phd_weight_multifeature_kernel<1>, bytes(1))) != RFSGPU_OK) return rc;
-    phd_weight_multifeature_kernel<1><<<f->N, 64, bytes(1), f->stream>>>(f->B, f->P, src, dst, nZ, ec, f->Q);
+  {  // one workgroup of WEIGHT_WPP waves per particle
+    const size_t b = (size_t)(2 * RFSGPU_MAX_Z * 8) + per + WEIGHT_SCRATCH_BYTES;
+    if ((rc = set_lds(f, phd_weight_multifeature_kernel<WEIGHT_WPP>, b)) != RFSGPU_OK) return rc;
+    phd_weight_multifeature_kernel<WEIGHT_WPP><<<f->N, WEIGHT_WPP * 64, b, f->stream>>>(f->B, f->P, src, dst, nZ, ec, f->Q);
   }
   HIPCHK(hipGetLastError());
   f->cur = dst;

@@ -244,14 +244,14 @@ __device__ double rfs_partitions_wave(const WeightLDS &s, int nE, int nZ, double
   return l;
 }
 
-// One sweep over the float keys ranks NS entries per lane (entries g0 + 64*k + lane).
+// One sweep over the float keys ranks NS entries per thread (entries g0 + NT*k + tid; NT threads share the mixture).
 template <int NS>
-__device__ __forceinline__ void rank_sweep_f32(const float *fkeys, int *perm, int N, int Npad, int g0, int lane) {
+__device__ __forceinline__ void rank_sweep_f32(const float *fkeys, int *perm, int N, int Npad, int g0, int tid, int NT) {
   float fm[NS];
   int cgt[NS];
 #pragma unroll
   for (int k = 0; k < NS; k++) {
-    const int m = g0 + 64 * k + lane;
+    const int m = g0 + NT * k + tid;
     fm[k] = (m < N) ? fkeys[m] : 3.0e38f;
     cgt[k] = 0;
   }
@@ -267,24 +267,37 @@ __device__ __forceinline__ void rank_sweep_f32(const float *fkeys, int *perm, in
   }
 #pragma unroll
   for (int k = 0; k < NS; k++) {
-    const int m = g0 + 64 * k + lane;
+    const int m = g0 + NT * k + tid;
     if (m < N) perm[cgt[k]] = m;
   }
 }
 
-template <int WPB>
-__global__ __launch_bounds__(WPB * 64) void phd_weight_multifeature_kernel(Buffers B, Params P, int src, int dst, int nZ, int evalCap,
-                                                                           MurtyQueue Q) {
+// Cross-wave scratch of the multi-wave kernel: a few doubles / ints after the per-particle LDS block.
+#define WEIGHT_SCRATCH_BYTES 64
+
+#ifndef WEIGHT_WAVES_PER_EU
+#define WEIGHT_WAVES_PER_EU 4  // <= 128 VGPRs: with 2 waves per particle all ~2000 particles of C2 are resident at once
+#endif
+// One workgroup of WPP waves per particle.  The entry-parallel steps (rank sort, sorted write-out, likelihood table) use
+// all threads; the intensity sums split the evaluation points between the waves (groups of 8); the serial steps
+// (evaluation-point selection, components, partition enumeration) run on wave 0 while wave 1 takes the weight sums.
+template <int WPP>
+__global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(WPP == 1 ? 2 : WEIGHT_WAVES_PER_EU)))
+void phd_weight_multifeature_kernel(Buffers B, Params P, int src, int dst, int nZ, int evalCap, MurtyQueue Q) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
+  constexpr int NT = WPP * 64;
   double *sZ = reinterpret_cast<double *>(smem_raw);
-  const int wave = threadIdx.x >> 6;
-  const int lane = threadIdx.x & 63;
-  for (int t = threadIdx.x; t < 2 * nZ; t += WPB * 64) sZ[t] = B.Z[t];
-  __syncthreads();
-  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
-  if (i >= B.N) return;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int i = blockIdx.x;
+  auto block_sync = [&]() { if (WPP == 1) wave_sync(); else __syncthreads(); };
+  for (int t = tid; t < 2 * nZ; t += NT) sZ[t] = B.Z[t];
   WeightLDS s;
-  carve_weight_lds(smem_raw + 2 * RFSGPU_MAX_Z * 8 + (size_t)wave * weight_lds_bytes_per_wave(B.cap, evalCap, nZ), B.cap, evalCap, nZ, s);
+  const size_t perBytes = weight_lds_bytes_per_wave(B.cap, evalCap, nZ);
+  carve_weight_lds(smem_raw + 2 * RFSGPU_MAX_Z * 8, B.cap, evalCap, nZ, s);
+  double *sScr = reinterpret_cast<double *>(smem_raw + 2 * RFSGPU_MAX_Z * 8 + perBytes);  // [0] sumPrev [1] sumCur
+  int *sScrI = reinterpret_cast<int *>(sScr + 4);                                           // [0] nE [1] missing-rank flag
 
   const int N = B.count[i];
   const double *sl = B.slab[src];
@@ -301,44 +314,50 @@ __global__ __launch_bounds__(WPB * 64) void phd_weight_multifeature_kernel(Buffe
     for (int pl = 0; pl < PL_COUNT; pl++) {
       const double *q = plane((double *)sl, B.cap, i, pl);
       double *d = plane(dl, B.cap, i, pl);
-      for (int m = lane; m < N; m += 64) d[m] = q[m];
+      for (int m = tid; m < N; m += NT) d[m] = q[m];
     }
-    if (lane == 0) B.weight[i] = RFS_DENORM_MIN;
+    if (tid == 0) B.weight[i] = RFS_DENORM_MIN;
     return;
   }
 
-  DBG_T(16, 0);
+  DBG_TB(16, 0);
+#ifdef RFS_PROFILE
+  const long long dbgT0 = (long long)__builtin_readcyclecounter();
+#endif
   // ---- 1. sort by weight: rank = #{ j : w_j > w_m  or (w_j == w_m and j < m) } ----
   // Rank sort, fp32 first: float conversion is monotone, so when all float keys of the mixture are distinct
-  //   rank = #{ j : (float)w_j > (float)w_m }  exactly (one fp32 compare + add per pair, NS entries per lane in one
+  //   rank = #{ j : (float)w_j > (float)w_m }  exactly (one fp32 compare + add per pair, NS entries per thread in one
   // sweep over the keys).  A float collision (or a true tie) shows up as a rank that nobody claims; the mixture is then
   // re-ranked with exact fp64 comparisons, (weight desc, index asc).
   float *fkeys = s.fkeys;
-  for (int m = lane; m < N; m += 64) { const double w = qW[m]; s.keys[m] = w; s.perm[m] = -1; }
-  wave_sync();
   const int Npad = (N + 7) & ~7;
-  for (int m = lane; m < Npad; m += 64) fkeys[m] = (m < N) ? (float)s.keys[m] : -3.0e38f;  // sentinel never ranks ahead
-  wave_sync();
-  for (int g0 = 0; g0 < N; g0 += 512) {
-    const int nSlots = (N - g0 + 63) >> 6;
+  for (int m = tid; m < Npad; m += NT) {
+    if (m < N) { const double w = qW[m]; s.keys[m] = w; s.perm[m] = -1; fkeys[m] = (float)w; }
+    else fkeys[m] = -3.0e38f;  // sentinel never ranks ahead
+  }
+  if (tid == 0) sScrI[1] = 0;
+  block_sync();
+  for (int g0 = 0; g0 < N; g0 += 8 * NT) {
+    const int nSlots = (N - g0 + NT - 1) / NT;
     switch (nSlots >= 8 ? 8 : nSlots) {
-      case 1: rank_sweep_f32<1>(fkeys, s.perm, N, Npad, g0, lane); break;
-      case 2: rank_sweep_f32<2>(fkeys, s.perm, N, Npad, g0, lane); break;
-      case 3: rank_sweep_f32<3>(fkeys, s.perm, N, Npad, g0, lane); break;
-      case 4: rank_sweep_f32<4>(fkeys, s.perm, N, Npad, g0, lane); break;
-      case 5: rank_sweep_f32<5>(fkeys, s.perm, N, Npad, g0, lane); break;
-      case 6: rank_sweep_f32<6>(fkeys, s.perm, N, Npad, g0, lane); break;
-      case 7: rank_sweep_f32<7>(fkeys, s.perm, N, Npad, g0, lane); break;
-      default: rank_sweep_f32<8>(fkeys, s.perm, N, Npad, g0, lane); break;
+      case 1: rank_sweep_f32<1>(fkeys, s.perm, N, Npad, g0, tid, NT); break;
+      case 2: rank_sweep_f32<2>(fkeys, s.perm, N, Npad, g0, tid, NT); break;
+      case 3: rank_sweep_f32<3>(fkeys, s.perm, N, Npad, g0, tid, NT); break;
+      case 4: rank_sweep_f32<4>(fkeys, s.perm, N, Npad, g0, tid, NT); break;
+      case 5: rank_sweep_f32<5>(fkeys, s.perm, N, Npad, g0, tid, NT); break;
+      case 6: rank_sweep_f32<6>(fkeys, s.perm, N, Npad, g0, tid, NT); break;
+      case 7: rank_sweep_f32<7>(fkeys, s.perm, N, Npad, g0, tid, NT); break;
+      default: rank_sweep_f32<8>(fkeys, s.perm, N, Npad, g0, tid, NT); break;
     }
   }
-  wave_sync();
+  block_sync();
   {
     bool missing = false;
-    for (int r = lane; r < N; r += 64) missing = missing | (s.perm[r] < 0);
-    if (__ballot(missing) != 0ull) {  // rare: exact re-rank of the whole mixture
-      wave_sync();
-      for (int m = lane; m < N; m += 64) {
+    for (int r = tid; r < N; r += NT) missing = missing | (s.perm[r] < 0);
+    if (__ballot(missing) != 0ull && lane == 0) sScrI[1] = 1;
+    block_sync();
+    if (sScrI[1] != 0) {  // rare: exact re-rank of the whole mixture
+      for (int m = tid; m < N; m += NT) {
         const double wm = s.keys[m];
         int rank = 0;
         for (int j = 0; j < N; j++) {
@@ -347,11 +366,11 @@ __global__ __launch_bounds__(WPB * 64) void phd_weight_multifeature_kernel(Buffe
         }
         s.perm[rank] = m;
       }
-      wave_sync();
+      block_sync();
     }
   }
   // sorted mixture -> other slab
-  for (int r = lane; r < N; r += 64) {
+  for (int r = tid; r < N; r += NT) {
     const int m = s.perm[r];
     // all gathers first (independent loads in flight together), then the coalesced stores
     const double v0 = s.keys[m], v1 = qWP[m], v2 = qMX[m], v3 = qMY[m], v4 = qSXX[m], v5 = qSXY[m], v6 = qSYY[m];
@@ -363,16 +382,16 @@ __global__ __launch_bounds__(WPB * 64) void phd_weight_multifeature_kernel(Buffe
     plane(dl, B.cap, i, PL_SXY)[r] = v5;
     plane(dl, B.cap, i, PL_SYY)[r] = v6;
   }
-  DBG_T(16, 8);
+  DBG_TB(16, 8);
 
-  DBG_T(16, 1);
+  DBG_TB(16, 1);
   PoseReg pr;
   load_pose(B, P, i, pr);
 
-  // ---- 2. evaluation points: first <= nEvalPoints sorted entries with w >= minW and Pd > 0 (:747-762) ----
-  int nE = 0;
-  bool evalOverflow = false;
-  {
+  // ---- 2. evaluation points: first <= nEvalPoints sorted entries with w >= minW and Pd > 0 (:747-762) ----  (wave 0)
+  if (wave == 0) {
+    int nE = 0;
+    bool evalOverflow = false;
     const int limit = nEvalPoints < RFSGPU_MAX_EVAL ? nEvalPoints : RFSGPU_MAX_EVAL;
     bool done = false;
     for (int c0 = 0; c0 < N && !done; c0 += 64) {
@@ -409,19 +428,24 @@ __global__ __launch_bounds__(WPB * 64) void phd_weight_multifeature_kernel(Buffe
     }
     // more evaluation points requested than the device path holds: refuse loudly (conservative)
     if (nE == limit && nEvalPoints > limit) evalOverflow = true;
+    if (evalOverflow && lane == 0) atomicOr(B.err, ERRBIT_EVALPTS);
+    if (lane == 0) sScrI[0] = nE;
   }
-  if (evalOverflow && lane == 0) atomicOr(B.err, ERRBIT_EVALPTS);
-  wave_sync();
+  // ---- 3a. weight sums (:765-775) ----  (the last wave, alongside step 2)
+  if (wave == WPP - 1) {
+    double sumPrev = 0.0, sumCur = 0.0;
+    for (int m = lane; m < N; m += 64) { sumPrev += qWP[m]; sumCur += s.keys[m]; }
+    sumPrev = wave_sum_dpp(sumPrev);
+    sumCur = wave_sum_dpp(sumCur);
+    if (lane == 0) { sScr[0] = sumPrev; sScr[1] = sumCur; }
+  }
+  block_sync();
+  const int nE = sScrI[0];
 
-  DBG_T(16, 2);
-  // ---- 3. weight sums (:765-775) and intensity products at the evaluation points (:776-800) ----
-  double sumPrev = 0.0, sumCur = 0.0;
-  for (int m = lane; m < N; m += 64) { sumPrev += qWP[m]; sumCur += s.keys[m]; }
-  sumPrev = wave_sum_dpp(sumPrev);
-  sumCur = wave_sum_dpp(sumCur);
-
-  double prodBefore = 1.0, prodAfter = 1.0;
-  for (int e0 = 0; e0 < nE; e0 += 8) {
+  DBG_TB(16, 2);
+  // ---- 3b. intensity at the evaluation points (:776-800): groups of 8 points, dealt to the waves ----
+  double *sumB = reinterpret_cast<double *>(s.compRows), *sumA = sumB + 64;  // [64] each (free until step 5)
+  for (int e0 = 8 * wave; e0 < nE; e0 += 8 * WPP) {
     double accB[8], accA[8], ex[8], ey[8];
 #pragma unroll
     for (int t = 0; t < 8; t++) {
@@ -446,25 +470,23 @@ __global__ __launch_bounds__(WPB * 64) void phd_weight_multifeature_kernel(Buffe
     }
 #pragma unroll
     for (int t = 0; t < 8; t++) {
-      if (e0 + t < nE) {
-        prodBefore *= (RFS_DENORM_MIN + wave_sum_dpp(accB[t]));
-        prodAfter *= (RFS_DENORM_MIN + wave_sum_dpp(accA[t]));
-      }
+      const double b = wave_sum_dpp(accB[t]), a = wave_sum_dpp(accA[t]);
+      if (lane == 0 && e0 + t < nE) { sumB[e0 + t] = b; sumA[e0 + t] = a; }
     }
   }
 
-  DBG_T(16, 3);
+  DBG_TB(16, 3);
   // ---- 4. likelihood table L[e][n] = N(z_n; h(x, e), S_e) * Pd_e, gated (:847-863) ----
-  if (lane < nE) {
+  if (tid < nE) {
     MeasOut mo;
-    rb_measure(P, pr, s.evX[lane], s.evY[lane], 0.0, 0.0, 0.0, mo);  // evalPt_copy.setCov(Zero)
+    rb_measure(P, pr, s.evX[tid], s.evY[tid], 0.0, 0.0, 0.0, mo);  // evalPt_copy.setCov(Zero)
     double i00, i01, i10, i11, det;
     inv2(mo.s00, mo.s01, mo.s10, mo.s11, i00, i01, i10, i11, det);
-    double *z = s.evZ + 7 * lane;
+    double *z = s.evZ + 7 * tid;
     z[0] = mo.z0; z[1] = mo.z1; z[2] = i00; z[3] = i01; z[4] = i10; z[5] = i11; z[6] = pdf_factor2(det);
   }
-  wave_sync();
-  for (int idx = lane; idx < nE * nZ; idx += 64) {
+  block_sync();
+  for (int idx = tid; idx < nE * nZ; idx += NT) {
     const int e = idx / nZ, n = idx - e * nZ;
     const double *z = s.evZ + 7 * e;
     const double d0 = sZ[2 * n] - z[0], d1 = sZ[2 * n + 1] - z[1];
@@ -474,20 +496,40 @@ __global__ __launch_bounds__(WPB * 64) void phd_weight_multifeature_kernel(Buffe
     if (md2 > P.weightingMd2) Lv = 0.0;
     s.L[idx] = Lv;
   }
-  wave_sync();
+  block_sync();
+  if (wave != 0) return;  // the rest is wave 0's
 
-  DBG_T(16, 4);
+  // the products over the evaluation points, in order (the sums were left in LDS by the waves)
+  double prodBefore = 1.0, prodAfter = 1.0;
+  for (int e = 0; e < nE; e++) {
+    prodBefore *= (RFS_DENORM_MIN + sumB[e]);
+    prodAfter *= (RFS_DENORM_MIN + sumA[e]);
+  }
+  const double sumPrev = sScr[0], sumCur = sScr[1];
+  wave_sync();  // (sumA / sumB live in the component scratch that step 5 reuses)
+
+  DBG_TB(16, 4);
+#ifdef RFS_PROFILE
+  const long long dbgT4 = (long long)__builtin_readcyclecounter();
+#endif
   // ---- 5./6. partition the table, sum the assignments of every partition (shared with the 3-D kernel) ----
   const double l = rfs_partitions_wave(s, nE, nZ, P.clutter, lane, i, Q, B.err);
   const double sensingArea = 2 * RFS_PI * (P.rmax - P.rmin);
   const double ml = l / (P.clutter * sensingArea);  // clutterIntensityIntegral (src/MeasurementModel_RngBrg.cpp:175-178)
 
-  DBG_T(16, 6);
+  DBG_TB(16, 6);
   // ---- 7. overall weight (:806-811) ----
   const double overall = ml * prodBefore / prodAfter * exp(sumCur - sumPrev);
   if (lane == 0) {
     const double wnew = overall * B.weight[i];
     B.weight[i] = wnew;
   }
-  DBG_T(16, 7);
+  DBG_TB(16, 7);
+#ifdef RFS_PROFILE
+  if (B.dbg && tid == 0) {
+    long long *d = B.dbg + 64 + 4 * (size_t)i;
+    const long long t = (long long)__builtin_readcyclecounter();
+    d[0] = t - dbgT0; d[1] = t - dbgT4; d[2] = nE; d[3] = N;
+  }
+#endif
 }

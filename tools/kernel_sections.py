@@ -62,3 +62,13 @@ if lib.rfsgpu_debug_per_particle(f._h, pp) == 0:
     print("merge per particle: N", q(nn & 0xffff))
     print("merge per particle: listed pairs", q((nn >> 16) & 0xffff))
     print("merge per particle: near-failing neighbours", q(nn >> 32))
+
+f.restore_state()
+f.update_map(scen["Z"])
+f.importance_weighting()
+if lib.rfsgpu_debug_per_particle(f._h, pp) == 0:
+    a = np.frombuffer(pp, dtype=np.int64).reshape(n, 4)
+    q = lambda v: "min %d p50 %d p90 %d p99 %d max %d" % (v.min(), np.percentile(v, 50), np.percentile(v, 90), np.percentile(v, 99), v.max())
+    print("weight per particle: total cycles", q(a[:, 0]))
+    print("weight per particle: components+partitions cycles", q(a[:, 1]))
+    print("weight per particle: evaluation points", q(a[:, 2]))

@@ -26,7 +26,7 @@ if sys.argv[1] == "--build":
     for spec in sys.argv[2:]:
         name, flags = spec.split("=", 1)
         cmd = [bm.hipcc()] + bm.FLAGS + flags.split() + [os.path.join(bm.CSRC, "rfsgpu_engine.hip"), "-o", lib_of(name)]
-        procs.append((name, subprocess.Popen(cmd)))
+        procs.append((name, subprocess.Popen(cmd, stderr=subprocess.DEVNULL)))
     for name, p in procs:
         print(name, "rc", p.wait())
 else:
