@@ -308,41 +308,63 @@ __device__ double murty_partition_sum(double *C, int n, int nR, int nC, MurtyAre
   return sum;
 }
 
-// One thread per queued partition.
-__global__ __launch_bounds__(64) void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err) {
-  const int nJobs = min(*Q.count, Q.maxJobs);
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= nJobs) return;
-  const MurtyJob J = Q.jobs[j];
-  const int n = J.nR + J.nC;
-  if (n > MURTY_N) { atomicOr(err, ERRBIT_MURTY); Q.results[j] = 1.0; return; }
-  MurtyArena A;
-  murty_carve(MS.arena + (size_t)j * MS.jobBytes, A);
-  bool ok;
-  const double v = murty_partition_sum(Q.mats + (size_t)j * MURTY_MAXN * MURTY_MAXN, n, J.nR, J.nC, A, ok);
-  if (!ok) atomicOr(err, ERRBIT_MURTY);
-  Q.results[j] = v;
-}
-
-// Multiply each particle's Murty factors into its weight, in partition (slot) order.
-__global__ void murty_apply_kernel(MurtyQueue Q, double *weight, int N) {
+// One thread per queued partition; the last workgroup to finish multiplies every particle's factors into its weight,
+// in partition (slot) order.  Q.count[0] = number of jobs, Q.count[1] = finished-workgroup ticket.  With an empty queue
+// (the common case: no partition above 8) every workgroup exits at once -- one empty launch, no host round trip.
+__global__ __launch_bounds__(64) void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err, double *weight, int N) {
   const int nJobs = min(*Q.count, Q.maxJobs);
   if (nJobs == 0) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  int last = -1;
-  double w = weight[i];
-  bool any = false;
-  while (true) {
-    int best = -1, bestSlot = 1 << 30;
-    for (int j = 0; j < nJobs; j++)
-      if (Q.jobs[j].particle == i && Q.jobs[j].slot > last && Q.jobs[j].slot < bestSlot) { best = j; bestSlot = Q.jobs[j].slot; }
-    if (best < 0) break;
-    w *= Q.results[best];
-    last = bestSlot;
-    any = true;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < nJobs) {
+    const MurtyJob J = Q.jobs[j];
+    const int n = J.nR + J.nC;
+    if (n > MURTY_N) {
+      atomicOr(err, ERRBIT_MURTY);
+      Q.results[j] = 1.0;
+    } else {
+      MurtyArena A;
+      murty_carve(MS.arena + (size_t)j * MS.jobBytes, A);
+      bool ok;
+      const double v = murty_partition_sum(Q.mats + (size_t)j * MURTY_MAXN * MURTY_MAXN, n, J.nR, J.nC, A, ok);
+      if (!ok) atomicOr(err, ERRBIT_MURTY);
+      Q.results[j] = v;
+    }
   }
-  if (any) weight[i] = w;
+  __shared__ int isLast;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) isLast = (atomicAdd(Q.count + 1, 1) == (int)gridDim.x - 1);
+  __syncthreads();
+  if (!isLast) return;
+  __threadfence();
+  if (threadIdx.x == 0) Q.count[1] = 0;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    int last = -1;
+    double w = weight[i];
+    bool any = false;
+    while (true) {
+      int best = -1, bestSlot = 1 << 30;
+      for (int q = 0; q < nJobs; q++)
+        if (Q.jobs[q].particle == i && Q.jobs[q].slot > last && Q.jobs[q].slot < bestSlot) { best = q; bestSlot = Q.jobs[q].slot; }
+      if (best < 0) break;
+      w *= __builtin_nontemporal_load(&Q.results[best]);
+      last = bestSlot;
+      any = true;
+    }
+    if (any) weight[i] = w;
+  }
+}
+
+// The measurement set of a step, by value in the kernel-argument block.
+struct ZArg {
+  double v[RFSGPU_MAX_Z * 3];
+};
+// Start of a step: measurement set -> device buffer (read by every kernel of the step and by the next predict), Murty
+// job counter := 0.
+__global__ __launch_bounds__(256) void stage_step_kernel(ZArg z, double *dZ, int nDoubles, int *murtyCount) {
+  const int t = threadIdx.x;
+  if (t < nDoubles) dZ[t] = z.v[t];
+  if (t == 0 && murtyCount) murtyCount[0] = 0;
 }
 
 static inline int murty_alloc(MurtyQueue &Q, MurtyScratch &MS, int N) {
@@ -352,12 +374,12 @@ static inline int murty_alloc(MurtyQueue &Q, MurtyScratch &MS, int N) {
   Q.maxJobs = maxJobs;
   MS.jobBytes = murty_job_bytes();
   bool ok = true;
-  ok &= hipMalloc(&Q.count, sizeof(int)) == hipSuccess;
+  ok &= hipMalloc(&Q.count, 2 * sizeof(int)) == hipSuccess;
   ok &= hipMalloc(&Q.jobs, (size_t)maxJobs * sizeof(MurtyJob)) == hipSuccess;
   ok &= hipMalloc(&Q.mats, (size_t)maxJobs * MURTY_MAXN * MURTY_MAXN * sizeof(double)) == hipSuccess;
   ok &= hipMalloc(&Q.results, (size_t)maxJobs * sizeof(double)) == hipSuccess;
   ok &= hipMalloc(&MS.arena, (size_t)maxJobs * MS.jobBytes) == hipSuccess;
-  if (ok) ok &= hipMemset(Q.count, 0, sizeof(int)) == hipSuccess;
+  if (ok) ok &= hipMemset(Q.count, 0, 2 * sizeof(int)) == hipSuccess;
   return ok ? 0 : 1;
 }
 static inline void murty_free(MurtyQueue &Q, MurtyScratch &MS) {
@@ -365,10 +387,8 @@ static inline void murty_free(MurtyQueue &Q, MurtyScratch &MS) {
   Q = MurtyQueue{};
   MS = MurtyScratch{};
 }
-// The job count lives on the device; both kernels exit immediately when it is zero, so the common case
-// (no partition above 8) costs two empty launches and no host round trip.
+// The job count lives on the device: one launch, which is empty when no partition exceeded 8.
 static inline int murty_launch(MurtyQueue &Q, MurtyScratch &MS, Buffers &B, hipStream_t stream) {
-  murty_jobs_kernel<<<(Q.maxJobs + 63) / 64, 64, 0, stream>>>(Q, MS, B.err);
-  murty_apply_kernel<<<(B.N + 255) / 256, 256, 0, stream>>>(Q, B.weight, B.N);
+  murty_jobs_kernel<<<(Q.maxJobs + 63) / 64, 64, 0, stream>>>(Q, MS, B.err, B.weight, B.N);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }

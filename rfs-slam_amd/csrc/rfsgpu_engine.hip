@@ -63,10 +63,6 @@ struct rfsgpu_filter {
   long long lastKernelNs[4] = {0, 0, 0, 0};
   bool phaseOpen = false;   // update_map ran, weighting/merge/prune may follow
   bool normPending = false; // a normalize_kernel event pair has not been accumulated yet
-  double *hZ = nullptr;     // pinned staging ring for the measurement set: ZRING slots
-  hipEvent_t evZ[8] = {};   // slot k's H2D copy finished
-  bool evZPending[8] = {};
-  unsigned zSlot = 0;
   // async steps: ring of per-phase event sets, harvested at the next sync
   hipEvent_t ring[RFSGPU_ASYNC_RING][4] = {};
   int ringCount = 0;        // async steps recorded since the last harvest
@@ -234,8 +230,6 @@ int rfsgpu_create(rfsgpu_filter **out, int model, int n_particles, int device_id
   ok &= hipHostMalloc(&f->hErr, sizeof(int)) == hipSuccess;
   ok &= hipHostMalloc(&f->hJobCount, sizeof(int)) == hipSuccess;
   ok &= hipHostMalloc(&f->hSums, 2 * sizeof(double)) == hipSuccess;
-  ok &= hipHostMalloc(&f->hZ, (size_t)8 * RFSGPU_MAX_Z * 3 * sizeof(double)) == hipSuccess;
-  for (int k = 0; k < 8; k++) ok &= hipEventCreateWithFlags(&f->evZ[k], hipEventDisableTiming) == hipSuccess;
   for (int k = 0; k < RFSGPU_ASYNC_RING; k++)
     for (int e = 0; e < 4; e++) ok &= hipEventCreate(&f->ring[k][e]) == hipSuccess;
   if (!ok) return bail(RFSGPU_ERR_HIP);
@@ -284,8 +278,6 @@ void rfsgpu_destroy(rfsgpu_filter *f) {
   if (f->hErr) hipHostFree(f->hErr);
   if (f->hJobCount) hipHostFree(f->hJobCount);
   if (f->hSums) hipHostFree(f->hSums);
-  if (f->hZ) hipHostFree(f->hZ);
-  for (int k = 0; k < 8; k++) if (f->evZ[k]) hipEventDestroy(f->evZ[k]);
   for (int k = 0; k < RFSGPU_ASYNC_RING; k++)
     for (int e = 0; e < 4; e++) if (f->ring[k][e]) hipEventDestroy(f->ring[k][e]);
   for (int k = 0; k < EV_COUNT; k++) if (f->ev[k]) hipEventDestroy(f->ev[k]);
@@ -615,8 +607,7 @@ static int launch_weighting(rfsgpu_filter *f) {
   const int nZ = f->nZ, ec = eval_cap(f);
   const size_t per = weight_lds_bytes_per_wave(f->cap, ec, nZ);
   const int src = f->cur, dst = f->cur ^ 1;
-  HIPCHK(hipMemsetAsync(f->Q.count, 0, sizeof(int), f->stream));
-  int rc;
+  int rc;  // (the Murty job counter was cleared by stage_step_kernel)
   if (f->D == 3) {
     const size_t b = (size_t)(3 * RFSGPU_MAX_Z + RFSGPU_VP_MAX_SCAN) * 8 + 2 * (per + (size_t)ec * 16 * 8);
     if ((rc = set_lds(f, vp_weighting_kernel<2>, b)) != RFSGPU_OK) return rc;
@@ -682,16 +673,15 @@ static int stage_measurements(rfsgpu_filter *f, const double *z, int n_z) {
   if (n_z < 0 || n_z > RFSGPU_MAX_Z) return fail(f, RFSGPU_ERR_INVALID, "at most RFSGPU_MAX_Z measurements per update");
   if (n_z > 0 && !z) return fail(f, RFSGPU_ERR_INVALID, "null measurement buffer");
   hipSetDevice(f->device);
-  if (n_z > 0) {
-    // through a ring of pinned staging slots: the H2D copy is truly asynchronous, and a slot is only reused after the
-    // copy that read it has completed (its event), so pipelined async steps never race on the staging memory
-    const unsigned k = f->zSlot++ & 7u;
-    if (f->evZPending[k]) { HIPCHK(hipEventSynchronize(f->evZ[k])); f->evZPending[k] = false; }
-    double *slot = f->hZ + (size_t)k * RFSGPU_MAX_Z * 3;
-    memcpy(slot, z, (size_t)n_z * f->D * sizeof(double));
-    HIPCHK(hipMemcpyAsync(f->B.Z, slot, (size_t)n_z * f->D * sizeof(double), hipMemcpyHostToDevice, f->stream));
-    HIPCHK(hipEventRecord(f->evZ[k], f->stream));
-    f->evZPending[k] = true;
+  {
+    // The measurement set (<= 1.5 KB) travels in the kernel-argument block of one tiny kernel that also clears the Murty
+    // queue for this step: no staging buffer, no copy-engine hop between compute kernels, and the caller's buffer is
+    // free again when this call returns.
+    ZArg za;
+    const int nd = n_z * f->D;
+    if (nd > 0) memcpy(za.v, z, (size_t)nd * sizeof(double));
+    stage_step_kernel<<<1, 256, 0, f->stream>>>(za, f->B.Z, nd, f->Q.count);
+    HIPCHK(hipGetLastError());
   }
   f->nZ = n_z;
   return RFSGPU_OK;

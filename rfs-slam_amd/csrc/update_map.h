@@ -193,9 +193,10 @@ __global__ __launch_bounds__(WPB * 64) void phd_update_map_kernel(Buffers B, Par
           w1 = (w1 > RFS_PI) ? w1 - 2 * RFS_PI : w1;
           w1 = (w1 < -RFS_PI) ? w1 + 2 * RFS_PI : w1;
           // bitwise (non-short-circuit) logic on purpose: no branches, the 8 chains interleave
-          redo = redo | (w1 > RFS_PI) | (w1 < -RFS_PI);
-          const bool g = !((int)useR & (int)(fabs(e0) > P.kfRange)) & !((int)useB & (int)(fabs(w1) > P.kfBearing));
-          gate |= (live & g & (z0 + u < nZ)) ? (1ull << (z0 + u)) : 0ull;
+          redo = ((int)redo | (int)(w1 > RFS_PI) | (int)(w1 < -RFS_PI)) != 0;
+          const int outR = (int)useR & (int)(fabs(e0) > P.kfRange), outB = (int)useB & (int)(fabs(w1) > P.kfBearing);
+          const bool g = (outR | outB) == 0;
+          gate |= ((int)live & (int)g & (int)(z0 + u < nZ)) ? (1ull << (z0 + u)) : 0ull;
         }
         if (__ballot(redo) != 0ull) {  // some bearing difference needs more than one wrap step: exact loop form
           for (int u = 0; u < 8 && z0 + u < nZ; u++) {
