@@ -275,6 +275,9 @@ __device__ __forceinline__ void rank_sweep_f32(const float *fkeys, int *perm, in
 // Cross-wave scratch of the multi-wave kernel: a few doubles / ints after the per-particle LDS block.
 #define WEIGHT_SCRATCH_BYTES 64
 
+#ifndef WEIGHT_EVAL_GROUP
+#define WEIGHT_EVAL_GROUP 8  // evaluation points whose sums a wave keeps in registers per pass over the mixture
+#endif
 #ifndef WEIGHT_WAVES_PER_EU
 #define WEIGHT_WAVES_PER_EU 4  // <= 128 VGPRs: with 2 waves per particle all ~2000 particles of C2 are resident at once
 #endif
@@ -443,33 +446,41 @@ void phd_weight_multifeature_kernel(Buffers B, Params P, int src, int dst, int n
   const int nE = sScrI[0];
 
   DBG_TB(16, 2);
-  // ---- 3b. intensity at the evaluation points (:776-800): groups of 8 points, dealt to the waves ----
+  // ---- 3b. intensity at the evaluation points (:776-800): groups of EG points, dealt to the waves ----
+  constexpr int EG = WEIGHT_EVAL_GROUP;
   double *sumB = reinterpret_cast<double *>(s.compRows), *sumA = sumB + 64;  // [64] each (free until step 5)
-  for (int e0 = 8 * wave; e0 < nE; e0 += 8 * WPP) {
-    double accB[8], accA[8], ex[8], ey[8];
+  for (int e0 = EG * wave; e0 < nE; e0 += EG * WPP) {
+    double accB[EG], accA[EG];
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
-      accB[t] = 0.0; accA[t] = 0.0;
-      const int e = (e0 + t < nE) ? e0 + t : e0;
-      ex[t] = s.evX[e]; ey[t] = s.evY[e];
-    }
+    for (int t = 0; t < EG; t++) { accB[t] = 0.0; accA[t] = 0.0; }
+    // the evaluation points are re-read from LDS (broadcast) inside the pair loop: two LDS reads per pair cost less
+    // than the 4*EG registers that holding them would take from the accumulators' budget (128 VGPRs at 4 waves/SIMD)
+    const double *gx = s.evX + e0, *gy = s.evY + e0;
+    const int nG = (nE - e0 < EG) ? nE - e0 : EG;
     for (int m = lane; m < N; m += 64) {
       const double w = s.keys[m], wp = qWP[m], mx = qMX[m], my = qMY[m];
       const double sxx = qSXX[m], sxy = qSXY[m], syy = qSYY[m];
       double i00, i01, i10, i11, det;
       inv2(sxx, sxy, sxy, syy, i00, i01, i10, i11, det);
-      const double factor = pdf_factor2(det);
+      // 1 / sqrt((2 pi)^2 det) once per Gaussian: the pair loop multiplies instead of dividing (<= 1.5 ulp from the
+      // reference's exp(.)/factor, far inside the 1e-9 weight tolerance) -- a division per pair costs as much as the exp
+      const double rfac = 1.0 / pdf_factor2(det);
+      int opaque = 0;
+      asm volatile("" : "+v"(opaque));  // keeps the (loop-invariant) LDS reads below inside the loop
 #pragma unroll
-      for (int t = 0; t < 8; t++) {
-        const double d0 = ex[t] - mx, d1 = ey[t] - my;
-        const double t0 = d0 * i00 + d1 * i10, t1 = d0 * i01 + d1 * i11;
-        const double lik = gauss_from_md2(t0 * d0 + t1 * d1, factor);
+      for (int t = 0; t < EG; t++) {
+        const int tt = ((t < nG) ? t : 0) + opaque;
+        const double d0 = gx[tt] - mx, d1 = gy[tt] - my;
+        const double t0 = d0 * i00 + d1 * i01, t1 = d0 * i01 + d1 * i11;  // (i10 == i01: Sigma is stored symmetric)
+        const double md2 = t0 * d0 + t1 * d1;
+        double lik = (md2 > 1500.0) ? 0.0 : exp(-0.5 * md2) * rfac;  // exactly 0 beyond 1500 (gauss_from_md2)
+        lik = (lik != lik) ? 0.0 : lik;                                // NaN -> 0 (include/RandomVec.hpp:417-434)
         accB[t] += wp * lik;
         accA[t] += w * lik;
       }
     }
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
+    for (int t = 0; t < EG; t++) {
       const double b = wave_sum_dpp(accB[t]), a = wave_sum_dpp(accA[t]);
       if (lane == 0 && e0 + t < nE) { sumB[e0 + t] = b; sumA[e0 + t] = a; }
     }
