@@ -64,7 +64,9 @@ struct rfsgpu_filter {
   bool phaseOpen = false;   // update_map ran, weighting/merge/prune may follow
   bool normPending = false; // a normalize_kernel event pair has not been accumulated yet
   // async steps: ring of per-phase event sets, harvested at the next sync
-  hipEvent_t ring[RFSGPU_ASYNC_RING][4] = {};
+  hipEvent_t ring[RFSGPU_ASYNC_RING][5] = {};  // step phases: 0 start, 1 map update done, 2 weighting (+Murty) done, 3 merge done, 4 weighting kernel done
+  bool ringHasMid[RFSGPU_ASYNC_RING] = {};
+  hipEvent_t evAfterWeightKernel = nullptr;   // where launch_weighting drops its mid-phase event (async steps only)
   int ringCount = 0;        // async steps recorded since the last harvest
   double statNs[3] = {0, 0, 0};
   int statSteps = 0;
@@ -231,7 +233,7 @@ int rfsgpu_create(rfsgpu_filter **out, int model, int n_particles, int device_id
   ok &= hipHostMalloc(&f->hJobCount, sizeof(int)) == hipSuccess;
   ok &= hipHostMalloc(&f->hSums, 2 * sizeof(double)) == hipSuccess;
   for (int k = 0; k < RFSGPU_ASYNC_RING; k++)
-    for (int e = 0; e < 4; e++) ok &= hipEventCreate(&f->ring[k][e]) == hipSuccess;
+    for (int e = 0; e < 5; e++) ok &= hipEventCreate(&f->ring[k][e]) == hipSuccess;
   if (!ok) return bail(RFSGPU_ERR_HIP);
   if (murty_alloc(f->Q, f->MS, f->N) != 0) return bail(RFSGPU_ERR_HIP);
   hipMemsetAsync(B.slab[0], 0, slabBytes, f->stream);
@@ -279,7 +281,7 @@ void rfsgpu_destroy(rfsgpu_filter *f) {
   if (f->hJobCount) hipHostFree(f->hJobCount);
   if (f->hSums) hipHostFree(f->hSums);
   for (int k = 0; k < RFSGPU_ASYNC_RING; k++)
-    for (int e = 0; e < 4; e++) if (f->ring[k][e]) hipEventDestroy(f->ring[k][e]);
+    for (int e = 0; e < 5; e++) if (f->ring[k][e]) hipEventDestroy(f->ring[k][e]);
   for (int k = 0; k < EV_COUNT; k++) if (f->ev[k]) hipEventDestroy(f->ev[k]);
   if (f->ownStream) hipStreamDestroy(f->ownStream);
   delete f;
@@ -624,6 +626,7 @@ static int launch_weighting(rfsgpu_filter *f) {
   }
   HIPCHK(hipGetLastError());
   f->cur = dst;
+  if (f->evAfterWeightKernel) HIPCHK(hipEventRecord(f->evAfterWeightKernel, f->stream));
   // Murty-200 for partitions with nR + nC > 8: runs only when the queue is non-empty (device-side early exit)
   rc = murty_launch(f->Q, f->MS, f->B, f->stream);
   if (rc != 0) return fail(f, RFSGPU_ERR_HIP, "murty launch failed");
@@ -779,6 +782,10 @@ static void harvest_async(rfsgpu_filter *f) {
     long long ns[3] = {0, 0, 0};
     accumulate(e[0], e[1], f->timing.mapUpdate_wall, &ns[0]);
     accumulate(e[1], e[2], f->timing.particleWeighting_wall, &ns[1]);
+    if (f->ringHasMid[k]) {  // kernel statistics: the weighting kernel alone, without the (usually empty) Murty launch
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, e[1], e[4]) == hipSuccess) ns[1] = (long long)(ms * 1.0e6);
+    }
     accumulate(e[2], e[3], f->timing.mapMerge_wall, &ns[2]);
     for (int q = 0; q < 3; q++) { f->statNs[q] += (double)ns[q]; f->lastKernelNs[q] = ns[q]; }
     f->statSteps++;
@@ -802,8 +809,13 @@ int rfsgpu_update_async(rfsgpu_filter *f, const double *z, int n_z) {
   HIPCHK(hipEventRecord(e[0], f->stream));
   if ((rc = launch_update_map(f)) != RFSGPU_OK) return rc;
   HIPCHK(hipEventRecord(e[1], f->stream));
+  f->ringHasMid[f->ringCount] = false;
   if (!f->cfg.useClusterProcess) {
-    if ((rc = launch_weighting(f)) != RFSGPU_OK) return rc;
+    f->evAfterWeightKernel = (f->D == 2) ? e[4] : nullptr;
+    rc = launch_weighting(f);
+    f->ringHasMid[f->ringCount] = f->evAfterWeightKernel != nullptr;
+    f->evAfterWeightKernel = nullptr;
+    if (rc != RFSGPU_OK) return rc;
   }
   HIPCHK(hipEventRecord(e[2], f->stream));
   if ((rc = launch_merge_prune(f)) != RFSGPU_OK) return rc;
