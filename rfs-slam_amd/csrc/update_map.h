@@ -106,8 +106,11 @@ __device__ __forceinline__ double pair_value(const Params &P, const LmKF &k, dou
 //    in landmark order, i.e. in the reference's summation order (clutter first, then m ascending).
 //  phase 2, dense over the survivor list (all 64 lanes busy): normalise, recompute the landmark's KF quantities, emit.
 //  phase 3: missed-detection weights (+ near-limit heuristic from the landmark's list segment), unused mask.
+#ifndef UPDMAP_WAVES_PER_EU
+#define UPDMAP_WAVES_PER_EU 2
+#endif
 template <int WPB>
-__global__ __launch_bounds__(WPB * 64) void phd_update_map_kernel(Buffers B, Params P, int cur, int nZ, const double *__restrict__ Zg) {
+__global__ __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(UPDMAP_WAVES_PER_EU))) void phd_update_map_kernel(Buffers B, Params P, int cur, int nZ, const double *__restrict__ Zg) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   // The measurement set is wave-uniform and read-only: it is read through the scalar cache (s_load into SGPRs, which
   // VALU instructions take as operands directly) where the index is uniform, and from an LDS copy where lanes index
