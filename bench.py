@@ -108,10 +108,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the device path)")
+    # Test hook (tests/test_gpu_parity.py): RFS_BENCH_SHARE_GPU=1 lets several ranks share one GPU over gloo so that the
+    # N>1 code path runs on a 1-GPU box; the judged runs use one GPU per rank over RCCL ("nccl").
+    share = os.environ.get("RFS_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if share else "nccl", rank=rank, world_size=world)
 
     from __graft_entry__ import load_package
     pkg = load_package()

@@ -497,6 +497,29 @@ def _full_size_check(pkg, ob, sc, scen, cap, subset=24, check_murty=False):
     dev.close()
 
 
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N>1 path (rank-local shards, broadcast measurement set, all-reduce of the weight sums on the engine's
+    stream, max-over-ranks timing, aggregate value) with two ranks sharing this box's GPU over gloo."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RFS_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--particles", "256", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=root, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                      # rank 0 prints exactly one JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 6 and d["warmup"] == 2
+    assert d["config"]["particles_total"] == 512
+    assert abs(d["value"] - 2 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-2 * d["value"]
+    assert d["roofline"]["frac"] > 0
+
+
 def test_full_size_c2(pkg, ob, sc):
     """configs[1]: 2000 particles x 200 GM landmarks x 30 measurements."""
     _full_size_check(pkg, ob, sc, sc.make_scenario(2000, 200, 30, seed=12345), cap=384)
