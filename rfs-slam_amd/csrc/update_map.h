@@ -106,6 +106,9 @@ __device__ __forceinline__ double pair_value(const Params &P, const LmKF &k, dou
 //    in landmark order, i.e. in the reference's summation order (clutter first, then m ascending).
 //  phase 2, dense over the survivor list (all 64 lanes busy): normalise, recompute the landmark's KF quantities, emit.
 //  phase 3: missed-detection weights (+ near-limit heuristic from the landmark's list segment), unused mask.
+#ifndef UPDMAP_GATE_BATCH
+#define UPDMAP_GATE_BATCH 8  // measurements whose gates are evaluated per trip (scalar loads up front, branch-free)
+#endif
 #ifndef UPDMAP_WAVES_PER_EU
 #define UPDMAP_WAVES_PER_EU 2
 #endif
@@ -180,17 +183,18 @@ __global__ __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(UPDMAP
       // addresses), the gate arithmetic is branch-free; the rare bearing difference beyond one wrap is redone exactly.
       const bool live = fov && k.ok;
       const bool useR = P.kfRange > 0, useB = P.kfBearing > 0;
-      for (int z0 = 0; z0 < nZ; z0 += 8) {
-        double zr[8], zb[8];
+      constexpr int GB = UPDMAP_GATE_BATCH;
+      for (int z0 = 0; z0 < nZ; z0 += GB) {
+        double zr[GB], zb[GB];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < GB; u++) {
           const int zz = (z0 + u < nZ) ? z0 + u : nZ - 1;
           zr[u] = Zg[2 * zz];
           zb[u] = Zg[2 * zz + 1];
         }
         bool redo = false;
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < GB; u++) {
           const double e0 = zr[u] - k.zx0;
           double w1 = zb[u] - k.zx1;
           w1 = (w1 > RFS_PI) ? w1 - 2 * RFS_PI : w1;
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(UPDMAP
           gate |= ((int)live & (int)g & (int)(z0 + u < nZ)) ? (1ull << (z0 + u)) : 0ull;
         }
         if (__ballot(redo) != 0ull) {  // some bearing difference needs more than one wrap step: exact loop form
-          for (int u = 0; u < 8 && z0 + u < nZ; u++) {
+          for (int u = 0; u < GB && z0 + u < nZ; u++) {
             const bool g = pair_gate(P, k, zr[u], zb[u]);
             const unsigned long long bit = 1ull << (z0 + u);
             gate = (live && g) ? (gate | bit) : (gate & ~bit);

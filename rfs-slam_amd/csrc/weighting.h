@@ -144,8 +144,15 @@ __device__ double enumerate_partition(const WeightLDS &s, int nZ, unsigned long 
 // points, columns = measurements) of the likelihood table s.L (nE x nZ, already gated, incl. Pd), the reference's
 // zero-partition merge + partition-indexing quirk, one lane per partition for the <= 8 enumeration, Murty jobs for the
 // rest.  Returns the product over the visited partitions (RBPHDFilter.hpp:865-990), before the clutter-integral division.
-__device__ double rfs_partitions_wave(const WeightLDS &s, int nE, int nZ, double clutter, int lane, int particle, MurtyQueue Q, int *err) {
+__device__ double rfs_partitions_wave(const WeightLDS &s, int nE, int nZ, double clutter, int lane, int particle, MurtyQueue Q, int *err,
+                                      long long *dbgp = nullptr) {
   // ---- 5. connected components of the bipartite graph (rows = eval points, cols = measurements) ----
+#ifdef RFS_PROFILE
+#define PART_T(k) do { if (dbgp && particle == 7 && lane == 0) dbgp[k] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define PART_T(k) do { } while (0)
+#endif
+  PART_T(27);
   unsigned long long myRow = 0, myCol = 0;
   if (lane < nE) for (int n = 0; n < nZ; n++) if (s.L[lane * nZ + n] != 0.0) myRow |= 1ull << n;
   if (lane < nZ) for (int e = 0; e < nE; e++) if (s.L[e * nZ + lane] != 0.0) myCol |= 1ull << e;
@@ -168,6 +175,7 @@ __device__ double rfs_partitions_wave(const WeightLDS &s, int nE, int nZ, double
     wave_sync();
     if (__ballot(ch) == 0ull) break;
   }
+  PART_T(28);
   // the log table replaces L from here on (zero partition needs no L; :907-917)
   for (int idx = lane; idx < nE * nZ; idx += 64) {
     double v = s.L[idx];
@@ -200,6 +208,7 @@ __device__ double rfs_partitions_wave(const WeightLDS &s, int nE, int nZ, double
   const unsigned long long mergedRows = wave_or_u64(zr), mergedCols = wave_or_u64(zc);
   const int nPartitions = ncc - (nZero > 0 ? nZero - 1 : 0);  // caller still indexes components [0, nPartitions) -- quirk kept
 
+  PART_T(29);
   // ---- 6. one lane per partition ----
   const double logc = log(clutter);
   for (int p = lane; p < nPartitions; p += 64) {
@@ -239,6 +248,10 @@ __device__ double rfs_partitions_wave(const WeightLDS &s, int nE, int nZ, double
     s.partLik[p] = pl;
   }
   wave_sync();
+  PART_T(30);
+#ifdef RFS_PROFILE
+  if (dbgp && particle == 7 && lane == 0) dbgp[31] = nPartitions;
+#endif
   double l = 1.0;
   for (int p = 0; p < nPartitions; p++) l *= s.partLik[p];
   return l;
@@ -524,7 +537,11 @@ void phd_weight_multifeature_kernel(Buffers B, Params P, int src, int dst, int n
   const long long dbgT4 = (long long)__builtin_readcyclecounter();
 #endif
   // ---- 5./6. partition the table, sum the assignments of every partition (shared with the 3-D kernel) ----
+#ifdef RFS_PROFILE
+  const double l = rfs_partitions_wave(s, nE, nZ, P.clutter, lane, i, Q, B.err, B.dbg);
+#else
   const double l = rfs_partitions_wave(s, nE, nZ, P.clutter, lane, i, Q, B.err);
+#endif
   const double sensingArea = 2 * RFS_PI * (P.rmax - P.rmin);
   const double ml = l / (P.clutter * sensingArea);  // clutterIntensityIntegral (src/MeasurementModel_RngBrg.cpp:175-178)
 
