@@ -530,6 +530,47 @@ def test_full_size_c3_shard(pkg, ob, sc):
     _full_size_check(pkg, ob, sc, sc.make_scenario(2500, 500, 30, seed=777, rmax=5.0), cap=704)
 
 
+def test_full_size_c4_victoria_park(pkg, ob, sc):
+    """configs[3]: Victoria Park model (3-D landmarks, scan-based Pd, artificial-clutter parameters), 5000 particles.
+    Two predict/update/normalise cycles at full size on the device; size-independent properties on every particle and
+    oracle parity on a subset of the particles (each particle's outputs depend on its own inputs only).  (The synthetic
+    state spreads the raw weights over > 30 decades, so a third cycle already hits 0 / inf in the reference arithmetic.)"""
+    n, subset = 5000, 24
+    scen = sc.make_vp_scenario(n, 40, 12, seed=4321, scan="ragged")
+    dev = pkg.RBPHDFilter(n, device_id=0, gm_capacity=192, model=pkg.capi.MODEL_VICTORIAPARK_3D)
+    sc.load_scenario(dev, scen)
+    idx = np.linspace(0, n - 1, subset).astype(int)
+    sub = dict(scen)
+    sub.update(n=subset, poses=scen["poses"][idx], w=scen["w"][idx], mean=scen["mean"][idx], cov=scen["cov"][idx],
+               particle_w=scen["particle_w"][idx])
+    if np.ndim(scen["pose_cov"]) == 3:
+        sub["pose_cov"] = scen["pose_cov"][idx]
+    orc = ob.OracleFilter(subset, stable_sort=True, model=pkg.capi.MODEL_VICTORIAPARK_3D)
+    sc.load_scenario(orc, sub)
+    rng = np.random.default_rng(9)
+    for step in range(2):
+        Z = scen["Z"] + rng.normal(0, 1e-3, scen["Z"].shape)
+        for f in (dev, orc):
+            f.predict_map(True)
+            f.update(Z)
+        wd, wo = dev.get_weights(), orc.get_weights()
+        assert np.all(np.isfinite(wd)) and np.all(wd >= 0) and (wd > 0).mean() > 0.9
+        np.testing.assert_allclose(wd[idx], wo, rtol=1e-8, atol=1e-300)
+        s = dev.weight_sums()
+        np.testing.assert_allclose(s[0], wd.sum(), rtol=1e-12)
+        dev.normalize_weights(s[0])
+        orc.set_weights(wo / wd.sum())            # same global normaliser as the full-size filter
+        np.testing.assert_allclose(dev.get_weights().sum(), 1.0, rtol=1e-12)
+        sizes = dev.gm_sizes()
+        assert sizes.min() > 0 and sizes.max() <= 192
+        P = scen["params"]
+        for k, i in enumerate(idx):
+            g = dev.export_gm(int(i))
+            assert np.all(g[0] >= P["prune_thr"]) and np.all(np.diff(g[0]) <= 0)
+            sc.assert_gm_close(g, orc.export_gm(k), GM_RTOL, GM_ATOL, ordered=True)
+    dev.close()
+
+
 def test_full_size_c5_murty_stress(pkg, ob, sc):
     """configs[4]: 1000 particles x 50 measurements, 40 evaluation points, 10-sigma weighting gate -> Murty-200 partitions."""
     scen = sc.make_scenario(1000, 200, 50, seed=555, n_clutter=10, n_eval=40, weighting_md=10.0, weights=(0.8, 1.0))
