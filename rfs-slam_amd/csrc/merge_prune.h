@@ -86,13 +86,11 @@ __device__ __forceinline__ bool merge_pair_passes(double e0, double e1, double a
 #define MERGE_WAVES_PER_EU 4  // 128 VGPRs: with 2 waves per particle all ~2000 particles of C2 are resident at once
 #endif
 template <int WPP, bool FUSE_PRUNE>
-__global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(MERGE_WAVES_PER_EU))) void gm_merge_kernel(Buffers B, Params P, int cur, int dst) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
+__device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params &P, const int cur, const int dst, const int i, const int tid,
+                                                  unsigned char *smem_raw) {
   constexpr int NT = WPP * 64;
-  const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
-  const int i = blockIdx.x;
   const int cap = B.cap;
   unsigned char *wbase = smem_raw;
   float *sRed = reinterpret_cast<float *>(smem_raw + merge_lds_bytes_per_wave(cap));  // [WPP][8] cross-wave reduction scratch
@@ -662,6 +660,12 @@ __global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(MERGE_
     d[0] = (long long)__builtin_readcyclecounter() - dbgT0; d[1] = dbgT3 - dbgT2; d[2] = dbgFallbacks | (dbgSlackN << 8) | (dbgUnlistN << 16); atomicAdd((unsigned long long *)&d[3], (unsigned long long)N | ((unsigned long long)min(dbgPairs, 65535u) << 16));
   }
 #endif
+}
+
+template <int WPP, bool FUSE_PRUNE>
+__global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(MERGE_WAVES_PER_EU))) void gm_merge_kernel(Buffers B, Params P, int cur, int dst) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  gm_merge_particle<WPP, FUSE_PRUNE>(B, P, cur, dst, (int)blockIdx.x, (int)threadIdx.x, smem_raw);
 }
 
 // LDS per wave: keys[cap] doubles

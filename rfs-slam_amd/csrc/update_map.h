@@ -112,22 +112,12 @@ __device__ __forceinline__ double pair_value(const Params &P, const LmKF &k, dou
 #ifndef UPDMAP_WAVES_PER_EU
 #define UPDMAP_WAVES_PER_EU 2
 #endif
-template <int WPB>
-__global__ __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(UPDMAP_WAVES_PER_EU))) void phd_update_map_kernel(Buffers B, Params P, int cur, int nZ, const double *__restrict__ Zg) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  // The measurement set is wave-uniform and read-only: it is read through the scalar cache (s_load into SGPRs, which
-  // VALU instructions take as operands directly) where the index is uniform, and from an LDS copy where lanes index
-  // it independently (phases 1b/2).
-  double *sZ = reinterpret_cast<double *>(smem_raw);  // [2*MAX_Z], block-shared
-  const int wave = threadIdx.x >> 6;
-  const int lane = threadIdx.x & 63;
-  for (int t = threadIdx.x; t < 2 * nZ; t += WPB * 64) sZ[t] = Zg[t];
-  __syncthreads();
-
-  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
-  if (i >= B.N) return;
+// One particle, one wavefront: `lane` of the calling wave, `sZ` the workgroup's LDS copy of the measurement set, `wb` this
+// wave's LDS block (update_map_lds_bytes_per_wave).  Shared by the stand-alone kernel and the fused step kernel.
+__device__ __forceinline__ void phd_update_map_particle(const Buffers &B, const Params &P, const int cur, const int nZ,
+                                                        const double *__restrict__ Zg, const int i, const int lane, const double *sZ,
+                                                        unsigned char *wb) {
   const int cap = B.cap;
-  unsigned char *wb = smem_raw + 2 * RFSGPU_MAX_Z * 8 + (size_t)wave * update_map_lds_bytes_per_wave(cap);
   double *sV = reinterpret_cast<double *>(wb);                 // [cap] survivor values Pd*w*lik
   double *sCol = sV + cap;                                      // [MAX_Z] final normalisers
   unsigned *sMZ = reinterpret_cast<unsigned *>(sCol + RFSGPU_MAX_Z);  // [cap] (m << 8) | z
@@ -338,4 +328,20 @@ __global__ __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(UPDMAP
     for (int z = 0; z < nZ; z++) prod *= readlane_f64(cs, z);
     if (lane == 0) B.weight[i] = exp(s) * prod * B.weight[i];
   }
+}
+
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(UPDMAP_WAVES_PER_EU))) void phd_update_map_kernel(Buffers B, Params P, int cur, int nZ, const double *__restrict__ Zg) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  // The measurement set is wave-uniform and read-only: it is read through the scalar cache (s_load into SGPRs, which
+  // VALU instructions take as operands directly) where the index is uniform, and from an LDS copy where lanes index
+  // it independently (phases 1b/2).
+  double *sZ = reinterpret_cast<double *>(smem_raw);  // [2*MAX_Z], block-shared
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  for (int t = threadIdx.x; t < 2 * nZ; t += WPB * 64) sZ[t] = Zg[t];
+  __syncthreads();
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
+  if (i >= B.N) return;
+  phd_update_map_particle(B, P, cur, nZ, Zg, i, lane, sZ, smem_raw + 2 * RFSGPU_MAX_Z * 8 + (size_t)wave * update_map_lds_bytes_per_wave(B.cap));
 }

@@ -298,15 +298,12 @@ __device__ __forceinline__ void rank_sweep_f32(const float *fkeys, int *perm, in
 // all threads; the intensity sums split the evaluation points between the waves (groups of 8); the serial steps
 // (evaluation-point selection, components, partition enumeration) run on wave 0 while wave 1 takes the weight sums.
 template <int WPP>
-__global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(WPP == 1 ? 2 : WEIGHT_WAVES_PER_EU)))
-void phd_weight_multifeature_kernel(Buffers B, Params P, int src, int dst, int nZ, int evalCap, MurtyQueue Q) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
+__device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Params &P, const int src, const int dst, const int nZ, const int evalCap,
+                                                    const MurtyQueue &Q, const int i, const int tid, unsigned char *smem_raw) {
   constexpr int NT = WPP * 64;
   double *sZ = reinterpret_cast<double *>(smem_raw);
-  const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
-  const int i = blockIdx.x;
   auto block_sync = [&]() { if (WPP == 1) wave_sync(); else __syncthreads(); };
   for (int t = tid; t < 2 * nZ; t += NT) sZ[t] = B.Z[t];
   WeightLDS s;
@@ -560,4 +557,11 @@ void phd_weight_multifeature_kernel(Buffers B, Params P, int src, int dst, int n
     d[0] = t - dbgT0; d[1] = t - dbgT4; d[2] = nE; d[3] = N;
   }
 #endif
+}
+
+template <int WPP>
+__global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(WPP == 1 ? 2 : WEIGHT_WAVES_PER_EU)))
+void phd_weight_multifeature_kernel(Buffers B, Params P, int src, int dst, int nZ, int evalCap, MurtyQueue Q) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  phd_weight_particle<WPP>(B, P, src, dst, nZ, evalCap, Q, (int)blockIdx.x, (int)threadIdx.x, smem_raw);
 }
