@@ -81,7 +81,7 @@ def pmc_traffic(kernel_name):
     except Exception:
         return None
     alias = {"phd_update_map": "phd_update_map_kernel", "phd_weight_multifeature": "phd_weight_multifeature_kernel",
-             "gm_merge_prune": "gm_merge_kernel"}[kernel_name]
+             "gm_merge_prune": "gm_merge_kernel", "phd_step_fused": "phd_step_fused_kernel"}[kernel_name]
     best = None
     for k, v in d.items():
         if k.startswith(alias) and (best is None or v["calls"] > best["calls"]):
@@ -185,14 +185,40 @@ def main():
     w = f.get_weights()
     assert np.all(np.isfinite(w)) and abs(w.sum() * world - 1.0) < 1e-6 or world > 1, "weights did not normalise"
 
+    # rfsgpu_update_async runs the step as ONE kernel (step_fused.h) unless RFSGPU_FUSED_STEP=0: kernel_time_stats then
+    # reports [fused step, 0, 0].  The per-phase breakdown (and the likelihood-sweep rate the north star asks for) comes
+    # from the three stand-alone kernels, measured with the same HIP events in an untimed pass after the region.
+    fused = kern_ms[1] == 0.0 and kern_ms[2] == 0.0
+    phase_ms = kern_ms
+    if fused:
+        acc = np.zeros(3)
+        reps = 20
+        for _ in range(reps):
+            f.restore_state()
+            f.update(Z)
+            acc += np.array(f.last_kernel_ns()[:3], dtype=np.float64)
+        phase_ms = acc / reps / 1e6
+
     if rank == 0:
         per_kernel = {}
         for k, name in enumerate(KERNELS):
-            gbs = bytes_k[name] / (kern_ms[k] * 1e-3) / 1e9 if kern_ms[k] > 0 else 0.0
-            per_kernel[name] = dict(ms=round(float(kern_ms[k]), 5), algorithmic_bytes=int(bytes_k[name]), achieved_GBps=round(gbs, 2))
-        dom = int(np.argmax(kern_ms))
-        dname = KERNELS[dom]
-        achieved = per_kernel[dname]["achieved_GBps"]
+            gbs = bytes_k[name] / (phase_ms[k] * 1e-3) / 1e9 if phase_ms[k] > 0 else 0.0
+            per_kernel[name] = dict(ms=round(float(phase_ms[k]), 5), algorithmic_bytes=int(bytes_k[name]), achieved_GBps=round(gbs, 2))
+        if fused:
+            tot_bytes = int(sum(bytes_k[name] for name in KERNELS))
+            dname = "phd_step_fused"
+            achieved = round(tot_bytes / (kern_ms[0] * 1e-3) / 1e9, 2)
+            fused_entry = dict(ms=round(float(kern_ms[0]), 5), algorithmic_bytes=tot_bytes, achieved_GBps=achieved,
+                               note="update_map + weighting + merge/prune of a particle in one workgroup, one launch per step; "
+                                    "measured inside the timed region")
+            per_kernel = {"phd_step_fused": fused_entry,
+                          "standalone_phases_untimed_pass": per_kernel}
+            sweep = per_kernel["standalone_phases_untimed_pass"]["phd_update_map"]
+        else:
+            dom = int(np.argmax(kern_ms))
+            dname = KERNELS[dom]
+            achieved = per_kernel[dname]["achieved_GBps"]
+            sweep = per_kernel["phd_update_map"]
         out = {
             "metric": "PHD filter-update steps/sec",
             # whole-job aggregate: every rank completes `steps` updates of its own 2000-particle shard in `dt`
@@ -217,7 +243,7 @@ def main():
                 "parallelism": f"particle-sharded x{world}, RCCL all-reduce of 2 doubles/step",
                 "gm_after_update": nAfter // n_local, "gm_after_prune": nKept // n_local,
                 "kernels": per_kernel,
-                "likelihood_sweep": per_kernel["phd_update_map"],
+                "likelihood_sweep": sweep,
             },
             "roofline": {"bound": "hbm", "kernel": dname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(dname),

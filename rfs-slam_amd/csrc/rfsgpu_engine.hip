@@ -5,6 +5,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -14,6 +15,7 @@
 #include "update_map.h"
 #include "weighting.h"
 #include "merge_prune.h"
+#include "step_fused.h"
 #include "murty.h"
 #include "vp.h"
 #include "birth.h"
@@ -66,6 +68,8 @@ struct rfsgpu_filter {
   // async steps: ring of per-phase event sets, harvested at the next sync
   hipEvent_t ring[RFSGPU_ASYNC_RING][5] = {};  // step phases: 0 start, 1 map update done, 2 weighting (+Murty) done, 3 merge done, 4 weighting kernel done
   bool ringHasMid[RFSGPU_ASYNC_RING] = {};
+  bool ringFused[RFSGPU_ASYNC_RING] = {};   // the step ran as ONE kernel: only events 0 and 3 were recorded
+  bool fuseSteps = true;    // rfsgpu_update_async uses phd_step_fused_kernel (2-D model); RFSGPU_FUSED_STEP=0 turns it off
   hipEvent_t evAfterWeightKernel = nullptr;   // where launch_weighting drops its mid-phase event (async steps only)
   int ringCount = 0;        // async steps recorded since the last harvest
   double statNs[3] = {0, 0, 0};
@@ -194,6 +198,7 @@ int rfsgpu_create(rfsgpu_filter **out, int model, int n_particles, int device_id
   f->model = model;
   f->D = (model == RFSGPU_MODEL_VICTORIAPARK_3D) ? 3 : 2;
   f->cap = ((gm_capacity + 63) / 64) * 64;
+  { const char *e = getenv("RFSGPU_FUSED_STEP"); if (e && e[0] == '0') f->fuseSteps = false; }
   if (f->cap > 2048) { delete f; return RFSGPU_ERR_INVALID; }
   auto bail = [&](int code) { rfsgpu_destroy(f); return code; };
   if (hipSetDevice(device_id) != hipSuccess) return bail(RFSGPU_ERR_NO_DEVICE);
@@ -780,6 +785,12 @@ static void harvest_async(rfsgpu_filter *f) {
   for (int k = 0; k < n; k++) {
     hipEvent_t *e = f->ring[k];
     long long ns[3] = {0, 0, 0};
+    if (f->ringFused[k]) {  // one kernel for the whole step: booked under mapUpdate, reported as kernel 0
+      accumulate(e[0], e[3], f->timing.mapUpdate_wall, &ns[0]);
+      for (int q = 0; q < 3; q++) { f->statNs[q] += (double)ns[q]; f->lastKernelNs[q] = ns[q]; }
+      f->statSteps++;
+      continue;
+    }
     accumulate(e[0], e[1], f->timing.mapUpdate_wall, &ns[0]);
     accumulate(e[1], e[2], f->timing.particleWeighting_wall, &ns[1]);
     if (f->ringHasMid[k]) {  // kernel statistics: the weighting kernel alone, without the (usually empty) Murty launch
@@ -807,6 +818,25 @@ int rfsgpu_update_async(rfsgpu_filter *f, const double *z, int n_z) {
   if (rc != RFSGPU_OK) return rc;
   hipEvent_t *e = f->ring[f->ringCount];
   HIPCHK(hipEventRecord(e[0], f->stream));
+  f->ringFused[f->ringCount] = false;
+  if (f->D == 2 && f->fuseSteps) {
+    // the whole step in one launch (step_fused.h); Murty partitions, if any, follow as usual
+    const int ec = eval_cap(f), useW = f->cfg.useClusterProcess ? 0 : 1;
+    const size_t b = step_fused_lds_bytes(f->cap, ec, f->nZ, STEP_WPP);
+    if ((rc = set_lds(f, phd_step_fused_kernel<STEP_WPP>, b)) != RFSGPU_OK) return rc;
+    phd_step_fused_kernel<STEP_WPP><<<f->N, STEP_WPP * 64, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q);
+    HIPCHK(hipGetLastError());
+    if (useW) {
+      if (murty_launch(f->Q, f->MS, f->B, f->stream) != 0) return fail(f, RFSGPU_ERR_HIP, "murty launch failed");
+    } else {
+      f->cur ^= 1;  // no sort pass: the merge wrote the other slab
+    }
+    HIPCHK(hipEventRecord(e[3], f->stream));
+    f->ringFused[f->ringCount] = true;
+    f->ringCount++;
+    f->timing.mapUpdate_cpu += now_ns() - t0;
+    return RFSGPU_OK;
+  }
   if ((rc = launch_update_map(f)) != RFSGPU_OK) return rc;
   HIPCHK(hipEventRecord(e[1], f->stream));
   f->ringHasMid[f->ringCount] = false;

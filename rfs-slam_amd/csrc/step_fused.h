@@ -1,0 +1,59 @@
+// step_fused.h -- one launch for the whole map update of a step (RBPHDFilter::update body, include/RBPHDFilter.hpp:469-520):
+// a workgroup of STEP_WPP waves owns one particle and takes it through updateMap -> importanceWeighting -> merge -> prune.
+//
+// Why: as three kernels, every phase ends with a tail in which the device waits for its slowest particles (a phase lasts
+// as long as its slowest particle, about twice the median at C2), and the slabs make a round trip through L2/HBM between
+// launches.  Fused, workgroups drift apart -- some are in the latency-bound map update while others are in the
+// ALU-heavy weighting -- so the SIMDs see a mix of work, a particle that is slow in one phase is usually not slow in
+// the next, and each particle's mixture is still warm in L2 when its next phase reads it.
+//
+// The phases are the per-particle device functions of the stand-alone kernels, unchanged (update_map.h, weighting.h,
+// merge_prune.h); they share one LDS allocation, separated by workgroup barriers.  The map update is single-wave code:
+// wave 0 runs it while the other waves of the workgroup wait at the barrier.
+#pragma once
+#include "common.h"
+#include "update_map.h"
+#include "weighting.h"
+#include "merge_prune.h"
+
+#ifndef STEP_WPP
+#define STEP_WPP 2
+#endif
+#ifndef STEP_WAVES_PER_EU
+#define STEP_WAVES_PER_EU 4  // <= 128 VGPRs: 8 workgroups of 2 waves per CU, i.e. all 2000 particles of C2 resident at once
+#endif
+
+__host__ __device__ inline size_t step_fused_lds_bytes(int cap, int evalCap, int nZ, int wpp) {
+  size_t a = (size_t)(2 * RFSGPU_MAX_Z * 8) + update_map_lds_bytes_per_wave(cap);
+  const size_t b = (size_t)(2 * RFSGPU_MAX_Z * 8) + weight_lds_bytes_per_wave(cap, evalCap, nZ) + WEIGHT_SCRATCH_BYTES;
+  const size_t c = merge_lds_bytes_per_block(cap, wpp);
+  if (b > a) a = b;
+  if (c > a) a = c;
+  return (a + 15) & ~(size_t)15;
+}
+
+// useWeighting == 0: SC-PHD (useClusterProcess_): the particle weight comes out of the map update, the mixture is not
+// sorted, merge works on the slab the update wrote.
+template <int WPP>
+__global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(STEP_WAVES_PER_EU)))
+void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, int useWeighting, MurtyQueue Q) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int i = blockIdx.x;
+  double *sZ = reinterpret_cast<double *>(smem_raw);
+  for (int t = tid; t < 2 * nZ; t += WPP * 64) sZ[t] = B.Z[t];
+  __syncthreads();
+  if (wave == 0) phd_update_map_particle(B, P, cur, nZ, B.Z, i, lane, sZ, smem_raw + 2 * RFSGPU_MAX_Z * 8);
+  __threadfence_block();  // the slab / count written by wave 0 -> the whole workgroup
+  __syncthreads();
+  int mergeSrc = cur;
+  if (useWeighting) {
+    phd_weight_particle<WPP>(B, P, cur, cur ^ 1, nZ, evalCap, Q, i, tid, smem_raw);
+    __threadfence_block();
+    __syncthreads();
+    mergeSrc = cur ^ 1;
+  }
+  gm_merge_particle<WPP, true>(B, P, mergeSrc, mergeSrc ^ 1, i, tid, smem_raw);
+}

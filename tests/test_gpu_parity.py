@@ -92,6 +92,36 @@ def test_update_fused_call_and_normalise(pkg, ob, sc, kw):
     assert abs(dev.get_weights().sum() - 1) < 1e-12
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("kw", SCENARIOS[:5] + [dict(n_particles=9, n_landmarks=40, n_z=7, seed=8, use_cluster=1)])
+def test_update_async_matches_oracle(pkg, ob, sc, kw, fused, monkeypatch):
+    """rfsgpu_update_async (stream-ordered steps; one fused kernel per step when RFSGPU_FUSED_STEP != 0, the three
+    stand-alone kernels otherwise): same results as the oracle's update, and bit-identical to the synchronous call."""
+    monkeypatch.setenv("RFSGPU_FUSED_STEP", fused)
+    scen = sc.make_scenario(**kw)
+    dev, orc = make_pair(pkg, ob, sc, scen)
+    ref, _ = make_pair(pkg, ob, sc, scen)
+    dev.update_async(scen["Z"])
+    dev.synchronize()
+    orc.update(scen["Z"])
+    ref.update(scen["Z"])
+    compare_weights(dev, orc)
+    compare_maps(sc, dev, orc, scen["n"], ordered=True)
+    assert np.array_equal(dev.get_weights(), ref.get_weights())
+    for i in range(scen["n"]):
+        for a, b in zip(dev.export_gm(i), ref.export_gm(i)):
+            assert np.array_equal(a, b)
+        assert np.array_equal(dev.get_unused(i), orc.get_unused(i))
+    # a second step on the evolved state (slab parity after a fused step)
+    for f in (dev, orc):
+        f.predict_map(True)
+    dev.update_async(scen["Z"])
+    dev.synchronize()
+    orc.update(scen["Z"])
+    compare_weights(dev, orc)
+    compare_maps(sc, dev, orc, scen["n"], ordered=True)
+
+
 def test_cluster_process_weighting(pkg, ob, sc):
     scen = sc.make_scenario(32, 90, 20, seed=11, use_cluster=True)
     dev, orc = make_pair(pkg, ob, sc, scen)

@@ -38,6 +38,9 @@ else:
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
         try:
             d = json.loads(r.stdout.strip().splitlines()[-1])
-            print(name, d["value"], d["ms_per_step"], {k: v["ms"] for k, v in d["config"]["kernels"].items()}, flush=True)
+            ks = d["config"]["kernels"]
+            flat = {k: v["ms"] for k, v in ks.items() if "ms" in v}
+            flat.update({k: v["ms"] for k, v in ks.get("standalone_phases_untimed_pass", {}).items()})
+            print(name, d["value"], d["ms_per_step"], flat, flush=True)
         except Exception:
             print(name, "FAILED", r.stdout[-300:], r.stderr[-600:], flush=True)
