@@ -19,6 +19,9 @@
 #ifndef STEP_WPP
 #define STEP_WPP 2
 #endif
+#ifndef STEP_GATE_BATCH
+#define STEP_GATE_BATCH 4
+#endif
 #ifndef STEP_WAVES_PER_EU
 #define STEP_WAVES_PER_EU 4  // <= 128 VGPRs: 8 workgroups of 2 waves per CU, i.e. all 2000 particles of C2 resident at once
 #endif
@@ -45,7 +48,7 @@ void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, in
   double *sZ = reinterpret_cast<double *>(smem_raw);
   for (int t = tid; t < 2 * nZ; t += WPP * 64) sZ[t] = B.Z[t];
   __syncthreads();
-  if (wave == 0) phd_update_map_particle(B, P, cur, nZ, B.Z, i, lane, sZ, smem_raw + 2 * RFSGPU_MAX_Z * 8);
+  if (wave == 0) phd_update_map_particle<STEP_GATE_BATCH>(B, P, cur, nZ, B.Z, i, lane, sZ, smem_raw + 2 * RFSGPU_MAX_Z * 8);
   __threadfence_block();  // the slab / count written by wave 0 -> the whole workgroup
   __syncthreads();
   int mergeSrc = cur;

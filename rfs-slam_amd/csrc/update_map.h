@@ -107,13 +107,15 @@ __device__ __forceinline__ double pair_value(const Params &P, const LmKF &k, dou
 //  phase 2, dense over the survivor list (all 64 lanes busy): normalise, recompute the landmark's KF quantities, emit.
 //  phase 3: missed-detection weights (+ near-limit heuristic from the landmark's list segment), unused mask.
 #ifndef UPDMAP_GATE_BATCH
-#define UPDMAP_GATE_BATCH 8  // measurements whose gates are evaluated per trip (scalar loads up front, branch-free)
+#define UPDMAP_GATE_BATCH 8
 #endif
 #ifndef UPDMAP_WAVES_PER_EU
 #define UPDMAP_WAVES_PER_EU 2
 #endif
 // One particle, one wavefront: `lane` of the calling wave, `sZ` the workgroup's LDS copy of the measurement set, `wb` this
 // wave's LDS block (update_map_lds_bytes_per_wave).  Shared by the stand-alone kernel and the fused step kernel.
+template <int GB>  // measurements whose gates are evaluated per trip (scalar loads up front, branch-free): 8 in the stand-alone
+                   // kernel, 4 inside the fused step kernel, whose 128-VGPR budget it shares
 __device__ __forceinline__ void phd_update_map_particle(const Buffers &B, const Params &P, const int cur, const int nZ,
                                                         const double *__restrict__ Zg, const int i, const int lane, const double *sZ,
                                                         unsigned char *wb) {
@@ -173,7 +175,6 @@ __device__ __forceinline__ void phd_update_map_particle(const Buffers &B, const 
       // addresses), the gate arithmetic is branch-free; the rare bearing difference beyond one wrap is redone exactly.
       const bool live = fov && k.ok;
       const bool useR = P.kfRange > 0, useB = P.kfBearing > 0;
-      constexpr int GB = UPDMAP_GATE_BATCH;
       for (int z0 = 0; z0 < nZ; z0 += GB) {
         double zr[GB], zb[GB];
 #pragma unroll
@@ -343,5 +344,5 @@ __global__ __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(UPDMAP
   __syncthreads();
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
   if (i >= B.N) return;
-  phd_update_map_particle(B, P, cur, nZ, Zg, i, lane, sZ, smem_raw + 2 * RFSGPU_MAX_Z * 8 + (size_t)wave * update_map_lds_bytes_per_wave(B.cap));
+  phd_update_map_particle<UPDMAP_GATE_BATCH>(B, P, cur, nZ, Zg, i, lane, sZ, smem_raw + 2 * RFSGPU_MAX_Z * 8 + (size_t)wave * update_map_lds_bytes_per_wave(B.cap));
 }
