@@ -192,14 +192,17 @@ int rfsgpu_predict_map(rfsgpu_filter *f, int add_birth);
  * (unless useClusterProcess), merge, prune.  z: n_z x d_z doubles.  n_z == 0 returns OK without
  * touching anything (:450-452).  Resampling / normalisation stay with the caller (below). */
 int rfsgpu_update(rfsgpu_filter *f, const double *z, int n_z);
-/* Stream-ordered form of rfsgpu_update: enqueues the same kernels and returns without waiting for the GPU.  Device-side
+/* Stream-ordered form of rfsgpu_update: enqueues the step and returns without waiting for the GPU.  With the 2-D model the
+ * step is ONE kernel (a workgroup takes its particle through updateMap, importanceWeighting, merge and prune; results are
+ * bit-identical to rfsgpu_update; the environment variable RFSGPU_FUSED_STEP=0 selects the three-kernel form).  Device-side
  * errors (capacity overflow, ...) surface at the next rfsgpu_synchronize() / synchronous call; per-phase HIP-event pairs of
  * up to RFSGPU_ASYNC_RING outstanding steps are harvested there into TimingInfo and rfsgpu_kernel_time_stats.  A host loop
  * that does not need the weights every step (no resampling decision pending) pipelines its steps with this. */
 #define RFSGPU_ASYNC_RING 256
 int rfsgpu_update_async(rfsgpu_filter *f, const double *z, int n_z);
 /* Average duration (ns) of each hot-path kernel group over the async steps harvested since the last call / reset:
- * [0]=phd_update_map [1]=phd_weight_multifeature(+murty) [2]=gm_merge(+prune); *n_steps = steps averaged. */
+ * [0]=phd_update_map [1]=phd_weight_multifeature [2]=gm_merge(+prune); *n_steps = steps averaged.  Steps that ran as one
+ * fused kernel report its duration in [0] and 0 in [1], [2] (their TimingInfo share is booked under mapUpdate). */
 int rfsgpu_kernel_time_stats(rfsgpu_filter *f, double *avg_ns3, int *n_steps);
 /* The same four phases one at a time (used by the parity tests and by profiling):          */
 int rfsgpu_update_map(rfsgpu_filter *f, const double *z, int n_z);      /* updateMap       :543-725 */
