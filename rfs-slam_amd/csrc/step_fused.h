@@ -8,8 +8,7 @@
 // the next, and each particle's mixture is still warm in L2 when its next phase reads it.
 //
 // The phases are the per-particle device functions of the stand-alone kernels, unchanged (update_map.h, weighting.h,
-// merge_prune.h); they share one LDS allocation, separated by workgroup barriers.  The map update is single-wave code:
-// wave 0 runs it while the other waves of the workgroup wait at the barrier.
+// merge_prune.h) -- the map update in its workgroup form -- sharing one LDS allocation, separated by workgroup barriers.
 #pragma once
 #include "common.h"
 #include "update_map.h"
@@ -27,7 +26,7 @@
 #endif
 
 __host__ __device__ inline size_t step_fused_lds_bytes(int cap, int evalCap, int nZ, int wpp) {
-  size_t a = (size_t)(2 * RFSGPU_MAX_Z * 8) + update_map_lds_bytes_per_wave(cap);
+  size_t a = (size_t)(2 * RFSGPU_MAX_Z * 8) + update_map_block_lds_bytes(cap);
   const size_t b = (size_t)(2 * RFSGPU_MAX_Z * 8) + weight_lds_bytes_per_wave(cap, evalCap, nZ) + WEIGHT_SCRATCH_BYTES;
   const size_t c = merge_lds_bytes_per_block(cap, wpp);
   if (b > a) a = b;
@@ -42,13 +41,13 @@ __global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(STEP_W
 void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, int useWeighting, MurtyQueue Q) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int i = blockIdx.x;
   double *sZ = reinterpret_cast<double *>(smem_raw);
   for (int t = tid; t < 2 * nZ; t += WPP * 64) sZ[t] = B.Z[t];
   __syncthreads();
-  if (wave == 0) phd_update_map_particle<STEP_GATE_BATCH>(B, P, cur, nZ, B.Z, i, lane, sZ, smem_raw + 2 * RFSGPU_MAX_Z * 8);
+  if (WPP == 1) phd_update_map_particle<STEP_GATE_BATCH>(B, P, cur, nZ, B.Z, i, lane, sZ, smem_raw + 2 * RFSGPU_MAX_Z * 8);
+  else phd_update_map_block<WPP, STEP_GATE_BATCH>(B, P, cur, nZ, B.Z, i, tid, sZ, smem_raw + 2 * RFSGPU_MAX_Z * 8);
   __threadfence_block();  // the slab / count written by wave 0 -> the whole workgroup
   __syncthreads();
   int mergeSrc = cur;

@@ -331,6 +331,253 @@ __device__ __forceinline__ void phd_update_map_particle(const Buffers &B, const 
   }
 }
 
+// LDS of the workgroup form below: the single-wave layout + cross-wave scratch.
+__host__ __device__ inline size_t update_map_block_lds_bytes(int cap) {
+  return update_map_lds_bytes_per_wave(cap) + (size_t)(cap / 64 + 1) * 4 + 128;
+}
+
+// The same map update by a workgroup of WPP waves (used inside the fused step kernel, where the particle's workgroup has
+// more than one wave): passes cover WPP*64 landmarks; the survivor list keeps its (m, z) order through a cross-wave
+// offset exchange, wave 0 folds the normalisers in list order (the reference's summation order), phases 2 and 3 are
+// split over all threads.  Bit-identical to phd_update_map_particle.
+template <int WPP, int GB>
+__device__ __forceinline__ void phd_update_map_block(const Buffers &B, const Params &P, const int cur, const int nZ,
+                                                     const double *__restrict__ Zg, const int i, const int tid, const double *sZ,
+                                                     unsigned char *wb) {
+  constexpr int NT = WPP * 64;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int cap = B.cap;
+  double *sV = reinterpret_cast<double *>(wb);                 // [cap] survivor values Pd*w*lik, later the normalised weights
+  double *sCol = sV + cap;                                      // [MAX_Z] final normalisers
+  unsigned *sMZ = reinterpret_cast<unsigned *>(sCol + RFSGPU_MAX_Z);  // [cap] (m << 8) | z
+  unsigned *sSeg = sMZ + cap;                                   // [cap] per landmark: (start << 8) | count
+  int *sKeep = reinterpret_cast<int *>(sSeg + cap);             // [cap/64 + 1] new Gaussians per 64-survivor chunk
+  int *sTot = sKeep + (cap / 64 + 1);                           // [2][8] survivors per wave of a pass (double-buffered)
+  int *sMisc = sTot + 16;                                       // [0] overflow flag [1] landmarks in FOV
+  unsigned *sUsed = reinterpret_cast<unsigned *>(sMisc + 2);    // [2] used-measurement mask (lo, hi)
+
+  const int nM = B.count[i];
+  const unsigned long long zmask = (nZ >= 64) ? ~0ull : ((1ull << nZ) - 1ull);
+  if (nM == 0) {  // :559-564
+    if (tid == 0) {
+      B.unusedMask[i] = zmask;
+      B.nInFov[i] = 0;
+    }
+    return;
+  }
+  double *slab = B.slab[cur];
+  double *pW = plane(slab, cap, i, PL_W), *pWP = plane(slab, cap, i, PL_WP);
+  double *pMX = plane(slab, cap, i, PL_MX), *pMY = plane(slab, cap, i, PL_MY);
+  double *pSXX = plane(slab, cap, i, PL_SXX), *pSXY = plane(slab, cap, i, PL_SXY), *pSYY = plane(slab, cap, i, PL_SYY);
+
+  PoseReg pr;
+  load_pose(B, P, i, pr);
+  if (tid < 4) { if (tid < 2) sMisc[tid] = 0; else sUsed[tid - 2] = 0u; }
+
+  const int nPass = (nM + NT - 1) / NT;
+  const int room = cap - nM;  // survivors that still fit as new Gaussians
+  int nFov = 0;
+  double cs = P.clutter;       // wave 0, lane z: normaliser of measurement z (reference: sum = clutter; sum += W[m][z] ...)
+  int nSurv = 0;
+  bool overflow = false;
+
+  // ---------------- phase 1 ----------------
+  for (int p = 0; p < nPass; p++) {
+    const int m = p * NT + tid;
+    const bool act = m < nM;
+    double w = 0, mx = 0, my = 0, sxx = 1, sxy = 0, syy = 1;
+    if (act) { w = pW[m]; mx = pMX[m]; my = pMY[m]; sxx = pSXX[m]; sxy = pSXY[m]; syy = pSYY[m]; }
+    LmKF k;
+    double range;
+    lm_precompute(P, pr, mx, my, sxx, sxy, syy, k, range);
+    bool close;
+    double pd = rb_pd(P, range, close);
+    if (close) pd = 1;  // :604-606
+    const bool fov = act && (pd != 0);
+    const double pdw = pd * w;
+    nFov += __popcll(__ballot(fov));
+    unsigned long long gate = 0;
+    {
+      const bool live = fov && k.ok;
+      const bool useR = P.kfRange > 0, useB = P.kfBearing > 0;
+      for (int z0 = 0; z0 < nZ; z0 += GB) {
+        double zr[GB], zb[GB];
+#pragma unroll
+        for (int u = 0; u < GB; u++) {
+          const int zz = (z0 + u < nZ) ? z0 + u : nZ - 1;
+          zr[u] = Zg[2 * zz];
+          zb[u] = Zg[2 * zz + 1];
+        }
+        bool redo = false;
+#pragma unroll
+        for (int u = 0; u < GB; u++) {
+          const double e0 = zr[u] - k.zx0;
+          double w1 = zb[u] - k.zx1;
+          w1 = (w1 > RFS_PI) ? w1 - 2 * RFS_PI : w1;
+          w1 = (w1 < -RFS_PI) ? w1 + 2 * RFS_PI : w1;
+          redo = ((int)redo | (int)(w1 > RFS_PI) | (int)(w1 < -RFS_PI)) != 0;
+          const int outR = (int)useR & (int)(fabs(e0) > P.kfRange), outB = (int)useB & (int)(fabs(w1) > P.kfBearing);
+          const bool g = (outR | outB) == 0;
+          gate |= ((int)live & (int)g & (int)(z0 + u < nZ)) ? (1ull << (z0 + u)) : 0ull;
+        }
+        if (__ballot(redo) != 0ull) {  // some bearing difference needs more than one wrap step: exact loop form
+          for (int u = 0; u < GB && z0 + u < nZ; u++) {
+            const bool g = pair_gate(P, k, zr[u], zb[u]);
+            const unsigned long long bit = 1ull << (z0 + u);
+            gate = (live && g) ? (gate | bit) : (gate & ~bit);
+          }
+        }
+      }
+    }
+    unsigned long long surv = 0;
+    for (unsigned long long g = gate; g; g &= g - 1) {
+      const int z = __builtin_ctzll(g);
+      if (pair_value(P, k, pdw, sZ[2 * z], sZ[2 * z + 1]) != 0.0) surv |= (1ull << z);
+    }
+    const int cnt = __popcll(surv);
+    const int off = wave_excl_scan(cnt, lane);
+    const int totalW = __builtin_amdgcn_readlane(off + cnt, 63);
+    int *tot = sTot + 8 * (p & 1);
+    if (lane == 0) tot[wave] = totalW;
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < WPP; w2++) { const int t = tot[w2]; before += (w2 < wave) ? t : 0; total += t; }
+    if (act) sSeg[m] = ((unsigned)(nSurv + before + off) << 8) | (unsigned)cnt;
+    {
+      int pos = nSurv + before + off;
+      for (unsigned long long g = surv; g; g &= g - 1) {
+        const int z = __builtin_ctzll(g);
+        if (pos < room) {
+          sV[pos] = pair_value(P, k, pdw, sZ[2 * z], sZ[2 * z + 1]);
+          sMZ[pos] = ((unsigned)m << 8) | (unsigned)z;
+        } else {
+          overflow = true;
+        }
+        pos++;
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {  // lane z folds this pass's survivors of measurement z into its normaliser, in landmark order
+      const int lo = nSurv, hi = (nSurv + total < room) ? nSurv + total : room;
+      int sIdx = lo;
+      for (; sIdx + 4 <= hi; sIdx += 4) {  // broadcast reads, four in flight; the adds stay in list (= landmark) order
+        const unsigned mz0 = sMZ[sIdx], mz1 = sMZ[sIdx + 1], mz2 = sMZ[sIdx + 2], mz3 = sMZ[sIdx + 3];
+        const double v0 = sV[sIdx], v1 = sV[sIdx + 1], v2 = sV[sIdx + 2], v3 = sV[sIdx + 3];
+        if ((int)(mz0 & 0xffu) == lane) cs += v0;
+        if ((int)(mz1 & 0xffu) == lane) cs += v1;
+        if ((int)(mz2 & 0xffu) == lane) cs += v2;
+        if ((int)(mz3 & 0xffu) == lane) cs += v3;
+      }
+      for (; sIdx < hi; sIdx++) {
+        const unsigned mz = sMZ[sIdx];
+        const double v = sV[sIdx];
+        if ((int)(mz & 0xffu) == lane) cs += v;
+      }
+    }
+    nSurv += total;
+  }
+  if (__ballot(overflow) != 0ull && lane == 0) atomicOr(&sMisc[0], 1);
+  if (lane == 0) atomicAdd(&sMisc[1], nFov);
+  if (wave == 0) sCol[lane] = cs;
+  __syncthreads();
+  if (sMisc[0] != 0 || nSurv > room) {
+    if (tid == 0) atomicOr(B.err, ERRBIT_CAPACITY);
+    nSurv = room < 0 ? 0 : (nSurv > room ? room : nSurv);
+  }
+
+  // ---------------- phase 2a: normalise in place, count the new Gaussians of every 64-survivor chunk ----------------
+  {
+    unsigned long long used = 0;
+    for (int s0 = wave * 64; s0 < nSurv; s0 += NT) {
+      const int sIdx = s0 + lane;
+      const bool act = sIdx < nSurv;
+      double wn = 0.0;
+      int z = 0;
+      if (act) { z = (int)(sMZ[sIdx] & 0xffu); wn = sV[sIdx] / sCol[z]; sV[sIdx] = wn; }
+      if (act && wn != 0.0) used |= (1ull << z);
+      const unsigned long long km = __ballot(act && (wn > 0.0));  // :677
+      if (lane == 0) sKeep[s0 >> 6] = __popcll(km);
+    }
+    used = wave_or_u64(used);
+    if (lane == 0) { atomicOr(&sUsed[0], (unsigned)(used & 0xffffffffull)); atomicOr(&sUsed[1], (unsigned)(used >> 32)); }
+  }
+  __syncthreads();
+  // ---------------- phase 2b: emit, dense over the survivors ----------------
+  int outBase = nM;
+  {
+    const int nChunks = (nSurv + 63) >> 6;
+    int myBase = nM, c = 0;
+    for (int s0 = wave * 64; s0 < nSurv; s0 += NT) {
+      for (; c < (s0 >> 6); c++) myBase += sKeep[c];
+      const int sIdx = s0 + lane;
+      const bool act = sIdx < nSurv;
+      unsigned mz = 0;
+      double wn = 0.0;
+      if (act) { mz = sMZ[sIdx]; wn = sV[sIdx]; }
+      const int m = (int)(mz >> 8), z = (int)(mz & 0xffu);
+      const bool keep = act && (wn > 0.0);
+      const unsigned long long km = __ballot(keep);
+      if (keep) {
+        const int pos = myBase + __popcll(km & ((1ull << lane) - 1ull));
+        const double mx = pMX[m], my = pMY[m], sxx = pSXX[m], sxy = pSXY[m], syy = pSYY[m];
+        LmKF k;
+        double range;
+        lm_precompute(P, pr, mx, my, sxx, sxy, syy, k, range);
+        const double nu0 = sZ[2 * z] - k.zx0;
+        const double nu1 = wrap_pi(sZ[2 * z + 1] - k.zx1);
+        pW[pos] = wn;
+        pWP[pos] = 0.0;  // addGaussian: weight_prev = 0 (GaussianMixture.hpp:267-284)
+        pMX[pos] = mx + (k.k00 * nu0 + k.k01 * nu1);
+        pMY[pos] = my + (k.k10 * nu0 + k.k11 * nu1);
+        pSXX[pos] = k.p00;
+        pSXY[pos] = k.p01;
+        pSYY[pos] = k.p11;
+      }
+    }
+    for (int c2 = 0; c2 < nChunks; c2++) outBase += sKeep[c2];
+  }
+
+  // ---------------- phase 3: missed-detection weights (:686-706); setWeight keeps the old weight in w_prev ----------------
+  for (int m = tid; m < nM; m += NT) {
+    const double w = pW[m];
+    const double dx = pMX[m] - pr.x, dy = pMY[m] - pr.y;
+    bool close;
+    double pd = rb_pd(P, sqrt(dx * dx + dy * dy), close);
+    if (close) pd = 1;
+    double w_k = (1 - pd) * w;
+    if (close && w > P.birthW) {
+      const unsigned seg = sSeg[m];
+      const int st = (int)(seg >> 8), c = (int)(seg & 0xffu);
+      double rowsum = 0.0;
+      for (int q = st; q < st + c && q < nSurv; q++) rowsum += sV[q];  // (already divided by the normaliser)
+      const double delta_w = pd * w - rowsum;
+      if (delta_w > 0) {
+        w_k += delta_w;
+        if (w_k > 1) w_k = 1;
+      }
+    }
+    pWP[m] = w;
+    pW[m] = w_k;
+  }
+  if (tid == 0) {
+    B.count[i] = outBase;
+    const unsigned long long used = (unsigned long long)sUsed[0] | ((unsigned long long)sUsed[1] << 32);
+    B.unusedMask[i] = (~used) & zmask;  // :709-720
+    B.nInFov[i] = sMisc[1];
+  }
+  if (P.useCluster) __syncthreads();  // (phase 3 left the prior weights in w_prev)
+  if (P.useCluster && wave == 0) {  // :570-580, :652-668 -- sum of the prior weights in the single-wave order
+    double wsum = 0.0;
+    for (int m = lane; m < nM; m += 64) wsum += pWP[m];
+    const double s2 = RFS_DENORM_MIN + wave_sum_dpp(wsum);
+    double prod = 1.0;
+    for (int z = 0; z < nZ; z++) prod *= readlane_f64(cs, z);
+    if (lane == 0) B.weight[i] = exp(s2) * prod * B.weight[i];
+  }
+}
+
 template <int WPB>
 __global__ __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(UPDMAP_WAVES_PER_EU))) void phd_update_map_kernel(Buffers B, Params P, int cur, int nZ, const double *__restrict__ Zg) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
