@@ -16,17 +16,17 @@
 #include "weighting.h"  // wave_sync
 
 // LDS per particle: per entry x, y, w, bound (4 doubles) + row record (u32) + grid-sorted index (u16) + slack (u16);
-// plus the 32x16 spatial grid (one cursor array, u32) and the list of possible partners (u32 each).  Covariances stay
+// plus the 32x32 spatial grid (one cursor array, two 16-bit cursors per word) and the list of possible partners (u32 each).  Covariances stay
 // in HBM/L2 and their inverses are formed on demand for the few pairs that survive the distance prefilter -- this
 // keeps the footprint at 40 B/entry so that 8 workgroups fit a CU and 2000 particles run in a single round.
 #define MERGE_GX 32  // grid cells along x
-#define MERGE_GY 16  // grid cells along y
+#define MERGE_GY 32  // grid cells along y
 #define MERGE_CELLS (MERGE_GX * MERGE_GY)
 #define MERGE_PAIR_CAP(cap) ((cap) > 320 ? (cap) : 320)  // listed partners per particle: ~0.7 per entry on dense maps
 #define MERGE_ROW_SLOTS 8   // prefilter survivors one row can list; a row with more is replayed by the sequential scan
 __host__ __device__ inline size_t merge_lds_bytes_per_wave(int cap) {
   // entries: 4 doubles + row record (u32) + grid-sorted index (u16) + prefilter slack (u16); grid: CELLS+4 u32; pair list: u32
-  return (((size_t)cap * (4 * 8 + 4 + 2 + 2)) + (size_t)(MERGE_CELLS + 4) * 4 + (size_t)MERGE_PAIR_CAP(cap) * 4 + 16 + 15) & ~(size_t)15;
+  return (((size_t)cap * (4 * 8 + 4 + 2 + 2)) + (size_t)(MERGE_CELLS / 2 + 4) * 4 + (size_t)MERGE_PAIR_CAP(cap) * 4 + 16 + 15) & ~(size_t)15;
 }
 // Row record (sRec[m]): [31:25] claim of the speculative round (lane, 0x7f = none) | [24] the row has a partner that
 // passes the exact test against the initial states | [23:20] number of listed survivors (15 = not listable) |
@@ -70,7 +70,7 @@ __device__ __forceinline__ bool merge_pair_passes(double e0, double e1, double a
 // gm_merge (+ optional fused gm_prune).
 // Phase 1 (parallel): every pair (a, j>a) is examined once against the INITIAL states -- which is exactly what the
 //   reference's sequential scan sees the first time it meets a pair, because a Gaussian only changes while it is the
-//   outer index.  Candidates come from a 32x16 uniform grid over the mixture's bounding box whose cell edges are >= the
+//   outer index.  Candidates come from a 32x32 uniform grid over the mixture's bounding box whose cell edges are >= the
 //   largest prefilter radius, so every pair that can pass lies in adjacent cells; each entry writes the list of its
 //   possible partners (higher indices only) and a slack bound for everything it did not list; the listed pairs are
 //   tested exactly.  A non-finite bound makes the cell edge infinite: everything falls into one cell and the search
@@ -96,8 +96,10 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
   float *sRed = reinterpret_cast<float *>(smem_raw + merge_lds_bytes_per_wave(cap));  // [WPP][8] cross-wave reduction scratch
   auto block_sync = [&]() { if (WPP == 1) wave_sync(); else __syncthreads(); };
   double *sMX = reinterpret_cast<double *>(wbase), *sMY = sMX + cap, *sW = sMX + 2 * cap, *sBnd = sMX + 3 * cap;
-  unsigned *sCellStart = reinterpret_cast<unsigned *>(sMX + 4 * cap);      // [CELLS + 1]: cell c's entries are sSorted[start[c] .. start[c+1])
-  unsigned *sRec = sCellStart + MERGE_CELLS + 4;                            // [cap] row records (see MERGE_REC_*)
+  // grid cursors, 16 bits each, two per word: cell c's entries are sSorted[cell_at(c) .. cell_at(c + 1))
+  unsigned *sCellStart = reinterpret_cast<unsigned *>(sMX + 4 * cap);      // [(CELLS + 1) halves]
+  auto cell_at = [&](int e) -> unsigned { return (sCellStart[e >> 1] >> (16 * (e & 1))) & 0xffffu; };
+  unsigned *sRec = sCellStart + MERGE_CELLS / 2 + 4;                        // [cap] row records (see MERGE_REC_*)
   unsigned *sPairs = sRec + cap;                                            // [PAIR_CAP] (a << 16) | (passes << 15) | (reserve << 14) | j
   unsigned *sPairCount = sPairs + MERGE_PAIR_CAP(cap);                      // [1] (+3 pad)
   unsigned short *sSorted = reinterpret_cast<unsigned short *>(sPairCount + 4);  // [cap] grid order; later: candidate rows, prune survivors
@@ -132,7 +134,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     fymin = fminf(fymin, fy); fymax = fmaxf(fymax, fy);
     frad = fmaxf(frad, sqrtf((float)bnd) * 1.0001f);
   }
-  for (int c = tid; c <= MERGE_CELLS; c += NT) sCellStart[c] = 0u;
+  for (int c = tid; c <= MERGE_CELLS / 2; c += NT) sCellStart[c] = 0u;
   fxmin = wave_min_f32(fxmin); fxmax = wave_max_f32(fxmax);
   fymin = wave_min_f32(fymin); fymax = wave_max_f32(fymax);
   frad = wave_max_f32(frad);
@@ -166,26 +168,37 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     if ((hole >> sidx) & 1u) continue;
     int cx, cy;
     cell_of(sMX[m], sMY[m], cx, cy);
-    atomicAdd(&sCellStart[cy * MERGE_GX + cx + 1], 1u);  // counts, shifted by one
+    const int e = cy * MERGE_GX + cx + 1;  // counts, shifted by one entry
+    atomicAdd(&sCellStart[e >> 1], 1u << (16 * (e & 1)));  // (a half never overflows: counts <= cap < 65536)
   }
   block_sync();
-  if (wave == 0) {  // start[c + 1] := entries in cells < c (the cursor of cell c); the scatter below advances it to end(c) = start(c + 1)
-    constexpr int PER = MERGE_CELLS / 64;
-    unsigned cnt[PER];
+  if (wave == 0) {  // entry[c + 1] := entries in cells < c (the cursor of cell c); the scatter below advances it to end(c) = start(c + 1)
+    // exclusive scan over the CELLS + 1 half-word entries: lane l owns entries 16l .. 16l + 15 (8 words); entry CELLS (the
+    // low half of the last word) receives the total
+    constexpr int WPL = MERGE_CELLS / 128;  // words per lane
+    unsigned wv[WPL];
     int tot = 0;
 #pragma unroll
-    for (int k = 0; k < PER; k++) { cnt[k] = sCellStart[PER * lane + k + 1]; tot += (int)cnt[k]; }
+    for (int k = 0; k < WPL; k++) { wv[k] = sCellStart[WPL * lane + k]; tot += (int)(wv[k] & 0xffffu) + (int)(wv[k] >> 16); }
     int off = wave_excl_scan(tot, lane);
     wave_sync();
 #pragma unroll
-    for (int k = 0; k < PER; k++) { sCellStart[PER * lane + k + 1] = (unsigned)off; off += (int)cnt[k]; }
+    for (int k = 0; k < WPL; k++) {
+      const unsigned lo = (unsigned)off;
+      off += (int)(wv[k] & 0xffffu);
+      const unsigned hi = (unsigned)off;
+      off += (int)(wv[k] >> 16);
+      sCellStart[WPL * lane + k] = lo | (hi << 16);
+    }
+    if (lane == 63) sCellStart[MERGE_CELLS / 2] = (unsigned)off;  // entry CELLS = the cursor of the last cell... (see below)
   }
   block_sync();
   for (int m = tid, sidx = 0; m < N; m += NT, sidx++) {
     if ((hole >> sidx) & 1u) continue;
     int cx, cy;
     cell_of(sMX[m], sMY[m], cx, cy);
-    const unsigned pos = atomicAdd(&sCellStart[cy * MERGE_GX + cx + 1], 1u);
+    const int e = cy * MERGE_GX + cx + 1;
+    const unsigned pos = (atomicAdd(&sCellStart[e >> 1], 1u << (16 * (e & 1))) >> (16 * (e & 1))) & 0xffffu;
     sSorted[pos] = (unsigned short)m;
   }
   if (tid == 0) *sPairCount = 0u;
@@ -212,7 +225,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     int nP = 0;
     double farE2 = 1.0e300;   // nearest neighbour that fails the prefilter by a factor >= 2 in distance
     for (int ry = (cy > 0 ? cy - 1 : 0); ry <= (cy < MERGE_GY - 1 ? cy + 1 : MERGE_GY - 1); ry++) {
-      const unsigned qs = sCellStart[ry * MERGE_GX + cxa], qe = sCellStart[ry * MERGE_GX + cxb + 1];
+      const unsigned qs = cell_at(ry * MERGE_GX + cxa), qe = cell_at(ry * MERGE_GX + cxb + 1);
       for (unsigned q = qs; q < qe; q += 4) {
         unsigned jj[4];
         double jx[4], jy[4], jb[4];
