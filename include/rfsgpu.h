@@ -107,6 +107,25 @@ typedef struct rfsgpu_kf_config {
   double bearingInnovationThreshold;
 } rfsgpu_kf_config;
 
+/* Mirrors FastSLAM::Config (include/FastSLAM.hpp:106-132), same member names without the trailing '_'.
+ * Defaults: FastSLAM constructor (:243-257). */
+typedef struct rfsgpu_fastslam_config {
+  int minUpdatesBeforeResample;
+  int minMeasurementsBeforeResample;
+  double landmarkExistencePrior;
+  double mapExistencePruneThreshold;
+  double minLogMeasurementLikelihood;
+  int nParticlesMax;
+  unsigned maxNDataAssocHypotheses;
+  double maxDataAssocLogLikelihoodDiff;
+  double landmarkCandidateMeasurementSupportDist;
+  unsigned landmarkCandidateMeasurementCountThreshold;
+  unsigned landmarkCandidateCurrentMeasurementCountThreshold;
+  unsigned landmarkCandidateMeasurementCheckThreshold;
+  double landmarkLockWeight;
+  unsigned pruningMeasurementsThreshold;
+} rfsgpu_fastslam_config;
+
 /* Mirrors RBPHDFilter::TimingInfo (include/RBPHDFilter.hpp:152-167), nanoseconds, accumulated.
  * *_wall come from HIP events around each phase's kernels; *_cpu is the host time spent inside
  * the corresponding ABI calls (launch + sync). */
@@ -258,6 +277,23 @@ int rfsgpu_last_kernel_ns(rfsgpu_filter *f, long long *ns4);
 /* MatPerm::calc (src/MatrixPermanent.cpp:41-112), batched: `batch` row-major n x n matrices in A
  * (host), permanents to out (host).  n <= 24.  Standalone (no filter handle needed). */
 int rfsgpu_mat_perm(const double *A, int n, int batch, double *out, int device_id);
+
+/* ---- FastSLAM 1.0 on the same handle (reference include/FastSLAM.hpp) --------------------------------
+ * The handle's mixtures double as FastSLAM's per-particle landmark maps: a Gaussian's weight is the landmark's
+ * log-odds of existence (FastSLAM.hpp:598-617), the birth-candidate lists are the landmark candidates
+ * (landmarkCandidates_, :84-88).  2-D range-bearing model.  The map part of FastSLAM::predict (:376-383, staticStep on
+ * every landmark) is rfsgpu_predict_map(f, 0). */
+void rfsgpu_default_fastslam_config(rfsgpu_fastslam_config *cfg);                       /* constructor defaults :243-257 */
+int rfsgpu_set_fastslam_config(rfsgpu_filter *f, const rfsgpu_fastslam_config *cfg);    /* public member `config`        */
+int rfsgpu_get_fastslam_config(const rfsgpu_filter *f, rfsgpu_fastslam_config *cfg);
+/* FastSLAM::updateMap for every particle (:387-418, 424-706): in-range landmarks, log-likelihood table, CostMatrix::reduce +
+ * best data association, Kalman correction of the associated landmarks, existence log-odds, pruning, new landmarks /
+ * candidates from the unassociated measurements, particle weight *= exp(sum of the associated log-likelihoods).
+ * n_z == 0 returns OK without touching anything (:401-402).  resampleWithMapCopy (:708-735) stays with the caller
+ * (rfsgpu_weight_sums / rfsgpu_normalize_weights / rfsgpu_resample_apply).  Multi-hypothesis FastSLAM
+ * (config.maxNDataAssocHypotheses > 1: particles multiply by Murty's k best associations) is NOT built:
+ * RFSGPU_ERR_UNSUPPORTED. */
+int rfsgpu_fastslam_update(rfsgpu_filter *f, const double *z, int n_z);
 
 #ifdef __cplusplus
 }

@@ -848,7 +848,65 @@ struct FilterBase {
   virtual void set_lmk_noise(const double *Q) = 0;
   virtual int export_candidates(int slot, int max_n, double *mean, double *cov, int *support, int *checks) = 0;
   virtual void import_candidates(int slot, int cnt, const double *mean, const double *cov, const int *support, const int *checks) = 0;
+  /* FastSLAM (include/FastSLAM.hpp) on the same state: mixtures = landmark maps with log-odds weights */
+  rfsgpu_fastslam_config fs;
+  virtual int fastslam_update() = 0;
 };
+
+static void fastslam_defaults(rfsgpu_fastslam_config *c, int n) { /* FastSLAM constructor, include/FastSLAM.hpp:243-257 */
+  c->minUpdatesBeforeResample = 1;
+  c->minMeasurementsBeforeResample = 1;
+  c->landmarkExistencePrior = 0.5;
+  c->mapExistencePruneThreshold = -3.0;
+  c->minLogMeasurementLikelihood = -10.0;
+  c->nParticlesMax = n * 3;
+  c->maxNDataAssocHypotheses = 1;
+  c->maxDataAssocLogLikelihoodDiff = 5;
+  c->landmarkCandidateMeasurementSupportDist = 1;
+  c->landmarkCandidateMeasurementCountThreshold = 1;
+  c->landmarkCandidateCurrentMeasurementCountThreshold = 1;
+  c->landmarkCandidateMeasurementCheckThreshold = 2;
+  c->landmarkLockWeight = 10;
+  c->pruningMeasurementsThreshold = 0;
+}
+
+/* CostMatrix::reduce + getCostMatrixReduced (src/CostMatrix.cpp:263-369) for an n x n table C with a LOWER limit `lim`
+ * (minVal == true, the FastSLAM call).  a_fixed[i] = column of row i if that pairing is the only possibility for both, else
+ * -1 (rows with no possibility at all included); iRed / jRed = the rows / columns left for the assignment solver; a
+ * 1 x 1 remainder is assigned directly (:331-336) and the reduced size reported as 0. */
+struct ReducedCost {
+  std::vector<int> a_fixed, iRed, jRed;
+  int nRed = 0;
+};
+static ReducedCost cost_matrix_reduce(std::vector<std::vector<double>> &C, int n, double lim) {
+  ReducedCost R;
+  std::vector<int> nMatch_i(n, 0), nMatch_j(n, 0), a_rev(n, -1);
+  R.a_fixed.assign(n, -1);
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) {
+      if (C[i][j] <= lim) {
+        C[i][j] = lim;
+      } else {
+        nMatch_i[i]++;
+        nMatch_j[j]++;
+        if (nMatch_i[i] == 1 && nMatch_j[j] == 1) { R.a_fixed[i] = j; a_rev[j] = i; }
+        if (nMatch_i[i] > 1) R.a_fixed[i] = -1;
+        if (nMatch_j[j] > 1) a_rev[j] = -1;
+      }
+    }
+  for (int k = 0; k < n; k++) {
+    if (R.a_fixed[k] != -1 && nMatch_j[R.a_fixed[k]] != 1) R.a_fixed[k] = -1;
+    if (a_rev[k] != -1 && nMatch_i[a_rev[k]] != 1) a_rev[k] = -1;
+    if (R.a_fixed[k] == -1) R.iRed.push_back(k);
+    if (a_rev[k] == -1) R.jRed.push_back(k);
+  }
+  R.nRed = (int)R.iRed.size(); /* == jRed.size() (asserted by the reference, :318) */
+  if (R.nRed == 1) {
+    R.a_fixed[R.iRed[0]] = R.jRed[0];
+    R.nRed = 0;
+  }
+  return R;
+}
 
 template <class M>
 struct FilterT : FilterBase {
@@ -877,6 +935,7 @@ struct FilterT : FilterBase {
     unused.assign(n, {});
     nInFov.assign(n, 0);
     memset(&timing, 0, sizeof(timing));
+    fastslam_defaults(&fs, n);
   }
 
   /* KalmanFilter::correct, vector overload: include/KalmanFilter.hpp:261-342.  One landmark against all measurements.
@@ -1155,9 +1214,9 @@ struct FilterT : FilterBase {
     }
   }
   /* GaussianMixture::prune(t)  (:477-521), binary search + linear walk restated literally. */
-  void prune_particle(int i) {
+  void prune_particle(int i) { prune_particle_t(i, cfg.gaussianPruningThreshold); }
+  void prune_particle_t(int i, const double t) { /* GaussianMixture::prune(t) :477-521 */
     std::vector<Gauss> &G = gm[i];
-    const double t = cfg.gaussianPruningThreshold;
     unsigned nPruned = 0;
     if (G.size() < 1) return;
     sort_by_weight(G);
@@ -1241,6 +1300,144 @@ struct FilterT : FilterBase {
       if (it == L.end()) it = L.begin(); /* for-loop's it++ on end(): wraps to begin() (== end() when the list is empty) */
       else ++it;
     }
+  }
+
+  /* FastSLAM::updateMap (include/FastSLAM.hpp:424-706) for one particle, single data-association hypothesis
+   * (config.maxNDataAssocHypotheses_ == 1: `murty.findNextBest` is called once == the Hungarian optimum of the reduced
+   * table; no particle copies). */
+  void fastslam_update_particle(int i) {
+    const int nZl = nZ;
+    const Pose &ps = pose[i];
+    std::vector<Gauss> &G = gm[i];
+    unsigned nM = gm_n[i];
+    std::vector<int> idx_inRange;
+    std::vector<double> pd_inRange;
+    for (unsigned m = 0; m < nM; m++) { /* :440-449 */
+      bool closeToLimit = false;
+      double pd = model.pd(ps, G[m].x, G[m].S, closeToLimit);
+      if (pd != 0 || closeToLimit) { idx_inRange.push_back((int)m); pd_inRange.push_back(pd); }
+    }
+    nM = idx_inRange.size();
+    unsigned nMZ = nM;
+    if ((unsigned)nZl > nM) nMZ = nZl;
+    const double lim = fs.minLogMeasurementLikelihood;
+    std::vector<std::vector<double>> T(nMZ, std::vector<double>(nMZ, lim)); /* :458-465 */
+    for (unsigned m = 0; m < nM; m++) {                                      /* :468-481 */
+      const Gauss &lm = G[idx_inRange[m]];
+      double z_exp[D];
+      MatD S;
+      bool ok = model.measure(ps, lm.x, lm.S, z_exp, S, nullptr);
+      for (int z = 0; z < nZl; z++)
+        if (ok) T[m][z] = fmax(lim, log(gauss_lik<D>(z_exp, S, &Z[(size_t)D * z], nullptr)));
+    }
+    ReducedCost R = cost_matrix_reduce(T, (int)nMZ, lim); /* :484-490 */
+    std::vector<int> da(nMZ, -1);                          /* da_current */
+    if (R.nRed == 0) {                                     /* :498-505 */
+      for (unsigned m = 0; m < nM; m++) da[m] = R.a_fixed[m];
+    } else {                                               /* :506-541, one pass of the loop */
+      std::vector<std::vector<double>> Cr(R.nRed, std::vector<double>(R.nRed));
+      std::vector<double *> rows(R.nRed);
+      for (int a = 0; a < R.nRed; a++) {
+        for (int b = 0; b < R.nRed; b++) Cr[a][b] = T[R.iRed[a]][R.jRed[b]];
+        rows[a] = Cr[a].data();
+      }
+      Murty murty(rows.data(), R.nRed);
+      std::vector<int> daVar;
+      double logLikelihoodSum = 0;
+      int nH = murty.findNextBest(daVar, logLikelihoodSum);
+      for (unsigned m = 0; m < nM; m++) da[m] = R.a_fixed[m];
+      if (nH != -1) {
+        for (int m = 0; m < R.nRed; m++) {
+          int z_o = R.jRed[daVar[m]];
+          int m_o = R.iRed[m];
+          da[m_o] = (z_o < nZl) ? z_o : -2;
+        }
+      } else {
+        /* the reference would carry on with nH == 0 hypotheses, i.e. leave the particle untouched (:543-551 loop runs 0 times) */
+        return;
+      }
+    }
+    /* one hypothesis: :559-703 */
+    const double nExpectedClutter = model.clutter_integral();
+    const double probFalseAlarm = nExpectedClutter / nZl;
+    double p_exist_given_Z = 0;
+    double logParticleWeight = 0;
+    nInFov[i] = 0;
+    std::vector<char> zUsed(nZl, 0);
+    const double prior = fs.landmarkExistencePrior;
+    for (unsigned m = 0; m < nM; m++) { /* :573-604 */
+      Gauss &lm = G[idx_inRange[m]];
+      int z = da[m];
+      bool isUpdatePerformed = false;
+      if (z < nZl && z >= 0 && T[m][z] > lim) isUpdatePerformed = kf_correct_one(ps, &Z[(size_t)D * z], lm.x, lm.S, lm.x, lm.S);
+      double w = lm.w;
+      if (isUpdatePerformed) {
+        nInFov[i]++;
+        zUsed[z] = 1;
+        logParticleWeight += T[m][z];
+        p_exist_given_Z = ((1 - pd_inRange[m]) * probFalseAlarm * prior + pd_inRange[m] * prior) /
+                          (probFalseAlarm + (1 - probFalseAlarm) * pd_inRange[m] * prior);
+      } else {
+        p_exist_given_Z = ((1 - pd_inRange[m]) * prior) / ((1 - prior) + (1 - pd_inRange[m]) * prior);
+        if (w > fs.landmarkLockWeight) p_exist_given_Z = 0.5;
+      }
+      w += log((p_exist_given_Z) / (1 - p_exist_given_Z));
+      lm.w_prev = lm.w; /* setWeight keeps the previous value (GaussianMixture.hpp:368-375) */
+      lm.w = w;
+    }
+    if ((unsigned)nZl >= fs.pruningMeasurementsThreshold) prune_particle_t(i, fs.mapExistencePruneThreshold); /* :611-612 */
+    const double newLandmarkWeight = log(prior / (1 - prior));
+    std::list<Candidate> &L = cand[i];
+    for (int z = 0; z < nZl; z++) { /* :615-690 */
+      if (zUsed[z]) continue;
+      const double *uz = &Z[(size_t)D * z];
+      bool isNewCandidate = true;
+      for (auto it = L.begin(); it != L.end(); it++) {
+        double z_exp[D];
+        MatD S;
+        model.measure(ps, it->x, it->S, z_exp, S, nullptr);
+        double d2 = md2<D>(z_exp, inv(S), uz);
+        if (d2 <= fs.landmarkCandidateMeasurementSupportDist * fs.landmarkCandidateMeasurementSupportDist) {
+          kf_correct_one(ps, uz, it->x, it->S, it->x, it->S);
+          (it->nSupportingMeasurements)++;
+          isNewCandidate = false;
+          break;
+        }
+      }
+      if (isNewCandidate) {
+        Candidate c;
+        c.nSupportingMeasurements = 1;
+        c.nChecks = 0;
+        model.inverse_measure(ps, uz, c.x, c.S);
+        if (fs.landmarkCandidateMeasurementCountThreshold == 1 || nInFov[i] <= fs.landmarkCandidateCurrentMeasurementCountThreshold)
+          add_gaussian(i, c.x, c.S, newLandmarkWeight);
+        else
+          L.push_back(c);
+      }
+      /* the promotion loop sits INSIDE the unused-measurement loop (:656-688); ++it after erase() returned end() wraps
+       * to begin() with libstdc++'s circular list, as in addBirthGaussians */
+      auto it = L.begin();
+      while (it != L.end()) {
+        it->nChecks++;
+        while (it->nSupportingMeasurements >= fs.landmarkCandidateMeasurementCountThreshold || it->nChecks > fs.landmarkCandidateMeasurementCheckThreshold ||
+               nInFov[i] <= fs.landmarkCandidateCurrentMeasurementCountThreshold) {
+          if (it->nSupportingMeasurements >= fs.landmarkCandidateMeasurementCountThreshold) add_gaussian(i, it->x, it->S, newLandmarkWeight * it->nChecks);
+          else if (nInFov[i] <= fs.landmarkCandidateCurrentMeasurementCountThreshold) add_gaussian(i, it->x, it->S, newLandmarkWeight * it->nChecks);
+          it = L.erase(it);
+          if (it != L.end()) it->nChecks++;
+          else break;
+        }
+        if (it == L.end()) it = L.begin();
+        else ++it;
+      }
+    }
+    weight[i] = weight[i] * exp(logParticleWeight); /* :696-697 */
+  }
+  int fastslam_update() override {
+    if (fs.maxNDataAssocHypotheses > 1) { err = "multi-hypothesis FastSLAM is not built"; return RFSGPU_ERR_UNSUPPORTED; }
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int i = 0; i < n; i++) fastslam_update_particle(i);
+    return RFSGPU_OK;
   }
 
   /* ---- FilterBase ---- */
@@ -1494,6 +1691,28 @@ int rfsor_importance_weighting(void *f) { F_(f)->importance_weighting(); return 
 int rfsor_merge(void *f) { F_(f)->merge(); return RFSGPU_OK; }
 int rfsor_prune(void *f) { F_(f)->prune(); return RFSGPU_OK; }
 /* RBPHDFilter::update body (:444-523). */
+/* probe: CostMatrix::reduce + getCostMatrixReduced on an n x n row-major table (modified in place like the reference's);
+ * a_fixed[n], iRed[n], jRed[n] filled, returns the reduced dimension */
+int rfsor_cost_matrix_reduce(double *C, int n, double lim, int *a_fixed, int *iRed, int *jRed) {
+  std::vector<std::vector<double>> T(n, std::vector<double>(n));
+  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) T[i][j] = C[(size_t)i * n + j];
+  orc::ReducedCost R = orc::cost_matrix_reduce(T, n, lim);
+  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) C[(size_t)i * n + j] = T[i][j];
+  for (int i = 0; i < n; i++) { a_fixed[i] = R.a_fixed[i]; iRed[i] = i < (int)R.iRed.size() ? R.iRed[i] : -1; jRed[i] = i < (int)R.jRed.size() ? R.jRed[i] : -1; }
+  return R.nRed;
+}
+void rfsor_default_fastslam_config(rfsgpu_fastslam_config *c) { orc::fastslam_defaults(c, 0); }
+int rfsor_set_fastslam_config(void *f, const rfsgpu_fastslam_config *c) { F_(f)->fs = *c; return RFSGPU_OK; }
+int rfsor_get_fastslam_config(const void *f, rfsgpu_fastslam_config *c) { *c = reinterpret_cast<const FilterBase *>(f)->fs; return RFSGPU_OK; }
+int rfsor_fastslam_update(void *f, const double *z, int n_z) {
+  FilterBase *F = F_(f);
+  if (n_z < 0) return RFSGPU_ERR_INVALID;
+  if (n_z == 0) return RFSGPU_OK; /* include/FastSLAM.hpp:401-402 */
+  F->Z.assign(z, z + (size_t)F->dz * n_z);
+  F->nZ = n_z;
+  return F->fastslam_update();
+}
+
 int rfsor_update(void *f, const double *z, int n_z) {
   FilterBase *F = F_(f);
   if (n_z == 0) return RFSGPU_OK; /* :450-452 */

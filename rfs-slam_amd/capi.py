@@ -75,6 +75,26 @@ class KFConfig(C.Structure):
     _fields_ = [("rangeInnovationThreshold", C.c_double), ("bearingInnovationThreshold", C.c_double)]
 
 
+class FastSlamConfig(C.Structure):
+    """FastSLAM::Config (include/FastSLAM.hpp:106-132)."""
+    _fields_ = [
+        ("minUpdatesBeforeResample", C.c_int),
+        ("minMeasurementsBeforeResample", C.c_int),
+        ("landmarkExistencePrior", C.c_double),
+        ("mapExistencePruneThreshold", C.c_double),
+        ("minLogMeasurementLikelihood", C.c_double),
+        ("nParticlesMax", C.c_int),
+        ("maxNDataAssocHypotheses", C.c_uint),
+        ("maxDataAssocLogLikelihoodDiff", C.c_double),
+        ("landmarkCandidateMeasurementSupportDist", C.c_double),
+        ("landmarkCandidateMeasurementCountThreshold", C.c_uint),
+        ("landmarkCandidateCurrentMeasurementCountThreshold", C.c_uint),
+        ("landmarkCandidateMeasurementCheckThreshold", C.c_uint),
+        ("landmarkLockWeight", C.c_double),
+        ("pruningMeasurementsThreshold", C.c_uint),
+    ]
+
+
 class Timing(C.Structure):
     """RBPHDFilter::TimingInfo (include/RBPHDFilter.hpp:152-167), ns."""
     _fields_ = [(n + s, C.c_longlong) for n in
@@ -93,6 +113,7 @@ ABI_SYMBOLS = [
     "set_stream", "bind_weight_sums_buffer", "save_state", "restore_state", "import_aux",
     "set_model_victoriapark", "set_laser_scan", "export_birth_candidates", "import_birth_candidates",
     "update_async", "kernel_time_stats",
+    "default_fastslam_config", "set_fastslam_config", "get_fastslam_config", "fastslam_update",
 ]
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -174,6 +195,27 @@ class CFilter:
         cfg = FilterConfig()
         self._call("get_filter_config", C.byref(cfg))
         return cfg
+
+    # -- FastSLAM on the same handle (include/FastSLAM.hpp) -------------------------------------
+    def default_fastslam_config(self):
+        cfg = FastSlamConfig()
+        fn = self._fn("default_fastslam_config")
+        fn.restype = None
+        fn(C.byref(cfg))
+        return cfg
+
+    def set_fastslam_config(self, cfg):
+        self._call("set_fastslam_config", C.byref(cfg))
+
+    def get_fastslam_config(self):
+        cfg = FastSlamConfig()
+        self._call("get_fastslam_config", C.byref(cfg))
+        return cfg
+
+    def fastslam_update(self, Z):
+        """FastSLAM::updateMap for every particle (:387-418); resampleWithMapCopy stays with the caller."""
+        Z = _f64(Z).reshape(-1, self.dz)
+        self._call("fastslam_update", self._ptr(Z), C.c_int(Z.shape[0]))
 
     def set_model_rngbrg(self, R, Pd, c, rmax, rmin, rbuf):
         m = RngBrgConfig()

@@ -179,3 +179,42 @@ def test_partition_no_eval_points(ob):
     L = np.zeros((0, 3))
     got, _, _ = ob.partition_likelihood(L, np.zeros(0), 0.5, 2.0)
     assert np.isclose(got, 0.5 ** 3 / 2.0)
+
+
+def test_cost_matrix_reduce_keeps_the_optimum(ob):
+    """CostMatrix::reduce (src/CostMatrix.cpp:263-340) as restated for FastSLAM: pairs fixed by the reduction are mutual
+    single possibilities, and the optimum of the full table equals the fixed score plus the optimum of the reduced
+    table (scipy's Hungarian as the independent solver)."""
+    import ctypes as C
+    from scipy.optimize import linear_sum_assignment
+    lib = ob.load()
+    rng = np.random.default_rng(3)
+    lim = -10.0
+    for trial in range(60):
+        n = int(rng.integers(1, 12))
+        T = np.full((n, n), lim)
+        k = int(rng.integers(0, 2 * n + 1))
+        for _ in range(k):
+            T[rng.integers(0, n), rng.integers(0, n)] = rng.uniform(-9.5, 2.0)
+        T0 = T.copy()
+        a_fixed = np.zeros(n, np.int32); iRed = np.zeros(n, np.int32); jRed = np.zeros(n, np.int32)
+        Tc = np.ascontiguousarray(T)
+        nRed = lib.rfsor_cost_matrix_reduce(Tc.ctypes.data_as(C.c_void_p), C.c_int(n), C.c_double(lim),
+                                            a_fixed.ctypes.data_as(C.c_void_p), iRed.ctypes.data_as(C.c_void_p), jRed.ctypes.data_as(C.c_void_p))
+        match = T0 > lim
+        fixed_score = 0.0
+        for i in range(n):
+            j = a_fixed[i]
+            if j >= 0 and match[i, j]:
+                assert match[i].sum() == 1 and match[:, j].sum() == 1
+            if j >= 0:
+                fixed_score += T0[i, j] if match[i, j] else lim
+        r, c = linear_sum_assignment(T0, maximize=True)
+        full = T0[r, c].sum()
+        if nRed > 0:
+            sub = T0[np.ix_(iRed[:nRed], jRed[:nRed])]
+            rr, cc = linear_sum_assignment(sub, maximize=True)
+            red = sub[rr, cc].sum()
+        else:
+            red = 0.0
+        np.testing.assert_allclose(fixed_score + red, full, rtol=0, atol=1e-9)
