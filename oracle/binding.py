@@ -49,6 +49,7 @@ class OracleFilter:
         lib.rfsor_set_stable_sort(obj._h, C.c_int(1 if stable_sort else 0))
         obj.murty_calls = lambda: _long(lib.rfsor_murty_calls, obj._h)
         obj.lonerow_bug_hits = lambda: _long(lib.rfsor_lonerow_bug_hits, obj._h)
+        obj.fs_solver_max_dim = lambda: _long(lib.rfsor_fs_solver_max_dim, obj._h)
         obj.set_stable_sort = lambda on: lib.rfsor_set_stable_sort(obj._h, C.c_int(1 if on else 0))
         return obj
 

@@ -832,6 +832,7 @@ struct FilterBase {
   bool stable_sort = false; /* false: std::sort exactly as the reference (GaussianMixture.hpp:523-534);
                                true : (weight desc, index asc) == what the device path implements */
   long murty_calls = 0, lonerow_bug_hits = 0;
+  long fs_solver_calls = 0, fs_solver_max_dim = 0; /* FastSLAM: reduced tables that needed the assignment solver */
   rfsgpu_timing timing;
   std::string err;
   virtual ~FilterBase() {}
@@ -1341,6 +1342,14 @@ struct FilterT : FilterBase {
         for (int b = 0; b < R.nRed; b++) Cr[a][b] = T[R.iRed[a]][R.jRed[b]];
         rows[a] = Cr[a].data();
       }
+#pragma omp critical(fs_counters)
+      {
+        fs_solver_calls++;
+        /* rows / columns of the reduced table that still have a possibility (the rest only see the floor) */
+        int live = 0;
+        for (int a = 0; a < R.nRed; a++) { bool any = false; for (int b = 0; b < R.nRed; b++) any |= Cr[a][b] > lim; live += any; }
+        if (live > fs_solver_max_dim) fs_solver_max_dim = live;
+      }
       Murty murty(rows.data(), R.nRed);
       std::vector<int> daVar;
       double logLikelihoodSum = 0;
@@ -1701,6 +1710,7 @@ int rfsor_cost_matrix_reduce(double *C, int n, double lim, int *a_fixed, int *iR
   for (int i = 0; i < n; i++) { a_fixed[i] = R.a_fixed[i]; iRed[i] = i < (int)R.iRed.size() ? R.iRed[i] : -1; jRed[i] = i < (int)R.jRed.size() ? R.jRed[i] : -1; }
   return R.nRed;
 }
+long rfsor_fs_solver_max_dim(void *f) { return F_(f)->fs_solver_max_dim; }
 void rfsor_default_fastslam_config(rfsgpu_fastslam_config *c) { orc::fastslam_defaults(c, 0); }
 int rfsor_set_fastslam_config(void *f, const rfsgpu_fastslam_config *c) { F_(f)->fs = *c; return RFSGPU_OK; }
 int rfsor_get_fastslam_config(const void *f, rfsgpu_fastslam_config *c) { *c = reinterpret_cast<const FilterBase *>(f)->fs; return RFSGPU_OK; }

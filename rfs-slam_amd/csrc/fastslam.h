@@ -1,0 +1,395 @@
+// fastslam.h -- FastSLAM 1.0 map update on the RB-PHD engine's state (reference include/FastSLAM.hpp:424-706, one
+// data-association hypothesis).  A particle's mixture is its landmark map, a Gaussian's weight the landmark's log-odds of
+// existence, the birth-candidate lists are the landmark candidates.  2-D range-bearing model.
+//
+// Three kernels per update (one wavefront per particle):
+//  fs_associate_update   in-range landmarks (ballot-compacted, :440-449) -> the log-likelihood table (:468-481) kept
+//                        SPARSE: only entries above the floor are stored (the reference fills an nMZ x nMZ table with the
+//                        floor) -> CostMatrix::reduce (src/CostMatrix.cpp:263-340): a pairing that is the only possibility
+//                        of its row and of its column is fixed; what remains ambiguous (rows and columns with competing
+//                        possibilities) goes through the Hungarian method (murty.h) as a small dense matrix padded with
+//                        the floor -> Kalman correction of the associated landmarks, existence log-odds (:573-604),
+//                        particle weight *= exp(sum of the associated log-likelihoods) (:696-697).
+//                        The reference runs the Hungarian method on the whole reduced table, rows and columns without any
+//                        possibility included; those can only take floor-valued cells, which never trigger an update
+//                        (:584), so the associations that matter are the maximum-weight matching of the ambiguous block --
+//                        identical unless two associations tie exactly.
+//  gm_prune<holes off>   GaussianMixture::prune(mapExistencePruneThreshold) (:611-612).
+//  fs_new_landmarks      unassociated measurements -> candidates / new landmarks and the promotion loop (:615-690), a short
+//                        serial walk on lane 0 (cf. birth.h).
+#pragma once
+#include "common.h"
+#include "murty.h"
+#include "birth.h"
+
+struct FsParams {
+  double prior;        // landmarkExistencePrior_
+  double minLog;       // minLogMeasurementLikelihood_
+  double lockW;        // landmarkLockWeight_
+  double pfa;          // clutterIntensityIntegral(nZ) / nZ   (:561-562)
+  double newW;         // log(prior / (1 - prior))            (:614)
+  double supportD2;    // landmarkCandidateMeasurementSupportDist_^2
+  unsigned countThr, curThr, checkThr;  // landmarkCandidateMeasurementCountThreshold_ / CurrentMeasurementCountThreshold_ / CheckThreshold_
+};
+
+#define FS_AMBIG_MAX 64   // rows / columns of the ambiguous block handled by the in-kernel Hungarian (MURTY_N)
+
+// per-particle scratch of the Hungarian method in HBM: the dense block + hungarian_run's work arrays
+__host__ __device__ inline size_t fs_arena_bytes() {
+  return ((size_t)FS_AMBIG_MAX * FS_AMBIG_MAX * 8 + 3 * FS_AMBIG_MAX * 8 + 6 * FS_AMBIG_MAX * 4 + 8 * FS_AMBIG_MAX + 63) & ~(size_t)63;
+}
+__device__ inline void fs_arena_carve(unsigned char *base, MurtyArena &A, unsigned char *&soln) {
+  unsigned char *p = base;
+  A.Ct = (double *)p; p += (size_t)FS_AMBIG_MAX * FS_AMBIG_MAX * 8;
+  A.lx = (double *)p; p += FS_AMBIG_MAX * 8;
+  A.ly = (double *)p; p += FS_AMBIG_MAX * 8;
+  A.slack = (double *)p; p += FS_AMBIG_MAX * 8;
+  A.xy = (int *)p; p += FS_AMBIG_MAX * 4;
+  A.yx = (int *)p; p += FS_AMBIG_MAX * 4;
+  A.p = (int *)p; p += 2 * FS_AMBIG_MAX * 4;
+  A.queue = (int *)p; p += 2 * FS_AMBIG_MAX * 4;
+  A.S = p; p += FS_AMBIG_MAX;
+  A.T = p; p += FS_AMBIG_MAX;
+  A.NS = p; p += FS_AMBIG_MAX;
+  A.xq = p; p += FS_AMBIG_MAX;
+  A.yq = p; p += FS_AMBIG_MAX;
+  soln = p;
+  A.nodeScore = nullptr; A.nodeParent = nullptr; A.heap = nullptr; A.nodeId = nullptr; A.nodeA = nullptr;
+}
+
+// LDS per wave: in-range list (index, Pd), assignment, row segment, log-weight contribution; sparse table (value, (row<<8)|z)
+__host__ __device__ inline size_t fs_lds_bytes_per_wave(int cap) {
+  return (size_t)cap * (2 + 8 + 2 + 4 + 8) + (size_t)2 * cap * (8 + 4) + 64 * 4 + 2 * FS_AMBIG_MAX * 2 + 64;
+}
+
+// One table cell: fmax(floor, log(N(z; z_exp, S)))  (:476-477; evalGaussianLikelihood uses the RAW difference and maps NaN to 0).
+// `lf` = log(factor) gives a cheap bound: cells more than 1 below the floor in that estimate are not evaluated.
+__device__ __forceinline__ double fs_cell(const MeasOut &mo, double i00, double i01, double i10, double i11, double factor, double lf,
+                                          double z0, double z1, double lim) {
+  const double e0 = z0 - mo.z0, e1 = z1 - mo.z1;
+  const double t0 = e0 * i00 + e1 * i10, t1 = e0 * i01 + e1 * i11;
+  const double md2 = t0 * e0 + t1 * e1;
+  if (-0.5 * md2 - lf < lim - 1.0) return lim;
+  double l = exp(-0.5 * md2) / factor;
+  if (l != l) l = 0.0;
+  return fmax(lim, log(l));
+}
+
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64) void fs_associate_update_kernel(Buffers B, Params P, FsParams F, int cur, int nZ, unsigned char *arena) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double *sZ = reinterpret_cast<double *>(smem_raw);
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  for (int t = threadIdx.x; t < 2 * nZ; t += WPB * 64) sZ[t] = B.Z[t];
+  __syncthreads();
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
+  if (i >= B.N) return;
+  const int cap = B.cap, LCAP = 2 * cap;
+  unsigned char *wb = smem_raw + 2 * RFSGPU_MAX_Z * 8 + (size_t)wave * fs_lds_bytes_per_wave(cap);
+  double *sPd = reinterpret_cast<double *>(wb);                    // [cap] Pd of in-range row k
+  double *sC = sPd + cap;                                           // [cap] log-weight contribution of row k
+  double *sMV = sC + cap;                                           // [LCAP] table values above the floor, (row, z) order
+  unsigned *sMZ = reinterpret_cast<unsigned *>(sMV + LCAP);         // [LCAP] (row << 8) | z
+  unsigned *sSeg = sMZ + LCAP;                                      // [cap] (start << 8) | count of row k's cells
+  int *sColCnt = reinterpret_cast<int *>(sSeg + cap);               // [64] cells above the floor per measurement
+  unsigned short *sIdx = reinterpret_cast<unsigned short *>(sColCnt + 64);  // [cap] mixture index of row k
+  short *sDa = reinterpret_cast<short *>(sIdx + cap);               // [cap] associated measurement of row k, or -1
+  unsigned short *sAR = reinterpret_cast<unsigned short *>(sDa + cap);      // [FS_AMBIG_MAX] ambiguous rows
+
+  const int nM = B.count[i];
+  const unsigned long long zmask = (nZ >= 64) ? ~0ull : ((1ull << nZ) - 1ull);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  double *slab = B.slab[cur];
+  double *pW = plane(slab, cap, i, PL_W), *pWP = plane(slab, cap, i, PL_WP);
+  double *pMX = plane(slab, cap, i, PL_MX), *pMY = plane(slab, cap, i, PL_MY);
+  double *pSXX = plane(slab, cap, i, PL_SXX), *pSXY = plane(slab, cap, i, PL_SXY), *pSYY = plane(slab, cap, i, PL_SYY);
+  PoseReg pr;
+  load_pose(B, P, i, pr);
+  const double lim = F.minLog;
+
+  // ---- A. in-range rows and the cells of the table above the floor ----
+  int nIn = 0, nList = 0;
+  bool overflow = false;
+  sColCnt[lane] = 0;
+  wave_sync();
+  for (int c0 = 0; c0 < nM; c0 += 64) {
+    const int m = c0 + lane;
+    const bool act = m < nM;
+    double mx = 0, my = 0, sxx = 1, sxy = 0, syy = 1;
+    if (act) { mx = pMX[m]; my = pMY[m]; sxx = pSXX[m]; sxy = pSXY[m]; syy = pSYY[m]; }
+    MeasOut mo;
+    rb_measure(P, pr, mx, my, sxx, sxy, syy, mo);
+    bool close;
+    const double pd = rb_pd(P, mo.range, close);
+    const bool inR = act && (pd != 0 || close);  // :446
+    double i00, i01, i10, i11, det;
+    inv2(mo.s00, mo.s01, mo.s10, mo.s11, i00, i01, i10, i11, det);
+    const double factor = pdf_factor2(det);
+    const double lf = log(factor);
+    unsigned long long cells = 0;
+    if (inR && mo.inRange)
+      for (int z = 0; z < nZ; z++)
+        if (fs_cell(mo, i00, i01, i10, i11, factor, lf, sZ[2 * z], sZ[2 * z + 1], lim) > lim) cells |= 1ull << z;
+    const unsigned long long im = __ballot(inR);
+    const int k = nIn + __popcll(im & lt);
+    const int cnt = __popcll(cells);
+    const int off = wave_excl_scan(cnt, lane);
+    const int total = __builtin_amdgcn_readlane(off + cnt, 63);
+    if (inR) {
+      sIdx[k] = (unsigned short)m;
+      sPd[k] = pd;
+      sSeg[k] = ((unsigned)(nList + off) << 8) | (unsigned)cnt;
+      sDa[k] = -1;
+      int pos = nList + off;
+      for (unsigned long long g = cells; g; g &= g - 1) {
+        const int z = __builtin_ctzll(g);
+        if (pos < LCAP) {
+          sMV[pos] = fs_cell(mo, i00, i01, i10, i11, factor, lf, sZ[2 * z], sZ[2 * z + 1], lim);
+          sMZ[pos] = ((unsigned)k << 8) | (unsigned)z;
+          atomicAdd(&sColCnt[z], 1);
+        } else {
+          overflow = true;
+        }
+        pos++;
+      }
+    }
+    nIn += __popcll(im);
+    nList += total;
+  }
+  if (__ballot(overflow) != 0ull) {
+    if (lane == 0) atomicOr(B.err, ERRBIT_CAPACITY);
+    nList = LCAP;
+  }
+  wave_sync();
+
+  // ---- B. CostMatrix::reduce: fix what is unambiguous, collect the ambiguous rows ----
+  int nRa = 0;
+  unsigned long long colAmb = 0;
+  bool tooBig = false;
+  for (int k0 = 0; k0 < nIn; k0 += 64) {
+    const int k = k0 + lane;
+    bool amb = false;
+    if (k < nIn) {
+      const unsigned seg = sSeg[k];
+      const int st = (int)(seg >> 8), cnt = (int)(seg & 0xffu);
+      if (cnt == 1) {
+        const int z = (int)(sMZ[st] & 0xffu);
+        if (sColCnt[z] == 1) sDa[k] = (short)z;  // the only possibility of the row and of the column
+        else amb = true;
+      } else if (cnt > 1) {
+        amb = true;
+      }
+      if (amb)
+        for (int q = st; q < st + cnt && q < nList; q++) colAmb |= 1ull << (sMZ[q] & 0xffu);
+    }
+    const unsigned long long am = __ballot(amb);
+    if (amb) {
+      const int a = nRa + __popcll(am & lt);
+      if (a < FS_AMBIG_MAX) sAR[a] = (unsigned short)k;
+      else tooBig = true;
+    }
+    nRa += __popcll(am);
+  }
+  colAmb = wave_or_u64(colAmb);
+  const int nCa = __popcll(colAmb);
+  if (__ballot(tooBig) != 0ull || nRa > FS_AMBIG_MAX) {
+    if (lane == 0) atomicOr(B.err, ERRBIT_MURTY);  // more competing associations than the in-kernel Hungarian holds: refuse
+    nRa = 0;
+  }
+  wave_sync();
+
+  // ---- C. Hungarian method on the ambiguous block (dense, padded with the floor) ----
+  if (nRa > 0) {
+    const int nA = nRa > nCa ? nRa : nCa;
+    MurtyArena A;
+    unsigned char *soln;
+    fs_arena_carve(arena + (size_t)i * fs_arena_bytes(), A, soln);
+    for (int t = lane; t < nA * nA; t += 64) A.Ct[t] = lim;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    wave_sync();
+    for (int a = lane; a < nRa; a += 64) {
+      const unsigned seg = sSeg[sAR[a]];
+      const int st = (int)(seg >> 8), cnt = (int)(seg & 0xffu);
+      for (int q = st; q < st + cnt && q < nList; q++) {
+        const int z = (int)(sMZ[q] & 0xffu);
+        const int b = __popcll(colAmb & ((1ull << z) - 1ull));
+        A.Ct[a * nA + b] = sMV[q];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    wave_sync();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane == 0) {
+      double cost;
+      if (hungarian_run(A.Ct, nA, nA, soln, &cost, A)) {
+        for (int a = 0; a < nRa; a++) {
+          const int b = soln[a];
+          if (b < nCa && A.Ct[a * nA + b] > lim) sDa[sAR[a]] = (short)nth_bit(colAmb, b);
+        }
+      } else {
+        atomicOr(B.err, ERRBIT_MURTY);  // the reference would leave the particle untouched (:511-515); refused loudly here
+      }
+    }
+    wave_sync();
+  }
+
+  // ---- D. Kalman correction of the associated landmarks, existence log-odds (:573-604) ----
+  unsigned long long used = 0;
+  int nUpd = 0;
+  for (int k0 = 0; k0 < nIn; k0 += 64) {
+    const int k = k0 + lane;
+    bool upd = false;
+    double val = 0.0;
+    if (k < nIn) {
+      const int m = sIdx[k];
+      const int z = sDa[k];
+      const double pd = sPd[k];
+      const double w = pW[m];
+      if (z >= 0) {
+        const unsigned seg = sSeg[k];
+        const int st = (int)(seg >> 8), cnt = (int)(seg & 0xffu);
+        bool found = false;
+        for (int q = st; q < st + cnt && q < nList; q++)
+          if ((int)(sMZ[q] & 0xffu) == z) { val = sMV[q]; found = true; }
+        if (found) {  // likelihoodTable[m][z] > floor (:584) -> kfs_.correct (KalmanFilter.hpp:209-259)
+          const double mx = pMX[m], my = pMY[m], sxx = pSXX[m], sxy = pSXY[m], syy = pSYY[m];
+          MeasOut mo;
+          rb_measure(P, pr, mx, my, sxx, sxy, syy, mo);
+          const double e0 = sZ[2 * z] - mo.z0;
+          const double w1 = wrap_pi(sZ[2 * z + 1] - mo.z1);
+          const bool gateR = !(P.kfRange > 0 && fabs(e0) > P.kfRange), gateB = !(P.kfBearing > 0 && fabs(w1) > P.kfBearing);
+          if (mo.inRange && gateR && gateB) {
+            double i00, i01, i10, i11, det;
+            inv2(mo.s00, mo.s01, mo.s10, mo.s11, i00, i01, i10, i11, det);
+            const double t00 = sxx * mo.h00 + sxy * mo.h01, t01 = sxx * mo.h10 + sxy * mo.h11;
+            const double t10 = sxy * mo.h00 + syy * mo.h01, t11 = sxy * mo.h10 + syy * mo.h11;
+            const double k00 = t00 * i00 + t01 * i10, k01 = t00 * i01 + t01 * i11;
+            const double k10 = t10 * i00 + t11 * i10, k11 = t10 * i01 + t11 * i11;
+            const double kh00 = k00 * mo.h00 + k01 * mo.h10, kh01 = k00 * mo.h01 + k01 * mo.h11;
+            const double kh10 = k10 * mo.h00 + k11 * mo.h10, kh11 = k10 * mo.h01 + k11 * mo.h11;
+            const double a00 = 1.0 - kh00, a01 = 0.0 - kh01, a10 = 0.0 - kh10, a11 = 1.0 - kh11;
+            const double q00 = a00 * sxx + a01 * sxy, q01 = a00 * sxy + a01 * syy;
+            const double q10 = a10 * sxx + a11 * sxy, q11 = a10 * sxy + a11 * syy;
+            pMX[m] = mx + (k00 * e0 + k01 * w1);
+            pMY[m] = my + (k10 * e0 + k11 * w1);
+            pSXX[m] = (q00 + q00) / 2;
+            pSXY[m] = (q01 + q10) / 2;
+            pSYY[m] = (q11 + q11) / 2;
+            upd = true;
+          }
+        }
+      }
+      double pe;
+      if (upd) {
+        used |= 1ull << z;
+        pe = ((1 - pd) * F.pfa * F.prior + pd * F.prior) / (F.pfa + (1 - F.pfa) * pd * F.prior);
+      } else {
+        pe = ((1 - pd) * F.prior) / ((1 - F.prior) + (1 - pd) * F.prior);
+        if (w > F.lockW) pe = 0.5;
+      }
+      pWP[m] = w;
+      pW[m] = w + log(pe / (1 - pe));
+      sC[k] = upd ? val : 0.0;
+    }
+    nUpd += __popcll(__ballot(upd));
+  }
+  used = wave_or_u64(used);
+  wave_sync();
+  if (lane == 0) {
+    double logw = 0.0;  // the reference adds the associated cells in landmark order (:588)
+    for (int k = 0; k < nIn; k++) logw += sC[k];  // (rows without an update hold 0)
+    B.weight[i] = B.weight[i] * exp(logw);
+    B.unusedMask[i] = (~used) & zmask;
+    B.nInFov[i] = nUpd;
+  }
+}
+
+// GaussianMixture::addGaussian(candidate, w, true) (:267-284) -- no process noise here (the update adds none)
+__device__ inline bool fs_append(const Buffers &B, int cur, int i, int &n, const Cand<2> &k, double w) {
+  if (n >= B.cap) return false;
+  double *slab = B.slab[cur];
+  plane(slab, B.cap, i, PL_W)[n] = w;
+  plane(slab, B.cap, i, PL_WP)[n] = 0.0;
+  plane(slab, B.cap, i, PL_MX)[n] = k.x[0];
+  plane(slab, B.cap, i, PL_MY)[n] = k.x[1];
+  plane(slab, B.cap, i, PL_SXX)[n] = k.S[0];
+  plane(slab, B.cap, i, PL_SXY)[n] = k.S[1];
+  plane(slab, B.cap, i, PL_SYY)[n] = k.S[3];
+  n++;
+  return true;
+}
+
+// New landmarks from the measurements no landmark took (:615-690): one thread per particle.
+__global__ __launch_bounds__(64) void fs_new_landmarks_kernel(Buffers B, Params P, FsParams F, int cur, int nZ) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B.N) return;
+  int n = B.count[i];
+  int nc = B.candCount[i];
+  const unsigned nfov = (unsigned)B.nInFov[i];
+  PoseReg pr;
+  load_pose(B, P, i, pr);
+  bool fail = false, listFull = false;
+  int *sup = B.candSup + (size_t)i * RFSGPU_MAX_CANDIDATES, *chk = B.candChk + (size_t)i * RFSGPU_MAX_CANDIDATES;
+  const unsigned long long um = B.unusedMask[i];
+  for (int zi = 0; zi < nZ; zi++) {  // measurements in index order (:615)
+    if (!((um >> zi) & 1ull)) continue;
+    const double *z = B.Z + (size_t)2 * zi;
+    bool isNew = true;
+    for (int c = 0; c < nc; c++) {
+      Cand<2> k;
+      cand_load<2>(B, i, c, k);
+      const double d2 = cand_support_md2<2>(P, pr, k, z);
+      if (d2 <= F.supportD2) {
+        cand_correct<2>(P, pr, k, z);
+        cand_store<2>(B, i, c, k);
+        sup[c]++;
+        isNew = false;
+        break;
+      }
+    }
+    if (isNew) {
+      Cand<2> k;
+      cand_inverse<2>(P, pr, z, k);
+      if (F.countThr == 1u || nfov <= F.curThr) {
+        if (!fs_append(B, cur, i, n, k, F.newW)) fail = true;
+      } else if (nc < RFSGPU_MAX_CANDIDATES) {
+        cand_store<2>(B, i, nc, k);
+        sup[nc] = 1;
+        chk[nc] = 0;
+        nc++;
+      } else {
+        listFull = true;
+      }
+    }
+    // the promotion loop runs once per unassociated measurement (:656-688), with the ++end() wrap of libstdc++'s list
+    int k = 0;
+    while (k < nc) {
+      chk[k]++;
+      bool atEnd = false;
+      while ((unsigned)sup[k] >= F.countThr || (unsigned)chk[k] > F.checkThr || nfov <= F.curThr) {
+        if ((unsigned)sup[k] >= F.countThr || nfov <= F.curThr) {
+          Cand<2> c;
+          cand_load<2>(B, i, k, c);
+          if (!fs_append(B, cur, i, n, c, F.newW * chk[k])) fail = true;
+        }
+        for (int t = k; t + 1 < nc; t++) {  // erase(it): shift the tail down, list order kept
+          Cand<2> c;
+          cand_load<2>(B, i, t + 1, c);
+          cand_store<2>(B, i, t, c);
+          sup[t] = sup[t + 1];
+          chk[t] = chk[t + 1];
+        }
+        nc--;
+        if (k < nc) chk[k]++;
+        else { atEnd = true; break; }
+      }
+      k = atEnd ? 0 : k + 1;
+    }
+  }
+  B.unusedMask[i] = 0ull;
+  B.candCount[i] = nc;
+  B.count[i] = n;
+  if (fail) atomicOr(B.err, ERRBIT_CAPACITY);
+  if (listFull) atomicOr(B.err, ERRBIT_BIRTHLIST);
+}

@@ -682,7 +682,8 @@ __global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(MERGE_
 }
 
 // LDS per wave: keys[cap] doubles
-template <int WPB>
+// NEG_IS_HOLE: the RB-PHD mixtures mark merged-away entries with w = -1; FastSLAM's log-odds weights are legitimately negative.
+template <int WPB, bool NEG_IS_HOLE = true>
 __global__ __launch_bounds__(WPB * 64) void gm_prune_kernel(Buffers B, Params P, int src, int dst) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int wave = threadIdx.x >> 6;
@@ -701,7 +702,7 @@ __global__ __launch_bounds__(WPB * 64) void gm_prune_kernel(Buffers B, Params P,
   int kept = 0;
   for (int m = lane; m < N; m += 64) {
     const double wm = keys[m];
-    const bool keep = (wm >= t) && (wm >= 0.0);  // holes carry -1
+    const bool keep = (wm >= t) && (!NEG_IS_HOLE || wm >= 0.0);  // holes carry -1
     int rank = 0;
     if (keep) {
       for (int j = 0; j < N; j++) {

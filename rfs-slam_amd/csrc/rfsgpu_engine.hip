@@ -19,6 +19,7 @@
 #include "murty.h"
 #include "vp.h"
 #include "birth.h"
+#include "fastslam.h"
 
 namespace {
 
@@ -69,6 +70,10 @@ struct rfsgpu_filter {
   hipEvent_t ring[RFSGPU_ASYNC_RING][5] = {};  // step phases: 0 start, 1 map update done, 2 weighting (+Murty) done, 3 merge done, 4 weighting kernel done
   bool ringHasMid[RFSGPU_ASYNC_RING] = {};
   bool ringFused[RFSGPU_ASYNC_RING] = {};   // the step ran as ONE kernel: only events 0 and 3 were recorded
+  rfsgpu_fastslam_config fs;          // FastSLAM::Config (rfsgpu_fastslam_update)
+  unsigned char *fsArena = nullptr;   // per-particle Hungarian scratch (allocated on first use)
+  bool holes = false;       // between rfsgpu_merge and rfsgpu_prune merged-away entries sit in the slab with w = -1; at any other
+                            // time a negative weight is a value (FastSLAM's log-odds) and every stored entry counts
   bool fuseSteps = true;    // rfsgpu_update_async uses phd_step_fused_kernel (2-D model); RFSGPU_FUSED_STEP=0 turns it off
   hipEvent_t evAfterWeightKernel = nullptr;   // where launch_weighting drops its mid-phase event (async steps only)
   int ringCount = 0;        // async steps recorded since the last harvest
@@ -198,6 +203,8 @@ int rfsgpu_create(rfsgpu_filter **out, int model, int n_particles, int device_id
   f->model = model;
   f->D = (model == RFSGPU_MODEL_VICTORIAPARK_3D) ? 3 : 2;
   f->cap = ((gm_capacity + 63) / 64) * 64;
+  rfsgpu_default_fastslam_config(&f->fs);
+  f->fs.nParticlesMax = 3 * n_particles;
   { const char *e = getenv("RFSGPU_FUSED_STEP"); if (e && e[0] == '0') f->fuseSteps = false; }
   if (f->cap > 2048) { delete f; return RFSGPU_ERR_INVALID; }
   auto bail = [&](int code) { rfsgpu_destroy(f); return code; };
@@ -279,7 +286,7 @@ void rfsgpu_destroy(rfsgpu_filter *f) {
   Buffers &B = f->B;
   hipFree(f->snapSlab); hipFree(f->snapWeight); hipFree(f->snapCount); hipFree(f->snapFov); hipFree(f->snapUnused);
   hipFree(B.slab[0]); hipFree(B.slab[1]); hipFree(B.count); hipFree(B.pose); hipFree(B.poseCov); hipFree(B.weight);
-  hipFree(B.unusedMask); hipFree(B.nInFov); hipFree(B.err); hipFree(B.Z); hipFree(f->ownSums); hipFree(f->dSrcSlot);
+  hipFree(B.unusedMask); hipFree(B.nInFov); hipFree(B.err); hipFree(B.Z); hipFree(f->ownSums); hipFree(f->dSrcSlot); if (f->fsArena) hipFree(f->fsArena);
   hipFree(B.scan); hipFree(B.candMean); hipFree(B.candCov); hipFree(B.candSup); hipFree(B.candChk); hipFree(B.candCount);
   murty_free(f->Q, f->MS);
   if (f->hErr) hipHostFree(f->hErr);
@@ -397,9 +404,13 @@ int rfsgpu_get_weights(rfsgpu_filter *f, double *w) {
 int rfsgpu_gm_sizes(rfsgpu_filter *f, int *sizes) {
   CHECK_HANDLE(f);
   hipSetDevice(f->device);
-  valid_count_kernel<<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->cur, f->dSrcSlot);  // dSrcSlot doubles as int scratch
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(sizes, f->dSrcSlot, (size_t)f->N * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+  if (f->holes) {
+    valid_count_kernel<<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->cur, f->dSrcSlot);  // dSrcSlot doubles as int scratch
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(sizes, f->dSrcSlot, (size_t)f->N * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+  } else {
+    HIPCHK(hipMemcpyAsync(sizes, f->B.count, (size_t)f->N * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+  }
   HIPCHK(hipStreamSynchronize(f->stream));
   return RFSGPU_OK;
 }
@@ -431,7 +442,7 @@ int rfsgpu_gm_size(rfsgpu_filter *f, int slot) {
   int n = 0;
   if (fetch_particle(f, slot, pl, n) != RFSGPU_OK) return -1;
   int k = 0;
-  for (int m = 0; m < n; m++) if (pl[m] >= 0) k++;  // plane 0 = weight
+  for (int m = 0; m < n; m++) if (!f->holes || pl[m] >= 0) k++;  // plane 0 = weight
   return k;
 }
 
@@ -446,7 +457,7 @@ int rfsgpu_export_gm(rfsgpu_filter *f, int slot, int max_n, int *n_out, double *
   const int D = f->D;
   int k = 0;
   for (int m = 0; m < n; m++) {
-    if (pl[m] < 0) continue;  // hole left by merge
+    if (f->holes && pl[m] < 0) continue;  // hole left by merge
     if (k < max_n) {
       if (w) w[k] = pl[m];
       if (w_prev) w_prev[k] = pl[1 * c + m];
@@ -724,6 +735,7 @@ int rfsgpu_importance_weighting(rfsgpu_filter *f) {
 }
 int rfsgpu_merge(rfsgpu_filter *f) {
   CHECK_HANDLE(f);
+  f->holes = true;
   long long t0 = now_ns();
   hipSetDevice(f->device);
   HIPCHK(hipEventRecord(f->ev[EV_W1], f->stream));
@@ -737,6 +749,7 @@ int rfsgpu_merge(rfsgpu_filter *f) {
 }
 int rfsgpu_prune(rfsgpu_filter *f) {
   CHECK_HANDLE(f);
+  f->holes = false;
   long long t0 = now_ns();
   hipSetDevice(f->device);
   HIPCHK(hipEventRecord(f->ev[EV_MG1], f->stream));
@@ -752,6 +765,7 @@ int rfsgpu_prune(rfsgpu_filter *f) {
 // All four phases back to back on the stream, ONE host sync at the end (RBPHDFilter::update body :444-523).
 int rfsgpu_update(rfsgpu_filter *f, const double *z, int n_z) {
   CHECK_HANDLE(f);
+  f->holes = false;
   if (n_z == 0) return RFSGPU_OK;  // :450-452
   long long t0 = now_ns();
   int rc = stage_measurements(f, z, n_z);
@@ -807,6 +821,7 @@ static void harvest_async(rfsgpu_filter *f) {
 
 int rfsgpu_update_async(rfsgpu_filter *f, const double *z, int n_z) {
   CHECK_HANDLE(f);
+  f->holes = false;
   if (n_z == 0) return RFSGPU_OK;  // :450-452
   long long t0 = now_ns();
   if (f->ringCount >= RFSGPU_ASYNC_RING) {  // ring full: drain (one sync per RFSGPU_ASYNC_RING steps)
@@ -1064,6 +1079,79 @@ int rfsgpu_debug_per_particle(rfsgpu_filter *f, long long *out4n) {
   return RFSGPU_OK;
 }
 #endif
+
+// ---- FastSLAM 1.0 (include/FastSLAM.hpp) on the same handle ----------------------------------------------------------
+void rfsgpu_default_fastslam_config(rfsgpu_fastslam_config *c) {  // constructor defaults, :243-257 (nParticlesMax = 3n is set per handle)
+  if (!c) return;
+  c->minUpdatesBeforeResample = 1;
+  c->minMeasurementsBeforeResample = 1;
+  c->landmarkExistencePrior = 0.5;
+  c->mapExistencePruneThreshold = -3.0;
+  c->minLogMeasurementLikelihood = -10.0;
+  c->nParticlesMax = 0;
+  c->maxNDataAssocHypotheses = 1;
+  c->maxDataAssocLogLikelihoodDiff = 5;
+  c->landmarkCandidateMeasurementSupportDist = 1;
+  c->landmarkCandidateMeasurementCountThreshold = 1;
+  c->landmarkCandidateCurrentMeasurementCountThreshold = 1;
+  c->landmarkCandidateMeasurementCheckThreshold = 2;
+  c->landmarkLockWeight = 10;
+  c->pruningMeasurementsThreshold = 0;
+}
+int rfsgpu_set_fastslam_config(rfsgpu_filter *f, const rfsgpu_fastslam_config *cfg) {
+  CHECK_HANDLE(f);
+  if (!cfg) return RFSGPU_ERR_INVALID;
+  f->fs = *cfg;
+  return RFSGPU_OK;
+}
+int rfsgpu_get_fastslam_config(const rfsgpu_filter *f, rfsgpu_fastslam_config *cfg) {
+  if (!f || !cfg) return RFSGPU_ERR_INVALID;
+  *cfg = f->fs;
+  return RFSGPU_OK;
+}
+int rfsgpu_fastslam_update(rfsgpu_filter *f, const double *z, int n_z) {
+  CHECK_HANDLE(f);
+  f->holes = false;
+  if (n_z == 0) return RFSGPU_OK;  // :401-402
+  if (f->D != 2) return fail(f, RFSGPU_ERR_UNSUPPORTED, "FastSLAM is built for the 2-D range-bearing model");
+  if (f->fs.maxNDataAssocHypotheses != 1) return fail(f, RFSGPU_ERR_UNSUPPORTED, "multi-hypothesis FastSLAM (maxNDataAssocHypotheses > 1) is not built");
+  int rc = stage_measurements(f, z, n_z);
+  if (rc != RFSGPU_OK) return rc;
+  hipSetDevice(f->device);
+  if (!f->fsArena) HIPCHK(hipMalloc(&f->fsArena, (size_t)f->N * fs_arena_bytes()));
+  FsParams F;
+  F.prior = f->fs.landmarkExistencePrior;
+  F.minLog = f->fs.minLogMeasurementLikelihood;
+  F.lockW = f->fs.landmarkLockWeight;
+  F.pfa = (f->P.clutter * (2 * RFS_PI * (f->P.rmax - f->P.rmin))) / n_z;  // clutterIntensityIntegral(nZ) / nZ (:561-562)
+  F.newW = log(F.prior / (1 - F.prior));
+  F.supportD2 = f->fs.landmarkCandidateMeasurementSupportDist * f->fs.landmarkCandidateMeasurementSupportDist;
+  F.countThr = f->fs.landmarkCandidateMeasurementCountThreshold;
+  F.curThr = f->fs.landmarkCandidateCurrentMeasurementCountThreshold;
+  F.checkThr = f->fs.landmarkCandidateMeasurementCheckThreshold;
+  const size_t per = fs_lds_bytes_per_wave(f->cap);
+  const size_t b2 = (size_t)(2 * RFSGPU_MAX_Z * 8) + 2 * per, b1 = (size_t)(2 * RFSGPU_MAX_Z * 8) + per;
+  if (b2 <= 64 * 1024) {
+    if ((rc = set_lds(f, fs_associate_update_kernel<2>, b2)) != RFSGPU_OK) return rc;
+    fs_associate_update_kernel<2><<<(f->N + 1) / 2, 128, b2, f->stream>>>(f->B, f->P, F, f->cur, n_z, f->fsArena);
+  } else {
+    if ((rc = set_lds(f, fs_associate_update_kernel<1>, b1)) != RFSGPU_OK) return rc;
+    fs_associate_update_kernel<1><<<f->N, 64, b1, f->stream>>>(f->B, f->P, F, f->cur, n_z, f->fsArena);
+  }
+  HIPCHK(hipGetLastError());
+  if ((unsigned)n_z >= f->fs.pruningMeasurementsThreshold) {  // :611-612
+    Params Pp = f->P;
+    Pp.pruneT = f->fs.mapExistencePruneThreshold;
+    const size_t pb = (size_t)f->cap * 8;
+    if ((rc = set_lds(f, (gm_prune_kernel<4, false>), 4 * pb)) != RFSGPU_OK) return rc;
+    gm_prune_kernel<4, false><<<(f->N + 3) / 4, 256, 4 * pb, f->stream>>>(f->B, Pp, f->cur, f->cur ^ 1);
+    HIPCHK(hipGetLastError());
+    f->cur ^= 1;
+  }
+  fs_new_landmarks_kernel<<<(f->N + 63) / 64, 64, 0, f->stream>>>(f->B, f->P, F, f->cur, n_z);
+  HIPCHK(hipGetLastError());
+  return check_device_errors(f);
+}
 
 int rfsgpu_mat_perm(const double *A, int n, int batch, double *out, int device_id) {
   if (!A || !out || n < 1 || n > 24 || batch < 0) return RFSGPU_ERR_INVALID;

@@ -368,6 +368,94 @@ def test_fused_merge_prune_stress_through_update(pkg, ob, sc, kind, M):
     compare_maps(sc, dev, orc, scen["n"], ordered=True)
 
 
+# ---- FastSLAM 1.0 on the same handle (include/FastSLAM.hpp) -----------------------------------------------------
+
+def _fastslam_pair(pkg, ob, sc, scen, cap=256, **cfg_over):
+    dev, orc = make_pair(pkg, ob, sc, scen, cap=cap)
+    for f in (dev, orc):
+        for i in range(scen["n"]):                       # landmark maps: weights are log-odds of existence
+            f.import_gm(i, np.log(scen["w"][i] / (1 - scen["w"][i] * 0.5)), scen["mean"][i], scen["cov"][i])
+        cfg = f.default_fastslam_config()
+        for k, v in cfg_over.items():
+            setattr(cfg, k, v)
+        f.set_fastslam_config(cfg)
+    return dev, orc
+
+
+def _compare_fastslam(sc, dev, orc, n):
+    compare_weights(dev, orc)
+    compare_maps(sc, dev, orc, n, ordered=True)
+    for i in range(n):
+        md, cd, sd, kd = dev.export_birth_candidates(i)
+        mo, co, so, ko = orc.export_birth_candidates(i)
+        assert list(sd) == list(so) and list(kd) == list(ko), i
+        np.testing.assert_allclose(md, mo, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(cd, (co + np.swapaxes(co, -1, -2)) / 2, rtol=1e-8, atol=1e-12)
+
+
+FS_SCENARIOS = [
+    dict(n_particles=16, n_landmarks=12, n_z=5, seed=61),
+    dict(n_particles=24, n_landmarks=70, n_z=19, seed=62),                       # ragged: 70 = 64 + 6
+    dict(n_particles=32, n_landmarks=200, n_z=30, seed=63, rmax=25.0),           # 200 landmarks over a 25 m disc
+    dict(n_particles=12, n_landmarks=130, n_z=30, seed=64, frac_in_fov=0.25, rmax=12.0),    # most landmarks out of range
+    dict(n_particles=8, n_landmarks=3, n_z=20, seed=65),                          # more measurements than landmarks
+    dict(n_particles=6, n_landmarks=40, n_z=64, seed=66),                         # max measurements
+]
+
+
+@pytest.mark.parametrize("kw", FS_SCENARIOS)
+def test_fastslam_update_matches_oracle(pkg, ob, sc, kw):
+    """FastSLAM::updateMap (in-range table, CostMatrix::reduce + Hungarian association, KF correction, existence log-odds,
+    pruning, new landmarks) on the device vs the oracle, three predict/update/normalise cycles."""
+    scen = sc.make_scenario(**kw)
+    dev, orc = _fastslam_pair(pkg, ob, sc, scen)
+    rng = np.random.default_rng(kw["seed"])
+    for step in range(3):
+        Z = scen["Z"] + rng.normal(0, 2e-3, scen["Z"].shape)
+        for f in (dev, orc):
+            f.predict_map(False)             # FastSLAM::predict: staticStep on every landmark (:376-383)
+            f.fastslam_update(Z)
+        _compare_fastslam(sc, dev, orc, scen["n"])
+        for f in (dev, orc):
+            s = f.weight_sums()
+            f.normalize_weights(s[0])
+
+
+def test_fastslam_candidate_lists_and_ambiguous_associations(pkg, ob, sc):
+    """Landmark candidates that need several supporting measurements, and a loose likelihood floor so that rows and columns
+    of the table compete (the in-kernel Hungarian path)."""
+    scen = sc.make_scenario(20, 60, 24, seed=71)
+    dev, orc = _fastslam_pair(pkg, ob, sc, scen, landmarkCandidateMeasurementCountThreshold=3, landmarkCandidateMeasurementCheckThreshold=4,
+                              landmarkCandidateCurrentMeasurementCountThreshold=0, landmarkCandidateMeasurementSupportDist=3.0,
+                              minLogMeasurementLikelihood=-60.0, pruningMeasurementsThreshold=5)
+    rng = np.random.default_rng(2)
+    seen = 0
+    for step in range(5):
+        Z = scen["Z"] + rng.normal(0, 5e-3, scen["Z"].shape)
+        for f in (dev, orc):
+            f.predict_map(False)
+            f.fastslam_update(Z)
+        _compare_fastslam(sc, dev, orc, scen["n"])
+        seen += sum(len(orc.export_birth_candidates(i)[2]) for i in range(scen["n"]))
+        for f in (dev, orc):
+            s = f.weight_sums()
+            f.normalize_weights(s[0])
+    assert seen > 0, "no landmark candidate was ever queued"
+    assert orc.fs_solver_max_dim() >= 2, "no particle had competing associations (the Hungarian path was not exercised)"
+
+
+def test_fastslam_refuses_multi_hypothesis(pkg, sc):
+    scen = sc.make_scenario(4, 5, 3, seed=1)
+    dev = pkg.RBPHDFilter(4, gm_capacity=64)
+    sc.load_scenario(dev, scen)
+    cfg = dev.default_fastslam_config()
+    cfg.maxNDataAssocHypotheses = 3
+    dev.set_fastslam_config(cfg)
+    with pytest.raises(pkg.capi.EngineError) as e:
+        dev.fastslam_update(scen["Z"])
+    assert e.value.status == pkg.capi.ERR_UNSUPPORTED
+
+
 # ---- Victoria Park model (3-D landmarks, scan-based Pd, birth-candidate lists) -----------------------------------------
 
 def make_vp_pair(pkg, ob, sc, scen, cap=192):
