@@ -39,6 +39,7 @@ def build(force=False, verbose=False, extra_flags=()):
 
 
 SIM = os.path.join(HERE, "host", "rbphdslam2d_sim")
+SIM_FASTSLAM = os.path.join(HERE, "host", "fastslam2d_sim")
 
 
 def build_host(force=False, verbose=False):
@@ -52,4 +53,9 @@ def build_host(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    # the same simulator around the FastSLAM filter class (reference: src/fastslam2dSim.cpp)
+    cmd2 = [c for c in cmd[:-1]] + [SIM_FASTSLAM, "-DUSE_FASTSLAM"]
+    if verbose:
+        print(" ".join(cmd2))
+    subprocess.check_call(cmd2)
     return SIM

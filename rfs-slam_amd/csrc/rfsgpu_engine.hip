@@ -1129,6 +1129,8 @@ int rfsgpu_fastslam_update(rfsgpu_filter *f, const double *z, int n_z) {
   F.countThr = f->fs.landmarkCandidateMeasurementCountThreshold;
   F.curThr = f->fs.landmarkCandidateCurrentMeasurementCountThreshold;
   F.checkThr = f->fs.landmarkCandidateMeasurementCheckThreshold;
+  const long long t0 = now_ns();
+  HIPCHK(hipEventRecord(f->ev[EV_UM0], f->stream));
   const size_t per = fs_lds_bytes_per_wave(f->cap);
   const size_t b2 = (size_t)(2 * RFSGPU_MAX_Z * 8) + 2 * per, b1 = (size_t)(2 * RFSGPU_MAX_Z * 8) + per;
   if (b2 <= 64 * 1024) {
@@ -1139,6 +1141,7 @@ int rfsgpu_fastslam_update(rfsgpu_filter *f, const double *z, int n_z) {
     fs_associate_update_kernel<1><<<f->N, 64, b1, f->stream>>>(f->B, f->P, F, f->cur, n_z, f->fsArena);
   }
   HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(f->ev[EV_UM1], f->stream));
   if ((unsigned)n_z >= f->fs.pruningMeasurementsThreshold) {  // :611-612
     Params Pp = f->P;
     Pp.pruneT = f->fs.mapExistencePruneThreshold;
@@ -1150,7 +1153,15 @@ int rfsgpu_fastslam_update(rfsgpu_filter *f, const double *z, int n_z) {
   }
   fs_new_landmarks_kernel<<<(f->N + 63) / 64, 64, 0, f->stream>>>(f->B, f->P, F, f->cur, n_z);
   HIPCHK(hipGetLastError());
-  return check_device_errors(f);
+  HIPCHK(hipEventRecord(f->ev[EV_PR1], f->stream));
+  rc = check_device_errors(f);  // syncs
+  // FastSLAM::TimingInfo buckets folded onto the handle's: data association + KF + weighting (one kernel) under
+  // mapUpdate / mapUpdate_kf, prune + new landmarks ("map management", :606-693) under mapPrune
+  accumulate(f->ev[EV_UM0], f->ev[EV_UM1], f->timing.mapUpdate_wall, &f->lastKernelNs[0]);
+  f->timing.mapUpdate_kf_wall = f->timing.mapUpdate_wall;
+  accumulate(f->ev[EV_UM1], f->ev[EV_PR1], f->timing.mapPrune_wall, &f->lastKernelNs[3]);
+  f->timing.mapUpdate_cpu += now_ns() - t0;
+  return rc;
 }
 
 int rfsgpu_mat_perm(const double *A, int n, int batch, double *out, int device_id) {

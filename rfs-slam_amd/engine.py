@@ -127,6 +127,42 @@ class RBPHDFilter(capi.CFilter):
         return True
 
 
+class FastSLAM(RBPHDFilter):
+    """rfs::FastSLAM (include/FastSLAM.hpp) for the 2-D range-bearing model on the same engine: the handle's mixtures are
+    the landmark maps (weights = log-odds of existence).  FastSLAM 1.0 only: maxNDataAssocHypotheses must stay 1."""
+
+    def __init__(self, n_particles, device_id=0, gm_capacity=512):
+        super().__init__(n_particles, device_id=device_id, gm_capacity=gm_capacity)
+        self.fs_config = self.default_fastslam_config()
+        self.fs_config.nParticlesMax = 3 * n_particles
+
+    # FastSLAM::predict (:362-385), map part: staticStep on every landmark, no births
+    def predict_map(self, add_birth=False):
+        super().predict_map(False)
+
+    # FastSLAM::update (:387-421) + resampleWithMapCopy (:708-735)
+    def update_and_resample(self, Z, u01_fn=np.random.random):
+        self.apply_config()
+        self.set_fastslam_config(self.fs_config)
+        self.nUpdatesSinceResample += 1
+        Z = np.asarray(Z, dtype=np.float64).reshape(-1, self.dz)
+        if Z.shape[0] == 0:
+            return False
+        self.nMeasurementsSinceResample += Z.shape[0]
+        self.fastslam_update(Z)
+        self.resampleOccured = False
+        if (self.nUpdatesSinceResample >= self.fs_config.minUpdatesBeforeResample and
+                self.nMeasurementsSinceResample >= self.fs_config.minMeasurementsBeforeResample):
+            self.resampleOccured = self.resample(u01_fn)      # landmark candidates travel with their particle
+        if self.resampleOccured:
+            self.nUpdatesSinceResample = 0
+            self.nMeasurementsSinceResample = 0
+        else:
+            s = self.weight_sums()
+            self.normalize_weights(s[0])
+        return self.resampleOccured
+
+
 def systematic_resample_plan(w, u01):
     """Systematic sampling + slot assignment of ParticleFilter::resample (ParticleFilter.hpp:419-479).
     Returns src_slot[k]: which (kept-in-place) particle slot k copies; k itself when it is kept."""

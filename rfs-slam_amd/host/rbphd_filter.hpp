@@ -195,7 +195,7 @@ class RBPHDFilter2d {
   }
   rfsgpu_filter *handle() { return h_; }
 
- private:
+ protected:
   rfsgpu_filter *h_ = nullptr;
   int n_;
   MotionModel_Odometry2d motion_;
@@ -309,6 +309,83 @@ class RBPHDFilter2d {
     for (int i = 0; i < n; i++) weights_[i] = 1.0;
     weightsStale_ = false;
     return true;
+  }
+};
+
+
+// rfs::FastSLAM<MotionModel_Odometry2d, StaticProcessModel<Landmark2d>, MeasurementModel_RngBrg, KalmanFilter_RngBrg>
+// (reference include/FastSLAM.hpp) over the same C ABI: the handle's mixtures are the landmark maps (weights = log-odds of
+// existence), rfsgpu_fastslam_update is updateMap for every particle.  FastSLAM 1.0: config.maxNDataAssocHypotheses_ must
+// stay 1 (the multi-hypothesis particle multiplication is not built; the call fails loudly otherwise).
+class FastSLAM2d : public RBPHDFilter2d {
+ public:
+  struct Config {  // FastSLAM::Config (FastSLAM.hpp:106-132), reference member names and constructor defaults (:243-257)
+    int minUpdatesBeforeResample_ = 1, minMeasurementsBeforeResample_ = 1;
+    bool reportTimingInfo_ = false;
+    double landmarkExistencePrior_ = 0.5, mapExistencePruneThreshold_ = -3.0, minLogMeasurementLikelihood_ = -10.0;
+    int nParticlesMax_ = 0;
+    unsigned maxNDataAssocHypotheses_ = 1;
+    double maxDataAssocLogLikelihoodDiff_ = 5, landmarkCandidateMeasurementSupportDist_ = 1;
+    unsigned landmarkCandidateMeasurementCountThreshold_ = 1, landmarkCandidateCurrentMeasurementCountThreshold_ = 1,
+             landmarkCandidateMeasurementCheckThreshold_ = 2;
+    double landmarkLockWeight_ = 10;
+    unsigned pruningMeasurementsThreshold_ = 0;
+  } config;
+
+  explicit FastSLAM2d(int n, int device_id = 0, int gm_capacity = 512) : RBPHDFilter2d(n, device_id, gm_capacity) { config.nParticlesMax_ = 3 * n; }
+
+  // FastSLAM::predict (:362-385): propagate the particles, staticStep on every landmark (no births in predict)
+  void predict(const Odometry2d &u, double dT, bool useModelNoise = true, bool useInputNoise = false) {
+    RBPHDFilter2d::predict(u, dT, useModelNoise, useInputNoise, /*birthGaussianCheck=*/false);
+  }
+
+  // FastSLAM::update (:387-421) + resampleWithMapCopy (:708-735)
+  void update(std::vector<Measurement2d> &Z) {
+    nUpdatesSinceResample_++;
+    std::vector<Measurement2d> meas;
+    meas.swap(Z);
+    Z.clear();
+    if (meas.empty()) return;  // :401-402
+    nMeasurementsSinceResample_ += (unsigned)meas.size();
+    pushConfig();
+    pushFastSlamConfig();
+    pushPoses();
+    std::vector<double> z(2 * meas.size());
+    for (size_t k = 0; k < meas.size(); k++) { z[2 * k] = meas[k].z[0]; z[2 * k + 1] = meas[k].z[1]; }
+    check(rfsgpu_fastslam_update(h_, z.data(), (int)meas.size()), "fastslam_update");
+    weightsStale_ = true;
+    resampleOccured_ = false;
+    // (nParticles_ never exceeds nParticlesMax_ with a single hypothesis, so the forced branch of :711-712 cannot fire)
+    if (nUpdatesSinceResample_ >= (unsigned)config.minUpdatesBeforeResample_ &&
+        nMeasurementsSinceResample_ >= (unsigned)config.minMeasurementsBeforeResample_)
+      resampleOccured_ = resample();  // landmark candidates travel with their particle (rfsgpu_resample_apply)
+    if (resampleOccured_) {
+      nUpdatesSinceResample_ = 0;
+      nMeasurementsSinceResample_ = 0;
+    } else {
+      normalizeWeights();
+    }
+  }
+
+ private:
+  void pushFastSlamConfig() {
+    rfsgpu_fastslam_config c;
+    rfsgpu_default_fastslam_config(&c);
+    c.minUpdatesBeforeResample = config.minUpdatesBeforeResample_;
+    c.minMeasurementsBeforeResample = config.minMeasurementsBeforeResample_;
+    c.landmarkExistencePrior = config.landmarkExistencePrior_;
+    c.mapExistencePruneThreshold = config.mapExistencePruneThreshold_;
+    c.minLogMeasurementLikelihood = config.minLogMeasurementLikelihood_;
+    c.nParticlesMax = config.nParticlesMax_;
+    c.maxNDataAssocHypotheses = config.maxNDataAssocHypotheses_;
+    c.maxDataAssocLogLikelihoodDiff = config.maxDataAssocLogLikelihoodDiff_;
+    c.landmarkCandidateMeasurementSupportDist = config.landmarkCandidateMeasurementSupportDist_;
+    c.landmarkCandidateMeasurementCountThreshold = config.landmarkCandidateMeasurementCountThreshold_;
+    c.landmarkCandidateCurrentMeasurementCountThreshold = config.landmarkCandidateCurrentMeasurementCountThreshold_;
+    c.landmarkCandidateMeasurementCheckThreshold = config.landmarkCandidateMeasurementCheckThreshold_;
+    c.landmarkLockWeight = config.landmarkLockWeight_;
+    c.pruningMeasurementsThreshold = config.pruningMeasurementsThreshold_;
+    check(rfsgpu_set_fastslam_config(h_, &c), "set_fastslam_config");
   }
 };
 

@@ -190,7 +190,19 @@ int main(int argc, char **argv) {
   }
 
   // ---------------- filter setup (:444-492) ----------------
+#ifdef USE_FASTSLAM
+  // fastslam2dSim (reference src/fastslam2dSim.cpp:444-482): same simulator, the FastSLAM filter class and its keys
+  FastSLAM2d filter(nParticles, device, 384);
+  filter.config.minUpdatesBeforeResample_ = c.i("config.filter.resampling.minTimesteps", 1);
+  filter.config.minLogMeasurementLikelihood_ = c.d("config.filter.weighting.minLogMeasurementLikelihood", -10.0);
+  filter.config.maxNDataAssocHypotheses_ = (unsigned)c.i("config.filter.update.maxNDataAssocHypotheses", 1);
+  filter.config.maxDataAssocLogLikelihoodDiff_ = c.d("config.filter.update.maxDataAssocLogLikelihoodDiff", 3.0);
+  filter.config.mapExistencePruneThreshold_ = c.d("config.filter.prune.threshold", -5.0);
+  filter.config.landmarkExistencePrior_ = 0.5;
+  (void)birthW; (void)newGaussMD; (void)nEvalPt; (void)minWeight; (void)weightThr; (void)useCluster; (void)minSteps; (void)mergeThr; (void)mergeInfl; (void)pruneThr;
+#else
   RBPHDFilter2d filter(nParticles, device, 384);
+#endif
   double Q[9] = {vardx, 0, 0, 0, vardy, 0, 0, 0, vardz};
   for (double &q : Q) q *= pNoiseInfl * dT * dT;
   filter.getProcessModel()->setNoise(Q);
@@ -205,8 +217,9 @@ int main(int argc, char **argv) {
   filter.getMeasurementModel()->config.rangeLimBuffer_ = rBuf;
   filter.getKalmanFilter()->config.rangeInnovationThreshold_ = innovR;
   filter.getKalmanFilter()->config.bearingInnovationThreshold_ = innovB;
-  filter.config.birthGaussianWeight_ = birthW;
   filter.setEffectiveParticleCountThreshold(effN);
+#ifndef USE_FASTSLAM
+  filter.config.birthGaussianWeight_ = birthW;
   filter.config.minUpdatesBeforeResample_ = minSteps;
   filter.config.newGaussianCreateInnovMDThreshold_ = newGaussMD;
   filter.config.importanceWeightingMeasurementLikelihoodMDThreshold_ = weightThr;
@@ -216,6 +229,7 @@ int main(int argc, char **argv) {
   filter.config.gaussianMergingCovarianceInflationFactor_ = mergeInfl;
   filter.config.gaussianPruningThreshold_ = pruneThr;
   filter.config.useClusterProcess_ = useCluster;
+#endif
 
   // ---------------- run (:540-643) ----------------
   FILE *fPose = nullptr, *fLm = nullptr;

@@ -248,6 +248,24 @@ def test_cpp_host_driver_end_to_end(pkg):
     assert mean_err < 0.3 and pose_err < 0.6
 
 
+def test_cpp_fastslam_driver_end_to_end(pkg):
+    """fastslam2d_sim: the same simulator around the C++ FastSLAM mirror (rfs_amd::FastSLAM2d -> rfsgpu_fastslam_update) on the
+    values of the reference's cfg/fastslam2dSim.xml: the landmark map must converge."""
+    import os
+    import re
+    import subprocess
+    pkg.build_mod.build_host()
+    exe = pkg.build_mod.SIM_FASTSLAM
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "fastslam2dSim_c1.xml")
+    out = subprocess.run([exe, "-c", cfg, "-t", "2", "-s", "2", "-n", "200"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    m = re.search(r"RESULT matched=(\d+) landmarks=(\d+) mean_err=([\d.]+) pose_err=([\d.]+)", out.stdout)
+    assert m, out.stdout[-2000:]
+    matched, total, mean_err, pose_err = int(m.group(1)), int(m.group(2)), float(m.group(3)), float(m.group(4))
+    assert total == 50 and matched >= 45, out.stdout[-800:]
+    assert mean_err < 0.2 and pose_err < 0.6
+
+
 def test_tied_weights_take_the_exact_rank_path(pkg, ob, sc):
     """Equal prior weights (common in real runs: all birth Gaussians share one weight) collide in the fp32 first pass of
     the device rank sort, which must then fall back to the exact (weight desc, index asc) order everywhere."""
@@ -442,6 +460,45 @@ def test_fastslam_candidate_lists_and_ambiguous_associations(pkg, ob, sc):
             f.normalize_weights(s[0])
     assert seen > 0, "no landmark candidate was ever queued"
     assert orc.fs_solver_max_dim() >= 2, "no particle had competing associations (the Hungarian path was not exercised)"
+
+
+def test_fastslam_host_mirror_resamples_with_candidates(pkg, ob, sc):
+    """rfs_slam_amd.FastSLAM.update_and_resample (FastSLAM::update + resampleWithMapCopy) against the oracle driven through the
+    same host logic and the same uniform draws: weights, maps and the candidate lists that travel with resampled particles."""
+    scen = sc.make_scenario(24, 40, 14, seed=81, rmax=8.0)
+    dev = pkg.FastSLAM(scen["n"], gm_capacity=256)
+    orc = ob.OracleFilter(scen["n"], stable_sort=True)
+    for f in (dev, orc):
+        sc.load_scenario(f, scen)
+        for i in range(scen["n"]):
+            f.import_gm(i, np.zeros(scen["w"][i].shape), scen["mean"][i], scen["cov"][i])
+        cfg = f.default_fastslam_config()
+        cfg.landmarkCandidateMeasurementCountThreshold = 2
+        cfg.landmarkCandidateCurrentMeasurementCountThreshold = 0
+        cfg.landmarkCandidateMeasurementCheckThreshold = 3
+        cfg.minUpdatesBeforeResample = 1
+        if f is dev:
+            dev.fs_config = cfg
+        f.set_fastslam_config(cfg)
+    dev.setEffectiveParticleCountThreshold(scen["n"])       # always below: resample at every opportunity
+    rng_d, rng_o, rz = np.random.default_rng(5), np.random.default_rng(5), np.random.default_rng(6)
+    resamples = 0
+    for step in range(4):
+        Z = scen["Z"] + rz.normal(0, 3e-3, scen["Z"].shape)
+        dev.predict_map()
+        orc.predict_map(False)
+        did = dev.update_and_resample(Z, u01_fn=rng_d.random)
+        # the oracle through the same host steps
+        orc.fastslam_update(Z)
+        s = orc.weight_sums()
+        orc.normalize_weights(s[0])
+        w = orc.get_weights()
+        if did:
+            src = pkg.engine.systematic_resample_plan(w, float(rng_o.random()))
+            orc.resample_apply(src)
+            resamples += 1
+        _compare_fastslam(sc, dev, orc, scen["n"])
+    assert resamples > 0
 
 
 def test_fastslam_refuses_multi_hypothesis(pkg, sc):
