@@ -7,12 +7,12 @@
 //                        SPARSE: only entries above the floor are stored (the reference fills an nMZ x nMZ table with the
 //                        floor) -> CostMatrix::reduce (src/CostMatrix.cpp:263-340): a pairing that is the only possibility
 //                        of its row and of its column is fixed; what remains ambiguous (rows and columns with competing
-//                        possibilities) goes through the Hungarian method (murty.h) as a small dense matrix padded with
-//                        the floor -> Kalman correction of the associated landmarks, existence log-odds (:573-604),
+//                        possibilities) falls apart into connected components, each solved by inspection (1 x n, n x 1) or
+//                        by the Hungarian method (murty.h) on a small dense block padded with the floor -> Kalman correction of the associated landmarks, existence log-odds (:573-604),
 //                        particle weight *= exp(sum of the associated log-likelihoods) (:696-697).
 //                        The reference runs the Hungarian method on the whole reduced table, rows and columns without any
 //                        possibility included; those can only take floor-valued cells, which never trigger an update
-//                        (:584), so the associations that matter are the maximum-weight matching of the ambiguous block --
+//                        (:584), so the associations that matter are the maximum-weight matching of the ambiguous part --
 //                        identical unless two associations tie exactly.
 //  gm_prune<holes off>   GaussianMixture::prune(mapExistencePruneThreshold) (:611-612).
 //  fs_new_landmarks      unassociated measurements -> candidates / new landmarks and the promotion loop (:615-690), a short
@@ -32,34 +32,37 @@ struct FsParams {
   unsigned countThr, curThr, checkThr;  // landmarkCandidateMeasurementCountThreshold_ / CurrentMeasurementCountThreshold_ / CheckThreshold_
 };
 
-#define FS_AMBIG_MAX 64   // rows / columns of the ambiguous block handled by the in-kernel Hungarian (MURTY_N)
+#define FS_AMBIG_MAX 64    // rows / columns of ONE connected component of competing associations (the in-kernel Hungarian, MURTY_N)
+#define FS_AMBIG_ROWS 256  // rows with competing associations per particle, over all components
+#define FS_SMALL 12        // components up to this size are solved in LDS, larger ones in the particle's HBM scratch
 
 // per-particle scratch of the Hungarian method in HBM: the dense block + hungarian_run's work arrays
-__host__ __device__ inline size_t fs_arena_bytes() {
-  return ((size_t)FS_AMBIG_MAX * FS_AMBIG_MAX * 8 + 3 * FS_AMBIG_MAX * 8 + 6 * FS_AMBIG_MAX * 4 + 8 * FS_AMBIG_MAX + 63) & ~(size_t)63;
+__host__ __device__ inline size_t fs_arena_bytes_n(int n) {
+  return ((size_t)n * n * 8 + 3 * (size_t)n * 8 + 6 * (size_t)n * 4 + 8 * (size_t)n + 63) & ~(size_t)63;
 }
-__device__ inline void fs_arena_carve(unsigned char *base, MurtyArena &A, unsigned char *&soln) {
+__host__ __device__ inline size_t fs_arena_bytes() { return fs_arena_bytes_n(FS_AMBIG_MAX); }
+__device__ inline void fs_arena_carve(unsigned char *base, MurtyArena &A, unsigned char *&soln, int n) {
   unsigned char *p = base;
-  A.Ct = (double *)p; p += (size_t)FS_AMBIG_MAX * FS_AMBIG_MAX * 8;
-  A.lx = (double *)p; p += FS_AMBIG_MAX * 8;
-  A.ly = (double *)p; p += FS_AMBIG_MAX * 8;
-  A.slack = (double *)p; p += FS_AMBIG_MAX * 8;
-  A.xy = (int *)p; p += FS_AMBIG_MAX * 4;
-  A.yx = (int *)p; p += FS_AMBIG_MAX * 4;
-  A.p = (int *)p; p += 2 * FS_AMBIG_MAX * 4;
-  A.queue = (int *)p; p += 2 * FS_AMBIG_MAX * 4;
-  A.S = p; p += FS_AMBIG_MAX;
-  A.T = p; p += FS_AMBIG_MAX;
-  A.NS = p; p += FS_AMBIG_MAX;
-  A.xq = p; p += FS_AMBIG_MAX;
-  A.yq = p; p += FS_AMBIG_MAX;
+  A.Ct = (double *)p; p += (size_t)n * n * 8;
+  A.lx = (double *)p; p += n * 8;
+  A.ly = (double *)p; p += n * 8;
+  A.slack = (double *)p; p += n * 8;
+  A.xy = (int *)p; p += n * 4;
+  A.yx = (int *)p; p += n * 4;
+  A.p = (int *)p; p += 2 * n * 4;
+  A.queue = (int *)p; p += 2 * n * 4;
+  A.S = p; p += n;
+  A.T = p; p += n;
+  A.NS = p; p += n;
+  A.xq = p; p += n;
+  A.yq = p; p += n;
   soln = p;
   A.nodeScore = nullptr; A.nodeParent = nullptr; A.heap = nullptr; A.nodeId = nullptr; A.nodeA = nullptr;
 }
 
 // LDS per wave: in-range list (index, Pd), assignment, row segment, log-weight contribution; sparse table (value, (row<<8)|z)
 __host__ __device__ inline size_t fs_lds_bytes_per_wave(int cap) {
-  return (size_t)cap * (2 + 8 + 2 + 4 + 8) + (size_t)2 * cap * (8 + 4) + 64 * 4 + 2 * FS_AMBIG_MAX * 2 + 64;
+  return (size_t)cap * (2 + 8 + 2 + 4 + 8) + (size_t)2 * cap * (8 + 4) + 64 * 4 + (size_t)FS_AMBIG_ROWS * (2 + 8) + fs_arena_bytes_n(FS_SMALL) + FS_AMBIG_MAX * 2 + 64 + 64;
 }
 
 // One table cell: fmax(floor, log(N(z; z_exp, S)))  (:476-477; evalGaussianLikelihood uses the RAW difference and maps NaN to 0).
@@ -95,7 +98,12 @@ __global__ __launch_bounds__(WPB * 64) void fs_associate_update_kernel(Buffers B
   int *sColCnt = reinterpret_cast<int *>(sSeg + cap);               // [64] cells above the floor per measurement
   unsigned short *sIdx = reinterpret_cast<unsigned short *>(sColCnt + 64);  // [cap] mixture index of row k
   short *sDa = reinterpret_cast<short *>(sIdx + cap);               // [cap] associated measurement of row k, or -1
-  unsigned short *sAR = reinterpret_cast<unsigned short *>(sDa + cap);      // [FS_AMBIG_MAX] ambiguous rows
+  unsigned short *sAR = reinterpret_cast<unsigned short *>(sDa + cap);      // [FS_AMBIG_ROWS] rows with competing associations
+  // 8-byte aligned from here: cap*(8+8) + LCAP*12 + cap*4 + 256 + cap*4 + ROWS*2 is a multiple of 8 (cap is a multiple of 64)
+  unsigned long long *sRM = reinterpret_cast<unsigned long long *>(sAR + FS_AMBIG_ROWS);  // [FS_AMBIG_ROWS] their measurement masks
+  double *sHL = reinterpret_cast<double *>(sRM + FS_AMBIG_ROWS);            // Hungarian scratch for small components
+  unsigned short *sRows = reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(sHL) + fs_arena_bytes_n(FS_SMALL));  // [FS_AMBIG_MAX]
+  unsigned char *sParent = reinterpret_cast<unsigned char *>(sRows + FS_AMBIG_MAX);                                          // [64]
 
   const int nM = B.count[i];
   const unsigned long long zmask = (nZ >= 64) ? ~0ull : ((1ull << nZ) - 1ull);
@@ -163,13 +171,13 @@ __global__ __launch_bounds__(WPB * 64) void fs_associate_update_kernel(Buffers B
   }
   wave_sync();
 
-  // ---- B. CostMatrix::reduce: fix what is unambiguous, collect the ambiguous rows ----
+  // ---- B. CostMatrix::reduce: fix what is unambiguous, collect the ambiguous rows (with their column masks) ----
   int nRa = 0;
-  unsigned long long colAmb = 0;
   bool tooBig = false;
   for (int k0 = 0; k0 < nIn; k0 += 64) {
     const int k = k0 + lane;
     bool amb = false;
+    unsigned long long rmask = 0;
     if (k < nIn) {
       const unsigned seg = sSeg[k];
       const int st = (int)(seg >> 8), cnt = (int)(seg & 0xffu);
@@ -181,58 +189,100 @@ __global__ __launch_bounds__(WPB * 64) void fs_associate_update_kernel(Buffers B
         amb = true;
       }
       if (amb)
-        for (int q = st; q < st + cnt && q < nList; q++) colAmb |= 1ull << (sMZ[q] & 0xffu);
+        for (int q = st; q < st + cnt && q < nList; q++) rmask |= 1ull << (sMZ[q] & 0xffu);
     }
     const unsigned long long am = __ballot(amb);
     if (amb) {
       const int a = nRa + __popcll(am & lt);
-      if (a < FS_AMBIG_MAX) sAR[a] = (unsigned short)k;
+      if (a < FS_AMBIG_ROWS) { sAR[a] = (unsigned short)k; sRM[a] = rmask; }
       else tooBig = true;
     }
     nRa += __popcll(am);
   }
-  colAmb = wave_or_u64(colAmb);
-  const int nCa = __popcll(colAmb);
-  if (__ballot(tooBig) != 0ull || nRa > FS_AMBIG_MAX) {
-    if (lane == 0) atomicOr(B.err, ERRBIT_MURTY);  // more competing associations than the in-kernel Hungarian holds: refuse
+  if (__ballot(tooBig) != 0ull) {
+    if (lane == 0) atomicOr(B.err, ERRBIT_MURTY);  // more competing rows than the kernel lists: refuse
     nRa = 0;
   }
   wave_sync();
 
-  // ---- C. Hungarian method on the ambiguous block (dense, padded with the floor) ----
-  if (nRa > 0) {
-    const int nA = nRa > nCa ? nRa : nCa;
-    MurtyArena A;
-    unsigned char *soln;
-    fs_arena_carve(arena + (size_t)i * fs_arena_bytes(), A, soln);
-    for (int t = lane; t < nA * nA; t += 64) A.Ct[t] = lim;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    wave_sync();
-    for (int a = lane; a < nRa; a += 64) {
-      const unsigned seg = sSeg[sAR[a]];
-      const int st = (int)(seg >> 8), cnt = (int)(seg & 0xffu);
-      for (int q = st; q < st + cnt && q < nList; q++) {
-        const int z = (int)(sMZ[q] & 0xffu);
-        const int b = __popcll(colAmb & ((1ull << z) - 1ull));
-        A.Ct[a * nA + b] = sMV[q];
+  // ---- C. the ambiguous part falls apart into connected components (rows linked by shared measurements); each is a
+  //         small assignment problem: dense block padded with the floor -> Hungarian method (lane 0, serial) ----
+  if (nRa > 0 && lane == 0) {
+    // union-find over the <= 64 measurement columns
+    unsigned char *parent = sParent;  // (LDS: private arrays indexed at run time would live in scratch memory)
+    for (int z = 0; z < 64; z++) parent[z] = (unsigned char)z;
+    auto find = [&](int z) { while (parent[z] != z) { parent[z] = parent[parent[z]]; z = parent[z]; } return z; };
+    unsigned long long colAmb = 0;
+    for (int a = 0; a < nRa; a++) {
+      const unsigned long long m = sRM[a];
+      colAmb |= m;
+      const int r0 = find(__builtin_ctzll(m));
+      for (unsigned long long g = m & (m - 1); g; g &= g - 1) {
+        const int r1 = find(__builtin_ctzll(g));
+        if (r1 != r0) parent[r1] = (unsigned char)r0;
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    wave_sync();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (lane == 0) {
+    MurtyArena Ag, Al;
+    unsigned char *solnG, *solnL;
+    fs_arena_carve(arena + (size_t)i * fs_arena_bytes(), Ag, solnG, FS_AMBIG_MAX);
+    fs_arena_carve(reinterpret_cast<unsigned char *>(sHL), Al, solnL, FS_SMALL);
+    for (unsigned long long roots = colAmb; roots; roots &= roots - 1) {
+      const int r = __builtin_ctzll(roots);
+      if (find(r) != r) continue;
+      unsigned long long cmask = 0;
+      for (unsigned long long g = colAmb; g; g &= g - 1) { const int z = __builtin_ctzll(g); if (find(z) == r) cmask |= 1ull << z; }
+      unsigned short *rows = sRows;
+      int nR = 0;
+      bool big = false;
+      for (int a = 0; a < nRa; a++)
+        if (sRM[a] & cmask) { if (nR < FS_AMBIG_MAX) rows[nR++] = (unsigned short)a; else big = true; }
+      const int nC = __popcll(cmask);
+      if (big) { atomicOr(B.err, ERRBIT_MURTY); continue; }  // a component beyond the in-kernel Hungarian's size: refuse
+      if (nR == 1) {  // one landmark, several measurements: the best cell (what the Hungarian optimum is, ties aside)
+        const unsigned seg = sSeg[sAR[rows[0]]];
+        const int st = (int)(seg >> 8), cnt = (int)(seg & 0xffu);
+        double bv = lim;
+        int bz = -1;
+        for (int q = st; q < st + cnt && q < nList; q++)
+          if (sMV[q] > bv) { bv = sMV[q]; bz = (int)(sMZ[q] & 0xffu); }
+        if (bz >= 0) sDa[sAR[rows[0]]] = (short)bz;
+        continue;
+      }
+      if (nC == 1) {  // several landmarks, one measurement: the landmark with the best cell takes it
+        double bv = lim;
+        int bx = -1;
+        for (int x = 0; x < nR; x++) {
+          const unsigned seg = sSeg[sAR[rows[x]]];
+          const double v = sMV[seg >> 8];  // (the row's only cell)
+          if (v > bv) { bv = v; bx = x; }
+        }
+        if (bx >= 0) sDa[sAR[rows[bx]]] = (short)__builtin_ctzll(cmask);
+        continue;
+      }
+      const int nA = nR > nC ? nR : nC;
+      MurtyArena &A = (nA <= FS_SMALL) ? Al : Ag;
+      unsigned char *soln = (nA <= FS_SMALL) ? solnL : solnG;
+      for (int t = 0; t < nA * nA; t++) A.Ct[t] = lim;
+      for (int x = 0; x < nR; x++) {
+        const unsigned seg = sSeg[sAR[rows[x]]];
+        const int st = (int)(seg >> 8), cnt = (int)(seg & 0xffu);
+        for (int q = st; q < st + cnt && q < nList; q++) {
+          const int z = (int)(sMZ[q] & 0xffu);
+          A.Ct[x * nA + __popcll(cmask & ((1ull << z) - 1ull))] = sMV[q];
+        }
+      }
       double cost;
       if (hungarian_run(A.Ct, nA, nA, soln, &cost, A)) {
-        for (int a = 0; a < nRa; a++) {
-          const int b = soln[a];
-          if (b < nCa && A.Ct[a * nA + b] > lim) sDa[sAR[a]] = (short)nth_bit(colAmb, b);
+        for (int x = 0; x < nR; x++) {
+          const int bcol = soln[x];
+          if (bcol < nC && A.Ct[x * nA + bcol] > lim) sDa[sAR[rows[x]]] = (short)nth_bit(cmask, bcol);
         }
       } else {
         atomicOr(B.err, ERRBIT_MURTY);  // the reference would leave the particle untouched (:511-515); refused loudly here
       }
     }
-    wave_sync();
   }
+  wave_sync();
 
   // ---- D. Kalman correction of the associated landmarks, existence log-odds (:573-604) ----
   unsigned long long used = 0;
