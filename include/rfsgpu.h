@@ -281,7 +281,7 @@ int rfsgpu_mat_perm(const double *A, int n, int batch, double *out, int device_i
 /* ---- FastSLAM 1.0 on the same handle (reference include/FastSLAM.hpp) --------------------------------
  * The handle's mixtures double as FastSLAM's per-particle landmark maps: a Gaussian's weight is the landmark's
  * log-odds of existence (FastSLAM.hpp:598-617), the birth-candidate lists are the landmark candidates
- * (landmarkCandidates_, :84-88).  2-D range-bearing model.  The map part of FastSLAM::predict (:376-383, staticStep on
+ * (landmarkCandidates_, :84-88).  Both measurement models.  The map part of FastSLAM::predict (:376-383, staticStep on
  * every landmark) is rfsgpu_predict_map(f, 0). */
 void rfsgpu_default_fastslam_config(rfsgpu_fastslam_config *cfg);                       /* constructor defaults :243-257 */
 int rfsgpu_set_fastslam_config(rfsgpu_filter *f, const rfsgpu_fastslam_config *cfg);    /* public member `config`        */

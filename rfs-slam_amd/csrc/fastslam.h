@@ -1,6 +1,6 @@
 // fastslam.h -- FastSLAM 1.0 map update on the RB-PHD engine's state (reference include/FastSLAM.hpp:424-706, one
 // data-association hypothesis).  A particle's mixture is its landmark map, a Gaussian's weight the landmark's log-odds of
-// existence, the birth-candidate lists are the landmark candidates.  2-D range-bearing model.
+// existence, the birth-candidate lists are the landmark candidates.  Both measurement models (template parameter D).
 //
 // Three kernels per update (one wavefront per particle):
 //  fs_associate_update   in-range landmarks (ballot-compacted, :440-449) -> the log-likelihood table (:468-481) kept
@@ -65,31 +65,75 @@ __host__ __device__ inline size_t fs_lds_bytes_per_wave(int cap) {
   return (size_t)cap * (2 + 8 + 2 + 4 + 8) + (size_t)2 * cap * (8 + 4) + 64 * 4 + (size_t)FS_AMBIG_ROWS * (2 + 8) + fs_arena_bytes_n(FS_SMALL) + FS_AMBIG_MAX * 2 + 64 + 64;
 }
 
-// One table cell: fmax(floor, log(N(z; z_exp, S)))  (:476-477; evalGaussianLikelihood uses the RAW difference and maps NaN to 0).
-// `lf` = log(factor) gives a cheap bound: cells more than 1 below the floor in that estimate are not evaluated.
-__device__ __forceinline__ double fs_cell(const MeasOut &mo, double i00, double i01, double i10, double i11, double factor, double lf,
-                                          double z0, double z1, double lim) {
-  const double e0 = z0 - mo.z0, e1 = z1 - mo.z1;
-  const double t0 = e0 * i00 + e1 * i10, t1 = e0 * i01 + e1 * i11;
-  const double md2 = t0 * e0 + t1 * e1;
-  if (-0.5 * md2 - lf < lim - 1.0) return lim;
-  double l = exp(-0.5 * md2) / factor;
+// Per-landmark quantities of one table row for either model (D = 2: range-bearing, D = 3: Victoria Park).
+template <int D>
+struct FsRow {
+  bool valid;      // measure() returned true (:472)
+  double pd;
+  bool close;
+  // D == 2
+  MeasOut mo;
+  double i00, i01, i10, i11, factor;
+  // D == 3
+  LmKF3 k3;
+  double lf;       // log(factor)
+};
+template <int D>
+__device__ __forceinline__ void fs_row(const Buffers &B, const Params &P, const PoseReg &pr, const double *slab, int cap, int i, int m, bool act,
+                                       FsRow<D> &r) {
+  if (D == 2) {
+    double mx = 0, my = 0, sxx = 1, sxy = 0, syy = 1;
+    if (act) {
+      mx = plane((double *)slab, cap, i, PL_MX)[m]; my = plane((double *)slab, cap, i, PL_MY)[m];
+      sxx = plane((double *)slab, cap, i, PL_SXX)[m]; sxy = plane((double *)slab, cap, i, PL_SXY)[m]; syy = plane((double *)slab, cap, i, PL_SYY)[m];
+    }
+    rb_measure(P, pr, mx, my, sxx, sxy, syy, r.mo);
+    r.valid = r.mo.inRange;
+    r.pd = rb_pd(P, r.mo.range, r.close);
+    double det;
+    inv2(r.mo.s00, r.mo.s01, r.mo.s10, r.mo.s11, r.i00, r.i01, r.i10, r.i11, det);
+    r.factor = pdf_factor2(det);
+    r.lf = log(r.factor);
+  } else {
+    Ent3 e;
+    e.w = 0; e.x = 10; e.y = 10; e.d = 1; e.xx = 1; e.xy = 0; e.xd = 0; e.yy = 1; e.yd = 0; e.dd = 1;
+    if (act) load_ent3(slab, cap, i, m, e, false);
+    r.valid = true;  // MeasurementModel_VictoriaPark::measure always returns true
+    r.pd = vp_pd(P, B.scan, B.nScan, pr.x, pr.y, pr.th, e, r.close);
+    lm_precompute3(P, pr.x, pr.y, pr.th, e, r.k3);
+    r.factor = r.k3.factor;
+    r.lf = log(r.factor);
+  }
+}
+// One table cell: fmax(floor, log(N(z; z_exp, S)))  (:476-477; evalGaussianLikelihood uses the RAW difference, NaN -> 0)
+template <int D>
+__device__ __forceinline__ double fs_cell_d(const FsRow<D> &r, const double *z, double lim) {
+  double md2;
+  if (D == 2) {
+    const double e0 = z[0] - r.mo.z0, e1 = z[1] - r.mo.z1;
+    const double t0 = e0 * r.i00 + e1 * r.i10, t1 = e0 * r.i01 + e1 * r.i11;
+    md2 = t0 * e0 + t1 * e1;
+  } else {
+    md2 = md2_3(r.k3.Si, z[0] - r.k3.zx0, z[1] - r.k3.zx1, z[2] - r.k3.zx2);
+  }
+  if (-0.5 * md2 - r.lf < lim - 1.0) return lim;  // cheap bound: clearly below the floor
+  double l = exp(-0.5 * md2) / r.factor;
   if (l != l) l = 0.0;
   return fmax(lim, log(l));
 }
 
-template <int WPB>
+template <int WPB, int D>
 __global__ __launch_bounds__(WPB * 64) void fs_associate_update_kernel(Buffers B, Params P, FsParams F, int cur, int nZ, unsigned char *arena) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double *sZ = reinterpret_cast<double *>(smem_raw);
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
-  for (int t = threadIdx.x; t < 2 * nZ; t += WPB * 64) sZ[t] = B.Z[t];
+  for (int t = threadIdx.x; t < D * nZ; t += WPB * 64) sZ[t] = B.Z[t];
   __syncthreads();
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
   if (i >= B.N) return;
   const int cap = B.cap, LCAP = 2 * cap;
-  unsigned char *wb = smem_raw + 2 * RFSGPU_MAX_Z * 8 + (size_t)wave * fs_lds_bytes_per_wave(cap);
+  unsigned char *wb = smem_raw + 3 * RFSGPU_MAX_Z * 8 + (size_t)wave * fs_lds_bytes_per_wave(cap);
   double *sPd = reinterpret_cast<double *>(wb);                    // [cap] Pd of in-range row k
   double *sC = sPd + cap;                                           // [cap] log-weight contribution of row k
   double *sMV = sC + cap;                                           // [LCAP] table values above the floor, (row, z) order
@@ -109,9 +153,7 @@ __global__ __launch_bounds__(WPB * 64) void fs_associate_update_kernel(Buffers B
   const unsigned long long zmask = (nZ >= 64) ? ~0ull : ((1ull << nZ) - 1ull);
   const unsigned long long lt = (1ull << lane) - 1ull;
   double *slab = B.slab[cur];
-  double *pW = plane(slab, cap, i, PL_W), *pWP = plane(slab, cap, i, PL_WP);
-  double *pMX = plane(slab, cap, i, PL_MX), *pMY = plane(slab, cap, i, PL_MY);
-  double *pSXX = plane(slab, cap, i, PL_SXX), *pSXY = plane(slab, cap, i, PL_SXY), *pSYY = plane(slab, cap, i, PL_SYY);
+  double *pW = slab + ((size_t)i * B.npl + 0) * cap, *pWP = slab + ((size_t)i * B.npl + 1) * cap;  // planes 0 / 1 in both layouts
   PoseReg pr;
   load_pose(B, P, i, pr);
   const double lim = F.minLog;
@@ -124,21 +166,14 @@ __global__ __launch_bounds__(WPB * 64) void fs_associate_update_kernel(Buffers B
   for (int c0 = 0; c0 < nM; c0 += 64) {
     const int m = c0 + lane;
     const bool act = m < nM;
-    double mx = 0, my = 0, sxx = 1, sxy = 0, syy = 1;
-    if (act) { mx = pMX[m]; my = pMY[m]; sxx = pSXX[m]; sxy = pSXY[m]; syy = pSYY[m]; }
-    MeasOut mo;
-    rb_measure(P, pr, mx, my, sxx, sxy, syy, mo);
-    bool close;
-    const double pd = rb_pd(P, mo.range, close);
-    const bool inR = act && (pd != 0 || close);  // :446
-    double i00, i01, i10, i11, det;
-    inv2(mo.s00, mo.s01, mo.s10, mo.s11, i00, i01, i10, i11, det);
-    const double factor = pdf_factor2(det);
-    const double lf = log(factor);
+    FsRow<D> row;
+    fs_row<D>(B, P, pr, slab, cap, i, m, act, row);
+    const double pd = row.pd;
+    const bool inR = act && (pd != 0 || row.close);  // :446
     unsigned long long cells = 0;
-    if (inR && mo.inRange)
+    if (inR && row.valid)
       for (int z = 0; z < nZ; z++)
-        if (fs_cell(mo, i00, i01, i10, i11, factor, lf, sZ[2 * z], sZ[2 * z + 1], lim) > lim) cells |= 1ull << z;
+        if (fs_cell_d<D>(row, sZ + D * z, lim) > lim) cells |= 1ull << z;
     const unsigned long long im = __ballot(inR);
     const int k = nIn + __popcll(im & lt);
     const int cnt = __popcll(cells);
@@ -153,7 +188,7 @@ __global__ __launch_bounds__(WPB * 64) void fs_associate_update_kernel(Buffers B
       for (unsigned long long g = cells; g; g &= g - 1) {
         const int z = __builtin_ctzll(g);
         if (pos < LCAP) {
-          sMV[pos] = fs_cell(mo, i00, i01, i10, i11, factor, lf, sZ[2 * z], sZ[2 * z + 1], lim);
+          sMV[pos] = fs_cell_d<D>(row, sZ + D * z, lim);
           sMZ[pos] = ((unsigned)k << 8) | (unsigned)z;
           atomicAdd(&sColCnt[z], 1);
         } else {
@@ -302,31 +337,49 @@ __global__ __launch_bounds__(WPB * 64) void fs_associate_update_kernel(Buffers B
         bool found = false;
         for (int q = st; q < st + cnt && q < nList; q++)
           if ((int)(sMZ[q] & 0xffu) == z) { val = sMV[q]; found = true; }
-        if (found) {  // likelihoodTable[m][z] > floor (:584) -> kfs_.correct (KalmanFilter.hpp:209-259)
-          const double mx = pMX[m], my = pMY[m], sxx = pSXX[m], sxy = pSXY[m], syy = pSYY[m];
-          MeasOut mo;
-          rb_measure(P, pr, mx, my, sxx, sxy, syy, mo);
-          const double e0 = sZ[2 * z] - mo.z0;
-          const double w1 = wrap_pi(sZ[2 * z + 1] - mo.z1);
-          const bool gateR = !(P.kfRange > 0 && fabs(e0) > P.kfRange), gateB = !(P.kfBearing > 0 && fabs(w1) > P.kfBearing);
-          if (mo.inRange && gateR && gateB) {
-            double i00, i01, i10, i11, det;
-            inv2(mo.s00, mo.s01, mo.s10, mo.s11, i00, i01, i10, i11, det);
-            const double t00 = sxx * mo.h00 + sxy * mo.h01, t01 = sxx * mo.h10 + sxy * mo.h11;
-            const double t10 = sxy * mo.h00 + syy * mo.h01, t11 = sxy * mo.h10 + syy * mo.h11;
-            const double k00 = t00 * i00 + t01 * i10, k01 = t00 * i01 + t01 * i11;
-            const double k10 = t10 * i00 + t11 * i10, k11 = t10 * i01 + t11 * i11;
-            const double kh00 = k00 * mo.h00 + k01 * mo.h10, kh01 = k00 * mo.h01 + k01 * mo.h11;
-            const double kh10 = k10 * mo.h00 + k11 * mo.h10, kh11 = k10 * mo.h01 + k11 * mo.h11;
-            const double a00 = 1.0 - kh00, a01 = 0.0 - kh01, a10 = 0.0 - kh10, a11 = 1.0 - kh11;
-            const double q00 = a00 * sxx + a01 * sxy, q01 = a00 * sxy + a01 * syy;
-            const double q10 = a10 * sxx + a11 * sxy, q11 = a10 * sxy + a11 * syy;
-            pMX[m] = mx + (k00 * e0 + k01 * w1);
-            pMY[m] = my + (k10 * e0 + k11 * w1);
-            pSXX[m] = (q00 + q00) / 2;
-            pSXY[m] = (q01 + q10) / 2;
-            pSYY[m] = (q11 + q11) / 2;
-            upd = true;
+        if (found) {  // likelihoodTable[m][z] > floor (:584) -> kfs_.correct (KalmanFilter.hpp:209-259), in place
+          if (D == 2) {
+            double *pMX = plane(slab, cap, i, PL_MX), *pMY = plane(slab, cap, i, PL_MY);
+            double *pSXX = plane(slab, cap, i, PL_SXX), *pSXY = plane(slab, cap, i, PL_SXY), *pSYY = plane(slab, cap, i, PL_SYY);
+            const double mx = pMX[m], my = pMY[m], sxx = pSXX[m], sxy = pSXY[m], syy = pSYY[m];
+            MeasOut mo;
+            rb_measure(P, pr, mx, my, sxx, sxy, syy, mo);
+            const double e0 = sZ[2 * z] - mo.z0;
+            const double w1 = wrap_pi(sZ[2 * z + 1] - mo.z1);
+            const bool gateR = !(P.kfRange > 0 && fabs(e0) > P.kfRange), gateB = !(P.kfBearing > 0 && fabs(w1) > P.kfBearing);
+            if (mo.inRange && gateR && gateB) {
+              double i00, i01, i10, i11, det;
+              inv2(mo.s00, mo.s01, mo.s10, mo.s11, i00, i01, i10, i11, det);
+              const double t00 = sxx * mo.h00 + sxy * mo.h01, t01 = sxx * mo.h10 + sxy * mo.h11;
+              const double t10 = sxy * mo.h00 + syy * mo.h01, t11 = sxy * mo.h10 + syy * mo.h11;
+              const double k00 = t00 * i00 + t01 * i10, k01 = t00 * i01 + t01 * i11;
+              const double k10 = t10 * i00 + t11 * i10, k11 = t10 * i01 + t11 * i11;
+              const double kh00 = k00 * mo.h00 + k01 * mo.h10, kh01 = k00 * mo.h01 + k01 * mo.h11;
+              const double kh10 = k10 * mo.h00 + k11 * mo.h10, kh11 = k10 * mo.h01 + k11 * mo.h11;
+              const double a00 = 1.0 - kh00, a01 = 0.0 - kh01, a10 = 0.0 - kh10, a11 = 1.0 - kh11;
+              const double q00 = a00 * sxx + a01 * sxy, q01 = a00 * sxy + a01 * syy;
+              const double q10 = a10 * sxx + a11 * sxy, q11 = a10 * sxy + a11 * syy;
+              pMX[m] = mx + (k00 * e0 + k01 * w1);
+              pMY[m] = my + (k10 * e0 + k11 * w1);
+              pSXX[m] = (q00 + q00) / 2;
+              pSXY[m] = (q01 + q10) / 2;
+              pSYY[m] = (q11 + q11) / 2;
+              upd = true;
+            }
+          } else {
+            Ent3 e;
+            load_ent3(slab, cap, i, m, e, false);
+            LmKF3 kf;
+            lm_precompute3(P, pr.x, pr.y, pr.th, e, kf);
+            double nu0, nu1;
+            if (vp_gate(P, kf, sZ[3 * z], sZ[3 * z + 1], nu0, nu1)) {  // KalmanFilter_VictoriaPark::calculateInnovation
+              const double nu2 = sZ[3 * z + 2] - kf.zx2;
+              plane3(slab, cap, i, P3_MX)[m] = e.x + ((kf.K[0] * nu0 + kf.K[1] * nu1) + kf.K[2] * nu2);
+              plane3(slab, cap, i, P3_MY)[m] = e.y + ((kf.K[3] * nu0 + kf.K[4] * nu1) + kf.K[5] * nu2);
+              plane3(slab, cap, i, P3_MD)[m] = e.d + ((kf.K[6] * nu0 + kf.K[7] * nu1) + kf.K[8] * nu2);
+              for (int t = 0; t < 6; t++) plane3(slab, cap, i, P3_SXX + t)[m] = kf.p[t];
+              upd = true;
+            }
           }
         }
       }
@@ -356,21 +409,32 @@ __global__ __launch_bounds__(WPB * 64) void fs_associate_update_kernel(Buffers B
 }
 
 // GaussianMixture::addGaussian(candidate, w, true) (:267-284) -- no process noise here (the update adds none)
-__device__ inline bool fs_append(const Buffers &B, int cur, int i, int &n, const Cand<2> &k, double w) {
+template <int D>
+__device__ inline bool fs_append(const Buffers &B, int cur, int i, int &n, const Cand<D> &k, double w) {
   if (n >= B.cap) return false;
   double *slab = B.slab[cur];
-  plane(slab, B.cap, i, PL_W)[n] = w;
-  plane(slab, B.cap, i, PL_WP)[n] = 0.0;
-  plane(slab, B.cap, i, PL_MX)[n] = k.x[0];
-  plane(slab, B.cap, i, PL_MY)[n] = k.x[1];
-  plane(slab, B.cap, i, PL_SXX)[n] = k.S[0];
-  plane(slab, B.cap, i, PL_SXY)[n] = k.S[1];
-  plane(slab, B.cap, i, PL_SYY)[n] = k.S[3];
+  if (D == 2) {
+    plane(slab, B.cap, i, PL_W)[n] = w;
+    plane(slab, B.cap, i, PL_WP)[n] = 0.0;
+    plane(slab, B.cap, i, PL_MX)[n] = k.x[0];
+    plane(slab, B.cap, i, PL_MY)[n] = k.x[1];
+    plane(slab, B.cap, i, PL_SXX)[n] = k.S[0];
+    plane(slab, B.cap, i, PL_SXY)[n] = k.S[1];
+    plane(slab, B.cap, i, PL_SYY)[n] = k.S[3];
+  } else {
+    plane3(slab, B.cap, i, P3_W)[n] = w;
+    plane3(slab, B.cap, i, P3_WP)[n] = 0.0;
+    plane3(slab, B.cap, i, P3_MX)[n] = k.x[0];
+    plane3(slab, B.cap, i, P3_MY)[n] = k.x[1];
+    plane3(slab, B.cap, i, P3_MD)[n] = k.x[2];
+    for (int t = 0; t < 6; t++) plane3(slab, B.cap, i, P3_SXX + t)[n] = k.S[t];
+  }
   n++;
   return true;
 }
 
 // New landmarks from the measurements no landmark took (:615-690): one thread per particle.
+template <int D>
 __global__ __launch_bounds__(64) void fs_new_landmarks_kernel(Buffers B, Params P, FsParams F, int cur, int nZ) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B.N) return;
@@ -384,27 +448,27 @@ __global__ __launch_bounds__(64) void fs_new_landmarks_kernel(Buffers B, Params 
   const unsigned long long um = B.unusedMask[i];
   for (int zi = 0; zi < nZ; zi++) {  // measurements in index order (:615)
     if (!((um >> zi) & 1ull)) continue;
-    const double *z = B.Z + (size_t)2 * zi;
+    const double *z = B.Z + (size_t)D * zi;
     bool isNew = true;
     for (int c = 0; c < nc; c++) {
-      Cand<2> k;
-      cand_load<2>(B, i, c, k);
-      const double d2 = cand_support_md2<2>(P, pr, k, z);
+      Cand<D> k;
+      cand_load<D>(B, i, c, k);
+      const double d2 = cand_support_md2<D>(P, pr, k, z);
       if (d2 <= F.supportD2) {
-        cand_correct<2>(P, pr, k, z);
-        cand_store<2>(B, i, c, k);
+        cand_correct<D>(P, pr, k, z);
+        cand_store<D>(B, i, c, k);
         sup[c]++;
         isNew = false;
         break;
       }
     }
     if (isNew) {
-      Cand<2> k;
-      cand_inverse<2>(P, pr, z, k);
+      Cand<D> k;
+      cand_inverse<D>(P, pr, z, k);
       if (F.countThr == 1u || nfov <= F.curThr) {
-        if (!fs_append(B, cur, i, n, k, F.newW)) fail = true;
+        if (!fs_append<D>(B, cur, i, n, k, F.newW)) fail = true;
       } else if (nc < RFSGPU_MAX_CANDIDATES) {
-        cand_store<2>(B, i, nc, k);
+        cand_store<D>(B, i, nc, k);
         sup[nc] = 1;
         chk[nc] = 0;
         nc++;
@@ -419,14 +483,14 @@ __global__ __launch_bounds__(64) void fs_new_landmarks_kernel(Buffers B, Params 
       bool atEnd = false;
       while ((unsigned)sup[k] >= F.countThr || (unsigned)chk[k] > F.checkThr || nfov <= F.curThr) {
         if ((unsigned)sup[k] >= F.countThr || nfov <= F.curThr) {
-          Cand<2> c;
-          cand_load<2>(B, i, k, c);
-          if (!fs_append(B, cur, i, n, c, F.newW * chk[k])) fail = true;
+          Cand<D> c;
+          cand_load<D>(B, i, k, c);
+          if (!fs_append<D>(B, cur, i, n, c, F.newW * chk[k])) fail = true;
         }
         for (int t = k; t + 1 < nc; t++) {  // erase(it): shift the tail down, list order kept
-          Cand<2> c;
-          cand_load<2>(B, i, t + 1, c);
-          cand_store<2>(B, i, t, c);
+          Cand<D> c;
+          cand_load<D>(B, i, t + 1, c);
+          cand_store<D>(B, i, t, c);
           sup[t] = sup[t + 1];
           chk[t] = chk[t + 1];
         }

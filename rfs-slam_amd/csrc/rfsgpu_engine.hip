@@ -1113,7 +1113,7 @@ int rfsgpu_fastslam_update(rfsgpu_filter *f, const double *z, int n_z) {
   CHECK_HANDLE(f);
   f->holes = false;
   if (n_z == 0) return RFSGPU_OK;  // :401-402
-  if (f->D != 2) return fail(f, RFSGPU_ERR_UNSUPPORTED, "FastSLAM is built for the 2-D range-bearing model");
+  if (f->D == 3 && f->B.nScan < 2) return fail(f, RFSGPU_ERR_INVALID, "Victoria Park model: rfsgpu_set_laser_scan must precede the update");
   if (f->fs.maxNDataAssocHypotheses != 1) return fail(f, RFSGPU_ERR_UNSUPPORTED, "multi-hypothesis FastSLAM (maxNDataAssocHypotheses > 1) is not built");
   int rc = stage_measurements(f, z, n_z);
   if (rc != RFSGPU_OK) return rc;
@@ -1123,7 +1123,8 @@ int rfsgpu_fastslam_update(rfsgpu_filter *f, const double *z, int n_z) {
   F.prior = f->fs.landmarkExistencePrior;
   F.minLog = f->fs.minLogMeasurementLikelihood;
   F.lockW = f->fs.landmarkLockWeight;
-  F.pfa = (f->P.clutter * (2 * RFS_PI * (f->P.rmax - f->P.rmin))) / n_z;  // clutterIntensityIntegral(nZ) / nZ (:561-562)
+  // clutterIntensityIntegral(nZ) / nZ (:561-562): c * sensing area (RngBrg.cpp:175-178) or the expected clutter number (VictoriaPark)
+  F.pfa = ((f->D == 2) ? f->P.clutter * (2 * RFS_PI * (f->P.rmax - f->P.rmin)) : f->P.vpExpClutter) / n_z;
   F.newW = log(F.prior / (1 - F.prior));
   F.supportD2 = f->fs.landmarkCandidateMeasurementSupportDist * f->fs.landmarkCandidateMeasurementSupportDist;
   F.countThr = f->fs.landmarkCandidateMeasurementCountThreshold;
@@ -1132,13 +1133,18 @@ int rfsgpu_fastslam_update(rfsgpu_filter *f, const double *z, int n_z) {
   const long long t0 = now_ns();
   HIPCHK(hipEventRecord(f->ev[EV_UM0], f->stream));
   const size_t per = fs_lds_bytes_per_wave(f->cap);
-  const size_t b2 = (size_t)(2 * RFSGPU_MAX_Z * 8) + 2 * per, b1 = (size_t)(2 * RFSGPU_MAX_Z * 8) + per;
-  if (b2 <= 64 * 1024) {
-    if ((rc = set_lds(f, fs_associate_update_kernel<2>, b2)) != RFSGPU_OK) return rc;
-    fs_associate_update_kernel<2><<<(f->N + 1) / 2, 128, b2, f->stream>>>(f->B, f->P, F, f->cur, n_z, f->fsArena);
+  const size_t b2 = (size_t)(3 * RFSGPU_MAX_Z * 8) + 2 * per, b1 = (size_t)(3 * RFSGPU_MAX_Z * 8) + per;
+  if (f->D == 2) {
+    if (b2 <= 64 * 1024) {
+      if ((rc = set_lds(f, (fs_associate_update_kernel<2, 2>), b2)) != RFSGPU_OK) return rc;
+      fs_associate_update_kernel<2, 2><<<(f->N + 1) / 2, 128, b2, f->stream>>>(f->B, f->P, F, f->cur, n_z, f->fsArena);
+    } else {
+      if ((rc = set_lds(f, (fs_associate_update_kernel<1, 2>), b1)) != RFSGPU_OK) return rc;
+      fs_associate_update_kernel<1, 2><<<f->N, 64, b1, f->stream>>>(f->B, f->P, F, f->cur, n_z, f->fsArena);
+    }
   } else {
-    if ((rc = set_lds(f, fs_associate_update_kernel<1>, b1)) != RFSGPU_OK) return rc;
-    fs_associate_update_kernel<1><<<f->N, 64, b1, f->stream>>>(f->B, f->P, F, f->cur, n_z, f->fsArena);
+    if ((rc = set_lds(f, (fs_associate_update_kernel<1, 3>), b1)) != RFSGPU_OK) return rc;
+    fs_associate_update_kernel<1, 3><<<f->N, 64, b1, f->stream>>>(f->B, f->P, F, f->cur, n_z, f->fsArena);
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(f->ev[EV_UM1], f->stream));
@@ -1151,7 +1157,8 @@ int rfsgpu_fastslam_update(rfsgpu_filter *f, const double *z, int n_z) {
     HIPCHK(hipGetLastError());
     f->cur ^= 1;
   }
-  fs_new_landmarks_kernel<<<(f->N + 63) / 64, 64, 0, f->stream>>>(f->B, f->P, F, f->cur, n_z);
+  if (f->D == 2) fs_new_landmarks_kernel<2><<<(f->N + 63) / 64, 64, 0, f->stream>>>(f->B, f->P, F, f->cur, n_z);
+  else fs_new_landmarks_kernel<3><<<(f->N + 63) / 64, 64, 0, f->stream>>>(f->B, f->P, F, f->cur, n_z);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(f->ev[EV_PR1], f->stream));
   rc = check_device_errors(f);  // syncs

@@ -501,6 +501,36 @@ def test_fastslam_host_mirror_resamples_with_candidates(pkg, ob, sc):
     assert resamples > 0
 
 
+@pytest.mark.parametrize("kw", [dict(n_particles=10, n_landmarks=30, n_z=9, seed=91, scan="const"),
+                                dict(n_particles=16, n_landmarks=70, n_z=18, seed=92, scan="ragged")])
+def test_fastslam_victoria_park_model(pkg, ob, sc, kw):
+    """FastSLAM::updateMap with the Victoria Park model (3-D landmarks, scan-based Pd, expected-clutter-number false-alarm
+    probability, candidate lists with several supporting measurements), device vs oracle over three cycles."""
+    scen = sc.make_vp_scenario(**kw)
+    dev, orc = make_vp_pair(pkg, ob, sc, scen)
+    for f in (dev, orc):
+        for i in range(scen["n"]):
+            f.import_gm(i, np.zeros(scen["w"][i].shape), scen["mean"][i], scen["cov"][i])
+        cfg = f.default_fastslam_config()
+        cfg.landmarkCandidateMeasurementCountThreshold = 2
+        cfg.landmarkCandidateCurrentMeasurementCountThreshold = 0
+        cfg.landmarkCandidateMeasurementCheckThreshold = 3
+        cfg.landmarkCandidateMeasurementSupportDist = 3.0
+        cfg.mapExistencePruneThreshold = -5.0
+        f.set_fastslam_config(cfg)
+    rng = np.random.default_rng(kw["seed"])
+    for step in range(3):
+        Z = scen["Z"] + rng.normal(0, 1e-3, scen["Z"].shape)
+        for f in (dev, orc):
+            f.predict_map(False)
+            f.fastslam_update(Z)
+        _compare_fastslam(sc, dev, orc, scen["n"])
+        assert sum(dev.landmarks_in_fov(i) for i in range(scen["n"])) > 0      # landmarks were associated and corrected
+        for f in (dev, orc):
+            s = f.weight_sums()
+            f.normalize_weights(s[0])
+
+
 def test_fastslam_refuses_multi_hypothesis(pkg, sc):
     scen = sc.make_scenario(4, 5, 3, seed=1)
     dev = pkg.RBPHDFilter(4, gm_capacity=64)
