@@ -28,8 +28,12 @@ def ackerman_step(x, u_v, u_r, dt, a=ACKERMAN):
 
 
 class VictoriaParkRun:
-    def __init__(self, f, data, params, seed=1, var_uv=0.2, var_ur=0.025, noise_inflation=20.0, added_clutter=3.0, eff_n=None):
+    def __init__(self, f, data, params, seed=1, var_uv=0.2, var_ur=0.025, noise_inflation=20.0, added_clutter=3.0, eff_n=None,
+                 filter="rbphd"):
+        # filter = "rbphd": src/rbphdslam_VictoriaPark.cpp; "fastslam": src/fastslam_VictoriaPark.cpp (same event loop around
+        # FastSLAM::predict / update: no births in predict, rfsgpu_fastslam_update)
         self.f, self.P = f, params
+        self.fastslam = filter == "fastslam"
         self.mgr, self.inputs, self.meas = data["manager"], data["inputs"], data["measurements"]
         self.rng = np.random.default_rng(seed)
         self.n = f.n
@@ -47,7 +51,7 @@ class VictoriaParkRun:
         f = self.f
         f.set_lmk_process_noise(np.diag([5e-4, 5e-4, 1e-4]) * dt * dt)   # varlm* x dt^2 (:497-500)
         f.set_poses(self.x, None)                                          # poses BEFORE propagation: birth uses them
-        f.predict_map(birth)
+        f.predict_map(False if self.fastslam else birth)
         if stationary:
             uv = np.full(self.n, u[0]); ur = np.full(self.n, u[1])
         else:                                                              # predict(u, dt, false, true): noise from the input
@@ -87,7 +91,10 @@ class VictoriaParkRun:
                 self.n_updates_since += 1
                 if len(Z):
                     self.n_meas_since += len(Z)
-                    f.update(Z)
+                    if self.fastslam:
+                        f.fastslam_update(Z)
+                    else:
+                        f.update(Z)
                     self.n_lidar += 1
                     fired = False
                     if self.n_updates_since >= P["min_updates"] and self.n_meas_since >= P["min_measurements"]:

@@ -663,6 +663,37 @@ def test_victoria_park_dataset_extract_device_vs_oracle(pkg, ob, sc):
         sc.assert_gm_close(dev.f.export_gm(i), orc.f.export_gm(i), 1e-7, 1e-9)
 
 
+def test_victoria_park_dataset_extract_fastslam(pkg, ob, sc):
+    """The same dataset extract through the FastSLAM event loop (src/fastslam_VictoriaPark.cpp: values of
+    cfg/fastslam_VictoriaPark_artificialClutter.xml for the FastSLAM-specific keys) on the device and on the oracle."""
+    import os
+    data = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "victoria_park_extract.npz"))
+    n = 32
+    P = dict(sc.VP_PARAMS)
+    runs = []
+    for make in (lambda: pkg.RBPHDFilter(n, gm_capacity=192, model=pkg.capi.MODEL_VICTORIAPARK_3D),
+                 lambda: ob.OracleFilter(n, stable_sort=True, model=pkg.capi.MODEL_VICTORIAPARK_3D)):
+        f = make()
+        sc.apply_vp_params(f, P, np.full(361, 70.0))
+        cfg = f.default_fastslam_config()
+        cfg.minLogMeasurementLikelihood = -15.0
+        cfg.mapExistencePruneThreshold = -5.0
+        cfg.landmarkCandidateMeasurementCountThreshold = 3
+        cfg.landmarkCandidateCurrentMeasurementCountThreshold = 0
+        cfg.landmarkCandidateMeasurementCheckThreshold = 5
+        cfg.landmarkCandidateMeasurementSupportDist = 3.0
+        f.set_fastslam_config(cfg)
+        runs.append(pkg.vp_driver.VictoriaParkRun(f, data, P, seed=5, filter="fastslam").run(n_messages=900))
+    dev, orc = runs
+    assert dev.n_lidar == orc.n_lidar and dev.n_lidar > 50
+    assert dev.n_resamples == orc.n_resamples
+    np.testing.assert_allclose(dev.f.get_weights(), orc.f.get_weights(), rtol=1e-6)
+    sizes = dev.f.gm_sizes()
+    assert np.array_equal(sizes, orc.f.gm_sizes()) and sizes.max() > 3
+    for i in range(n):
+        sc.assert_gm_close(dev.f.export_gm(i), orc.f.export_gm(i), 1e-7, 1e-9)
+
+
 # ---- BASELINE.json full-size configurations: size-independent properties + oracle parity on a particle subset -------------
 
 def _full_size_check(pkg, ob, sc, scen, cap, subset=24, check_murty=False):
