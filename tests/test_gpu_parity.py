@@ -197,6 +197,56 @@ def test_capacity_overflow_is_reported(pkg, sc):
     assert e.value.status == pkg.capi.ERR_CAPACITY
 
 
+def test_async_edge_cases(pkg, ob, sc):
+    """The stream-ordered (fused-kernel) path on the edge cases of the synchronous one: capacity overflow surfaces at the next
+    synchronisation, an empty measurement set is a no-op, empty maps give every particle the denorm-min weight, and a run of
+    pipelined steps without intermediate syncs equals the same steps done synchronously."""
+    scen = sc.make_scenario(4, 60, 30, seed=16)
+    dev = pkg.RBPHDFilter(4, gm_capacity=64)
+    sc.load_scenario(dev, scen)
+    dev.update_async(scen["Z"])                      # no error yet: nothing has been waited for
+    with pytest.raises(pkg.capi.EngineError) as e:
+        dev.synchronize()
+    assert e.value.status == pkg.capi.ERR_CAPACITY
+
+    scen = sc.make_scenario(8, 5, 6, seed=13)
+    dev = pkg.RBPHDFilter(8, gm_capacity=64)
+    orc = ob.OracleFilter(8)
+    for f in (dev, orc):
+        sc.load_scenario(f, scen, maps=False)
+    dev.update_async(np.zeros((0, 2)))
+    dev.synchronize()
+    np.testing.assert_array_equal(dev.get_weights(), np.ones(8))
+    dev.update_async(scen["Z"])
+    dev.synchronize()
+    orc.update(scen["Z"])
+    assert np.array_equal(dev.gm_sizes(), np.zeros(8, np.int32))
+    np.testing.assert_array_equal(dev.get_weights(), orc.get_weights())
+
+    scen = sc.make_scenario(16, 40, 12, seed=19)
+    a, _ = make_pair(pkg, ob, sc, scen)
+    b, _ = make_pair(pkg, ob, sc, scen)
+    rng = np.random.default_rng(1)
+    Zs = [scen["Z"] + rng.normal(0, 1e-3, scen["Z"].shape) for _ in range(6)]
+    for Z in Zs:                                     # pipelined: predict + update + normalise, never waiting
+        a.predict_map(True)
+        a.update_async(Z)
+        a.weight_sums_async()
+        a.normalize_weights(0.0, a.weight_sums_device_ptr())
+    a.synchronize()
+    for Z in Zs:
+        b.predict_map(True)
+        b.update(Z)
+        s = b.weight_sums()
+        b.normalize_weights(s[0])
+    np.testing.assert_array_equal(a.get_weights(), b.get_weights())
+    for i in range(scen["n"]):
+        for x, y in zip(a.export_gm(i), b.export_gm(i)):
+            np.testing.assert_array_equal(x, y)
+    avg, nsteps = a.kernel_time_stats()
+    assert nsteps == 0 or avg[0] > 0                 # (statistics were harvested by synchronize())
+
+
 def test_get_landmark_and_bad_indices(pkg, sc):
     scen = sc.make_scenario(4, 10, 4, seed=17)
     dev = pkg.RBPHDFilter(4, gm_capacity=64)
