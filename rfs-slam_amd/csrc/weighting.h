@@ -456,89 +456,114 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
   const int nE = sScrI[0];
 
   DBG_TB(16, 2);
-  // ---- 3b. intensity at the evaluation points (:776-800): groups of EG points, dealt to the waves ----
+  // ---- 3b / 4-6: two independent strands after the evaluation points are known ----
+  //   intensity at the evaluation points (:776-800): groups of EG points in registers, a pass over the mixture per group;
+  //   likelihood table (:847-863) -> partitions -> assignment sums (:865-990).
+  // With one wave they run one after the other.  With several, wave 0 takes the table and the (largely serial) partition
+  // work while the other waves share the intensity groups: neither strand reads what the other writes (the sums go to the
+  // rank-sort permutation's storage, free since step 2).
   constexpr int EG = WEIGHT_EVAL_GROUP;
-  double *sumB = reinterpret_cast<double *>(s.compRows), *sumA = sumB + 64;  // [64] each (free until step 5)
-  for (int e0 = EG * wave; e0 < nE; e0 += EG * WPP) {
-    double accB[EG], accA[EG];
+  const bool split = WPP > 1 && (size_t)B.cap * 4 >= 128 * sizeof(double);  // (the permutation's storage must hold 2 x 64 doubles)
+  double *sumB = reinterpret_cast<double *>(split ? (void *)s.perm : (void *)s.compRows), *sumA = sumB + 64;  // [64] each
+  const int iw = split ? wave - 1 : wave, nIw = split ? WPP - 1 : WPP;  // this wave's share of the intensity groups
+  if (!split || wave > 0) {
+    for (int e0 = EG * iw; e0 < nE; e0 += EG * nIw) {
+      double accB[EG], accA[EG];
 #pragma unroll
-    for (int t = 0; t < EG; t++) { accB[t] = 0.0; accA[t] = 0.0; }
-    // the evaluation points are re-read from LDS (broadcast) inside the pair loop: two LDS reads per pair cost less
-    // than the 4*EG registers that holding them would take from the accumulators' budget (128 VGPRs at 4 waves/SIMD)
-    const double *gx = s.evX + e0, *gy = s.evY + e0;
-    const int nG = (nE - e0 < EG) ? nE - e0 : EG;
-    for (int m = lane; m < N; m += 64) {
-      const double w = s.keys[m], wp = qWP[m], mx = qMX[m], my = qMY[m];
-      const double sxx = qSXX[m], sxy = qSXY[m], syy = qSYY[m];
-      double i00, i01, i10, i11, det;
-      inv2(sxx, sxy, sxy, syy, i00, i01, i10, i11, det);
-      // 1 / sqrt((2 pi)^2 det) once per Gaussian: the pair loop multiplies instead of dividing (<= 1.5 ulp from the
-      // reference's exp(.)/factor, far inside the 1e-9 weight tolerance) -- a division per pair costs as much as the exp
-      const double rfac = 1.0 / pdf_factor2(det);
-      int opaque = 0;
-      asm volatile("" : "+v"(opaque));  // keeps the (loop-invariant) LDS reads below inside the loop
+      for (int t = 0; t < EG; t++) { accB[t] = 0.0; accA[t] = 0.0; }
+      // the evaluation points are re-read from LDS (broadcast) inside the pair loop: two LDS reads per pair cost less
+      // than the 4*EG registers that holding them would take from the accumulators' budget (128 VGPRs at 4 waves/SIMD)
+      const double *gx = s.evX + e0, *gy = s.evY + e0;
+      const int nG = (nE - e0 < EG) ? nE - e0 : EG;
+      for (int m = lane; m < N; m += 64) {
+        const double w = s.keys[m], wp = qWP[m], mx = qMX[m], my = qMY[m];
+        const double sxx = qSXX[m], sxy = qSXY[m], syy = qSYY[m];
+        double i00, i01, i10, i11, det;
+        inv2(sxx, sxy, sxy, syy, i00, i01, i10, i11, det);
+        // 1 / sqrt((2 pi)^2 det) once per Gaussian: the pair loop multiplies instead of dividing (<= 1.5 ulp from the
+        // reference's exp(.)/factor, far inside the 1e-9 weight tolerance) -- a division per pair costs as much as the exp
+        const double rfac = 1.0 / pdf_factor2(det);
+        int opaque = 0;
+        asm volatile("" : "+v"(opaque));  // keeps the (loop-invariant) LDS reads below inside the loop
+#pragma unroll
+        for (int t = 0; t < EG; t++) {
+          const int tt = ((t < nG) ? t : 0) + opaque;
+          const double d0 = gx[tt] - mx, d1 = gy[tt] - my;
+          const double t0 = d0 * i00 + d1 * i01, t1 = d0 * i01 + d1 * i11;  // (i10 == i01: Sigma is stored symmetric)
+          const double md2 = t0 * d0 + t1 * d1;
+          double lik = (md2 > 1500.0) ? 0.0 : exp(-0.5 * md2) * rfac;  // exactly 0 beyond 1500 (gauss_from_md2)
+          lik = (lik != lik) ? 0.0 : lik;                                // NaN -> 0 (include/RandomVec.hpp:417-434)
+          accB[t] += wp * lik;
+          accA[t] += w * lik;
+        }
+      }
 #pragma unroll
       for (int t = 0; t < EG; t++) {
-        const int tt = ((t < nG) ? t : 0) + opaque;
-        const double d0 = gx[tt] - mx, d1 = gy[tt] - my;
-        const double t0 = d0 * i00 + d1 * i01, t1 = d0 * i01 + d1 * i11;  // (i10 == i01: Sigma is stored symmetric)
-        const double md2 = t0 * d0 + t1 * d1;
-        double lik = (md2 > 1500.0) ? 0.0 : exp(-0.5 * md2) * rfac;  // exactly 0 beyond 1500 (gauss_from_md2)
-        lik = (lik != lik) ? 0.0 : lik;                                // NaN -> 0 (include/RandomVec.hpp:417-434)
-        accB[t] += wp * lik;
-        accA[t] += w * lik;
+        const double b = wave_sum_dpp(accB[t]), a = wave_sum_dpp(accA[t]);
+        if (lane == 0 && e0 + t < nE) { sumB[e0 + t] = b; sumA[e0 + t] = a; }
       }
     }
-#pragma unroll
-    for (int t = 0; t < EG; t++) {
-      const double b = wave_sum_dpp(accB[t]), a = wave_sum_dpp(accA[t]);
-      if (lane == 0 && e0 + t < nE) { sumB[e0 + t] = b; sumA[e0 + t] = a; }
-    }
+
   }
+  if (!split) block_sync();
 
   DBG_TB(16, 3);
-  // ---- 4. likelihood table L[e][n] = N(z_n; h(x, e), S_e) * Pd_e, gated (:847-863) ----
-  if (tid < nE) {
-    MeasOut mo;
-    rb_measure(P, pr, s.evX[tid], s.evY[tid], 0.0, 0.0, 0.0, mo);  // evalPt_copy.setCov(Zero)
-    double i00, i01, i10, i11, det;
-    inv2(mo.s00, mo.s01, mo.s10, mo.s11, i00, i01, i10, i11, det);
-    double *z = s.evZ + 7 * tid;
-    z[0] = mo.z0; z[1] = mo.z1; z[2] = i00; z[3] = i01; z[4] = i10; z[5] = i11; z[6] = pdf_factor2(det);
+  double l = 1.0;
+  if (!split || wave == 0) {
+    // ---- 4. likelihood table L[e][n] = N(z_n; h(x, e), S_e) * Pd_e, gated (:847-863) ----
+    const int t0i = split ? lane : tid, tN = split ? 64 : NT;
+    if (t0i < nE) {
+      MeasOut mo;
+      rb_measure(P, pr, s.evX[t0i], s.evY[t0i], 0.0, 0.0, 0.0, mo);  // evalPt_copy.setCov(Zero)
+      double i00, i01, i10, i11, det;
+      inv2(mo.s00, mo.s01, mo.s10, mo.s11, i00, i01, i10, i11, det);
+      double *z = s.evZ + 7 * t0i;
+      z[0] = mo.z0; z[1] = mo.z1; z[2] = i00; z[3] = i01; z[4] = i10; z[5] = i11; z[6] = pdf_factor2(det);
+    }
+    if (split) wave_sync(); else block_sync();
+    for (int idx = t0i; idx < nE * nZ; idx += tN) {
+      const int e = idx / nZ, n = idx - e * nZ;
+      const double *z = s.evZ + 7 * e;
+      const double d0 = sZ[2 * n] - z[0], d1 = sZ[2 * n + 1] - z[1];
+      const double t0 = d0 * z[2] + d1 * z[4], t1 = d0 * z[3] + d1 * z[5];
+      const double md2 = t0 * d0 + t1 * d1;
+      double Lv = gauss_from_md2(md2, z[6]) * s.evPd[e];
+      if (md2 > P.weightingMd2) Lv = 0.0;
+      s.L[idx] = Lv;
+    }
+    if (split) wave_sync(); else block_sync();
   }
-  block_sync();
-  for (int idx = tid; idx < nE * nZ; idx += NT) {
-    const int e = idx / nZ, n = idx - e * nZ;
-    const double *z = s.evZ + 7 * e;
-    const double d0 = sZ[2 * n] - z[0], d1 = sZ[2 * n + 1] - z[1];
-    const double t0 = d0 * z[2] + d1 * z[4], t1 = d0 * z[3] + d1 * z[5];
-    const double md2 = t0 * d0 + t1 * d1;
-    double Lv = gauss_from_md2(md2, z[6]) * s.evPd[e];
-    if (md2 > P.weightingMd2) Lv = 0.0;
-    s.L[idx] = Lv;
-  }
-  block_sync();
-  if (wave != 0) return;  // the rest is wave 0's
-
-  // the products over the evaluation points, in order (the sums were left in LDS by the waves)
   double prodBefore = 1.0, prodAfter = 1.0;
-  for (int e = 0; e < nE; e++) {
-    prodBefore *= (RFS_DENORM_MIN + sumB[e]);
-    prodAfter *= (RFS_DENORM_MIN + sumA[e]);
+  if (!split) {
+    if (wave != 0) return;  // the rest is wave 0's
+    // the products over the evaluation points, in order (the sums were left in LDS by the waves)
+    for (int e = 0; e < nE; e++) {
+      prodBefore *= (RFS_DENORM_MIN + sumB[e]);
+      prodAfter *= (RFS_DENORM_MIN + sumA[e]);
+    }
+    wave_sync();  // (sumA / sumB live in the component scratch that step 5 reuses)
   }
-  const double sumPrev = sScr[0], sumCur = sScr[1];
-  wave_sync();  // (sumA / sumB live in the component scratch that step 5 reuses)
-
   DBG_TB(16, 4);
 #ifdef RFS_PROFILE
   const long long dbgT4 = (long long)__builtin_readcyclecounter();
 #endif
-  // ---- 5./6. partition the table, sum the assignments of every partition (shared with the 3-D kernel) ----
+  if (wave == 0) {
+    // ---- 5./6. partition the table, sum the assignments of every partition (shared with the 3-D kernel) ----
 #ifdef RFS_PROFILE
-  const double l = rfs_partitions_wave(s, nE, nZ, P.clutter, lane, i, Q, B.err, B.dbg);
+    l = rfs_partitions_wave(s, nE, nZ, P.clutter, lane, i, Q, B.err, B.dbg);
 #else
-  const double l = rfs_partitions_wave(s, nE, nZ, P.clutter, lane, i, Q, B.err);
+    l = rfs_partitions_wave(s, nE, nZ, P.clutter, lane, i, Q, B.err);
 #endif
+  }
+  if (split) {
+    block_sync();          // the intensity sums of the other waves are complete
+    if (wave != 0) return;
+    for (int e = 0; e < nE; e++) {
+      prodBefore *= (RFS_DENORM_MIN + sumB[e]);
+      prodAfter *= (RFS_DENORM_MIN + sumA[e]);
+    }
+  }
+  const double sumPrev = sScr[0], sumCur = sScr[1];
   const double sensingArea = 2 * RFS_PI * (P.rmax - P.rmin);
   const double ml = l / (P.clutter * sensingArea);  // clutterIntensityIntegral (src/MeasurementModel_RngBrg.cpp:175-178)
 
