@@ -3,11 +3,9 @@
 //
 // gm_merge keeps the reference's sequential-greedy semantics exactly: for i ascending, j ascending > i, j is
 // absorbed into i as soon as md2_i(j) <= t^2 or md2_j(i) <= t^2, and i's mean/covariance change before j+1 is
-// tested.  Wave-parallel form: the whole mixture (mean, packed covariance, its inverse, weight) is staged in
-// LDS; for the current i the 64 lanes test 64 candidates j at once against i's CURRENT state, the lowest
-// passing lane is merged (ballot + ctz), and only lanes above it are re-tested against the new state.
-// Holes (absorbed Gaussians; landmark == NULL, weight 0 in the reference) are written back with weight -1 so
-// that gm_prune drops them.
+// tested.  How that becomes parallel work (grid-based candidate lists against the initial states, speculative row
+// replay with ordered validation) is described at gm_merge_particle below.  Holes (absorbed Gaussians; landmark == NULL,
+// weight 0 in the reference) are written back with weight -1 so that gm_prune drops them.
 //
 // gm_prune: rank-sort the survivors (w >= threshold) by (weight desc, index asc) and compact them into the
 // other slab.  The reference keeps exactly the sorted prefix with w >= t (binary search + linear walk).

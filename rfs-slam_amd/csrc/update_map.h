@@ -3,14 +3,15 @@
 // (src/KalmanFilter_RngBrg.cpp:52-65) and MeasurementModel_RngBrg::{measure, probabilityOfDetection}
 // fused into one kernel.
 //
-// One 64-lane wavefront per particle; lanes stride over that particle's landmarks (pass*64 + lane).
-// The measurement set is staged once per block in LDS.  The nM x nZ weight table of the reference never
-// exists: pass 1 keeps, per landmark, a 64-bit mask of the measurements that survive the gates (LDS) and
-// accumulates the per-measurement normalisers in the reference's summation order (clutter, then landmarks in
-// index order: ballot + readlane in lane order); pass 2 recomputes the few surviving pairs, normalises,
-// appends the new Gaussians in (m,z) row-major order through a wave prefix sum, and writes the
-// missed-detection weights.  HBM traffic per particle = one read of the mixture per pass + the appended
-// records + the weight planes.
+// Two forms of the same per-particle routine (see the comments above each): phd_update_map_particle, one wavefront per
+// particle (the stand-alone kernel), and phd_update_map_block, a workgroup per particle (inside the fused step kernel).
+// The measurement set is staged once per workgroup in LDS and, where the index is wave-uniform, read through the scalar
+// cache.  The nM x nZ weight table of the reference never exists: phase 1 builds each landmark's innovation-gate bitmask,
+// puts only the gated pairs through the Mahalanobis gate and the Gaussian, and writes the survivors into a dense
+// (m, z)-row-major list in LDS (list position == output slot); lane z folds the survivors of measurement z into its
+// normaliser in the reference's summation order (clutter, then landmarks ascending).  Phase 2 is dense over the list:
+// normalise, recompute the landmark's KF quantities, emit.  Phase 3: missed-detection weights + near-limit heuristic.
+// HBM traffic per particle = one read of the mixture + the appended records + the weight planes.
 #pragma once
 #include "common.h"
 

@@ -3,13 +3,14 @@
 // (src/CostMatrix.cpp:92-157) + the <=8 partial-assignment enumeration that the reference drives through
 // PermutationLexicographic (src/PermutationLexicographic.cpp:38-96).
 //
-// One wavefront per particle.  Steps: (1) rank-sort the mixture by weight (weight desc, index asc) in LDS and
-// write the sorted mixture to the other slab (the order merge needs); (2) pick the evaluation points;
-// (3) intensity products before/after the update -- lanes stride over Gaussians, 8 evaluation points at a time
-// in registers; (4) likelihood table L (nE x nZ) in LDS; (5) bipartite connected components by min-label
-// propagation over 64-bit adjacency masks, numbered like BGL's DFS discovery order (by smallest vertex), incl.
-// the reference's zero-partition merge and its partition-indexing quirk; (6) one lane per partition sums the
-// partial assignments; partitions with nR+nC > 8 go to the Murty work queue (murty.h).
+// One workgroup of WPP waves per particle (phd_weight_particle).  Steps: (1) rank-sort the mixture by weight (weight
+// desc, index asc; fp32 first pass, exact fp64 completion) on all threads and write the sorted mixture to the other slab
+// (the order merge needs); (2) pick the evaluation points (wave 0) while the last wave sums the weights; then two
+// concurrent strands -- (3) intensity products before/after the update on waves 1.., lanes over Gaussians, 8 evaluation
+// points at a time in registers; (4) likelihood table L (nE x nZ) in LDS, (5) bipartite connected components by
+// min-label propagation over 64-bit adjacency masks, numbered like BGL's DFS discovery order (by smallest vertex), incl.
+// the reference's zero-partition merge and its partition-indexing quirk, (6) one lane per partition sums the partial
+// assignments, on wave 0; partitions with nR+nC > 8 go to the Murty work queue (murty.h).  (7) the particle weight.
 #pragma once
 #include "common.h"
 
