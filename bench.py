@@ -95,7 +95,11 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--particles", type=int, default=N_PARTICLES)
+    ap.add_argument("--particles", type=int, default=N_PARTICLES, help="particles per GPU")
+    ap.add_argument("--shards-per-gpu", type=int, default=1,
+                    help="independent shards (handles, HIP streams) the GPU's particles are split into.  Measured on MI355X at C2a: "
+                         "2 shards that never meet overlap each other's short serial kernels (+20 %% throughput), but the per-step "
+                         "weight normalisation couples them again and the gain is lost (4390 vs 4780 steps/s), so the default is 1")
     args = ap.parse_args()
 
     import torch
@@ -131,37 +135,78 @@ def main():
         dist.broadcast(zt, 0)
         scen["Z"] = zt.cpu().numpy()
 
-    f = pkg.RBPHDFilter(n_local, device_id=local_rank, gm_capacity=CAP)
-    sc.load_scenario(f, scen)
-    ts = torch.cuda.Stream()      # engine kernels, RCCL all-reduce and the timing events all order on this stream
-    torch.cuda.set_stream(ts)
-    f.set_stream(ts.cuda_stream)
-    sums = torch.zeros(2, dtype=torch.float64, device="cuda")
-    f.bind_weight_sums_buffer(sums.data_ptr())
-    f.save_state()
+    # The GPU's particles are held by S shards (handles), each on its own HIP stream (default 1; see --shards-per-gpu).
+    # Shards -- on one GPU or on different GPUs -- only meet in the weight normalisation: per-shard {sum w, sum w^2} ->
+    # RCCL all-reduce (N > 1) -> on-device divide by the sum over all shards.
+    S = args.shards_per_gpu
+    if n_local % S:
+        raise SystemExit("--particles must be divisible by --shards-per-gpu")
+    n_sh = n_local // S
+    dev = torch.device("cuda", local_rank)
+    shards, streams, evs = [], [], []
+    parts = torch.zeros(S, 2, dtype=torch.float64, device=dev)   # shard k's {sum w, sum w^2} lands in parts[k]
+    for k in range(S):
+        sub = dict(scen)
+        lo, hi = k * n_sh, (k + 1) * n_sh
+        sub.update(n=n_sh, poses=scen["poses"][lo:hi], w=scen["w"][lo:hi], mean=scen["mean"][lo:hi], cov=scen["cov"][lo:hi],
+                   particle_w=scen["particle_w"][lo:hi])
+        if np.ndim(scen["pose_cov"]) == 3:
+            sub["pose_cov"] = scen["pose_cov"][lo:hi]
+        fk = pkg.RBPHDFilter(n_sh, device_id=local_rank, gm_capacity=CAP)
+        sc.load_scenario(fk, sub)
+        tk = torch.cuda.Stream()
+        fk.set_stream(tk.cuda_stream)      # engine kernels and the timing events of this shard order on this stream
+        fk.bind_weight_sums_buffer(parts[k].data_ptr())
+        fk.save_state()
+        shards.append(fk); streams.append(tk); evs.append(torch.cuda.Event())
+    ev_red = torch.cuda.Event()
     Z = scen["Z"]
-    sh = pkg.sharded.ShardedRBPHDFilter(f, device=torch.device("cuda", local_rank))
+    f = shards[0]
+    parts_ptr = parts.data_ptr()
 
     def step():
-        f.restore_state()
-        f.update_async(Z)   # stream-ordered: the host never waits inside a step; device errors surface at the final sync
-        # device reduction of {sum w, sum w^2} -> RCCL all-reduce over xGMI (the only collective on the path, N>1)
-        # -> on-device divide; no host round trip for the sums
-        sh.normalize(sums)
+        for k in range(S):
+            fk = shards[k]
+            fk.restore_state()
+            fk.update_async(Z)   # stream-ordered: the host never waits inside a step; device errors surface at the final sync
+            fk.weight_sums_async()
+            if S > 1 or world > 1:
+                evs[k].record(streams[k])
+        # every shard divides by the sum over all shards of all GPUs: the per-shard pairs sit side by side in `parts`; across
+        # GPUs they are all-reduced in place (the only collective on the path: 2*S doubles over xGMI); the divide adds the S
+        # entries on the device.  Shard 0's stream carries the reduction.
+        if world > 1:
+            with torch.cuda.stream(streams[0]):
+                for k in range(1, S):
+                    streams[0].wait_event(evs[k])
+                dist.all_reduce(parts)
+                ev_red.record(streams[0])
+            for k in range(1, S):
+                streams[k].wait_event(ev_red)
+        elif S > 1:
+            for k in range(S):
+                for j in range(S):
+                    if j != k:
+                        streams[k].wait_event(evs[j])
+        for k in range(S):
+            shards[k].normalize_weights(0.0, parts_ptr, S)   # divisor read on the device
 
     for _ in range(args.warmup):
         step()
-    # shapes for the algorithmic byte counts (one instrumented step, untimed)
-    f.restore_state()
-    nM = int(f.gm_sizes().sum())
-    f.update_map(Z)
-    nAfter = int(f.gm_sizes().sum())
-    f.importance_weighting(); f.merge(); f.prune()
-    nKept = int(f.gm_sizes().sum())
-    bytes_k = algorithmic_bytes(n_local, nM, nAfter - nM, nKept, N_Z)
+    # shapes for the algorithmic byte counts (one instrumented step of every shard, untimed)
+    nM = nAfter = nKept = 0
+    for fk in shards:
+        fk.restore_state()
+        nM += int(fk.gm_sizes().sum())
+        fk.update_map(Z)
+        nAfter += int(fk.gm_sizes().sum())
+        fk.importance_weighting(); fk.merge(); fk.prune()
+        nKept += int(fk.gm_sizes().sum())
+    bytes_k = algorithmic_bytes(n_local, nM, nAfter - nM, nKept, N_Z)   # per step of this GPU (all its shards)
 
-    f.synchronize()
-    f.kernel_time_stats()       # discard the warm-up statistics
+    for fk in shards:
+        fk.synchronize()
+        fk.kernel_time_stats()       # discard the warm-up statistics
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -177,26 +222,36 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    f.synchronize()             # raises if any step overflowed / hit an unsupported case
-    # per-kernel HIP-event pairs recorded on the engine's stream inside every timed step, harvested after the region
-    kern_avg, n_harvested = f.kernel_time_stats()
+    # per-kernel HIP-event pairs recorded on each shard's stream inside every timed step, harvested after the region
+    kern_ms = np.zeros(3)
+    for fk in shards:
+        fk.synchronize()             # raises if any step overflowed / hit an unsupported case
+        ka, _ = fk.kernel_time_stats()
+        kern_ms += np.array(ka) / 1e6
+    kern_ms /= S                     # average duration of ONE launch (one shard); S launches run concurrently
     ms_per_step = dt / args.steps * 1e3
-    kern_ms = np.array(kern_avg) / 1e6
-    w = f.get_weights()
-    assert np.all(np.isfinite(w)) and abs(w.sum() * world - 1.0) < 1e-6 or world > 1, "weights did not normalise"
+    wsum = sum(float(fk.get_weights().sum()) for fk in shards)
+    assert np.isfinite(wsum) and (world > 1 or abs(wsum - 1.0) < 1e-6), "weights did not normalise"
 
     # rfsgpu_update_async runs the step as ONE kernel (step_fused.h) unless RFSGPU_FUSED_STEP=0: kernel_time_stats then
     # reports [fused step, 0, 0].  The per-phase breakdown (and the likelihood-sweep rate the north star asks for) comes
-    # from the three stand-alone kernels, measured with the same HIP events in an untimed pass after the region.
+    # from the three stand-alone kernels on the whole GPU's particles in ONE handle, measured with the same HIP events in an
+    # untimed pass after the region.
     fused = kern_ms[1] == 0.0 and kern_ms[2] == 0.0
     phase_ms = kern_ms
     if fused:
+        for fk in shards[1:]:
+            fk.close()
+        fa = pkg.RBPHDFilter(n_local, device_id=local_rank, gm_capacity=CAP)
+        sc.load_scenario(fa, scen)
+        fa.save_state()
         acc = np.zeros(3)
         reps = 20
-        for _ in range(reps):
-            f.restore_state()
-            f.update(Z)
-            acc += np.array(f.last_kernel_ns()[:3], dtype=np.float64)
+        for r in range(reps + 3):
+            fa.restore_state()
+            fa.update(Z)
+            if r >= 3:
+                acc += np.array(fa.last_kernel_ns()[:3], dtype=np.float64)
         phase_ms = acc / reps / 1e6
 
     if rank == 0:
@@ -207,10 +262,22 @@ def main():
         if fused:
             tot_bytes = int(sum(bytes_k[name] for name in KERNELS))
             dname = "phd_step_fused"
-            achieved = round(tot_bytes / (kern_ms[0] * 1e-3) / 1e9, 2)
+            per_launch = round((tot_bytes / S) / (kern_ms[0] * 1e-3) / 1e9, 2)
+            if S == 1:
+                achieved = per_launch
+                how = "algorithmic bytes of the launch / its HIP-event duration"
+            else:
+                # The S launches of a step (one per shard, tot_bytes / S each) overlap on the device, so a single launch's
+                # bytes / duration understates what the device moves while they run.  Reported instead: the bytes of ALL S
+                # launches over the WHOLE step time (which also contains the short serial kernels) -- a lower bound on the
+                # device-level rate during the fused kernels, never an overstatement.
+                achieved = round(tot_bytes / (ms_per_step * 1e-3) / 1e9, 2)
+                how = (f"algorithmic bytes of the {S} overlapping launches of a step / step time (lower bound); one launch alone: "
+                       f"{per_launch} GB/s over {round(float(kern_ms[0]), 5)} ms")
             fused_entry = dict(ms=round(float(kern_ms[0]), 5), algorithmic_bytes=tot_bytes, achieved_GBps=achieved,
-                               note="update_map + weighting + merge/prune of a particle in one workgroup, one launch per step; "
-                                    "measured inside the timed region")
+                               launches_per_step=S, algorithmic_bytes_per_launch=tot_bytes // S, per_launch_GBps=per_launch,
+                               note="update_map + weighting + merge/prune of a particle in one workgroup; one launch per shard "
+                                    "per step, measured inside the timed region")
             per_kernel = {"phd_step_fused": fused_entry,
                           "standalone_phases_untimed_pass": per_kernel}
             sweep = per_kernel["standalone_phases_untimed_pass"]["phd_update_map"]
@@ -238,15 +305,17 @@ def main():
                 "workload": f"C2a: {n_local} particles/GPU x {N_LANDMARKS} GM landmarks x {N_Z} measurements/step, all landmarks in FOV, "
                             "2D RngBrg model, multi-feature weighting (nEvalPt 15), state re-seeded from a device snapshot every step",
                 "particles_total": n_local * world,
+                "shards_per_gpu": S,
                 "unit_definition": "one step = one update(Z) of one shard of %d particles; value sums the shard-steps of all ranks "
                                    "(global filter of %d particles: %.3f updates/s)" % (n_local, n_local * world, args.steps / dt),
-                "parallelism": f"particle-sharded x{world}, RCCL all-reduce of 2 doubles/step",
+                "parallelism": f"particle-sharded: {world} GPU(s) x {S} shard(s) per GPU on separate HIP streams, RCCL all-reduce of 2 doubles/step",
                 "gm_after_update": nAfter // n_local, "gm_after_prune": nKept // n_local,
                 "kernels": per_kernel,
                 "likelihood_sweep": sweep,
             },
             "roofline": {"bound": "hbm", "kernel": dname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(dname),
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(dname), "achieved_definition": how if fused else
+                         "algorithmic bytes of the launch / its HIP-event duration",
                          "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload)"},
         }
         if not args.no_cpu_baseline:

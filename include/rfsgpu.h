@@ -245,6 +245,10 @@ void *rfsgpu_weight_sums_device_ptr(rfsgpu_filter *f);
 /* w_i /= sum (sum = global sum over all shards).  If sum_dev != NULL the divisor is read on the
  * device from sum_dev[0] (after an in-place all-reduce) and `sum` is ignored. */
 int rfsgpu_normalize_weights(rfsgpu_filter *f, double sum, const void *sum_dev);
+/* The same when several shards (handles on one GPU and / or other GPUs) share the normalisation: sum_dev points to
+ * n_parts consecutive {sum w, sum w^2} pairs (each shard's rfsgpu_bind_weight_sums_buffer slot, all-reduced in place
+ * across GPUs); the divisor is the sum of their first elements, added in index order on the device. */
+int rfsgpu_normalize_weights_parts(rfsgpu_filter *f, double sum, const void *sum_dev, int n_parts);
 /* Apply a resampling decision: slot k takes a deep copy of slot src_slot[k]'s map, unused list and
  * FOV count (Particle::copy -> GaussianMixture copy-ctor); src_slot[k] == k keeps it.  All weights
  * are reset to 1 (ParticleFilter.hpp:486-489).  Sources must be slots that keep themselves. */

@@ -1763,6 +1763,10 @@ int rfsor_normalize_weights(void *f, double sum, const void *sum_dev) {
   for (int i = 0; i < F->n; i++) F->weight[i] = F->weight[i] / sum;
   return RFSGPU_OK;
 }
+int rfsor_normalize_weights_parts(void *f, double sum, const void *sum_dev, int n_parts) {
+  (void)n_parts;
+  return rfsor_normalize_weights(f, sum, sum_dev); /* the CPU side always gets the total on the host */
+}
 int rfsor_resample_apply(void *f, const int *src) {
   FilterBase *F = F_(f);
   for (int k = 0; k < F->n; k++) if (src[k] < 0 || src[k] >= F->n || src[src[k]] != src[k]) return RFSGPU_ERR_INVALID;

@@ -114,6 +114,7 @@ ABI_SYMBOLS = [
     "set_model_victoriapark", "set_laser_scan", "export_birth_candidates", "import_birth_candidates",
     "update_async", "kernel_time_stats",
     "default_fastslam_config", "set_fastslam_config", "get_fastslam_config", "fastslam_update",
+    "normalize_weights_parts",
 ]
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -377,8 +378,11 @@ class CFilter:
         self._call("weight_sums", self._ptr(out))
         return out
 
-    def normalize_weights(self, total, sum_dev_ptr=None):
-        self._call("normalize_weights", C.c_double(total), C.c_void_p(sum_dev_ptr))
+    def normalize_weights(self, total, sum_dev_ptr=None, n_parts=1):
+        if n_parts == 1:
+            self._call("normalize_weights", C.c_double(total), C.c_void_p(sum_dev_ptr))
+        else:
+            self._call("normalize_weights_parts", C.c_double(total), C.c_void_p(sum_dev_ptr), C.c_int(n_parts))
 
     def resample_apply(self, src_slot):
         s = np.ascontiguousarray(src_slot, dtype=np.int32)

@@ -732,8 +732,13 @@ __global__ __launch_bounds__(1024) void weight_sums_kernel(const double *w, int 
     out2[0] = x; out2[1] = y;
   }
 }
-__global__ void normalize_kernel(double *w, int N, double sum, const double *sumDev) {
-  const double sdiv = sumDev ? sumDev[0] : sum;
+// sumDev: nParts pairs {sum w, sum w^2} (one per shard sharing the normalisation); the divisor is their sum, in order
+__global__ void normalize_kernel(double *w, int N, double sum, const double *sumDev, int nParts) {
+  double sdiv = sum;
+  if (sumDev) {
+    sdiv = sumDev[0];
+    for (int p = 1; p < nParts; p++) sdiv += sumDev[2 * p];
+  }
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < N) w[k] = w[k] / sdiv;
 }

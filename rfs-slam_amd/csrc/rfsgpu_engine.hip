@@ -944,12 +944,14 @@ int rfsgpu_weight_sums(rfsgpu_filter *f, double *out) {
   out[1] = f->hSums[1];
   return RFSGPU_OK;
 }
-int rfsgpu_normalize_weights(rfsgpu_filter *f, double sum, const void *sum_dev) {
+int rfsgpu_normalize_weights(rfsgpu_filter *f, double sum, const void *sum_dev) { return rfsgpu_normalize_weights_parts(f, sum, sum_dev, 1); }
+int rfsgpu_normalize_weights_parts(rfsgpu_filter *f, double sum, const void *sum_dev, int n_parts) {
   CHECK_HANDLE(f);
+  if (n_parts < 1) return RFSGPU_ERR_INVALID;
   hipSetDevice(f->device);
   long long t0 = now_ns();
   HIPCHK(hipEventRecord(f->ev[EV_R0], f->stream));
-  normalize_kernel<<<(f->N + 255) / 256, 256, 0, f->stream>>>(f->B.weight, f->N, sum, (const double *)sum_dev);
+  normalize_kernel<<<(f->N + 255) / 256, 256, 0, f->stream>>>(f->B.weight, f->N, sum, (const double *)sum_dev, n_parts);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(f->ev[EV_R1], f->stream));
   // stream-ordered, no host sync: the next call that syncs (or rfsgpu_synchronize) completes it; its event pair is
