@@ -268,3 +268,98 @@ def test_resample_decision_properties(ob):
         assert np.all(np.abs(counts - 50 * wn) < 1 + 1e-9)
     fired2, _, _ = ob.resample_decide(np.ones(50), 25.0, 0.3)
     assert not fired2
+
+
+# ---- FastSLAM 1.0 update (include/FastSLAM.hpp:424-706), written from the equations with scipy's assignment solver ------
+
+def np_fastslam_update(P, F, pose, pose_cov, w_particle, lw, mu, Sig, Z):
+    """One particle, no candidate queue (count threshold 1): returns (new particle weight, log-odds, means, covariances)
+    before pruning order is applied (sorted by log-odds descending, entries below the prune threshold dropped)."""
+    from scipy.optimize import linear_sum_assignment
+    nZ = len(Z)
+    lim = F["minLog"]
+    rows = []
+    for m in range(len(lw)):
+        zexp, H, S, ok, r = np_measure(P, pose, pose_cov, mu[m], Sig[m])
+        pd, close = np_pd(P, r)
+        if pd != 0 or close:
+            rows.append((m, pd, zexp, H, S, ok))
+    nM = len(rows)
+    n = max(nM, nZ)
+    T = np.full((n, n), lim)
+    for k, (m, pd, zexp, H, S, ok) in enumerate(rows):
+        if ok:
+            for z in range(nZ):
+                T[k, z] = max(lim, multivariate_normal(zexp, S).logpdf(Z[z]))      # raw difference, like the reference
+    r_idx, c_idx = linear_sum_assignment(T, maximize=True)
+    da = dict(zip(r_idx, c_idx))
+    pfa = P["clutter"] * 2 * np.pi * (P["rmax"] - P["rmin"]) / nZ
+    prior = F["prior"]
+    lw, mu, Sig = lw.copy(), mu.copy(), Sig.copy()
+    used = np.zeros(nZ, bool)
+    logw = 0.0
+    for k, (m, pd, zexp, H, S, ok) in enumerate(rows):
+        z = da.get(k, -1)
+        upd = False
+        if 0 <= z < nZ and T[k, z] > lim:
+            e = Z[z] - zexp
+            nu = np.array([e[0], wrap(e[1])])
+            if not ((P["kf_range"] > 0 and abs(nu[0]) > P["kf_range"]) or (P["kf_bearing"] > 0 and abs(nu[1]) > P["kf_bearing"])):
+                K = Sig[m] @ H.T @ np.linalg.inv(S)
+                Pn = (np.eye(2) - K @ H) @ Sig[m]
+                mu[m] = mu[m] + K @ nu
+                Sig[m] = (Pn + Pn.T) / 2
+                upd = True
+        if upd:
+            used[z] = True
+            logw += T[k, z]
+            pe = ((1 - pd) * pfa * prior + pd * prior) / (pfa + (1 - pfa) * pd * prior)
+        else:
+            pe = ((1 - pd) * prior) / ((1 - prior) + (1 - pd) * prior)
+            if lw[m] > F["lock"]:
+                pe = 0.5
+        lw[m] = lw[m] + np.log(pe / (1 - pe))
+    keep = lw >= F["prune"]
+    lw, mu, Sig = lw[keep], mu[keep], Sig[keep]
+    order = np.argsort(-lw, kind="stable")
+    lw, mu, Sig = lw[order], mu[order], Sig[order]
+    new_w = np.log(prior / (1 - prior))
+    for z in range(nZ):
+        if not used[z]:
+            a = pose[2] + Z[z][1]
+            x = pose[:2] + Z[z][0] * np.array([np.cos(a), np.sin(a)])
+            Hi = np.array([[np.cos(a), -Z[z][0] * np.sin(a)], [np.sin(a), Z[z][0] * np.cos(a)]])
+            lw = np.append(lw, new_w)
+            mu = np.vstack([mu, x]) if len(mu) else x[None]
+            Sig = np.concatenate([Sig, (Hi @ np.asarray(P["R"]) @ Hi.T)[None]]) if len(Sig) else (Hi @ np.asarray(P["R"]) @ Hi.T)[None]
+    return w_particle * np.exp(logw), lw, mu, Sig
+
+
+@pytest.mark.parametrize("seed,nm,nz,rmax", [(3, 12, 6, 5.0), (4, 40, 14, 10.0), (5, 5, 12, 5.0)])
+def test_fastslam_update_against_numpy(ob, sc, seed, nm, nz, rmax):
+    """The oracle's FastSLAM restatement (CostMatrix::reduce + Murty's first = Hungarian optimum on the reduced table) against
+    a direct formulation: scipy's assignment on the FULL table, numpy KF / log-odds algebra, immediate landmark creation."""
+    n = 6
+    scen = sc.make_scenario(n, nm, nz, seed=seed, rmax=rmax)
+    P = scen["params"]
+    orc = ob.OracleFilter(n, stable_sort=True)
+    sc.load_scenario(orc, scen)
+    lw0 = np.random.default_rng(seed).uniform(-1.0, 2.0, (n, nm))
+    for i in range(n):
+        orc.import_gm(i, lw0[i], scen["mean"][i], scen["cov"][i])
+    cfg = orc.default_fastslam_config()
+    orc.set_fastslam_config(cfg)
+    orc.fastslam_update(scen["Z"])
+    F = dict(minLog=cfg.minLogMeasurementLikelihood, prior=cfg.landmarkExistencePrior, lock=cfg.landmarkLockWeight, prune=cfg.mapExistencePruneThreshold)
+    Pn = dict(R=np.asarray(P["R"]).reshape(2, 2), rmin=P["rmin"], rmax=P["rmax"], rbuf=P["rbuf"], Pd=P["Pd"], clutter=P["clutter"],
+              kf_range=P["kf_range"], kf_bearing=P["kf_bearing"])
+    pose_cov = np.asarray(scen["pose_cov"]).reshape(3, 3)
+    w = orc.get_weights()
+    for i in range(n):
+        wi, lw, mu, Sig = np_fastslam_update(Pn, F, scen["poses"][i], pose_cov, 1.0, lw0[i], scen["mean"][i], scen["cov"][i], scen["Z"])
+        np.testing.assert_allclose(w[i], wi, rtol=1e-9)
+        g = orc.export_gm(i)
+        assert len(g[0]) == len(lw)
+        np.testing.assert_allclose(g[0], lw, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(g[2], mu, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(g[3], Sig, rtol=1e-8, atol=1e-14)
