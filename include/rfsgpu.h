@@ -149,6 +149,13 @@ int rfsgpu_abi_version(void);
  * Gaussian slots (rounded up to a multiple of 64); must cover the transient size right after the
  * map update (nM + new Gaussians).  Exceeding it sets RFSGPU_ERR_CAPACITY, never corrupts memory. */
 int rfsgpu_create(rfsgpu_filter **out, int model, int n_particles, int device_id, int gm_capacity);
+/* The same with room for the particle set to GROW up to max_particles (>= n_particles): FastSLAM's multi-hypothesis
+ * update multiplies particles (FastSLAM.hpp:543-551, ParticleFilter::copyParticle) until resampleWithMapCopy brings the
+ * set back to its initial size.  rfsgpu_n_particles = nParticles_ now; every array argument of the other calls has that
+ * many entries. */
+int rfsgpu_create_ex(rfsgpu_filter **out, int model, int n_particles, int device_id, int gm_capacity, int max_particles);
+int rfsgpu_n_particles(const rfsgpu_filter *f);
+int rfsgpu_max_particles(const rfsgpu_filter *f);
 /* Replaces ~RBPHDFilter (:395-403). */
 void rfsgpu_destroy(rfsgpu_filter *f);
 /* Human-readable text for the last non-OK status on this handle (never NULL). */
@@ -253,6 +260,10 @@ int rfsgpu_normalize_weights_parts(rfsgpu_filter *f, double sum, const void *sum
  * FOV count (Particle::copy -> GaussianMixture copy-ctor); src_slot[k] == k keeps it.  All weights
  * are reset to 1 (ParticleFilter.hpp:486-489).  Sources must be slots that keep themselves. */
 int rfsgpu_resample_apply(rfsgpu_filter *f, const int *src_slot);
+/* ParticleFilter::resample(n) with n < nParticles_ (:417-483; FastSLAM::resampleWithMapCopy): the first n_out slots
+ * receive src_slot[0..n_out), the particle count becomes n_out.  A source below n_out must keep itself; sources at or
+ * beyond n_out are dropped after the copy. */
+int rfsgpu_resample_apply_n(rfsgpu_filter *f, const int *src_slot, int n_out);
 
 /* ---- timing / misc ---------------------------------------------------------------------------- */
 

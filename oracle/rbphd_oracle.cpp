@@ -852,7 +852,9 @@ struct FilterBase {
   virtual void import_candidates(int slot, int cnt, const double *mean, const double *cov, const int *support, const int *checks) = 0;
   /* FastSLAM (include/FastSLAM.hpp) on the same state: mixtures = landmark maps with log-odds weights */
   rfsgpu_fastslam_config fs;
+  bool fs_resample_occured = false; /* FastSLAM::resampleOccured_: the previous update ended in a resampling */
   virtual int fastslam_update() = 0;
+  virtual void shrink(int n_out) = 0;
 };
 
 static void fastslam_defaults(rfsgpu_fastslam_config *c, int n) { /* FastSLAM constructor, include/FastSLAM.hpp:243-257 */
@@ -1304,16 +1306,23 @@ struct FilterT : FilterBase {
     }
   }
 
-  /* FastSLAM::updateMap (include/FastSLAM.hpp:424-706) for one particle, single data-association hypothesis
-   * (config.maxNDataAssocHypotheses_ == 1: `murty.findNextBest` is called once == the Hungarian optimum of the reduced
-   * table; no particle copies). */
-  void fastslam_update_particle(int i) {
+  /* FastSLAM::updateMap (include/FastSLAM.hpp:424-706), split the way the reference's own control flow falls apart:
+   * (1) data association of one particle -> up to maxNDataAssocHypotheses_ assignments (:430-541), (2) particle copies for
+   * the extra hypotheses (:543-556, ParticleFilter::copyParticle), (3) the map / weight update of one particle under one
+   * assignment (:559-703). */
+  struct FsAssoc {
+    std::vector<int> idx_inRange;
+    std::vector<double> pd_inRange;
+    std::vector<std::vector<double>> T;     /* likelihoodTable after reduce() */
+    std::vector<std::vector<int>> da;       /* da[h][m] */
+  };
+  void fastslam_associate(int i, FsAssoc &A) {
     const int nZl = nZ;
     const Pose &ps = pose[i];
     std::vector<Gauss> &G = gm[i];
     unsigned nM = gm_n[i];
-    std::vector<int> idx_inRange;
-    std::vector<double> pd_inRange;
+    std::vector<int> &idx_inRange = A.idx_inRange;
+    std::vector<double> &pd_inRange = A.pd_inRange;
     for (unsigned m = 0; m < nM; m++) { /* :440-449 */
       bool closeToLimit = false;
       double pd = model.pd(ps, G[m].x, G[m].S, closeToLimit);
@@ -1323,8 +1332,9 @@ struct FilterT : FilterBase {
     unsigned nMZ = nM;
     if ((unsigned)nZl > nM) nMZ = nZl;
     const double lim = fs.minLogMeasurementLikelihood;
-    std::vector<std::vector<double>> T(nMZ, std::vector<double>(nMZ, lim)); /* :458-465 */
-    for (unsigned m = 0; m < nM; m++) {                                      /* :468-481 */
+    std::vector<std::vector<double>> &T = A.T;
+    T.assign(nMZ, std::vector<double>(nMZ, lim)); /* :458-465 */
+    for (unsigned m = 0; m < nM; m++) {           /* :468-481 */
       const Gauss &lm = G[idx_inRange[m]];
       double z_exp[D];
       MatD S;
@@ -1333,40 +1343,58 @@ struct FilterT : FilterBase {
         if (ok) T[m][z] = fmax(lim, log(gauss_lik<D>(z_exp, S, &Z[(size_t)D * z], nullptr)));
     }
     ReducedCost R = cost_matrix_reduce(T, (int)nMZ, lim); /* :484-490 */
-    std::vector<int> da(nMZ, -1);                          /* da_current */
     if (R.nRed == 0) {                                     /* :498-505 */
+      std::vector<int> da(nMZ, -1);
       for (unsigned m = 0; m < nM; m++) da[m] = R.a_fixed[m];
-    } else {                                               /* :506-541, one pass of the loop */
-      std::vector<std::vector<double>> Cr(R.nRed, std::vector<double>(R.nRed));
-      std::vector<double *> rows(R.nRed);
-      for (int a = 0; a < R.nRed; a++) {
-        for (int b = 0; b < R.nRed; b++) Cr[a][b] = T[R.iRed[a]][R.jRed[b]];
-        rows[a] = Cr[a].data();
-      }
+      A.da.push_back(da);
+      return;
+    }
+    std::vector<std::vector<double>> Cr(R.nRed, std::vector<double>(R.nRed));
+    std::vector<double *> rows(R.nRed);
+    for (int a = 0; a < R.nRed; a++) {
+      for (int b = 0; b < R.nRed; b++) Cr[a][b] = T[R.iRed[a]][R.jRed[b]];
+      rows[a] = Cr[a].data();
+    }
 #pragma omp critical(fs_counters)
-      {
-        fs_solver_calls++;
-        /* rows / columns of the reduced table that still have a possibility (the rest only see the floor) */
-        int live = 0;
-        for (int a = 0; a < R.nRed; a++) { bool any = false; for (int b = 0; b < R.nRed; b++) any |= Cr[a][b] > lim; live += any; }
-        if (live > fs_solver_max_dim) fs_solver_max_dim = live;
-      }
-      Murty murty(rows.data(), R.nRed);
+    {
+      fs_solver_calls++;
+      /* rows / columns of the reduced table that still have a possibility (the rest only see the floor) */
+      int live = 0;
+      for (int a = 0; a < R.nRed; a++) { bool any = false; for (int b = 0; b < R.nRed; b++) any |= Cr[a][b] > lim; live += any; }
+      if (live > fs_solver_max_dim) fs_solver_max_dim = live;
+    }
+    Murty murty(rows.data(), R.nRed);
+    unsigned nH = 0;                                       /* :506-541 */
+    double bestScore = 0;
+    while (nH < fs.maxNDataAssocHypotheses) {
       std::vector<int> daVar;
       double logLikelihoodSum = 0;
-      int nH = murty.findNextBest(daVar, logLikelihoodSum);
+      const unsigned nH_old = nH;
+      const int k = murty.findNextBest(daVar, logLikelihoodSum);
+      if (k == -1) { nH = nH_old; break; }
+      nH = (unsigned)k;
+      if (k == 1) bestScore = logLikelihoodSum;            /* Murty::getBestScore() */
+      if (bestScore - logLikelihoodSum >= fs.maxDataAssocLogLikelihoodDiff) { nH--; break; }
+      std::vector<int> da(nMZ, -1);
       for (unsigned m = 0; m < nM; m++) da[m] = R.a_fixed[m];
-      if (nH != -1) {
-        for (int m = 0; m < R.nRed; m++) {
-          int z_o = R.jRed[daVar[m]];
-          int m_o = R.iRed[m];
-          da[m_o] = (z_o < nZl) ? z_o : -2;
-        }
-      } else {
-        /* the reference would carry on with nH == 0 hypotheses, i.e. leave the particle untouched (:543-551 loop runs 0 times) */
-        return;
+      for (int m = 0; m < R.nRed; m++) {
+        int z_o = R.jRed[daVar[m]];
+        int m_o = R.iRed[m];
+        da[m_o] = (z_o < nZl) ? z_o : -2;
       }
+      A.da.push_back(da);
     }
+    /* nH == 0 (the solver failed at once): no hypothesis, the particle is left untouched (:543-551 runs 0 times) */
+  }
+  void fastslam_apply(int i, const FsAssoc &A, const std::vector<int> &da) {
+    const int nZl = nZ;
+    const Pose &ps = pose[i];
+    std::vector<Gauss> &G = gm[i];
+    const std::vector<int> &idx_inRange = A.idx_inRange;
+    const std::vector<double> &pd_inRange = A.pd_inRange;
+    const std::vector<std::vector<double>> &T = A.T;
+    const unsigned nM = idx_inRange.size();
+    const double lim = fs.minLogMeasurementLikelihood;
     /* one hypothesis: :559-703 */
     const double nExpectedClutter = model.clutter_integral();
     const double probFalseAlarm = nExpectedClutter / nZl;
@@ -1444,9 +1472,46 @@ struct FilterT : FilterBase {
     weight[i] = weight[i] * exp(logParticleWeight); /* :696-697 */
   }
   int fastslam_update() override {
-    if (fs.maxNDataAssocHypotheses > 1) { err = "multi-hypothesis FastSLAM is not built"; return RFSGPU_ERR_UNSUPPORTED; }
+    const int n0 = n; /* stopIdx: particles added during this update are not visited (:389-391) */
+    std::vector<FsAssoc> assoc(n0);
 #pragma omp parallel for schedule(dynamic, 4)
-    for (int i = 0; i < n; i++) fastslam_update_particle(i);
+    for (int i = 0; i < n0; i++) fastslam_associate(i, assoc[i]);
+    /* landmarkCandidates_.resize(nParticles * maxNDataAssocHypotheses) (:392-395): only ever grows, old lists stay */
+    if (cand.size() < (size_t)n0 * fs.maxNDataAssocHypotheses) cand.resize((size_t)n0 * fs.maxNDataAssocHypotheses);
+    /* particle copies, in particle order (the reference does this inside an omp critical section, i.e. in arrival order;
+     * its single-threaded order is restated): pi[0] = i, pi[h] = nParticles_ - h after the copies (:543-556) */
+    std::vector<std::vector<int>> pi(n0);
+    for (int i = 0; i < n0; i++) {
+      const int nH = (int)assoc[i].da.size();
+      pi[i].assign(nH > 0 ? nH : 1, i);
+      if (nH > 1) {
+        const double newWeight = weight[i] / nH;
+        weight[i] = newWeight;
+        for (int c = 0; c < nH - 1; c++) { /* ParticleFilter::copyParticle (ParticleFilter.hpp:273-294) */
+          pose.push_back(pose[i]);
+          weight.push_back(newWeight);
+          gm.push_back(gm[i]);
+          gm_n.push_back(gm_n[i]);
+          unused.push_back(unused[i]);
+          nInFov.push_back(nInFov[i]);
+          n++;
+          if (cand.size() < (size_t)n) cand.resize(n);
+        }
+        for (int h = 1; h < nH; h++) {
+          pi[i][h] = n - h;
+          if (fs_resample_occured) cand[pi[i][h]] = cand[pi[i][0]];
+        }
+      }
+    }
+    /* the updates, one per (particle, hypothesis) */
+    std::vector<std::pair<int, int>> work;
+    for (int i = 0; i < n0; i++)
+      for (int h = 0; h < (int)assoc[i].da.size(); h++) work.push_back({i, h});
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int t = 0; t < (int)work.size(); t++) {
+      const int i = work[t].first, h = work[t].second;
+      fastslam_apply(pi[i][h], assoc[i], assoc[i].da[h]);
+    }
     return RFSGPU_OK;
   }
 
@@ -1527,6 +1592,11 @@ struct FilterT : FilterBase {
     cand[dst] = cand[src]; /* birthGaussians_[i] = birthGaussians_[i_prev] (:1005-1011) */
   }
   void set_lmk_noise(const double *Q) override { memcpy(Qlm.a, Q, D * D * sizeof(double)); }
+  void shrink(int n_out) override {
+    n = n_out;
+    pose.resize(n); weight.resize(n); gm.resize(n); gm_n.resize(n); unused.resize(n); nInFov.resize(n);
+    /* cand (landmarkCandidates_ / birthGaussians_) keeps its size: stale lists stay in the slots beyond n */
+  }
   int export_candidates(int slot, int max_n, double *mean, double *cov, int *support, int *checks) override {
     int k = 0;
     for (const Candidate &c : cand[slot]) {
@@ -1597,6 +1667,12 @@ int rfsor_create(void **out, int model, int n_particles, int device_id, int gm_c
   *out = F;
   return RFSGPU_OK;
 }
+int rfsor_create_ex(void **out, int model, int n_particles, int device_id, int gm_capacity, int max_particles) {
+  if (max_particles < n_particles) return RFSGPU_ERR_INVALID;
+  return rfsor_create(out, model, n_particles, device_id, gm_capacity); /* the CPU state grows on demand */
+}
+int rfsor_n_particles(const void *f) { return f ? reinterpret_cast<const FilterBase *>(f)->n : -1; }
+int rfsor_max_particles(const void *f) { return f ? 1 << 30 : -1; }
 void rfsor_destroy(void *f) { delete F_(f); }
 const char *rfsor_last_error(const void *f) { return f ? reinterpret_cast<const FilterBase *>(f)->err.c_str() : "null handle"; }
 
@@ -1767,15 +1843,19 @@ int rfsor_normalize_weights_parts(void *f, double sum, const void *sum_dev, int 
   (void)n_parts;
   return rfsor_normalize_weights(f, sum, sum_dev); /* the CPU side always gets the total on the host */
 }
-int rfsor_resample_apply(void *f, const int *src) {
+int rfsor_resample_apply_n(void *f, const int *src, int n_out) {
   FilterBase *F = F_(f);
-  for (int k = 0; k < F->n; k++) if (src[k] < 0 || src[k] >= F->n || src[src[k]] != src[k]) return RFSGPU_ERR_INVALID;
-  for (int k = 0; k < F->n; k++) {
-    if (src[k] != k) F->copy_particle(k, src[k]);
+  if (n_out < 1 || n_out > F->n) return RFSGPU_ERR_INVALID;
+  for (int k = 0; k < n_out; k++) if (src[k] < 0 || src[k] >= F->n || (src[k] < n_out && src[src[k]] != src[k])) return RFSGPU_ERR_INVALID;
+  for (int k = 0; k < n_out; k++) {
+    if (src[k] != k) F->copy_particle(k, src[k]); /* (poses are the host's: it pushes the resampled poses afterwards) */
     F->weight[k] = 1;
   }
+  F->shrink(n_out); /* particleSet_.resize(n) (ParticleFilter.hpp:481-483); the candidate lists beyond n stay where they are */
   return RFSGPU_OK;
 }
+int rfsor_resample_apply(void *f, const int *src) { return rfsor_resample_apply_n(f, src, F_(f)->n); }
+int rfsor_fastslam_set_resample_occured(void *f, int flag) { F_(f)->fs_resample_occured = flag != 0; return RFSGPU_OK; }
 
 /* ParticleFilter::resample (include/ParticleFilter.hpp:399-492) decision + systematic sampling +
  * slot assignment, given the uniform draw u01 (= the reference's single drand48()).

@@ -114,7 +114,7 @@ ABI_SYMBOLS = [
     "set_model_victoriapark", "set_laser_scan", "export_birth_candidates", "import_birth_candidates",
     "update_async", "kernel_time_stats",
     "default_fastslam_config", "set_fastslam_config", "get_fastslam_config", "fastslam_update",
-    "normalize_weights_parts",
+    "normalize_weights_parts", "create_ex", "n_particles", "max_particles", "resample_apply_n",
 ]
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -137,18 +137,25 @@ def _f64(a, shape=None):
 class CFilter:
     """One filter handle behind the C ABI (one GPU / one shard of particles)."""
 
-    def __init__(self, lib, prefix, n_particles, model=MODEL_RNGBRG_2D, device_id=0, gm_capacity=512):
+    def __init__(self, lib, prefix, n_particles, model=MODEL_RNGBRG_2D, device_id=0, gm_capacity=512, max_particles=None):
         self._lib, self._p = lib, prefix
-        self.n = int(n_particles)
         self.model = model
         self.dm = self.dz = 3 if model == MODEL_VICTORIAPARK_3D else 2
         self._h = C.c_void_p()
-        fn = self._fn("create")
+        fn = self._fn("create_ex")
         fn.restype = C.c_int
-        rc = fn(C.byref(self._h), C.c_int(model), C.c_int(self.n), C.c_int(device_id), C.c_int(gm_capacity))
+        rc = fn(C.byref(self._h), C.c_int(model), C.c_int(int(n_particles)), C.c_int(device_id), C.c_int(gm_capacity),
+                C.c_int(int(max_particles) if max_particles is not None else int(n_particles)))
         if rc != OK:
             self._h = C.c_void_p()
             raise EngineError(rc, "create failed (no gfx950 device / bad arguments)")
+
+    @property
+    def n(self):
+        """nParticles_: the particle count NOW (the multi-hypothesis FastSLAM update and resample_apply_n change it)."""
+        fn = self._fn("n_particles")
+        fn.restype = C.c_int
+        return fn(self._h)
 
     # -- plumbing ------------------------------------------------------------------------------
     def _fn(self, name):
@@ -384,10 +391,15 @@ class CFilter:
         else:
             self._call("normalize_weights_parts", C.c_double(total), C.c_void_p(sum_dev_ptr), C.c_int(n_parts))
 
-    def resample_apply(self, src_slot):
+    def resample_apply(self, src_slot, n_out=None):
+        """ParticleFilter::resample's copies; n_out < n shrinks the particle set (resample(n), ParticleFilter.hpp:417-483)."""
         s = np.ascontiguousarray(src_slot, dtype=np.int32)
-        assert s.size == self.n
-        self._call("resample_apply", self._ptr(s))
+        if n_out is None:
+            assert s.size == self.n
+            self._call("resample_apply", self._ptr(s))
+        else:
+            assert s.size == n_out
+            self._call("resample_apply_n", self._ptr(s), C.c_int(int(n_out)))
 
     # -- timing --------------------------------------------------------------------------------
     def getTimingInfo(self):

@@ -33,7 +33,9 @@ enum { EV_UM0 = 0, EV_UM1, EV_W1, EV_MG1, EV_PR1, EV_P0, EV_P1, EV_R0, EV_R1, EV
 
 struct rfsgpu_filter {
   int device = 0;
-  int N = 0, cap = 0;
+  int N = 0, cap = 0;       // particles in use, Gaussians per particle
+  int snapN = 0;            // particle count of the saved state
+  int Ncap = 0;             // particle slots allocated (rfsgpu_create_ex >= N): the multi-hypothesis FastSLAM update grows N up to it
   int model = RFSGPU_MODEL_RNGBRG_2D;
   int D = 2;          // d_m == d_z
   rfsgpu_vp_config vp{};
@@ -193,6 +195,10 @@ void rfsgpu_default_filter_config(rfsgpu_filter_config *c) {  // RBPHDFilter.hpp
 }
 
 int rfsgpu_create(rfsgpu_filter **out, int model, int n_particles, int device_id, int gm_capacity) {
+  return rfsgpu_create_ex(out, model, n_particles, device_id, gm_capacity, n_particles);
+}
+int rfsgpu_create_ex(rfsgpu_filter **out, int model, int n_particles, int device_id, int gm_capacity, int max_particles) {
+  if (max_particles < n_particles) return RFSGPU_ERR_INVALID;
   if (!out || n_particles <= 0 || (model != RFSGPU_MODEL_RNGBRG_2D && model != RFSGPU_MODEL_VICTORIAPARK_3D) || gm_capacity <= 0) return RFSGPU_ERR_INVALID;
   *out = nullptr;
   int ndev = 0;
@@ -200,6 +206,7 @@ int rfsgpu_create(rfsgpu_filter **out, int model, int n_particles, int device_id
   rfsgpu_filter *f = new rfsgpu_filter();
   f->device = device_id;
   f->N = n_particles;
+  f->Ncap = max_particles;
   f->model = model;
   f->D = (model == RFSGPU_MODEL_VICTORIAPARK_3D) ? 3 : 2;
   f->cap = ((gm_capacity + 63) / 64) * 64;
@@ -220,45 +227,45 @@ int rfsgpu_create(rfsgpu_filter **out, int model, int n_particles, int device_id
   B.N = f->N;
   B.cap = f->cap;
   B.npl = (f->D == 3) ? (int)P3_COUNT : (int)PL_COUNT;
-  const size_t slabBytes = (size_t)f->N * B.npl * f->cap * sizeof(double);
+  const size_t slabBytes = (size_t)f->Ncap * B.npl * f->cap * sizeof(double);
   bool ok = true;
   ok &= hipMalloc(&B.slab[0], slabBytes) == hipSuccess;
   ok &= hipMalloc(&B.slab[1], slabBytes) == hipSuccess;
-  ok &= hipMalloc(&B.count, f->N * sizeof(int)) == hipSuccess;
-  ok &= hipMalloc(&B.pose, (size_t)f->N * 3 * sizeof(double)) == hipSuccess;
-  ok &= hipMalloc(&B.poseCov, (size_t)f->N * 9 * sizeof(double)) == hipSuccess;
-  ok &= hipMalloc(&B.weight, f->N * sizeof(double)) == hipSuccess;
-  ok &= hipMalloc(&B.unusedMask, f->N * sizeof(unsigned long long)) == hipSuccess;
-  ok &= hipMalloc(&B.nInFov, f->N * sizeof(int)) == hipSuccess;
+  ok &= hipMalloc(&B.count, f->Ncap * sizeof(int)) == hipSuccess;
+  ok &= hipMalloc(&B.pose, (size_t)f->Ncap * 3 * sizeof(double)) == hipSuccess;
+  ok &= hipMalloc(&B.poseCov, (size_t)f->Ncap * 9 * sizeof(double)) == hipSuccess;
+  ok &= hipMalloc(&B.weight, f->Ncap * sizeof(double)) == hipSuccess;
+  ok &= hipMalloc(&B.unusedMask, f->Ncap * sizeof(unsigned long long)) == hipSuccess;
+  ok &= hipMalloc(&B.nInFov, f->Ncap * sizeof(int)) == hipSuccess;
   ok &= hipMalloc(&B.err, sizeof(int)) == hipSuccess;
   ok &= hipMalloc(&B.Z, RFSGPU_MAX_Z * 3 * sizeof(double)) == hipSuccess;
   ok &= hipMalloc(&B.scan, RFSGPU_VP_MAX_SCAN * sizeof(double)) == hipSuccess;
-  ok &= hipMalloc(&B.candMean, (size_t)f->N * RFSGPU_MAX_CANDIDATES * 3 * sizeof(double)) == hipSuccess;
-  ok &= hipMalloc(&B.candCov, (size_t)f->N * RFSGPU_MAX_CANDIDATES * 6 * sizeof(double)) == hipSuccess;
-  ok &= hipMalloc(&B.candSup, (size_t)f->N * RFSGPU_MAX_CANDIDATES * sizeof(int)) == hipSuccess;
-  ok &= hipMalloc(&B.candChk, (size_t)f->N * RFSGPU_MAX_CANDIDATES * sizeof(int)) == hipSuccess;
-  ok &= hipMalloc(&B.candCount, (size_t)f->N * sizeof(int)) == hipSuccess;
+  ok &= hipMalloc(&B.candMean, (size_t)f->Ncap * RFSGPU_MAX_CANDIDATES * 3 * sizeof(double)) == hipSuccess;
+  ok &= hipMalloc(&B.candCov, (size_t)f->Ncap * RFSGPU_MAX_CANDIDATES * 6 * sizeof(double)) == hipSuccess;
+  ok &= hipMalloc(&B.candSup, (size_t)f->Ncap * RFSGPU_MAX_CANDIDATES * sizeof(int)) == hipSuccess;
+  ok &= hipMalloc(&B.candChk, (size_t)f->Ncap * RFSGPU_MAX_CANDIDATES * sizeof(int)) == hipSuccess;
+  ok &= hipMalloc(&B.candCount, (size_t)f->Ncap * sizeof(int)) == hipSuccess;
   ok &= hipMalloc(&f->ownSums, 2 * sizeof(double)) == hipSuccess;
   f->dSums = f->ownSums;
-  ok &= hipMalloc(&f->dSrcSlot, f->N * sizeof(int)) == hipSuccess;
+  ok &= hipMalloc(&f->dSrcSlot, f->Ncap * sizeof(int)) == hipSuccess;
   ok &= hipHostMalloc(&f->hErr, sizeof(int)) == hipSuccess;
   ok &= hipHostMalloc(&f->hJobCount, sizeof(int)) == hipSuccess;
   ok &= hipHostMalloc(&f->hSums, 2 * sizeof(double)) == hipSuccess;
   for (int k = 0; k < RFSGPU_ASYNC_RING; k++)
     for (int e = 0; e < 5; e++) ok &= hipEventCreate(&f->ring[k][e]) == hipSuccess;
   if (!ok) return bail(RFSGPU_ERR_HIP);
-  if (murty_alloc(f->Q, f->MS, f->N) != 0) return bail(RFSGPU_ERR_HIP);
+  if (murty_alloc(f->Q, f->MS, f->Ncap) != 0) return bail(RFSGPU_ERR_HIP);
   hipMemsetAsync(B.slab[0], 0, slabBytes, f->stream);
   hipMemsetAsync(B.slab[1], 0, slabBytes, f->stream);
-  hipMemsetAsync(B.count, 0, f->N * sizeof(int), f->stream);
-  hipMemsetAsync(B.pose, 0, (size_t)f->N * 3 * sizeof(double), f->stream);
-  hipMemsetAsync(B.poseCov, 0, (size_t)f->N * 9 * sizeof(double), f->stream);
-  hipMemsetAsync(B.unusedMask, 0, f->N * sizeof(unsigned long long), f->stream);
-  hipMemsetAsync(B.nInFov, 0, f->N * sizeof(int), f->stream);
+  hipMemsetAsync(B.count, 0, f->Ncap * sizeof(int), f->stream);
+  hipMemsetAsync(B.pose, 0, (size_t)f->Ncap * 3 * sizeof(double), f->stream);
+  hipMemsetAsync(B.poseCov, 0, (size_t)f->Ncap * 9 * sizeof(double), f->stream);
+  hipMemsetAsync(B.unusedMask, 0, f->Ncap * sizeof(unsigned long long), f->stream);
+  hipMemsetAsync(B.nInFov, 0, f->Ncap * sizeof(int), f->stream);
   hipMemsetAsync(B.err, 0, sizeof(int), f->stream);
   hipMemsetAsync(B.Z, 0, RFSGPU_MAX_Z * 3 * sizeof(double), f->stream);
   hipMemsetAsync(B.scan, 0, RFSGPU_VP_MAX_SCAN * sizeof(double), f->stream);
-  hipMemsetAsync(B.candCount, 0, (size_t)f->N * sizeof(int), f->stream);
+  hipMemsetAsync(B.candCount, 0, (size_t)f->Ncap * sizeof(int), f->stream);
   B.nScan = 0;
   set_weights_kernel<<<(f->N + 255) / 256, 256, 0, f->stream>>>(B.weight, f->N, 1.0);
   if (hipStreamSynchronize(f->stream) != hipSuccess) return bail(RFSGPU_ERR_HIP);
@@ -960,13 +967,20 @@ int rfsgpu_normalize_weights_parts(rfsgpu_filter *f, double sum, const void *sum
   f->timing.particleResample_cpu += now_ns() - t0;
   return RFSGPU_OK;
 }
-int rfsgpu_resample_apply(rfsgpu_filter *f, const int *src_slot) {
+int rfsgpu_n_particles(const rfsgpu_filter *f) { return f ? f->N : -1; }
+int rfsgpu_max_particles(const rfsgpu_filter *f) { return f ? f->Ncap : -1; }
+int rfsgpu_resample_apply(rfsgpu_filter *f, const int *src_slot) { return f ? rfsgpu_resample_apply_n(f, src_slot, f->N) : RFSGPU_ERR_INVALID; }
+int rfsgpu_resample_apply_n(rfsgpu_filter *f, const int *src_slot, int n_out) {
   CHECK_HANDLE(f);
-  if (!src_slot) return RFSGPU_ERR_INVALID;
-  for (int k = 0; k < f->N; k++) {
+  if (!src_slot || n_out < 1 || n_out > f->N) return RFSGPU_ERR_INVALID;
+  const int nIn = f->N;
+  for (int k = 0; k < n_out; k++) {
     const int s = src_slot[k];
-    if (s < 0 || s >= f->N || src_slot[s] != s) return fail(f, RFSGPU_ERR_INVALID, "resample_apply: a source slot must keep itself");
+    // a source is either a surviving slot that keeps itself or a slot beyond the new count (dropped after the copy)
+    if (s < 0 || s >= nIn || (s < n_out && src_slot[s] != s)) return fail(f, RFSGPU_ERR_INVALID, "resample_apply: a source slot below the new count must keep itself");
   }
+  f->N = n_out;
+  f->B.N = n_out;
   hipSetDevice(f->device);
   long long t0 = now_ns();
   HIPCHK(hipMemcpyAsync(f->dSrcSlot, src_slot, (size_t)f->N * sizeof(int), hipMemcpyHostToDevice, f->stream));
@@ -1024,14 +1038,14 @@ int rfsgpu_bind_weight_sums_buffer(rfsgpu_filter *f, void *dev_ptr) {
 int rfsgpu_save_state(rfsgpu_filter *f) {
   CHECK_HANDLE(f);
   hipSetDevice(f->device);
-  const size_t slabBytes = (size_t)f->N * f->B.npl * f->cap * sizeof(double);
+  const size_t slabBytes = (size_t)f->Ncap * f->B.npl * f->cap * sizeof(double);
   if (!f->snapSlab) {
     bool ok = true;
     ok &= hipMalloc(&f->snapSlab, slabBytes) == hipSuccess;
-    ok &= hipMalloc(&f->snapWeight, f->N * sizeof(double)) == hipSuccess;
-    ok &= hipMalloc(&f->snapCount, f->N * sizeof(int)) == hipSuccess;
-    ok &= hipMalloc(&f->snapFov, f->N * sizeof(int)) == hipSuccess;
-    ok &= hipMalloc(&f->snapUnused, f->N * sizeof(unsigned long long)) == hipSuccess;
+    ok &= hipMalloc(&f->snapWeight, f->Ncap * sizeof(double)) == hipSuccess;
+    ok &= hipMalloc(&f->snapCount, f->Ncap * sizeof(int)) == hipSuccess;
+    ok &= hipMalloc(&f->snapFov, f->Ncap * sizeof(int)) == hipSuccess;
+    ok &= hipMalloc(&f->snapUnused, f->Ncap * sizeof(unsigned long long)) == hipSuccess;
     if (!ok) return fail(f, RFSGPU_ERR_HIP, "save_state: out of device memory");
   }
   HIPCHK(hipMemcpyAsync(f->snapSlab, f->B.slab[f->cur], slabBytes, hipMemcpyDeviceToDevice, f->stream));
@@ -1041,12 +1055,15 @@ int rfsgpu_save_state(rfsgpu_filter *f) {
   HIPCHK(hipMemcpyAsync(f->snapUnused, f->B.unusedMask, f->N * sizeof(unsigned long long), hipMemcpyDeviceToDevice, f->stream));
   HIPCHK(hipStreamSynchronize(f->stream));
   f->snapNZ = f->nZ;
+  f->snapN = f->N;
   return RFSGPU_OK;
 }
 int rfsgpu_restore_state(rfsgpu_filter *f) {
   CHECK_HANDLE(f);
   if (!f->snapSlab) return fail(f, RFSGPU_ERR_INVALID, "restore_state: nothing saved");
   hipSetDevice(f->device);
+  f->N = f->snapN;  // (the particle count is part of the state: the multi-hypothesis FastSLAM update changes it)
+  f->B.N = f->N;
   // only the live entries are copied (one block per particle); asynchronous on the handle's stream
   restore_state_kernel<<<f->N, 256, 0, f->stream>>>(f->B, f->cur, f->snapSlab, f->snapWeight, f->snapCount, f->snapFov, f->snapUnused);
   HIPCHK(hipGetLastError());
@@ -1066,8 +1083,8 @@ int rfsgpu_debug_sections(rfsgpu_filter *f, long long *out64) {
   CHECK_HANDLE(f);
   hipSetDevice(f->device);
   if (!f->B.dbg) {
-    HIPCHK(hipMalloc(&f->B.dbg, (64 + 4 * (size_t)f->N) * sizeof(long long)));
-    HIPCHK(hipMemset(f->B.dbg, 0, (64 + 4 * (size_t)f->N) * sizeof(long long)));
+    HIPCHK(hipMalloc(&f->B.dbg, (64 + 4 * (size_t)f->Ncap) * sizeof(long long)));
+    HIPCHK(hipMemset(f->B.dbg, 0, (64 + 4 * (size_t)f->Ncap) * sizeof(long long)));
   }
   HIPCHK(hipMemcpy(out64, f->B.dbg, 64 * sizeof(long long), hipMemcpyDeviceToHost));
   return RFSGPU_OK;
@@ -1120,7 +1137,7 @@ int rfsgpu_fastslam_update(rfsgpu_filter *f, const double *z, int n_z) {
   int rc = stage_measurements(f, z, n_z);
   if (rc != RFSGPU_OK) return rc;
   hipSetDevice(f->device);
-  if (!f->fsArena) HIPCHK(hipMalloc(&f->fsArena, (size_t)f->N * fs_arena_bytes()));
+  if (!f->fsArena) HIPCHK(hipMalloc(&f->fsArena, (size_t)f->Ncap * fs_arena_bytes()));
   FsParams F;
   F.prior = f->fs.landmarkExistencePrior;
   F.minLog = f->fs.minLogMeasurementLikelihood;

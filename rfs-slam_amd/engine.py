@@ -36,8 +36,9 @@ def mat_perm(A, device_id=0):
 class RBPHDFilter(capi.CFilter):
     """Device-resident RB-PHD filter shard (one GPU).  Mirrors rfs::RBPHDFilter for the update path."""
 
-    def __init__(self, n_particles, device_id=0, gm_capacity=512, model=capi.MODEL_RNGBRG_2D):
-        super().__init__(load_library(), "rfsgpu_", n_particles, model=model, device_id=device_id, gm_capacity=gm_capacity)
+    def __init__(self, n_particles, device_id=0, gm_capacity=512, model=capi.MODEL_RNGBRG_2D, max_particles=None):
+        super().__init__(load_library(), "rfsgpu_", n_particles, model=model, device_id=device_id, gm_capacity=gm_capacity,
+                         max_particles=max_particles)
         self.config = self.default_filter_config()
         self.effNParticles_t = n_particles / 4.0  # ParticleFilter.hpp:232
         self.nUpdatesSinceResample = 0
