@@ -305,10 +305,19 @@ int rfsgpu_get_fastslam_config(const rfsgpu_filter *f, rfsgpu_fastslam_config *c
  * best data association, Kalman correction of the associated landmarks, existence log-odds, pruning, new landmarks /
  * candidates from the unassociated measurements, particle weight *= exp(sum of the associated log-likelihoods).
  * n_z == 0 returns OK without touching anything (:401-402).  resampleWithMapCopy (:708-735) stays with the caller
- * (rfsgpu_weight_sums / rfsgpu_normalize_weights / rfsgpu_resample_apply).  Multi-hypothesis FastSLAM
- * (config.maxNDataAssocHypotheses > 1: particles multiply by Murty's k best associations) is NOT built:
- * RFSGPU_ERR_UNSUPPORTED. */
+ * (rfsgpu_weight_sums / rfsgpu_normalize_weights / rfsgpu_resample_apply[_n]).
+ * Multi-hypothesis FastSLAM (config.maxNDataAssocHypotheses in 2..16): every particle keeps Murty's k best associations
+ * within maxDataAssocLogLikelihoodDiff of the best and is copied once per extra hypothesis (:506-556,
+ * ParticleFilter::copyParticle): the particle set GROWS (rfsgpu_n_particles; room from rfsgpu_create_ex, else
+ * RFSGPU_ERR_CAPACITY).  The copies are appended in particle order; rfsgpu_particle_parents tells the host which slot each
+ * particle was copied from (itself for the originals) so that it can duplicate its poses.  Limit of this path: landmarks in
+ * range and measurements <= 64 each (Murty runs on the dense reduced table like the reference). */
 int rfsgpu_fastslam_update(rfsgpu_filter *f, const double *z, int n_z);
+/* FastSLAM::resampleOccured_ (whether the previous update ended in a resampling): decides if the copies of a multiplied
+ * particle inherit its landmark candidates (:551-553).  The host mirror sets it after its resampleWithMapCopy. */
+int rfsgpu_fastslam_set_resample_occured(rfsgpu_filter *f, int flag);
+/* parent[k] = the slot particle k was copied from by the last rfsgpu_fastslam_update (k itself when it was not a copy). */
+int rfsgpu_particle_parents(rfsgpu_filter *f, int *parent, int max_n);
 
 #ifdef __cplusplus
 }

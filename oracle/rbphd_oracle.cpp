@@ -852,6 +852,7 @@ struct FilterBase {
   virtual void import_candidates(int slot, int cnt, const double *mean, const double *cov, const int *support, const int *checks) = 0;
   /* FastSLAM (include/FastSLAM.hpp) on the same state: mixtures = landmark maps with log-odds weights */
   rfsgpu_fastslam_config fs;
+  std::vector<int> parents; /* source slot of every particle after the last FastSLAM update */
   bool fs_resample_occured = false; /* FastSLAM::resampleOccured_: the previous update ended in a resampling */
   virtual int fastslam_update() = 0;
   virtual void shrink(int n_out) = 0;
@@ -1481,6 +1482,8 @@ struct FilterT : FilterBase {
     /* particle copies, in particle order (the reference does this inside an omp critical section, i.e. in arrival order;
      * its single-threaded order is restated): pi[0] = i, pi[h] = nParticles_ - h after the copies (:543-556) */
     std::vector<std::vector<int>> pi(n0);
+    parents.resize(n0);
+    for (int i = 0; i < n0; i++) parents[i] = i;
     for (int i = 0; i < n0; i++) {
       const int nH = (int)assoc[i].da.size();
       pi[i].assign(nH > 0 ? nH : 1, i);
@@ -1494,6 +1497,7 @@ struct FilterT : FilterBase {
           gm_n.push_back(gm_n[i]);
           unused.push_back(unused[i]);
           nInFov.push_back(nInFov[i]);
+          parents.push_back(i);
           n++;
           if (cand.size() < (size_t)n) cand.resize(n);
         }
@@ -1856,6 +1860,12 @@ int rfsor_resample_apply_n(void *f, const int *src, int n_out) {
 }
 int rfsor_resample_apply(void *f, const int *src) { return rfsor_resample_apply_n(f, src, F_(f)->n); }
 int rfsor_fastslam_set_resample_occured(void *f, int flag) { F_(f)->fs_resample_occured = flag != 0; return RFSGPU_OK; }
+int rfsor_particle_parents(void *f, int *parent, int max_n) {
+  FilterBase *F = F_(f);
+  if (max_n < F->n) return RFSGPU_ERR_INVALID;
+  for (int k = 0; k < F->n; k++) parent[k] = (k < (int)F->parents.size()) ? F->parents[k] : k;
+  return RFSGPU_OK;
+}
 
 /* ParticleFilter::resample (include/ParticleFilter.hpp:399-492) decision + systematic sampling +
  * slot assignment, given the uniform draw u01 (= the reference's single drand48()).

@@ -115,6 +115,7 @@ ABI_SYMBOLS = [
     "update_async", "kernel_time_stats",
     "default_fastslam_config", "set_fastslam_config", "get_fastslam_config", "fastslam_update",
     "normalize_weights_parts", "create_ex", "n_particles", "max_particles", "resample_apply_n",
+    "fastslam_set_resample_occured", "particle_parents",
 ]
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -219,6 +220,16 @@ class CFilter:
         cfg = FastSlamConfig()
         self._call("get_fastslam_config", C.byref(cfg))
         return cfg
+
+    def fastslam_set_resample_occured(self, flag):
+        self._call("fastslam_set_resample_occured", C.c_int(1 if flag else 0))
+
+    def particle_parents(self):
+        """Which slot each particle was copied from by the last (multi-hypothesis) fastslam_update."""
+        n = self.n
+        p = np.empty(n, dtype=np.int32)
+        self._call("particle_parents", self._ptr(p), C.c_int(n))
+        return p
 
     def fastslam_update(self, Z):
         """FastSLAM::updateMap for every particle (:387-418); resampleWithMapCopy stays with the caller."""

@@ -122,6 +122,68 @@ __device__ __forceinline__ double fs_cell_d(const FsRow<D> &r, const double *z, 
   return fmax(lim, log(l));
 }
 
+// kfs_.correct(pose, Z[z], lm, lm) (KalmanFilter.hpp:209-259) on landmark m of particle slot i, in place; true when the
+// correction was performed (measure() valid and the innovation inside the gates).
+template <int D>
+__device__ __forceinline__ bool fs_kf_correct(const Params &P, const PoseReg &pr, double *slab, int cap, int i, int m, const double *sZ, int z) {
+  bool upd = false;
+  if (D == 2) {
+    double *pMX = plane(slab, cap, i, PL_MX), *pMY = plane(slab, cap, i, PL_MY);
+    double *pSXX = plane(slab, cap, i, PL_SXX), *pSXY = plane(slab, cap, i, PL_SXY), *pSYY = plane(slab, cap, i, PL_SYY);
+    const double mx = pMX[m], my = pMY[m], sxx = pSXX[m], sxy = pSXY[m], syy = pSYY[m];
+    MeasOut mo;
+    rb_measure(P, pr, mx, my, sxx, sxy, syy, mo);
+    const double e0 = sZ[2 * z] - mo.z0;
+    const double w1 = wrap_pi(sZ[2 * z + 1] - mo.z1);
+    const bool gateR = !(P.kfRange > 0 && fabs(e0) > P.kfRange), gateB = !(P.kfBearing > 0 && fabs(w1) > P.kfBearing);
+    if (mo.inRange && gateR && gateB) {
+      double i00, i01, i10, i11, det;
+      inv2(mo.s00, mo.s01, mo.s10, mo.s11, i00, i01, i10, i11, det);
+      const double t00 = sxx * mo.h00 + sxy * mo.h01, t01 = sxx * mo.h10 + sxy * mo.h11;
+      const double t10 = sxy * mo.h00 + syy * mo.h01, t11 = sxy * mo.h10 + syy * mo.h11;
+      const double k00 = t00 * i00 + t01 * i10, k01 = t00 * i01 + t01 * i11;
+      const double k10 = t10 * i00 + t11 * i10, k11 = t10 * i01 + t11 * i11;
+      const double kh00 = k00 * mo.h00 + k01 * mo.h10, kh01 = k00 * mo.h01 + k01 * mo.h11;
+      const double kh10 = k10 * mo.h00 + k11 * mo.h10, kh11 = k10 * mo.h01 + k11 * mo.h11;
+      const double a00 = 1.0 - kh00, a01 = 0.0 - kh01, a10 = 0.0 - kh10, a11 = 1.0 - kh11;
+      const double q00 = a00 * sxx + a01 * sxy, q01 = a00 * sxy + a01 * syy;
+      const double q10 = a10 * sxx + a11 * sxy, q11 = a10 * sxy + a11 * syy;
+      pMX[m] = mx + (k00 * e0 + k01 * w1);
+      pMY[m] = my + (k10 * e0 + k11 * w1);
+      pSXX[m] = (q00 + q00) / 2;
+      pSXY[m] = (q01 + q10) / 2;
+      pSYY[m] = (q11 + q11) / 2;
+      upd = true;
+    }
+  } else {
+    Ent3 e;
+    load_ent3(slab, cap, i, m, e, false);
+    LmKF3 kf;
+    lm_precompute3(P, pr.x, pr.y, pr.th, e, kf);
+    double nu0, nu1;
+    if (vp_gate(P, kf, sZ[3 * z], sZ[3 * z + 1], nu0, nu1)) {  // KalmanFilter_VictoriaPark::calculateInnovation
+      const double nu2 = sZ[3 * z + 2] - kf.zx2;
+      plane3(slab, cap, i, P3_MX)[m] = e.x + ((kf.K[0] * nu0 + kf.K[1] * nu1) + kf.K[2] * nu2);
+      plane3(slab, cap, i, P3_MY)[m] = e.y + ((kf.K[3] * nu0 + kf.K[4] * nu1) + kf.K[5] * nu2);
+      plane3(slab, cap, i, P3_MD)[m] = e.d + ((kf.K[6] * nu0 + kf.K[7] * nu1) + kf.K[8] * nu2);
+      for (int t = 0; t < 6; t++) plane3(slab, cap, i, P3_SXX + t)[m] = kf.p[t];
+      upd = true;
+    }
+  }
+  return upd;
+}
+// The existence log-odds of one in-range landmark after the association step (:586-603).
+__device__ __forceinline__ double fs_existence_step(const FsParams &F, double w, double pd, bool upd) {
+  double pe;
+  if (upd) {
+    pe = ((1 - pd) * F.pfa * F.prior + pd * F.prior) / (F.pfa + (1 - F.pfa) * pd * F.prior);
+  } else {
+    pe = ((1 - pd) * F.prior) / ((1 - F.prior) + (1 - pd) * F.prior);
+    if (w > F.lockW) pe = 0.5;
+  }
+  return w + log(pe / (1 - pe));
+}
+
 template <int WPB, int D>
 __global__ __launch_bounds__(WPB * 64) void fs_associate_update_kernel(Buffers B, Params P, FsParams F, int cur, int nZ, unsigned char *arena) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -337,62 +399,11 @@ __global__ __launch_bounds__(WPB * 64) void fs_associate_update_kernel(Buffers B
         bool found = false;
         for (int q = st; q < st + cnt && q < nList; q++)
           if ((int)(sMZ[q] & 0xffu) == z) { val = sMV[q]; found = true; }
-        if (found) {  // likelihoodTable[m][z] > floor (:584) -> kfs_.correct (KalmanFilter.hpp:209-259), in place
-          if (D == 2) {
-            double *pMX = plane(slab, cap, i, PL_MX), *pMY = plane(slab, cap, i, PL_MY);
-            double *pSXX = plane(slab, cap, i, PL_SXX), *pSXY = plane(slab, cap, i, PL_SXY), *pSYY = plane(slab, cap, i, PL_SYY);
-            const double mx = pMX[m], my = pMY[m], sxx = pSXX[m], sxy = pSXY[m], syy = pSYY[m];
-            MeasOut mo;
-            rb_measure(P, pr, mx, my, sxx, sxy, syy, mo);
-            const double e0 = sZ[2 * z] - mo.z0;
-            const double w1 = wrap_pi(sZ[2 * z + 1] - mo.z1);
-            const bool gateR = !(P.kfRange > 0 && fabs(e0) > P.kfRange), gateB = !(P.kfBearing > 0 && fabs(w1) > P.kfBearing);
-            if (mo.inRange && gateR && gateB) {
-              double i00, i01, i10, i11, det;
-              inv2(mo.s00, mo.s01, mo.s10, mo.s11, i00, i01, i10, i11, det);
-              const double t00 = sxx * mo.h00 + sxy * mo.h01, t01 = sxx * mo.h10 + sxy * mo.h11;
-              const double t10 = sxy * mo.h00 + syy * mo.h01, t11 = sxy * mo.h10 + syy * mo.h11;
-              const double k00 = t00 * i00 + t01 * i10, k01 = t00 * i01 + t01 * i11;
-              const double k10 = t10 * i00 + t11 * i10, k11 = t10 * i01 + t11 * i11;
-              const double kh00 = k00 * mo.h00 + k01 * mo.h10, kh01 = k00 * mo.h01 + k01 * mo.h11;
-              const double kh10 = k10 * mo.h00 + k11 * mo.h10, kh11 = k10 * mo.h01 + k11 * mo.h11;
-              const double a00 = 1.0 - kh00, a01 = 0.0 - kh01, a10 = 0.0 - kh10, a11 = 1.0 - kh11;
-              const double q00 = a00 * sxx + a01 * sxy, q01 = a00 * sxy + a01 * syy;
-              const double q10 = a10 * sxx + a11 * sxy, q11 = a10 * sxy + a11 * syy;
-              pMX[m] = mx + (k00 * e0 + k01 * w1);
-              pMY[m] = my + (k10 * e0 + k11 * w1);
-              pSXX[m] = (q00 + q00) / 2;
-              pSXY[m] = (q01 + q10) / 2;
-              pSYY[m] = (q11 + q11) / 2;
-              upd = true;
-            }
-          } else {
-            Ent3 e;
-            load_ent3(slab, cap, i, m, e, false);
-            LmKF3 kf;
-            lm_precompute3(P, pr.x, pr.y, pr.th, e, kf);
-            double nu0, nu1;
-            if (vp_gate(P, kf, sZ[3 * z], sZ[3 * z + 1], nu0, nu1)) {  // KalmanFilter_VictoriaPark::calculateInnovation
-              const double nu2 = sZ[3 * z + 2] - kf.zx2;
-              plane3(slab, cap, i, P3_MX)[m] = e.x + ((kf.K[0] * nu0 + kf.K[1] * nu1) + kf.K[2] * nu2);
-              plane3(slab, cap, i, P3_MY)[m] = e.y + ((kf.K[3] * nu0 + kf.K[4] * nu1) + kf.K[5] * nu2);
-              plane3(slab, cap, i, P3_MD)[m] = e.d + ((kf.K[6] * nu0 + kf.K[7] * nu1) + kf.K[8] * nu2);
-              for (int t = 0; t < 6; t++) plane3(slab, cap, i, P3_SXX + t)[m] = kf.p[t];
-              upd = true;
-            }
-          }
-        }
+        if (found) upd = fs_kf_correct<D>(P, pr, slab, cap, i, m, sZ, z);  // likelihoodTable[m][z] > floor (:584)
       }
-      double pe;
-      if (upd) {
-        used |= 1ull << z;
-        pe = ((1 - pd) * F.pfa * F.prior + pd * F.prior) / (F.pfa + (1 - F.pfa) * pd * F.prior);
-      } else {
-        pe = ((1 - pd) * F.prior) / ((1 - F.prior) + (1 - pd) * F.prior);
-        if (w > F.lockW) pe = 0.5;
-      }
+      if (upd) used |= 1ull << z;
       pWP[m] = w;
-      pW[m] = w + log(pe / (1 - pe));
+      pW[m] = fs_existence_step(F, w, pd, upd);
       sC[k] = upd ? val : 0.0;
     }
     nUpd += __popcll(__ballot(upd));

@@ -20,6 +20,7 @@
 #include "vp.h"
 #include "birth.h"
 #include "fastslam.h"
+#include "fastslam_mh.h"
 
 namespace {
 
@@ -74,6 +75,10 @@ struct rfsgpu_filter {
   bool ringFused[RFSGPU_ASYNC_RING] = {};   // the step ran as ONE kernel: only events 0 and 3 were recorded
   rfsgpu_fastslam_config fs;          // FastSLAM::Config (rfsgpu_fastslam_update)
   unsigned char *fsArena = nullptr;   // per-particle Hungarian scratch (allocated on first use)
+  unsigned char *mhArena = nullptr;   // multi-hypothesis FastSLAM: per-particle table / Murty arena / assignments
+  int *mhInts = nullptr;              // [5][Ncap] slotSrc, slotHyp, slotNH, copyDst, copySrc
+  bool fsResampleOccured = false;     // FastSLAM::resampleOccured_ of the previous update (rfsgpu_fastslam_set_resample_occured)
+  std::vector<int> parents;           // source slot of every particle after the last FastSLAM update (identity when none multiplied)
   bool holes = false;       // between rfsgpu_merge and rfsgpu_prune merged-away entries sit in the slab with w = -1; at any other
                             // time a negative weight is a value (FastSLAM's log-odds) and every stored entry counts
   bool fuseSteps = true;    // rfsgpu_update_async uses phd_step_fused_kernel (2-D model); RFSGPU_FUSED_STEP=0 turns it off
@@ -293,7 +298,7 @@ void rfsgpu_destroy(rfsgpu_filter *f) {
   Buffers &B = f->B;
   hipFree(f->snapSlab); hipFree(f->snapWeight); hipFree(f->snapCount); hipFree(f->snapFov); hipFree(f->snapUnused);
   hipFree(B.slab[0]); hipFree(B.slab[1]); hipFree(B.count); hipFree(B.pose); hipFree(B.poseCov); hipFree(B.weight);
-  hipFree(B.unusedMask); hipFree(B.nInFov); hipFree(B.err); hipFree(B.Z); hipFree(f->ownSums); hipFree(f->dSrcSlot); if (f->fsArena) hipFree(f->fsArena);
+  hipFree(B.unusedMask); hipFree(B.nInFov); hipFree(B.err); hipFree(B.Z); hipFree(f->ownSums); hipFree(f->dSrcSlot); if (f->fsArena) hipFree(f->fsArena); if (f->mhArena) hipFree(f->mhArena); if (f->mhInts) hipFree(f->mhInts);
   hipFree(B.scan); hipFree(B.candMean); hipFree(B.candCov); hipFree(B.candSup); hipFree(B.candChk); hipFree(B.candCount);
   murty_free(f->Q, f->MS);
   if (f->hErr) hipHostFree(f->hErr);
@@ -1128,16 +1133,7 @@ int rfsgpu_get_fastslam_config(const rfsgpu_filter *f, rfsgpu_fastslam_config *c
   *cfg = f->fs;
   return RFSGPU_OK;
 }
-int rfsgpu_fastslam_update(rfsgpu_filter *f, const double *z, int n_z) {
-  CHECK_HANDLE(f);
-  f->holes = false;
-  if (n_z == 0) return RFSGPU_OK;  // :401-402
-  if (f->D == 3 && f->B.nScan < 2) return fail(f, RFSGPU_ERR_INVALID, "Victoria Park model: rfsgpu_set_laser_scan must precede the update");
-  if (f->fs.maxNDataAssocHypotheses != 1) return fail(f, RFSGPU_ERR_UNSUPPORTED, "multi-hypothesis FastSLAM (maxNDataAssocHypotheses > 1) is not built");
-  int rc = stage_measurements(f, z, n_z);
-  if (rc != RFSGPU_OK) return rc;
-  hipSetDevice(f->device);
-  if (!f->fsArena) HIPCHK(hipMalloc(&f->fsArena, (size_t)f->Ncap * fs_arena_bytes()));
+static FsParams fs_params(const rfsgpu_filter *f, int n_z) {
   FsParams F;
   F.prior = f->fs.landmarkExistencePrior;
   F.minLog = f->fs.minLogMeasurementLikelihood;
@@ -1149,6 +1145,115 @@ int rfsgpu_fastslam_update(rfsgpu_filter *f, const double *z, int n_z) {
   F.countThr = f->fs.landmarkCandidateMeasurementCountThreshold;
   F.curThr = f->fs.landmarkCandidateCurrentMeasurementCountThreshold;
   F.checkThr = f->fs.landmarkCandidateMeasurementCheckThreshold;
+  return F;
+}
+// prune by the existence threshold (:611-612) + new landmarks / candidates (:615-690) over all f->N particles
+static int fastslam_map_management(rfsgpu_filter *f, const FsParams &F, int n_z) {
+  int rc;
+  if ((unsigned)n_z >= f->fs.pruningMeasurementsThreshold) {
+    Params Pp = f->P;
+    Pp.pruneT = f->fs.mapExistencePruneThreshold;
+    const size_t pb = (size_t)f->cap * 8;
+    if ((rc = set_lds(f, (gm_prune_kernel<4, false>), 4 * pb)) != RFSGPU_OK) return rc;
+    gm_prune_kernel<4, false><<<(f->N + 3) / 4, 256, 4 * pb, f->stream>>>(f->B, Pp, f->cur, f->cur ^ 1);
+    HIPCHK(hipGetLastError());
+    f->cur ^= 1;
+  }
+  if (f->D == 2) fs_new_landmarks_kernel<2><<<(f->N + 63) / 64, 64, 0, f->stream>>>(f->B, f->P, F, f->cur, n_z);
+  else fs_new_landmarks_kernel<3><<<(f->N + 63) / 64, 64, 0, f->stream>>>(f->B, f->P, F, f->cur, n_z);
+  HIPCHK(hipGetLastError());
+  return RFSGPU_OK;
+}
+// Multi-hypothesis update (fastslam_mh.h).  Host part: the slots of the particle copies, in particle order.
+static int fastslam_update_mh(rfsgpu_filter *f, const double *z, int n_z) {
+  if (f->D == 3 && f->B.nScan < 2) return fail(f, RFSGPU_ERR_INVALID, "Victoria Park model: rfsgpu_set_laser_scan must precede the update");
+  int rc = stage_measurements(f, z, n_z);
+  if (rc != RFSGPU_OK) return rc;
+  hipSetDevice(f->device);
+  const long long t0 = now_ns();
+  const FsMhLayout L = fs_mh_layout();
+  if (!f->mhArena) HIPCHK(hipMalloc(&f->mhArena, (size_t)f->Ncap * L.total));
+  if (!f->mhInts) HIPCHK(hipMalloc(&f->mhInts, (size_t)5 * f->Ncap * sizeof(int)));
+  const FsParams F = fs_params(f, n_z);
+  const int N0 = f->N, kmax = (int)f->fs.maxNDataAssocHypotheses;
+  HIPCHK(hipEventRecord(f->ev[EV_UM0], f->stream));
+  if (f->D == 2) fs_mh_associate_kernel<2><<<N0, 64, 0, f->stream>>>(f->B, f->P, F, f->cur, n_z, kmax, f->fs.maxDataAssocLogLikelihoodDiff, f->mhArena);
+  else fs_mh_associate_kernel<3><<<N0, 64, 0, f->stream>>>(f->B, f->P, F, f->cur, n_z, kmax, f->fs.maxDataAssocLogLikelihoodDiff, f->mhArena);
+  HIPCHK(hipGetLastError());
+  std::vector<int> nH(N0);
+  HIPCHK(hipMemcpy2DAsync(nH.data(), sizeof(int), f->mhArena + L.offHdr + 2 * sizeof(int), L.total, sizeof(int), N0, hipMemcpyDeviceToHost, f->stream));
+  if ((rc = check_device_errors(f)) != RFSGPU_OK) return rc;  // syncs
+  // pi[0] = i; after particle i's nH - 1 copies were appended: pi[h] = nParticles_ - h (:543-556)
+  std::vector<int> slotSrc(N0), slotHyp(N0), slotNH(N0), cDst, cSrc;
+  int n = N0;
+  for (int i = 0; i < N0; i++) { slotSrc[i] = i; slotHyp[i] = nH[i] > 0 ? 0 : -1; slotNH[i] = nH[i]; }
+  for (int i = 0; i < N0; i++) {
+    if (nH[i] <= 1) continue;
+    const int first = n;
+    n += nH[i] - 1;
+    if (n > f->Ncap) return fail(f, RFSGPU_ERR_CAPACITY, "the particle copies of the multi-hypothesis update exceed max_particles (rfsgpu_create_ex)");
+    slotSrc.resize(n); slotHyp.resize(n); slotNH.resize(n);
+    for (int h = 1; h < nH[i]; h++) {
+      const int slot = n - h;
+      slotSrc[slot] = i; slotHyp[slot] = h; slotNH[slot] = nH[i];
+      cDst.push_back(slot); cSrc.push_back(i);
+    }
+    (void)first;
+  }
+  int *dSlotSrc = f->mhInts, *dSlotHyp = dSlotSrc + f->Ncap, *dSlotNH = dSlotHyp + f->Ncap, *dDst = dSlotNH + f->Ncap, *dSrc = dDst + f->Ncap;
+  HIPCHK(hipMemcpyAsync(dSlotSrc, slotSrc.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, f->stream));
+  HIPCHK(hipMemcpyAsync(dSlotHyp, slotHyp.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, f->stream));
+  HIPCHK(hipMemcpyAsync(dSlotNH, slotNH.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, f->stream));
+  const int nNew = n - N0;
+  if (nNew > 0) {
+    HIPCHK(hipMemcpyAsync(dDst, cDst.data(), (size_t)nNew * sizeof(int), hipMemcpyHostToDevice, f->stream));
+    HIPCHK(hipMemcpyAsync(dSrc, cSrc.data(), (size_t)nNew * sizeof(int), hipMemcpyHostToDevice, f->stream));
+    fs_mh_copy_kernel<<<nNew, 256, 0, f->stream>>>(f->B, f->cur, dDst, dSrc, f->fsResampleOccured ? 1 : 0, f->P.poseCovStride);
+    HIPCHK(hipGetLastError());
+    f->N = n;
+    f->B.N = n;
+    fs_mh_split_weights_kernel<<<(n + 255) / 256, 256, 0, f->stream>>>(f->B.weight, dSlotSrc, dSlotNH, n, 0);
+    fs_mh_split_weights_kernel<<<(n + 255) / 256, 256, 0, f->stream>>>(f->B.weight, dSlotSrc, dSlotNH, n, 1);
+    HIPCHK(hipGetLastError());
+  }
+  if (f->D == 2) fs_mh_apply_kernel<2><<<n, 64, 0, f->stream>>>(f->B, f->P, F, f->cur, n_z, dSlotSrc, dSlotHyp, f->mhArena);
+  else fs_mh_apply_kernel<3><<<n, 64, 0, f->stream>>>(f->B, f->P, F, f->cur, n_z, dSlotSrc, dSlotHyp, f->mhArena);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(f->ev[EV_UM1], f->stream));
+  if ((rc = fastslam_map_management(f, F, n_z)) != RFSGPU_OK) return rc;
+  HIPCHK(hipEventRecord(f->ev[EV_PR1], f->stream));
+  f->parents = slotSrc;
+  rc = check_device_errors(f);
+  accumulate(f->ev[EV_UM0], f->ev[EV_UM1], f->timing.mapUpdate_wall, &f->lastKernelNs[0]);
+  f->timing.mapUpdate_kf_wall = f->timing.mapUpdate_wall;
+  accumulate(f->ev[EV_UM1], f->ev[EV_PR1], f->timing.mapPrune_wall, &f->lastKernelNs[3]);
+  f->timing.mapUpdate_cpu += now_ns() - t0;
+  return rc;
+}
+int rfsgpu_fastslam_set_resample_occured(rfsgpu_filter *f, int flag) {
+  CHECK_HANDLE(f);
+  f->fsResampleOccured = flag != 0;
+  return RFSGPU_OK;
+}
+int rfsgpu_particle_parents(rfsgpu_filter *f, int *parent, int max_n) {
+  CHECK_HANDLE(f);
+  if (!parent || max_n < f->N) return RFSGPU_ERR_INVALID;
+  for (int k = 0; k < f->N; k++) parent[k] = (k < (int)f->parents.size()) ? f->parents[k] : k;
+  return RFSGPU_OK;
+}
+int rfsgpu_fastslam_update(rfsgpu_filter *f, const double *z, int n_z) {
+  CHECK_HANDLE(f);
+  f->holes = false;
+  if (n_z == 0) return RFSGPU_OK;  // :401-402
+  if (f->D == 3 && f->B.nScan < 2) return fail(f, RFSGPU_ERR_INVALID, "Victoria Park model: rfsgpu_set_laser_scan must precede the update");
+  if (f->fs.maxNDataAssocHypotheses < 1 || f->fs.maxNDataAssocHypotheses > FSMH_MAX_HYP)
+    return fail(f, RFSGPU_ERR_UNSUPPORTED, "maxNDataAssocHypotheses must be in [1, 16]");
+  if (f->fs.maxNDataAssocHypotheses > 1) return fastslam_update_mh(f, z, n_z);
+  int rc = stage_measurements(f, z, n_z);
+  if (rc != RFSGPU_OK) return rc;
+  hipSetDevice(f->device);
+  if (!f->fsArena) HIPCHK(hipMalloc(&f->fsArena, (size_t)f->Ncap * fs_arena_bytes()));
+  const FsParams F = fs_params(f, n_z);
   const long long t0 = now_ns();
   HIPCHK(hipEventRecord(f->ev[EV_UM0], f->stream));
   const size_t per = fs_lds_bytes_per_wave(f->cap);
@@ -1167,19 +1272,9 @@ int rfsgpu_fastslam_update(rfsgpu_filter *f, const double *z, int n_z) {
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(f->ev[EV_UM1], f->stream));
-  if ((unsigned)n_z >= f->fs.pruningMeasurementsThreshold) {  // :611-612
-    Params Pp = f->P;
-    Pp.pruneT = f->fs.mapExistencePruneThreshold;
-    const size_t pb = (size_t)f->cap * 8;
-    if ((rc = set_lds(f, (gm_prune_kernel<4, false>), 4 * pb)) != RFSGPU_OK) return rc;
-    gm_prune_kernel<4, false><<<(f->N + 3) / 4, 256, 4 * pb, f->stream>>>(f->B, Pp, f->cur, f->cur ^ 1);
-    HIPCHK(hipGetLastError());
-    f->cur ^= 1;
-  }
-  if (f->D == 2) fs_new_landmarks_kernel<2><<<(f->N + 63) / 64, 64, 0, f->stream>>>(f->B, f->P, F, f->cur, n_z);
-  else fs_new_landmarks_kernel<3><<<(f->N + 63) / 64, 64, 0, f->stream>>>(f->B, f->P, F, f->cur, n_z);
-  HIPCHK(hipGetLastError());
+  if ((rc = fastslam_map_management(f, F, n_z)) != RFSGPU_OK) return rc;
   HIPCHK(hipEventRecord(f->ev[EV_PR1], f->stream));
+  f->parents.clear();
   rc = check_device_errors(f);  // syncs
   // FastSLAM::TimingInfo buckets folded onto the handle's: data association + KF + weighting (one kernel) under
   // mapUpdate / mapUpdate_kf, prune + new landmarks ("map management", :606-693) under mapPrune

@@ -164,9 +164,13 @@ class FastSLAM(RBPHDFilter):
         return self.resampleOccured
 
 
-def systematic_resample_plan(w, u01):
+def systematic_resample_plan(w, u01, n_out=None):
     """Systematic sampling + slot assignment of ParticleFilter::resample (ParticleFilter.hpp:419-479).
-    Returns src_slot[k]: which (kept-in-place) particle slot k copies; k itself when it is kept."""
+    Returns src_slot[k]: which (kept-in-place) particle slot k copies; k itself when it is kept.
+    n_out < len(w): resample(n) as FastSLAM::resampleWithMapCopy calls it -- n_out samples from all particles, kept or
+    copied into the first n_out slots (cases 1-4 of :459-478); the returned plan has n_out entries."""
+    if n_out is not None and n_out < w.size:
+        return _systematic_resample_plan_shrink(w, u01, int(n_out))
     n = w.size
     interval = 1.0 / float(n)
     sample_point = interval * u01
@@ -192,6 +196,38 @@ def systematic_resample_plan(w, u01):
             continue
         while nxt < n and sampled[nxt]:
             nxt += 1
+        src[nxt] = idx
+        nxt += 1
+    return src
+
+
+def _systematic_resample_plan_shrink(w, u01, n):
+    N = w.size
+    interval = 1.0 / float(n)
+    sample_point = interval * u01
+    idx = 0
+    cumulative = w[0]
+    sampled = np.zeros(N, dtype=bool)
+    sampled_idx = np.zeros(n, dtype=np.int64)
+    for i in range(n):
+        while sample_point > cumulative and idx < N - 1:
+            idx += 1
+            cumulative += w[idx]
+        sampled_idx[i] = idx
+        sampled[idx] = True
+        sample_point += interval
+    src = np.arange(n, dtype=np.int32)
+    nxt = 0
+    prev = -1
+    for i in range(n):
+        idx = int(sampled_idx[i])
+        first = not (i > 0 and idx == prev)
+        prev = idx
+        if idx < n and first:          # case 1: stays where it is
+            continue
+        while nxt < N and sampled[nxt]:
+            nxt += 1
+        assert nxt < n, "copies always land below the new count"
         src[nxt] = idx
         nxt += 1
     return src

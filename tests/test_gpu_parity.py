@@ -581,16 +581,76 @@ def test_fastslam_victoria_park_model(pkg, ob, sc, kw):
             f.normalize_weights(s[0])
 
 
-def test_fastslam_refuses_multi_hypothesis(pkg, sc):
+@pytest.mark.parametrize("kw,hyp,diff", [(dict(n_particles=6, n_landmarks=12, n_z=6, seed=5, rmax=5.0), 3, 50.0),
+                                         (dict(n_particles=10, n_landmarks=25, n_z=10, seed=7, rmax=6.0), 4, 3.0),
+                                         (dict(n_particles=8, n_landmarks=4, n_z=9, seed=9, rmax=5.0), 2, 5.0)])
+def test_multi_hypothesis_fastslam(pkg, ob, sc, kw, hyp, diff):
+    """MH-FastSLAM (maxNDataAssocHypotheses > 1): Murty's k best associations on the dense reduced table, particle copies in
+    particle order (pi[h] = nParticles_ - h), per-hypothesis updates, then resample(nParticles_init) with map and candidate
+    copies -- device vs oracle: particle counts, parents, weights, maps, candidate lists, over several cycles."""
+    scen = sc.make_scenario(**kw)
+    n0 = scen["n"]
+    dev = pkg.RBPHDFilter(n0, gm_capacity=128, max_particles=n0 * hyp * 4)
+    orc = ob.OracleFilter(n0, stable_sort=True)
+    for f in (dev, orc):
+        sc.load_scenario(f, scen)
+        for i in range(n0):
+            f.import_gm(i, np.zeros(scen["w"][i].shape), scen["mean"][i], scen["cov"][i])
+        cfg = f.default_fastslam_config()
+        cfg.maxNDataAssocHypotheses = hyp
+        cfg.maxDataAssocLogLikelihoodDiff = diff
+        cfg.landmarkCandidateMeasurementCountThreshold = 2
+        cfg.landmarkCandidateCurrentMeasurementCountThreshold = 0
+        cfg.landmarkCandidateMeasurementCheckThreshold = 3
+        f.set_fastslam_config(cfg)
+    rng, rz = np.random.default_rng(11), np.random.default_rng(12)
+    grew = 0
+    poses = scen["poses"].copy()
+    for step in range(4):
+        Z = scen["Z"] + rz.normal(0, 3e-3, scen["Z"].shape)
+        for f in (dev, orc):
+            f.predict_map(False)
+            f.fastslam_update(Z)
+        assert dev.n == orc.n
+        par = dev.particle_parents()
+        assert np.array_equal(par, orc.particle_parents())
+        grew += int(dev.n > len(poses))
+        poses = poses[par]                                     # the host duplicates its poses
+        _compare_fastslam(sc, dev, orc, dev.n)
+        for f in (dev, orc):
+            s = f.weight_sums()
+            f.normalize_weights(s[0])
+        resampled = dev.n > n0 or step == 2                    # resampleWithMapCopy: back to the initial size
+        if resampled:
+            w = orc.get_weights()
+            plan = pkg.engine.systematic_resample_plan(w, float(rng.random()), n_out=n0)
+            for f in (dev, orc):
+                f.resample_apply(plan, n_out=n0)
+            poses = poses[plan]
+            assert dev.n == n0 and orc.n == n0
+            _compare_fastslam(sc, dev, orc, n0)
+        for f in (dev, orc):
+            f.fastslam_set_resample_occured(resampled)
+            f.set_poses(poses, scen["pose_cov"])
+    assert grew > 0, "no particle was ever multiplied"
+
+
+def test_fastslam_hypothesis_count_limit(pkg, sc):
     scen = sc.make_scenario(4, 5, 3, seed=1)
     dev = pkg.RBPHDFilter(4, gm_capacity=64)
     sc.load_scenario(dev, scen)
     cfg = dev.default_fastslam_config()
-    cfg.maxNDataAssocHypotheses = 3
+    cfg.maxNDataAssocHypotheses = 17
     dev.set_fastslam_config(cfg)
     with pytest.raises(pkg.capi.EngineError) as e:
         dev.fastslam_update(scen["Z"])
     assert e.value.status == pkg.capi.ERR_UNSUPPORTED
+    cfg.maxNDataAssocHypotheses = 3                 # no room for the copies: refused, not truncated
+    dev.set_fastslam_config(cfg)
+    try:
+        dev.fastslam_update(scen["Z"])
+    except pkg.capi.EngineError as e2:
+        assert e2.status == pkg.capi.ERR_CAPACITY
 
 
 # ---- Victoria Park model (3-D landmarks, scan-based Pd, birth-candidate lists) -----------------------------------------
