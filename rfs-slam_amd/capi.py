@@ -158,6 +158,13 @@ class CFilter:
         fn.restype = C.c_int
         return fn(self._h)
 
+    @property
+    def max_particles(self):
+        """The particle capacity the handle was created with (rfsgpu_create_ex)."""
+        fn = self._fn("max_particles")
+        fn.restype = C.c_int
+        return fn(self._h)
+
     # -- plumbing ------------------------------------------------------------------------------
     def _fn(self, name):
         return getattr(self._lib, self._p + name)

@@ -10,7 +10,8 @@
 // enumeration (murty.h: the same Hungarian method, node pool and heap discipline as the oracle's restatement) on it.
 // nMZ = max(landmarks in range, measurements) <= 64 (MURTY_N); beyond that the update refuses loudly.
 //
-//  fs_mh_associate   one wavefront per particle: lanes build the table rows; lane 0 reduces it and runs Murty.
+//  fs_mh_associate   one wavefront per particle: lanes build the table rows, reduce it (row / column counters on lanes) and
+//                    run Murty with the wave-parallel Hungarian solver of hungarian_wave.h.
 //                    Leaves per particle: the in-range list, the table, nH and the nH assignments (HBM).
 //  (host)            slots of the copies, in particle order: pi[h] = nParticles_ - h after each particle's copies (:543-556)
 //  fs_mh_copy        one workgroup per new slot: the source particle's map, counters, pose, weight / nH (+ candidates when
@@ -19,10 +20,12 @@
 //  then gm_prune / fs_new_landmarks of fastslam.h over the grown set.
 #pragma once
 #include "fastslam.h"
+#include "hungarian_wave.h"
 
 #define FSMH_N MURTY_N          // max table dimension
 #define FSMH_MAX_HYP 16         // max config.maxNDataAssocHypotheses_ handled
 #define FSMH_NODES (1 + FSMH_MAX_HYP * FSMH_N)
+#define FSMH_LDS_N 48           // Murty sub-problems up to this dimension are solved in an LDS tile (18 KB: 8 wavefronts per CU)
 
 // Per-particle HBM block: table T, reduced table Cr, Murty's arena, and the results.
 struct FsMhLayout {
@@ -73,90 +76,148 @@ __device__ inline void fs_mh_carve(unsigned char *base, const FsMhLayout &L, Mur
   A.nodeA = base + L.offNodeA;
 }
 
-// Murty::findNextBest driven like FastSLAM.hpp:506-541: up to kmax assignments of the n x n table C (maximisation), stopping
-// at the first whose score is maxDiff or more below the best.  out[h * FSMH_N + row] = column.  Returns nH.
-// (src/MurtyAlgorithm.cpp:137-320 with realAssign_n{R,C}_ == n, i.e. no setRealAssignmentBlock; same structure as
-// murty_partition_sum in murty.h.)
-__device__ int fs_mh_kbest(double *C, int n, int kmax, double maxDiff, MurtyArena &A, unsigned char *out) {
+// k-th (0-based) set bit of m
+__device__ __forceinline__ int fs_kth_bit(unsigned long long m, int k) {
+  for (int i = 0; i < k; i++) m &= m - 1ull;
+  return m ? __builtin_ctzll(m) : 0;
+}
+__device__ __forceinline__ void fs_mh_publish() {  // stores of one lane -> loads of the wave's other lanes (global memory)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// One child of a Murty expansion: rows nn.. of C restricted to the free columns -> Ct (lane c writes column c), the negative
+// constraints of the partition chain (:247-265), then the solver.  False when the constraint row has no possibility left
+// or the solver finds no assignment.  LDT = leading dimension of Ct.
+template <int LDT>
+__device__ __forceinline__ bool fs_mh_child(double *Ct, const double *C, int n, int nn, int nFree, int pn, int parent, int colRemap,
+                                            unsigned long long freeCols, MurtyArena &A, int &aTmp, unsigned char *queue, long long *prof) {
   const double bigNumber = 10000.0;
+  const int lane = threadIdx.x & 63;
+  if (lane < nFree) {
+#pragma unroll 4
+    for (int r = 0; r < nFree; r++) Ct[r * LDT + lane] = C[(nn + r) * n + colRemap];
+  }
+  int current = pn, curPart = nn;
+  for (;;) {  // the walk is uniform (same loads on every lane)
+    const int next = (current == pn) ? parent : (int)A.nodeParent[current];
+    const int naCol = A.nodeA[(size_t)next * FSMH_N + curPart];
+    const int di = curPart - nn;
+    const int dj = __popcll(freeCols & ((1ull << naCol) - 1ull));
+    if (lane == dj) Ct[di * LDT + dj] = -bigNumber;
+    current = next;
+    if (current == 0) break;
+    curPart = A.nodeId[current];
+    if (curPart < nn) break;
+  }
+  if (__ballot(lane < nFree && Ct[lane] != -bigNumber) == 0) return false;   // the constraint row is reduced row 0
+  double s = 0;
+#ifdef RFS_PROFILE
+  const long long tH = (long long)__builtin_readcyclecounter();
+#endif
+  const bool okH = hungarian_wave(Ct, LDT, nFree, aTmp, &s, queue, prof);
+#ifdef RFS_PROFILE
+  if (prof) { prof[1] += (long long)__builtin_readcyclecounter() - tH; prof[2]++; }
+#endif
+  return okH;
+}
+
+// Murty::findNextBest driven like FastSLAM.hpp:506-541: up to kmax assignments of the n x n table C (maximisation), stopping
+// at the first whose score is maxDiff or more below the best.  out[h * FSMH_N + row] = column.  Returns nH (uniform).
+// (src/MurtyAlgorithm.cpp:137-320 with realAssign_n{R,C}_ == n, i.e. no setRealAssignmentBlock; same partition tree, heap
+// discipline and negative-constraint walk as murty_partition_sum in murty.h.)  One wavefront: row r's assignment lives on
+// lane r, the sub-problem tables are built a row per step with lane c writing column c, the inner solver is
+// hungarian_wave; the node pool and the heap are lane 0's (scalars broadcast with readfirstlane).
+__device__ int fs_mh_kbest(double *C, int n, int kmax, double maxDiff, MurtyArena &A, unsigned char *out, unsigned char *queue,
+                           double *ldsTile, long long *prof = nullptr) {
+  const int lane = threadIdx.x & 63;
   int nNodes = 0, heapLen = 0;
   double best;
   {
     double s;
-    unsigned char *a = A.nodeA;  // node 0
-    if (!hungarian_run(C, n, n, a, &s, A)) return 0;  // rank -1 on the first call: no hypothesis (:511-515)
-    A.nodeId[0] = 0;
-    A.nodeParent[0] = -1;
-    A.nodeScore[0] = s;
+    int a0;
+    if (!hungarian_wave(C, n, n, a0, &s, queue)) return 0;  // rank -1 on the first call: no hypothesis (:511-515)
+    if (lane < n) { A.nodeA[lane] = (unsigned char)a0; out[lane] = (unsigned char)a0; }
+    if (lane == 0) {
+      A.nodeId[0] = 0;
+      A.nodeParent[0] = -1;
+      A.nodeScore[0] = s;
+      int hl = 0;
+      heap_push(A.heap, hl, 0, A.nodeScore);
+    }
     nNodes = 1;
-    heap_push(A.heap, heapLen, 0, A.nodeScore);
+    heapLen = 1;
     best = s;
     if (best - s >= maxDiff) return 0;  // (only with maxDiff <= 0)
-    for (int r = 0; r < n; r++) out[r] = a[r];
   }
   int nH = 1;
-  int rowRemap[FSMH_N], rowRemapR[FSMH_N], colRemap[FSMH_N], colRemapR[FSMH_N];
   while (nH < kmax) {
     if (heapLen == 0) break;  // rank == -1
-    const short parent = heap_pop(A.heap, heapLen, A.nodeScore);
-    const int parent_partition = A.nodeId[parent];
-    const unsigned char *a_parent = A.nodeA + (size_t)parent * FSMH_N;
+    fs_mh_publish();
+    int parent = 0, parent_partition = 0;
+    if (lane == 0) {
+      int hl = heapLen;
+      parent = heap_pop(A.heap, hl, A.nodeScore);
+      parent_partition = A.nodeId[parent];
+    }
+    heapLen--;
+    parent = __builtin_amdgcn_readfirstlane(parent);
+    parent_partition = __builtin_amdgcn_readfirstlane(parent_partition);
+    const int aPar = (lane < n) ? A.nodeA[(size_t)parent * FSMH_N + lane] : 0;          // own earlier store
+    const double termPar = (lane < n) ? C[lane * n + aPar] : 0.0;
+    double fixedScore = 0;
+    for (int r = 0; r < parent_partition; r++) fixedScore += readlane_f64(termPar, r);
+    unsigned long long usedCols = wave_or_u64((lane < parent_partition) ? (1ull << aPar) : 0ull);
     const int partitionMax = n - 1;  // realAssign_nR_ == n_
     for (int nn = parent_partition; nn < partitionMax; nn++) {
+      if (nn > parent_partition) {  // rows 0..nn-1 fixed to the parent's choice
+        fixedScore += readlane_f64(termPar, nn - 1);
+        usedCols |= 1ull << __builtin_amdgcn_readlane(aPar, nn - 1);
+      }
       if (nNodes >= FSMH_NODES) return -1;
-      const short pn = (short)nNodes++;
-      A.nodeId[pn] = (unsigned char)nn;
-      A.nodeParent[pn] = parent;
-      unsigned char *a = A.nodeA + (size_t)pn * FSMH_N;
-      unsigned long long freeCols = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
-      double fixedScore = 0;
-      for (int r = 0; r < nn; r++) {
-        a[r] = a_parent[r];
-        freeCols &= ~(1ull << a[r]);
-        fixedScore += C[r * n + a[r]];
-      }
+      const int pn = nNodes++;
+      const unsigned long long freeCols = ((n >= 64) ? ~0ull : ((1ull << n) - 1ull)) & ~usedCols;
       const int nFree = n - nn;
-      for (int r = 0; r < nFree; r++) { rowRemap[r] = nn + r; rowRemapR[nn + r] = r; }
-      int nf = 0;
-      for (int c = 0; c < n; c++)
-        if ((freeCols >> c) & 1ull) { colRemap[nf] = c; colRemapR[c] = nf; nf++; }
-      for (int r = 0; r < nFree; r++)
-        for (int c = 0; c < nFree; c++) A.Ct[r * FSMH_N + c] = C[rowRemap[r] * n + colRemap[c]];
-      short current = pn;
-      do {  // negative constraints (:247-265)
-        const int currentPart = A.nodeId[current];
-        const short next = A.nodeParent[current];
-        const unsigned char *na = A.nodeA + (size_t)next * FSMH_N;
-        const int di = rowRemapR[currentPart];
-        const int dj = colRemapR[na[currentPart]];
-        A.Ct[di * FSMH_N + dj] = -bigNumber;
-        current = next;
-      } while (current != 0 && A.nodeId[current] >= A.nodeId[pn]);
-      bool possible = false;
-      const int constraintRow = rowRemapR[nn];
-      for (int c = 0; c < nFree; c++)
-        if (A.Ct[constraintRow * FSMH_N + c] != -bigNumber) { possible = true; break; }
-      if (possible) {
-        unsigned char aTmp[FSMH_N];
-        double s = 0;
-        if (!hungarian_run(A.Ct, FSMH_N, nFree, aTmp, &s, A)) continue;
-        double sAcc = 0;
-        for (int r = 0; r < nFree; r++) {
-          const int ia = rowRemap[r], ja = colRemap[aTmp[r]];
-          a[ia] = (unsigned char)ja;
-          sAcc += C[ia * n + ja];
+      const int colRemap = (lane < nFree) ? fs_kth_bit(freeCols, lane) : 0;     // reduced column `lane` -> column of C
+      if (lane == 0) { A.nodeId[pn] = (unsigned char)nn; A.nodeParent[pn] = (short)parent; }
+      bool pushed = false;
+      double sAcc = 0;
+      int aNew = aPar;
+      {
+        int aTmp = 0;
+        // the solver's dependent row reads: LDS latency when the sub-problem fits the tile (two inlined instances so that
+        // the LDS one compiles to ds_read / ds_write instead of flat accesses)
+        const bool okH = (nFree <= FSMH_LDS_N)
+                             ? fs_mh_child<FSMH_LDS_N>(ldsTile, C, n, nn, nFree, pn, parent, colRemap, freeCols, A, aTmp, queue, prof)
+                             : fs_mh_child<FSMH_N>(A.Ct, C, n, nn, nFree, pn, parent, colRemap, freeCols, A, aTmp, queue, prof);
+        if (okH) {
+          const int ja = __shfl((lane < nFree) ? colRemap : 0, (lane < nFree) ? aTmp : 0, 64);
+          const double term = (lane < nFree) ? C[(nn + lane) * n + ja] : 0.0;
+          for (int r = 0; r < nFree; r++) sAcc += readlane_f64(term, r);
+          sAcc += fixedScore;
+          const int jaShift = __shfl(ja, (lane >= nn) ? lane - nn : 0, 64);
+          if (lane >= nn) aNew = jaShift;
+          pushed = true;
         }
-        sAcc += fixedScore;
-        A.nodeScore[pn] = sAcc;
-        heap_push(A.heap, heapLen, pn, A.nodeScore);
       }
+      if (lane < n) A.nodeA[(size_t)pn * FSMH_N + lane] = (unsigned char)aNew;
+      if (pushed && lane == 0) {
+        A.nodeScore[pn] = sAcc;
+        int hl = heapLen;
+        heap_push(A.heap, hl, (short)pn, A.nodeScore);
+      }
+      if (pushed) heapLen++;
+      fs_mh_publish();
     }
     if (heapLen == 0) break;
-    const short top = A.heap[0];
-    const double s = A.nodeScore[top];
+    int top = 0;
+    double s = 0;
+    if (lane == 0) { top = A.heap[0]; s = A.nodeScore[top]; }
+    top = __builtin_amdgcn_readfirstlane(top);
+    s = readlane_f64(s, 0);
     if (best - s >= maxDiff) break;  // :520-523
-    const unsigned char *a = A.nodeA + (size_t)top * FSMH_N;
-    for (int r = 0; r < n; r++) out[nH * FSMH_N + r] = a[r];
+    if (lane < n) out[nH * FSMH_N + lane] = A.nodeA[(size_t)top * FSMH_N + lane];
     nH++;
   }
   return nH;
@@ -167,6 +228,8 @@ template <int D>
 __global__ __launch_bounds__(64) void fs_mh_associate_kernel(Buffers B, Params P, FsParams F, int cur, int nZ, int kmax, double maxDiff,
                                                            unsigned char *arena) {
   __shared__ double sZ[3 * RFSGPU_MAX_Z];
+  __shared__ unsigned char sQueue[2 * FSMH_N];
+  __shared__ double sTile[FSMH_LDS_N * FSMH_LDS_N];
   const int lane = threadIdx.x;
   const int i = blockIdx.x;
   for (int t = lane; t < D * nZ; t += 64) sZ[t] = B.Z[t];
@@ -221,52 +284,65 @@ __global__ __launch_bounds__(64) void fs_mh_associate_kernel(Buffers B, Params P
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   wave_sync();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  if (lane != 0) return;
 
   // ---- CostMatrix::reduce (src/CostMatrix.cpp:263-340) ----
+  // Row x's counters on lane x, column y's on lane y.  The serial scan fixes (x, y) exactly when y is row x's only match and
+  // x is column y's only match (a pair seen while either count is already 2 is never fixed, and one fixed early is undone
+  // by the final count checks), so counts + the single match index decide it.
   short *da = (short *)(base + L.offDa);
-  int nMatchI[FSMH_N], nMatchJ[FSMH_N], aFixed[FSMH_N], aRev[FSMH_N], iRed[FSMH_N], jRed[FSMH_N];
-  for (int x = 0; x < nMZ; x++) { nMatchI[x] = 0; nMatchJ[x] = 0; aFixed[x] = -1; aRev[x] = -1; }
-  for (int x = 0; x < nMZ; x++)
-    for (int y = 0; y < nMZ; y++)
-      if (T[x * nMZ + y] > lim) {
-        nMatchI[x]++; nMatchJ[y]++;
-        if (nMatchI[x] == 1 && nMatchJ[y] == 1) { aFixed[x] = y; aRev[y] = x; }
-        if (nMatchI[x] > 1) aFixed[x] = -1;
-        if (nMatchJ[y] > 1) aRev[y] = -1;
-      }
-  int nRed = 0, nRedJ = 0;
+  const bool inT = lane < nMZ;
+  int nMatchI = 0, nMatchJ = 0, yStar = 0, xStar = 0;
   for (int x = 0; x < nMZ; x++) {
-    if (aFixed[x] != -1 && nMatchJ[aFixed[x]] != 1) aFixed[x] = -1;
-    if (aRev[x] != -1 && nMatchI[aRev[x]] != 1) aRev[x] = -1;
-    if (aFixed[x] == -1) iRed[nRed++] = x;
-    if (aRev[x] == -1) jRed[nRedJ++] = x;
+    const unsigned long long mk = __ballot(inT && T[x * nMZ + lane] > lim);
+    if (lane == x) { nMatchI = __popcll(mk); yStar = mk ? __builtin_ctzll(mk) : 0; }
+    if ((mk >> lane) & 1ull) { if (nMatchJ == 0) xStar = x; nMatchJ++; }
   }
-  if (nRed == 1) { aFixed[iRed[0]] = jRed[0]; nRed = 0; }
+  const int nJatStar = __shfl(nMatchJ, yStar, 64), nIatStar = __shfl(nMatchI, xStar, 64);
+  int aFixed = (inT && nMatchI == 1 && nJatStar == 1) ? yStar : -1;
+  const int aRev = (inT && nMatchJ == 1 && nIatStar == 1) ? xStar : -1;
+  const unsigned long long redI = __ballot(inT && aFixed == -1), redJ = __ballot(inT && aRev == -1);
+  int nRed = __popcll(redI);
+  const int iRed = fs_kth_bit(redI, lane), jRed = fs_kth_bit(redJ, lane);     // meaningful on lanes < nRed
+  if (nRed == 1) {                                                              // a 1 x 1 remainder is assigned (:325-331)
+    if (lane == __builtin_ctzll(redI)) aFixed = __builtin_ctzll(redJ);
+    nRed = 0;
+  }
   int nH = 0;
   if (nRed == 0) {  // :498-505
-    for (int m = 0; m < nIn; m++) da[m] = (short)aFixed[m];
+    if (lane < nIn) da[lane] = (short)aFixed;
     nH = 1;
   } else {
     double *Cr = (double *)(base + L.offCr);
-    for (int x = 0; x < nRed; x++)
-      for (int y = 0; y < nRed; y++) Cr[x * nRed + y] = T[iRed[x] * nMZ + jRed[y]];
+    for (int x = 0; x < nRed; x++) {
+      const int ix = __builtin_amdgcn_readlane(iRed, x);
+      if (lane < nRed) Cr[x * nRed + lane] = T[ix * nMZ + jRed];
+    }
     MurtyArena A;
     fs_mh_carve(base, L, A);
     unsigned char *outR = base + L.offRes;
-    nH = fs_mh_kbest(Cr, nRed, kmax, maxDiff, A, outR);
-    if (nH < 0) { atomicOr(B.err, ERRBIT_MURTY); nH = 0; }
+#ifdef RFS_PROFILE
+    long long prof[9] = {(long long)__builtin_readcyclecounter(), 0, 0, nRed, 0, 0, 0, 0, 0};
+    nH = fs_mh_kbest(Cr, nRed, kmax, maxDiff, A, outR, sQueue, sTile, prof);
+    if (B.dbg && lane == 0) {
+      long long *o = B.dbg + 64 + 4 * (size_t)i;
+      o[0] = (long long)__builtin_readcyclecounter() - prof[0]; o[1] = prof[1]; o[2] = prof[2]; o[3] = prof[3];
+      if (i == 7) printf("particle 7: children %lld dims %lld main-loop steps %lld bfs iterations %lld label updates %lld; solver cycles %lld of which main loop %lld\n",
+                         prof[2], prof[7], prof[4], prof[5], prof[6], prof[1], prof[8]);
+    }
+#else
+    nH = fs_mh_kbest(Cr, nRed, kmax, maxDiff, A, outR, sQueue, sTile);
+#endif
+    if (nH < 0) { if (lane == 0) atomicOr(B.err, ERRBIT_MURTY); nH = 0; }
+    const int myRedRow = __popcll(redI & lt);                                   // reduced row of table row `lane`
     for (int h = 0; h < nH; h++) {  // :525-540
-      short *d = da + h * FSMH_N;
-      for (int m = 0; m < nIn; m++) d[m] = (short)aFixed[m];
-      for (int x = 0; x < nRed; x++) {
-        const int z_o = jRed[outR[h * FSMH_N + x]];
-        const int m_o = iRed[x];
-        if (m_o < FSMH_N) d[m_o] = (short)((z_o < nZ) ? z_o : -2);
-      }
+      const int res = (lane < nRed) ? outR[h * FSMH_N + lane] : 0;              // own store in fs_mh_kbest
+      const int z_o = __shfl(jRed, res, 64);
+      const int val = (z_o < nZ) ? z_o : -2;
+      const int mine = __shfl(val, myRedRow, 64);
+      if (lane < nIn) da[h * FSMH_N + lane] = (short)((aFixed != -1) ? aFixed : mine);
     }
   }
-  hdr[0] = nIn; hdr[1] = nMZ; hdr[2] = nH;
+  if (lane == 0) { hdr[0] = nIn; hdr[1] = nMZ; hdr[2] = nH; }
 }
 
 // One workgroup per NEW slot: ParticleFilter::copyParticle (ParticleFilter.hpp:273-294) of slot src -> slot dst.

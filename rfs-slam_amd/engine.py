@@ -40,7 +40,9 @@ class RBPHDFilter(capi.CFilter):
         super().__init__(load_library(), "rfsgpu_", n_particles, model=model, device_id=device_id, gm_capacity=gm_capacity,
                          max_particles=max_particles)
         self.config = self.default_filter_config()
+        self.n_init = n_particles
         self.effNParticles_t = n_particles / 4.0  # ParticleFilter.hpp:232
+        self.effNParticles_t_percent = self.effNParticles_t / n_particles
         self.nUpdatesSinceResample = 0
         self.nMeasurementsSinceResample = 0
         self.resampleOccured = False
@@ -48,6 +50,7 @@ class RBPHDFilter(capi.CFilter):
     # ParticleFilter::setEffectiveParticleCountThreshold (ParticleFilter.hpp:386-391)
     def setEffectiveParticleCountThreshold(self, t):
         self.effNParticles_t = float(t)
+        self.effNParticles_t_percent = float(t) / self.n   # the particle count at the time of the call (:390)
 
     def apply_config(self):
         self.set_filter_config(self.config)
@@ -115,27 +118,42 @@ class RBPHDFilter(capi.CFilter):
         return self.resampleOccured
 
     # ParticleFilter::resample (ParticleFilter.hpp:399-492): host logic on the N weights.
-    def resample(self, u01_fn=np.random.random):
+    # resample(n, forceResample): n == 0 or n > nParticles_ keeps the count (:417-418); a smaller n shrinks the particle set
+    # (FastSLAM::resampleWithMapCopy after multi-hypothesis growth).  The plan of the last resampling stays in
+    # `last_resample_plan` so that a caller holding per-particle host data (poses) can apply the same copies.
+    def resample(self, u01_fn=np.random.random, n_out=0, force=False):
         s = self.weight_sums()
         self.normalize_weights(s[0])
         w = self.get_weights()
         n = self.n
-        neff = 1.0 / float(np.sum(w * w))
-        if neff > self.effNParticles_t and neff / n > self.effNParticles_t / n:
-            return False
-        src = systematic_resample_plan(w, float(u01_fn()))
-        self.resample_apply(src)
+        if not force:
+            neff = 1.0 / float(np.sum(w * w))
+            if neff > self.effNParticles_t and neff / n > self.effNParticles_t_percent:
+                return False
+        if n_out == 0 or n_out > n:
+            n_out = n
+        src = systematic_resample_plan(w, float(u01_fn()), n_out)
+        self.resample_apply(src, n_out)
+        self.last_resample_plan = src
         return True
 
 
 class FastSLAM(RBPHDFilter):
     """rfs::FastSLAM (include/FastSLAM.hpp) for the 2-D range-bearing model on the same engine: the handle's mixtures are
-    the landmark maps (weights = log-odds of existence).  FastSLAM 1.0 only: maxNDataAssocHypotheses must stay 1."""
+    the landmark maps (weights = log-odds of existence).  With fs_config.maxNDataAssocHypotheses > 1 (MH-FastSLAM) an update
+    multiplies particles (one per kept association hypothesis, :462-476): build the filter with `max_hypotheses` so that the
+    handle has room for nParticlesMax * max_hypotheses particles; `parents` (slot -> the particle it was copied from in the
+    last update) and `last_resample_plan` let a caller holding poses follow the copies."""
 
-    def __init__(self, n_particles, device_id=0, gm_capacity=512):
-        super().__init__(n_particles, device_id=device_id, gm_capacity=gm_capacity)
+    def __init__(self, n_particles, device_id=0, gm_capacity=512, max_hypotheses=1, n_particles_max=None):
+        n_max = 3 * n_particles if n_particles_max is None else int(n_particles_max)    # FastSLAM.hpp:250
+        cap = max(n_particles, n_max) * max(1, int(max_hypotheses)) if max_hypotheses > 1 else None
+        super().__init__(n_particles, device_id=device_id, gm_capacity=gm_capacity, max_particles=cap)
         self.fs_config = self.default_fastslam_config()
-        self.fs_config.nParticlesMax = 3 * n_particles
+        self.fs_config.nParticlesMax = n_max
+        self.fs_config.maxNDataAssocHypotheses = max(1, int(max_hypotheses))
+        self.parents = np.arange(n_particles, dtype=np.int32)
+        self.last_resample_plan = None
 
     # FastSLAM::predict (:362-385), map part: staticStep on every landmark, no births
     def predict_map(self, add_birth=False):
@@ -150,11 +168,16 @@ class FastSLAM(RBPHDFilter):
         if Z.shape[0] == 0:
             return False
         self.nMeasurementsSinceResample += Z.shape[0]
-        self.fastslam_update(Z)
+        self.fastslam_update(Z)                               # the particle count may have grown (self.n)
+        self.parents = self.particle_parents()
         self.resampleOccured = False
-        if (self.nUpdatesSinceResample >= self.fs_config.minUpdatesBeforeResample and
+        self.last_resample_plan = None
+        if self.n > self.fs_config.nParticlesMax:             # :711-712 forced, back to the initial count
+            self.resampleOccured = self.resample(u01_fn, self.n_init, True)
+        elif (self.nUpdatesSinceResample >= self.fs_config.minUpdatesBeforeResample and
                 self.nMeasurementsSinceResample >= self.fs_config.minMeasurementsBeforeResample):
-            self.resampleOccured = self.resample(u01_fn)      # landmark candidates travel with their particle
+            self.resampleOccured = self.resample(u01_fn, self.n_init)   # landmark candidates travel with their particle
+        self.fastslam_set_resample_occured(self.resampleOccured)
         if self.resampleOccured:
             self.nUpdatesSinceResample = 0
             self.nMeasurementsSinceResample = 0

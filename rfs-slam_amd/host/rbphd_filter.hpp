@@ -117,10 +117,13 @@ class RBPHDFilter2d {
   } config;
   typedef rfsgpu_timing TimingInfo;  // same 14 fields as RBPHDFilter::TimingInfo (:152-167)
 
-  explicit RBPHDFilter2d(int n, int device_id = 0, int gm_capacity = 512) : n_(n), poses_(n), weights_(n, 1.0), rng_(std::rand()) {
-    int rc = rfsgpu_create(&h_, RFSGPU_MODEL_RNGBRG_2D, n, device_id, gm_capacity);
-    if (rc != RFSGPU_OK) throw std::runtime_error("rfsgpu_create failed with status " + std::to_string(rc) + " (no gfx950 device? there is no CPU fallback)");
+  // max_particles > n reserves room for particle sets that grow (MH-FastSLAM); 0 = n.
+  explicit RBPHDFilter2d(int n, int device_id = 0, int gm_capacity = 512, int max_particles = 0)
+      : n_(n), nInit_(n), poses_(n), weights_(n, 1.0), rng_(std::rand()) {
+    int rc = rfsgpu_create_ex(&h_, RFSGPU_MODEL_RNGBRG_2D, n, device_id, gm_capacity, max_particles > n ? max_particles : n);
+    if (rc != RFSGPU_OK) throw std::runtime_error("rfsgpu_create_ex failed with status " + std::to_string(rc) + " (no gfx950 device? there is no CPU fallback)");
     effNParticles_t_ = double(n) / 4.0;  // ParticleFilter.hpp:232
+    effNParticles_t_percent_ = effNParticles_t_ / n;
   }
   ~RBPHDFilter2d() { rfsgpu_destroy(h_); }
   RBPHDFilter2d(const RBPHDFilter2d &) = delete;
@@ -131,7 +134,10 @@ class RBPHDFilter2d {
   MeasurementModel *getMeasurementModel() { return &meas_; }
   KalmanFilter *getKalmanFilter() { return &kf_; }
   int getParticleCount() const { return n_; }
-  void setEffectiveParticleCountThreshold(double t) { effNParticles_t_ = t; }
+  void setEffectiveParticleCountThreshold(double t) {  // ParticleFilter.hpp:386-391
+    effNParticles_t_ = t;
+    effNParticles_t_percent_ = t / n_;
+  }
   double getEffectiveParticleCountThreshold() const { return effNParticles_t_; }
   const Pose2d &getParticlePose(int i) const { return poses_[i]; }
   double getParticleWeight(int i) {
@@ -197,7 +203,7 @@ class RBPHDFilter2d {
 
  protected:
   rfsgpu_filter *h_ = nullptr;
-  int n_;
+  int n_, nInit_;
   MotionModel_Odometry2d motion_;
   LmkProcessModel lmk_;
   MeasurementModel meas_;
@@ -205,7 +211,7 @@ class RBPHDFilter2d {
   std::vector<Pose2d> poses_;
   std::vector<double> weights_;
   std::mt19937 rng_;
-  double effNParticles_t_;
+  double effNParticles_t_, effNParticles_t_percent_;
   unsigned nUpdatesSinceResample_ = 0, nMeasurementsSinceResample_ = 0;
   bool resampleOccured_ = false, posesDirty_ = true, weightsStale_ = false;
   TimingInfo timing_{};
@@ -265,25 +271,28 @@ class RBPHDFilter2d {
     check(rfsgpu_normalize_weights(h_, s[0], nullptr), "normalize_weights");
     weightsStale_ = true;
   }
-  // ParticleFilter::resample (ParticleFilter.hpp:399-492).
-  bool resample() {
+  // ParticleFilter::resample(n, forceResample) (ParticleFilter.hpp:399-492).  nOut == 0 or > nParticles_ keeps the count; a
+  // smaller nOut draws nOut samples from all particles and shrinks the set (FastSLAM::resampleWithMapCopy).
+  bool resample(unsigned nOut = 0, bool force = false) {
     normalizeWeights();
     pullWeights();
-    double s2 = 0;
-    for (int i = 0; i < n_; i++) s2 += weights_[i] * weights_[i];
-    const double nEff = 1.0 / s2;
-    const double t_percent = effNParticles_t_ / n_;
-    if (nEff > effNParticles_t_ && nEff / n_ > t_percent) return false;
-    const int n = n_;
+    const int N = n_;
+    if (!force) {
+      double s2 = 0;
+      for (int i = 0; i < N; i++) s2 += weights_[i] * weights_[i];
+      const double nEff = 1.0 / s2;
+      if (nEff > effNParticles_t_ && nEff / N > effNParticles_t_percent_) return false;
+    }
+    const int n = (nOut == 0 || (int)nOut > N) ? N : (int)nOut;
     const double u01 = drand48();
     unsigned idx = 0;
     const double interval = 1.0 / double(n);
     double sample_point = interval * u01;
     double cumulative = weights_[0];
-    std::vector<char> sampled(n, 0);
+    std::vector<char> sampled(N, 0);
     std::vector<unsigned> sampled_idx(n, 0);
     for (int i = 0; i < n; i++) {
-      while (sample_point > cumulative && (int)idx < n - 1) {
+      while (sample_point > cumulative && (int)idx < N - 1) {
         idx++;
         cumulative += weights_[idx];
       }
@@ -298,15 +307,18 @@ class RBPHDFilter2d {
       idx = sampled_idx[i];
       const bool firstTime = !(i > 0 && idx == idx_prev);
       idx_prev = idx;
-      if (firstTime) continue;  // case 1: keeps its slot
-      while (next_unsampled < (unsigned)n && sampled[next_unsampled] == 1) next_unsampled++;
-      src[next_unsampled] = (int)idx;
-      poses_[next_unsampled] = poses_[idx];  // Particle::copy copies the pose too
+      if ((int)idx < n && firstTime) continue;  // case 1: keeps its slot
+      while (next_unsampled < (unsigned)N && sampled[next_unsampled] == 1) next_unsampled++;
+      src[next_unsampled] = (int)idx;           // cases 2-4: a copy (or a move from beyond the new count) into a free slot
+      poses_[next_unsampled] = poses_[idx];     // Particle::copy copies the pose too
       next_unsampled++;
     }
-    check(rfsgpu_resample_apply(h_, src.data()), "resample_apply");
+    if (n == N) check(rfsgpu_resample_apply(h_, src.data()), "resample_apply");
+    else check(rfsgpu_resample_apply_n(h_, src.data(), n), "resample_apply_n");
+    n_ = n;
+    poses_.resize(n);
+    weights_.assign(n, 1.0);
     posesDirty_ = true;
-    for (int i = 0; i < n; i++) weights_[i] = 1.0;
     weightsStale_ = false;
     return true;
   }
@@ -315,8 +327,9 @@ class RBPHDFilter2d {
 
 // rfs::FastSLAM<MotionModel_Odometry2d, StaticProcessModel<Landmark2d>, MeasurementModel_RngBrg, KalmanFilter_RngBrg>
 // (reference include/FastSLAM.hpp) over the same C ABI: the handle's mixtures are the landmark maps (weights = log-odds of
-// existence), rfsgpu_fastslam_update is updateMap for every particle.  FastSLAM 1.0: config.maxNDataAssocHypotheses_ must
-// stay 1 (the multi-hypothesis particle multiplication is not built; the call fails loudly otherwise).
+// existence), rfsgpu_fastslam_update is updateMap for every particle.  config.maxNDataAssocHypotheses_ > 1 (MH-FastSLAM)
+// multiplies particles inside an update: construct with max_hypotheses so that the handle has room for
+// nParticlesMax_ * max_hypotheses particles (the call fails loudly with RFSGPU_ERR_CAPACITY otherwise).
 class FastSLAM2d : public RBPHDFilter2d {
  public:
   struct Config {  // FastSLAM::Config (FastSLAM.hpp:106-132), reference member names and constructor defaults (:243-257)
@@ -332,7 +345,11 @@ class FastSLAM2d : public RBPHDFilter2d {
     unsigned pruningMeasurementsThreshold_ = 0;
   } config;
 
-  explicit FastSLAM2d(int n, int device_id = 0, int gm_capacity = 512) : RBPHDFilter2d(n, device_id, gm_capacity) { config.nParticlesMax_ = 3 * n; }
+  explicit FastSLAM2d(int n, int device_id = 0, int gm_capacity = 512, unsigned max_hypotheses = 1)
+      : RBPHDFilter2d(n, device_id, gm_capacity, max_hypotheses > 1 ? 3 * n * (int)max_hypotheses : n) {
+    config.nParticlesMax_ = 3 * n;  // FastSLAM.hpp:250
+    config.maxNDataAssocHypotheses_ = max_hypotheses;
+  }
 
   // FastSLAM::predict (:362-385): propagate the particles, staticStep on every landmark (no births in predict)
   void predict(const Odometry2d &u, double dT, bool useModelNoise = true, bool useInputNoise = false) {
@@ -354,11 +371,22 @@ class FastSLAM2d : public RBPHDFilter2d {
     for (size_t k = 0; k < meas.size(); k++) { z[2 * k] = meas[k].z[0]; z[2 * k + 1] = meas[k].z[1]; }
     check(rfsgpu_fastslam_update(h_, z.data(), (int)meas.size()), "fastslam_update");
     weightsStale_ = true;
+    const int nNow = rfsgpu_n_particles(h_);
+    if (nNow != n_) {  // hypotheses beyond the first became new particles (:462-476): their poses are their parents'
+      std::vector<int> parent(nNow);
+      check(rfsgpu_particle_parents(h_, parent.data(), nNow), "particle_parents");
+      poses_.resize(nNow);
+      for (int i = n_; i < nNow; i++) poses_[i] = poses_[parent[i]];
+      weights_.resize(nNow, 1.0);
+      n_ = nNow;
+    }
     resampleOccured_ = false;
-    // (nParticles_ never exceeds nParticlesMax_ with a single hypothesis, so the forced branch of :711-712 cannot fire)
-    if (nUpdatesSinceResample_ >= (unsigned)config.minUpdatesBeforeResample_ &&
-        nMeasurementsSinceResample_ >= (unsigned)config.minMeasurementsBeforeResample_)
-      resampleOccured_ = resample();  // landmark candidates travel with their particle (rfsgpu_resample_apply)
+    if (n_ > config.nParticlesMax_)  // :711-712
+      resampleOccured_ = resample((unsigned)nInit_, true);
+    else if (nUpdatesSinceResample_ >= (unsigned)config.minUpdatesBeforeResample_ &&
+             nMeasurementsSinceResample_ >= (unsigned)config.minMeasurementsBeforeResample_)
+      resampleOccured_ = resample((unsigned)nInit_);  // landmark candidates travel with their particle (rfsgpu_resample_apply)
+    check(rfsgpu_fastslam_set_resample_occured(h_, resampleOccured_ ? 1 : 0), "fastslam_set_resample_occured");
     if (resampleOccured_) {
       nUpdatesSinceResample_ = 0;
       nMeasurementsSinceResample_ = 0;

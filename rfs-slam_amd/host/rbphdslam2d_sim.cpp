@@ -192,7 +192,7 @@ int main(int argc, char **argv) {
   // ---------------- filter setup (:444-492) ----------------
 #ifdef USE_FASTSLAM
   // fastslam2dSim (reference src/fastslam2dSim.cpp:444-482): same simulator, the FastSLAM filter class and its keys
-  FastSLAM2d filter(nParticles, device, 384);
+  FastSLAM2d filter(nParticles, device, 384, (unsigned)c.i("config.filter.update.maxNDataAssocHypotheses", 1));
   filter.config.minUpdatesBeforeResample_ = c.i("config.filter.resampling.minTimesteps", 1);
   filter.config.minLogMeasurementLikelihood_ = c.d("config.filter.weighting.minLogMeasurementLikelihood", -10.0);
   filter.config.maxNDataAssocHypotheses_ = (unsigned)c.i("config.filter.update.maxNDataAssocHypotheses", 1);
@@ -245,7 +245,7 @@ int main(int argc, char **argv) {
     const double time = k * dT;
     filter.predict(odom[k], dT);
     if (k <= 100)
-      for (int i = 0; i < nParticles; i++) { Pose2d p = gtPose[k]; filter.setParticlePose(i, p); }
+      for (int i = 0; i < filter.getParticleCount(); i++) { Pose2d p = gtPose[k]; filter.setParticlePose(i, p); }
     std::vector<Measurement2d> Z;
     while (zIdx < measurements.size() && std::fabs(measurements[zIdx].t - time) < 1e-9) Z.push_back(measurements[zIdx++]);
     if (!Z.empty()) nUpdates++;
@@ -253,7 +253,7 @@ int main(int argc, char **argv) {
     if (fPose || fLm) {
       int best = 0;
       double bw = -1;
-      for (int i = 0; i < nParticles; i++) {
+      for (int i = 0; i < filter.getParticleCount(); i++) {  // the count varies under MH-FastSLAM
         const double w = filter.getParticleWeight(i);
         const Pose2d &x = filter.getParticlePose(i);
         if (fPose) std::fprintf(fPose, "%f   %d   %f   %f   %f   %f\n", time, i, x.x[0], x.x[1], x.x[2], w);
@@ -276,7 +276,7 @@ int main(int argc, char **argv) {
   // ---------------- result summary: map error of the best particle ----------------
   int best = 0;
   double bw = -1;
-  for (int i = 0; i < nParticles; i++) { const double w = filter.getParticleWeight(i); if (w > bw) { bw = w; best = i; } }
+  for (int i = 0; i < filter.getParticleCount(); i++) { const double w = filter.getParticleWeight(i); if (w > bw) { bw = w; best = i; } }
   const int n = filter.getGMSize(best);
   int matched = 0, strong = 0;
   double errSum = 0;

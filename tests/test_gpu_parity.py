@@ -316,6 +316,24 @@ def test_cpp_fastslam_driver_end_to_end(pkg):
     assert mean_err < 0.2 and pose_err < 0.6
 
 
+def test_cpp_mhfastslam_driver_end_to_end(pkg):
+    """fastslam2d_sim on the values of the reference's cfg/mhfastslam2dSim.xml (3 association hypotheses per particle): the
+    particle set grows inside updates and is resampled back to its initial size by rfs_amd::FastSLAM2d; the map must converge."""
+    import os
+    import re
+    import subprocess
+    pkg.build_mod.build_host()
+    exe = pkg.build_mod.SIM_FASTSLAM
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "mhfastslam2dSim_c1.xml")
+    out = subprocess.run([exe, "-c", cfg, "-t", "2", "-s", "2", "-n", "100"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-500:]
+    m = re.search(r"RESULT matched=(\d+) landmarks=(\d+) mean_err=([\d.]+) pose_err=([\d.]+)", out.stdout)
+    assert m, out.stdout[-2000:]
+    matched, total, mean_err, pose_err = int(m.group(1)), int(m.group(2)), float(m.group(3)), float(m.group(4))
+    assert total == 50 and matched >= 45, out.stdout[-800:]
+    assert mean_err < 0.2 and pose_err < 0.6
+
+
 def test_tied_weights_take_the_exact_rank_path(pkg, ob, sc):
     """Equal prior weights (common in real runs: all birth Gaussians share one weight) collide in the fp32 first pass of
     the device rank sort, which must then fall back to the exact (weight desc, index asc) order everywhere."""
@@ -633,6 +651,62 @@ def test_multi_hypothesis_fastslam(pkg, ob, sc, kw, hyp, diff):
             f.fastslam_set_resample_occured(resampled)
             f.set_poses(poses, scen["pose_cov"])
     assert grew > 0, "no particle was ever multiplied"
+
+
+def test_mh_fastslam_host_mirror(pkg, ob, sc):
+    """rfs_slam_amd.FastSLAM with max_hypotheses > 1 (FastSLAM::update + resampleWithMapCopy: forced resample(nParticles_init)
+    once the count passes nParticlesMax, conditional otherwise, resampleOccured_ fed back into the next update's candidate
+    inheritance) against the oracle taken through the same host steps with the same uniform draws."""
+    scen = sc.make_scenario(n_particles=8, n_landmarks=14, n_z=7, seed=15, rmax=5.0)
+    n0 = scen["n"]
+    dev = pkg.FastSLAM(n0, gm_capacity=128, max_hypotheses=3, n_particles_max=12)
+    orc = ob.OracleFilter(n0, stable_sort=True)
+    assert dev.max_particles >= 36
+    for f in (dev, orc):
+        sc.load_scenario(f, scen)
+        for i in range(n0):
+            f.import_gm(i, np.zeros(scen["w"][i].shape), scen["mean"][i], scen["cov"][i])
+    cfg = dev.fs_config
+    cfg.maxDataAssocLogLikelihoodDiff = 30.0
+    cfg.landmarkCandidateMeasurementCountThreshold = 2
+    cfg.landmarkCandidateCurrentMeasurementCountThreshold = 0
+    cfg.landmarkCandidateMeasurementCheckThreshold = 3
+    cfg.minUpdatesBeforeResample = 2
+    orc.set_fastslam_config(cfg)
+    dev.setEffectiveParticleCountThreshold(n0)                 # resample whenever the counters allow it
+    rng_d, rng_o, rz = np.random.default_rng(21), np.random.default_rng(21), np.random.default_rng(22)
+    poses = scen["poses"].copy()
+    forced = shrunk = 0
+    upd_o = 0
+    for step in range(5):
+        Z = scen["Z"] + rz.normal(0, 3e-3, scen["Z"].shape)
+        dev.predict_map()
+        orc.predict_map(False)
+        did = dev.update_and_resample(Z, u01_fn=rng_d.random)
+        # the oracle through FastSLAM::update's host steps
+        upd_o += 1
+        orc.fastslam_update(Z)
+        assert np.array_equal(dev.parents, orc.particle_parents())
+        poses = poses[dev.parents]
+        n_grown = orc.n
+        s = orc.weight_sums()
+        orc.normalize_weights(s[0])
+        want = n_grown > cfg.nParticlesMax or upd_o >= cfg.minUpdatesBeforeResample
+        assert did == want
+        if did:
+            forced += int(n_grown > cfg.nParticlesMax)
+            shrunk += int(n_grown > n0)
+            plan = pkg.engine.systematic_resample_plan(orc.get_weights(), float(rng_o.random()), n_out=n0)
+            assert np.array_equal(plan, dev.last_resample_plan)
+            orc.resample_apply(plan, n_out=n0)
+            poses = poses[plan]
+            upd_o = 0
+        orc.fastslam_set_resample_occured(did)
+        assert dev.n == orc.n and (not did or dev.n == n0)
+        _compare_fastslam(sc, dev, orc, dev.n)
+        for f in (dev, orc):
+            f.set_poses(poses, scen["pose_cov"])
+    assert forced > 0 and shrunk > 0
 
 
 def test_fastslam_hypothesis_count_limit(pkg, sc):

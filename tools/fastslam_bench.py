@@ -11,9 +11,9 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package
 pkg = load_package()
 sc = pkg.scenarios
-N, NM, NZ = [int(os.environ.get(k, d)) for k, d in (("FS_N", 2000), ("FS_NM", 200), ("FS_NZ", 30))]
+N, NM, NZ, HYP = [int(os.environ.get(k, d)) for k, d in (("FS_N", 2000), ("FS_NM", 200), ("FS_NZ", 30), ("FS_HYP", 1))]
 scen = sc.make_scenario(N, NM, NZ, seed=4242, rmax=25.0)
-f = pkg.FastSLAM(N, gm_capacity=384)
+f = pkg.FastSLAM(N, gm_capacity=384, max_hypotheses=HYP)    # FS_HYP > 1: MH-FastSLAM (dense table: keep FS_NM, FS_NZ <= 64)
 sc.load_scenario(f, scen)
 for i in range(N):
     f.import_gm(i, np.zeros(NM), scen["mean"][i], scen["cov"][i])
@@ -30,8 +30,8 @@ for _ in range(S):
 f.synchronize()
 dt = time.perf_counter() - t0
 ns = f.last_kernel_ns()
-print("device: %.4f ms/update (%.1f updates/s); associate+KF kernel %.1f us, prune+new landmarks %.1f us; map size after %d" %
-      (dt / S * 1e3, S / dt, ns[0] / 1e3, ns[3] / 1e3, int(f.gm_sizes().mean())))
+print("device: %.4f ms/update (%.1f updates/s); associate+KF kernel %.1f us, prune+new landmarks %.1f us; map size after %d; particles after %d" %
+      (dt / S * 1e3, S / dt, ns[0] / 1e3, ns[3] / 1e3, int(f.gm_sizes().mean()), f.n))
 if "--cpu" in sys.argv:
     import importlib
     ob = importlib.import_module("oracle.binding")
@@ -41,7 +41,9 @@ if "--cpu" in sys.argv:
     sc.load_scenario(o, sub)
     for i in range(n):
         o.import_gm(i, np.zeros(NM), scen["mean"][i], scen["cov"][i])
-    o.set_fastslam_config(o.default_fastslam_config())
+    ocfg = o.default_fastslam_config()
+    ocfg.maxNDataAssocHypotheses = HYP
+    o.set_fastslam_config(ocfg)
     t0 = time.perf_counter()
     o.fastslam_update(scen["Z"])
     dt = time.perf_counter() - t0
