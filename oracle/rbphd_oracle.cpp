@@ -14,7 +14,7 @@
  *   - Hungarian / Murty k-best scores : the reference's own src/BruteForceAssignment.cpp (its example
  *     checker for Murty, src/examples/linearAssignment_MurtyAlgorithm.cpp:99-130) compiled into oracle/_ref.
  * Everything else (updateMap, KF correct, RngBrg / VictoriaPark models, importanceWeighting, CostMatrixGeneral
- * partition, merge, prune, birth Gaussians, resample, and the FastSLAM 1.0 update incl. CostMatrix::reduce) is a
+ * partition, merge, prune, birth Gaussians, resample, and the FastSLAM / MH-FastSLAM update incl. CostMatrix::reduce and Murty's k best associations) is a
  * line-by-line restatement with NO reference-produced golden vectors: "parity unpinned" for those rows; they are
  * cross-checked only against independent numpy/scipy formulations in tests/ (CostMatrix::reduce: the reduced
  * problem keeps the optimum of the full one, scipy's Hungarian as the solver).

@@ -1,5 +1,5 @@
 // fastslam.h -- FastSLAM 1.0 map update on the RB-PHD engine's state (reference include/FastSLAM.hpp:424-706, one
-// data-association hypothesis).  A particle's mixture is its landmark map, a Gaussian's weight the landmark's log-odds of
+// data-association hypothesis; several hypotheses per particle: fastslam_mh.h).  A particle's mixture is its landmark map, a Gaussian's weight the landmark's log-odds of
 // existence, the birth-candidate lists are the landmark candidates.  Both measurement models (template parameter D).
 //
 // Three kernels per update (one wavefront per particle):
