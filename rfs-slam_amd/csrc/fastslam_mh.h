@@ -20,7 +20,6 @@
 //  then gm_prune / fs_new_landmarks of fastslam.h over the grown set.
 #pragma once
 #include "fastslam.h"
-#include "hungarian_wave.h"
 
 #define FSMH_N MURTY_N          // max table dimension
 #define FSMH_MAX_HYP 16         // max config.maxNDataAssocHypotheses_ handled
@@ -76,146 +75,28 @@ __device__ inline void fs_mh_carve(unsigned char *base, const FsMhLayout &L, Mur
   A.nodeA = base + L.offNodeA;
 }
 
-// k-th (0-based) set bit of m
-__device__ __forceinline__ int fs_kth_bit(unsigned long long m, int k) {
-  for (int i = 0; i < k; i++) m &= m - 1ull;
-  return m ? __builtin_ctzll(m) : 0;
-}
-__device__ __forceinline__ void fs_mh_publish() {  // stores of one lane -> loads of the wave's other lanes (global memory)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-// One child of a Murty expansion: rows nn.. of C restricted to the free columns -> Ct (lane c writes column c), the negative
-// constraints of the partition chain (:247-265), then the solver.  False when the constraint row has no possibility left
-// or the solver finds no assignment.  LDT = leading dimension of Ct.
-template <int LDT>
-__device__ __forceinline__ bool fs_mh_child(double *Ct, const double *C, int n, int nn, int nFree, int pn, int parent, int colRemap,
-                                            unsigned long long freeCols, MurtyArena &A, int &aTmp, unsigned char *queue, long long *prof) {
-  const double bigNumber = 10000.0;
-  const int lane = threadIdx.x & 63;
-  if (lane < nFree) {
-#pragma unroll 4
-    for (int r = 0; r < nFree; r++) Ct[r * LDT + lane] = C[(nn + r) * n + colRemap];
-  }
-  int current = pn, curPart = nn;
-  for (;;) {  // the walk is uniform (same loads on every lane)
-    const int next = (current == pn) ? parent : (int)A.nodeParent[current];
-    const int naCol = A.nodeA[(size_t)next * FSMH_N + curPart];
-    const int di = curPart - nn;
-    const int dj = __popcll(freeCols & ((1ull << naCol) - 1ull));
-    if (lane == dj) Ct[di * LDT + dj] = -bigNumber;
-    current = next;
-    if (current == 0) break;
-    curPart = A.nodeId[current];
-    if (curPart < nn) break;
-  }
-  if (__ballot(lane < nFree && Ct[lane] != -bigNumber) == 0) return false;   // the constraint row is reduced row 0
-  double s = 0;
-#ifdef RFS_PROFILE
-  const long long tH = (long long)__builtin_readcyclecounter();
-#endif
-  const bool okH = hungarian_wave(Ct, LDT, nFree, aTmp, &s, queue, prof);
-#ifdef RFS_PROFILE
-  if (prof) { prof[1] += (long long)__builtin_readcyclecounter() - tH; prof[2]++; }
-#endif
-  return okH;
-}
-
 // Murty::findNextBest driven like FastSLAM.hpp:506-541: up to kmax assignments of the n x n table C (maximisation), stopping
 // at the first whose score is maxDiff or more below the best.  out[h * FSMH_N + row] = column.  Returns nH (uniform).
-// (src/MurtyAlgorithm.cpp:137-320 with realAssign_n{R,C}_ == n, i.e. no setRealAssignmentBlock; same partition tree, heap
-// discipline and negative-constraint walk as murty_partition_sum in murty.h.)  One wavefront: row r's assignment lives on
-// lane r, the sub-problem tables are built a row per step with lane c writing column c, the inner solver is
-// hungarian_wave; the node pool and the heap are lane 0's (scalars broadcast with readfirstlane).
-__device__ int fs_mh_kbest(double *C, int n, int kmax, double maxDiff, MurtyArena &A, unsigned char *out, unsigned char *queue,
-                           double *ldsTile, long long *prof = nullptr) {
+// (src/MurtyAlgorithm.cpp:137-320 with realAssign_n{R,C}_ == n, i.e. no setRealAssignmentBlock: murty.h's wave-per-problem
+// pieces with the dummy-range rule switched off.)
+__device__ __forceinline__ int fs_mh_kbest(double *C, int n, int kmax, double maxDiff, MurtyArena &A, unsigned char *out, unsigned char *queue,
+                                           double *ldsTile, long long *prof = nullptr) {
   const int lane = threadIdx.x & 63;
   int nNodes = 0, heapLen = 0;
+  int a0;
   double best;
-  {
-    double s;
-    int a0;
-    if (!hungarian_wave(C, n, n, a0, &s, queue)) return 0;  // rank -1 on the first call: no hypothesis (:511-515)
-    if (lane < n) { A.nodeA[lane] = (unsigned char)a0; out[lane] = (unsigned char)a0; }
-    if (lane == 0) {
-      A.nodeId[0] = 0;
-      A.nodeParent[0] = -1;
-      A.nodeScore[0] = s;
-      int hl = 0;
-      heap_push(A.heap, hl, 0, A.nodeScore);
-    }
-    nNodes = 1;
-    heapLen = 1;
-    best = s;
-    if (best - s >= maxDiff) return 0;  // (only with maxDiff <= 0)
-  }
+  if (!murty_root_wave(C, n, A, a0, best, queue)) return 0;  // rank -1 on the first call: no hypothesis (:511-515)
+  if (lane < n) out[lane] = (unsigned char)a0;
+  nNodes = 1;
+  heapLen = 1;
+  if (0.0 >= maxDiff) return 0;  // best - best >= maxDiff (only with maxDiff <= 0)
   int nH = 1;
   while (nH < kmax) {
     if (heapLen == 0) break;  // rank == -1
-    fs_mh_publish();
-    int parent = 0, parent_partition = 0;
-    if (lane == 0) {
-      int hl = heapLen;
-      parent = heap_pop(A.heap, hl, A.nodeScore);
-      parent_partition = A.nodeId[parent];
-    }
-    heapLen--;
-    parent = __builtin_amdgcn_readfirstlane(parent);
-    parent_partition = __builtin_amdgcn_readfirstlane(parent_partition);
-    const int aPar = (lane < n) ? A.nodeA[(size_t)parent * FSMH_N + lane] : 0;          // own earlier store
-    const double termPar = (lane < n) ? C[lane * n + aPar] : 0.0;
-    double fixedScore = 0;
-    for (int r = 0; r < parent_partition; r++) fixedScore += readlane_f64(termPar, r);
-    unsigned long long usedCols = wave_or_u64((lane < parent_partition) ? (1ull << aPar) : 0ull);
-    const int partitionMax = n - 1;  // realAssign_nR_ == n_
-    for (int nn = parent_partition; nn < partitionMax; nn++) {
-      if (nn > parent_partition) {  // rows 0..nn-1 fixed to the parent's choice
-        fixedScore += readlane_f64(termPar, nn - 1);
-        usedCols |= 1ull << __builtin_amdgcn_readlane(aPar, nn - 1);
-      }
-      if (nNodes >= FSMH_NODES) return -1;
-      const int pn = nNodes++;
-      const unsigned long long freeCols = ((n >= 64) ? ~0ull : ((1ull << n) - 1ull)) & ~usedCols;
-      const int nFree = n - nn;
-      const int colRemap = (lane < nFree) ? fs_kth_bit(freeCols, lane) : 0;     // reduced column `lane` -> column of C
-      if (lane == 0) { A.nodeId[pn] = (unsigned char)nn; A.nodeParent[pn] = (short)parent; }
-      bool pushed = false;
-      double sAcc = 0;
-      int aNew = aPar;
-      {
-        int aTmp = 0;
-        // the solver's dependent row reads: LDS latency when the sub-problem fits the tile (two inlined instances so that
-        // the LDS one compiles to ds_read / ds_write instead of flat accesses)
-        const bool okH = (nFree <= FSMH_LDS_N)
-                             ? fs_mh_child<FSMH_LDS_N>(ldsTile, C, n, nn, nFree, pn, parent, colRemap, freeCols, A, aTmp, queue, prof)
-                             : fs_mh_child<FSMH_N>(A.Ct, C, n, nn, nFree, pn, parent, colRemap, freeCols, A, aTmp, queue, prof);
-        if (okH) {
-          const int ja = __shfl((lane < nFree) ? colRemap : 0, (lane < nFree) ? aTmp : 0, 64);
-          const double term = (lane < nFree) ? C[(nn + lane) * n + ja] : 0.0;
-          for (int r = 0; r < nFree; r++) sAcc += readlane_f64(term, r);
-          sAcc += fixedScore;
-          const int jaShift = __shfl(ja, (lane >= nn) ? lane - nn : 0, 64);
-          if (lane >= nn) aNew = jaShift;
-          pushed = true;
-        }
-      }
-      if (lane < n) A.nodeA[(size_t)pn * FSMH_N + lane] = (unsigned char)aNew;
-      if (pushed && lane == 0) {
-        A.nodeScore[pn] = sAcc;
-        int hl = heapLen;
-        heap_push(A.heap, hl, (short)pn, A.nodeScore);
-      }
-      if (pushed) heapLen++;
-      fs_mh_publish();
-    }
+    if (!murty_expand_wave<FSMH_LDS_N>(C, n, n - 1, n, FSMH_NODES, A, nNodes, heapLen, queue, ldsTile, prof)) return -1;
     if (heapLen == 0) break;
-    int top = 0;
-    double s = 0;
-    if (lane == 0) { top = A.heap[0]; s = A.nodeScore[top]; }
-    top = __builtin_amdgcn_readfirstlane(top);
-    s = readlane_f64(s, 0);
+    int top;
+    const double s = murty_top_wave(A, top);
     if (best - s >= maxDiff) break;  // :520-523
     if (lane < n) out[nH * FSMH_N + lane] = A.nodeA[(size_t)top * FSMH_N + lane];
     nH++;
@@ -302,7 +183,7 @@ __global__ __launch_bounds__(64) void fs_mh_associate_kernel(Buffers B, Params P
   const int aRev = (inT && nMatchJ == 1 && nIatStar == 1) ? xStar : -1;
   const unsigned long long redI = __ballot(inT && aFixed == -1), redJ = __ballot(inT && aRev == -1);
   int nRed = __popcll(redI);
-  const int iRed = fs_kth_bit(redI, lane), jRed = fs_kth_bit(redJ, lane);     // meaningful on lanes < nRed
+  const int iRed = murty_kth_bit(redI, lane), jRed = murty_kth_bit(redJ, lane);     // meaningful on lanes < nRed
   if (nRed == 1) {                                                              // a 1 x 1 remainder is assigned (:325-331)
     if (lane == __builtin_ctzll(redI)) aFixed = __builtin_ctzll(redJ);
     nRed = 0;

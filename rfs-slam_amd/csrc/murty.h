@@ -12,6 +12,7 @@
 #pragma once
 #include "common.h"
 #include "weighting.h"
+#include "hungarian_wave.h"
 
 #define MURTY_N 64             /* max extended dimension nR + nC handled on the device */
 #define MURTY_KBEST 200
@@ -220,7 +221,178 @@ __device__ inline short heap_pop(short *h, int &len, const double *score) {
   return top;
 }
 
-// One partition: sum of exp(score) over the <= 200 best assignments (RBPHDFilter.hpp:948-959).
+// ---- one WAVEFRONT per Murty problem (hungarian_wave.h as the inner solver) --------------------------------------------
+// Row r's assignment lives on lane r, sub-problem tables are built a row per step with lane c writing column c, the node
+// pool and the heap are lane 0's (scalars broadcast with readfirstlane).  Same partition tree, heap discipline,
+// negative-constraint walk and score arithmetic as the serial restatement above (and the oracle's).
+
+// k-th (0-based) set bit of m
+__device__ __forceinline__ int murty_kth_bit(unsigned long long m, int k) {
+  for (int i = 0; i < k; i++) m &= m - 1ull;
+  return m ? __builtin_ctzll(m) : 0;
+}
+__device__ __forceinline__ void murty_publish() {  // stores of one lane -> loads of the wave's other lanes (global memory)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// One child of a Murty expansion: rows nn.. of C restricted to the free columns -> Ct (lane c writes column c), the negative
+// constraints of the partition chain (src/MurtyAlgorithm.cpp:247-265, incl. the dummy-column range test on the REDUCED
+// column index), then the solver.  False when the constraint row has no possibility left or the solver finds no
+// assignment.  LDT = leading dimension of Ct.  realNC == n switches the dummy-range rule off (FastSLAM's use).
+template <int LDT>
+__device__ __forceinline__ bool murty_child_wave(double *Ct, const double *C, int n, int nn, int nFree, int pn, int parent, int colRemap,
+                                                 unsigned long long freeCols, int realNC, MurtyArena &A, int &aTmp, unsigned char *queue,
+                                                 long long *prof) {
+  const double bigNumber = 10000.0;
+  const int lane = threadIdx.x & 63;
+  if (lane < nFree) {
+#pragma unroll 4
+    for (int r = 0; r < nFree; r++) Ct[r * LDT + lane] = C[(nn + r) * n + colRemap];
+  }
+  int current = pn, curPart = nn;
+  for (;;) {  // the walk is uniform (same loads on every lane)
+    const int next = (current == pn) ? parent : (int)A.nodeParent[current];
+    const int naCol = A.nodeA[(size_t)next * MURTY_N + curPart];
+    const int di = curPart - nn;
+    const int dj = __popcll(freeCols & ((1ull << naCol) - 1ull));
+    if (lane == dj || (dj >= realNC && lane >= realNC && lane < nFree)) Ct[di * LDT + lane] = -bigNumber;
+    current = next;
+    if (current == 0) break;
+    curPart = A.nodeId[current];
+    if (curPart < nn) break;
+  }
+  if (__ballot(lane < nFree && Ct[lane] != -bigNumber) == 0) return false;   // the constraint row is reduced row 0
+  double s = 0;
+#ifdef RFS_PROFILE
+  const long long tH = (long long)__builtin_readcyclecounter();
+#endif
+  const bool okH = hungarian_wave(Ct, LDT, nFree, aTmp, &s, queue, prof);
+#ifdef RFS_PROFILE
+  if (prof) { prof[1] += (long long)__builtin_readcyclecounter() - tH; prof[2]++; }
+#endif
+  return okH;
+}
+
+// Murty::findNextBest's expansion step (:160-330): pop the best node, create its children for the partitions
+// parent_partition .. partitionMax-1, push the feasible ones.  Sub-problems up to LDSN wide are solved in the LDS tile (two
+// inlined solver instances so that the LDS one compiles to ds_read / ds_write).  False when the node pool is exhausted.
+template <int LDSN>
+__device__ __forceinline__ bool murty_expand_wave(const double *C, int n, int partitionMax, int realNC, int maxNodes, MurtyArena &A,
+                                                  int &nNodes, int &heapLen, unsigned char *queue, double *ldsTile, long long *prof) {
+  const int lane = threadIdx.x & 63;
+  murty_publish();
+  int parent = 0, parent_partition = 0;
+  if (lane == 0) {
+    int hl = heapLen;
+    parent = heap_pop(A.heap, hl, A.nodeScore);
+    parent_partition = A.nodeId[parent];
+  }
+  heapLen--;
+  parent = __builtin_amdgcn_readfirstlane(parent);
+  parent_partition = __builtin_amdgcn_readfirstlane(parent_partition);
+  const int aPar = (lane < n) ? A.nodeA[(size_t)parent * MURTY_N + lane] : 0;          // own earlier store
+  const double termPar = (lane < n) ? C[lane * n + aPar] : 0.0;
+  double fixedScore = 0;
+  for (int r = 0; r < parent_partition; r++) fixedScore += readlane_f64(termPar, r);
+  unsigned long long usedCols = wave_or_u64((lane < parent_partition) ? (1ull << aPar) : 0ull);
+  for (int nn = parent_partition; nn < partitionMax; nn++) {
+    if (nn > parent_partition) {  // rows 0..nn-1 fixed to the parent's choice
+      fixedScore += readlane_f64(termPar, nn - 1);
+      usedCols |= 1ull << __builtin_amdgcn_readlane(aPar, nn - 1);
+    }
+    if (nNodes >= maxNodes) return false;
+    const int pn = nNodes++;
+    const unsigned long long freeCols = ((n >= 64) ? ~0ull : ((1ull << n) - 1ull)) & ~usedCols;
+    const int nFree = n - nn;
+    const int colRemap = (lane < nFree) ? murty_kth_bit(freeCols, lane) : 0;     // reduced column `lane` -> column of C
+    if (lane == 0) { A.nodeId[pn] = (unsigned char)nn; A.nodeParent[pn] = (short)parent; }
+    bool pushed = false;
+    double sAcc = 0;
+    int aNew = aPar;
+    {
+      int aTmp = 0;
+      const bool okH = (nFree <= LDSN)
+                           ? murty_child_wave<LDSN>(ldsTile, C, n, nn, nFree, pn, parent, colRemap, freeCols, realNC, A, aTmp, queue, prof)
+                           : murty_child_wave<MURTY_N>(A.Ct, C, n, nn, nFree, pn, parent, colRemap, freeCols, realNC, A, aTmp, queue, prof);
+      if (okH) {
+        const int ja = __shfl((lane < nFree) ? colRemap : 0, (lane < nFree) ? aTmp : 0, 64);
+        const double term = (lane < nFree) ? C[(nn + lane) * n + ja] : 0.0;
+        for (int r = 0; r < nFree; r++) sAcc += readlane_f64(term, r);
+        sAcc += fixedScore;
+        const int jaShift = __shfl(ja, (lane >= nn) ? lane - nn : 0, 64);
+        if (lane >= nn) aNew = jaShift;
+        pushed = true;
+      }
+    }
+    if (lane < n) A.nodeA[(size_t)pn * MURTY_N + lane] = (unsigned char)aNew;
+    if (pushed && lane == 0) {
+      A.nodeScore[pn] = sAcc;
+      int hl = heapLen;
+      heap_push(A.heap, hl, (short)pn, A.nodeScore);
+    }
+    if (pushed) heapLen++;
+    murty_publish();
+  }
+  return true;
+}
+// root: the solver on the full table (:147-158); node 0.  False when there is no assignment.
+__device__ __forceinline__ bool murty_root_wave(double *C, int n, MurtyArena &A, int &a0, double &s, unsigned char *queue) {
+  const int lane = threadIdx.x & 63;
+  if (!hungarian_wave(C, n, n, a0, &s, queue)) return false;
+  if (lane < n) A.nodeA[lane] = (unsigned char)a0;
+  if (lane == 0) {
+    A.nodeId[0] = 0;
+    A.nodeParent[0] = -1;
+    A.nodeScore[0] = s;
+    int hl = 0;
+    heap_push(A.heap, hl, 0, A.nodeScore);
+  }
+  return true;
+}
+// score of the heap's top (uniform); top = its node
+__device__ __forceinline__ double murty_top_wave(MurtyArena &A, int &top) {
+  const int lane = threadIdx.x & 63;
+  int t = 0;
+  double s = 0;
+  if (lane == 0) { t = A.heap[0]; s = A.nodeScore[t]; }
+  top = __builtin_amdgcn_readfirstlane(t);
+  return readlane_f64(s, 0);
+}
+
+// One partition, one wavefront: sum of exp(score) over the <= 200 best assignments (RBPHDFilter.hpp:948-959).
+#define MURTY_LDS_N 32   // sub-problems up to this dimension are solved in an 8 KB LDS tile
+__device__ __forceinline__ double murty_partition_sum_wave(double *C, int n, int nR, int nC, MurtyArena &A, bool &ok, unsigned char *queue,
+                                                           double *ldsTile) {
+  ok = true;
+  const double BIG_NEG = -1000.0;
+  int nNodes = 0, heapLen = 0;
+  const int realNR = nR > n ? n : nR, realNC = nC > n ? n : nC;
+  int a0;
+  double s;
+  if (!murty_root_wave(C, n, A, a0, s, queue)) { ok = false; return 0.0; }
+  nNodes = 1;
+  heapLen = 1;
+  if (s < BIG_NEG) return 0.0;
+  double sum = exp(s);
+  const int partitionMax = (realNR == n) ? n - 1 : realNR;
+  for (int k = 1; k < MURTY_KBEST; k++) {
+    if (heapLen == 0) break;  // rank == -1
+    if (!murty_expand_wave<MURTY_LDS_N>(C, n, partitionMax, realNC, MURTY_MAX_NODES, A, nNodes, heapLen, queue, ldsTile, nullptr)) {
+      ok = false;
+      return sum;
+    }
+    if (heapLen == 0) break;
+    int top;
+    const double st = murty_top_wave(A, top);
+    if (st < BIG_NEG) break;
+    sum += exp(st);
+  }
+  return sum;
+}
+
+// The same, one THREAD per problem (kept as the plain restatement the wave form is checked against in review; unused).
 __device__ double murty_partition_sum(double *C, int n, int nR, int nC, MurtyArena &A, bool &ok) {
   ok = true;
   const double bigNumber = 10000.0, BIG_NEG = -1000.0;
@@ -308,27 +480,32 @@ __device__ double murty_partition_sum(double *C, int n, int nR, int nC, MurtyAre
   return sum;
 }
 
-// One thread per queued partition; the last workgroup to finish multiplies every particle's factors into its weight,
-// in partition (slot) order.  Q.count[0] = number of jobs, Q.count[1] = finished-workgroup ticket.  With an empty queue
-// (the common case: no partition above 8) every workgroup exits at once -- one empty launch, no host round trip.
-__global__ __launch_bounds__(64) void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err, double *weight, int N) {
+// One wavefront per queued partition (MURTY_JOB_WAVES per workgroup, jobs strided over the grid); the last workgroup to
+// finish multiplies every particle's factors into its weight, in partition (slot) order.  Q.count[0] = number of jobs,
+// Q.count[1] = finished-workgroup ticket.  With an empty queue (the common case: no partition above 8) every workgroup
+// exits at once -- one empty launch, no host round trip.
+#define MURTY_JOB_WAVES 4
+#define MURTY_JOB_BLOCKS 512
+__global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err, double *weight, int N) {
   const int nJobs = min(*Q.count, Q.maxJobs);
   if (nJobs == 0) return;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < nJobs) {
+  __shared__ double sTile[MURTY_JOB_WAVES][MURTY_LDS_N * MURTY_LDS_N];
+  __shared__ unsigned char sQueue[MURTY_JOB_WAVES][2 * MURTY_N];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int j = blockIdx.x * MURTY_JOB_WAVES + wave; j < nJobs; j += gridDim.x * MURTY_JOB_WAVES) {
     const MurtyJob J = Q.jobs[j];
     const int n = J.nR + J.nC;
+    double v = 1.0;
     if (n > MURTY_N) {
-      atomicOr(err, ERRBIT_MURTY);
-      Q.results[j] = 1.0;
+      if (lane == 0) atomicOr(err, ERRBIT_MURTY);
     } else {
       MurtyArena A;
       murty_carve(MS.arena + (size_t)j * MS.jobBytes, A);
       bool ok;
-      const double v = murty_partition_sum(Q.mats + (size_t)j * MURTY_MAXN * MURTY_MAXN, n, J.nR, J.nC, A, ok);
-      if (!ok) atomicOr(err, ERRBIT_MURTY);
-      Q.results[j] = v;
+      v = murty_partition_sum_wave(Q.mats + (size_t)j * MURTY_MAXN * MURTY_MAXN, n, J.nR, J.nC, A, ok, sQueue[wave], sTile[wave]);
+      if (!ok && lane == 0) atomicOr(err, ERRBIT_MURTY);
     }
+    if (lane == 0) Q.results[j] = v;
   }
   __shared__ int isLast;
   __threadfence();
@@ -389,6 +566,7 @@ static inline void murty_free(MurtyQueue &Q, MurtyScratch &MS) {
 }
 // The job count lives on the device: one launch, which is empty when no partition exceeded 8.
 static inline int murty_launch(MurtyQueue &Q, MurtyScratch &MS, Buffers &B, hipStream_t stream) {
-  murty_jobs_kernel<<<(Q.maxJobs + 63) / 64, 64, 0, stream>>>(Q, MS, B.err, B.weight, B.N);
+  const int blocks = std::min(MURTY_JOB_BLOCKS, (Q.maxJobs + MURTY_JOB_WAVES - 1) / MURTY_JOB_WAVES);
+  murty_jobs_kernel<<<blocks, 64 * MURTY_JOB_WAVES, 0, stream>>>(Q, MS, B.err, B.weight, B.N);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
