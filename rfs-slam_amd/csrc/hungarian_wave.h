@@ -11,7 +11,7 @@
 // load.  n <= 64.  Every scalar decision is made from ballots and readlanes, so control flow is wave-uniform.
 //
 // All 64 lanes call hungarian_wave together.  C: n x n, leading dimension ld, LDS or global (lane y only ever touches
-// column y; the table is published to the other lanes on return).  queue: 2 * 64 bytes of LDS owned by the calling wave.
+// column y; the table is published to the other lanes on return).  (`queue` is unused: the BFS queue lives in registers.)
 // On return lane x < n holds xy[x] (the column assigned to row x); *cost (uniform) = sum_x C[x][xy[x]] added in row order.
 #pragma once
 #include "common.h"
@@ -53,7 +53,6 @@ __device__ __forceinline__ double wave_ordered_sum(double v, int n) {
 __device__ __forceinline__ bool hungarian_wave(double *C, int ld, int n, int &xyOut, double *cost, unsigned char *queue, long long *prof = nullptr) {
   const int lane = threadIdx.x & 63;
   const bool in = lane < n;
-  const unsigned long long lt = (1ull << lane) - 1ull;
   double *Ccol = C + lane;           // column `lane`
   // row-indexed state (lane = x) and column-indexed state (lane = y)
   double lx = 0, ly = 0, slack = 0;
@@ -148,35 +147,34 @@ __device__ __forceinline__ bool hungarian_wave(double *C, int ld, int n, int &xy
     const int y = __builtin_ctzll(cand);
     int x_t = __builtin_amdgcn_readlane(yx, y);
     if (x_t == -1) {
-      // augmenting path root -> y by breadth-first search over tight edges (:420-523), same visiting order
+      // augmenting path root -> y by breadth-first search over tight edges (:420-523), same visiting order.  The queue
+      // (<= 2n node ids) lives in two registers spread over the lanes: entry k on lane k & 63 of q0 (k < 64) or q1.
       const int target = y + n;
-      int qh = 0, qt = 0;
-      if (lane == 0) queue[0] = (unsigned char)root;
-      qt = 1;
+      int qh = 0, qt = 1;
+      int q0 = root, q1 = 0;
       xq = (lane == root); yq = false;
       px = -1; py = -1;
       bool found = false;
-      wave_sync();
       // The reference dequeues until the target column comes out; its path back only follows parents that were set before
       // the target was DISCOVERED (p[] is written once per node), so the search can stop at the discovery: same xy / yx.
       while (qh < qt) {
 #ifdef RFS_PROFILE
         if (prof) prof[5]++;
 #endif
-        int t = queue[qh];
+        int t = (qh < 64) ? __builtin_amdgcn_readlane(q0, qh) : __builtin_amdgcn_readlane(q1, qh - 64);
         qh++;
         if (t < n) {
           const double lxt = readlane_f64(lx, t);
           const int xyt = __builtin_amdgcn_readlane(xy, t);
           const bool push = in && fabs(lxt + ly - Ccol[t * ld]) < 1e-12 && !yq && xyt != lane;
           const unsigned long long pm = __ballot(push);
-          if (push) {
-            yq = true;
-            py = t;
-            queue[qt + __popcll(pm & lt)] = (unsigned char)(lane + n);
-          }
-          qt += __popcll(pm);
+          if (push) { yq = true; py = t; }
           if ((pm >> y) & 1ull) { found = true; break; }
+          for (unsigned long long g = pm; g; g &= g - 1ull) {      // enqueue in ascending column order
+            const int v = __builtin_ctzll(g) + n;
+            if (lane == (qt & 63)) { if (qt < 64) q0 = v; else q1 = v; }
+            qt++;
+          }
         } else {
           t -= n;
           const int x = __builtin_amdgcn_readlane(yx, t);        // the only row that can pass `yx[t] == x`
@@ -186,12 +184,11 @@ __device__ __forceinline__ bool hungarian_wave(double *C, int ld, int n, int &xy
             const bool Sx = (__ballot(S) >> x) & 1ull, xqx = (__ballot(xq) >> x) & 1ull;
             if (tight && Sx && !xqx) {
               if (lane == x) { xq = true; px = t + n; }
-              if (lane == 0) queue[qt] = (unsigned char)x;
+              if (lane == (qt & 63)) { if (qt < 64) q0 = x; else q1 = x; }
               qt++;
             }
           }
         }
-        wave_sync();
       }
       if (found) {
         int t = target;

@@ -364,7 +364,7 @@ __device__ __forceinline__ double murty_top_wave(MurtyArena &A, int &top) {
 // One partition, one wavefront: sum of exp(score) over the <= 200 best assignments (RBPHDFilter.hpp:948-959).
 #define MURTY_LDS_N 32   // sub-problems up to this dimension are solved in an 8 KB LDS tile
 __device__ __forceinline__ double murty_partition_sum_wave(double *C, int n, int nR, int nC, MurtyArena &A, bool &ok, unsigned char *queue,
-                                                           double *ldsTile) {
+                                                           double *ldsTile, long long *prof = nullptr) {
   ok = true;
   const double BIG_NEG = -1000.0;
   int nNodes = 0, heapLen = 0;
@@ -379,7 +379,7 @@ __device__ __forceinline__ double murty_partition_sum_wave(double *C, int n, int
   const int partitionMax = (realNR == n) ? n - 1 : realNR;
   for (int k = 1; k < MURTY_KBEST; k++) {
     if (heapLen == 0) break;  // rank == -1
-    if (!murty_expand_wave<MURTY_LDS_N>(C, n, partitionMax, realNC, MURTY_MAX_NODES, A, nNodes, heapLen, queue, ldsTile, nullptr)) {
+    if (!murty_expand_wave<MURTY_LDS_N>(C, n, partitionMax, realNC, MURTY_MAX_NODES, A, nNodes, heapLen, queue, ldsTile, prof)) {
       ok = false;
       return sum;
     }
@@ -491,7 +491,8 @@ __global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQ
   if (nJobs == 0) return;
   __shared__ double sTile[MURTY_JOB_WAVES][MURTY_LDS_N * MURTY_LDS_N];
   __shared__ unsigned char sQueue[MURTY_JOB_WAVES][2 * MURTY_N];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // (readfirstlane: tells the compiler the wave index is uniform, so that the whole search compiles to scalar control flow)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   for (int j = blockIdx.x * MURTY_JOB_WAVES + wave; j < nJobs; j += gridDim.x * MURTY_JOB_WAVES) {
     const MurtyJob J = Q.jobs[j];
     const int n = J.nR + J.nC;
@@ -502,7 +503,15 @@ __global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQ
       MurtyArena A;
       murty_carve(MS.arena + (size_t)j * MS.jobBytes, A);
       bool ok;
+#ifdef RFS_PROFILE
+      long long prof[9] = {(long long)__builtin_readcyclecounter(), 0, 0, n, 0, 0, 0, 0, 0};
+      v = murty_partition_sum_wave(Q.mats + (size_t)j * MURTY_MAXN * MURTY_MAXN, n, J.nR, J.nC, A, ok, sQueue[wave], sTile[wave], prof);
+      if (lane == 0 && (j & 255) == 0)
+        printf("murty job %d: n %d (nR %d nC %d) total cycles %lld, child solver cycles %lld (main loop %lld), children %lld dims %lld, steps %lld bfs %lld label updates %lld\n", j, n,
+               J.nR, J.nC, (long long)__builtin_readcyclecounter() - prof[0], prof[1], prof[8], prof[2], prof[7], prof[4], prof[5], prof[6]);
+#else
       v = murty_partition_sum_wave(Q.mats + (size_t)j * MURTY_MAXN * MURTY_MAXN, n, J.nR, J.nC, A, ok, sQueue[wave], sTile[wave]);
+#endif
       if (!ok && lane == 0) atomicOr(err, ERRBIT_MURTY);
     }
     if (lane == 0) Q.results[j] = v;
