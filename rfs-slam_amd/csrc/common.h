@@ -24,6 +24,7 @@ struct Params {
   // MeasurementModel_RngBrg
   double R[4];
   double Pd, clutter, rmax, rmin, rbuf;
+  double rmaxIn, rmaxOut, rminIn, rminOut;  // rmax - rbuf, rmax + rbuf, rmin + rbuf, rmin - rbuf (host-computed: kernel arguments stay in SGPRs)
   // KalmanFilter_RngBrg
   double kfRange, kfBearing;
   // RBPHDFilter::Config
@@ -98,6 +99,11 @@ __device__ __forceinline__ void wave_sync() {
 }
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// a wave-uniform double the compiler computed with the vector ALU -> an SGPR pair (no VGPR held across loops, no spill)
+__device__ __forceinline__ double uniform_f64(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double readlane_f64(double v, int srcLane) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), srcLane);
   int hi = __builtin_amdgcn_readlane(__double2hiint(v), srcLane);
@@ -199,10 +205,10 @@ __device__ __forceinline__ double rb_pd(const Params &P, double range, bool &clo
   double pd;
   if (range <= P.rmax && range >= P.rmin) {
     pd = P.Pd;
-    if (range >= (P.rmax - P.rbuf) || range <= (P.rmin + P.rbuf)) close = true;
+    if (range >= P.rmaxIn || range <= P.rminIn) close = true;
   } else {
     pd = 0;
-    if (range <= (P.rmax + P.rbuf) && range >= (P.rmin - P.rbuf)) close = true;
+    if (range <= P.rmaxOut && range >= P.rminOut) close = true;
   }
   return pd;
 }
@@ -246,7 +252,8 @@ __device__ __forceinline__ void rb_measure(const Params &P, const PoseReg &pr, d
   double u0[3], u1[3];
 #pragma unroll
   for (int j = 0; j < 3; j++) {
-    u0[j] = r00 * pr.P[j] + r01 * pr.P[3 + j] + 0.0 * pr.P[6 + j];
+    // (0.0 * P: kept for the reference's inf / NaN propagation; per-particle uniform, so it lives in SGPRs)
+    u0[j] = r00 * pr.P[j] + r01 * pr.P[3 + j] + uniform_f64(0.0 * pr.P[6 + j]);
     u1[j] = r10 * pr.P[j] + r11 * pr.P[3 + j] + (-1.0) * pr.P[6 + j];
   }
   double b00 = u0[0] * r00 + u0[1] * r01 + u0[2] * 0.0;

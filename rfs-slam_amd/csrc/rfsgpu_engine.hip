@@ -116,6 +116,7 @@ static void rebuild_params(rfsgpu_filter *f) {
   P.rmax = f->rb.rangeLimMax;
   P.rmin = f->rb.rangeLimMin;
   P.rbuf = f->rb.rangeLimBuffer;
+  P.rmaxIn = P.rmax - P.rbuf; P.rmaxOut = P.rmax + P.rbuf; P.rminIn = P.rmin + P.rbuf; P.rminOut = P.rmin - P.rbuf;
   P.kfRange = f->kf.rangeInnovationThreshold;
   P.kfBearing = f->kf.bearingInnovationThreshold;
   P.birthW = f->cfg.birthGaussianWeight;

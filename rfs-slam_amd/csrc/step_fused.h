@@ -51,11 +51,17 @@ void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, in
   __threadfence_block();  // the slab / count written by wave 0 -> the whole workgroup
   __syncthreads();
   int mergeSrc = cur;
+  // Each phase gets its own copy of the thread index behind a compiler barrier: otherwise address arithmetic common to the
+  // phases (tid * 8, ...) is hoisted to the top of the kernel and held -- or spilled -- across all of them.
+  int tidW = threadIdx.x;
+  asm volatile("" : "+v"(tidW));
   if (useWeighting) {
-    phd_weight_particle<WPP>(B, P, cur, cur ^ 1, nZ, evalCap, Q, i, tid, smem_raw);
+    phd_weight_particle<WPP>(B, P, cur, cur ^ 1, nZ, evalCap, Q, i, tidW, smem_raw);
     __threadfence_block();
     __syncthreads();
     mergeSrc = cur ^ 1;
   }
-  gm_merge_particle<WPP, true>(B, P, mergeSrc, mergeSrc ^ 1, i, tid, smem_raw);
+  int tidM = threadIdx.x;
+  asm volatile("" : "+v"(tidM));
+  gm_merge_particle<WPP, true>(B, P, mergeSrc, mergeSrc ^ 1, i, tidM, smem_raw);
 }

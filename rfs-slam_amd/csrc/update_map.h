@@ -580,7 +580,7 @@ __device__ __forceinline__ void phd_update_map_block(const Buffers &B, const Par
 }
 
 template <int WPB>
-__global__ __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(UPDMAP_WAVES_PER_EU))) void phd_update_map_kernel(Buffers B, Params P, int cur, int nZ, const double *__restrict__ Zg) {
+__global__ __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(UPDMAP_WAVES_PER_EU, UPDMAP_WAVES_PER_EU))) void phd_update_map_kernel(Buffers B, Params P, int cur, int nZ, const double *__restrict__ Zg) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   // The measurement set is wave-uniform and read-only: it is read through the scalar cache (s_load into SGPRs, which
   // VALU instructions take as operands directly) where the index is uniform, and from an LDS copy where lanes index
