@@ -32,8 +32,8 @@ struct MurtyQueue {
 
 struct WeightLDS {
   double *keys;                // [cap]
-  int *perm;                   // [cap]
-  float *fkeys;                // [cap + 8]
+  int *perm;                   // [cap rounded up to 64] (doubles as the sorted-chunk buffer of the rank sort)
+  float *fkeys;                // [cap rounded up to 64]
   double *evX, *evY, *evPd;    // [evalCap]
   double *evLog1mPd;           // [evalCap]
   int *evIdx;                  // [evalCap] sorted position of the evaluation point
@@ -47,8 +47,8 @@ struct WeightLDS {
 __host__ __device__ inline size_t weight_lds_bytes_per_wave(int cap, int evalCap, int nZ) {
   size_t b = 0;
   b += (size_t)cap * 8;            // keys
-  b += (size_t)cap * 4;            // perm
-  b += (size_t)(cap + 8) * 4;      // fkeys (float keys for the rank sort, padded to a multiple of 8)
+  b += (size_t)((cap + 63) & ~63) * 4;   // perm
+  b += (size_t)((cap + 63) & ~63) * 4;   // fkeys (float keys for the rank sort, whole 64-entry chunks)
   b += (size_t)evalCap * 8 * 4;    // evX evY evPd evLog1mPd
   b += (size_t)evalCap * 4;        // evIdx
   b += (size_t)evalCap * 7 * 8;    // evZ
@@ -71,8 +71,8 @@ __device__ __forceinline__ void carve_weight_lds(unsigned char *base, int cap, i
   s.compRows = (unsigned long long *)p; p += 128 * 8;
   s.compCols = (unsigned long long *)p; p += 128 * 8;
   s.partLik = (double *)p; p += 128 * 8;
-  s.perm = (int *)p; p += (size_t)cap * 4;
-  s.fkeys = (float *)p; p += (size_t)(cap + 8) * 4;
+  s.perm = (int *)p; p += (size_t)((cap + 63) & ~63) * 4;
+  s.fkeys = (float *)p; p += (size_t)((cap + 63) & ~63) * 4;
   s.evIdx = (int *)p; p += (size_t)evalCap * 4;
   s.labR = (int *)p; p += 64 * 4;
   s.labC = (int *)p; p += 64 * 4;
@@ -258,34 +258,6 @@ __device__ double rfs_partitions_wave(const WeightLDS &s, int nE, int nZ, double
   return l;
 }
 
-// One sweep over the float keys ranks NS entries per thread (entries g0 + NT*k + tid; NT threads share the mixture).
-template <int NS>
-__device__ __forceinline__ void rank_sweep_f32(const float *fkeys, int *perm, int N, int Npad, int g0, int tid, int NT) {
-  float fm[NS];
-  int cgt[NS];
-#pragma unroll
-  for (int k = 0; k < NS; k++) {
-    const int m = g0 + NT * k + tid;
-    fm[k] = (m < N) ? fkeys[m] : 3.0e38f;
-    cgt[k] = 0;
-  }
-  for (int j = 0; j < Npad; j += 8) {
-    float fj[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) fj[u] = fkeys[j + u];  // wave-uniform: LDS broadcast reads, 8 in flight
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-#pragma unroll
-      for (int k = 0; k < NS; k++) cgt[k] += (fj[u] > fm[k]) ? 1 : 0;
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < NS; k++) {
-    const int m = g0 + NT * k + tid;
-    if (m < N) perm[cgt[k]] = m;
-  }
-}
-
 // Cross-wave scratch of the multi-wave kernel: a few doubles / ints after the per-particle LDS block.
 #define WEIGHT_SCRATCH_BYTES 64
 
@@ -339,30 +311,59 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
   const long long dbgT0 = (long long)__builtin_readcyclecounter();
 #endif
   // ---- 1. sort by weight: rank = #{ j : w_j > w_m  or (w_j == w_m and j < m) } ----
-  // Rank sort, fp32 first: float conversion is monotone, so when all float keys of the mixture are distinct
-  //   rank = #{ j : (float)w_j > (float)w_m }  exactly (one fp32 compare + add per pair, NS entries per thread in one
-  // sweep over the keys).  A float collision (or a true tie) shows up as a rank that nobody claims; the mixture is then
-  // re-ranked with exact fp64 comparisons, (weight desc, index asc).
+  // fp32 first: float conversion is monotone, so when all float keys of the mixture are distinct
+  //   rank = #{ j : (float)w_j > (float)w_m }  exactly.  A float collision (or a true tie) shows up as a rank that nobody
+  // claims; the mixture is then re-ranked with exact fp64 comparisons, (weight desc, index asc).
+  // The count is taken chunk-wise: every 64-entry chunk is rank-sorted on its own (64 broadcast compares per entry), then
+  // an entry's rank is the sum of its positions in all the sorted chunks, each found by a 7-step binary search --
+  // 64 + 7 * N/64 probes per entry instead of N.
   float *fkeys = s.fkeys;
-  const int Npad = (N + 7) & ~7;
-  for (int m = tid; m < Npad; m += NT) {
-    if (m < N) { const double w = qW[m]; s.keys[m] = w; s.perm[m] = -1; fkeys[m] = (float)w; }
+  float *sorted = reinterpret_cast<float *>(s.perm);
+  const int nChunks = (N + 63) >> 6;
+  for (int m = tid; m < nChunks * 64; m += NT) {
+    if (m < N) { const double w = qW[m]; s.keys[m] = w; fkeys[m] = (float)w; }
     else fkeys[m] = -3.0e38f;  // sentinel never ranks ahead
+    sorted[m] = -3.0e38f;      // (slots a tie leaves unclaimed must still be ordered data for the searches)
   }
   if (tid == 0) sScrI[1] = 0;
   block_sync();
-  for (int g0 = 0; g0 < N; g0 += 8 * NT) {
-    const int nSlots = (N - g0 + NT - 1) / NT;
-    switch (nSlots >= 8 ? 8 : nSlots) {
-      case 1: rank_sweep_f32<1>(fkeys, s.perm, N, Npad, g0, tid, NT); break;
-      case 2: rank_sweep_f32<2>(fkeys, s.perm, N, Npad, g0, tid, NT); break;
-      case 3: rank_sweep_f32<3>(fkeys, s.perm, N, Npad, g0, tid, NT); break;
-      case 4: rank_sweep_f32<4>(fkeys, s.perm, N, Npad, g0, tid, NT); break;
-      case 5: rank_sweep_f32<5>(fkeys, s.perm, N, Npad, g0, tid, NT); break;
-      case 6: rank_sweep_f32<6>(fkeys, s.perm, N, Npad, g0, tid, NT); break;
-      case 7: rank_sweep_f32<7>(fkeys, s.perm, N, Npad, g0, tid, NT); break;
-      default: rank_sweep_f32<8>(fkeys, s.perm, N, Npad, g0, tid, NT); break;
+  for (int m = tid; m < nChunks * 64; m += NT) {        // a wave's 64 entries are one chunk: its keys are broadcast reads
+    const float fm = fkeys[m];
+    const float *ck = fkeys + (m & ~63);
+    int r = 0;
+#pragma unroll 8
+    for (int j = 0; j < 64; j++) r += (ck[j] > fm) ? 1 : 0;
+    if (m < N) sorted[(m & ~63) + r] = fm;
+  }
+  block_sync();
+  for (int m = tid; m < N; m += NT) {
+    const float fm = fkeys[m];
+    int rank = 0;
+    for (int b0 = 0; b0 < nChunks; b0 += 4) {           // four searches in flight
+      const float *p0 = sorted + 64 * b0;
+      const float *p1 = sorted + 64 * min(b0 + 1, nChunks - 1), *p2 = sorted + 64 * min(b0 + 2, nChunks - 1), *p3 = sorted + 64 * min(b0 + 3, nChunks - 1);
+      int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+      for (int st = 32; st >= 1; st >>= 1) {
+        c0 += (p0[c0 + st - 1] > fm) ? st : 0;
+        c1 += (p1[c1 + st - 1] > fm) ? st : 0;
+        c2 += (p2[c2 + st - 1] > fm) ? st : 0;
+        c3 += (p3[c3 + st - 1] > fm) ? st : 0;
+      }
+      c0 += (p0[c0] > fm) ? 1 : 0;
+      c1 += (p1[c1] > fm) ? 1 : 0;
+      c2 += (p2[c2] > fm) ? 1 : 0;
+      c3 += (p3[c3] > fm) ? 1 : 0;
+      rank += c0 + ((b0 + 1 < nChunks) ? c1 : 0) + ((b0 + 2 < nChunks) ? c2 : 0) + ((b0 + 3 < nChunks) ? c3 : 0);
     }
+    reinterpret_cast<int *>(fkeys)[m] = rank;            // own slot: nobody else reads fkeys[m] any more
+  }
+  block_sync();
+  for (int m = tid; m < N; m += NT) s.perm[m] = -1;
+  block_sync();
+  for (int m = tid; m < N; m += NT) {
+    const int rank = reinterpret_cast<int *>(fkeys)[m];
+    if (rank < N) s.perm[rank] = m;                       // (ranks collide -- and may overshoot -- only when keys tie)
   }
   block_sync();
   {

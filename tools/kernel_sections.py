@@ -24,7 +24,7 @@ lib = C.CDLL(prof_lib)
 pkg.engine._lib = lib
 sc = pkg.scenarios
 n, nm, nz, cap = [int(x) for x in (sys.argv[1:5] + [2000, 200, 30, 384][len(sys.argv[1:5]):])]
-scen = sc.make_scenario(n, nm, nz, seed=12345)
+scen = sc.make_scenario(n, nm, nz, seed=12345, **({"rmax": float(os.environ["KS_RMAX"])} if "KS_RMAX" in os.environ else {}))
 f = pkg.RBPHDFilter(n, gm_capacity=cap)
 sc.load_scenario(f, scen)
 out = (C.c_longlong * 64)()
