@@ -310,80 +310,97 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
 #ifdef RFS_PROFILE
   const long long dbgT0 = (long long)__builtin_readcyclecounter();
 #endif
-  // ---- 1. sort by weight: rank = #{ j : w_j > w_m  or (w_j == w_m and j < m) } ----
-  // fp32 first: float conversion is monotone, so when all float keys of the mixture are distinct
-  //   rank = #{ j : (float)w_j > (float)w_m }  exactly.  A float collision (or a true tie) shows up as a rank that nobody
-  // claims; the mixture is then re-ranked with exact fp64 comparisons, (weight desc, index asc).
-  // The count is taken chunk-wise: every 64-entry chunk is rank-sorted on its own (64 broadcast compares per entry), then
-  // an entry's rank is the sum of its positions in all the sorted chunks, each found by a 7-step binary search --
-  // 64 + 7 * N/64 probes per entry instead of N.
-  float *fkeys = s.fkeys;
-  float *sorted = reinterpret_cast<float *>(s.perm);
+  // ---- 1. sort by weight: rank = #{ j : w_j > w_m  or (w_j == w_m and j < m) } ----  (exact, fp64, ties by index)
+  // Chunk-wise: every 64-entry chunk (one wave's entries: its keys are LDS broadcast reads) is rank-sorted on its own --
+  // 64 compares per entry; a wave whose ranks do not add up to 0 + 1 + ... has tied keys and redoes its chunk with the
+  // index tie-break (births share one weight, so ties are ordinary in a running filter) -- then an entry's rank is its
+  // chunk rank plus, per other chunk, the number of keys ahead of it there: a 7-probe binary search in that sorted chunk,
+  // counting ">=" in chunks of lower indices and ">" in chunks of higher ones.  64 + 7 N/64 probes per entry, not N.
+  double *sorted = reinterpret_cast<double *>(s.perm);   // perm + fkeys: 8 bytes per entry; perm is written after the searches
   const int nChunks = (N + 63) >> 6;
-  for (int m = tid; m < nChunks * 64; m += NT) {
-    if (m < N) { const double w = qW[m]; s.keys[m] = w; fkeys[m] = (float)w; }
-    else fkeys[m] = -3.0e38f;  // sentinel never ranks ahead
-    sorted[m] = -3.0e38f;      // (slots a tie leaves unclaimed must still be ordered data for the searches)
-  }
-  if (tid == 0) sScrI[1] = 0;
+  for (int m = tid; m < N; m += NT) s.keys[m] = qW[m];
   block_sync();
-  for (int m = tid; m < nChunks * 64; m += NT) {        // a wave's 64 entries are one chunk: its keys are broadcast reads
-    const float fm = fkeys[m];
-    const float *ck = fkeys + (m & ~63);
-    int r = 0;
-#pragma unroll 8
-    for (int j = 0; j < 64; j++) r += (ck[j] > fm) ? 1 : 0;
-    if (m < N) sorted[(m & ~63) + r] = fm;
-  }
-  block_sync();
-  for (int m = tid; m < N; m += NT) {
-    const float fm = fkeys[m];
-    int rank = 0;
-    for (int b0 = 0; b0 < nChunks; b0 += 4) {           // four searches in flight
-      const float *p0 = sorted + 64 * b0;
-      const float *p1 = sorted + 64 * min(b0 + 1, nChunks - 1), *p2 = sorted + 64 * min(b0 + 2, nChunks - 1), *p3 = sorted + 64 * min(b0 + 3, nChunks - 1);
-      int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  constexpr int NS = 8;                                    // entries per thread held in registers
+  if (N <= NS * NT) {
+    int rl[NS];
 #pragma unroll
-      for (int st = 32; st >= 1; st >>= 1) {
-        c0 += (p0[c0 + st - 1] > fm) ? st : 0;
-        c1 += (p1[c1 + st - 1] > fm) ? st : 0;
-        c2 += (p2[c2 + st - 1] > fm) ? st : 0;
-        c3 += (p3[c3 + st - 1] > fm) ? st : 0;
-      }
-      c0 += (p0[c0] > fm) ? 1 : 0;
-      c1 += (p1[c1] > fm) ? 1 : 0;
-      c2 += (p2[c2] > fm) ? 1 : 0;
-      c3 += (p3[c3] > fm) ? 1 : 0;
-      rank += c0 + ((b0 + 1 < nChunks) ? c1 : 0) + ((b0 + 2 < nChunks) ? c2 : 0) + ((b0 + 3 < nChunks) ? c3 : 0);
-    }
-    reinterpret_cast<int *>(fkeys)[m] = rank;            // own slot: nobody else reads fkeys[m] any more
-  }
-  block_sync();
-  for (int m = tid; m < N; m += NT) s.perm[m] = -1;
-  block_sync();
-  for (int m = tid; m < N; m += NT) {
-    const int rank = reinterpret_cast<int *>(fkeys)[m];
-    if (rank < N) s.perm[rank] = m;                       // (ranks collide -- and may overshoot -- only when keys tie)
-  }
-  block_sync();
-  {
-    bool missing = false;
-    for (int r = tid; r < N; r += NT) missing = missing | (s.perm[r] < 0);
-    if (__ballot(missing) != 0ull && lane == 0) sScrI[1] = 1;
-    block_sync();
-    if (sScrI[1] != 0) {  // rare: exact re-rank of the whole mixture
-      for (int m = tid; m < N; m += NT) {
-        const double wm = s.keys[m];
-        int rank = 0;
-        for (int j = 0; j < N; j++) {
-          const double wj = s.keys[j];
-          rank += ((wj > wm) | ((wj == wm) & (j < m))) ? 1 : 0;
+    for (int k = 0; k < NS; k++) {
+      const int m = tid + NT * k;                          // (m & 63) == lane: the wave's 64 entries are chunk m >> 6
+      const int base = m & ~63;
+      rl[k] = 0;
+      if (base < N) {                                      // wave-uniform
+        const int len = min(64, N - base);
+        const double km = (m < N) ? s.keys[m] : 0.0;
+        const double *ck = s.keys + base;
+        int r = 0;
+#pragma unroll 8
+        for (int j = 0; j < len; j++) r += (ck[j] > km) ? 1 : 0;
+        if (wave_sum_i_dpp((m < N) ? r : 0) != len * (len - 1) / 2) {   // tied keys in this chunk
+          r = 0;
+          for (int j = 0; j < len; j++) { const double kj = ck[j]; r += ((kj > km) | ((kj == km) & (j < lane))) ? 1 : 0; }
         }
-        s.perm[rank] = m;
+        rl[k] = r;
+        if (m < N) sorted[base + r] = km;
       }
-      block_sync();
+    }
+    block_sync();
+    DBG_TB(16, 9);
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+      const int m = tid + NT * k;
+      if ((m & ~63) < N) {
+        const int c = m >> 6;
+        const double km = (m < N) ? s.keys[m] : 0.0;
+        int rank = rl[k];
+        for (int b0 = 0; b0 < nChunks; b0 += 4) {          // four searches in flight
+          int cnt[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) cnt[u] = 0;
+          const double *pb[4];
+          int len[4];
+          bool ge[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int b = min(b0 + u, nChunks - 1);
+            pb[u] = sorted + 64 * b;
+            len[u] = (b0 + u < nChunks && b0 + u != c) ? min(64, N - 64 * b) : 0;   // own chunk / past the end: nothing counted
+            ge[u] = b < c;
+          }
+#pragma unroll
+          for (int st = 32; st >= 0; st = (st > 1) ? (st >> 1) : (st - 1)) {        // steps 32 16 8 4 2 1, then the last probe
+            const int stp = st ? st : 1;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const int idx = cnt[u] + stp - 1;
+              const double v = pb[u][min(idx, 63)];
+              const bool ok = (idx < len[u]) && (ge[u] ? (v >= km) : (v > km));
+              cnt[u] += ok ? stp : 0;
+            }
+          }
+          rank += cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        }
+        rl[k] = rank;
+      }
+    }
+    block_sync();                                          // all searches done: the sorted chunks are dead, perm may be written
+#pragma unroll
+    for (int k = 0; k < NS; k++) {
+      const int m = tid + NT * k;
+      if (m < N) s.perm[rl[k]] = m;
+    }
+  } else {  // more entries than the register slots cover: all-pairs ranking
+    for (int m = tid; m < N; m += NT) {
+      const double wm = s.keys[m];
+      int rank = 0;
+      for (int j = 0; j < N; j++) {
+        const double wj = s.keys[j];
+        rank += ((wj > wm) | ((wj == wm) & (j < m))) ? 1 : 0;
+      }
+      s.perm[rank] = m;                                    // (perm does not alias keys)
     }
   }
+  DBG_TB(16, 10);
+  block_sync();
   // sorted mixture -> other slab
   for (int r = tid; r < N; r += NT) {
     const int m = s.perm[r];

@@ -334,14 +334,21 @@ def test_cpp_mhfastslam_driver_end_to_end(pkg):
     assert mean_err < 0.2 and pose_err < 0.6
 
 
-def test_tied_weights_take_the_exact_rank_path(pkg, ob, sc):
-    """Equal prior weights (common in real runs: all birth Gaussians share one weight) collide in the fp32 first pass of
-    the device rank sort, which must then fall back to the exact (weight desc, index asc) order everywhere."""
-    scen = sc.make_scenario(16, 90, 14, seed=23)
+@pytest.mark.parametrize("n_lm,cap", [(90, 256), (330, 512)])
+def test_tied_weights_rank_by_index(pkg, ob, sc, n_lm, cap):
+    """Equal prior weights (ordinary in real runs: all birth Gaussians share one weight): the sort is (weight desc, index
+    asc).  The device ranks 64-entry chunks and merges the chunk ranks, so ties inside a chunk (the wave redoes its chunk
+    with the index tie-break) and ties ACROSS chunks (">=" towards lower chunks, ">" towards higher ones) both matter:
+    330 landmarks with a handful of distinct weights tie across six chunks."""
+    scen = sc.make_scenario(16, n_lm, 14, seed=23)
     scen["w"][:, ::3] = 0.5                                  # many exact ties
-    scen["w"][:, 1::3] = np.float64(np.float32(0.7)) + 1e-12 * np.arange(30)[None, :]   # distinct in fp64, equal in fp32
-    dev, orc = make_pair(pkg, ob, sc, scen)
+    scen["w"][:, 1::3] = np.float64(np.float32(0.7)) + 1e-12 * np.arange(n_lm // 3)[None, :]   # distinct in fp64, equal in fp32
+    if n_lm > 128:
+        scen["w"][:, 2::3] = np.array([0.9, 0.5, 0.31])[np.arange(n_lm // 3) % 3][None, :]      # a few values, tied all over
+    dev = pkg.RBPHDFilter(scen["n"], gm_capacity=cap)
+    orc = ob.OracleFilter(scen["n"], stable_sort=True)
     for f in (dev, orc):
+        sc.load_scenario(f, scen)
         f.update_map(scen["Z"])
         f.importance_weighting()
     compare_weights(dev, orc)
@@ -350,10 +357,6 @@ def test_tied_weights_take_the_exact_rank_path(pkg, ob, sc):
         f.merge()
         f.prune()
     compare_maps(sc, dev, orc, scen["n"], ordered=True)
-    dev2, orc2 = make_pair(pkg, ob, sc, scen)
-    for f in (dev2, orc2):
-        f.update(scen["Z"])                                  # fused merge+prune path
-    compare_maps(sc, dev2, orc2, scen["n"], ordered=True)
 
 
 def _clustered_mixtures(sc, n_particles, n_gauss, kind, seed):

@@ -43,7 +43,7 @@ for base, ns in names.items():
         d = t[base + k + 1] - t[base + k]
         print(f"{nm_:28s} {d:10d} cycles")
 print("update_map pass0: precompute %d, gates %d, maha+lik %d, scan+write %d, fold %d" % (t[4]-t[0], t[5]-t[4], t[6]-t[5], t[7]-t[6], t[8]-t[7]))
-print("weight: rank sort %d, write %d" % (t[16+8]-t[16], t[17]-t[16+8]))
+print("weight: key load + chunk sort %d, merge ranks + scatter %d, fallback check + sorted write-out %d" % (t[16+9]-t[16], t[16+10]-t[16+9], t[16+8]-t[16+10]))
 print("weight partitions: masks+components %d, log table %d, component masks/zero merge %d, enumeration %d; partitions %d" % (t[28]-t[27], t[29]-t[28], t[29]-t[29], t[30]-t[29], t[31]))
 print("merge phase2: rows %d, speculative %d, validate %d, tail %d" % (t[41]-t[34], t[42]-t[41], t[43]-t[42], t[35]-t[43]))
 print("merge fallbacks: unlistable %d, slack %d, >8 merges %d, claim conflicts %d of %d active rows" % (t[52], t[53], t[54], t[55], t[56]))
