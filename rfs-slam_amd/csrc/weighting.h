@@ -341,6 +341,7 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
         }
         rl[k] = r;
         if (m < N) sorted[base + r] = km;
+        else sorted[m] = -1.7976931348623157e308;            // tail of the last chunk: never ahead of anything
       }
     }
     block_sync();
@@ -352,33 +353,29 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
         const int c = m >> 6;
         const double km = (m < N) ? s.keys[m] : 0.0;
         int rank = rl[k];
-        for (int b0 = 0; b0 < nChunks; b0 += 4) {          // four searches in flight
-          int cnt[4];
+        // chunks of lower indices count ">=", chunks of higher ones ">" (two uniform loops: no per-probe select); the last
+        // chunk's tail holds -DBL_MAX sentinels, so no probe needs a length check; cnt + st - 1 <= 63 by construction
+        auto search4 = [&](int bFirst, int bEnd, auto pred) {
+          for (int b0 = bFirst; b0 < bEnd; b0 += 4) {      // four searches in flight
+            const double *p0 = sorted + 64 * b0, *p1 = sorted + 64 * min(b0 + 1, bEnd - 1), *p2 = sorted + 64 * min(b0 + 2, bEnd - 1),
+                         *p3 = sorted + 64 * min(b0 + 3, bEnd - 1);
+            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
 #pragma unroll
-          for (int u = 0; u < 4; u++) cnt[u] = 0;
-          const double *pb[4];
-          int len[4];
-          bool ge[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const int b = min(b0 + u, nChunks - 1);
-            pb[u] = sorted + 64 * b;
-            len[u] = (b0 + u < nChunks && b0 + u != c) ? min(64, N - 64 * b) : 0;   // own chunk / past the end: nothing counted
-            ge[u] = b < c;
-          }
-#pragma unroll
-          for (int st = 32; st >= 0; st = (st > 1) ? (st >> 1) : (st - 1)) {        // steps 32 16 8 4 2 1, then the last probe
-            const int stp = st ? st : 1;
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-              const int idx = cnt[u] + stp - 1;
-              const double v = pb[u][min(idx, 63)];
-              const bool ok = (idx < len[u]) && (ge[u] ? (v >= km) : (v > km));
-              cnt[u] += ok ? stp : 0;
+            for (int st = 32; st >= 1; st >>= 1) {
+              c0 += pred(p0[c0 + st - 1]) ? st : 0;
+              c1 += pred(p1[c1 + st - 1]) ? st : 0;
+              c2 += pred(p2[c2 + st - 1]) ? st : 0;
+              c3 += pred(p3[c3 + st - 1]) ? st : 0;
             }
+            c0 += pred(p0[c0]) ? 1 : 0;
+            c1 += pred(p1[c1]) ? 1 : 0;
+            c2 += pred(p2[c2]) ? 1 : 0;
+            c3 += pred(p3[c3]) ? 1 : 0;
+            rank += c0 + ((b0 + 1 < bEnd) ? c1 : 0) + ((b0 + 2 < bEnd) ? c2 : 0) + ((b0 + 3 < bEnd) ? c3 : 0);
           }
-          rank += cnt[0] + cnt[1] + cnt[2] + cnt[3];
-        }
+        };
+        search4(0, c, [&](double v) { return v >= km; });
+        search4(c + 1, nChunks, [&](double v) { return v > km; });
         rl[k] = rank;
       }
     }
