@@ -6,9 +6,11 @@
 // the dummy-column test on the REDUCED column index, :256-262), same tolerances (1e-14 / 1e-12) and in-place
 // offset add/subtract in the Hungarian solver, same binary-heap discipline as std::priority_queue.
 //
-// Jobs are produced by phd_weight_multifeature_kernel (weighting.h) into a device queue; this kernel consumes
-// them (one thread per job: the algorithm is a serial tree search) and multiplies each job's partition
-// likelihood into its particle's weight in partition order.  All scratch lives in HBM (per-job arena).
+// Jobs are produced by phd_weight_multifeature_kernel (weighting.h) into a device queue; murty_jobs_kernel consumes
+// them -- one WAVEFRONT per job: the tree search stays serial, the Hungarian solver inside it (hungarian_wave.h) and the
+// sub-problem / assignment bookkeeping run across the lanes -- and multiplies each job's partition likelihood into its
+// particle's weight in partition order.  Node pool, heap and root table live in HBM (per-job arena), sub-problem tables
+// in an LDS tile.  hungarian_run below is the one-thread form of the solver (still used by fastslam.h's small blocks).
 #pragma once
 #include "common.h"
 #include "weighting.h"
@@ -388,94 +390,6 @@ __device__ __forceinline__ double murty_partition_sum_wave(double *C, int n, int
     const double st = murty_top_wave(A, top);
     if (st < BIG_NEG) break;
     sum += exp(st);
-  }
-  return sum;
-}
-
-// The same, one THREAD per problem (kept as the plain restatement the wave form is checked against in review; unused).
-__device__ double murty_partition_sum(double *C, int n, int nR, int nC, MurtyArena &A, bool &ok) {
-  ok = true;
-  const double bigNumber = 10000.0, BIG_NEG = -1000.0;
-  int nNodes = 0, heapLen = 0;
-  int realNR = nR > n ? n : nR, realNC = nC > n ? n : nC;
-  // first call (:147-158): Hungarian on the full matrix
-  {
-    double s;
-    unsigned char *a = A.nodeA;  // node 0
-    if (!hungarian_run(C, n, n, a, &s, A)) { ok = false; return 0.0; }
-    A.nodeId[0] = 0;
-    A.nodeParent[0] = -1;
-    A.nodeScore[0] = s;
-    nNodes = 1;
-    heap_push(A.heap, heapLen, 0, A.nodeScore);
-    if (s < BIG_NEG) return 0.0;
-  }
-  double sum = exp(A.nodeScore[0]);
-  int rowRemap[MURTY_N], rowRemapR[MURTY_N], colRemap[MURTY_N], colRemapR[MURTY_N];
-  for (int k = 1; k < MURTY_KBEST; k++) {
-    if (heapLen == 0) break;  // rank == -1
-    const short parent = heap_pop(A.heap, heapLen, A.nodeScore);
-    const int parent_partition = A.nodeId[parent];
-    const unsigned char *a_parent = A.nodeA + (size_t)parent * MURTY_N;
-    int partitionMax = realNR;
-    if (realNR == n) partitionMax = n - 1;
-    for (int nn = parent_partition; nn < partitionMax; nn++) {
-      if (nNodes >= MURTY_MAX_NODES) { ok = false; return sum; }
-      const short pn = (short)nNodes++;
-      A.nodeId[pn] = (unsigned char)nn;
-      A.nodeParent[pn] = parent;
-      unsigned char *a = A.nodeA + (size_t)pn * MURTY_N;
-      unsigned long long freeCols = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
-      double fixedScore = 0;
-      for (int r = 0; r < nn; r++) {  // rows < parent_partition, then [parent_partition, nn): same source, same order
-        a[r] = a_parent[r];
-        freeCols &= ~(1ull << a[r]);
-        fixedScore += C[r * n + a[r]];
-      }
-      const int nFree = n - nn;
-      for (int r = 0; r < nFree; r++) { rowRemap[r] = nn + r; rowRemapR[nn + r] = r; }
-      int nf = 0;
-      for (int c = 0; c < n; c++)
-        if ((freeCols >> c) & 1ull) { colRemap[nf] = c; colRemapR[c] = nf; nf++; }
-      for (int r = 0; r < nFree; r++)
-        for (int c = 0; c < nFree; c++) A.Ct[r * MURTY_N + c] = C[rowRemap[r] * n + colRemap[c]];
-      // negative constraints (:247-265)
-      short current = pn;
-      do {
-        const int currentPart = A.nodeId[current];
-        const short next = A.nodeParent[current];
-        const unsigned char *na = A.nodeA + (size_t)next * MURTY_N;
-        const int di = rowRemapR[currentPart];
-        const int dj = colRemapR[na[currentPart]];
-        A.Ct[di * MURTY_N + dj] = -bigNumber;
-        if (dj >= realNC)
-          for (int yy = 0; yy < nFree; yy++)
-            if (yy >= realNC) A.Ct[di * MURTY_N + yy] = -bigNumber;
-        current = next;
-      } while (current != 0 && A.nodeId[current] >= A.nodeId[pn]);
-      bool possible = false;
-      const int constraintRow = rowRemapR[nn];
-      for (int c = 0; c < nFree; c++)
-        if (A.Ct[constraintRow * MURTY_N + c] != -bigNumber) { possible = true; break; }
-      if (possible) {
-        unsigned char aTmp[MURTY_N];
-        double s = 0;
-        if (!hungarian_run(A.Ct, MURTY_N, nFree, aTmp, &s, A)) continue;
-        double sAcc = 0;
-        for (int r = 0; r < nFree; r++) {
-          const int ia = rowRemap[r], ja = colRemap[aTmp[r]];
-          a[ia] = (unsigned char)ja;
-          sAcc += C[ia * n + ja];
-        }
-        sAcc += fixedScore;
-        A.nodeScore[pn] = sAcc;
-        heap_push(A.heap, heapLen, pn, A.nodeScore);
-      }
-    }
-    if (heapLen == 0) break;
-    const double s = A.nodeScore[A.heap[0]];
-    if (s < BIG_NEG) break;
-    sum += exp(s);
   }
   return sum;
 }
