@@ -31,6 +31,9 @@ if "--cpu" in sys.argv:
     ob = importlib.import_module("oracle.binding")
     n = 512
     sub = dict(scen); sub.update(n=n, poses=scen["poses"][:n], w=scen["w"][:n], mean=scen["mean"][:n], cov=scen["cov"][:n], particle_w=scen["particle_w"][:n])
+    ow = ob.OracleFilter(n, model=pkg.capi.MODEL_VICTORIAPARK_3D)                     # warm-up instance: the first OpenMP region pays for starting the thread team
+    sc.load_scenario(ow, sub)
+    ow.update(scen["Z"])
     o = ob.OracleFilter(n, model=pkg.capi.MODEL_VICTORIAPARK_3D)
     sc.load_scenario(o, sub)
     t0 = time.perf_counter()
