@@ -222,13 +222,23 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     unsigned long long buf0 = 0ull, buf1 = 0ull;  // up to 8 survivors, 16 bits each
     int nP = 0;
     double farE2 = 1.0e300;   // nearest neighbour that fails the prefilter by a factor >= 2 in distance
-    for (int ry = (cy > 0 ? cy - 1 : 0); ry <= (cy < MERGE_GY - 1 ? cy + 1 : MERGE_GY - 1); ry++) {
-      const unsigned qs = cell_at(ry * MERGE_GX + cxa), qe = cell_at(ry * MERGE_GX + cxb + 1);
-      for (unsigned q = qs; q < qe; q += 4) {
+    // the three cell rows are three contiguous ranges of the sorted list; they are walked as ONE sequence (same order as
+    // row by row), so that only the last trip of four is partly empty instead of the last trip of every row
+    const unsigned qs1 = cell_at(cy * MERGE_GX + cxa), n1 = cell_at(cy * MERGE_GX + cxb + 1) - qs1;
+    unsigned qs0 = 0, n0 = 0, qs2 = 0, n2 = 0;
+    if (cy > 0) { qs0 = cell_at((cy - 1) * MERGE_GX + cxa); n0 = cell_at((cy - 1) * MERGE_GX + cxb + 1) - qs0; }
+    if (cy < MERGE_GY - 1) { qs2 = cell_at((cy + 1) * MERGE_GX + cxa); n2 = cell_at((cy + 1) * MERGE_GX + cxb + 1) - qs2; }
+    const unsigned n01 = n0 + n1, tot = n01 + n2;       // (tot >= 1: the entry itself)
+    {
+      for (unsigned q = 0; q < tot; q += 4) {
         unsigned jj[4];
         double jx[4], jy[4], jb[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) jj[k] = sSorted[(q + k < qe) ? q + k : qe - 1];
+        for (int k = 0; k < 4; k++) {
+          const unsigned t = (q + k < tot) ? q + k : tot - 1;
+          const unsigned pos = (t < n0) ? qs0 + t : ((t < n01) ? qs1 + (t - n0) : qs2 + (t - n01));
+          jj[k] = sSorted[pos];
+        }
 #pragma unroll
         for (int k = 0; k < 4; k++) { jx[k] = sMX[jj[k]]; jy[k] = sMY[jj[k]]; jb[k] = sBnd[jj[k]]; }
 #pragma unroll
@@ -236,7 +246,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
           const double e0 = jx[k] - ax, e1 = jy[k] - ay;
           const double e2 = e0 * e0 + e1 * e1, T = fmax(ab, jb[k]);
           // higher index only (the entry plays `a`); NaN distances fall through to the exact test like the reference
-          const bool cand = (q + k < qe) & (jj[k] > (unsigned)m);
+          const bool cand = (q + k < tot) & (jj[k] > (unsigned)m);
           const bool c = cand & !(e2 > T);
           // neighbours within twice the prefilter radius are listed too, as RESERVE partners (bit 14): they cannot pass
           // now, but may once the row has merged and moved; everything farther bounds the row's slack from below
