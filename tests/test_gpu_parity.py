@@ -998,3 +998,15 @@ def test_full_size_c5_murty_stress(pkg, ob, sc):
     """configs[4]: 1000 particles x 50 measurements, 40 evaluation points, 10-sigma weighting gate -> Murty-200 partitions."""
     scen = sc.make_scenario(1000, 200, 50, seed=555, n_clutter=10, n_eval=40, weighting_md=10.0, weights=(0.8, 1.0))
     _full_size_check(pkg, ob, sc, scen, cap=448, subset=16, check_murty=True)
+
+
+def test_randomised_differential_run():
+    """tools/fuzz_parity.py: random shapes (1..330 landmarks around the 64-entry chunk boundaries), ranges, SC-PHD / multi-
+    feature, tied / quantised / sub-fp32 weights, two update cycles each, fused and three-kernel path, device vs oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "40", "2024"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "0 failures" in out.stdout

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Randomised differential run, device vs oracle (GPU box): random shapes / ranges / weight ties / strategies, two full
+update() cycles each (map update, weighting, merge, prune, normalise) with the fused and the three-kernel path.
+    python tools/fuzz_parity.py [n_cases] [seed]"""
+import os
+import sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package
+import importlib
+pkg = load_package()
+sc = pkg.scenarios
+ob = importlib.import_module("oracle.binding")
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+for case in range(n_cases):
+    n = int(rng.integers(3, 12))
+    nlm = int(rng.choice([1, 5, 40, 63, 64, 65, 127, 128, 129, 200, 257, 330]))
+    nz = int(rng.integers(1, 25))
+    rmax = float(rng.choice([2.5, 4.0, 6.0]))
+    kw = dict(n_particles=n, n_landmarks=nlm, n_z=nz, seed=int(rng.integers(1 << 30)), rmax=rmax,
+              frac_in_fov=float(rng.choice([1.0, 0.6, 0.2])), use_cluster=bool(rng.integers(0, 2)) if rng.random() < 0.3 else None)
+    scen = sc.make_scenario(**kw)
+    mode = int(rng.integers(0, 4))
+    if mode == 1:
+        scen["w"][:, ::2] = 0.5                                            # ties everywhere
+    elif mode == 2:
+        scen["w"][:] = np.round(scen["w"] * 4) / 4                          # a handful of distinct weights
+    elif mode == 3:
+        scen["w"][:, ::5] = 1e-42 * (1 + np.arange(scen["w"][:, ::5].shape[1]))[None, :]   # below fp32's normal range
+    cap = 768
+    for fused in (1, 0):
+        os.environ["RFSGPU_FUSED_STEP"] = str(fused)
+        dev = pkg.RBPHDFilter(n, gm_capacity=cap)
+        orc = ob.OracleFilter(n, stable_sort=True)
+        try:
+            for f in (dev, orc):
+                sc.load_scenario(f, scen)
+            for cyc in range(2):
+                Z = scen["Z"] + 1e-3 * cyc
+                dev.update_async(Z); dev.synchronize()
+                orc.update(Z)
+                wd, wo = dev.get_weights(), orc.get_weights()
+                np.testing.assert_allclose(wd / wd.sum(), wo / wo.sum(), rtol=1e-9, atol=1e-300)
+                assert np.array_equal(dev.gm_sizes(), orc.gm_sizes())
+                for i in range(n):
+                    sc.assert_gm_close(dev.export_gm(i), orc.export_gm(i), 1e-10, 1e-12, ordered=True)
+                for f in (dev, orc):
+                    s = f.weight_sums(); f.normalize_weights(s[0]); f.predict_map(True)
+        except Exception as e:  # noqa: BLE001
+            bad += 1
+            print("CASE", case, "fused", fused, kw, "mode", mode, "->", type(e).__name__, str(e)[:300], flush=True)
+        dev.close()
+print("fuzz: %d cases x 2 paths, %d failures" % (n_cases, bad))
+sys.exit(1 if bad else 0)
