@@ -1009,4 +1009,16 @@ def test_randomised_differential_run():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "40", "2024"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
-    assert "0 failures" in out.stdout
+    assert ", 0 failures" in out.stdout
+
+
+def test_randomised_differential_run_fastslam():
+    """tools/fuzz_fastslam.py: random FastSLAM / MH-FastSLAM set-ups (1..5 hypotheses, likelihood windows, candidate thresholds),
+    four cycles with particle growth and resample(nParticles_init), device vs oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_fastslam.py"), "40", "2025"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert ", 0 failures" in out.stdout
