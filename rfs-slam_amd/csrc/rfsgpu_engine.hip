@@ -81,6 +81,7 @@ struct rfsgpu_filter {
   std::vector<int> parents;           // source slot of every particle after the last FastSLAM update (identity when none multiplied)
   bool holes = false;       // between rfsgpu_merge and rfsgpu_prune merged-away entries sit in the slab with w = -1; at any other
                             // time a negative weight is a value (FastSLAM's log-odds) and every stored entry counts
+  int nCU = 256;            // multiProcessorCount of the device
   bool fuseSteps = true;    // rfsgpu_update_async uses phd_step_fused_kernel (2-D model); RFSGPU_FUSED_STEP=0 turns it off
   hipEvent_t evAfterWeightKernel = nullptr;   // where launch_weighting drops its mid-phase event (async steps only)
   int ringCount = 0;        // async steps recorded since the last harvest
@@ -225,6 +226,7 @@ int rfsgpu_create_ex(rfsgpu_filter **out, int model, int n_particles, int device
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return bail(RFSGPU_ERR_NO_DEVICE);
   f->maxLds = (int)prop.sharedMemPerBlock;
+  f->nCU = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (hipStreamCreateWithFlags(&f->ownStream, hipStreamNonBlocking) != hipSuccess) return bail(RFSGPU_ERR_HIP);
   f->stream = f->ownStream;
   for (int k = 0; k < EV_COUNT; k++)
@@ -851,8 +853,13 @@ int rfsgpu_update_async(rfsgpu_filter *f, const double *z, int n_z) {
     // the whole step in one launch (step_fused.h); Murty partitions, if any, follow as usual
     const int ec = eval_cap(f), useW = f->cfg.useClusterProcess ? 0 : 1;
     const size_t b = step_fused_lds_bytes(f->cap, ec, f->nZ, STEP_WPP);
-    if ((rc = set_lds(f, phd_step_fused_kernel<STEP_WPP>, b)) != RFSGPU_OK) return rc;
-    phd_step_fused_kernel<STEP_WPP><<<f->N, STEP_WPP * 64, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q);
+    if ((rc = set_lds(f, (phd_step_fused_kernel<STEP_WPP, true>), b)) != RFSGPU_OK) return rc;
+    if ((rc = set_lds(f, (phd_step_fused_kernel<STEP_WPP, false>), b)) != RFSGPU_OK) return rc;
+    // phase priorities only when every workgroup is resident at once: 16 waves per CU at 128 VGPRs, LDS permitting
+    const int perCU = (int)std::min<size_t>(16 / STEP_WPP, b ? (size_t)(160 * 1024) / b : 16);
+    const int phasePrio = (long long)perCU * f->nCU >= f->N ? 1 : 0;
+    if (phasePrio) phd_step_fused_kernel<STEP_WPP, true><<<f->N, STEP_WPP * 64, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q);
+    else phd_step_fused_kernel<STEP_WPP, false><<<f->N, STEP_WPP * 64, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q);
     HIPCHK(hipGetLastError());
     if (useW) {
       if (murty_launch(f->Q, f->MS, f->B, f->stream) != 0) return fail(f, RFSGPU_ERR_HIP, "murty launch failed");
@@ -1089,8 +1096,8 @@ int rfsgpu_debug_sections(rfsgpu_filter *f, long long *out64) {
   CHECK_HANDLE(f);
   hipSetDevice(f->device);
   if (!f->B.dbg) {
-    HIPCHK(hipMalloc(&f->B.dbg, (64 + 4 * (size_t)f->Ncap) * sizeof(long long)));
-    HIPCHK(hipMemset(f->B.dbg, 0, (64 + 4 * (size_t)f->Ncap) * sizeof(long long)));
+    HIPCHK(hipMalloc(&f->B.dbg, (64 + 8 * (size_t)f->Ncap) * sizeof(long long)));
+    HIPCHK(hipMemset(f->B.dbg, 0, (64 + 8 * (size_t)f->Ncap) * sizeof(long long)));
   }
   HIPCHK(hipMemcpy(out64, f->B.dbg, 64 * sizeof(long long), hipMemcpyDeviceToHost));
   return RFSGPU_OK;
@@ -1101,6 +1108,14 @@ int rfsgpu_debug_per_particle(rfsgpu_filter *f, long long *out4n) {
   if (!f->B.dbg) return RFSGPU_ERR_INVALID;
   hipSetDevice(f->device);
   HIPCHK(hipMemcpy(out4n, f->B.dbg + 64, 4 * (size_t)f->N * sizeof(long long), hipMemcpyDeviceToHost));
+  return RFSGPU_OK;
+}
+// second block of four: the fused step kernel's phase clock per particle (start, after map update, after weighting, end)
+int rfsgpu_debug_per_particle_fused(rfsgpu_filter *f, long long *out4n) {
+  CHECK_HANDLE(f);
+  if (!f->B.dbg) return RFSGPU_ERR_INVALID;
+  hipSetDevice(f->device);
+  HIPCHK(hipMemcpy(out4n, f->B.dbg + 64 + 4 * (size_t)f->N, 4 * (size_t)f->N * sizeof(long long), hipMemcpyDeviceToHost));
   return RFSGPU_OK;
 }
 #endif

@@ -36,7 +36,7 @@ __host__ __device__ inline size_t step_fused_lds_bytes(int cap, int evalCap, int
 
 // useWeighting == 0: SC-PHD (useClusterProcess_): the particle weight comes out of the map update, the mixture is not
 // sorted, merge works on the slab the update wrote.
-template <int WPP>
+template <int WPP, bool PHASE_PRIO>
 __global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(STEP_WAVES_PER_EU)))
 void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, int useWeighting, MurtyQueue Q) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -44,17 +44,34 @@ void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, in
   const int lane = tid & 63;
   const int i = blockIdx.x;
   double *sZ = reinterpret_cast<double *>(smem_raw);
+  // Issue priority falls from phase to phase (s_setprio): the SIMD arbiter otherwise always prefers its oldest waves, so the
+  // last workgroups to arrive on a CU crawl through the map update while the first ones race ahead, and the launch lasts as
+  // long as those stragglers.  With a workgroup that is a phase behind outranking the ones ahead, the eight workgroups of
+  // a CU finish together.  Only when the whole grid is resident at once (PHASE_PRIO, picked by the host): with several
+  // rounds of workgroups per CU, newcomers outranking workgroups that are about to free their slots costs more than it gives
+  // (measured: +2.3 % at 2000 x 200, -5 % at 2500 x 500).  Level 3 is set inside phd_update_map_block.
   for (int t = tid; t < 2 * nZ; t += WPP * 64) sZ[t] = B.Z[t];
   __syncthreads();
+#ifdef RFS_PROFILE
+  long long *fd = B.dbg ? B.dbg + 64 + 4 * (size_t)B.N + 4 * (size_t)i : nullptr;
+  if (fd && tid == 0) {  // start tick | (XCC_ID << 60) | (HW_ID[15:0] << 44)
+    const unsigned hw = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 4), xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20);
+    fd[0] = (long long)((wall_clock64() & 0xfffffffffffull) | ((unsigned long long)(hw & 0xffffu) << 44) | ((unsigned long long)(xcc & 0xfu) << 60));
+  }
+#endif
   if (WPP == 1) phd_update_map_particle<STEP_GATE_BATCH>(B, P, cur, nZ, B.Z, i, lane, sZ, smem_raw + 2 * RFSGPU_MAX_Z * 8);
-  else phd_update_map_block<WPP, STEP_GATE_BATCH>(B, P, cur, nZ, B.Z, i, tid, sZ, smem_raw + 2 * RFSGPU_MAX_Z * 8);
+  else phd_update_map_block<WPP, STEP_GATE_BATCH>(B, P, cur, nZ, B.Z, i, tid, sZ, smem_raw + 2 * RFSGPU_MAX_Z * 8, PHASE_PRIO);
   __threadfence_block();  // the slab / count written by wave 0 -> the whole workgroup
   __syncthreads();
+#ifdef RFS_PROFILE
+  if (fd && tid == 0) fd[1] = (long long)wall_clock64();
+#endif
   int mergeSrc = cur;
   // Each phase gets its own copy of the thread index behind a compiler barrier: otherwise address arithmetic common to the
   // phases (tid * 8, ...) is hoisted to the top of the kernel and held -- or spilled -- across all of them.
   int tidW = threadIdx.x;
   asm volatile("" : "+v"(tidW));
+  if (PHASE_PRIO) __builtin_amdgcn_s_setprio(2);
   if (useWeighting) {
     phd_weight_particle<WPP>(B, P, cur, cur ^ 1, nZ, evalCap, Q, i, tidW, smem_raw);
     __threadfence_block();
@@ -63,5 +80,12 @@ void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, in
   }
   int tidM = threadIdx.x;
   asm volatile("" : "+v"(tidM));
+  if (PHASE_PRIO) __builtin_amdgcn_s_setprio(1);
+#ifdef RFS_PROFILE
+  if (fd && tid == 0) fd[2] = (long long)wall_clock64();
+#endif
   gm_merge_particle<WPP, true>(B, P, mergeSrc, mergeSrc ^ 1, i, tidM, smem_raw);
+#ifdef RFS_PROFILE
+  if (fd && tid == 0) fd[3] = (long long)wall_clock64();
+#endif
 }

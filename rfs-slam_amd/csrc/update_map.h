@@ -344,7 +344,7 @@ __host__ __device__ inline size_t update_map_block_lds_bytes(int cap) {
 template <int WPP, int GB>
 __device__ __forceinline__ void phd_update_map_block(const Buffers &B, const Params &P, const int cur, const int nZ,
                                                      const double *__restrict__ Zg, const int i, const int tid, const double *sZ,
-                                                     unsigned char *wb) {
+                                                     unsigned char *wb, const bool phasePrio = false) {
   constexpr int NT = WPP * 64;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
@@ -383,6 +383,9 @@ __device__ __forceinline__ void phd_update_map_block(const Buffers &B, const Par
   int nSurv = 0;
   bool overflow = false;
 
+  // (step_fused.h: issue priority falls from phase to phase; raised here rather than at the kernel's first instruction,
+  //  where the scheduling barrier it forms made the register allocator spill 84 B per lane)
+  if (phasePrio) __builtin_amdgcn_s_setprio(3);
   // ---------------- phase 1 ----------------
   for (int p = 0; p < nPass; p++) {
     const int m = p * NT + tid;

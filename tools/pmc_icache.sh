@@ -1,14 +1,13 @@
 #!/bin/bash
-# SQ instruction-mix counters for the hot kernels (tuning aid): are the kernels issue-bound or latency-bound?
-# usage: tools/pmc_sq.sh <tag>      (GPU box; writes gpurun_out/sq_<tag>/)
+# Instruction-cache counters of the hot kernels (tuning aid).  usage: tools/pmc_icache.sh <tag>   (GPU box)
 set -u
 TAG=${1:-x}
-OUT=gpurun_out/sq_$TAG
+OUT=gpurun_out/ic_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 ARGS="--steps 20 --warmup 3 --no-cpu-baseline"
 k=0
-for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU" "SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_ANY"; do
+for set in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" "SQ_IFETCH SQ_IFETCH_LEVEL SQC_TC_INST_REQ SQC_ICACHE_BUSY_CYCLES" "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQ_WAVE_CYCLES"; do
   k=$((k+1))
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$k -o p -- python bench.py $ARGS > $OUT/log$k.txt 2>&1
 done
@@ -24,5 +23,5 @@ for name, cs in agg.items():
         continue
     print(name)
     for c, v in sorted(cs.items()):
-        print("   %-24s %14.0f" % (c, sum(v) / len(v)))
+        print("   %-28s %14.0f" % (c, sum(v) / len(v)))
 PY
