@@ -44,12 +44,12 @@ void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, in
   const int lane = tid & 63;
   const int i = blockIdx.x;
   double *sZ = reinterpret_cast<double *>(smem_raw);
-  // Issue priority falls from phase to phase (s_setprio): the SIMD arbiter otherwise always prefers its oldest waves, so the
+  // Issue priority falls from phase to phase (s_setprio 2/3 -> 1 -> 0): the SIMD arbiter otherwise always prefers its oldest waves, so the
   // last workgroups to arrive on a CU crawl through the map update while the first ones race ahead, and the launch lasts as
   // long as those stragglers.  With a workgroup that is a phase behind outranking the ones ahead, the eight workgroups of
   // a CU finish together.  Only when the whole grid is resident at once (PHASE_PRIO, picked by the host): with several
   // rounds of workgroups per CU, newcomers outranking workgroups that are about to free their slots costs more than it gives
-  // (measured: +2.3 % at 2000 x 200, -5 % at 2500 x 500).  Level 3 is set inside phd_update_map_block.
+  // (measured: +2.3 % at 2000 x 200, -5 % at 2500 x 500).  Levels: map update 2 (3 for a SIMD's last arrivals), weighting 1, merge 0; the first is set inside phd_update_map_block.
   for (int t = tid; t < 2 * nZ; t += WPP * 64) sZ[t] = B.Z[t];
   __syncthreads();
 #ifdef RFS_PROFILE
@@ -71,7 +71,7 @@ void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, in
   // phases (tid * 8, ...) is hoisted to the top of the kernel and held -- or spilled -- across all of them.
   int tidW = threadIdx.x;
   asm volatile("" : "+v"(tidW));
-  if (PHASE_PRIO) __builtin_amdgcn_s_setprio(2);
+  if (PHASE_PRIO) __builtin_amdgcn_s_setprio(1);
   if (useWeighting) {
     phd_weight_particle<WPP>(B, P, cur, cur ^ 1, nZ, evalCap, Q, i, tidW, smem_raw);
     __threadfence_block();
@@ -80,7 +80,7 @@ void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, in
   }
   int tidM = threadIdx.x;
   asm volatile("" : "+v"(tidM));
-  if (PHASE_PRIO) __builtin_amdgcn_s_setprio(1);
+  if (PHASE_PRIO) __builtin_amdgcn_s_setprio(0);
 #ifdef RFS_PROFILE
   if (fd && tid == 0) fd[2] = (long long)wall_clock64();
 #endif
