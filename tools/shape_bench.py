@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """RB-PHD update rate at an arbitrary shape (not the headline metric: bench.py) -- e.g. configs[2]'s shard, 2500 particles x
 500 Gaussians x 30 measurements with a 5 m range limit:
-    SB_N=2500 SB_NM=500 SB_NZ=30 SB_RMAX=5 SB_CAP=704 python tools/shape_bench.py [--cpu]
+    SB_N=2500 SB_NM=500 SB_NZ=30 SB_RMAX=5 SB_CAP=640 python tools/shape_bench.py [--cpu]
 State re-seeded from a device snapshot every step; fused step (update_async) and the three stand-alone kernels."""
 import os
 import sys
@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package
 pkg = load_package()
 sc = pkg.scenarios
-N, NM, NZ, CAP = [int(os.environ.get(k, d)) for k, d in (("SB_N", 2500), ("SB_NM", 500), ("SB_NZ", 30), ("SB_CAP", 704))]
+N, NM, NZ, CAP = [int(os.environ.get(k, d)) for k, d in (("SB_N", 2500), ("SB_NM", 500), ("SB_NZ", 30), ("SB_CAP", 640))]
 RMAX = float(os.environ.get("SB_RMAX", 5.0))
 scen = sc.make_scenario(N, NM, NZ, seed=777, rmax=RMAX)
 f = pkg.RBPHDFilter(N, gm_capacity=CAP)
