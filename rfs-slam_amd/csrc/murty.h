@@ -7,8 +7,9 @@
 // offset add/subtract in the Hungarian solver, same binary-heap discipline as std::priority_queue.
 //
 // Jobs are produced by phd_weight_multifeature_kernel (weighting.h) into a device queue; murty_jobs_kernel consumes
-// them -- one WAVEFRONT per job: the tree search stays serial, the Hungarian solver inside it (hungarian_wave.h) and the
-// sub-problem / assignment bookkeeping run across the lanes -- and multiplies each job's partition likelihood into its
+// them -- one workgroup of two wavefronts per job: the tree search stays serial, the Hungarian solver inside it
+// (hungarian_wave.h) and the sub-problem / assignment bookkeeping run across the lanes, the children of an expansion across
+// the waves -- and multiplies each job's partition likelihood into its
 // particle's weight in partition order.  Node pool, heap and root table live in HBM (per-job arena), sub-problem tables
 // in an LDS tile.  hungarian_run below is the one-thread form of the solver (still used by fastslam.h's small blocks).
 #pragma once
@@ -40,7 +41,7 @@ struct MurtyArena {
 
 __host__ __device__ inline size_t murty_job_bytes() {
   size_t b = 0;
-  b += (size_t)MURTY_N * MURTY_N * 8;      // Ct
+  b += (size_t)4 * MURTY_N * MURTY_N * 8;  // Ct, one per wave of the job's workgroup (MURTY_JOB_WAVES <= 4)
   b += 3 * MURTY_N * 8;                    // lx ly slack
   b += (1 + 1 + 2 + 2) * MURTY_N * 4;      // xy yx p queue
   b += 5 * MURTY_N;                        // flags
@@ -54,7 +55,7 @@ __host__ __device__ inline size_t murty_job_bytes() {
 
 __device__ inline void murty_carve(unsigned char *base, MurtyArena &A) {
   unsigned char *p = base;
-  A.Ct = (double *)p; p += (size_t)MURTY_N * MURTY_N * 8;
+  A.Ct = (double *)p; p += (size_t)4 * MURTY_N * MURTY_N * 8;
   A.lx = (double *)p; p += MURTY_N * 8;
   A.ly = (double *)p; p += MURTY_N * 8;
   A.slack = (double *)p; p += MURTY_N * 8;
@@ -394,41 +395,153 @@ __device__ __forceinline__ double murty_partition_sum_wave(double *C, int n, int
   return sum;
 }
 
-// One wavefront per queued partition (MURTY_JOB_WAVES per workgroup, jobs strided over the grid); the last workgroup to
+// One partition, one WORKGROUP of W wavefronts: the same enumeration with the children of an expansion -- independent
+// sub-problems -- shared out among the waves (child c of the popped node to wave c mod W, each in its own LDS tile); wave 0
+// pops, and after a barrier pushes the children in partition order and takes the next score, exactly as the one-wave
+// form does.  ctl: [0] parent [1] its partition [2] nodes so far [3] heap length [4] stop [5] ok.
+template <int W>
+__device__ __forceinline__ double murty_partition_sum_block(double *C, int n, int nR, int nC, MurtyArena &A, bool &ok, double *myTile, int *ctl,
+                                                            double *sSum, double *sScore, unsigned char *sPushed, const int wave) {
+  const double BIG_NEG = -1000.0;
+  const int lane = threadIdx.x & 63;
+  const int realNR = nR > n ? n : nR, realNC = nC > n ? n : nC;
+  const int partitionMax = (realNR == n) ? n - 1 : realNR;
+  if (wave == 0) {
+    int a0;
+    double s = 0;
+    const bool okr = murty_root_wave(C, n, A, a0, s, nullptr);
+    if (lane == 0) {
+      const bool go = okr && !(s < BIG_NEG);
+      ctl[2] = 1; ctl[3] = okr ? 1 : 0; ctl[4] = go ? 0 : 1; ctl[5] = okr ? 1 : 0;
+      *sSum = go ? exp(s) : 0.0;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  // (values read back from LDS are wave-uniform, but only readfirstlane tells the compiler so: without it the whole search
+  //  would be compiled as divergent control flow)
+#ifdef RFS_PROFILE
+  long long tp[4] = {0, 0, 0, 0};
+  long long tq = (long long)__builtin_readcyclecounter();
+#define MB_STAMP(i) do { const long long tn = (long long)__builtin_readcyclecounter(); tp[i] += tn - tq; tq = tn; } while (0)
+#else
+#define MB_STAMP(i) do { } while (0)
+#endif
+  for (int k = 1; k < MURTY_KBEST && __builtin_amdgcn_readfirstlane(ctl[4]) == 0; k++) {
+    MB_STAMP(3);
+    if (wave == 0 && lane == 0) {
+      int hl = ctl[3];
+      const int parent = heap_pop(A.heap, hl, A.nodeScore);
+      ctl[0] = parent; ctl[1] = A.nodeId[parent]; ctl[3] = hl;
+    }
+    __threadfence_block();
+    __syncthreads();
+    MB_STAMP(0);
+    const int parent = __builtin_amdgcn_readfirstlane(ctl[0]), pp = __builtin_amdgcn_readfirstlane(ctl[1]), nNodes = __builtin_amdgcn_readfirstlane(ctl[2]);
+    const int cnt = partitionMax - pp;
+    const bool poolFull = cnt > 0 && nNodes + cnt > MURTY_MAX_NODES;
+    if (!poolFull && cnt > 0) {
+      const int aPar = (lane < n) ? A.nodeA[(size_t)parent * MURTY_N + lane] : 0;
+      const double termPar = (lane < n) ? C[lane * n + aPar] : 0.0;
+      for (int c = wave; c < cnt; c += W) {
+        const int nn = pp + c, pn = nNodes + c;
+        double fixedScore = 0;
+        for (int r = 0; r < nn; r++) fixedScore += readlane_f64(termPar, r);   // rows 0..nn-1 fixed to the parent's choice
+        const unsigned long long usedCols = wave_or_u64((lane < nn) ? (1ull << aPar) : 0ull);
+        const unsigned long long freeCols = ((n >= 64) ? ~0ull : ((1ull << n) - 1ull)) & ~usedCols;
+        const int nFree = n - nn;
+        const int colRemap = (lane < nFree) ? murty_kth_bit(freeCols, lane) : 0;
+        if (lane == 0) { A.nodeId[pn] = (unsigned char)nn; A.nodeParent[pn] = (short)parent; }
+        bool pushed = false;
+        double sAcc = 0;
+        int aNew = aPar, aTmp = 0;
+        const bool okH = (nFree <= MURTY_LDS_N)
+                             ? murty_child_wave<MURTY_LDS_N>(myTile, C, n, nn, nFree, pn, parent, colRemap, freeCols, realNC, A, aTmp, nullptr, nullptr)
+                             : murty_child_wave<MURTY_N>(A.Ct + (size_t)wave * MURTY_N * MURTY_N, C, n, nn, nFree, pn, parent, colRemap, freeCols, realNC, A, aTmp, nullptr, nullptr);
+        if (okH) {
+          const int ja = __shfl((lane < nFree) ? colRemap : 0, (lane < nFree) ? aTmp : 0, 64);
+          const double term = (lane < nFree) ? C[(nn + lane) * n + ja] : 0.0;
+          for (int r = 0; r < nFree; r++) sAcc += readlane_f64(term, r);
+          sAcc += fixedScore;
+          const int jaShift = __shfl(ja, (lane >= nn) ? lane - nn : 0, 64);
+          if (lane >= nn) aNew = jaShift;
+          pushed = true;
+        }
+        if (lane < n) A.nodeA[(size_t)pn * MURTY_N + lane] = (unsigned char)aNew;
+        if (lane == 0) { sPushed[c] = pushed ? 1 : 0; sScore[c] = sAcc; }
+      }
+    }
+    MB_STAMP(1);
+    __threadfence_block();
+    __syncthreads();
+    if (wave == 0 && lane == 0) {
+      int stop = 0;
+      if (poolFull) {
+        ctl[5] = 0;
+        stop = 1;
+      } else {
+        int hl = ctl[3];
+        for (int c = 0; c < cnt; c++)
+          if (sPushed[c]) {
+            A.nodeScore[nNodes + c] = sScore[c];
+            heap_push(A.heap, hl, (short)(nNodes + c), A.nodeScore);
+          }
+        ctl[2] = nNodes + (cnt > 0 ? cnt : 0);
+        ctl[3] = hl;
+        if (hl == 0) stop = 1;  // rank == -1
+        else {
+          const double st = A.nodeScore[A.heap[0]];
+          if (st < BIG_NEG) stop = 1;
+          else *sSum += exp(st);
+        }
+      }
+      ctl[4] = stop;
+    }
+    __threadfence_block();
+    __syncthreads();
+    MB_STAMP(2);
+  }
+#ifdef RFS_PROFILE
+  if (wave == 0 && lane == 0 && (blockIdx.x & 255) == 0) printf("murty block job: n %d nodes %d; cycles pop+barrier %lld, children %lld, push+top+barriers %lld, loop head %lld\n", n, ctl[2], tp[0], tp[1], tp[2], tp[3]);
+#endif
+  ok = __builtin_amdgcn_readfirstlane(ctl[5]) != 0;
+  return *sSum;
+}
+
+// One workgroup of MURTY_JOB_WAVES wavefronts per queued partition (jobs strided over the grid); the last workgroup to
 // finish multiplies every particle's factors into its weight, in partition (slot) order.  Q.count[0] = number of jobs,
 // Q.count[1] = finished-workgroup ticket.  With an empty queue (the common case: no partition above 8) every workgroup
 // exits at once -- one empty launch, no host round trip.
-#define MURTY_JOB_WAVES 4
-#define MURTY_JOB_BLOCKS 512
+#ifndef MURTY_JOB_WAVES
+#define MURTY_JOB_WAVES 2
+#endif
+#define MURTY_JOB_BLOCKS 2048
 __global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err, double *weight, int N) {
   const int nJobs = min(*Q.count, Q.maxJobs);
   if (nJobs == 0) return;
   __shared__ double sTile[MURTY_JOB_WAVES][MURTY_LDS_N * MURTY_LDS_N];
-  __shared__ unsigned char sQueue[MURTY_JOB_WAVES][2 * MURTY_N];
+  __shared__ double sScore[MURTY_N];
+  __shared__ double sSum;
+  __shared__ int sCtl[8];
+  __shared__ unsigned char sPushed[MURTY_N];
   // (readfirstlane: tells the compiler the wave index is uniform, so that the whole search compiles to scalar control flow)
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-  for (int j = blockIdx.x * MURTY_JOB_WAVES + wave; j < nJobs; j += gridDim.x * MURTY_JOB_WAVES) {
+  for (int j = blockIdx.x; j < nJobs; j += gridDim.x) {
     const MurtyJob J = Q.jobs[j];
     const int n = J.nR + J.nC;
     double v = 1.0;
     if (n > MURTY_N) {
-      if (lane == 0) atomicOr(err, ERRBIT_MURTY);
+      if (threadIdx.x == 0) atomicOr(err, ERRBIT_MURTY);
     } else {
       MurtyArena A;
       murty_carve(MS.arena + (size_t)j * MS.jobBytes, A);
       bool ok;
-#ifdef RFS_PROFILE
-      long long prof[9] = {(long long)__builtin_readcyclecounter(), 0, 0, n, 0, 0, 0, 0, 0};
-      v = murty_partition_sum_wave(Q.mats + (size_t)j * MURTY_MAXN * MURTY_MAXN, n, J.nR, J.nC, A, ok, sQueue[wave], sTile[wave], prof);
-      if (lane == 0 && (j & 255) == 0)
-        printf("murty job %d: n %d (nR %d nC %d) total cycles %lld, child solver cycles %lld (main loop %lld), children %lld dims %lld, steps %lld bfs %lld label updates %lld\n", j, n,
-               J.nR, J.nC, (long long)__builtin_readcyclecounter() - prof[0], prof[1], prof[8], prof[2], prof[7], prof[4], prof[5], prof[6]);
-#else
-      v = murty_partition_sum_wave(Q.mats + (size_t)j * MURTY_MAXN * MURTY_MAXN, n, J.nR, J.nC, A, ok, sQueue[wave], sTile[wave]);
-#endif
-      if (!ok && lane == 0) atomicOr(err, ERRBIT_MURTY);
+      v = murty_partition_sum_block<MURTY_JOB_WAVES>(Q.mats + (size_t)j * MURTY_MAXN * MURTY_MAXN, n, J.nR, J.nC, A, ok, sTile[wave], sCtl, &sSum, sScore,
+                                                     sPushed, wave);
+      if (!ok && threadIdx.x == 0) atomicOr(err, ERRBIT_MURTY);
     }
-    if (lane == 0) Q.results[j] = v;
+    if (threadIdx.x == 0) Q.results[j] = v;
+    __syncthreads();   // the control words are reused by the next job
   }
   __shared__ int isLast;
   __threadfence();
@@ -489,7 +602,7 @@ static inline void murty_free(MurtyQueue &Q, MurtyScratch &MS) {
 }
 // The job count lives on the device: one launch, which is empty when no partition exceeded 8.
 static inline int murty_launch(MurtyQueue &Q, MurtyScratch &MS, Buffers &B, hipStream_t stream) {
-  const int blocks = std::min(MURTY_JOB_BLOCKS, (Q.maxJobs + MURTY_JOB_WAVES - 1) / MURTY_JOB_WAVES);
+  const int blocks = std::min(MURTY_JOB_BLOCKS, Q.maxJobs);
   murty_jobs_kernel<<<blocks, 64 * MURTY_JOB_WAVES, 0, stream>>>(Q, MS, B.err, B.weight, B.N);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }

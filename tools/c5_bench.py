@@ -10,6 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package
 pkg = load_package()
+if os.environ.get("RFS_LIB"):
+    pkg.engine.LIB = os.environ["RFS_LIB"]      # a tools/variant_bench.py --build variant
 sc = pkg.scenarios
 N = int(os.environ.get("C5_N", 1000))
 scen = sc.make_scenario(N, 200, 50, seed=555, n_clutter=10, n_eval=40, weighting_md=10.0, weights=(0.8, 1.0))
