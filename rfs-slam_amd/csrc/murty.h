@@ -364,37 +364,9 @@ __device__ __forceinline__ double murty_top_wave(MurtyArena &A, int &top) {
   return readlane_f64(s, 0);
 }
 
-// One partition, one wavefront: sum of exp(score) over the <= 200 best assignments (RBPHDFilter.hpp:948-959).
 #define MURTY_LDS_N 32   // sub-problems up to this dimension are solved in an 8 KB LDS tile
-__device__ __forceinline__ double murty_partition_sum_wave(double *C, int n, int nR, int nC, MurtyArena &A, bool &ok, unsigned char *queue,
-                                                           double *ldsTile, long long *prof = nullptr) {
-  ok = true;
-  const double BIG_NEG = -1000.0;
-  int nNodes = 0, heapLen = 0;
-  const int realNR = nR > n ? n : nR, realNC = nC > n ? n : nC;
-  int a0;
-  double s;
-  if (!murty_root_wave(C, n, A, a0, s, queue)) { ok = false; return 0.0; }
-  nNodes = 1;
-  heapLen = 1;
-  if (s < BIG_NEG) return 0.0;
-  double sum = exp(s);
-  const int partitionMax = (realNR == n) ? n - 1 : realNR;
-  for (int k = 1; k < MURTY_KBEST; k++) {
-    if (heapLen == 0) break;  // rank == -1
-    if (!murty_expand_wave<MURTY_LDS_N>(C, n, partitionMax, realNC, MURTY_MAX_NODES, A, nNodes, heapLen, queue, ldsTile, prof)) {
-      ok = false;
-      return sum;
-    }
-    if (heapLen == 0) break;
-    int top;
-    const double st = murty_top_wave(A, top);
-    if (st < BIG_NEG) break;
-    sum += exp(st);
-  }
-  return sum;
-}
 
+// One partition: sum of exp(score) over the <= 200 best assignments (RBPHDFilter.hpp:948-959).
 // One partition, one WORKGROUP of W wavefronts: the same enumeration with the children of an expansion -- independent
 // sub-problems -- shared out among the waves (child c of the popped node to wave c mod W, each in its own LDS tile); wave 0
 // pops, and after a barrier pushes the children in partition order and takes the next score, exactly as the one-wave
