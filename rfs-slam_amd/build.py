@@ -40,13 +40,16 @@ def build(force=False, verbose=False, extra_flags=()):
 
 SIM = os.path.join(HERE, "host", "rbphdslam2d_sim")
 SIM_FASTSLAM = os.path.join(HERE, "host", "fastslam2d_sim")
+SIM_VP = os.path.join(HERE, "host", "rbphdslam_vp")
 
 
 def build_host(force=False, verbose=False):
     """Compile the C++ host driver (plain g++, links the C-ABI library only)."""
     src = os.path.join(HERE, "host", "rbphdslam2d_sim.cpp")
-    hdr = os.path.join(HERE, "host", "rbphd_filter.hpp")
-    if not force and os.path.exists(SIM) and os.path.getmtime(SIM) > max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(LIB)):
+    src_vp = os.path.join(HERE, "host", "rbphdslam_vp.cpp")
+    hdrs = [os.path.join(HERE, "host", "rbphd_filter.hpp"), os.path.join(HERE, "host", "xml_cfg.hpp")]
+    newest = max([os.path.getmtime(p) for p in [src, src_vp, LIB] + hdrs])
+    if not force and all(os.path.exists(p) and os.path.getmtime(p) > newest for p in (SIM, SIM_FASTSLAM, SIM_VP)):
         return SIM
     cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "host"), src,
            "-L" + HERE, "-lrfsgpu", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib", "-o", SIM]
@@ -58,4 +61,9 @@ def build_host(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd2))
     subprocess.check_call(cmd2)
+    # the Victoria Park host loop (reference: src/rbphdslam_VictoriaPark.cpp)
+    cmd3 = [src_vp if c == src else c for c in cmd[:-1]] + [SIM_VP]
+    if verbose:
+        print(" ".join(cmd3))
+    subprocess.check_call(cmd3)
     return SIM

@@ -118,9 +118,9 @@ class RBPHDFilter2d {
   typedef rfsgpu_timing TimingInfo;  // same 14 fields as RBPHDFilter::TimingInfo (:152-167)
 
   // max_particles > n reserves room for particle sets that grow (MH-FastSLAM); 0 = n.
-  explicit RBPHDFilter2d(int n, int device_id = 0, int gm_capacity = 512, int max_particles = 0)
+  explicit RBPHDFilter2d(int n, int device_id = 0, int gm_capacity = 512, int max_particles = 0, int model = RFSGPU_MODEL_RNGBRG_2D)
       : n_(n), nInit_(n), poses_(n), weights_(n, 1.0), rng_(std::rand()) {
-    int rc = rfsgpu_create_ex(&h_, RFSGPU_MODEL_RNGBRG_2D, n, device_id, gm_capacity, max_particles > n ? max_particles : n);
+    int rc = rfsgpu_create_ex(&h_, model, n, device_id, gm_capacity, max_particles > n ? max_particles : n);
     if (rc != RFSGPU_OK) throw std::runtime_error("rfsgpu_create_ex failed with status " + std::to_string(rc) + " (no gfx950 device? there is no CPU fallback)");
     effNParticles_t_ = double(n) / 4.0;  // ParticleFilter.hpp:232
     effNParticles_t_percent_ = effNParticles_t_ / n;
@@ -220,6 +220,19 @@ class RBPHDFilter2d {
     if (rc != RFSGPU_OK) throw std::runtime_error(std::string(what) + ": " + rfsgpu_last_error(h_));
   }
   void pushConfig() {
+    pushFilterConfig();
+    rfsgpu_rngbrg_config m;
+    std::memcpy(m.R, meas_.R, sizeof(m.R));
+    m.probabilityOfDetection = meas_.config.probabilityOfDetection_;
+    m.uniformClutterIntensity = meas_.config.uniformClutterIntensity_;
+    m.rangeLimMax = meas_.config.rangeLimMax_;
+    m.rangeLimMin = meas_.config.rangeLimMin_;
+    m.rangeLimBuffer = meas_.config.rangeLimBuffer_;
+    check(rfsgpu_set_model_rngbrg(h_, &m), "set_model_rngbrg");
+    check(rfsgpu_set_lmk_process_noise(h_, lmk_.Q), "set_lmk_process_noise");
+  }
+  // RBPHDFilter::Config + the Kalman filter's gates: the model-independent part
+  void pushFilterConfig() {
     rfsgpu_filter_config c;
     c.birthGaussianWeight = config.birthGaussianWeight_;
     c.birthGaussianMeasurementCountThreshold = config.birthGaussianMeasurementCountThreshold_;
@@ -237,17 +250,8 @@ class RBPHDFilter2d {
     c.minMeasurementsBeforeResample = config.minMeasurementsBeforeResample_;
     c.useClusterProcess = config.useClusterProcess_ ? 1 : 0;
     check(rfsgpu_set_filter_config(h_, &c), "set_filter_config");
-    rfsgpu_rngbrg_config m;
-    std::memcpy(m.R, meas_.R, sizeof(m.R));
-    m.probabilityOfDetection = meas_.config.probabilityOfDetection_;
-    m.uniformClutterIntensity = meas_.config.uniformClutterIntensity_;
-    m.rangeLimMax = meas_.config.rangeLimMax_;
-    m.rangeLimMin = meas_.config.rangeLimMin_;
-    m.rangeLimBuffer = meas_.config.rangeLimBuffer_;
-    check(rfsgpu_set_model_rngbrg(h_, &m), "set_model_rngbrg");
     rfsgpu_kf_config k{kf_.config.rangeInnovationThreshold_, kf_.config.bearingInnovationThreshold_};
     check(rfsgpu_set_kf_config(h_, &k), "set_kf_config");
-    check(rfsgpu_set_lmk_process_noise(h_, lmk_.Q), "set_lmk_process_noise");
   }
   void pushPoses() {
     if (!posesDirty_) return;
@@ -414,6 +418,140 @@ class FastSLAM2d : public RBPHDFilter2d {
     c.landmarkLockWeight = config.landmarkLockWeight_;
     c.pruningMeasurementsThreshold = config.pruningMeasurementsThreshold_;
     check(rfsgpu_set_fastslam_config(h_, &c), "set_fastslam_config");
+  }
+};
+
+// ---- Victoria Park (reference src/rbphdslam_VictoriaPark.cpp) ----------------------------------------------------------
+struct Measurement3d {      // MeasurementModel_VictoriaPark::TMeasurement: range, bearing, trunk diameter
+  double z[3] = {0, 0, 0};
+  double t = 0;
+};
+struct AckermanInput {      // MotionModel_Ackerman2d::TInput: speed, steering angle (+ their variances for predict's input noise)
+  double u[2] = {0, 0};
+  double var[2] = {0, 0};
+};
+
+// MotionModel_Ackerman2d::step (reference src/ProcessModel_Ackerman2D.cpp:47-78): host-side, 3 doubles per particle.
+class MotionModel_Ackerman2d {
+ public:
+  void setAckermanParams(double h, double l, double dx, double dy) { h_ = h; l_ = l; dx_ = dx; dy_ = dy; }
+  void step(Pose2d &s_k, const Pose2d &s_km, double u_v, double u_r, double dt) const {
+    const double r = s_km.x[2];
+    const double c = std::cos(r), s = std::sin(r), t = std::tan(u_r);
+    const double v = u_v / (1 - t * h_ / l_);
+    s_k = s_km;
+    s_k.x[0] = s_km.x[0] + dt * (v * c - v / l_ * t * (dx_ * s + dy_ * c));
+    s_k.x[1] = s_km.x[1] + dt * (v * s + v / l_ * t * (dx_ * c - dy_ * s));
+    double th = s_km.x[2] + dt * v / l_ * t;
+    if (th > PI_) th -= 2 * PI_;
+    else if (th < -PI_) th += 2 * PI_;
+    s_k.x[2] = th;
+  }
+
+ private:
+  double h_ = 0.76, l_ = 2.83, dx_ = 3.78, dy_ = 0.50;
+  const double PI_ = std::acos(-1.0);
+};
+
+// rfs::RBPHDFilter<MotionModel_Ackerman2d, StaticProcessModel<Landmark3d>, MeasurementModel_VictoriaPark,
+// KalmanFilter_VictoriaPark> over the C ABI (model RFSGPU_MODEL_VICTORIAPARK_3D): the members the reference's Victoria Park
+// driver touches (src/rbphdslam_VictoriaPark.cpp:344-398, 497-583), same names and argument meaning.  The pose, its host RNG
+// and the resampling logic are the base class's.
+class RBPHDFilterVP : public RBPHDFilter2d {
+ public:
+  struct MeasurementModelVP {
+    struct Config {  // MeasurementModel_VictoriaPark::Config (include/MeasurementModel_VictoriaPark.hpp:150-158)
+      std::vector<double> probabilityOfDetection_;
+      double expectedClutterNumber_ = 0, rangeLimMax_ = 0, rangeLimMin_ = 0, bearingLimitMax_ = 0, bearingLimitMin_ = 0, bufferZonePd_ = 0;
+    } config;
+    double R[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Slb = 0;
+    std::vector<double> scan;
+    bool scanDirty = true;
+    void setNoise(const double Rin[9], double SlbIn) { std::memcpy(R, Rin, sizeof(R)); Slb = SlbIn; }
+    void setLaserScan(const std::vector<double> &s) { scan = s; scanDirty = true; }
+  };
+  struct LmkProcessModel3d {
+    double Q[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    void setNoise(const double Qin[9]) { std::memcpy(Q, Qin, sizeof(Q)); }
+  };
+
+  explicit RBPHDFilterVP(int n, int device_id = 0, int gm_capacity = 192) : RBPHDFilter2d(n, device_id, gm_capacity, 0, RFSGPU_MODEL_VICTORIAPARK_3D) {}
+
+  MotionModel_Ackerman2d *getProcessModel() { return &ackerman_; }
+  LmkProcessModel3d *getLmkProcessModel() { return &lmk3_; }
+  MeasurementModelVP *getMeasurementModel() { return &measVP_; }
+
+  // RBPHDFilter::predict(u, dT, useModelNoise = false, useInputNoise, birthGaussianCheck) (:415-442) with
+  // ProcessModel::sample's input-noise branch (include/ProcessModel.hpp:126-150): every particle draws its own input.
+  void predict(const AckermanInput &u, double dT, bool /*useModelNoise*/, bool useInputNoise, bool birthGaussianCheck) {
+    pushConfigVP();
+    pushPoses();
+    check(rfsgpu_predict_map(h_, birthGaussianCheck ? 1 : 0), "predict_map");
+    std::normal_distribution<double> N01(0.0, 1.0);
+    for (int i = 0; i < n_; i++) {
+      double uv = u.u[0], ur = u.u[1];
+      if (useInputNoise) { uv += std::sqrt(u.var[0]) * N01(rng_); ur += std::sqrt(u.var[1]) * N01(rng_); }
+      Pose2d xk;
+      ackerman_.step(xk, poses_[i], uv, ur, dT);
+      poses_[i] = xk;
+    }
+    posesDirty_ = true;
+  }
+
+  // RBPHDFilter::update (:444-541); Z is consumed.
+  void update(std::vector<Measurement3d> &Z) {
+    nUpdatesSinceResample_++;
+    std::vector<Measurement3d> meas;
+    meas.swap(Z);
+    Z.clear();
+    if (meas.empty()) return;  // :450-452
+    nMeasurementsSinceResample_ += (unsigned)meas.size();
+    pushConfigVP();
+    pushPoses();
+    std::vector<double> z(3 * meas.size());
+    for (size_t k = 0; k < meas.size(); k++) std::memcpy(&z[3 * k], meas[k].z, 3 * sizeof(double));
+    check(rfsgpu_update(h_, z.data(), (int)meas.size()), "update");
+    weightsStale_ = true;
+    resampleOccured_ = false;
+    if (nUpdatesSinceResample_ >= (unsigned)config.minUpdatesBeforeResample_ &&
+        nMeasurementsSinceResample_ >= (unsigned)config.minMeasurementsBeforeResample_)
+      resampleOccured_ = resample();
+    if (resampleOccured_) {
+      nUpdatesSinceResample_ = 0;
+      nMeasurementsSinceResample_ = 0;
+    } else {
+      normalizeWeights();
+    }
+  }
+
+  bool getLandmark(int i, int m, double u[3], double S[9], double &w) { return rfsgpu_get_landmark(h_, i, m, u, S, &w) == RFSGPU_OK; }
+
+ private:
+  MotionModel_Ackerman2d ackerman_;
+  LmkProcessModel3d lmk3_;
+  MeasurementModelVP measVP_;
+
+  void pushConfigVP() {
+    pushFilterConfig();
+    rfsgpu_vp_config m;
+    std::memset(&m, 0, sizeof(m));
+    std::memcpy(m.R, measVP_.R, sizeof(m.R));
+    m.Slb = measVP_.Slb;
+    m.nPd = (int)measVP_.config.probabilityOfDetection_.size();
+    if (m.nPd > RFSGPU_VP_MAX_PD) throw std::runtime_error("probabilityOfDetection_ table longer than RFSGPU_VP_MAX_PD");
+    for (int k = 0; k < m.nPd; k++) m.PdTable[k] = measVP_.config.probabilityOfDetection_[k];
+    m.expectedClutterNumber = measVP_.config.expectedClutterNumber_;
+    m.rangeLimMax = measVP_.config.rangeLimMax_;
+    m.rangeLimMin = measVP_.config.rangeLimMin_;
+    m.bearingLimitMax = measVP_.config.bearingLimitMax_;
+    m.bearingLimitMin = measVP_.config.bearingLimitMin_;
+    m.bufferZonePd = measVP_.config.bufferZonePd_;
+    check(rfsgpu_set_model_victoriapark(h_, &m), "set_model_victoriapark");
+    check(rfsgpu_set_lmk_process_noise(h_, lmk3_.Q), "set_lmk_process_noise");
+    if (measVP_.scanDirty && !measVP_.scan.empty()) {
+      check(rfsgpu_set_laser_scan(h_, measVP_.scan.data(), (int)measVP_.scan.size()), "set_laser_scan");
+      measVP_.scanDirty = false;
+    }
   }
 };
 

@@ -23,48 +23,11 @@
 #include <vector>
 
 #include "rbphd_filter.hpp"
+#include "xml_cfg.hpp"
 
 using namespace rfs_amd;
 
 static const double PI = std::acos(-1.0);
-
-// ---- tiny XML reader: flattens <a><b>v</b></a> into {"a.b": "v"}; comments skipped (enough for cfg/*.xml) ----
-static std::map<std::string, std::string> read_xml(const std::string &fn) {
-  std::ifstream in(fn);
-  std::map<std::string, std::string> kv;
-  if (!in) return kv;
-  std::string s((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
-  std::vector<std::string> stack;
-  size_t p = 0;
-  std::string text;
-  while (p < s.size()) {
-    if (s.compare(p, 4, "<!--") == 0) { size_t e = s.find("-->", p); p = (e == std::string::npos) ? s.size() : e + 3; continue; }
-    if (s[p] == '<') {
-      size_t e = s.find('>', p);
-      if (e == std::string::npos) break;
-      std::string tag = s.substr(p + 1, e - p - 1);
-      if (!tag.empty() && tag[0] == '/') {
-        std::string path;
-        for (auto &t : stack) path += (path.empty() ? "" : ".") + t;
-        size_t a = text.find_first_not_of(" \t\r\n"), b = text.find_last_not_of(" \t\r\n");
-        if (a != std::string::npos) kv[path] = text.substr(a, b - a + 1);
-        if (!stack.empty()) stack.pop_back();
-      } else if (!tag.empty() && tag[0] != '?' && tag.back() != '/') {
-        stack.push_back(tag.substr(0, tag.find_first_of(" \t")));
-      }
-      text.clear();
-      p = e + 1;
-    } else {
-      text += s[p++];
-    }
-  }
-  return kv;
-}
-struct Cfg {
-  std::map<std::string, std::string> kv;
-  double d(const std::string &k, double def) const { auto it = kv.find(k); return it == kv.end() ? def : std::atof(it->second.c_str()); }
-  int i(const std::string &k, int def) const { auto it = kv.find(k); return it == kv.end() ? def : std::atoi(it->second.c_str()); }
-};
 
 struct Landmark { double x[2]; };
 
@@ -83,7 +46,7 @@ int main(int argc, char **argv) {
     else if (s == "-d") device = std::atoi(next().c_str());
   }
   Cfg c;
-  if (!cfgFile.empty()) c.kv = read_xml(cfgFile);
+  if (!cfgFile.empty()) c = read_xml_cfg(cfgFile);
   // defaults = shipped cfg/rbphdslam2dSim.xml values
   int kMax = c.i("config.timesteps", 3000);
   const double dT = c.d("config.sec_per_timestep", 0.1);

@@ -1022,3 +1022,55 @@ def test_randomised_differential_run_fastslam():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_fastslam.py"), "40", "2025"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert ", 0 failures" in out.stdout
+
+
+def _vp_cpp(pkg, *args):
+    import os
+    import subprocess
+    pkg.build_mod.build_host()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [pkg.build_mod.SIM_VP, "-c", os.path.join(root, "tests", "golden", "rbphdslam_VictoriaPark_c4.xml"),
+           "-d", os.path.join(root, "tests", "golden", "vp_extract")] + [str(a) for a in args]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-500:]
+    return out.stdout
+
+
+def test_cpp_victoria_park_driver_matches_the_python_loop(pkg, sc, tmp_path):
+    """host/rbphdslam_vp (C++: XML configuration of the reference's cfg/rbphdslam_VictoriaPark_artificialClutter.xml, the
+    dataset's text files, Ackerman model, rfs_amd::RBPHDFilterVP) against rfs_slam_amd.vp_driver on the same 900 messages
+    with the host randomness switched off (no input noise, no artificial clutter: all particles stay identical, nothing
+    depends on a random stream): the best particle's final pose and map must agree."""
+    import os
+    import re
+    n = 16
+    _vp_cpp(pkg, "-n", n, "-e", n / 2.0, "-o", tmp_path, "--no-input-noise", "--no-clutter")
+    rows = [ln.split() for ln in open(os.path.join(tmp_path, "finalMap.dat")) if not ln.startswith("#")]
+    cpp = np.array(rows, dtype=np.float64)
+    pose = np.array(re.search(r"# pose (.*)", open(os.path.join(tmp_path, "finalMap.dat")).read()).group(1).split(), dtype=np.float64)
+    data = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "victoria_park_extract.npz"))
+    P = dict(sc.VP_PARAMS)
+    f = pkg.RBPHDFilter(n, gm_capacity=192, model=pkg.capi.MODEL_VICTORIAPARK_3D)
+    sc.apply_vp_params(f, P, np.full(361, 70.0))
+    run = pkg.vp_driver.VictoriaParkRun(f, data, P, seed=1, var_uv=0.0, var_ur=0.0, added_clutter=0.0).run(n_messages=900)
+    w, wp, mean, cov = f.export_gm(0)
+    assert cpp.shape[0] == len(w) and len(w) > 3
+    np.testing.assert_allclose(pose, run.x[0], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(cpp[:, 0], w, rtol=1e-9)
+    np.testing.assert_allclose(cpp[:, 1:4], mean, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(cpp[:, 4:], np.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], 1), rtol=1e-8, atol=1e-12)
+
+
+def test_cpp_victoria_park_driver_end_to_end(pkg, tmp_path):
+    """The same driver with everything on (input noise, Poisson(3) artificial clutter, resampling), 200 particles: runs the 900
+    messages, resamples, keeps a map, writes the reference's log formats."""
+    import os
+    import re
+    out = _vp_cpp(pkg, "-n", 200, "-s", 3, "-o", tmp_path)
+    m = re.search(r"RESULT lidar=(\d+) resamples=(\d+) best=(\d+) map=(\d+) strong=(\d+)", out)
+    assert m, out[-1500:]
+    lidar, resamples, _, nmap, strong = [int(g) for g in m.groups()]
+    assert lidar > 50 and resamples > 0 and nmap > 3 and strong > 0
+    pose_rows = open(os.path.join(tmp_path, "particlePose.dat")).read().splitlines()
+    assert len(pose_rows) == lidar * 200 and len(pose_rows[0].split()) == 6
+    assert len(open(os.path.join(tmp_path, "landmarkEst.dat")).readline().split()) == 8
