@@ -6,8 +6,8 @@
 // effect of its `it++` on end(): with libstdc++'s circular list that wraps to begin(), so when the LAST candidate is erased
 // while others remain, the survivors are visited again.  Then StaticProcessModel::staticStep, Sigma += Q, on every
 // Gaussian (ProcessModel.hpp:195-208) -- births get Q added where they are created.
-// The candidate logic is a short serial walk per particle: lane 0 of the particle's wave runs it, all lanes do the
-// Sigma += Q sweep.  (The 2-D immediate-birth case keeps its lane-parallel kernel in merge_prune.h.)
+// One wavefront per particle: candidate c sits on lane c, so the support distance of a measurement to all candidates is one
+// lane-parallel evaluation; the walk itself keeps the reference's order.  All lanes do the Sigma += Q sweep.  (The 2-D immediate-birth case keeps its lane-parallel kernel in merge_prune.h.)
 #pragma once
 #include "common.h"
 #include "vp.h"
@@ -140,6 +140,13 @@ __device__ bool birth_append(const Buffers &B, const Params &P, int cur, int i, 
   return true;
 }
 
+// the same without the capacity check / count (the wave-parallel walk keeps n uniform)
+template <int D>
+__device__ void birth_write(const Buffers &B, const Params &P, int cur, int i, int n, const Cand<D> &k) {
+  int nn = n;
+  birth_append<D>(B, P, cur, i, nn, k);
+}
+
 template <int D, int WPB>
 __global__ __launch_bounds__(WPB * 64) void predict_map_general_kernel(Buffers B, Params P, int cur, int addBirth, int nZprev) {
   const int wave = threadIdx.x >> 6;
@@ -148,76 +155,82 @@ __global__ __launch_bounds__(WPB * 64) void predict_map_general_kernel(Buffers B
   if (i >= B.N) return;
   const int cap = B.cap;
   const int nOld = B.count[i];
-  if (lane == 0 && addBirth) {
+  if (addBirth) {
+    // Candidate c of the particle lives on lane c (RFSGPU_MAX_CANDIDATES == 64): loaded once, kept in registers, stored once.
+    // The reference's walk over the unused measurements and over the list stays serial where its order is observable
+    // (first matching candidate in list order, list order kept by erase, the ++end() wrap); what is per candidate --
+    // the support distance of a measurement to every candidate -- runs across the lanes.
     int n = nOld;
     int nc = B.candCount[i];
     const unsigned nfov = (unsigned)B.nInFov[i];
     PoseReg pr;
     load_pose(B, P, i, pr);
     bool fail = false, listFull = false;
+    int *supG = B.candSup + (size_t)i * RFSGPU_MAX_CANDIDATES, *chkG = B.candChk + (size_t)i * RFSGPU_MAX_CANDIDATES;
+    Cand<D> k;
+    for (int t = 0; t < 3; t++) k.x[t] = 0.0;
+    for (int t = 0; t < 6; t++) k.S[t] = 0.0;
+    int sup = 0, chk = 0;
+    if (lane < nc) { cand_load<D>(B, i, lane, k); sup = supG[lane]; chk = chkG[lane]; }
     unsigned long long um = (nZprev > 0) ? B.unusedMask[i] : 0ull;
     while (um) {  // back to front (:1013-1017)
       const int zi = 63 - __builtin_clzll(um);
       um &= ~(1ull << zi);
       const double *z = B.Z + (size_t)D * zi;
-      bool isNew = true;
-      for (int c = 0; c < nc; c++) {
-        Cand<D> k;
-        cand_load<D>(B, i, c, k);
-        const double d2 = cand_support_md2<D>(P, pr, k, z);
-        if (d2 <= P.birthSupportD2) {
-          cand_correct<D>(P, pr, k, z);
-          cand_store<D>(B, i, c, k);
-          B.candSup[(size_t)i * RFSGPU_MAX_CANDIDATES + c]++;
-          isNew = false;
-          break;
-        }
-      }
-      if (isNew) {
-        Cand<D> k;
-        cand_inverse<D>(P, pr, z, k);
+      double d2 = 1.0e300;
+      if (lane < nc) d2 = cand_support_md2<D>(P, pr, k, z);
+      const unsigned long long hit = __ballot(lane < nc && d2 <= P.birthSupportD2);
+      if (hit != 0ull) {                                   // the first candidate in list order that supports it
+        if (lane == __builtin_ctzll(hit)) { cand_correct<D>(P, pr, k, z); sup++; }
+      } else {
+        Cand<D> kn;
+        cand_inverse<D>(P, pr, z, kn);                     // (the same values on every lane)
         if (P.birthCountThr == 1u || nfov <= P.birthCurThr) {
-          if (!birth_append<D>(B, P, cur, i, n, k)) fail = true;
+          if (n < cap) { if (lane == 0) birth_write<D>(B, P, cur, i, n, kn); n++; }
+          else fail = true;
         } else if (nc < RFSGPU_MAX_CANDIDATES) {
-          cand_store<D>(B, i, nc, k);
-          B.candSup[(size_t)i * RFSGPU_MAX_CANDIDATES + nc] = 1;
-          B.candChk[(size_t)i * RFSGPU_MAX_CANDIDATES + nc] = 0;
+          if (lane == nc) { k = kn; sup = 1; chk = 0; }
           nc++;
         } else {
           listFull = true;
         }
       }
     }
-    B.unusedMask[i] = 0ull;
     // promotion / expiry (:1062-1080) with the ++end() wrap
-    int *sup = B.candSup + (size_t)i * RFSGPU_MAX_CANDIDATES, *chk = B.candChk + (size_t)i * RFSGPU_MAX_CANDIDATES;
-    int k = 0;
-    while (k < nc) {
-      chk[k]++;
+    int kk = 0;
+    while (kk < nc) {
+      if (lane == kk) chk++;
       bool atEnd = false;
-      while ((unsigned)sup[k] >= P.birthCountThr || (unsigned)chk[k] > P.birthCheckThr || nfov <= P.birthCurThr) {
-        if ((unsigned)sup[k] >= P.birthCountThr || nfov <= P.birthCurThr) {
-          Cand<D> c;
-          cand_load<D>(B, i, k, c);
-          if (!birth_append<D>(B, P, cur, i, n, c)) fail = true;
+      for (;;) {
+        const unsigned supk = (unsigned)__builtin_amdgcn_readlane(sup, kk), chkk = (unsigned)__builtin_amdgcn_readlane(chk, kk);
+        if (!(supk >= P.birthCountThr || chkk > P.birthCheckThr || nfov <= P.birthCurThr)) break;
+        if (supk >= P.birthCountThr || nfov <= P.birthCurThr) {
+          if (n < cap) { if (lane == kk) birth_write<D>(B, P, cur, i, n, k); n++; }
+          else fail = true;
         }
-        for (int t = k; t + 1 < nc; t++) {  // erase(it): shift the tail down, list order kept
-          Cand<D> c;
-          cand_load<D>(B, i, t + 1, c);
-          cand_store<D>(B, i, t, c);
-          sup[t] = sup[t + 1];
-          chk[t] = chk[t + 1];
+        {  // erase(it): the tail moves down one lane, list order kept
+          const int from = (lane >= kk && lane < 63) ? lane + 1 : lane;
+#pragma unroll
+          for (int t = 0; t < 3; t++) k.x[t] = __shfl(k.x[t], from, 64);
+#pragma unroll
+          for (int t = 0; t < 6; t++) k.S[t] = __shfl(k.S[t], from, 64);
+          sup = __shfl(sup, from, 64);
+          chk = __shfl(chk, from, 64);
         }
         nc--;
-        if (k < nc) chk[k]++;
+        if (kk < nc) { if (lane == kk) chk++; }
         else { atEnd = true; break; }
       }
-      k = atEnd ? 0 : k + 1;
+      kk = atEnd ? 0 : kk + 1;
     }
-    B.candCount[i] = nc;
-    B.count[i] = n;
-    if (fail) atomicOr(B.err, ERRBIT_CAPACITY);
-    if (listFull) atomicOr(B.err, ERRBIT_BIRTHLIST);
+    if (lane < nc) { cand_store<D>(B, i, lane, k); supG[lane] = sup; chkG[lane] = chk; }
+    if (lane == 0) {
+      B.unusedMask[i] = 0ull;
+      B.candCount[i] = nc;
+      B.count[i] = n;
+      if (fail) atomicOr(B.err, ERRBIT_CAPACITY);
+      if (listFull) atomicOr(B.err, ERRBIT_BIRTHLIST);
+    }
   }
   // staticStep on the pre-existing Gaussians
   double *slab = B.slab[cur];

@@ -235,6 +235,15 @@ int main(int argc, char **argv) {
   for (int g = 0; g < nMap; g++) { double mu[3], S[9], w; filter.getLandmark(best, g, mu, S, w); strong += (w >= 0.5) ? 1 : 0; }
   const Pose2d &bp = filter.getParticlePose(best);
   std::printf("particles %d  messages %d  lidar updates %d  resamplings %d  wall %.3f s\n", nParticles, nMsg, nLidar, nResample, wall);
+  RBPHDFilter2d::TimingInfo *ti = filter.getTimingInfo();
+  std::printf("Elapsed Timing Information [nsec]\n");  // format of the reference drivers' timing printout
+  std::printf("%-22s%15s%15s\n", "", "wall", "cpu");
+  std::printf("%-22s%15lld%15lld\n", "Prediction", ti->predict_wall, ti->predict_cpu);
+  std::printf("%-22s%15lld%15lld\n", "Map Update", ti->mapUpdate_wall, ti->mapUpdate_cpu);
+  std::printf("%-22s%15lld%15lld\n", "Weighting", ti->particleWeighting_wall, ti->particleWeighting_cpu);
+  std::printf("%-22s%15lld%15lld\n", "Map Merge", ti->mapMerge_wall, ti->mapMerge_cpu);
+  std::printf("%-22s%15lld%15lld\n", "Map Prune", ti->mapPrune_wall, ti->mapPrune_cpu);
+  std::printf("%-22s%15lld%15lld\n", "Resampling", ti->particleResample_wall, ti->particleResample_cpu);
   std::printf("RESULT lidar=%d resamples=%d best=%d map=%d strong=%d pose=%.6f,%.6f,%.6f ms_per_update=%.4f\n", nLidar, nResample, best, nMap, strong, bp.x[0], bp.x[1],
               bp.x[2], nLidar ? wall * 1e3 / nLidar : 0.0);
   return 0;
