@@ -256,11 +256,14 @@ class RBPHDFilter2d {
   void pushPoses() {
     if (!posesDirty_) return;
     std::vector<double> x(3 * (size_t)n_), P(9 * (size_t)n_);
+    bool anyCov = false;
     for (int i = 0; i < n_; i++) {
       std::memcpy(&x[3 * i], poses_[i].x, 3 * sizeof(double));
       std::memcpy(&P[9 * i], poses_[i].P, 9 * sizeof(double));
+      for (int t = 0; t < 9; t++) anyCov = anyCov || (poses_[i].P[t] != 0.0);
     }
-    check(rfsgpu_set_poses(h_, x.data(), P.data(), 9), "set_poses");
+    // (all-zero covariances -- setParticlePose'd poses, the Ackerman model -- cross as "no covariance": 24 B per particle)
+    check(rfsgpu_set_poses(h_, x.data(), anyCov ? P.data() : nullptr, anyCov ? 9 : 0), "set_poses");
     posesDirty_ = false;
   }
   void pullWeights() {
