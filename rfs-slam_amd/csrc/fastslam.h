@@ -444,77 +444,86 @@ __device__ inline bool fs_append(const Buffers &B, int cur, int i, int &n, const
   return true;
 }
 
-// New landmarks from the measurements no landmark took (:615-690): one thread per particle.
+// New landmarks from the measurements no landmark took (:615-690): one wavefront per particle, landmark candidate c on lane c
+// (as in birth.h: the support distance of a measurement to all candidates is one lane-parallel evaluation, the walk keeps the
+// reference's order -- measurements in index order, first supporting candidate in list order, the promotion loop once per
+// unassociated measurement with its ++end() wrap).
+#define FS_NEWLM_WPB 4
 template <int D>
-__global__ __launch_bounds__(64) void fs_new_landmarks_kernel(Buffers B, Params P, FsParams F, int cur, int nZ) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(64 * FS_NEWLM_WPB) void fs_new_landmarks_kernel(Buffers B, Params P, FsParams F, int cur, int nZ) {
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * FS_NEWLM_WPB + wave);
   if (i >= B.N) return;
   int n = B.count[i];
   int nc = B.candCount[i];
+  const int cap = B.cap;
   const unsigned nfov = (unsigned)B.nInFov[i];
   PoseReg pr;
   load_pose(B, P, i, pr);
   bool fail = false, listFull = false;
-  int *sup = B.candSup + (size_t)i * RFSGPU_MAX_CANDIDATES, *chk = B.candChk + (size_t)i * RFSGPU_MAX_CANDIDATES;
+  int *supG = B.candSup + (size_t)i * RFSGPU_MAX_CANDIDATES, *chkG = B.candChk + (size_t)i * RFSGPU_MAX_CANDIDATES;
+  Cand<D> k;
+  for (int t = 0; t < 3; t++) k.x[t] = 0.0;
+  for (int t = 0; t < 6; t++) k.S[t] = 0.0;
+  int sup = 0, chk = 0;
+  if (lane < nc) { cand_load<D>(B, i, lane, k); sup = supG[lane]; chk = chkG[lane]; }
   const unsigned long long um = B.unusedMask[i];
   for (int zi = 0; zi < nZ; zi++) {  // measurements in index order (:615)
     if (!((um >> zi) & 1ull)) continue;
     const double *z = B.Z + (size_t)D * zi;
-    bool isNew = true;
-    for (int c = 0; c < nc; c++) {
-      Cand<D> k;
-      cand_load<D>(B, i, c, k);
-      const double d2 = cand_support_md2<D>(P, pr, k, z);
-      if (d2 <= F.supportD2) {
-        cand_correct<D>(P, pr, k, z);
-        cand_store<D>(B, i, c, k);
-        sup[c]++;
-        isNew = false;
-        break;
-      }
-    }
-    if (isNew) {
-      Cand<D> k;
-      cand_inverse<D>(P, pr, z, k);
+    double d2 = 1.0e300;
+    if (lane < nc) d2 = cand_support_md2<D>(P, pr, k, z);
+    const unsigned long long hit = __ballot(lane < nc && d2 <= F.supportD2);
+    if (hit != 0ull) {
+      if (lane == __builtin_ctzll(hit)) { cand_correct<D>(P, pr, k, z); sup++; }
+    } else {
+      Cand<D> kn;
+      cand_inverse<D>(P, pr, z, kn);
       if (F.countThr == 1u || nfov <= F.curThr) {
-        if (!fs_append<D>(B, cur, i, n, k, F.newW)) fail = true;
+        if (n < cap) { if (lane == 0) { int nn = n; fs_append<D>(B, cur, i, nn, kn, F.newW); } n++; }
+        else fail = true;
       } else if (nc < RFSGPU_MAX_CANDIDATES) {
-        cand_store<D>(B, i, nc, k);
-        sup[nc] = 1;
-        chk[nc] = 0;
+        if (lane == nc) { k = kn; sup = 1; chk = 0; }
         nc++;
       } else {
         listFull = true;
       }
     }
     // the promotion loop runs once per unassociated measurement (:656-688), with the ++end() wrap of libstdc++'s list
-    int k = 0;
-    while (k < nc) {
-      chk[k]++;
+    int kk = 0;
+    while (kk < nc) {
+      if (lane == kk) chk++;
       bool atEnd = false;
-      while ((unsigned)sup[k] >= F.countThr || (unsigned)chk[k] > F.checkThr || nfov <= F.curThr) {
-        if ((unsigned)sup[k] >= F.countThr || nfov <= F.curThr) {
-          Cand<D> c;
-          cand_load<D>(B, i, k, c);
-          if (!fs_append<D>(B, cur, i, n, c, F.newW * chk[k])) fail = true;
+      for (;;) {
+        const unsigned supk = (unsigned)__builtin_amdgcn_readlane(sup, kk), chkk = (unsigned)__builtin_amdgcn_readlane(chk, kk);
+        if (!(supk >= F.countThr || chkk > F.checkThr || nfov <= F.curThr)) break;
+        if (supk >= F.countThr || nfov <= F.curThr) {
+          if (n < cap) { if (lane == kk) { int nn = n; fs_append<D>(B, cur, i, nn, k, F.newW * chk); } n++; }
+          else fail = true;
         }
-        for (int t = k; t + 1 < nc; t++) {  // erase(it): shift the tail down, list order kept
-          Cand<D> c;
-          cand_load<D>(B, i, t + 1, c);
-          cand_store<D>(B, i, t, c);
-          sup[t] = sup[t + 1];
-          chk[t] = chk[t + 1];
+        {  // erase(it): the tail moves down one lane, list order kept
+          const int from = (lane >= kk && lane < 63) ? lane + 1 : lane;
+#pragma unroll
+          for (int t = 0; t < 3; t++) k.x[t] = __shfl(k.x[t], from, 64);
+#pragma unroll
+          for (int t = 0; t < 6; t++) k.S[t] = __shfl(k.S[t], from, 64);
+          sup = __shfl(sup, from, 64);
+          chk = __shfl(chk, from, 64);
         }
         nc--;
-        if (k < nc) chk[k]++;
+        if (kk < nc) { if (lane == kk) chk++; }
         else { atEnd = true; break; }
       }
-      k = atEnd ? 0 : k + 1;
+      kk = atEnd ? 0 : kk + 1;
     }
   }
-  B.unusedMask[i] = 0ull;
-  B.candCount[i] = nc;
-  B.count[i] = n;
-  if (fail) atomicOr(B.err, ERRBIT_CAPACITY);
-  if (listFull) atomicOr(B.err, ERRBIT_BIRTHLIST);
+  if (lane < nc) { cand_store<D>(B, i, lane, k); supG[lane] = sup; chkG[lane] = chk; }
+  if (lane == 0) {
+    B.unusedMask[i] = 0ull;
+    B.candCount[i] = nc;
+    B.count[i] = n;
+    if (fail) atomicOr(B.err, ERRBIT_CAPACITY);
+    if (listFull) atomicOr(B.err, ERRBIT_BIRTHLIST);
+  }
 }

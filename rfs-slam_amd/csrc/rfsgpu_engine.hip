@@ -1175,8 +1175,8 @@ static int fastslam_map_management(rfsgpu_filter *f, const FsParams &F, int n_z)
     HIPCHK(hipGetLastError());
     f->cur ^= 1;
   }
-  if (f->D == 2) fs_new_landmarks_kernel<2><<<(f->N + 63) / 64, 64, 0, f->stream>>>(f->B, f->P, F, f->cur, n_z);
-  else fs_new_landmarks_kernel<3><<<(f->N + 63) / 64, 64, 0, f->stream>>>(f->B, f->P, F, f->cur, n_z);
+  if (f->D == 2) fs_new_landmarks_kernel<2><<<(f->N + FS_NEWLM_WPB - 1) / FS_NEWLM_WPB, 64 * FS_NEWLM_WPB, 0, f->stream>>>(f->B, f->P, F, f->cur, n_z);
+  else fs_new_landmarks_kernel<3><<<(f->N + FS_NEWLM_WPB - 1) / FS_NEWLM_WPB, 64 * FS_NEWLM_WPB, 0, f->stream>>>(f->B, f->P, F, f->cur, n_z);
   HIPCHK(hipGetLastError());
   return RFSGPU_OK;
 }
