@@ -140,6 +140,75 @@ __device__ double vp_pd(const Params &P, const double *scan, int nScan, double p
   return mx;
 }
 
+// The same for the 64 landmarks of a wave at once.  The number of shifted copies differs wildly between landmarks (a fresh,
+// thin, far landmark: 3 sigma of lateral uncertainty over twice its diameter -- dozens; an established one: one), so a lane
+// looping over its own copies leaves the wave waiting for its worst landmark.  Here the (landmark, copy) evaluations of all
+// lanes are laid end to end and dealt out to the lanes; minimum and maximum (exact in any order: the values come from the
+// Pd table) are folded with LDS atomics on the bit patterns (the values are >= 0).  `ws`: VP_PD_SCRATCH_BYTES of LDS per wave.
+#define VP_PD_SCRATCH_BYTES (64 * (5 * 8 + 2 * 8) + 65 * 4 + 4)
+__device__ double vp_pd_wave(const Params &P, const double *scan, int nScan, double px, double py, double pth, const Ent3 &e, bool act, bool &close,
+                             unsigned char *ws) {
+  const int lane = threadIdx.x & 63;
+  double *lx = reinterpret_cast<double *>(ws), *ly = lx + 64, *ld = ly + 64, *lp0 = ld + 64, *lp1 = lp0 + 64;
+  unsigned long long *lmn = reinterpret_cast<unsigned long long *>(lp1 + 64), *lmx = lmn + 64;
+  int *pre = reinterpret_cast<int *>(lmx + 64);
+  VPMeas o;
+  vp_measure(P, px, py, pth, e.x, e.y, e.d, 0.0, 0.0, 0.0, 0.0, o);
+  const double angle = atan2(o.z1, o.z0) + pth;  // sic (:165-166)
+  const double p0 = -sin(angle), p1 = cos(angle);
+  const double r0 = p0 * e.xx + p1 * e.xy, r1 = p0 * e.xy + p1 * e.yy;
+  double sd = r0 * p0 + r1 * p1;
+  sd = 3 * sqrt(sd);
+  sd = fmax(sd, 0.2);
+  // n = how many i = 1, 2, ... satisfy (i - 1) * (2 d) < sd, the loop condition evaluated as the reference writes it
+  int n = 0;
+  if (act) {
+    const double step = 2 * e.d;
+    if (!(step > 0)) {
+      n = ((0.0 * step) < sd) ? 100000 : 0;               // non-positive diameter: the reference never terminates
+    } else {
+      double g = floor(sd / step);
+      if (g > 100000.0) g = 100000.0;
+      n = (int)g;                                          // near ceil(sd / step): settle it with the exact condition
+      while (n > 0 && !((n - 1) * step < sd)) n--;
+      while (n < 100000 && (n * step < sd)) n++;
+    }
+  }
+  lx[lane] = e.x; ly[lane] = e.y; ld[lane] = e.d; lp0[lane] = p0; lp1[lane] = p1;
+  lmn[lane] = 0x7ff0000000000000ull;                       // +inf
+  lmx[lane] = 0ull;                                        // pd >= 0
+  const int cnt = 2 * n;
+  const int off = wave_excl_scan(cnt, lane);
+  const int total = __builtin_amdgcn_readlane(off + cnt, 63);
+  pre[lane] = off;
+  if (lane == 63) pre[64] = total;
+  wave_sync();
+  for (int t = lane; t < total; t += 64) {
+    int l = 0;                                             // owner: the last landmark whose block starts at or before t
+#pragma unroll
+    for (int st = 32; st >= 1; st >>= 1) l += (pre[l + st] <= t) ? st : 0;
+    const int j = t - pre[l];
+    const int i = (j >> 1) + 1;
+    const double dd = ld[l];
+    const double sh = i * 2 * dd;
+    const double sg = (j & 1) ? -1.0 : 1.0;
+    bool c2;
+    const double p = (j & 1) ? vp_pd2(P, scan, nScan, px, py, pth, lx[l] - sh * lp0[l], ly[l] - sh * lp1[l], dd, c2)
+                             : vp_pd2(P, scan, nScan, px, py, pth, lx[l] + sh * lp0[l], ly[l] + sh * lp1[l], dd, c2);
+    (void)sg;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(p);
+    atomicMin(&lmn[l], bits);
+    atomicMax(&lmx[l], bits);
+  }
+  wave_sync();
+  double mn = __longlong_as_double((long long)lmn[lane]), mx = __longlong_as_double((long long)lmx[lane]);
+  const double p = vp_pd2(P, scan, nScan, px, py, pth, e.x, e.y, e.d, close);   // the unshifted landmark last: `close` is its verdict
+  mn = fmin(mn, p); mx = fmax(mx, p);
+  if (mn == 0 && mx > 0) close = true;
+  wave_sync();                                             // (the scratch is reused by the next pass)
+  return mx;
+}
+
 // Landmark-level quantities of KalmanFilter::correct for the 3-D model.
 struct LmKF3 {
   double zx0, zx1, zx2;
@@ -206,7 +275,7 @@ __device__ __forceinline__ double vp_value(const Params &P, const LmKF3 &k, doub
 }
 
 // LDS per wave: survivor list (value, packed (m,z)) + per-landmark segment + stored Pd + final normalisers.
-__host__ __device__ inline size_t vp_update_lds_bytes_per_wave(int cap) { return (size_t)cap * (8 + 4 + 4 + 8) + RFSGPU_MAX_Z * 8; }
+__host__ __device__ inline size_t vp_update_lds_bytes_per_wave(int cap) { return (((size_t)cap * (8 + 4 + 4 + 8) + RFSGPU_MAX_Z * 8 + VP_PD_SCRATCH_BYTES) + 15) & ~(size_t)15; }
 
 // RBPHDFilter::updateMap for the Victoria Park model (same phases as phd_update_map_kernel).
 template <int WPB>
@@ -250,7 +319,8 @@ __global__ __launch_bounds__(WPB * 64) void vp_update_map_kernel(Buffers B, Para
     e.w = 0; e.x = 10; e.y = 10; e.d = 1; e.xx = 1; e.xy = 0; e.xd = 0; e.yy = 1; e.yd = 0; e.dd = 1;
     if (act) load_ent3(slab, cap, i, m, e, true);
     bool close = false;
-    double pd = act ? vp_pd(P, sScan, B.nScan, px, py, pth, e, close) : 0.0;
+    double pd = vp_pd_wave(P, sScan, B.nScan, px, py, pth, e, act, close, reinterpret_cast<unsigned char *>(sSeg + cap));
+    if (!act) { pd = 0.0; close = false; }
     if (close) pd = 1;  // RBPHDFilter.hpp:604-606
     const bool fov = act && (pd != 0);
     const double pdw = pd * e.w;
