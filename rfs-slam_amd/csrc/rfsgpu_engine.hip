@@ -642,7 +642,7 @@ static int launch_weighting(rfsgpu_filter *f) {
   const int src = f->cur, dst = f->cur ^ 1;
   int rc;  // (the Murty job counter was cleared by stage_step_kernel)
   if (f->D == 3) {
-    const size_t b = (size_t)(3 * RFSGPU_MAX_Z + RFSGPU_VP_MAX_SCAN) * 8 + 2 * (per + (size_t)ec * 16 * 8);
+    const size_t b = (size_t)(3 * RFSGPU_MAX_Z + RFSGPU_VP_MAX_SCAN) * 8 + 2 * vp_weight_lds_bytes_per_wave(f->cap, ec, nZ);
     if ((rc = set_lds(f, vp_weighting_kernel<2>, b)) != RFSGPU_OK) return rc;
     vp_weighting_kernel<2><<<(f->N + 1) / 2, 128, b, f->stream>>>(f->B, f->P, src, dst, nZ, ec, f->Q);
     HIPCHK(hipGetLastError());

@@ -436,6 +436,9 @@ __global__ __launch_bounds__(WPB * 64) void vp_update_map_kernel(Buffers B, Para
 }
 
 // RBPHDFilter::importanceWeighting for the Victoria Park model (same steps as phd_weight_multifeature_kernel).
+__host__ __device__ inline size_t vp_weight_lds_bytes_per_wave(int cap, int evalCap, int nZ) {
+  return (weight_lds_bytes_per_wave(cap, evalCap, nZ) + (size_t)evalCap * 16 * 8 + VP_PD_SCRATCH_BYTES + 15) & ~(size_t)15;
+}
 template <int WPB>
 __global__ __launch_bounds__(WPB * 64) void vp_weighting_kernel(Buffers B, Params P, int src, int dst, int nZ, int evalCap, MurtyQueue Q) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -451,11 +454,10 @@ __global__ __launch_bounds__(WPB * 64) void vp_weighting_kernel(Buffers B, Param
   const int cap = B.cap;
   WeightLDS s;
   // evX/evY hold x,y; the diameter of the evaluation points goes into evZ's spare slot via a separate array below
-  carve_weight_lds(smem_raw + (3 * RFSGPU_MAX_Z + RFSGPU_VP_MAX_SCAN) * 8 + (size_t)wave * (weight_lds_bytes_per_wave(cap, evalCap, nZ) + (size_t)evalCap * 16 * 8),
-                   cap, evalCap, nZ, s);
-  double *evD = reinterpret_cast<double *>(smem_raw + (3 * RFSGPU_MAX_Z + RFSGPU_VP_MAX_SCAN) * 8 +
-                                           (size_t)wave * (weight_lds_bytes_per_wave(cap, evalCap, nZ) + (size_t)evalCap * 16 * 8) +
-                                           weight_lds_bytes_per_wave(cap, evalCap, nZ));  // [evalCap][16]: d, z_exp(3), Si(9), factor
+  unsigned char *wbase = smem_raw + (3 * RFSGPU_MAX_Z + RFSGPU_VP_MAX_SCAN) * 8 + (size_t)wave * vp_weight_lds_bytes_per_wave(cap, evalCap, nZ);
+  carve_weight_lds(wbase, cap, evalCap, nZ, s);
+  double *evD = reinterpret_cast<double *>(wbase + weight_lds_bytes_per_wave(cap, evalCap, nZ));  // [evalCap][16]: d, z_exp(3), Si(9), factor
+  unsigned char *pdScratch = wbase + weight_lds_bytes_per_wave(cap, evalCap, nZ) + (size_t)evalCap * 16 * 8;          // vp_pd_wave
   const int N = B.count[i];
   const double *sl = B.slab[src];
   double *dl = B.slab[dst];
@@ -496,15 +498,18 @@ __global__ __launch_bounds__(WPB * 64) void vp_weighting_kernel(Buffers B, Param
       bool below = true, cand = false;
       Ent3 e;
       double pd = 0;
+      e.w = 0; e.x = 10; e.y = 10; e.d = 1; e.xx = 1; e.xy = 0; e.xd = 0; e.yy = 1; e.yd = 0; e.dd = 1;
       if (r < N) {
         const int m = s.perm[r];
         below = s.keys[m] < P.evalMinW;
         load_ent3(sl, cap, i, m, e, false);
-        if (!below) {
-          bool close;
-          pd = vp_pd(P, sScan, B.nScan, px, py, pth, e, close);
-          cand = pd > 0;
-        }
+      }
+      {
+        bool close;
+        const bool want = (r < N) && !below;
+        pd = vp_pd_wave(P, sScan, B.nScan, px, py, pth, e, want, close, pdScratch);
+        if (!want) pd = 0;
+        cand = pd > 0;
       }
       const unsigned long long belowMask = __ballot(below);
       const unsigned long long valid = belowMask ? ((1ull << __builtin_ctzll(belowMask)) - 1ull) : ~0ull;
