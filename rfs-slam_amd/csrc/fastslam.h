@@ -80,7 +80,7 @@ struct FsRow {
 };
 template <int D>
 __device__ __forceinline__ void fs_row(const Buffers &B, const Params &P, const PoseReg &pr, const double *slab, int cap, int i, int m, bool act,
-                                       FsRow<D> &r) {
+                                       FsRow<D> &r, unsigned char *pdScratch = nullptr) {  // pdScratch: VP_PD_SCRATCH_BYTES of the wave's LDS (D == 3)
   if (D == 2) {
     double mx = 0, my = 0, sxx = 1, sxy = 0, syy = 1;
     if (act) {
@@ -99,7 +99,9 @@ __device__ __forceinline__ void fs_row(const Buffers &B, const Params &P, const 
     e.w = 0; e.x = 10; e.y = 10; e.d = 1; e.xx = 1; e.xy = 0; e.xd = 0; e.yy = 1; e.yd = 0; e.dd = 1;
     if (act) load_ent3(slab, cap, i, m, e, false);
     r.valid = true;  // MeasurementModel_VictoriaPark::measure always returns true
-    r.pd = vp_pd(P, B.scan, B.nScan, pr.x, pr.y, pr.th, e, r.close);
+    // all 64 lanes call this together: the shifted-copy evaluations are shared out over the wave (vp.h)
+    r.pd = vp_pd_wave(P, B.scan, B.nScan, pr.x, pr.y, pr.th, e, act, r.close, pdScratch);
+    if (!act) { r.pd = 0.0; r.close = false; }
     lm_precompute3(P, pr.x, pr.y, pr.th, e, r.k3);
     r.factor = r.k3.factor;
     r.lf = log(r.factor);
@@ -187,6 +189,7 @@ __device__ __forceinline__ double fs_existence_step(const FsParams &F, double w,
 template <int WPB, int D>
 __global__ __launch_bounds__(WPB * 64) void fs_associate_update_kernel(Buffers B, Params P, FsParams F, int cur, int nZ, unsigned char *arena) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
+  __shared__ __align__(16) unsigned char sPdScratch[WPB][(D == 3) ? ((VP_PD_SCRATCH_BYTES + 15) & ~15) : 16];
   double *sZ = reinterpret_cast<double *>(smem_raw);
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(WPB * 64) void fs_associate_update_kernel(Buffers B
     const int m = c0 + lane;
     const bool act = m < nM;
     FsRow<D> row;
-    fs_row<D>(B, P, pr, slab, cap, i, m, act, row);
+    fs_row<D>(B, P, pr, slab, cap, i, m, act, row, sPdScratch[wave]);
     const double pd = row.pd;
     const bool inR = act && (pd != 0 || row.close);  // :446
     unsigned long long cells = 0;

@@ -110,6 +110,7 @@ __global__ __launch_bounds__(64) void fs_mh_associate_kernel(Buffers B, Params P
                                                            unsigned char *arena) {
   __shared__ double sZ[3 * RFSGPU_MAX_Z];
   __shared__ unsigned char sQueue[2 * FSMH_N];
+  __shared__ __align__(16) unsigned char sPdScratch[(D == 3) ? ((VP_PD_SCRATCH_BYTES + 15) & ~15) : 16];
   __shared__ double sTile[FSMH_LDS_N * FSMH_LDS_N];
   const int lane = threadIdx.x;
   const int i = blockIdx.x;
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(64) void fs_mh_associate_kernel(Buffers B, Params P
   for (int c0 = 0; c0 < nM; c0 += 64) {
     const int m = c0 + lane;
     FsRow<D> row;
-    fs_row<D>(B, P, pr, slab, cap, i, m, m < nM, row);
+    fs_row<D>(B, P, pr, slab, cap, i, m, m < nM, row, sPdScratch);
     nIn += __popcll(__ballot((m < nM) && (row.pd != 0 || row.close)));
   }
   const int nMZ = nIn > nZ ? nIn : nZ;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(64) void fs_mh_associate_kernel(Buffers B, Params P
     const int m = c0 + lane;
     const bool act = m < nM;
     FsRow<D> row;
-    fs_row<D>(B, P, pr, slab, cap, i, m, act, row);
+    fs_row<D>(B, P, pr, slab, cap, i, m, act, row, sPdScratch);
     const bool inR = act && (row.pd != 0 || row.close);
     const unsigned long long im = __ballot(inR);
     if (inR) {
