@@ -115,32 +115,10 @@ __device__ double vp_pd2(const Params &P, const double *scan, int nScan, double 
   if (P.PdTable[numPoints] == 0) close = false;
   return P.PdTable[numPoints];
 }
-// probabilityOfDetection(): :153-199 (max over laterally shifted copies; `angle` formed as the reference writes it).
-__device__ double vp_pd(const Params &P, const double *scan, int nScan, double px, double py, double pth, const Ent3 &e, bool &close) {
-  VPMeas o;
-  vp_measure(P, px, py, pth, e.x, e.y, e.d, 0.0, 0.0, 0.0, 0.0, o);
-  const double angle = atan2(o.z1, o.z0) + pth;  // sic (:165-166)
-  const double p0 = -sin(angle), p1 = cos(angle);
-  const double r0 = p0 * e.xx + p1 * e.xy, r1 = p0 * e.xy + p1 * e.yy;
-  double sd = r0 * p0 + r1 * p1;
-  sd = 3 * sqrt(sd);
-  sd = fmax(sd, 0.2);
-  double mn = 1.7976931348623157e308, mx = -1.7976931348623157e308;
-  for (int i = 1; (i - 1) * (2 * e.d) < sd; i++) {
-    if (i > 100000) break;  // non-positive diameter: the reference never terminates
-    const double s = i * 2 * e.d;
-    double p = vp_pd2(P, scan, nScan, px, py, pth, e.x + s * p0, e.y + s * p1, e.d, close);
-    mn = fmin(mn, p); mx = fmax(mx, p);
-    p = vp_pd2(P, scan, nScan, px, py, pth, e.x - s * p0, e.y - s * p1, e.d, close);
-    mn = fmin(mn, p); mx = fmax(mx, p);
-  }
-  const double p = vp_pd2(P, scan, nScan, px, py, pth, e.x, e.y, e.d, close);
-  mn = fmin(mn, p); mx = fmax(mx, p);
-  if (mn == 0 && mx > 0) close = true;
-  return mx;
-}
-
-// The same for the 64 landmarks of a wave at once.  The number of shifted copies differs wildly between landmarks (a fresh,
+// probabilityOfDetection(): :153-199 -- the maximum of probabilityOfDetection2 over the landmark and its copies shifted
+// sideways by i * 2 * diameter, i = 1, 2, ... while (i - 1) * 2 * diameter < max(3 sigma_perp, 0.2); `angle` formed as the
+// reference writes it; closeToLimit = (min == 0 && max > 0), else what the last call (the unshifted landmark) left.
+// Evaluated for the 64 landmarks of a wave at once.  The number of shifted copies differs wildly between landmarks (a fresh,
 // thin, far landmark: 3 sigma of lateral uncertainty over twice its diameter -- dozens; an established one: one), so a lane
 // looping over its own copies leaves the wave waiting for its worst landmark.  Here the (landmark, copy) evaluations of all
 // lanes are laid end to end and dealt out to the lanes; minimum and maximum (exact in any order: the values come from the
