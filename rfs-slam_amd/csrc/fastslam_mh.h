@@ -10,8 +10,9 @@
 // enumeration (murty.h: the same Hungarian method, node pool and heap discipline as the oracle's restatement) on it.
 // nMZ = max(landmarks in range, measurements) <= 64 (MURTY_N); beyond that the update refuses loudly.
 //
-//  fs_mh_associate   one wavefront per particle: lanes build the table rows, reduce it (row / column counters on lanes) and
-//                    run Murty with the wave-parallel Hungarian solver of hungarian_wave.h.
+//  fs_mh_associate   one workgroup of two wavefronts per particle: wave 0's lanes build the table rows and reduce it (row /
+//                    column counters on lanes); Murty runs in murty.h's block form (children of an expansion shared out
+//                    over the waves, the wave-parallel Hungarian solver of hungarian_wave.h inside).
 //                    Leaves per particle: the in-range list, the table, nH and the nH assignments (HBM).
 //  (host)            slots of the copies, in particle order: pi[h] = nParticles_ - h after each particle's copies (:543-556)
 //  fs_mh_copy        one workgroup per new slot: the source particle's map, counters, pose, weight / nH (+ candidates when
@@ -24,7 +25,8 @@
 #define FSMH_N MURTY_N          // max table dimension
 #define FSMH_MAX_HYP 16         // max config.maxNDataAssocHypotheses_ handled
 #define FSMH_NODES (1 + FSMH_MAX_HYP * FSMH_N)
-#define FSMH_LDS_N 48           // Murty sub-problems up to this dimension are solved in an LDS tile (18 KB: 8 wavefronts per CU)
+#define FSMH_LDS_N 32           // Murty sub-problems up to this dimension are solved in an LDS tile (8 KB per wave)
+#define FSMH_WAVES 2            // wavefronts per particle in fs_mh_associate: the children of a Murty expansion are shared out
 
 // Per-particle HBM block: table T, reduced table Cr, Murty's arena, and the results.
 struct FsMhLayout {
@@ -35,7 +37,7 @@ __host__ __device__ inline FsMhLayout fs_mh_layout() {
   size_t o = 0;
   L.offT = o; o += (size_t)FSMH_N * FSMH_N * 8;
   L.offCr = o; o += (size_t)FSMH_N * FSMH_N * 8;
-  L.offCt = o; o += (size_t)FSMH_N * FSMH_N * 8;
+  L.offCt = o; o += (size_t)FSMH_WAVES * FSMH_N * FSMH_N * 8;   // one per wave of the particle's workgroup
   L.offWork = o; o += (size_t)3 * FSMH_N * 8 + 6 * FSMH_N * 4 + 8 * FSMH_N;   // lx ly slack | xy yx p queue | flags
   o = (o + 7) & ~(size_t)7;
   L.offNodeScore = o; o += (size_t)FSMH_NODES * 8;
@@ -75,156 +77,173 @@ __device__ inline void fs_mh_carve(unsigned char *base, const FsMhLayout &L, Mur
   A.nodeA = base + L.offNodeA;
 }
 
-// Murty::findNextBest driven like FastSLAM.hpp:506-541: up to kmax assignments of the n x n table C (maximisation), stopping
-// at the first whose score is maxDiff or more below the best.  out[h * FSMH_N + row] = column.  Returns nH (uniform).
-// (src/MurtyAlgorithm.cpp:137-320 with realAssign_n{R,C}_ == n, i.e. no setRealAssignmentBlock: murty.h's wave-per-problem
-// pieces with the dummy-range rule switched off.)
-__device__ __forceinline__ int fs_mh_kbest(double *C, int n, int kmax, double maxDiff, MurtyArena &A, unsigned char *out, unsigned char *queue,
-                                           double *ldsTile, long long *prof = nullptr) {
-  const int lane = threadIdx.x & 63;
-  int nNodes = 0, heapLen = 0;
-  int a0;
-  double best;
-  if (!murty_root_wave(C, n, A, a0, best, queue)) return 0;  // rank -1 on the first call: no hypothesis (:511-515)
-  if (lane < n) out[lane] = (unsigned char)a0;
-  nNodes = 1;
-  heapLen = 1;
-  if (0.0 >= maxDiff) return 0;  // best - best >= maxDiff (only with maxDiff <= 0)
-  int nH = 1;
-  while (nH < kmax) {
-    if (heapLen == 0) break;  // rank == -1
-    if (!murty_expand_wave<FSMH_LDS_N>(C, n, n - 1, n, FSMH_NODES, A, nNodes, heapLen, queue, ldsTile, prof)) return -1;
-    if (heapLen == 0) break;
-    int top;
-    const double s = murty_top_wave(A, top);
-    if (best - s >= maxDiff) break;  // :520-523
-    if (lane < n) out[nH * FSMH_N + lane] = A.nodeA[(size_t)top * FSMH_N + lane];
-    nH++;
-  }
-  return nH;
-}
-
 // errBits: ERRBIT_MURTY when the table is larger than FSMH_N or Murty runs out of nodes.
 template <int D>
-__global__ __launch_bounds__(64) void fs_mh_associate_kernel(Buffers B, Params P, FsParams F, int cur, int nZ, int kmax, double maxDiff,
-                                                           unsigned char *arena) {
+__global__ __launch_bounds__(64 * FSMH_WAVES) __attribute__((amdgpu_waves_per_eu(D == 2 ? 4 : 3)))   // 2-D: <= 128 VGPRs, 8 workgroups per CU, 2048 particles at once
+void fs_mh_associate_kernel(Buffers B, Params P, FsParams F, int cur, int nZ, int kmax, double maxDiff,
+                                                                        unsigned char *arena) {
   __shared__ double sZ[3 * RFSGPU_MAX_Z];
-  __shared__ unsigned char sQueue[2 * FSMH_N];
   __shared__ __align__(16) unsigned char sPdScratch[(D == 3) ? ((VP_PD_SCRATCH_BYTES + 15) & ~15) : 16];
-  __shared__ double sTile[FSMH_LDS_N * FSMH_LDS_N];
-  const int lane = threadIdx.x;
+  __shared__ double sTile[FSMH_WAVES][FSMH_LDS_N * FSMH_LDS_N];
+  __shared__ double sScore[FSMH_N];
+  __shared__ double sBest;
+  __shared__ int sCtl[8], sNRed, sNH;
+  __shared__ unsigned char sPushed[FSMH_N];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int i = blockIdx.x;
-  for (int t = lane; t < D * nZ; t += 64) sZ[t] = B.Z[t];
-  wave_sync();
+  for (int t = threadIdx.x; t < D * nZ; t += 64 * FSMH_WAVES) sZ[t] = B.Z[t];
+  if (threadIdx.x == 0) { sNRed = 0; sNH = 0; }
+  __syncthreads();
+#ifdef RFS_PROFILE
+  long long *fd = B.dbg ? B.dbg + 64 + 4 * (size_t)B.N + 4 * (size_t)blockIdx.x : nullptr;
+  if (fd && threadIdx.x == 0) fd[0] = (long long)wall_clock64();
+#endif
   const FsMhLayout L = fs_mh_layout();
   unsigned char *base = arena + (size_t)i * L.total;
   double *T = (double *)(base + L.offT);
   unsigned short *gIdx = (unsigned short *)(base + L.offIdx);
   double *gPd = (double *)(base + L.offPd);
   int *hdr = (int *)(base + L.offHdr);
-  const int cap = B.cap;
-  const int nM = B.count[i];
-  const double *slab = B.slab[cur];
-  PoseReg pr;
-  load_pose(B, P, i, pr);
-  const double lim = F.minLog;
-  const unsigned long long lt = (1ull << lane) - 1ull;
-
-  // in-range count first (the table dimension is needed before rows can be written)
-  int nIn = 0;
-  for (int c0 = 0; c0 < nM; c0 += 64) {
-    const int m = c0 + lane;
-    FsRow<D> row;
-    fs_row<D>(B, P, pr, slab, cap, i, m, m < nM, row, sPdScratch);
-    nIn += __popcll(__ballot((m < nM) && (row.pd != 0 || row.close)));
-  }
-  const int nMZ = nIn > nZ ? nIn : nZ;
-  if (nMZ > FSMH_N) {
-    if (lane == 0) { atomicOr(B.err, ERRBIT_MURTY); hdr[0] = 0; hdr[1] = 0; hdr[2] = 0; }
-    return;
-  }
-  for (int t = lane; t < nMZ * nMZ; t += 64) T[t] = lim;  // :458-465
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  wave_sync();
-  int k0 = 0;
-  for (int c0 = 0; c0 < nM; c0 += 64) {
-    const int m = c0 + lane;
-    const bool act = m < nM;
-    FsRow<D> row;
-    fs_row<D>(B, P, pr, slab, cap, i, m, act, row, sPdScratch);
-    const bool inR = act && (row.pd != 0 || row.close);
-    const unsigned long long im = __ballot(inR);
-    if (inR) {
-      const int k = k0 + __popcll(im & lt);
-      gIdx[k] = (unsigned short)m;
-      gPd[k] = row.pd;
-      if (row.valid)
-        for (int z = 0; z < nZ; z++) T[k * nMZ + z] = fs_cell_d<D>(row, sZ + D * z, lim);  // :468-481
-    }
-    k0 += __popcll(im);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  wave_sync();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
-  // ---- CostMatrix::reduce (src/CostMatrix.cpp:263-340) ----
-  // Row x's counters on lane x, column y's on lane y.  The serial scan fixes (x, y) exactly when y is row x's only match and
-  // x is column y's only match (a pair seen while either count is already 2 is never fixed, and one fixed early is undone
-  // by the final count checks), so counts + the single match index decide it.
+  double *Cr = (double *)(base + L.offCr);
+  unsigned char *outR = base + L.offRes;
   short *da = (short *)(base + L.offDa);
-  const bool inT = lane < nMZ;
-  int nMatchI = 0, nMatchJ = 0, yStar = 0, xStar = 0;
-  for (int x = 0; x < nMZ; x++) {
-    const unsigned long long mk = __ballot(inT && T[x * nMZ + lane] > lim);
-    if (lane == x) { nMatchI = __popcll(mk); yStar = mk ? __builtin_ctzll(mk) : 0; }
-    if ((mk >> lane) & 1ull) { if (nMatchJ == 0) xStar = x; nMatchJ++; }
-  }
-  const int nJatStar = __shfl(nMatchJ, yStar, 64), nIatStar = __shfl(nMatchI, xStar, 64);
-  int aFixed = (inT && nMatchI == 1 && nJatStar == 1) ? yStar : -1;
-  const int aRev = (inT && nMatchJ == 1 && nIatStar == 1) ? xStar : -1;
-  const unsigned long long redI = __ballot(inT && aFixed == -1), redJ = __ballot(inT && aRev == -1);
-  int nRed = __popcll(redI);
-  const int iRed = murty_kth_bit(redI, lane), jRed = murty_kth_bit(redJ, lane);     // meaningful on lanes < nRed
-  if (nRed == 1) {                                                              // a 1 x 1 remainder is assigned (:325-331)
-    if (lane == __builtin_ctzll(redI)) aFixed = __builtin_ctzll(redJ);
-    nRed = 0;
-  }
-  int nH = 0;
-  if (nRed == 0) {  // :498-505
-    if (lane < nIn) da[lane] = (short)aFixed;
-    nH = 1;
-  } else {
-    double *Cr = (double *)(base + L.offCr);
-    for (int x = 0; x < nRed; x++) {
-      const int ix = __builtin_amdgcn_readlane(iRed, x);
-      if (lane < nRed) Cr[x * nRed + lane] = T[ix * nMZ + jRed];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  // wave 0's state across the Murty stage
+  int nIn = 0, nMZ = 0, aFixed = -1, jRed = 0, nRed = 0;
+  unsigned long long redI = 0;
+  bool tooBig = false;
+
+  if (wave == 0) {   // table, CostMatrix::reduce: one wave
+    const int cap = B.cap;
+    const int nM = B.count[i];
+    const double *slab = B.slab[cur];
+    PoseReg pr;
+    load_pose(B, P, i, pr);
+    const double lim = F.minLog;
+    // in-range count first (the table dimension is needed before rows can be written)
+    for (int c0 = 0; c0 < nM; c0 += 64) {
+      const int m = c0 + lane;
+      FsRow<D> row;
+      fs_row<D>(B, P, pr, slab, cap, i, m, m < nM, row, sPdScratch);
+      nIn += __popcll(__ballot((m < nM) && (row.pd != 0 || row.close)));
     }
+    nMZ = nIn > nZ ? nIn : nZ;
+    tooBig = nMZ > FSMH_N;
+    if (!tooBig) {
+      for (int t = lane; t < nMZ * nMZ; t += 64) T[t] = lim;  // :458-465
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      wave_sync();
+      int k0 = 0;
+      for (int c0 = 0; c0 < nM; c0 += 64) {
+        const int m = c0 + lane;
+        const bool act = m < nM;
+        FsRow<D> row;
+        fs_row<D>(B, P, pr, slab, cap, i, m, act, row, sPdScratch);
+        const bool inR = act && (row.pd != 0 || row.close);
+        const unsigned long long im = __ballot(inR);
+        if (inR) {
+          const int k = k0 + __popcll(im & lt);
+          gIdx[k] = (unsigned short)m;
+          gPd[k] = row.pd;
+          if (row.valid)
+            for (int z = 0; z < nZ; z++) T[k * nMZ + z] = fs_cell_d<D>(row, sZ + D * z, lim);  // :468-481
+        }
+        k0 += __popcll(im);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      wave_sync();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+      // ---- CostMatrix::reduce (src/CostMatrix.cpp:263-340) ----
+      // Row x's counters on lane x, column y's on lane y.  The serial scan fixes (x, y) exactly when y is row x's only match
+      // and x is column y's only match (a pair seen while either count is already 2 is never fixed, and one fixed early is
+      // undone by the final count checks), so counts + the single match index decide it.
+      const bool inT = lane < nMZ;
+      int nMatchI = 0, nMatchJ = 0, yStar = 0, xStar = 0;
+      for (int x = 0; x < nMZ; x++) {
+        const unsigned long long mk = __ballot(inT && T[x * nMZ + lane] > lim);
+        if (lane == x) { nMatchI = __popcll(mk); yStar = mk ? __builtin_ctzll(mk) : 0; }
+        if ((mk >> lane) & 1ull) { if (nMatchJ == 0) xStar = x; nMatchJ++; }
+      }
+      const int nJatStar = __shfl(nMatchJ, yStar, 64), nIatStar = __shfl(nMatchI, xStar, 64);
+      aFixed = (inT && nMatchI == 1 && nJatStar == 1) ? yStar : -1;
+      const int aRev = (inT && nMatchJ == 1 && nIatStar == 1) ? xStar : -1;
+      redI = __ballot(inT && aFixed == -1);
+      const unsigned long long redJ = __ballot(inT && aRev == -1);
+      nRed = __popcll(redI);
+      const int iRed = murty_kth_bit(redI, lane);     // meaningful on lanes < nRed
+      jRed = murty_kth_bit(redJ, lane);
+      if (nRed == 1) {                                                              // a 1 x 1 remainder is assigned (:325-331)
+        if (lane == __builtin_ctzll(redI)) aFixed = __builtin_ctzll(redJ);
+        nRed = 0;
+      }
+      if (nRed > 0) {
+        for (int x = 0; x < nRed; x++) {
+          const int ix = __builtin_amdgcn_readlane(iRed, x);
+          if (lane < nRed) Cr[x * nRed + lane] = T[ix * nMZ + jRed];
+        }
+        if (lane == 0) sNRed = nRed;
+      }
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+#ifdef RFS_PROFILE
+  if (fd && threadIdx.x == 0) fd[1] = (long long)wall_clock64();
+#endif
+
+  // ---- Murty's k best assignments of the reduced table (FastSLAM.hpp:506-541; src/MurtyAlgorithm.cpp:137-320 with
+  //      realAssign_n{R,C}_ == n, i.e. no setRealAssignmentBlock): the whole workgroup, murty.h's block form ----
+  const int nRedS = __builtin_amdgcn_readfirstlane(sNRed);
+  bool okM = true;
+  if (nRedS > 0) {
     MurtyArena A;
     fs_mh_carve(base, L, A);
-    unsigned char *outR = base + L.offRes;
-#ifdef RFS_PROFILE
-    long long prof[9] = {(long long)__builtin_readcyclecounter(), 0, 0, nRed, 0, 0, 0, 0, 0};
-    nH = fs_mh_kbest(Cr, nRed, kmax, maxDiff, A, outR, sQueue, sTile, prof);
-    if (B.dbg && lane == 0) {
-      long long *o = B.dbg + 64 + 4 * (size_t)i;
-      o[0] = (long long)__builtin_readcyclecounter() - prof[0]; o[1] = prof[1]; o[2] = prof[2]; o[3] = prof[3];
-      if (i == 7) printf("particle 7: children %lld dims %lld main-loop steps %lld bfs iterations %lld label updates %lld; solver cycles %lld of which main loop %lld\n",
-                         prof[2], prof[7], prof[4], prof[5], prof[6], prof[1], prof[8]);
-    }
-#else
-    nH = fs_mh_kbest(Cr, nRed, kmax, maxDiff, A, outR, sQueue, sTile);
-#endif
-    if (nH < 0) { if (lane == 0) atomicOr(B.err, ERRBIT_MURTY); nH = 0; }
-    const int myRedRow = __popcll(redI & lt);                                   // reduced row of table row `lane`
-    for (int h = 0; h < nH; h++) {  // :525-540
-      const int res = (lane < nRed) ? outR[h * FSMH_N + lane] : 0;              // own store in fs_mh_kbest
-      const int z_o = __shfl(jRed, res, 64);
-      const int val = (z_o < nZ) ? z_o : -2;
-      const int mine = __shfl(val, myRedRow, 64);
-      if (lane < nIn) da[h * FSMH_N + lane] = (short)((aFixed != -1) ? aFixed : mine);
-    }
+    murty_kbest_block<FSMH_WAVES, FSMH_LDS_N>(
+        Cr, nRedS, nRedS - 1, nRedS, FSMH_NODES, kmax, A, okM, sTile[wave], sCtl, sScore, sPushed, wave,
+        [&](double s) {                                     // the best assignment (:506-518)
+          sBest = s;
+          if (0.0 >= maxDiff) return true;                  // (best - best >= maxDiff: only with maxDiff <= 0)
+          for (int r = 0; r < nRedS; r++) outR[r] = A.nodeA[r];
+          sNH = 1;
+          return false;
+        },
+        [&](double st, int top) {                           // the next one, while it is within maxDiff of the best (:520-540)
+          if (sBest - st >= maxDiff) return true;
+          const int h = sNH;
+          for (int r = 0; r < nRedS; r++) outR[h * FSMH_N + r] = A.nodeA[(size_t)top * FSMH_N + r];
+          sNH = h + 1;
+          return false;
+        });
   }
-  if (lane == 0) { hdr[0] = nIn; hdr[1] = nMZ; hdr[2] = nH; }
+  __threadfence_block();
+  __syncthreads();
+#ifdef RFS_PROFILE
+  if (fd && threadIdx.x == 0) { fd[2] = (long long)wall_clock64(); fd[3] = sNRed; }
+#endif
+
+  if (wave == 0) {
+    int nH = 0;
+    if (tooBig) {
+      if (lane == 0) atomicOr(B.err, ERRBIT_MURTY);
+      nIn = 0; nMZ = 0;
+    } else if (nRed == 0) {  // :498-505
+      if (lane < nIn) da[lane] = (short)aFixed;
+      nH = 1;
+    } else {
+      nH = __builtin_amdgcn_readfirstlane(sNH);
+      if (!okM) { if (lane == 0) atomicOr(B.err, ERRBIT_MURTY); nH = 0; }
+      const int myRedRow = __popcll(redI & lt);                                   // reduced row of table row `lane`
+      for (int h = 0; h < nH; h++) {  // :525-540
+        const int res = (lane < nRed) ? outR[h * FSMH_N + lane] : 0;
+        const int z_o = __shfl(jRed, res, 64);
+        const int val = (z_o < nZ) ? z_o : -2;
+        const int mine = __shfl(val, myRedRow, 64);
+        if (lane < nIn) da[h * FSMH_N + lane] = (short)((aFixed != -1) ? aFixed : mine);
+      }
+    }
+    if (lane == 0) { hdr[0] = nIn; hdr[1] = nMZ; hdr[2] = nH; }
+  }
 }
 
 // One workgroup per NEW slot: ParticleFilter::copyParticle (ParticleFilter.hpp:273-294) of slot src -> slot dst.

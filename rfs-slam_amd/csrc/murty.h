@@ -278,68 +278,6 @@ __device__ __forceinline__ bool murty_child_wave(double *Ct, const double *C, in
   return okH;
 }
 
-// Murty::findNextBest's expansion step (:160-330): pop the best node, create its children for the partitions
-// parent_partition .. partitionMax-1, push the feasible ones.  Sub-problems up to LDSN wide are solved in the LDS tile (two
-// inlined solver instances so that the LDS one compiles to ds_read / ds_write).  False when the node pool is exhausted.
-template <int LDSN>
-__device__ __forceinline__ bool murty_expand_wave(const double *C, int n, int partitionMax, int realNC, int maxNodes, MurtyArena &A,
-                                                  int &nNodes, int &heapLen, unsigned char *queue, double *ldsTile, long long *prof) {
-  const int lane = threadIdx.x & 63;
-  murty_publish();
-  int parent = 0, parent_partition = 0;
-  if (lane == 0) {
-    int hl = heapLen;
-    parent = heap_pop(A.heap, hl, A.nodeScore);
-    parent_partition = A.nodeId[parent];
-  }
-  heapLen--;
-  parent = __builtin_amdgcn_readfirstlane(parent);
-  parent_partition = __builtin_amdgcn_readfirstlane(parent_partition);
-  const int aPar = (lane < n) ? A.nodeA[(size_t)parent * MURTY_N + lane] : 0;          // own earlier store
-  const double termPar = (lane < n) ? C[lane * n + aPar] : 0.0;
-  double fixedScore = 0;
-  for (int r = 0; r < parent_partition; r++) fixedScore += readlane_f64(termPar, r);
-  unsigned long long usedCols = wave_or_u64((lane < parent_partition) ? (1ull << aPar) : 0ull);
-  for (int nn = parent_partition; nn < partitionMax; nn++) {
-    if (nn > parent_partition) {  // rows 0..nn-1 fixed to the parent's choice
-      fixedScore += readlane_f64(termPar, nn - 1);
-      usedCols |= 1ull << __builtin_amdgcn_readlane(aPar, nn - 1);
-    }
-    if (nNodes >= maxNodes) return false;
-    const int pn = nNodes++;
-    const unsigned long long freeCols = ((n >= 64) ? ~0ull : ((1ull << n) - 1ull)) & ~usedCols;
-    const int nFree = n - nn;
-    const int colRemap = (lane < nFree) ? murty_kth_bit(freeCols, lane) : 0;     // reduced column `lane` -> column of C
-    if (lane == 0) { A.nodeId[pn] = (unsigned char)nn; A.nodeParent[pn] = (short)parent; }
-    bool pushed = false;
-    double sAcc = 0;
-    int aNew = aPar;
-    {
-      int aTmp = 0;
-      const bool okH = (nFree <= LDSN)
-                           ? murty_child_wave<LDSN>(ldsTile, C, n, nn, nFree, pn, parent, colRemap, freeCols, realNC, A, aTmp, queue, prof)
-                           : murty_child_wave<MURTY_N>(A.Ct, C, n, nn, nFree, pn, parent, colRemap, freeCols, realNC, A, aTmp, queue, prof);
-      if (okH) {
-        const int ja = __shfl((lane < nFree) ? colRemap : 0, (lane < nFree) ? aTmp : 0, 64);
-        const double term = (lane < nFree) ? C[(nn + lane) * n + ja] : 0.0;
-        for (int r = 0; r < nFree; r++) sAcc += readlane_f64(term, r);
-        sAcc += fixedScore;
-        const int jaShift = __shfl(ja, (lane >= nn) ? lane - nn : 0, 64);
-        if (lane >= nn) aNew = jaShift;
-        pushed = true;
-      }
-    }
-    if (lane < n) A.nodeA[(size_t)pn * MURTY_N + lane] = (unsigned char)aNew;
-    if (pushed && lane == 0) {
-      A.nodeScore[pn] = sAcc;
-      int hl = heapLen;
-      heap_push(A.heap, hl, (short)pn, A.nodeScore);
-    }
-    if (pushed) heapLen++;
-    murty_publish();
-  }
-  return true;
-}
 // root: the solver on the full table (:147-158); node 0.  False when there is no assignment.
 __device__ __forceinline__ bool murty_root_wave(double *C, int n, MurtyArena &A, int &a0, double &s, unsigned char *queue) {
   const int lane = threadIdx.x & 63;
@@ -352,55 +290,45 @@ __device__ __forceinline__ bool murty_root_wave(double *C, int n, MurtyArena &A,
     int hl = 0;
     heap_push(A.heap, hl, 0, A.nodeScore);
   }
+  murty_publish();   // node 0's assignment is read back lane-crossed (the caller's policies, the first expansion)
   return true;
 }
-// score of the heap's top (uniform); top = its node
-__device__ __forceinline__ double murty_top_wave(MurtyArena &A, int &top) {
-  const int lane = threadIdx.x & 63;
-  int t = 0;
-  double s = 0;
-  if (lane == 0) { t = A.heap[0]; s = A.nodeScore[t]; }
-  top = __builtin_amdgcn_readfirstlane(t);
-  return readlane_f64(s, 0);
-}
-
 #define MURTY_LDS_N 32   // sub-problems up to this dimension are solved in an 8 KB LDS tile
 
 // One partition: sum of exp(score) over the <= 200 best assignments (RBPHDFilter.hpp:948-959).
-// One partition, one WORKGROUP of W wavefronts: the same enumeration with the children of an expansion -- independent
-// sub-problems -- shared out among the waves (child c of the popped node to wave c mod W, each in its own LDS tile); wave 0
-// pops, and after a barrier pushes the children in partition order and takes the next score, exactly as the one-wave
-// form does.  ctl: [0] parent [1] its partition [2] nodes so far [3] heap length [4] stop [5] ok.
-template <int W>
-__device__ __forceinline__ double murty_partition_sum_block(double *C, int n, int nR, int nC, MurtyArena &A, bool &ok, double *myTile, int *ctl,
-                                                            double *sSum, double *sScore, unsigned char *sPushed, const int wave) {
-  const double BIG_NEG = -1000.0;
+// Murty's ranked enumeration by one WORKGROUP of W wavefronts: the children of an expansion -- independent sub-problems --
+// are shared out among the waves (child c of the popped node to wave c mod W, each in its own LDS tile of LDSN x LDSN);
+// wave 0 pops, and after a barrier pushes the children in partition order and looks at the next score, exactly as the
+// one-wave form does.  What happens with the scores is the caller's: onRoot(score) and onTop(score, node) run on wave 0's
+// lane 0 and return true to stop (onTop is called for the 2nd, 3rd, ... best, at most maxK - 1 times).
+// ctl: [0] parent [1] its partition [2] nodes so far [3] heap length [4] stop [5] ok.
+template <int W, int LDSN, class FRoot, class FTop>
+__device__ __forceinline__ void murty_kbest_block(double *C, int n, int partitionMax, int realNC, int maxNodes, int maxK, MurtyArena &A, bool &ok,
+                                                  double *myTile, int *ctl, double *sScore, unsigned char *sPushed, const int wave, FRoot onRoot,
+                                                  FTop onTop) {
   const int lane = threadIdx.x & 63;
-  const int realNR = nR > n ? n : nR, realNC = nC > n ? n : nC;
-  const int partitionMax = (realNR == n) ? n - 1 : realNR;
-  if (wave == 0) {
-    int a0;
-    double s = 0;
-    const bool okr = murty_root_wave(C, n, A, a0, s, nullptr);
-    if (lane == 0) {
-      const bool go = okr && !(s < BIG_NEG);
-      ctl[2] = 1; ctl[3] = okr ? 1 : 0; ctl[4] = go ? 0 : 1; ctl[5] = okr ? 1 : 0;
-      *sSum = go ? exp(s) : 0.0;
-    }
-  }
-  __threadfence_block();
-  __syncthreads();
-  // (values read back from LDS are wave-uniform, but only readfirstlane tells the compiler so: without it the whole search
-  //  would be compiled as divergent control flow)
 #ifdef RFS_PROFILE
-  long long tp[4] = {0, 0, 0, 0};
+  long long tp[5] = {0, 0, 0, 0, 0};
   long long tq = (long long)__builtin_readcyclecounter();
 #define MB_STAMP(i) do { const long long tn = (long long)__builtin_readcyclecounter(); tp[i] += tn - tq; tq = tn; } while (0)
 #else
 #define MB_STAMP(i) do { } while (0)
 #endif
-  for (int k = 1; k < MURTY_KBEST && __builtin_amdgcn_readfirstlane(ctl[4]) == 0; k++) {
-    MB_STAMP(3);
+  if (wave == 0) {
+    int a0;
+    double s = 0;
+    const bool okr = murty_root_wave(C, n, A, a0, s, nullptr);
+    if (lane == 0) {
+      ctl[2] = 1; ctl[3] = okr ? 1 : 0; ctl[5] = okr ? 1 : 0;
+      ctl[4] = (!okr || onRoot(s)) ? 1 : 0;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  MB_STAMP(4);
+  // (values read back from LDS are wave-uniform, but only readfirstlane tells the compiler so: without it the whole search
+  //  would be compiled as divergent control flow)
+  for (int k = 1; k < maxK && __builtin_amdgcn_readfirstlane(ctl[4]) == 0; k++) {
     if (wave == 0 && lane == 0) {
       int hl = ctl[3];
       const int parent = heap_pop(A.heap, hl, A.nodeScore);
@@ -411,7 +339,7 @@ __device__ __forceinline__ double murty_partition_sum_block(double *C, int n, in
     MB_STAMP(0);
     const int parent = __builtin_amdgcn_readfirstlane(ctl[0]), pp = __builtin_amdgcn_readfirstlane(ctl[1]), nNodes = __builtin_amdgcn_readfirstlane(ctl[2]);
     const int cnt = partitionMax - pp;
-    const bool poolFull = cnt > 0 && nNodes + cnt > MURTY_MAX_NODES;
+    const bool poolFull = cnt > 0 && nNodes + cnt > maxNodes;
     if (!poolFull && cnt > 0) {
       const int aPar = (lane < n) ? A.nodeA[(size_t)parent * MURTY_N + lane] : 0;
       const double termPar = (lane < n) ? C[lane * n + aPar] : 0.0;
@@ -427,8 +355,8 @@ __device__ __forceinline__ double murty_partition_sum_block(double *C, int n, in
         bool pushed = false;
         double sAcc = 0;
         int aNew = aPar, aTmp = 0;
-        const bool okH = (nFree <= MURTY_LDS_N)
-                             ? murty_child_wave<MURTY_LDS_N>(myTile, C, n, nn, nFree, pn, parent, colRemap, freeCols, realNC, A, aTmp, nullptr, nullptr)
+        const bool okH = (nFree <= LDSN)
+                             ? murty_child_wave<LDSN>(myTile, C, n, nn, nFree, pn, parent, colRemap, freeCols, realNC, A, aTmp, nullptr, nullptr)
                              : murty_child_wave<MURTY_N>(A.Ct + (size_t)wave * MURTY_N * MURTY_N, C, n, nn, nFree, pn, parent, colRemap, freeCols, realNC, A, aTmp, nullptr, nullptr);
         if (okH) {
           const int ja = __shfl((lane < nFree) ? colRemap : 0, (lane < nFree) ? aTmp : 0, 64);
@@ -446,6 +374,7 @@ __device__ __forceinline__ double murty_partition_sum_block(double *C, int n, in
     MB_STAMP(1);
     __threadfence_block();
     __syncthreads();
+    MB_STAMP(3);
     if (wave == 0 && lane == 0) {
       int stop = 0;
       if (poolFull) {
@@ -462,9 +391,8 @@ __device__ __forceinline__ double murty_partition_sum_block(double *C, int n, in
         ctl[3] = hl;
         if (hl == 0) stop = 1;  // rank == -1
         else {
-          const double st = A.nodeScore[A.heap[0]];
-          if (st < BIG_NEG) stop = 1;
-          else *sSum += exp(st);
+          const int top = A.heap[0];
+          if (onTop(A.nodeScore[top], top)) stop = 1;
         }
       }
       ctl[4] = stop;
@@ -474,9 +402,23 @@ __device__ __forceinline__ double murty_partition_sum_block(double *C, int n, in
     MB_STAMP(2);
   }
 #ifdef RFS_PROFILE
-  if (wave == 0 && lane == 0 && (blockIdx.x & 255) == 0) printf("murty block job: n %d nodes %d; cycles pop+barrier %lld, children %lld, push+top+barriers %lld, loop head %lld\n", n, ctl[2], tp[0], tp[1], tp[2], tp[3]);
+  if (lane == 0 && (blockIdx.x & 255) == 7) printf("murty block %d wave %d: n %d nodes %d; cycles root %lld, pop+barrier %lld, own children %lld, wait for the other waves %lld, push+top+barrier %lld\n", (int)blockIdx.x, wave, n, ctl[2], tp[4], tp[0], tp[1], tp[3], tp[2]);
 #endif
   ok = __builtin_amdgcn_readfirstlane(ctl[5]) != 0;
+}
+
+// One partition: sum of exp(score) over the <= 200 best assignments (RBPHDFilter.hpp:948-959).
+template <int W>
+__device__ __forceinline__ double murty_partition_sum_block(double *C, int n, int nR, int nC, MurtyArena &A, bool &ok, double *myTile, int *ctl,
+                                                            double *sSum, double *sScore, unsigned char *sPushed, const int wave) {
+  const double BIG_NEG = -1000.0;
+  const int realNR = nR > n ? n : nR, realNC = nC > n ? n : nC;
+  const int partitionMax = (realNR == n) ? n - 1 : realNR;
+  if (threadIdx.x == 0) *sSum = 0.0;
+  murty_kbest_block<W, MURTY_LDS_N>(
+      C, n, partitionMax, realNC, MURTY_MAX_NODES, MURTY_KBEST, A, ok, myTile, ctl, sScore, sPushed, wave,
+      [&](double s) { if (s < BIG_NEG) return true; *sSum = exp(s); return false; },
+      [&](double st, int) { if (st < BIG_NEG) return true; *sSum += exp(st); return false; });
   return *sSum;
 }
 

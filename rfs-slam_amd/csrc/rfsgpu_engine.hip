@@ -1193,8 +1193,8 @@ static int fastslam_update_mh(rfsgpu_filter *f, const double *z, int n_z) {
   const FsParams F = fs_params(f, n_z);
   const int N0 = f->N, kmax = (int)f->fs.maxNDataAssocHypotheses;
   HIPCHK(hipEventRecord(f->ev[EV_UM0], f->stream));
-  if (f->D == 2) fs_mh_associate_kernel<2><<<N0, 64, 0, f->stream>>>(f->B, f->P, F, f->cur, n_z, kmax, f->fs.maxDataAssocLogLikelihoodDiff, f->mhArena);
-  else fs_mh_associate_kernel<3><<<N0, 64, 0, f->stream>>>(f->B, f->P, F, f->cur, n_z, kmax, f->fs.maxDataAssocLogLikelihoodDiff, f->mhArena);
+  if (f->D == 2) fs_mh_associate_kernel<2><<<N0, 64 * FSMH_WAVES, 0, f->stream>>>(f->B, f->P, F, f->cur, n_z, kmax, f->fs.maxDataAssocLogLikelihoodDiff, f->mhArena);
+  else fs_mh_associate_kernel<3><<<N0, 64 * FSMH_WAVES, 0, f->stream>>>(f->B, f->P, F, f->cur, n_z, kmax, f->fs.maxDataAssocLogLikelihoodDiff, f->mhArena);
   HIPCHK(hipGetLastError());
   std::vector<int> nH(N0);
   HIPCHK(hipMemcpy2DAsync(nH.data(), sizeof(int), f->mhArena + L.offHdr + 2 * sizeof(int), L.total, sizeof(int), N0, hipMemcpyDeviceToHost, f->stream));
