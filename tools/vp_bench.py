@@ -9,6 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package
 pkg = load_package()
+if os.environ.get("RFS_LIB"):
+    pkg.engine.LIB = os.environ["RFS_LIB"]      # a tools/variant_bench.py --build variant
 sc = pkg.scenarios
 N, NM, NZ = [int(os.environ.get(k, d)) for k, d in (("VP_N", 5000), ("VP_NM", 40), ("VP_NZ", 12))]
 scen = sc.make_vp_scenario(N, NM, NZ, seed=4321, scan="ragged")
