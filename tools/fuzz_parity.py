@@ -16,7 +16,51 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 murty = 0
+n_vp = 0
+
+
+def vp_case(case):
+    """Victoria Park model: 3-D landmarks, scan-based Pd with uncertain / thin landmarks (many shifted copies), birth candidates."""
+    global bad, n_vp
+    n = int(rng.integers(3, 10))
+    kw = dict(n_particles=n, n_landmarks=int(rng.choice([3, 20, 63, 64, 65, 90])), n_z=int(rng.integers(1, 20)), seed=int(rng.integers(1 << 30)),
+              scan=str(rng.choice(["const", "ragged"])))
+    scen = sc.make_vp_scenario(**kw)
+    if rng.random() < 0.5:      # thin, uncertain landmarks: dozens of laterally shifted copies in the Pd evaluation
+        scen["mean"][:, ::3, 2] = rng.uniform(0.03, 0.15)
+        scen["cov"][:, ::3, 0, 0] *= rng.uniform(20, 400)
+        scen["cov"][:, ::3, 1, 1] *= rng.uniform(20, 400)
+    dev = pkg.RBPHDFilter(n, gm_capacity=256, model=pkg.capi.MODEL_VICTORIAPARK_3D)
+    orc = ob.OracleFilter(n, stable_sort=True, model=pkg.capi.MODEL_VICTORIAPARK_3D)
+    try:
+        for f in (dev, orc):
+            sc.load_scenario(f, scen)
+        for cyc in range(3):
+            Z = scen["Z"] + 1e-3 * cyc
+            for f in (dev, orc):
+                f.predict_map(True)
+                f.update(Z)
+            wd, wo = dev.get_weights(), orc.get_weights()
+            np.testing.assert_allclose(wd / wd.sum(), wo / wo.sum(), rtol=1e-9, atol=1e-300)
+            assert np.array_equal(dev.gm_sizes(), orc.gm_sizes())
+            for i in range(n):
+                sc.assert_gm_close(dev.export_gm(i), orc.export_gm(i), 1e-10, 1e-12)
+                md, cd, sd, kd = dev.export_birth_candidates(i)
+                mo, co, so, ko = orc.export_birth_candidates(i)
+                assert list(sd) == list(so) and list(kd) == list(ko), i
+            for f in (dev, orc):
+                s = f.weight_sums(); f.normalize_weights(s[0])
+        n_vp += 1
+    except Exception as e:  # noqa: BLE001
+        bad += 1
+        print("VP CASE", case, kw, "->", type(e).__name__, str(e)[:300], flush=True)
+    dev.close()
+
+
 for case in range(n_cases):
+    if rng.random() < 0.25:
+        vp_case(case)
+        continue
     n = int(rng.integers(3, 12))
     nlm = int(rng.choice([1, 5, 40, 63, 64, 65, 127, 128, 129, 200, 257, 330]))
     nz = int(rng.integers(1, 25))
@@ -61,5 +105,5 @@ for case in range(n_cases):
         dev.close()
     if fused == 0 and "weighting_md" in kw:
         murty += orc.murty_calls()
-print("fuzz: %d cases x 2 paths, %d failures (Murty problems solved along the way: %d)" % (n_cases, bad, murty))
+print("fuzz: %d cases (2-D ones on both paths; %d Victoria Park ones), %d failures (Murty problems solved along the way: %d)" % (n_cases, n_vp, bad, murty))
 sys.exit(1 if bad else 0)
