@@ -173,6 +173,10 @@ int rfsgpu_set_model_victoriapark(rfsgpu_filter *f, const rfsgpu_vp_config *cfg)
 /* MeasurementModel_VictoriaPark::setLaserScan (src/MeasurementModel_VictoriaPark.cpp:267-281): the raw scan used by the
  * occlusion-based Pd and by the clutter intensity (expected clutter / field-of-view area); n <= RFSGPU_VP_MAX_SCAN. */
 int rfsgpu_set_laser_scan(rfsgpu_filter *f, const double *scan, int n);
+/* Probe for tests: MeasurementModel_VictoriaPark::probabilityOfDetection (src/MeasurementModel_VictoriaPark.cpp:153-199) of the
+ * first max_n Gaussians of particle `slot` under the current pose and scan, as the kernels evaluate it: Pd and the
+ * isCloseToSensingLimit flag. */
+int rfsgpu_vp_probe_pd(rfsgpu_filter *f, int slot, double *pd, int *close_to_limit, int max_n);
 /* getLmkProcessModel()->setNoise(Q) (include/ProcessModel.hpp:195-208); Q is d_m x d_m. */
 int rfsgpu_set_lmk_process_noise(rfsgpu_filter *f, const double *Q);
 

@@ -1967,6 +1967,22 @@ void rfsor_vp_measure(void *f, const double *pose3, const double *lx3, const dou
   memcpy(H9, H.a, sizeof(H.a));
 }
 double rfsor_vp_clutter(void *f) { return FVP_(f)->model.clutter(); }
+/* mirror of rfsgpu_vp_probe_pd: Pd / near-limit flag of the first max_n Gaussians of particle `slot` */
+int rfsor_vp_probe_pd(void *f, int slot, double *pd, int *close_to_limit, int max_n) {
+  auto *F = FVP_(f);
+  if (!F || slot < 0 || slot >= F->n) return RFSGPU_ERR_INVALID;
+  const int n = std::min(max_n, F->gm_size(slot));
+  std::vector<double> w(n), wp(n), mean(3 * (size_t)n), cov(9 * (size_t)n);
+  F->export_gm(slot, n, w.data(), wp.data(), mean.data(), cov.data());
+  for (int m = 0; m < n; m++) {
+    orc::M3 S;
+    memcpy(S.a, &cov[9 * (size_t)m], sizeof(S.a));
+    bool close;
+    pd[m] = F->model.pd(F->pose[slot], &mean[3 * (size_t)m], S, close);
+    close_to_limit[m] = close ? 1 : 0;
+  }
+  return RFSGPU_OK;
+}
 
 /* PermutationLexicographic restatement, flattened: writes up to max_perm permutations of length nM+nZ. */
 int rfsor_permlex_all(unsigned nM, unsigned nZ, unsigned *out, int max_perm) {

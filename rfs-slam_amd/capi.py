@@ -115,7 +115,7 @@ ABI_SYMBOLS = [
     "update_async", "kernel_time_stats",
     "default_fastslam_config", "set_fastslam_config", "get_fastslam_config", "fastslam_update",
     "normalize_weights_parts", "create_ex", "n_particles", "max_particles", "resample_apply_n",
-    "fastslam_set_resample_occured", "particle_parents",
+    "fastslam_set_resample_occured", "particle_parents", "vp_probe_pd",
 ]
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -227,6 +227,14 @@ class CFilter:
         cfg = FastSlamConfig()
         self._call("get_fastslam_config", C.byref(cfg))
         return cfg
+
+    def vp_probe_pd(self, slot):
+        """Probe: Pd and the near-limit flag of every Gaussian of particle `slot` (Victoria Park model), as the kernels see them."""
+        n = int(self.gm_sizes()[slot])
+        pd = np.empty(max(n, 1), dtype=np.float64)
+        cl = np.empty(max(n, 1), dtype=np.int32)
+        self._call("vp_probe_pd", C.c_int(int(slot)), self._ptr(pd), self._ptr(cl), C.c_int(n))
+        return pd[:n], cl[:n].astype(bool)
 
     def fastslam_set_resample_occured(self, flag):
         self._call("fastslam_set_resample_occured", C.c_int(1 if flag else 0))

@@ -363,6 +363,24 @@ int rfsgpu_set_laser_scan(rfsgpu_filter *f, const double *scan, int n) {
   rebuild_params(f);
   return RFSGPU_OK;
 }
+int rfsgpu_vp_probe_pd(rfsgpu_filter *f, int slot, double *pd, int *close_to_limit, int max_n) {
+  CHECK_HANDLE(f);
+  if (f->model != RFSGPU_MODEL_VICTORIAPARK_3D || slot < 0 || slot >= f->N || !pd || !close_to_limit) return fail(f, RFSGPU_ERR_INVALID, "vp_probe_pd: bad arguments");
+  if (f->B.nScan < 2) return fail(f, RFSGPU_ERR_INVALID, "vp_probe_pd: rfsgpu_set_laser_scan first");
+  hipSetDevice(f->device);
+  const int n = std::min(max_n, f->cap);
+  double *dPd = nullptr;
+  int *dCl = nullptr;
+  HIPCHK(hipMalloc(&dPd, (size_t)f->cap * sizeof(double)));
+  HIPCHK(hipMalloc(&dCl, (size_t)f->cap * sizeof(int)));
+  vp_probe_pd_kernel<<<1, 64, 0, f->stream>>>(f->B, f->P, f->cur, slot, dPd, dCl);
+  HIPCHK(hipMemcpyAsync(pd, dPd, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  HIPCHK(hipMemcpyAsync(close_to_limit, dCl, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  hipFree(dPd);
+  hipFree(dCl);
+  return RFSGPU_OK;
+}
 int rfsgpu_set_kf_config(rfsgpu_filter *f, const rfsgpu_kf_config *c) {
   CHECK_HANDLE(f);
   if (!c) return RFSGPU_ERR_INVALID;

@@ -137,12 +137,14 @@ __device__ double vp_pd_wave(const Params &P, const double *scan, int nScan, dou
   const double r0 = p0 * e.xx + p1 * e.xy, r1 = p0 * e.xy + p1 * e.yy;
   double sd = r0 * p0 + r1 * p1;
   sd = 3 * sqrt(sd);
-  sd = fmax(sd, 0.2);
+  sd = (sd < 0.2) ? 0.2 : sd;   // std::max(sd, 0.2) as the reference has it: a NaN (indefinite covariance) stays NaN -> no shifted copies
   // n = how many i = 1, 2, ... satisfy (i - 1) * (2 d) < sd, the loop condition evaluated as the reference writes it
   int n = 0;
   if (act) {
     const double step = 2 * e.d;
-    if (!(step > 0)) {
+    if (!(sd == sd)) {
+      n = 0;                                               // NaN: the loop condition is false from the start
+    } else if (!(step > 0)) {
       n = ((0.0 * step) < sd) ? 100000 : 0;               // non-positive diameter: the reference never terminates
     } else {
       double g = floor(sd / step);
@@ -185,6 +187,23 @@ __device__ double vp_pd_wave(const Params &P, const double *scan, int nScan, dou
   if (mn == 0 && mx > 0) close = true;
   wave_sync();                                             // (the scratch is reused by the next pass)
   return mx;
+}
+
+// Probe for tests (rfsgpu_vp_probe_pd): Pd and the near-limit flag of every Gaussian of one particle, as the kernels see them.
+__global__ __launch_bounds__(64) void vp_probe_pd_kernel(Buffers B, Params P, int cur, int slot, double *pdOut, int *closeOut) {
+  __shared__ __align__(16) unsigned char ws[(VP_PD_SCRATCH_BYTES + 15) & ~15];
+  const int lane = threadIdx.x;
+  const int n = B.count[slot];
+  const double px = B.pose[3 * slot], py = B.pose[3 * slot + 1], pth = B.pose[3 * slot + 2];
+  for (int c0 = 0; c0 < n; c0 += 64) {
+    const int m = c0 + lane;
+    Ent3 e;
+    e.w = 0; e.x = 10; e.y = 10; e.d = 1; e.xx = 1; e.xy = 0; e.xd = 0; e.yy = 1; e.yd = 0; e.dd = 1;
+    if (m < n) load_ent3(B.slab[cur], B.cap, slot, m, e, false);
+    bool close = false;
+    const double pd = vp_pd_wave(P, B.scan, B.nScan, px, py, pth, e, m < n, close, ws);
+    if (m < n) { pdOut[m] = pd; closeOut[m] = close ? 1 : 0; }
+  }
 }
 
 // Landmark-level quantities of KalmanFilter::correct for the 3-D model.

@@ -1074,3 +1074,25 @@ def test_cpp_victoria_park_driver_end_to_end(pkg, tmp_path):
     pose_rows = open(os.path.join(tmp_path, "particlePose.dat")).read().splitlines()
     assert len(pose_rows) == lidar * 200 and len(pose_rows[0].split()) == 6
     assert len(open(os.path.join(tmp_path, "landmarkEst.dat")).readline().split()) == 8
+
+
+def test_vp_pd_probe_matches_oracle_incl_indefinite_covariances(pkg, ob, sc):
+    """MeasurementModel_VictoriaPark::probabilityOfDetection per Gaussian, device (rfsgpu_vp_probe_pd: what the kernels evaluate)
+    vs oracle: thin and uncertain landmarks (dozens of laterally shifted copies), and INDEFINITE covariances, where the
+    reference's `std::max(3 * sqrt(negative), 0.2)` keeps the NaN (no shifted copies at all) -- `fmax` would not."""
+    scen = sc.make_vp_scenario(6, 70, 9, seed=77, scan="ragged")
+    scen["mean"][:, ::3, 2] = 0.06                     # thin
+    scen["cov"][:, ::3, 0, 0] *= 300.0                 # uncertain
+    scen["cov"][:, ::3, 1, 1] *= 300.0
+    scen["cov"][:, 1::7, 0, 0] = -0.7                  # indefinite: perp' Sigma perp < 0 for most directions
+    scen["cov"][:, 1::7, 1, 1] = -0.3
+    dev, orc = make_vp_pair(pkg, ob, sc, scen)
+    differs_from_fmax = 0
+    for i in range(scen["n"]):
+        pd_d, cl_d = dev.vp_probe_pd(i)
+        pd_o, cl_o = orc.vp_probe_pd(i)
+        assert len(pd_d) == 70
+        assert np.array_equal(pd_d, pd_o), (i, np.nonzero(pd_d != pd_o)[0])
+        assert np.array_equal(cl_d, cl_o), (i, np.nonzero(cl_d != cl_o)[0])
+        differs_from_fmax += int(np.any(pd_d[1::7] != pd_d[1::7][0]))
+    assert np.any(dev.vp_probe_pd(0)[0] > 0)

@@ -13,6 +13,9 @@ pkg = load_package()
 sc = pkg.scenarios
 ob = importlib.import_module("oracle.binding")
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+ONLY = set(int(x) for x in os.environ["FUZZ_ONLY"].split(",")) if os.environ.get("FUZZ_ONLY") else None   # rerun these case numbers only
+if os.environ.get("RFS_LIB"):
+    pkg.engine.LIB = os.environ["RFS_LIB"]
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 murty = 0
@@ -30,6 +33,8 @@ def vp_case(case):
         scen["mean"][:, ::3, 2] = rng.uniform(0.03, 0.15)
         scen["cov"][:, ::3, 0, 0] *= rng.uniform(20, 400)
         scen["cov"][:, ::3, 1, 1] *= rng.uniform(20, 400)
+    if ONLY is not None and case not in ONLY:
+        return
     dev = pkg.RBPHDFilter(n, gm_capacity=256, model=pkg.capi.MODEL_VICTORIAPARK_3D)
     orc = ob.OracleFilter(n, stable_sort=True, model=pkg.capi.MODEL_VICTORIAPARK_3D)
     try:
@@ -37,9 +42,35 @@ def vp_case(case):
             sc.load_scenario(f, scen)
         for cyc in range(3):
             Z = scen["Z"] + 1e-3 * cyc
-            for f in (dev, orc):
-                f.predict_map(True)
-                f.update(Z)
+            if os.environ.get("FUZZ_DEBUG"):       # phase by phase, to see where a mismatch starts
+                for f in (dev, orc):
+                    f.predict_map(True)
+                    f.update_map(Z)
+                for i in range(n):
+                    try:
+                        sc.assert_gm_close(dev.export_gm(i), orc.export_gm(i), 1e-10, 1e-12, ordered=True)
+                    except AssertionError as e:
+                        print("  cycle", cyc, "particle", i, "after update_map:", str(e)[:200].replace("\n", " "), flush=True)
+                    if dev.landmarks_in_fov(i) != orc.landmarks_in_fov(i):
+                        print("  cycle", cyc, "particle", i, "landmarks in FOV", dev.landmarks_in_fov(i), orc.landmarks_in_fov(i))
+                for i in range(n):
+                    pd_d, cl_d = dev.vp_probe_pd(i)
+                    pd_o, cl_o = orc.vp_probe_pd(i)
+                    if not (np.array_equal(pd_d, pd_o) and np.array_equal(cl_d, cl_o)):
+                        k = np.nonzero((pd_d != pd_o) | (cl_d != cl_o))[0]
+                        g = dev.export_gm(i)
+                        print("  cycle", cyc, "particle", i, "Pd differs at Gaussians", k.tolist(), "device", pd_d[k], cl_d[k], "oracle", pd_o[k], cl_o[k],
+                              "w", g[0][k], "d", g[2][k, 2], "sxx", g[3][k, 0, 0], flush=True)
+                for f in (dev, orc):
+                    f.importance_weighting()
+                wd, wo = dev.get_weights(), orc.get_weights()
+                print("  cycle", cyc, "weights after weighting rel diff", np.abs(wd - wo) / np.abs(wo))
+                for f in (dev, orc):
+                    f.merge(); f.prune()
+            else:
+                for f in (dev, orc):
+                    f.predict_map(True)
+                    f.update(Z)
             wd, wo = dev.get_weights(), orc.get_weights()
             np.testing.assert_allclose(wd / wd.sum(), wo / wo.sum(), rtol=1e-9, atol=1e-300)
             assert np.array_equal(dev.gm_sizes(), orc.gm_sizes())
@@ -81,6 +112,8 @@ for case in range(n_cases):
     elif mode == 3:
         scen["w"][:, ::5] = 1e-42 * (1 + np.arange(scen["w"][:, ::5].shape[1]))[None, :]   # below fp32's normal range
     cap = 768
+    if ONLY is not None and case not in ONLY:
+        continue
     for fused in (1, 0):
         os.environ["RFSGPU_FUSED_STEP"] = str(fused)
         dev = pkg.RBPHDFilter(n, gm_capacity=cap)
