@@ -111,6 +111,8 @@ for case in range(n_cases):
         scen["w"][:] = np.round(scen["w"] * 4) / 4                          # a handful of distinct weights
     elif mode == 3:
         scen["w"][:, ::5] = 1e-42 * (1 + np.arange(scen["w"][:, ::5].shape[1]))[None, :]   # below fp32's normal range
+    birth = (int(rng.integers(2, 4)), int(rng.integers(2, 5)), int(rng.integers(0, 4)), float(rng.uniform(0.5, 1.5))) if rng.random() < 0.4 else None
+    n_cyc = 4 if birth is not None else 2
     cap = 768
     if ONLY is not None and case not in ONLY:
         continue
@@ -121,7 +123,14 @@ for case in range(n_cases):
         try:
             for f in (dev, orc):
                 sc.load_scenario(f, scen)
-            for cyc in range(2):
+                if birth is not None:       # birth candidates with support / check counters (predict_map_general)
+                    cfg = f.get_filter_config()
+                    cfg.birthGaussianMeasurementCountThreshold, cfg.birthGaussianMeasurementCheckThreshold = birth[0], birth[1]
+                    cfg.birthGaussianCurrentMeasurementCountThreshold, cfg.birthGaussianMeasurementSupportDist = birth[2], birth[3]
+                    f.set_filter_config(cfg)
+                    if hasattr(f, "config"):
+                        f.config = cfg
+            for cyc in range(n_cyc):
                 Z = scen["Z"] + 1e-3 * cyc
                 dev.update_async(Z); dev.synchronize()
                 orc.update(Z)
@@ -132,6 +141,12 @@ for case in range(n_cases):
                     sc.assert_gm_close(dev.export_gm(i), orc.export_gm(i), 1e-10, 1e-12, ordered=True)
                 for f in (dev, orc):
                     s = f.weight_sums(); f.normalize_weights(s[0]); f.predict_map(True)
+                if birth is not None:
+                    for i in range(n):
+                        md, cd, sd, kd = dev.export_birth_candidates(i)
+                        mo, co, so, ko = orc.export_birth_candidates(i)
+                        assert list(sd) == list(so) and list(kd) == list(ko), ("candidates", i)
+                        np.testing.assert_allclose(md, mo, rtol=1e-9, atol=1e-11)
         except Exception as e:  # noqa: BLE001
             bad += 1
             print("CASE", case, "fused", fused, kw, "mode", mode, "->", type(e).__name__, str(e)[:300], flush=True)
