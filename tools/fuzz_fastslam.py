@@ -37,10 +37,21 @@ for case in range(n_cases):
               rmax=float(rng.choice([4.0, 5.0, 8.0])))
     if hyp == 1 and rng.random() < 0.4:
         kw.update(n_landmarks=int(rng.choice([70, 130, 200])), n_z=int(rng.integers(10, 40)), rmax=float(rng.choice([12.0, 25.0])))
-    scen = sc.make_scenario(**kw)
+    vp = rng.random() < 0.3          # Victoria Park model (3-D landmarks, scan-based Pd)
+    if vp:
+        kw = dict(n_particles=n0, n_landmarks=int(rng.choice([3, 10, 30, 60])), n_z=int(rng.integers(1, 14)), seed=int(rng.integers(1 << 30)),
+                  scan=str(rng.choice(["const", "ragged"])))
+        scen = sc.make_vp_scenario(**kw)
+        if rng.random() < 0.5:
+            scen["mean"][:, ::3, 2] = rng.uniform(0.04, 0.2)
+            scen["cov"][:, ::3, 0, 0] *= rng.uniform(10, 200)
+            scen["cov"][:, ::3, 1, 1] *= rng.uniform(10, 200)
+    else:
+        scen = sc.make_scenario(**kw)
     diff = float(rng.choice([2.0, 5.0, 50.0]))
-    dev = pkg.RBPHDFilter(n0, gm_capacity=320, max_particles=n0 * hyp * 4)
-    orc = ob.OracleFilter(n0, stable_sort=True)
+    model = pkg.capi.MODEL_VICTORIAPARK_3D if vp else pkg.capi.MODEL_RNGBRG_2D
+    dev = pkg.RBPHDFilter(n0, gm_capacity=320, max_particles=n0 * hyp * 4, model=model)
+    orc = ob.OracleFilter(n0, stable_sort=True, model=model)
     try:
         for f in (dev, orc):
             sc.load_scenario(f, scen)
@@ -80,7 +91,7 @@ for case in range(n_cases):
                 f.set_poses(poses, scen["pose_cov"])
     except Exception as e:  # noqa: BLE001
         bad += 1
-        print("CASE", case, kw, "hyp", hyp, "diff", diff, "->", type(e).__name__, str(e)[:300], flush=True)
+        print("VP CASE" if vp else "CASE", case, kw, "hyp", hyp, "diff", diff, "->", type(e).__name__, str(e)[:300], flush=True)
     dev.close()
 print("fastslam fuzz: %d cases, %d failures (updates that multiplied particles: %d)" % (n_cases, bad, grown))
 sys.exit(1 if bad else 0)
