@@ -103,7 +103,13 @@ for case in range(n_cases):
                   weighting_md=float(rng.choice([8.0, 10.0])), n_eval=int(rng.choice([25, 40])), n_clutter=int(rng.integers(4, 12)),
                   use_cluster=None, frac_in_fov=1.0, weights=(0.8, 1.0))
         n = kw["n_particles"]
+    if rng.random() < 0.2:
+        kw["per_particle_pose_cov"] = True
     scen = sc.make_scenario(**kw)
+    indefinite = rng.random() < 0.15
+    if indefinite:   # indefinite covariances cannot arise from the filter's own updates, but the reference defines what happens;
+        scen["cov"][:, ::4, 0, 0] = -scen["cov"][:, ::4, 0, 0]   # the algebra is ill-conditioned there (FMA vs strict rounding
+        #                                                          is amplified): same decisions, looser value tolerances
     mode = int(rng.integers(0, 4))
     if mode == 1:
         scen["w"][:, ::2] = 0.5                                            # ties everywhere
@@ -135,10 +141,10 @@ for case in range(n_cases):
                 dev.update_async(Z); dev.synchronize()
                 orc.update(Z)
                 wd, wo = dev.get_weights(), orc.get_weights()
-                np.testing.assert_allclose(wd / wd.sum(), wo / wo.sum(), rtol=1e-9 if "weighting_md" not in kw else 1e-8, atol=1e-300)
+                np.testing.assert_allclose(wd / wd.sum(), wo / wo.sum(), rtol=1e-6 if indefinite else (1e-9 if "weighting_md" not in kw else 1e-8), atol=1e-300)
                 assert np.array_equal(dev.gm_sizes(), orc.gm_sizes())
                 for i in range(n):
-                    sc.assert_gm_close(dev.export_gm(i), orc.export_gm(i), 1e-10, 1e-12, ordered=True)
+                    sc.assert_gm_close(dev.export_gm(i), orc.export_gm(i), 1e-7 if indefinite else 1e-10, 1e-9 if indefinite else 1e-12, ordered=True)
                 for f in (dev, orc):
                     s = f.weight_sums(); f.normalize_weights(s[0]); f.predict_map(True)
                 if birth is not None:
