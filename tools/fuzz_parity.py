@@ -94,7 +94,7 @@ for case in range(n_cases):
         continue
     n = int(rng.integers(3, 12))
     nlm = int(rng.choice([1, 5, 40, 63, 64, 65, 127, 128, 129, 200, 257, 330]))
-    nz = int(rng.integers(1, 25))
+    nz = int(rng.integers(1, 25)) if rng.random() < 0.9 else int(rng.integers(40, 65))   # up to RFSGPU_MAX_Z
     rmax = float(rng.choice([2.5, 4.0, 6.0]))
     kw = dict(n_particles=n, n_landmarks=nlm, n_z=nz, seed=int(rng.integers(1 << 30)), rmax=rmax,
               frac_in_fov=float(rng.choice([1.0, 0.6, 0.2])), use_cluster=bool(rng.integers(0, 2)) if rng.random() < 0.3 else None)
