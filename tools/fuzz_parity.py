@@ -93,7 +93,7 @@ for case in range(n_cases):
         vp_case(case)
         continue
     n = int(rng.integers(3, 12))
-    nlm = int(rng.choice([1, 5, 40, 63, 64, 65, 127, 128, 129, 200, 257, 330]))
+    nlm = int(rng.choice([1, 5, 40, 63, 64, 65, 127, 128, 129, 200, 257, 330, 500]))
     nz = int(rng.integers(1, 25)) if rng.random() < 0.9 else int(rng.integers(40, 65))   # up to RFSGPU_MAX_Z
     rmax = float(rng.choice([2.5, 4.0, 6.0]))
     kw = dict(n_particles=n, n_landmarks=nlm, n_z=nz, seed=int(rng.integers(1 << 30)), rmax=rmax,
