@@ -153,6 +153,8 @@ int main(int argc, char **argv) {
   bool stationary = true, birthCheck = true;
   size_t zIdx = 0;
   int nLidar = 0, nResample = 0;
+  double tPredict = 0, tUpdate = 0;   // host wall time inside the two filter calls
+  auto now = [] { return std::chrono::steady_clock::now(); };
   const auto t0 = std::chrono::steady_clock::now();
   for (int k = 0; k < nMsg; k++) {
     const ManagerMsg &m = msgs[k];
@@ -160,7 +162,8 @@ int main(int argc, char **argv) {
     const double dt = m.t - t_km;
     const double Qlm[9] = {varlm[0] * dt * dt, 0, 0, 0, varlm[1] * dt * dt, 0, 0, 0, varlm[2] * dt * dt};
     filter.getLmkProcessModel()->setNoise(Qlm);
-    filter.predict(u_km, dt, false, !stationary && inputNoise, birthCheck);   // (stationary: all particles sit still)
+    { const auto ta = now(); filter.predict(u_km, dt, false, !stationary && inputNoise, birthCheck);   // (stationary: all particles sit still)
+      tPredict += std::chrono::duration<double>(now() - ta).count(); }
     birthCheck = false;
     if (m.type == 2) {
       if (m.idx >= 0 && m.idx < (int)inputs.size()) { u_km.u[0] = inputs[m.idx].v; u_km.u[1] = inputs[m.idx].r * urScale; }
@@ -188,7 +191,7 @@ int main(int argc, char **argv) {
       if (Z.size() > RFSGPU_MAX_Z) Z.resize(RFSGPU_MAX_Z);
       filter.getMeasurementModel()->setLaserScan(syntheticScan);
       const bool any = !Z.empty();
-      filter.update(Z);
+      { const auto ta = now(); filter.update(Z); tUpdate += std::chrono::duration<double>(now() - ta).count(); }
       if (any) { nLidar++; nResample += filter.resampleOccured() ? 1 : 0; }
       birthCheck = true;
       if (fPose || fLm) {
@@ -234,7 +237,8 @@ int main(int argc, char **argv) {
   int strong = 0;
   for (int g = 0; g < nMap; g++) { double mu[3], S[9], w; filter.getLandmark(best, g, mu, S, w); strong += (w >= 0.5) ? 1 : 0; }
   const Pose2d &bp = filter.getParticlePose(best);
-  std::printf("particles %d  messages %d  lidar updates %d  resamplings %d  wall %.3f s\n", nParticles, nMsg, nLidar, nResample, wall);
+  std::printf("particles %d  messages %d  lidar updates %d  resamplings %d  wall %.3f s  (inside predict() %.3f s, inside update() %.3f s)\n", nParticles, nMsg, nLidar,
+              nResample, wall, tPredict, tUpdate);
   RBPHDFilter2d::TimingInfo *ti = filter.getTimingInfo();
   std::printf("Elapsed Timing Information [nsec]\n");  // format of the reference drivers' timing printout
   std::printf("%-22s%15s%15s\n", "", "wall", "cpu");
