@@ -439,7 +439,7 @@ __global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQ
   __shared__ int sCtl[8];
   __shared__ unsigned char sPushed[MURTY_N];
   // (readfirstlane: tells the compiler the wave index is uniform, so that the whole search compiles to scalar control flow)
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   for (int j = blockIdx.x; j < nJobs; j += gridDim.x) {
     const MurtyJob J = Q.jobs[j];
     const int n = J.nR + J.nC;
