@@ -1,24 +1,39 @@
 #!/usr/bin/env python3
-"""bench.py -- PHD filter-update steps/s of the MI355X-native RB-PHD update engine.
+"""bench.py -- PHD filter-update steps/s of the MI355X-native RB-PHD update engine (BASELINE.json metric).
 
 One "step" = one RBPHDFilter::update() body (map update + particle weighting + GM merge + prune; reference
-include/RBPHDFilter.hpp:444-523) over one batch of synthetic input + the weight normalisation
-({sum w, sum w^2} reduction, RCCL all-reduce across ranks when N>1, divide).  Workload = BASELINE.json
-configs[1] ("C2a"): 2000 particles x 200 GM landmarks x 30 measurements per GPU, all landmarks in
-the field of view (worst case: 6000 landmark-measurement pairs per particle), fp64.  The C2a state collapses
-after one update (Pd = 0.99), so every step starts from the same device-resident snapshot
-(rfsgpu_restore_state, a device-to-device copy of the live Gaussians, INSIDE the timed region).
+include/RBPHDFilter.hpp:444-523) over one batch of synthetic input + the weight normalisation ({sum w, sum w^2}
+reduction, RCCL all-reduce across ranks when N>1, divide).  Workloads:
 
-  python bench.py --gpus N --steps K --warmup W
+  c2a  BASELINE configs[1]: 2000 particles x 200 GM landmarks x 30 measurements, all landmarks in the field of view
+       (worst case: 6000 landmark-measurement pairs per particle).  DEFAULT at --gpus 1.  The state collapses after one update
+       (Pd = 0.99), so every step starts from a device-resident snapshot (rfsgpu_restore_state, inside the timed region).
+  c3   BASELINE configs[2]'s shard: 2500 particles x 500 GM landmarks x 30 measurements per GPU, range limit 5 m
+       (20 000 particles over 8 GPUs).  DEFAULT at --gpus N > 1.  Same re-seeding.  One global resampling step with
+       cross-shard mixture migration is timed separately after the region (`resample_migration`).
+  c2b  the C2 map with ~30 landmarks inside the field of view, NOT re-seeded: predict (births) + update + normalise per step,
+       a fresh noisy measurement set every step; median over the steps is reported beside the mean.
+
+  python bench.py --gpus N --steps K --warmup W [--workload c2a|c2b|c3]
   N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Particles shard across ranks with no data-path collective except the 2-double all-reduce (weak scaling:
-2000 particles per GPU).  Rank 0 prints ONE JSON line.
+Particles shard across ranks with no data-path collective except the 2-double all-reduce (weak scaling).  Rank 0 prints
+ONE JSON line.  roofline.achieved = SURVEY 8(d)'s bytes_step / the fused step kernel's average HIP-event duration inside the
+timed region; roofline.traffic = HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of this same
+workload, collected live by two short child runs (N = 1, rank 0; --no-pmc skips them).
 """
-import argparse
-import json
 import os
+# the CPU-baseline leg's OpenMP team: bound to cores, decided before any OpenMP runtime is loaded
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
+import argparse
+import csv
+import glob
+import json
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -26,81 +41,156 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_PARTICLES, N_LANDMARKS, N_Z, CAP = 2000, 200, 30, 384
+N_Z = 30
+WORKLOADS = {
+    "c2a": dict(n=2000, nm=200, cap=384, rmax=None, frac=1.0, reseed=True,
+                label="C2a (BASELINE configs[1]): {n} particles/GPU x 200 GM landmarks x 30 measurements/step, all landmarks in FOV, "
+                      "2D RngBrg model, multi-feature weighting (nEvalPt 15), state re-seeded from a device snapshot every step"),
+    "c3": dict(n=2500, nm=500, cap=640, rmax=5.0, frac=1.0, reseed=True,
+               label="C3 shard (BASELINE configs[2]: 20000 particles x 500 GM landmarks over 8 GPUs): {n} particles/GPU x 500 GM landmarks x "
+                     "30 measurements/step, range limit 5 m, 2D RngBrg model, multi-feature weighting (nEvalPt 15), state re-seeded from a "
+                     "device snapshot every step"),
+    "c2b": dict(n=2000, nm=200, cap=384, rmax=None, frac=0.15, reseed=False,
+                label="C2b steady state: {n} particles/GPU x 200 GM landmarks (30 inside the FOV) x 30 measurements/step, NOT re-seeded: "
+                      "predict (births) + update + normalise per step, fresh measurement noise and clutter every step"),
+}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-BG = 48                # packed 2-D Gaussian record: w, mu(2), Sigma upper triangle(3) doubles (SURVEY §8d)
-KERNELS = ["phd_update_map", "phd_weight_multifeature", "gm_merge_prune"]   # rfsgpu_update runs merge+prune fused
+BG = 48                # packed 2-D Gaussian record: w, mu(2), Sigma upper triangle(3) doubles (SURVEY 8(d))
+KERNELS = ["phd_update_map", "phd_weight_multifeature", "gm_merge_prune"]   # the three stand-alone kernels of rfsgpu_update
+FUSED = "phd_step_fused_kernel"
 
 
-def algorithmic_bytes(n_particles, nM, nNew, nKept, nZ):
-    """ALGORITHMIC HBM bytes per launch of each hot-path kernel (DESIGN.md 'Kernels').
-    nM / nNew / nKept are sums over particles of: Gaussians before the update, appended, surviving prune."""
-    sweep = nM * BG + nNew * BG + nM * 8 + n_particles * (24 + 8) + nZ * 16
-    weight = (nM + nNew) * (BG + 8) + (nM + nNew) * BG + n_particles * (24 + 8)   # read w,w_prev,mu,Sigma; write sorted; weight out
-    merge_prune = (nM + nNew) * BG + nKept * BG + n_particles * 4                 # read once, write the compacted survivors
+def survey_bytes(n_particles, nM, nNew, nKept, nZ):
+    """SURVEY 8(d), verbatim: bytes_sweep = sum_i[nM_i*B_g + nNew_i*B_g + nM_i*8] + N_p*(24+8) + nZ*8*d_z;
+    bytes_step = bytes_sweep + sum_i (nM_i+nNew_i)*B_g + sum_i nKept_i*B_g + N_p*8.  nM/nNew/nKept are sums over particles."""
+    sweep = nM * BG + nNew * BG + nM * 8 + n_particles * (24 + 8) + nZ * 8 * 2
+    step = sweep + (nM + nNew) * BG + nKept * BG + n_particles * 8
+    return sweep, step
+
+
+def design_bytes(n_particles, nM, nNew, nKept, nZ):
+    """What THIS design's kernels move by construction (DESIGN.md 'Kernels'), beyond the SURVEY formula: the w_prev plane
+    (56-byte records), the weighting phase's own read of the mixture and the merge phase's read of it."""
+    sweep = nM * BG + nNew * (BG + 8) + nM * 16 + n_particles * (24 + 8) + nZ * 16
+    weight = (nM + nNew) * (BG + 8) + n_particles * (24 + 8)
+    merge_prune = (nM + nNew) * BG + nKept * (BG + 8) + n_particles * 4
     return dict(zip(KERNELS, [sweep, weight, merge_prune]))
 
 
-def cpu_baseline(sc, scen_full, seconds_budget=20.0):
-    """The oracle (CPU restatement of the same path, oracle/, g++ -O2 -fopenmp, OpenMP `parallel for` over particles
-    exactly like the reference) timed on this box's host cores on a bounded sample of the same workload, scaled to the
-    full particle count (the path is embarrassingly parallel over particles).  Reported baseline only -- never part
-    of the measured GPU path."""
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline (reported beside the GPU number; never part of the measured path)
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(sc, wl, n_full, seconds_budget=24.0):
+    """The oracle (CPU restatement of the same path; OpenMP `parallel for` over particles in every phase exactly like the
+    reference) compiled -O3 -march=native -fopenmp ON THIS HOST (oracle.binding.build_fast; the parity tests keep the strict
+    -O2 -ffp-contract=off build), timed on a bounded sample of the same workload and scaled to the full particle count
+    (the path is independent per particle)."""
+    import ctypes as C
     from oracle import binding as ob
-    out, info = {}, {}
-    cores = ob.max_threads()
-    for label, threads, n_s in (("1thread", 1, 64), ("allcores", cores, min(scen_full["n"], max(64, 8 * cores)))):
+    so, flags = ob.build_fast()
+    lib = C.CDLL(so)
+    model, logical, physical = ob.cpu_info()
+    res, info = {}, {}
+    for label, threads, n_s in (("1thread", 1, 64), ("allcores", physical, min(n_full, max(256, 16 * physical)))):
         ob.set_threads(threads)
-        scen = sc.make_scenario(n_s, N_LANDMARKS, N_Z, seed=12345)
-        orc = ob.OracleFilter(n_s, stable_sort=False)
+        lib.rfsor_set_threads(C.c_int(threads))
+        scen = sc.make_scenario(n_s, wl["nm"], N_Z, seed=12345, rmax=wl["rmax"], frac_in_fov=wl["frac"])
+        warm = ob.OracleFilter(n_s, stable_sort=False, lib=lib)     # starts the thread team, touches the allocator arenas
+        sc.load_scenario(warm, scen)
+        warm.update(scen["Z"])
+        warm.close()
         reps, t_acc, times = 0, 0.0, []
         while t_acc < seconds_budget / 2 and reps < 30:
+            orc = ob.OracleFilter(n_s, stable_sort=False, lib=lib)
             sc.load_scenario(orc, scen)
             t0 = time.perf_counter()
             orc.update(scen["Z"])
             s = orc.weight_sums()
             orc.normalize_weights(s[0])
             times.append(time.perf_counter() - t0)
+            orc.close()
             t_acc += times[-1]
             reps += 1
-        out[label] = 1.0 / (float(np.median(times)) / n_s * scen_full["n"])   # median repetition (the box's load varies)
-        info[label] = n_s
-        orc.close()
-    ob.set_threads(cores)
-    return dict(value=round(out["allcores"], 4), unit="steps/s", cores=cores, kind="port",
-                single_thread_value=round(out["1thread"], 4),
-                sample=f"update()+normalise on {info['allcores']} of {scen_full['n']} particles with {cores} OpenMP threads "
-                       f"({info['1thread']} particles for the 1-thread figure), same 200-landmark x 30-measurement state, "
-                       "scaled by particle count")
+        res[label] = 1.0 / (float(np.median(times)) / n_s * n_full)   # median repetition (the box's load varies)
+        info[label] = (n_s, reps)
+    ob.set_threads(physical)
+    eff = res["allcores"] / (res["1thread"] * physical)
+    return dict(value=round(res["allcores"], 4), unit="steps/s", cores=physical, kind="port",
+                single_thread_value=round(res["1thread"], 4), parallel_efficiency=round(eff, 3),
+                cpu_model=model, logical_cpus=logical, omp_num_threads=physical,
+                omp_proc_bind=os.environ.get("OMP_PROC_BIND"), omp_places=os.environ.get("OMP_PLACES"),
+                compiler_flags="g++ -std=c++17 " + " ".join(flags),
+                sample=f"update()+normalise on {info['allcores'][0]} of {n_full} particles with {physical} OpenMP threads, one per physical "
+                       f"core (median of {info['allcores'][1]} repetitions; {info['1thread'][0]} particles for the 1-thread figure), same "
+                       f"{wl['nm']}-landmark x {N_Z}-measurement state, scaled by particle count")
 
 
-def pmc_traffic(kernel_name):
-    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC summary (profiles/pmc_latest.json, made by
-    tools/profile_round.sh + tools/pmc_summary.py on this workload): (2*FETCH_SIZE + WRITE_SIZE)*1024."""
+# ---------------------------------------------------------------------------------------------------------------------
+# live HBM traffic (rocprofv3 PMC passes of a short child run of this same workload)
+# ---------------------------------------------------------------------------------------------------------------------
+def pmc_pass(counter, child_args, timeout_s):
+    """Average `counter` per launch of every kernel over one `rocprofv3 --kernel-trace --pmc <counter>` child run."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    d = tempfile.mkdtemp(prefix="rfs_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+           sys.executable, os.path.abspath(__file__), "--pmc-child"] + child_args
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-    except Exception:
-        return None
-    alias = {"phd_update_map": "phd_update_map_kernel", "phd_weight_multifeature": "phd_weight_multifeature_kernel",
-             "gm_merge_prune": "gm_merge_kernel", "phd_step_fused": "phd_step_fused_kernel"}[kernel_name]
-    best = None
-    for k, v in d.items():
-        if k.startswith(alias) and (best is None or v["calls"] > best["calls"]):
-            best = v
-    return int(best["hbm_bytes"]) if best else None
+        r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        shutil.rmtree(d, ignore_errors=True)
+        return None, f"rocprofv3 pass timed out after {timeout_s} s"
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    if r.returncode != 0 or not files:
+        tail = r.stdout.decode(errors="replace")[-300:]
+        shutil.rmtree(d, ignore_errors=True)
+        return None, f"rocprofv3 pass failed (rc {r.returncode}): {tail}"
+    agg = {}
+    for fpath in files:
+        with open(fpath) as fh:
+            for row in csv.DictReader(fh):
+                if row.get("Counter_Name", counter) != counter:
+                    continue
+                name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                agg.setdefault(name, []).append(float(row["Counter_Value"]))
+    shutil.rmtree(d, ignore_errors=True)
+    return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}, None
 
 
+def live_traffic(kernel_prefix, child_args, timeout_s=240):
+    """HBM bytes per launch of the kernel whose name starts with `kernel_prefix`: (2*FETCH_SIZE + WRITE_SIZE)*1024 -- rocprofv3
+    reports both in KiB and gfx950's FETCH_SIZE tallies 128-byte read requests at 64 bytes (MI355X_MICROARCH.md, HBM section;
+    confirmed on restore_state_kernel, a pure copy).  Two separate passes, as the guide prescribes."""
+    out = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        agg, err = pmc_pass(counter, child_args, timeout_s)
+        if agg is None:
+            return None, err
+        hit = [(k, v) for k, v in agg.items() if k.startswith(kernel_prefix)]
+        if not hit:
+            return None, f"no {kernel_prefix} launches in the {counter} pass"
+        k, (avg, calls) = max(hit, key=lambda kv: kv[1][1])
+        out[counter] = (avg, calls)
+    b = (2.0 * out["FETCH_SIZE"][0] + out["WRITE_SIZE"][0]) * 1024.0
+    return dict(bytes=int(b), fetch_size_kib=round(out["FETCH_SIZE"][0], 1), write_size_kib=round(out["WRITE_SIZE"][0], 1),
+                launches=out["FETCH_SIZE"][1]), None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None, help="default: c2a at --gpus 1, c3 (configs[2]'s shard) at --gpus N > 1")
+    ap.add_argument("--particles", type=int, default=None, help="particles per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--particles", type=int, default=N_PARTICLES, help="particles per GPU")
-    ap.add_argument("--shards-per-gpu", type=int, default=1,
-                    help="independent shards (handles, HIP streams) the GPU's particles are split into.  Measured on MI355X at C2a: "
-                         "2 shards that never meet overlap each other's short serial kernels (+20 %% throughput), but the per-step "
-                         "weight normalisation couples them again and the gain is lost (4390 vs 4780 steps/s), so the default is 1")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 PMC child runs (roofline.traffic = null)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     import torch
@@ -127,93 +217,93 @@ def main():
     pkg = load_package()
     sc = pkg.scenarios
 
-    n_local = args.particles
-    scen = sc.make_scenario(n_local, N_LANDMARKS, N_Z, seed=12345 + rank)
+    wname = args.workload or ("c2a" if world == 1 else "c3")
+    wl = WORKLOADS[wname]
+    n_local = args.particles or wl["n"]
+    CAP = wl["cap"]
+    scen = sc.make_scenario(n_local, wl["nm"], N_Z, seed=12345 + rank, rmax=wl["rmax"], frac_in_fov=wl["frac"])
     # all ranks see the same measurement set (one sensor scan per step)
-    scen["Z"] = sc.make_scenario(4, N_LANDMARKS, N_Z, seed=12345)["Z"] if rank else scen["Z"]
     if world > 1:
-        zt = torch.from_numpy(scen["Z"].copy()).cuda()
+        zt = torch.from_numpy(np.ascontiguousarray(scen["Z"])).cuda()
         dist.broadcast(zt, 0)
         scen["Z"] = zt.cpu().numpy()
-
-    # The GPU's particles are held by S shards (handles), each on its own HIP stream (default 1; see --shards-per-gpu).
-    # Shards -- on one GPU or on different GPUs -- only meet in the weight normalisation: per-shard {sum w, sum w^2} ->
-    # RCCL all-reduce (N > 1) -> on-device divide by the sum over all shards.
-    S = args.shards_per_gpu
-    if n_local % S:
-        raise SystemExit("--particles must be divisible by --shards-per-gpu")
-    n_sh = n_local // S
     dev = torch.device("cuda", local_rank)
-    shards, streams, evs = [], [], []
-    parts = torch.zeros(S, 2, dtype=torch.float64, device=dev)   # shard k's {sum w, sum w^2} lands in parts[k]
-    for k in range(S):
-        sub = dict(scen)
-        lo, hi = k * n_sh, (k + 1) * n_sh
-        sub.update(n=n_sh, poses=scen["poses"][lo:hi], w=scen["w"][lo:hi], mean=scen["mean"][lo:hi], cov=scen["cov"][lo:hi],
-                   particle_w=scen["particle_w"][lo:hi])
-        if np.ndim(scen["pose_cov"]) == 3:
-            sub["pose_cov"] = scen["pose_cov"][lo:hi]
-        fk = pkg.RBPHDFilter(n_sh, device_id=local_rank, gm_capacity=CAP)
-        sc.load_scenario(fk, sub)
-        tk = torch.cuda.Stream()
-        fk.set_stream(tk.cuda_stream)      # engine kernels and the timing events of this shard order on this stream
-        fk.bind_weight_sums_buffer(parts[k].data_ptr())
-        fk.save_state()
-        shards.append(fk); streams.append(tk); evs.append(torch.cuda.Event())
-    ev_red = torch.cuda.Event()
+    sums = torch.zeros(2, dtype=torch.float64, device=dev)     # this shard's {sum w, sum w^2}; all-reduced in place when N > 1
+    f = pkg.RBPHDFilter(n_local, device_id=local_rank, gm_capacity=CAP)
+    sc.load_scenario(f, scen)
+    stream = torch.cuda.Stream()
+    f.set_stream(stream.cuda_stream)          # engine kernels, the RCCL all-reduce and the timing events order on this stream
+    f.bind_weight_sums_buffer(sums.data_ptr())
+    f.save_state()
     Z = scen["Z"]
-    f = shards[0]
-    parts_ptr = parts.data_ptr()
+    sums_ptr = sums.data_ptr()
 
-    def step():
-        for k in range(S):
-            fk = shards[k]
-            fk.restore_state()
-            fk.update_async(Z)   # stream-ordered: the host never waits inside a step; device errors surface at the final sync
-            fk.weight_sums_async()
-            if S > 1 or world > 1:
-                evs[k].record(streams[k])
-        # every shard divides by the sum over all shards of all GPUs: the per-shard pairs sit side by side in `parts`; across
-        # GPUs they are all-reduced in place (the only collective on the path: 2*S doubles over xGMI); the divide adds the S
-        # entries on the device.  Shard 0's stream carries the reduction.
-        if world > 1:
-            with torch.cuda.stream(streams[0]):
-                for k in range(1, S):
-                    streams[0].wait_event(evs[k])
-                dist.all_reduce(parts)
-                ev_red.record(streams[0])
-            for k in range(1, S):
-                streams[k].wait_event(ev_red)
-        elif S > 1:
-            for k in range(S):
-                for j in range(S):
-                    if j != k:
-                        streams[k].wait_event(evs[j])
-        for k in range(S):
-            shards[k].normalize_weights(0.0, parts_ptr, S)   # divisor read on the device
+    if wl["reseed"]:
+        def step(k):
+            f.restore_state()
+            f.update_async(Z)             # stream-ordered: the host never waits inside a step; device errors surface at the final sync
+            f.weight_sums_async()
+            if world > 1:                 # the only collective on the path: 2 doubles over xGMI
+                with torch.cuda.stream(stream):
+                    dist.all_reduce(sums)
+            f.normalize_weights(0.0, sums_ptr, 1)   # divisor read on the device
+    else:
+        # C2b: a ring of measurement sets of the same scene (fresh detection noise and clutter), no re-seeding
+        rngz = np.random.default_rng(999)
+        gt, P = scen["gt"], scen["params"]
+        vis = np.nonzero(scen["in_fov"])[0]
+        Zring = []
+        for _ in range(32):
+            det = rngz.choice(vis, min(24, vis.size), replace=False)
+            zr = np.hypot(gt[det, 0], gt[det, 1]) + rngz.normal(0, np.sqrt(P["R"][0, 0]), det.size)
+            zb = np.arctan2(gt[det, 1], gt[det, 0]) + rngz.normal(0, np.sqrt(P["R"][1, 1]), det.size)
+            ncl = N_Z - det.size
+            Zk = np.concatenate([np.stack([zr, zb], 1), np.stack([rngz.uniform(P["rmin"], P["rmax"], ncl), rngz.uniform(-np.pi, np.pi, ncl)], 1)], 0)
+            Zring.append(np.ascontiguousarray(Zk[rngz.permutation(N_Z)]))
 
-    for _ in range(args.warmup):
-        step()
-    # shapes for the algorithmic byte counts (one instrumented step of every shard, untimed)
-    nM = nAfter = nKept = 0
-    for fk in shards:
-        fk.restore_state()
-        nM += int(fk.gm_sizes().sum())
-        fk.update_map(Z)
-        nAfter += int(fk.gm_sizes().sum())
-        fk.importance_weighting(); fk.merge(); fk.prune()
-        nKept += int(fk.gm_sizes().sum())
-    bytes_k = algorithmic_bytes(n_local, nM, nAfter - nM, nKept, N_Z)   # per step of this GPU (all its shards)
+        def step(k):
+            f.predict_map(True)           # births from the previous step's unused measurements + Sigma += Q
+            f.update_async(Zring[k % len(Zring)])
+            f.weight_sums_async()
+            if world > 1:
+                with torch.cuda.stream(stream):
+                    dist.all_reduce(sums)
+            f.normalize_weights(0.0, sums_ptr, 1)
 
-    for fk in shards:
-        fk.synchronize()
-        fk.kernel_time_stats()       # discard the warm-up statistics
+    if args.pmc_child:                    # the short run the parent profiles with rocprofv3 --pmc (no output, no baselines)
+        for k in range(13):
+            step(k)
+        f.synchronize()
+        return
+
+    for k in range(args.warmup):
+        step(k)
+    # shapes for the algorithmic byte counts (one instrumented step, untimed)
+    if wl["reseed"]:
+        f.restore_state()
+    nM = int(f.gm_sizes().sum())
+    f.update_map(Z)
+    nAfter = int(f.gm_sizes().sum())
+    f.importance_weighting(); f.merge(); f.prune()
+    nKept = int(f.gm_sizes().sum())
+    if not wl["reseed"]:
+        f.restore_state()
+        for k in range(args.warmup):
+            step(k)
+    bytes_sweep, bytes_step = survey_bytes(n_local, nM, nAfter - nM, nKept, N_Z)
+    dbytes = design_bytes(n_local, nM, nAfter - nM, nKept, N_Z)
+
+    f.synchronize()
+    f.kernel_time_stats()            # discard the warm-up statistics
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    per_step = []
+    for k in range(args.steps):
+        step(k)
+        if not wl["reseed"]:         # (C2b's predict_map syncs anyway: per-step wall times for the median)
+            per_step.append(time.perf_counter())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -223,74 +313,77 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # per-kernel HIP-event pairs recorded on each shard's stream inside every timed step, harvested after the region
-    kern_ms = np.zeros(3)
-    for fk in shards:
-        fk.synchronize()             # raises if any step overflowed / hit an unsupported case
-        ka, _ = fk.kernel_time_stats()
-        kern_ms += np.array(ka) / 1e6
-    kern_ms /= S                     # average duration of ONE launch (one shard); S launches run concurrently
+    f.synchronize()                  # raises if any step overflowed / hit an unsupported case
+    ka, _ = f.kernel_time_stats()    # HIP-event pairs recorded on the engine's stream inside every timed step
+    kern_ms = np.array(ka) / 1e6
     ms_per_step = dt / args.steps * 1e3
-    wsum = sum(float(fk.get_weights().sum()) for fk in shards)
+    wsum = float(f.get_weights().sum())
     assert np.isfinite(wsum) and (world > 1 or abs(wsum - 1.0) < 1e-6), "weights did not normalise"
-
-    # rfsgpu_update_async runs the step as ONE kernel (step_fused.h) unless RFSGPU_FUSED_STEP=0: kernel_time_stats then
-    # reports [fused step, 0, 0].  The per-phase breakdown (and the likelihood-sweep rate the north star asks for) comes
-    # from the three stand-alone kernels on the whole GPU's particles in ONE handle, measured with the same HIP events in an
-    # untimed pass after the region.
     fused = kern_ms[1] == 0.0 and kern_ms[2] == 0.0
+
+    # weak-scaling reference on the SAME workload: this rank's shard alone, without the collective (N > 1 only)
+    solo = None
+    if world > 1 and wl["reseed"]:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            f.restore_state(); f.update_async(Z); f.weight_sums_async(); f.normalize_weights(0.0, sums_ptr, 1)
+        torch.cuda.synchronize()
+        st = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+        dist.all_reduce(st, op=dist.ReduceOp.MAX)
+        solo = args.steps / float(st.item())
+        f.synchronize(); f.kernel_time_stats()
+
+    # one global resampling step with cross-shard migration (N > 1), timed on its own
+    migr = None
+    if world > 1 and wl["reseed"]:
+        migr = pkg.sharded.bench_resample_migration(pkg, f, rank, world, dev, stream=stream, sums=sums, reps=3)
+
+    # per-phase breakdown (and the likelihood-sweep rate the north star asks for): the three stand-alone kernels, HIP events,
+    # untimed pass after the region
     phase_ms = kern_ms
-    if fused:
-        for fk in shards[1:]:
-            fk.close()
-        fa = pkg.RBPHDFilter(n_local, device_id=local_rank, gm_capacity=CAP)
-        sc.load_scenario(fa, scen)
-        fa.save_state()
+    if fused and wl["reseed"]:
         acc = np.zeros(3)
         reps = 20
         for r in range(reps + 3):
-            fa.restore_state()
-            fa.update(Z)
+            f.restore_state()
+            f.update(Z)
             if r >= 3:
-                acc += np.array(fa.last_kernel_ns()[:3], dtype=np.float64)
+                acc += np.array(f.last_kernel_ns()[:3], dtype=np.float64)
         phase_ms = acc / reps / 1e6
 
     if rank == 0:
         per_kernel = {}
         for k, name in enumerate(KERNELS):
-            gbs = bytes_k[name] / (phase_ms[k] * 1e-3) / 1e9 if phase_ms[k] > 0 else 0.0
-            per_kernel[name] = dict(ms=round(float(phase_ms[k]), 5), algorithmic_bytes=int(bytes_k[name]), achieved_GBps=round(gbs, 2))
-        if fused:
-            tot_bytes = int(sum(bytes_k[name] for name in KERNELS))
-            dname = "phd_step_fused"
-            per_launch = round((tot_bytes / S) / (kern_ms[0] * 1e-3) / 1e9, 2)
-            if S == 1:
-                achieved = per_launch
-                how = "algorithmic bytes of the launch / its HIP-event duration"
+            if phase_ms[k] > 0:
+                per_kernel[name] = dict(ms=round(float(phase_ms[k]), 5), design_bytes=int(dbytes[name]),
+                                        design_GBps=round(dbytes[name] / (phase_ms[k] * 1e-3) / 1e9, 2))
+        sweep_ms = float(phase_ms[0]) if phase_ms[0] > 0 and not (fused and not wl["reseed"]) else None
+        sweep = None
+        if sweep_ms:
+            g = bytes_sweep / (sweep_ms * 1e-3) / 1e9
+            sweep = dict(kernel="phd_update_map_kernel (stand-alone form, untimed pass)", ms=round(sweep_ms, 5), algorithmic_bytes=int(bytes_sweep),
+                         achieved_GBps=round(g, 2), frac=round(g / HBM_PEAK_GBS, 6))
+        dom_ms = float(kern_ms[0]) if fused else float(kern_ms.sum())
+        achieved = bytes_step / (dom_ms * 1e-3) / 1e9
+        design_total = int(sum(dbytes.values()))
+        traffic, traffic_note = None, "skipped (--no-pmc)" if args.no_pmc else None
+        if not args.no_pmc and world == 1 and fused:
+            child = ["--workload", wname, "--no-pmc", "--no-cpu-baseline"] + (["--particles", str(n_local)] if args.particles else [])
+            tr, err = live_traffic(FUSED, child)
+            if tr is None:
+                traffic_note = "PMC collection failed: " + str(err)
             else:
-                # The S launches of a step (one per shard, tot_bytes / S each) overlap on the device, so a single launch's
-                # bytes / duration understates what the device moves while they run.  Reported instead: the bytes of ALL S
-                # launches over the WHOLE step time (which also contains the short serial kernels) -- a lower bound on the
-                # device-level rate during the fused kernels, never an overstatement.
-                achieved = round(tot_bytes / (ms_per_step * 1e-3) / 1e9, 2)
-                how = (f"algorithmic bytes of the {S} overlapping launches of a step / step time (lower bound); one launch alone: "
-                       f"{per_launch} GB/s over {round(float(kern_ms[0]), 5)} ms")
-            fused_entry = dict(ms=round(float(kern_ms[0]), 5), algorithmic_bytes=tot_bytes, achieved_GBps=achieved,
-                               launches_per_step=S, algorithmic_bytes_per_launch=tot_bytes // S, per_launch_GBps=per_launch,
-                               note="update_map + weighting + merge/prune of a particle in one workgroup; one launch per shard "
-                                    "per step, measured inside the timed region")
-            per_kernel = {"phd_step_fused": fused_entry,
-                          "standalone_phases_untimed_pass": per_kernel}
-            sweep = per_kernel["standalone_phases_untimed_pass"]["phd_update_map"]
-        else:
-            dom = int(np.argmax(kern_ms))
-            dname = KERNELS[dom]
-            achieved = per_kernel[dname]["achieved_GBps"]
-            sweep = per_kernel["phd_update_map"]
+                traffic = tr["bytes"]
+                traffic_note = (f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, two child runs of this workload in this invocation: "
+                                f"avg over {tr['launches']} launches, FETCH_SIZE {tr['fetch_size_kib']} KiB, WRITE_SIZE {tr['write_size_kib']} KiB, "
+                                f"bytes = (2*FETCH + WRITE)*1024 (gfx950 correction, MI355X_MICROARCH.md)")
+        elif not args.no_pmc:
+            traffic_note = "collected at --gpus 1 only"
         out = {
             "metric": "PHD filter-update steps/sec",
-            # whole-job aggregate: every rank completes `steps` updates of its own 2000-particle shard in `dt`
-            # (weak scaling: the filter grows with the GPUs); at N=1 this is the plain filter-update rate
+            # whole-job aggregate: every rank completes `steps` updates of its own shard in `dt` (weak scaling: the filter grows
+            # with the GPUs); at N=1 this is the plain filter-update rate
             "value": round(world * args.steps / dt, 3),
             "unit": "steps/s",
             "n_gpus": world,
@@ -303,24 +396,44 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"C2a: {n_local} particles/GPU x {N_LANDMARKS} GM landmarks x {N_Z} measurements/step, all landmarks in FOV, "
-                            "2D RngBrg model, multi-feature weighting (nEvalPt 15), state re-seeded from a device snapshot every step",
+                "workload": wl["label"].format(n=n_local),
+                "workload_key": wname,
                 "particles_total": n_local * world,
-                "shards_per_gpu": S,
+                "gm_capacity": CAP,
                 "unit_definition": "one step = one update(Z) of one shard of %d particles; value sums the shard-steps of all ranks "
                                    "(global filter of %d particles: %.3f updates/s)" % (n_local, n_local * world, args.steps / dt),
-                "parallelism": f"particle-sharded: {world} GPU(s) x {S} shard(s) per GPU on separate HIP streams, RCCL all-reduce of 2 doubles/step",
-                "gm_after_update": nAfter // n_local, "gm_after_prune": nKept // n_local,
-                "kernels": per_kernel,
+                "parallelism": f"particle-sharded: {world} GPU(s), one process per GPU, RCCL all-reduce of 2 doubles/step on the engine's stream",
+                "gm_before": nM // n_local, "gm_after_update": nAfter // n_local, "gm_after_prune": nKept // n_local,
+                "kernels": {"phd_step_fused" if fused else "three_kernels": dict(ms=round(dom_ms, 5), survey_bytes_step=int(bytes_step),
+                                                                                  design_bytes=design_total),
+                            "standalone_phases_untimed_pass": per_kernel},
                 "likelihood_sweep": sweep,
             },
-            "roofline": {"bound": "hbm", "kernel": dname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(dname), "achieved_definition": how if fused else
-                         "algorithmic bytes of the launch / its HIP-event duration",
-                         "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload)"},
+            "roofline": {"bound": "hbm", "kernel": "phd_step_fused" if fused else "update_map+weighting+merge_prune",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "algorithmic_bytes": int(bytes_step),
+                         "achieved_definition": "SURVEY 8(d) bytes_step of one launch (sum over its particles) / the kernel's average HIP-event "
+                                                "duration on the engine's stream inside the timed region",
+                         "traffic_source": traffic_note,
+                         "traffic_over_algorithmic": round(traffic / bytes_step, 3) if traffic else None,
+                         "design_bytes": design_total,
+                         "design_bytes_note": "what this design's phases move by construction (w_prev plane + the weighting and merge phases' own "
+                                              "reads of the mixture); NOT used for achieved/frac",
+                         "likelihood_sweep_frac": sweep["frac"] if sweep else None,
+                         "likelihood_sweep_GBps": sweep["achieved_GBps"] if sweep else None},
         }
+        if per_step:
+            d = np.diff(np.array([t0] + per_step)) * 1e3
+            out["config"]["ms_per_step_median"] = round(float(np.median(d)), 5)
+            out["config"]["ms_per_step_p90"] = round(float(np.percentile(d, 90)), 5)
+        if solo is not None:
+            out["config"]["same_workload_single_shard_steps_per_s"] = round(solo, 3)
+            out["config"]["weak_scaling_efficiency_vs_own_shard_alone"] = round((world * args.steps / dt) / (world * solo), 4)
+        if migr is not None:
+            out["config"]["resample_migration"] = migr
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sc, scen)
+            out["cpu_baseline"] = cpu_baseline(sc, wl, n_local)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

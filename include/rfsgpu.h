@@ -269,6 +269,21 @@ int rfsgpu_resample_apply(rfsgpu_filter *f, const int *src_slot);
  * beyond n_out are dropped after the copy. */
 int rfsgpu_resample_apply_n(rfsgpu_filter *f, const int *src_slot, int n_out);
 
+/* ---- cross-shard migration for GLOBAL resampling over several GPUs ---------------------------------------
+ * The reference resamples over the whole particle set (ParticleFilter::resample, include/ParticleFilter.hpp:399-492) and a
+ * child is a deep copy of its parent (Particle::copy, include/Particle.hpp:218-223, + the per-slot birth state of
+ * include/RBPHDFilter.hpp:1005-1011).  When parent and child live on different GPUs the parent travels as one packed ROW
+ * of rfsgpu_slab_row_bytes() bytes -- pose (+ covariance), mixture, unused-measurement list, FOV count, birth candidates --
+ * between DEVICE buffers: export on the source handle, transport by the caller (RCCL send/recv between processes,
+ * hipMemcpyPeerAsync inside one process: rfsgpu_group_*), import on the destination handle.  Both calls are stream-ordered
+ * on the handle's stream and never synchronise the host; `slots` is a host array that is free again on return.
+ * Rows are only meaningful between handles of the same model and gm_capacity. */
+size_t rfsgpu_slab_row_bytes(const rfsgpu_filter *f);
+int rfsgpu_export_slab_rows(rfsgpu_filter *f, const int *slots, int n, void *dev_rows);        /* rows[k] <- particle slots[k] */
+int rfsgpu_import_slab_rows(rfsgpu_filter *f, const int *slots, int n, const void *dev_rows);  /* particle slots[k] <- rows[k] */
+/* Device pointer of the N particle weights (for an all-gather that stays on the GPUs); valid for the handle's lifetime. */
+void *rfsgpu_weights_device_ptr(rfsgpu_filter *f);
+
 /* ---- timing / misc ---------------------------------------------------------------------------- */
 
 int rfsgpu_get_timing(rfsgpu_filter *f, rfsgpu_timing *t);              /* getTimingInfo :1219-1232 */

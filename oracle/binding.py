@@ -24,6 +24,47 @@ def load():
     return C.CDLL(build())
 
 
+def build_fast():
+    """The same restatement compiled the way SURVEY 8(d) specifies the CPU baseline: -O3 -march=native -fopenmp (FMA
+    contraction on), for bench.py's `cpu_baseline` leg ONLY -- the parity tests keep the strict -O2 -ffp-contract=off
+    library.  Compiled on the machine that runs it (-march=native), keyed on the CPU model; returns (path, flags)."""
+    import hashlib
+    try:
+        model = [l for l in open("/proc/cpuinfo") if l.startswith("model name")][0].split(":", 1)[1].strip()
+    except Exception:
+        model = "unknown"
+    tag = hashlib.sha1(model.encode()).hexdigest()[:10]
+    src = os.path.join(_HERE, "rbphd_oracle.cpp")
+    out_dir = os.path.join(_HERE, "_fast")
+    os.makedirs(out_dir, exist_ok=True)
+    for flags in (["-O3", "-march=native", "-fopenmp"], ["-O3", "-march=x86-64-v3", "-fopenmp"], ["-O3", "-fopenmp"]):
+        so = os.path.join(out_dir, "librbphd_oracle_fast_%s_%s.so" % (tag, hashlib.sha1(" ".join(flags).encode()).hexdigest()[:6]))
+        if os.path.exists(so) and os.path.getmtime(so) >= os.path.getmtime(src):
+            return so, flags
+        cmd = ["g++", "-std=c++17"] + flags + ["-fPIC", "-shared", "-Wno-unused-variable", "-I" + os.path.join(_ROOT, "include"), "-o", so, src]
+        if subprocess.call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 0:
+            return so, flags
+    raise RuntimeError("could not compile the -O3 oracle for the CPU baseline")
+
+
+def cpu_info():
+    """(model name, logical CPUs, physical cores) of this host."""
+    model, cores = "unknown", set()
+    phys = core = None
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                model = l.split(":", 1)[1].strip()
+            elif l.startswith("physical id"):
+                phys = l.split(":", 1)[1].strip()
+            elif l.startswith("core id"):
+                core = l.split(":", 1)[1].strip()
+                cores.add((phys, core))
+    except Exception:
+        pass
+    return model, os.cpu_count() or 1, (len(cores) or os.cpu_count() or 1)
+
+
 def load_ref():
     """The two reference classes compiled from /root/reference (None when not built)."""
     so = os.path.join(_HERE, "_ref", "librfs_ref.so")
@@ -42,9 +83,9 @@ def _capi():
 class OracleFilter:
     """Same interface as the product's filter class, backed by the CPU restatement."""
 
-    def __new__(cls, n_particles, stable_sort=True, **kw):
+    def __new__(cls, n_particles, stable_sort=True, lib=None, **kw):
         capi = _capi()
-        lib = load()
+        lib = lib or load()
         obj = capi.CFilter(lib, "rfsor_", n_particles, **kw)
         lib.rfsor_set_stable_sort(obj._h, C.c_int(1 if stable_sort else 0))
         obj.murty_calls = lambda: _long(lib.rfsor_murty_calls, obj._h)

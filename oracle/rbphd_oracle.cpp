@@ -1852,13 +1852,73 @@ int rfsor_resample_apply_n(void *f, const int *src, int n_out) {
   if (n_out < 1 || n_out > F->n) return RFSGPU_ERR_INVALID;
   for (int k = 0; k < n_out; k++) if (src[k] < 0 || src[k] >= F->n || (src[k] < n_out && src[src[k]] != src[k])) return RFSGPU_ERR_INVALID;
   for (int k = 0; k < n_out; k++) {
-    if (src[k] != k) F->copy_particle(k, src[k]); /* (poses are the host's: it pushes the resampled poses afterwards) */
+    if (src[k] != k) { F->copy_particle(k, src[k]); F->pose[k] = F->pose[src[k]]; } /* Particle::copy carries the pose (Particle.hpp:218-223) */
     F->weight[k] = 1;
   }
   F->shrink(n_out); /* particleSet_.resize(n) (ParticleFilter.hpp:481-483); the candidate lists beyond n stay where they are */
   return RFSGPU_OK;
 }
 int rfsor_resample_apply(void *f, const int *src) { return rfsor_resample_apply_n(f, src, F_(f)->n); }
+
+/* Cross-shard migration rows (the CPU stand-in of rfsgpu_{slab_row_bytes, export_slab_rows, import_slab_rows}): the same
+ * content -- pose (+ covariance), mixture, unused list, FOV count, birth candidates (Particle::copy,
+ * include/Particle.hpp:218-223; RBPHDFilter.hpp:1005-1011) -- in a fixed-size record in HOST memory, so that the multi-GPU
+ * host logic (rfs-slam_amd/sharded.py) runs unchanged over gloo with this library on every rank. */
+enum { ROW_MAXG = 1024, ROW_HDR = 96 };
+static size_t row_doubles(const FilterBase *F) {
+  return ROW_HDR + (size_t)ROW_MAXG * (2 + F->dm + F->dm * F->dm) + (size_t)RFSGPU_MAX_CANDIDATES * (F->dm + F->dm * F->dm + 2);
+}
+size_t rfsor_slab_row_bytes(const void *f) { return row_doubles((const FilterBase *)f) * sizeof(double); }
+int rfsor_export_slab_rows(void *f, const int *slots, int n, void *rows) {
+  FilterBase *F = F_(f);
+  const int D = F->dm;
+  for (int k = 0; k < n; k++) {
+    const int s = slots[k];
+    if (s < 0 || s >= F->n) return RFSGPU_ERR_INVALID;
+    double *r = (double *)rows + (size_t)k * row_doubles(F);
+    const int cnt = F->gm_size(s);
+    if (cnt > ROW_MAXG || (int)F->unused[s].size() > 64) return RFSGPU_ERR_CAPACITY;
+    r[0] = cnt; r[1] = F->nInFov[s]; r[2] = (double)F->unused[s].size();
+    for (size_t u = 0; u < F->unused[s].size(); u++) r[3 + u] = F->unused[s][u];
+    memcpy(r + 67, F->pose[s].x, 3 * sizeof(double));
+    memcpy(r + 70, F->pose[s].P, 9 * sizeof(double));
+    double *g = r + ROW_HDR, *gw = g, *gwp = g + ROW_MAXG, *gm = gwp + ROW_MAXG, *gc = gm + (size_t)ROW_MAXG * D;
+    F->export_gm(s, ROW_MAXG, gw, gwp, gm, gc);
+    double *c = gc + (size_t)ROW_MAXG * D * D, *cmean = c, *ccov = cmean + RFSGPU_MAX_CANDIDATES * D;
+    std::vector<int> sup(RFSGPU_MAX_CANDIDATES), chk(RFSGPU_MAX_CANDIDATES);
+    const int nc = F->export_candidates(s, RFSGPU_MAX_CANDIDATES, cmean, ccov, sup.data(), chk.data());
+    if (nc > RFSGPU_MAX_CANDIDATES) return RFSGPU_ERR_CAPACITY;
+    r[79] = nc;
+    double *ci = ccov + (size_t)RFSGPU_MAX_CANDIDATES * D * D;
+    for (int q = 0; q < nc; q++) { ci[2 * q] = sup[q]; ci[2 * q + 1] = chk[q]; }
+  }
+  return RFSGPU_OK;
+}
+int rfsor_import_slab_rows(void *f, const int *slots, int n, const void *rows) {
+  FilterBase *F = F_(f);
+  const int D = F->dm;
+  for (int k = 0; k < n; k++) {
+    const int s = slots[k];
+    if (s < 0 || s >= F->n) return RFSGPU_ERR_INVALID;
+    const double *r = (const double *)rows + (size_t)k * row_doubles(F);
+    const int cnt = (int)r[0];
+    F->nInFov[s] = (unsigned)r[1];
+    F->unused[s].clear();
+    for (int u = 0; u < (int)r[2]; u++) F->unused[s].push_back((unsigned)r[3 + u]);
+    memcpy(F->pose[s].x, r + 67, 3 * sizeof(double));
+    memcpy(F->pose[s].P, r + 70, 9 * sizeof(double));
+    const double *g = r + ROW_HDR, *gw = g, *gm = g + 2 * (size_t)ROW_MAXG, *gc = gm + (size_t)ROW_MAXG * D;
+    F->import_gm(s, cnt, gw, gm, gc);
+    const double *c = gc + (size_t)ROW_MAXG * D * D, *cmean = c, *ccov = cmean + RFSGPU_MAX_CANDIDATES * D;
+    const double *ci = ccov + (size_t)RFSGPU_MAX_CANDIDATES * D * D;
+    const int nc = (int)r[79];
+    std::vector<int> sup(nc), chk(nc);
+    for (int q = 0; q < nc; q++) { sup[q] = (int)ci[2 * q]; chk[q] = (int)ci[2 * q + 1]; }
+    F->import_candidates(s, nc, cmean, ccov, sup.data(), chk.data());
+  }
+  return RFSGPU_OK;
+}
+void *rfsor_weights_device_ptr(void *f) { return (void *)F_(f)->weight.data(); }
 int rfsor_fastslam_set_resample_occured(void *f, int flag) { F_(f)->fs_resample_occured = flag != 0; return RFSGPU_OK; }
 int rfsor_particle_parents(void *f, int *parent, int max_n) {
   FilterBase *F = F_(f);

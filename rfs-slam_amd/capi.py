@@ -116,6 +116,7 @@ ABI_SYMBOLS = [
     "default_fastslam_config", "set_fastslam_config", "get_fastslam_config", "fastslam_update",
     "normalize_weights_parts", "create_ex", "n_particles", "max_particles", "resample_apply_n",
     "fastslam_set_resample_occured", "particle_parents", "vp_probe_pd",
+    "slab_row_bytes", "export_slab_rows", "import_slab_rows", "weights_device_ptr",
 ]
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -141,6 +142,7 @@ class CFilter:
     def __init__(self, lib, prefix, n_particles, model=MODEL_RNGBRG_2D, device_id=0, gm_capacity=512, max_particles=None):
         self._lib, self._p = lib, prefix
         self.model = model
+        self.device_id = device_id
         self.dm = self.dz = 3 if model == MODEL_VICTORIAPARK_3D else 2
         self._h = C.c_void_p()
         fn = self._fn("create_ex")
@@ -426,6 +428,25 @@ class CFilter:
         else:
             assert s.size == n_out
             self._call("resample_apply_n", self._ptr(s), C.c_int(int(n_out)))
+
+    # -- cross-shard migration (packed rows in the backend's own memory space: device memory for the engine) ----------
+    def slab_row_bytes(self):
+        fn = self._fn("slab_row_bytes")
+        fn.restype = C.c_size_t
+        return int(fn(self._h))
+
+    def export_slab_rows(self, slots, rows_ptr):
+        s = np.ascontiguousarray(slots, dtype=np.int32)
+        self._call("export_slab_rows", self._ptr(s), C.c_int(s.size), C.c_void_p(rows_ptr))
+
+    def import_slab_rows(self, slots, rows_ptr):
+        s = np.ascontiguousarray(slots, dtype=np.int32)
+        self._call("import_slab_rows", self._ptr(s), C.c_int(s.size), C.c_void_p(rows_ptr))
+
+    def weights_device_ptr(self):
+        fn = self._fn("weights_device_ptr")
+        fn.restype = C.c_void_p
+        return fn(self._h)
 
     # -- timing --------------------------------------------------------------------------------
     def getTimingInfo(self):

@@ -759,7 +759,7 @@ __global__ void set_weights_kernel(double *w, int N, double v) {
 
 // Resample copy: slot k takes slot src[k]'s mixture (Particle::copy -> GaussianMixture copy ctor).
 // One block per destination slot; sources are slots that keep themselves, so in-place is hazard-free.
-__global__ __launch_bounds__(256) void resample_gather_kernel(Buffers B, int cur, const int *srcSlot) {
+__global__ __launch_bounds__(256) void resample_gather_kernel(Buffers B, int cur, const int *srcSlot, int poseCovStride) {
   const int k = blockIdx.x;
   const int s = srcSlot[k];
   if (s == k) return;
@@ -778,11 +778,67 @@ __global__ __launch_bounds__(256) void resample_gather_kernel(Buffers B, int cur
     B.candSup[(size_t)k * RFSGPU_MAX_CANDIDATES + t] = B.candSup[(size_t)s * RFSGPU_MAX_CANDIDATES + t];
     B.candChk[(size_t)k * RFSGPU_MAX_CANDIDATES + t] = B.candChk[(size_t)s * RFSGPU_MAX_CANDIDATES + t];
   }
+  // the pose travels with the particle too (Particle::copy, include/Particle.hpp:218-223)
+  if (threadIdx.x < 3) B.pose[3 * (size_t)k + threadIdx.x] = B.pose[3 * (size_t)s + threadIdx.x];
+  if (poseCovStride == 9 && threadIdx.x < 9) B.poseCov[9 * (size_t)k + threadIdx.x] = B.poseCov[9 * (size_t)s + threadIdx.x];
   if (threadIdx.x == 0) {
     B.count[k] = n;
     B.unusedMask[k] = B.unusedMask[s];
     B.nInFov[k] = B.nInFov[s];
     B.candCount[k] = nc;
+  }
+}
+
+// ---- cross-shard migration of whole particles (multi-GPU resampling) ----------------------------------------
+// A particle leaves / enters a shard as one fixed-size packed ROW in a device buffer: header (16 doubles: count, FOV count,
+// unused mask, pose, pose covariance, candidate count) | npl planes of `cap` doubles (the first `count` of each are live) |
+// the birth-candidate block.  The rows of all migrants of a step sit back to back, so that the transport (RCCL send/recv
+// between processes, hipMemcpyPeerAsync inside one process) moves device memory to device memory and the host only ever
+// sees slot indices.  What Particle::copy + RBPHDFilter.hpp:1005-1011 carry: pose, mixture, unused list, FOV count, candidates.
+#define RFSGPU_ROW_HEADER_DOUBLES 16
+__host__ __device__ inline size_t slab_row_bytes(int npl, int cap) {
+  return (size_t)RFSGPU_ROW_HEADER_DOUBLES * 8 + (size_t)npl * cap * 8 + (size_t)RFSGPU_MAX_CANDIDATES * (3 + 6) * 8 + (size_t)RFSGPU_MAX_CANDIDATES * 2 * 4;
+}
+template <bool EXPORT>
+__global__ __launch_bounds__(256) void slab_rows_kernel(Buffers B, int cur, const int *slots, unsigned char *rows, int poseCovStride) {
+  const int s = slots[blockIdx.x];
+  unsigned char *row = rows + (size_t)blockIdx.x * slab_row_bytes(B.npl, B.cap);
+  double *hdr = reinterpret_cast<double *>(row);
+  double *pl = hdr + RFSGPU_ROW_HEADER_DOUBLES;
+  double *cm = pl + (size_t)B.npl * B.cap, *cc = cm + RFSGPU_MAX_CANDIDATES * 3;
+  int *cs = reinterpret_cast<int *>(cc + RFSGPU_MAX_CANDIDATES * 6), *ck = cs + RFSGPU_MAX_CANDIDATES;
+  double *slab = B.slab[cur] + (size_t)s * B.npl * (size_t)B.cap;
+  const size_t cb = (size_t)s * RFSGPU_MAX_CANDIDATES;
+  if (EXPORT) {
+    const int n = B.count[s], nc = B.candCount[s];
+    for (int p = 0; p < B.npl; p++)
+      for (int m = threadIdx.x; m < n; m += blockDim.x) pl[(size_t)p * B.cap + m] = slab[(size_t)p * B.cap + m];
+    for (int t = threadIdx.x; t < nc * 3; t += blockDim.x) cm[t] = B.candMean[cb * 3 + t];
+    for (int t = threadIdx.x; t < nc * 6; t += blockDim.x) cc[t] = B.candCov[cb * 6 + t];
+    for (int t = threadIdx.x; t < nc; t += blockDim.x) { cs[t] = B.candSup[cb + t]; ck[t] = B.candChk[cb + t]; }
+    if (threadIdx.x < 3) hdr[3 + threadIdx.x] = B.pose[3 * (size_t)s + threadIdx.x];
+    if (threadIdx.x < 9) hdr[6 + threadIdx.x] = B.poseCov[(size_t)poseCovStride * s + threadIdx.x];
+    if (threadIdx.x == 0) {
+      hdr[0] = (double)n;
+      hdr[1] = (double)B.nInFov[s];
+      hdr[2] = __longlong_as_double((long long)B.unusedMask[s]);
+      hdr[15] = (double)nc;
+    }
+  } else {
+    const int n = (int)hdr[0], nc = (int)hdr[15];
+    for (int p = 0; p < B.npl; p++)
+      for (int m = threadIdx.x; m < n; m += blockDim.x) slab[(size_t)p * B.cap + m] = pl[(size_t)p * B.cap + m];
+    for (int t = threadIdx.x; t < nc * 3; t += blockDim.x) B.candMean[cb * 3 + t] = cm[t];
+    for (int t = threadIdx.x; t < nc * 6; t += blockDim.x) B.candCov[cb * 6 + t] = cc[t];
+    for (int t = threadIdx.x; t < nc; t += blockDim.x) { B.candSup[cb + t] = cs[t]; B.candChk[cb + t] = ck[t]; }
+    if (threadIdx.x < 3) B.pose[3 * (size_t)s + threadIdx.x] = hdr[3 + threadIdx.x];
+    if (poseCovStride == 9 && threadIdx.x < 9) B.poseCov[9 * (size_t)s + threadIdx.x] = hdr[6 + threadIdx.x];
+    if (threadIdx.x == 0) {
+      B.count[s] = n;
+      B.nInFov[s] = (int)hdr[1];
+      B.unusedMask[s] = (unsigned long long)__double_as_longlong(hdr[2]);
+      B.candCount[s] = nc;
+    }
   }
 }
 

@@ -60,6 +60,7 @@ struct rfsgpu_filter {
   int nZ = 0;  // measurements of the last update (birth uses them)
   double *dSums = nullptr;  // [2]
   int *dSrcSlot = nullptr;  // [N]
+  int *dRowSlots = nullptr; // [Ncap] slots of the rows being exported / imported (allocated on first use)
   MurtyQueue Q{};
   MurtyScratch MS{};
   int *hErr = nullptr;      // pinned
@@ -301,7 +302,7 @@ void rfsgpu_destroy(rfsgpu_filter *f) {
   Buffers &B = f->B;
   hipFree(f->snapSlab); hipFree(f->snapWeight); hipFree(f->snapCount); hipFree(f->snapFov); hipFree(f->snapUnused);
   hipFree(B.slab[0]); hipFree(B.slab[1]); hipFree(B.count); hipFree(B.pose); hipFree(B.poseCov); hipFree(B.weight);
-  hipFree(B.unusedMask); hipFree(B.nInFov); hipFree(B.err); hipFree(B.Z); hipFree(f->ownSums); hipFree(f->dSrcSlot); if (f->fsArena) hipFree(f->fsArena); if (f->mhArena) hipFree(f->mhArena); if (f->mhInts) hipFree(f->mhInts);
+  hipFree(B.unusedMask); hipFree(B.nInFov); hipFree(B.err); hipFree(B.Z); hipFree(f->ownSums); hipFree(f->dSrcSlot); if (f->dRowSlots) hipFree(f->dRowSlots); if (f->fsArena) hipFree(f->fsArena); if (f->mhArena) hipFree(f->mhArena); if (f->mhInts) hipFree(f->mhInts);
   hipFree(B.scan); hipFree(B.candMean); hipFree(B.candCov); hipFree(B.candSup); hipFree(B.candChk); hipFree(B.candCount);
   murty_free(f->Q, f->MS);
   if (f->hErr) hipHostFree(f->hErr);
@@ -1016,7 +1017,7 @@ int rfsgpu_resample_apply_n(rfsgpu_filter *f, const int *src_slot, int n_out) {
   long long t0 = now_ns();
   HIPCHK(hipMemcpyAsync(f->dSrcSlot, src_slot, (size_t)f->N * sizeof(int), hipMemcpyHostToDevice, f->stream));
   HIPCHK(hipEventRecord(f->ev[EV_R0], f->stream));
-  resample_gather_kernel<<<f->N, 256, 0, f->stream>>>(f->B, f->cur, f->dSrcSlot);
+  resample_gather_kernel<<<f->N, 256, 0, f->stream>>>(f->B, f->cur, f->dSrcSlot, f->P.poseCovStride);
   set_weights_kernel<<<(f->N + 255) / 256, 256, 0, f->stream>>>(f->B.weight, f->N, 1.0);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(f->ev[EV_R1], f->stream));
@@ -1025,6 +1026,31 @@ int rfsgpu_resample_apply_n(rfsgpu_filter *f, const int *src_slot, int n_out) {
   f->timing.particleResample_cpu += now_ns() - t0;
   return RFSGPU_OK;
 }
+
+// ---- cross-shard migration (multi-GPU resampling): packed rows in DEVICE buffers, stream-ordered, no host sync -----------
+size_t rfsgpu_slab_row_bytes(const rfsgpu_filter *f) { return f ? slab_row_bytes(f->B.npl, f->cap) : 0; }
+static int slab_rows(rfsgpu_filter *f, const int *slots, int n, void *dev_rows, bool exporting) {
+  if (n == 0) return RFSGPU_OK;
+  if (!slots || !dev_rows || n < 0 || n > f->N) return fail(f, RFSGPU_ERR_INVALID, "slab rows: bad arguments");
+  for (int k = 0; k < n; k++)
+    if (slots[k] < 0 || slots[k] >= f->N) return fail(f, RFSGPU_ERR_INVALID, "slab rows: slot out of range");
+  hipSetDevice(f->device);
+  if (!f->dRowSlots) HIPCHK(hipMalloc(&f->dRowSlots, (size_t)f->Ncap * sizeof(int)));
+  HIPCHK(hipMemcpyAsync(f->dRowSlots, slots, (size_t)n * sizeof(int), hipMemcpyHostToDevice, f->stream));
+  if (exporting) slab_rows_kernel<true><<<n, 256, 0, f->stream>>>(f->B, f->cur, f->dRowSlots, (unsigned char *)dev_rows, f->P.poseCovStride);
+  else slab_rows_kernel<false><<<n, 256, 0, f->stream>>>(f->B, f->cur, f->dRowSlots, (unsigned char *)dev_rows, f->P.poseCovStride);
+  HIPCHK(hipGetLastError());
+  return RFSGPU_OK;
+}
+int rfsgpu_export_slab_rows(rfsgpu_filter *f, const int *slots, int n, void *dev_rows) {
+  CHECK_HANDLE(f);
+  return slab_rows(f, slots, n, dev_rows, true);
+}
+int rfsgpu_import_slab_rows(rfsgpu_filter *f, const int *slots, int n, const void *dev_rows) {
+  CHECK_HANDLE(f);
+  return slab_rows(f, slots, n, const_cast<void *>(dev_rows), false);
+}
+void *rfsgpu_weights_device_ptr(rfsgpu_filter *f) { return f ? (void *)f->B.weight : nullptr; }
 
 // ---- timing / misc -----------------------------------------------------------------------------------
 

@@ -46,6 +46,7 @@ class RBPHDFilter(capi.CFilter):
         self.nUpdatesSinceResample = 0
         self.nMeasurementsSinceResample = 0
         self.resampleOccured = False
+        self.last_resample_plan = None    # src slot per slot of the last resampling that fired (None when the last call did not)
 
     # ParticleFilter::setEffectiveParticleCountThreshold (ParticleFilter.hpp:386-391)
     def setEffectiveParticleCountThreshold(self, t):
@@ -122,6 +123,7 @@ class RBPHDFilter(capi.CFilter):
     # (FastSLAM::resampleWithMapCopy after multi-hypothesis growth).  The plan of the last resampling stays in
     # `last_resample_plan` so that a caller holding per-particle host data (poses) can apply the same copies.
     def resample(self, u01_fn=np.random.random, n_out=0, force=False):
+        self.last_resample_plan = None
         s = self.weight_sums()
         self.normalize_weights(s[0])
         w = self.get_weights()
@@ -194,6 +196,37 @@ def systematic_resample_plan(w, u01, n_out=None):
     copied into the first n_out slots (cases 1-4 of :459-478); the returned plan has n_out entries."""
     if n_out is not None and n_out < w.size:
         return _systematic_resample_plan_shrink(w, u01, int(n_out))
+    w = np.asarray(w, dtype=np.float64)
+    n = w.size
+    if n >= 256 and not (w < 0).any() and np.isfinite(w).all():
+        return _systematic_resample_plan_vectorised(w, u01)
+    return _systematic_resample_plan_loop(w, u01)
+
+
+def _systematic_resample_plan_vectorised(w, u01):
+    """The same plan without Python loops (20 000 particles at configs[2]).  np.cumsum adds sequentially in index order, i.e.
+    the reference's `cumulative_weight += w[idx]` and `sample_point += sample_interval` roundings exactly; with non-negative
+    weights the running sum is non-decreasing, so `while (sample_point > cumulative && idx < n-1) idx++` is a search."""
+    n = w.size
+    interval = 1.0 / float(n)
+    cum = np.cumsum(w)
+    steps = np.full(n, interval)
+    steps[0] = interval * u01
+    sp = np.cumsum(steps)
+    sampled_idx = np.minimum(np.searchsorted(cum, sp, side="left"), n - 1)
+    sampled_idx = np.maximum.accumulate(sampled_idx)      # (idx never moves back; a no-op for monotone sums)
+    sampled = np.zeros(n, dtype=bool)
+    sampled[sampled_idx] = True
+    first = np.ones(n, dtype=bool)
+    first[1:] = sampled_idx[1:] != sampled_idx[:-1]
+    dups = sampled_idx[~first]                             # sources of the copies, in sampling order
+    free = np.nonzero(~sampled)[0]                         # un-sampled slots, ascending: they take the copies in order
+    src = np.arange(n, dtype=np.int32)
+    src[free[:dups.size]] = dups
+    return src
+
+
+def _systematic_resample_plan_loop(w, u01):
     n = w.size
     interval = 1.0 / float(n)
     sample_point = interval * u01

@@ -2,14 +2,18 @@
 
 Every phase of RBPHDFilter::update() before resampling is independent per particle (reference
 include/RBPHDFilter.hpp:469-520), so the only collective on the per-step path is the all-reduce (sum) of
-{sum w, sum w^2} -- 2 doubles over RCCL/xGMI -- for ParticleFilter::normalizeWeights / the N_eff test
-(include/ParticleFilter.hpp:352-363, 405-415).  When resampling fires, the reference's GLOBAL systematic
-resampling (ParticleFilter.hpp:419-479) is kept: the N weights are all-gathered, every rank computes the same plan
-from the same uniform draw, local children are a device gather (rfsgpu_resample_apply), cross-shard children migrate
-as packed mixtures.  Shard-local resampling would change results and is not offered.
+{sum w, sum w^2} -- 2 doubles over RCCL/xGMI, written by the engine into a device tensor and consumed on the device -- for
+ParticleFilter::normalizeWeights / the N_eff test (include/ParticleFilter.hpp:352-363, 405-415).  When resampling fires, the
+reference's GLOBAL systematic resampling (ParticleFilter.hpp:419-479) is kept: the N weights are all-gathered (device
+tensors), every rank computes the same plan from the same uniform draw, local children are a device gather
+(rfsgpu_resample_apply), cross-shard children migrate as packed rows from device memory to device memory
+(rfsgpu_export_slab_rows -> RCCL send/recv -> rfsgpu_import_slab_rows): the host only ever handles slot indices.
+Shard-local resampling would change results and is not offered.
 
-Backend-agnostic: `local` is any object with the filter interface of capi.CFilter (the device engine in production;
-tests substitute a CPU stand-in to exercise this host logic under gloo).
+Backend-agnostic: `local` is any object with the filter interface of capi.CFilter (the device engine in production; the
+tests substitute the CPU oracle, whose rows live in host memory, to run this host logic under gloo).  With the gloo backend
+and device rows (two ranks sharing one GPU in the tests) the rows are staged through the host, because gloo has no
+device-to-device send/recv; over RCCL ("nccl") nothing is staged.
 """
 import numpy as np
 import torch
@@ -18,45 +22,84 @@ import torch.distributed as dist
 from .engine import systematic_resample_plan
 
 
+class _DevArray:
+    """Zero-copy view of engine-owned device memory for torch (CUDA array interface v2)."""
+
+    def __init__(self, ptr, n, typestr="<f8"):
+        self.__cuda_array_interface__ = dict(shape=(n,), typestr=typestr, data=(int(ptr), False), version=2, strides=None)
+
+
 class ShardedRBPHDFilter:
-    def __init__(self, local, group=None, device=None):
+    def __init__(self, local, group=None, device=None, stream=None, sums=None):
         self.f = local
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.backend = dist.get_backend(group) if dist.is_initialized() else None
         self.n_local = local.n
         self.n_total = self.n_local * self.world
-        self.device = device if device is not None else torch.device("cpu")
+        if device is None:   # the device engine's rows / sums / weights are device memory; any other backend (the CPU oracle) lives on the host
+            device = torch.device("cuda", local.device_id) if getattr(local, "_p", "") == "rfsgpu_" else torch.device("cpu")
+        self.device = device
+        self.on_gpu = self.device.type == "cuda"
         self.effNParticles_t = self.n_total / 4.0          # ParticleFilter.hpp:232
         self.nUpdatesSinceResample = 0
         self.nMeasurementsSinceResample = 0
         self.resampleOccured = False
+        self.last_resample_plan = None                     # global slot -> global source slot of the last resampling
+        self.last_migration = dict(rows_sent=0, rows_received=0, bytes_sent=0)
+        self.stream = None
+        self.sums = None
+        self._w_view = None
+        if self.on_gpu:
+            # engine kernels, the RCCL collectives and the row transport all order on ONE stream; the weight sums live in a
+            # device tensor that the all-reduce updates in place and normalize_kernel reads: no host round trip per step
+            self.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
+            self.f.set_stream(self.stream.cuda_stream)
+            self.sums = sums if sums is not None else torch.zeros(2, dtype=torch.float64, device=self.device)
+            self.f.bind_weight_sums_buffer(self.sums.data_ptr())
+            try:
+                self._w_view = torch.as_tensor(_DevArray(self.f.weights_device_ptr(), self.n_local), device=self.device)
+            except Exception:
+                self._w_view = None                        # (fallback: weights through the host, see gather_weights)
 
     # -- collectives ---------------------------------------------------------------------------------------
-    def _allreduce_sums(self, sums_tensor=None):
-        """{sum w, sum w^2} over all shards.  With a device tensor bound to the engine the reduction never
-        leaves the GPU; otherwise the 2 doubles go through a host tensor (tests / CPU stand-in)."""
-        if sums_tensor is not None:
+    def _stream_ctx(self):
+        return torch.cuda.stream(self.stream) if self.on_gpu else _NullCtx()
+
+    def normalize(self, need_totals=False):
+        """normalizeWeights over ALL shards.  Device engine: weight sums -> all-reduce in place -> on-device divide, all on
+        the engine's stream; the two totals come back to the host only when the caller needs N_eff (16 bytes)."""
+        if self.on_gpu:
             self.f.weight_sums_async()
             if self.world > 1:
-                dist.all_reduce(sums_tensor, group=self.group)
-            return sums_tensor
-        s = torch.from_numpy(np.asarray(self.f.weight_sums(), dtype=np.float64)).to(self.device)
+                with self._stream_ctx():
+                    dist.all_reduce(self.sums, group=self.group)
+            self.f.normalize_weights(0.0, self.sums.data_ptr())   # divisor read on the device
+            if not need_totals:
+                return None
+            with self._stream_ctx():
+                tot = self.sums.cpu()
+            return tot.numpy()
+        s = torch.from_numpy(np.asarray(self.f.weight_sums(), dtype=np.float64))
         if self.world > 1:
             dist.all_reduce(s, group=self.group)
-        return s
-
-    def normalize(self, sums_tensor=None):
-        s = self._allreduce_sums(sums_tensor)
-        if sums_tensor is not None:
-            self.f.normalize_weights(0.0, sums_tensor.data_ptr())   # divisor read on the device
-            return None
-        tot = s.cpu().numpy()
+        tot = s.numpy()
         self.f.normalize_weights(float(tot[0]))
         return tot
 
     def gather_weights(self):
-        w = torch.from_numpy(self.f.get_weights()).to(self.device)
+        """All N weights on every rank (host array, for the systematic-resampling plan): all-gather of device tensors."""
+        if self.on_gpu and self._w_view is not None:
+            with self._stream_ctx():
+                if self.world == 1:
+                    return self._w_view.cpu().numpy()
+                out = torch.empty(self.n_total, dtype=torch.float64, device=self.device)
+                dist.all_gather_into_tensor(out, self._w_view, group=self.group)
+                return out.cpu().numpy()
+        w = torch.from_numpy(self.f.get_weights())
+        if self.on_gpu:
+            w = w.to(self.device)
         if self.world == 1:
             return w.cpu().numpy()
         out = [torch.empty_like(w) for _ in range(self.world)]
@@ -70,7 +113,10 @@ class ShardedRBPHDFilter:
         if Z.shape[0] == 0:
             return False
         self.nMeasurementsSinceResample += Z.shape[0]
-        self.f.update(Z)
+        if self.on_gpu:
+            self.f.update_async(Z)        # stream-ordered; device errors surface at the next synchronize()
+        else:
+            self.f.update(Z)
         cfg = self.f.get_filter_config()
         self.resampleOccured = False
         if (self.nUpdatesSinceResample >= cfg.minUpdatesBeforeResample and
@@ -80,52 +126,125 @@ class ShardedRBPHDFilter:
             self.nUpdatesSinceResample = 0
             self.nMeasurementsSinceResample = 0
         else:
-            self.normalize()
+            self.normalize()          # (after a resample() that did not fire this is a second division, as in the reference :537-539)
+        if self.on_gpu:
+            self.f.synchronize()
         return self.resampleOccured
 
     # -- ParticleFilter::resample with global semantics (:399-492) -----------------------------------------
     def resample(self, u01=None):
-        tot = self.normalize()                        # weights now sum to 1 across all shards
+        self.last_resample_plan = None
+        tot = self.normalize(need_totals=True)        # weights now sum to 1 across all shards
         # N_eff = 1 / sum (w_i / S)^2 = S^2 / sum w_i^2  (tot holds the pre-normalisation sums)
         neff = float(tot[0] * tot[0] / tot[1])
         if neff > self.effNParticles_t and neff / self.n_total > self.effNParticles_t / self.n_total:
             return False
         # one uniform draw for the whole filter (the reference's single drand48()): rank 0 decides
-        u = torch.tensor([np.random.random() if u01 is None else float(u01)], dtype=torch.float64, device=self.device)
+        u = torch.tensor([np.random.random() if u01 is None else float(u01)], dtype=torch.float64)
         if self.world > 1:
-            dist.broadcast(u, 0, group=self.group)
+            if self.on_gpu and self.backend == "nccl":
+                with self._stream_ctx():
+                    ud = u.to(self.device)
+                    dist.broadcast(ud, 0, group=self.group)
+                    u = ud.cpu()
+            else:
+                dist.broadcast(u, 0, group=self.group)
         w_all = self.gather_weights()
         plan = systematic_resample_plan(w_all, float(u.item()))   # global slot -> global source slot
         self.apply_plan(plan)
+        self.last_resample_plan = plan
         return True
 
     def apply_plan(self, plan):
-        n, r = self.n_local, self.rank
+        """Carry out a global resampling plan: cross-shard children first leave as packed rows (device memory), local
+        children are a device gather, then the received rows are unpacked into this shard's dead slots."""
+        n, r, W = self.n_local, self.rank, self.world
         lo = r * n
-        # 1. what I must send: children on other ranks whose source is one of my slots
-        outgoing = {}
-        for g in np.nonzero(plan != np.arange(self.n_total))[0]:
-            s = int(plan[g])
-            if lo <= s < lo + n and not (lo <= g < lo + n):
-                w, _, mean, cov = self.f.export_gm(s - lo)
-                outgoing[int(g)] = (w, mean, cov, self.f.get_unused(s - lo), self.f.landmarks_in_fov(s - lo),
-                                    self.f.export_birth_candidates(s - lo))
-        if self.world > 1:
-            gathered = [None] * self.world
-            dist.all_gather_object(gathered, outgoing, group=self.group)
-        else:
-            gathered = [outgoing]
-        # 2. local children: device gather (sources keep themselves, so in place is hazard-free)
-        local_src = np.arange(n, dtype=np.int32)
-        for k in range(n):
-            s = int(plan[lo + k])
-            if lo <= s < lo + n:
-                local_src[k] = s - lo
-        self.f.resample_apply(local_src)              # also resets every weight to 1 (ParticleFilter.hpp:486-489)
-        # 3. migrated children: import the packed mixtures into the dead slots
-        for d in gathered:
-            for g, (w, mean, cov, unused, nfov, cands) in d.items():
-                if lo <= g < lo + n:
-                    self.f.import_gm(g - lo, w, mean, cov)
-                    self.f.import_aux(g - lo, unused, nfov)
-                    self.f.import_birth_candidates(g - lo, *cands)   # birthGaussians_ travel with the particle (:1005-1011)
+        plan = np.asarray(plan, dtype=np.int64)
+        g_all = np.nonzero(plan != np.arange(self.n_total))[0]             # children (ascending global slot)
+        src_rank, dst_rank = plan[g_all] // n, g_all // n
+        cross = src_rank != dst_rank
+        # rows I send, grouped by destination rank, children in ascending order (the receiver derives the same order)
+        send_g = [g_all[cross & (src_rank == r) & (dst_rank == d)] for d in range(W)]
+        recv_g = [g_all[cross & (dst_rank == r) & (src_rank == s)] for s in range(W)]
+        n_send, n_recv = sum(len(x) for x in send_g), sum(len(x) for x in recv_g)
+        R = self.f.slab_row_bytes() if (n_send or n_recv) else 0
+        rows_dev = self.device if self.on_gpu else torch.device("cpu")
+        with self._stream_ctx():
+            send_buf = torch.empty(max(n_send, 1) * max(R, 1), dtype=torch.uint8, device=rows_dev)
+            recv_buf = torch.empty(max(n_recv, 1) * max(R, 1), dtype=torch.uint8, device=rows_dev)
+            if n_send:
+                slots = np.concatenate([plan[g] - lo for g in send_g]).astype(np.int32)
+                self.f.export_slab_rows(slots, send_buf.data_ptr())
+            if W > 1 and (n_send or n_recv):
+                staged = self.on_gpu and self.backend != "nccl"          # gloo: no device-to-device send/recv
+                sb = send_buf.cpu() if staged else send_buf
+                rb = torch.empty_like(recv_buf, device="cpu") if staged else recv_buf
+                ops, off = [], 0
+                for d in range(W):
+                    k = len(send_g[d])
+                    if k:
+                        ops.append(dist.P2POp(dist.isend, sb[off * R:(off + k) * R], d, group=self.group))
+                        off += k
+                off = 0
+                for s in range(W):
+                    k = len(recv_g[s])
+                    if k:
+                        ops.append(dist.P2POp(dist.irecv, rb[off * R:(off + k) * R], s, group=self.group))
+                        off += k
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()                                           # nccl: the stream waits; gloo: the host does
+                if staged:
+                    recv_buf.copy_(rb)
+            # local children: device gather (sources keep themselves, so in place is hazard-free); resets every weight to 1
+            local_src = np.arange(n, dtype=np.int32)
+            mine = g_all[(dst_rank == r) & ~cross]
+            local_src[mine - lo] = (plan[mine] - lo).astype(np.int32)
+            self.f.resample_apply(local_src)
+            if n_recv:
+                slots = (np.concatenate(recv_g) - lo).astype(np.int32)
+                self.f.import_slab_rows(slots, recv_buf.data_ptr())
+            if self.on_gpu:
+                self.f.synchronize()                                     # the buffers may be released after this
+        self.last_migration = dict(rows_sent=int(n_send), rows_received=int(n_recv), bytes_sent=int(n_send * R))
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def bench_resample_migration(pkg, f, rank, world, dev, stream=None, sums=None, reps=3):
+    """bench.py's separate figure: ONE global resampling step with cross-shard migration on the benchmark's shards.  The
+    weights are skewed by rank (rank r's particles weigh r + 1), so the systematic plan sends about a third of the
+    higher ranks' particles' children to lower ranks.  Returns max-over-ranks time, rows and bytes moved."""
+    import time
+    sh = ShardedRBPHDFilter(f, device=dev, stream=stream, sums=sums)
+    sh.effNParticles_t = sh.n_total + 1.0                       # force
+    times = []
+    for rep in range(reps + 1):
+        f.restore_state()
+        f.set_weights(np.full(f.n, float(rank + 1)))
+        f.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        fired = sh.resample(u01=0.37)
+        f.synchronize()
+        dt = time.perf_counter() - t0
+        assert fired
+        if rep:
+            times.append(dt)
+    t = torch.tensor([float(np.median(times)), float(sh.last_migration["rows_sent"]), float(sh.last_migration["bytes_sent"])],
+                     dtype=torch.float64, device=dev)
+    tmax = t.clone()
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return dict(ms=round(float(tmax[0]) * 1e3, 4), rows_migrated_total=int(t[1].item()), bytes_migrated_total=int(t[2].item()),
+                row_bytes=int(f.slab_row_bytes()),
+                note="one forced global systematic resampling: all-reduce + all-gather of the weights, plan on the host, local gather, "
+                     "cross-shard children as packed rows device->device over RCCL send/recv; weights skewed by rank so that rows move")

@@ -31,7 +31,17 @@ def shard_scen(scen, rank, world):
     return out
 
 
-def _worker(rank, world, port, n_total, force_resample, q):
+def make_scen(sc, n_total, big=False):
+    if big:   # configs[2]-sized mixtures: 500 Gaussians per particle, 5 m range limit
+        scen = sc.make_scenario(n_total, 500, 30, seed=77, rmax=5.0, params=dict(min_updates=1))
+        scen["particle_w"] = np.random.default_rng(3).uniform(0.05, 1.0, n_total) ** 3
+    else:
+        scen = sc.make_scenario(n_total, 40, 12, seed=31, params=dict(min_updates=1))
+        scen["particle_w"] = np.random.default_rng(1).uniform(0.2, 1.0, n_total)
+    return scen
+
+
+def _worker(rank, world, port, n_total, force_resample, q, big=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -41,25 +51,26 @@ def _worker(rank, world, port, n_total, force_resample, q):
     pkg = load_package()
     sc = pkg.scenarios
     ob.set_threads(1)
-    scen = sc.make_scenario(n_total, 40, 12, seed=31, params=dict(min_updates=1))
-    scen["particle_w"] = np.random.default_rng(1).uniform(0.2, 1.0, n_total)
+    scen = make_scen(sc, n_total, big)
     local = ob.OracleFilter(n_total // world, stable_sort=True)
     sc.load_scenario(local, shard_scen(scen, rank, world))
     sh = pkg.sharded.ShardedRBPHDFilter(local)
     sh.effNParticles_t = n_total + 1.0 if force_resample else 1e-9     # always / never resample
-    fired = sh.update(scen["Z"], u01=0.4321)
-    res = dict(rank=rank, fired=fired, w=local.get_weights(), sizes=local.gm_sizes(),
-               maps=[local.export_gm(i) for i in range(local.n)], unused=[local.get_unused(i) for i in range(local.n)])
+    # (the 500-landmark state drives the raw weights to 0 in one update: the big case resamples the loaded state directly)
+    fired = sh.resample(u01=0.4321) if big else sh.update(scen["Z"], u01=0.4321)
+    res = dict(rank=rank, fired=fired, w=local.get_weights(), sizes=local.gm_sizes(), poses=local.get_poses(),
+               maps=[local.export_gm(i) for i in range(local.n)], unused=[local.get_unused(i) for i in range(local.n)],
+               migration=sh.last_migration)
     q.put(res)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def run_world(n_total, force_resample, world=2):
+def run_world(n_total, force_resample, world=2, big=False):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, force_resample, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, force_resample, q, big)) for r in range(world)]
     for p in procs:
         p.start()
     out = [q.get() for _ in range(world)]
@@ -69,15 +80,14 @@ def run_world(n_total, force_resample, world=2):
     return sorted(out, key=lambda d: d["rank"])
 
 
-def single_process(pkg, ob, n_total, force_resample):
+def single_process(pkg, ob, n_total, force_resample, big=False):
     sc = pkg.scenarios
-    scen = sc.make_scenario(n_total, 40, 12, seed=31, params=dict(min_updates=1))
-    scen["particle_w"] = np.random.default_rng(1).uniform(0.2, 1.0, n_total)
+    scen = make_scen(sc, n_total, big)
     f = ob.OracleFilter(n_total, stable_sort=True)
     sc.load_scenario(f, scen)
     sh = pkg.sharded.ShardedRBPHDFilter(f)     # world 1: same host code path, no collectives
     sh.effNParticles_t = n_total + 1.0 if force_resample else 1e-9
-    fired = sh.update(scen["Z"], u01=0.4321)
+    fired = sh.resample(u01=0.4321) if big else sh.update(scen["Z"], u01=0.4321)
     return f, fired
 
 
@@ -100,11 +110,47 @@ def test_two_rank_update_matches_single_process(pkg, ob, force_resample):
         assert all(o["fired"] == force_resample for o in out)
         sc.assert_gm_close(maps[i], ref.export_gm(i), 1e-13, 0, ordered=True)
         assert np.array_equal(unused[i], ref.get_unused(i))
+    # the pose travels with the particle (Particle::copy): kept slots keep theirs, children carry their parent's
+    np.testing.assert_array_equal(np.concatenate([o["poses"] for o in out]), ref.get_poses())
     if force_resample:
         assert np.array_equal(w, np.ones(n_total))     # weights reset to 1 (ParticleFilter.hpp:486-489)
+        assert sum(o["migration"]["rows_sent"] for o in out) == sum(o["migration"]["rows_received"] for o in out) > 0
         # the plan really moved particles across the shard boundary (otherwise the test shows nothing)
         ref2, _ = single_process(pkg, ob, n_total, False)
         plan = pkg.engine.systematic_resample_plan(ref2.get_weights(), 0.4321)
         half = n_total // 2
         crossed = [(g, s) for g, s in enumerate(plan) if (g < half) != (s < half)]
         assert len(crossed) > 0
+
+
+def test_two_rank_migration_of_c3_sized_mixtures(pkg, ob):
+    """configs[2]'s shape: 500-Gaussian mixtures cross the shard boundary as packed rows in a forced global resampling; poses,
+    maps, unused lists and weights equal the single-process filter's."""
+    n_total = 8
+    ref, fired = single_process(pkg, ob, n_total, True, big=True)
+    assert fired
+    out = run_world(n_total, True, big=True)
+    sc = pkg.scenarios
+    maps = [m for o in out for m in o["maps"]]
+    assert np.array_equal(np.concatenate([o["sizes"] for o in out]), ref.gm_sizes())
+    assert ref.gm_sizes().max() > 100
+    for i in range(n_total):
+        sc.assert_gm_close(maps[i], ref.export_gm(i), 1e-13, 0, ordered=True)
+    np.testing.assert_array_equal(np.concatenate([o["poses"] for o in out]), ref.get_poses())
+    assert sum(o["migration"]["rows_sent"] for o in out) > 0
+    assert all(o["migration"]["bytes_sent"] == o["migration"]["rows_sent"] * ref.slab_row_bytes() for o in out)
+
+
+def test_vectorised_resample_plan_equals_the_reference_loop(pkg):
+    e = pkg.engine
+    rng = np.random.default_rng(5)
+    for t in range(60):
+        n = int(rng.integers(256, 2500))
+        w = rng.uniform(0, 1, n) ** int(rng.integers(1, 12))
+        if t % 4 == 0:
+            w[rng.integers(0, n, n // 3)] = 0.0
+        w /= w.sum()
+        u = float(rng.random())
+        assert np.array_equal(e._systematic_resample_plan_loop(w, u), e._systematic_resample_plan_vectorised(w, u))
+    w = np.full(20000, 1.0 / 20000)
+    assert np.array_equal(e.systematic_resample_plan(w, 0.5), np.arange(20000))

@@ -32,7 +32,7 @@ def _worker(rank, world, port, n_total, force_resample, q):
     sh = pkg.sharded.ShardedRBPHDFilter(local)
     sh.effNParticles_t = n_total + 1.0 if force_resample else 1e-9     # always / never resample
     fired = sh.update(scen["Z"], u01=0.4321)
-    q.put(dict(rank=rank, fired=fired, w=local.get_weights(), sizes=local.gm_sizes(),
+    q.put(dict(rank=rank, fired=fired, w=local.get_weights(), sizes=local.gm_sizes(), poses=local.get_poses(), migration=sh.last_migration,
                maps=[local.export_gm(i) for i in range(local.n)], unused=[local.get_unused(i) for i in range(local.n)]))
     dist.barrier()
     dist.destroy_process_group()
@@ -71,5 +71,7 @@ def test_two_ranks_device_engine_match_single_filter(pkg, force_resample):
     for i in range(n_total):
         sc.assert_gm_close(maps[i], ref.export_gm(i), 1e-13, 0, ordered=True)
         assert np.array_equal(unused[i], ref.get_unused(i))
+    np.testing.assert_array_equal(np.concatenate([o["poses"] for o in out]), ref.get_poses())
     if force_resample:
         assert np.array_equal(w, np.ones(n_total))
+        assert sum(o["migration"]["rows_sent"] for o in out) > 0     # packed rows really crossed the shard boundary
