@@ -230,6 +230,12 @@ int rfsgpu_update(rfsgpu_filter *f, const double *z, int n_z);
  * that does not need the weights every step (no resampling decision pending) pipelines its steps with this. */
 #define RFSGPU_ASYNC_RING 256
 int rfsgpu_update_async(rfsgpu_filter *f, const double *z, int n_z);
+/* The same step followed -- in the same post kernel that runs the Murty partitions -- by the weight reduction of
+ * ParticleFilter::normalizeWeights (include/ParticleFilter.hpp:352-363): {sum w, sum w^2} of this shard go to the bound sums
+ * buffer (rfsgpu_bind_weight_sums_buffer / rfsgpu_weight_sums_device_ptr); with normalize != 0 (a filter that lives on one
+ * GPU) the weights are divided by the sum right there, otherwise the caller all-reduces the pair across its shards and calls
+ * rfsgpu_normalize_weights.  Two launches per step (fused step + post) instead of five. */
+int rfsgpu_step_async(rfsgpu_filter *f, const double *z, int n_z, int normalize);
 /* Average duration (ns) of each hot-path kernel group over the async steps harvested since the last call / reset:
  * [0]=phd_update_map [1]=phd_weight_multifeature [2]=gm_merge(+prune); *n_steps = steps averaged.  Steps that ran as one
  * fused kernel report its duration in [0] and 0 in [1], [2] (their TimingInfo share is booked under mapUpdate). */

@@ -116,7 +116,7 @@ ABI_SYMBOLS = [
     "default_fastslam_config", "set_fastslam_config", "get_fastslam_config", "fastslam_update",
     "normalize_weights_parts", "create_ex", "n_particles", "max_particles", "resample_apply_n",
     "fastslam_set_resample_occured", "particle_parents", "vp_probe_pd",
-    "slab_row_bytes", "export_slab_rows", "import_slab_rows", "weights_device_ptr",
+    "slab_row_bytes", "export_slab_rows", "import_slab_rows", "weights_device_ptr", "step_async",
 ]
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")

@@ -12,6 +12,9 @@
 #include <stdint.h>
 
 #define RFS_WAVE 64
+// LDS head of every hot-path kernel: the measurement set as doubles [2*MAX_Z] | an fp32 copy for the innovation-gate
+// prefilter, ranges [MAX_Z] then bearings [MAX_Z] | {max |range|, max |bearing|} as floats (+ pad)
+#define RFS_Z_LDS_BYTES (2 * RFSGPU_MAX_Z * 8 + 2 * RFSGPU_MAX_Z * 4 + 16)
 #define RFS_PI 3.14159265358979323846 /* == acos(-1) in fp64 (reference include/RandomVec.hpp:55) */
 #define RFS_DENORM_MIN 4.9406564584124654e-324
 
@@ -51,6 +54,11 @@ struct Params {
   double bmax, bmin, bufferPd;
   double Qlm6[6];          // packed xx, xy, xd, yy, yd, dd
   double twoPiPowD;        // pow(2*pi, d_z) as the host libm rounds it (RandomVec.hpp:419)
+};
+
+// The measurement set of a step, by value in the kernel-argument block (<= 1.5 KB): no staging buffer, no copy-engine hop.
+struct ZArg {
+  double v[RFSGPU_MAX_Z * 3];
 };
 
 struct Buffers {
@@ -173,14 +181,18 @@ __device__ __forceinline__ float wave_max_f32(float v) {
   return v;
 }
 
-// exclusive prefix sum over the wave (small ints)
+// exclusive prefix sum over the wave (small ints): Hillis-Steele inside each 16-lane row with row_shr DPP moves, then the row
+// totals across rows with row_bcast:15 / :31 -- six VALU instructions, no LDS permute and no lane-address registers (the
+// ds_bpermute form kept six shuffle addresses alive across whole kernels, which the fused kernel paid for in scratch)
 __device__ __forceinline__ int wave_excl_scan(int v, int lane) {
+  (void)lane;
   int x = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    int y = __shfl_up(x, o, 64);
-    if (lane >= o) x += y;
-  }
+  x += dpp_i32<0x111, 0xf>(x);  // row_shr:1
+  x += dpp_i32<0x112, 0xf>(x);  // row_shr:2
+  x += dpp_i32<0x114, 0xf>(x);  // row_shr:4
+  x += dpp_i32<0x118, 0xf>(x);  // row_shr:8  -> inclusive scan inside every row
+  x += dpp_i32<0x142, 0xa>(x);  // row_bcast:15 into rows 1 and 3
+  x += dpp_i32<0x143, 0xc>(x);  // row_bcast:31 into rows 2 and 3
   return x - v;
 }
 

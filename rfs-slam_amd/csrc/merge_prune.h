@@ -13,18 +13,21 @@
 #include "common.h"
 #include "weighting.h"  // wave_sync
 
-// LDS per particle: per entry x, y, w, bound (4 doubles) + row record (u32) + grid-sorted index (u16) + slack (u16);
-// plus the 32x32 spatial grid (one cursor array, two 16-bit cursors per word) and the list of possible partners (u32 each).  Covariances stay
-// in HBM/L2 and their inverses are formed on demand for the few pairs that survive the distance prefilter -- this
-// keeps the footprint at 40 B/entry so that 8 workgroups fit a CU and 2000 particles run in a single round.
+// LDS per particle, 28 B per entry: position (x, y) and prefilter RADIUS as fp32 (the radius' sign is the liveness flag),
+// weight as fp64 (prune's sort key, the merge's w_a + w_j test), row record (u32), grid-sorted index (u16), slack (u16); plus
+// the 32x32 spatial grid (one cursor array, two 16-bit cursors per word) and the list of possible partners (u32 each).
+// Everything the EXACT tests need (means, covariances) is read from the slab (HBM / L2) for the few pairs that survive the
+// distance prefilter; the fp32 copies only feed the prefilter, whose thresholds carry the fp32 rounding bound, so it can
+// let extra pairs through but never drop one.  (Until r02 the entries were 40 B -- x, y, bound as fp64 -- which set the
+// fused kernel's LDS block and with it how many particles of the configs[2] shard are resident.)
 #define MERGE_GX 32  // grid cells along x
 #define MERGE_GY 32  // grid cells along y
 #define MERGE_CELLS (MERGE_GX * MERGE_GY)
 #define MERGE_PAIR_CAP(cap) ((cap) > 320 ? (cap) : 320)  // listed partners per particle: ~0.7 per entry on dense maps
 #define MERGE_ROW_SLOTS 8   // prefilter survivors one row can list; a row with more is replayed by the sequential scan
 __host__ __device__ inline size_t merge_lds_bytes_per_wave(int cap) {
-  // entries: 4 doubles + row record (u32) + grid-sorted index (u16) + prefilter slack (u16); grid: CELLS+4 u32; pair list: u32
-  return (((size_t)cap * (4 * 8 + 4 + 2 + 2)) + (size_t)(MERGE_CELLS / 2 + 4) * 4 + (size_t)MERGE_PAIR_CAP(cap) * 4 + 16 + 15) & ~(size_t)15;
+  // entries: w (f64) + x, y, radius (f32) + row record (u32) + grid-sorted index (u16) + prefilter slack (u16); grid: CELLS/2+4 u32; pair list: u32
+  return (((size_t)cap * (8 + 3 * 4 + 4 + 2 + 2)) + (size_t)(MERGE_CELLS / 2 + 4) * 4 + (size_t)MERGE_PAIR_CAP(cap) * 4 + 16 + 15) & ~(size_t)15;
 }
 // Row record (sRec[m]): [31:25] claim of the speculative round (lane, 0x7f = none) | [24] the row has a partner that
 // passes the exact test against the initial states | [23:20] number of listed survivors (15 = not listable) |
@@ -45,6 +48,10 @@ __device__ __forceinline__ double merge_bound(double t2, double xx, double xy, d
   const double det = xx * yy - xy * xy;
   const bool sane = (det > 0.0) && (tr > 0.0) && (tr < 1.7e308);
   return sane ? t2 * tr * (1.0 + 1e-6) : __builtin_huge_val();
+}
+// The prefilter radius sqrt(bound) as an fp32 that is >= the exact value (sqrt and the conversion round by < 2e-7).
+__device__ __forceinline__ float merge_radius_f32(double bound) {
+  return __builtin_amdgcn_sqrtf((float)bound) * (1.f + 1e-6f) + 1e-37f;
 }
 
 // The exact pair test of GaussianMixture::merge (:434-447) for e = x_j - x_a:
@@ -78,6 +85,9 @@ __device__ __forceinline__ bool merge_pair_passes(double e0, double e1, double a
 //   ascending row order; see the comments in the kernel.
 // FUSE_PRUNE: survivors (w >= pruneT, not absorbed) are rank-sorted by (weight desc, index asc) and compacted into
 //   the other slab straight from here (GaussianMixture::prune :477-521), saving gm_prune's launch and re-read.
+// `perm` (LDS, or null): the order the mixture is to be merged in, as a permutation of the slab's entries -- entry m of the
+//   merge is slab entry perm[m].  The fused step kernel passes the weight-sorted order left by the weighting phase
+//   (sortByWeight, include/RBPHDFilter.hpp:733), so that the sorted mixture is never written out and read back.
 // One workgroup of WPP waves per particle: the entry- and pair-parallel phases (stage, grid, phase 1, prune) are spread
 // over all WPP*64 threads, which is what fills the SIMDs at ~2000 particles; phase 2 is run by wave 0.
 #ifndef MERGE_WAVES_PER_EU
@@ -85,7 +95,7 @@ __device__ __forceinline__ bool merge_pair_passes(double e0, double e1, double a
 #endif
 template <int WPP, bool FUSE_PRUNE>
 __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params &P, const int cur, const int dst, const int i, const int tid,
-                                                  unsigned char *smem_raw) {
+                                                  unsigned char *smem_raw, const unsigned short *perm = nullptr) {
   constexpr int NT = WPP * 64;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
@@ -93,9 +103,11 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
   unsigned char *wbase = smem_raw;
   float *sRed = reinterpret_cast<float *>(smem_raw + merge_lds_bytes_per_wave(cap));  // [WPP][8] cross-wave reduction scratch
   auto block_sync = [&]() { if (WPP == 1) wave_sync(); else __syncthreads(); };
-  double *sMX = reinterpret_cast<double *>(wbase), *sMY = sMX + cap, *sW = sMX + 2 * cap, *sBnd = sMX + 3 * cap;
+  double *sW = reinterpret_cast<double *>(wbase);                          // [cap] weight (exact)
+  float *sX = reinterpret_cast<float *>(sW + cap), *sY = sX + cap;          // [cap] position, fp32 (prefilter only)
+  float *sRad = sY + cap;                                                   // [cap] prefilter radius, fp32, >= exact; < 0: absorbed
   // grid cursors, 16 bits each, two per word: cell c's entries are sSorted[cell_at(c) .. cell_at(c + 1))
-  unsigned *sCellStart = reinterpret_cast<unsigned *>(sMX + 4 * cap);      // [(CELLS + 1) halves]
+  unsigned *sCellStart = reinterpret_cast<unsigned *>(sRad + cap);          // [(CELLS + 1) halves]
   auto cell_at = [&](int e) -> unsigned { return (sCellStart[e >> 1] >> (16 * (e & 1))) & 0xffffu; };
   unsigned *sRec = sCellStart + MERGE_CELLS / 2 + 4;                        // [cap] row records (see MERGE_REC_*)
   unsigned *sPairs = sRec + cap;                                            // [PAIR_CAP] (a << 16) | (passes << 15) | (reserve << 14) | j
@@ -108,6 +120,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
   double *pW = plane(slab, cap, i, PL_W), *pMX = plane(slab, cap, i, PL_MX), *pMY = plane(slab, cap, i, PL_MY);
   double *pSXX = plane(slab, cap, i, PL_SXX), *pSXY = plane(slab, cap, i, PL_SXY), *pSYY = plane(slab, cap, i, PL_SYY);
   const double t2 = P.mergeT2, f = P.mergeInfl;
+  auto phys = [&](int m) -> int { return perm ? (int)perm[m] : m; };       // slab entry of merge entry m
 
   DBG_TB(32, 0);
 #ifdef RFS_PROFILE
@@ -120,23 +133,28 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
 #endif
   // ---- stage; hole flags live in per-lane registers: bit s of `hole` <=> entry s*64+lane is a hole ----
   unsigned hole = 0;
-  float fxmin = 3.0e38f, fxmax = -3.0e38f, fymin = 3.0e38f, fymax = -3.0e38f, frad = 0.f;
+  float fxmin = 3.0e38f, fxmax = -3.0e38f, fymin = 3.0e38f, fymax = -3.0e38f, frad = 0.f, fabsmax = 0.f;
   for (int m = tid, sidx = 0; m < N; m += NT, sidx++) {
-    const double w = pW[m], mx = pMX[m], my = pMY[m];
-    const double bnd = merge_bound(t2, pSXX[m], pSXY[m], pSYY[m]);
-    sMX[m] = mx; sMY[m] = my; sW[m] = w; sBnd[m] = bnd;
-    sRec[m] = MERGE_REC_NOCLAIM;
-    if (w < 0) { hole |= 1u << sidx; sBnd[m] = -1.0; continue; }  // already absorbed (merge called twice); bound < 0 marks a hole
+    const int pm = phys(m);
+    const double w = pW[pm], mx = pMX[pm], my = pMY[pm];
+    const double bnd = merge_bound(t2, pSXX[pm], pSXY[pm], pSYY[pm]);
     const float fx = (float)mx, fy = (float)my;
+    sX[m] = fx; sY[m] = fy; sW[m] = w;
+    sRec[m] = MERGE_REC_NOCLAIM;
+    if (w < 0) { hole |= 1u << sidx; sRad[m] = -1.f; continue; }  // already absorbed (merge called twice); radius < 0 marks a hole
+    const float rad = merge_radius_f32(bnd);
+    sRad[m] = rad;
     fxmin = fminf(fxmin, fx); fxmax = fmaxf(fxmax, fx);
     fymin = fminf(fymin, fy); fymax = fmaxf(fymax, fy);
-    frad = fmaxf(frad, sqrtf((float)bnd) * 1.0001f);
+    fabsmax = fmaxf(fabsmax, fmaxf(fabsf(fx), fabsf(fy)));
+    frad = fmaxf(frad, rad * 1.0001f);
   }
   for (int c = tid; c <= MERGE_CELLS / 2; c += NT) sCellStart[c] = 0u;
   fxmin = wave_min_f32(fxmin); fxmax = wave_max_f32(fxmax);
   fymin = wave_min_f32(fymin); fymax = wave_max_f32(fymax);
   frad = wave_max_f32(frad);
-  if (WPP > 1 && lane == 0) { float *r = sRed + wave * 8; r[0] = fxmin; r[1] = fxmax; r[2] = fymin; r[3] = fymax; r[4] = frad; }
+  fabsmax = wave_max_f32(fabsmax);
+  if (WPP > 1 && lane == 0) { float *r = sRed + wave * 8; r[0] = fxmin; r[1] = fxmax; r[2] = fymin; r[3] = fymax; r[4] = frad; r[5] = fabsmax; }
   block_sync();
 
   DBG_TB(32, 1);
@@ -146,18 +164,23 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     for (int w2 = 0; w2 < WPP; w2++) {
       const float *r = sRed + w2 * 8;
       fxmin = fminf(fxmin, r[0]); fxmax = fmaxf(fxmax, r[1]); fymin = fminf(fymin, r[2]); fymax = fmaxf(fymax, r[3]); frad = fmaxf(frad, r[4]);
+      fabsmax = fmaxf(fabsmax, r[5]);
     }
   }
+  // |fp32 coordinate difference - exact difference| <= errAbs: two conversions (2^-24 |x| each) and one subtraction; NaN / inf
+  // coordinates make it NaN / inf, and every comparison below then keeps the pair (the exact test decides)
+  const float errAbs = 3.0e-7f * fabsmax + 1e-37f;
   // float rounding of the box / radius is covered by the 1e-3 relative slack on the cell edges; indices are clamped
   // (clamping is monotone, so adjacency is preserved for out-of-box values).  Cell edges are >= the largest prefilter
   // radius in both directions, so every pair that can pass lies in adjacent cells.
   const double x0 = (double)fxmin - 1e-3 * fabs((double)fxmin) - 1e-30, y0 = (double)fymin - 1e-3 * fabs((double)fymin) - 1e-30;
   const double spanx = (double)fxmax - x0, spany = (double)fymax - y0;
   const double cellx = fmax((double)frad, spanx / MERGE_GX) * 1.001 + 1e-300, celly = fmax((double)frad, spany / MERGE_GY) * 1.001 + 1e-300;
-  const bool degenerate = !(cellx < 1.0e300) || !(celly < 1.0e300) || !(spanx == spanx) || !(spany == spany);  // inf / NaN -> a single cell
-  const double invCx = degenerate ? 0.0 : 1.0 / cellx, invCy = degenerate ? 0.0 : 1.0 / celly;
-  auto cell_of = [&](double x, double y, int &cx, int &cy) {
-    int ix = (int)((x - x0) * invCx), iy = (int)((y - y0) * invCy);
+  const bool degenerate = !(cellx < 1.0e30) || !(celly < 1.0e30) || !(spanx == spanx) || !(spany == spany) || !(errAbs < 1.0e30f);  // inf / NaN -> a single cell
+  const float x0f = (float)x0, y0f = (float)y0;
+  const float invCx = degenerate ? 0.f : (float)(1.0 / cellx) * (1.f - 1e-6f), invCy = degenerate ? 0.f : (float)(1.0 / celly) * (1.f - 1e-6f);
+  auto cell_of = [&](float x, float y, int &cx, int &cy) {
+    int ix = (int)((x - x0f) * invCx), iy = (int)((y - y0f) * invCy);
     cx = ix < 0 ? 0 : (ix >= MERGE_GX ? MERGE_GX - 1 : ix);
     cy = iy < 0 ? 0 : (iy >= MERGE_GY ? MERGE_GY - 1 : iy);
     if (degenerate) { cx = 0; cy = 0; }
@@ -165,7 +188,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
   for (int m = tid, sidx = 0; m < N; m += NT, sidx++) {
     if ((hole >> sidx) & 1u) continue;
     int cx, cy;
-    cell_of(sMX[m], sMY[m], cx, cy);
+    cell_of(sX[m], sY[m], cx, cy);
     const int e = cy * MERGE_GX + cx + 1;  // counts, shifted by one entry
     atomicAdd(&sCellStart[e >> 1], 1u << (16 * (e & 1)));  // (a half never overflows: counts <= cap < 65536)
   }
@@ -194,7 +217,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
   for (int m = tid, sidx = 0; m < N; m += NT, sidx++) {
     if ((hole >> sidx) & 1u) continue;
     int cx, cy;
-    cell_of(sMX[m], sMY[m], cx, cy);
+    cell_of(sX[m], sY[m], cx, cy);
     const int e = cy * MERGE_GX + cx + 1;
     const unsigned pos = (atomicAdd(&sCellStart[e >> 1], 1u << (16 * (e & 1))) >> (16 * (e & 1))) & 0xffffu;
     sSorted[pos] = (unsigned short)m;
@@ -203,25 +226,26 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
   block_sync();
   DBG_TB(32, 8);
   // ---- phase 1: every pair (a, j > a) against the INITIAL states ----
-  // 1a: each entry scans the 3x3 cells around it, four neighbours per trip, with the branch-free distance prefilter.
-  //     Survivors with a higher index are collected in registers and written as ONE contiguous segment of the pair
-  //     list (one atomicAdd per row).  The scan also keeps the row's SLACK: the smallest (distance - prefilter radius)
-  //     among the neighbours that fail, bounded by what separates it from entries outside the 3x3 cells.  While the row
-  //     later moves / grows by less than its slack, no other entry can start passing, so the segment stays the
-  //     complete list of possible partners.
-  // 1b: the list is processed with all lanes busy (one pair per lane): both covariances are fetched together, the
-  //     exact Mahalanobis test runs, and the verdict is kept in the pair's own word (bit 15) and in the row record.
+  // 1a: each entry scans the 3x3 cells around it, four neighbours per trip, with the branch-free fp32 distance prefilter
+  //     |x_j - x_a| <= max(r_a, r_j) + rounding bound.  Survivors with a higher index are collected in registers and written
+  //     as ONE contiguous segment of the pair list (one atomicAdd per row).  The scan also keeps the row's SLACK: the
+  //     smallest (distance - prefilter radius) among the neighbours that fail, bounded by what separates it from entries
+  //     outside the 3x3 cells.  While the row later moves / grows by less than its slack, no other entry can start passing,
+  //     so the segment stays the complete list of possible partners.
+  // 1b: the list is processed with all lanes busy (one pair per lane): means and covariances of both entries are fetched
+  //     together from the slab, the exact Mahalanobis test runs, and the verdict is kept in the pair's own word (bit 15)
+  //     and in the row record.
   const int pairCap = MERGE_PAIR_CAP(cap);
-  const float slackOut = (float)(fmin(cellx, celly)) * (1.f - 4e-6f) - frad * (1.f + 4e-6f);
+  const float slackOut = (float)(fmin(cellx, celly)) * (1.f - 4e-6f) - frad * (1.f + 4e-6f) - 3.f * errAbs;
   for (int m = tid, sidx = 0; m < N; m += NT, sidx++) {
     if ((hole >> sidx) & 1u) continue;
-    const double ax = sMX[m], ay = sMY[m], ab = sBnd[m];
+    const float ax = sX[m], ay = sY[m], ar = sRad[m];
     int cx, cy;
     cell_of(ax, ay, cx, cy);
     const int cxa = cx > 0 ? cx - 1 : 0, cxb = cx < MERGE_GX - 1 ? cx + 1 : MERGE_GX - 1;
     unsigned long long buf0 = 0ull, buf1 = 0ull;  // up to 8 survivors, 16 bits each
     int nP = 0;
-    double farE2 = 1.0e300;   // nearest neighbour that fails the prefilter by a factor >= 2 in distance
+    float farE2 = 3.0e38f;   // nearest neighbour that fails the prefilter by a factor >= 2 in distance
     // the three cell rows are three contiguous ranges of the sorted list; they are walked as ONE sequence (same order as
     // row by row), so that only the last trip of four is partly empty instead of the last trip of every row
     const unsigned qs1 = cell_at(cy * MERGE_GX + cxa), n1 = cell_at(cy * MERGE_GX + cxb + 1) - qs1;
@@ -232,7 +256,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     {
       for (unsigned q = 0; q < tot; q += 4) {
         unsigned jj[4];
-        double jx[4], jy[4], jb[4];
+        float jx[4], jy[4], jr[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const unsigned t = (q + k < tot) ? q + k : tot - 1;
@@ -240,19 +264,21 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
           jj[k] = sSorted[pos];
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) { jx[k] = sMX[jj[k]]; jy[k] = sMY[jj[k]]; jb[k] = sBnd[jj[k]]; }
+        for (int k = 0; k < 4; k++) { jx[k] = sX[jj[k]]; jy[k] = sY[jj[k]]; jr[k] = sRad[jj[k]]; }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          const double e0 = jx[k] - ax, e1 = jy[k] - ay;
-          const double e2 = e0 * e0 + e1 * e1, T = fmax(ab, jb[k]);
+          const float e0 = jx[k] - ax, e1 = jy[k] - ay;
+          const float e2 = e0 * e0 + e1 * e1;
+          const float thr = fmaxf(ar, jr[k]) + 1.5f * errAbs;       // exact |e| <= exact radius  =>  fp32 |e| <= thr (+ ulps)
+          const float T = thr * thr * (1.f + 1e-5f);
           // higher index only (the entry plays `a`); NaN distances fall through to the exact test like the reference
           const bool cand = (q + k < tot) & (jj[k] > (unsigned)m);
           const bool c = cand & !(e2 > T);
           // neighbours within twice the prefilter radius are listed too, as RESERVE partners (bit 14): they cannot pass
           // now, but may once the row has merged and moved; everything farther bounds the row's slack from below
-          const bool reserve = cand & !c & (e2 < 4.0 * T);
+          const bool reserve = cand & !c & (e2 < 4.0f * T);
           const bool farFail = cand & !c & !reserve;
-          farE2 = farFail ? fmin(farE2, e2) : farE2;  // sqrt(e2) - sqrt(T) >= sqrt(e2) / 2 for these
+          farE2 = farFail ? fminf(farE2, e2) : farE2;  // exact distance - exact radius >= sqrt(e2) / 2 for these
           if (c | reserve) {
             const unsigned long long v = (unsigned long long)(jj[k] | (reserve ? 0x4000u : 0u)) << (16 * (nP & 3));
             if (nP < 4) buf0 |= v; else if (nP < 8) buf1 |= v;
@@ -283,7 +309,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
       }
     }
     sRec[m] = rec;
-    float slackMin = __builtin_amdgcn_sqrtf((float)farE2) * (0.5f - 4e-6f);
+    float slackMin = __builtin_amdgcn_sqrtf(farE2) * (0.5f - 4e-6f);
     slackMin = degenerate ? 0.f : fminf(slackMin, slackOut);
     sSlack[m] = (slackMin > 0.f) ? (unsigned short)(__float_as_uint(slackMin) >> 16) : (unsigned short)0;
   }
@@ -296,10 +322,11 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
         const unsigned pr2 = sPairs[pi];
         const int a = (int)(pr2 >> 16), j = (int)(pr2 & 0x3fffu);
         if (pr2 != 0xffffffffu && !(pr2 & 0x4000u)) {  // (unused words and reserve partners need no test)
-          // both covariances up front: six independent loads in flight
-          const double axx = pSXX[a], axy = pSXY[a], ayy = pSYY[a];
-          const double jxx = pSXX[j], jxy = pSXY[j], jyy = pSYY[j];
-          const double e0 = sMX[j] - sMX[a], e1 = sMY[j] - sMY[a];
+          const int pa = phys(a), pj = phys(j);
+          // both entries up front: ten independent loads in flight
+          const double axx = pSXX[pa], axy = pSXY[pa], ayy = pSYY[pa];
+          const double jxx = pSXX[pj], jxy = pSXY[pj], jyy = pSYY[pj];
+          const double e0 = pMX[pj] - pMX[pa], e1 = pMY[pj] - pMY[pa];
           double a00, a01, a10, a11, det;
           inv2(axx, axy, axy, ayy, a00, a01, a10, a11, det);
           const double u0 = e0 * a00 + e1 * a01, u1 = e0 * a01 + e1 * a11;
@@ -327,7 +354,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
   dbgPairs = *sPairCount;
 #endif
   // ---- phase 2: replay the rows that have a candidate, with the exact greedy rule ----
-  // Liveness lives in LDS from here on: sBnd[j] < 0  <=>  j has been absorbed.
+  // Liveness lives in LDS from here on: sRad[j] < 0  <=>  j has been absorbed.
   //
   // Speculative lane-parallel replay + ordered validation.  Up to 64 candidate rows at a time, one per lane, are
   // replayed independently against the states every entry had when the round started: the lane walks its row's listed
@@ -374,8 +401,10 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
         j0 = (int)lo;
       }
     }
-    double ax = sMX[a], ay = sMY[a], aw = sW[a], ab = sBnd[a];
-    double axx = pSXX[a], axy = pSXY[a], ayy = pSYY[a];
+    const int pa = phys(a);
+    double ax = pMX[pa], ay = pMY[pa], aw = sW[a];
+    double axx = pSXX[pa], axy = pSXY[pa], ayy = pSYY[pa];
+    double ab = merge_bound(t2, axx, axy, ayy);
     double a00, a01, a10, a11, adet;
     inv2(axx, axy, axy, ayy, a00, a01, a10, a11, adet);
     bool changed = false;
@@ -386,21 +415,28 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
       dbgChunks++;
 #endif
       double jx = 0, jy = 0, jw = 0, jb = -1.0;
-      if (j > a && j < N) { jx = sMX[j]; jy = sMY[j]; jw = sW[j]; jb = sBnd[j]; }
+      int pj = 0;
+      if (j > a && j < N) {
+        pj = phys(j);
+        jx = pMX[pj]; jy = pMY[pj]; jw = sW[j];
+        const float r = sRad[j];
+        jb = (r < 0.f) ? -1.0 : (double)r * (double)r * (1.0 + 1e-5);   // >= the entry's exact bound
+      }
       bool live = !(jb < 0.0);
       while (true) {
         bool pass = false;
         if (live && lane >= floorLane) {
           const double e0 = jx - ax, e1 = jy - ay;
-          if (!((e0 * e0 + e1 * e1) > fmax(ab, jb))) pass = merge_pair_passes(e0, e1, a00, a01, a11, aw, jw, pSXX, pSXY, pSYY, j, t2);
+          if (!((e0 * e0 + e1 * e1) > fmax(ab, jb))) pass = merge_pair_passes(e0, e1, a00, a01, a11, aw, jw, pSXX, pSXY, pSYY, pj, t2);
         }
         const unsigned long long pm = __ballot(pass);
         if (pm == 0ull) break;
         const int l = __builtin_ctzll(pm);
         const int jj = c0 + l;
+        const int pjj = phys(jj);
         // merge jj into a (GaussianMixture.hpp:444-471), wave-uniform arithmetic
         const double w1 = aw, w2 = sW[jj];
-        const double x2 = sMX[jj], y2 = sMY[jj], bxx = pSXX[jj], bxy = pSXY[jj], byy = pSYY[jj];
+        const double x2 = pMX[pjj], y2 = pMY[pjj], bxx = pSXX[pjj], bxy = pSXY[pjj], byy = pSYY[pjj];
         const double wm = w1 + w2;
         const double xm = (ax * w1 + x2 * w2) / wm, ym = (ay * w1 + y2 * w2) / wm;
         const double d10 = xm - ax, d11 = ym - ay, d20 = xm - x2, d21 = ym - y2;
@@ -414,7 +450,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
 #ifdef RFS_PROFILE
         dbgMerges++;
 #endif
-        if (lane == l) { sBnd[jj] = -1.0; live = false; }
+        if (lane == l) { sRad[jj] = -1.f; live = false; }
         floorLane = l + 1;
         if (floorLane >= 64) break;
       }
@@ -423,7 +459,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     if (changed) {
       anyMerge = true;
       sW[a] = aw;  // uniform store; the other LDS fields of a are never read again (a is behind the scan)
-      if (lane == 0) { pW[a] = aw; pMX[a] = ax; pMY[a] = ay; pSXX[a] = axx; pSXY[a] = axy; pSYY[a] = ayy; }
+      if (lane == 0) { pW[pa] = aw; pMX[pa] = ax; pMY[pa] = ay; pSXX[pa] = axx; pSXY[pa] = axy; pSYY[pa] = ayy; }
     }
     wave_sync();
   };
@@ -432,7 +468,8 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     const int cnt = (nRowsTotal - r0 < 64) ? nRowsTotal - r0 : 64;
     // ---- speculative replay, one row per lane ----
     const int a = (lane < cnt) ? (int)sRows[r0 + lane] : 0;
-    const bool active = (lane < cnt) && !(sBnd[a] < 0.0);
+    const int pa = phys(a);
+    const bool active = (lane < cnt) && !(sRad[a] < 0.f);
     int nAbs = 0;
     bool ovf = false;
     [[maybe_unused]] int dbgWhy = 0;  // (profile builds report why rows fell back to the sequential scan)
@@ -454,11 +491,11 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
         for (int k = 0; k < MERGE_ROW_SLOTS; k++) it[k] = (k < n) ? (sPairs[base + k] & 0xffffu) : 0xffffffffu;
 #pragma unroll
         for (int k = 0; k < MERGE_ROW_SLOTS; k++)
-          if (k < n && sBnd[it[k] & 0x3fffu] < 0.0) it[k] = 0xffffffffu;
-        ax = sMX[a]; ay = sMY[a]; aw = sW[a];
-        axx = pSXX[a]; axy = pSXY[a]; ayy = pSYY[a];
+          if (k < n && sRad[it[k] & 0x3fffu] < 0.f) it[k] = 0xffffffffu;
+        ax = pMX[pa]; ay = pMY[pa]; aw = sW[a];
+        axx = pSXX[pa]; axy = pSXY[pa]; ayy = pSYY[pa];
         const float slack = __uint_as_float((unsigned)sSlack[a] << 16);
-        const float rPass = __builtin_amdgcn_sqrtf((float)sBnd[a]) * (1.f - 4e-6f);
+        const float rPass = sRad[a] * (1.f - 1e-5f);     // <= the row's exact initial radius
         float shift = 0.f;
         bool changed = false;
         double a00 = 0, a01 = 0, a11 = 0;
@@ -477,8 +514,9 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
           cur = j;
           bool pass = (best & 0x8000u) != 0u;  // verdict of phase 1b: valid while the row is in its initial state
           if (!changed && !pass) continue;
-          const double jw = sW[j], jx = sMX[j], jy = sMY[j];
-          const double jxx = pSXX[j], jxy = pSXY[j], jyy = pSYY[j];
+          const int pj = phys((int)j);
+          const double jw = sW[j], jx = pMX[pj], jy = pMY[pj];
+          const double jxx = pSXX[pj], jxy = pSXY[pj], jyy = pSYY[pj];
           if (changed) {
             const double e0 = jx - ax, e1 = jy - ay;
             const double u0 = e0 * a00 + e1 * a01, u1 = e0 * a01 + e1 * a11;
@@ -559,7 +597,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     const int firstDirty = cm ? __builtin_ctzll(cm) : 64;
     const bool commitNow = active && lane < firstDirty && ((alivem >> lane) & 1ull) && nAbs > 0;
     if (commitNow) {
-      for (int k = 0; k < nAbs; k++) sBnd[sSpec[lane * 8 + k]] = -1.0;
+      for (int k = 0; k < nAbs; k++) sRad[sSpec[lane * 8 + k]] = -1.f;
     }
     unsigned long long commit = __ballot(commitNow);
 #ifdef RFS_PROFILE
@@ -569,7 +607,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     for (int l = firstDirty; l < cnt; l++) {
       if (!((actm >> l) & 1ull)) continue;
       const int al = __builtin_amdgcn_readlane(a, l);
-      if (sBnd[al] < 0.0) continue;  // absorbed by an earlier row of this round: the row no longer exists
+      if (sRad[al] < 0.f) continue;  // absorbed by an earlier row of this round: the row no longer exists
 #ifdef RFS_PROFILE
       dbgRows++;
 #endif
@@ -577,7 +615,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
       const bool ovl = (__ballot(ovf) >> l) & 1ull;
       bool taken = false;
       int mine = 0;
-      if (lane < nl) { mine = sSpec[l * 8 + lane]; taken = sBnd[mine] < 0.0; }
+      if (lane < nl) { mine = sSpec[l * 8 + lane]; taken = sRad[mine] < 0.f; }
       if (ovl) {
         seq_replay(al);  // the row could not be finished from its list: the reference's scan, exactly
       } else if (__ballot(taken) != 0ull) {
@@ -589,12 +627,12 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
           seq_replay(al);
         } else {
           const int nl2 = __builtin_amdgcn_readlane(nAbs, l);
-          if (lane < nl2) sBnd[sSpec[l * 8 + lane]] = -1.0;
+          if (lane < nl2) sRad[sSpec[l * 8 + lane]] = -1.f;
           if (nl2 > 0) commit |= 1ull << l;
           wave_sync();
         }
       } else {
-        if (lane < nl) sBnd[mine] = -1.0;
+        if (lane < nl) sRad[mine] = -1.f;
         if (nl > 0) commit |= 1ull << l;
         wave_sync();
       }
@@ -602,7 +640,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     if ((commit >> lane) & 1ull) {  // committed rows publish their merged state
       anyMerge = true;
       sW[a] = aw;
-      pW[a] = aw; pMX[a] = ax; pMY[a] = ay; pSXX[a] = axx; pSXY[a] = axy; pSYY[a] = ayy;
+      pW[pa] = aw; pMX[pa] = ax; pMY[pa] = ay; pSXX[pa] = axx; pSXY[pa] = axy; pSYY[pa] = ayy;
     }
     anyMerge = __ballot(anyMerge) != 0ull;
     // claims are per round
@@ -625,12 +663,12 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
   anyMerge = sRed[0] != 0.f;
   // hole flags back into the per-thread registers used by the write-back / prune below
   for (int m = tid, sidx = 0; m < N; m += NT, sidx++)
-    if (sBnd[m] < 0.0) hole |= 1u << sidx;
+    if (sRad[m] < 0.f) hole |= 1u << sidx;
 
   if (!FUSE_PRUNE) {
     if (!anyMerge) return;
     for (int m = tid, sidx = 0; m < N; m += NT, sidx++)
-      if ((hole >> sidx) & 1u) pW[m] = -1.0;
+      if ((hole >> sidx) & 1u) pW[phys(m)] = -1.0;
     return;
   }
 
@@ -658,7 +696,10 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
   nSurv = (int)*sPairCount;
   for (int q = tid; q < nSurv; q += NT) {
     const int m = sSorted[q];
+    const int pm = phys(m);
     const double wm = sW[m];
+    // the survivor's record first (independent loads in flight while the rank is counted)
+    const double vx = pMX[pm], vy = pMY[pm], vxx = pSXX[pm], vxy = pSXY[pm], vyy = pSYY[pm];
     int rank = 0;
     for (int q2 = 0; q2 < nSurv; q2++) {
       const int j2 = sSorted[q2];
@@ -667,11 +708,11 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     }
     plane(dl, cap, i, PL_W)[rank] = wm;
     plane(dl, cap, i, PL_WP)[rank] = 0.0;
-    plane(dl, cap, i, PL_MX)[rank] = pMX[m];
-    plane(dl, cap, i, PL_MY)[rank] = pMY[m];
-    plane(dl, cap, i, PL_SXX)[rank] = pSXX[m];
-    plane(dl, cap, i, PL_SXY)[rank] = pSXY[m];
-    plane(dl, cap, i, PL_SYY)[rank] = pSYY[m];
+    plane(dl, cap, i, PL_MX)[rank] = vx;
+    plane(dl, cap, i, PL_MY)[rank] = vy;
+    plane(dl, cap, i, PL_SXX)[rank] = vxx;
+    plane(dl, cap, i, PL_SXY)[rank] = vxy;
+    plane(dl, cap, i, PL_SYY)[rank] = vyy;
   }
   if (tid == 0) B.count[i] = nSurv;
   DBG_TB(32, 4);

@@ -430,9 +430,41 @@ __device__ __forceinline__ double murty_partition_sum_block(double *C, int n, in
 #define MURTY_JOB_WAVES 2
 #endif
 #define MURTY_JOB_BLOCKS 2048
-__global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err, double *weight, int N) {
+// Besides the Murty jobs this is the step's POST kernel: whoever finishes last (block 0 alone when the queue is empty -- the
+// usual case: at the shipped 3-sigma gate Murty is never entered) multiplies the Murty factors into the particle weights,
+// clears the queue for the next step and, when `sums` is given, leaves {sum w, sum w^2} of the shard there
+// (ParticleFilter::normalizeWeights / N_eff, include/ParticleFilter.hpp:352-363, 405-415) and -- `normalize` != 0, a filter
+// that lives on one GPU -- divides the weights by the sum right away.  One launch instead of three (Murty, sums, divide).
+__device__ __forceinline__ void step_post_tail(double *weight, int N, double *sums, int normalize) {
+  if (!sums) return;
+  __shared__ double sA[MURTY_JOB_WAVES], sB[MURTY_JOB_WAVES];
+  __shared__ double sDiv;
+  double a = 0, b = 0;
+  for (int k = threadIdx.x; k < N; k += blockDim.x) { const double v = weight[k]; a += v; b += v * v; }
+  a = wave_sum_dpp(a); b = wave_sum_dpp(b);
+  if ((threadIdx.x & 63) == 0) { sA[threadIdx.x >> 6] = a; sB[threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double x = 0, y = 0;
+    for (int k = 0; k < MURTY_JOB_WAVES; k++) { x += sA[k]; y += sB[k]; }
+    sums[0] = x; sums[1] = y;
+    sDiv = x;
+  }
+  if (!normalize) return;
+  __syncthreads();
+  const double d = sDiv;
+  for (int k = threadIdx.x; k < N; k += blockDim.x) weight[k] = weight[k] / d;
+}
+__global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err, double *weight, int N, double *sums,
+                                                                         int normalize, ZArg zarg, double *dZ, int nZdoubles) {
+  // (a fused step carries the measurement set in its kernel arguments; the device copy the next predict reads is written here)
+  if (blockIdx.x == 0 && dZ && (int)threadIdx.x < nZdoubles) dZ[threadIdx.x] = zarg.v[threadIdx.x];
+  if (blockIdx.x == 0 && dZ && (int)threadIdx.x + 128 < nZdoubles) dZ[threadIdx.x + 128] = zarg.v[threadIdx.x + 128];
   const int nJobs = min(*Q.count, Q.maxJobs);
-  if (nJobs == 0) return;
+  if (nJobs == 0) {
+    if (blockIdx.x == 0) step_post_tail(weight, N, sums, normalize);
+    return;
+  }
   __shared__ double sTile[MURTY_JOB_WAVES][MURTY_LDS_N * MURTY_LDS_N];
   __shared__ double sScore[MURTY_N];
   __shared__ double sSum;
@@ -464,7 +496,7 @@ __global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQ
   __syncthreads();
   if (!isLast) return;
   __threadfence();
-  if (threadIdx.x == 0) Q.count[1] = 0;
+  if (threadIdx.x == 0) { Q.count[1] = 0; Q.count[0] = 0; }   // the queue is consumed: empty for the next step
   for (int i = threadIdx.x; i < N; i += blockDim.x) {
     int last = -1;
     double w = weight[i];
@@ -480,12 +512,10 @@ __global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQ
     }
     if (any) weight[i] = w;
   }
+  __syncthreads();
+  step_post_tail(weight, N, sums, normalize);
 }
 
-// The measurement set of a step, by value in the kernel-argument block.
-struct ZArg {
-  double v[RFSGPU_MAX_Z * 3];
-};
 // Start of a step: measurement set -> device buffer (read by every kernel of the step and by the next predict), Murty
 // job counter := 0.
 __global__ __launch_bounds__(256) void stage_step_kernel(ZArg z, double *dZ, int nDoubles, int *murtyCount) {
@@ -515,8 +545,10 @@ static inline void murty_free(MurtyQueue &Q, MurtyScratch &MS) {
   MS = MurtyScratch{};
 }
 // The job count lives on the device: one launch, which is empty when no partition exceeded 8.
-static inline int murty_launch(MurtyQueue &Q, MurtyScratch &MS, Buffers &B, hipStream_t stream) {
+static inline int murty_launch(MurtyQueue &Q, MurtyScratch &MS, Buffers &B, hipStream_t stream, double *sums = nullptr, int normalize = 0,
+                               const ZArg *za = nullptr, int nZdoubles = 0) {
   const int blocks = std::min(MURTY_JOB_BLOCKS, Q.maxJobs);
-  murty_jobs_kernel<<<blocks, 64 * MURTY_JOB_WAVES, 0, stream>>>(Q, MS, B.err, B.weight, B.N);
+  static const ZArg none{};
+  murty_jobs_kernel<<<blocks, 64 * MURTY_JOB_WAVES, 0, stream>>>(Q, MS, B.err, B.weight, B.N, sums, normalize, za ? *za : none, za ? B.Z : nullptr, nZdoubles);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }

@@ -632,7 +632,7 @@ static int launch_update_map(rfsgpu_filter *f) {
     HIPCHK(hipGetLastError());
     return RFSGPU_OK;
   }
-  auto bytes = [&](int wpb) { return (size_t)(2 * RFSGPU_MAX_Z * 8) + (size_t)wpb * update_map_lds_bytes_per_wave(f->cap); };
+  auto bytes = [&](int wpb) { return (size_t)RFS_Z_LDS_BYTES + (size_t)wpb * update_map_lds_bytes_per_wave(f->cap); };
   int rc;
   if (bytes(4) <= 64 * 1024) {
     if ((rc = set_lds(f, phd_update_map_kernel<4>, bytes(4))) != RFSGPU_OK) return rc;
@@ -670,7 +670,7 @@ static int launch_weighting(rfsgpu_filter *f) {
     return RFSGPU_OK;
   }
   {  // one workgroup of WEIGHT_WPP waves per particle
-    const size_t b = (size_t)(2 * RFSGPU_MAX_Z * 8) + per + WEIGHT_SCRATCH_BYTES;
+    const size_t b = (size_t)RFS_Z_LDS_BYTES + per + WEIGHT_SCRATCH_BYTES;
     if ((rc = set_lds(f, phd_weight_multifeature_kernel<WEIGHT_WPP>, b)) != RFSGPU_OK) return rc;
     phd_weight_multifeature_kernel<WEIGHT_WPP><<<f->N, WEIGHT_WPP * 64, b, f->stream>>>(f->B, f->P, src, dst, nZ, ec, f->Q);
   }
@@ -853,8 +853,9 @@ static void harvest_async(rfsgpu_filter *f) {
   f->ringCount = 0;
 }
 
-int rfsgpu_update_async(rfsgpu_filter *f, const double *z, int n_z) {
-  CHECK_HANDLE(f);
+// Shared body of the stream-ordered steps.  with_sums: the step's post kernel also leaves {sum w, sum w^2} in the bound sums
+// buffer (and divides the weights by the sum when normalize != 0).
+static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool with_sums, int normalize) {
   f->holes = false;
   if (n_z == 0) return RFSGPU_OK;  // :450-452
   long long t0 = now_ns();
@@ -863,34 +864,40 @@ int rfsgpu_update_async(rfsgpu_filter *f, const double *z, int n_z) {
     HIPCHK(hipStreamSynchronize(f->stream));
     harvest_async(f);
   }
-  int rc = stage_measurements(f, z, n_z);
-  if (rc != RFSGPU_OK) return rc;
+  int rc;
   hipEvent_t *e = f->ring[f->ringCount];
-  HIPCHK(hipEventRecord(e[0], f->stream));
   f->ringFused[f->ringCount] = false;
   if (f->D == 2 && f->fuseSteps) {
-    // the whole step in one launch (step_fused.h); Murty partitions, if any, follow as usual
+    // the whole step in one launch (step_fused.h), the measurement set riding in its kernel arguments; then the post kernel:
+    // Murty partitions (if any), queue reset, weight sums / normalisation
+    if (n_z < 0 || n_z > RFSGPU_MAX_Z) return fail(f, RFSGPU_ERR_INVALID, "at most RFSGPU_MAX_Z measurements per update");
+    if (!z) return fail(f, RFSGPU_ERR_INVALID, "null measurement buffer");
+    hipSetDevice(f->device);
+    ZArg za;
+    memcpy(za.v, z, (size_t)n_z * 2 * sizeof(double));
+    f->nZ = n_z;
+    HIPCHK(hipEventRecord(e[0], f->stream));
     const int ec = eval_cap(f), useW = f->cfg.useClusterProcess ? 0 : 1;
-    const size_t b = step_fused_lds_bytes(f->cap, ec, f->nZ, STEP_WPP);
+    const size_t b = step_fused_lds_total(f->cap, ec, f->nZ, STEP_WPP);
     if ((rc = set_lds(f, (phd_step_fused_kernel<STEP_WPP, true>), b)) != RFSGPU_OK) return rc;
     if ((rc = set_lds(f, (phd_step_fused_kernel<STEP_WPP, false>), b)) != RFSGPU_OK) return rc;
     // phase priorities only when every workgroup is resident at once: 16 waves per CU at 128 VGPRs, LDS permitting
     const int perCU = (int)std::min<size_t>(16 / STEP_WPP, b ? (size_t)(160 * 1024) / b : 16);
     const int phasePrio = (long long)perCU * f->nCU >= f->N ? 1 : 0;
-    if (phasePrio) phd_step_fused_kernel<STEP_WPP, true><<<f->N, STEP_WPP * 64, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q);
-    else phd_step_fused_kernel<STEP_WPP, false><<<f->N, STEP_WPP * 64, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q);
+    if (phasePrio) phd_step_fused_kernel<STEP_WPP, true><<<f->N, STEP_WPP * 64, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
+    else phd_step_fused_kernel<STEP_WPP, false><<<f->N, STEP_WPP * 64, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
     HIPCHK(hipGetLastError());
-    if (useW) {
-      if (murty_launch(f->Q, f->MS, f->B, f->stream) != 0) return fail(f, RFSGPU_ERR_HIP, "murty launch failed");
-    } else {
-      f->cur ^= 1;  // no sort pass: the merge wrote the other slab
-    }
     HIPCHK(hipEventRecord(e[3], f->stream));
+    if (murty_launch(f->Q, f->MS, f->B, f->stream, with_sums ? f->dSums : nullptr, normalize, &za, 2 * n_z) != 0) return fail(f, RFSGPU_ERR_HIP, "post kernel launch failed");
+    f->cur ^= 1;  // the map update works in place, the weighting phase leaves only a permutation in LDS, merge + prune write the other slab
     f->ringFused[f->ringCount] = true;
     f->ringCount++;
     f->timing.mapUpdate_cpu += now_ns() - t0;
     return RFSGPU_OK;
   }
+  rc = stage_measurements(f, z, n_z);
+  if (rc != RFSGPU_OK) return rc;
+  HIPCHK(hipEventRecord(e[0], f->stream));
   if ((rc = launch_update_map(f)) != RFSGPU_OK) return rc;
   HIPCHK(hipEventRecord(e[1], f->stream));
   f->ringHasMid[f->ringCount] = false;
@@ -906,7 +913,24 @@ int rfsgpu_update_async(rfsgpu_filter *f, const double *z, int n_z) {
   HIPCHK(hipEventRecord(e[3], f->stream));
   f->ringCount++;
   f->timing.mapUpdate_cpu += now_ns() - t0;
+  if (with_sums) {
+    if ((rc = rfsgpu_weight_sums_async(f)) != RFSGPU_OK) return rc;
+    if (normalize) return rfsgpu_normalize_weights(f, 0.0, f->dSums);
+  }
   return RFSGPU_OK;
+}
+int rfsgpu_update_async(rfsgpu_filter *f, const double *z, int n_z) {
+  CHECK_HANDLE(f);
+  return update_async_impl(f, z, n_z, false, 0);
+}
+int rfsgpu_step_async(rfsgpu_filter *f, const double *z, int n_z, int normalize) {
+  CHECK_HANDLE(f);
+  if (n_z == 0) {  // no update (:450-452), but the weights are still summed / normalised as the caller asked
+    int rc = rfsgpu_weight_sums_async(f);
+    if (rc != RFSGPU_OK) return rc;
+    return normalize ? rfsgpu_normalize_weights(f, 0.0, f->dSums) : RFSGPU_OK;
+  }
+  return update_async_impl(f, z, n_z, true, normalize);
 }
 
 int rfsgpu_kernel_time_stats(rfsgpu_filter *f, double *avg_ns3, int *n_steps) {

@@ -18,39 +18,41 @@
 #ifndef STEP_WPP
 #define STEP_WPP 2
 #endif
-#ifndef STEP_GATE_BATCH
-#define STEP_GATE_BATCH 4
-#endif
 #ifndef STEP_WAVES_PER_EU
 #define STEP_WAVES_PER_EU 4  // <= 128 VGPRs: 8 workgroups of 2 waves per CU, i.e. all 2000 particles of C2 resident at once
 #endif
 
 __host__ __device__ inline size_t step_fused_lds_bytes(int cap, int evalCap, int nZ, int wpp) {
-  size_t a = (size_t)(2 * RFSGPU_MAX_Z * 8) + update_map_block_lds_bytes(cap);
-  const size_t b = (size_t)(2 * RFSGPU_MAX_Z * 8) + weight_lds_bytes_per_wave(cap, evalCap, nZ) + WEIGHT_SCRATCH_BYTES;
+  size_t a = (size_t)RFS_Z_LDS_BYTES + update_map_block_lds_bytes(cap);
+  const size_t b = (size_t)RFS_Z_LDS_BYTES + weight_lds_bytes_per_wave(cap, evalCap, nZ) + WEIGHT_SCRATCH_BYTES;
   const size_t c = merge_lds_bytes_per_block(cap, wpp);
   if (b > a) a = b;
   if (c > a) a = c;
   return (a + 15) & ~(size_t)15;
+}
+// + the sorting permutation ([cap] u16) handed from the weighting phase to the merge phase, behind every phase's own layout
+__host__ __device__ inline size_t step_fused_lds_total(int cap, int evalCap, int nZ, int wpp) {
+  return step_fused_lds_bytes(cap, evalCap, nZ, wpp) + (((size_t)cap * 2 + 15) & ~(size_t)15);
 }
 
 // useWeighting == 0: SC-PHD (useClusterProcess_): the particle weight comes out of the map update, the mixture is not
 // sorted, merge works on the slab the update wrote.
 template <int WPP, bool PHASE_PRIO>
 __global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(STEP_WAVES_PER_EU)))
-void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, int useWeighting, MurtyQueue Q) {
+void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, int useWeighting, MurtyQueue Q, ZArg zarg) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int i = blockIdx.x;
-  double *sZ = reinterpret_cast<double *>(smem_raw);
   // Issue priority falls from phase to phase (s_setprio 2/3 -> 1 -> 0): the SIMD arbiter otherwise always prefers its oldest waves, so the
   // last workgroups to arrive on a CU crawl through the map update while the first ones race ahead, and the launch lasts as
   // long as those stragglers.  With a workgroup that is a phase behind outranking the ones ahead, the eight workgroups of
   // a CU finish together.  Only when the whole grid is resident at once (PHASE_PRIO, picked by the host): with several
   // rounds of workgroups per CU, newcomers outranking workgroups that are about to free their slots costs more than it gives
   // (measured: +2.3 % at 2000 x 200, -5 % at 2500 x 500).  Levels: map update 2 (3 for a SIMD's last arrivals), weighting 1, merge 0; the first is set inside phd_update_map_block.
-  for (int t = tid; t < 2 * nZ; t += WPP * 64) sZ[t] = B.Z[t];
+  // The measurement set arrives in the kernel-argument block (no staging launch); the step's post kernel leaves it in the
+  // device buffer that later kernels read (the next predict's births).  (Writing it from here cost 112 B/lane of scratch.)
+  stage_measurements_lds(smem_raw, [&](int t) { return zarg.v[t]; }, nZ, tid, WPP * 64);
   __syncthreads();
 #ifdef RFS_PROFILE
   long long *fd = B.dbg ? B.dbg + 64 + 4 * (size_t)B.N + 4 * (size_t)i : nullptr;
@@ -59,8 +61,8 @@ void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, in
     fd[0] = (long long)((wall_clock64() & 0xfffffffffffull) | ((unsigned long long)(hw & 0xffffu) << 44) | ((unsigned long long)(xcc & 0xfu) << 60));
   }
 #endif
-  if (WPP == 1) phd_update_map_particle<STEP_GATE_BATCH>(B, P, cur, nZ, B.Z, i, lane, sZ, smem_raw + 2 * RFSGPU_MAX_Z * 8);
-  else phd_update_map_block<WPP, STEP_GATE_BATCH>(B, P, cur, nZ, B.Z, i, tid, sZ, smem_raw + 2 * RFSGPU_MAX_Z * 8, PHASE_PRIO);
+  if (WPP == 1) phd_update_map_particle(B, P, cur, nZ, i, lane, smem_raw, smem_raw + RFS_Z_LDS_BYTES);
+  else phd_update_map_block<WPP>(B, P, cur, nZ, i, tid, smem_raw, smem_raw + RFS_Z_LDS_BYTES, PHASE_PRIO);
   __threadfence_block();  // the slab / count written by wave 0 -> the whole workgroup
   __syncthreads();
 #ifdef RFS_PROFILE
@@ -72,11 +74,15 @@ void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, in
   int tidW = threadIdx.x;
   asm volatile("" : "+v"(tidW));
   if (PHASE_PRIO) __builtin_amdgcn_s_setprio(1);
+  // The weighting phase sorts the mixture by weight (sortByWeight, include/RBPHDFilter.hpp:733) -- as a permutation kept in
+  // LDS; the merge phase walks the slab through it, so the sorted mixture is never written out and read back.
+  unsigned short *sPerm = reinterpret_cast<unsigned short *>(smem_raw + step_fused_lds_bytes(B.cap, evalCap, nZ, WPP));
+  const unsigned short *mergePerm = nullptr;
   if (useWeighting) {
-    phd_weight_particle<WPP>(B, P, cur, cur ^ 1, nZ, evalCap, Q, i, tidW, smem_raw);
+    phd_weight_particle<WPP>(B, P, cur, cur ^ 1, nZ, evalCap, Q, i, tidW, smem_raw, sPerm);
     __threadfence_block();
     __syncthreads();
-    mergeSrc = cur ^ 1;
+    mergePerm = sPerm;
   }
   int tidM = threadIdx.x;
   asm volatile("" : "+v"(tidM));
@@ -84,7 +90,7 @@ void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, in
 #ifdef RFS_PROFILE
   if (fd && tid == 0) fd[2] = (long long)wall_clock64();
 #endif
-  gm_merge_particle<WPP, true>(B, P, mergeSrc, mergeSrc ^ 1, i, tidM, smem_raw);
+  gm_merge_particle<WPP, true>(B, P, mergeSrc, mergeSrc ^ 1, i, tidM, smem_raw, mergePerm);
 #ifdef RFS_PROFILE
   if (fd && tid == 0) fd[3] = (long long)wall_clock64();
 #endif

@@ -99,29 +99,137 @@ __device__ __forceinline__ double pair_value(const Params &P, const LmKF &k, dou
   return pdw * lik;
 }
 
+// ---- innovation-gate prefilter in packed fp32 ------------------------------------------------------------------------------
+// The gates of KalmanFilter_RngBrg::calculateInnovation (src/KalmanFilter_RngBrg.cpp:52-65) reject almost every
+// (landmark, measurement) pair, and evaluating them in fp64 for all nM x nZ pairs was the largest single item of the map
+// update.  The sweep over the measurement set therefore runs in fp32, two measurements per packed instruction (v_pk_*), with
+// thresholds widened by a bound on the fp32 rounding of the operands, the difference and the 2-pi reduction: it can only
+// let extra pairs through, never drop one.  Every candidate then goes through the exact fp64 gate (pair_gate) before its
+// likelihood is evaluated, so results are unchanged.
+typedef float f2_t __attribute__((ext_vector_type(2)));
+
+// Stages the measurement set into the LDS head (RFS_Z_LDS_BYTES): doubles, the fp32 copy, and the two maxima the prefilter's
+// error bound needs.  All threads of the block call it; the caller synchronises afterwards.
+// `zsrc(t)` yields double t of the set (a device buffer, or the kernel-argument block indexed in place -- taking the
+// address of a by-value kernel argument would make the compiler copy it to scratch).
+template <class ZSrc>
+__device__ __forceinline__ void stage_measurements_lds(unsigned char *smem_raw, ZSrc zsrc, int nZ, int tid, int nThreads) {
+  double *sZ = reinterpret_cast<double *>(smem_raw);
+  float *sZf = reinterpret_cast<float *>(smem_raw + 2 * RFSGPU_MAX_Z * 8);
+  for (int t = tid; t < 2 * nZ; t += nThreads) sZ[t] = zsrc(t);
+  if (tid < 64) {
+    float ar = 0.f, ab = 0.f;
+    const int z = tid < nZ ? tid : 0;
+    const float zr = nZ > 0 ? (float)zsrc(2 * z) : 0.f, zb = nZ > 0 ? (float)zsrc(2 * z + 1) : 0.f;
+    sZf[tid] = zr;                       // (entries beyond nZ repeat measurement 0: the sweep reads whole pairs)
+    sZf[RFSGPU_MAX_Z + tid] = zb;
+    ar = wave_max_f32(fabsf(zr));
+    ab = wave_max_f32(fabsf(zb));
+    if (tid == 0) { sZf[2 * RFSGPU_MAX_Z] = ar; sZf[2 * RFSGPU_MAX_Z + 1] = ab; }
+  }
+}
+
+// Candidate mask of one landmark: bit z set if measurement z MAY pass both innovation gates.
+__device__ __forceinline__ unsigned long long gate_candidates(const Params &P, const LmKF &k, const bool live, const int nZ, const float *sZf) {
+  const float zx0 = (float)k.zx0, zx1 = (float)k.zx1;
+  const float zrMax = sZf[2 * RFSGPU_MAX_Z], zbMax = sZf[2 * RFSGPU_MAX_Z + 1];
+  const float inf = __builtin_huge_valf();
+  // |computed - exact| <= 2^-23 (|a| + |b|) for the rounded operands and difference; the bearing also carries the fp32 2-pi
+  // reduction (|k| <= (zbMax + pi) / 2pi + 1 multiples of a constant that is off by < 2e-7)
+  float thrR = (P.kfRange > 0) ? (float)P.kfRange * (1.f + 1e-6f) + 2.5e-7f * (zrMax + fabsf(zx0)) + 1e-30f : inf;
+  float thrB = (P.kfBearing > 0) ? (float)P.kfBearing * (1.f + 1e-6f) + 1e-6f * (zbMax + 3.2f) + 1e-6f : inf;
+  if (!(zbMax < 50.f)) thrB = inf;       // far outside any sensible bearing range (or NaN): the exact test decides
+  if (!(zrMax < 1.0e30f)) thrR = inf;
+  const f2_t vx0 = {zx0, zx0}, vx1 = {zx1, zx1};
+  const f2_t twoPi = {6.2831853071795864769f, 6.2831853071795864769f}, inv2Pi = {0.15915494309189533577f, 0.15915494309189533577f};
+  unsigned lo = 0, hi = 0;
+#pragma unroll 1
+  for (int half = 0; half < 2; half++) {
+    const int zBase = 32 * half;
+    if (zBase >= nZ) break;
+    unsigned bits = 0;
+    const f2_t *pr = reinterpret_cast<const f2_t *>(sZf + zBase), *pb = reinterpret_cast<const f2_t *>(sZf + RFSGPU_MAX_Z + zBase);
+    const int nPairs = (min(nZ - zBase, 32) + 1) >> 1;
+#pragma unroll 4
+    for (int q = 0; q < nPairs; q++) {
+      const f2_t zr = pr[q], zb = pb[q];     // uniform address: LDS broadcast reads of two measurements each
+      const f2_t e0 = zr - vx0;
+      f2_t w = zb - vx1;
+      f2_t kk = w * inv2Pi;
+      kk.x = __builtin_rintf(kk.x); kk.y = __builtin_rintf(kk.y);
+      w = w - kk * twoPi;
+      // !(x > t) form: a NaN is a candidate
+      const bool c0 = ((int)!(fabsf(e0.x) > thrR) & (int)!(fabsf(w.x) > thrB)) != 0;
+      const bool c1 = ((int)!(fabsf(e0.y) > thrR) & (int)!(fabsf(w.y) > thrB)) != 0;
+      bits |= (c0 ? 1u : 0u) << (2 * q);
+      bits |= (c1 ? 2u : 0u) << (2 * q);
+    }
+    if (half == 0) lo = bits; else hi = bits;
+  }
+  unsigned long long m = ((unsigned long long)hi << 32) | lo;
+  m &= (nZ >= 64) ? ~0ull : ((1ull << nZ) - 1ull);
+  return live ? m : 0ull;
+}
+
+// New Gaussian of a surviving (landmark, measurement) pair: KalmanFilter::correct's mean (include/KalmanFilter.hpp:311-316)
+// with the wrapped innovation, and the landmark's updated covariance.
+__device__ __forceinline__ void emit_updated(const LmKF &k, double mx, double my, double z0, double z1, double *pMX, double *pMY, double *pSXX,
+                                             double *pSXY, double *pSYY, int pos) {
+  const double nu0 = z0 - k.zx0;
+  const double nu1 = wrap_pi(z1 - k.zx1);
+  pMX[pos] = mx + (k.k00 * nu0 + k.k01 * nu1);
+  pMY[pos] = my + (k.k10 * nu0 + k.k11 * nu1);
+  pSXX[pos] = k.p00;
+  pSXY[pos] = k.p01;
+  pSYY[pos] = k.p11;
+}
+
+#define UPDMAP_KEEP 4  // survivor values a lane keeps in registers between the likelihood loop and the list write
+
 // Structure (one wavefront per particle):
-//  phase 1, per pass of 64 landmarks: KF quantities once per landmark; a cheap sweep over the measurements builds each
-//    landmark's innovation-gate bitmask; only the set bits (a few per landmark) go through the Mahalanobis gate and the
-//    Gaussian; survivors are written into a dense (m,z)-row-major list in LDS through a wave prefix sum -- list position
-//    == output slot of the new Gaussian; lane z then folds this pass's survivors of measurement z into its normaliser
-//    in landmark order, i.e. in the reference's summation order (clutter first, then m ascending).
-//  phase 2, dense over the survivor list (all 64 lanes busy): normalise, recompute the landmark's KF quantities, emit.
+//  phase 1, per pass of 64 landmarks: KF quantities once per landmark; the packed-fp32 sweep over the measurements gives each
+//    landmark's candidate mask; only the set bits (a few per landmark) go through the exact innovation gates, the Mahalanobis
+//    gate and the Gaussian; survivors are written into a dense (m,z)-row-major list in LDS through a wave prefix sum -- list
+//    position == output slot of the new Gaussian, whose mean and covariance are written to the slab right there (the lane
+//    still holds the landmark's gain and updated covariance); lane z then folds this pass's survivors of measurement z into
+//    its normaliser in landmark order, i.e. in the reference's summation order (clutter first, then m ascending).
+//  phase 2, dense over the survivor list: normalise, write the weights.  (A new Gaussian whose normalised weight is not
+//    positive -- only through inf / NaN arithmetic -- is dropped by an in-place compaction of the appended block.)
 //  phase 3: missed-detection weights (+ near-limit heuristic from the landmark's list segment), unused mask.
-#ifndef UPDMAP_GATE_BATCH
-#define UPDMAP_GATE_BATCH 8
-#endif
 #ifndef UPDMAP_WAVES_PER_EU
 #define UPDMAP_WAVES_PER_EU 2
 #endif
-// One particle, one wavefront: `lane` of the calling wave, `sZ` the workgroup's LDS copy of the measurement set, `wb` this
-// wave's LDS block (update_map_lds_bytes_per_wave).  Shared by the stand-alone kernel and the fused step kernel.
-template <int GB>  // measurements whose gates are evaluated per trip (scalar loads up front, branch-free): 8 in the stand-alone
-                   // kernel, 4 inside the fused step kernel, whose 128-VGPR budget it shares
-__device__ __forceinline__ void phd_update_map_particle(const Buffers &B, const Params &P, const int cur, const int nZ,
-                                                        const double *__restrict__ Zg, const int i, const int lane, const double *sZ,
-                                                        unsigned char *wb) {
+
+// In-place, order-preserving removal of the appended Gaussians whose normalised weight (sV[q]) is not > 0; executed by ONE
+// wave (the rare path of phase 2).  Returns the number kept.
+__device__ __forceinline__ int compact_appended(const double *sV, int nM, int nSurv, int lane, double *pW, double *pWP, double *pMX, double *pMY,
+                                                double *pSXX, double *pSXY, double *pSYY) {
+  int out = 0;
+  for (int s0 = 0; s0 < nSurv; s0 += 64) {
+    const int q = s0 + lane;
+    const bool keep = (q < nSurv) && (sV[q] > 0.0);
+    const unsigned long long km = __ballot(keep);
+    double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0;
+    if (keep) { v0 = sV[q]; v1 = pMX[nM + q]; v2 = pMY[nM + q]; v3 = pSXX[nM + q]; v4 = pSXY[nM + q]; v5 = pSYY[nM + q]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    wave_sync();
+    if (keep) {
+      const int d = nM + out + __popcll(km & ((1ull << lane) - 1ull));
+      pW[d] = v0; pWP[d] = 0.0; pMX[d] = v1; pMY[d] = v2; pSXX[d] = v3; pSXY[d] = v4; pSYY[d] = v5;
+    }
+    out += __popcll(km);
+  }
+  return out;
+}
+
+// One particle, one wavefront: `lane` of the calling wave, `smemZ` the workgroup's staged measurement set (RFS_Z_LDS_BYTES), `wb`
+// this wave's LDS block (update_map_lds_bytes_per_wave).  The stand-alone kernel's form.
+__device__ __forceinline__ void phd_update_map_particle(const Buffers &B, const Params &P, const int cur, const int nZ, const int i,
+                                                        const int lane, const unsigned char *smemZ, unsigned char *wb) {
+  const double *sZ = reinterpret_cast<const double *>(smemZ);
+  const float *sZf = reinterpret_cast<const float *>(smemZ + 2 * RFSGPU_MAX_Z * 8);
   const int cap = B.cap;
-  double *sV = reinterpret_cast<double *>(wb);                 // [cap] survivor values Pd*w*lik
+  double *sV = reinterpret_cast<double *>(wb);                 // [cap] survivor values Pd*w*lik, later the normalised weights
   double *sCol = sV + cap;                                      // [MAX_Z] final normalisers
   unsigned *sMZ = reinterpret_cast<unsigned *>(sCol + RFSGPU_MAX_Z);  // [cap] (m << 8) | z
   unsigned *sSeg = sMZ + cap;                                   // [cap] per landmark: (start << 8) | count
@@ -169,66 +277,46 @@ __device__ __forceinline__ void phd_update_map_particle(const Buffers &B, const 
     nFov += __popcll(__ballot(fov));
     if (P.useCluster) wsum += act ? w : 0.0;
     if (p == 0) DBG_T(0, 4);
-    // innovation gates for every measurement (cheap), as a bitmask
-    unsigned long long gate = 0;
-    {
-      // Eight measurements per trip: their 16 doubles are fetched with wide scalar loads up front (uniform
-      // addresses), the gate arithmetic is branch-free; the rare bearing difference beyond one wrap is redone exactly.
-      const bool live = fov && k.ok;
-      const bool useR = P.kfRange > 0, useB = P.kfBearing > 0;
-      for (int z0 = 0; z0 < nZ; z0 += GB) {
-        double zr[GB], zb[GB];
+    const unsigned long long cand = gate_candidates(P, k, fov && k.ok, nZ, sZf);
+    if (p == 0) DBG_T(0, 5);
+    // exact innovation gates + Mahalanobis gate + likelihood for the candidates
+    unsigned long long surv = 0;
+    double keepV[UPDMAP_KEEP];
 #pragma unroll
-        for (int u = 0; u < GB; u++) {
-          const int zz = (z0 + u < nZ) ? z0 + u : nZ - 1;
-          zr[u] = Zg[2 * zz];
-          zb[u] = Zg[2 * zz + 1];
-        }
-        bool redo = false;
+    for (int t = 0; t < UPDMAP_KEEP; t++) keepV[t] = 0.0;
+    int cnt = 0;
+    for (unsigned long long g = cand; g; g &= g - 1) {
+      const int z = __builtin_ctzll(g);
+      const double z0 = sZ[2 * z], z1 = sZ[2 * z + 1];
+      if (!pair_gate(P, k, z0, z1)) continue;
+      const double v = pair_value(P, k, pdw, z0, z1);
+      if (v != 0.0) {
+        surv |= (1ull << z);
 #pragma unroll
-        for (int u = 0; u < GB; u++) {
-          const double e0 = zr[u] - k.zx0;
-          double w1 = zb[u] - k.zx1;
-          w1 = (w1 > RFS_PI) ? w1 - 2 * RFS_PI : w1;
-          w1 = (w1 < -RFS_PI) ? w1 + 2 * RFS_PI : w1;
-          // bitwise (non-short-circuit) logic on purpose: no branches, the 8 chains interleave
-          redo = ((int)redo | (int)(w1 > RFS_PI) | (int)(w1 < -RFS_PI)) != 0;
-          const int outR = (int)useR & (int)(fabs(e0) > P.kfRange), outB = (int)useB & (int)(fabs(w1) > P.kfBearing);
-          const bool g = (outR | outB) == 0;
-          gate |= ((int)live & (int)g & (int)(z0 + u < nZ)) ? (1ull << (z0 + u)) : 0ull;
-        }
-        if (__ballot(redo) != 0ull) {  // some bearing difference needs more than one wrap step: exact loop form
-          for (int u = 0; u < GB && z0 + u < nZ; u++) {
-            const bool g = pair_gate(P, k, zr[u], zb[u]);
-            const unsigned long long bit = 1ull << (z0 + u);
-            gate = (live && g) ? (gate | bit) : (gate & ~bit);
-          }
-        }
+        for (int t = 0; t < UPDMAP_KEEP; t++) keepV[t] = (cnt == t) ? v : keepV[t];
+        cnt++;
       }
     }
-    if (p == 0) DBG_T(0, 5);
-    // Mahalanobis gate + likelihood only for the set bits
-    unsigned long long surv = 0;
-    for (unsigned long long g = gate; g; g &= g - 1) {
-      const int z = __builtin_ctzll(g);
-      if (pair_value(P, k, pdw, sZ[2 * z], sZ[2 * z + 1]) != 0.0) surv |= (1ull << z);
-    }
     if (p == 0) DBG_T(0, 6);
-    const int cnt = __popcll(surv);
     const int off = wave_excl_scan(cnt, lane);
     const int total = __builtin_amdgcn_readlane(off + cnt, 63);
     if (act) sSeg[m] = ((unsigned)(nSurv + off) << 8) | (unsigned)cnt;
     {
-      int pos = nSurv + off;
-      for (unsigned long long g = surv; g; g &= g - 1) {
+      int pos = nSurv + off, q = 0;
+      for (unsigned long long g = surv; g; g &= g - 1, q++, pos++) {
         const int z = __builtin_ctzll(g);
         if (pos < room) {
-          sV[pos] = pair_value(P, k, pdw, sZ[2 * z], sZ[2 * z + 1]);
+          const double z0 = sZ[2 * z], z1 = sZ[2 * z + 1];
+          double v = keepV[0];
+#pragma unroll
+          for (int t = 1; t < UPDMAP_KEEP; t++) v = (q == t) ? keepV[t] : v;
+          if (q >= UPDMAP_KEEP) v = pair_value(P, k, pdw, z0, z1);
+          sV[pos] = v;
           sMZ[pos] = ((unsigned)m << 8) | (unsigned)z;
+          emit_updated(k, mx, my, z0, z1, pMX, pMY, pSXX, pSXY, pSYY, nM + pos);
         } else {
           overflow = true;
         }
-        pos++;
       }
     }
     wave_sync();
@@ -262,38 +350,25 @@ __device__ __forceinline__ void phd_update_map_particle(const Buffers &B, const 
   sCol[lane] = cs;
   wave_sync();
 
-  // ---------------- phase 2: dense over survivors ----------------
-  int outBase = nM;
+  // ---------------- phase 2: normalise, write the weights of the appended Gaussians ----------------
   unsigned long long used = 0;
+  bool dropAny = false;
   for (int s0 = 0; s0 < nSurv; s0 += 64) {
     const int sIdx = s0 + lane;
     const bool act = sIdx < nSurv;
-    unsigned mz = 0;
-    double v = 0.0;
-    if (act) { mz = sMZ[sIdx]; v = sV[sIdx]; }
-    const int m = (int)(mz >> 8), z = (int)(mz & 0xffu);
-    const double wn = act ? v / sCol[z] : 0.0;
+    double wn = 0.0;
+    int z = 0;
+    if (act) { z = (int)(sMZ[sIdx] & 0xffu); wn = sV[sIdx] / sCol[z]; sV[sIdx] = wn; }
     if (act && wn != 0.0) used |= (1ull << z);
-    const bool keep = act && (wn > 0.0);  // :677
-    const unsigned long long km = __ballot(keep);
-    if (keep) {
-      const int pos = outBase + __popcll(km & ((1ull << lane) - 1ull));
-      const double mx = pMX[m], my = pMY[m], sxx = pSXX[m], sxy = pSXY[m], syy = pSYY[m];
-      LmKF k;
-      double range;
-      lm_precompute(P, pr, mx, my, sxx, sxy, syy, k, range);
-      const double nu0 = sZ[2 * z] - k.zx0;
-      const double nu1 = wrap_pi(sZ[2 * z + 1] - k.zx1);
-      pW[pos] = wn;
-      pWP[pos] = 0.0;  // addGaussian: weight_prev = 0 (GaussianMixture.hpp:267-284)
-      pMX[pos] = mx + (k.k00 * nu0 + k.k01 * nu1);
-      pMY[pos] = my + (k.k10 * nu0 + k.k11 * nu1);
-      pSXX[pos] = k.p00;
-      pSXY[pos] = k.p01;
-      pSYY[pos] = k.p11;
-    }
-    outBase += __popcll(km);
+    if (act) { pW[nM + sIdx] = wn; pWP[nM + sIdx] = 0.0; }  // addGaussian: weight_prev = 0 (GaussianMixture.hpp:267-284)
+    dropAny |= act && !(wn > 0.0);  // :677
   }
+  int outBase = nM + nSurv;
+  if (__ballot(dropAny) != 0ull) {
+    wave_sync();
+    outBase = nM + compact_appended(sV, nM, nSurv, lane, pW, pWP, pMX, pMY, pSXX, pSXY, pSYY);
+  }
+  wave_sync();
 
   // ---------------- phase 3: missed-detection weights (:686-706); setWeight keeps the old weight in w_prev ----------------
   for (int m = lane; m < nM; m += 64) {
@@ -307,7 +382,7 @@ __device__ __forceinline__ void phd_update_map_particle(const Buffers &B, const 
       const unsigned seg = sSeg[m];
       const int st = (int)(seg >> 8), c = (int)(seg & 0xffu);
       double rowsum = 0.0;
-      for (int q = st; q < st + c && q < nSurv; q++) rowsum += sV[q] / sCol[sMZ[q] & 0xffu];
+      for (int q = st; q < st + c && q < nSurv; q++) rowsum += sV[q];  // (already divided by the normaliser)
       const double delta_w = pd * w - rowsum;
       if (delta_w > 0) {
         w_k += delta_w;
@@ -334,18 +409,19 @@ __device__ __forceinline__ void phd_update_map_particle(const Buffers &B, const 
 
 // LDS of the workgroup form below: the single-wave layout + cross-wave scratch.
 __host__ __device__ inline size_t update_map_block_lds_bytes(int cap) {
-  return update_map_lds_bytes_per_wave(cap) + (size_t)(cap / 64 + 1) * 4 + 128;
+  return update_map_lds_bytes_per_wave(cap) + 128;
 }
 
 // The same map update by a workgroup of WPP waves (used inside the fused step kernel, where the particle's workgroup has
 // more than one wave): passes cover WPP*64 landmarks; the survivor list keeps its (m, z) order through a cross-wave
 // offset exchange, wave 0 folds the normalisers in list order (the reference's summation order), phases 2 and 3 are
 // split over all threads.  Bit-identical to phd_update_map_particle.
-template <int WPP, int GB>
-__device__ __forceinline__ void phd_update_map_block(const Buffers &B, const Params &P, const int cur, const int nZ,
-                                                     const double *__restrict__ Zg, const int i, const int tid, const double *sZ,
-                                                     unsigned char *wb, const bool phasePrio = false) {
+template <int WPP>
+__device__ __forceinline__ void phd_update_map_block(const Buffers &B, const Params &P, const int cur, const int nZ, const int i, const int tid,
+                                                     const unsigned char *smemZ, unsigned char *wb, const bool phasePrio = false) {
   constexpr int NT = WPP * 64;
+  const double *sZ = reinterpret_cast<const double *>(smemZ);
+  const float *sZf = reinterpret_cast<const float *>(smemZ + 2 * RFSGPU_MAX_Z * 8);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int cap = B.cap;
@@ -353,10 +429,9 @@ __device__ __forceinline__ void phd_update_map_block(const Buffers &B, const Par
   double *sCol = sV + cap;                                      // [MAX_Z] final normalisers
   unsigned *sMZ = reinterpret_cast<unsigned *>(sCol + RFSGPU_MAX_Z);  // [cap] (m << 8) | z
   unsigned *sSeg = sMZ + cap;                                   // [cap] per landmark: (start << 8) | count
-  int *sKeep = reinterpret_cast<int *>(sSeg + cap);             // [cap/64 + 1] new Gaussians per 64-survivor chunk
-  int *sTot = sKeep + (cap / 64 + 1);                           // [2][8] survivors per wave of a pass (double-buffered)
-  int *sMisc = sTot + 16;                                       // [0] overflow flag [1] landmarks in FOV
-  unsigned *sUsed = reinterpret_cast<unsigned *>(sMisc + 2);    // [2] used-measurement mask (lo, hi)
+  int *sTot = reinterpret_cast<int *>(sSeg + cap);              // [2][8] survivors per wave of a pass (double-buffered)
+  int *sMisc = sTot + 16;                                       // [0] overflow flag [1] landmarks in FOV [2] a new Gaussian has to be dropped
+  unsigned *sUsed = reinterpret_cast<unsigned *>(sMisc + 4);    // [2] used-measurement mask (lo, hi)
 
   const int nM = B.count[i];
   const unsigned long long zmask = (nZ >= 64) ? ~0ull : ((1ull << nZ) - 1ull);
@@ -374,7 +449,7 @@ __device__ __forceinline__ void phd_update_map_block(const Buffers &B, const Par
 
   PoseReg pr;
   load_pose(B, P, i, pr);
-  if (tid < 4) { if (tid < 2) sMisc[tid] = 0; else sUsed[tid - 2] = 0u; }
+  if (tid < 6) { if (tid < 4) sMisc[tid] = 0; else sUsed[tid - 4] = 0u; }
 
   const int nPass = (nM + NT - 1) / NT;
   const int room = cap - nM;  // survivors that still fit as new Gaussians
@@ -403,45 +478,24 @@ __device__ __forceinline__ void phd_update_map_block(const Buffers &B, const Par
     const bool fov = act && (pd != 0);
     const double pdw = pd * w;
     nFov += __popcll(__ballot(fov));
-    unsigned long long gate = 0;
-    {
-      const bool live = fov && k.ok;
-      const bool useR = P.kfRange > 0, useB = P.kfBearing > 0;
-      for (int z0 = 0; z0 < nZ; z0 += GB) {
-        double zr[GB], zb[GB];
+    const unsigned long long cand = gate_candidates(P, k, fov && k.ok, nZ, sZf);
+    unsigned long long surv = 0;
+    double keepV[UPDMAP_KEEP];
 #pragma unroll
-        for (int u = 0; u < GB; u++) {
-          const int zz = (z0 + u < nZ) ? z0 + u : nZ - 1;
-          zr[u] = Zg[2 * zz];
-          zb[u] = Zg[2 * zz + 1];
-        }
-        bool redo = false;
+    for (int t = 0; t < UPDMAP_KEEP; t++) keepV[t] = 0.0;
+    int cnt = 0;
+    for (unsigned long long g = cand; g; g &= g - 1) {
+      const int z = __builtin_ctzll(g);
+      const double z0 = sZ[2 * z], z1 = sZ[2 * z + 1];
+      if (!pair_gate(P, k, z0, z1)) continue;
+      const double v = pair_value(P, k, pdw, z0, z1);
+      if (v != 0.0) {
+        surv |= (1ull << z);
 #pragma unroll
-        for (int u = 0; u < GB; u++) {
-          const double e0 = zr[u] - k.zx0;
-          double w1 = zb[u] - k.zx1;
-          w1 = (w1 > RFS_PI) ? w1 - 2 * RFS_PI : w1;
-          w1 = (w1 < -RFS_PI) ? w1 + 2 * RFS_PI : w1;
-          redo = ((int)redo | (int)(w1 > RFS_PI) | (int)(w1 < -RFS_PI)) != 0;
-          const int outR = (int)useR & (int)(fabs(e0) > P.kfRange), outB = (int)useB & (int)(fabs(w1) > P.kfBearing);
-          const bool g = (outR | outB) == 0;
-          gate |= ((int)live & (int)g & (int)(z0 + u < nZ)) ? (1ull << (z0 + u)) : 0ull;
-        }
-        if (__ballot(redo) != 0ull) {  // some bearing difference needs more than one wrap step: exact loop form
-          for (int u = 0; u < GB && z0 + u < nZ; u++) {
-            const bool g = pair_gate(P, k, zr[u], zb[u]);
-            const unsigned long long bit = 1ull << (z0 + u);
-            gate = (live && g) ? (gate | bit) : (gate & ~bit);
-          }
-        }
+        for (int t = 0; t < UPDMAP_KEEP; t++) keepV[t] = (cnt == t) ? v : keepV[t];
+        cnt++;
       }
     }
-    unsigned long long surv = 0;
-    for (unsigned long long g = gate; g; g &= g - 1) {
-      const int z = __builtin_ctzll(g);
-      if (pair_value(P, k, pdw, sZ[2 * z], sZ[2 * z + 1]) != 0.0) surv |= (1ull << z);
-    }
-    const int cnt = __popcll(surv);
     const int off = wave_excl_scan(cnt, lane);
     const int totalW = __builtin_amdgcn_readlane(off + cnt, 63);
     int *tot = sTot + 8 * (p & 1);
@@ -452,16 +506,21 @@ __device__ __forceinline__ void phd_update_map_block(const Buffers &B, const Par
     for (int w2 = 0; w2 < WPP; w2++) { const int t = tot[w2]; before += (w2 < wave) ? t : 0; total += t; }
     if (act) sSeg[m] = ((unsigned)(nSurv + before + off) << 8) | (unsigned)cnt;
     {
-      int pos = nSurv + before + off;
-      for (unsigned long long g = surv; g; g &= g - 1) {
+      int pos = nSurv + before + off, q = 0;
+      for (unsigned long long g = surv; g; g &= g - 1, q++, pos++) {
         const int z = __builtin_ctzll(g);
         if (pos < room) {
-          sV[pos] = pair_value(P, k, pdw, sZ[2 * z], sZ[2 * z + 1]);
+          const double z0 = sZ[2 * z], z1 = sZ[2 * z + 1];
+          double v = keepV[0];
+#pragma unroll
+          for (int t = 1; t < UPDMAP_KEEP; t++) v = (q == t) ? keepV[t] : v;
+          if (q >= UPDMAP_KEEP) v = pair_value(P, k, pdw, z0, z1);
+          sV[pos] = v;
           sMZ[pos] = ((unsigned)m << 8) | (unsigned)z;
+          emit_updated(k, mx, my, z0, z1, pMX, pMY, pSXX, pSXY, pSYY, nM + pos);
         } else {
           overflow = true;
         }
-        pos++;
       }
     }
     __syncthreads();
@@ -493,9 +552,10 @@ __device__ __forceinline__ void phd_update_map_block(const Buffers &B, const Par
     nSurv = room < 0 ? 0 : (nSurv > room ? room : nSurv);
   }
 
-  // ---------------- phase 2a: normalise in place, count the new Gaussians of every 64-survivor chunk ----------------
+  // ---------------- phase 2: normalise in place, write the weights of the appended Gaussians ----------------
   {
     unsigned long long used = 0;
+    bool dropAny = false;
     for (int s0 = wave * 64; s0 < nSurv; s0 += NT) {
       const int sIdx = s0 + lane;
       const bool act = sIdx < nSurv;
@@ -503,46 +563,24 @@ __device__ __forceinline__ void phd_update_map_block(const Buffers &B, const Par
       int z = 0;
       if (act) { z = (int)(sMZ[sIdx] & 0xffu); wn = sV[sIdx] / sCol[z]; sV[sIdx] = wn; }
       if (act && wn != 0.0) used |= (1ull << z);
-      const unsigned long long km = __ballot(act && (wn > 0.0));  // :677
-      if (lane == 0) sKeep[s0 >> 6] = __popcll(km);
+      if (act) { pW[nM + sIdx] = wn; pWP[nM + sIdx] = 0.0; }  // addGaussian: weight_prev = 0 (GaussianMixture.hpp:267-284)
+      dropAny |= act && !(wn > 0.0);  // :677
     }
     used = wave_or_u64(used);
     if (lane == 0) { atomicOr(&sUsed[0], (unsigned)(used & 0xffffffffull)); atomicOr(&sUsed[1], (unsigned)(used >> 32)); }
+    if (__ballot(dropAny) != 0ull && lane == 0) atomicOr(&sMisc[2], 1);
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
-  // ---------------- phase 2b: emit, dense over the survivors ----------------
-  int outBase = nM;
-  {
-    const int nChunks = (nSurv + 63) >> 6;
-    int myBase = nM, c = 0;
-    for (int s0 = wave * 64; s0 < nSurv; s0 += NT) {
-      for (; c < (s0 >> 6); c++) myBase += sKeep[c];
-      const int sIdx = s0 + lane;
-      const bool act = sIdx < nSurv;
-      unsigned mz = 0;
-      double wn = 0.0;
-      if (act) { mz = sMZ[sIdx]; wn = sV[sIdx]; }
-      const int m = (int)(mz >> 8), z = (int)(mz & 0xffu);
-      const bool keep = act && (wn > 0.0);
-      const unsigned long long km = __ballot(keep);
-      if (keep) {
-        const int pos = myBase + __popcll(km & ((1ull << lane) - 1ull));
-        const double mx = pMX[m], my = pMY[m], sxx = pSXX[m], sxy = pSXY[m], syy = pSYY[m];
-        LmKF k;
-        double range;
-        lm_precompute(P, pr, mx, my, sxx, sxy, syy, k, range);
-        const double nu0 = sZ[2 * z] - k.zx0;
-        const double nu1 = wrap_pi(sZ[2 * z + 1] - k.zx1);
-        pW[pos] = wn;
-        pWP[pos] = 0.0;  // addGaussian: weight_prev = 0 (GaussianMixture.hpp:267-284)
-        pMX[pos] = mx + (k.k00 * nu0 + k.k01 * nu1);
-        pMY[pos] = my + (k.k10 * nu0 + k.k11 * nu1);
-        pSXX[pos] = k.p00;
-        pSXY[pos] = k.p01;
-        pSYY[pos] = k.p11;
-      }
+  int outBase = nM + nSurv;
+  if (sMisc[2] != 0) {  // rare: a normalised weight that is not positive (inf / NaN arithmetic) -- drop it, keep the order
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (wave == 0) {
+      const int kept = compact_appended(sV, nM, nSurv, lane, pW, pWP, pMX, pMY, pSXX, pSXY, pSYY);
+      if (lane == 0) sMisc[3] = kept;
     }
-    for (int c2 = 0; c2 < nChunks; c2++) outBase += sKeep[c2];
+    __syncthreads();
+    outBase = nM + sMisc[3];
   }
 
   // ---------------- phase 3: missed-detection weights (:686-706); setWeight keeps the old weight in w_prev ----------------
@@ -587,15 +625,11 @@ __device__ __forceinline__ void phd_update_map_block(const Buffers &B, const Par
 template <int WPB>
 __global__ __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(UPDMAP_WAVES_PER_EU, UPDMAP_WAVES_PER_EU))) void phd_update_map_kernel(Buffers B, Params P, int cur, int nZ, const double *__restrict__ Zg) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  // The measurement set is wave-uniform and read-only: it is read through the scalar cache (s_load into SGPRs, which
-  // VALU instructions take as operands directly) where the index is uniform, and from an LDS copy where lanes index
-  // it independently (phases 1b/2).
-  double *sZ = reinterpret_cast<double *>(smem_raw);  // [2*MAX_Z], block-shared
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
-  for (int t = threadIdx.x; t < 2 * nZ; t += WPB * 64) sZ[t] = Zg[t];
+  stage_measurements_lds(smem_raw, [&](int t) { return Zg[t]; }, nZ, (int)threadIdx.x, WPB * 64);
   __syncthreads();
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
   if (i >= B.N) return;
-  phd_update_map_particle<UPDMAP_GATE_BATCH>(B, P, cur, nZ, Zg, i, lane, sZ, smem_raw + 2 * RFSGPU_MAX_Z * 8 + (size_t)wave * update_map_lds_bytes_per_wave(B.cap));
+  phd_update_map_particle(B, P, cur, nZ, i, lane, smem_raw, smem_raw + RFS_Z_LDS_BYTES + (size_t)wave * update_map_lds_bytes_per_wave(B.cap));
 }

@@ -83,61 +83,64 @@ __device__ __forceinline__ int nth_bit(unsigned long long m, int k) {  // index 
   return __builtin_ctzll(m);
 }
 
-// Sum over all partial assignments of one partition (rows = eval points, cols = measurements):
-//   sum exp( sum_{assigned} logL + sum_{missed} log(1-Pd) + (#unassigned cols) * log c )
-// == the loop at include/RBPHDFilter.hpp:961-988 (terms are identical; only the order of the outer sum differs
-// from the lexicographic one).  Pairs whose log-likelihood is the -1000 floor are skipped: their term is
-// exp(<= -1000 + ...) == 0 exactly in fp64 as long as the remaining log-terms sum to < 255.
-__device__ double enumerate_partition(const WeightLDS &s, int nZ, unsigned long long rmask, unsigned long long cmask, double logc) {
+// Sum over all partial assignments of one partition (rows = eval points, cols = measurements), r + c <= 8:
+//   sum over matchings M of  prod_{(i,j) in M} L[i][j] * prod_{rows i unmatched} (1 - Pd_i) * clutter^(#unmatched cols)
+// The reference walks the assignments in lexicographic order and forms each term as exp(sum of logs) with the log table
+// floored at -1000 (include/RBPHDFilter.hpp:907-917, 961-988); a floored cell makes its term exp(<= -1000 + ...) == 0 exactly,
+// and a cell is floored exactly when L == 0 (a positive double has log >= -745), i.e. when the product form gives 0 as well.
+// Here the same sum is built by a subset recurrence over the SMALLER side of the partition (min(r, c) <= 4, so 16 states,
+// all register-resident with static indexing): the items of the larger side are taken one at a time,
+//   f'[S] = f[S] * u + sum_{b in S} f[S - b] * a[b],   u = the item's "left unmatched" factor, a[b] = its L against small item b,
+// and at the end every state is closed with the unmatched factors of the small side.  No exp, no log, no data-dependent
+// control flow: one lane per partition costs <= 7 items x ~50 fused multiply-adds, against up to 209 terms x (exp + walk) of
+// the enumeration.  The terms are the reference's up to the rounding of exp(log a + log b) vs a * b and the order of the
+// additions (a few ulp, against the 1e-9 tolerance on particle weights).
+__device__ double enumerate_partition(const WeightLDS &s, int nZ, unsigned long long rmask, unsigned long long cmask, double clutter) {
   const int r = __popcll(rmask), c = __popcll(cmask);
-  unsigned long long rowsPk = 0, colsPk = 0;  // one byte per local index
-  for (int a = 0; a < r; a++) rowsPk |= (unsigned long long)nth_bit(rmask, a) << (8 * a);
-  for (int b = 0; b < c; b++) colsPk |= (unsigned long long)nth_bit(cmask, b) << (8 * b);
-#define ROWI(a) ((int)((rowsPk >> (8 * (a))) & 0xff))
-#define COLI(b) ((int)((colsPk >> (8 * (b))) & 0xff))
-#define NIB(a) ((int)((ch >> (4 * (a))) & 0xfull))
-#define SETNIB(a, v) ch = (ch & ~(0xfull << (4 * (a)))) | ((unsigned long long)(v) << (4 * (a)))
-  double lik = 0.0;
-  unsigned long long ch = 0;  // nibble a = column choice of row a (c == miss)
-  unsigned used = 0;
-  int a = 0;
-  while (true) {
-    if (a == r) {
-      double pll = 0.0;
-      int k = 0;
-      for (int a2 = 0; a2 < r; a2++) {
-        int b = NIB(a2);
-        if (b < c) { pll += s.L[ROWI(a2) * nZ + COLI(b)]; k++; }
-        else pll += s.evLog1mPd[ROWI(a2)];
-      }
-      for (int t = k; t < c; t++) pll += logc;
-      lik += exp(pll);
-      a--;
-      if (a < 0) break;
-      int b = NIB(a);
-      if (b < c) used &= ~(1u << b);
-      SETNIB(a, b + 1);
-      continue;
+  const bool colsSmall = c <= r;
+  const unsigned long long smallMask = colsSmall ? cmask : rmask;
+  unsigned long long largeMask = colsSmall ? rmask : cmask;
+  const int k = colsSmall ? c : r;
+  int sm[4];
+  double h[4];  // the small item's factor when it stays unmatched
+  {
+    unsigned long long mm = smallMask;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      sm[b] = (b < k) ? __builtin_ctzll(mm) : 0;
+      h[b] = (b < k) ? (colsSmall ? clutter : 1.0 - s.evPd[sm[b]]) : 1.0;
+      if (b < k) mm &= mm - 1;
     }
-    int b = NIB(a);
-    while (b < c && (((used >> b) & 1u) || s.L[ROWI(a) * nZ + COLI(b)] <= -1000.0)) b++;
-    if (b > c) {  // exhausted this row -> backtrack
-      SETNIB(a, 0);
-      a--;
-      if (a < 0) break;
-      int b2 = NIB(a);
-      if (b2 < c) used &= ~(1u << b2);
-      SETNIB(a, b2 + 1);
-      continue;
-    }
-    SETNIB(a, b);
-    if (b < c) used |= (1u << b);
-    a++;
   }
-#undef ROWI
-#undef COLI
-#undef NIB
-#undef SETNIB
+  double f[16];
+  f[0] = 1.0;
+#pragma unroll
+  for (int S = 1; S < 16; S++) f[S] = 0.0;
+  for (; largeMask; largeMask &= largeMask - 1) {
+    const int idx = __builtin_ctzll(largeMask);
+    const double u = colsSmall ? 1.0 - s.evPd[idx] : clutter;
+    double a[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) a[b] = (b < k) ? (colsSmall ? s.L[idx * nZ + sm[b]] : s.L[sm[b] * nZ + idx]) : 0.0;
+#pragma unroll
+    for (int S = 15; S >= 1; S--) {  // descending: f[S - b] is still the previous item's value
+      double acc = f[S] * u;
+#pragma unroll
+      for (int b = 0; b < 4; b++)
+        if ((S >> b) & 1) acc += f[S ^ (1 << b)] * a[b];
+      f[S] = acc;
+    }
+    f[0] *= u;
+  }
+  double lik = 0.0;
+#pragma unroll
+  for (int S = 0; S < 16; S++) {
+    double g = f[S];
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+      if (!((S >> b) & 1)) g *= h[b];
+    lik += g;
+  }
   return lik;
 }
 
@@ -177,13 +180,7 @@ __device__ double rfs_partitions_wave(const WeightLDS &s, int nE, int nZ, double
     if (__ballot(ch) == 0ull) break;
   }
   PART_T(28);
-  // the log table replaces L from here on (zero partition needs no L; :907-917)
-  for (int idx = lane; idx < nE * nZ; idx += 64) {
-    double v = s.L[idx];
-    if (v == 0.0) v = -1000.0;
-    else { v = log(v); if (v < -1000.0) v = -1000.0; }
-    s.L[idx] = v;
-  }
+  // (the reference's log table, :907-917, is formed only where Murty needs it: see enumerate_partition)
   const unsigned long long rootR = __ballot(lane < nE && labR == lane);
   const unsigned long long rootC = __ballot(lane < nZ && labC == nE + lane);
   const int nRootR = __popcll(rootR);
@@ -211,7 +208,6 @@ __device__ double rfs_partitions_wave(const WeightLDS &s, int nE, int nZ, double
 
   PART_T(29);
   // ---- 6. one lane per partition ----
-  const double logc = log(clutter);
   for (int p = lane; p < nPartitions; p += 64) {
     unsigned long long rmask = s.compRows[p], cmask = s.compCols[p];
     double pl;
@@ -222,12 +218,13 @@ __device__ double rfs_partitions_wave(const WeightLDS &s, int nE, int nZ, double
       for (unsigned long long mm = rmask; mm; mm &= mm - 1) pl *= s.evPd[__builtin_ctzll(mm)];
       for (unsigned long long mm = cmask; mm; mm &= mm - 1) pl *= clutter;
     } else if (__popcll(rmask) + __popcll(cmask) <= 8) {
-      pl = enumerate_partition(s, nZ, rmask, cmask, logc);
+      pl = enumerate_partition(s, nZ, rmask, cmask, clutter);
     } else {
       // Murty-200 (:920-959): queue the extended matrix; the factor is multiplied in by murty_kernel
       pl = 1.0;
       int job = Q.count ? atomicAdd(Q.count, 1) : Q.maxJobs;
       const int nR = __popcll(rmask), nC = __popcll(cmask), n = nR + nC;
+      const double logc = log(clutter);
       if (job < Q.maxJobs && n <= MURTY_MAXN) {
         MurtyJob J;
         J.particle = particle; J.nR = nR; J.nC = nC; J.slot = p;
@@ -236,7 +233,11 @@ __device__ double rfs_partitions_wave(const WeightLDS &s, int nE, int nZ, double
         for (int a = 0; a < n; a++)
           for (int b = 0; b < n; b++) {
             double v;
-            if (a < nR && b < nC) v = s.L[nth_bit(rmask, a) * nZ + nth_bit(cmask, b)];
+            if (a < nR && b < nC) {  // log table with the -1000 floor (:907-917)
+              v = s.L[nth_bit(rmask, a) * nZ + nth_bit(cmask, b)];
+              if (v == 0.0) v = -1000.0;
+              else { v = log(v); if (v < -1000.0) v = -1000.0; }
+            }
             else if (a < nR) v = (a == b - nC) ? s.evLog1mPd[nth_bit(rmask, a)] : -1000.0;
             else if (b < nC) v = (a - nR == b) ? logc : -1000.0;
             else v = 0.0;
@@ -270,19 +271,23 @@ __device__ double rfs_partitions_wave(const WeightLDS &s, int nE, int nZ, double
 // One workgroup of WPP waves per particle.  The entry-parallel steps (rank sort, sorted write-out, likelihood table) use
 // all threads; the intensity sums split the evaluation points between the waves (groups of 8); the serial steps
 // (evaluation-point selection, components, partition enumeration) run on wave 0 while wave 1 takes the weight sums.
+// permOut (LDS, [cap] u16) != null: instead of writing the weight-sorted mixture to the other slab (what the stand-alone kernel
+// does -- the order GaussianMixture::merge then walks), only the sorting permutation is left there for the merge phase of the
+// fused step kernel, which reads the slab through it; `dst` is then unused.
 template <int WPP>
 __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Params &P, const int src, const int dst, const int nZ, const int evalCap,
-                                                    const MurtyQueue &Q, const int i, const int tid, unsigned char *smem_raw) {
+                                                    const MurtyQueue &Q, const int i, const int tid, unsigned char *smem_raw,
+                                                    unsigned short *permOut = nullptr) {
   constexpr int NT = WPP * 64;
   double *sZ = reinterpret_cast<double *>(smem_raw);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   auto block_sync = [&]() { if (WPP == 1) wave_sync(); else __syncthreads(); };
-  for (int t = tid; t < 2 * nZ; t += NT) sZ[t] = B.Z[t];
+  if (!permOut) for (int t = tid; t < 2 * nZ; t += NT) sZ[t] = B.Z[t];   // (inside the fused step kernel the staged set of the map update is still there)
   WeightLDS s;
   const size_t perBytes = weight_lds_bytes_per_wave(B.cap, evalCap, nZ);
-  carve_weight_lds(smem_raw + 2 * RFSGPU_MAX_Z * 8, B.cap, evalCap, nZ, s);
-  double *sScr = reinterpret_cast<double *>(smem_raw + 2 * RFSGPU_MAX_Z * 8 + perBytes);  // [0] sumPrev [1] sumCur
+  carve_weight_lds(smem_raw + RFS_Z_LDS_BYTES, B.cap, evalCap, nZ, s);
+  double *sScr = reinterpret_cast<double *>(smem_raw + RFS_Z_LDS_BYTES + perBytes);  // [0] sumPrev [1] sumCur
   int *sScrI = reinterpret_cast<int *>(sScr + 4);                                           // [0] nE [1] missing-rank flag
 
   const int N = B.count[i];
@@ -297,10 +302,14 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
   int nEvalPoints = ((unsigned)P.evalCount > (unsigned)N) ? N : P.evalCount;
   if (nEvalPoints == 0) {
     // weight := denorm_min, mixture NOT sorted (:742-745): copy through unchanged
-    for (int pl = 0; pl < PL_COUNT; pl++) {
-      const double *q = plane((double *)sl, B.cap, i, pl);
-      double *d = plane(dl, B.cap, i, pl);
-      for (int m = tid; m < N; m += NT) d[m] = q[m];
+    if (permOut) {
+      for (int m = tid; m < N; m += NT) permOut[m] = (unsigned short)m;
+    } else {
+      for (int pl = 0; pl < PL_COUNT; pl++) {
+        const double *q = plane((double *)sl, B.cap, i, pl);
+        double *d = plane(dl, B.cap, i, pl);
+        for (int m = tid; m < N; m += NT) d[m] = q[m];
+      }
     }
     if (tid == 0) B.weight[i] = RFS_DENORM_MIN;
     return;
@@ -398,7 +407,10 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
   }
   DBG_TB(16, 10);
   block_sync();
-  // sorted mixture -> other slab
+  // sorted mixture -> other slab (or just the permutation, for the fused step's merge phase)
+  if (permOut) {
+    for (int r = tid; r < N; r += NT) permOut[r] = (unsigned short)s.perm[r];
+  } else
   for (int r = tid; r < N; r += NT) {
     const int m = s.perm[r];
     // all gathers first (independent loads in flight together), then the coalesced stores
@@ -537,15 +549,56 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
       z[0] = mo.z0; z[1] = mo.z1; z[2] = i00; z[3] = i01; z[4] = i10; z[5] = i11; z[6] = pdf_factor2(det);
     }
     if (split) wave_sync(); else block_sync();
-    for (int idx = t0i; idx < nE * nZ; idx += tN) {
-      const int e = idx / nZ, n = idx - e * nZ;
+    auto table_md2 = [&](int idx, int &e) -> double {
+      e = idx / nZ;
+      const int n = idx - e * nZ;
       const double *z = s.evZ + 7 * e;
       const double d0 = sZ[2 * n] - z[0], d1 = sZ[2 * n + 1] - z[1];
       const double t0 = d0 * z[2] + d1 * z[4], t1 = d0 * z[3] + d1 * z[5];
-      const double md2 = t0 * d0 + t1 * d1;
-      double Lv = gauss_from_md2(md2, z[6]) * s.evPd[e];
-      if (md2 > P.weightingMd2) Lv = 0.0;
-      s.L[idx] = Lv;
+      return t0 * d0 + t1 * d1;
+    };
+    if (split || WPP == 1) {
+      // One wave fills the table.  Almost every cell fails the Mahalanobis gate (:855-859) and is 0: the sweep computes
+      // md2 only and collects the few cells inside the gate; the Gaussian (exp) is then evaluated densely over that list.
+      int *list = s.labR;                       // [128]: labR + labC, written only later by the component search
+      int nList = 0;
+      for (int i0 = 0; i0 < nE * nZ; i0 += 64) {
+        const int idx = i0 + lane;
+        bool in = false;
+        if (idx < nE * nZ) {
+          int e;
+          const double md2 = table_md2(idx, e);
+          in = !(md2 > P.weightingMd2);         // (a NaN md2 stays in: its likelihood is 0 through the NaN guard)
+          s.L[idx] = 0.0;
+        }
+        const unsigned long long m = __ballot(in);
+        const int pos = nList + __popcll(m & ((1ull << lane) - 1ull));
+        if (in) {
+          if (pos < 128) list[pos] = idx;
+          else {                                 // list full: evaluate on the spot
+            int e;
+            const double md2 = table_md2(idx, e);
+            s.L[idx] = gauss_from_md2(md2, s.evZ[7 * e + 6]) * s.evPd[e];
+          }
+        }
+        nList += __popcll(m);
+      }
+      wave_sync();
+      nList = nList < 128 ? nList : 128;
+      for (int q = lane; q < nList; q += 64) {
+        const int idx = list[q];
+        int e;
+        const double md2 = table_md2(idx, e);
+        s.L[idx] = gauss_from_md2(md2, s.evZ[7 * e + 6]) * s.evPd[e];
+      }
+    } else {
+      for (int idx = t0i; idx < nE * nZ; idx += tN) {
+        int e;
+        const double md2 = table_md2(idx, e);
+        double Lv = gauss_from_md2(md2, s.evZ[7 * e + 6]) * s.evPd[e];
+        if (md2 > P.weightingMd2) Lv = 0.0;
+        s.L[idx] = Lv;
+      }
     }
     if (split) wave_sync(); else block_sync();
   }

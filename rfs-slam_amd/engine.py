@@ -66,6 +66,11 @@ class RBPHDFilter(capi.CFilter):
         Z, n = self._z(Z)
         self._call("update_async", self._ptr(Z), n)
 
+    def step_async(self, Z, normalize=True):
+        """update_async + the weight reduction (and, with normalize, the division) in the step's post kernel."""
+        Z, n = self._z(Z)
+        self._call("step_async", self._ptr(Z), n, C.c_int(1 if normalize else 0))
+
     def kernel_time_stats(self):
         avg = (C.c_double * 3)()
         n = C.c_int()

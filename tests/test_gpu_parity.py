@@ -122,6 +122,46 @@ def test_update_async_matches_oracle(pkg, ob, sc, kw, fused, monkeypatch):
     compare_maps(sc, dev, orc, scen["n"], ordered=True)
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("normalize", [True, False])
+def test_step_async_sums_and_normalises_in_the_post_kernel(pkg, ob, sc, fused, normalize, monkeypatch):
+    """rfsgpu_step_async: the step's post kernel (Murty partitions, queue reset, weight sums, optional division) gives the
+    update_async + weight_sums + normalize_weights results, over several steps, with and without Murty partitions."""
+    monkeypatch.setenv("RFSGPU_FUSED_STEP", fused)
+    for kw in (dict(n_particles=48, n_landmarks=60, n_z=14, seed=3), dict(n_particles=24, n_landmarks=60, n_z=30, seed=21, n_eval=25, weighting_md=10.0, weights=(0.8, 1.0))):
+        scen = sc.make_scenario(**kw)
+        dev, orc = make_pair(pkg, ob, sc, scen)
+        ref, _ = make_pair(pkg, ob, sc, scen)
+        for step in range(3):
+            if step:
+                for f in (dev, ref, orc):
+                    f.predict_map(True)
+            dev.step_async(scen["Z"], normalize)
+            dev.synchronize()
+            ref.update_async(scen["Z"])
+            s_ref = ref.weight_sums()
+            orc.update(scen["Z"])
+            s_orc = orc.weight_sums()
+            if kw.get("weighting_md"):
+                assert orc.murty_calls() > 0
+            ptr = dev.weight_sums_device_ptr()
+            import ctypes
+            import torch
+            sums = torch.as_tensor(pkg.sharded._DevArray(ptr, 2), device="cuda").cpu().numpy()
+            np.testing.assert_allclose(sums, s_ref, rtol=1e-13)
+            np.testing.assert_allclose(sums, s_orc, rtol=1e-8)
+            if normalize:
+                ref.normalize_weights(s_ref[0])
+                orc.normalize_weights(s_orc[0])
+                assert abs(dev.get_weights().sum() - 1) < 1e-12
+            np.testing.assert_allclose(dev.get_weights(), ref.get_weights(), rtol=1e-13)
+            np.testing.assert_allclose(dev.get_weights(), orc.get_weights(), rtol=1e-8)
+            for i in range(scen["n"]):
+                for a, b in zip(dev.export_gm(i), ref.export_gm(i)):
+                    assert np.array_equal(a, b)
+        dev.close(); ref.close(); orc.close()
+
+
 def test_cluster_process_weighting(pkg, ob, sc):
     scen = sc.make_scenario(32, 90, 20, seed=11, use_cluster=True)
     dev, orc = make_pair(pkg, ob, sc, scen)
