@@ -290,6 +290,43 @@ int rfsgpu_import_slab_rows(rfsgpu_filter *f, const int *slots, int n, const voi
 /* Device pointer of the N particle weights (for an all-gather that stays on the GPUs); valid for the handle's lifetime. */
 void *rfsgpu_weights_device_ptr(rfsgpu_filter *f);
 
+/* ---- one filter over several GPUs from ONE host thread (SURVEY 8(b) "device_ids[], n_dev"; 8(e)) ------------------------
+ * The particle set of rfs::RBPHDFilter is cut into contiguous blocks, one shard (an rfsgpu_filter) per listed device.  What a
+ * C++ host standing where rfs::RBPHDFilter stands needs to use more than one GPU:
+ *   predict / update / normalise / resample over the whole set, configuration broadcast to all shards, map access by global
+ *   particle index.  Shards run their fused steps concurrently; they meet in the weight normalisation (per-shard sums added on
+ *   the host in shard order) and in resampling, which stays GLOBAL (ParticleFilter::resample, include/ParticleFilter.hpp:399-492):
+ *   cross-device children travel as packed rows with hipMemcpyPeerAsync (rfsgpu_export/import_slab_rows).
+ * device_ids may repeat a device (several shards on one GPU: how the single-GPU tests drive this code). */
+typedef struct rfsgpu_group rfsgpu_group;
+int rfsgpu_group_create(rfsgpu_group **out, int model, int n_particles, const int *device_ids, int n_dev, int gm_capacity);
+void rfsgpu_group_destroy(rfsgpu_group *g);
+const char *rfsgpu_group_last_error(const rfsgpu_group *g);
+int rfsgpu_group_n_shards(const rfsgpu_group *g);
+int rfsgpu_group_n_particles(const rfsgpu_group *g);
+rfsgpu_filter *rfsgpu_group_shard(rfsgpu_group *g, int k);                    /* the shard's own handle (map import/export, timing) */
+int rfsgpu_group_locate(const rfsgpu_group *g, int particle, int *shard, int *slot);
+int rfsgpu_group_set_filter_config(rfsgpu_group *g, const rfsgpu_filter_config *c);
+int rfsgpu_group_set_model_rngbrg(rfsgpu_group *g, const rfsgpu_rngbrg_config *c);
+int rfsgpu_group_set_kf_config(rfsgpu_group *g, const rfsgpu_kf_config *c);
+int rfsgpu_group_set_lmk_process_noise(rfsgpu_group *g, const double *Q);
+int rfsgpu_group_set_poses(rfsgpu_group *g, const double *x, const double *cov, int cov_stride);   /* N poses, as rfsgpu_set_poses */
+int rfsgpu_group_get_poses(rfsgpu_group *g, double *x);
+int rfsgpu_group_set_weights(rfsgpu_group *g, const double *w);
+int rfsgpu_group_get_weights(rfsgpu_group *g, double *w);
+int rfsgpu_group_predict_map(rfsgpu_group *g, int add_birth);                 /* RBPHDFilter::predict, map part (:415-442) */
+/* RBPHDFilter::update body (:444-523) on every shard; weights stay un-normalised; sums_out (may be null) = {sum w, sum w^2}. */
+int rfsgpu_group_update(rfsgpu_group *g, const double *z, int n_z, double *sums_out);
+int rfsgpu_group_normalize(rfsgpu_group *g, double *sums_out);               /* normalizeWeights over all N (:352-363) */
+/* ParticleFilter::resample (:399-492) with the caller's uniform draw (the reference's one drand48()); *fired tells whether the
+ * N_eff test let it happen; plan_out (may be null, N ints): global source slot of every slot, for per-particle host data. */
+int rfsgpu_group_resample(rfsgpu_group *g, double eff_n_threshold, double u01, int *fired, int *plan_out);
+int rfsgpu_group_apply_plan(rfsgpu_group *g, const int *src);                /* a resampling plan computed elsewhere */
+int rfsgpu_group_migration_stats(const rfsgpu_group *g, long long *rows, long long *bytes);
+int rfsgpu_group_gm_size(rfsgpu_group *g, int particle);                     /* getGMSize, global index */
+int rfsgpu_group_get_landmark(rfsgpu_group *g, int particle, int m, double *mean, double *cov, double *w);
+int rfsgpu_group_synchronize(rfsgpu_group *g);
+
 /* ---- timing / misc ---------------------------------------------------------------------------- */
 
 int rfsgpu_get_timing(rfsgpu_filter *f, rfsgpu_timing *t);              /* getTimingInfo :1219-1232 */

@@ -117,6 +117,10 @@ ABI_SYMBOLS = [
     "normalize_weights_parts", "create_ex", "n_particles", "max_particles", "resample_apply_n",
     "fastslam_set_resample_occured", "particle_parents", "vp_probe_pd",
     "slab_row_bytes", "export_slab_rows", "import_slab_rows", "weights_device_ptr", "step_async",
+    "group_create", "group_destroy", "group_last_error", "group_n_shards", "group_n_particles", "group_shard", "group_locate",
+    "group_set_filter_config", "group_set_model_rngbrg", "group_set_kf_config", "group_set_lmk_process_noise", "group_set_poses",
+    "group_get_poses", "group_set_weights", "group_get_weights", "group_predict_map", "group_update", "group_normalize",
+    "group_resample", "group_apply_plan", "group_migration_stats", "group_gm_size", "group_get_landmark", "group_synchronize",
 ]
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -139,11 +143,15 @@ def _f64(a, shape=None):
 class CFilter:
     """One filter handle behind the C ABI (one GPU / one shard of particles)."""
 
-    def __init__(self, lib, prefix, n_particles, model=MODEL_RNGBRG_2D, device_id=0, gm_capacity=512, max_particles=None):
+    def __init__(self, lib, prefix, n_particles, model=MODEL_RNGBRG_2D, device_id=0, gm_capacity=512, max_particles=None, borrowed=None):
         self._lib, self._p = lib, prefix
         self.model = model
         self.device_id = device_id
         self.dm = self.dz = 3 if model == MODEL_VICTORIAPARK_3D else 2
+        self._borrowed = borrowed is not None
+        if self._borrowed:          # a shard handle owned by an rfsgpu_group
+            self._h = C.c_void_p(borrowed)
+            return
         self._h = C.c_void_p()
         fn = self._fn("create_ex")
         fn.restype = C.c_int
@@ -182,6 +190,9 @@ class CFilter:
         return rc
 
     def close(self):
+        if getattr(self, "_borrowed", False):
+            self._h = C.c_void_p()
+            return
         if getattr(self, "_h", None) and self._h.value:
             d = self._fn("destroy")
             d.restype = None
@@ -474,3 +485,136 @@ def mat_perm(lib, prefix, A, device_id=0):
     if rc != OK:
         raise EngineError(rc, "mat_perm failed")
     return out
+
+
+class Group:
+    """rfsgpu_group_*: one filter over several GPUs from one host thread (contiguous particle blocks, one shard per device)."""
+
+    def __init__(self, lib, n_particles, device_ids, gm_capacity=512, model=MODEL_RNGBRG_2D):
+        self._lib = lib
+        self._g = C.c_void_p()
+        ids = np.ascontiguousarray(device_ids, dtype=np.int32)
+        lib.rfsgpu_group_create.restype = C.c_int
+        rc = lib.rfsgpu_group_create(C.byref(self._g), C.c_int(model), C.c_int(int(n_particles)), ids.ctypes.data_as(C.c_void_p), C.c_int(ids.size),
+                                     C.c_int(gm_capacity))
+        if rc != OK:
+            self._g = C.c_void_p()
+            raise EngineError(rc, "group_create failed")
+        self.n = int(n_particles)
+        self.dm = self.dz = 3 if model == MODEL_VICTORIAPARK_3D else 2
+        lib.rfsgpu_group_shard.restype = C.c_void_p
+        self.shards = [CFilter(lib, "rfsgpu_", 0, model=model, device_id=int(ids[k]), gm_capacity=gm_capacity,
+                               borrowed=lib.rfsgpu_group_shard(self._g, C.c_int(k))) for k in range(ids.size)]
+
+    def _call(self, name, *args):
+        fn = getattr(self._lib, "rfsgpu_group_" + name)
+        fn.restype = C.c_int
+        rc = fn(self._g, *args)
+        if rc != OK:
+            le = self._lib.rfsgpu_group_last_error
+            le.restype = C.c_char_p
+            raise EngineError(rc, (le(self._g) or b"").decode())
+
+    def close(self):
+        if self._g and self._g.value:
+            for s in self.shards:
+                s.close()
+            self._lib.rfsgpu_group_destroy.restype = None
+            self._lib.rfsgpu_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def locate(self, particle):
+        k, s = C.c_int(), C.c_int()
+        self._call("locate", C.c_int(int(particle)), C.byref(k), C.byref(s))
+        return k.value, s.value
+
+    def set_filter_config(self, cfg):
+        self._call("set_filter_config", C.byref(cfg))
+
+    def set_model_rngbrg(self, R, Pd, c, rmax, rmin, rbuf):
+        m = RngBrgConfig()
+        R = _f64(R, (4,))
+        for k in range(4):
+            m.R[k] = R[k]
+        m.probabilityOfDetection, m.uniformClutterIntensity = Pd, c
+        m.rangeLimMax, m.rangeLimMin, m.rangeLimBuffer = rmax, rmin, rbuf
+        self._call("set_model_rngbrg", C.byref(m))
+
+    def set_kf_config(self, range_thr, bearing_thr):
+        self._call("set_kf_config", C.byref(KFConfig(range_thr, bearing_thr)))
+
+    def set_lmk_process_noise(self, Q):
+        self._call("set_lmk_process_noise", _f64(Q, (self.dm * self.dm,)).ctypes.data_as(C.c_void_p))
+
+    def default_filter_config(self):
+        return self.shards[0].default_filter_config()
+
+    def set_poses(self, x, cov=None):
+        x = _f64(x, (self.n, 3))
+        if cov is None:
+            self._call("set_poses", x.ctypes.data_as(C.c_void_p), C.c_void_p(), C.c_int(0))
+        else:
+            cov = _f64(cov)
+            self._call("set_poses", x.ctypes.data_as(C.c_void_p), cov.ctypes.data_as(C.c_void_p), C.c_int(0 if cov.size == 9 else 9))
+
+    def get_poses(self):
+        x = np.empty((self.n, 3))
+        self._call("get_poses", x.ctypes.data_as(C.c_void_p))
+        return x
+
+    def set_weights(self, w):
+        self._call("set_weights", _f64(w, (self.n,)).ctypes.data_as(C.c_void_p))
+
+    def get_weights(self):
+        w = np.empty(self.n)
+        self._call("get_weights", w.ctypes.data_as(C.c_void_p))
+        return w
+
+    def import_gm(self, i, w, mean, cov):
+        k, s = self.locate(i)
+        self.shards[k].import_gm(s, w, mean, cov)
+
+    def export_gm(self, i):
+        k, s = self.locate(i)
+        return self.shards[k].export_gm(s)
+
+    def get_unused(self, i):
+        k, s = self.locate(i)
+        return self.shards[k].get_unused(s)
+
+    def gm_sizes(self):
+        return np.concatenate([s.gm_sizes() for s in self.shards])
+
+    def predict_map(self, add_birth=True):
+        self._call("predict_map", C.c_int(1 if add_birth else 0))
+
+    def update(self, Z):
+        Z = _f64(Z).reshape(-1, self.dz)
+        sums = np.empty(2)
+        self._call("update", Z.ctypes.data_as(C.c_void_p), C.c_int(Z.shape[0]), sums.ctypes.data_as(C.c_void_p))
+        return sums
+
+    def normalize(self):
+        sums = np.empty(2)
+        self._call("normalize", sums.ctypes.data_as(C.c_void_p))
+        return sums
+
+    def resample(self, eff_n_threshold, u01):
+        fired = C.c_int()
+        plan = np.empty(self.n, dtype=np.int32)
+        self._call("resample", C.c_double(eff_n_threshold), C.c_double(u01), C.byref(fired), plan.ctypes.data_as(C.c_void_p))
+        return bool(fired.value), (plan if fired.value else None)
+
+    def migration_stats(self):
+        r, b = C.c_longlong(), C.c_longlong()
+        self._call("migration_stats", C.byref(r), C.byref(b))
+        return r.value, b.value
+
+    def synchronize(self):
+        self._call("synchronize")

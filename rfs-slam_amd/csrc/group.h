@@ -1,0 +1,323 @@
+// group.h -- rfsgpu_group_*: ONE filter over SEVERAL GPUs from a single host thread ("rfsgpu_create(model, n,
+// device_ids[], n_dev, ...)", 8(e)).  The particle set of rfs::RBPHDFilter (include/RBPHDFilter.hpp:72-251) is cut into
+// contiguous blocks, one rfsgpu_filter shard per listed device; every phase of update() before resampling is independent per
+// particle (:469-520) and runs on all shards concurrently (stream-ordered fused steps); the shards meet
+//   * in normalizeWeights / N_eff (include/ParticleFilter.hpp:352-363, 405-415): each shard's post kernel leaves {sum w, sum w^2},
+//     the 2 x n_dev doubles are added on the host in shard order and every shard divides by the same total, and
+//   * in resample (:399-492), which keeps the reference's GLOBAL systematic resampling: one plan over all N weights, local
+//     children by a device gather, cross-device children as packed rows (rfsgpu_export_slab_rows) moved with
+//     hipMemcpyPeerAsync over xGMI and unpacked on the destination (rfsgpu_import_slab_rows).
+// (The multi-process form of the same logic, over RCCL, is rfs-slam_amd/sharded.py.)  Included at the end of rfsgpu_engine.hip.
+#pragma once
+
+struct rfsgpu_group {
+  std::vector<rfsgpu_filter *> shard;
+  std::vector<int> first;      // first global particle index of every shard (+ total at the end)
+  int N = 0;
+  std::vector<unsigned char *> sendBuf, recvBuf;   // per shard, device memory on its device, grown on demand
+  std::vector<size_t> sendCap, recvCap;
+  std::vector<hipEvent_t> evExport;
+  std::vector<int> lastPlan;
+  long long rowsMigrated = 0, bytesMigrated = 0;
+  std::string err;
+};
+
+static int gfail(rfsgpu_group *g, int code, const std::string &msg) {
+  g->err = msg;
+  return code;
+}
+#define GCHK(call)                                                                      \
+  do {                                                                                  \
+    hipError_t e_ = (call);                                                             \
+    if (e_ != hipSuccess) return gfail(g, RFSGPU_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+#define GFWD(k, call)                                                                   \
+  do {                                                                                  \
+    int rc_ = (call);                                                                   \
+    if (rc_ != RFSGPU_OK) return gfail(g, rc_, std::string("shard ") + std::to_string(k) + ": " + rfsgpu_last_error(g->shard[k])); \
+  } while (0)
+
+// ParticleFilter::resample's systematic sampling + slot assignment (include/ParticleFilter.hpp:419-479), given the uniform draw.
+static void systematic_plan(const std::vector<double> &w, double u01, std::vector<int> &src) {
+  const int n = (int)w.size();
+  std::vector<int> sampledIdx(n);
+  std::vector<char> sampled(n, 0);
+  const double interval = 1.0 / double(n);
+  double samplePoint = interval * u01, cumulative = w[0];
+  int idx = 0;
+  for (int i = 0; i < n; i++) {
+    while (samplePoint > cumulative && idx < n - 1) { idx++; cumulative += w[idx]; }
+    sampledIdx[i] = idx;
+    sampled[idx] = 1;
+    samplePoint += interval;
+  }
+  src.resize(n);
+  for (int i = 0; i < n; i++) src[i] = i;
+  int next = 0, prev = -1;
+  for (int i = 0; i < n; i++) {
+    const int s = sampledIdx[i];
+    const bool first = !(i > 0 && s == prev);
+    prev = s;
+    if (first) continue;                       // the particle keeps its own slot (:459-463)
+    while (next < n && sampled[next]) next++;  // copies go into the un-sampled slots, in order (:464-477)
+    src[next] = s;
+    next++;
+  }
+}
+
+extern "C" {
+
+int rfsgpu_group_create(rfsgpu_group **out, int model, int n_particles, const int *device_ids, int n_dev, int gm_capacity) {
+  if (!out || !device_ids || n_dev < 1 || n_particles < n_dev) return RFSGPU_ERR_INVALID;
+  *out = nullptr;
+  rfsgpu_group *g = new rfsgpu_group();
+  g->N = n_particles;
+  g->first.resize(n_dev + 1);
+  for (int k = 0; k <= n_dev; k++) g->first[k] = (int)((long long)n_particles * k / n_dev);
+  for (int k = 0; k < n_dev; k++) {
+    rfsgpu_filter *f = nullptr;
+    const int rc = rfsgpu_create(&f, model, g->first[k + 1] - g->first[k], device_ids[k], gm_capacity);
+    if (rc != RFSGPU_OK) { rfsgpu_group_destroy(g); return rc; }
+    g->shard.push_back(f);
+  }
+  g->sendBuf.assign(n_dev, nullptr); g->recvBuf.assign(n_dev, nullptr);
+  g->sendCap.assign(n_dev, 0); g->recvCap.assign(n_dev, 0);
+  g->evExport.assign(n_dev, nullptr);
+  for (int k = 0; k < n_dev; k++) {
+    hipSetDevice(device_ids[k]);
+    if (hipEventCreateWithFlags(&g->evExport[k], hipEventDisableTiming) != hipSuccess) { rfsgpu_group_destroy(g); return RFSGPU_ERR_HIP; }
+    for (int j = 0; j < n_dev; j++)   // xGMI peer access for the row transport (already-enabled / same-device answers are fine)
+      if (device_ids[j] != device_ids[k]) { int can = 0; if (hipDeviceCanAccessPeer(&can, device_ids[k], device_ids[j]) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(device_ids[j], 0); }
+    (void)hipGetLastError();
+  }
+  *out = g;
+  return RFSGPU_OK;
+}
+void rfsgpu_group_destroy(rfsgpu_group *g) {
+  if (!g) return;
+  for (size_t k = 0; k < g->shard.size(); k++) {
+    if (g->shard[k]) hipSetDevice(g->shard[k]->device);
+    if (k < g->sendBuf.size() && g->sendBuf[k]) hipFree(g->sendBuf[k]);
+    if (k < g->recvBuf.size() && g->recvBuf[k]) hipFree(g->recvBuf[k]);
+    if (k < g->evExport.size() && g->evExport[k]) hipEventDestroy(g->evExport[k]);
+    rfsgpu_destroy(g->shard[k]);
+  }
+  delete g;
+}
+const char *rfsgpu_group_last_error(const rfsgpu_group *g) { return g ? g->err.c_str() : "null group"; }
+int rfsgpu_group_n_shards(const rfsgpu_group *g) { return g ? (int)g->shard.size() : -1; }
+int rfsgpu_group_n_particles(const rfsgpu_group *g) { return g ? g->N : -1; }
+rfsgpu_filter *rfsgpu_group_shard(rfsgpu_group *g, int k) { return (g && k >= 0 && k < (int)g->shard.size()) ? g->shard[k] : nullptr; }
+int rfsgpu_group_locate(const rfsgpu_group *g, int particle, int *shard, int *slot) {
+  if (!g || particle < 0 || particle >= g->N || !shard || !slot) return RFSGPU_ERR_INVALID;
+  int k = 0;
+  while (particle >= g->first[k + 1]) k++;
+  *shard = k;
+  *slot = particle - g->first[k];
+  return RFSGPU_OK;
+}
+
+// configuration: the same structs on every shard (RBPHDFilter keeps one copy per OpenMP thread and broadcasts them at update, :460-464)
+int rfsgpu_group_set_filter_config(rfsgpu_group *g, const rfsgpu_filter_config *c) {
+  if (!g) return RFSGPU_ERR_INVALID;
+  for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_set_filter_config(g->shard[k], c));
+  return RFSGPU_OK;
+}
+int rfsgpu_group_set_model_rngbrg(rfsgpu_group *g, const rfsgpu_rngbrg_config *c) {
+  if (!g) return RFSGPU_ERR_INVALID;
+  for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_set_model_rngbrg(g->shard[k], c));
+  return RFSGPU_OK;
+}
+int rfsgpu_group_set_kf_config(rfsgpu_group *g, const rfsgpu_kf_config *c) {
+  if (!g) return RFSGPU_ERR_INVALID;
+  for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_set_kf_config(g->shard[k], c));
+  return RFSGPU_OK;
+}
+int rfsgpu_group_set_lmk_process_noise(rfsgpu_group *g, const double *Q) {
+  if (!g) return RFSGPU_ERR_INVALID;
+  for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_set_lmk_process_noise(g->shard[k], Q));
+  return RFSGPU_OK;
+}
+int rfsgpu_group_set_poses(rfsgpu_group *g, const double *x, const double *cov, int cov_stride) {
+  if (!g || !x) return RFSGPU_ERR_INVALID;
+  for (size_t k = 0; k < g->shard.size(); k++)
+    GFWD(k, rfsgpu_set_poses(g->shard[k], x + 3 * (size_t)g->first[k], cov ? cov + (size_t)cov_stride * g->first[k] : nullptr, cov_stride));
+  return RFSGPU_OK;
+}
+int rfsgpu_group_get_poses(rfsgpu_group *g, double *x) {
+  if (!g || !x) return RFSGPU_ERR_INVALID;
+  for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_get_poses(g->shard[k], x + 3 * (size_t)g->first[k]));
+  return RFSGPU_OK;
+}
+int rfsgpu_group_set_weights(rfsgpu_group *g, const double *w) {
+  if (!g || !w) return RFSGPU_ERR_INVALID;
+  for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_set_weights(g->shard[k], w + g->first[k]));
+  return RFSGPU_OK;
+}
+int rfsgpu_group_get_weights(rfsgpu_group *g, double *w) {
+  if (!g || !w) return RFSGPU_ERR_INVALID;
+  for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_get_weights(g->shard[k], w + g->first[k]));
+  return RFSGPU_OK;
+}
+int rfsgpu_group_predict_map(rfsgpu_group *g, int add_birth) {
+  if (!g) return RFSGPU_ERR_INVALID;
+  for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_predict_map(g->shard[k], add_birth));
+  return RFSGPU_OK;
+}
+int rfsgpu_group_synchronize(rfsgpu_group *g) {
+  if (!g) return RFSGPU_ERR_INVALID;
+  for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_synchronize(g->shard[k]));
+  return RFSGPU_OK;
+}
+
+// {sum w, sum w^2} over all shards (each shard's pair was left by its post kernel / weight_sums kernel), added in shard order.
+static int group_totals(rfsgpu_group *g, bool launch_sums, double tot[2]) {
+  const int S = (int)g->shard.size();
+  for (int k = 0; k < S; k++) {
+    rfsgpu_filter *f = g->shard[k];
+    hipSetDevice(f->device);
+    if (launch_sums) GFWD(k, rfsgpu_weight_sums_async(f));
+    GCHK(hipMemcpyAsync(f->hSums, f->dSums, 2 * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  }
+  tot[0] = tot[1] = 0.0;
+  for (int k = 0; k < S; k++) {
+    GFWD(k, rfsgpu_synchronize(g->shard[k]));     // also surfaces device-side errors of the async steps
+    tot[0] += g->shard[k]->hSums[0];
+    tot[1] += g->shard[k]->hSums[1];
+  }
+  return RFSGPU_OK;
+}
+
+// RBPHDFilter::update body on every shard (:444-523): one fused step + post kernel per shard, all shards in flight together.
+// Leaves the weights un-normalised; sums_out (may be null) receives {sum w, sum w^2} over all shards.
+int rfsgpu_group_update(rfsgpu_group *g, const double *z, int n_z, double *sums_out) {
+  if (!g) return RFSGPU_ERR_INVALID;
+  for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_step_async(g->shard[k], z, n_z, 0));
+  double tot[2];
+  const int rc = group_totals(g, false, tot);
+  if (rc != RFSGPU_OK) return rc;
+  if (sums_out) { sums_out[0] = tot[0]; sums_out[1] = tot[1]; }
+  return RFSGPU_OK;
+}
+// ParticleFilter::normalizeWeights over the whole particle set (:352-363).
+int rfsgpu_group_normalize(rfsgpu_group *g, double *sums_out) {
+  if (!g) return RFSGPU_ERR_INVALID;
+  double tot[2];
+  int rc = group_totals(g, true, tot);
+  if (rc != RFSGPU_OK) return rc;
+  for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_normalize_weights(g->shard[k], tot[0], nullptr));
+  if (sums_out) { sums_out[0] = tot[0]; sums_out[1] = tot[1]; }
+  return RFSGPU_OK;
+}
+
+static int grow(rfsgpu_group *g, unsigned char *&buf, size_t &cap, size_t need) {
+  if (need <= cap) return RFSGPU_OK;
+  if (buf) GCHK(hipFree(buf));
+  buf = nullptr; cap = 0;
+  GCHK(hipMalloc(&buf, need));
+  cap = need;
+  return RFSGPU_OK;
+}
+
+// Carry out a global plan (src[global slot] = global source slot; a source keeps itself).
+int rfsgpu_group_apply_plan(rfsgpu_group *g, const int *src) {
+  if (!g || !src) return RFSGPU_ERR_INVALID;
+  const int S = (int)g->shard.size();
+  auto shard_of = [&](int p) { int k = 0; while (p >= g->first[k + 1]) k++; return k; };
+  for (int p = 0; p < g->N; p++)
+    if (src[p] < 0 || src[p] >= g->N || src[src[p]] != src[p]) return gfail(g, RFSGPU_ERR_INVALID, "apply_plan: a source must be a slot that keeps itself");
+  // children that cross a shard boundary, grouped (source shard -> destination shard), ascending destination slot
+  std::vector<std::vector<std::vector<int>>> cross(S, std::vector<std::vector<int>>(S));
+  std::vector<std::vector<int>> localSrc(S);
+  for (int k = 0; k < S; k++) { localSrc[k].resize(g->first[k + 1] - g->first[k]); for (size_t q = 0; q < localSrc[k].size(); q++) localSrc[k][q] = (int)q; }
+  for (int p = 0; p < g->N; p++) {
+    if (src[p] == p) continue;
+    const int kd = shard_of(p), ks = shard_of(src[p]);
+    if (kd == ks) localSrc[kd][p - g->first[kd]] = src[p] - g->first[kd];
+    else cross[ks][kd].push_back(p);
+  }
+  const size_t R = rfsgpu_slab_row_bytes(g->shard[0]);
+  // 1. export on every source shard (its stream), all destinations back to back in one buffer
+  std::vector<std::vector<size_t>> sendOff(S, std::vector<size_t>(S, 0)), recvOff(S, std::vector<size_t>(S, 0));
+  for (int ks = 0; ks < S; ks++) {
+    std::vector<int> slots;
+    for (int kd = 0; kd < S; kd++) { sendOff[ks][kd] = slots.size(); for (int p : cross[ks][kd]) slots.push_back(src[p] - g->first[ks]); }
+    if (slots.empty()) continue;
+    rfsgpu_filter *f = g->shard[ks];
+    hipSetDevice(f->device);
+    int rc = grow(g, g->sendBuf[ks], g->sendCap[ks], slots.size() * R);
+    if (rc != RFSGPU_OK) return rc;
+    GFWD(ks, rfsgpu_export_slab_rows(f, slots.data(), (int)slots.size(), g->sendBuf[ks]));
+    GCHK(hipEventRecord(g->evExport[ks], f->stream));
+    g->rowsMigrated += (long long)slots.size();
+    g->bytesMigrated += (long long)(slots.size() * R);
+  }
+  // 2. per destination shard: wait for the exporters, pull the rows device-to-device, gather the local children, unpack
+  for (int kd = 0; kd < S; kd++) {
+    rfsgpu_filter *f = g->shard[kd];
+    hipSetDevice(f->device);
+    std::vector<int> slots;
+    for (int ks = 0; ks < S; ks++) { recvOff[kd][ks] = slots.size(); for (int p : cross[ks][kd]) slots.push_back(p - g->first[kd]); }
+    if (!slots.empty()) {
+      int rc = grow(g, g->recvBuf[kd], g->recvCap[kd], slots.size() * R);
+      if (rc != RFSGPU_OK) return rc;
+      for (int ks = 0; ks < S; ks++) {
+        const size_t n = cross[ks][kd].size();
+        if (!n) continue;
+        GCHK(hipStreamWaitEvent(f->stream, g->evExport[ks], 0));
+        const rfsgpu_filter *fs = g->shard[ks];
+        if (fs->device == f->device)
+          GCHK(hipMemcpyAsync(g->recvBuf[kd] + recvOff[kd][ks] * R, g->sendBuf[ks] + sendOff[ks][kd] * R, n * R, hipMemcpyDeviceToDevice, f->stream));
+        else
+          GCHK(hipMemcpyPeerAsync(g->recvBuf[kd] + recvOff[kd][ks] * R, f->device, g->sendBuf[ks] + sendOff[ks][kd] * R, fs->device, n * R, f->stream));
+      }
+    }
+    GFWD(kd, rfsgpu_resample_apply(f, localSrc[kd].data()));   // also resets every weight to 1 (:486-489); syncs the shard's stream
+    if (!slots.empty()) GFWD(kd, rfsgpu_import_slab_rows(f, slots.data(), (int)slots.size(), g->recvBuf[kd]));
+  }
+  for (int k = 0; k < S; k++) GFWD(k, rfsgpu_synchronize(g->shard[k]));   // (send buffers are reused by the next resampling)
+  g->lastPlan.assign(src, src + g->N);
+  return RFSGPU_OK;
+}
+
+// ParticleFilter::resample (:399-492) over the whole particle set: normalise; N_eff = 1 / sum w^2; resample only if
+// N_eff <= eff_n_threshold or N_eff / N <= eff_n_threshold / N (:412); systematic sampling with the caller's uniform draw.
+// plan_out (may be null, N ints) receives the global plan when *fired.
+int rfsgpu_group_resample(rfsgpu_group *g, double eff_n_threshold, double u01, int *fired, int *plan_out) {
+  if (!g || !fired) return RFSGPU_ERR_INVALID;
+  *fired = 0;
+  double tot[2];
+  int rc = rfsgpu_group_normalize(g, tot);
+  if (rc != RFSGPU_OK) return rc;
+  const double nEff = tot[0] * tot[0] / tot[1];   // = 1 / sum (w / S)^2
+  if (nEff > eff_n_threshold && nEff / g->N > eff_n_threshold / g->N) return RFSGPU_OK;
+  std::vector<double> w(g->N);
+  rc = rfsgpu_group_get_weights(g, w.data());
+  if (rc != RFSGPU_OK) return rc;
+  std::vector<int> plan;
+  systematic_plan(w, u01, plan);
+  rc = rfsgpu_group_apply_plan(g, plan.data());
+  if (rc != RFSGPU_OK) return rc;
+  if (plan_out) memcpy(plan_out, plan.data(), (size_t)g->N * sizeof(int));
+  *fired = 1;
+  return RFSGPU_OK;
+}
+int rfsgpu_group_migration_stats(const rfsgpu_group *g, long long *rows, long long *bytes) {
+  if (!g) return RFSGPU_ERR_INVALID;
+  if (rows) *rows = g->rowsMigrated;
+  if (bytes) *bytes = g->bytesMigrated;
+  return RFSGPU_OK;
+}
+// map access by GLOBAL particle index (getGMSize / getLandmark, include/RBPHDFilter.hpp:1152-1178)
+int rfsgpu_group_gm_size(rfsgpu_group *g, int particle) {
+  int k, s;
+  if (rfsgpu_group_locate(g, particle, &k, &s) != RFSGPU_OK) return -1;
+  return rfsgpu_gm_size(g->shard[k], s);
+}
+int rfsgpu_group_get_landmark(rfsgpu_group *g, int particle, int m, double *mean, double *cov, double *w) {
+  int k, s;
+  if (rfsgpu_group_locate(g, particle, &k, &s) != RFSGPU_OK) return RFSGPU_ERR_INVALID;
+  return rfsgpu_get_landmark(g->shard[k], s, m, mean, cov, w);
+}
+
+}  // extern "C"

@@ -1392,3 +1392,5 @@ int rfsgpu_mat_perm(const double *A, int n, int batch, double *out, int device_i
 }
 
 }  // extern "C"
+
+#include "group.h"

@@ -33,6 +33,11 @@ def mat_perm(A, device_id=0):
     return capi.mat_perm(load_library(), "rfsgpu_", A, device_id)
 
 
+def FilterGroup(n_particles, device_ids, gm_capacity=512, model=capi.MODEL_RNGBRG_2D):
+    """One filter over several GPUs from this process (rfsgpu_group_*): contiguous particle blocks, one shard per device id."""
+    return capi.Group(load_library(), n_particles, device_ids, gm_capacity=gm_capacity, model=model)
+
+
 class RBPHDFilter(capi.CFilter):
     """Device-resident RB-PHD filter shard (one GPU).  Mirrors rfs::RBPHDFilter for the update path."""
 

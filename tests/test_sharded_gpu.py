@@ -75,3 +75,55 @@ def test_two_ranks_device_engine_match_single_filter(pkg, force_resample):
     if force_resample:
         assert np.array_equal(w, np.ones(n_total))
         assert sum(o["migration"]["rows_sent"] for o in out) > 0     # packed rows really crossed the shard boundary
+
+
+@pytest.mark.parametrize("n_shards", [2, 3])
+def test_group_of_shards_in_one_process_matches_single_filter(pkg, n_shards):
+    """rfsgpu_group_* (the C-ABI's own multi-GPU form: one host thread, a shard per device id, hipMemcpyPeerAsync row transport) with
+    every shard on this box's one GPU: update + normalise + forced global resampling (rows cross the shard boundaries), then a
+    second predict/update cycle, equal a single handle holding all particles."""
+    sc = pkg.scenarios
+    n_total = 30
+    scen = sc.make_scenario(n_total, 40, 12, seed=31, params=dict(min_updates=1))
+    scen["particle_w"] = np.random.default_rng(1).uniform(0.2, 1.0, n_total)
+    ref = pkg.RBPHDFilter(n_total, device_id=0, gm_capacity=192)
+    sc.load_scenario(ref, scen)
+    grp = pkg.FilterGroup(n_total, [0] * n_shards, gm_capacity=192)
+    sc.load_scenario(grp, scen)
+    assert [s.n for s in grp.shards] == [10] * 3 if n_shards == 3 else [15, 15]
+
+    ref.update(scen["Z"])
+    sums = grp.update(scen["Z"])
+    np.testing.assert_allclose(sums, ref.weight_sums(), rtol=1e-13)
+    np.testing.assert_array_equal(grp.get_weights(), ref.get_weights())
+    # forced resampling: the same global plan, poses / maps / unused lists follow their particles across shards
+    s_ref = ref.weight_sums()
+    ref.normalize_weights(s_ref[0])
+    plan_ref = pkg.engine.systematic_resample_plan(ref.get_weights(), 0.4321)
+    x = ref.get_poses()
+    ref.resample_apply(plan_ref)
+    fired, plan = grp.resample(n_total + 1.0, 0.4321)
+    assert fired
+    rows, nbytes = grp.migration_stats()
+    if np.array_equal(plan, plan_ref):      # (the group's sums are added per shard: the normalised weights may differ in the last bit)
+        assert rows > 0 and nbytes == rows * grp.shards[0].slab_row_bytes()
+        np.testing.assert_array_equal(grp.get_poses(), x[plan_ref])
+        assert np.array_equal(grp.gm_sizes(), ref.gm_sizes())
+        for i in range(n_total):
+            for a, b in zip(grp.export_gm(i), ref.export_gm(i)):
+                assert np.array_equal(a, b)
+            assert np.array_equal(grp.get_unused(i), ref.get_unused(i))
+        np.testing.assert_array_equal(grp.get_weights(), np.ones(n_total))
+        # a second cycle on the resampled state
+        ref.set_poses(x[plan_ref], scen["pose_cov"])
+        ref.predict_map(True)
+        grp.predict_map(True)
+        ref.update(scen["Z"])
+        grp.update(scen["Z"])
+        np.testing.assert_array_equal(grp.get_weights(), ref.get_weights())
+        for i in range(n_total):
+            for a, b in zip(grp.export_gm(i), ref.export_gm(i)):
+                assert np.array_equal(a, b)
+    else:
+        pytest.fail("the group's resampling plan differs from the single filter's")
+    grp.close(); ref.close()

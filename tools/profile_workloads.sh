@@ -1,0 +1,32 @@
+#!/bin/bash
+# rocprofv3 evidence for a round, on the GPU box, for every workload of SURVEY 8(d):
+#   c2a / c3  bench.py (its own JSON line carries the live PMC traffic of the fused kernel) + a --kernel-trace --stats pass
+#   c4        tools/vp_bench.py (Victoria Park, 5000 particles)     kernel-trace + two PMC passes (FETCH_SIZE, WRITE_SIZE)
+#   c5        tools/c5_bench.py (Murty stress, 1000 particles)      kernel-trace + two PMC passes
+# PMC passes carry --kernel-trace only (gpurun refuses pmc + other trace domains).   usage: tools/profile_workloads.sh <tag>
+set -u
+TAG=${1:-rXX}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+run_trace() {  # name, command...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${name}_trace -o trace -- "$@" > $OUT/${name}_trace.log 2>&1
+}
+run_pmc() {    # name, counter, command...
+  local name=$1 ctr=$2; shift 2
+  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/${name}_pmc_$ctr -o pmc -- "$@" > $OUT/${name}_pmc_$ctr.log 2>&1
+}
+python bench.py --workload c2a > $OUT/c2a_bench.log 2>&1
+python bench.py --workload c3 --no-cpu-baseline > $OUT/c3_bench.log 2>&1
+python bench.py --workload c2b --no-cpu-baseline --no-pmc > $OUT/c2b_bench.log 2>&1
+run_trace c2a python bench.py --workload c2a --steps 50 --warmup 5 --no-cpu-baseline --no-pmc
+run_trace c3 python bench.py --workload c3 --steps 50 --warmup 5 --no-cpu-baseline --no-pmc
+run_trace c4 python tools/vp_bench.py
+run_trace c5 python tools/c5_bench.py
+for c in FETCH_SIZE WRITE_SIZE; do
+  run_pmc c4 $c python tools/vp_bench.py
+  C5_STEPS=4 run_pmc c5 $c python tools/c5_bench.py
+done
+find $OUT -name "*.csv" | wc -l
+grep -h '"metric"' $OUT/c2a_bench.log | tail -1 | cut -c1-200
