@@ -1,0 +1,397 @@
+/*
+ * RBPHDFilter_rfsgpu.hpp -- the reference-side binding of librfsgpu.so, written out in full.
+ *
+ * WHAT THIS IS.  A replacement for the reference's `include/RBPHDFilter.hpp`: install it AS `RBPHDFilter.hpp` in a
+ * directory that precedes `/root/reference/include` on the include path (or `#include` it from a patched copy of that
+ * header).  It declares `rfs::RBPHDFilter<RobotProcessModel, LmkProcessModel, MeasurementModel, KalmanFilter>` with the
+ * same template signature, base class, public members and public `config` / `timingInfo_` objects as the reference
+ * (include/RBPHDFilter.hpp:72-251), so that `src/rbphdslam2dSim.cpp` (:446-491 setup, :588 predict, :592 setParticlePose,
+ * :607 update, :613-620 particle log, :628-633 getGMSize/getLandmark, :656-690 timing) and
+ * `src/rbphdslam_VictoriaPark.cpp` (:344, :365-398, :513-543, :555-583, :637-657) compile against it unchanged.  The map of
+ * every particle lives on the GPU behind the C ABI (include/rfsgpu.h); poses, weights, the process model, the random
+ * numbers and the resampling DECISION stay on the host exactly where the reference has them.
+ *
+ * STATUS.  This translation unit needs Eigen3 and Boost (through the reference's own headers), which this repository's
+ * build image does not have, so it has not been compiled here; it is reviewed line by line against the reference
+ * headers cited next to each member.  The same logic, with plain-array stand-ins for Pose2d / Landmark2d /
+ * Measurement2d, is what `rfs-slam_amd/host/rbphd_filter.hpp` compiles and what the tests run.
+ *
+ * Supported template tuples (anything else is refused at compile time -- there is no CPU fallback in the product):
+ *   <MotionModel_Odometry2d, StaticProcessModel<Landmark2d>, MeasurementModel_RngBrg,       KalmanFilter_RngBrg>
+ *   <MotionModel_Ackerman2d, StaticProcessModel<Landmark3d>, MeasurementModel_VictoriaPark, KalmanFilter_VictoriaPark>
+ * The one thing the Victoria Park tuple needs from the reference: read access to two private members of
+ * MeasurementModel_VictoriaPark that the driver sets through the model (src/rbphdslam_VictoriaPark.cpp:344
+ * `setNoise(R, Slb)`, :560 `setLaserScan(scan)`; include/MeasurementModel_VictoriaPark.hpp:149,151), i.e. two added lines:
+ *     double getSlb() const { return Slb_; }
+ *     const std::vector<double> &getLaserScan() const { return laserscan_; }
+ * (or, without touching that class, `pFilter_->setLaserScan(scan)` / `pFilter_->setSlb(Slb)` below next to the two calls).
+ */
+#ifndef RBPHDFILTER_HPP   /* the reference's own include guard: this file stands in for that header */
+#define RBPHDFILTER_HPP
+
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include <boost/timer/timer.hpp>
+#include <Eigen/Core>
+
+#include "GaussianMixture.hpp"
+#include "KalmanFilter_RngBrg.hpp"
+#include "KalmanFilter_VictoriaPark.hpp"
+#include "MeasurementModel_RngBrg.hpp"
+#include "MeasurementModel_VictoriaPark.hpp"
+#include "ParticleFilter.hpp"
+#include "ProcessModel_Ackerman2D.hpp"
+#include "ProcessModel_Odometry2D.hpp"
+#include "Timer.hpp"
+
+#include "rfsgpu.h"
+
+namespace rfs {
+
+/* ---- which engine model a template tuple maps to -------------------------------------------------------------------- */
+template <class MeasurementModel> struct rfsgpu_model_of;  /* undefined: unsupported tuples do not compile */
+template <> struct rfsgpu_model_of<MeasurementModel_RngBrg> { enum { value = RFSGPU_MODEL_RNGBRG_2D, dim = 2 }; };
+template <> struct rfsgpu_model_of<MeasurementModel_VictoriaPark> { enum { value = RFSGPU_MODEL_VICTORIAPARK_3D, dim = 3 }; };
+
+template <class RobotProcessModel, class LmkProcessModel, class MeasurementModel, class KalmanFilter>
+class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, GaussianMixture<typename MeasurementModel::TLandmark> > {
+ public:
+  EIGEN_MAKE_ALIGNED_OPERATOR_NEW;
+
+  typedef typename RobotProcessModel::TState TPose;
+  typedef typename RobotProcessModel::TInput TInput;
+  typedef typename MeasurementModel::TLandmark TLandmark;
+  typedef typename MeasurementModel::TMeasurement TMeasurement;
+  typedef GaussianMixture<TLandmark> TGM;
+  typedef typename TGM::Gaussian TGaussian;
+
+  /* include/RBPHDFilter.hpp:90-146, member for member */
+  struct Config {
+    double birthGaussianWeight_;
+    uint birthGaussianMeasurementCountThreshold_;
+    uint birthGaussianMeasurementCheckThreshold_;
+    double birthGaussianMeasurementSupportDist_;
+    uint birthGaussianCurrentMeasurementCountThreshold_;
+    double newGaussianCreateInnovMDThreshold_;
+    int importanceWeightingEvalPointCount_;
+    double importanceWeightingEvalPointGuassianWeight_;
+    double importanceWeightingMeasurementLikelihoodMDThreshold_;
+    double gaussianMergingThreshold_;
+    double gaussianMergingCovarianceInflationFactor_;
+    double gaussianPruningThreshold_;
+    int minUpdatesBeforeResample_;
+    int minMeasurementsBeforeResample_;
+    bool useClusterProcess_;
+  } config;
+
+  /* include/RBPHDFilter.hpp:152-167, member for member (nanoseconds, as boost::timer reports them) */
+  struct TimingInfo {
+    long long predict_wall;
+    long long predict_cpu;
+    long long mapUpdate_wall;
+    long long mapUpdate_cpu;
+    long long mapUpdate_kf_wall;
+    long long mapUpdate_kf_cpu;
+    long long particleWeighting_wall;
+    long long particleWeighting_cpu;
+    long long mapMerge_wall;
+    long long mapMerge_cpu;
+    long long mapPrune_wall;
+    long long mapPrune_cpu;
+    long long particleResample_wall;
+    long long particleResample_cpu;
+  } timingInfo_;
+
+  /* :370-382 -- the constructor's defaults.  (The reference leaves importanceWeightingEvalPointGuassianWeight_ and
+   * useClusterProcess_ uninitialised; both drivers assign them, :485,490.  They start at 0 / false here.) */
+  explicit RBPHDFilter(int n)
+      : ParticleFilter<RobotProcessModel, MeasurementModel, GaussianMixture<TLandmark> >(n), engine_(NULL) {
+    lmkModelPtr_ = new LmkProcessModel;
+    kf_ = new KalmanFilter(lmkModelPtr_, this->getMeasurementModel());
+    config.birthGaussianWeight_ = 0.25;
+    config.birthGaussianMeasurementCountThreshold_ = 1;
+    config.birthGaussianMeasurementCheckThreshold_ = 1;
+    config.birthGaussianMeasurementSupportDist_ = 1;
+    config.birthGaussianCurrentMeasurementCountThreshold_ = 1;
+    config.gaussianMergingThreshold_ = 0.5;
+    config.gaussianMergingCovarianceInflationFactor_ = 1.5;
+    config.gaussianPruningThreshold_ = 0.2;
+    config.importanceWeightingEvalPointCount_ = 8;
+    config.importanceWeightingEvalPointGuassianWeight_ = 0;
+    config.importanceWeightingMeasurementLikelihoodMDThreshold_ = 3.0;
+    config.newGaussianCreateInnovMDThreshold_ = 0.2;
+    config.minUpdatesBeforeResample_ = 1;
+    config.minMeasurementsBeforeResample_ = 1;
+    config.useClusterProcess_ = false;
+    nUpdatesSinceResample_ = 0;
+    nMeasurementsSinceResample_ = 0;
+    resampleOccured_ = false;
+    /* The engine: device and per-particle capacity come from the environment (the reference constructor has no such
+     * arguments): RFSGPU_DEVICE (default 0), RFSGPU_GM_CAPACITY (default 512: room for nM_max + 4 nZ Gaussians). */
+    const char *dev = std::getenv("RFSGPU_DEVICE"), *cap = std::getenv("RFSGPU_GM_CAPACITY");
+    const int rc = rfsgpu_create(&engine_, rfsgpu_model_of<MeasurementModel>::value, n, dev ? std::atoi(dev) : 0, cap ? std::atoi(cap) : 512);
+    if (rc != RFSGPU_OK) throw std::runtime_error("rfsgpu_create failed (no gfx950 device?): status " + std::to_string(rc));
+  }
+
+  ~RBPHDFilter() {
+    rfsgpu_destroy(engine_);
+    delete kf_;
+    delete lmkModelPtr_;
+  }
+
+  LmkProcessModel *getLmkProcessModel() { return lmkModelPtr_; }   /* :402-404 */
+  KalmanFilter *getKalmanFilter() { return kf_; }                   /* :1189-1191 (one object: no per-thread copies to broadcast) */
+
+  /* MeasurementModel_VictoriaPark only: see the header comment */
+  void setLaserScan(const std::vector<double> &scan) { laserScan_ = scan; }
+  void setSlb(double Slb) { Slb_ = Slb; haveSlb_ = true; }
+
+  /* :415-442.  Births use the pose BEFORE propagation (:423-426), so the poses go to the device first. */
+  void predict(TInput u, TimeStamp const &dT, bool useModelNoise = true, bool useInputNoise = false, bool birthGaussianCheck = true) {
+    timer_predict_.resume();
+    pushConfiguration();
+    pushPoses();
+    check(rfsgpu_predict_map(engine_, birthGaussianCheck ? 1 : 0), "predict_map");   /* addBirthGaussians :1000-1084 + staticStep :433-439 */
+    this->propagate(u, dT, useModelNoise, useInputNoise, true);                      /* :429, host RNG, keeps the trajectory */
+    timer_predict_.stop();
+  }
+
+  /* :444-541 */
+  void update(std::vector<TMeasurement> &Z) {
+    nUpdatesSinceResample_++;
+    this->setMeasurements(Z);                              /* Z is consumed (include/ParticleFilter.hpp:316-320) */
+    if (this->measurements_.size() == 0) return;           /* :451-452 */
+    nMeasurementsSinceResample_ += this->measurements_.size();
+    const int nZ = (int)this->measurements_.size();
+    const int D = rfsgpu_model_of<MeasurementModel>::dim;
+    std::vector<double> z((size_t)nZ * D);
+    for (int k = 0; k < nZ; k++) {
+      typename TMeasurement::Vec v = this->measurements_[k].get();
+      for (int d = 0; d < D; d++) z[(size_t)D * k + d] = v[d];
+    }
+    pushConfiguration();
+    pushPoses();
+    pushWeights();
+    timer_mapUpdate_.resume();
+    check(rfsgpu_update(engine_, z.data(), nZ), "update");   /* updateMap + importanceWeighting + merge + prune, :469-520 */
+    timer_mapUpdate_.stop();
+    pullWeights();
+
+    timer_particleResample_.resume();                       /* :524-539, unchanged */
+    resampleOccured_ = false;
+    if (nUpdatesSinceResample_ >= config.minUpdatesBeforeResample_ && nMeasurementsSinceResample_ >= config.minMeasurementsBeforeResample_) {
+      resampleOccured_ = resampleWithDeviceMaps();
+    }
+    if (resampleOccured_) {
+      nUpdatesSinceResample_ = 0;
+      nMeasurementsSinceResample_ = 0;
+    } else {
+      this->normalizeWeights();
+    }
+    timer_particleResample_.stop();
+  }
+
+  int getGMSize(int i) {                                     /* :1152-1158 */
+    if (i >= 0 && i < this->nParticles_) return rfsgpu_gm_size(engine_, i);
+    return -1;
+  }
+
+  bool getLandmark(const int i, const int m, typename TLandmark::Vec &u, typename TLandmark::Mat &S, double &w) {   /* :1160-1178 */
+    const int sz = getGMSize(i);
+    if (sz == -1 || m < 0 || m >= sz) return false;
+    const int D = rfsgpu_model_of<MeasurementModel>::dim;
+    double mean[3], cov[9];
+    if (rfsgpu_get_landmark(engine_, i, m, mean, cov, &w) != RFSGPU_OK) return false;
+    for (int r = 0; r < D; r++) {
+      u[r] = mean[r];
+      for (int c = 0; c < D; c++) S(r, c) = cov[D * r + c];
+    }
+    return true;
+  }
+
+  void setParticlePose(int i, TPose &p) { *(this->particleSet_[i]) = p; }   /* :1180-1186 */
+
+  TimingInfo *getTimingInfo() {                              /* :1219-1232: host timers for what stays on the host, the */
+    rfsgpu_timing t;                                         /* engine's HIP-event buckets for what runs on the device  */
+    rfsgpu_get_timing(engine_, &t);
+    timer_predict_.elapsed(timingInfo_.predict_wall, timingInfo_.predict_cpu);
+    timingInfo_.mapUpdate_wall = t.mapUpdate_wall;                   timingInfo_.mapUpdate_cpu = t.mapUpdate_cpu;
+    timingInfo_.mapUpdate_kf_wall = t.mapUpdate_kf_wall;             timingInfo_.mapUpdate_kf_cpu = t.mapUpdate_kf_cpu;
+    timingInfo_.particleWeighting_wall = t.particleWeighting_wall;   timingInfo_.particleWeighting_cpu = t.particleWeighting_cpu;
+    timingInfo_.mapMerge_wall = t.mapMerge_wall;                     timingInfo_.mapMerge_cpu = t.mapMerge_cpu;
+    timingInfo_.mapPrune_wall = t.mapPrune_wall;                     timingInfo_.mapPrune_cpu = t.mapPrune_cpu;
+    timer_particleResample_.elapsed(timingInfo_.particleResample_wall, timingInfo_.particleResample_cpu);
+    return &timingInfo_;
+  }
+
+ private:
+  rfsgpu_filter *engine_;
+  LmkProcessModel *lmkModelPtr_;
+  KalmanFilter *kf_;
+  std::vector<double> laserScan_;
+  double Slb_ = 0;
+  bool haveSlb_ = false;
+  int nUpdatesSinceResample_, nMeasurementsSinceResample_;
+  bool resampleOccured_;
+  Timer timer_predict_, timer_mapUpdate_, timer_particleResample_;
+
+  void check(int rc, const char *what) {
+    if (rc != RFSGPU_OK) throw std::runtime_error(std::string("rfsgpu ") + what + ": " + rfsgpu_last_error(engine_));
+  }
+
+  /* The three config structs of the reference objects -> the engine, before every predict / update (they are public members
+   * the driver may change at any time; src/rbphdslam_VictoriaPark.cpp:510,538 changes the landmark noise every step). */
+  void pushConfiguration() {
+    rfsgpu_filter_config c;
+    c.birthGaussianWeight = config.birthGaussianWeight_;
+    c.birthGaussianMeasurementCountThreshold = config.birthGaussianMeasurementCountThreshold_;
+    c.birthGaussianMeasurementCheckThreshold = config.birthGaussianMeasurementCheckThreshold_;
+    c.birthGaussianMeasurementSupportDist = config.birthGaussianMeasurementSupportDist_;
+    c.birthGaussianCurrentMeasurementCountThreshold = config.birthGaussianCurrentMeasurementCountThreshold_;
+    c.newGaussianCreateInnovMDThreshold = config.newGaussianCreateInnovMDThreshold_;
+    c.importanceWeightingEvalPointCount = config.importanceWeightingEvalPointCount_;
+    c.importanceWeightingEvalPointGuassianWeight = config.importanceWeightingEvalPointGuassianWeight_;
+    c.importanceWeightingMeasurementLikelihoodMDThreshold = config.importanceWeightingMeasurementLikelihoodMDThreshold_;
+    c.gaussianMergingThreshold = config.gaussianMergingThreshold_;
+    c.gaussianMergingCovarianceInflationFactor = config.gaussianMergingCovarianceInflationFactor_;
+    c.gaussianPruningThreshold = config.gaussianPruningThreshold_;
+    c.minUpdatesBeforeResample = config.minUpdatesBeforeResample_;
+    c.minMeasurementsBeforeResample = config.minMeasurementsBeforeResample_;
+    c.useClusterProcess = config.useClusterProcess_ ? 1 : 0;
+    check(rfsgpu_set_filter_config(engine_, &c), "set_filter_config");
+
+    rfsgpu_kf_config k;
+    k.rangeInnovationThreshold = kf_->config.rangeInnovationThreshold_;
+    k.bearingInnovationThreshold = kf_->config.bearingInnovationThreshold_;
+    check(rfsgpu_set_kf_config(engine_, &k), "set_kf_config");
+
+    typename TLandmark::Mat Q;
+    lmkModelPtr_->getNoise(Q);                                    /* include/ProcessModel.hpp:92-95 */
+    const int D = rfsgpu_model_of<MeasurementModel>::dim;
+    double q[9];
+    for (int r = 0; r < D; r++)
+      for (int cc = 0; cc < D; cc++) q[D * r + cc] = Q(r, cc);
+    check(rfsgpu_set_lmk_process_noise(engine_, q), "set_lmk_process_noise");
+    pushModel(this->getMeasurementModel());
+  }
+  void pushModel(MeasurementModel_RngBrg *m) {                     /* include/MeasurementModel_RngBrg.hpp:65-71 */
+    rfsgpu_rngbrg_config c;
+    MeasurementModel_RngBrg::TMeasurement::Mat R;
+    m->getNoise(R);
+    c.R[0] = R(0, 0); c.R[1] = R(0, 1); c.R[2] = R(1, 0); c.R[3] = R(1, 1);
+    c.probabilityOfDetection = m->config.probabilityOfDetection_;
+    c.uniformClutterIntensity = m->config.uniformClutterIntensity_;
+    c.rangeLimMax = m->config.rangeLimMax_;
+    c.rangeLimMin = m->config.rangeLimMin_;
+    c.rangeLimBuffer = m->config.rangeLimBuffer_;
+    check(rfsgpu_set_model_rngbrg(engine_, &c), "set_model_rngbrg");
+  }
+  void pushModel(MeasurementModel_VictoriaPark *m) {               /* include/MeasurementModel_VictoriaPark.hpp:136-152 */
+    rfsgpu_vp_config c;
+    Measurement3d::Mat R;
+    m->getNoise(R);
+    for (int r = 0; r < 3; r++)
+      for (int cc = 0; cc < 3; cc++) c.R[3 * r + cc] = R(r, cc);
+    c.Slb = haveSlb_ ? Slb_ : m->getSlb();                          /* the Slb handed to setNoise(R, Slb) (:59) */
+    if (laserScan_.empty()) laserScan_ = m->getLaserScan();
+    c.nPd = (int)m->config.probabilityOfDetection_.size();
+    if (c.nPd > RFSGPU_VP_MAX_PD) throw std::runtime_error("rfsgpu: Pd table longer than RFSGPU_VP_MAX_PD");
+    for (int k = 0; k < c.nPd; k++) c.PdTable[k] = m->config.probabilityOfDetection_[k];
+    c.expectedClutterNumber = m->config.expectedClutterNumber_;
+    c.rangeLimMax = m->config.rangeLimMax_;
+    c.rangeLimMin = m->config.rangeLimMin_;
+    c.bearingLimitMax = m->config.bearingLimitMax_;
+    c.bearingLimitMin = m->config.bearingLimitMin_;
+    c.bufferZonePd = m->config.bufferZonePd_;
+    check(rfsgpu_set_model_victoriapark(engine_, &c), "set_model_victoriapark");
+    if (!laserScan_.empty()) check(rfsgpu_set_laser_scan(engine_, laserScan_.data(), (int)laserScan_.size()), "set_laser_scan");
+  }
+
+  /* pose mean + covariance of every particle (the covariance enters S in the 2-D model, src/MeasurementModel_RngBrg.cpp:102) */
+  void pushPoses() {
+    const int n = this->nParticles_;
+    std::vector<double> x((size_t)3 * n), P((size_t)9 * n);
+    for (int i = 0; i < n; i++) {
+      typename TPose::Vec v;
+      typename TPose::Mat S;
+      this->particleSet_[i]->get(v, S);
+      for (int r = 0; r < 3; r++) {
+        x[(size_t)3 * i + r] = v[r];
+        for (int c = 0; c < 3; c++) P[(size_t)9 * i + 3 * r + c] = S(r, c);
+      }
+    }
+    check(rfsgpu_set_poses(engine_, x.data(), P.data(), 9), "set_poses");
+  }
+  void pushWeights() {
+    std::vector<double> w(this->nParticles_);
+    for (int i = 0; i < this->nParticles_; i++) w[i] = this->particleSet_[i]->getWeight();
+    check(rfsgpu_set_weights(engine_, w.data()), "set_weights");
+  }
+  void pullWeights() {
+    std::vector<double> w(this->nParticles_);
+    check(rfsgpu_get_weights(engine_, w.data()), "get_weights");
+    for (int i = 0; i < this->nParticles_; i++) this->particleSet_[i]->setWeight(w[i]);
+  }
+
+  /* ParticleFilter::resample() (include/ParticleFilter.hpp:399-492) with n = nParticles_, restated only because the maps are
+   * not in Particle::data_: the decision, the draw and the slot assignment are the reference's, statement for statement;
+   * `particleSet_[next] = particleSet_[idx]->copy()` (:473) becomes a host copy of the pose part plus src_slot[next] = idx,
+   * and ONE rfsgpu_resample_apply(src_slot) deep-copies the maps, unused-measurement lists, FOV counts and birth candidates on
+   * the device (what Particle::copy, include/Particle.hpp:218-223, and addBirthGaussians' lazy copy, :1005-1011, carry). */
+  bool resampleWithDeviceMaps() {
+    this->normalizeWeights();                                                   /* :402 */
+    const int n = this->nParticles_;
+    double sum_of_weight_squared = 0;                                            /* :405-415 */
+    for (int i = 0; i < n; i++) {
+      const double w_i = this->particleSet_[i]->getWeight();
+      sum_of_weight_squared += (w_i * w_i);
+    }
+    const double nEffParticles = 1.0 / sum_of_weight_squared;
+    if (nEffParticles > this->effNParticles_t_ && nEffParticles / n > this->effNParticles_t_percent_) return false;
+
+    const double randomNum_0_to_1 = drand48();                                  /* :421 */
+    unsigned int idx = 0;
+    const double sample_interval = 1.0 / double(n);
+    double sample_point = sample_interval * randomNum_0_to_1;
+    double cumulative_weight = this->particleSet_[idx]->getWeight();
+    std::vector<char> flag_particle_sampled(n, 0);
+    std::vector<unsigned int> sampled_idx(n, 0);
+    for (int i = 0; i < n; i++) {                                               /* :433-444 */
+      while (sample_point > cumulative_weight) {
+        idx++;
+        cumulative_weight += this->particleSet_[idx]->getWeight();
+      }
+      sampled_idx[i] = idx;
+      flag_particle_sampled[idx] = 1;
+      sample_point += sample_interval;
+    }
+    std::vector<int> src_slot(n);
+    for (int i = 0; i < n; i++) src_slot[i] = i;
+    unsigned int idx_prev = 0, next_unsampled_idx = 0;
+    for (int i = 0; i < n; i++) {                                               /* :446-479 */
+      bool firstTime = true;
+      idx = sampled_idx[i];
+      if (i > 0 && idx == idx_prev) firstTime = false;
+      idx_prev = idx;
+      if (firstTime) {                                                           /* case 1 (idx < n always holds here) */
+        this->particleSet_[idx]->setParentId(this->particleSet_[idx]->getId());
+      } else {                                                                   /* case 2 */
+        while (flag_particle_sampled[next_unsampled_idx] == 1) next_unsampled_idx++;
+        this->particleSet_[next_unsampled_idx] = this->particleSet_[idx]->copy();   /* pose, id (data_ is empty on this path) */
+        this->particleSet_[next_unsampled_idx]->setParentId(this->particleSet_[idx]->getId());
+        src_slot[next_unsampled_idx] = (int)idx;
+        next_unsampled_idx++;
+      }
+    }
+    check(rfsgpu_resample_apply(engine_, src_slot.data()), "resample_apply");   /* also resets the device weights to 1 */
+    for (int i = 0; i < n; i++) this->particleSet_[i]->setWeight(1);            /* :486-489 */
+    return true;
+  }
+};
+
+}  // namespace rfs
+
+#endif

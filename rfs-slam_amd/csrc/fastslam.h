@@ -36,7 +36,7 @@ struct FsParams {
 #define FS_AMBIG_ROWS 256  // rows with competing associations per particle, over all components
 #define FS_SMALL 12        // components up to this size are solved in LDS, larger ones in the particle's HBM scratch
 
-// per-particle scratch of the Hungarian method in HBM: the dense block + hungarian_run's work arrays
+// per-particle scratch of the Hungarian method in HBM: the dense block (sized with room for per-row / per-column work arrays)
 __host__ __device__ inline size_t fs_arena_bytes_n(int n) {
   return ((size_t)n * n * 8 + 3 * (size_t)n * 8 + 6 * (size_t)n * 4 + 8 * (size_t)n + 63) & ~(size_t)63;
 }
@@ -306,79 +306,96 @@ __global__ __launch_bounds__(WPB * 64) void fs_associate_update_kernel(Buffers B
   wave_sync();
 
   // ---- C. the ambiguous part falls apart into connected components (rows linked by shared measurements); each is a
-  //         small assignment problem: dense block padded with the floor -> Hungarian method (lane 0, serial) ----
-  if (nRa > 0 && lane == 0) {
-    // union-find over the <= 64 measurement columns
+  //         small assignment problem: dense block padded with the floor -> the wave-parallel Hungarian method
+  //         (hungarian_wave.h: same traversal order, tolerances and tie-breaks as the reference's solver).  The component
+  //         walk itself is wave-uniform: every lane follows the same scalar control flow over the LDS lists, lane 0 does
+  //         the (tiny) serial bookkeeping, lanes x < nR fill and read row x of the block. ----
+  if (nRa > 0) {
     unsigned char *parent = sParent;  // (LDS: private arrays indexed at run time would live in scratch memory)
-    for (int z = 0; z < 64; z++) parent[z] = (unsigned char)z;
-    auto find = [&](int z) { while (parent[z] != z) { parent[z] = parent[parent[z]]; z = parent[z]; } return z; };
-    unsigned long long colAmb = 0;
-    for (int a = 0; a < nRa; a++) {
-      const unsigned long long m = sRM[a];
-      colAmb |= m;
-      const int r0 = find(__builtin_ctzll(m));
-      for (unsigned long long g = m & (m - 1); g; g &= g - 1) {
-        const int r1 = find(__builtin_ctzll(g));
-        if (r1 != r0) parent[r1] = (unsigned char)r0;
+    if (lane == 0) {  // union-find over the <= 64 measurement columns, left fully compressed
+      for (int z = 0; z < 64; z++) parent[z] = (unsigned char)z;
+      auto find = [&](int z) { while (parent[z] != z) { parent[z] = parent[parent[z]]; z = parent[z]; } return z; };
+      for (int a = 0; a < nRa; a++) {
+        const unsigned long long m = sRM[a];
+        const int r0 = find(__builtin_ctzll(m));
+        for (unsigned long long g = m & (m - 1); g; g &= g - 1) {
+          const int r1 = find(__builtin_ctzll(g));
+          if (r1 != r0) parent[r1] = (unsigned char)r0;
+        }
       }
+      for (int z = 0; z < 64; z++) parent[z] = (unsigned char)find(z);
     }
-    MurtyArena Ag, Al;
-    unsigned char *solnG, *solnL;
-    fs_arena_carve(arena + (size_t)i * fs_arena_bytes(), Ag, solnG, FS_AMBIG_MAX);
-    fs_arena_carve(reinterpret_cast<unsigned char *>(sHL), Al, solnL, FS_SMALL);
+    wave_sync();
+    unsigned long long colAmb = 0;
+    for (int a = 0; a < nRa; a++) colAmb |= sRM[a];
+    double *CtG = reinterpret_cast<double *>(arena + (size_t)i * fs_arena_bytes());   // [64 x 64] in the particle's HBM scratch
+    double *CtL = sHL;                                                                // [FS_SMALL x FS_SMALL] in LDS
     for (unsigned long long roots = colAmb; roots; roots &= roots - 1) {
       const int r = __builtin_ctzll(roots);
-      if (find(r) != r) continue;
+      if (parent[r] != r) continue;
       unsigned long long cmask = 0;
-      for (unsigned long long g = colAmb; g; g &= g - 1) { const int z = __builtin_ctzll(g); if (find(z) == r) cmask |= 1ull << z; }
+      for (unsigned long long g = colAmb; g; g &= g - 1) { const int z = __builtin_ctzll(g); if (parent[z] == r) cmask |= 1ull << z; }
       unsigned short *rows = sRows;
       int nR = 0;
       bool big = false;
+      wave_sync();  // (the previous component's readers of `rows` are done)
       for (int a = 0; a < nRa; a++)
-        if (sRM[a] & cmask) { if (nR < FS_AMBIG_MAX) rows[nR++] = (unsigned short)a; else big = true; }
+        if (sRM[a] & cmask) { if (nR < FS_AMBIG_MAX) { if (lane == 0) rows[nR] = (unsigned short)a; nR++; } else big = true; }
+      wave_sync();
       const int nC = __popcll(cmask);
-      if (big) { atomicOr(B.err, ERRBIT_MURTY); continue; }  // a component beyond the in-kernel Hungarian's size: refuse
+      if (big) { if (lane == 0) atomicOr(B.err, ERRBIT_MURTY); continue; }  // a component beyond the in-kernel Hungarian's size: refuse
       if (nR == 1) {  // one landmark, several measurements: the best cell (what the Hungarian optimum is, ties aside)
-        const unsigned seg = sSeg[sAR[rows[0]]];
-        const int st = (int)(seg >> 8), cnt = (int)(seg & 0xffu);
-        double bv = lim;
-        int bz = -1;
-        for (int q = st; q < st + cnt && q < nList; q++)
-          if (sMV[q] > bv) { bv = sMV[q]; bz = (int)(sMZ[q] & 0xffu); }
-        if (bz >= 0) sDa[sAR[rows[0]]] = (short)bz;
+        if (lane == 0) {
+          const unsigned seg = sSeg[sAR[rows[0]]];
+          const int st = (int)(seg >> 8), cnt = (int)(seg & 0xffu);
+          double bv = lim;
+          int bz = -1;
+          for (int q = st; q < st + cnt && q < nList; q++)
+            if (sMV[q] > bv) { bv = sMV[q]; bz = (int)(sMZ[q] & 0xffu); }
+          if (bz >= 0) sDa[sAR[rows[0]]] = (short)bz;
+        }
         continue;
       }
       if (nC == 1) {  // several landmarks, one measurement: the landmark with the best cell takes it
-        double bv = lim;
-        int bx = -1;
-        for (int x = 0; x < nR; x++) {
-          const unsigned seg = sSeg[sAR[rows[x]]];
-          const double v = sMV[seg >> 8];  // (the row's only cell)
-          if (v > bv) { bv = v; bx = x; }
+        if (lane == 0) {
+          double bv = lim;
+          int bx = -1;
+          for (int x = 0; x < nR; x++) {
+            const unsigned seg = sSeg[sAR[rows[x]]];
+            const double v = sMV[seg >> 8];  // (the row's only cell)
+            if (v > bv) { bv = v; bx = x; }
+          }
+          if (bx >= 0) sDa[sAR[rows[bx]]] = (short)__builtin_ctzll(cmask);
         }
-        if (bx >= 0) sDa[sAR[rows[bx]]] = (short)__builtin_ctzll(cmask);
         continue;
       }
       const int nA = nR > nC ? nR : nC;
-      MurtyArena &A = (nA <= FS_SMALL) ? Al : Ag;
-      unsigned char *soln = (nA <= FS_SMALL) ? solnL : solnG;
-      for (int t = 0; t < nA * nA; t++) A.Ct[t] = lim;
-      for (int x = 0; x < nR; x++) {
-        const unsigned seg = sSeg[sAR[rows[x]]];
+      double *Ct = (nA <= FS_SMALL) ? CtL : CtG;
+      for (int t = lane; t < nA * nA; t += 64) Ct[t] = lim;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      wave_sync();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (lane < nR) {
+        const unsigned seg = sSeg[sAR[rows[lane]]];
         const int st = (int)(seg >> 8), cnt = (int)(seg & 0xffu);
         for (int q = st; q < st + cnt && q < nList; q++) {
           const int z = (int)(sMZ[q] & 0xffu);
-          A.Ct[x * nA + __popcll(cmask & ((1ull << z) - 1ull))] = sMV[q];
+          Ct[lane * nA + __popcll(cmask & ((1ull << z) - 1ull))] = sMV[q];
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      wave_sync();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       double cost;
-      if (hungarian_run(A.Ct, nA, nA, soln, &cost, A)) {
-        for (int x = 0; x < nR; x++) {
-          const int bcol = soln[x];
-          if (bcol < nC && A.Ct[x * nA + bcol] > lim) sDa[sAR[rows[x]]] = (short)nth_bit(cmask, bcol);
+      int xy = -1;
+      if (hungarian_wave(Ct, nA, nA, xy, &cost, nullptr)) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (lane < nR) {
+          const int bcol = xy;
+          if (bcol >= 0 && bcol < nC && Ct[lane * nA + bcol] > lim) sDa[sAR[rows[lane]]] = (short)nth_bit(cmask, bcol);
         }
       } else {
-        atomicOr(B.err, ERRBIT_MURTY);  // the reference would leave the particle untouched (:511-515); refused loudly here
+        if (lane == 0) atomicOr(B.err, ERRBIT_MURTY);  // the reference would leave the particle untouched (:511-515); refused loudly here
       }
     }
   }

@@ -1,5 +1,5 @@
 // hungarian_wave.h -- HungarianMethod::run (reference include/HungarianMethod.hpp:91-587, maximise) with one WAVEFRONT per
-// problem instead of one thread (hungarian_run in murty.h).
+// problem instead of one thread.
 //
 // The reference's solver is a serial search whose tie-breaks are observable: with exactly tied assignment scores (FastSLAM's
 // floor-valued table cells tie all the time) WHICH optimal assignment comes out depends on the order rows / columns are

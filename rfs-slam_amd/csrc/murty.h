@@ -11,7 +11,7 @@
 // (hungarian_wave.h) and the sub-problem / assignment bookkeeping run across the lanes, the children of an expansion across
 // the waves -- and multiplies each job's partition likelihood into its
 // particle's weight in partition order.  Node pool, heap and root table live in HBM (per-job arena), sub-problem tables
-// in an LDS tile.  hungarian_run below is the one-thread form of the solver (still used by fastslam.h's small blocks).
+// in an LDS tile.  (The one-thread form of the solver that round 1 still carried for FastSLAM's small blocks is gone: every caller uses hungarian_wave.)
 #pragma once
 #include "common.h"
 #include "weighting.h"
@@ -73,117 +73,6 @@ __device__ inline void murty_carve(unsigned char *base, MurtyArena &A) {
   A.yq = p; p += MURTY_N;
   A.nodeId = p; p += MURTY_MAX_NODES;
   A.nodeA = p;
-}
-
-// HungarianMethod::run, maximize = true (include/HungarianMethod.hpp:91-587).  C is n x n with leading
-// dimension ld, modified in place and restored exactly like the reference.  Returns false on the reference's
-// "Cannot find alternating path" exit (:513-523).
-__device__ bool hungarian_run(double *C, int ld, int n, unsigned char *soln, double *cost, MurtyArena &A) {
-  double *lx = A.lx, *ly = A.ly, *slack = A.slack;
-  int *xy = A.xy, *yx = A.yx, *p = A.p, *q = A.queue;
-  unsigned char *S = A.S, *T = A.T, *NS = A.NS, *x_q = A.xq, *y_q = A.yq;
-  int x, x_t, y, root = 0;
-  bool pickFreeVertex = true;
-  for (x = 0; x < n; x++) { xy[x] = -1; S[x] = 0; yx[x] = -1; T[x] = 0; }
-  double offset = 0;
-  for (x = 0; x < n; x++)
-    for (y = 0; y < n; y++)
-      if (C[x * ld + y] < offset) offset = C[x * ld + y];
-  for (x = 0; x < n; x++)
-    for (y = 0; y < n; y++) C[x * ld + y] -= offset;
-  for (x = 0; x < n; x++) {  // step 1 (:162-190)
-    lx[x] = 0.0;
-    ly[x] = 0.0;
-    for (y = 0; y < n; y++)
-      if (C[x * ld + y] >= lx[x]) { lx[x] = C[x * ld + y]; xy[x] = y; }
-    int yy = xy[x];
-    x_t = yx[yy];
-    if (yx[yy] != -1) {
-      if (C[x * ld + yy] > C[x_t * ld + yy]) { xy[x_t] = -1; yx[yy] = x; }
-      else xy[x] = -1;
-    } else {
-      yx[yy] = x;
-    }
-  }
-  for (int guard = 0; guard < 8 * MURTY_N * MURTY_N; guard++) {
-    if (pickFreeVertex) {  // step 2
-      for (x = 0; x < n; x++) S[x] = 0;
-      for (y = 0; y < n; y++) { T[y] = 0; NS[y] = 0; }
-      for (x = 0; x < n; x++) if (xy[x] == -1) break;
-      if (x == n) {
-        if (offset != 0)
-          for (x = 0; x < n; x++)
-            for (y = 0; y < n; y++) C[x * ld + y] = C[x * ld + y] + offset;
-        double c = 0;
-        for (x = 0; x < n; x++) { soln[x] = (unsigned char)xy[x]; c += C[x * ld + xy[x]]; }
-        *cost = c;
-        return true;
-      }
-      root = x;
-      S[x] = 1;
-      for (y = 0; y < n; y++) {
-        slack[y] = lx[x] + ly[y] - C[x * ld + y];
-        if (fabs(slack[y]) < 1e-14) { slack[y] = 0; NS[y] = 1; }
-      }
-    }
-    bool updateLabel = true;  // step 3
-    for (y = 0; y < n; y++) if (NS[y] != T[y]) { updateLabel = false; break; }
-    if (updateLabel) {
-      double a = 1.7976931348623157e308;
-      for (y = 0; y < n; y++) if (!T[y]) a = fmin(a, slack[y]);
-      for (x = 0; x < n; x++) if (S[x]) lx[x] -= a;
-      for (y = 0; y < n; y++) if (T[y]) ly[y] += a;
-      for (y = 0; y < n; y++) {
-        if (!T[y]) slack[y] -= a;
-        if (slack[y] == 0) NS[y] = 1;
-      }
-    }
-    for (y = 0; y < n; y++) if (NS[y] && !T[y]) break;  // step 4
-    if (y >= n) return false;
-    x_t = yx[y];
-    if (x_t == -1) {
-      bool found = false;
-      const int target = y + n;
-      int qh = 0, qt = 0;
-      q[qt++] = root;
-      for (x = 0; x < n; x++) { x_q[x] = 0; y_q[x] = 0; }
-      x_q[root] = 1;
-      for (x = 0; x < 2 * n; x++) p[x] = -1;
-      while (qh < qt) {
-        int t = q[qh];
-        if (t == target) {
-          while (t != root) {
-            if (t >= n) { x_t = p[t]; xy[x_t] = t - n; yx[t - n] = x_t; }
-            t = p[t];
-          }
-          found = true;
-          break;
-        }
-        qh++;
-        if (t < n) {
-          for (y = 0; y < n; y++)
-            if (fabs(lx[t] + ly[y] - C[t * ld + y]) < 1e-12 && !y_q[y] && xy[t] != y) { y_q[y] = 1; p[y + n] = t; q[qt++] = y + n; }
-        } else {
-          t -= n;
-          for (x = 0; x < n; x++)
-            if (fabs(lx[x] + ly[t] - C[x * ld + t]) < 1e-12 && S[x] && !x_q[x] && yx[t] == x) { x_q[x] = 1; p[x] = t + n; q[qt++] = x; }
-        }
-      }
-      if (!found) return false;
-      pickFreeVertex = true;
-    } else {
-      S[x_t] = 1;
-      T[y] = 1;
-      for (int y_t = 0; y_t < n; y_t++)
-        if (fabs(lx[x_t] + ly[y_t] - C[x_t * ld + y_t]) < 1e-14) NS[y_t] = 1;
-      for (int yy = 0; yy < n; yy++) {
-        double sx = lx[x_t] + ly[yy] - C[x_t * ld + yy];
-        if (sx < slack[yy]) slack[yy] = sx;
-      }
-      pickFreeVertex = false;
-    }
-  }
-  return false;
 }
 
 // std::priority_queue<MurtyNode*, vector, MurtyNodeCompare> == libstdc++ push_heap / pop_heap on scores.
