@@ -236,6 +236,15 @@ int rfsgpu_update_async(rfsgpu_filter *f, const double *z, int n_z);
  * GPU) the weights are divided by the sum right there, otherwise the caller all-reduces the pair across its shards and calls
  * rfsgpu_normalize_weights.  Two launches per step (fused step + post) instead of five. */
 int rfsgpu_step_async(rfsgpu_filter *f, const double *z, int n_z, int normalize);
+/* The host side of an asynchronous filter loop (what the Victoria Park driver needs per lidar message: one call for the
+ * inputs, one for the step, no host wait -- src/rbphdslam_VictoriaPark.cpp:555-583):
+ *   rfsgpu_set_step_inputs_async  poses (+ covariance; x == NULL leaves them) and, Victoria Park model, the laser scan
+ *                                 (MeasurementModel_VictoriaPark::setLaserScan; scan == NULL leaves it) through a pinned ring;
+ *   rfsgpu_predict_map_async      rfsgpu_predict_map without the error-word readback.
+ * Device-side errors (capacity, ...) of asynchronous calls surface at the next synchronising call (rfsgpu_synchronize,
+ * rfsgpu_weight_sums, rfsgpu_get_weights, ...). */
+int rfsgpu_set_step_inputs_async(rfsgpu_filter *f, const double *x, const double *cov, int cov_stride, const double *scan, int n_scan);
+int rfsgpu_predict_map_async(rfsgpu_filter *f, int add_birth);
 /* Average duration (ns) of each hot-path kernel group over the async steps harvested since the last call / reset:
  * [0]=phd_update_map [1]=phd_weight_multifeature [2]=gm_merge(+prune); *n_steps = steps averaged.  Steps that ran as one
  * fused kernel report its duration in [0] and 0 in [1], [2] (their TimingInfo share is booked under mapUpdate). */

@@ -51,7 +51,7 @@ def build_host(force=False, verbose=False):
     newest = max([os.path.getmtime(p) for p in [src, src_vp, LIB] + hdrs])
     if not force and all(os.path.exists(p) and os.path.getmtime(p) > newest for p in (SIM, SIM_FASTSLAM, SIM_VP)):
         return SIM
-    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "host"), src,
+    cmd = ["g++", "-std=c++17", "-O2", "-fopenmp", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "host"), src,
            "-L" + HERE, "-lrfsgpu", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib", "-o", SIM]
     if verbose:
         print(" ".join(cmd))

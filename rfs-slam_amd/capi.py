@@ -116,7 +116,7 @@ ABI_SYMBOLS = [
     "default_fastslam_config", "set_fastslam_config", "get_fastslam_config", "fastslam_update",
     "normalize_weights_parts", "create_ex", "n_particles", "max_particles", "resample_apply_n",
     "fastslam_set_resample_occured", "particle_parents", "vp_probe_pd",
-    "slab_row_bytes", "export_slab_rows", "import_slab_rows", "weights_device_ptr", "step_async",
+    "slab_row_bytes", "export_slab_rows", "import_slab_rows", "weights_device_ptr", "step_async", "set_step_inputs_async", "predict_map_async",
     "group_create", "group_destroy", "group_last_error", "group_n_shards", "group_n_particles", "group_shard", "group_locate",
     "group_set_filter_config", "group_set_model_rngbrg", "group_set_kf_config", "group_set_lmk_process_noise", "group_set_poses",
     "group_get_poses", "group_set_weights", "group_get_weights", "group_predict_map", "group_update", "group_normalize",
@@ -439,6 +439,25 @@ class CFilter:
         else:
             assert s.size == n_out
             self._call("resample_apply_n", self._ptr(s), C.c_int(int(n_out)))
+
+    # -- asynchronous host loop -----------------------------------------------------------------------------------
+    def set_step_inputs_async(self, x=None, cov=None, scan=None):
+        xp = cp = sp = C.c_void_p()
+        stride, ns = 0, 0
+        if x is not None:
+            x = _f64(x, (self.n, 3))
+            xp = self._ptr(x)
+            if cov is not None:
+                cov = _f64(cov)
+                stride = 0 if cov.size == 9 else 9
+                cp = self._ptr(cov)
+        if scan is not None:
+            scan = _f64(scan).reshape(-1)
+            sp, ns = self._ptr(scan), scan.size
+        self._call("set_step_inputs_async", xp, cp, C.c_int(stride), sp, C.c_int(ns))
+
+    def predict_map_async(self, add_birth=True):
+        self._call("predict_map_async", C.c_int(1 if add_birth else 0))
 
     # -- cross-shard migration (packed rows in the backend's own memory space: device memory for the engine) ----------
     def slab_row_bytes(self):

@@ -61,6 +61,10 @@ struct rfsgpu_filter {
   double *dSums = nullptr;  // [2]
   int *dSrcSlot = nullptr;  // [N]
   int *dRowSlots = nullptr; // [Ncap] slots of the rows being exported / imported (allocated on first use)
+  double *hStage[4] = {nullptr, nullptr, nullptr, nullptr};  // pinned staging ring of rfsgpu_set_step_inputs_async
+  hipEvent_t evStage[4] = {};
+  int stageNext = 0;
+  bool predPending = false;  // rfsgpu_predict_map_async's event pair has not been accumulated yet
   MurtyQueue Q{};
   MurtyScratch MS{};
   int *hErr = nullptr;      // pinned
@@ -308,6 +312,7 @@ void rfsgpu_destroy(rfsgpu_filter *f) {
   if (f->hErr) hipHostFree(f->hErr);
   if (f->hJobCount) hipHostFree(f->hJobCount);
   if (f->hSums) hipHostFree(f->hSums);
+  for (int k = 0; k < 4; k++) { if (f->hStage[k]) hipHostFree(f->hStage[k]); if (f->evStage[k]) hipEventDestroy(f->evStage[k]); }
   for (int k = 0; k < RFSGPU_ASYNC_RING; k++)
     for (int e = 0; e < 5; e++) if (f->ring[k][e]) hipEventDestroy(f->ring[k][e]);
   for (int k = 0; k < EV_COUNT; k++) if (f->ev[k]) hipEventDestroy(f->ev[k]);
@@ -965,6 +970,80 @@ int rfsgpu_predict_map(rfsgpu_filter *f, int add_birth) {
   return rc;
 }
 
+// RBPHDFilter::predict's map part without the error-word readback: stream-ordered, errors surface at the next synchronising call.
+int rfsgpu_predict_map_async(rfsgpu_filter *f, int add_birth) {
+  CHECK_HANDLE(f);
+  long long t0 = now_ns();
+  hipSetDevice(f->device);
+  if (f->predPending && hipEventQuery(f->ev[EV_P1]) == hipSuccess) {   // the previous async predict has long finished: book it
+    accumulate(f->ev[EV_P0], f->ev[EV_P1], f->timing.predict_wall, nullptr);
+    f->predPending = false;
+  }
+  const bool rec = !f->predPending;
+  if (rec) HIPCHK(hipEventRecord(f->ev[EV_P0], f->stream));
+  if (f->D == 3)
+    predict_map_general_kernel<3, 4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
+  else if (f->cfg.birthGaussianMeasurementCountThreshold != 1u)
+    predict_map_general_kernel<2, 4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
+  else
+    predict_map_kernel<4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
+  HIPCHK(hipGetLastError());
+  if (rec) { HIPCHK(hipEventRecord(f->ev[EV_P1], f->stream)); f->predPending = true; }
+  f->timing.predict_cpu += now_ns() - t0;
+  return RFSGPU_OK;
+}
+
+// Everything a step consumes from the host in ONE stream-ordered call: poses (+ covariance) and, for the Victoria Park model,
+// the laser scan (MeasurementModel_VictoriaPark::setLaserScan, src/MeasurementModel_VictoriaPark.cpp:267-281).  The caller's
+// buffers are copied into a pinned staging ring before the call returns; the host never waits for the device (except when all
+// four ring slots are still in flight).  x may be null (poses unchanged), scan may be null (scan unchanged / 2-D model).
+int rfsgpu_set_step_inputs_async(rfsgpu_filter *f, const double *x, const double *cov, int cov_stride, const double *scan, int n_scan) {
+  CHECK_HANDLE(f);
+  if (cov && cov_stride != 0 && cov_stride != 9) return fail(f, RFSGPU_ERR_INVALID, "set_step_inputs: cov_stride must be 0 or 9");
+  if (scan && (f->model != RFSGPU_MODEL_VICTORIAPARK_3D || n_scan < 2 || n_scan > RFSGPU_VP_MAX_SCAN)) return fail(f, RFSGPU_ERR_INVALID, "set_step_inputs: laser scan needs the Victoria Park model and 2..RFSGPU_VP_MAX_SCAN beams");
+  if (!x && !scan) return RFSGPU_OK;
+  hipSetDevice(f->device);
+  const int k = f->stageNext;
+  f->stageNext = (k + 1) & 3;
+  const size_t slotDoubles = (size_t)f->Ncap * 12 + RFSGPU_VP_MAX_SCAN;
+  if (!f->hStage[k]) {
+    HIPCHK(hipHostMalloc(&f->hStage[k], slotDoubles * sizeof(double)));
+    HIPCHK(hipEventCreateWithFlags(&f->evStage[k], hipEventDisableTiming));
+  } else {
+    HIPCHK(hipEventSynchronize(f->evStage[k]));   // the copies issued from this slot four calls ago
+  }
+  double *h = f->hStage[k];
+  if (x) {
+    memcpy(h, x, (size_t)f->N * 3 * sizeof(double));
+    HIPCHK(hipMemcpyAsync(f->B.pose, h, (size_t)f->N * 3 * sizeof(double), hipMemcpyHostToDevice, f->stream));
+    double *hc = h + (size_t)f->Ncap * 3;
+    if (cov) {
+      const size_t n = cov_stride == 9 ? (size_t)f->N * 9 : 9;
+      memcpy(hc, cov, n * sizeof(double));
+      HIPCHK(hipMemcpyAsync(f->B.poseCov, hc, n * sizeof(double), hipMemcpyHostToDevice, f->stream));
+      f->P.poseCovStride = cov_stride;
+    } else {
+      memset(hc, 0, 9 * sizeof(double));
+      HIPCHK(hipMemcpyAsync(f->B.poseCov, hc, 9 * sizeof(double), hipMemcpyHostToDevice, f->stream));
+      f->P.poseCovStride = 0;
+    }
+  }
+  if (scan) {
+    double area = 0;
+    for (int q = 1; q < n_scan; q++) area += scan[q] * scan[q - 1];
+    area += scan[0] * scan[n_scan - 1];
+    area *= sin(acos(-1) / 360) / 2;
+    f->vpClutter = f->vp.expectedClutterNumber / area;
+    double *hs = h + (size_t)f->Ncap * 12;
+    memcpy(hs, scan, (size_t)n_scan * sizeof(double));
+    HIPCHK(hipMemcpyAsync(f->B.scan, hs, (size_t)n_scan * sizeof(double), hipMemcpyHostToDevice, f->stream));
+    f->B.nScan = n_scan;
+    rebuild_params(f);
+  }
+  HIPCHK(hipEventRecord(f->evStage[k], f->stream));
+  return RFSGPU_OK;
+}
+
 int rfsgpu_get_unused(rfsgpu_filter *f, int slot, int *idx, int max_n, int *n_out) {
   CHECK_HANDLE(f);
   if (slot < 0 || slot >= f->N) return RFSGPU_ERR_INVALID;
@@ -1081,11 +1160,12 @@ void *rfsgpu_weights_device_ptr(rfsgpu_filter *f) { return f ? (void *)f->B.weig
 int rfsgpu_get_timing(rfsgpu_filter *f, rfsgpu_timing *t) {
   CHECK_HANDLE(f);
   if (!t) return RFSGPU_ERR_INVALID;
-  if (f->normPending) {
+  if (f->normPending || f->predPending) {
     hipSetDevice(f->device);
     HIPCHK(hipStreamSynchronize(f->stream));
-    accumulate(f->ev[EV_R0], f->ev[EV_R1], f->timing.particleResample_wall, nullptr);
-    f->normPending = false;
+    if (f->normPending) accumulate(f->ev[EV_R0], f->ev[EV_R1], f->timing.particleResample_wall, nullptr);
+    if (f->predPending) accumulate(f->ev[EV_P0], f->ev[EV_P1], f->timing.predict_wall, nullptr);
+    f->normPending = f->predPending = false;
   }
   *t = f->timing;
   return RFSGPU_OK;

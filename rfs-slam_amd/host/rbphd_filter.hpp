@@ -10,6 +10,7 @@
 // Eigen/Boost are not available in this image, so Pose2d / Landmark2d / Measurement2d are plain structs here;
 // INTEGRATION.md shows the Eigen-typed binding for the reference tree.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -280,8 +281,8 @@ class RBPHDFilter2d {
   }
   // ParticleFilter::resample(n, forceResample) (ParticleFilter.hpp:399-492).  nOut == 0 or > nParticles_ keeps the count; a
   // smaller nOut draws nOut samples from all particles and shrinks the set (FastSLAM::resampleWithMapCopy).
-  bool resample(unsigned nOut = 0, bool force = false) {
-    normalizeWeights();
+  bool resample(unsigned nOut = 0, bool force = false, bool alreadyNormalized = false) {
+    if (!alreadyNormalized) normalizeWeights();
     pullWeights();
     const int N = n_;
     if (!force) {
@@ -488,20 +489,37 @@ class RBPHDFilterVP : public RBPHDFilter2d {
   // ProcessModel::sample's input-noise branch (include/ProcessModel.hpp:126-150): every particle draws its own input.
   void predict(const AckermanInput &u, double dT, bool /*useModelNoise*/, bool useInputNoise, bool birthGaussianCheck) {
     pushConfigVP();
-    pushPoses();
-    check(rfsgpu_predict_map(h_, birthGaussianCheck ? 1 : 0), "predict_map");
-    std::normal_distribution<double> N01(0.0, 1.0);
-    for (int i = 0; i < n_; i++) {
-      double uv = u.u[0], ur = u.u[1];
-      if (useInputNoise) { uv += std::sqrt(u.var[0]) * N01(rng_); ur += std::sqrt(u.var[1]) * N01(rng_); }
-      Pose2d xk;
-      ackerman_.step(xk, poses_[i], uv, ur, dT);
-      poses_[i] = xk;
+    pushInputsAsync();
+    check(rfsgpu_predict_map_async(h_, birthGaussianCheck ? 1 : 0), "predict_map");   // stream-ordered: no host wait
+    // ParticleFilter::propagate (include/ParticleFilter.hpp:322-339) is a serial loop over one random stream in the reference;
+    // at 5000 particles that host loop (two normal draws + the Ackerman step per particle) costs more than the device work of
+    // a lidar message.  Here the particles are taken in fixed chunks of 256, each with its own generator seeded from ONE draw of
+    // the filter's master stream per predict: same statistics, results independent of the thread count, chunks in parallel.
+    const unsigned long long stepSeed = rng_();
+    const double sv = std::sqrt(u.var[0]), sr = std::sqrt(u.var[1]);
+    const int nChunks = (n_ + 255) / 256;
+    // (a handful of threads: RFS_HOST_THREADS, default 8 -- an OpenMP team as wide as the host's logical CPU count would
+    //  oversubscribe a container with a CPU quota and spin)
+    static const int hostThreads = [] { const char *e = std::getenv("RFS_HOST_THREADS"); const int v = e ? std::atoi(e) : 8; return v < 1 ? 1 : v; }();
+#pragma omp parallel for schedule(static) num_threads(hostThreads)
+    for (int c = 0; c < nChunks; c++) {
+      std::mt19937_64 eng(stepSeed + 0xD1B54A32D192ED03ull * (unsigned long long)(c + 1));
+      std::normal_distribution<double> N01(0.0, 1.0);
+      const int hi = std::min(n_, (c + 1) * 256);
+      for (int i = c * 256; i < hi; i++) {
+        double uv = u.u[0], ur = u.u[1];
+        if (useInputNoise) { uv += sv * N01(eng); ur += sr * N01(eng); }
+        Pose2d xk;
+        ackerman_.step(xk, poses_[i], uv, ur, dT);
+        poses_[i] = xk;
+      }
     }
     posesDirty_ = true;
   }
 
-  // RBPHDFilter::update (:444-541); Z is consumed.
+  // RBPHDFilter::update (:444-541); Z is consumed.  One lidar message = one input call + one step call, both stream-ordered
+  // (src/rbphdslam_VictoriaPark.cpp:555-583).  The host waits for the device only when the resampling test is due
+  // (minUpdatesBeforeResample_ / minMeasurementsBeforeResample_, :528-531), for the 16 bytes the N_eff test needs.
   void update(std::vector<Measurement3d> &Z) {
     nUpdatesSinceResample_++;
     std::vector<Measurement3d> meas;
@@ -510,21 +528,36 @@ class RBPHDFilterVP : public RBPHDFilter2d {
     if (meas.empty()) return;  // :450-452
     nMeasurementsSinceResample_ += (unsigned)meas.size();
     pushConfigVP();
-    pushPoses();
+    pushInputsAsync();
     std::vector<double> z(3 * meas.size());
     for (size_t k = 0; k < meas.size(); k++) std::memcpy(&z[3 * k], meas[k].z, 3 * sizeof(double));
-    check(rfsgpu_update(h_, z.data(), (int)meas.size()), "update");
+    // the step + normalizeWeights in its post launch: what update() does when no resampling happens (:537-539), and what
+    // resample() does first when it is attempted (include/ParticleFilter.hpp:402)
+    check(rfsgpu_step_async(h_, z.data(), (int)meas.size(), 1), "step");
     weightsStale_ = true;
     resampleOccured_ = false;
     if (nUpdatesSinceResample_ >= (unsigned)config.minUpdatesBeforeResample_ &&
         nMeasurementsSinceResample_ >= (unsigned)config.minMeasurementsBeforeResample_)
-      resampleOccured_ = resample();
+      resampleOccured_ = resampleNormalized();
     if (resampleOccured_) {
       nUpdatesSinceResample_ = 0;
       nMeasurementsSinceResample_ = 0;
-    } else {
-      normalizeWeights();
     }
+  }
+
+  // ParticleFilter::resample (:399-492) on weights that the step has already normalised: N_eff = 1 / sum w^2 from the device
+  // reduction; no resampling -> the reference divides by the (now ~1) sum once more (RBPHDFilter.hpp:537-539), so does this.
+  bool resampleNormalized() {
+    double s[2];
+    check(rfsgpu_weight_sums(h_, s), "weight_sums");                 // the one host wait of the message
+    check(rfsgpu_synchronize(h_), "synchronize");                    // device-side errors of the asynchronous calls
+    const double nEff = 1.0 / s[1];
+    if (nEff > effNParticles_t_ && nEff / n_ > effNParticles_t_percent_) {
+      check(rfsgpu_normalize_weights(h_, s[0], nullptr), "normalize_weights");
+      weightsStale_ = true;
+      return false;
+    }
+    return resample(0, true, /*alreadyNormalized=*/true);
   }
 
   bool getLandmark(int i, int m, double u[3], double S[9], double &w) { return rfsgpu_get_landmark(h_, i, m, u, S, &w) == RFSGPU_OK; }
@@ -551,10 +584,25 @@ class RBPHDFilterVP : public RBPHDFilter2d {
     m.bufferZonePd = measVP_.config.bufferZonePd_;
     check(rfsgpu_set_model_victoriapark(h_, &m), "set_model_victoriapark");
     check(rfsgpu_set_lmk_process_noise(h_, lmk3_.Q), "set_lmk_process_noise");
-    if (measVP_.scanDirty && !measVP_.scan.empty()) {
-      check(rfsgpu_set_laser_scan(h_, measVP_.scan.data(), (int)measVP_.scan.size()), "set_laser_scan");
-      measVP_.scanDirty = false;
+  }
+  // poses (+ covariances) and the laser scan of this message -> the device, one stream-ordered call
+  void pushInputsAsync() {
+    const bool scanNow = measVP_.scanDirty && !measVP_.scan.empty();
+    if (!posesDirty_ && !scanNow) return;
+    std::vector<double> x, P;
+    bool anyCov = false;
+    if (posesDirty_) {
+      x.resize(3 * (size_t)n_); P.resize(9 * (size_t)n_);
+      for (int i = 0; i < n_; i++) {
+        std::memcpy(&x[3 * i], poses_[i].x, 3 * sizeof(double));
+        std::memcpy(&P[9 * i], poses_[i].P, 9 * sizeof(double));
+        for (int t = 0; t < 9; t++) anyCov = anyCov || (poses_[i].P[t] != 0.0);
+      }
     }
+    check(rfsgpu_set_step_inputs_async(h_, posesDirty_ ? x.data() : nullptr, anyCov ? P.data() : nullptr, anyCov ? 9 : 0,
+                                       scanNow ? measVP_.scan.data() : nullptr, scanNow ? (int)measVP_.scan.size() : 0), "set_step_inputs");
+    posesDirty_ = false;
+    measVP_.scanDirty = false;
   }
 };
 
