@@ -166,6 +166,16 @@ const char *rfsgpu_last_error(const rfsgpu_filter *f);
 void rfsgpu_default_filter_config(rfsgpu_filter_config *cfg);            /* RBPHDFilter.hpp:370-382 */
 int rfsgpu_set_filter_config(rfsgpu_filter *f, const rfsgpu_filter_config *cfg);   /* filter.config.* */
 int rfsgpu_get_filter_config(const rfsgpu_filter *f, rfsgpu_filter_config *cfg);
+/* How rfsMeasurementLikelihood evaluates a partition with nR + nC > 8 (include/RBPHDFilter.hpp:920-959):
+ *   RFSGPU_PARTITION_MURTY200 (default) the reference's way, bug-compatible: Murty's ranked assignments on the extended matrix,
+ *                             sum of at most 200 terms, stop below score -1000 (murty.h);
+ *   RFSGPU_PARTITION_EXACT    the untruncated sum over all partial assignments (the quantity the truncation approximates) by a
+ *                             subset recurrence over the smaller side of the partition (<= 9 items; larger partitions still
+ *                             go to Murty).  Not the reference's numbers: an opt-in, timed beside the default. */
+#define RFSGPU_PARTITION_MURTY200 0
+#define RFSGPU_PARTITION_EXACT 1
+int rfsgpu_set_partition_mode(rfsgpu_filter *f, int mode);
+int rfsgpu_get_partition_mode(const rfsgpu_filter *f);
 int rfsgpu_set_model_rngbrg(rfsgpu_filter *f, const rfsgpu_rngbrg_config *cfg);    /* getMeasurementModel()->config / setNoise */
 int rfsgpu_set_kf_config(rfsgpu_filter *f, const rfsgpu_kf_config *cfg);           /* getKalmanFilter()->config */
 /* Victoria Park model: getMeasurementModel()->config / setNoise(R, Slb) (src/rbphdslam_VictoriaPark.cpp:371-378). */

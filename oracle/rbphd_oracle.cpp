@@ -715,8 +715,35 @@ struct CostMatrixGeneral {
 
 /* The partition / enumeration / Murty part of rfsMeasurementLikelihood (include/RBPHDFilter.hpp:865-996) on a filled
  * likelihood table.  Returns prod over partitions (NOT yet divided by the clutter integral). */
+/* Checker for the engine's opt-in RFSGPU_PARTITION_EXACT mode (NOT reference behaviour): the untruncated sum over all partial
+ * assignments of one partition, by dynamic programming over the subsets of its smaller side (raw likelihoods, not logs). */
+static double exact_partition_sum(const std::vector<std::vector<double>> &L, unsigned nRows, unsigned nCols, const std::vector<double> &oneMinusPd,
+                                  const std::vector<double> &clut) {
+  const bool colsSmall = nCols <= nRows;
+  const unsigned k = colsSmall ? nCols : nRows, nItems = colsSmall ? nRows : nCols;
+  std::vector<double> f((size_t)1 << k, 0.0);
+  f[0] = 1.0;
+  for (unsigned it = 0; it < nItems; it++) {
+    const double u = colsSmall ? oneMinusPd[it] : clut[it];
+    for (size_t S = f.size(); S-- > 0;) {
+      double acc = f[S] * u;
+      for (unsigned b = 0; b < k; b++)
+        if ((S >> b) & 1) acc += f[S ^ ((size_t)1 << b)] * (colsSmall ? L[it][b] : L[b][it]);
+      f[S] = acc;
+    }
+  }
+  double tot = 0;
+  for (size_t S = 0; S < f.size(); S++) {
+    double g = f[S];
+    for (unsigned b = 0; b < k; b++)
+      if (!((S >> b) & 1)) g *= colsSmall ? clut[b] : oneMinusPd[b];
+    tot += g;
+  }
+  return tot;
+}
+
 static double partitions_likelihood(CostMatrixGeneral &cm, const std::vector<double> &evalPtPd, const std::vector<double> &clutter,
-                                    long *murty_calls, long *lonerow_hits) {
+                                    long *murty_calls, long *lonerow_hits, bool exact_mode = false) {
   int nP = cm.partition();
   double l = 1;
   const double BIG_NEG_NUM = -1000;
@@ -735,6 +762,14 @@ static double partitions_likelihood(CostMatrixGeneral &cm, const std::vector<dou
       for (unsigned c = 0; c < nCols; c++) partition_likelihood *= clutter[colIdx[c]];
     } else {
       if (nCols == 0 && nRows == 1 && lonerow_hits) (*lonerow_hits)++;
+      if (exact_mode && useMurty && std::min(nRows, nCols) <= 9) { /* RFSGPU_PARTITION_EXACT: see exact_partition_sum */
+        std::vector<std::vector<double>> Lp(nRows, std::vector<double>(nCols));
+        std::vector<double> omp(nRows), cl(nCols);
+        for (unsigned r = 0; r < nRows; r++) { omp[r] = 1 - evalPtPd[rowIdx[r]]; for (unsigned c = 0; c < nCols; c++) Lp[r][c] = Cp[r][c]; }
+        for (unsigned c = 0; c < nCols; c++) cl[c] = clutter[colIdx[c]];
+        l *= exact_partition_sum(Lp, nRows, nCols, omp, cl);
+        continue;
+      }
       for (unsigned r = 0; r < nRows; r++)
         for (unsigned c = 0; c < nCols; c++) {
           if (Cp[r][c] == 0) Cp[r][c] = BIG_NEG_NUM;
@@ -830,6 +865,7 @@ struct FilterBase {
   std::vector<unsigned> nInFov;
   std::vector<double> Z; /* measurements_ (dz doubles each) */
   int nZ = 0;
+  bool exact_partitions = false; /* checker for RFSGPU_PARTITION_EXACT (not reference behaviour) */
   bool stable_sort = false; /* false: std::sort exactly as the reference (GaussianMixture.hpp:523-534);
                                true : (weight desc, index asc) == what the device path implements */
   long murty_calls = 0, lonerow_bug_hits = 0;
@@ -1131,7 +1167,7 @@ struct FilterT : FilterBase {
     }
     std::vector<double> clutter(nZ);
     for (int nn = 0; nn < nZ; nn++) clutter[nn] = model.clutter();
-    double l = partitions_likelihood(cm, evalPtPd, clutter, mc, lr);
+    double l = partitions_likelihood(cm, evalPtPd, clutter, mc, lr, exact_partitions);
     return l / model.clutter_integral();
   }
 
@@ -1681,6 +1717,7 @@ void rfsor_destroy(void *f) { delete F_(f); }
 const char *rfsor_last_error(const void *f) { return f ? reinterpret_cast<const FilterBase *>(f)->err.c_str() : "null handle"; }
 
 int rfsor_set_filter_config(void *f, const rfsgpu_filter_config *c) { F_(f)->cfg = *c; return RFSGPU_OK; }
+int rfsor_set_partition_mode(void *f, int mode) { F_(f)->exact_partitions = mode == RFSGPU_PARTITION_EXACT; return RFSGPU_OK; }
 int rfsor_get_filter_config(const void *f, rfsgpu_filter_config *c) { *c = reinterpret_cast<const FilterBase *>(f)->cfg; return RFSGPU_OK; }
 int rfsor_set_model_rngbrg(void *f, const rfsgpu_rngbrg_config *c) {
   auto *F = FRB_(f);

@@ -116,7 +116,7 @@ ABI_SYMBOLS = [
     "default_fastslam_config", "set_fastslam_config", "get_fastslam_config", "fastslam_update",
     "normalize_weights_parts", "create_ex", "n_particles", "max_particles", "resample_apply_n",
     "fastslam_set_resample_occured", "particle_parents", "vp_probe_pd",
-    "slab_row_bytes", "export_slab_rows", "import_slab_rows", "weights_device_ptr", "step_async", "set_step_inputs_async", "predict_map_async",
+    "slab_row_bytes", "export_slab_rows", "import_slab_rows", "weights_device_ptr", "step_async", "set_step_inputs_async", "predict_map_async", "set_partition_mode", "get_partition_mode",
     "group_create", "group_destroy", "group_last_error", "group_n_shards", "group_n_particles", "group_shard", "group_locate",
     "group_set_filter_config", "group_set_model_rngbrg", "group_set_kf_config", "group_set_lmk_process_noise", "group_set_poses",
     "group_get_poses", "group_set_weights", "group_get_weights", "group_predict_map", "group_update", "group_normalize",
@@ -439,6 +439,10 @@ class CFilter:
         else:
             assert s.size == n_out
             self._call("resample_apply_n", self._ptr(s), C.c_int(int(n_out)))
+
+    def set_partition_mode(self, exact):
+        """Partitions with nR + nC > 8: Murty-200 as the reference (False, default) or the exact subset recurrence (True)."""
+        self._call("set_partition_mode", C.c_int(1 if exact else 0))
 
     # -- asynchronous host loop -----------------------------------------------------------------------------------
     def set_step_inputs_async(self, x=None, cov=None, scan=None):

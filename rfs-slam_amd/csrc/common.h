@@ -44,6 +44,7 @@ struct Params {
   unsigned birthCountThr, birthCurThr, birthCheckThr;
   double birthSupportD2;   // birthGaussianMeasurementSupportDist^2
   int poseCovStride;       // 0 shared, 9 per particle
+  int exactPartitions;     // rfsgpu_set_partition_mode: partitions with nR + nC > 8 by the exact subset recurrence instead of Murty-200
   // MeasurementModel_VictoriaPark (model 1); R[] above then holds its 2x2 range-bearing block
   double R9[9];
   double Slb;

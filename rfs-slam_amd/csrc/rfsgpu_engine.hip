@@ -329,6 +329,13 @@ int rfsgpu_set_filter_config(rfsgpu_filter *f, const rfsgpu_filter_config *c) {
   rebuild_params(f);
   return RFSGPU_OK;
 }
+int rfsgpu_set_partition_mode(rfsgpu_filter *f, int mode) {
+  CHECK_HANDLE(f);
+  if (mode != RFSGPU_PARTITION_MURTY200 && mode != RFSGPU_PARTITION_EXACT) return fail(f, RFSGPU_ERR_INVALID, "unknown partition mode");
+  f->P.exactPartitions = mode == RFSGPU_PARTITION_EXACT ? 1 : 0;
+  return RFSGPU_OK;
+}
+int rfsgpu_get_partition_mode(const rfsgpu_filter *f) { return f ? (f->P.exactPartitions ? RFSGPU_PARTITION_EXACT : RFSGPU_PARTITION_MURTY200) : -1; }
 int rfsgpu_get_filter_config(const rfsgpu_filter *f, rfsgpu_filter_config *c) {
   if (!f || !c) return RFSGPU_ERR_INVALID;
   *c = f->cfg;

@@ -579,7 +579,7 @@ __global__ __launch_bounds__(WPB * 64) void vp_weighting_kernel(Buffers B, Param
     s.L[idx] = Lv;
   }
   wave_sync();
-  const double l = rfs_partitions_wave(s, nE, nZ, P.vpClutter, lane, i, Q, B.err);
+  const double l = rfs_partitions_wave(s, nE, nZ, P.vpClutter, lane, i, Q, B.err, P.exactPartitions);
   const double ml = l / P.vpExpClutter;  // clutterIntensityIntegral (:287-290)
   const double overall = ml * prodBefore / prodAfter * exp(sumCur - sumPrev);
   if (lane == 0) B.weight[i] = overall * B.weight[i];

@@ -144,12 +144,83 @@ __device__ double enumerate_partition(const WeightLDS &s, int nZ, unsigned long 
   return lik;
 }
 
+// The same sum for a partition of ANY size whose smaller side has k <= RFS_EXACT_MAX_SMALL items, by the whole wave: the 2^k
+// subset states are spread over the wave -- the low 3 bits of a state index pick one of 8 registers, the higher bits the lane --
+// so an item of the larger side costs 8 k fused multiply-adds per lane plus (k - 3) lane exchanges per register.  This is the
+// EXACT (untruncated) multi-feature likelihood of the partition; the reference hands partitions with r + c > 8 to Murty's
+// ranked enumeration and stops after the 200 best assignments (include/RBPHDFilter.hpp:920-959), which is what the default
+// (bug-compatible) mode reproduces through murty.h.  Selected by rfsgpu_set_partition_mode(RFSGPU_PARTITION_EXACT).
+#define RFS_EXACT_MAX_SMALL 9
+__device__ double partition_exact_wave(const WeightLDS &s, int nZ, unsigned long long rmask, unsigned long long cmask, double clutter, int lane) {
+  const int r = __popcll(rmask), c = __popcll(cmask);
+  const bool colsSmall = c <= r;
+  const unsigned long long smallMask = colsSmall ? cmask : rmask;
+  unsigned long long largeMask = colsSmall ? rmask : cmask;
+  const int k = colsSmall ? c : r;                 // <= RFS_EXACT_MAX_SMALL (caller)
+  int sm[RFS_EXACT_MAX_SMALL];
+  double h[RFS_EXACT_MAX_SMALL];
+  {
+    unsigned long long mm = smallMask;
+#pragma unroll
+    for (int b = 0; b < RFS_EXACT_MAX_SMALL; b++) {
+      sm[b] = (b < k) ? __builtin_ctzll(mm) : 0;
+      h[b] = (b < k) ? (colsSmall ? clutter : 1.0 - s.evPd[sm[b]]) : 1.0;
+      if (b < k) mm &= mm - 1;
+    }
+  }
+  double f[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) f[q] = (lane == 0 && q == 0) ? 1.0 : 0.0;
+  for (; largeMask; largeMask &= largeMask - 1) {
+    const int idx = __builtin_ctzll(largeMask);
+    const double u = colsSmall ? 1.0 - s.evPd[idx] : clutter;
+    double a[RFS_EXACT_MAX_SMALL];
+#pragma unroll
+    for (int b = 0; b < RFS_EXACT_MAX_SMALL; b++) a[b] = (b < k) ? (colsSmall ? s.L[idx * nZ + sm[b]] : s.L[sm[b] * nZ + idx]) : 0.0;
+    double g[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      double acc = f[q] * u;
+#pragma unroll
+      for (int b = 0; b < 3; b++)
+        if ((q >> b) & 1) acc += f[q ^ (1 << b)] * a[b];
+      g[q] = acc;
+    }
+#pragma unroll
+    for (int b = 3; b < RFS_EXACT_MAX_SMALL; b++) {
+      if (b >= k) break;                            // (uniform)
+      const bool has = (lane >> (b - 3)) & 1;
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const double partner = __shfl_xor(f[q], 1 << (b - 3), 64);   // state with bit b cleared lives in lane ^ (1 << (b - 3))
+        g[q] += has ? partner * a[b] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) f[q] = g[q];
+  }
+  double gl = 1.0;                                  // unmatched small items of the lane bits
+#pragma unroll
+  for (int b = 3; b < RFS_EXACT_MAX_SMALL; b++)
+    if (!((lane >> (b - 3)) & 1)) gl *= h[b];
+  double part = 0.0;
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    double gq = f[q];
+#pragma unroll
+    for (int b = 0; b < 3; b++)
+      if (!((q >> b) & 1)) gq *= h[b];
+    part += gq;
+  }
+  return wave_sum_dpp(part * gl);
+}
+
 // Steps 5-6 of the particle weight, model-independent: connected components of the bipartite graph (rows = evaluation
 // points, columns = measurements) of the likelihood table s.L (nE x nZ, already gated, incl. Pd), the reference's
 // zero-partition merge + partition-indexing quirk, one lane per partition for the <= 8 enumeration, Murty jobs for the
 // rest.  Returns the product over the visited partitions (RBPHDFilter.hpp:865-990), before the clutter-integral division.
 __device__ double rfs_partitions_wave(const WeightLDS &s, int nE, int nZ, double clutter, int lane, int particle, MurtyQueue Q, int *err,
-                                      long long *dbgp = nullptr) {
+                                      int exactMode = 0, long long *dbgp = nullptr) {
   // ---- 5. connected components of the bipartite graph (rows = eval points, cols = measurements) ----
 #ifdef RFS_PROFILE
 #define PART_T(k) do { if (dbgp && particle == 7 && lane == 0) dbgp[k] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -208,8 +279,12 @@ __device__ double rfs_partitions_wave(const WeightLDS &s, int nE, int nZ, double
 
   PART_T(29);
   // ---- 6. one lane per partition ----
-  for (int p = lane; p < nPartitions; p += 64) {
-    unsigned long long rmask = s.compRows[p], cmask = s.compCols[p];
+  for (int p0 = 0; p0 < nPartitions; p0 += 64) {
+    const int p = p0 + lane;
+    bool wantExact = false;
+    unsigned long long rmask = 0, cmask = 0;
+    if (p < nPartitions) {
+    rmask = s.compRows[p]; cmask = s.compCols[p];
     double pl;
     if (p == combined) {  // all landmarks mis-detected, all measurements outliers (:891-900; Pd, not 1-Pd)
       rmask = mergedRows;
@@ -219,6 +294,9 @@ __device__ double rfs_partitions_wave(const WeightLDS &s, int nE, int nZ, double
       for (unsigned long long mm = cmask; mm; mm &= mm - 1) pl *= clutter;
     } else if (__popcll(rmask) + __popcll(cmask) <= 8) {
       pl = enumerate_partition(s, nZ, rmask, cmask, clutter);
+    } else if (exactMode && min(__popcll(rmask), __popcll(cmask)) <= RFS_EXACT_MAX_SMALL) {
+      wantExact = true;   // the whole wave takes it below
+      pl = 1.0;
     } else {
       // Murty-200 (:920-959): queue the extended matrix; the factor is multiplied in by murty_kernel
       pl = 1.0;
@@ -248,6 +326,13 @@ __device__ double rfs_partitions_wave(const WeightLDS &s, int nE, int nZ, double
       }
     }
     s.partLik[p] = pl;
+    }
+    // exact mode: the large partitions of this batch, one after the other, by the whole wave
+    for (unsigned long long em = __ballot(wantExact); em; em &= em - 1) {
+      const int src = __builtin_ctzll(em);
+      const double v = partition_exact_wave(s, nZ, readlane_u64(rmask, src), readlane_u64(cmask, src), clutter, lane);
+      if (lane == src) s.partLik[p] = v;
+    }
   }
   wave_sync();
   PART_T(30);
@@ -619,9 +704,9 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
   if (wave == 0) {
     // ---- 5./6. partition the table, sum the assignments of every partition (shared with the 3-D kernel) ----
 #ifdef RFS_PROFILE
-    l = rfs_partitions_wave(s, nE, nZ, P.clutter, lane, i, Q, B.err, B.dbg);
+    l = rfs_partitions_wave(s, nE, nZ, P.clutter, lane, i, Q, B.err, P.exactPartitions, B.dbg);
 #else
-    l = rfs_partitions_wave(s, nE, nZ, P.clutter, lane, i, Q, B.err);
+    l = rfs_partitions_wave(s, nE, nZ, P.clutter, lane, i, Q, B.err, P.exactPartitions);
 #endif
   }
   if (split) {

@@ -162,6 +162,34 @@ def test_step_async_sums_and_normalises_in_the_post_kernel(pkg, ob, sc, fused, n
         dev.close(); ref.close(); orc.close()
 
 
+def test_exact_partition_mode(pkg, ob, sc):
+    """RFSGPU_PARTITION_EXACT (opt-in, not the reference's numbers): partitions with nR + nC > 8 by the wave-wide subset recurrence
+    instead of Murty-200.  Device == the oracle's independent dynamic programme; and the default mode's weights (Murty, 200-term
+    truncation) stay within a loose factor of the exact ones -- the truncation only drops small terms."""
+    scen = sc.make_scenario(24, 60, 30, seed=21, n_eval=25, weighting_md=10.0, weights=(0.8, 1.0))
+    dev, orc = make_pair(pkg, ob, sc, scen)
+    dev.set_partition_mode(True)
+    orc.set_partition_mode(True)
+    dev.update(scen["Z"])
+    orc.update(scen["Z"])
+    assert orc.murty_calls() == 0            # every large partition went through the exact path
+    compare_weights(dev, orc)
+    compare_maps(sc, dev, orc, scen["n"])
+    dflt, odef = make_pair(pkg, ob, sc, scen)
+    dflt.update(scen["Z"])
+    odef.update(scen["Z"])
+    assert odef.murty_calls() > 0
+    we, wm = dev.get_weights(), dflt.get_weights()
+    assert np.all(wm <= we * (1 + 1e-9))     # a truncated sum of positive terms never exceeds the full one
+    assert np.all(wm >= we * 0.5)
+    # the fused / asynchronous path takes the same branch
+    dev2, _ = make_pair(pkg, ob, sc, scen)
+    dev2.set_partition_mode(True)
+    dev2.update_async(scen["Z"])
+    dev2.synchronize()
+    np.testing.assert_array_equal(dev2.get_weights(), we)
+
+
 def test_cluster_process_weighting(pkg, ob, sc):
     scen = sc.make_scenario(32, 90, 20, seed=11, use_cluster=True)
     dev, orc = make_pair(pkg, ob, sc, scen)
