@@ -576,11 +576,21 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
   // work while the other waves share the intensity groups: neither strand reads what the other writes (the sums go to the
   // rank-sort permutation's storage, free since step 2).
   constexpr int EG = WEIGHT_EVAL_GROUP;
-  const bool split = WPP > 1 && (size_t)B.cap * 4 >= 128 * sizeof(double);  // (the permutation's storage must hold 2 x 64 doubles)
+  const bool split = WPP > 1 && (size_t)B.cap * 4 >= 128 * sizeof(double);  // (the sort's scratch, perm + fkeys = 8 B per entry, must hold 4 x 64 doubles)
   double *sumB = reinterpret_cast<double *>(split ? (void *)s.perm : (void *)s.compRows), *sumA = sumB + 64;  // [64] each
+  double *sumB0 = sumA + 64, *sumA0 = sumB0 + 64;   // split mode: wave 0's partial sums over ITS share of the mixture
   const int iw = split ? wave - 1 : wave, nIw = split ? WPP - 1 : WPP;  // this wave's share of the intensity groups
-  if (!split || wave > 0) {
-    for (int e0 = EG * iw; e0 < nE; e0 += EG * nIw) {
+  // In split mode wave 0 can also take the intensity sums over the last WEIGHT_W0_SHARE_NUM / 5 of the mixture's 64-entry chunks once
+  // it is through with its own strand; the two partial sums of an evaluation point are then added in a fixed order.
+  const int nChunksI = (N + 63) >> 6;
+#ifndef WEIGHT_W0_SHARE_NUM
+#define WEIGHT_W0_SHARE_NUM 0   // measured at C2a (r02k): with a 2/5 share the weighting phase went from 36 to 40 us -- wave 0's strand is
+#endif                          // not the shorter one any more once the intensity pass has lost its second Gaussian prep; kept as a knob
+  const int w0Chunks = (split && nChunksI >= 3) ? (WEIGHT_W0_SHARE_NUM * nChunksI) / 5 : 0;
+  const int mSplit = (split && w0Chunks > 0) ? 64 * (nChunksI - w0Chunks) : N;   // waves >= 1: entries [0, mSplit); wave 0: [mSplit, N)
+  // groups e0 = EG * first, step EG * stride; entries [mLo, mHi); results of evaluation point e to outB[e] / outA[e]
+  auto intensity = [&](const int mLo, const int mHi, const int first, const int stride, double *outB, double *outA) {
+    for (int e0 = EG * first; e0 < nE; e0 += EG * stride) {
       double accB[EG], accA[EG];
 #pragma unroll
       for (int t = 0; t < EG; t++) { accB[t] = 0.0; accA[t] = 0.0; }
@@ -588,7 +598,7 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
       // than the 4*EG registers that holding them would take from the accumulators' budget (128 VGPRs at 4 waves/SIMD)
       const double *gx = s.evX + e0, *gy = s.evY + e0;
       const int nG = (nE - e0 < EG) ? nE - e0 : EG;
-      for (int m = lane; m < N; m += 64) {
+      for (int m = mLo + lane; m < mHi; m += 64) {
         const double w = s.keys[m], wp = qWP[m], mx = qMX[m], my = qMY[m];
         const double sxx = qSXX[m], sxy = qSXY[m], syy = qSYY[m];
         double i00, i01, i10, i11, det;
@@ -613,11 +623,11 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
 #pragma unroll
       for (int t = 0; t < EG; t++) {
         const double b = wave_sum_dpp(accB[t]), a = wave_sum_dpp(accA[t]);
-        if (lane == 0 && e0 + t < nE) { sumB[e0 + t] = b; sumA[e0 + t] = a; }
+        if (lane == 0 && e0 + t < nE) { outB[e0 + t] = b; outA[e0 + t] = a; }
       }
     }
-
-  }
+  };
+  if (!split || wave > 0) intensity(0, mSplit, iw, nIw, sumB, sumA);
   if (!split) block_sync();
 
   DBG_TB(16, 3);
@@ -710,11 +720,13 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
 #endif
   }
   if (split) {
+    if (wave == 0 && w0Chunks > 0) intensity(mSplit, N, 0, 1, sumB0, sumA0);   // wave 0's share of the mixture
     block_sync();          // the intensity sums of the other waves are complete
     if (wave != 0) return;
     for (int e = 0; e < nE; e++) {
-      prodBefore *= (RFS_DENORM_MIN + sumB[e]);
-      prodAfter *= (RFS_DENORM_MIN + sumA[e]);
+      const double b = (w0Chunks > 0) ? sumB[e] + sumB0[e] : sumB[e], a = (w0Chunks > 0) ? sumA[e] + sumA0[e] : sumA[e];
+      prodBefore *= (RFS_DENORM_MIN + b);
+      prodAfter *= (RFS_DENORM_MIN + a);
     }
   }
   const double sumPrev = sScr[0], sumCur = sScr[1];

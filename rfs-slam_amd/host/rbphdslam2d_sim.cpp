@@ -199,6 +199,10 @@ int main(int argc, char **argv) {
   if (!outDir.empty()) {
     fPose = std::fopen((outDir + "/particlePose.dat").c_str(), "w");
     fLm = std::fopen((outDir + "/landmarkEst.dat").c_str(), "w");
+    if (FILE *fg = std::fopen((outDir + "/gtLandmark.dat").c_str(), "w")) {   // src/rbphdslam2dSim.cpp:396-406: x y (time first observed)
+      for (const Landmark &lm : gtLm) std::fprintf(fg, "%f   %f   %f\n", lm.x[0], lm.x[1], -1.0);
+      std::fclose(fg);
+    }
   }
   srand48(simSeed);
   size_t zIdx = 0;

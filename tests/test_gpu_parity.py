@@ -366,6 +366,51 @@ def test_cpp_host_driver_end_to_end(pkg):
     assert mean_err < 0.3 and pose_err < 0.6
 
 
+def ospa(est, truth, cutoff, order):
+    """rfs::OSPA (reference include/OSPA.hpp:122-203): cost matrix min(|a - b|, c) padded with c to a square of n = max(n1, n2),
+    optimal assignment (the reference runs its Hungarian method; scipy's solver finds the same optimum), (sum C^p / n)^(1/p)."""
+    from scipy.optimize import linear_sum_assignment
+    n1, n2 = len(est), len(truth)
+    n = max(n1, n2)
+    if n == 0:
+        return 0.0
+    Cm = np.full((n, n), float(cutoff))
+    if n1 and n2:
+        d = np.linalg.norm(np.asarray(est)[:, None, :] - np.asarray(truth)[None, :, :], axis=2)
+        Cm[:n1, :n2] = np.minimum(d, cutoff)
+    r, c = linear_sum_assignment(Cm)
+    return float((np.sum(Cm[r, c] ** order) / n) ** (1.0 / order))
+
+
+def test_cpp_host_driver_map_quality_ospa(pkg, tmp_path):
+    """End-to-end SLAM quality of the C++ driver on the shipped C1 configuration, from its own log files (the reference's formats:
+    landmarkEst.dat `t i mu_x mu_y S_xx S_xy S_yy w`, gtLandmark.dat `x y t_first_obs`): OSPA (include/OSPA.hpp, cutoff 0.5 m,
+    order 1) of the final best-particle map (Gaussians with w >= 0.5) against the 50 ground-truth landmarks.  Yardstick: the
+    survey's probe of the reference itself on this configuration mapped 48 of 50 landmarks with a mean error of 0.11 m
+    (SURVEY 8(b)), i.e. OSPA = (48 * 0.11 + 2 * 0.5) / 50 = 0.126 m; the build must not be worse than 0.15 m."""
+    import os
+    import subprocess
+    exe = pkg.build_mod.build_host()
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "rbphdslam2dSim_c1.xml")
+    vals = []
+    for t, sd in ((1, 2), (2, 1), (3, 2)):   # three realisations (the host's random streams are not the reference's boost streams:
+        d = os.path.join(tmp_path, f"run_{t}_{sd}")   # a seed pair does not name the same run there and here); median judged
+        os.makedirs(d)
+        out = subprocess.run([exe, "-c", cfg, "-t", str(t), "-s", str(sd), "-n", "200", "-o", d], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        gt = np.loadtxt(os.path.join(d, "gtLandmark.dat"))[:, :2]
+        est = np.loadtxt(os.path.join(d, "landmarkEst.dat"))
+        last = est[est[:, 0] == est[:, 0].max()]
+        strong = last[last[:, 7] >= 0.5][:, 2:4]
+        assert gt.shape[0] == 50
+        vals.append(ospa(strong, gt, 0.5, 1.0))
+    assert np.median(vals) <= 0.15, vals
+    # known answers of the metric itself
+    assert ospa(gt, gt, 0.5, 1.0) == 0.0
+    assert abs(ospa(gt[:48], gt, 0.5, 1.0) - 2 * 0.5 / 50) < 1e-12
+    assert abs(ospa(gt + 0.03, gt, 0.5, 2.0) - 0.03 * np.sqrt(2)) < 1e-9
+
+
 def test_cpp_fastslam_driver_end_to_end(pkg):
     """fastslam2d_sim: the same simulator around the C++ FastSLAM mirror (rfs_amd::FastSLAM2d -> rfsgpu_fastslam_update) on the
     values of the reference's cfg/fastslam2dSim.xml: the landmark map must converge."""
