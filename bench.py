@@ -393,7 +393,10 @@ def main():
     # one global resampling step with cross-shard migration (N > 1), timed on its own
     migr = None
     if world > 1 and wl["reseed"]:
-        migr = pkg.sharded.bench_resample_migration(pkg, f, rank, world, dev, stream=stream, sums=sums, reps=3)
+        try:
+            migr = pkg.sharded.bench_resample_migration(pkg, f, rank, world, dev, stream=stream, sums=sums, reps=3)
+        except Exception as e:   # noqa: BLE001 -- a side figure must never cost the headline line
+            migr = dict(error=repr(e)[:300])
 
     # per-phase breakdown (and the likelihood-sweep rate the north star asks for): the three stand-alone kernels, HIP events,
     # untimed pass after the region

@@ -345,7 +345,7 @@ __device__ __forceinline__ void step_post_tail(double *weight, int N, double *su
   for (int k = threadIdx.x; k < N; k += blockDim.x) weight[k] = weight[k] / d;
 }
 __global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err, double *weight, int N, double *sums,
-                                                                         int normalize, ZArg zarg, double *dZ, int nZdoubles) {
+                                                                         int normalize, ZArg zarg, double *dZ, int nZdoubles, int *hostSeen) {
   // (a fused step carries the measurement set in its kernel arguments; the device copy the next predict reads is written here)
   if (blockIdx.x == 0 && dZ && (int)threadIdx.x < nZdoubles) dZ[threadIdx.x] = zarg.v[threadIdx.x];
   if (blockIdx.x == 0 && dZ && (int)threadIdx.x + 128 < nZdoubles) dZ[threadIdx.x + 128] = zarg.v[threadIdx.x + 128];
@@ -386,6 +386,7 @@ __global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQ
   if (!isLast) return;
   __threadfence();
   if (threadIdx.x == 0) { Q.count[1] = 0; Q.count[0] = 0; }   // the queue is consumed: empty for the next step
+  if (threadIdx.x == 0 && hostSeen) *hostSeen = 1;            // (pinned host word: this filter does reach the Murty path -- see murty_launch)
   for (int i = threadIdx.x; i < N; i += blockDim.x) {
     int last = -1;
     double w = weight[i];
@@ -434,10 +435,16 @@ static inline void murty_free(MurtyQueue &Q, MurtyScratch &MS) {
   MS = MurtyScratch{};
 }
 // The job count lives on the device: one launch, which is empty when no partition exceeded 8.
+// `hostSeen` (pinned, device-visible): set by the kernel once any step has queued Murty jobs.  Until then the launch is a small
+// one (the queue is almost always empty -- at the shipped 3-sigma gate Murty is never entered -- and dispatching 2048 idle
+// workgroups costs ~4 us per step); a filter that has shown Murty work gets the full grid from the next step on.  Correct
+// either way: jobs are strided over whatever grid there is.
 static inline int murty_launch(MurtyQueue &Q, MurtyScratch &MS, Buffers &B, hipStream_t stream, double *sums = nullptr, int normalize = 0,
-                               const ZArg *za = nullptr, int nZdoubles = 0) {
-  const int blocks = std::min(MURTY_JOB_BLOCKS, Q.maxJobs);
+                               const ZArg *za = nullptr, int nZdoubles = 0, int *hostSeen = nullptr) {
+  int blocks = std::min(MURTY_JOB_BLOCKS, Q.maxJobs);
+  if (hostSeen && *hostSeen == 0) blocks = std::min(blocks, 64);
   static const ZArg none{};
-  murty_jobs_kernel<<<blocks, 64 * MURTY_JOB_WAVES, 0, stream>>>(Q, MS, B.err, B.weight, B.N, sums, normalize, za ? *za : none, za ? B.Z : nullptr, nZdoubles);
+  murty_jobs_kernel<<<blocks, 64 * MURTY_JOB_WAVES, 0, stream>>>(Q, MS, B.err, B.weight, B.N, sums, normalize, za ? *za : none, za ? B.Z : nullptr, nZdoubles,
+                                                                 hostSeen);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }

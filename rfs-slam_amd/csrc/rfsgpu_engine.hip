@@ -263,6 +263,7 @@ int rfsgpu_create_ex(rfsgpu_filter **out, int model, int n_particles, int device
   ok &= hipMalloc(&f->dSrcSlot, f->Ncap * sizeof(int)) == hipSuccess;
   ok &= hipHostMalloc(&f->hErr, sizeof(int)) == hipSuccess;
   ok &= hipHostMalloc(&f->hJobCount, sizeof(int)) == hipSuccess;
+  if (ok) *f->hJobCount = 0;   // set by the post kernel once a step has queued Murty jobs (murty_launch)
   ok &= hipHostMalloc(&f->hSums, 2 * sizeof(double)) == hipSuccess;
   for (int k = 0; k < RFSGPU_ASYNC_RING; k++)
     for (int e = 0; e < 5; e++) ok &= hipEventCreate(&f->ring[k][e]) == hipSuccess;
@@ -900,7 +901,7 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
     else phd_step_fused_kernel<STEP_WPP, false><<<f->N, STEP_WPP * 64, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e[3], f->stream));
-    if (murty_launch(f->Q, f->MS, f->B, f->stream, with_sums ? f->dSums : nullptr, normalize, &za, 2 * n_z) != 0) return fail(f, RFSGPU_ERR_HIP, "post kernel launch failed");
+    if (murty_launch(f->Q, f->MS, f->B, f->stream, with_sums ? f->dSums : nullptr, normalize, &za, 2 * n_z, f->hJobCount) != 0) return fail(f, RFSGPU_ERR_HIP, "post kernel launch failed");
     f->cur ^= 1;  // the map update works in place, the weighting phase leaves only a permutation in LDS, merge + prune write the other slab
     f->ringFused[f->ringCount] = true;
     f->ringCount++;
