@@ -31,6 +31,10 @@ extern "C" {
 #define RFSGPU_ABI_VERSION 1
 
 /* Maximum measurements per update() (one 64-bit association mask per landmark). */
+/* Hard limits of the device path (the reference has none; all are refused LOUDLY -- an error status, never a silent
+ * truncation -- and all are far above BASELINE.json's configurations): RFSGPU_MAX_Z measurements per update,
+ * RFSGPU_MAX_EVAL evaluation points, Murty extended dimension nR + nC <= 64, gm_capacity <= 2048 Gaussians per particle,
+ * RFSGPU_MAX_CANDIDATES birth / landmark candidates per particle. */
 #define RFSGPU_MAX_Z 64
 /* Maximum evaluation points for the multi-feature particle weight. */
 #define RFSGPU_MAX_EVAL 64
@@ -361,9 +365,10 @@ int rfsgpu_set_stream(rfsgpu_filter *f, void *hip_stream);
 /* Let rfsgpu_weight_sums_async write {sum w, sum w^2} into a caller-owned device buffer (2 doubles),
  * e.g. a tensor the multi-GPU host all-reduces in place over RCCL.  NULL restores the internal one. */
 int rfsgpu_bind_weight_sums_buffer(rfsgpu_filter *f, void *dev_ptr);
-/* Device-side snapshot / restore of the whole particle state (maps, sizes, weights, unused lists):
- * one snapshot slot per handle, allocated on first use.  Used to re-seed a state between timed
- * steps and by tests; the reference has no equivalent (it has no checkpointing at all). */
+/* Device-side snapshot / restore of the MAP state of every particle (mixtures, sizes, particle weights, unused-measurement
+ * lists, FOV counts): one snapshot slot per handle, allocated on first use.  A benchmarking / testing helper -- it is how a
+ * timed step is re-seeded -- NOT a checkpoint: poses, the birth-candidate lists and the staged measurement set are not part of
+ * it (callers that use candidate lists re-import them).  The reference has no equivalent (it has no checkpointing at all). */
 int rfsgpu_save_state(rfsgpu_filter *f);
 int rfsgpu_restore_state(rfsgpu_filter *f);
 /* Duration in ns of the most recent launch of each hot-path kernel, from HIP events on the

@@ -167,10 +167,20 @@ static int check_device_errors(rfsgpu_filter *f) {
   const int e = *f->hErr;
   if (e == 0) return RFSGPU_OK;
   HIPCHK(hipMemsetAsync(f->B.err, 0, sizeof(int), f->stream));
-  if (e & ERRBIT_CAPACITY) return fail(f, RFSGPU_ERR_CAPACITY, "a particle's Gaussian mixture outgrew gm_capacity (raise it in rfsgpu_create)");
-  if (e & ERRBIT_MURTY) return fail(f, RFSGPU_ERR_UNSUPPORTED, "Murty job queue overflow or partition larger than MURTY_MAXN");
-  if (e & ERRBIT_EVALPTS) return fail(f, RFSGPU_ERR_UNSUPPORTED, "more than RFSGPU_MAX_EVAL evaluation points requested");
-  if (e & ERRBIT_BIRTHLIST) return fail(f, RFSGPU_ERR_UNSUPPORTED, "birth-candidate list mode (birthGaussianMeasurementCountThreshold > 1) is not on the device path");
+  // every flag that was raised goes into the message; the status code is the first one's
+  std::string msg;
+  int code = RFSGPU_OK;
+  auto add = [&](int bit, int c, const char *m) {
+    if (!(e & bit)) return;
+    if (!msg.empty()) msg += "; ";
+    msg += m;
+    if (code == RFSGPU_OK) code = c;
+  };
+  add(ERRBIT_CAPACITY, RFSGPU_ERR_CAPACITY, "a particle's Gaussian mixture outgrew gm_capacity (raise it in rfsgpu_create)");
+  add(ERRBIT_MURTY, RFSGPU_ERR_UNSUPPORTED, "Murty job queue overflow, a partition larger than MURTY_MAXN, or a FastSLAM association component beyond the in-kernel solver");
+  add(ERRBIT_EVALPTS, RFSGPU_ERR_UNSUPPORTED, "more than RFSGPU_MAX_EVAL evaluation points requested");
+  add(ERRBIT_BIRTHLIST, RFSGPU_ERR_UNSUPPORTED, "a particle's birth-candidate / landmark-candidate list outgrew RFSGPU_MAX_CANDIDATES");
+  if (code != RFSGPU_OK) { f->err = msg; return code; }
   return fail(f, RFSGPU_ERR_HIP, "unknown device error flag");
 }
 
@@ -386,13 +396,14 @@ int rfsgpu_vp_probe_pd(rfsgpu_filter *f, int slot, double *pd, int *close_to_lim
   double *dPd = nullptr;
   int *dCl = nullptr;
   HIPCHK(hipMalloc(&dPd, (size_t)f->cap * sizeof(double)));
-  HIPCHK(hipMalloc(&dCl, (size_t)f->cap * sizeof(int)));
+  if (hipMalloc(&dCl, (size_t)f->cap * sizeof(int)) != hipSuccess) { hipFree(dPd); return fail(f, RFSGPU_ERR_HIP, "vp_probe_pd: out of device memory"); }
   vp_probe_pd_kernel<<<1, 64, 0, f->stream>>>(f->B, f->P, f->cur, slot, dPd, dCl);
-  HIPCHK(hipMemcpyAsync(pd, dPd, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, f->stream));
-  HIPCHK(hipMemcpyAsync(close_to_limit, dCl, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, f->stream));
-  HIPCHK(hipStreamSynchronize(f->stream));
+  hipError_t e1 = hipMemcpyAsync(pd, dPd, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, f->stream);
+  hipError_t e2 = hipMemcpyAsync(close_to_limit, dCl, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, f->stream);
+  hipError_t e3 = hipStreamSynchronize(f->stream);
   hipFree(dPd);
   hipFree(dCl);
+  HIPCHK(e1); HIPCHK(e2); HIPCHK(e3);
   return RFSGPU_OK;
 }
 int rfsgpu_set_kf_config(rfsgpu_filter *f, const rfsgpu_kf_config *c) {
@@ -1215,7 +1226,11 @@ int rfsgpu_save_state(rfsgpu_filter *f) {
     ok &= hipMalloc(&f->snapCount, f->Ncap * sizeof(int)) == hipSuccess;
     ok &= hipMalloc(&f->snapFov, f->Ncap * sizeof(int)) == hipSuccess;
     ok &= hipMalloc(&f->snapUnused, f->Ncap * sizeof(unsigned long long)) == hipSuccess;
-    if (!ok) return fail(f, RFSGPU_ERR_HIP, "save_state: out of device memory");
+    if (!ok) {
+      hipFree(f->snapSlab); hipFree(f->snapWeight); hipFree(f->snapCount); hipFree(f->snapFov); hipFree(f->snapUnused);
+      f->snapSlab = nullptr; f->snapWeight = nullptr; f->snapCount = nullptr; f->snapFov = nullptr; f->snapUnused = nullptr;
+      return fail(f, RFSGPU_ERR_HIP, "save_state: out of device memory");
+    }
   }
   HIPCHK(hipMemcpyAsync(f->snapSlab, f->B.slab[f->cur], slabBytes, hipMemcpyDeviceToDevice, f->stream));
   HIPCHK(hipMemcpyAsync(f->snapWeight, f->B.weight, f->N * sizeof(double), hipMemcpyDeviceToDevice, f->stream));

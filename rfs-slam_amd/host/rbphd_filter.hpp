@@ -585,22 +585,18 @@ class RBPHDFilterVP : public RBPHDFilter2d {
     check(rfsgpu_set_model_victoriapark(h_, &m), "set_model_victoriapark");
     check(rfsgpu_set_lmk_process_noise(h_, lmk3_.Q), "set_lmk_process_noise");
   }
-  // poses (+ covariances) and the laser scan of this message -> the device, one stream-ordered call
+  // poses and the laser scan of this message -> the device, one stream-ordered call.  (No pose covariances: the Victoria Park
+  // measurement model rebuilds the pose from its mean only, src/MeasurementModel_VictoriaPark.cpp:112-114.)
+  std::vector<double> xbuf_;
   void pushInputsAsync() {
     const bool scanNow = measVP_.scanDirty && !measVP_.scan.empty();
     if (!posesDirty_ && !scanNow) return;
-    std::vector<double> x, P;
-    bool anyCov = false;
     if (posesDirty_) {
-      x.resize(3 * (size_t)n_); P.resize(9 * (size_t)n_);
-      for (int i = 0; i < n_; i++) {
-        std::memcpy(&x[3 * i], poses_[i].x, 3 * sizeof(double));
-        std::memcpy(&P[9 * i], poses_[i].P, 9 * sizeof(double));
-        for (int t = 0; t < 9; t++) anyCov = anyCov || (poses_[i].P[t] != 0.0);
-      }
+      xbuf_.resize(3 * (size_t)n_);
+      for (int i = 0; i < n_; i++) { xbuf_[3 * i] = poses_[i].x[0]; xbuf_[3 * i + 1] = poses_[i].x[1]; xbuf_[3 * i + 2] = poses_[i].x[2]; }
     }
-    check(rfsgpu_set_step_inputs_async(h_, posesDirty_ ? x.data() : nullptr, anyCov ? P.data() : nullptr, anyCov ? 9 : 0,
-                                       scanNow ? measVP_.scan.data() : nullptr, scanNow ? (int)measVP_.scan.size() : 0), "set_step_inputs");
+    check(rfsgpu_set_step_inputs_async(h_, posesDirty_ ? xbuf_.data() : nullptr, nullptr, 0, scanNow ? measVP_.scan.data() : nullptr,
+                                       scanNow ? (int)measVP_.scan.size() : 0), "set_step_inputs");
     posesDirty_ = false;
     measVP_.scanDirty = false;
   }
