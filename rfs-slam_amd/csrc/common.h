@@ -292,11 +292,74 @@ __device__ __forceinline__ void inv2(double s00, double s01, double s10, double 
 }
 __device__ __forceinline__ double pdf_factor2(double det) { return sqrt((2 * RFS_PI) * (2 * RFS_PI) * det); }
 
+// exp(x) for the Gaussian likelihoods of the hot loops (the one transcendental they are made of: ~100 wave-level evaluations per
+// particle and step).  Argument reduction x = k ln2 + r (|r| <= ln2 / 2, two-constant Cody-Waite), Taylor polynomial of degree
+// 11 by Horner, v_ldexp: 17 VALU instructions against ~35 of the library routine (whose extra work -- special-case selects and a
+// coefficient table re-materialised with v_mov at every call site -- is what the loops were spending their issue slots on).
+// Relative error <= 1e-14 (truncation 0.3466^12 / 12! = 6e-15 + Horner rounding): four orders inside the tightest tolerance
+// (1e-10 on mixture components).
+#ifndef RFS_FAST_EXP
+#define RFS_FAST_EXP 1
+#endif
+// A double constant held in an SGPR pair: the two s_mov_b32 are opaque to the optimiser (it can hoist and share them, but not
+// turn them back into a vector-register constant), and a scalar operand costs the VALU instruction that uses it nothing.
+constexpr unsigned double_bits_lo(double v) { return (unsigned)(__builtin_bit_cast(unsigned long long, v) & 0xffffffffull); }
+constexpr unsigned double_bits_hi(double v) { return (unsigned)(__builtin_bit_cast(unsigned long long, v) >> 32); }
+template <unsigned LO, unsigned HI>
+__device__ __forceinline__ double sgpr_const_f64() {
+  int lo, hi;
+  asm("s_mov_b32 %0, %1" : "=s"(lo) : "n"(LO));
+  asm("s_mov_b32 %0, %1" : "=s"(hi) : "n"(HI));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double rfs_exp(double x) {
+#if RFS_FAST_EXP
+  // branch-free (a wave-uniform escape to the library routine would split the callers' unrolled pair loops into separate
+  // blocks and cost them their instruction-level parallelism): the argument is clamped to [-760, 710] -- exp is exactly 0
+  // below and +inf above that range in fp64, and the reduction below returns exactly that at the clamps -- and a NaN argument
+  // is passed through at the end.
+  const double xin = x;
+  x = fmin(fmax(x, -760.0), 710.0);
+  // The coefficients live in SGPR pairs and enter the fused multiply-adds as the scalar operand: written as inline asm because
+  // the compiler, left to itself, copies every coefficient into a vector register first (v_mov x 2 per term, or 24 VGPRs
+  // hoisted around the unrolled loops and spilled).
+#define RFS_C(v) sgpr_const_f64<double_bits_lo(v), double_bits_hi(v)>()
+#define RFS_FMA_S(acc, x_, c_) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(acc) : "v"(acc), "v"(x_), "s"(c_))
+#define RFS_MUL_S(out, x_, c_) asm("v_mul_f64 %0, %1, %2" : "=v"(out) : "v"(x_), "s"(c_))
+  double kx;
+  { const double c = RFS_C(1.4426950408889634074); RFS_MUL_S(kx, x, c); }
+  const double k = __builtin_rint(kx);
+  double r = x;
+  { const double c = RFS_C(-6.93147180369123816490e-01); asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(k), "s"(c), "v"(r)); }
+  { const double c = RFS_C(-1.90821492927058770002e-10); asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(k), "s"(c), "v"(r)); }
+  double p;
+  { const double c11 = RFS_C(2.5052108385441718775e-08), c10 = RFS_C(2.7557319223985890653e-07);   // 1/11!, 1/10!
+    p = c11; RFS_FMA_S(p, r, c10); }
+  { const double c = RFS_C(2.7557319223985892511e-06); RFS_FMA_S(p, r, c); }  // 1/9!
+  { const double c = RFS_C(2.4801587301587301566e-05); RFS_FMA_S(p, r, c); }  // 1/8!
+  { const double c = RFS_C(1.9841269841269841253e-04); RFS_FMA_S(p, r, c); }  // 1/7!
+  { const double c = RFS_C(1.3888888888888889419e-03); RFS_FMA_S(p, r, c); }  // 1/6!
+  { const double c = RFS_C(8.3333333333333332177e-03); RFS_FMA_S(p, r, c); }  // 1/5!
+  { const double c = RFS_C(4.1666666666666664354e-02); RFS_FMA_S(p, r, c); }  // 1/4!
+  { const double c = RFS_C(1.6666666666666665741e-01); RFS_FMA_S(p, r, c); }  // 1/3!
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+#undef RFS_C
+#undef RFS_FMA_S
+#undef RFS_MUL_S
+  const double res = __builtin_amdgcn_ldexp(p, (int)k);
+  return (xin != xin) ? xin : res;
+#else
+  return exp(x);
+#endif
+}
+
 // exp(-0.5*md2)/factor with the reference's NaN->0 guard (include/RandomVec.hpp:417-434).
 // md2 > 1500 => exp(-750) is exactly 0 in fp64, so the transcendental is skipped (bit-identical result).
 __device__ __forceinline__ double gauss_from_md2(double md2, double factor) {
   if (md2 > 1500.0) return 0.0;
-  double l = exp(-0.5 * md2) / factor;
+  double l = rfs_exp(-0.5 * md2) / factor;
   if (l != l) l = 0.0;
   return l;
 }

@@ -614,7 +614,7 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
           const double d0 = gx[tt] - mx, d1 = gy[tt] - my;
           const double t0 = d0 * i00 + d1 * i01, t1 = d0 * i01 + d1 * i11;  // (i10 == i01: Sigma is stored symmetric)
           const double md2 = t0 * d0 + t1 * d1;
-          double lik = (md2 > 1500.0) ? 0.0 : exp(-0.5 * md2) * rfac;  // exactly 0 beyond 1500 (gauss_from_md2)
+          double lik = (md2 > 1500.0) ? 0.0 : rfs_exp(-0.5 * md2) * rfac;  // exactly 0 beyond 1500 (gauss_from_md2)
           lik = (lik != lik) ? 0.0 : lik;                                // NaN -> 0 (include/RandomVec.hpp:417-434)
           accB[t] += wp * lik;
           accA[t] += w * lik;
