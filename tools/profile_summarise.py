@@ -80,5 +80,11 @@ if os.path.exists(p):
     if lines:
         md.append("## c2b: bench.py --workload c2b (steady state, no re-seed)\n\n```\n" + lines[-1] + "\n```\n")
         json.dump(json.loads(lines[-1]), open(os.path.join(prof, f"{tag}_c2b_bench_line.json"), "w"), indent=1)
+for extra, title in (("c5_exact.log", "c5 in RFSGPU_PARTITION_EXACT mode (tools/c5_bench.py --exact)"), ("matperm.log", "batched MatPerm::calc, n = 8..20 (tools/matperm_bench.py)")):
+    p = os.path.join(src, extra)
+    if os.path.exists(p):
+        lines = [l.rstrip() for l in open(p) if l.startswith("C5 ") or l.startswith("|")]
+        if lines:
+            md.append(f"## {title}\n\n" + "\n".join(lines) + "\n")
 open(os.path.join(prof, f"{tag}_summary.md"), "w").write("\n".join(md) + "\n")
 print("\n".join(md)[:6000])

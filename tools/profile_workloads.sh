@@ -24,6 +24,8 @@ run_trace c2a python bench.py --workload c2a --steps 50 --warmup 5 --no-cpu-base
 run_trace c3 python bench.py --workload c3 --steps 50 --warmup 5 --no-cpu-baseline --no-pmc
 run_trace c4 python tools/vp_bench.py
 run_trace c5 python tools/c5_bench.py
+python tools/c5_bench.py --exact > $OUT/c5_exact.log 2>&1
+python tools/matperm_bench.py > $OUT/matperm.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   run_pmc c4 $c python tools/vp_bench.py
   C5_STEPS=4 run_pmc c5 $c python tools/c5_bench.py
