@@ -7,13 +7,14 @@ ParticleFilter::normalizeWeights / the N_eff test (include/ParticleFilter.hpp:35
 reference's GLOBAL systematic resampling (ParticleFilter.hpp:419-479) is kept: the N weights are all-gathered (device
 tensors), every rank computes the same plan from the same uniform draw, local children are a device gather
 (rfsgpu_resample_apply), cross-shard children migrate as packed rows from device memory to device memory
-(rfsgpu_export_slab_rows -> RCCL send/recv -> rfsgpu_import_slab_rows): the host only ever handles slot indices.
+(rfsgpu_export_slab_rows -> one RCCL all-to-all with per-peer byte counts -> rfsgpu_import_slab_rows): the host only ever
+handles slot indices.
 Shard-local resampling would change results and is not offered.
 
 Backend-agnostic: `local` is any object with the filter interface of capi.CFilter (the device engine in production; the
 tests substitute the CPU oracle, whose rows live in host memory, to run this host logic under gloo).  With the gloo backend
 and device rows (two ranks sharing one GPU in the tests) the rows are staged through the host, because gloo has no
-device-to-device send/recv; over RCCL ("nccl") nothing is staged.
+device-to-device transport (point-to-point send/recv there); over RCCL ("nccl") nothing is staged.
 """
 import numpy as np
 import torch
@@ -176,7 +177,13 @@ class ShardedRBPHDFilter:
             if n_send:
                 slots = np.concatenate([plan[g] - lo for g in send_g]).astype(np.int32)
                 self.f.export_slab_rows(slots, send_buf.data_ptr())
-            if W > 1 and (n_send or n_recv):
+            if W > 1 and self.on_gpu and self.backend == "nccl":
+                # RCCL: ONE all-to-all with per-peer byte counts (every rank derives both lists from the same plan); a collective
+                # every rank joins, rows move device to device over xGMI
+                in_splits = [len(send_g[d]) * R for d in range(W)]
+                out_splits = [len(recv_g[q]) * R for q in range(W)]
+                dist.all_to_all_single(recv_buf[:n_recv * R], send_buf[:n_send * R], out_splits, in_splits, group=self.group)
+            elif W > 1 and (n_send or n_recv):
                 staged = self.on_gpu and self.backend != "nccl"          # gloo: no device-to-device send/recv
                 sb = send_buf.cpu() if staged else send_buf
                 rb = torch.empty_like(recv_buf, device="cpu") if staged else recv_buf
