@@ -23,7 +23,8 @@ if "--build" in sys.argv:
 lib = C.CDLL(prof_lib)
 pkg.engine._lib = lib
 sc = pkg.scenarios
-n, nm, nz, cap = [int(x) for x in (sys.argv[1:5] + [2000, 200, 30, 384][len(sys.argv[1:5]):])]
+_pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+n, nm, nz, cap = [int(x) for x in (_pos[:4] + [2000, 200, 30, 384][len(_pos[:4]):])]
 scen = sc.make_scenario(n, nm, nz, seed=12345, **({"rmax": float(os.environ["KS_RMAX"])} if "KS_RMAX" in os.environ else {}))
 f = pkg.RBPHDFilter(n, gm_capacity=cap)
 sc.load_scenario(f, scen)
@@ -32,7 +33,11 @@ lib.rfsgpu_debug_sections(f._h, out)  # allocates the stamp buffer
 f.save_state()
 for _ in range(3):
     f.restore_state()
-    f.update(scen["Z"])
+    if "--fused" in sys.argv:      # the same stamps inside the fused step kernel (weighting and merge phases; particle 7)
+        f.update_async(scen["Z"])
+        f.synchronize()
+    else:
+        f.update(scen["Z"])
 lib.rfsgpu_debug_sections(f._h, out)
 t = np.array(list(out), dtype=np.int64)
 names = {0: ["update_map: pass1", "update_map: pass2"],
