@@ -65,6 +65,7 @@ struct rfsgpu_filter {
   hipEvent_t evStage[4] = {};
   int stageNext = 0;
   bool predPending = false;  // rfsgpu_predict_map_async's event pair has not been accumulated yet
+  bool poseCovZero = false;  // B.poseCov[0..9) holds zeros (the "no covariance" form), so a further cov == NULL push need not rewrite it
   MurtyQueue Q{};
   MurtyScratch MS{};
   int *hErr = nullptr;      // pinned
@@ -430,9 +431,11 @@ int rfsgpu_set_poses(rfsgpu_filter *f, const double *x, const double *cov, int c
     const size_t n = cov_stride == 9 ? (size_t)f->N * 9 : 9;
     HIPCHK(hipMemcpyAsync(f->B.poseCov, cov, n * sizeof(double), hipMemcpyHostToDevice, f->stream));
     f->P.poseCovStride = cov_stride;
+    f->poseCovZero = false;
   } else {
     HIPCHK(hipMemsetAsync(f->B.poseCov, 0, 9 * sizeof(double), f->stream));
     f->P.poseCovStride = 0;
+    f->poseCovZero = true;
   }
   HIPCHK(hipStreamSynchronize(f->stream));  // caller's buffers may be pageable / reused
   return RFSGPU_OK;
@@ -1041,9 +1044,13 @@ int rfsgpu_set_step_inputs_async(rfsgpu_filter *f, const double *x, const double
       memcpy(hc, cov, n * sizeof(double));
       HIPCHK(hipMemcpyAsync(f->B.poseCov, hc, n * sizeof(double), hipMemcpyHostToDevice, f->stream));
       f->P.poseCovStride = cov_stride;
+      f->poseCovZero = false;
     } else {
-      memset(hc, 0, 9 * sizeof(double));
-      HIPCHK(hipMemcpyAsync(f->B.poseCov, hc, 9 * sizeof(double), hipMemcpyHostToDevice, f->stream));
+      if (!f->poseCovZero) {   // (the shared all-zero covariance is written once, not per call)
+        memset(hc, 0, 9 * sizeof(double));
+        HIPCHK(hipMemcpyAsync(f->B.poseCov, hc, 9 * sizeof(double), hipMemcpyHostToDevice, f->stream));
+        f->poseCovZero = true;
+      }
       f->P.poseCovStride = 0;
     }
   }

@@ -11,12 +11,14 @@
 // INTEGRATION.md shows the Eigen-typed binding for the reference tree.
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <random>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rfsgpu.h"
@@ -151,6 +153,7 @@ class RBPHDFilter2d {
   void setParticlePose(int i, const Pose2d &p) {
     poses_[i] = p;
     posesDirty_ = true;
+    xbufFresh_ = false;
   }
 
   // RBPHDFilter::predict (:415-442): birth Gaussians at the pre-propagation pose, host propagation, Sigma += Q.
@@ -215,6 +218,7 @@ class RBPHDFilter2d {
   double effNParticles_t_, effNParticles_t_percent_;
   unsigned nUpdatesSinceResample_ = 0, nMeasurementsSinceResample_ = 0;
   bool resampleOccured_ = false, posesDirty_ = true, weightsStale_ = false;
+  bool xbufFresh_ = false;   // (RBPHDFilterVP) its packed pose buffer already holds the current poses
   TimingInfo timing_{};
 
   void check(int rc, const char *what) {
@@ -327,6 +331,7 @@ class RBPHDFilter2d {
     poses_.resize(n);
     weights_.assign(n, 1.0);
     posesDirty_ = true;
+    xbufFresh_ = false;
     weightsStale_ = false;
     return true;
   }
@@ -487,10 +492,19 @@ class RBPHDFilterVP : public RBPHDFilter2d {
 
   // RBPHDFilter::predict(u, dT, useModelNoise = false, useInputNoise, birthGaussianCheck) (:415-442) with
   // ProcessModel::sample's input-noise branch (include/ProcessModel.hpp:126-150): every particle draws its own input.
+  double tCfg_ = 0, tIn_ = 0, tPm_ = 0, tProp_ = 0;   // host seconds per section of predict() (printed by the driver with -v)
   void predict(const AckermanInput &u, double dT, bool /*useModelNoise*/, bool useInputNoise, bool birthGaussianCheck) {
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t0 = now();
     pushConfigVP();
+    auto t1 = now();
     pushInputsAsync();
+    auto t2 = now();
     check(rfsgpu_predict_map_async(h_, birthGaussianCheck ? 1 : 0), "predict_map");   // stream-ordered: no host wait
+    auto t3 = now();
+    tCfg_ += std::chrono::duration<double>(t1 - t0).count(); tIn_ += std::chrono::duration<double>(t2 - t1).count();
+    tPm_ += std::chrono::duration<double>(t3 - t2).count();
+    struct Acc { double &a; std::chrono::steady_clock::time_point t; ~Acc() { a += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); } } acc{tProp_, t3};
     // ParticleFilter::propagate (include/ParticleFilter.hpp:322-339) is a serial loop over one random stream in the reference;
     // at 5000 particles that host loop (two normal draws + the Ackerman step per particle) costs more than the device work of
     // a lidar message.  Here the particles are taken in fixed chunks of 256, each with its own generator seeded from ONE draw of
@@ -498,9 +512,20 @@ class RBPHDFilterVP : public RBPHDFilter2d {
     const unsigned long long stepSeed = rng_();
     const double sv = std::sqrt(u.var[0]), sr = std::sqrt(u.var[1]);
     const int nChunks = (n_ + 255) / 256;
-    // (a handful of threads: RFS_HOST_THREADS, default 8 -- an OpenMP team as wide as the host's logical CPU count would
-    //  oversubscribe a container with a CPU quota and spin)
-    static const int hostThreads = [] { const char *e = std::getenv("RFS_HOST_THREADS"); const int v = e ? std::atoi(e) : 8; return v < 1 ? 1 : v; }();
+    xbuf_.resize(3 * (size_t)n_);
+    double *xb = xbuf_.data();
+    // (RFS_HOST_THREADS, default min(16, CPUs the container may use) -- an OpenMP team as wide as the host's logical CPU count
+    //  would oversubscribe a container with a CPU quota and spin)
+    static const int hostThreads = [] {
+      if (const char *e = std::getenv("RFS_HOST_THREADS")) { const int v = std::atoi(e); return v < 1 ? 1 : v; }
+      int v = (int)std::thread::hardware_concurrency();
+      if (FILE *fq = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {   // a container's CPU quota, when there is one
+        long long q = 0, per = 0;
+        if (std::fscanf(fq, "%lld %lld", &q, &per) == 2 && q > 0 && per > 0) v = std::min<long long>(v, q / per);
+        std::fclose(fq);
+      }
+      return std::max(1, std::min(v, 16));
+    }();
 #pragma omp parallel for schedule(static) num_threads(hostThreads)
     for (int c = 0; c < nChunks; c++) {
       std::mt19937_64 eng(stepSeed + 0xD1B54A32D192ED03ull * (unsigned long long)(c + 1));
@@ -512,9 +537,11 @@ class RBPHDFilterVP : public RBPHDFilter2d {
         Pose2d xk;
         ackerman_.step(xk, poses_[i], uv, ur, dT);
         poses_[i] = xk;
+        xb[3 * i] = xk.x[0]; xb[3 * i + 1] = xk.x[1]; xb[3 * i + 2] = xk.x[2];   // the packed copy the next input push sends
       }
     }
     posesDirty_ = true;
+    xbufFresh_ = true;
   }
 
   // RBPHDFilter::update (:444-541); Z is consumed.  One lidar message = one input call + one step call, both stream-ordered
@@ -591,10 +618,11 @@ class RBPHDFilterVP : public RBPHDFilter2d {
   void pushInputsAsync() {
     const bool scanNow = measVP_.scanDirty && !measVP_.scan.empty();
     if (!posesDirty_ && !scanNow) return;
-    if (posesDirty_) {
+    if (posesDirty_ && !xbufFresh_) {   // (poses changed by something other than predict(): setParticlePose, resampling)
       xbuf_.resize(3 * (size_t)n_);
       for (int i = 0; i < n_; i++) { xbuf_[3 * i] = poses_[i].x[0]; xbuf_[3 * i + 1] = poses_[i].x[1]; xbuf_[3 * i + 2] = poses_[i].x[2]; }
     }
+    xbufFresh_ = false;
     check(rfsgpu_set_step_inputs_async(h_, posesDirty_ ? xbuf_.data() : nullptr, nullptr, 0, scanNow ? measVP_.scan.data() : nullptr,
                                        scanNow ? (int)measVP_.scan.size() : 0), "set_step_inputs");
     posesDirty_ = false;

@@ -239,6 +239,7 @@ int main(int argc, char **argv) {
   const Pose2d &bp = filter.getParticlePose(best);
   std::printf("particles %d  messages %d  lidar updates %d  resamplings %d  wall %.3f s  (inside predict() %.3f s, inside update() %.3f s)\n", nParticles, nMsg, nLidar,
               nResample, wall, tPredict, tUpdate);
+  std::printf("predict() host sections [s]: config %.4f  inputs %.4f  predict_map launch %.4f  propagate %.4f\n", filter.tCfg_, filter.tIn_, filter.tPm_, filter.tProp_);
   RBPHDFilter2d::TimingInfo *ti = filter.getTimingInfo();
   std::printf("Elapsed Timing Information [nsec]\n");  // format of the reference drivers' timing printout
   std::printf("%-22s%15s%15s\n", "", "wall", "cpu");
