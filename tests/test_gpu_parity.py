@@ -59,6 +59,36 @@ def test_update_map_phase(pkg, ob, sc, kw):
         np.testing.assert_allclose(dev.export_gm(i)[1], orc.export_gm(i)[1], rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("fused", [False, True])
+def test_new_gaussians_whose_normalised_weight_underflows_are_dropped_in_order(pkg, ob, sc, fused):
+    """RBPHDFilter.hpp:677 keeps a new Gaussian only if its normalised weight is > 0.  The device writes every survivor of the
+    gates to its slab slot first and compacts afterwards when some weight turns out not to be positive -- the rare path, forced
+    here: a huge clutter intensity and a share of landmarks with weights near the bottom of the fp64 range make v / normaliser
+    underflow to exactly 0 for some (not all) of the appended Gaussians.  Order and content must stay the reference's."""
+    scen = sc.make_scenario(24, 90, 20, seed=77, params=dict(clutter=1e10), weights=(0.5, 1.0))
+    rng = np.random.default_rng(4)
+    tiny = rng.random(scen["w"].shape) < 0.4
+    scen["w"][tiny] = 1e-322
+    dev, orc = make_pair(pkg, ob, sc, scen)
+    if fused:
+        dev.update_async(scen["Z"]); dev.synchronize()
+        orc.update(scen["Z"])
+        compare_maps(sc, dev, orc, scen["n"], ordered=True)
+        return
+    before = dev.gm_sizes().copy()
+    dev.update_map(scen["Z"])
+    orc.update_map(scen["Z"])
+    compare_maps(sc, dev, orc, scen["n"], ordered=True)
+    for i in range(scen["n"]):
+        assert np.array_equal(dev.get_unused(i), orc.get_unused(i))
+    assert (dev.gm_sizes() > before).any()          # some new Gaussians survive ...
+    # ... and some were dropped: an update of the same state with ordinary clutter appends strictly more
+    scen2 = dict(scen); scen2["params"] = dict(scen["params"], clutter=1e-4)
+    dev2, _ = make_pair(pkg, ob, sc, scen2)
+    dev2.update_map(scen["Z"])
+    assert (dev2.gm_sizes() > dev.gm_sizes()).any()
+
+
 @pytest.mark.parametrize("kw", SCENARIOS)
 def test_all_phases_stepwise(pkg, ob, sc, kw):
     scen = sc.make_scenario(**kw)
