@@ -60,7 +60,8 @@ struct rfsgpu_filter {
   int nZ = 0;  // measurements of the last update (birth uses them)
   double *dSums = nullptr;  // [2]
   int *dSrcSlot = nullptr;  // [N]
-  int *dRowSlots = nullptr; // [Ncap] slots of the rows being exported / imported (allocated on first use)
+  int *dRowSlots = nullptr; // slots of the rows being exported / imported (allocated on first use, grown on demand)
+  int rowSlotsCap = 0;
   double *hStage[4] = {nullptr, nullptr, nullptr, nullptr};  // pinned staging ring of rfsgpu_set_step_inputs_async
   hipEvent_t evStage[4] = {};
   int stageNext = 0;
@@ -1160,11 +1161,19 @@ int rfsgpu_resample_apply_n(rfsgpu_filter *f, const int *src_slot, int n_out) {
 size_t rfsgpu_slab_row_bytes(const rfsgpu_filter *f) { return f ? slab_row_bytes(f->B.npl, f->cap) : 0; }
 static int slab_rows(rfsgpu_filter *f, const int *slots, int n, void *dev_rows, bool exporting) {
   if (n == 0) return RFSGPU_OK;
-  if (!slots || !dev_rows || n < 0 || n > f->N) return fail(f, RFSGPU_ERR_INVALID, "slab rows: bad arguments");
+  if (!slots || !dev_rows || n < 0) return fail(f, RFSGPU_ERR_INVALID, "slab rows: bad arguments");
   for (int k = 0; k < n; k++)
     if (slots[k] < 0 || slots[k] >= f->N) return fail(f, RFSGPU_ERR_INVALID, "slab rows: slot out of range");
   hipSetDevice(f->device);
-  if (!f->dRowSlots) HIPCHK(hipMalloc(&f->dRowSlots, (size_t)f->Ncap * sizeof(int)));
+  if (n > f->rowSlotsCap) {   // (a slot may be exported many times -- one heavy parent, many children elsewhere -- so n is not bounded by N)
+    HIPCHK(hipStreamSynchronize(f->stream));
+    if (f->dRowSlots) HIPCHK(hipFree(f->dRowSlots));
+    f->dRowSlots = nullptr;
+    f->rowSlotsCap = 0;
+    const int want = std::max(n, f->Ncap);
+    HIPCHK(hipMalloc(&f->dRowSlots, (size_t)want * sizeof(int)));
+    f->rowSlotsCap = want;
+  }
   HIPCHK(hipMemcpyAsync(f->dRowSlots, slots, (size_t)n * sizeof(int), hipMemcpyHostToDevice, f->stream));
   if (exporting) slab_rows_kernel<true><<<n, 256, 0, f->stream>>>(f->B, f->cur, f->dRowSlots, (unsigned char *)dev_rows, f->P.poseCovStride);
   else slab_rows_kernel<false><<<n, 256, 0, f->stream>>>(f->B, f->cur, f->dRowSlots, (unsigned char *)dev_rows, f->P.poseCovStride);

@@ -128,7 +128,18 @@ class RBPHDFilter2d {
     effNParticles_t_ = double(n) / 4.0;  // ParticleFilter.hpp:232
     effNParticles_t_percent_ = effNParticles_t_ / n;
   }
-  ~RBPHDFilter2d() { rfsgpu_destroy(h_); }
+  // The same filter over SEVERAL GPUs from this one host thread (rfsgpu_group_*: contiguous particle blocks, one shard per
+  // device id, global resampling with peer-copy migration).  Everything below dispatches on g_; the public interface is
+  // unchanged.  (2-D model; device ids may repeat, which is how a single-GPU box exercises it.)
+  RBPHDFilter2d(int n, const std::vector<int> &device_ids, int gm_capacity = 512)
+      : n_(n), nInit_(n), poses_(n), weights_(n, 1.0), rng_(std::rand()) {
+    int rc = rfsgpu_group_create(&g_, RFSGPU_MODEL_RNGBRG_2D, n, device_ids.data(), (int)device_ids.size(), gm_capacity);
+    if (rc != RFSGPU_OK) throw std::runtime_error("rfsgpu_group_create failed with status " + std::to_string(rc));
+    h_ = rfsgpu_group_shard(g_, 0);   // (timing buckets are read from shard 0: all shards run the same launches)
+    effNParticles_t_ = double(n) / 4.0;
+    effNParticles_t_percent_ = effNParticles_t_ / n;
+  }
+  ~RBPHDFilter2d() { if (g_) rfsgpu_group_destroy(g_); else rfsgpu_destroy(h_); }
   RBPHDFilter2d(const RBPHDFilter2d &) = delete;
   RBPHDFilter2d &operator=(const RBPHDFilter2d &) = delete;
 
@@ -160,7 +171,7 @@ class RBPHDFilter2d {
   void predict(const Odometry2d &u, double /*dT*/, bool useModelNoise = true, bool /*useInputNoise*/ = false, bool birthGaussianCheck = true) {
     pushConfig();
     pushPoses();
-    check(rfsgpu_predict_map(h_, birthGaussianCheck ? 1 : 0), "predict_map");
+    check(g_ ? rfsgpu_group_predict_map(g_, birthGaussianCheck ? 1 : 0) : rfsgpu_predict_map(h_, birthGaussianCheck ? 1 : 0), "predict_map");
     for (int i = 0; i < n_; i++) {  // ParticleFilter::propagate
       Pose2d xk;
       motion_.sample(xk, poses_[i], u, useModelNoise, rng_);
@@ -181,7 +192,7 @@ class RBPHDFilter2d {
     pushPoses();
     std::vector<double> z(2 * meas.size());
     for (size_t k = 0; k < meas.size(); k++) { z[2 * k] = meas[k].z[0]; z[2 * k + 1] = meas[k].z[1]; }
-    check(rfsgpu_update(h_, z.data(), (int)meas.size()), "update");
+    check(g_ ? rfsgpu_group_update(g_, z.data(), (int)meas.size(), nullptr) : rfsgpu_update(h_, z.data(), (int)meas.size()), "update");
     weightsStale_ = true;
     resampleOccured_ = false;
     if (nUpdatesSinceResample_ >= (unsigned)config.minUpdatesBeforeResample_ &&
@@ -196,8 +207,10 @@ class RBPHDFilter2d {
   }
 
   // RBPHDFilter::getGMSize / getLandmark (:1152-1178)
-  int getGMSize(int i) { return rfsgpu_gm_size(h_, i); }
-  bool getLandmark(int i, int m, double u[2], double S[4], double &w) { return rfsgpu_get_landmark(h_, i, m, u, S, &w) == RFSGPU_OK; }
+  int getGMSize(int i) { return g_ ? rfsgpu_group_gm_size(g_, i) : rfsgpu_gm_size(h_, i); }
+  bool getLandmark(int i, int m, double u[2], double S[4], double &w) {
+    return (g_ ? rfsgpu_group_get_landmark(g_, i, m, u, S, &w) : rfsgpu_get_landmark(h_, i, m, u, S, &w)) == RFSGPU_OK;
+  }
 
   TimingInfo *getTimingInfo() {
     rfsgpu_get_timing(h_, &timing_);
@@ -207,6 +220,7 @@ class RBPHDFilter2d {
 
  protected:
   rfsgpu_filter *h_ = nullptr;
+  rfsgpu_group *g_ = nullptr;   // set: the particle set is sharded over several devices
   int n_, nInit_;
   MotionModel_Odometry2d motion_;
   LmkProcessModel lmk_;
@@ -222,7 +236,7 @@ class RBPHDFilter2d {
   TimingInfo timing_{};
 
   void check(int rc, const char *what) {
-    if (rc != RFSGPU_OK) throw std::runtime_error(std::string(what) + ": " + rfsgpu_last_error(h_));
+    if (rc != RFSGPU_OK) throw std::runtime_error(std::string(what) + ": " + (g_ ? rfsgpu_group_last_error(g_) : rfsgpu_last_error(h_)));
   }
   void pushConfig() {
     pushFilterConfig();
@@ -233,8 +247,8 @@ class RBPHDFilter2d {
     m.rangeLimMax = meas_.config.rangeLimMax_;
     m.rangeLimMin = meas_.config.rangeLimMin_;
     m.rangeLimBuffer = meas_.config.rangeLimBuffer_;
-    check(rfsgpu_set_model_rngbrg(h_, &m), "set_model_rngbrg");
-    check(rfsgpu_set_lmk_process_noise(h_, lmk_.Q), "set_lmk_process_noise");
+    check(g_ ? rfsgpu_group_set_model_rngbrg(g_, &m) : rfsgpu_set_model_rngbrg(h_, &m), "set_model_rngbrg");
+    check(g_ ? rfsgpu_group_set_lmk_process_noise(g_, lmk_.Q) : rfsgpu_set_lmk_process_noise(h_, lmk_.Q), "set_lmk_process_noise");
   }
   // RBPHDFilter::Config + the Kalman filter's gates: the model-independent part
   void pushFilterConfig() {
@@ -254,9 +268,9 @@ class RBPHDFilter2d {
     c.minUpdatesBeforeResample = config.minUpdatesBeforeResample_;
     c.minMeasurementsBeforeResample = config.minMeasurementsBeforeResample_;
     c.useClusterProcess = config.useClusterProcess_ ? 1 : 0;
-    check(rfsgpu_set_filter_config(h_, &c), "set_filter_config");
+    check(g_ ? rfsgpu_group_set_filter_config(g_, &c) : rfsgpu_set_filter_config(h_, &c), "set_filter_config");
     rfsgpu_kf_config k{kf_.config.rangeInnovationThreshold_, kf_.config.bearingInnovationThreshold_};
-    check(rfsgpu_set_kf_config(h_, &k), "set_kf_config");
+    check(g_ ? rfsgpu_group_set_kf_config(g_, &k) : rfsgpu_set_kf_config(h_, &k), "set_kf_config");
   }
   void pushPoses() {
     if (!posesDirty_) return;
@@ -268,19 +282,24 @@ class RBPHDFilter2d {
       for (int t = 0; t < 9; t++) anyCov = anyCov || (poses_[i].P[t] != 0.0);
     }
     // (all-zero covariances -- setParticlePose'd poses, the Ackerman model -- cross as "no covariance": 24 B per particle)
-    check(rfsgpu_set_poses(h_, x.data(), anyCov ? P.data() : nullptr, anyCov ? 9 : 0), "set_poses");
+    check(g_ ? rfsgpu_group_set_poses(g_, x.data(), anyCov ? P.data() : nullptr, anyCov ? 9 : 0)
+             : rfsgpu_set_poses(h_, x.data(), anyCov ? P.data() : nullptr, anyCov ? 9 : 0), "set_poses");
     posesDirty_ = false;
   }
   void pullWeights() {
     if (!weightsStale_) return;
-    check(rfsgpu_get_weights(h_, weights_.data()), "get_weights");
+    check(g_ ? rfsgpu_group_get_weights(g_, weights_.data()) : rfsgpu_get_weights(h_, weights_.data()), "get_weights");
     weightsStale_ = false;
   }
   // ParticleFilter::normalizeWeights (ParticleFilter.hpp:352-363): sum on the device, divide on the device.
   void normalizeWeights() {
     double s[2];
-    check(rfsgpu_weight_sums(h_, s), "weight_sums");
-    check(rfsgpu_normalize_weights(h_, s[0], nullptr), "normalize_weights");
+    if (g_) {
+      check(rfsgpu_group_normalize(g_, s), "group_normalize");
+    } else {
+      check(rfsgpu_weight_sums(h_, s), "weight_sums");
+      check(rfsgpu_normalize_weights(h_, s[0], nullptr), "normalize_weights");
+    }
     weightsStale_ = true;
   }
   // ParticleFilter::resample(n, forceResample) (ParticleFilter.hpp:399-492).  nOut == 0 or > nParticles_ keeps the count; a
@@ -325,7 +344,10 @@ class RBPHDFilter2d {
       poses_[next_unsampled] = poses_[idx];     // Particle::copy copies the pose too
       next_unsampled++;
     }
-    if (n == N) check(rfsgpu_resample_apply(h_, src.data()), "resample_apply");
+    if (g_) {
+      if (n != N) throw std::runtime_error("resample(n < nParticles) is not offered by the multi-GPU form");
+      check(rfsgpu_group_apply_plan(g_, src.data()), "group_apply_plan");   // local gathers + peer-copy migration
+    } else if (n == N) check(rfsgpu_resample_apply(h_, src.data()), "resample_apply");
     else check(rfsgpu_resample_apply_n(h_, src.data(), n), "resample_apply_n");
     n_ = n;
     poses_.resize(n);

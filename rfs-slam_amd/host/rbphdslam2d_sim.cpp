@@ -19,6 +19,7 @@
 #include <map>
 #include <random>
 #include <sstream>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -34,6 +35,7 @@ struct Landmark { double x[2]; };
 int main(int argc, char **argv) {
   std::string cfgFile, outDir;
   int trajSeed = 1, simSeed = 1, nParticlesOverride = -1, kMaxOverride = -1, device = 0;
+  std::vector<int> devices;
   for (int a = 1; a < argc; a++) {
     std::string s = argv[a];
     auto next = [&]() { return (a + 1 < argc) ? std::string(argv[++a]) : std::string(); };
@@ -44,6 +46,17 @@ int main(int argc, char **argv) {
     else if (s == "-k") kMaxOverride = std::atoi(next().c_str());
     else if (s == "-o") outDir = next();
     else if (s == "-d") device = std::atoi(next().c_str());
+    else if (s == "--devices") {   // e.g. "0,1,2,3" (ids may repeat): one shard of the particle set per entry, rfsgpu_group_*
+      std::string list = next();
+      size_t pos = 0;
+      while (pos <= list.size()) {
+        const size_t comma = list.find(',', pos);
+        const std::string tok = list.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+        if (!tok.empty()) devices.push_back(std::atoi(tok.c_str()));
+        if (comma == std::string::npos) break;
+        pos = comma + 1;
+      }
+    }
   }
   Cfg c;
   if (!cfgFile.empty()) c = read_xml_cfg(cfgFile);
@@ -164,7 +177,9 @@ int main(int argc, char **argv) {
   filter.config.landmarkExistencePrior_ = 0.5;
   (void)birthW; (void)newGaussMD; (void)nEvalPt; (void)minWeight; (void)weightThr; (void)useCluster; (void)minSteps; (void)mergeThr; (void)mergeInfl; (void)pruneThr;
 #else
-  RBPHDFilter2d filter(nParticles, device, 384);
+  std::unique_ptr<RBPHDFilter2d> filterOwner(devices.size() > 1 ? new RBPHDFilter2d(nParticles, devices, 384) : new RBPHDFilter2d(nParticles, device, 384));
+  RBPHDFilter2d &filter = *filterOwner;
+  if (devices.size() > 1) std::printf("particle set sharded over %zu device entries (rfsgpu_group_*)\n", devices.size());
 #endif
   double Q[9] = {vardx, 0, 0, 0, vardy, 0, 0, 0, vardz};
   for (double &q : Q) q *= pNoiseInfl * dT * dT;
