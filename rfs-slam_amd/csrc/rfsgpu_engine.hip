@@ -90,6 +90,7 @@ struct rfsgpu_filter {
                             // time a negative weight is a value (FastSLAM's log-odds) and every stored entry counts
   int nCU = 256;            // multiProcessorCount of the device
   bool fuseSteps = true;    // rfsgpu_update_async uses phd_step_fused_kernel (2-D model); RFSGPU_FUSED_STEP=0 turns it off
+  int stepWppOverride = 0;  // RFSGPU_STEP_WPP: waves per particle of the fused step kernel (2 or 3); 0 = chosen per launch
   hipEvent_t evAfterWeightKernel = nullptr;   // where launch_weighting drops its mid-phase event (async steps only)
   int ringCount = 0;        // async steps recorded since the last harvest
   double statNs[3] = {0, 0, 0};
@@ -237,6 +238,7 @@ int rfsgpu_create_ex(rfsgpu_filter **out, int model, int n_particles, int device
   rfsgpu_default_fastslam_config(&f->fs);
   f->fs.nParticlesMax = 3 * n_particles;
   { const char *e = getenv("RFSGPU_FUSED_STEP"); if (e && e[0] == '0') f->fuseSteps = false; }
+  { const char *e = getenv("RFSGPU_STEP_WPP"); if (e) f->stepWppOverride = atoi(e); }
   if (f->cap > 2048) { delete f; return RFSGPU_ERR_INVALID; }
   auto bail = [&](int code) { rfsgpu_destroy(f); return code; };
   if (hipSetDevice(device_id) != hipSuccess) return bail(RFSGPU_ERR_NO_DEVICE);
@@ -906,14 +908,29 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
     f->nZ = n_z;
     HIPCHK(hipEventRecord(e[0], f->stream));
     const int ec = eval_cap(f), useW = f->cfg.useClusterProcess ? 0 : 1;
-    const size_t b = step_fused_lds_total(f->cap, ec, f->nZ, STEP_WPP);
-    if ((rc = set_lds(f, (phd_step_fused_kernel<STEP_WPP, true>), b)) != RFSGPU_OK) return rc;
-    if ((rc = set_lds(f, (phd_step_fused_kernel<STEP_WPP, false>), b)) != RFSGPU_OK) return rc;
+    // Waves per particle: two, unless the two-wave grid cannot be resident at once (large mixtures: the LDS block limits the
+    // workgroups per CU) -- then three waves per particle finish each workgroup sooner and free its slot (measured on the
+    // configs[2] shard, 2500 x 500 x 30 at cap 640: fused step 327 -> 263 us; at C2a, where all 2000 two-wave workgroups are
+    // resident, three waves lose: 133 -> 180 us).  RFSGPU_STEP_WPP = 2 | 3 overrides.
+    const size_t b2 = step_fused_lds_total(f->cap, ec, f->nZ, 2);
+    const int perCU2 = (int)std::min<size_t>(8, b2 ? (size_t)(160 * 1024) / b2 : 8);
+    int wpp = ((long long)perCU2 * f->nCU >= f->N) ? 2 : 3;
+    if (f->stepWppOverride == 2 || f->stepWppOverride == 3) wpp = f->stepWppOverride;
+    const size_t b = step_fused_lds_total(f->cap, ec, f->nZ, wpp);
     // phase priorities only when every workgroup is resident at once: 16 waves per CU at 128 VGPRs, LDS permitting
-    const int perCU = (int)std::min<size_t>(16 / STEP_WPP, b ? (size_t)(160 * 1024) / b : 16);
+    const int perCU = (int)std::min<size_t>(16 / wpp, b ? (size_t)(160 * 1024) / b : 16);
     const int phasePrio = (long long)perCU * f->nCU >= f->N ? 1 : 0;
-    if (phasePrio) phd_step_fused_kernel<STEP_WPP, true><<<f->N, STEP_WPP * 64, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
-    else phd_step_fused_kernel<STEP_WPP, false><<<f->N, STEP_WPP * 64, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
+    if (wpp == 2) {
+      if ((rc = set_lds(f, (phd_step_fused_kernel<2, true>), b)) != RFSGPU_OK) return rc;
+      if ((rc = set_lds(f, (phd_step_fused_kernel<2, false>), b)) != RFSGPU_OK) return rc;
+      if (phasePrio) phd_step_fused_kernel<2, true><<<f->N, 128, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
+      else phd_step_fused_kernel<2, false><<<f->N, 128, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
+    } else {
+      if ((rc = set_lds(f, (phd_step_fused_kernel<3, true>), b)) != RFSGPU_OK) return rc;
+      if ((rc = set_lds(f, (phd_step_fused_kernel<3, false>), b)) != RFSGPU_OK) return rc;
+      if (phasePrio) phd_step_fused_kernel<3, true><<<f->N, 192, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
+      else phd_step_fused_kernel<3, false><<<f->N, 192, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e[3], f->stream));
     if (murty_launch(f->Q, f->MS, f->B, f->stream, with_sums ? f->dSums : nullptr, normalize, &za, 2 * n_z, f->hJobCount) != 0) return fail(f, RFSGPU_ERR_HIP, "post kernel launch failed");

@@ -220,6 +220,32 @@ def test_exact_partition_mode(pkg, ob, sc):
     np.testing.assert_array_equal(dev2.get_weights(), we)
 
 
+@pytest.mark.parametrize("kw", [SCENARIOS[1], SCENARIOS[2], SCENARIOS[3], dict(n_particles=12, n_landmarks=500, n_z=30, seed=9, rmax=5.0),
+                                dict(n_particles=9, n_landmarks=40, n_z=7, seed=8, use_cluster=1)])
+def test_fused_step_with_three_waves_per_particle(pkg, ob, sc, kw, monkeypatch):
+    """The fused step kernel's three-wave form (what the engine picks when the two-wave grid cannot be resident at once, e.g. the
+    configs[2] shard; forced here with RFSGPU_STEP_WPP=3): bit-identical to the synchronous three-kernel path over two steps."""
+    monkeypatch.setenv("RFSGPU_STEP_WPP", "3")
+    scen = sc.make_scenario(**kw)
+    cap = 704 if kw["n_landmarks"] >= 500 else 512
+    dev, orc = make_pair(pkg, ob, sc, scen, cap=cap)
+    ref, _ = make_pair(pkg, ob, sc, scen, cap=cap)
+    for step in range(2):
+        if step:
+            for f in (dev, ref, orc):
+                f.predict_map(True)
+        dev.step_async(scen["Z"], False)
+        dev.synchronize()
+        ref.update(scen["Z"])
+        orc.update(scen["Z"])
+        assert np.array_equal(dev.get_weights(), ref.get_weights())
+        for i in range(scen["n"]):
+            for a, b in zip(dev.export_gm(i), ref.export_gm(i)):
+                assert np.array_equal(a, b)
+        compare_weights(dev, orc)
+        compare_maps(sc, dev, orc, scen["n"], ordered=True)
+
+
 def test_cluster_process_weighting(pkg, ob, sc):
     scen = sc.make_scenario(32, 90, 20, seed=11, use_cluster=True)
     dev, orc = make_pair(pkg, ob, sc, scen)
