@@ -44,7 +44,7 @@ for k, (calls, avg) in sorted(dur.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
     out[k] = dict(calls=calls, avg_ns=avg, fetch_kib=fetch[k], write_kib=write.get(k, 0.0), hbm_bytes=b)
     lines.append(f"| `{k}` | {calls} | {avg/1e3:.2f} | {fetch[k]:.1f} | {write.get(k,0):.1f} | {b/1e6:.2f} MB | {b/avg:.1f} |")
 json.dump(out, open(os.path.join(prof, f"{tag}_pmc.json"), "w"), indent=1)
-json.dump(out, open(os.path.join(prof, "pmc_latest.json"), "w"), indent=1)
+# (round 1 also wrote profiles/pmc_latest.json for bench.py to read; bench.py measures the traffic live since round 2)
 bench = [l for l in open(os.path.join(src, "bench_trace.log")) if '"metric"' in l]
 with open(os.path.join(prof, f"{tag}_summary.md"), "w") as fh:
     fh.write(f"# {tag}: rocprofv3 summary (tools/profile_round.sh {tag}; MI355X, 1 GPU)\n\n")
