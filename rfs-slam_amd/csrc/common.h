@@ -93,6 +93,13 @@ struct Buffers {
 #define DBG_T(base, k) do { } while (0)
 #define DBG_TB(base, k) do { } while (0)
 #endif
+// Tuning aid (tools/cut_profile.py): a -DRFS_STOP_AT=k build ends every wave at cut point k, so the SQ counters of the
+// truncated kernel give the cumulative instruction counts up to that point.  Absent from product builds.
+#ifdef RFS_STOP_AT
+#define RFS_CUT(k) do { if (RFS_STOP_AT == (k)) __builtin_amdgcn_endpgm(); } while (0)
+#else
+#define RFS_CUT(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ double *plane(double *slab, int cap, int particle, int pl) {
   return slab + ((size_t)particle * PL_COUNT + pl) * (size_t)cap;
@@ -181,6 +188,22 @@ __device__ __forceinline__ float wave_max_f32(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// min / max of a u32 over the wave with DPP moves (lanes without a partner keep their own value)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_keep_u32(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  v = max(v, dpp_keep_u32<0xb1, 0xf>(v));
+  v = max(v, dpp_keep_u32<0x4e, 0xf>(v));
+  v = max(v, dpp_keep_u32<0x114, 0xf>(v));
+  v = max(v, dpp_keep_u32<0x118, 0xf>(v));
+  v = max(v, dpp_keep_u32<0x142, 0xa>(v));
+  v = max(v, dpp_keep_u32<0x143, 0xc>(v));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) { return ~wave_max_u32(~v); }
 
 // exclusive prefix sum over the wave (small ints): Hillis-Steele inside each 16-lane row with row_shr DPP moves, then the row
 // totals across rows with row_bcast:15 / :31 -- six VALU instructions, no LDS permute and no lane-address registers (the

@@ -158,6 +158,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
   block_sync();
 
   DBG_TB(32, 1);
+  RFS_CUT(20);
   // ---- phase 1: grid build ----
   if (WPP > 1) {
 #pragma unroll
@@ -225,6 +226,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
   if (tid == 0) *sPairCount = 0u;
   block_sync();
   DBG_TB(32, 8);
+  RFS_CUT(21);
   // ---- phase 1: every pair (a, j > a) against the INITIAL states ----
   // 1a: each entry scans the 3x3 cells around it, four neighbours per trip, with the branch-free fp32 distance prefilter
   //     |x_j - x_a| <= max(r_a, r_j) + rounding bound.  Survivors with a higher index are collected in registers and written
@@ -314,6 +316,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     sSlack[m] = (slackMin > 0.f) ? (unsigned short)(__float_as_uint(slackMin) >> 16) : (unsigned short)0;
   }
   block_sync();
+  RFS_CUT(22);
   {
     const int nPairs = (int)min(*sPairCount, (unsigned)pairCap);
     for (int p0 = 0; p0 < nPairs; p0 += NT) {
@@ -349,6 +352,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
   block_sync();
 
   DBG_TB(32, 2);
+  RFS_CUT(23);
 #ifdef RFS_PROFILE
   dbgT2 = (long long)__builtin_readcyclecounter();
   dbgPairs = *sPairCount;
@@ -673,6 +677,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
   }
 
   DBG_TB(32, 3);
+  RFS_CUT(24);
   // ---- fused prune: keep w >= t (not absorbed), order (weight desc, index asc), compact into the other slab ----
   for (int m = tid, sidx = 0; m < N; m += NT, sidx++)
     if ((hole >> sidx) & 1u) sW[m] = -1.0;

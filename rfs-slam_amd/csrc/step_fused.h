@@ -65,6 +65,7 @@ void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, in
   else phd_update_map_block<WPP>(B, P, cur, nZ, i, tid, smem_raw, smem_raw + RFS_Z_LDS_BYTES, PHASE_PRIO);
   __threadfence_block();  // the slab / count written by wave 0 -> the whole workgroup
   __syncthreads();
+  RFS_CUT(8);
 #ifdef RFS_PROFILE
   if (fd && tid == 0) fd[1] = (long long)wall_clock64();
 #endif
@@ -84,6 +85,7 @@ void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, in
     __syncthreads();
     mergePerm = sPerm;
   }
+  RFS_CUT(16);
   int tidM = threadIdx.x;
   asm volatile("" : "+v"(tidM));
   if (PHASE_PRIO) __builtin_amdgcn_s_setprio(0);

@@ -478,7 +478,9 @@ __device__ __forceinline__ void phd_update_map_block(const Buffers &B, const Par
     const bool fov = act && (pd != 0);
     const double pdw = pd * w;
     nFov += __popcll(__ballot(fov));
+    RFS_CUT(1);
     const unsigned long long cand = gate_candidates(P, k, fov && k.ok, nZ, sZf);
+    RFS_CUT(2);
     unsigned long long surv = 0;
     double keepV[UPDMAP_KEEP];
 #pragma unroll
@@ -496,6 +498,7 @@ __device__ __forceinline__ void phd_update_map_block(const Buffers &B, const Par
         cnt++;
       }
     }
+    RFS_CUT(3);
     const int off = wave_excl_scan(cnt, lane);
     const int totalW = __builtin_amdgcn_readlane(off + cnt, 63);
     int *tot = sTot + 8 * (p & 1);
@@ -524,6 +527,7 @@ __device__ __forceinline__ void phd_update_map_block(const Buffers &B, const Par
       }
     }
     __syncthreads();
+    RFS_CUT(4);
     if (wave == 0) {  // lane z folds this pass's survivors of measurement z into its normaliser, in landmark order
       const int lo = nSurv, hi = (nSurv + total < room) ? nSurv + total : room;
       int sIdx = lo;
@@ -542,7 +546,9 @@ __device__ __forceinline__ void phd_update_map_block(const Buffers &B, const Par
       }
     }
     nSurv += total;
+    RFS_CUT(5);
   }
+  RFS_CUT(6);
   if (__ballot(overflow) != 0ull && lane == 0) atomicOr(&sMisc[0], 1);
   if (lane == 0) atomicAdd(&sMisc[1], nFov);
   if (wave == 0) sCol[lane] = cs;
@@ -583,6 +589,7 @@ __device__ __forceinline__ void phd_update_map_block(const Buffers &B, const Par
     outBase = nM + sMisc[3];
   }
 
+  RFS_CUT(7);
   // ---------------- phase 3: missed-detection weights (:686-706); setWeight keeps the old weight in w_prev ----------------
   for (int m = tid; m < nM; m += NT) {
     const double w = pW[m];

@@ -347,6 +347,116 @@ __device__ double rfs_partitions_wave(const WeightLDS &s, int nE, int nZ, double
 // Cross-wave scratch of the multi-wave kernel: a few doubles / ints after the per-particle LDS block.
 #define WEIGHT_SCRATCH_BYTES 64
 
+// ---- rank sort by buckets ---------------------------------------------------------------------------------------------------
+// rank(m) = #{ j : key_j > key_m  or (key_j == key_m and j < m) }  -- the order of sortByWeight with ties by index.
+// Counting that against all entries (or against sorted 64-entry chunks, the form below this one) was 15 % of the fused
+// step's vector instructions at 2000 x 200.  Here the keys' order-preserving u64 images are cut into NB buckets over the
+// range of their upper words (an LDS histogram, one wave-wide scan, a scatter -- the merge phase's grid build in one
+// dimension), and an entry is compared only with the members of its own bucket: rank = entries in the buckets ahead + the
+// members of its bucket that are ahead of it.  Exact for every input (the u64 image is a total order consistent with the
+// fp64 one; -0 is folded into +0); a mixture whose keys crowd into one bucket (many equal weights) makes the walks long, and
+// the caller then falls back to the chunk form (returns false).
+__device__ __forceinline__ unsigned long long sort_key_u64(double w) {
+  const long long b = __double_as_longlong(w + 0.0);
+  return (unsigned long long)b ^ ((unsigned long long)(b >> 63) | 0x8000000000000000ull);
+}
+__host__ __device__ inline int rank_sort_log_buckets(int cap) { return cap >= 344 ? 10 : (cap >= 176 ? 9 : (cap >= 90 ? 8 : 7)); }  // NB*2 + 16 + cap*2 <= cap*8
+#ifndef RANK_SORT_MAX_BUCKET
+#define RANK_SORT_MAX_BUCKET 32
+#endif
+// keys [N] in LDS; hist: 8 * ((cap + 63) & ~63) bytes of LDS scratch; xscr: 12 ints of LDS scratch; ranks of entries tid + NT * k to rl[k].
+// All threads of the block call it; the caller synchronises before it reuses `hist`.
+template <int WPP, int NS, class Sync>
+__device__ __forceinline__ bool bucket_rank_sort(const double *keys, const int N, const int tid, unsigned *hist, const int cap, int *xscr, int (&rl)[NS],
+                                                 Sync block_sync) {
+  constexpr int NT = WPP * 64;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int logNB = rank_sort_log_buckets(cap), NB = 1 << logNB;
+  unsigned short *order = reinterpret_cast<unsigned short *>(hist + NB / 2 + 4);    // [N] entries in bucket order
+  auto cell_at = [&](int e) -> unsigned { return (hist[e >> 1] >> (16 * (e & 1))) & 0xffffu; };
+  unsigned hmin = 0xffffffffu, hmax = 0u;
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    const int m = tid + NT * k;
+    if (m < N) {
+      const unsigned h = (unsigned)(sort_key_u64(keys[m]) >> 32);
+      hmin = min(hmin, h);
+      hmax = max(hmax, h);
+    }
+  }
+  hmin = wave_min_u32(hmin);
+  hmax = wave_max_u32(hmax);
+  if (lane == 0) { xscr[wave] = (int)hmin; xscr[4 + wave] = (int)hmax; }
+  for (int c = tid; c <= NB / 2; c += NT) hist[c] = 0u;
+  block_sync();
+#pragma unroll
+  for (int w2 = 0; w2 < WPP; w2++) { hmin = min(hmin, (unsigned)xscr[w2]); hmax = max(hmax, (unsigned)xscr[4 + w2]); }
+  const unsigned range = hmax - hmin;
+  const int bits = range ? 32 - __builtin_clz(range) : 0;
+  const int sh = bits > logNB ? bits - logNB : 0;                                  // (range >> sh) < NB
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    const int m = tid + NT * k;
+    if (m < N) {
+      const int e = (int)((hmax - (unsigned)(sort_key_u64(keys[m]) >> 32)) >> sh) + 1;  // largest keys first; counts shifted by one entry
+      atomicAdd(&hist[e >> 1], 1u << (16 * (e & 1)));
+    }
+  }
+  block_sync();
+  if (wave == 0) {  // exclusive scan over the NB + 1 half-word entries; lane l owns words [WPL l, WPL (l + 1)), the last entry gets the total
+    const int WPL = NB >> 7;
+    int tot = 0;
+    unsigned mx = (lane == 63) ? (hist[NB / 2] & 0xffffu) : 0u;                     // (the last bucket's count sits in the extra entry)
+    for (int k = 0; k < WPL; k++) {
+      const unsigned v = hist[WPL * lane + k];
+      tot += (int)(v & 0xffffu) + (int)(v >> 16);
+      mx = max(mx, max(v & 0xffffu, v >> 16));
+    }
+    int off = wave_excl_scan(tot, lane);
+    mx = wave_max_u32(mx);
+    for (int k = 0; k < WPL; k++) {
+      const unsigned v = hist[WPL * lane + k];
+      const unsigned lo = (unsigned)off;
+      off += (int)(v & 0xffffu);
+      const unsigned hi = (unsigned)off;
+      off += (int)(v >> 16);
+      hist[WPL * lane + k] = lo | (hi << 16);
+    }
+    if (lane == 63) hist[NB / 2] = (unsigned)off;
+    if (lane == 0) xscr[8] = (int)mx;
+  }
+  block_sync();
+  if (xscr[8] > RANK_SORT_MAX_BUCKET) return false;
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    const int m = tid + NT * k;
+    if (m < N) {
+      const int e = (int)((hmax - (unsigned)(sort_key_u64(keys[m]) >> 32)) >> sh) + 1;
+      const unsigned pos = (atomicAdd(&hist[e >> 1], 1u << (16 * (e & 1))) >> (16 * (e & 1))) & 0xffffu;
+      order[pos] = (unsigned short)m;
+    }
+  }
+  block_sync();   // entry c of the histogram is now the start of bucket c, entry c + 1 its end
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    const int m = tid + NT * k;
+    rl[k] = 0;
+    if (m < N) {
+      const unsigned long long u = sort_key_u64(keys[m]);
+      const int b = (int)((hmax - (unsigned)(u >> 32)) >> sh);
+      const int st = (int)cell_at(b), en = (int)cell_at(b + 1);
+      int r = st;
+      for (int q = st; q < en; q++) {
+        const int j = order[q];
+        const unsigned long long uj = sort_key_u64(keys[j]);
+        r += ((uj > u) | ((uj == u) & (j < m))) ? 1 : 0;
+      }
+      rl[k] = r;
+    }
+  }
+  return true;
+}
+
 #ifndef WEIGHT_EVAL_GROUP
 #define WEIGHT_EVAL_GROUP 8  // evaluation points whose sums a wave keeps in registers per pass over the mixture
 #endif
@@ -417,6 +527,8 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
   constexpr int NS = 8;                                    // entries per thread held in registers
   if (N <= NS * NT) {
     int rl[NS];
+    if (!bucket_rank_sort<WPP, NS>(s.keys, N, tid, reinterpret_cast<unsigned *>(s.perm), B.cap, s.labR, rl, block_sync)) {
+    block_sync();
 #pragma unroll
     for (int k = 0; k < NS; k++) {
       const int m = tid + NT * k;                          // (m & 63) == lane: the wave's 64 entries are chunk m >> 6
@@ -440,6 +552,7 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
     }
     block_sync();
     DBG_TB(16, 9);
+    RFS_CUT(10);
 #pragma unroll
     for (int k = 0; k < NS; k++) {
       const int m = tid + NT * k;
@@ -473,7 +586,8 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
         rl[k] = rank;
       }
     }
-    block_sync();                                          // all searches done: the sorted chunks are dead, perm may be written
+    }
+    block_sync();                                          // all ranks known: the sort's scratch is dead, perm may be written
 #pragma unroll
     for (int k = 0; k < NS; k++) {
       const int m = tid + NT * k;
@@ -491,6 +605,7 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
     }
   }
   DBG_TB(16, 10);
+  RFS_CUT(11);
   block_sync();
   // sorted mixture -> other slab (or just the permutation, for the fused step's merge phase)
   if (permOut) {
@@ -509,6 +624,7 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
     plane(dl, B.cap, i, PL_SYY)[r] = v6;
   }
   DBG_TB(16, 8);
+  RFS_CUT(12);
 
   DBG_TB(16, 1);
   PoseReg pr;
@@ -569,6 +685,7 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
   const int nE = sScrI[0];
 
   DBG_TB(16, 2);
+  RFS_CUT(13);
   // ---- 3b / 4-6: two independent strands after the evaluation points are known ----
   //   intensity at the evaluation points (:776-800): groups of EG points in registers, a pass over the mixture per group;
   //   likelihood table (:847-863) -> partitions -> assignment sums (:865-990).
@@ -627,6 +744,9 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
       }
     }
   };
+#ifdef RFS_STOP_AT
+  if ((RFS_STOP_AT == 14 || RFS_STOP_AT == 15) && split && wave > 0) __builtin_amdgcn_endpgm();   // wave 0's strand alone
+#endif
   if (!split || wave > 0) intensity(0, mSplit, iw, nIw, sumB, sumA);
   if (!split) block_sync();
 
@@ -708,6 +828,7 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
     wave_sync();  // (sumA / sumB live in the component scratch that step 5 reuses)
   }
   DBG_TB(16, 4);
+  RFS_CUT(14);
 #ifdef RFS_PROFILE
   const long long dbgT4 = (long long)__builtin_readcyclecounter();
 #endif
@@ -719,6 +840,7 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
     l = rfs_partitions_wave(s, nE, nZ, P.clutter, lane, i, Q, B.err, P.exactPartitions);
 #endif
   }
+  RFS_CUT(15);
   if (split) {
     if (wave == 0 && w0Chunks > 0) intensity(mSplit, N, 0, 1, sumB0, sumA0);   // wave 0's share of the mixture
     block_sync();          // the intensity sums of the other waves are complete

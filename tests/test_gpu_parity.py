@@ -553,6 +553,34 @@ def test_tied_weights_rank_by_index(pkg, ob, sc, n_lm, cap):
     compare_maps(sc, dev, orc, scen["n"], ordered=True)
 
 
+@pytest.mark.parametrize("n_lm,cap,fused", [(30, 64, False), (70, 128, True), (120, 192, False), (200, 384, True), (200, 384, False), (420, 640, True)])
+def test_rank_sort_over_a_wide_range_of_weights(pkg, ob, sc, n_lm, cap, fused):
+    """The weighting phase ranks the mixture through a histogram over the upper words of the keys (weighting.h,
+    bucket_rank_sort): weights spread over 200 decades (the bucket width adapts), clusters closer than a bucket, a few exact
+    ties, and every bucket-count tier of the LDS budget (cap 64 ... 640).  Order and weights against the oracle."""
+    scen = sc.make_scenario(10, n_lm, 12, seed=n_lm + cap)
+    rng = np.random.default_rng(cap)
+    w = scen["w"]
+    k = n_lm // 4
+    w[:, :k] = 10.0 ** rng.uniform(-200, 0, (w.shape[0], k))                # 200 decades
+    w[:, k:2 * k] = 0.4 + 1e-13 * rng.integers(0, 50, (w.shape[0], k))       # inside one bucket, a few exact ties
+    w[:, 2 * k:2 * k + 5] = 0.25                                            # exact ties
+    dev = pkg.RBPHDFilter(scen["n"], gm_capacity=cap)
+    orc = ob.OracleFilter(scen["n"], stable_sort=True)
+    for f in (dev, orc):
+        sc.load_scenario(f, scen)
+    if fused:
+        dev.update_async(scen["Z"])
+        dev.synchronize()
+        orc.update(scen["Z"])
+    else:
+        for f in (dev, orc):
+            f.update_map(scen["Z"])
+            f.importance_weighting()
+    compare_weights(dev, orc)
+    compare_maps(sc, dev, orc, scen["n"], ordered=True)
+
+
 def _clustered_mixtures(sc, n_particles, n_gauss, kind, seed):
     """Mixtures built to hit every path of the device merge: dense clusters (chains of merges, rows that share partners,
     rows absorbed by earlier rows), coincident means, crowded neighbourhoods (more partners than a row can list),

@@ -76,3 +76,8 @@ seen = {}
 for k in order:
     key = int(cu_key[k]); rank_in_cu[k] = seen.get(key, 0); seen[key] = rank_in_cu[k] + 1
 print("  slow fraction by arrival order on the CU:", [round(float(slow[rank_in_cu == r].mean()), 2) for r in range(rank_in_cu.max() + 1)])
+end = a[:, 3] - t0
+cu_end = np.array([end[inv == k].max() for k in range(len(keys))])
+cu_sum = np.array([(a[inv == k, 3] - a[inv == k, 0]).sum() for k in range(len(keys))])
+print("  per (XCC, CU): last workgroup ends [us]:", q(cu_end), "; sum of its workgroups' durations [us]:", q(cu_sum))
+print("  corr(workgroups on the CU, CU end) %.3f; mean end by count: %s" % (np.corrcoef(cnt, cu_end)[0, 1], {int(c): round(float(cu_end[cnt == c].mean()), 1) for c in np.unique(cnt)}))
