@@ -23,6 +23,8 @@
 #define MERGE_GX 32  // grid cells along x
 #define MERGE_GY 32  // grid cells along y
 #define MERGE_CELLS (MERGE_GX * MERGE_GY)
+#define MERGE_LOG_CELLS 10  // log2(MERGE_CELLS): the fused prune's rank sort reuses the grid's cursor array as its histogram
+static_assert((1 << MERGE_LOG_CELLS) == MERGE_CELLS, "MERGE_LOG_CELLS");
 #define MERGE_PAIR_CAP(cap) ((cap) > 320 ? (cap) : 320)  // listed partners per particle: ~0.7 per entry on dense maps
 #define MERGE_ROW_SLOTS 8   // prefilter survivors one row can list; a row with more is replayed by the sequential scan
 __host__ __device__ inline size_t merge_lds_bytes_per_wave(int cap) {
@@ -699,25 +701,45 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
   }
   block_sync();
   nSurv = (int)*sPairCount;
-  for (int q = tid; q < nSurv; q += NT) {
-    const int m = sSorted[q];
+  auto put = [&](const int rank, const int m) {
     const int pm = phys(m);
-    const double wm = sW[m];
-    // the survivor's record first (independent loads in flight while the rank is counted)
     const double vx = pMX[pm], vy = pMY[pm], vxx = pSXX[pm], vxy = pSXY[pm], vyy = pSYY[pm];
-    int rank = 0;
-    for (int q2 = 0; q2 < nSurv; q2++) {
-      const int j2 = sSorted[q2];
-      const double wj = sW[j2];
-      rank += (wj > wm || (wj == wm && j2 < m)) ? 1 : 0;
-    }
-    plane(dl, cap, i, PL_W)[rank] = wm;
+    plane(dl, cap, i, PL_W)[rank] = sW[m];
     plane(dl, cap, i, PL_WP)[rank] = 0.0;
     plane(dl, cap, i, PL_MX)[rank] = vx;
     plane(dl, cap, i, PL_MY)[rank] = vy;
     plane(dl, cap, i, PL_SXX)[rank] = vxx;
     plane(dl, cap, i, PL_SXY)[rank] = vxy;
     plane(dl, cap, i, PL_SYY)[rank] = vyy;
+  };
+  // ranks among the survivors through the weighting phase's bucket sort (weighting.h): the grid's cursor array is the
+  // histogram (MERGE_CELLS buckets), the pair list holds the bucket order, ties rank by list position (= ascending index)
+  constexpr int NS = 8;
+  bool ranked = false;
+  if (nSurv <= NS * NT) {
+    int rl[NS];
+    ranked = bucket_rank_sort<WPP, NS>([&](int q) { return sW[sSorted[q]]; }, nSurv, tid, sCellStart, reinterpret_cast<unsigned short *>(sPairs),
+                                       MERGE_LOG_CELLS, reinterpret_cast<int *>(sRed), rl, block_sync);
+    if (ranked) {
+#pragma unroll
+      for (int k = 0; k < NS; k++) {
+        const int q = tid + NT * k;
+        if (q < nSurv) put(rl[k], sSorted[q]);
+      }
+    }
+  }
+  if (!ranked) {  // crowded buckets (many equal weights) or more survivors than the register slots cover: all pairs
+    for (int q = tid; q < nSurv; q += NT) {
+      const int m = sSorted[q];
+      const double wm = sW[m];
+      int rank = 0;
+      for (int q2 = 0; q2 < nSurv; q2++) {
+        const int j2 = sSorted[q2];
+        const double wj = sW[j2];
+        rank += (wj > wm || (wj == wm && j2 < m)) ? 1 : 0;
+      }
+      put(rank, m);
+    }
   }
   if (tid == 0) B.count[i] = nSurv;
   DBG_TB(32, 4);

@@ -364,33 +364,33 @@ __host__ __device__ inline int rank_sort_log_buckets(int cap) { return cap >= 34
 #ifndef RANK_SORT_MAX_BUCKET
 #define RANK_SORT_MAX_BUCKET 32
 #endif
-// keys [N] in LDS; hist: 8 * ((cap + 63) & ~63) bytes of LDS scratch; xscr: 12 ints of LDS scratch; ranks of entries tid + NT * k to rl[k].
-// All threads of the block call it; the caller synchronises before it reuses `hist`.
-template <int WPP, int NS, class Sync>
-__device__ __forceinline__ bool bucket_rank_sort(const double *keys, const int N, const int tid, unsigned *hist, const int cap, int *xscr, int (&rl)[NS],
-                                                 Sync block_sync) {
+// keyAt(m): key of entry m < N (LDS reads; ties rank by m); hist: (NB / 2 + 4) words of LDS scratch for NB = 1 << logNB buckets; order: [N]
+// u16 of LDS scratch; xscr: 2 WPP + 1 ints of LDS scratch; the ranks of entries tid + NT * k go to rl[k] (N <= NS * NT).
+// All threads of the block call it; the caller synchronises before it reuses the scratch.
+template <int WPP, int NS, class KeyAt, class Sync>
+__device__ __forceinline__ bool bucket_rank_sort(KeyAt keyAt, const int N, const int tid, unsigned *hist, unsigned short *order, const int logNB, int *xscr,
+                                                 int (&rl)[NS], Sync block_sync) {
   constexpr int NT = WPP * 64;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int logNB = rank_sort_log_buckets(cap), NB = 1 << logNB;
-  unsigned short *order = reinterpret_cast<unsigned short *>(hist + NB / 2 + 4);    // [N] entries in bucket order
+  const int NB = 1 << logNB;
   auto cell_at = [&](int e) -> unsigned { return (hist[e >> 1] >> (16 * (e & 1))) & 0xffffu; };
   unsigned hmin = 0xffffffffu, hmax = 0u;
 #pragma unroll
   for (int k = 0; k < NS; k++) {
     const int m = tid + NT * k;
     if (m < N) {
-      const unsigned h = (unsigned)(sort_key_u64(keys[m]) >> 32);
+      const unsigned h = (unsigned)(sort_key_u64(keyAt(m)) >> 32);
       hmin = min(hmin, h);
       hmax = max(hmax, h);
     }
   }
   hmin = wave_min_u32(hmin);
   hmax = wave_max_u32(hmax);
-  if (lane == 0) { xscr[wave] = (int)hmin; xscr[4 + wave] = (int)hmax; }
+  if (lane == 0) { xscr[wave] = (int)hmin; xscr[WPP + wave] = (int)hmax; }
   for (int c = tid; c <= NB / 2; c += NT) hist[c] = 0u;
   block_sync();
 #pragma unroll
-  for (int w2 = 0; w2 < WPP; w2++) { hmin = min(hmin, (unsigned)xscr[w2]); hmax = max(hmax, (unsigned)xscr[4 + w2]); }
+  for (int w2 = 0; w2 < WPP; w2++) { hmin = min(hmin, (unsigned)xscr[w2]); hmax = max(hmax, (unsigned)xscr[WPP + w2]); }
   const unsigned range = hmax - hmin;
   const int bits = range ? 32 - __builtin_clz(range) : 0;
   const int sh = bits > logNB ? bits - logNB : 0;                                  // (range >> sh) < NB
@@ -398,7 +398,7 @@ __device__ __forceinline__ bool bucket_rank_sort(const double *keys, const int N
   for (int k = 0; k < NS; k++) {
     const int m = tid + NT * k;
     if (m < N) {
-      const int e = (int)((hmax - (unsigned)(sort_key_u64(keys[m]) >> 32)) >> sh) + 1;  // largest keys first; counts shifted by one entry
+      const int e = (int)((hmax - (unsigned)(sort_key_u64(keyAt(m)) >> 32)) >> sh) + 1;  // largest keys first; counts shifted by one entry
       atomicAdd(&hist[e >> 1], 1u << (16 * (e & 1)));
     }
   }
@@ -423,15 +423,15 @@ __device__ __forceinline__ bool bucket_rank_sort(const double *keys, const int N
       hist[WPL * lane + k] = lo | (hi << 16);
     }
     if (lane == 63) hist[NB / 2] = (unsigned)off;
-    if (lane == 0) xscr[8] = (int)mx;
+    if (lane == 0) xscr[2 * WPP] = (int)mx;
   }
   block_sync();
-  if (xscr[8] > RANK_SORT_MAX_BUCKET) return false;
+  if (xscr[2 * WPP] > RANK_SORT_MAX_BUCKET) return false;
 #pragma unroll
   for (int k = 0; k < NS; k++) {
     const int m = tid + NT * k;
     if (m < N) {
-      const int e = (int)((hmax - (unsigned)(sort_key_u64(keys[m]) >> 32)) >> sh) + 1;
+      const int e = (int)((hmax - (unsigned)(sort_key_u64(keyAt(m)) >> 32)) >> sh) + 1;
       const unsigned pos = (atomicAdd(&hist[e >> 1], 1u << (16 * (e & 1))) >> (16 * (e & 1))) & 0xffffu;
       order[pos] = (unsigned short)m;
     }
@@ -442,13 +442,13 @@ __device__ __forceinline__ bool bucket_rank_sort(const double *keys, const int N
     const int m = tid + NT * k;
     rl[k] = 0;
     if (m < N) {
-      const unsigned long long u = sort_key_u64(keys[m]);
+      const unsigned long long u = sort_key_u64(keyAt(m));
       const int b = (int)((hmax - (unsigned)(u >> 32)) >> sh);
       const int st = (int)cell_at(b), en = (int)cell_at(b + 1);
       int r = st;
       for (int q = st; q < en; q++) {
         const int j = order[q];
-        const unsigned long long uj = sort_key_u64(keys[j]);
+        const unsigned long long uj = sort_key_u64(keyAt(j));
         r += ((uj > u) | ((uj == u) & (j < m))) ? 1 : 0;
       }
       rl[k] = r;
@@ -527,7 +527,10 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
   constexpr int NS = 8;                                    // entries per thread held in registers
   if (N <= NS * NT) {
     int rl[NS];
-    if (!bucket_rank_sort<WPP, NS>(s.keys, N, tid, reinterpret_cast<unsigned *>(s.perm), B.cap, s.labR, rl, block_sync)) {
+    const int logNB = rank_sort_log_buckets(B.cap);
+    unsigned *hist = reinterpret_cast<unsigned *>(s.perm);  // histogram + bucket-ordered list inside the 8 B per entry of perm + fkeys
+    if (!bucket_rank_sort<WPP, NS>([&](int m) { return s.keys[m]; }, N, tid, hist, reinterpret_cast<unsigned short *>(hist + (1 << logNB) / 2 + 4), logNB,
+                                   s.labR, rl, block_sync)) {
     block_sync();
 #pragma unroll
     for (int k = 0; k < NS; k++) {
