@@ -257,6 +257,12 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     if (cy > 0) { qs0 = cell_at((cy - 1) * MERGE_GX + cxa); n0 = cell_at((cy - 1) * MERGE_GX + cxb + 1) - qs0; }
     if (cy < MERGE_GY - 1) { qs2 = cell_at((cy + 1) * MERGE_GX + cxa); n2 = cell_at((cy + 1) * MERGE_GX + cxb + 1) - qs2; }
     const unsigned n01 = n0 + n1, tot = n01 + n2;       // (tot >= 1: the entry itself)
+#ifdef RFS_PROFILE
+    if (B.dbg && i == 7) {   // (this run's numbers: the host clears the words before the launch it reports)
+      atomicAdd((unsigned long long *)&B.dbg[58], (unsigned long long)tot);
+      { const int k6 = (wave * 3 + (sidx < 2 ? sidx : 2)) % 6; atomicMax((unsigned long long *)&B.dbg[k6 == 0 ? 57 : (k6 == 1 ? 59 : 58 + k6)], (unsigned long long)((tot + 3u) >> 2)); }
+    }
+#endif
     {
       for (unsigned q = 0; q < tot; q += 4) {
         unsigned jj[4];

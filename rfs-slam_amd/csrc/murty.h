@@ -386,6 +386,16 @@ __global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQ
   if (!isLast) return;
   __threadfence();
   if (threadIdx.x == 0) { Q.count[1] = 0; Q.count[0] = 0; }   // the queue is consumed: empty for the next step
+#ifdef RFS_PROFILE
+  if (threadIdx.x == 0) {
+    int hist[MURTY_N + 1];
+    for (int k = 0; k <= MURTY_N; k++) hist[k] = 0;
+    for (int q = 0; q < nJobs; q++) { const int n = Q.jobs[q].nR + Q.jobs[q].nC; hist[n > MURTY_N ? MURTY_N : n]++; }
+    printf("murty jobs %d; by extended dimension:", nJobs);
+    for (int k = 0; k <= MURTY_N; k++) if (hist[k]) printf(" %d:%d", k, hist[k]);
+    printf("\n");
+  }
+#endif
   if (threadIdx.x == 0 && hostSeen) *hostSeen = 1;            // (pinned host word: this filter does reach the Murty path -- see murty_launch)
   for (int i = threadIdx.x; i < N; i += blockDim.x) {
     int last = -1;

@@ -350,7 +350,7 @@ __device__ double rfs_partitions_wave(const WeightLDS &s, int nE, int nZ, double
 // ---- rank sort by buckets ---------------------------------------------------------------------------------------------------
 // rank(m) = #{ j : key_j > key_m  or (key_j == key_m and j < m) }  -- the order of sortByWeight with ties by index.
 // Counting that against all entries (or against sorted 64-entry chunks, the form below this one) was 15 % of the fused
-// step's vector instructions at 2000 x 200.  Here the keys' order-preserving u64 images are cut into NB buckets over the
+// step's vector instructions at 2000 x 200.  Here the keys' order-preserving u64 images are cut into NB equal buckets over the
 // range of their upper words (an LDS histogram, one wave-wide scan, a scatter -- the merge phase's grid build in one
 // dimension), and an entry is compared only with the members of its own bucket: rank = entries in the buckets ahead + the
 // members of its bucket that are ahead of it.  Exact for every input (the u64 image is a total order consistent with the
@@ -391,14 +391,15 @@ __device__ __forceinline__ bool bucket_rank_sort(KeyAt keyAt, const int N, const
   block_sync();
 #pragma unroll
   for (int w2 = 0; w2 < WPP; w2++) { hmin = min(hmin, (unsigned)xscr[w2]); hmax = max(hmax, (unsigned)xscr[WPP + w2]); }
-  const unsigned range = hmax - hmin;
-  const int bits = range ? 32 - __builtin_clz(range) : 0;
-  const int sh = bits > logNB ? bits - logNB : 0;                                  // (range >> sh) < NB
+  // bucket of an upper word h: (hmax - h) scaled onto [0, NB) in fp32 -- conversion, product with a positive constant and
+  // truncation are all monotone, which is all the ranks need; the clamp covers the rounding at the far end
+  const float bscale = (float)NB * (1.f - 1e-6f) * __builtin_amdgcn_rcpf((float)(hmax - hmin) + 1.f);
+  auto bucket_of = [&](unsigned h) -> int { return min((int)((float)(hmax - h) * bscale), NB - 1); };
 #pragma unroll
   for (int k = 0; k < NS; k++) {
     const int m = tid + NT * k;
     if (m < N) {
-      const int e = (int)((hmax - (unsigned)(sort_key_u64(keyAt(m)) >> 32)) >> sh) + 1;  // largest keys first; counts shifted by one entry
+      const int e = bucket_of((unsigned)(sort_key_u64(keyAt(m)) >> 32)) + 1;  // largest keys first; counts shifted by one entry
       atomicAdd(&hist[e >> 1], 1u << (16 * (e & 1)));
     }
   }
@@ -431,7 +432,7 @@ __device__ __forceinline__ bool bucket_rank_sort(KeyAt keyAt, const int N, const
   for (int k = 0; k < NS; k++) {
     const int m = tid + NT * k;
     if (m < N) {
-      const int e = (int)((hmax - (unsigned)(sort_key_u64(keyAt(m)) >> 32)) >> sh) + 1;
+      const int e = bucket_of((unsigned)(sort_key_u64(keyAt(m)) >> 32)) + 1;
       const unsigned pos = (atomicAdd(&hist[e >> 1], 1u << (16 * (e & 1))) >> (16 * (e & 1))) & 0xffffu;
       order[pos] = (unsigned short)m;
     }
@@ -443,7 +444,7 @@ __device__ __forceinline__ bool bucket_rank_sort(KeyAt keyAt, const int N, const
     rl[k] = 0;
     if (m < N) {
       const unsigned long long u = sort_key_u64(keyAt(m));
-      const int b = (int)((hmax - (unsigned)(u >> 32)) >> sh);
+      const int b = bucket_of((unsigned)(u >> 32));
       const int st = (int)cell_at(b), en = (int)cell_at(b + 1);
       int r = st;
       for (int q = st; q < en; q++) {

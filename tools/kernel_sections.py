@@ -53,6 +53,7 @@ print("weight partitions: masks+components %d, log table %d, component masks/zer
 print("merge phase2: rows %d, speculative %d, validate %d, tail %d" % (t[41]-t[34], t[42]-t[41], t[43]-t[42], t[35]-t[43]))
 print("merge fallbacks: unlistable %d, slack %d, >8 merges %d, claim conflicts %d of %d active rows" % (t[52], t[53], t[54], t[55], t[56]))
 print("merge: grid build %d, candidate scan %d; phase2 rows %d merges %d chunks %d N %d" % (t[40]-t[33], t[34]-t[40], t[48], t[49], t[50], t[51]))
+print("merge candidate scan (particle 7, 3 runs): neighbours examined per run %d; trips of four per chunk-wave iteration (max over the runs) %s" % (t[58] // 3, [int(t[k]) for k in (57, 59, 60, 61, 62, 63)]))
 print("kernel ns (events):", f.last_kernel_ns())
 
 import numpy as np
