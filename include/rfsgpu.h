@@ -34,7 +34,7 @@ extern "C" {
 /* Hard limits of the device path (the reference has none; all are refused LOUDLY -- an error status, never a silent
  * truncation -- and all are far above BASELINE.json's configurations): RFSGPU_MAX_Z measurements per update,
  * RFSGPU_MAX_EVAL evaluation points, Murty extended dimension nR + nC <= 64, gm_capacity <= 2048 Gaussians per particle,
- * RFSGPU_MAX_CANDIDATES birth / landmark candidates per particle. */
+ * RFSGPU_MAX_CANDIDATES birth candidates per particle on the RB-PHD path (64 landmark candidates on the FastSLAM path). */
 #define RFSGPU_MAX_Z 64
 /* Maximum evaluation points for the multi-feature particle weight. */
 #define RFSGPU_MAX_EVAL 64
@@ -59,7 +59,7 @@ enum rfsgpu_model {
 /* Maximum entries of the Victoria Park Pd table / beams of a laser scan / birth candidates per particle. */
 #define RFSGPU_VP_MAX_PD 16
 #define RFSGPU_VP_MAX_SCAN 720
-#define RFSGPU_MAX_CANDIDATES 64
+#define RFSGPU_MAX_CANDIDATES 256
 
 /* Mirrors RBPHDFilter::Config, include/RBPHDFilter.hpp:90-146 (same meaning, same defaults
  * :370-382 when filled by rfsgpu_default_filter_config). */
@@ -259,6 +259,26 @@ int rfsgpu_step_async(rfsgpu_filter *f, const double *z, int n_z, int normalize)
  * rfsgpu_weight_sums, rfsgpu_get_weights, ...). */
 int rfsgpu_set_step_inputs_async(rfsgpu_filter *f, const double *x, const double *cov, int cov_stride, const double *scan, int n_scan);
 int rfsgpu_predict_map_async(rfsgpu_filter *f, int add_birth);
+/* ParticleFilter::propagate (include/ParticleFilter.hpp:322-339) for the Victoria Park driver's process model, on the device:
+ * MotionModel_Ackerman2d::step (src/ProcessModel_Ackerman2D.cpp:47-78) applied to every particle's pose with its own noisy
+ * input u + N(0, diag(var)) (ProcessModel::sample's input-noise branch, include/ProcessModel.hpp:126-150).  u = {speed,
+ * steering angle}; var = their variances (NULL: no noise); geom = {h, l, dx, dy} (setAckermanParams).  The normal deviates come
+ * from Philox4x32-10 keyed by `seed` with counter (particle, call): the reference's single serial boost stream has no parallel
+ * form, the distribution is what is kept (csrc/motion.h).  Stream-ordered, no host wait.  OPTIONAL: a host that keeps the
+ * reference's own ParticleFilter::propagate sends poses with rfsgpu_set_poses / rfsgpu_set_step_inputs_async instead; the
+ * Victoria Park driver of this repository uses it because its host loop, not a kernel, was what bounded a run. */
+int rfsgpu_propagate_ackerman_async(rfsgpu_filter *f, const double *u, const double *var, double dt, const double *geom, unsigned long long seed,
+                                    unsigned long long call);
+/* ParticleFilter::propagate (include/ParticleFilter.hpp:322-339) for the Victoria Park driver's process model, on the device:
+ * MotionModel_Ackerman2d::step (src/ProcessModel_Ackerman2D.cpp:47-78) applied to every particle's pose with its own noisy
+ * input u + N(0, diag(var)) (ProcessModel::sample's input-noise branch, include/ProcessModel.hpp:126-150).  u = {speed,
+ * steering angle}; var = their variances (NULL: no noise); geom = {h, l, dx, dy} (setAckermanParams).  The normal deviates come
+ * from Philox4x32-10 keyed by `seed` with counter (particle, call): the reference's single serial boost stream has no parallel
+ * form, the distribution is what is kept (csrc/motion.h).  Stream-ordered, no host wait.  OPTIONAL: a host that keeps the
+ * reference's own ParticleFilter::propagate sends poses with rfsgpu_set_poses / rfsgpu_set_step_inputs_async instead; the
+ * Victoria Park driver of this repository uses it because its host loop, not a kernel, was what bounded a run. */
+int rfsgpu_propagate_ackerman_async(rfsgpu_filter *f, const double *u, const double *var, double dt, const double *geom, unsigned long long seed,
+                                    unsigned long long call);
 /* Average duration (ns) of each hot-path kernel group over the async steps harvested since the last call / reset:
  * [0]=phd_update_map [1]=phd_weight_multifeature [2]=gm_merge(+prune); *n_steps = steps averaged.  Steps that ran as one
  * fused kernel report its duration in [0] and 0 in [1], [2] (their TimingInfo share is booked under mapUpdate). */

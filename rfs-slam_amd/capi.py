@@ -16,7 +16,7 @@ ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_NO_DEVICE, ERR_UNSUPPORTED = 1, 2, 3, 4,
 MODEL_RNGBRG_2D = 0
 MODEL_VICTORIAPARK_3D = 1
 VP_MAX_PD = 16
-MAX_CANDIDATES = 64
+MAX_CANDIDATES = 256
 MAX_Z = 64
 MAX_EVAL = 64
 
@@ -116,7 +116,7 @@ ABI_SYMBOLS = [
     "default_fastslam_config", "set_fastslam_config", "get_fastslam_config", "fastslam_update",
     "normalize_weights_parts", "create_ex", "n_particles", "max_particles", "resample_apply_n",
     "fastslam_set_resample_occured", "particle_parents", "vp_probe_pd",
-    "slab_row_bytes", "export_slab_rows", "import_slab_rows", "weights_device_ptr", "step_async", "set_step_inputs_async", "predict_map_async", "set_partition_mode", "get_partition_mode",
+    "slab_row_bytes", "export_slab_rows", "import_slab_rows", "weights_device_ptr", "step_async", "set_step_inputs_async", "predict_map_async", "propagate_ackerman_async", "set_partition_mode", "get_partition_mode",
     "group_create", "group_destroy", "group_last_error", "group_n_shards", "group_n_particles", "group_shard", "group_locate",
     "group_set_filter_config", "group_set_model_rngbrg", "group_set_kf_config", "group_set_lmk_process_noise", "group_set_poses",
     "group_get_poses", "group_set_weights", "group_get_weights", "group_predict_map", "group_update", "group_normalize",
@@ -462,6 +462,13 @@ class CFilter:
 
     def predict_map_async(self, add_birth=True):
         self._call("predict_map_async", C.c_int(1 if add_birth else 0))
+
+    def propagate_ackerman_async(self, u, var, dt, geom, seed, call):
+        """ParticleFilter::propagate with MotionModel_Ackerman2d on the device (csrc/motion.h); var None: noise-free."""
+        up = (C.c_double * 2)(float(u[0]), float(u[1]))
+        vp = (C.c_double * 2)(float(var[0]), float(var[1])) if var is not None else None
+        gp = (C.c_double * 4)(*[float(g) for g in geom])
+        self._call("propagate_ackerman_async", up, vp, C.c_double(float(dt)), gp, C.c_ulonglong(int(seed)), C.c_ulonglong(int(call)))
 
     # -- cross-shard migration (packed rows in the backend's own memory space: device memory for the engine) ----------
     def slab_row_bytes(self):

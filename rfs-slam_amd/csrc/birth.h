@@ -6,8 +6,8 @@
 // effect of its `it++` on end(): with libstdc++'s circular list that wraps to begin(), so when the LAST candidate is erased
 // while others remain, the survivors are visited again.  Then StaticProcessModel::staticStep, Sigma += Q, on every
 // Gaussian (ProcessModel.hpp:195-208) -- births get Q added where they are created.
-// One wavefront per particle: candidate c sits on lane c, so the support distance of a measurement to all candidates is one
-// lane-parallel evaluation; the walk itself keeps the reference's order.  All lanes do the Sigma += Q sweep.  (The 2-D immediate-birth case keeps its lane-parallel kernel in merge_prune.h.)
+// One wavefront per particle: the candidate list is staged in LDS, the support distance of a measurement to the candidates is
+// evaluated 64 at a time across the lanes; the walk itself keeps the reference's order.  All lanes do the Sigma += Q sweep.  (The 2-D immediate-birth case keeps its lane-parallel kernel in merge_prune.h.)
 #pragma once
 #include "common.h"
 #include "vp.h"
@@ -147,8 +147,29 @@ __device__ void birth_write(const Buffers &B, const Params &P, int cur, int i, i
   birth_append<D>(B, P, cur, i, nn, k);
 }
 
+// LDS image of one particle's candidate list (struct of arrays, list order = index): 80 B per candidate.
+template <int D>
+struct CandLDS {
+  double x[3][RFSGPU_MAX_CANDIDATES];
+  double S[6][RFSGPU_MAX_CANDIDATES];
+  int sup[RFSGPU_MAX_CANDIDATES], chk[RFSGPU_MAX_CANDIDATES];
+  __device__ void get(int c, Cand<D> &k) const {
+#pragma unroll
+    for (int t = 0; t < 3; t++) k.x[t] = x[t][c];
+#pragma unroll
+    for (int t = 0; t < 6; t++) k.S[t] = S[t][c];
+  }
+  __device__ void put(int c, const Cand<D> &k) {
+#pragma unroll
+    for (int t = 0; t < 3; t++) x[t][c] = k.x[t];
+#pragma unroll
+    for (int t = 0; t < 6; t++) S[t][c] = k.S[t];
+  }
+};
+
 template <int D, int WPB>
 __global__ __launch_bounds__(WPB * 64) void predict_map_general_kernel(Buffers B, Params P, int cur, int addBirth, int nZprev) {
+  __shared__ CandLDS<D> sCand[WPB];
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
@@ -156,10 +177,13 @@ __global__ __launch_bounds__(WPB * 64) void predict_map_general_kernel(Buffers B
   const int cap = B.cap;
   const int nOld = B.count[i];
   if (addBirth) {
-    // Candidate c of the particle lives on lane c (RFSGPU_MAX_CANDIDATES == 64): loaded once, kept in registers, stored once.
-    // The reference's walk over the unused measurements and over the list stays serial where its order is observable
-    // (first matching candidate in list order, list order kept by erase, the ++end() wrap); what is per candidate --
-    // the support distance of a measurement to every candidate -- runs across the lanes.
+    // The particle's candidate list (<= RFSGPU_MAX_CANDIDATES) is staged in LDS in list order.  The reference's walk over
+    // the unused measurements and over the list stays serial where its order is observable (first matching candidate in
+    // list order, list order kept by erase, the ++end() wrap); what is per candidate -- the support distance of a
+    // measurement to every candidate -- runs across the lanes, 64 candidates at a time.  (Until r02 the list lived on the
+    // lanes, one candidate each, which capped it at 64: Victoria Park with artificial clutter and CheckCountThreshold 10
+    // keeps ~60 +- 20 candidates per particle, and about half of all seeds overflowed at 5000 particles.)
+    CandLDS<D> &L = sCand[wave];
     int n = nOld;
     int nc = B.candCount[i];
     const unsigned nfov = (unsigned)B.nInFov[i];
@@ -167,21 +191,46 @@ __global__ __launch_bounds__(WPB * 64) void predict_map_general_kernel(Buffers B
     load_pose(B, P, i, pr);
     bool fail = false, listFull = false;
     int *supG = B.candSup + (size_t)i * RFSGPU_MAX_CANDIDATES, *chkG = B.candChk + (size_t)i * RFSGPU_MAX_CANDIDATES;
-    Cand<D> k;
-    for (int t = 0; t < 3; t++) k.x[t] = 0.0;
-    for (int t = 0; t < 6; t++) k.S[t] = 0.0;
-    int sup = 0, chk = 0;
-    if (lane < nc) { cand_load<D>(B, i, lane, k); sup = supG[lane]; chk = chkG[lane]; }
+    for (int c = lane; c < nc; c += 64) {
+      Cand<D> k;
+      for (int t = 0; t < 3; t++) k.x[t] = 0.0;
+      for (int t = 0; t < 6; t++) k.S[t] = 0.0;
+      cand_load<D>(B, i, c, k);
+      L.put(c, k);
+      L.sup[c] = supG[c];
+      L.chk[c] = chkG[c];
+    }
+    wave_sync();
     unsigned long long um = (nZprev > 0) ? B.unusedMask[i] : 0ull;
     while (um) {  // back to front (:1013-1017)
       const int zi = 63 - __builtin_clzll(um);
       um &= ~(1ull << zi);
       const double *z = B.Z + (size_t)D * zi;
-      double d2 = 1.0e300;
-      if (lane < nc) d2 = cand_support_md2<D>(P, pr, k, z);
-      const unsigned long long hit = __ballot(lane < nc && d2 <= P.birthSupportD2);
-      if (hit != 0ull) {                                   // the first candidate in list order that supports it
-        if (lane == __builtin_ctzll(hit)) { cand_correct<D>(P, pr, k, z); sup++; }
+      int first = -1;                                       // the first candidate in list order that supports it
+      for (int c0 = 0; c0 < nc && first < 0; c0 += 64) {
+        const int c = c0 + lane;
+        double d2 = 1.0e300;
+        if (c < nc) {
+          Cand<D> k;
+          for (int t = 0; t < 3; t++) k.x[t] = 0.0;
+          for (int t = 0; t < 6; t++) k.S[t] = 0.0;
+          L.get(c, k);
+          d2 = cand_support_md2<D>(P, pr, k, z);
+        }
+        const unsigned long long hit = __ballot(c < nc && d2 <= P.birthSupportD2);
+        if (hit != 0ull) first = c0 + __builtin_ctzll(hit);
+      }
+      if (first >= 0) {
+        if (lane == 0) {
+          Cand<D> k;
+          for (int t = 0; t < 3; t++) k.x[t] = 0.0;
+          for (int t = 0; t < 6; t++) k.S[t] = 0.0;
+          L.get(first, k);
+          cand_correct<D>(P, pr, k, z);
+          L.put(first, k);
+          L.sup[first]++;
+        }
+        wave_sync();
       } else {
         Cand<D> kn;
         cand_inverse<D>(P, pr, z, kn);                     // (the same values on every lane)
@@ -189,8 +238,9 @@ __global__ __launch_bounds__(WPB * 64) void predict_map_general_kernel(Buffers B
           if (n < cap) { if (lane == 0) birth_write<D>(B, P, cur, i, n, kn); n++; }
           else fail = true;
         } else if (nc < RFSGPU_MAX_CANDIDATES) {
-          if (lane == nc) { k = kn; sup = 1; chk = 0; }
+          if (lane == 0) { L.put(nc, kn); L.sup[nc] = 1; L.chk[nc] = 0; }
           nc++;
+          wave_sync();
         } else {
           listFull = true;
         }
@@ -199,31 +249,53 @@ __global__ __launch_bounds__(WPB * 64) void predict_map_general_kernel(Buffers B
     // promotion / expiry (:1062-1080) with the ++end() wrap
     int kk = 0;
     while (kk < nc) {
-      if (lane == kk) chk++;
+      if (lane == 0) L.chk[kk]++;
+      wave_sync();
       bool atEnd = false;
       for (;;) {
-        const unsigned supk = (unsigned)__builtin_amdgcn_readlane(sup, kk), chkk = (unsigned)__builtin_amdgcn_readlane(chk, kk);
+        const unsigned supk = (unsigned)L.sup[kk], chkk = (unsigned)L.chk[kk];
         if (!(supk >= P.birthCountThr || chkk > P.birthCheckThr || nfov <= P.birthCurThr)) break;
         if (supk >= P.birthCountThr || nfov <= P.birthCurThr) {
-          if (n < cap) { if (lane == kk) birth_write<D>(B, P, cur, i, n, k); n++; }
-          else fail = true;
+          if (n < cap) {
+            if (lane == 0) {
+              Cand<D> k;
+              for (int t = 0; t < 3; t++) k.x[t] = 0.0;
+              for (int t = 0; t < 6; t++) k.S[t] = 0.0;
+              L.get(kk, k);
+              birth_write<D>(B, P, cur, i, n, k);
+            }
+            n++;
+          } else fail = true;
         }
-        {  // erase(it): the tail moves down one lane, list order kept
-          const int from = (lane >= kk && lane < 63) ? lane + 1 : lane;
-#pragma unroll
-          for (int t = 0; t < 3; t++) k.x[t] = __shfl(k.x[t], from, 64);
-#pragma unroll
-          for (int t = 0; t < 6; t++) k.S[t] = __shfl(k.S[t], from, 64);
-          sup = __shfl(sup, from, 64);
-          chk = __shfl(chk, from, 64);
+        // erase(it): the tail moves down one place, list order kept (64 entries at a time, ascending: every lane reads its
+        // source before any lane of the same step writes, and a step only writes places the earlier steps have read)
+        for (int c0 = kk; c0 < nc - 1; c0 += 64) {
+          const int c = c0 + lane;
+          const bool mv = c < nc - 1;
+          Cand<D> k;
+          for (int t = 0; t < 3; t++) k.x[t] = 0.0;
+          for (int t = 0; t < 6; t++) k.S[t] = 0.0;
+          int su = 0, ch = 0;
+          if (mv) { L.get(c + 1, k); su = L.sup[c + 1]; ch = L.chk[c + 1]; }
+          wave_sync();
+          if (mv) { L.put(c, k); L.sup[c] = su; L.chk[c] = ch; }
+          wave_sync();
         }
         nc--;
-        if (kk < nc) { if (lane == kk) chk++; }
+        if (kk < nc) { if (lane == 0) L.chk[kk]++; wave_sync(); }
         else { atEnd = true; break; }
       }
       kk = atEnd ? 0 : kk + 1;
     }
-    if (lane < nc) { cand_store<D>(B, i, lane, k); supG[lane] = sup; chkG[lane] = chk; }
+    for (int c = lane; c < nc; c += 64) {
+      Cand<D> k;
+      for (int t = 0; t < 3; t++) k.x[t] = 0.0;
+      for (int t = 0; t < 6; t++) k.S[t] = 0.0;
+      L.get(c, k);
+      cand_store<D>(B, i, c, k);
+      supG[c] = L.sup[c];
+      chkG[c] = L.chk[c];
+    }
     if (lane == 0) {
       B.unusedMask[i] = 0ull;
       B.candCount[i] = nc;

@@ -18,6 +18,7 @@
 //  fs_new_landmarks      unassociated measurements -> candidates / new landmarks and the promotion loop (:615-690), a short
 //                        serial walk on lane 0 (cf. birth.h).
 #pragma once
+#define FS_LANE_CANDIDATES 64   // landmark candidates per particle on the FastSLAM path (one per lane); the storage stride is RFSGPU_MAX_CANDIDATES
 #include "common.h"
 #include "murty.h"
 #include "birth.h"
@@ -487,6 +488,7 @@ __global__ __launch_bounds__(64 * FS_NEWLM_WPB) void fs_new_landmarks_kernel(Buf
   for (int t = 0; t < 3; t++) k.x[t] = 0.0;
   for (int t = 0; t < 6; t++) k.S[t] = 0.0;
   int sup = 0, chk = 0;
+  if (nc > FS_LANE_CANDIDATES) { listFull = true; nc = FS_LANE_CANDIDATES; }   // (a list imported longer than this path holds: refused loudly)
   if (lane < nc) { cand_load<D>(B, i, lane, k); sup = supG[lane]; chk = chkG[lane]; }
   const unsigned long long um = B.unusedMask[i];
   for (int zi = 0; zi < nZ; zi++) {  // measurements in index order (:615)
@@ -503,7 +505,7 @@ __global__ __launch_bounds__(64 * FS_NEWLM_WPB) void fs_new_landmarks_kernel(Buf
       if (F.countThr == 1u || nfov <= F.curThr) {
         if (n < cap) { if (lane == 0) { int nn = n; fs_append<D>(B, cur, i, nn, kn, F.newW); } n++; }
         else fail = true;
-      } else if (nc < RFSGPU_MAX_CANDIDATES) {
+      } else if (nc < FS_LANE_CANDIDATES) {   // (FastSLAM's landmark candidates still live one per lane)
         if (lane == nc) { k = kn; sup = 1; chk = 0; }
         nc++;
       } else {

@@ -869,22 +869,29 @@ __global__ __launch_bounds__(256) void resample_gather_kernel(Buffers B, int cur
 // the birth-candidate block.  The rows of all migrants of a step sit back to back, so that the transport (RCCL send/recv
 // between processes, hipMemcpyPeerAsync inside one process) moves device memory to device memory and the host only ever
 // sees slot indices.  What Particle::copy + RBPHDFilter.hpp:1005-1011 carry: pose, mixture, unused list, FOV count, candidates.
+// rowCand: candidates a row has room for -- RFSGPU_MAX_CANDIDATES for a filter whose configuration keeps candidate lists, 0
+// for one that does not (the 2-D simulator's CountThreshold == 1: 20 KB per migrant that would only ever carry zeros).
 #define RFSGPU_ROW_HEADER_DOUBLES 16
-__host__ __device__ inline size_t slab_row_bytes(int npl, int cap) {
-  return (size_t)RFSGPU_ROW_HEADER_DOUBLES * 8 + (size_t)npl * cap * 8 + (size_t)RFSGPU_MAX_CANDIDATES * (3 + 6) * 8 + (size_t)RFSGPU_MAX_CANDIDATES * 2 * 4;
+__host__ __device__ inline size_t slab_row_bytes(int npl, int cap, int rowCand) {
+  return (size_t)RFSGPU_ROW_HEADER_DOUBLES * 8 + (size_t)npl * cap * 8 + (size_t)rowCand * (3 + 6) * 8 + (size_t)rowCand * 2 * 4;
 }
 template <bool EXPORT>
-__global__ __launch_bounds__(256) void slab_rows_kernel(Buffers B, int cur, const int *slots, unsigned char *rows, int poseCovStride) {
+__global__ __launch_bounds__(256) void slab_rows_kernel(Buffers B, int cur, const int *slots, unsigned char *rows, int poseCovStride, int rowCand) {
   const int s = slots[blockIdx.x];
-  unsigned char *row = rows + (size_t)blockIdx.x * slab_row_bytes(B.npl, B.cap);
+  unsigned char *row = rows + (size_t)blockIdx.x * slab_row_bytes(B.npl, B.cap, rowCand);
   double *hdr = reinterpret_cast<double *>(row);
   double *pl = hdr + RFSGPU_ROW_HEADER_DOUBLES;
-  double *cm = pl + (size_t)B.npl * B.cap, *cc = cm + RFSGPU_MAX_CANDIDATES * 3;
-  int *cs = reinterpret_cast<int *>(cc + RFSGPU_MAX_CANDIDATES * 6), *ck = cs + RFSGPU_MAX_CANDIDATES;
+  double *cm = pl + (size_t)B.npl * B.cap, *cc = cm + (size_t)rowCand * 3;
+  int *cs = reinterpret_cast<int *>(cc + (size_t)rowCand * 6), *ck = cs + rowCand;
   double *slab = B.slab[cur] + (size_t)s * B.npl * (size_t)B.cap;
   const size_t cb = (size_t)s * RFSGPU_MAX_CANDIDATES;
   if (EXPORT) {
-    const int n = B.count[s], nc = B.candCount[s];
+    const int n = B.count[s];
+    int nc = B.candCount[s];
+    if (nc > rowCand) {   // a list the row has no room for (the configuration says there is none): refused loudly, never dropped silently
+      if (threadIdx.x == 0) atomicOr(B.err, ERRBIT_BIRTHLIST);
+      nc = rowCand;
+    }
     for (int p = 0; p < B.npl; p++)
       for (int m = threadIdx.x; m < n; m += blockDim.x) pl[(size_t)p * B.cap + m] = slab[(size_t)p * B.cap + m];
     for (int t = threadIdx.x; t < nc * 3; t += blockDim.x) cm[t] = B.candMean[cb * 3 + t];

@@ -21,6 +21,7 @@
 #include "birth.h"
 #include "fastslam.h"
 #include "fastslam_mh.h"
+#include "motion.h"
 
 namespace {
 
@@ -66,6 +67,7 @@ struct rfsgpu_filter {
   hipEvent_t evStage[4] = {};
   int stageNext = 0;
   bool predPending = false;  // rfsgpu_predict_map_async's event pair has not been accumulated yet
+  bool candUsed = false;     // candidate lists were imported or the FastSLAM path ran with landmark candidates: migration rows carry them
   bool poseCovZero = false;  // B.poseCov[0..9) holds zeros (the "no covariance" form), so a further cov == NULL push need not rewrite it
   MurtyQueue Q{};
   MurtyScratch MS{};
@@ -622,6 +624,7 @@ int rfsgpu_import_birth_candidates(rfsgpu_filter *f, int slot, int n, const doub
   CHECK_HANDLE(f);
   if (slot < 0 || slot >= f->N || n < 0 || n > RFSGPU_MAX_CANDIDATES) return fail(f, RFSGPU_ERR_INVALID, "import_birth_candidates: bad arguments");
   hipSetDevice(f->device);
+  if (n > 0) f->candUsed = true;
   const int D = f->D;
   static const int idx3[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
   std::vector<double> m((size_t)RFSGPU_MAX_CANDIDATES * 3, 0.0), c((size_t)RFSGPU_MAX_CANDIDATES * 6, 0.0);
@@ -997,9 +1000,9 @@ int rfsgpu_predict_map(rfsgpu_filter *f, int add_birth) {
   hipSetDevice(f->device);
   HIPCHK(hipEventRecord(f->ev[EV_P0], f->stream));
   if (f->D == 3)
-    predict_map_general_kernel<3, 4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
+    predict_map_general_kernel<3, 2><<<(f->N + 1) / 2, 128, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
   else if (f->cfg.birthGaussianMeasurementCountThreshold != 1u)
-    predict_map_general_kernel<2, 4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
+    predict_map_general_kernel<2, 2><<<(f->N + 1) / 2, 128, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
   else  // CountThreshold == 1: every unused measurement is born at once, no candidate can exist -> lane-parallel kernel
     predict_map_kernel<4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
   HIPCHK(hipGetLastError());
@@ -1022,14 +1025,33 @@ int rfsgpu_predict_map_async(rfsgpu_filter *f, int add_birth) {
   const bool rec = !f->predPending;
   if (rec) HIPCHK(hipEventRecord(f->ev[EV_P0], f->stream));
   if (f->D == 3)
-    predict_map_general_kernel<3, 4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
+    predict_map_general_kernel<3, 2><<<(f->N + 1) / 2, 128, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
   else if (f->cfg.birthGaussianMeasurementCountThreshold != 1u)
-    predict_map_general_kernel<2, 4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
+    predict_map_general_kernel<2, 2><<<(f->N + 1) / 2, 128, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
   else
     predict_map_kernel<4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
   HIPCHK(hipGetLastError());
   if (rec) { HIPCHK(hipEventRecord(f->ev[EV_P1], f->stream)); f->predPending = true; }
   f->timing.predict_cpu += now_ns() - t0;
+  return RFSGPU_OK;
+}
+
+// ParticleFilter::propagate for the Ackerman model on the device (motion.h): stream-ordered, no host wait.  u = {speed,
+// steering}, var = their noise variances (null or zeros: noise-free), geom = {h, l, dx, dy}; (seed, call) key the generator.
+int rfsgpu_propagate_ackerman_async(rfsgpu_filter *f, const double *u, const double *var, double dt, const double *geom, unsigned long long seed,
+                                    unsigned long long call) {
+  CHECK_HANDLE(f);
+  if (!u || !geom || !(dt == dt)) return fail(f, RFSGPU_ERR_INVALID, "propagate_ackerman: bad arguments");
+  if (var && (var[0] < 0 || var[1] < 0)) return fail(f, RFSGPU_ERR_INVALID, "propagate_ackerman: negative variance");
+  hipSetDevice(f->device);
+  AckermanStep A;
+  A.uv = u[0]; A.ur = u[1];
+  A.sv = var ? std::sqrt(var[0]) : 0.0; A.sr = var ? std::sqrt(var[1]) : 0.0;
+  A.dt = dt;
+  A.h = geom[0]; A.l = geom[1]; A.dx = geom[2]; A.dy = geom[3];
+  A.seed = seed; A.call = call;
+  propagate_ackerman_kernel<<<(f->N + 255) / 256, 256, 0, f->stream>>>(f->B.pose, f->N, A);
+  HIPCHK(hipGetLastError());
   return RFSGPU_OK;
 }
 
@@ -1175,7 +1197,11 @@ int rfsgpu_resample_apply_n(rfsgpu_filter *f, const int *src_slot, int n_out) {
 }
 
 // ---- cross-shard migration (multi-GPU resampling): packed rows in DEVICE buffers, stream-ordered, no host sync -----------
-size_t rfsgpu_slab_row_bytes(const rfsgpu_filter *f) { return f ? slab_row_bytes(f->B.npl, f->cap) : 0; }
+// candidates a migration row carries: the whole list for a filter that keeps one, nothing for a configuration that never does
+static int row_cand(const rfsgpu_filter *f) {
+  return (f->model == RFSGPU_MODEL_VICTORIAPARK_3D || f->cfg.birthGaussianMeasurementCountThreshold != 1u || f->candUsed) ? RFSGPU_MAX_CANDIDATES : 0;
+}
+size_t rfsgpu_slab_row_bytes(const rfsgpu_filter *f) { return f ? slab_row_bytes(f->B.npl, f->cap, row_cand(f)) : 0; }
 static int slab_rows(rfsgpu_filter *f, const int *slots, int n, void *dev_rows, bool exporting) {
   if (n == 0) return RFSGPU_OK;
   if (!slots || !dev_rows || n < 0) return fail(f, RFSGPU_ERR_INVALID, "slab rows: bad arguments");
@@ -1192,8 +1218,8 @@ static int slab_rows(rfsgpu_filter *f, const int *slots, int n, void *dev_rows, 
     f->rowSlotsCap = want;
   }
   HIPCHK(hipMemcpyAsync(f->dRowSlots, slots, (size_t)n * sizeof(int), hipMemcpyHostToDevice, f->stream));
-  if (exporting) slab_rows_kernel<true><<<n, 256, 0, f->stream>>>(f->B, f->cur, f->dRowSlots, (unsigned char *)dev_rows, f->P.poseCovStride);
-  else slab_rows_kernel<false><<<n, 256, 0, f->stream>>>(f->B, f->cur, f->dRowSlots, (unsigned char *)dev_rows, f->P.poseCovStride);
+  if (exporting) slab_rows_kernel<true><<<n, 256, 0, f->stream>>>(f->B, f->cur, f->dRowSlots, (unsigned char *)dev_rows, f->P.poseCovStride, row_cand(f));
+  else slab_rows_kernel<false><<<n, 256, 0, f->stream>>>(f->B, f->cur, f->dRowSlots, (unsigned char *)dev_rows, f->P.poseCovStride, row_cand(f));
   HIPCHK(hipGetLastError());
   return RFSGPU_OK;
 }
@@ -1363,6 +1389,7 @@ static FsParams fs_params(const rfsgpu_filter *f, int n_z) {
   F.newW = log(F.prior / (1 - F.prior));
   F.supportD2 = f->fs.landmarkCandidateMeasurementSupportDist * f->fs.landmarkCandidateMeasurementSupportDist;
   F.countThr = f->fs.landmarkCandidateMeasurementCountThreshold;
+  if (F.countThr != 1u) const_cast<rfsgpu_filter *>(f)->candUsed = true;   // (migration rows carry the lists from now on)
   F.curThr = f->fs.landmarkCandidateCurrentMeasurementCountThreshold;
   F.checkThr = f->fs.landmarkCandidateMeasurementCheckThreshold;
   return F;

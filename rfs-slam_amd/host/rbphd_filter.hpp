@@ -153,7 +153,10 @@ class RBPHDFilter2d {
     effNParticles_t_percent_ = t / n_;
   }
   double getEffectiveParticleCountThreshold() const { return effNParticles_t_; }
-  const Pose2d &getParticlePose(int i) const { return poses_[i]; }
+  const Pose2d &getParticlePose(int i) const {
+    pullPoses();
+    return poses_[i];
+  }
   double getParticleWeight(int i) {
     pullWeights();
     return weights_[i];
@@ -162,6 +165,7 @@ class RBPHDFilter2d {
 
   // RBPHDFilter::setParticlePose (:1181-1186)
   void setParticlePose(int i, const Pose2d &p) {
+    pullPoses();
     poses_[i] = p;
     posesDirty_ = true;
     xbufFresh_ = false;
@@ -226,7 +230,17 @@ class RBPHDFilter2d {
   LmkProcessModel lmk_;
   MeasurementModel meas_;
   KalmanFilter kf_;
-  std::vector<Pose2d> poses_;
+  mutable std::vector<Pose2d> poses_;
+  // device-side propagation (RBPHDFilterVP::setDeviceMotion): the device owns the poses, the host copy is fetched on demand
+  bool devicePoses_ = false;
+  mutable bool hostPosesStale_ = false;
+  void pullPoses() const {
+    if (!hostPosesStale_) return;
+    std::vector<double> x(3 * (size_t)n_);
+    if (rfsgpu_get_poses(h_, x.data()) != RFSGPU_OK) throw std::runtime_error(std::string("get_poses: ") + rfsgpu_last_error(h_));
+    for (int i = 0; i < n_; i++) std::memcpy(poses_[i].x, &x[3 * i], 3 * sizeof(double));
+    hostPosesStale_ = false;
+  }
   std::vector<double> weights_;
   std::mt19937 rng_;
   double effNParticles_t_, effNParticles_t_percent_;
@@ -352,8 +366,12 @@ class RBPHDFilter2d {
     n_ = n;
     poses_.resize(n);
     weights_.assign(n, 1.0);
-    posesDirty_ = true;
-    xbufFresh_ = false;
+    if (devicePoses_ && hostPosesStale_) {   // the device gathered its own (current) poses with the maps; the host copy stays stale
+      posesDirty_ = false;
+    } else {
+      posesDirty_ = true;
+      xbufFresh_ = false;
+    }
     weightsStale_ = false;
     return true;
   }
@@ -466,6 +484,7 @@ struct AckermanInput {      // MotionModel_Ackerman2d::TInput: speed, steering a
 class MotionModel_Ackerman2d {
  public:
   void setAckermanParams(double h, double l, double dx, double dy) { h_ = h; l_ = l; dx_ = dx; dy_ = dy; }
+  void getAckermanParams(double g[4]) const { g[0] = h_; g[1] = l_; g[2] = dx_; g[3] = dy_; }
   void step(Pose2d &s_k, const Pose2d &s_km, double u_v, double u_r, double dt) const {
     const double r = s_km.x[2];
     const double c = std::cos(r), s = std::sin(r), t = std::tan(u_r);
@@ -509,6 +528,9 @@ class RBPHDFilterVP : public RBPHDFilter2d {
   explicit RBPHDFilterVP(int n, int device_id = 0, int gm_capacity = 192) : RBPHDFilter2d(n, device_id, gm_capacity, 0, RFSGPU_MODEL_VICTORIAPARK_3D) {}
 
   MotionModel_Ackerman2d *getProcessModel() { return &ackerman_; }
+  // ParticleFilter::propagate on the device (rfsgpu_propagate_ackerman_async, csrc/motion.h): poses stay there, the host fetches
+  // them when asked (getParticlePose).  Off by default: the host loop below is the reference's shape.
+  void setDeviceMotion(bool on, unsigned long long seed = 0) { pullPoses(); devicePoses_ = on; motionSeed_ = seed; }
   LmkProcessModel3d *getLmkProcessModel() { return &lmk3_; }
   MeasurementModelVP *getMeasurementModel() { return &measVP_; }
 
@@ -520,13 +542,26 @@ class RBPHDFilterVP : public RBPHDFilter2d {
     auto t0 = now();
     pushConfigVP();
     auto t1 = now();
-    pushInputsAsync();
+    // The device reads the poses in two places only: the map update, and the births of the first predict after an update --
+    // and those are born at the poses the update just used, which are on the device already (update() pushed them, a
+    // resampling gathered them there).  So the poses of a run of odometry messages are NOT sent message by message: only
+    // when something other than propagation changed them (setParticlePose, resampling on the host side), or by update().
+    if (posesDirty_ && !xbufFresh_) pushInputsAsync();
     auto t2 = now();
     check(rfsgpu_predict_map_async(h_, birthGaussianCheck ? 1 : 0), "predict_map");   // stream-ordered: no host wait
     auto t3 = now();
     tCfg_ += std::chrono::duration<double>(t1 - t0).count(); tIn_ += std::chrono::duration<double>(t2 - t1).count();
     tPm_ += std::chrono::duration<double>(t3 - t2).count();
     struct Acc { double &a; std::chrono::steady_clock::time_point t; ~Acc() { a += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); } } acc{tProp_, t3};
+    if (devicePoses_) {
+      if (posesDirty_) pushInputsAsync();   // (poses set on the host since the last device step)
+      const double zeroVar[2] = {0, 0};
+      double geom[4];
+      ackerman_.getAckermanParams(geom);
+      check(rfsgpu_propagate_ackerman_async(h_, u.u, useInputNoise ? u.var : zeroVar, dT, geom, motionSeed_, motionCall_++), "propagate_ackerman");
+      hostPosesStale_ = true;
+      return;
+    }
     // ParticleFilter::propagate (include/ParticleFilter.hpp:322-339) is a serial loop over one random stream in the reference;
     // at 5000 particles that host loop (two normal draws + the Ackerman step per particle) costs more than the device work of
     // a lidar message.  Here the particles are taken in fixed chunks of 256, each with its own generator seeded from ONE draw of
@@ -613,6 +648,7 @@ class RBPHDFilterVP : public RBPHDFilter2d {
 
  private:
   MotionModel_Ackerman2d ackerman_;
+  unsigned long long motionSeed_ = 0, motionCall_ = 0;
   LmkProcessModel3d lmk3_;
   MeasurementModelVP measVP_;
 

@@ -7,7 +7,7 @@
 // landmarkEst.dat).  LASER.txt is missing from the reference tree (.MISSING_LARGE_BLOBS), so unless a lidar file is found
 // the raw scan is the synthetic one SURVEY 8d prescribes: 361 beams at rangeLimitMax.
 //
-//   rbphdslam_vp -c cfg.xml [-d dataDir] [-n nParticles] [-m nMessages] [-e effNParticle] [-s seed] [-o outDir] [--device k]
+//   rbphdslam_vp -c cfg.xml [-d dataDir] [-n nParticles] [-m nMessages] [-e effNParticle] [-s seed] [-o outDir] [--device k] [--host-motion] [--repeat K]
 //                [--no-input-noise] [--no-clutter]
 #include <chrono>
 #include <cmath>
@@ -48,7 +48,8 @@ int main(int argc, char **argv) {
   std::string cfgFile, dataDir, outDir;
   int nParticlesOverride = -1, nMsgOverride = -1, seed = 1, device = 0;
   double effNOverride = -1;
-  bool inputNoise = true, clutter = true;
+  bool inputNoise = true, clutter = true, deviceMotion = true;
+  int repeat = 1;
   for (int a = 1; a < argc; a++) {
     std::string s = argv[a];
     auto next = [&]() { return (a + 1 < argc) ? std::string(argv[++a]) : std::string(); };
@@ -62,6 +63,8 @@ int main(int argc, char **argv) {
     else if (s == "--device") device = std::atoi(next().c_str());
     else if (s == "--no-input-noise") inputNoise = false;
     else if (s == "--no-clutter") clutter = false;
+    else if (s == "--repeat") repeat = std::max(1, std::atoi(next().c_str()));   // the whole run K times in this process (fresh filter each): the first pass carries the GPU's clock ramp
+    else if (s == "--host-motion") deviceMotion = false;   // ParticleFilter::propagate on the host (the reference's shape) instead of the device kernel
   }
   Cfg c;
   if (!cfgFile.empty()) c = read_xml_cfg(cfgFile);
@@ -99,10 +102,13 @@ int main(int argc, char **argv) {
   if (nMsg <= 0 || nMsg > (int)msgs.size()) nMsg = (int)msgs.size();
   const std::vector<double> syntheticScan(361, rMax);   // LASER.txt is missing from the reference tree
 
+  for (int pass = 0; pass < repeat; pass++) {
+  if (repeat > 1) { std::printf("---- pass %d of %d ----\n", pass + 1, repeat); if (pass > 0) outDir.clear(); }
   // ---------------- filter set-up (:344-398) ----------------
   RBPHDFilterVP filter(nParticles, device, 192);
   filter.getProcessModel()->setAckermanParams(c.d("config.process.AckermanModel.rearWheelOffset", 0.76), c.d("config.process.AckermanModel.frontToRearDist", 2.83),
                                               c.d("config.process.AckermanModel.sensorOffset_x", 3.78), c.d("config.process.AckermanModel.sensorOffset_y", 0.50));
+  filter.setDeviceMotion(deviceMotion, 0x9E3779B97F4A7C15ull * (unsigned long long)(seed + 1));
   double R[9] = {0};
   for (int k = 0; k < 3; k++) R[4 * k] = varz[k] * zNoiseInfl;
   filter.getMeasurementModel()->setNoise(R, varza);
@@ -237,8 +243,8 @@ int main(int argc, char **argv) {
   int strong = 0;
   for (int g = 0; g < nMap; g++) { double mu[3], S[9], w; filter.getLandmark(best, g, mu, S, w); strong += (w >= 0.5) ? 1 : 0; }
   const Pose2d &bp = filter.getParticlePose(best);
-  std::printf("particles %d  messages %d  lidar updates %d  resamplings %d  wall %.3f s  (inside predict() %.3f s, inside update() %.3f s)\n", nParticles, nMsg, nLidar,
-              nResample, wall, tPredict, tUpdate);
+  std::printf("particles %d  messages %d  lidar updates %d  resamplings %d  wall %.3f s  (inside predict() %.3f s, inside update() %.3f s)  propagation on the %s\n", nParticles, nMsg, nLidar,
+              nResample, wall, tPredict, tUpdate, deviceMotion ? "device" : "host");
   std::printf("predict() host sections [s]: config %.4f  inputs %.4f  predict_map launch %.4f  propagate %.4f\n", filter.tCfg_, filter.tIn_, filter.tPm_, filter.tProp_);
   RBPHDFilter2d::TimingInfo *ti = filter.getTimingInfo();
   std::printf("Elapsed Timing Information [nsec]\n");  // format of the reference drivers' timing printout
@@ -251,5 +257,6 @@ int main(int argc, char **argv) {
   std::printf("%-22s%15lld%15lld\n", "Resampling", ti->particleResample_wall, ti->particleResample_cpu);
   std::printf("RESULT lidar=%d resamples=%d best=%d map=%d strong=%d pose=%.6f,%.6f,%.6f ms_per_update=%.4f\n", nLidar, nResample, best, nMap, strong, bp.x[0], bp.x[1],
               bp.x[2], nLidar ? wall * 1e3 / nLidar : 0.0);
+  }
   return 0;
 }

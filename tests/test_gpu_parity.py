@@ -1048,6 +1048,47 @@ def test_2d_birth_candidate_list_mode(pkg, ob, sc):
     assert seen > 0
 
 
+def test_2d_birth_candidate_lists_longer_than_a_wavefront(pkg, ob, sc):
+    """Candidate lists of 100-200 entries (clutter that is never seen twice, CheckThreshold 8): the list is staged in LDS and
+    walked 64 candidates at a time (birth.h); support matches in the second / third chunk, promotions, expiry with the erase
+    moving a tail longer than a wavefront, the ++end() wrap.  Lists, supports, checks and maps against the oracle."""
+    scen = sc.make_scenario(6, 5, 6, seed=46)
+    dev, orc = make_pair(pkg, ob, sc, scen, cap=256)
+    for f in (dev, orc):
+        cfg = f.get_filter_config()
+        cfg.birthGaussianMeasurementCountThreshold = 3
+        cfg.birthGaussianMeasurementCheckThreshold = 8
+        cfg.birthGaussianMeasurementSupportDist = 1.0
+        cfg.birthGaussianCurrentMeasurementCountThreshold = 0
+        f.set_filter_config(cfg)
+    rng = np.random.default_rng(9)
+    longest, shrank, promoted = 0, False, 0
+    prev = None
+    persistent = np.column_stack([rng.uniform(1.0, 4.5, 4), rng.uniform(-3, 3, 4)])     # seen in every scan: promoted after three
+    for step in range(14):
+        clutter = np.column_stack([rng.uniform(0.5, 4.8, 18), rng.uniform(-3.1, 3.1, 18)])
+        Z = np.vstack([scen["Z"][:3] + rng.normal(0, 1e-3, (3, 2)), persistent + rng.normal(0, 1e-3, persistent.shape), clutter if step < 11 else clutter[:2]])
+        for f in (dev, orc):
+            f.predict_map(True)
+            f.update(Z)
+            s = f.weight_sums()
+            f.normalize_weights(s[0])
+        compare_maps(sc, dev, orc, scen["n"])
+        lens = []
+        for i in range(scen["n"]):
+            md, cd, sd, kd = dev.export_birth_candidates(i)
+            mo, co, so, ko = orc.export_birth_candidates(i)
+            assert list(sd) == list(so) and list(kd) == list(ko), (step, i)
+            np.testing.assert_allclose(md, mo, rtol=1e-9, atol=1e-11)
+            np.testing.assert_allclose(cd, co, rtol=1e-8, atol=1e-12)
+            lens.append(len(so))
+        longest = max(longest, max(lens))
+        if prev is not None and max(lens) < prev:
+            shrank = True
+        prev = max(lens)
+    assert longest > 130 and shrank, (longest, shrank)
+
+
 def test_victoria_park_dataset_extract_device_vs_oracle(pkg, ob, sc):
     """Config 4 in miniature: the first sensor messages of the Victoria Park dataset (tests/golden/victoria_park_extract.npz,
     extracted from the reference's data files) through the event-driven host loop -- predict with birth candidates, artificial
