@@ -390,14 +390,6 @@ def main():
         solo = args.steps / float(st.item())
         f.synchronize(); f.kernel_time_stats()
 
-    # one global resampling step with cross-shard migration (N > 1), timed on its own
-    migr = None
-    if world > 1 and wl["reseed"]:
-        try:
-            migr = pkg.sharded.bench_resample_migration(pkg, f, rank, world, dev, stream=stream, sums=sums, reps=3)
-        except Exception as e:   # noqa: BLE001 -- a side figure must never cost the headline line
-            migr = dict(error=repr(e)[:300])
-
     # per-phase breakdown (and the likelihood-sweep rate the north star asks for): the three stand-alone kernels, HIP events,
     # untimed pass after the region
     phase_ms = kern_ms
@@ -489,11 +481,40 @@ def main():
         if solo is not None:
             out["config"]["same_workload_single_shard_steps_per_s"] = round(solo, 3)
             out["config"]["weak_scaling_efficiency_vs_own_shard_alone"] = round((world * args.steps / dt) / (world * solo), 4)
-        if migr is not None:
-            out["config"]["resample_migration"] = migr
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # (rank 0 at N = 1 only)
             out["cpu_baseline"] = cpu_baseline(wname, n_local, args.particles)
-        print(json.dumps(out), flush=True)
+    else:
+        out = None
+
+    def finish(migr):
+        if rank == 0:
+            if migr is not None:
+                out["config"]["resample_migration"] = migr
+            print(json.dumps(out), flush=True)
+
+    # One global resampling step with cross-shard migration (N > 1), timed on its own -- LAST, and under a watchdog: it is a side
+    # figure, and neither an exception in it nor a collective that never completes may cost the line above.
+    migr = None
+    if world > 1 and wl["reseed"]:
+        import threading
+        dist.barrier()
+        finished = threading.Event()
+
+        def bail():
+            if finished.is_set():
+                return
+            finish(dict(error="no result within 120 s (a collective of this side measurement did not complete); the numbers of the timed region are unaffected"))
+            os._exit(0)
+        timer = threading.Timer(120.0, bail)
+        timer.daemon = True
+        timer.start()
+        try:
+            migr = pkg.sharded.bench_resample_migration(pkg, f, rank, world, dev, stream=stream, sums=sums, reps=3)
+        except Exception as e:   # noqa: BLE001
+            migr = dict(error=repr(e)[:300])
+        finished.set()
+        timer.cancel()
+    finish(migr)
     if world > 1:
         dist.destroy_process_group()
 
