@@ -361,6 +361,10 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
 
   DBG_TB(32, 2);
   RFS_CUT(23);
+#ifndef MERGE_P2_PRIO
+#define MERGE_P2_PRIO 0
+#endif
+  __builtin_amdgcn_s_setprio(MERGE_P2_PRIO);   // (step_fused.h: the last level of the fused step's falling issue priority; a no-op elsewhere)
 #ifdef RFS_PROFILE
   dbgT2 = (long long)__builtin_readcyclecounter();
   dbgPairs = *sPairCount;
@@ -686,6 +690,9 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
 
   DBG_TB(32, 3);
   RFS_CUT(24);
+#ifdef MERGE_PRUNE_PRIO
+  __builtin_amdgcn_s_setprio(MERGE_PRUNE_PRIO);
+#endif
   // ---- fused prune: keep w >= t (not absorbed), order (weight desc, index asc), compact into the other slab ----
   for (int m = tid, sidx = 0; m < N; m += NT, sidx++)
     if ((hole >> sidx) & 1u) sW[m] = -1.0;

@@ -49,7 +49,9 @@ void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, in
   // long as those stragglers.  With a workgroup that is a phase behind outranking the ones ahead, the eight workgroups of
   // a CU finish together.  Only when the whole grid is resident at once (PHASE_PRIO, picked by the host): with several
   // rounds of workgroups per CU, newcomers outranking workgroups that are about to free their slots costs more than it gives
-  // (measured: +2.3 % at 2000 x 200, -5 % at 2500 x 500).  Levels: map update 2 (3 for a SIMD's last arrivals), weighting 1, merge 0; the first is set inside phd_update_map_block.
+  // (measured: +2.3 % at 2000 x 200, -5 % at 2500 x 500).  Levels: map update 2 (3 for a SIMD's last arrivals; set inside
+  // phd_update_map_block), weighting 2, the parallel half of the merge (stage, grid, candidate scan, pair tests) 1, its replay and
+  // the prune 0 (set inside gm_merge_particle) -- r02: one more level inside the merge bought another 1 % (126.7 -> 125.3 us).
   // The measurement set arrives in the kernel-argument block (no staging launch); the step's post kernel leaves it in the
   // device buffer that later kernels read (the next predict's births).  (Writing it from here cost 112 B/lane of scratch.)
   stage_measurements_lds(smem_raw, [&](int t) { return zarg.v[t]; }, nZ, tid, WPP * 64);
@@ -74,7 +76,13 @@ void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, in
   // phases (tid * 8, ...) is hoisted to the top of the kernel and held -- or spilled -- across all of them.
   int tidW = threadIdx.x;
   asm volatile("" : "+v"(tidW));
-  if (PHASE_PRIO) __builtin_amdgcn_s_setprio(1);
+#ifndef STEP_W_PRIO
+#define STEP_W_PRIO 2
+#endif
+#ifndef STEP_MERGE_PRIO
+#define STEP_MERGE_PRIO 1
+#endif
+  if (PHASE_PRIO) __builtin_amdgcn_s_setprio(STEP_W_PRIO);
   // The weighting phase sorts the mixture by weight (sortByWeight, include/RBPHDFilter.hpp:733) -- as a permutation kept in
   // LDS; the merge phase walks the slab through it, so the sorted mixture is never written out and read back.
   unsigned short *sPerm = reinterpret_cast<unsigned short *>(smem_raw + step_fused_lds_bytes(B.cap, evalCap, nZ, WPP));
@@ -88,7 +96,7 @@ void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, in
   RFS_CUT(16);
   int tidM = threadIdx.x;
   asm volatile("" : "+v"(tidM));
-  if (PHASE_PRIO) __builtin_amdgcn_s_setprio(0);
+  if (PHASE_PRIO) __builtin_amdgcn_s_setprio(STEP_MERGE_PRIO);
 #ifdef RFS_PROFILE
   if (fd && tid == 0) fd[2] = (long long)wall_clock64();
 #endif

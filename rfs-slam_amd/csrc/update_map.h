@@ -462,7 +462,10 @@ __device__ __forceinline__ void phd_update_map_block(const Buffers &B, const Par
   //  where the scheduling barrier it forms made the register allocator spill 84 B per lane)
   //  Inside this phase, where all workgroups of a CU start together, the waves in the last hardware slot of their SIMD
   //  (HW_ID.wave_id: the last arrivals, which the arbiter ranks lowest) get the level above the others.
-  if (phasePrio) { if ((__builtin_amdgcn_s_getreg((4 - 1) << 11 | 4) & 0xfu) >= 3u) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); }
+#ifndef STEP_MAP_PRIO
+#define STEP_MAP_PRIO 2
+#endif
+  if (phasePrio) { if ((__builtin_amdgcn_s_getreg((4 - 1) << 11 | 4) & 0xfu) >= 3u) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(STEP_MAP_PRIO); }
   // ---------------- phase 1 ----------------
   for (int p = 0; p < nPass; p++) {
     const int m = p * NT + tid;
