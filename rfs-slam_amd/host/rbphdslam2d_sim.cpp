@@ -135,6 +135,7 @@ int main(int argc, char **argv) {
     odom[k].u[2] += std::sqrt(vardz) * dT * N01(gen);
   }
   std::vector<Measurement2d> measurements;
+  std::vector<double> lmkFirstObs(gtLm.size(), -1.0);
   {
     const double meanClutter = clutter * 2 * PI * (rMax - rMin);
     double cmf[100], pmf = std::exp(-meanClutter), mp = 1, fact = 1;
@@ -142,7 +143,8 @@ int main(int argc, char **argv) {
     for (int i = 1; i < 100; i++) { mp *= meanClutter; fact *= i; cmf[i] = cmf[i - 1] + mp / fact * std::exp(-meanClutter); }
     for (int k = 1; k < kMax; k++) {
       const double t = k * dT;
-      for (const Landmark &lm : gtLm) {
+      for (size_t li = 0; li < gtLm.size(); li++) {
+        const Landmark &lm = gtLm[li];
         const double dx = lm.x[0] - gtPose[k].x[0], dy = lm.x[1] - gtPose[k].x[1];
         double r = std::sqrt(dx * dx + dy * dy);
         double b = std::atan2(dy, dx) - gtPose[k].x[2];
@@ -151,7 +153,10 @@ int main(int argc, char **argv) {
         b += std::sqrt(varzb) * N01(gen);
         while (b > PI) b -= 2 * PI;
         while (b < -PI) b += 2 * PI;
-        if (success && r <= rMax && r >= rMin && drand48() <= Pd) { Measurement2d z; z.z[0] = r; z.z[1] = b; z.t = t; measurements.push_back(z); }
+        if (success) {
+          if (r <= rMax && r >= rMin && drand48() <= Pd) { Measurement2d z; z.z[0] = r; z.z[1] = b; z.t = t; measurements.push_back(z); }
+          if (lmkFirstObs[li] < 0) lmkFirstObs[li] = t;   // lmkFirstObsTime_: first time in sensor range, detected or not (src/rbphdslam2dSim.cpp:337-339)
+        }
       }
       const double u = drand48();
       int nC = 0;
@@ -214,8 +219,32 @@ int main(int argc, char **argv) {
   if (!outDir.empty()) {
     fPose = std::fopen((outDir + "/particlePose.dat").c_str(), "w");
     fLm = std::fopen((outDir + "/landmarkEst.dat").c_str(), "w");
-    if (FILE *fg = std::fopen((outDir + "/gtLandmark.dat").c_str(), "w")) {   // src/rbphdslam2dSim.cpp:396-406: x y (time first observed)
-      for (const Landmark &lm : gtLm) std::fprintf(fg, "%f   %f   %f\n", lm.x[0], lm.x[1], -1.0);
+    // exportSimData (src/rbphdslam2dSim.cpp:380-440): the files analysis2dSim reads (tools/analysis2d_sim.py here)
+    if (FILE *fg = std::fopen((outDir + "/gtLandmark.dat").c_str(), "w")) {   // x y (time first observed; -1: never)
+      for (size_t li = 0; li < gtLm.size(); li++) std::fprintf(fg, "%f   %f   %f\n", gtLm[li].x[0], gtLm[li].x[1], lmkFirstObs[li]);
+      std::fclose(fg);
+    }
+    if (FILE *fg = std::fopen((outDir + "/gtPose.dat").c_str(), "w")) {
+      for (int k = 0; k < kMax; k++) std::fprintf(fg, "%f   %f   %f   %f\n", k * dT, gtPose[k].x[0], gtPose[k].x[1], gtPose[k].x[2]);
+      std::fclose(fg);
+    }
+    if (FILE *fg = std::fopen((outDir + "/odometry.dat").c_str(), "w")) {
+      for (int k = 0; k < kMax; k++) std::fprintf(fg, "%f   %f   %f   %f\n", k * dT, odom[k].u[0], odom[k].u[1], odom[k].u[2]);
+      std::fclose(fg);
+    }
+    if (FILE *fg = std::fopen((outDir + "/measurement.dat").c_str(), "w")) {
+      for (const Measurement2d &z : measurements) std::fprintf(fg, "%f   %f   %f\n", z.t, z.z[0], z.z[1]);
+      std::fclose(fg);
+    }
+    if (FILE *fg = std::fopen((outDir + "/deadReckoning.dat").c_str(), "w")) {   // the noisy odometry integrated from the origin (:322-330)
+      Pose2d dr;
+      std::fprintf(fg, "%f   %f   %f   %f\n", 0.0, dr.x[0], dr.x[1], dr.x[2]);
+      for (int k = 1; k < kMax; k++) {
+        Pose2d nx;
+        MotionModel_Odometry2d::step(nx, dr, odom[k]);
+        dr = nx;
+        std::fprintf(fg, "%f   %f   %f   %f\n", k * dT, dr.x[0], dr.x[1], dr.x[2]);
+      }
       std::fclose(fg);
     }
   }

@@ -528,6 +528,35 @@ def test_cpp_mhfastslam_driver_end_to_end(pkg):
     assert mean_err < 0.2 and pose_err < 0.6
 
 
+def test_cpp_host_driver_logs_through_analysis2d_sim(pkg, tmp_path):
+    """f3 end to end: host/rbphdslam2d_sim writes the reference driver's log files (gtPose, gtLandmark with first-in-range
+    times, odometry, measurement, deadReckoning, particlePose, landmarkEst), tools/analysis2d_sim.py (analysis2dSim,
+    src/analysis2dSim.cpp) turns them into the reference's error files: the filter must beat dead reckoning by a wide margin,
+    count the landmarks, and keep the COLA map error (cutoff 0.2 m: a landmark further off than that counts as missing) low."""
+    import importlib.util
+    import os
+    import subprocess
+    exe = pkg.build_mod.build_host()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(tmp_path, "run")
+    os.makedirs(d)
+    out = subprocess.run([exe, "-c", os.path.join(root, "tests", "golden", "rbphdslam2dSim_c1.xml"), "-t", "1", "-s", "2", "-n", "200", "-o", d],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    spec = importlib.util.spec_from_file_location("analysis2d_sim", os.path.join(root, "tools", "analysis2d_sim.py"))
+    a = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(a)
+    dr, pose, mp = a.analyse(d + "/")
+    assert pose.shape[0] == 2999 and dr.shape[0] == 2999 and mp.shape[0] == 2999
+    assert pose[-1, 4] < 0.5 and pose[-1, 4] < dr[-1, 4] / 3 and pose[:, 4].mean() < 0.3
+    assert int(mp[-1, 1]) == 50 and abs(mp[-1, 2] - 50) < 5          # landmarks in range so far, cardinality estimate
+    assert mp[-1, 3] < 25 and mp[:, 3].mean() < 15                  # COLA: 0 = perfect, 50 = nothing mapped
+    assert np.all(np.diff(mp[:, 1]) >= 0)                           # the observable set only grows
+    for name, cols in (("poseEstError.dat", 5), ("deadReckoningError.dat", 5), ("landmarkEstError.dat", 4), ("gtPose.dat", 4), ("deadReckoning.dat", 4),
+                       ("odometry.dat", 4), ("measurement.dat", 3), ("gtLandmark.dat", 3)):
+        assert len(open(os.path.join(d, name)).readline().split()) == cols, name
+
+
 @pytest.mark.parametrize("n_lm,cap", [(90, 256), (330, 512)])
 def test_tied_weights_rank_by_index(pkg, ob, sc, n_lm, cap):
     """Equal prior weights (ordinary in real runs: all birth Gaussians share one weight): the sort is (weight desc, index
