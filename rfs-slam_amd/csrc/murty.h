@@ -198,6 +198,7 @@ __device__ __forceinline__ void murty_kbest_block(double *C, int n, int partitio
   const int lane = threadIdx.x & 63;
 #ifdef RFS_PROFILE
   long long tp[5] = {0, 0, 0, 0, 0};
+  long long hp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // hungarian_wave's counters: [1] cycles [2] solves [4] main-loop trips [5] BFS dequeues [6] label updates [7] sum of n [8] main-loop cycles
   long long tq = (long long)__builtin_readcyclecounter();
 #define MB_STAMP(i) do { const long long tn = (long long)__builtin_readcyclecounter(); tp[i] += tn - tq; tq = tn; } while (0)
 #else
@@ -245,8 +246,13 @@ __device__ __forceinline__ void murty_kbest_block(double *C, int n, int partitio
         double sAcc = 0;
         int aNew = aPar, aTmp = 0;
         const bool okH = (nFree <= LDSN)
+#ifdef RFS_PROFILE
+                             ? murty_child_wave<LDSN>(myTile, C, n, nn, nFree, pn, parent, colRemap, freeCols, realNC, A, aTmp, nullptr, hp)
+                             : murty_child_wave<MURTY_N>(A.Ct + (size_t)wave * MURTY_N * MURTY_N, C, n, nn, nFree, pn, parent, colRemap, freeCols, realNC, A, aTmp, nullptr, hp);
+#else
                              ? murty_child_wave<LDSN>(myTile, C, n, nn, nFree, pn, parent, colRemap, freeCols, realNC, A, aTmp, nullptr, nullptr)
                              : murty_child_wave<MURTY_N>(A.Ct + (size_t)wave * MURTY_N * MURTY_N, C, n, nn, nFree, pn, parent, colRemap, freeCols, realNC, A, aTmp, nullptr, nullptr);
+#endif
         if (okH) {
           const int ja = __shfl((lane < nFree) ? colRemap : 0, (lane < nFree) ? aTmp : 0, 64);
           const double term = (lane < nFree) ? C[(nn + lane) * n + ja] : 0.0;
@@ -292,6 +298,7 @@ __device__ __forceinline__ void murty_kbest_block(double *C, int n, int partitio
   }
 #ifdef RFS_PROFILE
   if (lane == 0 && (blockIdx.x & 255) == 7) printf("murty block %d wave %d: n %d nodes %d; cycles root %lld, pop+barrier %lld, own children %lld, wait for the other waves %lld, push+top+barrier %lld\n", (int)blockIdx.x, wave, n, ctl[2], tp[4], tp[0], tp[1], tp[3], tp[2]);
+  if (lane == 0 && (blockIdx.x & 255) == 7 && hp[2] > 0) printf("   wave %d solver: %lld solves, mean dimension %.1f, %lld cycles per solve (%lld in the main loop); per solve: %.1f main-loop trips, %.1f BFS dequeues, %.1f label updates -> %lld cycles per trip\n", wave, hp[2], (double)hp[7] / hp[2], hp[1] / hp[2], hp[8] / hp[2], (double)hp[4] / hp[2], (double)hp[5] / hp[2], (double)hp[6] / hp[2], hp[4] ? hp[8] / hp[4] : 0);
 #endif
   ok = __builtin_amdgcn_readfirstlane(ctl[5]) != 0;
 }
