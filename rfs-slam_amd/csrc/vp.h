@@ -585,11 +585,28 @@ __global__ __launch_bounds__(WPB * 64) void vp_weighting_kernel(Buffers B, Param
   if (lane == 0) B.weight[i] = overall * B.weight[i];
 }
 
-// LDS per wave for the merge: 16 doubles per Gaussian (x, y, d, Sigma(6), Sigma^-1(6), w)
-__host__ __device__ inline size_t vp_merge_lds_bytes_per_wave(int cap) { return (size_t)cap * 16 * 8 + (size_t)cap * 2; }
+// LDS per wave for the merge: 42 B per Gaussian -- position (x, y, d), prefilter bound and weight as doubles, a u16 survivor list.
+// (Until r02 every entry was staged with its covariance AND the inverse, 130 B: 25 KB per wave at cap 192, six waves per CU, and
+// the 5000 particles of configs[3] took 3.3 rounds.  Now the distance prefilter below runs on the LDS copy and everything the
+// exact test needs comes from the slab for the few pairs that survive it; all 5000 waves are resident at once.)
+__host__ __device__ inline size_t vp_merge_lds_bytes_per_wave(int cap) { return (((size_t)cap * (5 * 8 + 2)) + 15) & ~(size_t)15; }
+
+// Necessary condition for a pair to pass GaussianMixture::merge's test with covariance S: e^T S^-1 e >= |e|^2 / lambda_max(S) >=
+// |e|^2 / tr(S) for a positive definite S, so md2 <= t^2 implies |e|^2 <= t^2 tr(S).  The bound carries a 1e-6 relative margin for
+// the rounding of the computed inverse / md2; a covariance that is not positive definite (Sylvester), not finite, or so
+// ill-conditioned that the computed md2 may be off by more than that margin gets an infinite bound -- always fully tested -- so
+// the prefilter never changes a decision of the exact test.
+__device__ __forceinline__ double merge_bound3(double t2, const Ent3 &e) {
+  double S[9];
+  full3(e, S);
+  const double tr = (e.xx + e.yy) + e.dd, m2 = e.xx * e.yy - e.xy * e.xy, det = det3(S);
+  const bool sane = (e.xx > 0.0) && (m2 > 0.0) && (det > 1e-9 * tr * tr * tr) && (tr < 1.0e100);
+  return sane ? t2 * tr * (1.0 + 1e-6) : __builtin_huge_val();
+}
 
 // GaussianMixture::merge for 3-D Gaussians: the exact sequential-greedy scan (lanes test 64 candidates j at once against
-// the current state of a, lowest passing lane merged, lanes above it re-tested), optional fused prune.
+// the current state of a, lowest passing lane merged, lanes above it re-tested), optional fused prune.  Merged rows are
+// written back in place (a row is never read again once the scan has passed it); the prune reads the slab.
 template <int WPB, bool FUSE_PRUNE>
 __global__ __launch_bounds__(WPB * 64) void vp_merge_kernel(Buffers B, Params P, int cur, int dst) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -599,9 +616,8 @@ __global__ __launch_bounds__(WPB * 64) void vp_merge_kernel(Buffers B, Params P,
   if (i >= B.N) return;
   const int cap = B.cap;
   double *sb = reinterpret_cast<double *>(smem_raw + (size_t)wave * vp_merge_lds_bytes_per_wave(cap));
-  // arrays: 0 x,1 y,2 d,3..8 Sigma,9..14 inverse (i00,i01,i02,i11,i12,i22), 15 w
-#define SA(k) (sb + (size_t)(k) * cap)
-  unsigned short *sIdx = reinterpret_cast<unsigned short *>(sb + (size_t)16 * cap);
+  double *sX = sb, *sY = sb + cap, *sD = sb + 2 * (size_t)cap, *sBnd = sb + 3 * (size_t)cap, *sW = sb + 4 * (size_t)cap;
+  unsigned short *sIdx = reinterpret_cast<unsigned short *>(sb + 5 * (size_t)cap);
   const int N = B.count[i];
   double *slab = B.slab[cur];
   const double t2 = P.mergeT2, f = P.mergeInfl;
@@ -609,23 +625,47 @@ __global__ __launch_bounds__(WPB * 64) void vp_merge_kernel(Buffers B, Params P,
   for (int m = lane, sidx = 0; m < N; m += 64, sidx++) {
     Ent3 e;
     load_ent3(slab, cap, i, m, e, true);
-    double Sm[9], Si[9];
-    full3(e, Sm);
-    inv3(Sm, Si);
-    SA(0)[m] = e.x; SA(1)[m] = e.y; SA(2)[m] = e.d;
-    SA(3)[m] = e.xx; SA(4)[m] = e.xy; SA(5)[m] = e.xd; SA(6)[m] = e.yy; SA(7)[m] = e.yd; SA(8)[m] = e.dd;
-    SA(9)[m] = Si[0]; SA(10)[m] = Si[1]; SA(11)[m] = Si[2]; SA(12)[m] = Si[4]; SA(13)[m] = Si[5]; SA(14)[m] = Si[8];
-    SA(15)[m] = e.w;
+    sX[m] = e.x; sY[m] = e.y; sD[m] = e.d;
+    sBnd[m] = merge_bound3(t2, e);
+    sW[m] = e.w;
     if (e.w < 0) hole |= 1u << sidx;
   }
   wave_sync();
+  // inverse of a stored covariance as the reference's test reads it: Eigen's cofactor inverse of the full matrix, of which the
+  // scan (like the r01 kernel, which kept exactly these six numbers per entry) uses the upper triangle mirrored
+  auto inverse_of = [&](const Ent3 &e, double I9[9]) {
+    double Sm[9], Si[9];
+    full3(e, Sm);
+    inv3(Sm, Si);
+    I9[0] = Si[0]; I9[1] = Si[1]; I9[2] = Si[2]; I9[3] = Si[1]; I9[4] = Si[4]; I9[5] = Si[5]; I9[6] = Si[2]; I9[7] = Si[5]; I9[8] = Si[8];
+  };
+  // Rows that can merge at all: a row's first merge needs a partner that passes the exact test against the row's INITIAL state,
+  // hence the distance prefilter on the initial states; a row without such a partner goes through the reference's scan
+  // unchanged, so it is skipped outright (its record is never fetched).  On a Victoria Park map that is all but a few rows.
+  unsigned rowFlag = 0;
+  for (int m = lane, sidx = 0; m < N; m += 64, sidx++) {
+    if ((hole >> sidx) & 1u) continue;
+    const double mx = sX[m], my = sY[m], md = sD[m], mb = sBnd[m];
+    bool c = false;
+    for (int j = m + 1; j < N && !c; j++) {
+      const double e0 = sX[j] - mx, e1 = sY[j] - my, e2 = sD[j] - md;
+      c = !(((e0 * e0 + e1 * e1) + e2 * e2) > fmax(mb, sBnd[j])) && !(sW[j] < 0);
+    }
+    if (c) rowFlag |= 1u << sidx;
+  }
   bool anyMerge = false;
-  for (int a = 0; a < N; a++) {
+  for (int r0 = 0; r0 < N; r0 += 64)
+  for (unsigned long long rows = __ballot((rowFlag >> (r0 >> 6)) & 1u); rows; rows &= rows - 1ull) {
+    const int a = r0 + __builtin_ctzll(rows);
+    Ent3 ea;
+    ea.w = 0;
+    load_ent3(slab, cap, i, a, ea, false);                       // (wave-uniform address: one broadcast load per plane)
     const unsigned ownerHole = (unsigned)__builtin_amdgcn_readlane((int)hole, a & 63);
     if ((ownerHole >> (a >> 6)) & 1u) continue;
-    double ax = SA(0)[a], ay = SA(1)[a], ad = SA(2)[a], aw = SA(15)[a];
-    double aS[9] = {SA(3)[a], SA(4)[a], SA(5)[a], SA(4)[a], SA(6)[a], SA(7)[a], SA(5)[a], SA(7)[a], SA(8)[a]};
-    double aI[9] = {SA(9)[a], SA(10)[a], SA(11)[a], SA(10)[a], SA(12)[a], SA(13)[a], SA(11)[a], SA(13)[a], SA(14)[a]};
+    double ax = ea.x, ay = ea.y, ad = ea.d, aw = sW[a], ab = sBnd[a];
+    double aS[9], aI[9];
+    full3(ea, aS);
+    inverse_of(ea, aI);
     bool changed = false;
     for (int c0 = (a + 1) & ~63; c0 < N; c0 += 64) {
       const int j = c0 + lane;
@@ -635,21 +675,29 @@ __global__ __launch_bounds__(WPB * 64) void vp_merge_kernel(Buffers B, Params P,
       while (true) {
         bool pass = false;
         if (live && lane >= floorLane) {
-          const double e0 = SA(0)[j] - ax, e1 = SA(1)[j] - ay, e2 = SA(2)[j] - ad;
-          bool far = md2_3(aI, e0, e1, e2) > t2;
-          if (far) {
-            const double jI[9] = {SA(9)[j], SA(10)[j], SA(11)[j], SA(10)[j], SA(12)[j], SA(13)[j], SA(11)[j], SA(13)[j], SA(14)[j]};
-            far = md2_3(jI, -e0, -e1, -e2) > t2;
+          const double e0 = sX[j] - ax, e1 = sY[j] - ay, e2 = sD[j] - ad;
+          if (!(((e0 * e0 + e1 * e1) + e2 * e2) > fmax(ab, sBnd[j]))) {   // (NaN distances and infinite bounds fall through to the exact test)
+            bool far = md2_3(aI, e0, e1, e2) > t2;
+            if (far) {
+              Ent3 ej;
+              load_ent3(slab, cap, i, j, ej, false);
+              double jI[9];
+              inverse_of(ej, jI);
+              far = md2_3(jI, -e0, -e1, -e2) > t2;
+            }
+            pass = !far && ((aw + sW[j]) != 0.0);
           }
-          pass = !far && ((aw + SA(15)[j]) != 0.0);
         }
         const unsigned long long pm = __ballot(pass);
         if (pm == 0ull) break;
         const int l = __builtin_ctzll(pm);
         const int jj = c0 + l;
-        const double w1 = aw, w2 = SA(15)[jj];
-        const double bx[3] = {SA(0)[jj], SA(1)[jj], SA(2)[jj]};
-        const double bS[9] = {SA(3)[jj], SA(4)[jj], SA(5)[jj], SA(4)[jj], SA(6)[jj], SA(7)[jj], SA(5)[jj], SA(7)[jj], SA(8)[jj]};
+        Ent3 eb;
+        load_ent3(slab, cap, i, jj, eb, false);                  // uniform
+        const double w1 = aw, w2 = sW[jj];
+        const double bx[3] = {eb.x, eb.y, eb.d};
+        double bS[9];
+        full3(eb, bS);
         const double wm = w1 + w2;
         const double axv[3] = {ax, ay, ad};
         double xm[3], d1[3], d2[3];
@@ -668,6 +716,12 @@ __global__ __launch_bounds__(WPB * 64) void vp_merge_kernel(Buffers B, Params P,
         inv3(aS, aI);
         // the reference inverts the full matrix; mirror its symmetric reads
         aI[3] = aI[1]; aI[6] = aI[2]; aI[7] = aI[5];
+        {
+          Ent3 em;
+          em.w = aw; em.x = ax; em.y = ay; em.d = ad;
+          em.xx = aS[0]; em.xy = aS[1]; em.xd = aS[2]; em.yy = aS[4]; em.yd = aS[5]; em.dd = aS[8];
+          ab = merge_bound3(t2, em);
+        }
         changed = true;
         if (lane == l) { hole |= 1u << slot; live = false; }
         floorLane = l + 1;
@@ -676,33 +730,34 @@ __global__ __launch_bounds__(WPB * 64) void vp_merge_kernel(Buffers B, Params P,
     }
     if (changed) {
       anyMerge = true;
-      SA(0)[a] = ax; SA(1)[a] = ay; SA(2)[a] = ad; SA(15)[a] = aw;
-      SA(3)[a] = aS[0]; SA(4)[a] = aS[1]; SA(5)[a] = aS[2]; SA(6)[a] = aS[4]; SA(7)[a] = aS[5]; SA(8)[a] = aS[8];
-    }
-  }
-  wave_sync();
-  if (!FUSE_PRUNE) {
-    if (!anyMerge) return;
-    for (int m = lane, sidx = 0; m < N; m += 64, sidx++) {
-      const bool h = (hole >> sidx) & 1u;
-      plane3(slab, cap, i, P3_W)[m] = h ? -1.0 : SA(15)[m];
-      if (!h) {
-        plane3(slab, cap, i, P3_MX)[m] = SA(0)[m]; plane3(slab, cap, i, P3_MY)[m] = SA(1)[m]; plane3(slab, cap, i, P3_MD)[m] = SA(2)[m];
-        plane3(slab, cap, i, P3_SXX)[m] = SA(3)[m]; plane3(slab, cap, i, P3_SXY)[m] = SA(4)[m]; plane3(slab, cap, i, P3_SXD)[m] = SA(5)[m];
-        plane3(slab, cap, i, P3_SYY)[m] = SA(6)[m]; plane3(slab, cap, i, P3_SYD)[m] = SA(7)[m]; plane3(slab, cap, i, P3_SDD)[m] = SA(8)[m];
+      sW[a] = aw;   // (uniform store; the position / bound of a are never read again: a is behind the scan)
+      if (lane == 0) {
+        plane3(slab, cap, i, P3_W)[a] = aw;
+        plane3(slab, cap, i, P3_MX)[a] = ax; plane3(slab, cap, i, P3_MY)[a] = ay; plane3(slab, cap, i, P3_MD)[a] = ad;
+        plane3(slab, cap, i, P3_SXX)[a] = aS[0]; plane3(slab, cap, i, P3_SXY)[a] = aS[1]; plane3(slab, cap, i, P3_SXD)[a] = aS[2];
+        plane3(slab, cap, i, P3_SYY)[a] = aS[4]; plane3(slab, cap, i, P3_SYD)[a] = aS[5]; plane3(slab, cap, i, P3_SDD)[a] = aS[8];
       }
     }
+  }
+  // in-place updates of merged rows (global memory, lane 0) -> visible to the wave's other lanes
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  wave_sync();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if (!FUSE_PRUNE) {
+    if (!anyMerge) return;
+    for (int m = lane, sidx = 0; m < N; m += 64, sidx++)
+      if ((hole >> sidx) & 1u) plane3(slab, cap, i, P3_W)[m] = -1.0;
     return;
   }
   for (int m = lane, sidx = 0; m < N; m += 64, sidx++)
-    if ((hole >> sidx) & 1u) SA(15)[m] = -1.0;
+    if ((hole >> sidx) & 1u) sW[m] = -1.0;
   wave_sync();
   double *dl = B.slab[dst];
   const double t = P.pruneT;
   int nSurv = 0;
   for (int c0 = 0; c0 < N; c0 += 64) {
     const int m = c0 + lane;
-    const double wm = (m < N) ? SA(15)[m] : -1.0;
+    const double wm = (m < N) ? sW[m] : -1.0;
     const bool keep = (wm >= t) && (wm >= 0.0);
     const unsigned long long km = __ballot(keep);
     if (keep) sIdx[nSurv + __popcll(km & ((1ull << lane) - 1ull))] = (unsigned short)m;
@@ -711,19 +766,20 @@ __global__ __launch_bounds__(WPB * 64) void vp_merge_kernel(Buffers B, Params P,
   wave_sync();
   for (int q = lane; q < nSurv; q += 64) {
     const int m = sIdx[q];
-    const double wm = SA(15)[m];
+    const double wm = sW[m];
+    Ent3 e;
+    load_ent3(slab, cap, i, m, e, false);   // the survivor's record first (independent loads in flight while the rank is counted)
     int rank = 0;
     for (int q2 = 0; q2 < nSurv; q2++) {
       const int j2 = sIdx[q2];
-      const double wj = SA(15)[j2];
+      const double wj = sW[j2];
       rank += ((wj > wm) | ((wj == wm) & (j2 < m))) ? 1 : 0;
     }
     plane3(dl, cap, i, P3_W)[rank] = wm;
     plane3(dl, cap, i, P3_WP)[rank] = 0.0;
-    plane3(dl, cap, i, P3_MX)[rank] = SA(0)[m]; plane3(dl, cap, i, P3_MY)[rank] = SA(1)[m]; plane3(dl, cap, i, P3_MD)[rank] = SA(2)[m];
-    plane3(dl, cap, i, P3_SXX)[rank] = SA(3)[m]; plane3(dl, cap, i, P3_SXY)[rank] = SA(4)[m]; plane3(dl, cap, i, P3_SXD)[rank] = SA(5)[m];
-    plane3(dl, cap, i, P3_SYY)[rank] = SA(6)[m]; plane3(dl, cap, i, P3_SYD)[rank] = SA(7)[m]; plane3(dl, cap, i, P3_SDD)[rank] = SA(8)[m];
+    plane3(dl, cap, i, P3_MX)[rank] = e.x; plane3(dl, cap, i, P3_MY)[rank] = e.y; plane3(dl, cap, i, P3_MD)[rank] = e.d;
+    plane3(dl, cap, i, P3_SXX)[rank] = e.xx; plane3(dl, cap, i, P3_SXY)[rank] = e.xy; plane3(dl, cap, i, P3_SXD)[rank] = e.xd;
+    plane3(dl, cap, i, P3_SYY)[rank] = e.yy; plane3(dl, cap, i, P3_SYD)[rank] = e.yd; plane3(dl, cap, i, P3_SDD)[rank] = e.dd;
   }
   if (lane == 0) B.count[i] = nSurv;
-#undef SA
 }
