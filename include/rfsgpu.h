@@ -259,6 +259,13 @@ int rfsgpu_step_async(rfsgpu_filter *f, const double *z, int n_z, int normalize)
  * rfsgpu_weight_sums, rfsgpu_get_weights, ...). */
 int rfsgpu_set_step_inputs_async(rfsgpu_filter *f, const double *x, const double *cov, int cov_stride, const double *scan, int n_scan);
 int rfsgpu_predict_map_async(rfsgpu_filter *f, int add_birth);
+/* A run of n consecutive predicts that add no births (each one: rfsgpu_set_lmk_process_noise(Q_k) + rfsgpu_predict_map_async(f, 0),
+ * i.e. StaticProcessModel::staticStep, Sigma += Q_k, include/ProcessModel.hpp:195-208) in ONE launch -- the additions are made
+ * one after the other, so the result has the same bits.  noises: [n][D*D] row-major, one per predict of the run (the drivers
+ * scale Q with the message interval), or NULL = the noise that is set now, n times.  A driver whose odometry messages outnumber
+ * its sensor messages (Victoria Park: 9 to 1) collects the birth-less predicts and flushes them before the next call that
+ * reads the maps. */
+int rfsgpu_static_steps_async(rfsgpu_filter *f, int n, const double *noises);
 /* ParticleFilter::propagate (include/ParticleFilter.hpp:322-339) for the Victoria Park driver's process model, on the device:
  * MotionModel_Ackerman2d::step (src/ProcessModel_Ackerman2D.cpp:47-78) applied to every particle's pose with its own noisy
  * input u + N(0, diag(var)) (ProcessModel::sample's input-noise branch, include/ProcessModel.hpp:126-150).  u = {speed,

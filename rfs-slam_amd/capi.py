@@ -116,7 +116,7 @@ ABI_SYMBOLS = [
     "default_fastslam_config", "set_fastslam_config", "get_fastslam_config", "fastslam_update",
     "normalize_weights_parts", "create_ex", "n_particles", "max_particles", "resample_apply_n",
     "fastslam_set_resample_occured", "particle_parents", "vp_probe_pd",
-    "slab_row_bytes", "export_slab_rows", "import_slab_rows", "weights_device_ptr", "step_async", "set_step_inputs_async", "predict_map_async", "propagate_ackerman_async", "set_partition_mode", "get_partition_mode",
+    "slab_row_bytes", "export_slab_rows", "import_slab_rows", "weights_device_ptr", "step_async", "set_step_inputs_async", "predict_map_async", "static_steps_async", "propagate_ackerman_async", "set_partition_mode", "get_partition_mode",
     "group_create", "group_destroy", "group_last_error", "group_n_shards", "group_n_particles", "group_shard", "group_locate",
     "group_set_filter_config", "group_set_model_rngbrg", "group_set_kf_config", "group_set_lmk_process_noise", "group_set_poses",
     "group_get_poses", "group_set_weights", "group_get_weights", "group_predict_map", "group_update", "group_normalize",
@@ -462,6 +462,13 @@ class CFilter:
 
     def predict_map_async(self, add_birth=True):
         self._call("predict_map_async", C.c_int(1 if add_birth else 0))
+
+    def static_steps_async(self, n, noises=None):
+        """A run of n birth-less predicts (Sigma += Q_k each) in one launch; noises [n][D][D] or None = the current noise n times."""
+        q = None
+        if noises is not None:
+            q = _f64(noises, (int(n), self.dm, self.dm))
+        self._call("static_steps_async", C.c_int(int(n)), self._ptr(q) if q is not None else None)
 
     def propagate_ackerman_async(self, u, var, dt, geom, seed, call):
         """ParticleFilter::propagate with MotionModel_Ackerman2d on the device (csrc/motion.h); var None: noise-free."""

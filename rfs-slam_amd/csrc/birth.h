@@ -167,8 +167,114 @@ struct CandLDS {
   }
 };
 
+// Two kernels share the birth step.  predict_map_general_kernel: one wavefront per particle, candidate c on lane c -- the fast form,
+// for every particle whose list stays within the 64 lanes during the call (candidates + unused measurements <= 64: almost all of
+// them); it also does the static step of EVERY particle.  predict_map_long_kernel: the same walk on a list staged in LDS
+// (<= RFSGPU_MAX_CANDIDATES), 64 candidates at a time, for the particles the first kernel left alone.  (r02: the LDS form alone,
+// for everybody, made a birth predict of the Victoria Park run 103 us where the lane form takes 47: 20 KB of LDS per wave.)
 template <int D, int WPB>
 __global__ __launch_bounds__(WPB * 64) void predict_map_general_kernel(Buffers B, Params P, int cur, int addBirth, int nZprev) {
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
+  if (i >= B.N) return;
+  const int cap = B.cap;
+  const int nOld = B.count[i];
+  // A list that may outgrow the lanes during this call (candidates + unused measurements > 64) is left to predict_map_long_kernel,
+  // which the host launches right after this one; the static step below is done here for every particle.
+  const bool longList = addBirth && (B.candCount[i] + ((nZprev > 0) ? __popcll(B.unusedMask[i]) : 0) > 64);
+  if (addBirth && !longList) {
+    // Candidate c of the particle lives on lane c (at most 64 here): loaded once, kept in registers, stored once.
+    // The reference's walk over the unused measurements and over the list stays serial where its order is observable
+    // (first matching candidate in list order, list order kept by erase, the ++end() wrap); what is per candidate --
+    // the support distance of a measurement to every candidate -- runs across the lanes.
+    int n = nOld;
+    int nc = B.candCount[i];
+    const unsigned nfov = (unsigned)B.nInFov[i];
+    PoseReg pr;
+    load_pose(B, P, i, pr);
+    bool fail = false, listFull = false;
+    int *supG = B.candSup + (size_t)i * RFSGPU_MAX_CANDIDATES, *chkG = B.candChk + (size_t)i * RFSGPU_MAX_CANDIDATES;
+    Cand<D> k;
+    for (int t = 0; t < 3; t++) k.x[t] = 0.0;
+    for (int t = 0; t < 6; t++) k.S[t] = 0.0;
+    int sup = 0, chk = 0;
+    if (lane < nc) { cand_load<D>(B, i, lane, k); sup = supG[lane]; chk = chkG[lane]; }
+    unsigned long long um = (nZprev > 0) ? B.unusedMask[i] : 0ull;
+    while (um) {  // back to front (:1013-1017)
+      const int zi = 63 - __builtin_clzll(um);
+      um &= ~(1ull << zi);
+      const double *z = B.Z + (size_t)D * zi;
+      double d2 = 1.0e300;
+      if (lane < nc) d2 = cand_support_md2<D>(P, pr, k, z);
+      const unsigned long long hit = __ballot(lane < nc && d2 <= P.birthSupportD2);
+      if (hit != 0ull) {                                   // the first candidate in list order that supports it
+        if (lane == __builtin_ctzll(hit)) { cand_correct<D>(P, pr, k, z); sup++; }
+      } else {
+        Cand<D> kn;
+        cand_inverse<D>(P, pr, z, kn);                     // (the same values on every lane)
+        if (P.birthCountThr == 1u || nfov <= P.birthCurThr) {
+          if (n < cap) { if (lane == 0) birth_write<D>(B, P, cur, i, n, kn); n++; }
+          else fail = true;
+        } else if (nc < 64) {   // (always: nc + unused <= 64 on this path)
+          if (lane == nc) { k = kn; sup = 1; chk = 0; }
+          nc++;
+        } else {
+          listFull = true;
+        }
+      }
+    }
+    // promotion / expiry (:1062-1080) with the ++end() wrap
+    int kk = 0;
+    while (kk < nc) {
+      if (lane == kk) chk++;
+      bool atEnd = false;
+      for (;;) {
+        const unsigned supk = (unsigned)__builtin_amdgcn_readlane(sup, kk), chkk = (unsigned)__builtin_amdgcn_readlane(chk, kk);
+        if (!(supk >= P.birthCountThr || chkk > P.birthCheckThr || nfov <= P.birthCurThr)) break;
+        if (supk >= P.birthCountThr || nfov <= P.birthCurThr) {
+          if (n < cap) { if (lane == kk) birth_write<D>(B, P, cur, i, n, k); n++; }
+          else fail = true;
+        }
+        {  // erase(it): the tail moves down one lane, list order kept
+          const int from = (lane >= kk && lane < 63) ? lane + 1 : lane;
+#pragma unroll
+          for (int t = 0; t < 3; t++) k.x[t] = __shfl(k.x[t], from, 64);
+#pragma unroll
+          for (int t = 0; t < 6; t++) k.S[t] = __shfl(k.S[t], from, 64);
+          sup = __shfl(sup, from, 64);
+          chk = __shfl(chk, from, 64);
+        }
+        nc--;
+        if (kk < nc) { if (lane == kk) chk++; }
+        else { atEnd = true; break; }
+      }
+      kk = atEnd ? 0 : kk + 1;
+    }
+    if (lane < nc) { cand_store<D>(B, i, lane, k); supG[lane] = sup; chkG[lane] = chk; }
+    if (lane == 0) {
+      B.unusedMask[i] = 0ull;
+      B.candCount[i] = nc;
+      B.count[i] = n;
+      if (fail) atomicOr(B.err, ERRBIT_CAPACITY);
+      if (listFull) atomicOr(B.err, ERRBIT_BIRTHLIST);
+    }
+  }
+  // staticStep on the pre-existing Gaussians
+  double *slab = B.slab[cur];
+  if (D == 2) {
+    double *pSXX = plane(slab, cap, i, PL_SXX), *pSXY = plane(slab, cap, i, PL_SXY), *pSYY = plane(slab, cap, i, PL_SYY);
+    for (int m = lane; m < nOld; m += 64) { pSXX[m] += P.Qlm[0]; pSXY[m] += P.Qlm[1]; pSYY[m] += P.Qlm[2]; }
+  } else {
+    for (int t = 0; t < 6; t++) {
+      double *p = plane3(slab, cap, i, P3_SXX + t);
+      for (int m = lane; m < nOld; m += 64) p[m] += P.Qlm6[t];
+    }
+  }
+}
+
+template <int D, int WPB>
+__global__ __launch_bounds__(WPB * 64) void predict_map_long_kernel(Buffers B, Params P, int cur, int nZprev) {
   __shared__ CandLDS<D> sCand[WPB];
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
@@ -176,7 +282,9 @@ __global__ __launch_bounds__(WPB * 64) void predict_map_general_kernel(Buffers B
   if (i >= B.N) return;
   const int cap = B.cap;
   const int nOld = B.count[i];
-  if (addBirth) {
+  // (only the particles predict_map_general_kernel left alone: candidates + unused measurements > one per lane)
+  if (B.candCount[i] + ((nZprev > 0) ? __popcll(B.unusedMask[i]) : 0) <= 64) return;
+  {
     // The particle's candidate list (<= RFSGPU_MAX_CANDIDATES) is staged in LDS in list order.  The reference's walk over
     // the unused measurements and over the list stays serial where its order is observable (first matching candidate in
     // list order, list order kept by erase, the ++end() wrap); what is per candidate -- the support distance of a
@@ -304,15 +412,32 @@ __global__ __launch_bounds__(WPB * 64) void predict_map_general_kernel(Buffers B
       if (listFull) atomicOr(B.err, ERRBIT_BIRTHLIST);
     }
   }
-  // staticStep on the pre-existing Gaussians
+}
+
+// StaticProcessModel::staticStep (include/ProcessModel.hpp:195-208), Sigma += Q on every Gaussian, for a RUN of predicts in one
+// launch: a predict that adds no births (every odometry message but the first after an update) is a static step and nothing
+// else, and the additions of a run made one after the other inside one kernel give the same bits as one launch per predict.
+// Every step of the run carries its own Q (the drivers scale it with the message interval).  One wavefront per particle.
+#define STATIC_RUN_MAX 16
+struct StaticRun {
+  int n;
+  double q[STATIC_RUN_MAX][6];   // packed: 2-D xx, xy, yy in [0..2]; 3-D xx, xy, xd, yy, yd, dd
+};
+template <int D, int WPB>
+__global__ __launch_bounds__(WPB * 64) void static_steps_kernel(Buffers B, int cur, StaticRun R) {
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
+  if (i >= B.N) return;
+  const int cap = B.cap, n = B.count[i];
   double *slab = B.slab[cur];
-  if (D == 2) {
-    double *pSXX = plane(slab, cap, i, PL_SXX), *pSXY = plane(slab, cap, i, PL_SXY), *pSYY = plane(slab, cap, i, PL_SYY);
-    for (int m = lane; m < nOld; m += 64) { pSXX[m] += P.Qlm[0]; pSXY[m] += P.Qlm[1]; pSYY[m] += P.Qlm[2]; }
-  } else {
-    for (int t = 0; t < 6; t++) {
-      double *p = plane3(slab, cap, i, P3_SXX + t);
-      for (int m = lane; m < nOld; m += 64) p[m] += P.Qlm6[t];
+  constexpr int NC = (D == 2) ? 3 : 6;
+  for (int t = 0; t < NC; t++) {
+    double *p = (D == 2) ? plane(slab, cap, i, PL_SXX + t) : plane3(slab, cap, i, P3_SXX + t);
+    for (int m = lane; m < n; m += 64) {
+      double a = p[m];
+      for (int r = 0; r < R.n; r++) a += R.q[r][t];
+      p[m] = a;
     }
   }
 }

@@ -1000,9 +1000,15 @@ int rfsgpu_predict_map(rfsgpu_filter *f, int add_birth) {
   hipSetDevice(f->device);
   HIPCHK(hipEventRecord(f->ev[EV_P0], f->stream));
   if (f->D == 3)
-    predict_map_general_kernel<3, 2><<<(f->N + 1) / 2, 128, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
+  {
+    predict_map_general_kernel<3, 4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
+    if (add_birth) predict_map_long_kernel<3, 2><<<(f->N + 1) / 2, 128, 0, f->stream>>>(f->B, f->P, f->cur, f->nZ);   // (lists longer than a wavefront; the others exit at once)
+  }
   else if (f->cfg.birthGaussianMeasurementCountThreshold != 1u)
-    predict_map_general_kernel<2, 2><<<(f->N + 1) / 2, 128, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
+  {
+    predict_map_general_kernel<2, 4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
+    if (add_birth) predict_map_long_kernel<2, 2><<<(f->N + 1) / 2, 128, 0, f->stream>>>(f->B, f->P, f->cur, f->nZ);
+  }
   else  // CountThreshold == 1: every unused measurement is born at once, no candidate can exist -> lane-parallel kernel
     predict_map_kernel<4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
   HIPCHK(hipGetLastError());
@@ -1025,14 +1031,43 @@ int rfsgpu_predict_map_async(rfsgpu_filter *f, int add_birth) {
   const bool rec = !f->predPending;
   if (rec) HIPCHK(hipEventRecord(f->ev[EV_P0], f->stream));
   if (f->D == 3)
-    predict_map_general_kernel<3, 2><<<(f->N + 1) / 2, 128, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
+  {
+    predict_map_general_kernel<3, 4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
+    if (add_birth) predict_map_long_kernel<3, 2><<<(f->N + 1) / 2, 128, 0, f->stream>>>(f->B, f->P, f->cur, f->nZ);   // (lists longer than a wavefront; the others exit at once)
+  }
   else if (f->cfg.birthGaussianMeasurementCountThreshold != 1u)
-    predict_map_general_kernel<2, 2><<<(f->N + 1) / 2, 128, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
+  {
+    predict_map_general_kernel<2, 4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
+    if (add_birth) predict_map_long_kernel<2, 2><<<(f->N + 1) / 2, 128, 0, f->stream>>>(f->B, f->P, f->cur, f->nZ);
+  }
   else
     predict_map_kernel<4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
   HIPCHK(hipGetLastError());
   if (rec) { HIPCHK(hipEventRecord(f->ev[EV_P1], f->stream)); f->predPending = true; }
   f->timing.predict_cpu += now_ns() - t0;
+  return RFSGPU_OK;
+}
+
+// A run of `n` predicts that add no births, in one launch (birth.h, static_steps_kernel): the same bits as n calls of
+// rfsgpu_set_lmk_process_noise(Q_k) + rfsgpu_predict_map_async(f, 0).  noises: [n][D*D] row-major, or NULL = the noise that is set
+// now, n times.  Stream-ordered.
+int rfsgpu_static_steps_async(rfsgpu_filter *f, int n, const double *noises) {
+  CHECK_HANDLE(f);
+  if (n < 0) return fail(f, RFSGPU_ERR_INVALID, "static_steps: negative count");
+  hipSetDevice(f->device);
+  const int D = f->D;
+  for (int k0 = 0; k0 < n; k0 += STATIC_RUN_MAX) {
+    StaticRun R;
+    R.n = std::min(STATIC_RUN_MAX, n - k0);
+    for (int r = 0; r < R.n; r++) {
+      const double *Q = noises ? noises + (size_t)(k0 + r) * D * D : f->Qlm;
+      if (D == 2) { R.q[r][0] = Q[0]; R.q[r][1] = Q[1]; R.q[r][2] = Q[3]; R.q[r][3] = R.q[r][4] = R.q[r][5] = 0.0; }
+      else { R.q[r][0] = Q[0]; R.q[r][1] = Q[1]; R.q[r][2] = Q[2]; R.q[r][3] = Q[4]; R.q[r][4] = Q[5]; R.q[r][5] = Q[8]; }
+    }
+    if (D == 3) static_steps_kernel<3, 4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->cur, R);
+    else static_steps_kernel<2, 4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->cur, R);
+    HIPCHK(hipGetLastError());
+  }
   return RFSGPU_OK;
 }
 

@@ -548,7 +548,15 @@ class RBPHDFilterVP : public RBPHDFilter2d {
     // when something other than propagation changed them (setParticlePose, resampling on the host side), or by update().
     if (posesDirty_ && !xbufFresh_) pushInputsAsync();
     auto t2 = now();
-    check(rfsgpu_predict_map_async(h_, birthGaussianCheck ? 1 : 0), "predict_map");   // stream-ordered: no host wait
+    // A predict that adds no births is one static step of the landmarks (Sigma += Q) and nothing else on the device: those are
+    // counted and applied in ONE launch before the next call that reads the maps (same additions, same order, same bits) --
+    // nine of ten Victoria Park messages are such predicts.
+    if (birthGaussianCheck) {
+      flushStatic();
+      check(rfsgpu_predict_map_async(h_, 1), "predict_map");   // stream-ordered: no host wait
+    } else {
+      pendingStatic_.insert(pendingStatic_.end(), lmk3_.Q, lmk3_.Q + 9);   // this predict's own Q (the driver scales it with dT)
+    }
     auto t3 = now();
     tCfg_ += std::chrono::duration<double>(t1 - t0).count(); tIn_ += std::chrono::duration<double>(t2 - t1).count();
     tPm_ += std::chrono::duration<double>(t3 - t2).count();
@@ -613,6 +621,7 @@ class RBPHDFilterVP : public RBPHDFilter2d {
     nMeasurementsSinceResample_ += (unsigned)meas.size();
     pushConfigVP();
     pushInputsAsync();
+    flushStatic();
     std::vector<double> z(3 * meas.size());
     for (size_t k = 0; k < meas.size(); k++) std::memcpy(&z[3 * k], meas[k].z, 3 * sizeof(double));
     // the step + normalizeWeights in its post launch: what update() does when no resampling happens (:537-539), and what
@@ -644,9 +653,18 @@ class RBPHDFilterVP : public RBPHDFilter2d {
     return resample(0, true, /*alreadyNormalized=*/true);
   }
 
-  bool getLandmark(int i, int m, double u[3], double S[9], double &w) { return rfsgpu_get_landmark(h_, i, m, u, S, &w) == RFSGPU_OK; }
+  bool getLandmark(int i, int m, double u[3], double S[9], double &w) {
+    flushStatic();
+    return rfsgpu_get_landmark(h_, i, m, u, S, &w) == RFSGPU_OK;
+  }
 
  private:
+  std::vector<double> pendingStatic_;   // the landmark process noise (3 x 3) of every birth-less predict not yet applied on the device
+  void flushStatic() {
+    if (pendingStatic_.empty()) return;
+    check(rfsgpu_static_steps_async(h_, (int)(pendingStatic_.size() / 9), pendingStatic_.data()), "static_steps");
+    pendingStatic_.clear();
+  }
   MotionModel_Ackerman2d ackerman_;
   unsigned long long motionSeed_ = 0, motionCall_ = 0;
   LmkProcessModel3d lmk3_;

@@ -98,3 +98,48 @@ def test_device_propagation_matches_the_restatement():
     f.propagate_ackerman_async((5.0, 0.0), (0.2, 0.0), 1.0, (0.0, 2.83, 0.0, 0.0), seed=100, call=5)
     f.synchronize()
     assert np.abs(f.get_poses()[:, 0] - v).max() > 0.1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["vp", "2d"])
+def test_static_steps_in_one_launch_give_the_same_bits(model):
+    """rfsgpu_static_steps_async(n, Q[n]) == n times (set_lmk_process_noise(Q_k); predict_map_async(0)): Sigma += Q_k in order, bit for bit."""
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    sc = pkg.scenarios
+    fs = []
+    for batched in (False, True):
+        if model == "vp":
+            f = pkg.RBPHDFilter(24, gm_capacity=64, model=pkg.capi.MODEL_VICTORIAPARK_3D)
+            sc.apply_vp_params(f, dict(sc.VP_PARAMS), np.full(361, 70.0))
+            rng = np.random.default_rng(1)
+            for i in range(24):
+                n = 5 + i % 7
+                mean = rng.normal(0, 20, (n, 3))
+                A = rng.normal(0, 1, (n, 3, 3))
+                cov = A @ A.transpose(0, 2, 1) * 0.01 + np.eye(3) * 1e-3
+                f.import_gm(i, rng.uniform(0.1, 1, n), mean, cov)
+        else:
+            scen = sc.make_scenario(24, 30, 6, seed=3)
+            f = pkg.RBPHDFilter(24, gm_capacity=64)
+            sc.load_scenario(f, scen)
+        D = 3 if model == "vp" else 2
+        Qs = [np.diag(np.arange(1, D + 1) * 1e-4 * (1 + 0.37 * k)) + 1e-6 * (k % 3) * (np.ones((D, D)) - np.eye(D)) for k in range(21)]
+        if batched:
+            f.static_steps_async(19, np.array(Qs[:19]))          # longer than one kernel-argument block: two launches
+            f.static_steps_async(0, None)
+            f.set_lmk_process_noise(Qs[19])
+            f.static_steps_async(2, None)                        # the noise that is set now, twice
+        else:
+            for k in range(19):
+                f.set_lmk_process_noise(Qs[k])
+                f.predict_map_async(False)
+            f.set_lmk_process_noise(Qs[19])
+            f.predict_map_async(False)
+            f.predict_map_async(False)
+        f.synchronize()
+        fs.append(f)
+    a, b = fs
+    for i in range(24):
+        for x, y in zip(a.export_gm(i), b.export_gm(i)):
+            assert np.array_equal(x, y)
