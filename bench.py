@@ -396,12 +396,14 @@ def main():
     if fused and wl["reseed"]:
         acc = np.zeros(3)
         reps = 20
+        f.set_phase_timing(True)      # (update() as three launches, each with its own event pair)
         for r in range(reps + 3):
             f.restore_state()
             f.update(Z)
             if r >= 3:
                 acc += np.array(f.last_kernel_ns()[:3], dtype=np.float64)
         phase_ms = acc / reps / 1e6
+        f.set_phase_timing(False)
 
     if rank == 0:
         per_kernel = {}

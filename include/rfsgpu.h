@@ -236,6 +236,11 @@ int rfsgpu_predict_map(rfsgpu_filter *f, int add_birth);
  * (unless useClusterProcess), merge, prune.  z: n_z x d_z doubles.  n_z == 0 returns OK without
  * touching anything (:450-452).  Resampling / normalisation stay with the caller (below). */
 int rfsgpu_update(rfsgpu_filter *f, const double *z, int n_z);
+/* rfsgpu_update runs the 2-D model's step as ONE fused launch by default and books its time under TimingInfo::mapUpdate.
+ * on != 0: the phases run as separate launches instead (updateMap, importanceWeighting, merge + prune), so that the
+ * mapUpdate / particleWeighting / mapMerge buckets of RBPHDFilter::TimingInfo (:152-167) are filled separately, as the
+ * reference's timing printout expects -- same results bit for bit, about a third more device time. */
+int rfsgpu_set_phase_timing(rfsgpu_filter *f, int on);
 /* Stream-ordered form of rfsgpu_update: enqueues the step and returns without waiting for the GPU.  With the 2-D model the
  * step is ONE kernel (a workgroup takes its particle through updateMap, importanceWeighting, merge and prune; results are
  * bit-identical to rfsgpu_update; the environment variable RFSGPU_FUSED_STEP=0 selects the three-kernel form).  Device-side

@@ -134,6 +134,10 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
     const char *dev = std::getenv("RFSGPU_DEVICE"), *cap = std::getenv("RFSGPU_GM_CAPACITY");
     const int rc = rfsgpu_create(&engine_, rfsgpu_model_of<MeasurementModel>::value, n, dev ? std::atoi(dev) : 0, cap ? std::atoi(cap) : 512);
     if (rc != RFSGPU_OK) throw std::runtime_error("rfsgpu_create failed (no gfx950 device?): status " + std::to_string(rc));
+    /* rfsgpu_update runs the 2-D step as one fused launch and books it under TimingInfo::mapUpdate_*; a driver whose timing
+     * printout (src/rbphdslam2dSim.cpp:664-679) should keep mapUpdate / particleWeighting / mapMerge apart sets
+     * RFSGPU_PHASE_TIMING=1 and gets separate launches -- the same results bit for bit, about a third more device time. */
+    if (const char *pt = std::getenv("RFSGPU_PHASE_TIMING")) rfsgpu_set_phase_timing(engine_, std::atoi(pt));
   }
 
   ~RBPHDFilter() {

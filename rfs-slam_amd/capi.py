@@ -116,7 +116,7 @@ ABI_SYMBOLS = [
     "default_fastslam_config", "set_fastslam_config", "get_fastslam_config", "fastslam_update",
     "normalize_weights_parts", "create_ex", "n_particles", "max_particles", "resample_apply_n",
     "fastslam_set_resample_occured", "particle_parents", "vp_probe_pd",
-    "slab_row_bytes", "export_slab_rows", "import_slab_rows", "weights_device_ptr", "step_async", "set_step_inputs_async", "predict_map_async", "static_steps_async", "propagate_ackerman_async", "set_partition_mode", "get_partition_mode",
+    "slab_row_bytes", "export_slab_rows", "import_slab_rows", "weights_device_ptr", "step_async", "set_step_inputs_async", "predict_map_async", "set_phase_timing", "static_steps_async", "propagate_ackerman_async", "set_partition_mode", "get_partition_mode",
     "group_create", "group_destroy", "group_last_error", "group_n_shards", "group_n_particles", "group_shard", "group_locate",
     "group_set_filter_config", "group_set_model_rngbrg", "group_set_kf_config", "group_set_lmk_process_noise", "group_set_poses",
     "group_get_poses", "group_set_weights", "group_get_weights", "group_predict_map", "group_update", "group_normalize",
@@ -459,6 +459,10 @@ class CFilter:
             scan = _f64(scan).reshape(-1)
             sp, ns = self._ptr(scan), scan.size
         self._call("set_step_inputs_async", xp, cp, C.c_int(stride), sp, C.c_int(ns))
+
+    def set_phase_timing(self, on=True):
+        """update() as three launches with per-phase TimingInfo / last_kernel_ns (True) or as one fused launch (False, default)."""
+        self._call("set_phase_timing", C.c_int(1 if on else 0))
 
     def predict_map_async(self, add_birth=True):
         self._call("predict_map_async", C.c_int(1 if add_birth else 0))

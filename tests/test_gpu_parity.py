@@ -122,6 +122,32 @@ def test_update_fused_call_and_normalise(pkg, ob, sc, kw):
     assert abs(dev.get_weights().sum() - 1) < 1e-12
 
 
+def test_update_is_one_fused_launch_unless_phase_timing_is_asked_for(pkg, sc):
+    """rfsgpu_update (what the reference-side binding calls): one fused launch by default, the whole step booked under
+    TimingInfo::mapUpdate; with rfsgpu_set_phase_timing the phases run as separate launches and fill their own buckets.
+    Same maps and weights, bit for bit."""
+    scen = sc.make_scenario(40, 90, 12, seed=77)
+    out = []
+    for phases in (False, True):
+        f = pkg.RBPHDFilter(scen["n"], gm_capacity=256)
+        sc.load_scenario(f, scen)
+        if phases:
+            f.set_phase_timing(True)
+        f.reset_timing()
+        f.update(scen["Z"])
+        t = f.getTimingInfo()
+        ns = f.last_kernel_ns()
+        if phases:
+            assert t.mapUpdate_wall > 0 and t.particleWeighting_wall > 0 and t.mapMerge_wall > 0 and ns[1] > 0 and ns[2] > 0
+        else:
+            assert t.mapUpdate_wall > 0 and t.particleWeighting_wall == 0 and t.mapMerge_wall == 0 and ns[0] > 0 and ns[1] == 0 and ns[2] == 0
+        out.append((f.get_weights(), [f.export_gm(i) for i in range(scen["n"])]))
+    assert np.array_equal(out[0][0], out[1][0])
+    for ga, gb in zip(out[0][1], out[1][1]):
+        for x, y in zip(ga, gb):
+            assert np.array_equal(x, y)
+
+
 @pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("kw", SCENARIOS[:5] + [dict(n_particles=9, n_landmarks=40, n_z=7, seed=8, use_cluster=1)])
 def test_update_async_matches_oracle(pkg, ob, sc, kw, fused, monkeypatch):

@@ -20,6 +20,7 @@ sc.load_scenario(f, scen)
 if "--exact" in sys.argv:      # RFSGPU_PARTITION_EXACT: untruncated partition sums instead of Murty-200 (opt-in; SURVEY 8(d) asks for both timings)
     f.set_partition_mode(True)
 f.save_state()
+f.set_phase_timing(True)   # (per-phase kernel times below)
 for _ in range(2):
     f.restore_state(); f.update(scen["Z"])
 S = int(os.environ.get("C5_STEPS", 10))

@@ -14,5 +14,6 @@ N = int(os.environ.get("C5_N", 1000))
 scen = sc.make_scenario(N, 200, 50, seed=555, n_clutter=10, n_eval=40, weighting_md=10.0, weights=(0.8, 1.0))
 f = pkg.RBPHDFilter(N, gm_capacity=448)
 sc.load_scenario(f, scen)
+f.set_phase_timing(True)
 f.update(scen["Z"])
 print("kernel ns:", f.last_kernel_ns())

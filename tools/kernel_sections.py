@@ -31,6 +31,7 @@ sc.load_scenario(f, scen)
 out = (C.c_longlong * 64)()
 lib.rfsgpu_debug_sections(f._h, out)  # allocates the stamp buffer
 f.save_state()
+f.set_phase_timing(True)   # (f.update below = the three stand-alone kernels)
 for _ in range(3):
     f.restore_state()
     if "--fused" in sys.argv:      # the same stamps inside the fused step kernel (weighting and merge phases; particle 7)

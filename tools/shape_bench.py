@@ -18,6 +18,7 @@ scen = sc.make_scenario(N, NM, NZ, seed=777, rmax=RMAX)
 f = pkg.RBPHDFilter(N, gm_capacity=CAP)
 sc.load_scenario(f, scen)
 f.save_state()
+f.set_phase_timing(True)   # (per-phase kernel times below)
 for _ in range(3):
     f.restore_state(); f.update(scen["Z"])
 ns = f.last_kernel_ns()
