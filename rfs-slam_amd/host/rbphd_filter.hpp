@@ -127,6 +127,8 @@ class RBPHDFilter2d {
     if (rc != RFSGPU_OK) throw std::runtime_error("rfsgpu_create_ex failed with status " + std::to_string(rc) + " (no gfx950 device? there is no CPU fallback)");
     effNParticles_t_ = double(n) / 4.0;  // ParticleFilter.hpp:232
     effNParticles_t_percent_ = effNParticles_t_ / n;
+    // (RFSGPU_PHASE_TIMING=1: update() as separate launches per phase, for a TimingInfo printout with its buckets apart)
+    if (const char *pt = std::getenv("RFSGPU_PHASE_TIMING")) rfsgpu_set_phase_timing(h_, std::atoi(pt));
   }
   // The same filter over SEVERAL GPUs from this one host thread (rfsgpu_group_*: contiguous particle blocks, one shard per
   // device id, global resampling with peer-copy migration).  Everything below dispatches on g_; the public interface is
