@@ -281,6 +281,10 @@ int rfsgpu_static_steps_async(rfsgpu_filter *f, int n, const double *noises);
  * Victoria Park driver of this repository uses it because its host loop, not a kernel, was what bounded a run. */
 int rfsgpu_propagate_ackerman_async(rfsgpu_filter *f, const double *u, const double *var, double dt, const double *geom, unsigned long long seed,
                                     unsigned long long call);
+/* A run of n such propagations (consecutive odometry messages: u [n][2], var [n][2] or NULL, dt [n], calls numbered call0,
+ * call0 + 1, ...) in ONE launch; every particle takes the steps one after the other: the same poses, bit for bit. */
+int rfsgpu_propagate_ackerman_run_async(rfsgpu_filter *f, int n, const double *u, const double *var, const double *dt, const double *geom,
+                                        unsigned long long seed, unsigned long long call0);
 /* ParticleFilter::propagate (include/ParticleFilter.hpp:322-339) for the Victoria Park driver's process model, on the device:
  * MotionModel_Ackerman2d::step (src/ProcessModel_Ackerman2D.cpp:47-78) applied to every particle's pose with its own noisy
  * input u + N(0, diag(var)) (ProcessModel::sample's input-noise branch, include/ProcessModel.hpp:126-150).  u = {speed,

@@ -116,7 +116,7 @@ ABI_SYMBOLS = [
     "default_fastslam_config", "set_fastslam_config", "get_fastslam_config", "fastslam_update",
     "normalize_weights_parts", "create_ex", "n_particles", "max_particles", "resample_apply_n",
     "fastslam_set_resample_occured", "particle_parents", "vp_probe_pd",
-    "slab_row_bytes", "export_slab_rows", "import_slab_rows", "weights_device_ptr", "step_async", "set_step_inputs_async", "predict_map_async", "set_phase_timing", "static_steps_async", "propagate_ackerman_async", "set_partition_mode", "get_partition_mode",
+    "slab_row_bytes", "export_slab_rows", "import_slab_rows", "weights_device_ptr", "step_async", "set_step_inputs_async", "predict_map_async", "set_phase_timing", "static_steps_async", "propagate_ackerman_async", "propagate_ackerman_run_async", "set_partition_mode", "get_partition_mode",
     "group_create", "group_destroy", "group_last_error", "group_n_shards", "group_n_particles", "group_shard", "group_locate",
     "group_set_filter_config", "group_set_model_rngbrg", "group_set_kf_config", "group_set_lmk_process_noise", "group_set_poses",
     "group_get_poses", "group_set_weights", "group_get_weights", "group_predict_map", "group_update", "group_normalize",
@@ -480,6 +480,16 @@ class CFilter:
         vp = (C.c_double * 2)(float(var[0]), float(var[1])) if var is not None else None
         gp = (C.c_double * 4)(*[float(g) for g in geom])
         self._call("propagate_ackerman_async", up, vp, C.c_double(float(dt)), gp, C.c_ulonglong(int(seed)), C.c_ulonglong(int(call)))
+
+    def propagate_ackerman_run_async(self, u, var, dt, geom, seed, call0):
+        """n propagations in one launch: u [n][2], var [n][2] or None, dt [n]."""
+        u = _f64(u).reshape(-1, 2)
+        n = u.shape[0]
+        v = _f64(var, (n, 2)) if var is not None else None
+        d = _f64(dt, (n,))
+        gp = (C.c_double * 4)(*[float(g) for g in geom])
+        self._call("propagate_ackerman_run_async", C.c_int(n), self._ptr(u), self._ptr(v) if v is not None else None, self._ptr(d), gp,
+                   C.c_ulonglong(int(seed)), C.c_ulonglong(int(call0)))
 
     # -- cross-shard migration (packed rows in the backend's own memory space: device memory for the engine) ----------
     def slab_row_bytes(self):

@@ -35,9 +35,17 @@ struct AckermanStep {
   unsigned long long seed, call;
 };
 
-__global__ __launch_bounds__(256) void propagate_ackerman_kernel(double *pose, int N, AckermanStep A) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
+// A run of steps (consecutive odometry messages, each with its own input, noise and interval) in one launch: every particle
+// takes them one after the other, so the poses have the same bits as one launch per message.
+#define ACKERMAN_RUN_MAX 16
+struct AckermanRun {
+  int n;
+  double uv[ACKERMAN_RUN_MAX], ur[ACKERMAN_RUN_MAX], sv[ACKERMAN_RUN_MAX], sr[ACKERMAN_RUN_MAX], dt[ACKERMAN_RUN_MAX];
+  double h, l, dx, dy;
+  unsigned long long seed, call0;
+};
+
+__device__ __forceinline__ void ackerman_step_particle(double *pose, int i, const AckermanStep &A) {
   double uv = A.uv, ur = A.ur;
   if (A.sv != 0.0 || A.sr != 0.0) {
     unsigned r[4];
@@ -56,4 +64,21 @@ __global__ __launch_bounds__(256) void propagate_ackerman_kernel(double *pose, i
   if (th > RFS_PI) th -= 2 * RFS_PI;
   else if (th < -RFS_PI) th += 2 * RFS_PI;
   pose[3 * i + 2] = th;
+}
+
+__global__ __launch_bounds__(256) void propagate_ackerman_kernel(double *pose, int N, AckermanStep A) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) ackerman_step_particle(pose, i, A);
+}
+
+__global__ __launch_bounds__(256) void propagate_ackerman_run_kernel(double *pose, int N, AckermanRun R) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  for (int k = 0; k < R.n; k++) {
+    AckermanStep A;
+    A.uv = R.uv[k]; A.ur = R.ur[k]; A.sv = R.sv[k]; A.sr = R.sr[k]; A.dt = R.dt[k];
+    A.h = R.h; A.l = R.l; A.dx = R.dx; A.dy = R.dy;
+    A.seed = R.seed; A.call = R.call0 + (unsigned long long)k;
+    ackerman_step_particle(pose, i, A);
+  }
 }

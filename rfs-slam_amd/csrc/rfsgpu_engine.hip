@@ -1098,6 +1098,32 @@ int rfsgpu_propagate_ackerman_async(rfsgpu_filter *f, const double *u, const dou
   return RFSGPU_OK;
 }
 
+// A run of n propagations (consecutive odometry messages) in one launch: u [n][2], var [n][2] or NULL, dt [n]; the calls are
+// numbered call0, call0 + 1, ...  Same poses, bit for bit, as n calls of rfsgpu_propagate_ackerman_async.
+int rfsgpu_propagate_ackerman_run_async(rfsgpu_filter *f, int n, const double *u, const double *var, const double *dt, const double *geom,
+                                        unsigned long long seed, unsigned long long call0) {
+  CHECK_HANDLE(f);
+  if (n < 0 || (n > 0 && (!u || !dt || !geom))) return fail(f, RFSGPU_ERR_INVALID, "propagate_ackerman_run: bad arguments");
+  for (int k = 0; k < n; k++)
+    if (!(dt[k] == dt[k]) || (var && (var[2 * k] < 0 || var[2 * k + 1] < 0))) return fail(f, RFSGPU_ERR_INVALID, "propagate_ackerman_run: bad interval / negative variance");
+  hipSetDevice(f->device);
+  for (int k0 = 0; k0 < n; k0 += ACKERMAN_RUN_MAX) {
+    AckermanRun R;
+    R.n = std::min(ACKERMAN_RUN_MAX, n - k0);
+    for (int r = 0; r < R.n; r++) {
+      const int k = k0 + r;
+      R.uv[r] = u[2 * k]; R.ur[r] = u[2 * k + 1];
+      R.sv[r] = var ? std::sqrt(var[2 * k]) : 0.0; R.sr[r] = var ? std::sqrt(var[2 * k + 1]) : 0.0;
+      R.dt[r] = dt[k];
+    }
+    R.h = geom[0]; R.l = geom[1]; R.dx = geom[2]; R.dy = geom[3];
+    R.seed = seed; R.call0 = call0 + (unsigned long long)k0;
+    propagate_ackerman_run_kernel<<<(f->N + 255) / 256, 256, 0, f->stream>>>(f->B.pose, f->N, R);
+    HIPCHK(hipGetLastError());
+  }
+  return RFSGPU_OK;
+}
+
 // Everything a step consumes from the host in ONE stream-ordered call: poses (+ covariance) and, for the Victoria Park model,
 // the laser scan (MeasurementModel_VictoriaPark::setLaserScan, src/MeasurementModel_VictoriaPark.cpp:267-281).  The caller's
 // buffers are copied into a pinned staging ring before the call returns; the host never waits for the device (except when all

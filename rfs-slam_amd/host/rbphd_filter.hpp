@@ -236,7 +236,22 @@ class RBPHDFilter2d {
   // device-side propagation (RBPHDFilterVP::setDeviceMotion): the device owns the poses, the host copy is fetched on demand
   bool devicePoses_ = false;
   mutable bool hostPosesStale_ = false;
+  // propagations queued for the device (RBPHDFilterVP with setDeviceMotion): a run of odometry messages goes out as ONE launch
+  // (rfsgpu_propagate_ackerman_run_async) before the next call that reads the poses
+  mutable std::vector<double> pendU_, pendVar_, pendDt_;
+  double pendGeom_[4] = {0, 0, 0, 0};
+  unsigned long long motionSeed_ = 0;
+  mutable unsigned long long motionCall_ = 0;
+  void flushMotion() const {
+    if (pendDt_.empty()) return;
+    const int n = (int)pendDt_.size();
+    if (rfsgpu_propagate_ackerman_run_async(h_, n, pendU_.data(), pendVar_.data(), pendDt_.data(), pendGeom_, motionSeed_, motionCall_) != RFSGPU_OK)
+      throw std::runtime_error(std::string("propagate_ackerman_run: ") + rfsgpu_last_error(h_));
+    motionCall_ += (unsigned long long)n;
+    pendU_.clear(); pendVar_.clear(); pendDt_.clear();
+  }
   void pullPoses() const {
+    flushMotion();
     if (!hostPosesStale_) return;
     std::vector<double> x(3 * (size_t)n_);
     if (rfsgpu_get_poses(h_, x.data()) != RFSGPU_OK) throw std::runtime_error(std::string("get_poses: ") + rfsgpu_last_error(h_));
@@ -321,6 +336,7 @@ class RBPHDFilter2d {
   // ParticleFilter::resample(n, forceResample) (ParticleFilter.hpp:399-492).  nOut == 0 or > nParticles_ keeps the count; a
   // smaller nOut draws nOut samples from all particles and shrinks the set (FastSLAM::resampleWithMapCopy).
   bool resample(unsigned nOut = 0, bool force = false, bool alreadyNormalized = false) {
+    flushMotion();
     if (!alreadyNormalized) normalizeWeights();
     pullWeights();
     const int N = n_;
@@ -532,7 +548,7 @@ class RBPHDFilterVP : public RBPHDFilter2d {
   MotionModel_Ackerman2d *getProcessModel() { return &ackerman_; }
   // ParticleFilter::propagate on the device (rfsgpu_propagate_ackerman_async, csrc/motion.h): poses stay there, the host fetches
   // them when asked (getParticlePose).  Off by default: the host loop below is the reference's shape.
-  void setDeviceMotion(bool on, unsigned long long seed = 0) { pullPoses(); devicePoses_ = on; motionSeed_ = seed; }
+  void setDeviceMotion(bool on, unsigned long long seed = 0) { pullPoses(); devicePoses_ = on; motionSeed_ = seed; motionCall_ = 0; }
   LmkProcessModel3d *getLmkProcessModel() { return &lmk3_; }
   MeasurementModelVP *getMeasurementModel() { return &measVP_; }
 
@@ -555,6 +571,7 @@ class RBPHDFilterVP : public RBPHDFilter2d {
     // nine of ten Victoria Park messages are such predicts.
     if (birthGaussianCheck) {
       flushStatic();
+      flushMotion();   // (the births below are born at the poses reached so far)
       check(rfsgpu_predict_map_async(h_, 1), "predict_map");   // stream-ordered: no host wait
     } else {
       pendingStatic_.insert(pendingStatic_.end(), lmk3_.Q, lmk3_.Q + 9);   // this predict's own Q (the driver scales it with dT)
@@ -568,7 +585,10 @@ class RBPHDFilterVP : public RBPHDFilter2d {
       const double zeroVar[2] = {0, 0};
       double geom[4];
       ackerman_.getAckermanParams(geom);
-      check(rfsgpu_propagate_ackerman_async(h_, u.u, useInputNoise ? u.var : zeroVar, dT, geom, motionSeed_, motionCall_++), "propagate_ackerman");
+      std::memcpy(pendGeom_, geom, sizeof(geom));
+      pendU_.insert(pendU_.end(), u.u, u.u + 2);
+      pendVar_.insert(pendVar_.end(), useInputNoise ? u.var : zeroVar, (useInputNoise ? u.var : zeroVar) + 2);
+      pendDt_.push_back(dT);                       // applied by flushMotion() before the next call that reads the poses
       hostPosesStale_ = true;
       return;
     }
@@ -622,6 +642,7 @@ class RBPHDFilterVP : public RBPHDFilter2d {
     if (meas.empty()) return;  // :450-452
     nMeasurementsSinceResample_ += (unsigned)meas.size();
     pushConfigVP();
+    flushMotion();
     pushInputsAsync();
     flushStatic();
     std::vector<double> z(3 * meas.size());
@@ -668,7 +689,6 @@ class RBPHDFilterVP : public RBPHDFilter2d {
     pendingStatic_.clear();
   }
   MotionModel_Ackerman2d ackerman_;
-  unsigned long long motionSeed_ = 0, motionCall_ = 0;
   LmkProcessModel3d lmk3_;
   MeasurementModelVP measVP_;
 

@@ -143,3 +143,34 @@ def test_static_steps_in_one_launch_give_the_same_bits(model):
     for i in range(24):
         for x, y in zip(a.export_gm(i), b.export_gm(i)):
             assert np.array_equal(x, y)
+
+
+@pytest.mark.gpu
+def test_a_run_of_propagations_in_one_launch_gives_the_same_bits():
+    """rfsgpu_propagate_ackerman_run_async(n, ...) == n calls of rfsgpu_propagate_ackerman_async with calls call0, call0 + 1, ..."""
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    n = 3000
+    rng = np.random.default_rng(11)
+    x0 = np.column_stack([rng.uniform(-50, 50, n), rng.uniform(-50, 50, n), rng.uniform(-np.pi, np.pi, n)])
+    steps = 21                                                   # more than one kernel-argument block
+    u = np.column_stack([rng.uniform(0, 6, steps), rng.uniform(-0.3, 0.3, steps)])
+    var = np.column_stack([np.full(steps, 0.2), np.full(steps, 0.025)])
+    var[4] = 0.0                                                 # a noise-free step in between
+    dt = rng.uniform(0.01, 0.05, steps)
+    out = []
+    for batched in (False, True):
+        f = pkg.RBPHDFilter(n, gm_capacity=64, model=pkg.capi.MODEL_VICTORIAPARK_3D)
+        f.set_poses(x0)
+        if batched:
+            f.propagate_ackerman_run_async(u, var, dt, GEOM, seed=5, call0=40)
+        else:
+            for k in range(steps):
+                f.propagate_ackerman_async(u[k], var[k], dt[k], GEOM, seed=5, call=40 + k)
+        f.synchronize()
+        out.append(f.get_poses())
+    assert np.array_equal(out[0], out[1])
+    want = x0
+    for k in range(steps):
+        want = ackerman_reference(want, u[k], var[k], dt[k], GEOM, 5, 40 + k)
+    np.testing.assert_allclose(out[1], want, rtol=1e-9, atol=1e-9)
