@@ -20,16 +20,18 @@
 // distance prefilter; the fp32 copies only feed the prefilter, whose thresholds carry the fp32 rounding bound, so it can
 // let extra pairs through but never drop one.  (Until r02 the entries were 40 B -- x, y, bound as fp64 -- which set the
 // fused kernel's LDS block and with it how many particles of the configs[2] shard are resident.)
-#define MERGE_GX 32  // grid cells along x
-#define MERGE_GY 32  // grid cells along y
-#define MERGE_CELLS (MERGE_GX * MERGE_GY)
-#define MERGE_LOG_CELLS 10  // log2(MERGE_CELLS): the fused prune's rank sort reuses the grid's cursor array as its histogram
-static_assert((1 << MERGE_LOG_CELLS) == MERGE_CELLS, "MERGE_LOG_CELLS");
+// The grid has (1 << GL) x (1 << GL) cells; GL is a template parameter of the merge (5, or 6 where the host finds that the 6 KB of
+// extra cursors do not cost a resident workgroup -- large mixtures, where cells of extent / 32 are several merge radii wide and
+// the 3 x 3 neighbourhood of an entry holds a multiple of the entries it needs to).  Results do not depend on GL: the grid only
+// proposes pairs, the exact tests decide, and a row that could meet partners beyond its listed ones falls back to the
+// reference's scan.  (A run-time GL was tried first: its cell arithmetic cost 3 us at configs[1].)
+#define MERGE_LOG_CELLS 10  // the fused prune's rank sort reuses the grid's cursor array as a 1024-bucket histogram (fits either grid)
+__host__ __device__ constexpr int merge_cells(int gridLog) { return 1 << (2 * gridLog); }
 #define MERGE_PAIR_CAP(cap) ((cap) > 320 ? (cap) : 320)  // listed partners per particle: ~0.7 per entry on dense maps
 #define MERGE_ROW_SLOTS 8   // prefilter survivors one row can list; a row with more is replayed by the sequential scan
-__host__ __device__ inline size_t merge_lds_bytes_per_wave(int cap) {
+__host__ __device__ inline size_t merge_lds_bytes_per_wave(int cap, int gridLog = 5) {
   // entries: w (f64) + x, y, radius (f32) + row record (u32) + grid-sorted index (u16) + prefilter slack (u16); grid: CELLS/2+4 u32; pair list: u32
-  return (((size_t)cap * (8 + 3 * 4 + 4 + 2 + 2)) + (size_t)(MERGE_CELLS / 2 + 4) * 4 + (size_t)MERGE_PAIR_CAP(cap) * 4 + 16 + 15) & ~(size_t)15;
+  return (((size_t)cap * (8 + 3 * 4 + 4 + 2 + 2)) + (size_t)(merge_cells(gridLog) / 2 + 4) * 4 + (size_t)MERGE_PAIR_CAP(cap) * 4 + 16 + 15) & ~(size_t)15;
 }
 // Row record (sRec[m]): [31:25] claim of the speculative round (lane, 0x7f = none) | [24] the row has a partner that
 // passes the exact test against the initial states | [23:20] number of listed survivors (15 = not listable) |
@@ -37,8 +39,8 @@ __host__ __device__ inline size_t merge_lds_bytes_per_wave(int cap) {
 #define MERGE_REC_NOCLAIM 0xfe000000u
 #define MERGE_REC_ISROW 0x01000000u
 // + cross-wave reduction scratch ([waves][8] floats) when a workgroup of several waves works on one particle
-__host__ __device__ inline size_t merge_lds_bytes_per_block(int cap, int wavesPerParticle) {
-  return merge_lds_bytes_per_wave(cap) + (size_t)wavesPerParticle * 32;
+__host__ __device__ inline size_t merge_lds_bytes_per_block(int cap, int wavesPerParticle, int gridLog = 5) {
+  return merge_lds_bytes_per_wave(cap, gridLog) + (size_t)wavesPerParticle * 32;
 }
 
 // Necessary condition for a pair to pass the merge test: md2 = e^T S^-1 e >= |e|^2 / lambda_max(S) >= |e|^2 / tr(S),
@@ -95,15 +97,16 @@ __device__ __forceinline__ bool merge_pair_passes(double e0, double e1, double a
 #ifndef MERGE_WAVES_PER_EU
 #define MERGE_WAVES_PER_EU 4  // 128 VGPRs: with 2 waves per particle all ~2000 particles of C2 are resident at once
 #endif
-template <int WPP, bool FUSE_PRUNE>
+template <int WPP, bool FUSE_PRUNE, int GL = 5>
 __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params &P, const int cur, const int dst, const int i, const int tid,
                                                   unsigned char *smem_raw, const unsigned short *perm = nullptr) {
   constexpr int NT = WPP * 64;
+  constexpr int MERGE_GX = 1 << GL, MERGE_GY = 1 << GL, MERGE_CELLS = MERGE_GX * MERGE_GY;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int cap = B.cap;
   unsigned char *wbase = smem_raw;
-  float *sRed = reinterpret_cast<float *>(smem_raw + merge_lds_bytes_per_wave(cap));  // [WPP][8] cross-wave reduction scratch
+  float *sRed = reinterpret_cast<float *>(smem_raw + merge_lds_bytes_per_wave(cap, GL));  // [WPP][8] cross-wave reduction scratch
   auto block_sync = [&]() { if (WPP == 1) wave_sync(); else __syncthreads(); };
   double *sW = reinterpret_cast<double *>(wbase);                          // [cap] weight (exact)
   float *sX = reinterpret_cast<float *>(sW + cap), *sY = sX + cap;          // [cap] position, fp32 (prefilter only)
@@ -200,19 +203,37 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     // exclusive scan over the CELLS + 1 half-word entries: lane l owns entries 16l .. 16l + 15 (8 words); entry CELLS (the
     // low half of the last word) receives the total
     constexpr int WPL = MERGE_CELLS / 128;  // words per lane
-    unsigned wv[WPL];
-    int tot = 0;
+    int off;
+    if constexpr (WPL <= 8) {
+      unsigned wv[WPL];
+      int tot = 0;
 #pragma unroll
-    for (int k = 0; k < WPL; k++) { wv[k] = sCellStart[WPL * lane + k]; tot += (int)(wv[k] & 0xffffu) + (int)(wv[k] >> 16); }
-    int off = wave_excl_scan(tot, lane);
-    wave_sync();
+      for (int k = 0; k < WPL; k++) { wv[k] = sCellStart[WPL * lane + k]; tot += (int)(wv[k] & 0xffffu) + (int)(wv[k] >> 16); }
+      off = wave_excl_scan(tot, lane);
+      wave_sync();
 #pragma unroll
-    for (int k = 0; k < WPL; k++) {
-      const unsigned lo = (unsigned)off;
-      off += (int)(wv[k] & 0xffffu);
-      const unsigned hi = (unsigned)off;
-      off += (int)(wv[k] >> 16);
-      sCellStart[WPL * lane + k] = lo | (hi << 16);
+      for (int k = 0; k < WPL; k++) {
+        const unsigned lo = (unsigned)off;
+        off += (int)(wv[k] & 0xffffu);
+        const unsigned hi = (unsigned)off;
+        off += (int)(wv[k] >> 16);
+        sCellStart[WPL * lane + k] = lo | (hi << 16);
+      }
+    } else {  // 64 x 64: 32 words per lane, read twice rather than held in registers
+      int tot = 0;
+      for (int k = 0; k < WPL; k += 4) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(&sCellStart[WPL * lane + k]);
+        tot += (int)(v.x & 0xffffu) + (int)(v.x >> 16) + (int)(v.y & 0xffffu) + (int)(v.y >> 16) + (int)(v.z & 0xffffu) + (int)(v.z >> 16) + (int)(v.w & 0xffffu) + (int)(v.w >> 16);
+      }
+      off = wave_excl_scan(tot, lane);
+      for (int k = 0; k < WPL; k++) {   // (every lane rewrites only its own words)
+        const unsigned v = sCellStart[WPL * lane + k];
+        const unsigned lo = (unsigned)off;
+        off += (int)(v & 0xffffu);
+        const unsigned hi = (unsigned)off;
+        off += (int)(v >> 16);
+        sCellStart[WPL * lane + k] = lo | (hi << 16);
+      }
     }
     if (lane == 63) sCellStart[MERGE_CELLS / 2] = (unsigned)off;  // entry CELLS = the cursor of the last cell... (see below)
   }
@@ -726,7 +747,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     plane(dl, cap, i, PL_SYY)[rank] = vyy;
   };
   // ranks among the survivors through the weighting phase's bucket sort (weighting.h): the grid's cursor array is the
-  // histogram (MERGE_CELLS buckets), the pair list holds the bucket order, ties rank by list position (= ascending index)
+  // histogram (1024 buckets, inside either grid's cursor array), the pair list holds the bucket order, ties rank by list position (= ascending index)
   constexpr int NS = 8;
   bool ranked = false;
   if (nSurv <= NS * NT) {

@@ -94,6 +94,7 @@ struct rfsgpu_filter {
   bool fuseSteps = true;    // rfsgpu_update / _update_async / _step_async use phd_step_fused_kernel (2-D model); RFSGPU_FUSED_STEP=0 turns it off
   bool phaseTiming = false; // rfsgpu_set_phase_timing: rfsgpu_update runs its phases as separate launches (TimingInfo per phase)
   int stepWppOverride = 0;  // RFSGPU_STEP_WPP: waves per particle of the fused step kernel (2 or 3); 0 = chosen per launch
+  int mergeGridOverride = 0; // RFSGPU_MERGE_GRID: log2 of the merge grid's cells per side in the three-wave fused kernel (5 or 6); 0 = chosen per launch
   hipEvent_t evAfterWeightKernel = nullptr;   // where launch_weighting drops its mid-phase event (async steps only)
   int ringCount = 0;        // async steps recorded since the last harvest
   double statNs[3] = {0, 0, 0};
@@ -242,6 +243,7 @@ int rfsgpu_create_ex(rfsgpu_filter **out, int model, int n_particles, int device
   f->fs.nParticlesMax = 3 * n_particles;
   { const char *e = getenv("RFSGPU_FUSED_STEP"); if (e && e[0] == '0') f->fuseSteps = false; }
   { const char *e = getenv("RFSGPU_STEP_WPP"); if (e) f->stepWppOverride = atoi(e); }
+  { const char *e = getenv("RFSGPU_MERGE_GRID"); if (e) f->mergeGridOverride = atoi(e); }
   if (f->cap > 2048) { delete f; return RFSGPU_ERR_INVALID; }
   auto bail = [&](int code) { rfsgpu_destroy(f); return code; };
   if (hipSetDevice(device_id) != hipSuccess) return bail(RFSGPU_ERR_NO_DEVICE);
@@ -937,10 +939,23 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
       if (phasePrio) phd_step_fused_kernel<2, true><<<f->N, 128, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
       else phd_step_fused_kernel<2, false><<<f->N, 128, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
     } else {
-      if ((rc = set_lds(f, (phd_step_fused_kernel<3, true>), b)) != RFSGPU_OK) return rc;
-      if ((rc = set_lds(f, (phd_step_fused_kernel<3, false>), b)) != RFSGPU_OK) return rc;
-      if (phasePrio) phd_step_fused_kernel<3, true><<<f->N, 192, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
-      else phd_step_fused_kernel<3, false><<<f->N, 192, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
+      // the 64 x 64 merge grid where its 6 KB of extra cursors leave as many three-wave workgroups resident (merge_prune.h);
+      // RFSGPU_MERGE_GRID = 5 | 6 overrides
+      const size_t b6 = step_fused_lds_total(f->cap, ec, f->nZ, 3, 6);
+      const int perCU6 = (int)std::min<size_t>(16 / 3, b6 ? (size_t)(160 * 1024) / b6 : 16);
+      const bool fine = f->mergeGridOverride ? f->mergeGridOverride == 6 : (perCU6 == perCU && perCU6 > 0);
+      if (fine) {
+        const int prio6 = (long long)perCU6 * f->nCU >= f->N ? 1 : 0;
+        if ((rc = set_lds(f, (phd_step_fused_kernel<3, true, 6>), b6)) != RFSGPU_OK) return rc;
+        if ((rc = set_lds(f, (phd_step_fused_kernel<3, false, 6>), b6)) != RFSGPU_OK) return rc;
+        if (prio6) phd_step_fused_kernel<3, true, 6><<<f->N, 192, b6, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
+        else phd_step_fused_kernel<3, false, 6><<<f->N, 192, b6, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
+      } else {
+        if ((rc = set_lds(f, (phd_step_fused_kernel<3, true>), b)) != RFSGPU_OK) return rc;
+        if ((rc = set_lds(f, (phd_step_fused_kernel<3, false>), b)) != RFSGPU_OK) return rc;
+        if (phasePrio) phd_step_fused_kernel<3, true><<<f->N, 192, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
+        else phd_step_fused_kernel<3, false><<<f->N, 192, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
+      }
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e[3], f->stream));

@@ -22,22 +22,22 @@
 #define STEP_WAVES_PER_EU 4  // <= 128 VGPRs: 8 workgroups of 2 waves per CU, i.e. all 2000 particles of C2 resident at once
 #endif
 
-__host__ __device__ inline size_t step_fused_lds_bytes(int cap, int evalCap, int nZ, int wpp) {
+__host__ __device__ inline size_t step_fused_lds_bytes(int cap, int evalCap, int nZ, int wpp, int gridLog = 5) {
   size_t a = (size_t)RFS_Z_LDS_BYTES + update_map_block_lds_bytes(cap);
   const size_t b = (size_t)RFS_Z_LDS_BYTES + weight_lds_bytes_per_wave(cap, evalCap, nZ) + WEIGHT_SCRATCH_BYTES;
-  const size_t c = merge_lds_bytes_per_block(cap, wpp);
+  const size_t c = merge_lds_bytes_per_block(cap, wpp, gridLog);
   if (b > a) a = b;
   if (c > a) a = c;
   return (a + 15) & ~(size_t)15;
 }
 // + the sorting permutation ([cap] u16) handed from the weighting phase to the merge phase, behind every phase's own layout
-__host__ __device__ inline size_t step_fused_lds_total(int cap, int evalCap, int nZ, int wpp) {
-  return step_fused_lds_bytes(cap, evalCap, nZ, wpp) + (((size_t)cap * 2 + 15) & ~(size_t)15);
+__host__ __device__ inline size_t step_fused_lds_total(int cap, int evalCap, int nZ, int wpp, int gridLog = 5) {
+  return step_fused_lds_bytes(cap, evalCap, nZ, wpp, gridLog) + (((size_t)cap * 2 + 15) & ~(size_t)15);
 }
 
 // useWeighting == 0: SC-PHD (useClusterProcess_): the particle weight comes out of the map update, the mixture is not
 // sorted, merge works on the slab the update wrote.
-template <int WPP, bool PHASE_PRIO>
+template <int WPP, bool PHASE_PRIO, int GL = 5>
 __global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(STEP_WAVES_PER_EU)))
 void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, int useWeighting, MurtyQueue Q, ZArg zarg) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -85,7 +85,7 @@ void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, in
   if (PHASE_PRIO) __builtin_amdgcn_s_setprio(STEP_W_PRIO);
   // The weighting phase sorts the mixture by weight (sortByWeight, include/RBPHDFilter.hpp:733) -- as a permutation kept in
   // LDS; the merge phase walks the slab through it, so the sorted mixture is never written out and read back.
-  unsigned short *sPerm = reinterpret_cast<unsigned short *>(smem_raw + step_fused_lds_bytes(B.cap, evalCap, nZ, WPP));
+  unsigned short *sPerm = reinterpret_cast<unsigned short *>(smem_raw + step_fused_lds_bytes(B.cap, evalCap, nZ, WPP, GL));
   const unsigned short *mergePerm = nullptr;
   if (useWeighting) {
     phd_weight_particle<WPP>(B, P, cur, cur ^ 1, nZ, evalCap, Q, i, tidW, smem_raw, sPerm);
@@ -100,7 +100,7 @@ void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, in
 #ifdef RFS_PROFILE
   if (fd && tid == 0) fd[2] = (long long)wall_clock64();
 #endif
-  gm_merge_particle<WPP, true>(B, P, mergeSrc, mergeSrc ^ 1, i, tidM, smem_raw, mergePerm);
+  gm_merge_particle<WPP, true, GL>(B, P, mergeSrc, mergeSrc ^ 1, i, tidM, smem_raw, mergePerm);
 #ifdef RFS_PROFILE
   if (fd && tid == 0) fd[3] = (long long)wall_clock64();
 #endif
