@@ -969,10 +969,15 @@ __global__ __launch_bounds__(256) void restore_state_kernel(Buffers B, int cur, 
                                                             const int *snapCount, const int *snapFov, const unsigned long long *snapUnused) {
   const int k = blockIdx.x;
   const int n = snapCount[k];
-  for (int pl = 0; pl < B.npl; pl++) {
-    const double *q = snapSlab + ((size_t)k * B.npl + pl) * (size_t)B.cap;
-    double *d = B.slab[cur] + ((size_t)k * B.npl + pl) * (size_t)B.cap;
-    for (int m = threadIdx.x; m < n; m += blockDim.x) d[m] = q[m];
+  // every plane's element of an entry is loaded before the first is stored: up to eleven loads in flight per thread
+  const double *q0 = snapSlab + (size_t)k * B.npl * (size_t)B.cap;
+  double *d0 = B.slab[cur] + (size_t)k * B.npl * (size_t)B.cap;
+  for (int m = threadIdx.x; m < n; m += blockDim.x) {
+    double v[11];
+#pragma unroll
+    for (int pl = 0; pl < 11; pl++) v[pl] = (pl < B.npl) ? q0[(size_t)pl * B.cap + m] : 0.0;
+#pragma unroll
+    for (int pl = 0; pl < 11; pl++) if (pl < B.npl) d0[(size_t)pl * B.cap + m] = v[pl];
   }
   if (threadIdx.x == 0) {
     B.count[k] = n;
