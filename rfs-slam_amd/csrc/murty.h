@@ -7,7 +7,7 @@
 // offset add/subtract in the Hungarian solver, same binary-heap discipline as std::priority_queue.
 //
 // Jobs are produced by phd_weight_multifeature_kernel (weighting.h) into a device queue; murty_jobs_kernel consumes
-// them -- one workgroup of two wavefronts per job: the tree search stays serial, the Hungarian solver inside it
+// them -- one workgroup of MURTY_JOB_WAVES (four) wavefronts per job: the tree search stays serial, the Hungarian solver inside it
 // (hungarian_wave.h) and the sub-problem / assignment bookkeeping run across the lanes, the children of an expansion across
 // the waves -- and multiplies each job's partition likelihood into its
 // particle's weight in partition order.  Node pool, heap and root table live in HBM (per-job arena), sub-problem tables
@@ -182,7 +182,9 @@ __device__ __forceinline__ bool murty_root_wave(double *C, int n, MurtyArena &A,
   murty_publish();   // node 0's assignment is read back lane-crossed (the caller's policies, the first expansion)
   return true;
 }
-#define MURTY_LDS_N 32   // sub-problems up to this dimension are solved in an 8 KB LDS tile
+#ifndef MURTY_LDS_N
+#define MURTY_LDS_N 24   // sub-problems up to this dimension are solved in a 4.5 KB LDS tile per wave (larger ones in the job's arena)
+#endif
 
 // One partition: sum of exp(score) over the <= 200 best assignments (RBPHDFilter.hpp:948-959).
 // Murty's ranked enumeration by one WORKGROUP of W wavefronts: the children of an expansion -- independent sub-problems --
@@ -323,7 +325,7 @@ __device__ __forceinline__ double murty_partition_sum_block(double *C, int n, in
 // Q.count[1] = finished-workgroup ticket.  With an empty queue (the common case: no partition above 8) every workgroup
 // exits at once -- one empty launch, no host round trip.
 #ifndef MURTY_JOB_WAVES
-#define MURTY_JOB_WAVES 2
+#define MURTY_JOB_WAVES 4   // measured at configs[4] (1918 jobs of dimension 9-15): 1 wave 26.8 ms, 2: 16.5, 3: 15.4, 4: 15.1 (14.9 with 16 x 16 tiles)
 #endif
 #define MURTY_JOB_BLOCKS 2048
 // Besides the Murty jobs this is the step's POST kernel: whoever finishes last (block 0 alone when the queue is empty -- the
