@@ -20,6 +20,10 @@
 #define MURTY_N 64             /* max extended dimension nR + nC handled on the device */
 #define MURTY_KBEST 200
 #define MURTY_MAX_NODES 6401   /* 1 root + <= 200 expansions x <= 32 children */
+#ifndef MURTY_JOB_WAVES
+#define MURTY_JOB_WAVES 4   // measured at configs[4] (1918 jobs of dimension 9-15): 1 wave 26.8 ms, 2: 16.5, 3: 15.4, 4: 15.1 (14.9 with 16 x 16 tiles)
+#endif
+#define MURTY_CT_WAVES (MURTY_JOB_WAVES > 4 ? MURTY_JOB_WAVES : 4)   /* (the multi-hypothesis FastSLAM search uses up to four waves on the same arena) */
 
 struct MurtyScratch {
   unsigned char *arena;   // [maxJobs][jobBytes]
@@ -41,7 +45,7 @@ struct MurtyArena {
 
 __host__ __device__ inline size_t murty_job_bytes() {
   size_t b = 0;
-  b += (size_t)4 * MURTY_N * MURTY_N * 8;  // Ct, one per wave of the job's workgroup (MURTY_JOB_WAVES <= 4)
+  b += (size_t)MURTY_CT_WAVES * MURTY_N * MURTY_N * 8;  // Ct, one per wave of the job's workgroup
   b += 3 * MURTY_N * 8;                    // lx ly slack
   b += (1 + 1 + 2 + 2) * MURTY_N * 4;      // xy yx p queue
   b += 5 * MURTY_N;                        // flags
@@ -55,7 +59,7 @@ __host__ __device__ inline size_t murty_job_bytes() {
 
 __device__ inline void murty_carve(unsigned char *base, MurtyArena &A) {
   unsigned char *p = base;
-  A.Ct = (double *)p; p += (size_t)4 * MURTY_N * MURTY_N * 8;
+  A.Ct = (double *)p; p += (size_t)MURTY_CT_WAVES * MURTY_N * MURTY_N * 8;
   A.lx = (double *)p; p += MURTY_N * 8;
   A.ly = (double *)p; p += MURTY_N * 8;
   A.slack = (double *)p; p += MURTY_N * 8;
@@ -324,9 +328,6 @@ __device__ __forceinline__ double murty_partition_sum_block(double *C, int n, in
 // finish multiplies every particle's factors into its weight, in partition (slot) order.  Q.count[0] = number of jobs,
 // Q.count[1] = finished-workgroup ticket.  With an empty queue (the common case: no partition above 8) every workgroup
 // exits at once -- one empty launch, no host round trip.
-#ifndef MURTY_JOB_WAVES
-#define MURTY_JOB_WAVES 4   // measured at configs[4] (1918 jobs of dimension 9-15): 1 wave 26.8 ms, 2: 16.5, 3: 15.4, 4: 15.1 (14.9 with 16 x 16 tiles)
-#endif
 #define MURTY_JOB_BLOCKS 2048
 // Besides the Murty jobs this is the step's POST kernel: whoever finishes last (block 0 alone when the queue is empty -- the
 // usual case: at the shipped 3-sigma gate Murty is never entered) multiplies the Murty factors into the particle weights,
@@ -368,8 +369,30 @@ __device__ __forceinline__ void step_post_tail(double *weight, int N, double *su
     for (int j = 0; j < U; j++) { const int k = k0 + j * (int)blockDim.x; if (k < N) weight[k] = v[j] / d; }
   }
 }
+// Longest jobs first: a job's duration grows with its extended dimension (2.3 ms at 9, 10 ms at 15 at configs[4]), the jobs are
+// queued in whatever order the particles' weighting phases reach them, and more jobs than resident workgroups means a second
+// round -- in which a 10 ms job started after the first 2 ms ones have finished sets the launch's length.  One workgroup sorts the
+// job indices by dimension, descending (counting sort; the order among equals is irrelevant: jobs are independent and their
+// factors are multiplied into the weights in slot order afterwards).
+__global__ __launch_bounds__(1024) void murty_order_kernel(MurtyQueue Q) {
+  __shared__ int hist[MURTY_N + 2];
+  const int nJobs = min(*Q.count, Q.maxJobs);
+  for (int k = threadIdx.x; k < MURTY_N + 2; k += blockDim.x) hist[k] = 0;
+  __syncthreads();
+  for (int j = threadIdx.x; j < nJobs; j += blockDim.x) {
+    const int n = min(Q.jobs[j].nR + Q.jobs[j].nC, MURTY_N + 1);
+    atomicAdd(&hist[MURTY_N + 1 - n], 1);            // bucket 0 = the largest dimension
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { int acc = 0; for (int k = 0; k < MURTY_N + 2; k++) { const int c = hist[k]; hist[k] = acc; acc += c; } }
+  __syncthreads();
+  for (int j = threadIdx.x; j < nJobs; j += blockDim.x) {
+    const int n = min(Q.jobs[j].nR + Q.jobs[j].nC, MURTY_N + 1);
+    Q.order[atomicAdd(&hist[MURTY_N + 1 - n], 1)] = j;
+  }
+}
 __global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err, double *weight, int N, double *sums,
-                                                                         int normalize, ZArg zarg, double *dZ, int nZdoubles, int *hostSeen) {
+                                                                         int normalize, ZArg zarg, double *dZ, int nZdoubles, int *hostSeen, int ordered) {
   // (a fused step carries the measurement set in its kernel arguments; the device copy the next predict reads is written here)
   if (blockIdx.x == 0 && dZ && (int)threadIdx.x < nZdoubles) dZ[threadIdx.x] = zarg.v[threadIdx.x];
   if (blockIdx.x == 0 && dZ && (int)threadIdx.x + 128 < nZdoubles) dZ[threadIdx.x + 128] = zarg.v[threadIdx.x + 128];
@@ -385,7 +408,8 @@ __global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQ
   __shared__ unsigned char sPushed[MURTY_N];
   // (readfirstlane: tells the compiler the wave index is uniform, so that the whole search compiles to scalar control flow)
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  for (int j = blockIdx.x; j < nJobs; j += gridDim.x) {
+  for (int jq = blockIdx.x; jq < nJobs; jq += gridDim.x) {
+    const int j = (ordered && Q.order) ? Q.order[jq] : jq;
     const MurtyJob J = Q.jobs[j];
     const int n = J.nR + J.nC;
     double v = 1.0;
@@ -459,12 +483,13 @@ static inline int murty_alloc(MurtyQueue &Q, MurtyScratch &MS, int N) {
   ok &= hipMalloc(&Q.jobs, (size_t)maxJobs * sizeof(MurtyJob)) == hipSuccess;
   ok &= hipMalloc(&Q.mats, (size_t)maxJobs * MURTY_MAXN * MURTY_MAXN * sizeof(double)) == hipSuccess;
   ok &= hipMalloc(&Q.results, (size_t)maxJobs * sizeof(double)) == hipSuccess;
+  ok &= hipMalloc(&Q.order, (size_t)maxJobs * sizeof(int)) == hipSuccess;
   ok &= hipMalloc(&MS.arena, (size_t)maxJobs * MS.jobBytes) == hipSuccess;
   if (ok) ok &= hipMemset(Q.count, 0, 2 * sizeof(int)) == hipSuccess;
   return ok ? 0 : 1;
 }
 static inline void murty_free(MurtyQueue &Q, MurtyScratch &MS) {
-  hipFree(Q.count); hipFree(Q.jobs); hipFree(Q.mats); hipFree(Q.results); hipFree(MS.arena);
+  hipFree(Q.count); hipFree(Q.jobs); hipFree(Q.mats); hipFree(Q.results); hipFree(Q.order); hipFree(MS.arena);
   Q = MurtyQueue{};
   MS = MurtyScratch{};
 }
@@ -478,7 +503,11 @@ static inline int murty_launch(MurtyQueue &Q, MurtyScratch &MS, Buffers &B, hipS
   int blocks = std::min(MURTY_JOB_BLOCKS, Q.maxJobs);
   if (hostSeen && *hostSeen == 0) blocks = std::min(blocks, 64);
   static const ZArg none{};
+  // (a filter that has shown Murty work -- or a caller without the pinned flag, i.e. the synchronous phase calls -- gets its jobs
+  //  ordered, longest first; ~5 us, and only then)
+  const int ordered = (Q.order && (!hostSeen || *hostSeen != 0)) ? 1 : 0;
+  if (ordered) murty_order_kernel<<<1, 1024, 0, stream>>>(Q);
   murty_jobs_kernel<<<blocks, 64 * MURTY_JOB_WAVES, 0, stream>>>(Q, MS, B.err, B.weight, B.N, sums, normalize, za ? *za : none, za ? B.Z : nullptr, nZdoubles,
-                                                                 hostSeen);
+                                                                 hostSeen, ordered);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }

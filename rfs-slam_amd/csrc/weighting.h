@@ -27,6 +27,7 @@ struct MurtyQueue {
   double *mats;        // [maxJobs][MURTY_MAXN*MURTY_MAXN]
   double *results;     // [maxJobs]
   int maxJobs;
+  int *order;          // [maxJobs] job indices, largest extended dimension first (murty_order_kernel); may be null
 };
 #define MURTY_MAXN 64
 
