@@ -965,19 +965,20 @@ __global__ __launch_bounds__(256) void valid_count_kernel(Buffers B, int cur, in
 }
 
 // rfsgpu_restore_state: copy the saved live entries back (one block per particle).
+template <int NPL>
 __global__ __launch_bounds__(256) void restore_state_kernel(Buffers B, int cur, const double *snapSlab, const double *snapWeight,
                                                             const int *snapCount, const int *snapFov, const unsigned long long *snapUnused) {
   const int k = blockIdx.x;
   const int n = snapCount[k];
-  // every plane's element of an entry is loaded before the first is stored: up to eleven loads in flight per thread
-  const double *q0 = snapSlab + (size_t)k * B.npl * (size_t)B.cap;
-  double *d0 = B.slab[cur] + (size_t)k * B.npl * (size_t)B.cap;
+  // every plane's element of an entry is loaded before the first is stored: NPL (7 or 11) loads in flight per thread
+  const double *q0 = snapSlab + (size_t)k * NPL * (size_t)B.cap;
+  double *d0 = B.slab[cur] + (size_t)k * NPL * (size_t)B.cap;
   for (int m = threadIdx.x; m < n; m += blockDim.x) {
-    double v[11];
+    double v[NPL];
 #pragma unroll
-    for (int pl = 0; pl < 11; pl++) v[pl] = (pl < B.npl) ? q0[(size_t)pl * B.cap + m] : 0.0;
+    for (int pl = 0; pl < NPL; pl++) v[pl] = q0[(size_t)pl * B.cap + m];
 #pragma unroll
-    for (int pl = 0; pl < 11; pl++) if (pl < B.npl) d0[(size_t)pl * B.cap + m] = v[pl];
+    for (int pl = 0; pl < NPL; pl++) d0[(size_t)pl * B.cap + m] = v[pl];
   }
   if (threadIdx.x == 0) {
     B.count[k] = n;

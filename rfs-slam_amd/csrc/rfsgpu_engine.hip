@@ -1397,7 +1397,8 @@ int rfsgpu_restore_state(rfsgpu_filter *f) {
   f->N = f->snapN;  // (the particle count is part of the state: the multi-hypothesis FastSLAM update changes it)
   f->B.N = f->N;
   // only the live entries are copied (one block per particle); asynchronous on the handle's stream
-  restore_state_kernel<<<f->N, 256, 0, f->stream>>>(f->B, f->cur, f->snapSlab, f->snapWeight, f->snapCount, f->snapFov, f->snapUnused);
+  if (f->B.npl == 7) restore_state_kernel<7><<<f->N, 256, 0, f->stream>>>(f->B, f->cur, f->snapSlab, f->snapWeight, f->snapCount, f->snapFov, f->snapUnused);
+  else restore_state_kernel<11><<<f->N, 256, 0, f->stream>>>(f->B, f->cur, f->snapSlab, f->snapWeight, f->snapCount, f->snapFov, f->snapUnused);
   HIPCHK(hipGetLastError());
   f->nZ = f->snapNZ;
   return RFSGPU_OK;
