@@ -190,6 +190,39 @@ __device__ __forceinline__ bool murty_root_wave(double *C, int n, MurtyArena &A,
 #define MURTY_LDS_N 24   // sub-problems up to this dimension are solved in a 4.5 KB LDS tile per wave (larger ones in the job's arena)
 #endif
 
+// Child c of node `par` (created at partition ppar): sub-problem, constraints, solution; aPar / termPar: the parent's
+// assignment and its terms, row r on lane r.  pn: the child's node number (only compared against in the constraint walk; a
+// child solved ahead of its parent's pop has none yet).  Out: pushed (a solution exists), its score and assignment.
+template <int LDSN>
+__device__ __forceinline__ void murty_solve_child(double *myTile, const double *C, const int n, const int realNC, MurtyArena &A, const int wave, const int par,
+                                                  const int ppar, const int c, const int pn, const int aPar, const double termPar, bool &pushed,
+                                                  double &sAcc, int &aNew, long long *prof) {
+  const int lane = threadIdx.x & 63;
+  const int nn = ppar + c;
+  double fixedScore = 0;
+  for (int r = 0; r < nn; r++) fixedScore += readlane_f64(termPar, r);   // rows 0..nn-1 fixed to the parent's choice
+  const unsigned long long usedCols = wave_or_u64((lane < nn) ? (1ull << aPar) : 0ull);
+  const unsigned long long freeCols = ((n >= 64) ? ~0ull : ((1ull << n) - 1ull)) & ~usedCols;
+  const int nFree = n - nn;
+  const int colRemap = (lane < nFree) ? murty_kth_bit(freeCols, lane) : 0;
+  pushed = false;
+  sAcc = 0;
+  aNew = aPar;
+  int aTmp = 0;
+  const bool okH = (nFree <= LDSN)
+                       ? murty_child_wave<LDSN>(myTile, C, n, nn, nFree, pn, par, colRemap, freeCols, realNC, A, aTmp, nullptr, prof)
+                       : murty_child_wave<MURTY_N>(A.Ct + (size_t)wave * MURTY_N * MURTY_N, C, n, nn, nFree, pn, par, colRemap, freeCols, realNC, A, aTmp, nullptr, prof);
+  if (okH) {
+    const int ja = __shfl((lane < nFree) ? colRemap : 0, (lane < nFree) ? aTmp : 0, 64);
+    const double term = (lane < nFree) ? C[(nn + lane) * n + ja] : 0.0;
+    for (int r = 0; r < nFree; r++) sAcc += readlane_f64(term, r);
+    sAcc += fixedScore;
+    const int jaShift = __shfl(ja, (lane >= nn) ? lane - nn : 0, 64);
+    if (lane >= nn) aNew = jaShift;
+    pushed = true;
+  }
+}
+
 // One partition: sum of exp(score) over the <= 200 best assignments (RBPHDFilter.hpp:948-959).
 // Murty's ranked enumeration by one WORKGROUP of W wavefronts: the children of an expansion -- independent sub-problems --
 // are shared out among the waves (child c of the popped node to wave c mod W, each in its own LDS tile of LDSN x LDSN);
@@ -241,33 +274,15 @@ __device__ __forceinline__ void murty_kbest_block(double *C, int n, int partitio
       const double termPar = (lane < n) ? C[lane * n + aPar] : 0.0;
       for (int c = wave; c < cnt; c += W) {
         const int nn = pp + c, pn = nNodes + c;
-        double fixedScore = 0;
-        for (int r = 0; r < nn; r++) fixedScore += readlane_f64(termPar, r);   // rows 0..nn-1 fixed to the parent's choice
-        const unsigned long long usedCols = wave_or_u64((lane < nn) ? (1ull << aPar) : 0ull);
-        const unsigned long long freeCols = ((n >= 64) ? ~0ull : ((1ull << n) - 1ull)) & ~usedCols;
-        const int nFree = n - nn;
-        const int colRemap = (lane < nFree) ? murty_kth_bit(freeCols, lane) : 0;
         if (lane == 0) { A.nodeId[pn] = (unsigned char)nn; A.nodeParent[pn] = (short)parent; }
         bool pushed = false;
         double sAcc = 0;
-        int aNew = aPar, aTmp = 0;
-        const bool okH = (nFree <= LDSN)
+        int aNew = aPar;
 #ifdef RFS_PROFILE
-                             ? murty_child_wave<LDSN>(myTile, C, n, nn, nFree, pn, parent, colRemap, freeCols, realNC, A, aTmp, nullptr, hp)
-                             : murty_child_wave<MURTY_N>(A.Ct + (size_t)wave * MURTY_N * MURTY_N, C, n, nn, nFree, pn, parent, colRemap, freeCols, realNC, A, aTmp, nullptr, hp);
+        murty_solve_child<LDSN>(myTile, C, n, realNC, A, wave, parent, pp, c, pn, aPar, termPar, pushed, sAcc, aNew, hp);
 #else
-                             ? murty_child_wave<LDSN>(myTile, C, n, nn, nFree, pn, parent, colRemap, freeCols, realNC, A, aTmp, nullptr, nullptr)
-                             : murty_child_wave<MURTY_N>(A.Ct + (size_t)wave * MURTY_N * MURTY_N, C, n, nn, nFree, pn, parent, colRemap, freeCols, realNC, A, aTmp, nullptr, nullptr);
+        murty_solve_child<LDSN>(myTile, C, n, realNC, A, wave, parent, pp, c, pn, aPar, termPar, pushed, sAcc, aNew, nullptr);
 #endif
-        if (okH) {
-          const int ja = __shfl((lane < nFree) ? colRemap : 0, (lane < nFree) ? aTmp : 0, 64);
-          const double term = (lane < nFree) ? C[(nn + lane) * n + ja] : 0.0;
-          for (int r = 0; r < nFree; r++) sAcc += readlane_f64(term, r);
-          sAcc += fixedScore;
-          const int jaShift = __shfl(ja, (lane >= nn) ? lane - nn : 0, 64);
-          if (lane >= nn) aNew = jaShift;
-          pushed = true;
-        }
         if (lane < n) A.nodeA[(size_t)pn * MURTY_N + lane] = (unsigned char)aNew;
         if (lane == 0) { sPushed[c] = pushed ? 1 : 0; sScore[c] = sAcc; }
       }
@@ -309,14 +324,284 @@ __device__ __forceinline__ void murty_kbest_block(double *C, int n, int partitio
   ok = __builtin_amdgcn_readfirstlane(ctl[5]) != 0;
 }
 
+// ---- the same search with the solves taken off the pop's path --------------------------------------------------------------
+// What a node expands to -- each child's sub-problem, its negative constraints along the parent chain, the solver's answer --
+// depends on the node and its ancestors only, not on WHEN the node is popped.  Here wave 0 alone runs the search (pop, push,
+// scores, stop rules: the sequence of murty_kbest_block, untouched), and the other waves of the workgroup are solvers with a
+// mailbox each: wave 0 hands them the children of the node it has just popped AND, when solvers are free, the children of the
+// nodes a coming pop is most likely to take (the heap's new top, then the better of the top's two children).  Answers are
+// parked in a small table keyed (node, child); a pop whose children are in the table costs heap work only.  Node numbers,
+// pushes and pops are exactly the serial ones: the table only replaces a solve by its own result.  No workgroup barrier inside
+// the search -- flags in LDS (release / acquire at workgroup scope); wave 0 never waits for anything but a solve in flight, the
+// solvers for nothing but a task or the end, so there is no cycle to wait in.
+#define MURTY_SPEC_SLOTS 8
+struct MurtySpec {
+  double score[MURTY_SPEC_SLOTS];
+  int ready[MURTY_SPEC_SLOTS];           // slot payload complete (solver: 1; wave 0 clears it when it hands the slot out)
+  int taskSeq[MURTY_CT_WAVES];           // wave 0 -> solver w: tasks posted so far
+  int doneSeq[MURTY_CT_WAVES];           // solver w -> wave 0: tasks finished so far
+  int taskNode[MURTY_CT_WAVES], taskC[MURTY_CT_WAVES], taskSlot[MURTY_CT_WAVES];
+  int quit;
+  int peekNode[2], peekPart[2];
+  unsigned char pushed[MURTY_SPEC_SLOTS];
+  unsigned char a[MURTY_SPEC_SLOTS][MURTY_N];
+};
+__device__ __forceinline__ int murty_flag_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void murty_flag_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+template <int W, int LDSN, class FRoot, class FTop>
+__device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitionMax, int realNC, int maxNodes, int maxK, MurtyArena &A, bool &ok,
+                                                  double *myTile, int *ctl, double *sScore, unsigned char *sPushed, const int wave, MurtySpec *spec,
+                                                  FRoot onRoot, FTop onTop) {
+  static_assert(W >= 2 && W <= MURTY_CT_WAVES, "one searching wave + at least one solver");
+  const int lane = threadIdx.x & 63;
+  if (wave == 0) {
+    if (lane < MURTY_SPEC_SLOTS) spec->ready[lane] = 0;
+    if (lane < MURTY_CT_WAVES) { spec->taskSeq[lane] = 0; spec->doneSeq[lane] = 0; }
+    if (lane == 0) spec->quit = 0;
+    int a0;
+    double s = 0;
+    const bool okr = murty_root_wave(C, n, A, a0, s, nullptr);
+    if (lane == 0) {
+      ctl[2] = 1; ctl[3] = okr ? 1 : 0; ctl[5] = okr ? 1 : 0;
+      ctl[4] = (!okr || onRoot(s)) ? 1 : 0;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+#ifdef RFS_PROFILE
+  long long hp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int dbgHit = 0, dbgPosted = 0, dbgDirect = 0, dbgSpec = 0, dbgPops = 0;
+  long long dbgWait = 0;
+  const long long dbgT0 = (long long)__builtin_readcyclecounter();
+  long long *const prof = hp;
+#else
+  long long *const prof = nullptr;
+#endif
+  if (wave != 0) {
+    // ---- solver ----
+    int seen = 0;
+    for (;;) {
+      int t;
+      while ((t = murty_flag_load(&spec->taskSeq[wave])) == seen) {
+        if (murty_flag_load(&spec->quit)) break;
+        __builtin_amdgcn_s_sleep(4);
+      }
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t == seen) break;   // the search is over
+      const int X = __builtin_amdgcn_readfirstlane(spec->taskNode[wave]), c = __builtin_amdgcn_readfirstlane(spec->taskC[wave]);
+      const int e = __builtin_amdgcn_readfirstlane(spec->taskSlot[wave]);
+      const int ppX = A.nodeId[X];
+      const int aPar = (lane < n) ? A.nodeA[(size_t)X * MURTY_N + lane] : 0;
+      const double termPar = (lane < n) ? C[lane * n + aPar] : 0.0;
+      bool pushed = false;
+      double sAcc = 0;
+      int aNew = aPar;
+      murty_solve_child<LDSN>(myTile, C, n, realNC, A, wave, X, ppX, c, 0x7ffe, aPar, termPar, pushed, sAcc, aNew, prof);
+      spec->a[e][lane] = (unsigned char)aNew;
+      if (lane == 0) { spec->score[e] = sAcc; spec->pushed[e] = pushed ? 1 : 0; }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) { murty_flag_store(&spec->ready[e], 1); murty_flag_store(&spec->doneSeq[wave], t); }
+      seen = t;
+    }
+  } else {
+    // ---- the search ----
+    int tNode = -1, tC = 0;   // lane e < MURTY_SPEC_SLOTS: the key of table slot e (node < 0: free)
+    int fifo = 0;             // next slot to recycle when none is free
+    int posted[W];            // tasks posted to solver w so far
+#pragma unroll
+    for (int w = 0; w < W; w++) posted[w] = 0;
+    for (int k = 1; k < maxK && __builtin_amdgcn_readfirstlane(ctl[4]) == 0; k++) {
+      if (lane == 0) {
+        int hl = ctl[3];
+        const int parent = heap_pop(A.heap, hl, A.nodeScore);
+        ctl[0] = parent; ctl[1] = A.nodeId[parent]; ctl[3] = hl;
+        // the nodes a coming pop is most likely to take: the new top, then the better of its two children
+        const int b1 = (hl > 0) ? (int)A.heap[0] : -1;
+        int b2 = (hl > 1) ? (int)A.heap[1] : -1;
+        if (hl > 2) { const int b3 = A.heap[2]; if (A.nodeScore[b3] > A.nodeScore[b2]) b2 = b3; }
+        spec->peekNode[0] = b1; spec->peekPart[0] = (b1 >= 0) ? (int)A.nodeId[b1] : 0;
+        spec->peekNode[1] = b2; spec->peekPart[1] = (b2 >= 0) ? (int)A.nodeId[b2] : 0;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (also: the nodes pushed so far are visible to the solvers before any task names them)
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const int parent = __builtin_amdgcn_readfirstlane(ctl[0]), pp = __builtin_amdgcn_readfirstlane(ctl[1]), nNodes = __builtin_amdgcn_readfirstlane(ctl[2]);
+      const int cnt = partitionMax - pp;
+      const bool poolFull = cnt > 0 && nNodes + cnt > maxNodes;
+#ifdef RFS_PROFILE
+      dbgPops++;
+#endif
+      if (!poolFull && cnt > 0) {
+        // which children of this node are in the table (solved or being solved)?
+        int mySlot = -1;
+#pragma unroll
+        for (int e = 0; e < MURTY_SPEC_SLOTS; e++) {
+          const int en = __builtin_amdgcn_readlane(tNode, e), ec = __builtin_amdgcn_readlane(tC, e);
+          if (en == parent && ec == lane) mySlot = e;
+        }
+#ifdef RFS_PROFILE
+        dbgHit += __popcll(__ballot(lane < cnt && mySlot >= 0));
+#endif
+        // solvers without a task in flight
+        unsigned freeW = 0;
+#pragma unroll
+        for (int w = 1; w < W; w++)
+          if (murty_flag_load(&spec->doneSeq[w]) == posted[w]) freeW |= 1u << w;
+        // a table slot for (X, c): a free one, else the oldest solved entry that does not belong to this pop; never one in flight
+        auto take_slot = [&](const int X, const int c) -> int {
+          const int rdy = (lane < MURTY_SPEC_SLOTS) ? murty_flag_load(&spec->ready[lane]) : 0;
+          const unsigned freeS = (unsigned)__ballot(lane < MURTY_SPEC_SLOTS && tNode < 0);
+          const unsigned evict = (unsigned)__ballot(lane < MURTY_SPEC_SLOTS && tNode >= 0 && tNode != parent && rdy != 0);
+          int e = -1;
+          if (freeS) e = __builtin_ctz(freeS);
+          else
+            for (int t = 0; t < MURTY_SPEC_SLOTS; t++) {
+              const int q = (fifo + t) & (MURTY_SPEC_SLOTS - 1);
+              if ((evict >> q) & 1u) { e = q; fifo = (q + 1) & (MURTY_SPEC_SLOTS - 1); break; }
+            }
+          if (e >= 0 && lane == e) { tNode = X; tC = c; spec->ready[e] = 0; }
+          return e;
+        };
+        auto post = [&](const int w, const int X, const int c, const int e) {
+          if (lane == 0) { spec->taskNode[w] = X; spec->taskC[w] = c; spec->taskSlot[w] = e; }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int ww = 1; ww < W; ww++)
+            if (ww == w) { posted[ww]++; if (lane == 0) murty_flag_store(&spec->taskSeq[ww], posted[ww]); }
+        };
+        // this node's missing children: the first one stays with wave 0 (it has nothing else to do until they are all there),
+        // the others go to free solvers
+        const unsigned long long miss = __ballot(lane < cnt && mySlot < 0);
+        unsigned long long direct = miss & (0ull - miss);
+        for (unsigned long long g = miss & ~direct; g; g &= g - 1ull) {
+          const int c = __builtin_ctzll(g);
+          const int e = freeW ? take_slot(parent, c) : -1;
+          if (e >= 0) {
+            const int w = __builtin_ctz(freeW);
+            freeW &= freeW - 1u;
+            post(w, parent, c, e);
+            if (lane == c) mySlot = e;
+#ifdef RFS_PROFILE
+            dbgPosted++;
+#endif
+          } else {
+            direct |= 1ull << c;
+          }
+        }
+        // solvers still free: children of the nodes next in the heap
+        for (int cand = 0; cand < 2 && freeW; cand++) {
+          const int X = __builtin_amdgcn_readfirstlane(spec->peekNode[cand]);
+          if (X < 0) continue;
+          const int cntX = partitionMax - __builtin_amdgcn_readfirstlane(spec->peekPart[cand]);
+          for (int c = 0; c < cntX && freeW; c++) {
+            if (__ballot(lane < MURTY_SPEC_SLOTS && tNode == X && tC == c) != 0ull) continue;   // in the table already
+            const int e = take_slot(X, c);
+            if (e < 0) { freeW = 0; break; }
+            const int w = __builtin_ctz(freeW);
+            freeW &= freeW - 1u;
+            post(w, X, c, e);
+#ifdef RFS_PROFILE
+            dbgSpec++;
+#endif
+          }
+        }
+        // the children nobody took: solved here
+        const int aPar = (lane < n) ? A.nodeA[(size_t)parent * MURTY_N + lane] : 0;
+        const double termPar = (lane < n) ? C[lane * n + aPar] : 0.0;
+        for (int c = 0; c < cnt; c++) {
+          const int nn = pp + c, pn = nNodes + c;
+          if (lane == 0) { A.nodeId[pn] = (unsigned char)nn; A.nodeParent[pn] = (short)parent; }
+          if (!((direct >> c) & 1ull)) continue;
+          bool pushed = false;
+          double sAcc = 0;
+          int aNew = aPar;
+          murty_solve_child<LDSN>(myTile, C, n, realNC, A, 0, parent, pp, c, pn, aPar, termPar, pushed, sAcc, aNew, prof);
+          if (lane < n) A.nodeA[(size_t)pn * MURTY_N + lane] = (unsigned char)aNew;
+          if (lane == 0) { sPushed[c] = pushed ? 1 : 0; sScore[c] = sAcc; }
+#ifdef RFS_PROFILE
+          dbgDirect++;
+#endif
+        }
+        // the others come out of the table
+        for (int c = 0; c < cnt; c++) {
+          if ((direct >> c) & 1ull) continue;
+          const int e = __builtin_amdgcn_readlane(mySlot, c);
+          const int pn = nNodes + c;
+#ifdef RFS_PROFILE
+          const long long tw = (long long)__builtin_readcyclecounter();
+#endif
+          while (!murty_flag_load(&spec->ready[e])) __builtin_amdgcn_s_sleep(2);
+#ifdef RFS_PROFILE
+          dbgWait += (long long)__builtin_readcyclecounter() - tw;
+#endif
+          const int aNew = spec->a[e][lane];
+          if (lane < n) A.nodeA[(size_t)pn * MURTY_N + lane] = (unsigned char)aNew;
+          if (lane == 0) { sPushed[c] = spec->pushed[e]; sScore[c] = spec->score[e]; }
+          if (lane == e) tNode = -1;   // the slot is free again
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (lane == 0) {
+        int stop = 0;
+        if (poolFull) {
+          ctl[5] = 0;
+          stop = 1;
+        } else {
+          int hl = ctl[3];
+          for (int c = 0; c < cnt; c++)
+            if (sPushed[c]) {
+              A.nodeScore[nNodes + c] = sScore[c];
+              heap_push(A.heap, hl, (short)(nNodes + c), A.nodeScore);
+            }
+          ctl[2] = nNodes + (cnt > 0 ? cnt : 0);
+          ctl[3] = hl;
+          if (hl == 0) stop = 1;  // rank == -1
+          else {
+            const int top = A.heap[0];
+            if (onTop(A.nodeScore[top], top)) stop = 1;
+          }
+        }
+        ctl[4] = stop;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    if (lane == 0) murty_flag_store(&spec->quit, 1);
+#ifdef RFS_PROFILE
+    if (lane == 0 && (blockIdx.x & 255) == 7)
+      printf("murty block %d: n %d pops %d nodes %d; children from the table %d, posted at the pop %d, solved by wave 0 %d, ahead of a pop %d; wave 0 waited %lld of %lld cycles\n",
+             (int)blockIdx.x, n, dbgPops, ctl[2], dbgHit, dbgPosted, dbgDirect, dbgSpec, dbgWait, (long long)__builtin_readcyclecounter() - dbgT0);
+#endif
+  }
+  __threadfence_block();
+  __syncthreads();
+  ok = __builtin_amdgcn_readfirstlane(ctl[5]) != 0;
+}
+
 // One partition: sum of exp(score) over the <= 200 best assignments (RBPHDFilter.hpp:948-959).
 template <int W>
 __device__ __forceinline__ double murty_partition_sum_block(double *C, int n, int nR, int nC, MurtyArena &A, bool &ok, double *myTile, int *ctl,
-                                                            double *sSum, double *sScore, unsigned char *sPushed, const int wave) {
+                                                            double *sSum, double *sScore, unsigned char *sPushed, const int wave,
+                                                            MurtySpec *spec = nullptr) {
   const double BIG_NEG = -1000.0;
   const int realNR = nR > n ? n : nR, realNC = nC > n ? n : nC;
   const int partitionMax = (realNR == n) ? n - 1 : realNR;
   if (threadIdx.x == 0) *sSum = 0.0;
+  if constexpr (W >= 2) {
+    if (spec) {
+      murty_kbest_async<W, MURTY_LDS_N>(
+          C, n, partitionMax, realNC, MURTY_MAX_NODES, MURTY_KBEST, A, ok, myTile, ctl, sScore, sPushed, wave, spec,
+          [&](double s) { if (s < BIG_NEG) return true; *sSum = exp(s); return false; },
+          [&](double st, int) { if (st < BIG_NEG) return true; *sSum += exp(st); return false; });
+      return *sSum;
+    }
+  }
   murty_kbest_block<W, MURTY_LDS_N>(
       C, n, partitionMax, realNC, MURTY_MAX_NODES, MURTY_KBEST, A, ok, myTile, ctl, sScore, sPushed, wave,
       [&](double s) { if (s < BIG_NEG) return true; *sSum = exp(s); return false; },
@@ -406,6 +691,12 @@ __global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQ
   __shared__ double sSum;
   __shared__ int sCtl[8];
   __shared__ unsigned char sPushed[MURTY_N];
+#if !defined(MURTY_NO_SPEC) && MURTY_JOB_WAVES >= 2
+  __shared__ MurtySpec sSpec;
+  MurtySpec *const spec = &sSpec;
+#else
+  MurtySpec *const spec = nullptr;
+#endif
   // (readfirstlane: tells the compiler the wave index is uniform, so that the whole search compiles to scalar control flow)
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   for (int jq = blockIdx.x; jq < nJobs; jq += gridDim.x) {
@@ -413,6 +704,9 @@ __global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQ
     const MurtyJob J = Q.jobs[j];
     const int n = J.nR + J.nC;
     double v = 1.0;
+#ifdef RFS_PROFILE
+    const long long dbgJob0 = (long long)wall_clock64();
+#endif
     if (n > MURTY_N) {
       if (threadIdx.x == 0) atomicOr(err, ERRBIT_MURTY);
     } else {
@@ -420,10 +714,13 @@ __global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQ
       murty_carve(MS.arena + (size_t)j * MS.jobBytes, A);
       bool ok;
       v = murty_partition_sum_block<MURTY_JOB_WAVES>(Q.mats + (size_t)j * MURTY_MAXN * MURTY_MAXN, n, J.nR, J.nC, A, ok, sTile[wave], sCtl, &sSum, sScore,
-                                                     sPushed, wave);
+                                                     sPushed, wave, spec);
       if (!ok && threadIdx.x == 0) atomicOr(err, ERRBIT_MURTY);
     }
     if (threadIdx.x == 0) Q.results[j] = v;
+#ifdef RFS_PROFILE
+    if (threadIdx.x == 0 && ((blockIdx.x & 63) == 7 || blockIdx.x >= 1900)) printf("murty job: block %d n %d started at tick %lld, ended at %lld\n", (int)blockIdx.x, n, dbgJob0, (long long)wall_clock64());
+#endif
     __syncthreads();   // the control words are reused by the next job
   }
   __shared__ int isLast;
@@ -444,23 +741,59 @@ __global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQ
     printf("\n");
   }
 #endif
+#ifdef RFS_PROFILE
+  const long long dbgTail0 = (long long)wall_clock64();
+#endif
   if (threadIdx.x == 0 && hostSeen) *hostSeen = 1;            // (pinned host word: this filter does reach the Murty path -- see murty_launch)
-  for (int i = threadIdx.x; i < N; i += blockDim.x) {
-    int last = -1;
-    double w = weight[i];
-    bool any = false;
-    while (true) {
-      int best = -1, bestSlot = 1 << 30;
-      for (int q = 0; q < nJobs; q++)
-        if (Q.jobs[q].particle == i && Q.jobs[q].slot > last && Q.jobs[q].slot < bestSlot) { best = q; bestSlot = Q.jobs[q].slot; }
-      if (best < 0) break;
-      w *= __builtin_nontemporal_load(&Q.results[best]);
-      last = bestSlot;
-      any = true;
+  // Every particle's factors, multiplied in partition (slot) order.  The jobs of a particle are chained through a list first
+  // (head per particle in the first job's arena, links in the order array -- both idle by now), so that a particle looks at
+  // its own few jobs only: scanning the whole queue per particle was 2.6 ms of a 9 ms launch at configs[4] (1000 x 1918).
+  if (Q.order && (size_t)N * sizeof(int) <= MS.jobBytes * (size_t)Q.maxJobs) {
+    int *head = reinterpret_cast<int *>(MS.arena), *next = Q.order;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) head[i] = -1;
+    __threadfence();
+    __syncthreads();
+    for (int q = threadIdx.x; q < nJobs; q += blockDim.x) next[q] = atomicExch(&head[Q.jobs[q].particle], q);
+    __threadfence();
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+      const int h = __builtin_nontemporal_load(&head[i]);
+      if (h < 0) continue;
+      int last = -1;
+      double w = weight[i];
+      while (true) {
+        int best = -1, bestSlot = 1 << 30;
+        for (int q = h; q >= 0; q = __builtin_nontemporal_load(&next[q])) {
+          const int sl = Q.jobs[q].slot;
+          if (sl > last && sl < bestSlot) { best = q; bestSlot = sl; }
+        }
+        if (best < 0) break;
+        w *= __builtin_nontemporal_load(&Q.results[best]);
+        last = bestSlot;
+      }
+      weight[i] = w;
     }
-    if (any) weight[i] = w;
+  } else {
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+      int last = -1;
+      double w = weight[i];
+      bool any = false;
+      while (true) {
+        int best = -1, bestSlot = 1 << 30;
+        for (int q = 0; q < nJobs; q++)
+          if (Q.jobs[q].particle == i && Q.jobs[q].slot > last && Q.jobs[q].slot < bestSlot) { best = q; bestSlot = Q.jobs[q].slot; }
+        if (best < 0) break;
+        w *= __builtin_nontemporal_load(&Q.results[best]);
+        last = bestSlot;
+        any = true;
+      }
+      if (any) weight[i] = w;
+    }
   }
   __syncthreads();
+#ifdef RFS_PROFILE
+  if (threadIdx.x == 0) printf("murty tail (last workgroup %d): factors into the weights %lld ticks of 10 ns, ends at tick %lld\n", (int)blockIdx.x, (long long)wall_clock64() - dbgTail0, (long long)wall_clock64());
+#endif
   step_post_tail(weight, N, sums, normalize);
 }
 
