@@ -21,7 +21,7 @@
 #define MURTY_KBEST 200
 #define MURTY_MAX_NODES 6401   /* 1 root + <= 200 expansions x <= 32 children */
 #ifndef MURTY_JOB_WAVES
-#define MURTY_JOB_WAVES 4   // measured at configs[4] (1918 jobs of dimension 9-15), barrier form: 1 wave 26.8 ms, 2: 16.5, 3: 15.4, 4: 15.1; search wave + solvers (murty_kbest_async): 3: 9.2, 4: 6.4, 5: 8.0, 6: 8.9
+#define MURTY_JOB_WAVES 4   // measured at configs[4] (1918 jobs of dimension 9-15), barrier form: 1 wave 26.8 ms, 2: 16.5, 3: 15.4, 4: 15.1; search wave + solvers (murty_kbest_async): 3: 8.9, 4: 6.4, 5: 7.9, 6: 8.9
 #endif
 #define MURTY_CT_WAVES (MURTY_JOB_WAVES > 4 ? MURTY_JOB_WAVES : 4)   /* (the multi-hypothesis FastSLAM search uses up to four waves on the same arena) */
 
