@@ -836,8 +836,8 @@ static inline int murty_launch(MurtyQueue &Q, MurtyScratch &MS, Buffers &B, hipS
   int blocks = std::min(MURTY_JOB_BLOCKS, Q.maxJobs);
   if (hostSeen && *hostSeen == 0) blocks = std::min(blocks, 64);
   static const ZArg none{};
-  // (a filter that has shown Murty work -- or a caller without the pinned flag, i.e. the synchronous phase calls -- gets its jobs
-  //  ordered, longest first; ~5 us, and only then)
+  // (a filter that has shown Murty work -- or a caller without the pinned flag -- gets its jobs ordered, longest first; ~5 us,
+  //  and only then)
   const int ordered = (Q.order && (!hostSeen || *hostSeen != 0)) ? 1 : 0;
   if (ordered) murty_order_kernel<<<1, 1024, 0, stream>>>(Q);
   murty_jobs_kernel<<<blocks, 64 * MURTY_JOB_WAVES, 0, stream>>>(Q, MS, B.err, B.weight, B.N, sums, normalize, za ? *za : none, za ? B.Z : nullptr, nZdoubles,

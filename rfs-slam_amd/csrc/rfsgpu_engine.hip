@@ -702,7 +702,7 @@ static int launch_weighting(rfsgpu_filter *f) {
     vp_weighting_kernel<2><<<(f->N + 1) / 2, 128, b, f->stream>>>(f->B, f->P, src, dst, nZ, ec, f->Q);
     HIPCHK(hipGetLastError());
     f->cur = dst;
-    if (murty_launch(f->Q, f->MS, f->B, f->stream) != 0) return fail(f, RFSGPU_ERR_HIP, "murty launch failed");
+    if (murty_launch(f->Q, f->MS, f->B, f->stream, nullptr, 0, nullptr, 0, f->hJobCount) != 0) return fail(f, RFSGPU_ERR_HIP, "murty launch failed");
     return RFSGPU_OK;
   }
   {  // one workgroup of WEIGHT_WPP waves per particle
@@ -714,7 +714,7 @@ static int launch_weighting(rfsgpu_filter *f) {
   f->cur = dst;
   if (f->evAfterWeightKernel) HIPCHK(hipEventRecord(f->evAfterWeightKernel, f->stream));
   // Murty-200 for partitions with nR + nC > 8: runs only when the queue is non-empty (device-side early exit)
-  rc = murty_launch(f->Q, f->MS, f->B, f->stream);
+  rc = murty_launch(f->Q, f->MS, f->B, f->stream, nullptr, 0, nullptr, 0, f->hJobCount);
   if (rc != 0) return fail(f, RFSGPU_ERR_HIP, "murty launch failed");
   return RFSGPU_OK;
 }
