@@ -1318,6 +1318,26 @@ def test_full_size_c5_murty_stress(pkg, ob, sc):
     _full_size_check(pkg, ob, sc, scen, cap=448, subset=16, check_murty=True)
 
 
+def test_murty_search_with_solver_waves_is_deterministic(pkg, sc):
+    """configs[4]'s shape at 200 particles, the same update four times from the same state, on both launch paths: the Murty jobs run
+    one searching wave + three solver waves per job with flags instead of barriers (murty.h, murty_kbest_async), and a race there
+    would show as weights that differ from run to run.  (The values themselves are checked against the oracle above.)"""
+    scen = sc.make_scenario(200, 200, 50, seed=556, n_clutter=10, n_eval=40, weighting_md=10.0, weights=(0.8, 1.0))
+    dev = pkg.RBPHDFilter(200, gm_capacity=448)
+    sc.load_scenario(dev, scen)
+    dev.save_state()
+    runs = []
+    for timing in (False, True, False, True):
+        dev.restore_state()
+        dev.set_phase_timing(timing)
+        dev.update(scen["Z"])
+        runs.append(dev.get_weights().copy())
+    dev.close()
+    assert np.all(np.isfinite(runs[0])) and np.ptp(runs[0]) > 0
+    for r in runs[1:]:
+        assert np.array_equal(r, runs[0])
+
+
 def test_randomised_differential_run():
     """tools/fuzz_parity.py: random shapes (1..330 landmarks around the 64-entry chunk boundaries), ranges, SC-PHD / multi-
     feature, tied / quantised / sub-fp32 weights, two update cycles each, fused and three-kernel path, device vs oracle."""
