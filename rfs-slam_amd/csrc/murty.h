@@ -335,6 +335,12 @@ __device__ __forceinline__ void murty_kbest_block(double *C, int n, int partitio
 // the search -- flags in LDS (release / acquire at workgroup scope); wave 0 never waits for anything but a solve in flight, the
 // solvers for nothing but a task or the end, so there is no cycle to wait in.
 #define MURTY_SPEC_SLOTS 8
+#ifndef MURTY_SOLVER_SLEEP
+#define MURTY_SOLVER_SLEEP 4   // x 64 cycles between two looks at the mailbox (1 ... 64 measured at configs[4]: 6.37-6.44 ms, no trend)
+#endif
+#ifndef MURTY_SEARCH_SLEEP
+#define MURTY_SEARCH_SLEEP 2
+#endif
 struct MurtySpec {
   double score[MURTY_SPEC_SLOTS];
   int ready[MURTY_SPEC_SLOTS];           // slot payload complete (solver: 1; wave 0 clears it when it hands the slot out)
@@ -385,7 +391,7 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
       int t;
       while ((t = murty_flag_load(&spec->taskSeq[wave])) == seen) {
         if (murty_flag_load(&spec->quit)) break;
-        __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_sleep(MURTY_SOLVER_SLEEP);
       }
       t = __builtin_amdgcn_readfirstlane(t);
       if (t == seen) break;   // the search is over
@@ -533,7 +539,7 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
 #ifdef RFS_PROFILE
           const long long tw = (long long)__builtin_readcyclecounter();
 #endif
-          while (!murty_flag_load(&spec->ready[e])) __builtin_amdgcn_s_sleep(2);
+          while (!murty_flag_load(&spec->ready[e])) __builtin_amdgcn_s_sleep(MURTY_SEARCH_SLEEP);
 #ifdef RFS_PROFILE
           dbgWait += (long long)__builtin_readcyclecounter() - tw;
 #endif
