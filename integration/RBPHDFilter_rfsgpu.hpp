@@ -11,20 +11,21 @@
  * every particle lives on the GPU behind the C ABI (include/rfsgpu.h); poses, weights, the process model, the random
  * numbers and the resampling DECISION stay on the host exactly where the reference has them.
  *
- * STATUS.  This translation unit needs Eigen3 and Boost (through the reference's own headers), which this repository's
- * build image does not have, so it has not been compiled here; it is reviewed line by line against the reference
- * headers cited next to each member.  The same logic, with plain-array stand-ins for Pose2d / Landmark2d /
- * Measurement2d, is what `rfs-slam_amd/host/rbphd_filter.hpp` compiles and what the tests run.
+ * STATUS.  Compiled and linked by tests/test_reference_binding.py: the UNMODIFIED `src/rbphdslam2dSim.cpp` and
+ * `src/rbphdslam_VictoriaPark.cpp` (+ the reference's own model / process / timer sources) against this file installed as
+ * `RBPHDFilter.hpp` (integration/include/) and librfsgpu.so.  The build image has neither Eigen3 nor Boost, so that test
+ * compiles over small stand-in headers (tests/support/stubs/, test support only); with the real libraries nothing else
+ * changes.  The same logic, with plain-array stand-ins for Pose2d / Landmark2d / Measurement2d, is what
+ * `rfs-slam_amd/host/rbphd_filter.hpp` compiles and what the GPU tests run.
  *
  * Supported template tuples (anything else is refused at compile time -- there is no CPU fallback in the product):
  *   <MotionModel_Odometry2d, StaticProcessModel<Landmark2d>, MeasurementModel_RngBrg,       KalmanFilter_RngBrg>
  *   <MotionModel_Ackerman2d, StaticProcessModel<Landmark3d>, MeasurementModel_VictoriaPark, KalmanFilter_VictoriaPark>
- * The one thing the Victoria Park tuple needs from the reference: read access to two private members of
- * MeasurementModel_VictoriaPark that the driver sets through the model (src/rbphdslam_VictoriaPark.cpp:344
- * `setNoise(R, Slb)`, :560 `setLaserScan(scan)`; include/MeasurementModel_VictoriaPark.hpp:149,151), i.e. two added lines:
- *     double getSlb() const { return Slb_; }
- *     const std::vector<double> &getLaserScan() const { return laserscan_; }
- * (or, without touching that class, `pFilter_->setLaserScan(scan)` / `pFilter_->setSlb(Slb)` below next to the two calls).
+ * Victoria Park: the filter needs two values the driver hands to the measurement model and the model keeps private
+ * (src/rbphdslam_VictoriaPark.cpp:371 `setNoise(R, Slb)`, :582 `setLaserScan(scan)`;
+ * include/MeasurementModel_VictoriaPark.hpp:149,151).  No reference file is touched for that: for this tuple
+ * `getMeasurementModel()` returns a handle (`rfsgpu_vp_model_handle`, below) that forwards every public member of the
+ * model -- `config` included -- and keeps a copy of those two arguments on the way through.
  */
 #ifndef RBPHDFILTER_HPP   /* the reference's own include guard: this file stands in for that header */
 #define RBPHDFILTER_HPP
@@ -55,6 +56,54 @@ namespace rfs {
 template <class MeasurementModel> struct rfsgpu_model_of;  /* undefined: unsupported tuples do not compile */
 template <> struct rfsgpu_model_of<MeasurementModel_RngBrg> { enum { value = RFSGPU_MODEL_RNGBRG_2D, dim = 2 }; };
 template <> struct rfsgpu_model_of<MeasurementModel_VictoriaPark> { enum { value = RFSGPU_MODEL_VICTORIAPARK_3D, dim = 3 }; };
+
+/* ---- what getMeasurementModel() hands to the driver ------------------------------------------------------------------ */
+/* MeasurementModel_VictoriaPark keeps Slb_ and laserscan_ private with no getters (include/MeasurementModel_VictoriaPark.hpp
+ * :149,151) and the device needs both.  The handle forwards the model's whole public interface (:29-134) and records them. */
+class rfsgpu_vp_model_handle {
+ public:
+  explicit rfsgpu_vp_model_handle(MeasurementModel_VictoriaPark *m) : config(m->config), m_(m), Slb_(0), haveSlb_(false), scanSerial_(0) {}
+  MeasurementModel_VictoriaPark::Config &config;                                     /* `->config.x = ...` (:373-379 of the driver) */
+  void setNoise(Measurement3d::Mat &R, double Slb) { m_->setNoise(R, Slb); Slb_ = Slb; haveSlb_ = true; }
+  void setNoise(Measurement3d::Mat &R) { m_->MeasurementModel<Pose2d, Landmark3d, Measurement3d>::setNoise(R); }
+  void getNoise(Measurement3d::Mat &R) { m_->getNoise(R); }
+  void setLaserScan(const std::vector<double> &scan) { m_->setLaserScan(scan); scan_ = scan; scanSerial_++; }
+  bool measure(const Pose2d &pose, const Landmark3d &lm, Measurement3d &z, Eigen::Matrix3d *jl = NULL, Eigen::Matrix3d *jp = NULL) { return m_->measure(pose, lm, z, jl, jp); }
+  void inverseMeasure(const Pose2d &pose, const Measurement3d &z, Landmark3d &lm) { m_->inverseMeasure(pose, z, lm); }
+  double probabilityOfDetection(const Pose2d &pose, const Landmark3d &lm, bool &lim) { return m_->probabilityOfDetection(pose, lm, lim); }
+  double probabilityOfDetection2(const Pose2d &pose, const Landmark3d &lm, bool &lim) { return m_->probabilityOfDetection2(pose, lm, lim); }
+  double clutterIntensity(Measurement3d &z, int nZ) { return m_->clutterIntensity(z, nZ); }
+  double clutterIntensityIntegral(int nZ = 0) { return m_->clutterIntensityIntegral(nZ); }
+  operator MeasurementModel_VictoriaPark *() const { return m_; }
+  MeasurementModel_VictoriaPark *model() const { return m_; }
+  /* for the filter */
+  bool haveSlb() const { return haveSlb_; }
+  double Slb() const { return Slb_; }
+  const std::vector<double> &laserScan() const { return scan_; }
+  unsigned long laserScanSerial() const { return scanSerial_; }
+ private:
+  MeasurementModel_VictoriaPark *m_;
+  double Slb_;
+  bool haveSlb_;
+  std::vector<double> scan_;
+  unsigned long scanSerial_;
+};
+template <class MeasurementModel> struct rfsgpu_model_access {           /* 2-D model: everything the device needs is public */
+  typedef MeasurementModel *pointer;
+  struct holder {
+    explicit holder(MeasurementModel *m) : m_(m) {}
+    pointer get() { return m_; }
+    MeasurementModel *m_;
+  };
+};
+template <> struct rfsgpu_model_access<MeasurementModel_VictoriaPark> {
+  typedef rfsgpu_vp_model_handle *pointer;
+  struct holder {
+    explicit holder(MeasurementModel_VictoriaPark *m) : h_(m) {}
+    pointer get() { return &h_; }
+    rfsgpu_vp_model_handle h_;
+  };
+};
 
 template <class RobotProcessModel, class LmkProcessModel, class MeasurementModel, class KalmanFilter>
 class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, GaussianMixture<typename MeasurementModel::TLandmark> > {
@@ -108,9 +157,9 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
   /* :370-382 -- the constructor's defaults.  (The reference leaves importanceWeightingEvalPointGuassianWeight_ and
    * useClusterProcess_ uninitialised; both drivers assign them, :485,490.  They start at 0 / false here.) */
   explicit RBPHDFilter(int n)
-      : ParticleFilter<RobotProcessModel, MeasurementModel, GaussianMixture<TLandmark> >(n), engine_(NULL) {
+      : ParticleFilter<RobotProcessModel, MeasurementModel, GaussianMixture<TLandmark> >(n), engine_(NULL), model_(this->pMeasurementModel_) {
     lmkModelPtr_ = new LmkProcessModel;
-    kf_ = new KalmanFilter(lmkModelPtr_, this->getMeasurementModel());
+    kf_ = new KalmanFilter(lmkModelPtr_, this->pMeasurementModel_);
     config.birthGaussianWeight_ = 0.25;
     config.birthGaussianMeasurementCountThreshold_ = 1;
     config.birthGaussianMeasurementCheckThreshold_ = 1;
@@ -149,9 +198,9 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
   LmkProcessModel *getLmkProcessModel() { return lmkModelPtr_; }   /* :402-404 */
   KalmanFilter *getKalmanFilter() { return kf_; }                   /* :1189-1191 (one object: no per-thread copies to broadcast) */
 
-  /* MeasurementModel_VictoriaPark only: see the header comment */
-  void setLaserScan(const std::vector<double> &scan) { laserScan_ = scan; }
-  void setSlb(double Slb) { Slb_ = Slb; haveSlb_ = true; }
+  /* include/ParticleFilter.hpp:112 -- hidden here so that, for the Victoria Park tuple, `setNoise(R, Slb)` and `setLaserScan`
+   * pass through the handle above (the 2-D tuple gets the model pointer itself, as in the reference) */
+  typename rfsgpu_model_access<MeasurementModel>::pointer getMeasurementModel() { return model_.get(); }
 
   /* :415-442.  Births use the pose BEFORE propagation (:423-426), so the poses go to the device first. */
   void predict(TInput u, TimeStamp const &dT, bool useModelNoise = true, bool useInputNoise = false, bool birthGaussianCheck = true) {
@@ -235,12 +284,19 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
   rfsgpu_filter *engine_;
   LmkProcessModel *lmkModelPtr_;
   KalmanFilter *kf_;
-  std::vector<double> laserScan_;
-  double Slb_ = 0;
-  bool haveSlb_ = false;
+  typename rfsgpu_model_access<MeasurementModel>::holder model_;
+  unsigned long scanPushed_ = 0;
   int nUpdatesSinceResample_, nMeasurementsSinceResample_;
   bool resampleOccured_;
   Timer timer_predict_, timer_mapUpdate_, timer_particleResample_;
+
+  /* include/ParticleFilter.hpp:140 (pure virtual) / include/RBPHDFilter.hpp:306 (private there too).  The reference calls it
+   * from inside update() only (:490); here the weighting of ALL particles is a phase of the device step that update() launches,
+   * so there is nothing a per-particle call could do on its own: it refuses instead of computing something else. */
+  void importanceWeighting(const uint idx) {
+    (void)idx;
+    throw std::logic_error("rfs::RBPHDFilter (rfsgpu): importanceWeighting(idx) runs on the device inside update(); it cannot be called on its own");
+  }
 
   void check(int rc, const char *what) {
     if (rc != RFSGPU_OK) throw std::runtime_error(std::string("rfsgpu ") + what + ": " + rfsgpu_last_error(engine_));
@@ -279,7 +335,7 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
     for (int r = 0; r < D; r++)
       for (int cc = 0; cc < D; cc++) q[D * r + cc] = Q(r, cc);
     check(rfsgpu_set_lmk_process_noise(engine_, q), "set_lmk_process_noise");
-    pushModel(this->getMeasurementModel());
+    pushModel(model_.get());
   }
   void pushModel(MeasurementModel_RngBrg *m) {                     /* include/MeasurementModel_RngBrg.hpp:65-71 */
     rfsgpu_rngbrg_config c;
@@ -293,14 +349,14 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
     c.rangeLimBuffer = m->config.rangeLimBuffer_;
     check(rfsgpu_set_model_rngbrg(engine_, &c), "set_model_rngbrg");
   }
-  void pushModel(MeasurementModel_VictoriaPark *m) {               /* include/MeasurementModel_VictoriaPark.hpp:136-152 */
+  void pushModel(rfsgpu_vp_model_handle *m) {                      /* include/MeasurementModel_VictoriaPark.hpp:136-152 */
     rfsgpu_vp_config c;
     Measurement3d::Mat R;
     m->getNoise(R);
     for (int r = 0; r < 3; r++)
       for (int cc = 0; cc < 3; cc++) c.R[3 * r + cc] = R(r, cc);
-    c.Slb = haveSlb_ ? Slb_ : m->getSlb();                          /* the Slb handed to setNoise(R, Slb) (:59) */
-    if (laserScan_.empty()) laserScan_ = m->getLaserScan();
+    if (!m->haveSlb()) throw std::runtime_error("rfsgpu: MeasurementModel_VictoriaPark::setNoise(R, Slb) has not been called through getMeasurementModel()");
+    c.Slb = m->Slb();                                                /* the Slb handed to setNoise(R, Slb) (:59) */
     c.nPd = (int)m->config.probabilityOfDetection_.size();
     if (c.nPd > RFSGPU_VP_MAX_PD) throw std::runtime_error("rfsgpu: Pd table longer than RFSGPU_VP_MAX_PD");
     for (int k = 0; k < c.nPd; k++) c.PdTable[k] = m->config.probabilityOfDetection_[k];
@@ -311,7 +367,10 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
     c.bearingLimitMin = m->config.bearingLimitMin_;
     c.bufferZonePd = m->config.bufferZonePd_;
     check(rfsgpu_set_model_victoriapark(engine_, &c), "set_model_victoriapark");
-    if (!laserScan_.empty()) check(rfsgpu_set_laser_scan(engine_, laserScan_.data(), (int)laserScan_.size()), "set_laser_scan");
+    if (m->laserScanSerial() != scanPushed_) {                        /* a new scan since the last push (driver :582) */
+      check(rfsgpu_set_laser_scan(engine_, m->laserScan().data(), (int)m->laserScan().size()), "set_laser_scan");
+      scanPushed_ = m->laserScanSerial();
+    }
   }
 
   /* pose mean + covariance of every particle (the covariance enters S in the 2-D model, src/MeasurementModel_RngBrg.cpp:102) */
