@@ -325,10 +325,43 @@ int rfsgpu_normalize_weights(rfsgpu_filter *f, double sum, const void *sum_dev);
  * n_parts consecutive {sum w, sum w^2} pairs (each shard's rfsgpu_bind_weight_sums_buffer slot, all-reduced in place
  * across GPUs); the divisor is the sum of their first elements, added in index order on the device. */
 int rfsgpu_normalize_weights_parts(rfsgpu_filter *f, double sum, const void *sum_dev, int n_parts);
-/* Apply a resampling decision: slot k takes a deep copy of slot src_slot[k]'s map, unused list and
- * FOV count (Particle::copy -> GaussianMixture copy-ctor); src_slot[k] == k keeps it.  All weights
- * are reset to 1 (ParticleFilter.hpp:486-489).  Sources must be slots that keep themselves. */
+/* Apply a resampling decision (the copy loop of ParticleFilter::resample, include/ParticleFilter.hpp:446-479): slot k takes what
+ * Particle::copy (include/Particle.hpp:218-223) carries from slot src_slot[k] -- the pose and a deep copy of the mixture -- and its
+ * id; src_slot[k] == k keeps the slot (case 1, :466-467).  All weights are reset to 1 (:486-489).  Sources must be slots that
+ * keep themselves.  The engine keeps the particles' id_ / idParent_ per slot exactly as that loop leaves them (a copy has its
+ * SOURCE's id; idParent_ = the source's id; a survivor's idParent_ = its own id, which differs from its slot once it has been
+ * a copy itself) and remembers that a resampling occurred (RBPHDFilter::resampleOccured_, cleared by the next update with
+ * measurements, include/RBPHDFilter.hpp:526).  What happens to the three per-SLOT arrays of RBPHDFilter -- unused_measurements_,
+ * birthGaussians_, nLandmarksInFOV_ -- is selected by rfsgpu_set_birth_inheritance (below). */
 int rfsgpu_resample_apply(rfsgpu_filter *f, const int *src_slot);
+/* Birth-state inheritance after a resampling (include/RBPHDFilter.hpp:1005-1011).
+ *   RFSGPU_INHERIT_REFERENCE (default)  the reference, statement for statement: nothing but pose + mixture moves at resampling
+ *       time; every rfsgpu_predict_map(add_birth = 1) while resampleOccured_ is set walks the slots in ascending order and, where
+ *       idParent_ != slot, first copies unused_measurements_ and birthGaussians_ from SLOT idParent_ in the state that slot is
+ *       in at that moment (a lower slot has already been through this predict's birth step, so its unused list is empty and
+ *       its candidates are one check older; a higher slot has not), then runs the slot's own birth step.  nLandmarksInFOV_ is
+ *       never copied.  On the device: a snapshot-ordered gather for the children of higher slots, then the birth step level by
+ *       level along the chains of lower-slot parents (csrc/birth.h).
+ *   RFSGPU_INHERIT_EAGER      rounds 1-2 of this engine ("the evident intent"): a child takes its parent's unused list, FOV count
+ *       and candidate list at resampling time, predict copies nothing.  NOT the reference's results in the step after a
+ *       resampling.  A handle on which rfsgpu_fastslam_update has run behaves this way whatever the mode: rfs::FastSLAM copies its
+       landmark-candidate lists right at resampling time (FastSLAM::resampleWithMapCopy, include/FastSLAM.hpp:747-753).
+ *   RFSGPU_INHERIT_EXTERNAL   resampling moves pose + mixture only and predict copies nothing: the host owns the rule (the
+ *       multi-GPU hosts, whose parent slot may live on another shard: rfsgpu_get/set_unused_masks). */
+#define RFSGPU_INHERIT_REFERENCE 0
+#define RFSGPU_INHERIT_EAGER 1
+#define RFSGPU_INHERIT_EXTERNAL 2
+int rfsgpu_set_birth_inheritance(rfsgpu_filter *f, int mode);
+int rfsgpu_get_birth_inheritance(const rfsgpu_filter *f);
+/* Particle::getId / getParentId of the particle in every slot (either pointer may be NULL); set: for a host that keeps the ids
+ * itself (the sharded hosts: ids are GLOBAL slot numbers there). */
+int rfsgpu_get_particle_ids(rfsgpu_filter *f, int *id, int *parent_id);
+int rfsgpu_set_particle_ids(rfsgpu_filter *f, const int *id, const int *parent_id);
+/* RBPHDFilter::resampleOccured_ as the engine tracks it (1 / 0). */
+int rfsgpu_resample_occured(const rfsgpu_filter *f);
+/* unused_measurements_ of all slots at once, one 64-bit mask per slot (bit z = measurement z of the last update is unused). */
+int rfsgpu_get_unused_masks(rfsgpu_filter *f, unsigned long long *masks);
+int rfsgpu_set_unused_masks(rfsgpu_filter *f, const unsigned long long *masks);
 /* ParticleFilter::resample(n) with n < nParticles_ (:417-483; FastSLAM::resampleWithMapCopy): the first n_out slots
  * receive src_slot[0..n_out), the particle count becomes n_out.  A source below n_out must keep itself; sources at or
  * beyond n_out are dropped after the copy. */
@@ -373,7 +406,12 @@ int rfsgpu_group_set_poses(rfsgpu_group *g, const double *x, const double *cov, 
 int rfsgpu_group_get_poses(rfsgpu_group *g, double *x);
 int rfsgpu_group_set_weights(rfsgpu_group *g, const double *w);
 int rfsgpu_group_get_weights(rfsgpu_group *g, double *w);
-int rfsgpu_group_predict_map(rfsgpu_group *g, int add_birth);                 /* RBPHDFilter::predict, map part (:415-442) */
+/* RBPHDFilter::predict, map part (:415-442), incl. the reference's birth-state inheritance after a resampling over GLOBAL slots
+ * for immediate-birth configurations (birthGaussianMeasurementCountThreshold == 1); configurations that keep candidate lists
+ * are refused after a resampling unless the group runs in RFSGPU_INHERIT_EAGER (rfsgpu_group_set_birth_inheritance). */
+int rfsgpu_group_predict_map(rfsgpu_group *g, int add_birth);
+int rfsgpu_group_set_birth_inheritance(rfsgpu_group *g, int mode);          /* RFSGPU_INHERIT_REFERENCE (default) | RFSGPU_INHERIT_EAGER */
+int rfsgpu_group_get_particle_ids(rfsgpu_group *g, int *id, int *parent_id); /* Particle::getId / getParentId by global slot */
 /* RBPHDFilter::update body (:444-523) on every shard; weights stay un-normalised; sums_out (may be null) = {sum w, sum w^2}. */
 int rfsgpu_group_update(rfsgpu_group *g, const double *z, int n_z, double *sums_out);
 int rfsgpu_group_normalize(rfsgpu_group *g, double *sums_out);               /* normalizeWeights over all N (:352-363) */

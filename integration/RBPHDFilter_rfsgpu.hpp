@@ -160,6 +160,9 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
       : ParticleFilter<RobotProcessModel, MeasurementModel, GaussianMixture<TLandmark> >(n), engine_(NULL), model_(this->pMeasurementModel_) {
     lmkModelPtr_ = new LmkProcessModel;
     kf_ = new KalmanFilter(lmkModelPtr_, this->pMeasurementModel_);
+    /* :362-364.  Particle::copy (include/Particle.hpp:218-223) dereferences data_, so every particle owns a mixture object as in
+     * the reference; it stays EMPTY here -- the particle's Gaussians live on the device (getGMSize / getLandmark read them). */
+    for (int i = 0; i < n; i++) this->particleSet_[i]->setData(boost::shared_ptr<TGM>(new TGM()));
     config.birthGaussianWeight_ = 0.25;
     config.birthGaussianMeasurementCountThreshold_ = 1;
     config.birthGaussianMeasurementCheckThreshold_ = 1;
@@ -401,9 +404,11 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
 
   /* ParticleFilter::resample() (include/ParticleFilter.hpp:399-492) with n = nParticles_, restated only because the maps are
    * not in Particle::data_: the decision, the draw and the slot assignment are the reference's, statement for statement;
-   * `particleSet_[next] = particleSet_[idx]->copy()` (:473) becomes a host copy of the pose part plus src_slot[next] = idx,
-   * and ONE rfsgpu_resample_apply(src_slot) deep-copies the maps, unused-measurement lists, FOV counts and birth candidates on
-   * the device (what Particle::copy, include/Particle.hpp:218-223, and addBirthGaussians' lazy copy, :1005-1011, carry). */
+   * `particleSet_[next] = particleSet_[idx]->copy()` (:473) copies the host part (pose, id, the empty mixture object) and sets
+   * src_slot[next] = idx; ONE rfsgpu_resample_apply(src_slot) then deep-copies the mixtures on the device.  The engine keeps the
+   * same id_ / idParent_ bookkeeping per slot as the Particle objects here and performs addBirthGaussians' lazy, slot-ordered
+   * copy of unused_measurements_ / birthGaussians_ (:1005-1011) inside the next rfsgpu_predict_map(1), exactly as written
+   * (RFSGPU_INHERIT_REFERENCE, the engine's default). */
   bool resampleWithDeviceMaps() {
     this->normalizeWeights();                                                   /* :402 */
     const int n = this->nParticles_;
@@ -425,6 +430,8 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
     for (int i = 0; i < n; i++) {                                               /* :433-444 */
       while (sample_point > cumulative_weight) {
         idx++;
+        if ((int)idx >= n) { idx = n - 1; break; }   /* (the reference reads past the end of particleSet_ when round-off leaves the
+                                                        last sample point above the final cumulative weight; clamped here) */
         cumulative_weight += this->particleSet_[idx]->getWeight();
       }
       sampled_idx[i] = idx;
@@ -443,7 +450,7 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
         this->particleSet_[idx]->setParentId(this->particleSet_[idx]->getId());
       } else {                                                                   /* case 2 */
         while (flag_particle_sampled[next_unsampled_idx] == 1) next_unsampled_idx++;
-        this->particleSet_[next_unsampled_idx] = this->particleSet_[idx]->copy();   /* pose, id (data_ is empty on this path) */
+        this->particleSet_[next_unsampled_idx] = this->particleSet_[idx]->copy();   /* pose, id, (empty) mixture object */
         this->particleSet_[next_unsampled_idx]->setParentId(this->particleSet_[idx]->getId());
         src_slot[next_unsampled_idx] = (int)idx;
         next_unsampled_idx++;

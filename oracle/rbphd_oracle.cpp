@@ -892,6 +892,19 @@ struct FilterBase {
   bool fs_resample_occured = false; /* FastSLAM::resampleOccured_: the previous update ended in a resampling */
   virtual int fastslam_update() = 0;
   virtual void shrink(int n_out) = 0;
+  /* Birth-state inheritance after a resampling.  The reference keeps three per-SLOT arrays in RBPHDFilter
+   * (unused_measurements_, birthGaussians_, nLandmarksInFOV_) that Particle::copy does not carry; the first two are copied
+   * lazily by the next addBirthGaussians, indexed with the particle's parent ID (include/RBPHDFilter.hpp:1005-1011) --
+   * RFSGPU_INHERIT_REFERENCE restates exactly that (ids as in include/ParticleFilter.hpp:446-479 + Particle::copy,
+   * include/Particle.hpp:218-223: a copy keeps its source's id_).  RFSGPU_INHERIT_EAGER is rounds 1-2's reading of the
+   * intent (child takes the parent's lists and FOV count at resampling time); RFSGPU_INHERIT_EXTERNAL: the host does it. */
+  int inherit_mode = RFSGPU_INHERIT_REFERENCE;
+  std::vector<unsigned> pid, ppid; /* Particle::id_ / idParent_ of the particle in each slot */
+  bool resample_occured = false;   /* RBPHDFilter::resampleOccured_ */
+  bool fastslam_handle = false;    /* rfsor_fastslam_update has run: rfs::FastSLAM copies its candidate lists at resampling time (FastSLAM.hpp:747-753) */
+  bool eager() const { return inherit_mode == RFSGPU_INHERIT_EAGER || fastslam_handle; }
+  void ensure_ids() { while ((int)pid.size() < n) { pid.push_back((unsigned)pid.size()); ppid.push_back((unsigned)ppid.size()); } }
+  virtual void copy_map(int dst, int src) = 0; /* what Particle::copy carries besides the pose: the mixture */
 };
 
 static void fastslam_defaults(rfsgpu_fastslam_config *c, int n) { /* FastSLAM constructor, include/FastSLAM.hpp:243-257 */
@@ -1592,7 +1605,15 @@ struct FilterT : FilterBase {
   }
   int predict_map(int add_birth) override {
     long long t0 = now_ns();
+    ensure_ids();
     for (int i = 0; i < n; i++) {
+      if (add_birth && inherit_mode == RFSGPU_INHERIT_REFERENCE && !fastslam_handle && resample_occured) { /* :1005-1011, slot by slot, as written */
+        const unsigned i_prev = ppid[i];
+        if (i_prev != (unsigned)i && i_prev < unused.size() && i_prev < cand.size()) {
+          unused[i] = unused[i_prev];
+          cand[i] = cand[i_prev];
+        }
+      }
       if (add_birth) add_birth_particle(i);
       for (Gauss &g : gm[i]) /* staticStep: S += Q (include/ProcessModel.hpp:195-208) */
         for (int k = 0; k < D * D; k++) g.S.a[k] += Qlm.a[k];
@@ -1631,6 +1652,7 @@ struct FilterT : FilterBase {
     unused[dst] = unused[src]; nInFov[dst] = nInFov[src];
     cand[dst] = cand[src]; /* birthGaussians_[i] = birthGaussians_[i_prev] (:1005-1011) */
   }
+  void copy_map(int dst, int src) override { gm[dst] = gm[src]; gm_n[dst] = gm_n[src]; }
   void set_lmk_noise(const double *Q) override { memcpy(Qlm.a, Q, D * D * sizeof(double)); }
   void shrink(int n_out) override {
     n = n_out;
@@ -1811,6 +1833,7 @@ int rfsor_update_map(void *f, const double *z, int n_z) {
   if (n_z < 0) return RFSGPU_ERR_INVALID;
   F->Z.assign(z, z + (size_t)F->dz * n_z);
   F->nZ = n_z;
+  if (n_z > 0) F->resample_occured = false; /* :526 (an update with measurements; the resampling decision follows it) */
   F->update_map();
   return RFSGPU_OK;
 }
@@ -1835,6 +1858,7 @@ int rfsor_get_fastslam_config(const void *f, rfsgpu_fastslam_config *c) { *c = r
 int rfsor_fastslam_update(void *f, const double *z, int n_z) {
   FilterBase *F = F_(f);
   if (n_z < 0) return RFSGPU_ERR_INVALID;
+  F->fastslam_handle = true;
   if (n_z == 0) return RFSGPU_OK; /* include/FastSLAM.hpp:401-402 */
   F->Z.assign(z, z + (size_t)F->dz * n_z);
   F->nZ = n_z;
@@ -1888,10 +1912,20 @@ int rfsor_resample_apply_n(void *f, const int *src, int n_out) {
   FilterBase *F = F_(f);
   if (n_out < 1 || n_out > F->n) return RFSGPU_ERR_INVALID;
   for (int k = 0; k < n_out; k++) if (src[k] < 0 || src[k] >= F->n || (src[k] < n_out && src[src[k]] != src[k])) return RFSGPU_ERR_INVALID;
+  F->ensure_ids();
   for (int k = 0; k < n_out; k++) {
-    if (src[k] != k) { F->copy_particle(k, src[k]); F->pose[k] = F->pose[src[k]]; } /* Particle::copy carries the pose (Particle.hpp:218-223) */
+    if (src[k] != k) {
+      if (F->eager()) F->copy_particle(k, src[k]);
+      else F->copy_map(k, src[k]);        /* Particle::copy: pose + mixture; the per-slot arrays of RBPHDFilter stay */
+      F->pose[k] = F->pose[src[k]];       /* Particle::copy carries the pose (Particle.hpp:218-223) */
+      F->pid[k] = F->pid[src[k]];         /* ... and the id (copy constructor); setParentId(source's id), ParticleFilter.hpp:473-474 */
+      F->ppid[k] = F->pid[src[k]];
+    } else {
+      F->ppid[k] = F->pid[k];             /* case 1, ParticleFilter.hpp:466-467 */
+    }
     F->weight[k] = 1;
   }
+  F->resample_occured = true;
   F->shrink(n_out); /* particleSet_.resize(n) (ParticleFilter.hpp:481-483); the candidate lists beyond n stay where they are */
   return RFSGPU_OK;
 }
@@ -1939,9 +1973,12 @@ int rfsor_import_slab_rows(void *f, const int *slots, int n, const void *rows) {
     if (s < 0 || s >= F->n) return RFSGPU_ERR_INVALID;
     const double *r = (const double *)rows + (size_t)k * row_doubles(F);
     const int cnt = (int)r[0];
-    F->nInFov[s] = (unsigned)r[1];
-    F->unused[s].clear();
-    for (int u = 0; u < (int)r[2]; u++) F->unused[s].push_back((unsigned)r[3 + u]);
+    const bool eager = F->eager(); /* otherwise only what Particle::copy carries is taken */
+    if (eager) {
+      F->nInFov[s] = (unsigned)r[1];
+      F->unused[s].clear();
+      for (int u = 0; u < (int)r[2]; u++) F->unused[s].push_back((unsigned)r[3 + u]);
+    }
     memcpy(F->pose[s].x, r + 67, 3 * sizeof(double));
     memcpy(F->pose[s].P, r + 70, 9 * sizeof(double));
     const double *g = r + ROW_HDR, *gw = g, *gm = g + 2 * (size_t)ROW_MAXG, *gc = gm + (size_t)ROW_MAXG * D;
@@ -1951,8 +1988,37 @@ int rfsor_import_slab_rows(void *f, const int *slots, int n, const void *rows) {
     const int nc = (int)r[79];
     std::vector<int> sup(nc), chk(nc);
     for (int q = 0; q < nc; q++) { sup[q] = (int)ci[2 * q]; chk[q] = (int)ci[2 * q + 1]; }
-    F->import_candidates(s, nc, cmean, ccov, sup.data(), chk.data());
+    if (eager) F->import_candidates(s, nc, cmean, ccov, sup.data(), chk.data());
   }
+  return RFSGPU_OK;
+}
+int rfsor_set_birth_inheritance(void *f, int mode) {
+  if (mode != RFSGPU_INHERIT_REFERENCE && mode != RFSGPU_INHERIT_EAGER && mode != RFSGPU_INHERIT_EXTERNAL) return RFSGPU_ERR_INVALID;
+  F_(f)->inherit_mode = mode;
+  return RFSGPU_OK;
+}
+int rfsor_get_birth_inheritance(const void *f) { return reinterpret_cast<const FilterBase *>(f)->inherit_mode; }
+int rfsor_get_particle_ids(void *f, int *id, int *parent_id) {
+  FilterBase *F = F_(f);
+  F->ensure_ids();
+  for (int k = 0; k < F->n; k++) { if (id) id[k] = (int)F->pid[k]; if (parent_id) parent_id[k] = (int)F->ppid[k]; }
+  return RFSGPU_OK;
+}
+int rfsor_set_particle_ids(void *f, const int *id, const int *parent_id) {
+  FilterBase *F = F_(f);
+  F->ensure_ids();
+  for (int k = 0; k < F->n; k++) { if (id) F->pid[k] = (unsigned)id[k]; if (parent_id) F->ppid[k] = (unsigned)parent_id[k]; }
+  return RFSGPU_OK;
+}
+int rfsor_resample_occured(const void *f) { return reinterpret_cast<const FilterBase *>(f)->resample_occured ? 1 : 0; }
+int rfsor_get_unused_masks(void *f, unsigned long long *masks) {
+  FilterBase *F = F_(f);
+  for (int k = 0; k < F->n; k++) { unsigned long long m = 0; for (unsigned u : F->unused[k]) m |= 1ull << u; masks[k] = m; }
+  return RFSGPU_OK;
+}
+int rfsor_set_unused_masks(void *f, const unsigned long long *masks) {
+  FilterBase *F = F_(f);
+  for (int k = 0; k < F->n; k++) { F->unused[k].clear(); for (unsigned u = 0; u < 64; u++) if (masks[k] >> u & 1ull) F->unused[k].push_back(u); }
   return RFSGPU_OK;
 }
 void *rfsor_weights_device_ptr(void *f) { return (void *)F_(f)->weight.data(); }

@@ -13,6 +13,7 @@ import numpy as np
 
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_NO_DEVICE, ERR_UNSUPPORTED = 1, 2, 3, 4, 5
+INHERIT_REFERENCE, INHERIT_EAGER, INHERIT_EXTERNAL = 0, 1, 2
 MODEL_RNGBRG_2D = 0
 MODEL_VICTORIAPARK_3D = 1
 VP_MAX_PD = 16
@@ -117,10 +118,11 @@ ABI_SYMBOLS = [
     "normalize_weights_parts", "create_ex", "n_particles", "max_particles", "resample_apply_n",
     "fastslam_set_resample_occured", "particle_parents", "vp_probe_pd",
     "slab_row_bytes", "export_slab_rows", "import_slab_rows", "weights_device_ptr", "step_async", "set_step_inputs_async", "predict_map_async", "set_phase_timing", "static_steps_async", "propagate_ackerman_async", "propagate_ackerman_run_async", "set_partition_mode", "get_partition_mode",
+    "set_birth_inheritance", "get_birth_inheritance", "get_particle_ids", "set_particle_ids", "resample_occured", "get_unused_masks", "set_unused_masks",
     "group_create", "group_destroy", "group_last_error", "group_n_shards", "group_n_particles", "group_shard", "group_locate",
     "group_set_filter_config", "group_set_model_rngbrg", "group_set_kf_config", "group_set_lmk_process_noise", "group_set_poses",
     "group_get_poses", "group_set_weights", "group_get_weights", "group_predict_map", "group_update", "group_normalize",
-    "group_resample", "group_apply_plan", "group_migration_stats", "group_gm_size", "group_get_landmark", "group_synchronize",
+    "group_resample", "group_apply_plan", "group_migration_stats", "group_gm_size", "group_get_landmark", "group_synchronize", "group_set_birth_inheritance", "group_get_particle_ids",
 ]
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -440,6 +442,42 @@ class CFilter:
             assert s.size == n_out
             self._call("resample_apply_n", self._ptr(s), C.c_int(int(n_out)))
 
+    # birth-state inheritance after a resampling (rfsgpu.h: RFSGPU_INHERIT_*; include/RBPHDFilter.hpp:1005-1011)
+    def set_birth_inheritance(self, mode):
+        self._call("set_birth_inheritance", C.c_int(int(mode)))
+
+    def get_birth_inheritance(self):
+        fn = self._fn("get_birth_inheritance")
+        fn.restype = C.c_int
+        return int(fn(self._h))
+
+    def get_particle_ids(self):
+        """(Particle::getId, Particle::getParentId) of the particle in every slot."""
+        ids = np.zeros(self.n, dtype=np.int32)
+        par = np.zeros(self.n, dtype=np.int32)
+        self._call("get_particle_ids", self._ptr(ids), self._ptr(par))
+        return ids, par
+
+    def set_particle_ids(self, ids=None, parent_ids=None):
+        a = None if ids is None else np.ascontiguousarray(ids, dtype=np.int32)
+        b = None if parent_ids is None else np.ascontiguousarray(parent_ids, dtype=np.int32)
+        self._call("set_particle_ids", C.c_void_p(None) if a is None else self._ptr(a), C.c_void_p(None) if b is None else self._ptr(b))
+
+    def resample_occured(self):
+        fn = self._fn("resample_occured")
+        fn.restype = C.c_int
+        return bool(fn(self._h))
+
+    def get_unused_masks(self):
+        m = np.zeros(self.n, dtype=np.uint64)
+        self._call("get_unused_masks", self._ptr(m))
+        return m
+
+    def set_unused_masks(self, masks):
+        m = np.ascontiguousarray(masks, dtype=np.uint64)
+        assert m.size == self.n
+        self._call("set_unused_masks", self._ptr(m))
+
     def set_partition_mode(self, exact):
         """Partitions with nR + nC > 8: Murty-200 as the reference (False, default) or the exact subset recurrence (True)."""
         self._call("set_partition_mode", C.c_int(1 if exact else 0))
@@ -644,6 +682,15 @@ class Group:
 
     def predict_map(self, add_birth=True):
         self._call("predict_map", C.c_int(1 if add_birth else 0))
+
+    def set_birth_inheritance(self, mode):
+        self._call("set_birth_inheritance", C.c_int(int(mode)))
+
+    def get_particle_ids(self):
+        ids = np.zeros(self.n, dtype=np.int32)
+        par = np.zeros(self.n, dtype=np.int32)
+        self._call("get_particle_ids", ids.ctypes.data_as(C.c_void_p), par.ctypes.data_as(C.c_void_p))
+        return ids, par
 
     def update(self, Z):
         Z = _f64(Z).reshape(-1, self.dz)

@@ -12,6 +12,42 @@
 #include "common.h"
 #include "vp.h"
 
+// ---- birth-state inheritance after a resampling: RBPHDFilter.hpp:1005-1011 as written -------------------------------------
+//   for i = 0 .. N-1:  if (resampleOccured_) { i_prev = particle[i].idParent_;  if (i_prev != i) { unused_measurements_[i] =
+//   unused_measurements_[i_prev];  birthGaussians_[i] = birthGaussians_[i_prev]; } }   ... then slot i's own birth step.
+// The arrays are per SLOT and i_prev is an ID, so what a slot receives depends on where the walk is: a HIGHER slot i_prev still
+// holds what it held before this predict (it may be overwritten later, by its own copy), a LOWER one has already been through
+// its birth step (empty unused list, candidates one check older and possibly promoted away).  On the device:
+//   level 0 = slots that keep their lists (i_prev == i) or copy from a higher slot.  Their sources are read before anything is
+//             written: kernel <0> copies source lists into a staging area indexed by the DESTINATION, kernel <1> commits them
+//             (a source may itself be a destination).  Then the birth launch for level 0.
+//   level L = slots whose i_prev is a lower slot of level L-1: kernel <2> copies the (final) lists of i_prev, then the birth
+//             launch for level L.  Two slots of one level never read each other.
+// FOV counts (nLandmarksInFOV_) are never copied by the reference, so they are not here either.
+struct BirthLists {
+  unsigned long long *unused;
+  int *count, *sup, *chk;
+  double *mean, *cov;
+};
+__device__ inline void birth_lists_copy(const BirthLists &S, int s, const BirthLists &Dst, int d) {
+  const int nc = S.count[s];
+  const size_t sb = (size_t)s * RFSGPU_MAX_CANDIDATES, db = (size_t)d * RFSGPU_MAX_CANDIDATES;
+  for (int t = threadIdx.x; t < nc * 3; t += blockDim.x) Dst.mean[db * 3 + t] = S.mean[sb * 3 + t];
+  for (int t = threadIdx.x; t < nc * 6; t += blockDim.x) Dst.cov[db * 6 + t] = S.cov[sb * 6 + t];
+  for (int t = threadIdx.x; t < nc; t += blockDim.x) { Dst.sup[db + t] = S.sup[sb + t]; Dst.chk[db + t] = S.chk[sb + t]; }
+  if (threadIdx.x == 0) { Dst.count[d] = nc; Dst.unused[d] = S.unused[s]; }
+}
+template <int PHASE>
+__global__ __launch_bounds__(128) void birth_inherit_kernel(Buffers B, BirthLists T, const int *parent, const int *level, int L) {
+  const int i = blockIdx.x;
+  const int p = parent[i];
+  if (p == i || level[i] != L) return;
+  BirthLists live{B.unusedMask, B.candCount, B.candSup, B.candChk, B.candMean, B.candCov};
+  if (PHASE == 0) birth_lists_copy(live, p, T, i);        // level 0, p > i: the source as it is before this predict
+  else if (PHASE == 1) birth_lists_copy(T, i, live, i);
+  else birth_lists_copy(live, p, live, i);                // level >= 1, p < i: the source after its own birth step
+}
+
 template <int D>
 struct Cand {
   double x[3];
@@ -173,13 +209,14 @@ struct CandLDS {
 // (<= RFSGPU_MAX_CANDIDATES), 64 candidates at a time, for the particles the first kernel left alone.  (r02: the LDS form alone,
 // for everybody, made a birth predict of the Victoria Park run 103 us where the lane form takes 47: 20 KB of LDS per wave.)
 template <int D, int WPB>
-__global__ __launch_bounds__(WPB * 64) void predict_map_general_kernel(Buffers B, Params P, int cur, int addBirth, int nZprev) {
+__global__ __launch_bounds__(WPB * 64) void predict_map_general_kernel(Buffers B, Params P, int cur, int addBirth, int nZprev, BirthLevel LV) {
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
   if (i >= B.N) return;
   const int cap = B.cap;
   const int nOld = B.count[i];
+  addBirth = addBirth && LV.mine(i);
   // A list that may outgrow the lanes during this call (candidates + unused measurements > 64) is left to predict_map_long_kernel,
   // which the host launches right after this one; the static step below is done here for every particle.
   const bool longList = addBirth && (B.candCount[i] + ((nZprev > 0) ? __popcll(B.unusedMask[i]) : 0) > 64);
@@ -261,6 +298,7 @@ __global__ __launch_bounds__(WPB * 64) void predict_map_general_kernel(Buffers B
     }
   }
   // staticStep on the pre-existing Gaussians
+  if (!LV.doStatic) return;
   double *slab = B.slab[cur];
   if (D == 2) {
     double *pSXX = plane(slab, cap, i, PL_SXX), *pSXY = plane(slab, cap, i, PL_SXY), *pSYY = plane(slab, cap, i, PL_SYY);
@@ -274,12 +312,13 @@ __global__ __launch_bounds__(WPB * 64) void predict_map_general_kernel(Buffers B
 }
 
 template <int D, int WPB>
-__global__ __launch_bounds__(WPB * 64) void predict_map_long_kernel(Buffers B, Params P, int cur, int nZprev) {
+__global__ __launch_bounds__(WPB * 64) void predict_map_long_kernel(Buffers B, Params P, int cur, int nZprev, BirthLevel LV) {
   __shared__ CandLDS<D> sCand[WPB];
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
   if (i >= B.N) return;
+  if (!LV.mine(i)) return;
   const int cap = B.cap;
   const int nOld = B.count[i];
   // (only the particles predict_map_general_kernel left alone: candidates + unused measurements > one per lane)

@@ -84,6 +84,16 @@ struct Buffers {
   long long *dbg;    // section timestamps (only written by -DRFS_PROFILE builds; NULL otherwise)
 };
 
+// Which particles a birth launch works on.  Normally all of them.  In the first predicts after a resampling the reference's
+// lazy copy of the per-slot birth state (RBPHDFilter.hpp:1005-1011, below) orders the slots: `level` then holds, per slot, the
+// length of its chain of LOWER-slot parents, and one launch takes one level; the static step is done by the first launch only.
+struct BirthLevel {
+  const int *level;   // nullptr: every particle
+  int cur;
+  int doStatic;
+  __device__ bool mine(int i) const { return level == nullptr || level[i] == cur; }
+};
+
 // Section timing for kernel tuning (tools/kernel_sections.py builds a separate -DRFS_PROFILE library):
 // particle `RFS_PROFILE_PARTICLE`'s lane 0 stamps s_memtime at section boundaries.
 #ifdef RFS_PROFILE

@@ -19,6 +19,11 @@ struct rfsgpu_group {
   std::vector<hipEvent_t> evExport;
   std::vector<int> lastPlan;
   long long rowsMigrated = 0, bytesMigrated = 0;
+  // birth-state inheritance after a resampling (include/RBPHDFilter.hpp:1005-1011): ids are GLOBAL slot numbers, so the group owns
+  // the rule and its shards run in RFSGPU_INHERIT_EXTERNAL (RFSGPU_INHERIT_EAGER: the shards copy eagerly, the group does nothing)
+  int inheritMode = RFSGPU_INHERIT_REFERENCE;
+  std::vector<int> pid, ppid;
+  bool resampleOccured = false;
   std::string err;
 };
 
@@ -78,8 +83,11 @@ int rfsgpu_group_create(rfsgpu_group **out, int model, int n_particles, const in
     rfsgpu_filter *f = nullptr;
     const int rc = rfsgpu_create(&f, model, g->first[k + 1] - g->first[k], device_ids[k], gm_capacity);
     if (rc != RFSGPU_OK) { rfsgpu_group_destroy(g); return rc; }
+    rfsgpu_set_birth_inheritance(f, RFSGPU_INHERIT_EXTERNAL);
     g->shard.push_back(f);
   }
+  g->pid.resize(n_particles); g->ppid.resize(n_particles);
+  for (int p = 0; p < n_particles; p++) g->pid[p] = g->ppid[p] = p;
   g->sendBuf.assign(n_dev, nullptr); g->recvBuf.assign(n_dev, nullptr);
   g->sendCap.assign(n_dev, 0); g->recvCap.assign(n_dev, 0);
   g->evExport.assign(n_dev, nullptr);
@@ -159,15 +167,55 @@ int rfsgpu_group_get_weights(rfsgpu_group *g, double *w) {
   for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_get_weights(g->shard[k], w + g->first[k]));
   return RFSGPU_OK;
 }
+// RFSGPU_INHERIT_REFERENCE (default) or RFSGPU_INHERIT_EAGER for the whole group (see rfsgpu_set_birth_inheritance).
+int rfsgpu_group_set_birth_inheritance(rfsgpu_group *g, int mode) {
+  if (!g || (mode != RFSGPU_INHERIT_REFERENCE && mode != RFSGPU_INHERIT_EAGER)) return RFSGPU_ERR_INVALID;
+  g->inheritMode = mode;
+  for (size_t k = 0; k < g->shard.size(); k++)
+    GFWD(k, rfsgpu_set_birth_inheritance(g->shard[k], mode == RFSGPU_INHERIT_EAGER ? RFSGPU_INHERIT_EAGER : RFSGPU_INHERIT_EXTERNAL));
+  return RFSGPU_OK;
+}
+int rfsgpu_group_get_particle_ids(rfsgpu_group *g, int *id, int *parent_id) {
+  if (!g) return RFSGPU_ERR_INVALID;
+  for (int p = 0; p < g->N; p++) { if (id) id[p] = g->pid[p]; if (parent_id) parent_id[p] = g->ppid[p]; }
+  return RFSGPU_OK;
+}
+// RBPHDFilter::predict, map part (:415-442).  In the predicts that follow a resampling the reference first copies, slot by slot in
+// ascending order, unused_measurements_ / birthGaussians_ from SLOT idParent_ in its current state (:1005-1011).  With immediate
+// births (birthGaussianMeasurementCountThreshold == 1, the 2-D simulator: no candidate list ever exists) that walk has a closed
+// form over the lists as they are before the predict -- own list if idParent_ == slot, the parent slot's list if it is a HIGHER
+// slot (not yet visited), nothing if it is a LOWER one (already consumed) -- which needs only the 8-byte masks of all shards.
+// Configurations that keep candidate lists would need the lists themselves to cross shards level by level: refused loudly
+// here (RFSGPU_INHERIT_EAGER is the opt-in that does not need it; a single-GPU filter implements the walk in full).
 int rfsgpu_group_predict_map(rfsgpu_group *g, int add_birth) {
   if (!g) return RFSGPU_ERR_INVALID;
+  if (add_birth && g->resampleOccured && g->inheritMode == RFSGPU_INHERIT_REFERENCE) {
+    const rfsgpu_filter *f0 = g->shard[0];
+    if (f0->D != 2 || f0->cfg.birthGaussianMeasurementCountThreshold != 1u || f0->candUsed)
+      return gfail(g, RFSGPU_ERR_UNSUPPORTED, "group predict after a resampling: the reference's slot-ordered copy of birth-candidate lists across shards is not "
+                                               "implemented (immediate births only); select RFSGPU_INHERIT_EAGER for this configuration");
+    std::vector<unsigned long long> m((size_t)g->N), mn((size_t)g->N);
+    for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_get_unused_masks(g->shard[k], m.data() + g->first[k]));
+    bool any = false;
+    for (int p = 0; p < g->N; p++) {
+      const int q = g->ppid[p];
+      mn[p] = (q == p || q < 0 || q >= g->N) ? m[p] : (q > p ? m[q] : 0ull);
+      any |= mn[p] != m[p];
+    }
+    if (any) for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_set_unused_masks(g->shard[k], mn.data() + g->first[k]));
+  }
   for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_predict_map(g->shard[k], add_birth));
   return RFSGPU_OK;
 }
+// (every shard is synchronised even when one reports an error: the others' streams and error words must not stay unharvested)
 int rfsgpu_group_synchronize(rfsgpu_group *g) {
   if (!g) return RFSGPU_ERR_INVALID;
-  for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_synchronize(g->shard[k]));
-  return RFSGPU_OK;
+  int first = RFSGPU_OK;
+  for (size_t k = 0; k < g->shard.size(); k++) {
+    const int rc = rfsgpu_synchronize(g->shard[k]);
+    if (rc != RFSGPU_OK && first == RFSGPU_OK) first = gfail(g, rc, std::string("shard ") + std::to_string(k) + ": " + rfsgpu_last_error(g->shard[k]));
+  }
+  return first;
 }
 
 // {sum w, sum w^2} over all shards (each shard's pair was left by its post kernel / weight_sums kernel), added in shard order.
@@ -180,8 +228,9 @@ static int group_totals(rfsgpu_group *g, bool launch_sums, double tot[2]) {
     GCHK(hipMemcpyAsync(f->hSums, f->dSums, 2 * sizeof(double), hipMemcpyDeviceToHost, f->stream));
   }
   tot[0] = tot[1] = 0.0;
+  const int rcs = rfsgpu_group_synchronize(g);    // all shards; also surfaces device-side errors of the async steps
+  if (rcs != RFSGPU_OK) return rcs;
   for (int k = 0; k < S; k++) {
-    GFWD(k, rfsgpu_synchronize(g->shard[k]));     // also surfaces device-side errors of the async steps
     tot[0] += g->shard[k]->hSums[0];
     tot[1] += g->shard[k]->hSums[1];
   }
@@ -193,6 +242,7 @@ static int group_totals(rfsgpu_group *g, bool launch_sums, double tot[2]) {
 int rfsgpu_group_update(rfsgpu_group *g, const double *z, int n_z, double *sums_out) {
   if (!g) return RFSGPU_ERR_INVALID;
   for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_step_async(g->shard[k], z, n_z, 0));
+  if (n_z > 0) g->resampleOccured = false;       // RBPHDFilter.hpp:526
   double tot[2];
   const int rc = group_totals(g, false, tot);
   if (rc != RFSGPU_OK) return rc;
@@ -237,6 +287,8 @@ int rfsgpu_group_apply_plan(rfsgpu_group *g, const int *src) {
     else cross[ks][kd].push_back(p);
   }
   const size_t R = rfsgpu_slab_row_bytes(g->shard[0]);
+  for (int k = 1; k < S; k++)   // source and destination must agree on the row layout (it depends on per-shard state in eager mode)
+    if (rfsgpu_slab_row_bytes(g->shard[k]) != R) return gfail(g, RFSGPU_ERR_INVALID, "apply_plan: shards disagree on the migration row size (candidate lists imported on some shards only?)");
   // 1. export on every source shard (its stream), all destinations back to back in one buffer
   std::vector<std::vector<size_t>> sendOff(S, std::vector<size_t>(S, 0)), recvOff(S, std::vector<size_t>(S, 0));
   for (int ks = 0; ks < S; ks++) {
@@ -277,6 +329,12 @@ int rfsgpu_group_apply_plan(rfsgpu_group *g, const int *src) {
   }
   for (int k = 0; k < S; k++) GFWD(k, rfsgpu_synchronize(g->shard[k]));   // (send buffers are reused by the next resampling)
   g->lastPlan.assign(src, src + g->N);
+  // ids as ParticleFilter::resample leaves them (:446-479; a copy keeps its source's id, Particle::copy), over GLOBAL slots
+  for (int p = 0; p < g->N; p++) {
+    if (src[p] != p) { g->pid[p] = g->pid[src[p]]; g->ppid[p] = g->pid[src[p]]; }
+    else g->ppid[p] = g->pid[p];
+  }
+  g->resampleOccured = true;
   return RFSGPU_OK;
 }
 

@@ -861,7 +861,7 @@ __global__ void set_weights_kernel(double *w, int N, double v) {
 
 // Resample copy: slot k takes slot src[k]'s mixture (Particle::copy -> GaussianMixture copy ctor).
 // One block per destination slot; sources are slots that keep themselves, so in-place is hazard-free.
-__global__ __launch_bounds__(256) void resample_gather_kernel(Buffers B, int cur, const int *srcSlot, int poseCovStride) {
+__global__ __launch_bounds__(256) void resample_gather_kernel(Buffers B, int cur, const int *srcSlot, int poseCovStride, int mapOnly) {
   const int k = blockIdx.x;
   const int s = srcSlot[k];
   if (s == k) return;
@@ -872,7 +872,14 @@ __global__ __launch_bounds__(256) void resample_gather_kernel(Buffers B, int cur
     double *d = slab + ((size_t)k * B.npl + pl) * (size_t)B.cap;
     for (int m = threadIdx.x; m < n; m += blockDim.x) d[m] = q[m];
   }
-  // birth bookkeeping travels with the particle (RBPHDFilter.hpp:1005-1011): unused list, FOV count, candidate list
+  // the pose travels with the particle (Particle::copy, include/Particle.hpp:218-223)
+  if (threadIdx.x < 3) B.pose[3 * (size_t)k + threadIdx.x] = B.pose[3 * (size_t)s + threadIdx.x];
+  if (poseCovStride == 9 && threadIdx.x < 9) B.poseCov[9 * (size_t)k + threadIdx.x] = B.poseCov[9 * (size_t)s + threadIdx.x];
+  if (mapOnly) {   // RFSGPU_INHERIT_REFERENCE / _EXTERNAL: the per-slot birth state stays where it is (birth.h, birth_inherit_kernel)
+    if (threadIdx.x == 0) B.count[k] = n;
+    return;
+  }
+  // RFSGPU_INHERIT_EAGER: birth bookkeeping travels with the particle: unused list, FOV count, candidate list
   const int nc = B.candCount[s];
   for (int t = threadIdx.x; t < nc * 3; t += blockDim.x) B.candMean[(size_t)k * RFSGPU_MAX_CANDIDATES * 3 + t] = B.candMean[(size_t)s * RFSGPU_MAX_CANDIDATES * 3 + t];
   for (int t = threadIdx.x; t < nc * 6; t += blockDim.x) B.candCov[(size_t)k * RFSGPU_MAX_CANDIDATES * 6 + t] = B.candCov[(size_t)s * RFSGPU_MAX_CANDIDATES * 6 + t];
@@ -880,9 +887,6 @@ __global__ __launch_bounds__(256) void resample_gather_kernel(Buffers B, int cur
     B.candSup[(size_t)k * RFSGPU_MAX_CANDIDATES + t] = B.candSup[(size_t)s * RFSGPU_MAX_CANDIDATES + t];
     B.candChk[(size_t)k * RFSGPU_MAX_CANDIDATES + t] = B.candChk[(size_t)s * RFSGPU_MAX_CANDIDATES + t];
   }
-  // the pose travels with the particle too (Particle::copy, include/Particle.hpp:218-223)
-  if (threadIdx.x < 3) B.pose[3 * (size_t)k + threadIdx.x] = B.pose[3 * (size_t)s + threadIdx.x];
-  if (poseCovStride == 9 && threadIdx.x < 9) B.poseCov[9 * (size_t)k + threadIdx.x] = B.poseCov[9 * (size_t)s + threadIdx.x];
   if (threadIdx.x == 0) {
     B.count[k] = n;
     B.unusedMask[k] = B.unusedMask[s];
@@ -904,7 +908,7 @@ __host__ __device__ inline size_t slab_row_bytes(int npl, int cap, int rowCand) 
   return (size_t)RFSGPU_ROW_HEADER_DOUBLES * 8 + (size_t)npl * cap * 8 + (size_t)rowCand * (3 + 6) * 8 + (size_t)rowCand * 2 * 4;
 }
 template <bool EXPORT>
-__global__ __launch_bounds__(256) void slab_rows_kernel(Buffers B, int cur, const int *slots, unsigned char *rows, int poseCovStride, int rowCand) {
+__global__ __launch_bounds__(256) void slab_rows_kernel(Buffers B, int cur, const int *slots, unsigned char *rows, int poseCovStride, int rowCand, int mapOnly) {
   const int s = slots[blockIdx.x];
   unsigned char *row = rows + (size_t)blockIdx.x * slab_row_bytes(B.npl, B.cap, rowCand);
   double *hdr = reinterpret_cast<double *>(row);
@@ -915,7 +919,7 @@ __global__ __launch_bounds__(256) void slab_rows_kernel(Buffers B, int cur, cons
   const size_t cb = (size_t)s * RFSGPU_MAX_CANDIDATES;
   if (EXPORT) {
     const int n = B.count[s];
-    int nc = B.candCount[s];
+    int nc = mapOnly ? 0 : B.candCount[s];   // (mapOnly: the row carries what Particle::copy carries -- pose + mixture)
     if (nc > rowCand) {   // a list the row has no room for (the configuration says there is none): refused loudly, never dropped silently
       if (threadIdx.x == 0) atomicOr(B.err, ERRBIT_BIRTHLIST);
       nc = rowCand;
@@ -934,7 +938,7 @@ __global__ __launch_bounds__(256) void slab_rows_kernel(Buffers B, int cur, cons
       hdr[15] = (double)nc;
     }
   } else {
-    const int n = (int)hdr[0], nc = (int)hdr[15];
+    const int n = (int)hdr[0], nc = mapOnly ? 0 : (int)hdr[15];
     for (int p = 0; p < B.npl; p++)
       for (int m = threadIdx.x; m < n; m += blockDim.x) slab[(size_t)p * B.cap + m] = pl[(size_t)p * B.cap + m];
     for (int t = threadIdx.x; t < nc * 3; t += blockDim.x) B.candMean[cb * 3 + t] = cm[t];
@@ -944,9 +948,11 @@ __global__ __launch_bounds__(256) void slab_rows_kernel(Buffers B, int cur, cons
     if (poseCovStride == 9 && threadIdx.x < 9) B.poseCov[9 * (size_t)s + threadIdx.x] = hdr[6 + threadIdx.x];
     if (threadIdx.x == 0) {
       B.count[s] = n;
-      B.nInFov[s] = (int)hdr[1];
-      B.unusedMask[s] = (unsigned long long)__double_as_longlong(hdr[2]);
-      B.candCount[s] = nc;
+      if (!mapOnly) {
+        B.nInFov[s] = (int)hdr[1];
+        B.unusedMask[s] = (unsigned long long)__double_as_longlong(hdr[2]);
+        B.candCount[s] = nc;
+      }
     }
   }
 }
@@ -993,11 +999,12 @@ __global__ __launch_bounds__(256) void restore_state_kernel(Buffers B, int cur, 
 // (:1000-1084) with MeasurementModel_RngBrg::inverseMeasure (src/MeasurementModel_RngBrg.cpp:117-136) --
 // then StaticProcessModel::staticStep, Sigma += Q (include/ProcessModel.hpp:195-208).
 template <int WPB>
-__global__ __launch_bounds__(WPB * 64) void predict_map_kernel(Buffers B, Params P, int cur, int addBirth, int nZprev) {
+__global__ __launch_bounds__(WPB * 64) void predict_map_kernel(Buffers B, Params P, int cur, int addBirth, int nZprev, BirthLevel LV) {
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
   if (i >= B.N) return;
+  addBirth = addBirth && LV.mine(i);
   const int cap = B.cap;
   double *slab = B.slab[cur];
   double *pW = plane(slab, cap, i, PL_W), *pWP = plane(slab, cap, i, PL_WP), *pMX = plane(slab, cap, i, PL_MX),
@@ -1045,6 +1052,7 @@ __global__ __launch_bounds__(WPB * 64) void predict_map_kernel(Buffers B, Params
       if (lane == 0) { B.count[i] = n; B.unusedMask[i] = 0ull; }
     }
   }
+  if (!LV.doStatic) return;
   for (int m = lane; m < nOld; m += 64) {
     pSXX[m] += P.Qlm[0];
     pSXY[m] += P.Qlm[1];

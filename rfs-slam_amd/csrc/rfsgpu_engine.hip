@@ -88,6 +88,15 @@ struct rfsgpu_filter {
   int *mhInts = nullptr;              // [5][Ncap] slotSrc, slotHyp, slotNH, copyDst, copySrc
   bool fsResampleOccured = false;     // FastSLAM::resampleOccured_ of the previous update (rfsgpu_fastslam_set_resample_occured)
   std::vector<int> parents;           // source slot of every particle after the last FastSLAM update (identity when none multiplied)
+  // birth-state inheritance after a resampling (rfsgpu_set_birth_inheritance; RBPHDFilter.hpp:1005-1011)
+  int inheritMode = RFSGPU_INHERIT_REFERENCE;
+  std::vector<int> pid, ppid;         // Particle::id_ / idParent_ of the particle in each slot (ParticleFilter.hpp:446-479)
+  bool resampleOccured = false;       // RBPHDFilter::resampleOccured_
+  bool fastSlamHandle = false;        // rfsgpu_fastslam_update has run: the filter class is rfs::FastSLAM, whose resampleWithMapCopy
+                                      // copies the candidate lists right at resampling time (FastSLAM.hpp:747-753) -> eager copies
+  int *dInhParent = nullptr, *dInhLevel = nullptr;   // [Ncap] each (allocated on first use)
+  BirthLists inhTmp{};                // staging area of birth_inherit_kernel<0/1> (allocated on first use)
+  std::vector<int> hInhParent, hInhLevel;
   bool holes = false;       // between rfsgpu_merge and rfsgpu_prune merged-away entries sit in the slab with w = -1; at any other
                             // time a negative weight is a value (FastSLAM's log-odds) and every stored entry counts
   int nCU = 256;            // multiProcessorCount of the device
@@ -327,6 +336,9 @@ void rfsgpu_destroy(rfsgpu_filter *f) {
   hipFree(f->snapSlab); hipFree(f->snapWeight); hipFree(f->snapCount); hipFree(f->snapFov); hipFree(f->snapUnused);
   hipFree(B.slab[0]); hipFree(B.slab[1]); hipFree(B.count); hipFree(B.pose); hipFree(B.poseCov); hipFree(B.weight);
   hipFree(B.unusedMask); hipFree(B.nInFov); hipFree(B.err); hipFree(B.Z); hipFree(f->ownSums); hipFree(f->dSrcSlot); if (f->dRowSlots) hipFree(f->dRowSlots); if (f->fsArena) hipFree(f->fsArena); if (f->mhArena) hipFree(f->mhArena); if (f->mhInts) hipFree(f->mhInts);
+  if (f->dInhParent) hipFree(f->dInhParent);
+  if (f->dInhLevel) hipFree(f->dInhLevel);
+  if (f->inhTmp.unused) { hipFree(f->inhTmp.unused); hipFree(f->inhTmp.count); hipFree(f->inhTmp.sup); hipFree(f->inhTmp.chk); hipFree(f->inhTmp.mean); hipFree(f->inhTmp.cov); }
   hipFree(B.scan); hipFree(B.candMean); hipFree(B.candCov); hipFree(B.candSup); hipFree(B.candChk); hipFree(B.candCount);
   murty_free(f->Q, f->MS);
   if (f->hErr) hipHostFree(f->hErr);
@@ -773,6 +785,7 @@ static int stage_measurements(rfsgpu_filter *f, const double *z, int n_z) {
     HIPCHK(hipGetLastError());
   }
   f->nZ = n_z;
+  if (n_z > 0) f->resampleOccured = false;   // RBPHDFilter.hpp:526 (an update with measurements; its resampling decision follows)
   return RFSGPU_OK;
 }
 
@@ -919,6 +932,7 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
     ZArg za;
     memcpy(za.v, z, (size_t)n_z * 2 * sizeof(double));
     f->nZ = n_z;
+    if (n_z > 0) f->resampleOccured = false;
     HIPCHK(hipEventRecord(e[0], f->stream));
     const int ec = eval_cap(f), useW = f->cfg.useClusterProcess ? 0 : 1;
     // Waves per particle: two, unless the two-wave grid cannot be resident at once (large mixtures: the LDS block limits the
@@ -1017,23 +1031,84 @@ int rfsgpu_kernel_time_stats(rfsgpu_filter *f, double *avg_ns3, int *n_steps) {
   return RFSGPU_OK;
 }
 
+// The birth + static-step launches of one predict.  LV selects the particles whose birth step runs (birth.h).
+static void launch_predict_kernels(rfsgpu_filter *f, int add_birth, const BirthLevel &LV) {
+  if (f->D == 3)
+  {
+    predict_map_general_kernel<3, 4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ, LV);
+    if (add_birth) predict_map_long_kernel<3, 2><<<(f->N + 1) / 2, 128, 0, f->stream>>>(f->B, f->P, f->cur, f->nZ, LV);   // (lists longer than a wavefront; the others exit at once)
+  }
+  else if (f->cfg.birthGaussianMeasurementCountThreshold != 1u)
+  {
+    predict_map_general_kernel<2, 4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ, LV);
+    if (add_birth) predict_map_long_kernel<2, 2><<<(f->N + 1) / 2, 128, 0, f->stream>>>(f->B, f->P, f->cur, f->nZ, LV);
+  }
+  else  // CountThreshold == 1: every unused measurement is born at once, no candidate can exist -> lane-parallel kernel
+    predict_map_kernel<4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ, LV);
+}
+
+// what a resampling copy / a migration row carries: pose + mixture only (RBPHDFilter: the per-slot birth state is copied
+// lazily by the next predict, or by the host), or the birth bookkeeping as well (RFSGPU_INHERIT_EAGER, and FastSLAM handles)
+static int map_only(const rfsgpu_filter *f) { return (f->inheritMode != RFSGPU_INHERIT_EAGER && !f->fastSlamHandle) ? 1 : 0; }
+static void ensure_ids(rfsgpu_filter *f) {
+  while ((int)f->pid.size() < f->Ncap) { f->pid.push_back((int)f->pid.size()); f->ppid.push_back((int)f->ppid.size()); }
+}
+
+// RBPHDFilter::predict's map part.  In the predicts that follow a resampling (resampleOccured_, RFSGPU_INHERIT_REFERENCE) the
+// reference's slot-ordered lazy copy of unused_measurements_ / birthGaussians_ (RBPHDFilter.hpp:1005-1011) precedes each slot's
+// birth step: see birth_inherit_kernel (birth.h) for how the walk is cut into levels.
+static int predict_launch(rfsgpu_filter *f, int add_birth) {
+  const BirthLevel all{nullptr, 0, 1};
+  if (!(add_birth && f->resampleOccured && f->inheritMode == RFSGPU_INHERIT_REFERENCE && !f->fastSlamHandle)) {
+    launch_predict_kernels(f, add_birth, all);
+    return RFSGPU_OK;
+  }
+  ensure_ids(f);
+  const int N = f->N;
+  bool any = false;
+  int maxLevel = 0;
+  f->hInhParent.resize(N);
+  f->hInhLevel.resize(N);
+  for (int i = 0; i < N; i++) {
+    int p = f->ppid[i];
+    if (p < 0 || p >= N) p = i;     // (an id beyond the current particle count: a slot the reference would index out of range)
+    f->hInhParent[i] = p;
+    f->hInhLevel[i] = (p >= i) ? 0 : f->hInhLevel[p] + 1;
+    any |= p != i;
+    if (f->hInhLevel[i] > maxLevel) maxLevel = f->hInhLevel[i];
+  }
+  if (!any) { launch_predict_kernels(f, add_birth, all); return RFSGPU_OK; }
+  if (!f->dInhParent) {
+    HIPCHK(hipMalloc(&f->dInhParent, (size_t)f->Ncap * sizeof(int)));
+    HIPCHK(hipMalloc(&f->dInhLevel, (size_t)f->Ncap * sizeof(int)));
+    const size_t nc = (size_t)f->Ncap * RFSGPU_MAX_CANDIDATES;
+    HIPCHK(hipMalloc(&f->inhTmp.unused, (size_t)f->Ncap * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&f->inhTmp.count, (size_t)f->Ncap * sizeof(int)));
+    HIPCHK(hipMalloc(&f->inhTmp.sup, nc * sizeof(int)));
+    HIPCHK(hipMalloc(&f->inhTmp.chk, nc * sizeof(int)));
+    HIPCHK(hipMalloc(&f->inhTmp.mean, nc * 3 * sizeof(double)));
+    HIPCHK(hipMalloc(&f->inhTmp.cov, nc * 6 * sizeof(double)));
+  }
+  // (pageable host vectors: hipMemcpyAsync from them returns after the copy has been staged, so they may be reused at once)
+  HIPCHK(hipMemcpyAsync(f->dInhParent, f->hInhParent.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, f->stream));
+  HIPCHK(hipMemcpyAsync(f->dInhLevel, f->hInhLevel.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, f->stream));
+  birth_inherit_kernel<0><<<N, 128, 0, f->stream>>>(f->B, f->inhTmp, f->dInhParent, f->dInhLevel, 0);
+  birth_inherit_kernel<1><<<N, 128, 0, f->stream>>>(f->B, f->inhTmp, f->dInhParent, f->dInhLevel, 0);
+  launch_predict_kernels(f, add_birth, BirthLevel{f->dInhLevel, 0, 1});
+  for (int L = 1; L <= maxLevel; L++) {
+    birth_inherit_kernel<2><<<N, 128, 0, f->stream>>>(f->B, f->inhTmp, f->dInhParent, f->dInhLevel, L);
+    launch_predict_kernels(f, add_birth, BirthLevel{f->dInhLevel, L, 0});
+  }
+  f->candUsed = f->candUsed || f->D == 3 || f->cfg.birthGaussianMeasurementCountThreshold != 1u;
+  return RFSGPU_OK;
+}
+
 int rfsgpu_predict_map(rfsgpu_filter *f, int add_birth) {
   CHECK_HANDLE(f);
   long long t0 = now_ns();
   hipSetDevice(f->device);
   HIPCHK(hipEventRecord(f->ev[EV_P0], f->stream));
-  if (f->D == 3)
-  {
-    predict_map_general_kernel<3, 4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
-    if (add_birth) predict_map_long_kernel<3, 2><<<(f->N + 1) / 2, 128, 0, f->stream>>>(f->B, f->P, f->cur, f->nZ);   // (lists longer than a wavefront; the others exit at once)
-  }
-  else if (f->cfg.birthGaussianMeasurementCountThreshold != 1u)
-  {
-    predict_map_general_kernel<2, 4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
-    if (add_birth) predict_map_long_kernel<2, 2><<<(f->N + 1) / 2, 128, 0, f->stream>>>(f->B, f->P, f->cur, f->nZ);
-  }
-  else  // CountThreshold == 1: every unused measurement is born at once, no candidate can exist -> lane-parallel kernel
-    predict_map_kernel<4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
+  { const int rcl = predict_launch(f, add_birth); if (rcl != RFSGPU_OK) return rcl; }
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(f->ev[EV_P1], f->stream));
   int rc = check_device_errors(f);
@@ -1053,18 +1128,7 @@ int rfsgpu_predict_map_async(rfsgpu_filter *f, int add_birth) {
   }
   const bool rec = !f->predPending;
   if (rec) HIPCHK(hipEventRecord(f->ev[EV_P0], f->stream));
-  if (f->D == 3)
-  {
-    predict_map_general_kernel<3, 4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
-    if (add_birth) predict_map_long_kernel<3, 2><<<(f->N + 1) / 2, 128, 0, f->stream>>>(f->B, f->P, f->cur, f->nZ);   // (lists longer than a wavefront; the others exit at once)
-  }
-  else if (f->cfg.birthGaussianMeasurementCountThreshold != 1u)
-  {
-    predict_map_general_kernel<2, 4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
-    if (add_birth) predict_map_long_kernel<2, 2><<<(f->N + 1) / 2, 128, 0, f->stream>>>(f->B, f->P, f->cur, f->nZ);
-  }
-  else
-    predict_map_kernel<4><<<(f->N + 3) / 4, 256, 0, f->stream>>>(f->B, f->P, f->cur, add_birth ? 1 : 0, f->nZ);
+  { const int rcl = predict_launch(f, add_birth); if (rcl != RFSGPU_OK) return rcl; }
   HIPCHK(hipGetLastError());
   if (rec) { HIPCHK(hipEventRecord(f->ev[EV_P1], f->stream)); f->predPending = true; }
   f->timing.predict_cpu += now_ns() - t0;
@@ -1266,11 +1330,20 @@ int rfsgpu_resample_apply_n(rfsgpu_filter *f, const int *src_slot, int n_out) {
   }
   f->N = n_out;
   f->B.N = n_out;
+  // ids as ParticleFilter::resample leaves them (:446-479): a copy has its source's id (Particle::copy) and idParent_ = that id;
+  // a slot that keeps its particle gets idParent_ = its own id (case 1).  Sources are never destinations, so in place is safe.
+  ensure_ids(f);
+  for (int k = 0; k < n_out; k++) {
+    const int s = src_slot[k];
+    if (s != k) { f->pid[k] = f->pid[s]; f->ppid[k] = f->pid[s]; }
+    else f->ppid[k] = f->pid[k];
+  }
+  f->resampleOccured = true;
   hipSetDevice(f->device);
   long long t0 = now_ns();
   HIPCHK(hipMemcpyAsync(f->dSrcSlot, src_slot, (size_t)f->N * sizeof(int), hipMemcpyHostToDevice, f->stream));
   HIPCHK(hipEventRecord(f->ev[EV_R0], f->stream));
-  resample_gather_kernel<<<f->N, 256, 0, f->stream>>>(f->B, f->cur, f->dSrcSlot, f->P.poseCovStride);
+  resample_gather_kernel<<<f->N, 256, 0, f->stream>>>(f->B, f->cur, f->dSrcSlot, f->P.poseCovStride, map_only(f));
   set_weights_kernel<<<(f->N + 255) / 256, 256, 0, f->stream>>>(f->B.weight, f->N, 1.0);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(f->ev[EV_R1], f->stream));
@@ -1280,9 +1353,47 @@ int rfsgpu_resample_apply_n(rfsgpu_filter *f, const int *src_slot, int n_out) {
   return RFSGPU_OK;
 }
 
+int rfsgpu_set_birth_inheritance(rfsgpu_filter *f, int mode) {
+  CHECK_HANDLE(f);
+  if (mode != RFSGPU_INHERIT_REFERENCE && mode != RFSGPU_INHERIT_EAGER && mode != RFSGPU_INHERIT_EXTERNAL) return fail(f, RFSGPU_ERR_INVALID, "set_birth_inheritance: unknown mode");
+  f->inheritMode = mode;
+  return RFSGPU_OK;
+}
+int rfsgpu_get_birth_inheritance(const rfsgpu_filter *f) { return f ? f->inheritMode : -1; }
+int rfsgpu_get_particle_ids(rfsgpu_filter *f, int *id, int *parent_id) {
+  CHECK_HANDLE(f);
+  ensure_ids(f);
+  for (int k = 0; k < f->N; k++) { if (id) id[k] = f->pid[k]; if (parent_id) parent_id[k] = f->ppid[k]; }
+  return RFSGPU_OK;
+}
+int rfsgpu_set_particle_ids(rfsgpu_filter *f, const int *id, const int *parent_id) {
+  CHECK_HANDLE(f);
+  ensure_ids(f);
+  for (int k = 0; k < f->N; k++) { if (id) f->pid[k] = id[k]; if (parent_id) f->ppid[k] = parent_id[k]; }
+  return RFSGPU_OK;
+}
+int rfsgpu_resample_occured(const rfsgpu_filter *f) { return f ? (f->resampleOccured ? 1 : 0) : -1; }
+int rfsgpu_get_unused_masks(rfsgpu_filter *f, unsigned long long *masks) {
+  CHECK_HANDLE(f);
+  if (!masks) return RFSGPU_ERR_INVALID;
+  hipSetDevice(f->device);
+  HIPCHK(hipMemcpyAsync(masks, f->B.unusedMask, (size_t)f->N * sizeof(unsigned long long), hipMemcpyDeviceToHost, f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  return RFSGPU_OK;
+}
+int rfsgpu_set_unused_masks(rfsgpu_filter *f, const unsigned long long *masks) {
+  CHECK_HANDLE(f);
+  if (!masks) return RFSGPU_ERR_INVALID;
+  hipSetDevice(f->device);
+  HIPCHK(hipMemcpyAsync(f->B.unusedMask, masks, (size_t)f->N * sizeof(unsigned long long), hipMemcpyHostToDevice, f->stream));
+  HIPCHK(hipStreamSynchronize(f->stream));
+  return RFSGPU_OK;
+}
+
 // ---- cross-shard migration (multi-GPU resampling): packed rows in DEVICE buffers, stream-ordered, no host sync -----------
 // candidates a migration row carries: the whole list for a filter that keeps one, nothing for a configuration that never does
 static int row_cand(const rfsgpu_filter *f) {
+  if (map_only(f)) return 0;   // a migrant carries what Particle::copy carries: pose + mixture
   return (f->model == RFSGPU_MODEL_VICTORIAPARK_3D || f->cfg.birthGaussianMeasurementCountThreshold != 1u || f->candUsed) ? RFSGPU_MAX_CANDIDATES : 0;
 }
 size_t rfsgpu_slab_row_bytes(const rfsgpu_filter *f) { return f ? slab_row_bytes(f->B.npl, f->cap, row_cand(f)) : 0; }
@@ -1302,8 +1413,8 @@ static int slab_rows(rfsgpu_filter *f, const int *slots, int n, void *dev_rows, 
     f->rowSlotsCap = want;
   }
   HIPCHK(hipMemcpyAsync(f->dRowSlots, slots, (size_t)n * sizeof(int), hipMemcpyHostToDevice, f->stream));
-  if (exporting) slab_rows_kernel<true><<<n, 256, 0, f->stream>>>(f->B, f->cur, f->dRowSlots, (unsigned char *)dev_rows, f->P.poseCovStride, row_cand(f));
-  else slab_rows_kernel<false><<<n, 256, 0, f->stream>>>(f->B, f->cur, f->dRowSlots, (unsigned char *)dev_rows, f->P.poseCovStride, row_cand(f));
+  if (exporting) slab_rows_kernel<true><<<n, 256, 0, f->stream>>>(f->B, f->cur, f->dRowSlots, (unsigned char *)dev_rows, f->P.poseCovStride, row_cand(f), map_only(f));
+  else slab_rows_kernel<false><<<n, 256, 0, f->stream>>>(f->B, f->cur, f->dRowSlots, (unsigned char *)dev_rows, f->P.poseCovStride, row_cand(f), map_only(f));
   HIPCHK(hipGetLastError());
   return RFSGPU_OK;
 }
@@ -1581,6 +1692,7 @@ int rfsgpu_particle_parents(rfsgpu_filter *f, int *parent, int max_n) {
 int rfsgpu_fastslam_update(rfsgpu_filter *f, const double *z, int n_z) {
   CHECK_HANDLE(f);
   f->holes = false;
+  f->fastSlamHandle = true;
   if (n_z == 0) return RFSGPU_OK;  // :401-402
   if (f->D == 3 && f->B.nScan < 2) return fail(f, RFSGPU_ERR_INVALID, "Victoria Park model: rfsgpu_set_laser_scan must precede the update");
   if (f->fs.maxNDataAssocHypotheses < 1 || f->fs.maxNDataAssocHypotheses > FSMH_MAX_HYP)

@@ -20,6 +20,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import capi
 from .engine import systematic_resample_plan
 
 
@@ -31,8 +32,17 @@ class _DevArray:
 
 
 class ShardedRBPHDFilter:
-    def __init__(self, local, group=None, device=None, stream=None, sums=None):
+    """inheritance: "reference" (default) = the reference's birth-state inheritance after a resampling (include/RBPHDFilter.hpp:
+    1005-1011) over GLOBAL slots -- ids are global, so this host owns the rule and the local engine runs in
+    RFSGPU_INHERIT_EXTERNAL; implemented for immediate-birth configurations (birthGaussianMeasurementCountThreshold == 1, the 2-D
+    simulator), where the slot-ordered walk needs only the 8-byte unused masks of all shards (predict_map below).  "eager" = a
+    child takes its parent's lists and FOV count at resampling time (rounds 1-2; not the reference's results)."""
+
+    def __init__(self, local, group=None, device=None, stream=None, sums=None, inheritance="reference"):
+        assert inheritance in ("reference", "eager")
+        self.inheritance = inheritance
         self.f = local
+        local.set_birth_inheritance(capi.INHERIT_EXTERNAL if inheritance == "reference" else capi.INHERIT_EAGER)
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -49,6 +59,8 @@ class ShardedRBPHDFilter:
         self.resampleOccured = False
         self.last_resample_plan = None                     # global slot -> global source slot of the last resampling
         self.last_migration = dict(rows_sent=0, rows_received=0, bytes_sent=0)
+        self.pid = np.arange(self.n_total, dtype=np.int64)     # Particle::id_ / idParent_ by GLOBAL slot (the same on every rank)
+        self.ppid = np.arange(self.n_total, dtype=np.int64)
         self.stream = None
         self.sums = None
         self._w_view = None
@@ -106,6 +118,42 @@ class ShardedRBPHDFilter:
         out = [torch.empty_like(w) for _ in range(self.world)]
         dist.all_gather(out, w, group=self.group)
         return torch.cat(out).cpu().numpy()
+
+    # -- RBPHDFilter::predict, map part (:415-442) ----------------------------------------------------------
+    def predict_map(self, add_birth=True):
+        """In the predicts that follow a resampling the reference first copies, slot by slot in ascending order,
+        unused_measurements_ / birthGaussians_ from SLOT idParent_ in its current state (:1005-1011).  With immediate births no
+        candidate list exists and the walk has a closed form over the lists as they are before the predict: own list if
+        idParent_ == slot, the parent slot's list if that is a HIGHER slot (not yet visited), nothing if it is a LOWER one
+        (already consumed).  One all-gather of N 8-byte masks, only in those predicts."""
+        if add_birth and self.resampleOccured and self.inheritance == "reference":
+            cfg = self.f.get_filter_config()
+            if cfg.birthGaussianMeasurementCountThreshold != 1 or self.f.dz != 2:
+                raise RuntimeError("sharded predict after a resampling: the reference's slot-ordered copy of birth-candidate lists across shards "
+                                   "is not implemented (immediate births only); construct with inheritance='eager' for this configuration")
+            m_all = self._gather_masks()
+            lo = self.rank * self.n_local
+            g = np.arange(lo, lo + self.n_local)
+            p = self.ppid[g]
+            new = np.where(p == g, m_all[g], np.where(p > g, m_all[np.clip(p, 0, self.n_total - 1)], np.uint64(0))).astype(np.uint64)
+            if np.any(new != m_all[g]):
+                self.f.set_unused_masks(new)
+        self.f.predict_map(add_birth)
+
+    def _gather_masks(self):
+        local = np.ascontiguousarray(self.f.get_unused_masks(), dtype=np.uint64)
+        if self.world == 1:
+            return local
+        t = torch.from_numpy(local.view(np.int64))
+        if self.on_gpu and self.backend == "nccl":
+            with self._stream_ctx():
+                t = t.to(self.device)
+                out = torch.empty(self.n_total, dtype=torch.int64, device=self.device)
+                dist.all_gather_into_tensor(out, t, group=self.group)
+                return out.cpu().numpy().view(np.uint64)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t, group=self.group)
+        return torch.cat(out).numpy().view(np.uint64)
 
     # -- RBPHDFilter::update incl. the resample-or-normalise tail (:444-541) -------------------------------
     def update(self, Z, u01=None):
@@ -214,6 +262,11 @@ class ShardedRBPHDFilter:
             if self.on_gpu:
                 self.f.synchronize()                                     # the buffers may be released after this
         self.last_migration = dict(rows_sent=int(n_send), rows_received=int(n_recv), bytes_sent=int(n_send * R))
+        # ids as ParticleFilter::resample leaves them (:446-479; a copy keeps its source's id, Particle::copy), over GLOBAL slots
+        child = plan != np.arange(self.n_total)
+        src_id = self.pid[plan]
+        self.pid = np.where(child, src_id, self.pid)
+        self.ppid = np.where(child, src_id, self.pid)
 
 
 class _NullCtx:

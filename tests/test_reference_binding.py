@@ -80,7 +80,9 @@ def test_binding_overrides_every_pure_virtual_and_touches_no_reference_header():
 def _cfg_2d(tmp_path, timesteps=None, particles=None):
     s = open(os.path.join(GOLDEN, "rbphdslam2dSim_c1.xml")).read()
     out = os.path.join(str(tmp_path), "log") + os.sep
-    s = re.sub(r"<logDirPrefix>.*?</logDirPrefix>", "<logDirPrefix>%s</logDirPrefix>" % out, s)
+    assert "<logging>" not in s           # (the re-typed C1 configuration carries no logging section; the driver reads these keys)
+    s = s.replace("<config>", "<config>\n  <logging><logResultsToFile>1</logResultsToFile><logTimingToFile>1</logTimingToFile>"
+                  "<logDirPrefix>%s</logDirPrefix></logging>" % out, 1)
     if timesteps:
         s = re.sub(r"<timesteps>\d+</timesteps>", "<timesteps>%d</timesteps>" % timesteps, s)
     if particles:

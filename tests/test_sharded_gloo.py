@@ -41,7 +41,15 @@ def make_scen(sc, n_total, big=False):
     return scen
 
 
-def _worker(rank, world, port, n_total, force_resample, q, big=False):
+def z_stream(scen, k):
+    """Measurement sets of the follow-up steps: the scenario's, jittered, with two measurements nobody has seen (-> unused)."""
+    rng = np.random.default_rng(1000 + k)
+    Z = scen["Z"] + rng.normal(0, 1e-3, scen["Z"].shape)
+    Z[-2:, 0] = rng.uniform(1.0, 2.0, 2)
+    return Z
+
+
+def _worker(rank, world, port, n_total, force_resample, q, big=False, cycles=0):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -58,7 +66,14 @@ def _worker(rank, world, port, n_total, force_resample, q, big=False):
     sh.effNParticles_t = n_total + 1.0 if force_resample else 1e-9     # always / never resample
     # (the 500-landmark state drives the raw weights to 0 in one update: the big case resamples the loaded state directly)
     fired = sh.resample(u01=0.4321) if big else sh.update(scen["Z"], u01=0.4321)
-    res = dict(rank=rank, fired=fired, w=local.get_weights(), sizes=local.gm_sizes(), poses=local.get_poses(),
+    rows_total = sh.last_migration["rows_sent"]
+    for k in range(cycles):       # predict (births; after a resampling: the reference's inheritance over GLOBAL slots) + update
+        sh.predict_map(True)
+        if k % 2 == 1:
+            sh.predict_map(True)  # a second predict while resampleOccured_ is still set
+        sh.update(z_stream(scen, k), u01=0.1 + 0.17 * k)
+        rows_total += sh.last_migration["rows_sent"]
+    res = dict(rank=rank, fired=fired, ids=(sh.pid.copy(), sh.ppid.copy()), rows_total=rows_total, w=local.get_weights(), sizes=local.gm_sizes(), poses=local.get_poses(),
                maps=[local.export_gm(i) for i in range(local.n)], unused=[local.get_unused(i) for i in range(local.n)],
                migration=sh.last_migration)
     q.put(res)
@@ -66,11 +81,11 @@ def _worker(rank, world, port, n_total, force_resample, q, big=False):
     dist.destroy_process_group()
 
 
-def run_world(n_total, force_resample, world=2, big=False):
+def run_world(n_total, force_resample, world=2, big=False, cycles=0):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, force_resample, q, big)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, force_resample, q, big, cycles)) for r in range(world)]
     for p in procs:
         p.start()
     out = [q.get() for _ in range(world)]
@@ -121,6 +136,51 @@ def test_two_rank_update_matches_single_process(pkg, ob, force_resample):
         half = n_total // 2
         crossed = [(g, s) for g, s in enumerate(plan) if (g < half) != (s < half)]
         assert len(crossed) > 0
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_resampling_cycles_inherit_birth_state_as_the_reference(pkg, ob, world):
+    """Forced global resamplings with predicts and updates in between, over 2 and 3 ranks: maps, unused lists, weights and particle
+    ids equal those of ONE plain filter holding all particles in RFSGPU_INHERIT_REFERENCE mode (the engine's own, single-GPU
+    implementation of include/RBPHDFilter.hpp:1005-1011) driven through the same decisions -- i.e. the sharded host's mask
+    exchange over GLOBAL slots reproduces the reference's slot-ordered copy across shard boundaries."""
+    n_total, cycles = 24, 4
+    sc = pkg.scenarios
+    scen = make_scen(sc, n_total)
+    ref = ob.OracleFilter(n_total, stable_sort=True)
+    assert ref.get_birth_inheritance() == pkg.capi.INHERIT_REFERENCE
+    sc.load_scenario(ref, scen)
+
+    def step(Z, u01):
+        ref.update(Z)
+        s = ref.weight_sums()
+        ref.normalize_weights(s[0])
+        fired, wn, src = ob.resample_decide(ref.get_weights(), n_total + 1.0, u01)
+        assert fired
+        ref.resample_apply(src)
+
+    step(scen["Z"], 0.4321)
+    for k in range(cycles):
+        ref.predict_map(True)
+        if k % 2 == 1:
+            ref.predict_map(True)
+        step(z_stream(scen, k), 0.1 + 0.17 * k)
+    out = run_world(n_total, True, world=world, cycles=cycles)
+    maps = [m for o in out for m in o["maps"]]
+    unused = [u for o in out for u in o["unused"]]
+    assert np.array_equal(np.concatenate([o["sizes"] for o in out]), ref.gm_sizes())
+    for i in range(n_total):
+        sc.assert_gm_close(maps[i], ref.export_gm(i), 1e-13, 0, ordered=True)
+        assert np.array_equal(unused[i], ref.get_unused(i))
+    np.testing.assert_array_equal(np.concatenate([o["poses"] for o in out]), ref.get_poses())
+    ids, par = ref.get_particle_ids()
+    for o in out:
+        assert np.array_equal(o["ids"][0], ids) and np.array_equal(o["ids"][1], par)
+    assert np.any(ids != np.arange(n_total))
+    lvl = np.zeros(n_total, dtype=int)
+    for i in range(n_total):
+        lvl[i] = 0 if par[i] >= i else lvl[par[i]] + 1
+    assert lvl.max() >= 1 and sum(o["rows_total"] for o in out) > 0
 
 
 def test_two_rank_migration_of_c3_sized_mixtures(pkg, ob):
