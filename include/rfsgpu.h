@@ -347,7 +347,9 @@ int rfsgpu_resample_apply(rfsgpu_filter *f, const int *src_slot);
  *       resampling.  A handle on which rfsgpu_fastslam_update has run behaves this way whatever the mode: rfs::FastSLAM copies its
        landmark-candidate lists right at resampling time (FastSLAM::resampleWithMapCopy, include/FastSLAM.hpp:747-753).
  *   RFSGPU_INHERIT_EXTERNAL   resampling moves pose + mixture only and predict copies nothing: the host owns the rule (the
- *       multi-GPU hosts, whose parent slot may live on another shard: rfsgpu_get/set_unused_masks). */
+ *       multi-GPU hosts, whose parent slot may live on another shard: rfsgpu_get/set_unused_masks).
+ * The environment variable RFSGPU_BIRTH_INHERITANCE=eager makes RFSGPU_INHERIT_EAGER the initial mode of new handles (A/B runs
+ * of unmodified hosts). */
 #define RFSGPU_INHERIT_REFERENCE 0
 #define RFSGPU_INHERIT_EAGER 1
 #define RFSGPU_INHERIT_EXTERNAL 2

@@ -14,4 +14,5 @@ from . import engine  # noqa: F401
 from . import scenarios  # noqa: F401
 from . import sharded  # noqa: F401
 from . import vp_driver  # noqa: F401
+from . import sim2d_driver  # noqa: F401
 from .engine import FastSLAM, FilterGroup, RBPHDFilter, load_library, mat_perm  # noqa: F401

@@ -83,7 +83,8 @@ int rfsgpu_group_create(rfsgpu_group **out, int model, int n_particles, const in
     rfsgpu_filter *f = nullptr;
     const int rc = rfsgpu_create(&f, model, g->first[k + 1] - g->first[k], device_ids[k], gm_capacity);
     if (rc != RFSGPU_OK) { rfsgpu_group_destroy(g); return rc; }
-    rfsgpu_set_birth_inheritance(f, RFSGPU_INHERIT_EXTERNAL);
+    if (f->inheritMode == RFSGPU_INHERIT_EAGER) g->inheritMode = RFSGPU_INHERIT_EAGER;   // (RFSGPU_BIRTH_INHERITANCE=eager in the environment)
+    else rfsgpu_set_birth_inheritance(f, RFSGPU_INHERIT_EXTERNAL);
     g->shard.push_back(f);
   }
   g->pid.resize(n_particles); g->ppid.resize(n_particles);

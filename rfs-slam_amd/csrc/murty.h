@@ -26,8 +26,9 @@
 #define MURTY_CT_WAVES (MURTY_JOB_WAVES > 4 ? MURTY_JOB_WAVES : 4)   /* (the multi-hypothesis FastSLAM search uses up to four waves on the same arena) */
 
 struct MurtyScratch {
-  unsigned char *arena;   // [maxJobs][jobBytes]
+  unsigned char *arena;   // [nArenas][jobBytes]: scratch that is live only while a workgroup works on a job -> one per WORKGROUP
   size_t jobBytes;
+  int nArenas;            // = the largest grid murty_jobs_kernel is launched with (r2: one per queue slot, 5 GB at 8192 slots)
 };
 
 struct MurtyArena {
@@ -685,8 +686,8 @@ __global__ __launch_bounds__(1024) void murty_order_kernel(MurtyQueue Q) {
 __global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err, double *weight, int N, double *sums,
                                                                          int normalize, ZArg zarg, double *dZ, int nZdoubles, int *hostSeen, int ordered) {
   // (a fused step carries the measurement set in its kernel arguments; the device copy the next predict reads is written here)
-  if (blockIdx.x == 0 && dZ && (int)threadIdx.x < nZdoubles) dZ[threadIdx.x] = zarg.v[threadIdx.x];
-  if (blockIdx.x == 0 && dZ && (int)threadIdx.x + 128 < nZdoubles) dZ[threadIdx.x + 128] = zarg.v[threadIdx.x + 128];
+  if (blockIdx.x == 0 && dZ)
+    for (int t = threadIdx.x; t < nZdoubles; t += blockDim.x) dZ[t] = zarg.v[t];
   const int nJobs = min(*Q.count, Q.maxJobs);
   if (nJobs == 0) {
     if (blockIdx.x == 0) step_post_tail(weight, N, sums, normalize);
@@ -713,11 +714,13 @@ __global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQ
 #ifdef RFS_PROFILE
     const long long dbgJob0 = (long long)wall_clock64();
 #endif
-    if (n > MURTY_N) {
+    if (n <= 0 || (unsigned)J.particle >= (unsigned)N) {
+      // a queue slot its producer reserved but could not fill (partition beyond MURTY_MAXN: the error bit is already set): skipped
+    } else if (n > MURTY_N || (int)blockIdx.x >= MS.nArenas) {
       if (threadIdx.x == 0) atomicOr(err, ERRBIT_MURTY);
     } else {
       MurtyArena A;
-      murty_carve(MS.arena + (size_t)j * MS.jobBytes, A);
+      murty_carve(MS.arena + (size_t)blockIdx.x * MS.jobBytes, A);
       bool ok;
       v = murty_partition_sum_block<MURTY_JOB_WAVES>(Q.mats + (size_t)j * MURTY_MAXN * MURTY_MAXN, n, J.nR, J.nC, A, ok, sTile[wave], sCtl, &sSum, sScore,
                                                      sPushed, wave, spec);
@@ -754,12 +757,16 @@ __global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQ
   // Every particle's factors, multiplied in partition (slot) order.  The jobs of a particle are chained through a list first
   // (head per particle in the first job's arena, links in the order array -- both idle by now), so that a particle looks at
   // its own few jobs only: scanning the whole queue per particle was 2.6 ms of a 9 ms launch at configs[4] (1000 x 1918).
-  if (Q.order && (size_t)N * sizeof(int) <= MS.jobBytes * (size_t)Q.maxJobs) {
+  if (Q.order && (size_t)N * sizeof(int) <= MS.jobBytes * (size_t)MS.nArenas) {
     int *head = reinterpret_cast<int *>(MS.arena), *next = Q.order;
     for (int i = threadIdx.x; i < N; i += blockDim.x) head[i] = -1;
     __threadfence();
     __syncthreads();
-    for (int q = threadIdx.x; q < nJobs; q += blockDim.x) next[q] = atomicExch(&head[Q.jobs[q].particle], q);
+    for (int q = threadIdx.x; q < nJobs; q += blockDim.x) {
+      const int pi = Q.jobs[q].particle;
+      if ((unsigned)pi < (unsigned)N && Q.jobs[q].nR + Q.jobs[q].nC > 0) next[q] = atomicExch(&head[pi], q);   // (skip-jobs: see above)
+      else next[q] = -1;
+    }
     __threadfence();
     __syncthreads();
     for (int i = threadIdx.x; i < N; i += blockDim.x) {
@@ -787,7 +794,7 @@ __global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQ
       while (true) {
         int best = -1, bestSlot = 1 << 30;
         for (int q = 0; q < nJobs; q++)
-          if (Q.jobs[q].particle == i && Q.jobs[q].slot > last && Q.jobs[q].slot < bestSlot) { best = q; bestSlot = Q.jobs[q].slot; }
+          if (Q.jobs[q].particle == i && Q.jobs[q].nR + Q.jobs[q].nC > 0 && Q.jobs[q].slot > last && Q.jobs[q].slot < bestSlot) { best = q; bestSlot = Q.jobs[q].slot; }
         if (best < 0) break;
         w *= __builtin_nontemporal_load(&Q.results[best]);
         last = bestSlot;
@@ -817,14 +824,16 @@ static inline int murty_alloc(MurtyQueue &Q, MurtyScratch &MS, int N) {
   if (maxJobs > 8192) maxJobs = 8192;
   Q.maxJobs = maxJobs;
   MS.jobBytes = murty_job_bytes();
+  MS.nArenas = std::min(MURTY_JOB_BLOCKS, maxJobs);
   bool ok = true;
   ok &= hipMalloc(&Q.count, 2 * sizeof(int)) == hipSuccess;
   ok &= hipMalloc(&Q.jobs, (size_t)maxJobs * sizeof(MurtyJob)) == hipSuccess;
   ok &= hipMalloc(&Q.mats, (size_t)maxJobs * MURTY_MAXN * MURTY_MAXN * sizeof(double)) == hipSuccess;
   ok &= hipMalloc(&Q.results, (size_t)maxJobs * sizeof(double)) == hipSuccess;
   ok &= hipMalloc(&Q.order, (size_t)maxJobs * sizeof(int)) == hipSuccess;
-  ok &= hipMalloc(&MS.arena, (size_t)maxJobs * MS.jobBytes) == hipSuccess;
+  ok &= hipMalloc(&MS.arena, (size_t)MS.nArenas * MS.jobBytes) == hipSuccess;
   if (ok) ok &= hipMemset(Q.count, 0, 2 * sizeof(int)) == hipSuccess;
+  if (ok) ok &= hipMemset(Q.jobs, 0, (size_t)maxJobs * sizeof(MurtyJob)) == hipSuccess;   // (an all-zero job is a skip-job)
   return ok ? 0 : 1;
 }
 static inline void murty_free(MurtyQueue &Q, MurtyScratch &MS) {

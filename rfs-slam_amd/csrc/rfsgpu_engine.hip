@@ -252,6 +252,7 @@ int rfsgpu_create_ex(rfsgpu_filter **out, int model, int n_particles, int device
   f->fs.nParticlesMax = 3 * n_particles;
   { const char *e = getenv("RFSGPU_FUSED_STEP"); if (e && e[0] == '0') f->fuseSteps = false; }
   { const char *e = getenv("RFSGPU_STEP_WPP"); if (e) f->stepWppOverride = atoi(e); }
+  { const char *e = getenv("RFSGPU_BIRTH_INHERITANCE"); if (e && !strcmp(e, "eager")) f->inheritMode = RFSGPU_INHERIT_EAGER; }   // (initial mode; rfsgpu_set_birth_inheritance)
   { const char *e = getenv("RFSGPU_MERGE_GRID"); if (e) f->mergeGridOverride = atoi(e); }
   if (f->cap > 2048) { delete f; return RFSGPU_ERR_INVALID; }
   auto bail = [&](int code) { rfsgpu_destroy(f); return code; };
@@ -1216,12 +1217,11 @@ int rfsgpu_set_step_inputs_async(rfsgpu_filter *f, const double *x, const double
   const int k = f->stageNext;
   f->stageNext = (k + 1) & 3;
   const size_t slotDoubles = (size_t)f->Ncap * 12 + RFSGPU_VP_MAX_SCAN;
-  if (!f->hStage[k]) {
-    HIPCHK(hipHostMalloc(&f->hStage[k], slotDoubles * sizeof(double)));
-    HIPCHK(hipEventCreateWithFlags(&f->evStage[k], hipEventDisableTiming));
-  } else {
-    HIPCHK(hipEventSynchronize(f->evStage[k]));   // the copies issued from this slot four calls ago
-  }
+  const bool fresh = !f->hStage[k] || !f->evStage[k];   // (either creation may have failed on an earlier call: each is retried on its own)
+  if (!f->hStage[k]) HIPCHK(hipHostMalloc(&f->hStage[k], slotDoubles * sizeof(double)));
+  if (!f->evStage[k]) HIPCHK(hipEventCreateWithFlags(&f->evStage[k], hipEventDisableTiming));
+  if (fresh) HIPCHK(hipStreamSynchronize(f->stream));    // nothing recorded on this slot's event yet
+  else HIPCHK(hipEventSynchronize(f->evStage[k]));       // the copies issued from this slot four calls ago
   double *h = f->hStage[k];
   if (x) {
     memcpy(h, x, (size_t)f->N * 3 * sizeof(double));

@@ -324,6 +324,11 @@ __device__ double rfs_partitions_wave(const WeightLDS &s, int nE, int nZ, double
           }
       } else {
         atomicOr(err, ERRBIT_MURTY);
+        if (job < Q.maxJobs) {   // the slot is reserved: leave a skip-job (dimension 0) in it, never stale or uninitialised contents
+          MurtyJob J;
+          J.particle = particle; J.nR = 0; J.nC = 0; J.slot = p;
+          Q.jobs[job] = J;
+        }
       }
     }
     s.partLik[p] = pl;

@@ -168,12 +168,16 @@ def test_update_async_matches_oracle(pkg, ob, sc, kw, fused, monkeypatch):
         for a, b in zip(dev.export_gm(i), ref.export_gm(i)):
             assert np.array_equal(a, b)
         assert np.array_equal(dev.get_unused(i), orc.get_unused(i))
-    # a second step on the evolved state (slab parity after a fused step)
+    # a second step on the evolved state (slab parity after a fused step).  The weights are normalised in between as a filter
+    # loop does (RBPHDFilter.hpp:537-539): the raw product of two steps underflows to 0 in the 64-measurement scenario, and a
+    # comparison of 0 / 0 would check nothing.
     for f in (dev, orc):
+        f.normalize_weights(f.weight_sums()[0])
         f.predict_map(True)
     dev.update_async(scen["Z"])
     dev.synchronize()
     orc.update(scen["Z"])
+    assert np.all(dev.get_weights() > 0) and np.all(orc.get_weights() > 0)
     compare_weights(dev, orc)
     compare_maps(sc, dev, orc, scen["n"], ordered=True)
 
@@ -566,9 +570,9 @@ def test_cpp_host_driver_logs_through_analysis2d_sim(pkg, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     d = os.path.join(tmp_path, "run")
     os.makedirs(d)
-    out = subprocess.run([exe, "-c", os.path.join(root, "tests", "golden", "rbphdslam2dSim_c1.xml"), "-t", "1", "-s", "2", "-n", "200", "-o", d],
-                         capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
+    out = subprocess.run([exe, "-c", os.path.join(root, "tests", "golden", "rbphdslam2dSim_c1.xml"), "-t", "2", "-s", "2", "-n", "200", "-o", d],
+                         capture_output=True, text=True, timeout=600)     # (a realisation on which the filter keeps track: see
+    assert out.returncode == 0, out.stderr[-2000:]                         #  test_c1_full_run_device_and_oracle_agree_on_map_quality)
     spec = importlib.util.spec_from_file_location("analysis2d_sim", os.path.join(root, "tools", "analysis2d_sim.py"))
     a = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(a)
@@ -1166,6 +1170,64 @@ def test_victoria_park_dataset_extract_device_vs_oracle(pkg, ob, sc):
     assert np.array_equal(sizes, orc.f.gm_sizes()) and sizes.max() > 3
     for i in range(n):
         sc.assert_gm_close(dev.f.export_gm(i), orc.f.export_gm(i), 1e-7, 1e-9)
+
+
+@pytest.mark.parametrize("n,steps,seed", [(100, 320, 1), (200, 300, 2)])
+def test_c1_trajectory_device_vs_oracle(pkg, ob, sc, n, steps, seed):
+    """Config C1 as a TRAJECTORY: the 2-D simulator's filter loop (src/rbphdslam2dSim.cpp:540-643: predict with
+    odometry and process noise, ground-truth poses for k <= 100, the measurements of the step, update, N_eff resampling with the
+    reference's birth-state inheritance) on the device and on the oracle through ONE realisation (one host RNG stream, shared
+    poses), compared after EVERY update: mixture sizes, unused lists, resampling decisions and plans exact; normalised weights
+    1e-8; maps (w, mu, Sigma) 1e-7."""
+    sd = pkg.sim2d_driver
+    data = sd.generate(traj_seed=seed, kmax=steps)
+    dev = pkg.RBPHDFilter(n, gm_capacity=256)
+    orc = ob.OracleFilter(n, stable_sort=True)
+    seen = dict(updates=0, max_size=0, births=0)
+
+    def check(k, run, fired):
+        if len(run.z_of_step) == 0:
+            return
+        sz = dev.gm_sizes()
+        assert np.array_equal(sz, orc.gm_sizes()), k
+        wd, wo = dev.get_weights(), orc.get_weights()
+        np.testing.assert_allclose(wd, wo, rtol=1e-8, atol=1e-300, err_msg=f"step {k}")
+        for i in range(0, n, 7 if k % 10 else 1):            # every particle every 10th step, a stride of 7 in between
+            sc.assert_gm_close(dev.export_gm(i), orc.export_gm(i), 1e-7, 1e-9)
+            assert list(dev.get_unused(i)) == list(orc.get_unused(i)), (k, i)
+        seen["updates"] += 1
+        seen["max_size"] = max(seen["max_size"], int(sz.max()))
+
+    run = sd.Sim2dRun([dev, orc], data, seed=seed + 10).run(on_step=check)
+    assert seen["updates"] > steps * 0.6 and seen["max_size"] >= 5
+    assert run.n_resamples >= 3                                   # several resamplings, each followed by a predict
+    assert np.array_equal(dev.get_particle_ids()[0], orc.get_particle_ids()[0])
+    assert np.any(dev.get_particle_ids()[0] != np.arange(n))
+    md, mo = sd.map_error(dev, 0, data["landmarks"]), sd.map_error(orc, 0, data["landmarks"])
+    assert md[0] == mo[0] and md[2] == mo[2] and md[0] >= 3
+
+
+def test_c1_full_run_device_and_oracle_agree_on_map_quality(pkg, ob, sc):
+    """The whole shipped C1 run (3000 steps, 50 landmarks) at 100 particles on device and oracle through one realisation, for two
+    realisations: final best-particle maps agree Gaussian by Gaussian, so a realisation on which the filter maps fewer landmarks
+    ("36 of 50") does so on the CPU restatement of the reference's algorithm exactly as on the device -- it is
+    a property of that realisation (particle depletion early on the trajectory), not of the engine."""
+    sd = pkg.sim2d_driver
+    results = []
+    for seed in (1, 4):
+        data = sd.generate(traj_seed=seed)
+        dev = pkg.RBPHDFilter(100, gm_capacity=256)
+        orc = ob.OracleFilter(100, stable_sort=True)
+        run = sd.Sim2dRun([dev, orc], data, seed=seed).run()
+        wd, wo = dev.get_weights(), orc.get_weights()
+        np.testing.assert_allclose(wd, wo, rtol=1e-6)
+        best = int(np.argmax(wd))
+        assert np.array_equal(dev.gm_sizes(), orc.gm_sizes())
+        sc.assert_gm_close(dev.export_gm(best), orc.export_gm(best), 1e-6, 1e-8)
+        md, mo = sd.map_error(dev, best, data["landmarks"]), sd.map_error(orc, best, data["landmarks"])
+        assert md[0] == mo[0] and md[2] == mo[2]
+        results.append((seed, md, run.n_resamples))
+    assert max(r[1][0] for r in results) >= 40, results           # at least one of the two realisations maps the scene well
 
 
 def test_victoria_park_dataset_extract_fastslam(pkg, ob, sc):
