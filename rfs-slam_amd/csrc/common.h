@@ -395,6 +395,13 @@ __device__ __forceinline__ double rfs_exp(double x) {
 
 // exp(-0.5*md2)/factor with the reference's NaN->0 guard (include/RandomVec.hpp:417-434).
 // md2 > 1500 => exp(-750) is exactly 0 in fp64, so the transcendental is skipped (bit-identical result).
+// the same with the reciprocal of the factor formed once by the caller (intensity sums: one factor per Gaussian, many points)
+__device__ __forceinline__ double gauss_from_md2_r(double md2, double rfactor) {
+  if (md2 > 1500.0) return 0.0;
+  double l = rfs_exp(-0.5 * md2) * rfactor;
+  if (l != l) l = 0.0;
+  return l;
+}
 __device__ __forceinline__ double gauss_from_md2(double md2, double factor) {
   if (md2 > 1500.0) return 0.0;
   double l = rfs_exp(-0.5 * md2) / factor;

@@ -674,7 +674,7 @@ static int launch_update_map(rfsgpu_filter *f) {
   const int nZ = f->nZ;
   if (f->D == 3) {
     if (f->B.nScan < 2) return fail(f, RFSGPU_ERR_INVALID, "Victoria Park model: rfsgpu_set_laser_scan must precede the update");
-    const size_t b = (size_t)(3 * RFSGPU_MAX_Z + RFSGPU_VP_MAX_SCAN) * 8 + 2 * vp_update_lds_bytes_per_wave(f->cap);
+    const size_t b = vp_shared_lds_bytes(nZ, f->B.nScan) + 2 * vp_update_lds_bytes_per_wave(f->cap);
     int rc3;
     if ((rc3 = set_lds(f, vp_update_map_kernel<2>, b)) != RFSGPU_OK) return rc3;
     vp_update_map_kernel<2><<<(f->N + 1) / 2, 128, b, f->stream>>>(f->B, f->P, f->cur, nZ);
@@ -710,7 +710,7 @@ static int launch_weighting(rfsgpu_filter *f) {
   const int src = f->cur, dst = f->cur ^ 1;
   int rc;  // (the Murty job counter was cleared by stage_step_kernel)
   if (f->D == 3) {
-    const size_t b = (size_t)(3 * RFSGPU_MAX_Z + RFSGPU_VP_MAX_SCAN) * 8 + 2 * vp_weight_lds_bytes_per_wave(f->cap, ec, nZ);
+    const size_t b = vp_shared_lds_bytes(nZ, f->B.nScan) + 2 * vp_weight_lds_bytes_per_wave(f->cap, ec, nZ);
     if ((rc = set_lds(f, vp_weighting_kernel<2>, b)) != RFSGPU_OK) return rc;
     vp_weighting_kernel<2><<<(f->N + 1) / 2, 128, b, f->stream>>>(f->B, f->P, src, dst, nZ, ec, f->Q);
     HIPCHK(hipGetLastError());
@@ -854,7 +854,7 @@ int rfsgpu_update(rfsgpu_filter *f, const double *z, int n_z) {
   if (n_z == 0) return RFSGPU_OK;  // :450-452
   // 2-D model: ONE fused launch (+ the post kernel) unless the caller asked for phase-resolved timing (rfsgpu_set_phase_timing):
   // the same bits either way, 26 % less device time at configs[1]; the whole step is then booked under TimingInfo::mapUpdate
-  if (f->D == 2 && f->fuseSteps && !f->phaseTiming) {
+  if (f->fuseSteps && !f->phaseTiming) {   // (r3: the Victoria Park model too -- vp_step_fused_kernel)
     const int rc = update_async_impl(f, z, n_z, false, 0);
     return rc != RFSGPU_OK ? rc : rfsgpu_synchronize(f);
   }
@@ -976,6 +976,38 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
     HIPCHK(hipEventRecord(e[3], f->stream));
     if (murty_launch(f->Q, f->MS, f->B, f->stream, with_sums ? f->dSums : nullptr, normalize, &za, 2 * n_z, f->hJobCount) != 0) return fail(f, RFSGPU_ERR_HIP, "post kernel launch failed");
     f->cur ^= 1;  // the map update works in place, the weighting phase leaves only a permutation in LDS, merge + prune write the other slab
+    f->ringFused[f->ringCount] = true;
+    f->ringCount++;
+    f->timing.mapUpdate_cpu += now_ns() - t0;
+    return RFSGPU_OK;
+  }
+  if (f->D == 3 && f->fuseSteps) {
+    // Victoria Park: the whole step in one launch (vp.h, vp_step_fused_kernel: one wavefront per particle through updateMap ->
+    // importanceWeighting -> merge + prune, the sorted order a permutation in LDS), then the post kernel as for the 2-D model
+    if (n_z < 0 || n_z > RFSGPU_MAX_Z) return fail(f, RFSGPU_ERR_INVALID, "at most RFSGPU_MAX_Z measurements per update");
+    if (!z) return fail(f, RFSGPU_ERR_INVALID, "null measurement buffer");
+    if (f->B.nScan < 2) return fail(f, RFSGPU_ERR_INVALID, "Victoria Park model: rfsgpu_set_laser_scan must precede the update");
+    hipSetDevice(f->device);
+    ZArg za;
+    memcpy(za.v, z, (size_t)n_z * 3 * sizeof(double));
+    f->nZ = n_z;
+    if (n_z > 0) f->resampleOccured = false;
+    HIPCHK(hipEventRecord(e[0], f->stream));
+    const int ec = eval_cap(f), useW = f->cfg.useClusterProcess ? 0 : 1;
+    const size_t shared = vp_shared_lds_bytes(f->nZ, f->B.nScan), per = vp_step_lds_bytes_per_wave(f->cap, ec, f->nZ);
+    if (shared + 2 * per <= (size_t)64 * 1024) {
+      const size_t b = shared + 2 * per;
+      if ((rc = set_lds(f, vp_step_fused_kernel<2>, b)) != RFSGPU_OK) return rc;
+      vp_step_fused_kernel<2><<<(f->N + 1) / 2, 128, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
+    } else {
+      const size_t b = shared + per;
+      if ((rc = set_lds(f, vp_step_fused_kernel<1>, b)) != RFSGPU_OK) return rc;
+      vp_step_fused_kernel<1><<<f->N, 64, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e[3], f->stream));
+    if (murty_launch(f->Q, f->MS, f->B, f->stream, with_sums ? f->dSums : nullptr, normalize, &za, 3 * n_z, f->hJobCount) != 0) return fail(f, RFSGPU_ERR_HIP, "post kernel launch failed");
+    f->cur ^= 1;
     f->ringFused[f->ringCount] = true;
     f->ringCount++;
     f->timing.mapUpdate_cpu += now_ns() - t0;

@@ -123,7 +123,7 @@ __device__ double vp_pd2(const Params &P, const double *scan, int nScan, double 
 // looping over its own copies leaves the wave waiting for its worst landmark.  Here the (landmark, copy) evaluations of all
 // lanes are laid end to end and dealt out to the lanes; minimum and maximum (exact in any order: the values come from the
 // Pd table) are folded with LDS atomics on the bit patterns (the values are >= 0).  `ws`: VP_PD_SCRATCH_BYTES of LDS per wave.
-#define VP_PD_SCRATCH_BYTES (64 * (5 * 8 + 2 * 8) + 65 * 4 + 4)
+#define VP_PD_SCRATCH_BYTES (64 * (5 * 8 + 2 * 8) + 65 * 4 + 4 + 64 * 4)
 __device__ double vp_pd_wave(const Params &P, const double *scan, int nScan, double px, double py, double pth, const Ent3 &e, bool act, bool &close,
                              unsigned char *ws) {
   const int lane = threadIdx.x & 63;
@@ -154,10 +154,14 @@ __device__ double vp_pd_wave(const Params &P, const double *scan, int nScan, dou
       while (n < 100000 && (n * step < sd)) n++;
     }
   }
+  int *lcl = pre + 66;                                     // the unshifted landmark's near-limit verdict
   lx[lane] = e.x; ly[lane] = e.y; ld[lane] = e.d; lp0[lane] = p0; lp1[lane] = p1;
   lmn[lane] = 0x7ff0000000000000ull;                       // +inf
   lmx[lane] = 0ull;                                        // pd >= 0
-  const int cnt = 2 * n;
+  lcl[lane] = 0;
+  // the pool: 2 n shifted copies + the landmark itself (r3: the unshifted evaluation used to be a separate round of all lanes --
+  // with 40 landmarks of one copy pair each that was 2 + 1 rounds of probabilityOfDetection2 where the pool needs 2)
+  const int cnt = act ? 2 * n + 1 : 0;
   const int off = wave_excl_scan(cnt, lane);
   const int total = __builtin_amdgcn_readlane(off + cnt, 63);
   pre[lane] = off;
@@ -168,25 +172,27 @@ __device__ double vp_pd_wave(const Params &P, const double *scan, int nScan, dou
 #pragma unroll
     for (int st = 32; st >= 1; st >>= 1) l += (pre[l + st] <= t) ? st : 0;
     const int j = t - pre[l];
+    const bool self = (t + 1 == pre[l + 1]);               // the last item of a landmark's block: the landmark where it is
     const int i = (j >> 1) + 1;
     const double dd = ld[l];
-    const double sh = i * 2 * dd;
-    const double sg = (j & 1) ? -1.0 : 1.0;
+    const double sh = self ? 0.0 : i * 2 * dd;
     bool c2;
-    const double p = (j & 1) ? vp_pd2(P, scan, nScan, px, py, pth, lx[l] - sh * lp0[l], ly[l] - sh * lp1[l], dd, c2)
-                             : vp_pd2(P, scan, nScan, px, py, pth, lx[l] + sh * lp0[l], ly[l] + sh * lp1[l], dd, c2);
-    (void)sg;
+    double qx, qy;
+    if (self) { qx = lx[l]; qy = ly[l]; }
+    else if (j & 1) { qx = lx[l] - sh * lp0[l]; qy = ly[l] - sh * lp1[l]; }
+    else { qx = lx[l] + sh * lp0[l]; qy = ly[l] + sh * lp1[l]; }
+    const double p = vp_pd2(P, scan, nScan, px, py, pth, qx, qy, dd, c2);
+    if (self) lcl[l] = c2 ? 1 : 0;                         // `close` is the unshifted landmark's verdict (the reference's last call)
     const unsigned long long bits = (unsigned long long)__double_as_longlong(p);
     atomicMin(&lmn[l], bits);
     atomicMax(&lmx[l], bits);
   }
   wave_sync();
-  double mn = __longlong_as_double((long long)lmn[lane]), mx = __longlong_as_double((long long)lmx[lane]);
-  const double p = vp_pd2(P, scan, nScan, px, py, pth, e.x, e.y, e.d, close);   // the unshifted landmark last: `close` is its verdict
-  mn = fmin(mn, p); mx = fmax(mx, p);
+  const double mn = __longlong_as_double((long long)lmn[lane]), mx = __longlong_as_double((long long)lmx[lane]);
+  close = lcl[lane] != 0;
   if (mn == 0 && mx > 0) close = true;
   wave_sync();                                             // (the scratch is reused by the next pass)
-  return mx;
+  return act ? mx : 0.0;
 }
 
 // Probe for tests (rfsgpu_vp_probe_pd): Pd and the near-limit flag of every Gaussian of one particle, as the kernels see them.
@@ -271,24 +277,19 @@ __device__ __forceinline__ double vp_value(const Params &P, const LmKF3 &k, doub
   return pdw * lik;
 }
 
+// LDS shared by the waves of a workgroup: the measurement set (3 nZ doubles) and the laser scan (nScan doubles) -- sized by what
+// is there (r02 reserved 64 measurements and 720 beams: 7.3 KB per workgroup where a Victoria Park scan has 361 beams and ~12
+// measurements; the LDS block is what decides how many particles a CU holds).
+__host__ __device__ inline size_t vp_shared_lds_bytes(int nZ, int nScan) { return (((size_t)(3 * nZ + nScan) * 8) + 15) & ~(size_t)15; }
 // LDS per wave: survivor list (value, packed (m,z)) + per-landmark segment + stored Pd + final normalisers.
 __host__ __device__ inline size_t vp_update_lds_bytes_per_wave(int cap) { return (((size_t)cap * (8 + 4 + 4 + 8) + RFSGPU_MAX_Z * 8 + VP_PD_SCRATCH_BYTES) + 15) & ~(size_t)15; }
 
 // RBPHDFilter::updateMap for the Victoria Park model (same phases as phd_update_map_kernel).
-template <int WPB>
-__global__ __launch_bounds__(WPB * 64) void vp_update_map_kernel(Buffers B, Params P, int cur, int nZ) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  double *sZ = reinterpret_cast<double *>(smem_raw);                 // [3*MAX_Z]
-  double *sScan = sZ + 3 * RFSGPU_MAX_Z;                              // [RFSGPU_VP_MAX_SCAN]
-  const int wave = threadIdx.x >> 6;
-  const int lane = threadIdx.x & 63;
-  for (int t = threadIdx.x; t < 3 * nZ; t += WPB * 64) sZ[t] = B.Z[t];
-  for (int t = threadIdx.x; t < B.nScan; t += WPB * 64) sScan[t] = B.scan[t];
-  __syncthreads();
-  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
-  if (i >= B.N) return;
+// One wavefront takes particle i through the map update.  sZ / sScan: the measurement set and the laser scan, staged in LDS by
+// the caller (shared by the waves of a workgroup); wb: vp_update_lds_bytes_per_wave(cap) bytes of LDS of this wave.
+__device__ void vp_update_map_particle(const Buffers &B, const Params &P, int cur, int nZ, int i, int lane, const double *sZ, const double *sScan,
+                                       unsigned char *wb) {
   const int cap = B.cap;
-  unsigned char *wb = smem_raw + (3 * RFSGPU_MAX_Z + RFSGPU_VP_MAX_SCAN) * 8 + (size_t)wave * vp_update_lds_bytes_per_wave(cap);
   double *sV = reinterpret_cast<double *>(wb);
   double *sPd = sV + cap;
   double *sCol = sPd + cap;
@@ -305,6 +306,7 @@ __global__ __launch_bounds__(WPB * 64) void vp_update_map_kernel(Buffers B, Para
   const double px = B.pose[3 * i], py = B.pose[3 * i + 1], pth = B.pose[3 * i + 2];
   const int nPass = (nM + 63) >> 6;
   const int room = cap - nM;
+  DBG_T(0, 0);
   int nFov = 0, nSurv = 0;
   double wsum = 0.0, cs = P.vpClutter;
   bool overflow = false;
@@ -318,6 +320,8 @@ __global__ __launch_bounds__(WPB * 64) void vp_update_map_kernel(Buffers B, Para
     bool close = false;
     double pd = vp_pd_wave(P, sScan, B.nScan, px, py, pth, e, act, close, reinterpret_cast<unsigned char *>(sSeg + cap));
     if (!act) { pd = 0.0; close = false; }
+    if (p == 0) DBG_T(0, 1);
+    RFS_CUT(101);
     if (close) pd = 1;  // RBPHDFilter.hpp:604-606
     const bool fov = act && (pd != 0);
     const double pdw = pd * e.w;
@@ -325,6 +329,8 @@ __global__ __launch_bounds__(WPB * 64) void vp_update_map_kernel(Buffers B, Para
     if (P.useCluster) wsum += act ? e.w : 0.0;
     LmKF3 k;
     lm_precompute3(P, px, py, pth, e, k);
+    if (p == 0) DBG_T(0, 2);
+    RFS_CUT(102);
     unsigned long long surv = 0;
     if (fov) {
       for (int z = 0; z < nZ; z++) {
@@ -332,6 +338,8 @@ __global__ __launch_bounds__(WPB * 64) void vp_update_map_kernel(Buffers B, Para
         if (vp_gate(P, k, sZ[3 * z], sZ[3 * z + 1], nu0, nu1) && vp_value(P, k, pdw, sZ[3 * z], sZ[3 * z + 1], sZ[3 * z + 2]) != 0.0) surv |= 1ull << z;
       }
     }
+    if (p == 0) DBG_T(0, 3);
+    RFS_CUT(103);
     const int cnt = __popcll(surv);
     const int off = wave_excl_scan(cnt, lane);
     const int total = __builtin_amdgcn_readlane(off + cnt, 63);
@@ -364,6 +372,8 @@ __global__ __launch_bounds__(WPB * 64) void vp_update_map_kernel(Buffers B, Para
   }
   sCol[lane] = cs;
   wave_sync();
+  DBG_T(0, 4);
+  RFS_CUT(104);
 
   int outBase = nM;
   unsigned long long used = 0;
@@ -401,6 +411,8 @@ __global__ __launch_bounds__(WPB * 64) void vp_update_map_kernel(Buffers B, Para
     }
     outBase += __popcll(km);
   }
+  DBG_T(0, 5);
+  RFS_CUT(105);
   for (int m = lane; m < nM; m += 64) {
     double *pW = plane3(slab, cap, i, P3_W), *pWP = plane3(slab, cap, i, P3_WP);
     const double w = pW[m];
@@ -419,6 +431,8 @@ __global__ __launch_bounds__(WPB * 64) void vp_update_map_kernel(Buffers B, Para
     pW[m] = w_k;
   }
   used = wave_or_u64(used);
+  DBG_T(0, 6);
+  RFS_CUT(106);
   if (lane == 0) {
     B.count[i] = outBase;
     B.unusedMask[i] = (~used) & zmask;
@@ -431,16 +445,11 @@ __global__ __launch_bounds__(WPB * 64) void vp_update_map_kernel(Buffers B, Para
     if (lane == 0) B.weight[i] = exp(s) * prod * B.weight[i];
   }
 }
-
-// RBPHDFilter::importanceWeighting for the Victoria Park model (same steps as phd_weight_multifeature_kernel).
-__host__ __device__ inline size_t vp_weight_lds_bytes_per_wave(int cap, int evalCap, int nZ) {
-  return (weight_lds_bytes_per_wave(cap, evalCap, nZ) + (size_t)evalCap * 16 * 8 + VP_PD_SCRATCH_BYTES + 15) & ~(size_t)15;
-}
 template <int WPB>
-__global__ __launch_bounds__(WPB * 64) void vp_weighting_kernel(Buffers B, Params P, int src, int dst, int nZ, int evalCap, MurtyQueue Q) {
+__global__ __launch_bounds__(WPB * 64) void vp_update_map_kernel(Buffers B, Params P, int cur, int nZ) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  double *sZ = reinterpret_cast<double *>(smem_raw);
-  double *sScan = sZ + 3 * RFSGPU_MAX_Z;
+  double *sZ = reinterpret_cast<double *>(smem_raw);                 // [3 nZ]
+  double *sScan = sZ + 3 * nZ;                                        // [nScan]
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   for (int t = threadIdx.x; t < 3 * nZ; t += WPB * 64) sZ[t] = B.Z[t];
@@ -448,13 +457,53 @@ __global__ __launch_bounds__(WPB * 64) void vp_weighting_kernel(Buffers B, Param
   __syncthreads();
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
   if (i >= B.N) return;
+  vp_update_map_particle(B, P, cur, nZ, i, lane, sZ, sScan, smem_raw + vp_shared_lds_bytes(nZ, B.nScan) + (size_t)wave * vp_update_lds_bytes_per_wave(B.cap));
+}
+
+// RBPHDFilter::importanceWeighting for the Victoria Park model (same steps as phd_weight_multifeature_kernel).
+// LDS of the weighting phase, per wave.  Its own layout since r3 (r02 took the 2-D kernel's WeightLDS -- with the float keys
+// and evaluation-point tables this model never touches -- and added its own arrays behind it: 15.2 KB at cap 192, which
+// held a CU to 8 waves once the three phases shared one allocation).  Early part: keys, sort permutation, evaluation points
+// (x, y, Pd, log(1 - Pd)) and their 16-double records (diameter, z_exp, S^-1, factor); late part, written only after the
+// evaluation points are chosen: likelihood table, component labels / masks, partition likelihoods -- the Pd scratch of the
+// selection (vp_pd_wave) lies over it.
+__host__ __device__ inline size_t vp_weight_lds_late_bytes(int evalCap, int nZ) {
+  size_t late = (size_t)evalCap * nZ * 8 + 64 * 4 * 2 + 128 * 8 * 2 + 128 * 8;
+  if (late < (size_t)VP_PD_SCRATCH_BYTES) late = VP_PD_SCRATCH_BYTES;
+  return late;
+}
+__host__ __device__ inline size_t vp_weight_lds_bytes_per_wave(int cap, int evalCap, int nZ) {
+  const size_t early = (size_t)cap * 8 + (size_t)((cap + 63) & ~63) * 4 + (size_t)evalCap * 8 * 4 + (size_t)evalCap * 16 * 8;
+  return (early + vp_weight_lds_late_bytes(evalCap, nZ) + 15) & ~(size_t)15;
+}
+__device__ __forceinline__ void carve_vp_weight_lds(unsigned char *base, int cap, int evalCap, int nZ, WeightLDS &s, double *&evD, unsigned char *&pdScratch) {
+  unsigned char *p = base;
+  s.keys = (double *)p; p += (size_t)cap * 8;
+  s.evX = (double *)p; p += (size_t)evalCap * 8;
+  s.evY = (double *)p; p += (size_t)evalCap * 8;
+  s.evPd = (double *)p; p += (size_t)evalCap * 8;
+  s.evLog1mPd = (double *)p; p += (size_t)evalCap * 8;
+  evD = (double *)p; p += (size_t)evalCap * 16 * 8;
+  pdScratch = p;                                            // (over the late part)
+  s.L = (double *)p; p += (size_t)evalCap * nZ * 8;
+  s.compRows = (unsigned long long *)p; p += 128 * 8;
+  s.compCols = (unsigned long long *)p; p += 128 * 8;
+  s.partLik = (double *)p; p += 128 * 8;
+  s.labR = (int *)p; p += 64 * 4;
+  s.labC = (int *)p; p += 64 * 4;
+  s.perm = (int *)(base + (size_t)cap * 8 + (size_t)evalCap * 8 * 4 + (size_t)evalCap * 16 * 8 + vp_weight_lds_late_bytes(evalCap, nZ));
+  s.fkeys = nullptr; s.evIdx = nullptr; s.evZ = nullptr;    // (2-D kernel only)
+}
+// One wavefront takes particle i through the weighting.  permOut == nullptr: the mixture sorted by weight is written to slab
+// `dst` (the stand-alone kernel; the merge kernel then works on that copy).  permOut != nullptr (the fused step): the sorted
+// order is handed on as a permutation in LDS (rank -> storage index, u16[cap]) and nothing is written to `dst`.
+__device__ void vp_weight_particle(const Buffers &B, const Params &P, int src, int dst, int nZ, int evalCap, const MurtyQueue &Q, int i, int lane,
+                                   const double *sZ, const double *sScan, unsigned char *wbase, unsigned short *permOut) {
   const int cap = B.cap;
   WeightLDS s;
-  // evX/evY hold x,y; the diameter of the evaluation points goes into evZ's spare slot via a separate array below
-  unsigned char *wbase = smem_raw + (3 * RFSGPU_MAX_Z + RFSGPU_VP_MAX_SCAN) * 8 + (size_t)wave * vp_weight_lds_bytes_per_wave(cap, evalCap, nZ);
-  carve_weight_lds(wbase, cap, evalCap, nZ, s);
-  double *evD = reinterpret_cast<double *>(wbase + weight_lds_bytes_per_wave(cap, evalCap, nZ));  // [evalCap][16]: d, z_exp(3), Si(9), factor
-  unsigned char *pdScratch = wbase + weight_lds_bytes_per_wave(cap, evalCap, nZ) + (size_t)evalCap * 16 * 8;          // vp_pd_wave
+  double *evD;                  // [evalCap][16]: d, z_exp(3), Si(9), factor
+  unsigned char *pdScratch;     // vp_pd_wave
+  carve_vp_weight_lds(wbase, cap, evalCap, nZ, s, evD, pdScratch);
   const int N = B.count[i];
   const double *sl = B.slab[src];
   double *dl = B.slab[dst];
@@ -463,12 +512,17 @@ __global__ __launch_bounds__(WPB * 64) void vp_weighting_kernel(Buffers B, Param
 
   int nEvalPoints = ((unsigned)P.evalCount > (unsigned)N) ? N : P.evalCount;
   if (nEvalPoints == 0) {
-    for (int pl = 0; pl < P3_COUNT; pl++)
-      for (int m = lane; m < N; m += 64) (dl + ((size_t)i * P3_COUNT + pl) * cap)[m] = (sl + ((size_t)i * P3_COUNT + pl) * cap)[m];
+    if (permOut) {
+      for (int m = lane; m < N; m += 64) permOut[m] = (unsigned short)m;
+    } else {
+      for (int pl = 0; pl < P3_COUNT; pl++)
+        for (int m = lane; m < N; m += 64) (dl + ((size_t)i * P3_COUNT + pl) * cap)[m] = (sl + ((size_t)i * P3_COUNT + pl) * cap)[m];
+    }
     if (lane == 0) B.weight[i] = RFS_DENORM_MIN;
     return;
   }
   // rank sort (exact fp64 form: Victoria Park mixtures are small)
+  DBG_T(16, 0);
   for (int m = lane; m < N; m += 64) s.keys[m] = qW[m];
   wave_sync();
   for (int m = lane; m < N; m += 64) {
@@ -481,17 +535,26 @@ __global__ __launch_bounds__(WPB * 64) void vp_weighting_kernel(Buffers B, Param
     s.perm[rank] = m;
   }
   wave_sync();
-  for (int r = lane; r < N; r += 64) {
-    const int m = s.perm[r];
-    for (int pl = 0; pl < P3_COUNT; pl++) (dl + ((size_t)i * P3_COUNT + pl) * cap)[r] = (sl + ((size_t)i * P3_COUNT + pl) * cap)[m];
+  if (permOut) {
+    for (int r = lane; r < N; r += 64) permOut[r] = (unsigned short)s.perm[r];
+  } else {
+    for (int r = lane; r < N; r += 64) {
+      const int m = s.perm[r];
+      for (int pl = 0; pl < P3_COUNT; pl++) (dl + ((size_t)i * P3_COUNT + pl) * cap)[r] = (sl + ((size_t)i * P3_COUNT + pl) * cap)[m];
+    }
   }
   // evaluation points
+  DBG_T(16, 1);
+  RFS_CUT(110);
   int nE = 0;
   {
     const int limit = nEvalPoints < RFSGPU_MAX_EVAL ? nEvalPoints : RFSGPU_MAX_EVAL;
     bool done = false;
-    for (int c0 = 0; c0 < N && !done; c0 += 64) {
-      const int r = c0 + lane;
+    // 16 ranks at a time (r02: 64): the selection stops at the first weight below the threshold or with `limit` points, i.e.
+    // within the first few ranks, and every rank looked at costs its probabilityOfDetection (Pd of the landmark and of its
+    // shifted copies, vp_pd_wave); the pooled evaluation of a 16-rank group is one round of the wave.  Same points, same order.
+    for (int c0 = 0; c0 < N && !done; c0 += 16) {
+      const int r = (lane < 16) ? c0 + lane : N;
       bool below = true, cand = false;
       Ent3 e;
       double pd = 0;
@@ -508,7 +571,7 @@ __global__ __launch_bounds__(WPB * 64) void vp_weighting_kernel(Buffers B, Param
         if (!want) pd = 0;
         cand = pd > 0;
       }
-      const unsigned long long belowMask = __ballot(below);
+      const unsigned long long belowMask = __ballot(below && (lane < 16) && (c0 + lane < N));   // (ranks that exist)
       const unsigned long long valid = belowMask ? ((1ull << __builtin_ctzll(belowMask)) - 1ull) : ~0ull;
       if (belowMask) done = true;
       const unsigned long long candMask = __ballot(cand) & valid;
@@ -528,15 +591,18 @@ __global__ __launch_bounds__(WPB * 64) void vp_weighting_kernel(Buffers B, Param
   }
   wave_sync();
   // weight sums + intensity products
+  DBG_T(16, 2);
+  RFS_CUT(111);
   double sumPrev = 0.0, sumCur = 0.0;
   for (int m = lane; m < N; m += 64) { sumPrev += qWP[m]; sumCur += s.keys[m]; }
   sumPrev = wave_sum_dpp(sumPrev);
   sumCur = wave_sum_dpp(sumCur);
   double prodBefore = 1.0, prodAfter = 1.0;
-  for (int e0 = 0; e0 < nE; e0 += 4) {
-    double accB[4], accA[4];
+  // (eight evaluation points per sweep of the mixture -- r02: four: every sweep inverts each Gaussian's covariance again)
+  for (int e0 = 0; e0 < nE; e0 += 8) {
+    double accB[8], accA[8];
 #pragma unroll
-    for (int t = 0; t < 4; t++) { accB[t] = 0.0; accA[t] = 0.0; }
+    for (int t = 0; t < 8; t++) { accB[t] = 0.0; accA[t] = 0.0; }
     for (int m = lane; m < N; m += 64) {
       Ent3 g;
       load_ent3(sl, cap, i, m, g, false);
@@ -544,23 +610,27 @@ __global__ __launch_bounds__(WPB * 64) void vp_weighting_kernel(Buffers B, Param
       double Sm[9], Si[9];
       full3(g, Sm);
       inv3(Sm, Si);
-      const double factor = sqrt(P.twoPiPowD * det3(Sm));
+      // (exp(.) * (1 / factor) instead of exp(.) / factor, as in the 2-D kernel: one division per Gaussian instead of one per
+      //  Gaussian and evaluation point; <= 1.5 ulp in a term of the intensity sum -- DESIGN, deviation 4)
+      const double rfactor = 1.0 / sqrt(P.twoPiPowD * det3(Sm));
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
+      for (int t = 0; t < 8; t++) {
         const int ev = (e0 + t < nE) ? e0 + t : e0;
-        const double lik = gauss_from_md2(md2_3(Si, s.evX[ev] - g.x, s.evY[ev] - g.y, evD[16 * ev] - g.d), factor);
+        const double lik = gauss_from_md2_r(md2_3(Si, s.evX[ev] - g.x, s.evY[ev] - g.y, evD[16 * ev] - g.d), rfactor);
         accB[t] += wp * lik;
         accA[t] += w * lik;
       }
     }
 #pragma unroll
-    for (int t = 0; t < 4; t++)
+    for (int t = 0; t < 8; t++)
       if (e0 + t < nE) {
         prodBefore *= (RFS_DENORM_MIN + wave_sum_dpp(accB[t]));
         prodAfter *= (RFS_DENORM_MIN + wave_sum_dpp(accA[t]));
       }
   }
   // likelihood table
+  DBG_T(16, 3);
+  RFS_CUT(112);
   if (lane < nE) {
     VPMeas o;
     vp_measure(P, px, py, pth, s.evX[lane], s.evY[lane], evD[16 * lane], 0.0, 0.0, 0.0, 0.0, o);  // evalPt_copy.setCov(Zero)
@@ -579,17 +649,44 @@ __global__ __launch_bounds__(WPB * 64) void vp_weighting_kernel(Buffers B, Param
     s.L[idx] = Lv;
   }
   wave_sync();
+  DBG_T(16, 4);
+  RFS_CUT(113);
   const double l = rfs_partitions_wave(s, nE, nZ, P.vpClutter, lane, i, Q, B.err, P.exactPartitions);
+  DBG_T(16, 5);
+  RFS_CUT(114);
   const double ml = l / P.vpExpClutter;  // clutterIntensityIntegral (:287-290)
   const double overall = ml * prodBefore / prodAfter * exp(sumCur - sumPrev);
   if (lane == 0) B.weight[i] = overall * B.weight[i];
+}
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64) void vp_weighting_kernel(Buffers B, Params P, int src, int dst, int nZ, int evalCap, MurtyQueue Q) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double *sZ = reinterpret_cast<double *>(smem_raw);
+  double *sScan = sZ + 3 * nZ;
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  for (int t = threadIdx.x; t < 3 * nZ; t += WPB * 64) sZ[t] = B.Z[t];
+  for (int t = threadIdx.x; t < B.nScan; t += WPB * 64) sScan[t] = B.scan[t];
+  __syncthreads();
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
+  if (i >= B.N) return;
+  vp_weight_particle(B, P, src, dst, nZ, evalCap, Q, i, lane, sZ, sScan,
+                     smem_raw + vp_shared_lds_bytes(nZ, B.nScan) + (size_t)wave * vp_weight_lds_bytes_per_wave(B.cap, evalCap, nZ), nullptr);
 }
 
 // LDS per wave for the merge: 42 B per Gaussian -- position (x, y, d), prefilter bound and weight as doubles, a u16 survivor list.
 // (Until r02 every entry was staged with its covariance AND the inverse, 130 B: 25 KB per wave at cap 192, six waves per CU, and
 // the 5000 particles of configs[3] took 3.3 rounds.  Now the distance prefilter below runs on the LDS copy and everything the
 // exact test needs comes from the slab for the few pairs that survive it; all 5000 waves are resident at once.)
-__host__ __device__ inline size_t vp_merge_lds_bytes_per_wave(int cap) { return (((size_t)cap * (5 * 8 + 2)) + 15) & ~(size_t)15; }
+// Two layouts share the block: the row-by-row scan's (mixtures longer than a wavefront: 42 B per Gaussian of capacity) and the
+// lane-parallel scan's (at most 64 Gaussians: the five arrays at stride 64, the survivor list, the six covariance planes and an
+// fp32 copy of position + prefilter radius for the candidate sweeps: 6.8 KB whatever the capacity).
+#define VP_MERGE_LANE_LDS_BYTES ((5 * 64 + 16 + 6 * 64) * 8 + 4 * 64 * 4 + 16)
+__host__ __device__ inline size_t vp_merge_lds_bytes_per_wave(int cap) {
+  size_t a = (size_t)cap * (5 * 8 + 2);
+  if (a < (size_t)VP_MERGE_LANE_LDS_BYTES) a = VP_MERGE_LANE_LDS_BYTES;
+  return (a + 15) & ~(size_t)15;
+}
 
 // Necessary condition for a pair to pass GaussianMixture::merge's test with covariance S: e^T S^-1 e >= |e|^2 / lambda_max(S) >=
 // |e|^2 / tr(S) for a positive definite S, so md2 <= t^2 implies |e|^2 <= t^2 tr(S).  The bound carries a 1e-6 relative margin for
@@ -604,31 +701,82 @@ __device__ __forceinline__ double merge_bound3(double t2, const Ent3 &e) {
   return sane ? t2 * tr * (1.0 + 1e-6) : __builtin_huge_val();
 }
 
+// sqrt of a prefilter bound as an fp32 number that is not smaller (2^-20 covers the conversion's rounding); a NaN bound -- the
+// fp64 comparison `!(d2 > bound)` then keeps everything -- becomes +inf.
+__device__ __forceinline__ float vp_radius_f32(double bound) {
+  if (!(bound == bound)) return __builtin_huge_valf();
+  return (float)(sqrt(bound) * (1.0 + 0x1p-20));
+}
+// One merge of GaussianMixture::merge (include/GaussianMixture.hpp:443-468) on the running state of row a: b is absorbed.
+// State: position, weight, full covariance aS (upper triangle mirrored), its inverse aI as the test reads it, prefilter bound ab.
+__device__ __forceinline__ void merge3_step(double t2, double f, const Ent3 &eb, double w2, double &ax, double &ay, double &ad, double &aw, double aS[9],
+                                            double aI[9], double &ab) {
+  const double w1 = aw;
+  const double bx[3] = {eb.x, eb.y, eb.d};
+  double bS[9];
+  full3(eb, bS);
+  const double wm = w1 + w2;
+  const double axv[3] = {ax, ay, ad};
+  double xm[3], d1[3], d2[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { xm[k] = (axv[k] * w1 + bx[k] * w2) / wm; d1[k] = xm[k] - axv[k]; d2[k] = xm[k] - bx[k]; }
+  double nS[9];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) nS[3 * r + c] = (w1 * (aS[3 * r + c] + (f * d1[r]) * d1[c]) + w2 * (bS[3 * r + c] + (f * d2[r]) * d2[c])) / wm;
+  ax = xm[0]; ay = xm[1]; ad = xm[2]; aw = wm;
+  // packed symmetric storage: keep the upper triangle (the lower one is its mirror up to rounding of f*d_r*d_c order)
+  nS[3] = nS[1]; nS[6] = nS[2]; nS[7] = nS[5];
+#pragma unroll
+  for (int k = 0; k < 9; k++) aS[k] = nS[k];
+  inv3(aS, aI);
+  // the reference inverts the full matrix; mirror its symmetric reads
+  aI[3] = aI[1]; aI[6] = aI[2]; aI[7] = aI[5];
+  Ent3 em;
+  em.w = aw; em.x = ax; em.y = ay; em.d = ad;
+  em.xx = aS[0]; em.xy = aS[1]; em.xd = aS[2]; em.yy = aS[4]; em.yd = aS[5]; em.dd = aS[8];
+  ab = merge_bound3(t2, em);
+}
+
 // GaussianMixture::merge for 3-D Gaussians: the exact sequential-greedy scan (lanes test 64 candidates j at once against
 // the current state of a, lowest passing lane merged, lanes above it re-tested), optional fused prune.  Merged rows are
 // written back in place (a row is never read again once the scan has passed it); the prune reads the slab.
-template <int WPB, bool FUSE_PRUNE>
-__global__ __launch_bounds__(WPB * 64) void vp_merge_kernel(Buffers B, Params P, int cur, int dst) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  const int wave = threadIdx.x >> 6;
-  const int lane = threadIdx.x & 63;
-  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
-  if (i >= B.N) return;
+// `perm` (the fused step): row r of the scan is entry perm[r] of the slab -- the mixture in weight order without a sorted copy;
+// nullptr: the slab itself is in scan order (the stand-alone kernel after vp_weighting_kernel's sorted copy).
+#ifndef VP_LANE_SCAN
+#define VP_LANE_SCAN 1   // tuning knob (tools/variant_bench.py): 0 = the row-by-row scan for every mixture
+#endif
+template <bool FUSE_PRUNE>
+__device__ void vp_merge_particle(const Buffers &B, const Params &P, int cur, int dst, int i, int lane, unsigned char *wmem, const unsigned short *perm) {
   const int cap = B.cap;
-  double *sb = reinterpret_cast<double *>(smem_raw + (size_t)wave * vp_merge_lds_bytes_per_wave(cap));
-  double *sX = sb, *sY = sb + cap, *sD = sb + 2 * (size_t)cap, *sBnd = sb + 3 * (size_t)cap, *sW = sb + 4 * (size_t)cap;
-  unsigned short *sIdx = reinterpret_cast<unsigned short *>(sb + 5 * (size_t)cap);
+  double *sb = reinterpret_cast<double *>(wmem);
+  auto at = [&](int r) -> int { return perm ? (int)perm[r] : r; };   // storage index of scan row r
   const int N = B.count[i];
+  const bool laneMode = VP_LANE_SCAN && N <= 64;
+  const size_t st = laneMode ? 64 : (size_t)cap;       // stride of the per-Gaussian arrays (see vp_merge_lds_bytes_per_wave)
+  double *sX = sb, *sY = sb + st, *sD = sb + 2 * st, *sBnd = sb + 3 * st, *sW = sb + 4 * st;
+  unsigned short *sIdx = reinterpret_cast<unsigned short *>(sb + 5 * st);
+  double *sCov = sb + 5 * 64 + 16;                      // [6][64]                      (lane mode only)
+  float *fX = reinterpret_cast<float *>(sCov + 6 * 64), *fY = fX + 64, *fD = fY + 64, *fR = fD + 64;   // fp32 position, prefilter radius
   double *slab = B.slab[cur];
   const double t2 = P.mergeT2, f = P.mergeInfl;
   unsigned hole = 0;
+  double posMax = 0.0;     // largest |coordinate| of the mixture (lane mode: error bound of the fp32 sweep)
+  DBG_T(32, 0);
   for (int m = lane, sidx = 0; m < N; m += 64, sidx++) {
     Ent3 e;
-    load_ent3(slab, cap, i, m, e, true);
+    load_ent3(slab, cap, i, at(m), e, true);
     sX[m] = e.x; sY[m] = e.y; sD[m] = e.d;
     sBnd[m] = merge_bound3(t2, e);
     sW[m] = e.w;
     if (e.w < 0) hole |= 1u << sidx;
+    if (laneMode) {
+      sCov[m] = e.xx; sCov[64 + m] = e.xy; sCov[128 + m] = e.xd; sCov[192 + m] = e.yy; sCov[256 + m] = e.yd; sCov[320 + m] = e.dd;
+      fX[m] = (float)e.x; fY[m] = (float)e.y; fD[m] = (float)e.d;
+      fR[m] = vp_radius_f32(sBnd[m]);
+      posMax = fmax(posMax, fmax(fmax(fabs(e.x), fabs(e.y)), fabs(e.d)));
+    }
   }
   wave_sync();
   // inverse of a stored covariance as the reference's test reads it: Eigen's cofactor inverse of the full matrix, of which the
@@ -643,6 +791,9 @@ __global__ __launch_bounds__(WPB * 64) void vp_merge_kernel(Buffers B, Params P,
   // hence the distance prefilter on the initial states; a row without such a partner goes through the reference's scan
   // unchanged, so it is skipped outright (its record is never fetched).  On a Victoria Park map that is all but a few rows.
   unsigned rowFlag = 0;
+  DBG_T(32, 1);
+  RFS_CUT(120);
+  if (N > 64 || !VP_LANE_SCAN)      // (mixtures of at most one wavefront take the lane-parallel scan below, which needs no row list)
   for (int m = lane, sidx = 0; m < N; m += 64, sidx++) {
     if ((hole >> sidx) & 1u) continue;
     const double mx = sX[m], my = sY[m], md = sD[m], mb = sBnd[m];
@@ -654,14 +805,14 @@ __global__ __launch_bounds__(WPB * 64) void vp_merge_kernel(Buffers B, Params P,
     if (c) rowFlag |= 1u << sidx;
   }
   bool anyMerge = false;
-  for (int r0 = 0; r0 < N; r0 += 64)
-  for (unsigned long long rows = __ballot((rowFlag >> (r0 >> 6)) & 1u); rows; rows &= rows - 1ull) {
-    const int a = r0 + __builtin_ctzll(rows);
+  DBG_T(32, 2);
+  // the reference's scan of ONE row, by the whole wave: 64 candidates at a time against the current state of a
+  auto serial_row = [&](const int a) {
     Ent3 ea;
     ea.w = 0;
-    load_ent3(slab, cap, i, a, ea, false);                       // (wave-uniform address: one broadcast load per plane)
+    load_ent3(slab, cap, i, at(a), ea, false);                       // (wave-uniform address: one broadcast load per plane)
     const unsigned ownerHole = (unsigned)__builtin_amdgcn_readlane((int)hole, a & 63);
-    if ((ownerHole >> (a >> 6)) & 1u) continue;
+    if ((ownerHole >> (a >> 6)) & 1u) return;
     double ax = ea.x, ay = ea.y, ad = ea.d, aw = sW[a], ab = sBnd[a];
     double aS[9], aI[9];
     full3(ea, aS);
@@ -680,7 +831,7 @@ __global__ __launch_bounds__(WPB * 64) void vp_merge_kernel(Buffers B, Params P,
             bool far = md2_3(aI, e0, e1, e2) > t2;
             if (far) {
               Ent3 ej;
-              load_ent3(slab, cap, i, j, ej, false);
+              load_ent3(slab, cap, i, at(j), ej, false);
               double jI[9];
               inverse_of(ej, jI);
               far = md2_3(jI, -e0, -e1, -e2) > t2;
@@ -693,35 +844,8 @@ __global__ __launch_bounds__(WPB * 64) void vp_merge_kernel(Buffers B, Params P,
         const int l = __builtin_ctzll(pm);
         const int jj = c0 + l;
         Ent3 eb;
-        load_ent3(slab, cap, i, jj, eb, false);                  // uniform
-        const double w1 = aw, w2 = sW[jj];
-        const double bx[3] = {eb.x, eb.y, eb.d};
-        double bS[9];
-        full3(eb, bS);
-        const double wm = w1 + w2;
-        const double axv[3] = {ax, ay, ad};
-        double xm[3], d1[3], d2[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) { xm[k] = (axv[k] * w1 + bx[k] * w2) / wm; d1[k] = xm[k] - axv[k]; d2[k] = xm[k] - bx[k]; }
-        double nS[9];
-#pragma unroll
-        for (int r = 0; r < 3; r++)
-#pragma unroll
-          for (int c = 0; c < 3; c++) nS[3 * r + c] = (w1 * (aS[3 * r + c] + (f * d1[r]) * d1[c]) + w2 * (bS[3 * r + c] + (f * d2[r]) * d2[c])) / wm;
-        ax = xm[0]; ay = xm[1]; ad = xm[2]; aw = wm;
-        // packed symmetric storage: keep the upper triangle (the lower one is its mirror up to rounding of f*d_r*d_c order)
-        nS[3] = nS[1]; nS[6] = nS[2]; nS[7] = nS[5];
-#pragma unroll
-        for (int k = 0; k < 9; k++) aS[k] = nS[k];
-        inv3(aS, aI);
-        // the reference inverts the full matrix; mirror its symmetric reads
-        aI[3] = aI[1]; aI[6] = aI[2]; aI[7] = aI[5];
-        {
-          Ent3 em;
-          em.w = aw; em.x = ax; em.y = ay; em.d = ad;
-          em.xx = aS[0]; em.xy = aS[1]; em.xd = aS[2]; em.yy = aS[4]; em.yd = aS[5]; em.dd = aS[8];
-          ab = merge_bound3(t2, em);
-        }
+        load_ent3(slab, cap, i, at(jj), eb, false);                  // uniform
+        merge3_step(t2, f, eb, sW[jj], ax, ay, ad, aw, aS, aI, ab);
         changed = true;
         if (lane == l) { hole |= 1u << slot; live = false; }
         floorLane = l + 1;
@@ -732,21 +856,145 @@ __global__ __launch_bounds__(WPB * 64) void vp_merge_kernel(Buffers B, Params P,
       anyMerge = true;
       sW[a] = aw;   // (uniform store; the position / bound of a are never read again: a is behind the scan)
       if (lane == 0) {
-        plane3(slab, cap, i, P3_W)[a] = aw;
-        plane3(slab, cap, i, P3_MX)[a] = ax; plane3(slab, cap, i, P3_MY)[a] = ay; plane3(slab, cap, i, P3_MD)[a] = ad;
-        plane3(slab, cap, i, P3_SXX)[a] = aS[0]; plane3(slab, cap, i, P3_SXY)[a] = aS[1]; plane3(slab, cap, i, P3_SXD)[a] = aS[2];
-        plane3(slab, cap, i, P3_SYY)[a] = aS[4]; plane3(slab, cap, i, P3_SYD)[a] = aS[5]; plane3(slab, cap, i, P3_SDD)[a] = aS[8];
+        const int sa = at(a);
+        plane3(slab, cap, i, P3_W)[sa] = aw;
+        plane3(slab, cap, i, P3_MX)[sa] = ax; plane3(slab, cap, i, P3_MY)[sa] = ay; plane3(slab, cap, i, P3_MD)[sa] = ad;
+        plane3(slab, cap, i, P3_SXX)[sa] = aS[0]; plane3(slab, cap, i, P3_SXY)[sa] = aS[1]; plane3(slab, cap, i, P3_SXD)[sa] = aS[2];
+        plane3(slab, cap, i, P3_SYY)[sa] = aS[4]; plane3(slab, cap, i, P3_SYD)[sa] = aS[5]; plane3(slab, cap, i, P3_SDD)[sa] = aS[8];
       }
     }
+  };
+  if (N <= 64 && VP_LANE_SCAN) {
+    // ---- lane-parallel scan (r3).  Row a's scan depends on the rest of the mixture in ONE way only: which of the entries
+    // above it earlier rows have already absorbed -- entries above a are in their initial state when the reference reaches a.
+    // So every lane runs its own row's scan against the initial mixture (j ascending, state updated at each merge: the very
+    // sequence of the reference), and the rows are then validated in order: a row whose absorbed set avoids everything
+    // absorbed before it did exactly what the reference does and is committed; a row that collides (two rows after the same
+    // entry) is redone by the whole wave against the true state (serial_row).  On a Victoria Park map the clusters -- a tree,
+    // its updated copies -- are disjoint, so every row commits; the serial form cost one wave-wide pass per row with a
+    // partner (40 k of a particle's 165 k cycles at configs[3], and 14 k more for the row list).
+    const int a = lane;
+    const unsigned long long holes0 = __ballot((hole & 1u) != 0);
+    const bool isRow = (a < N) && !((holes0 >> a) & 1ull);
+    // (every entry the scan touches comes from the LDS copy made above -- the same doubles the slab holds: a merge inside the
+    //  candidate loop that waits for ten dependent global loads is what made the first lane-parallel form as slow as the serial one)
+    auto staged = [&](int m, Ent3 &e) {
+      e.x = sX[m]; e.y = sY[m]; e.d = sD[m];
+      e.xx = sCov[m]; e.xy = sCov[64 + m]; e.xd = sCov[128 + m]; e.yy = sCov[192 + m]; e.yd = sCov[256 + m]; e.dd = sCov[320 + m];
+    };
+    Ent3 ea;
+    ea.w = 0; ea.x = 10; ea.y = 10; ea.d = 1; ea.xx = 1; ea.xy = 0; ea.xd = 0; ea.yy = 1; ea.yd = 0; ea.dd = 1;
+    if (isRow) staged(a, ea);
+    double ax = ea.x, ay = ea.y, ad = ea.d, aw = isRow ? sW[a] : 0.0, ab = isRow ? sBnd[a] : 0.0;
+    double aS[9], aI[9];
+    full3(ea, aS);
+    inverse_of(ea, aI);
+    unsigned long long absorbed = 0ull;
+    // Candidates by bit mask: a uniform sweep over j (LDS broadcasts, no divergence, unrolled) marks the entries above the row
+    // that pass the distance prefilter against the row's CURRENT state; the lowest marked entry then goes through the exact test
+    // (all rows that have one, at once) and, if it merges, the row's mask above it is rebuilt from the new state by another sweep.
+    // The sweep runs in fp32 on the staged copies and keeps a SUPERSET of what the fp64 prefilter |e|^2 <= max(bound_a, bound_j)
+    // keeps (whatever it lets through is decided by the exact fp64 test anyway): with u = 2^-24, every fp32 difference is
+    // within eta = 2^-22 max|coordinate| of the true one, so |e| <= sqrt(B) implies |e_f| <= sqrt(B) + 2 eta; the radii are
+    // rounded up, the product carries 2^-18 for its own roundings; NaN / inf (positions, bounds) compare as "keep".
+    const float etaAll = wave_max_f32((float)(posMax * (1.0 + 0x1p-20))) * (2.0f * 0x1p-22f * (1.0f + 0x1p-20f));
+    auto sweep = [&](const int from, const bool want) -> unsigned long long {   // entries j > from passing the prefilter
+      const float fax = (float)ax, fay = (float)ay, fad = (float)ad;
+      const float ra = vp_radius_f32(ab);
+      const float eta2 = fmaxf(etaAll, fmaxf(fmaxf(fabsf(fax), fabsf(fay)), fabsf(fad)) * (2.0f * 0x1p-22f * (1.0f + 0x1p-20f)));
+      unsigned long long m = 0ull;
+#pragma unroll 4
+      for (int j = 1; j < N; j++) {
+        const float e0 = fX[j] - fax, e1 = fY[j] - fay, e2 = fD[j] - fad;
+        const float R = fmaxf(ra, fR[j]) + eta2;
+        const bool c = !(fmaf(e0, e0, fmaf(e1, e1, e2 * e2)) > (R * R) * (1.0f + 0x1p-18f));
+        m |= (c && j > from) ? (1ull << j) : 0ull;
+      }
+      return want ? (m & ~holes0) : 0ull;
+    };
+    unsigned long long cand = sweep(a, isRow);
+    // FIND, then MERGE TOGETHER: every row first walks its own marked entries (ascending) through the exact test until one
+    // passes -- cheap, and rows differ in how many they reject; then all rows that found one merge at once and rebuild their
+    // masks at once.  A merge is a dozen fp64 divisions and a sweep is a pass over the mixture: paying them once per ROUND
+    // (the largest number of merges any row makes: one or two) instead of once per row or once per absorbed entry is the point.
+    while (true) {
+      int jm = -1;
+      while (__ballot(cand != 0ull && jm < 0) != 0ull) {
+        if (cand != 0ull && jm < 0) {
+          const int j = __builtin_ctzll(cand);
+          cand &= cand - 1ull;
+          const double e0 = sX[j] - ax, e1 = sY[j] - ay, e2 = sD[j] - ad;
+          bool far = md2_3(aI, e0, e1, e2) > t2;
+          if (far) {
+            Ent3 ej;
+            staged(j, ej);
+            double jI[9];
+            inverse_of(ej, jI);
+            far = md2_3(jI, -e0, -e1, -e2) > t2;
+          }
+          if (!far && ((aw + sW[j]) != 0.0)) jm = j;
+        }
+      }
+      if (__ballot(jm >= 0) == 0ull) break;
+      if (jm >= 0) {
+        Ent3 eb;
+        staged(jm, eb);
+        merge3_step(t2, f, eb, sW[jm], ax, ay, ad, aw, aS, aI, ab);
+        absorbed |= 1ull << jm;
+      }
+      const unsigned long long fresh = sweep(jm, jm >= 0);     // (wave-wide; rows that found nothing are finished: cand == 0)
+      if (jm >= 0) cand = fresh;
+    }
+    // ordered validation
+    DBG_T(32, 5);
+#ifdef RFS_PROFILE
+    int dbgConf = 0, dbgRows = 0, dbgAbs = 0;
+#endif
+    unsigned long long holes = holes0, commit = 0ull;
+    for (unsigned long long rm = __ballot(absorbed != 0ull); rm; rm &= rm - 1ull) {
+      const int r = __builtin_ctzll(rm);
+      if ((holes >> r) & 1ull) continue;                       // an earlier row absorbed r itself
+      const unsigned long long m = readlane_u64(absorbed, r);
+#ifdef RFS_PROFILE
+      dbgRows++; dbgAbs += __popcll(m); if ((m & holes) != 0ull) dbgConf++;
+#endif
+      if ((m & holes) == 0ull) {
+        holes |= m;
+        commit |= 1ull << r;
+      } else {                                                 // collision: the true scan of r skips entries that are gone
+        hole = (hole & ~1u) | (unsigned)((holes >> lane) & 1ull);
+        serial_row(r);
+        holes = __ballot((hole & 1u) != 0);
+      }
+    }
+    DBG_T(32, 6);
+#ifdef RFS_PROFILE
+    if (B.dbg && i == 7 && lane == 0) { B.dbg[40] = dbgRows; B.dbg[41] = dbgConf; B.dbg[42] = dbgAbs; B.dbg[43] = N; }
+#endif
+    hole = (hole & ~1u) | (unsigned)((holes >> lane) & 1ull);
+    if ((commit >> lane) & 1ull) {
+      const int sa = at(a);
+      sW[a] = aw;
+      plane3(slab, cap, i, P3_W)[sa] = aw;
+      plane3(slab, cap, i, P3_MX)[sa] = ax; plane3(slab, cap, i, P3_MY)[sa] = ay; plane3(slab, cap, i, P3_MD)[sa] = ad;
+      plane3(slab, cap, i, P3_SXX)[sa] = aS[0]; plane3(slab, cap, i, P3_SXY)[sa] = aS[1]; plane3(slab, cap, i, P3_SXD)[sa] = aS[2];
+      plane3(slab, cap, i, P3_SYY)[sa] = aS[4]; plane3(slab, cap, i, P3_SYD)[sa] = aS[5]; plane3(slab, cap, i, P3_SDD)[sa] = aS[8];
+    }
+    if (commit != 0ull) anyMerge = true;
+  } else {
+    for (int r0 = 0; r0 < N; r0 += 64)
+      for (unsigned long long rows = __ballot((rowFlag >> (r0 >> 6)) & 1u); rows; rows &= rows - 1ull) serial_row(r0 + __builtin_ctzll(rows));
   }
-  // in-place updates of merged rows (global memory, lane 0) -> visible to the wave's other lanes
+  // in-place updates of merged rows (global memory) -> visible to the wave's other lanes
+  DBG_T(32, 3);
+  RFS_CUT(121);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   wave_sync();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   if (!FUSE_PRUNE) {
     if (!anyMerge) return;
     for (int m = lane, sidx = 0; m < N; m += 64, sidx++)
-      if ((hole >> sidx) & 1u) plane3(slab, cap, i, P3_W)[m] = -1.0;
+      if ((hole >> sidx) & 1u) plane3(slab, cap, i, P3_W)[at(m)] = -1.0;
     return;
   }
   for (int m = lane, sidx = 0; m < N; m += 64, sidx++)
@@ -768,7 +1016,7 @@ __global__ __launch_bounds__(WPB * 64) void vp_merge_kernel(Buffers B, Params P,
     const int m = sIdx[q];
     const double wm = sW[m];
     Ent3 e;
-    load_ent3(slab, cap, i, m, e, false);   // the survivor's record first (independent loads in flight while the rank is counted)
+    load_ent3(slab, cap, i, at(m), e, false);   // the survivor's record first (independent loads in flight while the rank is counted)
     int rank = 0;
     for (int q2 = 0; q2 < nSurv; q2++) {
       const int j2 = sIdx[q2];
@@ -782,4 +1030,60 @@ __global__ __launch_bounds__(WPB * 64) void vp_merge_kernel(Buffers B, Params P,
     plane3(dl, cap, i, P3_SYY)[rank] = e.yy; plane3(dl, cap, i, P3_SYD)[rank] = e.yd; plane3(dl, cap, i, P3_SDD)[rank] = e.dd;
   }
   if (lane == 0) B.count[i] = nSurv;
+  DBG_T(32, 4);
 }
+template <int WPB, bool FUSE_PRUNE>
+__global__ __launch_bounds__(WPB * 64) void vp_merge_kernel(Buffers B, Params P, int cur, int dst) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
+  if (i >= B.N) return;
+  vp_merge_particle<FUSE_PRUNE>(B, P, cur, dst, i, lane, smem_raw + (size_t)wave * vp_merge_lds_bytes_per_wave(B.cap), nullptr);
+}
+
+// ---- the whole Victoria Park step in ONE launch (RBPHDFilter::update body, include/RBPHDFilter.hpp:469-520) -------------------
+// One wavefront owns a particle and takes it through updateMap -> importanceWeighting -> merge + prune; WPB particles share a
+// workgroup (and the LDS copies of the measurement set and the laser scan).  As three kernels every phase re-read the 11-plane
+// slab from HBM and the weighting wrote a sorted copy of it that the merge read back (r02: 138 MB of traffic per update at
+// 5000 particles x 40-50 Gaussians against 57.8 MB algorithmic); here the map update's output is still in cache when the
+// weighting reads it, the sorted order is a u16 permutation in LDS (as in the 2-D fused step) and the mixture is written once
+// more only by the prune's compaction into the other slab.  The phases are the device functions of the stand-alone kernels:
+// same arithmetic in the same order, bit-identical results.  useWeighting == 0: SC-PHD (the weight comes out of the map update,
+// the mixture is not sorted).
+__host__ __device__ inline size_t vp_step_lds_bytes_per_wave(int cap, int evalCap, int nZ) {
+  size_t a = vp_update_lds_bytes_per_wave(cap);
+  const size_t b = vp_weight_lds_bytes_per_wave(cap, evalCap, nZ), c = vp_merge_lds_bytes_per_wave(cap);
+  if (b > a) a = b;
+  if (c > a) a = c;
+  return ((a + 15) & ~(size_t)15) + (((size_t)cap * 2 + 15) & ~(size_t)15);   // + the permutation
+}
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64) void vp_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, int useWeighting, MurtyQueue Q, ZArg zarg) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  double *sZ = reinterpret_cast<double *>(smem_raw);
+  double *sScan = sZ + 3 * nZ;
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  for (int t = threadIdx.x; t < 3 * nZ; t += WPB * 64) sZ[t] = zarg.v[t];     // the measurement set rides in the kernel arguments
+  for (int t = threadIdx.x; t < B.nScan; t += WPB * 64) sScan[t] = B.scan[t];
+  __syncthreads();
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
+  if (i >= B.N) return;
+  const size_t per = vp_step_lds_bytes_per_wave(B.cap, evalCap, nZ);
+  unsigned char *wmem = smem_raw + vp_shared_lds_bytes(nZ, B.nScan) + (size_t)wave * per;
+  unsigned short *sPerm = reinterpret_cast<unsigned short *>(wmem + per - (((size_t)B.cap * 2 + 15) & ~(size_t)15));
+  vp_update_map_particle(B, P, cur, nZ, i, lane, sZ, sScan, wmem);
+  // (one wave: the slab rows it wrote are its own; order the global writes before the reads of the next phase)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  wave_sync();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const unsigned short *perm = nullptr;
+  if (useWeighting) {
+    vp_weight_particle(B, P, cur, cur ^ 1, nZ, evalCap, Q, i, lane, sZ, sScan, wmem, sPerm);
+    wave_sync();
+    perm = sPerm;
+  }
+  vp_merge_particle<true>(B, P, cur, cur ^ 1, i, lane, wmem, perm);
+}
+

@@ -1077,6 +1077,44 @@ def test_vp_fused_update_and_birth_candidates_multi_step(pkg, ob, sc):
     assert promoted > 0, "scenario never produced a birth candidate"
 
 
+@pytest.mark.parametrize("kw", [dict(n_particles=40, n_landmarks=45, n_z=12, seed=91), dict(n_particles=33, n_landmarks=130, n_z=18, seed=92),
+                                dict(n_particles=12, n_landmarks=20, n_z=7, seed=93, use_cluster=1)])
+def test_vp_fused_step_is_bit_identical_to_the_three_kernel_path(pkg, sc, kw):
+    """rfsgpu_update with the Victoria Park model is ONE launch (vp_step_fused_kernel: the sorted order a permutation in LDS, no
+    sorted copy of the 11-plane slab) unless phase timing is asked for: maps, weights, unused lists and FOV counts must have the
+    same bits as the three stand-alone kernels give, over several predict / update steps, incl. the SC-PHD weighting."""
+    use_cluster = kw.pop("use_cluster", 0)
+    scen = sc.make_vp_scenario(**kw)
+    fs = []
+    for timing in (False, True):
+        f = pkg.RBPHDFilter(scen["n"], gm_capacity=256, model=pkg.capi.MODEL_VICTORIAPARK_3D)
+        sc.load_scenario(f, scen)
+        if use_cluster:
+            cfg = f.get_filter_config()
+            cfg.useClusterProcess = 1
+            f.set_filter_config(cfg)
+        f.set_phase_timing(timing)
+        fs.append(f)
+    rng = np.random.default_rng(8)
+    for step in range(4):
+        Z = scen["Z"] + rng.normal(0, 1, scen["Z"].shape) * np.array([0.05, 0.002, 0.01])
+        for f in fs:
+            f.predict_map(True)
+            f.update(Z)
+        a, b = fs
+        assert np.array_equal(a.get_weights(), b.get_weights()), step
+        assert np.array_equal(a.gm_sizes(), b.gm_sizes())
+        assert a.gm_sizes().max() > 5
+        for i in range(scen["n"]):
+            for x, y in zip(a.export_gm(i), b.export_gm(i)):
+                assert np.array_equal(x, y), (step, i)
+            assert list(a.get_unused(i)) == list(b.get_unused(i)) and a.landmarks_in_fov(i) == b.landmarks_in_fov(i)
+        for f in fs:
+            f.normalize_weights(f.weight_sums()[0])
+    t = fs[0].getTimingInfo()
+    assert t.mapUpdate_wall > 0 and t.particleWeighting_wall == 0      # the fused path books the whole step under mapUpdate
+
+
 def test_2d_birth_candidate_list_mode(pkg, ob, sc):
     """The candidate-list branch of addBirthGaussians with the 2-D model (birthGaussianMeasurementCountThreshold > 1)."""
     scen = sc.make_scenario(12, 6, 8, seed=45)
