@@ -299,6 +299,9 @@ int rfsgpu_propagate_ackerman_async(rfsgpu_filter *f, const double *u, const dou
  * [0]=phd_update_map [1]=phd_weight_multifeature [2]=gm_merge(+prune); *n_steps = steps averaged.  Steps that ran as one
  * fused kernel report its duration in [0] and 0 in [1], [2] (their TimingInfo share is booked under mapUpdate). */
 int rfsgpu_kernel_time_stats(rfsgpu_filter *f, double *avg_ns3, int *n_steps);
+/* Average duration (ns) of the step's post kernel (Murty-200 partitions when any were queued, queue reset, weight sums /
+ * division) over the fused steps the last rfsgpu_kernel_time_stats call covered. */
+double rfsgpu_post_kernel_avg_ns(const rfsgpu_filter *f);
 /* The same four phases one at a time (used by the parity tests and by profiling):          */
 int rfsgpu_update_map(rfsgpu_filter *f, const double *z, int n_z);      /* updateMap       :543-725 */
 int rfsgpu_importance_weighting(rfsgpu_filter *f);                       /* importanceWeighting :728-997 */

@@ -107,6 +107,8 @@ struct rfsgpu_filter {
   hipEvent_t evAfterWeightKernel = nullptr;   // where launch_weighting drops its mid-phase event (async steps only)
   int ringCount = 0;        // async steps recorded since the last harvest
   double statNs[3] = {0, 0, 0};
+  double lastPostNs = 0;
+  double statPostNs = 0;    // fused steps: the post kernel's share (rfsgpu_post_kernel_time_stats)
   int statSteps = 0;
   std::string err;
   int maxLds = 0;
@@ -893,6 +895,10 @@ static void harvest_async(rfsgpu_filter *f) {
     if (f->ringFused[k]) {  // one kernel for the whole step: booked under mapUpdate, reported as kernel 0
       accumulate(e[0], e[3], f->timing.mapUpdate_wall, &ns[0]);
       for (int q = 0; q < 3; q++) { f->statNs[q] += (double)ns[q]; f->lastKernelNs[q] = ns[q]; }
+      {   // the post kernel (Murty jobs if any, queue reset, weight sums / division): event 1 is free on this path
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e[3], e[1]) == hipSuccess) f->statPostNs += (double)ms * 1.0e6;
+      }
       f->statSteps++;
       continue;
     }
@@ -975,6 +981,7 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e[3], f->stream));
     if (murty_launch(f->Q, f->MS, f->B, f->stream, with_sums ? f->dSums : nullptr, normalize, &za, 2 * n_z, f->hJobCount) != 0) return fail(f, RFSGPU_ERR_HIP, "post kernel launch failed");
+    HIPCHK(hipEventRecord(e[1], f->stream));
     f->cur ^= 1;  // the map update works in place, the weighting phase leaves only a permutation in LDS, merge + prune write the other slab
     f->ringFused[f->ringCount] = true;
     f->ringCount++;
@@ -1007,6 +1014,7 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e[3], f->stream));
     if (murty_launch(f->Q, f->MS, f->B, f->stream, with_sums ? f->dSums : nullptr, normalize, &za, 3 * n_z, f->hJobCount) != 0) return fail(f, RFSGPU_ERR_HIP, "post kernel launch failed");
+    HIPCHK(hipEventRecord(e[1], f->stream));
     f->cur ^= 1;
     f->ringFused[f->ringCount] = true;
     f->ringCount++;
@@ -1059,10 +1067,15 @@ int rfsgpu_kernel_time_stats(rfsgpu_filter *f, double *avg_ns3, int *n_steps) {
   harvest_async(f);
   for (int q = 0; q < 3; q++) avg_ns3[q] = f->statSteps ? f->statNs[q] / f->statSteps : 0.0;
   *n_steps = f->statSteps;
+  f->lastPostNs = f->statSteps ? f->statPostNs / f->statSteps : 0.0;
   f->statSteps = 0;
   f->statNs[0] = f->statNs[1] = f->statNs[2] = 0.0;
+  f->statPostNs = 0.0;
   return RFSGPU_OK;
 }
+// Average duration (ns) of the step's POST kernel (murty_jobs_kernel: the Murty-200 partitions when the queue is not empty, queue
+// reset, weight sums / division) over the fused steps covered by the last rfsgpu_kernel_time_stats call.
+double rfsgpu_post_kernel_avg_ns(const rfsgpu_filter *f) { return f ? f->lastPostNs : 0.0; }
 
 // The birth + static-step launches of one predict.  LV selects the particles whose birth step runs (birth.h).
 static void launch_predict_kernels(rfsgpu_filter *f, int add_birth, const BirthLevel &LV) {

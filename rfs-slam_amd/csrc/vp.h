@@ -287,8 +287,11 @@ __host__ __device__ inline size_t vp_update_lds_bytes_per_wave(int cap) { return
 // RBPHDFilter::updateMap for the Victoria Park model (same phases as phd_update_map_kernel).
 // One wavefront takes particle i through the map update.  sZ / sScan: the measurement set and the laser scan, staged in LDS by
 // the caller (shared by the waves of a workgroup); wb: vp_update_lds_bytes_per_wave(cap) bytes of LDS of this wave.
-__device__ void vp_update_map_particle(const Buffers &B, const Params &P, int cur, int nZ, int i, int lane, const double *sZ, const double *sScan,
-                                       unsigned char *wb) {
+// pdCache (the fused step; may be null): receives, per landmark, the Pd-table index of its probabilityOfDetection (255: exactly 0
+// by an early return) -- the weighting phase asks for the same number again when it picks evaluation points among landmarks
+// the update has not moved.  Returns the number of landmarks before the update.
+__device__ int vp_update_map_particle(const Buffers &B, const Params &P, int cur, int nZ, int i, int lane, const double *sZ, const double *sScan,
+                                      unsigned char *wb, unsigned char *pdCache = nullptr) {
   const int cap = B.cap;
   double *sV = reinterpret_cast<double *>(wb);
   double *sPd = sV + cap;
@@ -300,7 +303,7 @@ __device__ void vp_update_map_particle(const Buffers &B, const Params &P, int cu
   const unsigned long long zmask = (nZ >= 64) ? ~0ull : ((1ull << nZ) - 1ull);
   if (nM == 0) {
     if (lane == 0) { B.unusedMask[i] = zmask; B.nInFov[i] = 0; }
-    return;
+    return 0;
   }
   double *slab = B.slab[cur];
   const double px = B.pose[3 * i], py = B.pose[3 * i + 1], pth = B.pose[3 * i + 2];
@@ -320,6 +323,11 @@ __device__ void vp_update_map_particle(const Buffers &B, const Params &P, int cu
     bool close = false;
     double pd = vp_pd_wave(P, sScan, B.nScan, px, py, pth, e, act, close, reinterpret_cast<unsigned char *>(sSeg + cap));
     if (!act) { pd = 0.0; close = false; }
+    if (pdCache && act) {          // (the value is a table entry or the 0.0 of an early return: kept as an index, one byte)
+      int idx = 255;
+      for (int k = 0; k < P.nPd; k++) idx = (P.PdTable[k] == pd) ? k : idx;
+      pdCache[m] = (unsigned char)idx;
+    }
     if (p == 0) DBG_T(0, 1);
     RFS_CUT(101);
     if (close) pd = 1;  // RBPHDFilter.hpp:604-606
@@ -444,6 +452,7 @@ __device__ void vp_update_map_particle(const Buffers &B, const Params &P, int cu
     for (int z = 0; z < nZ; z++) prod *= readlane_f64(cs, z);
     if (lane == 0) B.weight[i] = exp(s) * prod * B.weight[i];
   }
+  return nM;
 }
 template <int WPB>
 __global__ __launch_bounds__(WPB * 64) void vp_update_map_kernel(Buffers B, Params P, int cur, int nZ) {
@@ -498,7 +507,8 @@ __device__ __forceinline__ void carve_vp_weight_lds(unsigned char *base, int cap
 // `dst` (the stand-alone kernel; the merge kernel then works on that copy).  permOut != nullptr (the fused step): the sorted
 // order is handed on as a permutation in LDS (rank -> storage index, u16[cap]) and nothing is written to `dst`.
 __device__ void vp_weight_particle(const Buffers &B, const Params &P, int src, int dst, int nZ, int evalCap, const MurtyQueue &Q, int i, int lane,
-                                   const double *sZ, const double *sScan, unsigned char *wbase, unsigned short *permOut) {
+                                   const double *sZ, const double *sScan, unsigned char *wbase, unsigned short *permOut,
+                                   const unsigned char *pdCache = nullptr, int nCached = 0) {
   const int cap = B.cap;
   WeightLDS s;
   double *evD;                  // [evalCap][16]: d, z_exp(3), Si(9), factor
@@ -553,25 +563,37 @@ __device__ void vp_weight_particle(const Buffers &B, const Params &P, int src, i
     // 16 ranks at a time (r02: 64): the selection stops at the first weight below the threshold or with `limit` points, i.e.
     // within the first few ranks, and every rank looked at costs its probabilityOfDetection (Pd of the landmark and of its
     // shifted copies, vp_pd_wave); the pooled evaluation of a 16-rank group is one round of the wave.  Same points, same order.
-    for (int c0 = 0; c0 < N && !done; c0 += 16) {
-      const int r = (lane < 16) ? c0 + lane : N;
+    // With the map update's Pd cache (the fused step) only Gaussians the update has created need an evaluation -- the top ranks,
+    // a dozen: one group of 64 ranks, one round.
+    const int G = pdCache ? 64 : 16;
+    for (int c0 = 0; c0 < N && !done; c0 += G) {
+      const int r = (lane < G) ? c0 + lane : N;
       bool below = true, cand = false;
       Ent3 e;
       double pd = 0;
       e.w = 0; e.x = 10; e.y = 10; e.d = 1; e.xx = 1; e.xy = 0; e.xd = 0; e.yy = 1; e.yd = 0; e.dd = 1;
+      bool cached = false;
       if (r < N) {
         const int m = s.perm[r];
         below = s.keys[m] < P.evalMinW;
         load_ent3(sl, cap, i, m, e, false);
+        if (pdCache && m < nCached) {       // a landmark the update left where it was: same pose, same mean, same covariance, same scan
+          const int idx = pdCache[m];
+          pd = (idx == 255) ? 0.0 : P.PdTable[idx];
+          cached = true;
+        }
       }
       {
         bool close;
         const bool want = (r < N) && !below;
-        pd = vp_pd_wave(P, sScan, B.nScan, px, py, pth, e, want, close, pdScratch);
+        if (__ballot(want && !cached) != 0ull) {
+          const double v = vp_pd_wave(P, sScan, B.nScan, px, py, pth, e, want && !cached, close, pdScratch);
+          if (!cached) pd = v;
+        }
         if (!want) pd = 0;
         cand = pd > 0;
       }
-      const unsigned long long belowMask = __ballot(below && (lane < 16) && (c0 + lane < N));   // (ranks that exist)
+      const unsigned long long belowMask = __ballot(below && (lane < G) && (c0 + lane < N));   // (ranks that exist)
       const unsigned long long valid = belowMask ? ((1ull << __builtin_ctzll(belowMask)) - 1ull) : ~0ull;
       if (belowMask) done = true;
       const unsigned long long candMask = __ballot(cand) & valid;
@@ -1056,7 +1078,7 @@ __host__ __device__ inline size_t vp_step_lds_bytes_per_wave(int cap, int evalCa
   const size_t b = vp_weight_lds_bytes_per_wave(cap, evalCap, nZ), c = vp_merge_lds_bytes_per_wave(cap);
   if (b > a) a = b;
   if (c > a) a = c;
-  return ((a + 15) & ~(size_t)15) + (((size_t)cap * 2 + 15) & ~(size_t)15);   // + the permutation
+  return ((a + 15) & ~(size_t)15) + (((size_t)cap * 2 + 15) & ~(size_t)15) + (((size_t)cap + 15) & ~(size_t)15);   // + the permutation + the Pd cache
 }
 template <int WPB>
 __global__ __launch_bounds__(WPB * 64) void vp_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, int useWeighting, MurtyQueue Q, ZArg zarg) {
@@ -1072,15 +1094,16 @@ __global__ __launch_bounds__(WPB * 64) void vp_step_fused_kernel(Buffers B, Para
   if (i >= B.N) return;
   const size_t per = vp_step_lds_bytes_per_wave(B.cap, evalCap, nZ);
   unsigned char *wmem = smem_raw + vp_shared_lds_bytes(nZ, B.nScan) + (size_t)wave * per;
-  unsigned short *sPerm = reinterpret_cast<unsigned short *>(wmem + per - (((size_t)B.cap * 2 + 15) & ~(size_t)15));
-  vp_update_map_particle(B, P, cur, nZ, i, lane, sZ, sScan, wmem);
+  unsigned char *sPdIdx = wmem + per - (((size_t)B.cap + 15) & ~(size_t)15);
+  unsigned short *sPerm = reinterpret_cast<unsigned short *>(sPdIdx - (((size_t)B.cap * 2 + 15) & ~(size_t)15));
+  const int nBefore = vp_update_map_particle(B, P, cur, nZ, i, lane, sZ, sScan, wmem, sPdIdx);
   // (one wave: the slab rows it wrote are its own; order the global writes before the reads of the next phase)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   wave_sync();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   const unsigned short *perm = nullptr;
   if (useWeighting) {
-    vp_weight_particle(B, P, cur, cur ^ 1, nZ, evalCap, Q, i, lane, sZ, sScan, wmem, sPerm);
+    vp_weight_particle(B, P, cur, cur ^ 1, nZ, evalCap, Q, i, lane, sZ, sScan, wmem, sPerm, sPdIdx, nBefore);
     wave_sync();
     perm = sPerm;
   }

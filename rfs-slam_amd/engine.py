@@ -82,6 +82,12 @@ class RBPHDFilter(capi.CFilter):
         self._call("kernel_time_stats", avg, C.byref(n))
         return list(avg), n.value
 
+    def post_kernel_avg_ns(self):
+        """Average duration of the step's post kernel over the fused steps the last kernel_time_stats() call covered."""
+        fn = self._fn("post_kernel_avg_ns")
+        fn.restype = C.c_double
+        return float(fn(self._h))
+
     def weight_sums_async(self):
         self._call("weight_sums_async")
 
