@@ -261,7 +261,8 @@ class ShardedRBPHDFilter:
                 self.f.import_slab_rows(slots, recv_buf.data_ptr())
             if self.on_gpu:
                 self.f.synchronize()                                     # the buffers may be released after this
-        self.last_migration = dict(rows_sent=int(n_send), rows_received=int(n_recv), bytes_sent=int(n_send * R))
+        self.last_migration = dict(rows_sent=int(n_send), rows_received=int(n_recv), bytes_sent=int(n_send * R),
+                                   rows_to_rank=[int(len(x)) for x in send_g], rows_from_rank=[int(len(x)) for x in recv_g])
         # ids as ParticleFilter::resample leaves them (:446-479; a copy keeps its source's id, Particle::copy), over GLOBAL slots
         child = plan != np.arange(self.n_total)
         src_id = self.pid[plan]
@@ -301,10 +302,17 @@ def bench_resample_migration(pkg, f, rank, world, dev, stream=None, sums=None, r
     t = torch.tensor([float(np.median(times)), float(sh.last_migration["rows_sent"]), float(sh.last_migration["bytes_sent"])],
                      dtype=torch.float64, device=dev)
     tmax = t.clone()
+    # who sent how many rows to whom (row r = rank r's per-destination counts): the all-to-all's split lists, zeros included
+    pair = torch.tensor(sh.last_migration.get("rows_to_rank", [0] * world), dtype=torch.float64, device=dev)
+    pairs = pair.clone().unsqueeze(0)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        allp = torch.zeros(world * world, dtype=torch.float64, device=dev)
+        allp[rank * world:(rank + 1) * world] = pair
+        dist.all_reduce(allp, op=dist.ReduceOp.SUM)
+        pairs = allp.reshape(world, world)
     return dict(ms=round(float(tmax[0]) * 1e3, 4), rows_migrated_total=int(t[1].item()), bytes_migrated_total=int(t[2].item()),
-                row_bytes=int(f.slab_row_bytes()),
+                row_bytes=int(f.slab_row_bytes()), rows_from_rank_to_rank=[[int(v) for v in row] for row in pairs.cpu().tolist()],
                 note="one forced global systematic resampling: all-reduce + all-gather of the weights, plan on the host, local gather, "
                      "cross-shard children as packed rows device->device over RCCL send/recv; weights skewed by rank so that rows move")

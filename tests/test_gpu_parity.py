@@ -462,19 +462,20 @@ def test_cpp_host_driver_sharded_over_device_entries(pkg):
     exe = pkg.build_mod.build_host()
     cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "rbphdslam2dSim_c1.xml")
     res = []
-    for extra in ([], ["--devices", "0,0,0"]):
-        out = subprocess.run([exe, "-c", cfg, "-t", "2", "-s", "2", "-n", "150"] + extra, capture_output=True, text=True, timeout=600)
+    for extra in ([], ["--devices", "0,0,0"], ["--devices", "0,0,0,0,0,0,0,0"]):       # (eight entries: configs[2]'s shard count)
+        out = subprocess.run([exe, "-c", cfg, "-t", "2", "-s", "2", "-n", "160"] + extra, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         m = re.search(r"RESULT matched=(\d+) landmarks=(\d+) mean_err=([\d.]+) pose_err=([\d.]+)", out.stdout)
         assert m, out.stdout[-2000:]
         res.append((int(m.group(1)), float(m.group(3)), float(m.group(4))))
         if extra:
-            assert "sharded over 3 device entries" in out.stdout
-    (m1, e1, p1), (m3, e3, p3) = res
+            assert "sharded over %d device entries" % (extra[1].count(",") + 1) in out.stdout
+    (m1, e1, p1), (m3, e3, p3), (m8, e8, p8) = res
     assert m3 >= 40 and e3 < 0.3 and p3 < 0.6
-    # same seeds, same arithmetic per particle; only the weight sums are added per shard (last-bit differences), so the two runs
+    # same seeds, same arithmetic per particle; only the weight sums are added per shard (last-bit differences), so the runs
     # normally coincide to the printed precision
     assert abs(m1 - m3) <= 3 and abs(e1 - e3) < 0.1
+    assert abs(m1 - m8) <= 3 and abs(e1 - e8) < 0.1
 
 
 def ospa(est, truth, cutoff, order):

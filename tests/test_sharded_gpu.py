@@ -127,3 +127,98 @@ def test_group_of_shards_in_one_process_matches_single_filter(pkg, n_shards):
     else:
         pytest.fail("the group's resampling plan differs from the single filter's")
     grp.close(); ref.close()
+
+
+def test_configs2_whole_as_eight_shards_on_one_device(pkg):
+    """BASELINE configs[2] as a whole -- 20 000 particles x 500 GM landmarks x 30 measurements, eight shards of 2500 -- on the one GPU of
+    this box (rfsgpu_group with device_ids = [0] * 8; every shard its own handle, stream, slabs and migration buffers, rows moved
+    device to device): update, global normalisation, a forced GLOBAL resampling whose plan crosses every shard boundary, then a
+    predict (births: the reference's birth-state inheritance over global slots) and a second update, against ONE handle holding
+    all 20 000 particles.  Weights to 1e-13 (the group adds the eight partial sums in shard order), everything else bit for bit."""
+    sc = pkg.scenarios
+    n_total, n_sh = 20000, 8
+    scen = sc.make_scenario(n_total, 500, 30, seed=77, rmax=5.0, params=dict(min_updates=1))
+    ref = pkg.RBPHDFilter(n_total, device_id=0, gm_capacity=640)
+    grp = pkg.FilterGroup(n_total, [0] * n_sh, gm_capacity=640)
+    assert [s.n for s in grp.shards] == [2500] * n_sh
+    for f in (ref, grp):
+        sc.load_scenario(f, scen)
+    sample = np.unique(np.concatenate([np.arange(0, n_total, 997), np.arange(2495, n_total, 2500), np.arange(2500, n_total, 2500)]))
+
+    def same_maps(idx):
+        for i in idx:
+            for a, b in zip(grp.export_gm(int(i)), ref.export_gm(int(i))):
+                assert np.array_equal(a, b), i
+            assert np.array_equal(grp.get_unused(int(i)), ref.get_unused(int(i)))
+
+    ref.update(scen["Z"])
+    sums = grp.update(scen["Z"])
+    np.testing.assert_allclose(sums, ref.weight_sums(), rtol=1e-12)
+    np.testing.assert_array_equal(grp.get_weights(), ref.get_weights())
+    assert np.array_equal(grp.gm_sizes(), ref.gm_sizes()) and ref.gm_sizes().min() > 50    # (500 before the update; ~85 survive the prune)
+    same_maps(sample)
+    # weights that make the plan interesting (the raw weights of a 500-landmark update span hundreds of orders of magnitude: one
+    # particle would take everything): heavier towards the high shards, so that children travel down across all boundaries
+    w = np.random.default_rng(5).uniform(0.05, 1.0, n_total) ** 2 * (1.0 + 3.0 * np.arange(n_total) / n_total)
+    for f in (ref, grp):
+        f.set_weights(w)
+    s_ref = ref.weight_sums()
+    ref.normalize_weights(s_ref[0])
+    plan_ref = pkg.engine.systematic_resample_plan(ref.get_weights(), 0.4321)
+    x = ref.get_poses()
+    ref.resample_apply(plan_ref)
+    fired, plan = grp.resample(n_total + 1.0, 0.4321)
+    assert fired
+    if not np.array_equal(plan, plan_ref):      # (normalised weights may differ in the last bit: sums added per shard)
+        diff = np.nonzero(plan != plan_ref)[0]
+        pytest.fail("the group's plan differs from the single filter's at %d slots" % diff.size)
+    src_shard, dst_shard = plan // 2500, np.arange(n_total) // 2500
+    crossing = np.nonzero(src_shard != dst_shard)[0]
+    pairs = {(int(a), int(b)) for a, b in zip(src_shard[crossing], dst_shard[crossing])}
+    assert crossing.size > 500 and len(pairs) >= 7          # rows crossed many shard boundaries
+    rows, nbytes = grp.migration_stats()
+    assert rows == crossing.size and nbytes == rows * grp.shards[0].slab_row_bytes()
+    np.testing.assert_array_equal(grp.get_poses(), x[plan_ref])
+    np.testing.assert_array_equal(grp.get_weights(), np.ones(n_total))
+    assert np.array_equal(grp.gm_sizes(), ref.gm_sizes())
+    same_maps(np.unique(np.concatenate([sample, crossing[:: max(1, crossing.size // 200)]])))
+    ids_g, par_g = grp.get_particle_ids()
+    ids_r, par_r = ref.get_particle_ids()
+    assert np.array_equal(ids_g, ids_r) and np.array_equal(par_g, par_r)
+    # second cycle: predict (births through the inheritance rule, parents on other shards) + update
+    ref.set_poses(x[plan_ref], scen["pose_cov"])
+    for f in (ref, grp):
+        f.predict_map(True)
+    assert np.array_equal(grp.gm_sizes(), ref.gm_sizes())
+    ref.update(scen["Z"])
+    grp.update(scen["Z"])
+    np.testing.assert_array_equal(grp.get_weights(), ref.get_weights())
+    assert np.array_equal(grp.gm_sizes(), ref.gm_sizes())
+    same_maps(np.unique(np.concatenate([sample, crossing[:: max(1, crossing.size // 200)]])))
+    grp.close(); ref.close()
+
+
+def test_bench_eight_ranks_share_the_gpu_end_to_end():
+    """bench.py --gpus 8 (configs[2]: eight ranks x 2500 particles x 500 landmarks, the driver's launch line) with the eight ranks sharing
+    this box's GPU over gloo (RFS_BENCH_SHARE_GPU=1): the timed region, the weak-scaling reference, and the forced global resampling
+    with migration -- every rank's per-peer row counts (the all-to-all's split lists) come back in the JSON: some pairs exchange
+    nothing, the totals balance."""
+    import json
+    import subprocess
+    env = dict(os.environ, RFS_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["particles_total"] == 20000 and d["config"]["workload_key"] == "c3"
+    m = d["config"]["resample_migration"]
+    assert "error" not in m, m
+    P = np.array(m["rows_from_rank_to_rank"])
+    assert P.shape == (8, 8) and np.all(np.diag(P) == 0)
+    assert P.sum() == m["rows_migrated_total"] > 1000
+    off = P[~np.eye(8, dtype=bool)]
+    assert np.any(off == 0) and np.any(off > 0)           # zero-length peers inside the same exchange
+    assert m["bytes_migrated_total"] == m["rows_migrated_total"] * m["row_bytes"]
