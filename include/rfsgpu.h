@@ -20,6 +20,23 @@
  *     (both 2 for RFSGPU_MODEL_RNGBRG_2D, both 3 for RFSGPU_MODEL_VICTORIAPARK_3D).
  *   - "slot" = particle index 0..n_particles-1.
  *   - the engine fails loudly: there is NO CPU fallback anywhere behind this ABI.
+ *
+ * STABLE CORE -- the 23 entry points a reference-side binding needs; integration/RBPHDFilter_rfsgpu.hpp (the class template that
+ * stands where rfs::RBPHDFilter stands, compiled under the unmodified reference drivers) uses 19 of them and nothing else
+ * (tests/test_abi.py checks the list against the linked drivers):
+ *   RFSGPU_CORE: rfsgpu_abi_version rfsgpu_create rfsgpu_destroy rfsgpu_last_error rfsgpu_default_filter_config
+ *   RFSGPU_CORE: rfsgpu_set_filter_config rfsgpu_set_model_rngbrg rfsgpu_set_model_victoriapark rfsgpu_set_laser_scan
+ *   RFSGPU_CORE: rfsgpu_set_kf_config rfsgpu_set_lmk_process_noise rfsgpu_set_poses rfsgpu_set_weights rfsgpu_get_weights
+ *   RFSGPU_CORE: rfsgpu_predict_map rfsgpu_update rfsgpu_resample_apply rfsgpu_set_birth_inheritance rfsgpu_gm_size
+ *   RFSGPU_CORE: rfsgpu_get_landmark rfsgpu_get_timing rfsgpu_set_phase_timing rfsgpu_synchronize
+ * Everything else is OPTIONAL and grouped below by who needs it:
+ *   [async]    stream-ordered forms for host loops that pipeline (rfsgpu_*_async, rfsgpu_step_async, rfsgpu_set_stream, ...);
+ *   [multi]    several GPUs: rfsgpu_group_* (one host thread), slab rows / device pointers (one process per GPU over RCCL);
+ *   [state]    state injection and probes for tests and tools (import / export of mixtures, candidate lists, ids, masks);
+ *   [bench]    snapshot / restore, kernel timing statistics, debug counters;
+ *   [fastslam] FastSLAM / MH-FastSLAM on the same handle, the optional device-side Ackerman propagation, rfsgpu_mat_perm.
+ * A maintainer wiring the reference to the library reads the CORE entries and INTEGRATION.md; nothing optional is required
+ * for correct results.
  */
 #ifndef RFSGPU_H
 #define RFSGPU_H
@@ -143,7 +160,7 @@ typedef struct rfsgpu_timing {
   long long particleResample_wall, particleResample_cpu;
 } rfsgpu_timing;
 
-/* ---- lifetime ------------------------------------------------------------------------------ */
+/* ---- [core] lifetime ------------------------------------------------------------------------------ */
 
 /* ABI version of the loaded library (== RFSGPU_ABI_VERSION). */
 int rfsgpu_abi_version(void);
@@ -165,7 +182,7 @@ void rfsgpu_destroy(rfsgpu_filter *f);
 /* Human-readable text for the last non-OK status on this handle (never NULL). */
 const char *rfsgpu_last_error(const rfsgpu_filter *f);
 
-/* ---- configuration (the three public config structs of the reference) ---------------------- */
+/* ---- [core] configuration (the three public config structs of the reference) ---------------------- */
 
 void rfsgpu_default_filter_config(rfsgpu_filter_config *cfg);            /* RBPHDFilter.hpp:370-382 */
 int rfsgpu_set_filter_config(rfsgpu_filter *f, const rfsgpu_filter_config *cfg);   /* filter.config.* */
@@ -194,7 +211,7 @@ int rfsgpu_vp_probe_pd(rfsgpu_filter *f, int slot, double *pd, int *close_to_lim
 /* getLmkProcessModel()->setNoise(Q) (include/ProcessModel.hpp:195-208); Q is d_m x d_m. */
 int rfsgpu_set_lmk_process_noise(rfsgpu_filter *f, const double *Q);
 
-/* ---- particle state crossing the boundary --------------------------------------------------- */
+/* ---- [core] particle state crossing the boundary --------------------------------------------------- */
 
 /* Poses after the host-side ParticleFilter::propagate / setParticlePose
  * (include/ParticleFilter.hpp:322-341, RBPHDFilter.hpp:1181-1186).  x: 3 doubles per particle
@@ -206,7 +223,7 @@ int rfsgpu_get_poses(rfsgpu_filter *f, double *x);
 int rfsgpu_set_weights(rfsgpu_filter *f, const double *w);
 int rfsgpu_get_weights(rfsgpu_filter *f, double *w);
 
-/* ---- map access (getGMSize / getLandmark, RBPHDFilter.hpp:1152-1178) + state injection ------ */
+/* ---- [core] map access (getGMSize / getLandmark, RBPHDFilter.hpp:1152-1178) + [state] injection ------ */
 
 int rfsgpu_gm_size(rfsgpu_filter *f, int slot);                        /* -1 on bad index */
 /* returns RFSGPU_OK, or RFSGPU_ERR_INVALID on a bad index (reference returns false). */
@@ -225,7 +242,7 @@ int rfsgpu_import_birth_candidates(rfsgpu_filter *f, int slot, int n, const doub
 /* All mixture sizes at once (n_particles ints). */
 int rfsgpu_gm_sizes(rfsgpu_filter *f, int *sizes);
 
-/* ---- the hot path --------------------------------------------------------------------------- */
+/* ---- [core] the hot path (+ its [async] forms) --------------------------------------------------------------------------- */
 
 /* Map part of RBPHDFilter::predict (:415-442): if add_birth, addBirthGaussians (:1000-1084) from
  * the previous update's measurements / unused lists at the CURRENT (pre-propagation) poses, then
@@ -313,7 +330,7 @@ int rfsgpu_get_unused(rfsgpu_filter *f, int slot, int *idx, int max_n, int *n_ou
 /* nLandmarksInFOV_[slot] (:601-613). */
 int rfsgpu_landmarks_in_fov(rfsgpu_filter *f, int slot, int *n_out);
 
-/* ---- weight normalisation / resampling (ParticleFilter.hpp:352-363, 399-492) ---------------- */
+/* ---- [core] resampling, [multi] weight normalisation (ParticleFilter.hpp:352-363, 399-492) ---------------- */
 
 /* Device reduction of this shard's {sum w, sum w^2}; out[2] on the host. */
 int rfsgpu_weight_sums(rfsgpu_filter *f, double *out);
@@ -372,7 +389,7 @@ int rfsgpu_set_unused_masks(rfsgpu_filter *f, const unsigned long long *masks);
  * beyond n_out are dropped after the copy. */
 int rfsgpu_resample_apply_n(rfsgpu_filter *f, const int *src_slot, int n_out);
 
-/* ---- cross-shard migration for GLOBAL resampling over several GPUs ---------------------------------------
+/* ---- [multi] cross-shard migration for GLOBAL resampling over several GPUs ---------------------------------------
  * The reference resamples over the whole particle set (ParticleFilter::resample, include/ParticleFilter.hpp:399-492) and a
  * child is a deep copy of its parent (Particle::copy, include/Particle.hpp:218-223, + the per-slot birth state of
  * include/RBPHDFilter.hpp:1005-1011).  When parent and child live on different GPUs the parent travels as one packed ROW
@@ -387,7 +404,7 @@ int rfsgpu_import_slab_rows(rfsgpu_filter *f, const int *slots, int n, const voi
 /* Device pointer of the N particle weights (for an all-gather that stays on the GPUs); valid for the handle's lifetime. */
 void *rfsgpu_weights_device_ptr(rfsgpu_filter *f);
 
-/* ---- one filter over several GPUs from ONE host thread (SURVEY 8(b) "device_ids[], n_dev"; 8(e)) ------------------------
+/* ---- [multi] one filter over several GPUs from ONE host thread (SURVEY 8(b) "device_ids[], n_dev"; 8(e)) ------------------------
  * The particle set of rfs::RBPHDFilter is cut into contiguous blocks, one shard (an rfsgpu_filter) per listed device.  What a
  * C++ host standing where rfs::RBPHDFilter stands needs to use more than one GPU:
  *   predict / update / normalise / resample over the whole set, configuration broadcast to all shards, map access by global
@@ -429,7 +446,7 @@ int rfsgpu_group_gm_size(rfsgpu_group *g, int particle);                     /* 
 int rfsgpu_group_get_landmark(rfsgpu_group *g, int particle, int m, double *mean, double *cov, double *w);
 int rfsgpu_group_synchronize(rfsgpu_group *g);
 
-/* ---- timing / misc ---------------------------------------------------------------------------- */
+/* ---- [core] timing, [bench] / misc ---------------------------------------------------------------------------- */
 
 int rfsgpu_get_timing(rfsgpu_filter *f, rfsgpu_timing *t);              /* getTimingInfo :1219-1232 */
 int rfsgpu_reset_timing(rfsgpu_filter *f);
@@ -458,7 +475,7 @@ int rfsgpu_last_kernel_ns(rfsgpu_filter *f, long long *ns4);
  * (host), permanents to out (host).  n <= 24.  Standalone (no filter handle needed). */
 int rfsgpu_mat_perm(const double *A, int n, int batch, double *out, int device_id);
 
-/* ---- FastSLAM 1.0 on the same handle (reference include/FastSLAM.hpp) --------------------------------
+/* ---- [fastslam] FastSLAM 1.0 on the same handle (reference include/FastSLAM.hpp) --------------------------------
  * The handle's mixtures double as FastSLAM's per-particle landmark maps: a Gaussian's weight is the landmark's
  * log-odds of existence (FastSLAM.hpp:598-617), the birth-candidate lists are the landmark candidates
  * (landmarkCandidates_, :84-88).  Both measurement models.  The map part of FastSLAM::predict (:376-383, staticStep on

@@ -73,3 +73,27 @@ def test_resample_plan_matches_oracle_restatement(pkg, ob):
             assert np.array_equal(plan, src)
             # every source keeps itself; kept slots are exactly the sampled ones
             assert np.all(src[src] == src)
+
+
+def core_symbols():
+    txt = open(os.path.join(ROOT, "include", "rfsgpu.h")).read()
+    return sorted({w for line in re.findall(r"RFSGPU_CORE:(.*)", txt) for w in line.split()})
+
+
+def test_stable_core_is_small_declared_and_sufficient_for_the_reference_side_binding(pkg):
+    """include/rfsgpu.h marks a stable core (98 exports are too many for a maintainer to face): every core name is a
+    declared export, the core stays small, and the reference-side binding uses nothing outside it -- checked on the binding's
+    source and, where they have been built (needs /root/reference), on the undefined symbols of the linked reference drivers."""
+    core = core_symbols()
+    assert 15 <= len(core) <= 25, core
+    assert set(core) <= set(declared_symbols())
+    src = open(os.path.join(ROOT, "integration", "RBPHDFilter_rfsgpu.hpp")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    used = set(re.findall(r"\b(rfsgpu_[a-z_0-9]+)\s*\(", src)) & set(declared_symbols())     # (the binding's helper classes also start with rfsgpu_)
+    assert used and used <= set(core), used - set(core)
+    import subprocess
+    for name in ("rbphdslam2dSim", "rbphdslam_VictoriaPark"):
+        exe = os.path.join(ROOT, "tests", "support", "_build", name)
+        if os.path.exists(exe):
+            und = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True).stdout
+            assert set(re.findall(r"\b(rfsgpu_\w+)", und)) <= set(core)
