@@ -223,7 +223,8 @@ def cpu_baseline(wname, n_full, particles_arg):
                 sample=f"update()+normalise on {best['sample_particles']} of {n_full} particles (the same sample in every setting; median of "
                        f"{best['repetitions']} repetitions), same landmark x measurement state, scaled by particle count; best ACCEPTED setting of "
                        "settings_tried (each a fresh process; cpus_used = process CPU seconds per wall second in the timed region; a setting is "
-                       "rejected when its speed-up over one thread exceeds 1.1 x cpus_used); timing_buckets_share = the oracle's TimingInfo "
+                       "rejected when its speed-up over one thread exceeds 1.1 x cpus_used -- a cgroup CPU quota is enforced per scheduling period, so a "
+                       "many-thread burst shorter than the period can outrun it inside the timed call without being sustainable); timing_buckets_share = the oracle's TimingInfo "
                        "buckets (RBPHDFilter::TimingInfo; predict and resample are not part of a step)")
 
 

@@ -920,13 +920,13 @@ __device__ void vp_merge_particle(const Buffers &B, const Params &P, int cur, in
     // within eta = 2^-22 max|coordinate| of the true one, so |e| <= sqrt(B) implies |e_f| <= sqrt(B) + 2 eta; the radii are
     // rounded up, the product carries 2^-18 for its own roundings; NaN / inf (positions, bounds) compare as "keep".
     const float etaAll = wave_max_f32((float)(posMax * (1.0 + 0x1p-20))) * (2.0f * 0x1p-22f * (1.0f + 0x1p-20f));
-    auto sweep = [&](const int from, const bool want) -> unsigned long long {   // entries j > from passing the prefilter
+    auto sweep = [&](const int from, const bool want, const int jStart) -> unsigned long long {   // entries j > from (>= jStart: uniform) passing the prefilter
       const float fax = (float)ax, fay = (float)ay, fad = (float)ad;
       const float ra = vp_radius_f32(ab);
       const float eta2 = fmaxf(etaAll, fmaxf(fmaxf(fabsf(fax), fabsf(fay)), fabsf(fad)) * (2.0f * 0x1p-22f * (1.0f + 0x1p-20f)));
       unsigned long long m = 0ull;
 #pragma unroll 4
-      for (int j = 1; j < N; j++) {
+      for (int j = jStart; j < N; j++) {
         const float e0 = fX[j] - fax, e1 = fY[j] - fay, e2 = fD[j] - fad;
         const float R = fmaxf(ra, fR[j]) + eta2;
         const bool c = !(fmaf(e0, e0, fmaf(e1, e1, e2 * e2)) > (R * R) * (1.0f + 0x1p-18f));
@@ -934,7 +934,7 @@ __device__ void vp_merge_particle(const Buffers &B, const Params &P, int cur, in
       }
       return want ? (m & ~holes0) : 0ull;
     };
-    unsigned long long cand = sweep(a, isRow);
+    unsigned long long cand = sweep(a, isRow, 1);
     // FIND, then MERGE TOGETHER: every row first walks its own marked entries (ascending) through the exact test until one
     // passes -- cheap, and rows differ in how many they reject; then all rows that found one merge at once and rebuild their
     // masks at once.  A merge is a dozen fp64 divisions and a sweep is a pass over the mixture: paying them once per ROUND
@@ -964,7 +964,11 @@ __device__ void vp_merge_particle(const Buffers &B, const Params &P, int cur, in
         merge3_step(t2, f, eb, sW[jm], ax, ay, ad, aw, aS, aI, ab);
         absorbed |= 1ull << jm;
       }
-      const unsigned long long fresh = sweep(jm, jm >= 0);     // (wave-wide; rows that found nothing are finished: cand == 0)
+      // (wave-wide; rows that found nothing are finished: cand == 0.  Only entries above the LOWEST entry absorbed in this round
+      //  can matter to anyone -- the mixture is in weight order and a fresh Gaussian's partner is the faded landmark it came
+      //  from, near the end of the order: the rebuild usually looks at a handful of entries, not at all of them.)
+      const int jLow = (int)wave_min_u32((jm >= 0) ? (unsigned)jm : 0xffffu) + 1;
+      const unsigned long long fresh = sweep(jm, jm >= 0, jLow);
       if (jm >= 0) cand = fresh;
     }
     // ordered validation

@@ -40,7 +40,7 @@ def pmc(name, ctr):
 
 md = [f"# {tag}: rocprofv3 summaries per workload (tools/profile_workloads.sh {tag}; MI355X, 1 GPU)\n"]
 for name, what in (("c2a", "bench.py --workload c2a (BASELINE configs[1])"), ("c3", "bench.py --workload c3 (configs[2]'s shard, 2500 x 500 x 30)"),
-                   ("c4", "tools/vp_bench.py (configs[3], Victoria Park, 5000 particles)"), ("c5", "tools/c5_bench.py (configs[4], Murty stress, 1000 particles)")):
+                   ("c4", "bench.py --workload c4 (configs[3], Victoria Park, 5000 particles)"), ("c5", "bench.py --workload c5 (configs[4], Murty stress, 1000 particles)")):
     st = find(f"{name}_trace/**/*kernel_stats.csv")
     if not st:
         md.append(f"## {name}: no trace found\n")
