@@ -1052,6 +1052,45 @@ def test_vp_phases_stepwise(pkg, ob, sc, kw):
     compare_maps(sc, dev, orc, scen["n"], ordered=True)
 
 
+@pytest.mark.parametrize("kind,M,cap", [("clusters", 60, 64), ("crowded", 48, 64), ("chain", 64, 64), ("coincident", 50, 128), ("clusters", 150, 192),
+                                        ("chain", 100, 128)])
+def test_vp_merge_stress_against_oracle(pkg, ob, sc, kind, M, cap):
+    """GaussianMixture::merge / prune for 3-D Gaussians on adversarial mixtures.  M <= 64: the lane-parallel scan of vp.h (every row
+    on its own lane, ordered validation) INCLUDING its collisions -- rows that go after the same entry (crowded spots, chains in
+    which a merge moves a row onto the next row's partner) are redone by the row-by-row scan; M > 64: the row-by-row scan alone.
+    Both the two-kernel form (merge, then prune) and the fused merge + prune inside an update."""
+    flat = _clustered_mixtures(sc, 10, M, kind, seed=1300 + M)
+    scen = sc.make_vp_scenario(10, M, 4, seed=1300 + M)
+    rng = np.random.default_rng(1400 + M)
+    scale = 15.0                                   # the 2-D test maps are metres wide; Victoria Park merges at ~1 m
+    scen["mean"] = np.concatenate([flat["mean"] * scale + np.array([0.0, 30.0]), rng.uniform(0.3, 0.5, (10, M, 1)) +
+                                   (rng.normal(0, 0.01, (10, M, 1)) if kind != "coincident" else 0.0)], axis=2)
+    cov = np.zeros((10, M, 3, 3))
+    cov[:, :, :2, :2] = flat["cov"] * scale * scale
+    cov[:, :, 2, 2] = rng.uniform(0.01, 0.04, (10, M)) ** 2
+    cov[:, :, 0, 2] = cov[:, :, 2, 0] = 0.1 * np.sqrt(cov[:, :, 0, 0] * cov[:, :, 2, 2]) * rng.uniform(-1, 1, (10, M))
+    scen["cov"] = cov
+    scen["w"] = flat["w"]
+    dev, orc = make_vp_pair(pkg, ob, sc, scen, cap=cap)
+    for f in (dev, orc):
+        f.merge()
+    compare_maps(sc, dev, orc, scen["n"], ordered=True)
+    assert dev.gm_sizes().max() < M
+    for f in (dev, orc):
+        f.prune()
+    compare_maps(sc, dev, orc, scen["n"], ordered=True)
+    for f in (dev, orc):
+        f.merge()
+        f.prune()
+    compare_maps(sc, dev, orc, scen["n"], ordered=True)
+    if M + 4 <= cap:                               # the same maps through the fused step (permutation, Pd cache, fused prune)
+        dev2, orc2 = make_vp_pair(pkg, ob, sc, scen, cap=cap)
+        for f in (dev2, orc2):
+            f.update(scen["Z"][:1] * 0 + np.array([[75.0, 0.1, 0.4]]))    # one measurement nobody gates: the maps only merge
+        compare_weights(dev2, orc2)
+        compare_maps(sc, dev2, orc2, scen["n"], ordered=True)
+
+
 def test_vp_fused_update_and_birth_candidates_multi_step(pkg, ob, sc):
     """Victoria Park cycle: predict (birth candidates with the 5/10/2 thresholds of the shipped cfg, scaled down so that
     promotions happen within the test) -> update, several steps; maps, weights and the candidate lists must agree."""
