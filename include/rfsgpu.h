@@ -391,9 +391,9 @@ int rfsgpu_resample_apply_n(rfsgpu_filter *f, const int *src_slot, int n_out);
 
 /* ---- [multi] cross-shard migration for GLOBAL resampling over several GPUs ---------------------------------------
  * The reference resamples over the whole particle set (ParticleFilter::resample, include/ParticleFilter.hpp:399-492) and a
- * child is a deep copy of its parent (Particle::copy, include/Particle.hpp:218-223, + the per-slot birth state of
- * include/RBPHDFilter.hpp:1005-1011).  When parent and child live on different GPUs the parent travels as one packed ROW
- * of rfsgpu_slab_row_bytes() bytes -- pose (+ covariance), mixture, unused-measurement list, FOV count, birth candidates --
+ * child is a deep copy of its parent (Particle::copy, include/Particle.hpp:218-223: pose + mixture).  When parent and child
+ * live on different GPUs the parent travels as one packed ROW of rfsgpu_slab_row_bytes() bytes -- pose (+ covariance) and
+ * mixture; with RFSGPU_INHERIT_EAGER (and on FastSLAM handles) also the unused-measurement list, FOV count and birth candidates --
  * between DEVICE buffers: export on the source handle, transport by the caller (RCCL send/recv between processes,
  * hipMemcpyPeerAsync inside one process: rfsgpu_group_*), import on the destination handle.  Both calls are stream-ordered
  * on the handle's stream and never synchronise the host; `slots` is a host array that is free again on return.
