@@ -1226,13 +1226,14 @@ def test_2d_birth_candidate_lists_longer_than_a_wavefront(pkg, ob, sc):
     assert longest > 130 and shrank, (longest, shrank)
 
 
-def test_victoria_park_dataset_extract_device_vs_oracle(pkg, ob, sc):
+@pytest.mark.parametrize("n", [32, 256])
+def test_victoria_park_dataset_extract_device_vs_oracle(pkg, ob, sc, n):
     """Config 4 in miniature: the first sensor messages of the Victoria Park dataset (tests/golden/victoria_park_extract.npz,
     extracted from the reference's data files) through the event-driven host loop -- predict with birth candidates, artificial
-    clutter, scan-based Pd, update, resampling -- on the device and on the oracle with the same host RNG stream."""
+    clutter, scan-based Pd, update, resampling (with the reference's birth-state inheritance: candidate lists, chains of
+    lower-slot parents) -- on the device and on the oracle with the same host RNG stream."""
     import os
     data = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "victoria_park_extract.npz"))
-    n = 32
     P = dict(sc.VP_PARAMS)
     runs = []
     for make in (lambda: pkg.RBPHDFilter(n, gm_capacity=192, model=pkg.capi.MODEL_VICTORIAPARK_3D),
@@ -1306,6 +1307,35 @@ def test_c1_full_run_device_and_oracle_agree_on_map_quality(pkg, ob, sc):
         assert md[0] == mo[0] and md[2] == mo[2]
         results.append((seed, md, run.n_resamples))
     assert max(r[1][0] for r in results) >= 40, results           # at least one of the two realisations maps the scene well
+
+
+def test_victoria_park_dataset_extract_at_full_size_fused_equals_three_kernels(pkg, sc):
+    """configs[3] at its 5000 particles on the REAL dataset extract (900 messages: ~90 scans with artificial clutter, resamplings,
+    birth candidates): the run with one fused launch per update and the run with the three stand-alone kernels (phase timing on)
+    through the same host RNG stream end with the same bits -- weights, every mixture size, and the maps of a sample of
+    particles -- and with a sane filter (finite weights, several resamplings, trees mapped)."""
+    import os
+    data = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "victoria_park_extract.npz"))
+    n = 5000
+    P = dict(sc.VP_PARAMS)
+    runs = []
+    for timing in (False, True):
+        f = pkg.RBPHDFilter(n, gm_capacity=192, model=pkg.capi.MODEL_VICTORIAPARK_3D)
+        sc.apply_vp_params(f, P, np.full(361, 70.0))
+        f.set_phase_timing(timing)
+        runs.append(pkg.vp_driver.VictoriaParkRun(f, data, P, seed=9).run(n_messages=900))
+    a, b = runs
+    assert a.n_lidar == b.n_lidar > 50 and a.n_resamples == b.n_resamples >= 2
+    wa, wb = a.f.get_weights(), b.f.get_weights()
+    assert np.all(np.isfinite(wa)) and np.array_equal(wa, wb)
+    sa = a.f.gm_sizes()
+    assert np.array_equal(sa, b.f.gm_sizes()) and sa.max() <= 192 and np.median(sa) >= 3
+    for i in range(0, n, 97):
+        for x, y in zip(a.f.export_gm(i), b.f.export_gm(i)):
+            assert np.array_equal(x, y), i
+    assert np.array_equal(a.f.get_particle_ids()[0], b.f.get_particle_ids()[0])
+    for r in runs:
+        r.f.close()
 
 
 def test_victoria_park_dataset_extract_fastslam(pkg, ob, sc):
