@@ -382,6 +382,12 @@ int rfsgpu_set_particle_ids(rfsgpu_filter *f, const int *id, const int *parent_i
 /* RBPHDFilter::resampleOccured_ as the engine tracks it (1 / 0). */
 int rfsgpu_resample_occured(const rfsgpu_filter *f);
 /* unused_measurements_ of all slots at once, one 64-bit mask per slot (bit z = measurement z of the last update is unused). */
+/* [multi] One level of the level-ordered birth step, for a host that carries out the reference's slot-ordered copy of the per-slot
+ * birth lists itself because parent slots live on other shards (ids are global there): the birth step runs for the slots whose
+ * level_of_slot[] == level; the static step of every Gaussian in the call with do_static != 0 (births of later calls get their
+ * + Q where they are created).  Between the calls the host moves lists with rfsgpu_get/set_unused_masks and
+ * rfsgpu_export/import_birth_candidates (rfs-slam_amd/sharded.py, rfsgpu_group_predict_map). */
+int rfsgpu_predict_map_level(rfsgpu_filter *f, int add_birth, const int *level_of_slot, int level, int do_static);
 int rfsgpu_get_unused_masks(rfsgpu_filter *f, unsigned long long *masks);
 int rfsgpu_set_unused_masks(rfsgpu_filter *f, const unsigned long long *masks);
 /* ParticleFilter::resample(n) with n < nParticles_ (:417-483; FastSLAM::resampleWithMapCopy): the first n_out slots
@@ -428,9 +434,9 @@ int rfsgpu_group_set_poses(rfsgpu_group *g, const double *x, const double *cov, 
 int rfsgpu_group_get_poses(rfsgpu_group *g, double *x);
 int rfsgpu_group_set_weights(rfsgpu_group *g, const double *w);
 int rfsgpu_group_get_weights(rfsgpu_group *g, double *w);
-/* RBPHDFilter::predict, map part (:415-442), incl. the reference's birth-state inheritance after a resampling over GLOBAL slots
- * for immediate-birth configurations (birthGaussianMeasurementCountThreshold == 1); configurations that keep candidate lists
- * are refused after a resampling unless the group runs in RFSGPU_INHERIT_EAGER (rfsgpu_group_set_birth_inheritance). */
+/* RBPHDFilter::predict, map part (:415-442), incl. the reference's birth-state inheritance after a resampling over GLOBAL slots:
+ * a gather over the unused masks for immediate-birth configurations (birthGaussianMeasurementCountThreshold == 1), the
+ * level-ordered walk with the lists moved between shards for configurations that keep candidate lists. */
 int rfsgpu_group_predict_map(rfsgpu_group *g, int add_birth);
 int rfsgpu_group_set_birth_inheritance(rfsgpu_group *g, int mode);          /* RFSGPU_INHERIT_REFERENCE (default) | RFSGPU_INHERIT_EAGER */
 int rfsgpu_group_get_particle_ids(rfsgpu_group *g, int *id, int *parent_id); /* Particle::getId / getParentId by global slot */

@@ -878,6 +878,7 @@ struct FilterBase {
   virtual int export_gm(int slot, int max_n, double *w, double *wp, double *mean, double *cov) = 0;
   virtual int get_landmark(int slot, int m, double *mean, double *cov, double *w) = 0;
   virtual int predict_map(int add_birth) = 0;
+  virtual int predict_map_level(int add_birth, const int *level_of_slot, int level, int do_static) = 0;
   virtual void update_map() = 0;
   virtual void importance_weighting() = 0;
   virtual void merge() = 0;
@@ -1621,6 +1622,19 @@ struct FilterT : FilterBase {
     timing.predict_wall += now_ns() - t0;
     return RFSGPU_OK;
   }
+  /* One level of the level-ordered form of predict's birth step (the multi-GPU hosts, which move the per-slot lists between
+   * shards themselves): the birth step of the slots whose level is `level`; the static step of EVERY Gaussian in the call
+   * with do_static, later births receive their + Q where they are created (a predict adds Q to births and old Gaussians alike). */
+  int predict_map_level(int add_birth, const int *level_of_slot, int level, int do_static) override {
+    for (int i = 0; i < n; i++) {
+      const size_t n0 = gm[i].size();
+      if (add_birth && level_of_slot[i] == level) add_birth_particle(i);
+      const size_t from = do_static ? 0 : n0;
+      for (size_t m = from; m < gm[i].size(); m++)
+        for (int k = 0; k < D * D; k++) gm[i][m].S.a[k] += Qlm.a[k];
+    }
+    return RFSGPU_OK;
+  }
   void update_map() override {
     long long t0 = now_ns();
 #pragma omp parallel for schedule(dynamic, 1)
@@ -1827,6 +1841,10 @@ int rfsor_import_birth_candidates(void *f, int slot, int n, const double *mean, 
 }
 
 int rfsor_predict_map(void *f, int add_birth) { return F_(f)->predict_map(add_birth); }
+int rfsor_predict_map_level(void *f, int add_birth, const int *level_of_slot, int level, int do_static) {
+  if (!level_of_slot) return RFSGPU_ERR_INVALID;
+  return F_(f)->predict_map_level(add_birth, level_of_slot, level, do_static);
+}
 
 int rfsor_update_map(void *f, const double *z, int n_z) {
   FilterBase *F = F_(f);

@@ -186,24 +186,72 @@ int rfsgpu_group_get_particle_ids(rfsgpu_group *g, int *id, int *parent_id) {
 // births (birthGaussianMeasurementCountThreshold == 1, the 2-D simulator: no candidate list ever exists) that walk has a closed
 // form over the lists as they are before the predict -- own list if idParent_ == slot, the parent slot's list if it is a HIGHER
 // slot (not yet visited), nothing if it is a LOWER one (already consumed) -- which needs only the 8-byte masks of all shards.
-// Configurations that keep candidate lists would need the lists themselves to cross shards level by level: refused loudly
-// here (RFSGPU_INHERIT_EAGER is the opt-in that does not need it; a single-GPU filter implements the walk in full).
+// Configurations that keep candidate lists take the walk in full, level by level over the global slots (group_predict_levels).
+struct GroupBirthList {
+  unsigned long long mask = 0;
+  int n = 0;
+  std::vector<double> mean, cov;
+  std::vector<int> sup, chk;
+};
+// Level 0 = slots that keep their lists or copy from a HIGHER slot (its lists as they are before this predict); level L = slots
+// whose parent id names a LOWER slot of level L - 1 (its lists after its own birth step) -- csrc/birth.h has the single-GPU form.
+// Per level: read the needed source lists (host-staged: this happens in the predicts that follow a resampling only), install
+// them in the destination slots, run the birth step of that level on every shard.
+static int group_predict_levels(rfsgpu_group *g, int add_birth) {
+  const int N = g->N, S = (int)g->shard.size();
+  const int D = g->shard[0]->D;
+  auto shard_of = [&](int p) { int k = 0; while (p >= g->first[k + 1]) k++; return k; };
+  std::vector<int> level((size_t)N, 0);
+  int maxL = 0;
+  for (int i = 0; i < N; i++) {
+    int p = g->ppid[i];
+    if (p < 0 || p >= N) p = i;
+    level[i] = (p >= i) ? 0 : level[p] + 1;
+    if (level[i] > maxL) maxL = level[i];
+  }
+  std::vector<unsigned long long> masks((size_t)N);
+  for (int L = 0; L <= maxL; L++) {
+    for (int k = 0; k < S; k++) GFWD(k, rfsgpu_get_unused_masks(g->shard[k], masks.data() + g->first[k]));
+    std::vector<int> dst;
+    for (int i = 0; i < N; i++) if (level[i] == L && g->ppid[i] != i && g->ppid[i] >= 0 && g->ppid[i] < N) dst.push_back(i);
+    std::vector<GroupBirthList> src(dst.size());
+    for (size_t t = 0; t < dst.size(); t++) {          // every source is read before any destination is written
+      const int q = g->ppid[dst[t]], kq = shard_of(q);
+      GroupBirthList &b = src[t];
+      b.mask = masks[q];
+      b.mean.resize((size_t)RFSGPU_MAX_CANDIDATES * D); b.cov.resize((size_t)RFSGPU_MAX_CANDIDATES * D * D);
+      b.sup.resize(RFSGPU_MAX_CANDIDATES); b.chk.resize(RFSGPU_MAX_CANDIDATES);
+      GFWD(kq, rfsgpu_export_birth_candidates(g->shard[kq], q - g->first[kq], RFSGPU_MAX_CANDIDATES, &b.n, b.mean.data(), b.cov.data(), b.sup.data(), b.chk.data()));
+      if (b.n > RFSGPU_MAX_CANDIDATES) b.n = RFSGPU_MAX_CANDIDATES;
+    }
+    for (size_t t = 0; t < dst.size(); t++) {
+      const int i = dst[t], ki = shard_of(i);
+      masks[i] = src[t].mask;
+      GFWD(ki, rfsgpu_import_birth_candidates(g->shard[ki], i - g->first[ki], src[t].n, src[t].mean.data(), src[t].cov.data(), src[t].sup.data(), src[t].chk.data()));
+    }
+    if (!dst.empty()) for (int k = 0; k < S; k++) GFWD(k, rfsgpu_set_unused_masks(g->shard[k], masks.data() + g->first[k]));
+    for (int k = 0; k < S; k++) GFWD(k, rfsgpu_predict_map_level(g->shard[k], add_birth, level.data() + g->first[k], L, L == 0 ? 1 : 0));
+  }
+  return RFSGPU_OK;
+}
 int rfsgpu_group_predict_map(rfsgpu_group *g, int add_birth) {
   if (!g) return RFSGPU_ERR_INVALID;
   if (add_birth && g->resampleOccured && g->inheritMode == RFSGPU_INHERIT_REFERENCE) {
     const rfsgpu_filter *f0 = g->shard[0];
-    if (f0->D != 2 || f0->cfg.birthGaussianMeasurementCountThreshold != 1u || f0->candUsed)
-      return gfail(g, RFSGPU_ERR_UNSUPPORTED, "group predict after a resampling: the reference's slot-ordered copy of birth-candidate lists across shards is not "
-                                               "implemented (immediate births only); select RFSGPU_INHERIT_EAGER for this configuration");
-    std::vector<unsigned long long> m((size_t)g->N), mn((size_t)g->N);
-    for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_get_unused_masks(g->shard[k], m.data() + g->first[k]));
-    bool any = false;
-    for (int p = 0; p < g->N; p++) {
-      const int q = g->ppid[p];
-      mn[p] = (q == p || q < 0 || q >= g->N) ? m[p] : (q > p ? m[q] : 0ull);
-      any |= mn[p] != m[p];
+    bool anyCopy = false;
+    for (int p = 0; p < g->N; p++) anyCopy |= g->ppid[p] != p;
+    if (anyCopy && (f0->D != 2 || f0->cfg.birthGaussianMeasurementCountThreshold != 1u || f0->candUsed)) return group_predict_levels(g, add_birth);
+    if (anyCopy) {
+      std::vector<unsigned long long> m((size_t)g->N), mn((size_t)g->N);
+      for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_get_unused_masks(g->shard[k], m.data() + g->first[k]));
+      bool any = false;
+      for (int p = 0; p < g->N; p++) {
+        const int q = g->ppid[p];
+        mn[p] = (q == p || q < 0 || q >= g->N) ? m[p] : (q > p ? m[q] : 0ull);
+        any |= mn[p] != m[p];
+      }
+      if (any) for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_set_unused_masks(g->shard[k], mn.data() + g->first[k]));
     }
-    if (any) for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_set_unused_masks(g->shard[k], mn.data() + g->first[k]));
   }
   for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_predict_map(g->shard[k], add_birth));
   return RFSGPU_OK;

@@ -1124,9 +1124,9 @@ static int predict_launch(rfsgpu_filter *f, int add_birth) {
     if (f->hInhLevel[i] > maxLevel) maxLevel = f->hInhLevel[i];
   }
   if (!any) { launch_predict_kernels(f, add_birth, all); return RFSGPU_OK; }
+  if (!f->dInhLevel) HIPCHK(hipMalloc(&f->dInhLevel, (size_t)f->Ncap * sizeof(int)));
   if (!f->dInhParent) {
     HIPCHK(hipMalloc(&f->dInhParent, (size_t)f->Ncap * sizeof(int)));
-    HIPCHK(hipMalloc(&f->dInhLevel, (size_t)f->Ncap * sizeof(int)));
     const size_t nc = (size_t)f->Ncap * RFSGPU_MAX_CANDIDATES;
     HIPCHK(hipMalloc(&f->inhTmp.unused, (size_t)f->Ncap * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&f->inhTmp.count, (size_t)f->Ncap * sizeof(int)));
@@ -1147,6 +1147,24 @@ static int predict_launch(rfsgpu_filter *f, int add_birth) {
   }
   f->candUsed = f->candUsed || f->D == 3 || f->cfg.birthGaussianMeasurementCountThreshold != 1u;
   return RFSGPU_OK;
+}
+
+// One level of the level-ordered birth step, for hosts that move the per-slot birth lists between shards themselves (rfsgpu.h).
+int rfsgpu_predict_map_level(rfsgpu_filter *f, int add_birth, const int *level_of_slot, int level, int do_static) {
+  CHECK_HANDLE(f);
+  if (!level_of_slot) return fail(f, RFSGPU_ERR_INVALID, "predict_map_level: null level array");
+  hipSetDevice(f->device);
+  if (!f->dInhLevel) HIPCHK(hipMalloc(&f->dInhLevel, (size_t)f->Ncap * sizeof(int)));
+  f->hInhLevel.assign(level_of_slot, level_of_slot + f->N);
+  HIPCHK(hipMemcpyAsync(f->dInhLevel, f->hInhLevel.data(), (size_t)f->N * sizeof(int), hipMemcpyHostToDevice, f->stream));
+  HIPCHK(hipEventRecord(f->ev[EV_P0], f->stream));
+  launch_predict_kernels(f, add_birth, BirthLevel{f->dInhLevel, level, do_static ? 1 : 0});
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(f->ev[EV_P1], f->stream));
+  const int rc = check_device_errors(f);
+  accumulate(f->ev[EV_P0], f->ev[EV_P1], f->timing.predict_wall, nullptr);
+  f->candUsed = f->candUsed || f->D == 3 || f->cfg.birthGaussianMeasurementCountThreshold != 1u;
+  return rc;
 }
 
 int rfsgpu_predict_map(rfsgpu_filter *f, int add_birth) {

@@ -35,8 +35,9 @@ class ShardedRBPHDFilter:
     """inheritance: "reference" (default) = the reference's birth-state inheritance after a resampling (include/RBPHDFilter.hpp:
     1005-1011) over GLOBAL slots -- ids are global, so this host owns the rule and the local engine runs in
     RFSGPU_INHERIT_EXTERNAL; implemented for immediate-birth configurations (birthGaussianMeasurementCountThreshold == 1, the 2-D
-    simulator), where the slot-ordered walk needs only the 8-byte unused masks of all shards (predict_map below).  "eager" = a
-    child takes its parent's lists and FOV count at resampling time (rounds 1-2; not the reference's results)."""
+    simulator) through the closed form of the slot-ordered walk over the 8-byte unused masks of all shards, and for configurations
+    that keep candidate lists by the walk itself, level by level (predict_map / _predict_levels below).  "eager" = a child takes
+    its parent's lists and FOV count at resampling time (rounds 1-2; not the reference's results)."""
 
     def __init__(self, local, group=None, device=None, stream=None, sums=None, inheritance="reference"):
         assert inheritance in ("reference", "eager")
@@ -126,19 +127,56 @@ class ShardedRBPHDFilter:
         candidate list exists and the walk has a closed form over the lists as they are before the predict: own list if
         idParent_ == slot, the parent slot's list if that is a HIGHER slot (not yet visited), nothing if it is a LOWER one
         (already consumed).  One all-gather of N 8-byte masks, only in those predicts."""
-        if add_birth and self.resampleOccured and self.inheritance == "reference":
+        if add_birth and self.resampleOccured and self.inheritance == "reference" and np.any(self.ppid != np.arange(self.n_total)):
             cfg = self.f.get_filter_config()
-            if cfg.birthGaussianMeasurementCountThreshold != 1 or self.f.dz != 2:
-                raise RuntimeError("sharded predict after a resampling: the reference's slot-ordered copy of birth-candidate lists across shards "
-                                   "is not implemented (immediate births only); construct with inheritance='eager' for this configuration")
-            m_all = self._gather_masks()
-            lo = self.rank * self.n_local
-            g = np.arange(lo, lo + self.n_local)
-            p = self.ppid[g]
-            new = np.where(p == g, m_all[g], np.where(p > g, m_all[np.clip(p, 0, self.n_total - 1)], np.uint64(0))).astype(np.uint64)
-            if np.any(new != m_all[g]):
-                self.f.set_unused_masks(new)
+            if cfg.birthGaussianMeasurementCountThreshold == 1 and self.f.dz == 2:
+                m_all = self._gather_masks()
+                lo = self.rank * self.n_local
+                g = np.arange(lo, lo + self.n_local)
+                p = self.ppid[g]
+                new = np.where(p == g, m_all[g], np.where(p > g, m_all[np.clip(p, 0, self.n_total - 1)], np.uint64(0))).astype(np.uint64)
+                if np.any(new != m_all[g]):
+                    self.f.set_unused_masks(new)
+            else:
+                self._predict_levels(add_birth)
+                return
         self.f.predict_map(add_birth)
+
+    def _predict_levels(self, add_birth):
+        """Configurations that keep birth-candidate lists (Victoria Park; CountThreshold > 1): the walk in full, level by level over
+        GLOBAL slots (csrc/birth.h has the single-GPU form).  Level 0 = slots that keep their lists or copy from a HIGHER slot (its
+        lists as they are before this predict); level L = slots whose parent id names a LOWER slot of level L - 1 (its lists after
+        its own birth step).  Per level: the owners of the needed source slots publish (unused mask, candidate list), every rank
+        installs what its slots need, then the shard runs the birth step of that level (rfsgpu_predict_map_level).  Host-staged
+        (an all-gather of small Python objects): it happens in the predicts that follow a resampling only."""
+        N, n, lo = self.n_total, self.n_local, self.rank * self.n_local
+        p = self.ppid
+        level = np.zeros(N, dtype=np.int32)
+        for i in range(N):
+            if p[i] < i:
+                level[i] = level[p[i]] + 1
+        local_levels = np.ascontiguousarray(level[lo:lo + n])
+        for L in range(int(level.max()) + 1):
+            dst = np.nonzero((level == L) & (p != np.arange(N)))[0]
+            srcs = np.unique(p[dst])
+            masks = self.f.get_unused_masks()
+            mine = {int(q): (int(masks[q - lo]), self.f.export_birth_candidates(int(q - lo))) for q in srcs if lo <= q < lo + n}
+            if self.world > 1:
+                parts = [None] * self.world
+                dist.all_gather_object(parts, mine, group=self.group)
+                table = {k: v for part in parts for k, v in part.items()}
+            else:
+                table = mine
+            changed = False
+            for i in dst:
+                if lo <= i < lo + n:
+                    m, (mean, cov, sup, chk) = table[int(p[i])]
+                    masks[i - lo] = np.uint64(m)
+                    self.f.import_birth_candidates(int(i - lo), mean, cov, sup, chk)
+                    changed = True
+            if changed:
+                self.f.set_unused_masks(masks)
+            self.f.predict_map_level(add_birth, local_levels, L, L == 0)
 
     def _gather_masks(self):
         local = np.ascontiguousarray(self.f.get_unused_masks(), dtype=np.uint64)

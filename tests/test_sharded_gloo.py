@@ -49,7 +49,17 @@ def z_stream(scen, k):
     return Z
 
 
-def _worker(rank, world, port, n_total, force_resample, q, big=False, cycles=0):
+def candidate_config(f):
+    """A configuration that keeps birth-candidate lists (CountThreshold > 1): the inheritance walk must carry the lists."""
+    cfg = f.get_filter_config()
+    cfg.birthGaussianMeasurementCountThreshold = 3
+    cfg.birthGaussianMeasurementCheckThreshold = 2
+    cfg.birthGaussianMeasurementSupportDist = 2.0
+    cfg.birthGaussianCurrentMeasurementCountThreshold = 0
+    f.set_filter_config(cfg)
+
+
+def _worker(rank, world, port, n_total, force_resample, q, big=False, cycles=0, cand=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -62,6 +72,8 @@ def _worker(rank, world, port, n_total, force_resample, q, big=False, cycles=0):
     scen = make_scen(sc, n_total, big)
     local = ob.OracleFilter(n_total // world, stable_sort=True)
     sc.load_scenario(local, shard_scen(scen, rank, world))
+    if cand:
+        candidate_config(local)
     sh = pkg.sharded.ShardedRBPHDFilter(local)
     sh.effNParticles_t = n_total + 1.0 if force_resample else 1e-9     # always / never resample
     # (the 500-landmark state drives the raw weights to 0 in one update: the big case resamples the loaded state directly)
@@ -75,17 +87,17 @@ def _worker(rank, world, port, n_total, force_resample, q, big=False, cycles=0):
         rows_total += sh.last_migration["rows_sent"]
     res = dict(rank=rank, fired=fired, ids=(sh.pid.copy(), sh.ppid.copy()), rows_total=rows_total, w=local.get_weights(), sizes=local.gm_sizes(), poses=local.get_poses(),
                maps=[local.export_gm(i) for i in range(local.n)], unused=[local.get_unused(i) for i in range(local.n)],
-               migration=sh.last_migration)
+               cands=[local.export_birth_candidates(i) for i in range(local.n)], migration=sh.last_migration)
     q.put(res)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def run_world(n_total, force_resample, world=2, big=False, cycles=0):
+def run_world(n_total, force_resample, world=2, big=False, cycles=0, cand=False):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, force_resample, q, big, cycles)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, force_resample, q, big, cycles, cand)) for r in range(world)]
     for p in procs:
         p.start()
     out = [q.get() for _ in range(world)]
@@ -138,18 +150,22 @@ def test_two_rank_update_matches_single_process(pkg, ob, force_resample):
         assert len(crossed) > 0
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_resampling_cycles_inherit_birth_state_as_the_reference(pkg, ob, world):
+@pytest.mark.parametrize("world,cand", [(2, False), (3, False), (2, True), (3, True)])
+def test_sharded_resampling_cycles_inherit_birth_state_as_the_reference(pkg, ob, world, cand):
     """Forced global resamplings with predicts and updates in between, over 2 and 3 ranks: maps, unused lists, weights and particle
     ids equal those of ONE plain filter holding all particles in RFSGPU_INHERIT_REFERENCE mode (the engine's own, single-GPU
     implementation of include/RBPHDFilter.hpp:1005-1011) driven through the same decisions -- i.e. the sharded host's mask
-    exchange over GLOBAL slots reproduces the reference's slot-ordered copy across shard boundaries."""
+    exchange over GLOBAL slots reproduces the reference's slot-ordered copy across shard boundaries.  cand: a configuration that
+    keeps birth-candidate lists -- the sharded host then carries out the walk level by level (lists of parent slots on other
+    ranks travel as objects), and the candidate lists (means, covariances, supports, checks) must match too."""
     n_total, cycles = 24, 4
     sc = pkg.scenarios
     scen = make_scen(sc, n_total)
     ref = ob.OracleFilter(n_total, stable_sort=True)
     assert ref.get_birth_inheritance() == pkg.capi.INHERIT_REFERENCE
     sc.load_scenario(ref, scen)
+    if cand:
+        candidate_config(ref)
 
     def step(Z, u01):
         ref.update(Z)
@@ -165,13 +181,21 @@ def test_sharded_resampling_cycles_inherit_birth_state_as_the_reference(pkg, ob,
         if k % 2 == 1:
             ref.predict_map(True)
         step(z_stream(scen, k), 0.1 + 0.17 * k)
-    out = run_world(n_total, True, world=world, cycles=cycles)
+    out = run_world(n_total, True, world=world, cycles=cycles, cand=cand)
     maps = [m for o in out for m in o["maps"]]
     unused = [u for o in out for u in o["unused"]]
+    cands = [c for o in out for c in o["cands"]]
     assert np.array_equal(np.concatenate([o["sizes"] for o in out]), ref.gm_sizes())
+    n_cand = 0
     for i in range(n_total):
         sc.assert_gm_close(maps[i], ref.export_gm(i), 1e-13, 0, ordered=True)
         assert np.array_equal(unused[i], ref.get_unused(i))
+        mr, cr, sr, kr = ref.export_birth_candidates(i)
+        assert list(cands[i][2]) == list(sr) and list(cands[i][3]) == list(kr), i
+        np.testing.assert_array_equal(cands[i][0], mr)
+        np.testing.assert_array_equal(cands[i][1], cr)
+        n_cand += len(sr)
+    assert (n_cand > 0) == cand
     np.testing.assert_array_equal(np.concatenate([o["poses"] for o in out]), ref.get_poses())
     ids, par = ref.get_particle_ids()
     for o in out:

@@ -222,3 +222,65 @@ def test_bench_eight_ranks_share_the_gpu_end_to_end():
     off = P[~np.eye(8, dtype=bool)]
     assert np.any(off == 0) and np.any(off > 0)           # zero-length peers inside the same exchange
     assert m["bytes_migrated_total"] == m["rows_migrated_total"] * m["row_bytes"]
+
+
+@pytest.mark.parametrize("n_shards", [3, 8])
+def test_group_with_birth_candidate_lists_inherits_as_a_single_filter(pkg, n_shards):
+    """A configuration that keeps birth-candidate lists (CountThreshold 3) over several shards: after forced global resamplings the
+    group carries out the reference's slot-ordered copy of unused lists AND candidate lists level by level across shard
+    boundaries (rfsgpu_group_predict_map -> rfsgpu_predict_map_level); maps, unused lists and candidate lists (supports, checks,
+    means, covariances) equal those of ONE handle in RFSGPU_INHERIT_REFERENCE mode through three predict / update / resample cycles."""
+    sc = pkg.scenarios
+    n_total = 48
+    scen = sc.make_scenario(n_total, 8, 9, seed=21, params=dict(min_updates=1))
+    ref = pkg.RBPHDFilter(n_total, device_id=0, gm_capacity=192)
+    grp = pkg.FilterGroup(n_total, [0] * n_shards, gm_capacity=192)
+    for f in (ref, grp):
+        sc.load_scenario(f, scen)
+        cfg = ref.get_filter_config()
+        cfg.birthGaussianMeasurementCountThreshold = 3
+        cfg.birthGaussianMeasurementCheckThreshold = 2
+        cfg.birthGaussianMeasurementSupportDist = 2.0
+        cfg.birthGaussianCurrentMeasurementCountThreshold = 0
+        f.set_filter_config(cfg)
+    rng = np.random.default_rng(3)
+    seen = 0
+    x = scen["poses"].copy()
+    for step in range(4):
+        Z = scen["Z"].copy()
+        Z[:, 0] += rng.normal(0, 2e-3, Z.shape[0])
+        Z[-2:, 0] = rng.uniform(1.0, 2.0, 2)                 # clutter nobody has seen: unused measurements -> candidates
+        for f in (ref, grp):
+            f.predict_map(True)
+        ref.update(Z)
+        grp.update(Z)
+        ramp = np.arange(n_total) / n_total                  # heavy slots alternate between the top and the bottom: parents above AND below
+        w = rng.uniform(0.05, 1.0, n_total) ** 2 * (1.0 + 2.0 * (ramp if step % 2 == 0 else 1.0 - ramp))
+        for f in (ref, grp):
+            f.set_weights(w)
+        ref.normalize_weights(ref.weight_sums()[0])
+        plan_ref = pkg.engine.systematic_resample_plan(ref.get_weights(), 0.1 + 0.2 * step)
+        ref.resample_apply(plan_ref)
+        fired, plan = grp.resample(n_total + 1.0, 0.1 + 0.2 * step)
+        assert fired and np.array_equal(plan, plan_ref)
+        x = x[plan_ref]
+        ref.set_poses(x, scen["pose_cov"])
+        grp.set_poses(x, scen["pose_cov"])
+    for f in (ref, grp):
+        f.predict_map(True)
+        f.predict_map(True)                                  # (resampleOccured_ still set: the copy runs again)
+    assert np.array_equal(grp.gm_sizes(), ref.gm_sizes())
+    for i in range(n_total):
+        for a, b in zip(grp.export_gm(i), ref.export_gm(i)):
+            assert np.array_equal(a, b), i
+        assert np.array_equal(grp.get_unused(i), ref.get_unused(i))
+        k, s_ = grp.locate(i)
+        cg, cr = grp.shards[k].export_birth_candidates(s_), ref.export_birth_candidates(i)
+        for a, b in zip(cg, cr):
+            assert np.array_equal(a, b), i
+        seen += len(cr[2])
+    assert seen > 0
+    ids_g, par_g = grp.get_particle_ids()
+    ids_r, par_r = ref.get_particle_ids()
+    assert np.array_equal(ids_g, ids_r) and np.array_equal(par_g, par_r) and np.any(par_r < np.arange(n_total))
+    grp.close(); ref.close()
