@@ -14,7 +14,7 @@ if os.environ.get("RFS_LIB"):
 sc = pkg.scenarios
 N, NM, NZ = [int(os.environ.get(k, d)) for k, d in (("VP_N", 5000), ("VP_NM", 40), ("VP_NZ", 12))]
 scen = sc.make_vp_scenario(N, NM, NZ, seed=4321, scan="ragged")
-f = pkg.RBPHDFilter(N, gm_capacity=192, model=pkg.capi.MODEL_VICTORIAPARK_3D)
+f = pkg.RBPHDFilter(N, gm_capacity=int(os.environ.get("VP_CAP", 192)), model=pkg.capi.MODEL_VICTORIAPARK_3D)
 sc.load_scenario(f, scen)
 f.save_state()
 for _ in range(5):
