@@ -16,12 +16,16 @@
 #include "common.h"
 #include "weighting.h"
 #include "hungarian_wave.h"
+#include "hungarian_quad.h"
 
 #define MURTY_N 64             /* max extended dimension nR + nC handled on the device */
 #define MURTY_KBEST 200
 #define MURTY_MAX_NODES 6401   /* 1 root + <= 200 expansions x <= 32 children */
 #ifndef MURTY_JOB_WAVES
-#define MURTY_JOB_WAVES 4   // measured at configs[4] (1918 jobs of dimension 9-15), barrier form: 1 wave 26.8 ms, 2: 16.5, 3: 15.4, 4: 15.1; search wave + solvers (murty_kbest_async): 3: 8.9, 4: 6.4, 5: 7.9, 6: 8.9
+// measured at configs[4] (1918 jobs of dimension 9-15), barrier form: 1 wave 26.8 ms, 2: 16.5, 3: 15.4, 4: 15.1; search wave + solvers
+// (murty_kbest_async) at the compiler's 92 VGPRs (5 waves per SIMD): 3: 8.9, 4: 6.3, 5: 7.8, 6: 8.9, 8: 8.4; capped at 64 VGPRs
+// (MURTY_WAVES_PER_EU 8: 100 B of scratch per lane, 1280 six-wave workgroups on the GPU at once): 4: 6.6, 5: 5.7, 6: 5.5, 7: 8.6, 8: 5.6
+#define MURTY_JOB_WAVES 6
 #endif
 #define MURTY_CT_WAVES (MURTY_JOB_WAVES > 4 ? MURTY_JOB_WAVES : 4)   /* (the multi-hypothesis FastSLAM search uses up to four waves on the same arena) */
 
@@ -42,6 +46,7 @@ struct MurtyArena {
   unsigned char *nodeId;   // [MAX_NODES]
   unsigned char *nodeA;    // [MAX_NODES][N]
   short *heap;             // [MAX_NODES]
+  unsigned short *nodeExcl;   // [MAX_NODES] (quad search, n <= 16): the columns child 0 of the node must not take in its first row
 };
 
 __host__ __device__ inline size_t murty_job_bytes() {
@@ -55,6 +60,7 @@ __host__ __device__ inline size_t murty_job_bytes() {
   b += (size_t)MURTY_MAX_NODES;            // id
   b += (size_t)MURTY_MAX_NODES * MURTY_N;  // assignments
   b += (size_t)MURTY_MAX_NODES * 2;        // heap
+  b += (size_t)MURTY_MAX_NODES * 2 + 2;    // nodeExcl
   return (b + 63) & ~(size_t)63;
 }
 
@@ -77,7 +83,8 @@ __device__ inline void murty_carve(unsigned char *base, MurtyArena &A) {
   A.xq = p; p += MURTY_N;
   A.yq = p; p += MURTY_N;
   A.nodeId = p; p += MURTY_MAX_NODES;
-  A.nodeA = p;
+  A.nodeA = p; p += (size_t)MURTY_MAX_NODES * MURTY_N;
+  A.nodeExcl = (unsigned short *)(((size_t)p + 1) & ~(size_t)1);
 }
 
 // std::priority_queue<MurtyNode*, vector, MurtyNodeCompare> == libstdc++ push_heap / pop_heap on scores.
@@ -335,41 +342,196 @@ __device__ __forceinline__ void murty_kbest_block(double *C, int n, int partitio
 // pushes and pops are exactly the serial ones: the table only replaces a solve by its own result.  No workgroup barrier inside
 // the search -- flags in LDS (release / acquire at workgroup scope); wave 0 never waits for anything but a solve in flight, the
 // solvers for nothing but a task or the end, so there is no cycle to wait in.
-#define MURTY_SPEC_SLOTS 8
+#ifndef MURTY_QUAD
+#define MURTY_QUAD 0           // 1: jobs of extended dimension <= 16 get solver waves of four 16-lane solvers each (hungarian_quad.h) -- bit-identical, measured slower, opt-in
+#endif
+#ifndef MURTY_SPEC_SLOTS
+#define MURTY_SPEC_SLOTS (MURTY_QUAD ? 16 : 8)
+#endif
 #ifndef MURTY_SOLVER_SLEEP
 #define MURTY_SOLVER_SLEEP 4   // x 64 cycles between two looks at the mailbox (1 ... 64 measured at configs[4]: 6.37-6.44 ms, no trend)
 #endif
 #ifndef MURTY_SEARCH_SLEEP
 #define MURTY_SEARCH_SLEEP 2
 #endif
+#ifndef MURTY_PEEK
+#define MURTY_PEEK (MURTY_QUAD ? 3 : 2)   // heap positions whose children are solved ahead of their pop when solvers are free
+#endif
+#define MURTY_VSOLVERS (MURTY_QUAD ? 4 * (MURTY_CT_WAVES - 1) : (MURTY_CT_WAVES - 1))   /* mailboxes 1..MURTY_VSOLVERS */
 struct MurtySpec {
   double score[MURTY_SPEC_SLOTS];
   int ready[MURTY_SPEC_SLOTS];           // slot payload complete (solver: 1; wave 0 clears it when it hands the slot out)
-  int taskSeq[MURTY_CT_WAVES];           // wave 0 -> solver w: tasks posted so far
-  int doneSeq[MURTY_CT_WAVES];           // solver w -> wave 0: tasks finished so far
-  int taskNode[MURTY_CT_WAVES], taskC[MURTY_CT_WAVES], taskSlot[MURTY_CT_WAVES];
+  int taskSeq[MURTY_VSOLVERS + 1];       // wave 0 -> solver v: tasks posted so far
+  int doneSeq[MURTY_VSOLVERS + 1];       // solver v -> wave 0: tasks finished so far
+  int taskNode[MURTY_VSOLVERS + 1], taskC[MURTY_VSOLVERS + 1], taskSlot[MURTY_VSOLVERS + 1];
   int quit;
-  int peekNode[2], peekPart[2];
+  int peekNode[4], peekPart[4];
   unsigned char pushed[MURTY_SPEC_SLOTS];
   unsigned char a[MURTY_SPEC_SLOTS][MURTY_N];
 };
 __device__ __forceinline__ int murty_flag_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void murty_flag_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-template <int W, int LDSN, class FRoot, class FTop>
+// ---- quad solver wave: four 16-lane virtual solvers (hungarian_quad.h), each with its own mailbox ----------------------
+// Quarter q of solver wave w serves mailbox v = 4 (w - 1) + q + 1.  A quarter is a little state machine -- idle (look at the
+// mailbox once), solving (one trip of the Hungarian main loop per turn) -- so that a quarter starts its next child while the
+// other quarters are in the middle of theirs; the wave leaves when the search has ended and every quarter is idle.
+// The child (murty_solve_child / murty_child_wave above, leading dimension 16): table, negative constraints, solver, score
+// terms added in row order, assignment in job columns -- the same arithmetic in the same order.
+struct MurtyQuadTask {
+  int t, e, X, c, nn, nFree, colRemap, aPar, ppX;
+  unsigned excl;
+  double fixedScore;
+};
+// first half: the three loads that depend on nothing but the node (issued, not waited for: the wave's other quarters run
+// their turn in between)
+__device__ __forceinline__ void murty_quad_fetch(MurtyQuadTask &k, const int n, MurtyArena &A, const int ql) {
+  k.ppX = A.nodeId[k.X];
+  k.aPar = (ql < n) ? (int)A.nodeA[(size_t)k.X * MURTY_N + ql] : 0;
+  k.excl = A.nodeExcl[k.X];
+}
+// second half: LDS and registers only.  sC: the job's table (n x n) in LDS.  The negative constraints (src/MurtyAlgorithm.cpp:247-265)
+// all fall into the child's first row: child c > 0 must not repeat the node's own choice for that row; child 0 -- whose
+// first row is the row the node itself was created at -- must not repeat the node's, its parent's, and the choices of the
+// ancestors above for as long as they were created at that row too: the set the search keeps per node (nodeExcl).  Lane dj of the constraint walk = the lane whose free column IS the excluded one; the dummy-range rule on the
+// REDUCED column index as there.
+__device__ __forceinline__ bool murty_quad_begin(MurtyQuadTask &k, HQState &h, HQScratch &sc, const double *sC, const int n, const int realNC, const int ql,
+                                                 const int qshift) {
+  const double bigNumber = 10000.0;
+  const int nn = k.ppX + k.c, nFree = n - nn;
+  const int aPar = k.aPar;
+  const double termPar = (ql < n) ? sC[ql * n + aPar] : 0.0;
+  sc.ap[ql] = (unsigned char)aPar;
+  sc.tp[ql] = termPar;
+  hq_sync();
+  double fixedScore = 0;
+  unsigned used = 0;
+  for (int r = 0; r < nn; r++) { fixedScore += sc.tp[r]; used |= 1u << sc.ap[r]; }   // rows 0..nn-1 fixed to the parent's choice
+  const unsigned freeCols = ((1u << n) - 1u) & ~used;
+  const int colRemap = (ql < nFree) ? murty_kth_bit((unsigned long long)freeCols, ql) : 0;
+  k.nn = nn; k.nFree = nFree; k.colRemap = colRemap; k.fixedScore = fixedScore;
+  const unsigned excl = (k.c == 0) ? k.excl : (1u << sc.ap[nn]);
+  const bool hit = ql < nFree && ((excl >> colRemap) & 1u);
+  const bool dummy = hq_ballot(hit && ql >= realNC, qshift) != 0;
+  if (ql < nFree) {
+    for (int r = 0; r < nFree; r++) {
+      double v = sC[(nn + r) * n + colRemap];
+      if (r == 0 && (hit || (dummy && ql >= realNC))) v = -bigNumber;
+      sc.tile[r * HQ_N + ql] = v;
+    }
+  }
+  hq_sync();
+  if (hq_ballot(ql < nFree && sc.tile[ql] != -bigNumber, qshift) == 0) return false;   // the constraint row is reduced row 0
+  hq_start(h, sc, nFree, ql, qshift);
+  return true;
+}
+// the solved (or failed) child -> table slot e, mailbox v
+__device__ __forceinline__ void murty_quad_finish(const MurtyQuadTask &k, const HQState &h, HQScratch &sc, const double *sC, const int n, const bool okH,
+                                                  MurtySpec *spec, const int v, const int ql) {
+  double sAcc = 0;
+  int aNew = k.aPar;
+  if (okH) {
+    const int aTmp = hq_nib(h.xyP, ql);
+    sc.cr[ql] = (unsigned char)k.colRemap;
+    hq_sync();
+    const int ja = (ql < k.nFree) ? (int)sc.cr[aTmp] : 0;
+    const double term = (ql < k.nFree) ? sC[(k.nn + ql) * n + ja] : 0.0;
+    sc.tp[ql] = term;
+    sc.jas[ql] = (unsigned char)ja;
+    hq_sync();
+    for (int r = 0; r < k.nFree; r++) sAcc += sc.tp[r];
+    sAcc += k.fixedScore;
+    if (ql >= k.nn) aNew = sc.jas[ql - k.nn];
+  }
+  spec->a[k.e][ql] = (unsigned char)aNew;
+  if (ql == 0) { spec->score[k.e] = sAcc; spec->pushed[k.e] = okH ? 1 : 0; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  if (ql == 0) { murty_flag_store(&spec->ready[k.e], 1); murty_flag_store(&spec->doneSeq[v], k.t); }
+}
+__device__ __forceinline__ void murty_quad_solver_wave(const double *C, const int n, const int realNC, MurtyArena &A, const int wave, MurtySpec *spec,
+                                                       HQScratch *quadScratch, double *sC) {
+  const int lane = threadIdx.x & 63, q = lane >> 4, ql = lane & 15, qshift = lane & 48;
+  const int v = 4 * (wave - 1) + q + 1;
+  HQScratch &sc = quadScratch[4 * (wave - 1) + q];
+  // the job's table -> LDS (after the root's solve, which rewrites it in place; every solver wave writes the same values and
+  // reads them after its own stores)
+  for (int t = lane; t < n * n; t += 64) sC[t] = C[t];
+  hq_sync();
+  HQState h;
+  MurtyQuadTask k;
+  k.t = 0;
+  int state = 0, seen = 0;   // 0 idle, 1 solving, 2 gone
+#ifdef RFS_PROFILE
+  long long pc[6] = {0, 0, 0, 0, 0, 0};   // cycles: begin, trips, finish; counts: turns, trips of this quarter, children of this quarter
+#define HQ_T0 const long long hqT0 = (long long)__builtin_readcyclecounter()
+#define HQ_ADD(i) pc[i] += (long long)__builtin_readcyclecounter() - hqT0
+#else
+#define HQ_T0 do { } while (0)
+#define HQ_ADD(i) do { } while (0)
+#endif
+  for (;;) {
+#ifdef RFS_PROFILE
+    pc[3]++;
+#endif
+    if (state == 0) {
+      const int t = murty_flag_load(&spec->taskSeq[v]);
+      if (t != seen) {
+        k.t = t;
+        k.e = spec->taskSlot[v];
+        k.X = spec->taskNode[v];
+        k.c = spec->taskC[v];
+        murty_quad_fetch(k, n, A, ql);
+        state = 3;
+      } else if (murty_flag_load(&spec->quit)) {
+        state = 2;
+      }
+    } else if (state == 3) {
+      HQ_T0;
+      if (murty_quad_begin(k, h, sc, sC, n, realNC, ql, qshift)) state = 1;
+      else { murty_quad_finish(k, h, sc, sC, n, false, spec, v, ql); seen = k.t; state = 0; }
+      HQ_ADD(0);
+#ifdef RFS_PROFILE
+      pc[5]++;
+#endif
+    } else if (state == 1) {
+      HQ_T0;
+      const int r = hq_trip(h, sc, ql, qshift);
+      HQ_ADD(1);
+#ifdef RFS_PROFILE
+      pc[4]++;
+#endif
+      if (r != 0) { HQ_T0; murty_quad_finish(k, h, sc, sC, n, r == 1, spec, v, ql); seen = k.t; state = 0; HQ_ADD(2); }
+    }
+    if (__ballot(state != 2) == 0ull) break;
+    if (__ballot(state == 1 || state == 3) == 0ull) __builtin_amdgcn_s_sleep(MURTY_SOLVER_SLEEP);
+  }
+#ifdef RFS_PROFILE
+  if (ql == 0 && (blockIdx.x & 255) == 7)
+    printf("quad solver block %d wave %d quarter %d (n %d): children %lld, trips %lld, turns %lld; cycles begin %lld, trips %lld, finish %lld\n", (int)blockIdx.x, wave, q, n,
+           pc[5], pc[4], pc[3], pc[0], pc[1], pc[2]);
+#endif
+}
+
+// QUAD: the job's extended dimension is <= 16 and the solver waves run murty_quad_solver_wave (NS = 4 (W - 1) mailboxes);
+// otherwise one mailbox per solver wave (hungarian_wave, any dimension up to MURTY_N).  The search is the same either way.
+template <int W, int LDSN, bool QUAD, class FRoot, class FTop>
 __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitionMax, int realNC, int maxNodes, int maxK, MurtyArena &A, bool &ok,
                                                   double *myTile, int *ctl, double *sScore, unsigned char *sPushed, const int wave, MurtySpec *spec,
-                                                  FRoot onRoot, FTop onTop) {
+                                                  HQScratch *quadScratch, double *sC, FRoot onRoot, FTop onTop) {
   static_assert(W >= 2 && W <= MURTY_CT_WAVES, "one searching wave + at least one solver");
+  constexpr int NS = QUAD ? 4 * (W - 1) : (W - 1);
+  static_assert(NS <= MURTY_VSOLVERS && NS < 32, "mailboxes");
   const int lane = threadIdx.x & 63;
   if (wave == 0) {
     if (lane < MURTY_SPEC_SLOTS) spec->ready[lane] = 0;
-    if (lane < MURTY_CT_WAVES) { spec->taskSeq[lane] = 0; spec->doneSeq[lane] = 0; }
+    if (lane <= MURTY_VSOLVERS) { spec->taskSeq[lane] = 0; spec->doneSeq[lane] = 0; }
     if (lane == 0) spec->quit = 0;
     int a0;
     double s = 0;
     const bool okr = murty_root_wave(C, n, A, a0, s, nullptr);
     if (lane == 0) {
+      if constexpr (QUAD) A.nodeExcl[0] = (unsigned short)(1u << a0);
       ctl[2] = 1; ctl[3] = okr ? 1 : 0; ctl[5] = okr ? 1 : 0;
       ctl[4] = (!okr || onRoot(s)) ? 1 : 0;
     }
@@ -386,50 +548,53 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
   long long *const prof = nullptr;
 #endif
   if (wave != 0) {
-    // ---- solver ----
-    int seen = 0;
-    for (;;) {
-      int t;
-      while ((t = murty_flag_load(&spec->taskSeq[wave])) == seen) {
-        if (murty_flag_load(&spec->quit)) break;
-        __builtin_amdgcn_s_sleep(MURTY_SOLVER_SLEEP);
+    if constexpr (QUAD) {
+      murty_quad_solver_wave(C, n, realNC, A, wave, spec, quadScratch, sC);
+    } else {
+      // ---- solver ----
+      int seen = 0;
+      for (;;) {
+        int t;
+        while ((t = murty_flag_load(&spec->taskSeq[wave])) == seen) {
+          if (murty_flag_load(&spec->quit)) break;
+          __builtin_amdgcn_s_sleep(MURTY_SOLVER_SLEEP);
+        }
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t == seen) break;   // the search is over
+        const int X = __builtin_amdgcn_readfirstlane(spec->taskNode[wave]), c = __builtin_amdgcn_readfirstlane(spec->taskC[wave]);
+        const int e = __builtin_amdgcn_readfirstlane(spec->taskSlot[wave]);
+        const int ppX = A.nodeId[X];
+        const int aPar = (lane < n) ? A.nodeA[(size_t)X * MURTY_N + lane] : 0;
+        const double termPar = (lane < n) ? C[lane * n + aPar] : 0.0;
+        bool pushed = false;
+        double sAcc = 0;
+        int aNew = aPar;
+        murty_solve_child<LDSN>(myTile, C, n, realNC, A, wave, X, ppX, c, 0x7ffe, aPar, termPar, pushed, sAcc, aNew, prof);
+        spec->a[e][lane] = (unsigned char)aNew;
+        if (lane == 0) { spec->score[e] = sAcc; spec->pushed[e] = pushed ? 1 : 0; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) { murty_flag_store(&spec->ready[e], 1); murty_flag_store(&spec->doneSeq[wave], t); }
+        seen = t;
       }
-      t = __builtin_amdgcn_readfirstlane(t);
-      if (t == seen) break;   // the search is over
-      const int X = __builtin_amdgcn_readfirstlane(spec->taskNode[wave]), c = __builtin_amdgcn_readfirstlane(spec->taskC[wave]);
-      const int e = __builtin_amdgcn_readfirstlane(spec->taskSlot[wave]);
-      const int ppX = A.nodeId[X];
-      const int aPar = (lane < n) ? A.nodeA[(size_t)X * MURTY_N + lane] : 0;
-      const double termPar = (lane < n) ? C[lane * n + aPar] : 0.0;
-      bool pushed = false;
-      double sAcc = 0;
-      int aNew = aPar;
-      murty_solve_child<LDSN>(myTile, C, n, realNC, A, wave, X, ppX, c, 0x7ffe, aPar, termPar, pushed, sAcc, aNew, prof);
-      spec->a[e][lane] = (unsigned char)aNew;
-      if (lane == 0) { spec->score[e] = sAcc; spec->pushed[e] = pushed ? 1 : 0; }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      if (lane == 0) { murty_flag_store(&spec->ready[e], 1); murty_flag_store(&spec->doneSeq[wave], t); }
-      seen = t;
     }
   } else {
     // ---- the search ----
     int tNode = -1, tC = 0;   // lane e < MURTY_SPEC_SLOTS: the key of table slot e (node < 0: free)
     int fifo = 0;             // next slot to recycle when none is free
-    int posted[W];            // tasks posted to solver w so far
-#pragma unroll
-    for (int w = 0; w < W; w++) posted[w] = 0;
+    int postedL = 0;          // lane v in 1..NS: tasks posted to mailbox v so far
     for (int k = 1; k < maxK && __builtin_amdgcn_readfirstlane(ctl[4]) == 0; k++) {
       if (lane == 0) {
         int hl = ctl[3];
         const int parent = heap_pop(A.heap, hl, A.nodeScore);
         ctl[0] = parent; ctl[1] = A.nodeId[parent]; ctl[3] = hl;
-        // the nodes a coming pop is most likely to take: the new top, then the better of its two children
+        // the nodes a coming pop is most likely to take: the new top, then the better of its two children, then the other one
         const int b1 = (hl > 0) ? (int)A.heap[0] : -1;
-        int b2 = (hl > 1) ? (int)A.heap[1] : -1;
-        if (hl > 2) { const int b3 = A.heap[2]; if (A.nodeScore[b3] > A.nodeScore[b2]) b2 = b3; }
+        int b2 = (hl > 1) ? (int)A.heap[1] : -1, b3 = (hl > 2) ? (int)A.heap[2] : -1;
+        if (b3 >= 0 && A.nodeScore[b3] > A.nodeScore[b2]) { const int tmp = b2; b2 = b3; b3 = tmp; }
         spec->peekNode[0] = b1; spec->peekPart[0] = (b1 >= 0) ? (int)A.nodeId[b1] : 0;
         spec->peekNode[1] = b2; spec->peekPart[1] = (b2 >= 0) ? (int)A.nodeId[b2] : 0;
+        spec->peekNode[2] = b3; spec->peekPart[2] = (b3 >= 0) ? (int)A.nodeId[b3] : 0;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (also: the nodes pushed so far are visible to the solvers before any task names them)
       __builtin_amdgcn_wave_barrier();
@@ -452,10 +617,7 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
         dbgHit += __popcll(__ballot(lane < cnt && mySlot >= 0));
 #endif
         // solvers without a task in flight
-        unsigned freeW = 0;
-#pragma unroll
-        for (int w = 1; w < W; w++)
-          if (murty_flag_load(&spec->doneSeq[w]) == posted[w]) freeW |= 1u << w;
+        unsigned freeW = (unsigned)__ballot(lane >= 1 && lane <= NS && murty_flag_load(&spec->doneSeq[(lane >= 1 && lane <= NS) ? lane : 0]) == postedL);
         // a table slot for (X, c): a free one, else the oldest solved entry that does not belong to this pop; never one in flight
         auto take_slot = [&](const int X, const int c) -> int {
           const int rdy = (lane < MURTY_SPEC_SLOTS) ? murty_flag_load(&spec->ready[lane]) : 0;
@@ -475,9 +637,7 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
           if (lane == 0) { spec->taskNode[w] = X; spec->taskC[w] = c; spec->taskSlot[w] = e; }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           __builtin_amdgcn_wave_barrier();
-#pragma unroll
-          for (int ww = 1; ww < W; ww++)
-            if (ww == w) { posted[ww]++; if (lane == 0) murty_flag_store(&spec->taskSeq[ww], posted[ww]); }
+          if (lane == w) { postedL++; murty_flag_store(&spec->taskSeq[w], postedL); }
         };
         // this node's missing children: the first one stays with wave 0 (it has nothing else to do until they are all there),
         // the others go to free solvers
@@ -499,7 +659,7 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
           }
         }
         // solvers still free: children of the nodes next in the heap
-        for (int cand = 0; cand < 2 && freeW; cand++) {
+        for (int cand = 0; cand < MURTY_PEEK && freeW; cand++) {
           const int X = __builtin_amdgcn_readfirstlane(spec->peekNode[cand]);
           if (X < 0) continue;
           const int cntX = partitionMax - __builtin_amdgcn_readfirstlane(spec->peekPart[cand]);
@@ -518,6 +678,18 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
         // the children nobody took: solved here
         const int aPar = (lane < n) ? A.nodeA[(size_t)parent * MURTY_N + lane] : 0;
         const double termPar = (lane < n) ? C[lane * n + aPar] : 0.0;
+        unsigned exclPar = 0;
+        if constexpr (QUAD) exclPar = A.nodeExcl[parent];
+        // (quad search) what child 0 of the new node -- child c of `parent`, created at row nn = pp + c -- must not take in its
+        // first row, which is row nn again: the constraint walk (src/MurtyAlgorithm.cpp:247-265) visits the node itself, its
+        // parent, and goes on upwards for as long as the ancestor was created at the same row.  So: the node's own choice for
+        // row nn, and either everything child 0 of the parent must not take (c == 0: same row) or the parent's choice for row nn.
+        auto note_excl = [&](const int c, const int pn, const int aNew) {
+          if constexpr (QUAD) {
+            const unsigned ex = (1u << __builtin_amdgcn_readlane(aNew, pp + c)) | (c == 0 ? exclPar : (1u << __builtin_amdgcn_readlane(aPar, pp + c)));
+            if (lane == 0) A.nodeExcl[pn] = (unsigned short)ex;
+          }
+        };
         for (int c = 0; c < cnt; c++) {
           const int nn = pp + c, pn = nNodes + c;
           if (lane == 0) { A.nodeId[pn] = (unsigned char)nn; A.nodeParent[pn] = (short)parent; }
@@ -528,6 +700,7 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
           murty_solve_child<LDSN>(myTile, C, n, realNC, A, 0, parent, pp, c, pn, aPar, termPar, pushed, sAcc, aNew, prof);
           if (lane < n) A.nodeA[(size_t)pn * MURTY_N + lane] = (unsigned char)aNew;
           if (lane == 0) { sPushed[c] = pushed ? 1 : 0; sScore[c] = sAcc; }
+          note_excl(c, pn, aNew);
 #ifdef RFS_PROFILE
           dbgDirect++;
 #endif
@@ -547,6 +720,7 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
           const int aNew = spec->a[e][lane];
           if (lane < n) A.nodeA[(size_t)pn * MURTY_N + lane] = (unsigned char)aNew;
           if (lane == 0) { sPushed[c] = spec->pushed[e]; sScore[c] = spec->score[e]; }
+          note_excl(c, pn, aNew);
           if (lane == e) tNode = -1;   // the slot is free again
         }
       }
@@ -595,26 +769,31 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
 template <int W>
 __device__ __forceinline__ double murty_partition_sum_block(double *C, int n, int nR, int nC, MurtyArena &A, bool &ok, double *myTile, int *ctl,
                                                             double *sSum, double *sScore, unsigned char *sPushed, const int wave,
-                                                            MurtySpec *spec = nullptr) {
+                                                            MurtySpec *spec = nullptr, HQScratch *quadScratch = nullptr, double *sC = nullptr) {
   const double BIG_NEG = -1000.0;
   const int realNR = nR > n ? n : nR, realNC = nC > n ? n : nC;
   const int partitionMax = (realNR == n) ? n - 1 : realNR;
   if (threadIdx.x == 0) *sSum = 0.0;
+  auto onRoot = [&](double s) { if (s < BIG_NEG) return true; *sSum = exp(s); return false; };
+  auto onTop = [&](double st, int) { if (st < BIG_NEG) return true; *sSum += exp(st); return false; };
   if constexpr (W >= 2) {
     if (spec) {
-      murty_kbest_async<W, MURTY_LDS_N>(
-          C, n, partitionMax, realNC, MURTY_MAX_NODES, MURTY_KBEST, A, ok, myTile, ctl, sScore, sPushed, wave, spec,
-          [&](double s) { if (s < BIG_NEG) return true; *sSum = exp(s); return false; },
-          [&](double st, int) { if (st < BIG_NEG) return true; *sSum += exp(st); return false; });
+#if MURTY_QUAD
+      if (quadScratch && n <= HQ_N) {
+        murty_kbest_async<W, MURTY_LDS_N, true>(C, n, partitionMax, realNC, MURTY_MAX_NODES, MURTY_KBEST, A, ok, myTile, ctl, sScore, sPushed, wave, spec,
+                                                quadScratch, sC, onRoot, onTop);
+        return *sSum;
+      }
+#endif
+      murty_kbest_async<W, MURTY_LDS_N, false>(C, n, partitionMax, realNC, MURTY_MAX_NODES, MURTY_KBEST, A, ok, myTile, ctl, sScore, sPushed, wave, spec,
+                                               nullptr, nullptr, onRoot, onTop);
       return *sSum;
     }
   }
-  murty_kbest_block<W, MURTY_LDS_N>(
-      C, n, partitionMax, realNC, MURTY_MAX_NODES, MURTY_KBEST, A, ok, myTile, ctl, sScore, sPushed, wave,
-      [&](double s) { if (s < BIG_NEG) return true; *sSum = exp(s); return false; },
-      [&](double st, int) { if (st < BIG_NEG) return true; *sSum += exp(st); return false; });
+  murty_kbest_block<W, MURTY_LDS_N>(C, n, partitionMax, realNC, MURTY_MAX_NODES, MURTY_KBEST, A, ok, myTile, ctl, sScore, sPushed, wave, onRoot, onTop);
   return *sSum;
 }
+
 
 // One workgroup of MURTY_JOB_WAVES wavefronts per queued partition (jobs strided over the grid); the last workgroup to
 // finish multiplies every particle's factors into its weight, in partition (slot) order.  Q.count[0] = number of jobs,
@@ -683,6 +862,10 @@ __global__ __launch_bounds__(1024) void murty_order_kernel(MurtyQueue Q) {
     Q.order[atomicAdd(&hist[MURTY_N + 1 - n], 1)] = j;
   }
 }
+#ifndef MURTY_WAVES_PER_EU
+#define MURTY_WAVES_PER_EU 8   // <= 64 VGPRs: five six-wave workgroups per CU instead of three (see MURTY_JOB_WAVES)
+#endif
+__attribute__((amdgpu_waves_per_eu(MURTY_WAVES_PER_EU)))
 __global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err, double *weight, int N, double *sums,
                                                                          int normalize, ZArg zarg, double *dZ, int nZdoubles, int *hostSeen, int ordered) {
   // (a fused step carries the measurement set in its kernel arguments; the device copy the next predict reads is written here)
@@ -704,6 +887,15 @@ __global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQ
 #else
   MurtySpec *const spec = nullptr;
 #endif
+#if MURTY_QUAD && !defined(MURTY_NO_SPEC) && MURTY_JOB_WAVES >= 2
+  __shared__ HQScratch sQuad[4 * (MURTY_JOB_WAVES - 1)];
+  __shared__ double sJobC[HQ_N * HQ_N];
+  HQScratch *const quad = sQuad;
+  double *const jobC = sJobC;
+#else
+  HQScratch *const quad = nullptr;
+  double *const jobC = nullptr;
+#endif
   // (readfirstlane: tells the compiler the wave index is uniform, so that the whole search compiles to scalar control flow)
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   for (int jq = blockIdx.x; jq < nJobs; jq += gridDim.x) {
@@ -723,7 +915,7 @@ __global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQ
       murty_carve(MS.arena + (size_t)blockIdx.x * MS.jobBytes, A);
       bool ok;
       v = murty_partition_sum_block<MURTY_JOB_WAVES>(Q.mats + (size_t)j * MURTY_MAXN * MURTY_MAXN, n, J.nR, J.nC, A, ok, sTile[wave], sCtl, &sSum, sScore,
-                                                     sPushed, wave, spec);
+                                                     sPushed, wave, spec, quad, jobC);
       if (!ok && threadIdx.x == 0) atomicOr(err, ERRBIT_MURTY);
     }
     if (threadIdx.x == 0) Q.results[j] = v;
