@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(256) void stage_step_kernel(ZArg z, double *dZ, int
 }
 
 static inline int murty_alloc(MurtyQueue &Q, MurtyScratch &MS, int N) {
-  int maxJobs = 4 * N;   // (configs[4] queues 1.9 jobs per particle on average and up to ~2.2 on some seeds; 0.6 MB of arena per job)
+  int maxJobs = 4 * N;   // (configs[4] queues 1.9 jobs per particle on average and up to ~2.2 on some seeds; 0.7 MB of arena per resident workgroup)
   if (maxJobs < 256) maxJobs = 256;
   if (maxJobs > 8192) maxJobs = 8192;
   Q.maxJobs = maxJobs;
