@@ -38,6 +38,25 @@ def build(force=False, verbose=False, extra_flags=()):
     return LIB
 
 
+# Test support, not product: the library with the quarter-wave Hungarian solver switched on (hungarian_quad.h; measured slower than
+# the shipped one-wave solvers, DESIGN 8 -- tests/test_gpu_parity.py checks that it returns the same bits).  Built next to the
+# other test artefacts (git-ignored, travels to the GPU box).
+QUAD_LIB = os.path.join(ROOT, "tests", "support", "_build", "librfsgpu_quad.so")
+QUAD_FLAGS = ["-DMURTY_QUAD=1", "-DMURTY_JOB_WAVES=3", "-DMURTY_WAVES_PER_EU=3"]
+
+
+def build_quad_variant(force=False, verbose=False):
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "rfsgpu.h")]
+    if not force and os.path.exists(QUAD_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(QUAD_LIB) for d in deps):
+        return QUAD_LIB
+    os.makedirs(os.path.dirname(QUAD_LIB), exist_ok=True)
+    cmd = [hipcc()] + FLAGS + QUAD_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", QUAD_LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return QUAD_LIB
+
+
 SIM = os.path.join(HERE, "host", "rbphdslam2d_sim")
 SIM_FASTSLAM = os.path.join(HERE, "host", "fastslam2d_sim")
 SIM_VP = os.path.join(HERE, "host", "rbphdslam_vp")
