@@ -807,7 +807,7 @@ __device__ __forceinline__ double murty_partition_sum_block(double *C, int n, in
 // that lives on one GPU -- divides the weights by the sum right away.  One launch instead of three (Murty, sums, divide).
 __device__ __forceinline__ void step_post_tail(double *weight, int N, double *sums, int normalize) {
   if (!sums) return;
-  __shared__ double sA[MURTY_JOB_WAVES], sB[MURTY_JOB_WAVES];
+  __shared__ double sA[16], sB[16];   // (one entry per wave of the block, whatever it was launched with)
   __shared__ double sDiv;
   // (eight loads in flight per thread: one block sums the whole shard, and taken one at a time the ~16 dependent L2 round trips
   //  of a 2000-particle shard were most of this kernel's 7 us; the order of the additions is unchanged)
@@ -825,7 +825,7 @@ __device__ __forceinline__ void step_post_tail(double *weight, int N, double *su
   __syncthreads();
   if (threadIdx.x == 0) {
     double x = 0, y = 0;
-    for (int k = 0; k < MURTY_JOB_WAVES; k++) { x += sA[k]; y += sB[k]; }
+    for (int k = 0; k < (int)(blockDim.x >> 6); k++) { x += sA[k]; y += sB[k]; }
     sums[0] = x; sums[1] = y;
     sDiv = x;
   }
@@ -865,8 +865,16 @@ __global__ __launch_bounds__(1024) void murty_order_kernel(MurtyQueue Q) {
 #ifndef MURTY_WAVES_PER_EU
 #define MURTY_WAVES_PER_EU 8   // <= 64 VGPRs: five six-wave workgroups per CU instead of three (see MURTY_JOB_WAVES)
 #endif
-__attribute__((amdgpu_waves_per_eu(MURTY_WAVES_PER_EU)))
-__global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err, double *weight, int N, double *sums,
+#ifndef MURTY_LIGHT_WAVES
+#define MURTY_LIGHT_WAVES 4
+#endif
+// Two instances.  <MURTY_JOB_WAVES, MURTY_WAVES_PER_EU>: the one for filters that have shown Murty work.  <MURTY_LIGHT_WAVES, 0>
+// (four waves, the compiler's own register count, no scratch): what a filter WITHOUT Murty work launches as its post kernel
+// step after step -- the capped instance needs scratch memory set up for every wave it dispatches and costs 0.2 us more per
+// step for nothing.  Both do the same thing with whatever the queue holds.
+template <int W, int WAVES_PER_EU>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(WAVES_PER_EU > 0 ? WAVES_PER_EU : 1, WAVES_PER_EU > 0 ? WAVES_PER_EU : 8)))
+void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err, double *weight, int N, double *sums,
                                                                          int normalize, ZArg zarg, double *dZ, int nZdoubles, int *hostSeen, int ordered) {
   // (a fused step carries the measurement set in its kernel arguments; the device copy the next predict reads is written here)
   if (blockIdx.x == 0 && dZ)
@@ -876,19 +884,19 @@ __global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQ
     if (blockIdx.x == 0) step_post_tail(weight, N, sums, normalize);
     return;
   }
-  __shared__ double sTile[MURTY_JOB_WAVES][MURTY_LDS_N * MURTY_LDS_N];
+  __shared__ double sTile[W][MURTY_LDS_N * MURTY_LDS_N];
   __shared__ double sScore[MURTY_N];
   __shared__ double sSum;
   __shared__ int sCtl[8];
   __shared__ unsigned char sPushed[MURTY_N];
-#if !defined(MURTY_NO_SPEC) && MURTY_JOB_WAVES >= 2
+#if !defined(MURTY_NO_SPEC)
   __shared__ MurtySpec sSpec;
   MurtySpec *const spec = &sSpec;
 #else
   MurtySpec *const spec = nullptr;
 #endif
-#if MURTY_QUAD && !defined(MURTY_NO_SPEC) && MURTY_JOB_WAVES >= 2
-  __shared__ HQScratch sQuad[4 * (MURTY_JOB_WAVES - 1)];
+#if MURTY_QUAD && !defined(MURTY_NO_SPEC)
+  __shared__ HQScratch sQuad[4 * (W - 1)];
   __shared__ double sJobC[HQ_N * HQ_N];
   HQScratch *const quad = sQuad;
   double *const jobC = sJobC;
@@ -914,7 +922,7 @@ __global__ __launch_bounds__(64 * MURTY_JOB_WAVES) void murty_jobs_kernel(MurtyQ
       MurtyArena A;
       murty_carve(MS.arena + (size_t)blockIdx.x * MS.jobBytes, A);
       bool ok;
-      v = murty_partition_sum_block<MURTY_JOB_WAVES>(Q.mats + (size_t)j * MURTY_MAXN * MURTY_MAXN, n, J.nR, J.nC, A, ok, sTile[wave], sCtl, &sSum, sScore,
+      v = murty_partition_sum_block<W>(Q.mats + (size_t)j * MURTY_MAXN * MURTY_MAXN, n, J.nR, J.nC, A, ok, sTile[wave], sCtl, &sSum, sScore,
                                                      sPushed, wave, spec, quad, jobC);
       if (!ok && threadIdx.x == 0) atomicOr(err, ERRBIT_MURTY);
     }
@@ -1047,7 +1055,11 @@ static inline int murty_launch(MurtyQueue &Q, MurtyScratch &MS, Buffers &B, hipS
   //  and only then)
   const int ordered = (Q.order && (!hostSeen || *hostSeen != 0)) ? 1 : 0;
   if (ordered) murty_order_kernel<<<1, 1024, 0, stream>>>(Q);
-  murty_jobs_kernel<<<blocks, 64 * MURTY_JOB_WAVES, 0, stream>>>(Q, MS, B.err, B.weight, B.N, sums, normalize, za ? *za : none, za ? B.Z : nullptr, nZdoubles,
-                                                                 hostSeen, ordered);
+  if (hostSeen && *hostSeen == 0)
+    murty_jobs_kernel<MURTY_LIGHT_WAVES, 0><<<blocks, 64 * MURTY_LIGHT_WAVES, 0, stream>>>(Q, MS, B.err, B.weight, B.N, sums, normalize, za ? *za : none,
+                                                                                         za ? B.Z : nullptr, nZdoubles, hostSeen, ordered);
+  else
+    murty_jobs_kernel<MURTY_JOB_WAVES, MURTY_WAVES_PER_EU><<<blocks, 64 * MURTY_JOB_WAVES, 0, stream>>>(Q, MS, B.err, B.weight, B.N, sums, normalize,
+                                                                                                      za ? *za : none, za ? B.Z : nullptr, nZdoubles, hostSeen, ordered);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
