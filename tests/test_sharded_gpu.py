@@ -224,6 +224,28 @@ def test_bench_eight_ranks_share_the_gpu_end_to_end():
     assert m["bytes_migrated_total"] == m["rows_migrated_total"] * m["row_bytes"]
 
 
+def test_bench_rccl_calls_with_one_rank():
+    """The calls the judged N > 1 runs make over RCCL ("nccl": init, broadcast of the measurement set, the 2-double all-reduce on the
+    engine's stream, the divide by the device-resident total, all_to_all_single of packed particle rows with the device buffers)
+    executed on this 1-GPU box: bench.py's N > 1 path under a one-rank torchrun (RFS_BENCH_FORCE_DIST=1).  What it cannot show is
+    the transport between two devices."""
+    import json
+    import subprocess
+    env = dict(os.environ, RFS_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    env.pop("RFS_BENCH_SHARE_GPU", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["workload_key"] == "c3" and d["value"] > 0
+    m = d["config"]["resample_migration"]
+    assert "error" not in m, m
+    assert m["rows_migrated_total"] == 0 and np.array(m["rows_from_rank_to_rank"]).shape == (1, 1)
+
+
 @pytest.mark.parametrize("n_shards", [3, 8])
 def test_group_with_birth_candidate_lists_inherits_as_a_single_filter(pkg, n_shards):
     """A configuration that keeps birth-candidate lists (CountThreshold 3) over several shards: after forced global resamplings the
