@@ -82,6 +82,11 @@ def vp_case(case):
                 assert list(sd) == list(so) and list(kd) == list(ko), i
             for f in (dev, orc):
                 s = f.weight_sums(); f.normalize_weights(s[0])
+            if cyc >= 1:     # resampling + the next predict's inheritance of the per-slot lists, from the second cycle on
+                w = orc.get_weights()
+                plan = pkg.engine.systematic_resample_plan(w / w.sum(), float(rng_aux.random()))
+                for f in (dev, orc):
+                    f.resample_apply(plan)
         n_vp += 1
     except Exception as e:  # noqa: BLE001
         bad += 1
@@ -165,6 +170,32 @@ for case in range(n_cases):
             for i in range(n):
                 sc.assert_gm_close(dev.export_gm(i), orc.export_gm(i), tol[0], tol[1], ordered=True)
                 assert list(dev.export_birth_candidates(i)[2]) == list(orc.export_birth_candidates(i)[2])
+            # ... and what follows a resampling in the reference: the next predict's slot-ordered inheritance of the unused-
+            # measurement / candidate lists (RBPHDFilter.hpp:1005-1011), an update on the inherited state, the next resampling
+            for rep in range(2):
+                for f in (dev, orc):
+                    f.predict_map(True)
+                assert np.array_equal(dev.gm_sizes(), orc.gm_sizes())
+                for i in range(n):
+                    sc.assert_gm_close(dev.export_gm(i), orc.export_gm(i), tol[0], tol[1], ordered=True)
+                    md, cd, sd, kd = dev.export_birth_candidates(i)
+                    mo, co, so, ko = orc.export_birth_candidates(i)
+                    assert list(sd) == list(so) and list(kd) == list(ko), ("candidates after the inheriting predict", rep, i)
+                Z2 = scen["Z"] + 1e-3 * (n_cyc + rep)
+                dev.update_async(Z2); dev.synchronize()
+                orc.update(Z2)
+                wd, wo = dev.get_weights(), orc.get_weights()
+                np.testing.assert_allclose(wd / wd.sum(), wo / wo.sum(), rtol=1e-6 if indefinite else (1e-9 if "weighting_md" not in kw else 1e-8), atol=1e-300)
+                assert np.array_equal(dev.gm_sizes(), orc.gm_sizes())
+                for i in range(n):
+                    sc.assert_gm_close(dev.export_gm(i), orc.export_gm(i), tol[0], tol[1], ordered=True)
+                assert np.array_equal(dev.get_unused_masks(), orc.get_unused_masks())
+                for f in (dev, orc):
+                    s = f.weight_sums(); f.normalize_weights(s[0])
+                w = orc.get_weights()
+                plan = pkg.engine.systematic_resample_plan(w / w.sum(), float(rng_aux.random()))
+                for f in (dev, orc):
+                    f.resample_apply(plan)
             dev.save_state()
             dev.update_async(scen["Z"]); dev.synchronize()
             first = [dev.export_gm(i) for i in range(n)], dev.get_weights().copy()
