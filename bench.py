@@ -392,7 +392,10 @@ def main():
                 f.normalize_weights(0.0, sums_ptr, 1)
 
     if args.pmc_child:                    # the short run the parent profiles with rocprofv3 --pmc (no output, no baselines)
-        for k in range(13):
+        for k in range(3):
+            step(k)
+        f.synchronize()                   # (a filter that queues Murty partitions switches to its full post-kernel instance once the host has seen the flag)
+        for k in range(3, 13):
             step(k)
         f.synchronize()
         return
