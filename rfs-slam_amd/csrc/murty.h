@@ -145,27 +145,38 @@ __device__ __forceinline__ void murty_publish() {  // stores of one lane -> load
 // constraints of the partition chain (src/MurtyAlgorithm.cpp:247-265, incl. the dummy-column range test on the REDUCED
 // column index), then the solver.  False when the constraint row has no possibility left or the solver finds no
 // assignment.  LDT = leading dimension of Ct.  realNC == n switches the dummy-range rule off (FastSLAM's use).
-template <int LDT>
+// MASK (jobs of extended dimension <= 16, murty_kbest_async's SMALL form): the walk over the partition chain is replaced by
+// its result, kept per node by the search -- all of a child's negative constraints fall into its FIRST row (every chain step
+// has curPart == nn), so they are a set of job columns: `excl`.  Lane dj of the walk = the lane whose free column is the
+// excluded one (an excluded column is never one of the child's fixed columns: it is an ancestor's choice for row nn, and the
+// ancestor shares the child's rows 0..nn-1).
+template <int LDT, bool MASK = false>
 __device__ __forceinline__ bool murty_child_wave(double *Ct, const double *C, int n, int nn, int nFree, int pn, int parent, int colRemap,
                                                  unsigned long long freeCols, int realNC, MurtyArena &A, int &aTmp, unsigned char *queue,
-                                                 long long *prof) {
+                                                 long long *prof, const unsigned excl = 0u) {
   const double bigNumber = 10000.0;
   const int lane = threadIdx.x & 63;
   if (lane < nFree) {
 #pragma unroll 4
     for (int r = 0; r < nFree; r++) Ct[r * LDT + lane] = C[(nn + r) * n + colRemap];
   }
-  int current = pn, curPart = nn;
-  for (;;) {  // the walk is uniform (same loads on every lane)
-    const int next = (current == pn) ? parent : (int)A.nodeParent[current];
-    const int naCol = A.nodeA[(size_t)next * MURTY_N + curPart];
-    const int di = curPart - nn;
-    const int dj = __popcll(freeCols & ((1ull << naCol) - 1ull));
-    if (lane == dj || (dj >= realNC && lane >= realNC && lane < nFree)) Ct[di * LDT + lane] = -bigNumber;
-    current = next;
-    if (current == 0) break;
-    curPart = A.nodeId[current];
-    if (curPart < nn) break;
+  if constexpr (MASK) {
+    const bool hit = lane < nFree && ((excl >> colRemap) & 1u);
+    const bool dummy = __ballot(hit && lane >= realNC) != 0ull;
+    if (hit || (dummy && lane >= realNC && lane < nFree)) Ct[lane] = -bigNumber;
+  } else {
+    int current = pn, curPart = nn;
+    for (;;) {  // the walk is uniform (same loads on every lane)
+      const int next = (current == pn) ? parent : (int)A.nodeParent[current];
+      const int naCol = A.nodeA[(size_t)next * MURTY_N + curPart];
+      const int di = curPart - nn;
+      const int dj = __popcll(freeCols & ((1ull << naCol) - 1ull));
+      if (lane == dj || (dj >= realNC && lane >= realNC && lane < nFree)) Ct[di * LDT + lane] = -bigNumber;
+      current = next;
+      if (current == 0) break;
+      curPart = A.nodeId[current];
+      if (curPart < nn) break;
+    }
   }
   if (__ballot(lane < nFree && Ct[lane] != -bigNumber) == 0) return false;   // the constraint row is reduced row 0
   double s = 0;
@@ -201,10 +212,12 @@ __device__ __forceinline__ bool murty_root_wave(double *C, int n, MurtyArena &A,
 // Child c of node `par` (created at partition ppar): sub-problem, constraints, solution; aPar / termPar: the parent's
 // assignment and its terms, row r on lane r.  pn: the child's node number (only compared against in the constraint walk; a
 // child solved ahead of its parent's pop has none yet).  Out: pushed (a solution exists), its score and assignment.
-template <int LDSN>
+// MASK: `exclNode` = what child 0 of `par` must not take in its first row (the search's per-node set); a child c > 0 must not
+// take the parent's own choice for that row.
+template <int LDSN, bool MASK = false>
 __device__ __forceinline__ void murty_solve_child(double *myTile, const double *C, const int n, const int realNC, MurtyArena &A, const int wave, const int par,
                                                   const int ppar, const int c, const int pn, const int aPar, const double termPar, bool &pushed,
-                                                  double &sAcc, int &aNew, long long *prof) {
+                                                  double &sAcc, int &aNew, long long *prof, const unsigned exclNode = 0u) {
   const int lane = threadIdx.x & 63;
   const int nn = ppar + c;
   double fixedScore = 0;
@@ -217,9 +230,11 @@ __device__ __forceinline__ void murty_solve_child(double *myTile, const double *
   sAcc = 0;
   aNew = aPar;
   int aTmp = 0;
+  unsigned excl = 0u;
+  if constexpr (MASK) excl = (c == 0) ? exclNode : (1u << __builtin_amdgcn_readlane(aPar, nn));
   const bool okH = (nFree <= LDSN)
-                       ? murty_child_wave<LDSN>(myTile, C, n, nn, nFree, pn, par, colRemap, freeCols, realNC, A, aTmp, nullptr, prof)
-                       : murty_child_wave<MURTY_N>(A.Ct + (size_t)wave * MURTY_N * MURTY_N, C, n, nn, nFree, pn, par, colRemap, freeCols, realNC, A, aTmp, nullptr, prof);
+                       ? murty_child_wave<LDSN, MASK>(myTile, C, n, nn, nFree, pn, par, colRemap, freeCols, realNC, A, aTmp, nullptr, prof, excl)
+                       : murty_child_wave<MURTY_N, MASK>(A.Ct + (size_t)wave * MURTY_N * MURTY_N, C, n, nn, nFree, pn, par, colRemap, freeCols, realNC, A, aTmp, nullptr, prof, excl);
   if (okH) {
     const int ja = __shfl((lane < nFree) ? colRemap : 0, (lane < nFree) ? aTmp : 0, 64);
     const double term = (lane < nFree) ? C[(nn + lane) * n + ja] : 0.0;
@@ -515,11 +530,16 @@ __device__ __forceinline__ void murty_quad_solver_wave(const double *C, const in
 
 // QUAD: the job's extended dimension is <= 16 and the solver waves run murty_quad_solver_wave (NS = 4 (W - 1) mailboxes);
 // otherwise one mailbox per solver wave (hungarian_wave, any dimension up to MURTY_N).  The search is the same either way.
-template <int W, int LDSN, bool QUAD, class FRoot, class FTop>
+// SMALL (extended dimension <= 16): the job's table is read from a copy in LDS (`sC`, taken after the root's solve, which
+// rewrites the table in place) and the children's negative constraints come from the per-node sets (`nodeExcl`) instead of the
+// walk over the partition chain -- a child's set-up then waits for ONE round of global loads (the node's row, its partition
+// index, its set) instead of three to five dependent ones.
+template <int W, int LDSN, bool QUAD, bool SMALL, class FRoot, class FTop>
 __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitionMax, int realNC, int maxNodes, int maxK, MurtyArena &A, bool &ok,
                                                   double *myTile, int *ctl, double *sScore, unsigned char *sPushed, const int wave, MurtySpec *spec,
                                                   HQScratch *quadScratch, double *sC, FRoot onRoot, FTop onTop) {
   static_assert(W >= 2 && W <= MURTY_CT_WAVES, "one searching wave + at least one solver");
+  static_assert(SMALL || !QUAD, "the quarter-wave solvers need the small form");
   constexpr int NS = QUAD ? 4 * (W - 1) : (W - 1);
   static_assert(NS <= MURTY_VSOLVERS && NS < 32, "mailboxes");
   const int lane = threadIdx.x & 63;
@@ -531,13 +551,20 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
     double s = 0;
     const bool okr = murty_root_wave(C, n, A, a0, s, nullptr);
     if (lane == 0) {
-      if constexpr (QUAD) A.nodeExcl[0] = (unsigned short)(1u << a0);
+      if constexpr (SMALL) A.nodeExcl[0] = (unsigned short)(1u << a0);
       ctl[2] = 1; ctl[3] = okr ? 1 : 0; ctl[5] = okr ? 1 : 0;
       ctl[4] = (!okr || onRoot(s)) ? 1 : 0;
     }
   }
   __threadfence_block();
   __syncthreads();
+  const double *Cs = C;   // where the children read the table from
+  if constexpr (SMALL) {
+    // (every wave writes the same values and reads them after its own stores; nobody writes the table after the root)
+    for (int t = lane; t < n * n; t += 64) sC[t] = C[t];
+    murty_publish();
+    Cs = sC;
+  }
 #ifdef RFS_PROFILE
   long long hp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   int dbgHit = 0, dbgPosted = 0, dbgDirect = 0, dbgSpec = 0, dbgPops = 0;
@@ -565,11 +592,13 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
         const int e = __builtin_amdgcn_readfirstlane(spec->taskSlot[wave]);
         const int ppX = A.nodeId[X];
         const int aPar = (lane < n) ? A.nodeA[(size_t)X * MURTY_N + lane] : 0;
-        const double termPar = (lane < n) ? C[lane * n + aPar] : 0.0;
+        unsigned exclX = 0u;
+        if constexpr (SMALL) exclX = A.nodeExcl[X];
+        const double termPar = (lane < n) ? Cs[lane * n + aPar] : 0.0;
         bool pushed = false;
         double sAcc = 0;
         int aNew = aPar;
-        murty_solve_child<LDSN>(myTile, C, n, realNC, A, wave, X, ppX, c, 0x7ffe, aPar, termPar, pushed, sAcc, aNew, prof);
+        murty_solve_child<LDSN, SMALL>(myTile, Cs, n, realNC, A, wave, X, ppX, c, 0x7ffe, aPar, termPar, pushed, sAcc, aNew, prof, exclX);
         spec->a[e][lane] = (unsigned char)aNew;
         if (lane == 0) { spec->score[e] = sAcc; spec->pushed[e] = pushed ? 1 : 0; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -677,15 +706,15 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
         }
         // the children nobody took: solved here
         const int aPar = (lane < n) ? A.nodeA[(size_t)parent * MURTY_N + lane] : 0;
-        const double termPar = (lane < n) ? C[lane * n + aPar] : 0.0;
+        const double termPar = (lane < n) ? Cs[lane * n + aPar] : 0.0;
         unsigned exclPar = 0;
-        if constexpr (QUAD) exclPar = A.nodeExcl[parent];
-        // (quad search) what child 0 of the new node -- child c of `parent`, created at row nn = pp + c -- must not take in its
+        if constexpr (SMALL) exclPar = A.nodeExcl[parent];
+        // (small form) what child 0 of the new node -- child c of `parent`, created at row nn = pp + c -- must not take in its
         // first row, which is row nn again: the constraint walk (src/MurtyAlgorithm.cpp:247-265) visits the node itself, its
         // parent, and goes on upwards for as long as the ancestor was created at the same row.  So: the node's own choice for
         // row nn, and either everything child 0 of the parent must not take (c == 0: same row) or the parent's choice for row nn.
         auto note_excl = [&](const int c, const int pn, const int aNew) {
-          if constexpr (QUAD) {
+          if constexpr (SMALL) {
             const unsigned ex = (1u << __builtin_amdgcn_readlane(aNew, pp + c)) | (c == 0 ? exclPar : (1u << __builtin_amdgcn_readlane(aPar, pp + c)));
             if (lane == 0) A.nodeExcl[pn] = (unsigned short)ex;
           }
@@ -697,7 +726,7 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
           bool pushed = false;
           double sAcc = 0;
           int aNew = aPar;
-          murty_solve_child<LDSN>(myTile, C, n, realNC, A, 0, parent, pp, c, pn, aPar, termPar, pushed, sAcc, aNew, prof);
+          murty_solve_child<LDSN, SMALL>(myTile, Cs, n, realNC, A, 0, parent, pp, c, pn, aPar, termPar, pushed, sAcc, aNew, prof, exclPar);
           if (lane < n) A.nodeA[(size_t)pn * MURTY_N + lane] = (unsigned char)aNew;
           if (lane == 0) { sPushed[c] = pushed ? 1 : 0; sScore[c] = sAcc; }
           note_excl(c, pn, aNew);
@@ -778,15 +807,13 @@ __device__ __forceinline__ double murty_partition_sum_block(double *C, int n, in
   auto onTop = [&](double st, int) { if (st < BIG_NEG) return true; *sSum += exp(st); return false; };
   if constexpr (W >= 2) {
     if (spec) {
-#if MURTY_QUAD
-      if (quadScratch && n <= HQ_N) {
-        murty_kbest_async<W, MURTY_LDS_N, true>(C, n, partitionMax, realNC, MURTY_MAX_NODES, MURTY_KBEST, A, ok, myTile, ctl, sScore, sPushed, wave, spec,
-                                                quadScratch, sC, onRoot, onTop);
+      if (sC && n <= HQ_N) {
+        murty_kbest_async<W, MURTY_LDS_N, (MURTY_QUAD != 0), true>(C, n, partitionMax, realNC, MURTY_MAX_NODES, MURTY_KBEST, A, ok, myTile, ctl, sScore, sPushed, wave,
+                                                                   spec, quadScratch, sC, onRoot, onTop);
         return *sSum;
       }
-#endif
-      murty_kbest_async<W, MURTY_LDS_N, false>(C, n, partitionMax, realNC, MURTY_MAX_NODES, MURTY_KBEST, A, ok, myTile, ctl, sScore, sPushed, wave, spec,
-                                               nullptr, nullptr, onRoot, onTop);
+      murty_kbest_async<W, MURTY_LDS_N, false, false>(C, n, partitionMax, realNC, MURTY_MAX_NODES, MURTY_KBEST, A, ok, myTile, ctl, sScore, sPushed, wave, spec,
+                                                      nullptr, nullptr, onRoot, onTop);
       return *sSum;
     }
   }
@@ -897,11 +924,14 @@ void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err, double *weight, 
 #endif
 #if MURTY_QUAD && !defined(MURTY_NO_SPEC)
   __shared__ HQScratch sQuad[4 * (W - 1)];
-  __shared__ double sJobC[HQ_N * HQ_N];
   HQScratch *const quad = sQuad;
-  double *const jobC = sJobC;
 #else
   HQScratch *const quad = nullptr;
+#endif
+#if !defined(MURTY_NO_SPEC) && !defined(MURTY_NO_SMALL)
+  __shared__ double sJobC[HQ_N * HQ_N];   // the job's table for the small form (murty_kbest_async)
+  double *const jobC = sJobC;
+#else
   double *const jobC = nullptr;
 #endif
   // (readfirstlane: tells the compiler the wave index is uniform, so that the whole search compiles to scalar control flow)
