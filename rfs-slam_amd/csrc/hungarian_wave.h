@@ -25,22 +25,27 @@ __device__ __forceinline__ double dpp_keep_f64(double v) {
   const int hi = __builtin_amdgcn_update_dpp(h, h, CTRL, ROW_MASK, 0xf, false);
   return __hiloint2double(hi, lo);
 }
+// (v_min_f64 / v_max_f64 as they are: fmin() / fmax() put a canonicalising v_max_f64 v, v, v in front of every step -- six more
+//  fp64 instructions in a chain that is all latency.  They differ from fmin / fmax for signalling NaNs only, which arithmetic
+//  does not produce.)
+__device__ __forceinline__ double raw_min_f64(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double raw_max_f64(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ double wave_min_f64(double v) {
-  v = fmin(v, dpp_keep_f64<0xb1, 0xf>(v));   // quad_perm [1,0,3,2]
-  v = fmin(v, dpp_keep_f64<0x4e, 0xf>(v));   // quad_perm [2,3,0,1]
-  v = fmin(v, dpp_keep_f64<0x114, 0xf>(v));  // row_shr:4
-  v = fmin(v, dpp_keep_f64<0x118, 0xf>(v));  // row_shr:8
-  v = fmin(v, dpp_keep_f64<0x142, 0xa>(v));  // row_bcast:15
-  v = fmin(v, dpp_keep_f64<0x143, 0xc>(v));  // row_bcast:31 -> lane 63
+  v = raw_min_f64(v, dpp_keep_f64<0xb1, 0xf>(v));   // quad_perm [1,0,3,2]
+  v = raw_min_f64(v, dpp_keep_f64<0x4e, 0xf>(v));   // quad_perm [2,3,0,1]
+  v = raw_min_f64(v, dpp_keep_f64<0x114, 0xf>(v));  // row_shr:4
+  v = raw_min_f64(v, dpp_keep_f64<0x118, 0xf>(v));  // row_shr:8
+  v = raw_min_f64(v, dpp_keep_f64<0x142, 0xa>(v));  // row_bcast:15
+  v = raw_min_f64(v, dpp_keep_f64<0x143, 0xc>(v));  // row_bcast:31 -> lane 63
   return readlane_f64(v, 63);
 }
 __device__ __forceinline__ double wave_max_f64(double v) {
-  v = fmax(v, dpp_keep_f64<0xb1, 0xf>(v));
-  v = fmax(v, dpp_keep_f64<0x4e, 0xf>(v));
-  v = fmax(v, dpp_keep_f64<0x114, 0xf>(v));
-  v = fmax(v, dpp_keep_f64<0x118, 0xf>(v));
-  v = fmax(v, dpp_keep_f64<0x142, 0xa>(v));
-  v = fmax(v, dpp_keep_f64<0x143, 0xc>(v));
+  v = raw_max_f64(v, dpp_keep_f64<0xb1, 0xf>(v));
+  v = raw_max_f64(v, dpp_keep_f64<0x4e, 0xf>(v));
+  v = raw_max_f64(v, dpp_keep_f64<0x114, 0xf>(v));
+  v = raw_max_f64(v, dpp_keep_f64<0x118, 0xf>(v));
+  v = raw_max_f64(v, dpp_keep_f64<0x142, 0xa>(v));
+  v = raw_max_f64(v, dpp_keep_f64<0x143, 0xc>(v));
   return readlane_f64(v, 63);
 }
 // sum of v over lanes 0..n-1 added in lane order (the reference's serial loops), uniform result
@@ -50,6 +55,11 @@ __device__ __forceinline__ double wave_ordered_sum(double v, int n) {
   return acc;
 }
 
+// SCRATCH (Murty's children: the table is a private LDS tile nobody reads afterwards, and the caller computes the score from the
+// job's table itself): offset and greedy start run ROW-parallel -- lane x walks row x for its minimum, then for its offset-free
+// maximum and the LAST column holding it (what the reference's `>=` scan keeps) -- instead of one wave-wide max-reduction per
+// row, and the end of the solve neither re-adds the offset nor sums the cost.  Same lx, xy, yx out of the start; *cost = 0.
+template <bool SCRATCH = false>
 __device__ __forceinline__ bool hungarian_wave(double *C, int ld, int n, int &xyOut, double *cost, unsigned char *queue, long long *prof = nullptr) {
   const int lane = threadIdx.x & 63;
   const bool in = lane < n;
@@ -60,12 +70,46 @@ __device__ __forceinline__ bool hungarian_wave(double *C, int ld, int n, int &xy
   bool S = false, T = false, NS = false;
   int px = -1, py = -1;              // BFS parents: p[x], p[y + n]
   bool xq = false, yq = false;
+  double offset = 0;
+  if constexpr (SCRATCH) {
+    double *Crow = C + lane * ld;    // row `lane`
+    double mn = 0;
+    if (in)
+      for (int j = 0; j < n; j++) mn = raw_min_f64(mn, Crow[j]);
+    offset = wave_min_f64(mn);
+    double m = -1.0;                 // (every real cell is >= 0 once the offset is gone)
+    int yy = 0;
+    if (in)
+      for (int j = 0; j < n; j++) {
+        const double v = Crow[j] - offset;
+        Crow[j] = v;
+        if (v >= m) { m = v; yy = j; }
+      }
+    lx = in ? m : 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the rows written above are read by columns from here on
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int x = 0; x < n; x++) {    // step 1 (:162-190): the rows claim their columns in row order
+      const int yyx = __builtin_amdgcn_readlane(yy, x);
+      const int x_t = __builtin_amdgcn_readlane(yx, yyx);
+      bool keep = true;
+      if (x_t != -1) {
+        const double mx = readlane_f64(lx, x), c_t = readlane_f64(lx, x_t);   // c_t == C[x_t][yyx]: yyx is row x_t's maximum
+        keep = mx > c_t;
+        if (keep && lane == x_t) xy = -1;
+      }
+      if (keep) {
+        if (lane == x) xy = yyx;
+        if (lane == yyx) yx = x;
+      }
+    }
+  } else {
 
   // offset = min(0, min C); C -= offset (:128-160)
   double mn = 0;
   if (in)
     for (int x = 0; x < n; x++) mn = fmin(mn, Ccol[x * ld]);
-  const double offset = wave_min_f64(mn);
+  offset = wave_min_f64(mn);
   if (in)
     for (int x = 0; x < n; x++) Ccol[x * ld] -= offset;
 
@@ -90,6 +134,7 @@ __device__ __forceinline__ bool hungarian_wave(double *C, int ld, int n, int &xy
     }
   }
 
+  }
   bool pickFreeVertex = true;
   int root = 0;
 #ifdef RFS_PROFILE
@@ -104,6 +149,11 @@ __device__ __forceinline__ bool hungarian_wave(double *C, int ld, int n, int &xy
       S = false; T = false; NS = false;
       const unsigned long long fr = __ballot(in && xy == -1);
       if (fr == 0) {
+        if constexpr (SCRATCH) {
+          *cost = 0;
+          xyOut = xy;
+          return true;
+        }
         if (offset != 0 && in)
           for (int x = 0; x < n; x++) Ccol[x * ld] = Ccol[x * ld] + offset;
         const double mine = in ? Ccol[yx * ld] : 0.0;            // C[x][xy[x]] sits with the lane of column xy[x]

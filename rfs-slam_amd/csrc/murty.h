@@ -183,7 +183,7 @@ __device__ __forceinline__ bool murty_child_wave(double *Ct, const double *C, in
 #ifdef RFS_PROFILE
   const long long tH = (long long)__builtin_readcyclecounter();
 #endif
-  const bool okH = hungarian_wave(Ct, LDT, nFree, aTmp, &s, queue, prof);
+  const bool okH = hungarian_wave<true>(Ct, LDT, nFree, aTmp, &s, queue, prof);
 #ifdef RFS_PROFILE
   if (prof) { prof[1] += (long long)__builtin_readcyclecounter() - tH; prof[2]++; }
 #endif
