@@ -125,6 +125,63 @@ __device__ inline short heap_pop(short *h, int &len, const double *score) {
   return top;
 }
 
+// The same heap with its first MURTY_HEAP_LDS positions (node id + a copy of the node's score) in LDS, the rest in the arena as
+// above: libstdc++'s pop_heap walks the hole down to a leaf before it pushes the last element back up -- every level two ids and
+// then their two scores, dependent loads -- and with everything in global memory that walk was most of the ~14 k cycles a pop
+// cost the searching wave beside its solves (configs[4], dimension 12).  Same comparisons in the same order.
+#ifndef MURTY_HEAP_LDS
+#define MURTY_HEAP_LDS 512
+#endif
+struct MurtyHeap {
+  short *lid;            // [MURTY_HEAP_LDS] LDS
+  double *lsc;           // [MURTY_HEAP_LDS] LDS
+  short *gid;            // arena (positions >= MURTY_HEAP_LDS)
+  const double *gscore;  // arena: score by node id
+};
+__device__ __forceinline__ short mheap_id(const MurtyHeap &H, int pos) { return pos < MURTY_HEAP_LDS ? H.lid[pos] : H.gid[pos]; }
+__device__ __forceinline__ double mheap_sc(const MurtyHeap &H, int pos) { return pos < MURTY_HEAP_LDS ? H.lsc[pos] : H.gscore[H.gid[pos]]; }
+__device__ __forceinline__ void mheap_set(const MurtyHeap &H, int pos, short id, double sc) {
+  if (pos < MURTY_HEAP_LDS) { H.lid[pos] = id; H.lsc[pos] = sc; }
+  else H.gid[pos] = id;
+}
+__device__ inline void mheap_push(const MurtyHeap &H, int &len, short v, double sv) {   // sv == gscore[v], already stored there
+  int hole = len++;
+  int parent = (hole - 1) / 2;
+  while (hole > 0 && mheap_sc(H, parent) < sv) {
+    mheap_set(H, hole, mheap_id(H, parent), mheap_sc(H, parent));
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  mheap_set(H, hole, v, sv);
+}
+__device__ inline short mheap_pop(const MurtyHeap &H, int &len) {
+  const short top = mheap_id(H, 0);
+  len--;
+  if (len == 0) return top;
+  const short value = mheap_id(H, len);
+  const double vs = mheap_sc(H, len);
+  int hole = 0, second = 0;
+  while (second < (len - 1) / 2) {
+    second = 2 * (second + 1);
+    if (mheap_sc(H, second) < mheap_sc(H, second - 1)) second--;
+    mheap_set(H, hole, mheap_id(H, second), mheap_sc(H, second));
+    hole = second;
+  }
+  if ((len & 1) == 0 && second == (len - 2) / 2) {
+    second = 2 * (second + 1);
+    mheap_set(H, hole, mheap_id(H, second - 1), mheap_sc(H, second - 1));
+    hole = second - 1;
+  }
+  int parent = (hole - 1) / 2;
+  while (hole > 0 && mheap_sc(H, parent) < vs) {
+    mheap_set(H, hole, mheap_id(H, parent), mheap_sc(H, parent));
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  mheap_set(H, hole, value, vs);
+  return top;
+}
+
 // ---- one WAVEFRONT per Murty problem (hungarian_wave.h as the inner solver) --------------------------------------------
 // Row r's assignment lives on lane r, sub-problem tables are built a row per step with lane c writing column c, the node
 // pool and the heap are lane 0's (scalars broadcast with readfirstlane).  Same partition tree, heap discipline,
@@ -206,7 +263,7 @@ __device__ __forceinline__ bool murty_root_wave(double *C, int n, MurtyArena &A,
   return true;
 }
 #ifndef MURTY_LDS_N
-#define MURTY_LDS_N 24   // sub-problems up to this dimension are solved in a 4.5 KB LDS tile per wave (larger ones in the job's arena)
+#define MURTY_LDS_N 20   // sub-problems up to this dimension are solved in a 3.1 KB LDS tile per wave (larger ones in the job's arena); 24 until the heap moved into LDS
 #endif
 
 // Child c of node `par` (created at partition ppar): sub-problem, constraints, solution; aPar / termPar: the parent's
@@ -537,7 +594,7 @@ __device__ __forceinline__ void murty_quad_solver_wave(const double *C, const in
 template <int W, int LDSN, bool QUAD, bool SMALL, class FRoot, class FTop>
 __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitionMax, int realNC, int maxNodes, int maxK, MurtyArena &A, bool &ok,
                                                   double *myTile, int *ctl, double *sScore, unsigned char *sPushed, const int wave, MurtySpec *spec,
-                                                  HQScratch *quadScratch, double *sC, FRoot onRoot, FTop onTop) {
+                                                  HQScratch *quadScratch, double *sC, const MurtyHeap H, FRoot onRoot, FTop onTop) {
   static_assert(W >= 2 && W <= MURTY_CT_WAVES, "one searching wave + at least one solver");
   static_assert(SMALL || !QUAD, "the quarter-wave solvers need the small form");
   constexpr int NS = QUAD ? 4 * (W - 1) : (W - 1);
@@ -551,6 +608,7 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
     double s = 0;
     const bool okr = murty_root_wave(C, n, A, a0, s, nullptr);
     if (lane == 0) {
+      if (okr) { H.lid[0] = 0; H.lsc[0] = s; }      // (murty_root_wave pushed node 0 onto the arena's heap: position 0 lives in LDS here)
       if constexpr (SMALL) A.nodeExcl[0] = (unsigned short)(1u << a0);
       ctl[2] = 1; ctl[3] = okr ? 1 : 0; ctl[5] = okr ? 1 : 0;
       ctl[4] = (!okr || onRoot(s)) ? 1 : 0;
@@ -615,12 +673,12 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
     for (int k = 1; k < maxK && __builtin_amdgcn_readfirstlane(ctl[4]) == 0; k++) {
       if (lane == 0) {
         int hl = ctl[3];
-        const int parent = heap_pop(A.heap, hl, A.nodeScore);
+        const int parent = mheap_pop(H, hl);
         ctl[0] = parent; ctl[1] = A.nodeId[parent]; ctl[3] = hl;
         // the nodes a coming pop is most likely to take: the new top, then the better of its two children, then the other one
-        const int b1 = (hl > 0) ? (int)A.heap[0] : -1;
-        int b2 = (hl > 1) ? (int)A.heap[1] : -1, b3 = (hl > 2) ? (int)A.heap[2] : -1;
-        if (b3 >= 0 && A.nodeScore[b3] > A.nodeScore[b2]) { const int tmp = b2; b2 = b3; b3 = tmp; }
+        const int b1 = (hl > 0) ? (int)mheap_id(H, 0) : -1;
+        int b2 = (hl > 1) ? (int)mheap_id(H, 1) : -1, b3 = (hl > 2) ? (int)mheap_id(H, 2) : -1;
+        if (b3 >= 0 && mheap_sc(H, 2) > mheap_sc(H, 1)) { const int tmp = b2; b2 = b3; b3 = tmp; }
         spec->peekNode[0] = b1; spec->peekPart[0] = (b1 >= 0) ? (int)A.nodeId[b1] : 0;
         spec->peekNode[1] = b2; spec->peekPart[1] = (b2 >= 0) ? (int)A.nodeId[b2] : 0;
         spec->peekNode[2] = b3; spec->peekPart[2] = (b3 >= 0) ? (int)A.nodeId[b3] : 0;
@@ -766,14 +824,14 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
           for (int c = 0; c < cnt; c++)
             if (sPushed[c]) {
               A.nodeScore[nNodes + c] = sScore[c];
-              heap_push(A.heap, hl, (short)(nNodes + c), A.nodeScore);
+              mheap_push(H, hl, (short)(nNodes + c), sScore[c]);
             }
           ctl[2] = nNodes + (cnt > 0 ? cnt : 0);
           ctl[3] = hl;
           if (hl == 0) stop = 1;  // rank == -1
           else {
-            const int top = A.heap[0];
-            if (onTop(A.nodeScore[top], top)) stop = 1;
+            const int top = mheap_id(H, 0);
+            if (onTop(mheap_sc(H, 0), top)) stop = 1;
           }
         }
         ctl[4] = stop;
@@ -785,8 +843,8 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
     if (lane == 0) murty_flag_store(&spec->quit, 1);
 #ifdef RFS_PROFILE
     if (lane == 0 && (blockIdx.x & 255) == 7)
-      printf("murty block %d: n %d pops %d nodes %d; children from the table %d, posted at the pop %d, solved by wave 0 %d, ahead of a pop %d; wave 0 waited %lld of %lld cycles\n",
-             (int)blockIdx.x, n, dbgPops, ctl[2], dbgHit, dbgPosted, dbgDirect, dbgSpec, dbgWait, (long long)__builtin_readcyclecounter() - dbgT0);
+      printf("murty block %d: n %d pops %d nodes %d; children from the table %d, posted at the pop %d, solved by wave 0 %d, ahead of a pop %d; wave 0 waited %lld of %lld cycles; its own solves: %lld, cycles in the solver %lld (main loop %lld), trips %lld, BFS dequeues %lld, label updates %lld, sum of dimensions %lld\n",
+             (int)blockIdx.x, n, dbgPops, ctl[2], dbgHit, dbgPosted, dbgDirect, dbgSpec, dbgWait, (long long)__builtin_readcyclecounter() - dbgT0, hp[2], hp[1], hp[8], hp[4], hp[5], hp[6], hp[7]);
 #endif
   }
   __threadfence_block();
@@ -798,7 +856,8 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
 template <int W>
 __device__ __forceinline__ double murty_partition_sum_block(double *C, int n, int nR, int nC, MurtyArena &A, bool &ok, double *myTile, int *ctl,
                                                             double *sSum, double *sScore, unsigned char *sPushed, const int wave,
-                                                            MurtySpec *spec = nullptr, HQScratch *quadScratch = nullptr, double *sC = nullptr) {
+                                                            MurtySpec *spec = nullptr, HQScratch *quadScratch = nullptr, double *sC = nullptr, short *heapId = nullptr,
+                                                            double *heapSc = nullptr) {
   const double BIG_NEG = -1000.0;
   const int realNR = nR > n ? n : nR, realNC = nC > n ? n : nC;
   const int partitionMax = (realNR == n) ? n - 1 : realNR;
@@ -807,13 +866,14 @@ __device__ __forceinline__ double murty_partition_sum_block(double *C, int n, in
   auto onTop = [&](double st, int) { if (st < BIG_NEG) return true; *sSum += exp(st); return false; };
   if constexpr (W >= 2) {
     if (spec) {
+      const MurtyHeap H{heapId, heapSc, A.heap, A.nodeScore};
       if (sC && n <= HQ_N) {
         murty_kbest_async<W, MURTY_LDS_N, (MURTY_QUAD != 0), true>(C, n, partitionMax, realNC, MURTY_MAX_NODES, MURTY_KBEST, A, ok, myTile, ctl, sScore, sPushed, wave,
-                                                                   spec, quadScratch, sC, onRoot, onTop);
+                                                                   spec, quadScratch, sC, H, onRoot, onTop);
         return *sSum;
       }
       murty_kbest_async<W, MURTY_LDS_N, false, false>(C, n, partitionMax, realNC, MURTY_MAX_NODES, MURTY_KBEST, A, ok, myTile, ctl, sScore, sPushed, wave, spec,
-                                                      nullptr, nullptr, onRoot, onTop);
+                                                      nullptr, nullptr, H, onRoot, onTop);
       return *sSum;
     }
   }
@@ -928,6 +988,8 @@ void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err, double *weight, 
 #else
   HQScratch *const quad = nullptr;
 #endif
+  __shared__ double sHeapSc[MURTY_HEAP_LDS];   // the searching wave's heap, first positions (mheap_*)
+  __shared__ short sHeapId[MURTY_HEAP_LDS];
 #if !defined(MURTY_NO_SPEC) && !defined(MURTY_NO_SMALL)
   __shared__ double sJobC[HQ_N * HQ_N];   // the job's table for the small form (murty_kbest_async)
   double *const jobC = sJobC;
@@ -953,7 +1015,7 @@ void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err, double *weight, 
       murty_carve(MS.arena + (size_t)blockIdx.x * MS.jobBytes, A);
       bool ok;
       v = murty_partition_sum_block<W>(Q.mats + (size_t)j * MURTY_MAXN * MURTY_MAXN, n, J.nR, J.nC, A, ok, sTile[wave], sCtl, &sSum, sScore,
-                                                     sPushed, wave, spec, quad, jobC);
+                                                     sPushed, wave, spec, quad, jobC, sHeapId, sHeapSc);
       if (!ok && threadIdx.x == 0) atomicOr(err, ERRBIT_MURTY);
     }
     if (threadIdx.x == 0) Q.results[j] = v;
