@@ -628,9 +628,12 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
   int dbgHit = 0, dbgPosted = 0, dbgDirect = 0, dbgSpec = 0, dbgPops = 0;
   long long dbgWait = 0;
   const long long dbgT0 = (long long)__builtin_readcyclecounter();
+  long long sec[6] = {0, 0, 0, 0, 0, 0}, secT = dbgT0;   // search sections: pop + peeks, table look-up + posts, own solves, results from the table, push + stop rule
+#define MS_STAMP(i) do { const long long tn = (long long)__builtin_readcyclecounter(); sec[i] += tn - secT; secT = tn; } while (0)
   long long *const prof = hp;
 #else
   long long *const prof = nullptr;
+#define MS_STAMP(i) do { } while (0)
 #endif
   if (wave != 0) {
     if constexpr (QUAD) {
@@ -692,6 +695,7 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
 #ifdef RFS_PROFILE
       dbgPops++;
 #endif
+      MS_STAMP(0);
       if (!poolFull && cnt > 0) {
         // which children of this node are in the table (solved or being solved)?
         int mySlot = -1;
@@ -762,6 +766,7 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
 #endif
           }
         }
+        MS_STAMP(1);
         // the children nobody took: solved here
         const int aPar = (lane < n) ? A.nodeA[(size_t)parent * MURTY_N + lane] : 0;
         const double termPar = (lane < n) ? Cs[lane * n + aPar] : 0.0;
@@ -792,6 +797,7 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
           dbgDirect++;
 #endif
         }
+        MS_STAMP(2);
         // the others come out of the table
         for (int c = 0; c < cnt; c++) {
           if ((direct >> c) & 1ull) continue;
@@ -810,6 +816,7 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
           note_excl(c, pn, aNew);
           if (lane == e) tNode = -1;   // the slot is free again
         }
+        MS_STAMP(3);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
@@ -839,12 +846,15 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      MS_STAMP(4);
     }
     if (lane == 0) murty_flag_store(&spec->quit, 1);
 #ifdef RFS_PROFILE
     if (lane == 0 && (blockIdx.x & 255) == 7)
       printf("murty block %d: n %d pops %d nodes %d; children from the table %d, posted at the pop %d, solved by wave 0 %d, ahead of a pop %d; wave 0 waited %lld of %lld cycles; its own solves: %lld, cycles in the solver %lld (main loop %lld), trips %lld, BFS dequeues %lld, label updates %lld, sum of dimensions %lld\n",
              (int)blockIdx.x, n, dbgPops, ctl[2], dbgHit, dbgPosted, dbgDirect, dbgSpec, dbgWait, (long long)__builtin_readcyclecounter() - dbgT0, hp[2], hp[1], hp[8], hp[4], hp[5], hp[6], hp[7]);
+    if (lane == 0 && (blockIdx.x & 255) == 7)
+      printf("murty sections block %d n %d: pop+peeks %lld, look-up+posts %lld, own solves %lld, table results %lld, push+stop %lld cycles\n", (int)blockIdx.x, n, sec[0], sec[1], sec[2], sec[3], sec[4]);
 #endif
   }
   __threadfence_block();
