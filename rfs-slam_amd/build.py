@@ -42,7 +42,7 @@ def build(force=False, verbose=False, extra_flags=()):
 # the shipped one-wave solvers, DESIGN 8 -- tests/test_gpu_parity.py checks that it returns the same bits).  Built next to the
 # other test artefacts (git-ignored, travels to the GPU box).
 QUAD_LIB = os.path.join(ROOT, "tests", "support", "_build", "librfsgpu_quad.so")
-QUAD_FLAGS = ["-DMURTY_QUAD=1", "-DMURTY_JOB_WAVES=3", "-DMURTY_WAVES_PER_EU=3"]
+QUAD_FLAGS = ["-DMURTY_QUAD=1", "-DMURTY_JOB_WAVES=3", "-DMURTY_WAVES_PER_EU=3", "-DMURTY_HEAP_LDS=32"]   # (a 32-entry LDS heap front: the search's heap spills into the arena in the test)
 
 
 def build_quad_variant(force=False, verbose=False):

@@ -435,6 +435,19 @@ def test_murty_partitions_match_oracle(pkg, ob, sc):
     compare_weights(dev, orc)
 
 
+def test_murty_partitions_of_every_size_class_match_oracle(pkg, ob, sc):
+    """60 measurements, 60 evaluation points, a 12-sigma weighting gate: partitions of extended dimension 9 ... 51 in one update
+    (tools/murty_dims.py shows the histogram), i.e. every form of the device search -- the small form (<= 16: table in LDS,
+    per-node constraint sets), sub-problems in the 20 x 20 LDS tiles, and sub-problems in the job's arena (> 20)."""
+    scen = sc.make_scenario(16, 200, 60, seed=3, n_clutter=10, n_eval=60, weighting_md=12.0, weights=(0.8, 1.0))
+    dev, orc = make_pair(pkg, ob, sc, scen, cap=768)
+    for f in (dev, orc):
+        f.update_map(scen["Z"])
+        f.importance_weighting()
+    assert orc.murty_calls() > 40, "scenario does not reach the Murty path"
+    compare_weights(dev, orc)
+
+
 def test_cpp_host_driver_end_to_end(pkg):
     """The C++ host mirror (rfs-slam_amd/host/rbphd_filter.hpp) driving the device path through the C ABI on the
     shipped C1 configuration (cfg values of the reference's rbphdslam2dSim.xml): the map must converge."""
