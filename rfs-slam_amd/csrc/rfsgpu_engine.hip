@@ -685,6 +685,16 @@ static int launch_update_map(rfsgpu_filter *f) {
   }
   auto bytes = [&](int wpb) { return (size_t)RFS_Z_LDS_BYTES + (size_t)wpb * update_map_lds_bytes_per_wave(f->cap); };
   int rc;
+  // two waves per particle, the fused step's form of the phase (configs[1]: 47.0 -> 38.9 us, configs[2]'s shard: 106.8 -> 75.4 us
+  // against one wave per particle, four particles per workgroup); RFSGPU_UPDMAP_WPP=1 selects the one-wave kernels
+  const size_t bb = (size_t)RFS_Z_LDS_BYTES + update_map_block_lds_bytes(f->cap);
+  static const int wppEnv = [] { const char *e = getenv("RFSGPU_UPDMAP_WPP"); return e ? atoi(e) : 0; }();
+  if (wppEnv != 1 && bb <= 64 * 1024) {
+    if ((rc = set_lds(f, phd_update_map_block_kernel<2>, bb)) != RFSGPU_OK) return rc;
+    phd_update_map_block_kernel<2><<<f->N, 128, bb, f->stream>>>(f->B, f->P, f->cur, nZ, f->B.Z);
+    HIPCHK(hipGetLastError());
+    return RFSGPU_OK;
+  }
   if (bytes(4) <= 64 * 1024) {
     if ((rc = set_lds(f, phd_update_map_kernel<4>, bytes(4))) != RFSGPU_OK) return rc;
     phd_update_map_kernel<4><<<(f->N + 3) / 4, 256, bytes(4), f->stream>>>(f->B, f->P, f->cur, nZ, f->B.Z);

@@ -643,3 +643,15 @@ __global__ __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(UPDMAP
   if (i >= B.N) return;
   phd_update_map_particle(B, P, cur, nZ, i, lane, smem_raw, smem_raw + RFS_Z_LDS_BYTES + (size_t)wave * update_map_lds_bytes_per_wave(B.cap));
 }
+
+// The stand-alone kernel in the workgroup form: WPP waves per particle (phd_update_map_block, bit-identical to the single-wave
+// routine).  One wave per particle leaves a 2000-particle launch at two waves per SIMD; with two waves per particle the phase
+// hides its latencies as it does inside the fused step.
+template <int WPP>
+__global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(UPDMAP_WAVES_PER_EU, 4))) void phd_update_map_block_kernel(Buffers B, Params P, int cur, int nZ, const double *__restrict__ Zg) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  stage_measurements_lds(smem_raw, [&](int t) { return Zg[t]; }, nZ, (int)threadIdx.x, WPP * 64);
+  __syncthreads();
+  phd_update_map_block<WPP>(B, P, cur, nZ, (int)blockIdx.x, (int)threadIdx.x, smem_raw, smem_raw + RFS_Z_LDS_BYTES);
+}
+
