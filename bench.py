@@ -484,7 +484,7 @@ def main():
         sweep = None
         if sweep_ms:
             g = bytes_sweep / (sweep_ms * 1e-3) / 1e9
-            sweep = dict(kernel=("vp_update_map_kernel" if vp else "phd_update_map_block_kernel<2>") + " (stand-alone form, untimed pass)", ms=round(sweep_ms, 5), algorithmic_bytes=int(bytes_sweep),
+            sweep = dict(kernel=("vp_update_map_kernel" if vp else "phd_update_map_block_kernel") + " (stand-alone form, untimed pass)", ms=round(sweep_ms, 5), algorithmic_bytes=int(bytes_sweep),
                          achieved_GBps=round(g, 2), frac=round(g / HBM_PEAK_GBS, 6))
         # the dominant kernel: the fused step, except where the Murty-200 post kernel outweighs it (configs[4])
         murty_dominant = fused and post_ms > float(kern_ms[0])

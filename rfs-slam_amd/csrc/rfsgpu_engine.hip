@@ -685,13 +685,24 @@ static int launch_update_map(rfsgpu_filter *f) {
   }
   auto bytes = [&](int wpb) { return (size_t)RFS_Z_LDS_BYTES + (size_t)wpb * update_map_lds_bytes_per_wave(f->cap); };
   int rc;
-  // two waves per particle, the fused step's form of the phase (configs[1]: 47.0 -> 38.9 us, configs[2]'s shard: 106.8 -> 75.4 us
-  // against one wave per particle, four particles per workgroup); RFSGPU_UPDMAP_WPP=1 selects the one-wave kernels
+  // The workgroup form of the phase (the fused step's), several waves per particle: two up to capacity 512, four above (a pass
+  // covers 64 landmarks per wave).  configs[1] (cap 384): 47.0 us with the one-wave kernel, 38.9 with two waves, 57.4 with three,
+  // 43.7 with four; configs[2]'s shard (cap 640): 106.8 / 75.4 / 77.1 / 67.8.  RFSGPU_UPDMAP_WPP = 1 .. 4 overrides (1: the
+  // one-wave kernels below).
   const size_t bb = (size_t)RFS_Z_LDS_BYTES + update_map_block_lds_bytes(f->cap);
   static const int wppEnv = [] { const char *e = getenv("RFSGPU_UPDMAP_WPP"); return e ? atoi(e) : 0; }();
-  if (wppEnv != 1 && bb <= 64 * 1024) {
-    if ((rc = set_lds(f, phd_update_map_block_kernel<2>, bb)) != RFSGPU_OK) return rc;
-    phd_update_map_block_kernel<2><<<f->N, 128, bb, f->stream>>>(f->B, f->P, f->cur, nZ, f->B.Z);
+  const int wppU = (wppEnv >= 1 && wppEnv <= 4) ? wppEnv : (f->cap > 512 ? 4 : 2);
+  if (wppU != 1 && bb <= 64 * 1024) {
+    if (wppU == 2) {
+      if ((rc = set_lds(f, phd_update_map_block_kernel<2>, bb)) != RFSGPU_OK) return rc;
+      phd_update_map_block_kernel<2><<<f->N, 128, bb, f->stream>>>(f->B, f->P, f->cur, nZ, f->B.Z);
+    } else if (wppU == 3) {
+      if ((rc = set_lds(f, phd_update_map_block_kernel<3>, bb)) != RFSGPU_OK) return rc;
+      phd_update_map_block_kernel<3><<<f->N, 192, bb, f->stream>>>(f->B, f->P, f->cur, nZ, f->B.Z);
+    } else {
+      if ((rc = set_lds(f, phd_update_map_block_kernel<4>, bb)) != RFSGPU_OK) return rc;
+      phd_update_map_block_kernel<4><<<f->N, 256, bb, f->stream>>>(f->B, f->P, f->cur, nZ, f->B.Z);
+    }
     HIPCHK(hipGetLastError());
     return RFSGPU_OK;
   }
