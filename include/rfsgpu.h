@@ -319,6 +319,10 @@ int rfsgpu_kernel_time_stats(rfsgpu_filter *f, double *avg_ns3, int *n_steps);
 /* Average duration (ns) of the step's post kernel (Murty-200 partitions when any were queued, queue reset, weight sums /
  * division) over the fused steps the last rfsgpu_kernel_time_stats call covered. */
 double rfsgpu_post_kernel_avg_ns(const rfsgpu_filter *f);
+/* The HIP events behind the two calls above ride on every `every`-th fused stream-ordered step only (default 1: on each).  Three
+ * event records per step cost a step of configs[1] 8 us of its 144 (each is a marker packet the queue drains before the next
+ * kernel starts); bench.py samples every 8th step of its timed region.  Statistics average over the sampled steps. */
+int rfsgpu_set_step_timing_stride(rfsgpu_filter *f, int every);
 /* The same four phases one at a time (used by the parity tests and by profiling):          */
 int rfsgpu_update_map(rfsgpu_filter *f, const double *z, int n_z);      /* updateMap       :543-725 */
 int rfsgpu_importance_weighting(rfsgpu_filter *f);                       /* importanceWeighting :728-997 */

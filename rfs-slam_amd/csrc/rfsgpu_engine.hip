@@ -103,6 +103,8 @@ struct rfsgpu_filter {
   bool fuseSteps = true;    // rfsgpu_update / _update_async / _step_async use phd_step_fused_kernel (2-D model); RFSGPU_FUSED_STEP=0 turns it off
   bool phaseTiming = false; // rfsgpu_set_phase_timing: rfsgpu_update runs its phases as separate launches (TimingInfo per phase)
   int stepWppOverride = 0;  // RFSGPU_STEP_WPP: waves per particle of the fused step kernel (2 or 3); 0 = chosen per launch
+  unsigned stepSeq = 0;      // fused steps launched so far
+  int timingStride = 1;      // every timingStride-th of them carries the timing events (rfsgpu_set_step_timing_stride)
   int mergeGridOverride = 0; // RFSGPU_MERGE_GRID: log2 of the merge grid's cells per side in the three-wave fused kernel (5 or 6); 0 = chosen per launch
   hipEvent_t evAfterWeightKernel = nullptr;   // where launch_weighting drops its mid-phase event (async steps only)
   int ringCount = 0;        // async steps recorded since the last harvest
@@ -961,7 +963,8 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
     memcpy(za.v, z, (size_t)n_z * 2 * sizeof(double));
     f->nZ = n_z;
     if (n_z > 0) f->resampleOccured = false;
-    HIPCHK(hipEventRecord(e[0], f->stream));
+    const bool timed = (f->stepSeq++ % (unsigned)f->timingStride) == 0;   // (rfsgpu_set_step_timing_stride)
+    if (timed) HIPCHK(hipEventRecord(e[0], f->stream));
     const int ec = eval_cap(f), useW = f->cfg.useClusterProcess ? 0 : 1;
     // Waves per particle: two, unless the two-wave grid cannot be resident at once (large mixtures: the LDS block limits the
     // workgroups per CU) -- then three waves per particle finish each workgroup sooner and free its slot (measured on the
@@ -1000,12 +1003,14 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
       }
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(e[3], f->stream));
+    if (timed) HIPCHK(hipEventRecord(e[3], f->stream));
     if (murty_launch(f->Q, f->MS, f->B, f->stream, with_sums ? f->dSums : nullptr, normalize, &za, 2 * n_z, f->hJobCount) != 0) return fail(f, RFSGPU_ERR_HIP, "post kernel launch failed");
-    HIPCHK(hipEventRecord(e[1], f->stream));
+    if (timed) HIPCHK(hipEventRecord(e[1], f->stream));
     f->cur ^= 1;  // the map update works in place, the weighting phase leaves only a permutation in LDS, merge + prune write the other slab
-    f->ringFused[f->ringCount] = true;
-    f->ringCount++;
+    if (timed) {
+      f->ringFused[f->ringCount] = true;
+      f->ringCount++;
+    }
     f->timing.mapUpdate_cpu += now_ns() - t0;
     return RFSGPU_OK;
   }
@@ -1020,7 +1025,8 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
     memcpy(za.v, z, (size_t)n_z * 3 * sizeof(double));
     f->nZ = n_z;
     if (n_z > 0) f->resampleOccured = false;
-    HIPCHK(hipEventRecord(e[0], f->stream));
+    const bool timed = (f->stepSeq++ % (unsigned)f->timingStride) == 0;
+    if (timed) HIPCHK(hipEventRecord(e[0], f->stream));
     const int ec = eval_cap(f), useW = f->cfg.useClusterProcess ? 0 : 1;
     const size_t shared = vp_shared_lds_bytes(f->nZ, f->B.nScan), per = vp_step_lds_bytes_per_wave(f->cap, ec, f->nZ);
     if (shared + 2 * per <= (size_t)64 * 1024) {
@@ -1033,12 +1039,14 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
       vp_step_fused_kernel<1><<<f->N, 64, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(e[3], f->stream));
+    if (timed) HIPCHK(hipEventRecord(e[3], f->stream));
     if (murty_launch(f->Q, f->MS, f->B, f->stream, with_sums ? f->dSums : nullptr, normalize, &za, 3 * n_z, f->hJobCount) != 0) return fail(f, RFSGPU_ERR_HIP, "post kernel launch failed");
-    HIPCHK(hipEventRecord(e[1], f->stream));
+    if (timed) HIPCHK(hipEventRecord(e[1], f->stream));
     f->cur ^= 1;
-    f->ringFused[f->ringCount] = true;
-    f->ringCount++;
+    if (timed) {
+      f->ringFused[f->ringCount] = true;
+      f->ringCount++;
+    }
     f->timing.mapUpdate_cpu += now_ns() - t0;
     return RFSGPU_OK;
   }
@@ -1097,6 +1105,12 @@ int rfsgpu_kernel_time_stats(rfsgpu_filter *f, double *avg_ns3, int *n_steps) {
 // Average duration (ns) of the step's POST kernel (murty_jobs_kernel: the Murty-200 partitions when the queue is not empty, queue
 // reset, weight sums / division) over the fused steps covered by the last rfsgpu_kernel_time_stats call.
 double rfsgpu_post_kernel_avg_ns(const rfsgpu_filter *f) { return f ? f->lastPostNs : 0.0; }
+int rfsgpu_set_step_timing_stride(rfsgpu_filter *f, int every) {
+  CHECK_HANDLE(f);
+  if (every < 1) return fail(f, RFSGPU_ERR_INVALID, "the timing stride is at least 1");
+  f->timingStride = every;
+  return RFSGPU_OK;
+}
 
 // The birth + static-step launches of one predict.  LV selects the particles whose birth step runs (birth.h).
 static void launch_predict_kernels(rfsgpu_filter *f, int add_birth, const BirthLevel &LV) {

@@ -88,6 +88,10 @@ class RBPHDFilter(capi.CFilter):
         fn.restype = C.c_double
         return float(fn(self._h))
 
+    def set_step_timing_stride(self, every):
+        """HIP events (kernel_time_stats / post_kernel_avg_ns) on every `every`-th fused stream-ordered step only."""
+        self._call("set_step_timing_stride", C.c_int(int(every)))
+
     def weight_sums_async(self):
         self._call("weight_sums_async")
 
