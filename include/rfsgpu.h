@@ -302,24 +302,14 @@ int rfsgpu_propagate_ackerman_async(rfsgpu_filter *f, const double *u, const dou
  * call0 + 1, ...) in ONE launch; every particle takes the steps one after the other: the same poses, bit for bit. */
 int rfsgpu_propagate_ackerman_run_async(rfsgpu_filter *f, int n, const double *u, const double *var, const double *dt, const double *geom,
                                         unsigned long long seed, unsigned long long call0);
-/* ParticleFilter::propagate (include/ParticleFilter.hpp:322-339) for the Victoria Park driver's process model, on the device:
- * MotionModel_Ackerman2d::step (src/ProcessModel_Ackerman2D.cpp:47-78) applied to every particle's pose with its own noisy
- * input u + N(0, diag(var)) (ProcessModel::sample's input-noise branch, include/ProcessModel.hpp:126-150).  u = {speed,
- * steering angle}; var = their variances (NULL: no noise); geom = {h, l, dx, dy} (setAckermanParams).  The normal deviates come
- * from Philox4x32-10 keyed by `seed` with counter (particle, call): the reference's single serial boost stream has no parallel
- * form, the distribution is what is kept (csrc/motion.h).  Stream-ordered, no host wait.  OPTIONAL: a host that keeps the
- * reference's own ParticleFilter::propagate sends poses with rfsgpu_set_poses / rfsgpu_set_step_inputs_async instead; the
- * Victoria Park driver of this repository uses it because its host loop, not a kernel, was what bounded a run. */
-int rfsgpu_propagate_ackerman_async(rfsgpu_filter *f, const double *u, const double *var, double dt, const double *geom, unsigned long long seed,
-                                    unsigned long long call);
-/* Average duration (ns) of each hot-path kernel group over the async steps harvested since the last call / reset:
+/* [bench] Average duration (ns) of each hot-path kernel group over the async steps harvested since the last call / reset:
  * [0]=phd_update_map [1]=phd_weight_multifeature [2]=gm_merge(+prune); *n_steps = steps averaged.  Steps that ran as one
  * fused kernel report its duration in [0] and 0 in [1], [2] (their TimingInfo share is booked under mapUpdate). */
 int rfsgpu_kernel_time_stats(rfsgpu_filter *f, double *avg_ns3, int *n_steps);
-/* Average duration (ns) of the step's post kernel (Murty-200 partitions when any were queued, queue reset, weight sums /
+/* [bench] Average duration (ns) of the step's post kernel (Murty-200 partitions when any were queued, queue reset, weight sums /
  * division) over the fused steps the last rfsgpu_kernel_time_stats call covered. */
 double rfsgpu_post_kernel_avg_ns(const rfsgpu_filter *f);
-/* The HIP events behind the two calls above ride on every `every`-th fused stream-ordered step only (default 1: on each).  Three
+/* [bench] The HIP events behind the two calls above ride on every `every`-th fused stream-ordered step only (default 1: on each).  Three
  * event records per step cost a step of configs[1] 8 us of its 144 (each is a marker packet the queue drains before the next
  * kernel starts); bench.py samples every 8th step of its timed region.  Statistics average over the sampled steps. */
 int rfsgpu_set_step_timing_stride(rfsgpu_filter *f, int every);
