@@ -444,7 +444,6 @@ def main():
 
     f.synchronize()                  # raises if any step overflowed / hit an unsupported case
     ka, n_timed = f.kernel_time_stats()    # HIP-event pairs recorded on the engine's stream inside the timed region (every timing_stride-th step)
-    f.set_step_timing_stride(1)
     kern_ms = np.array(ka) / 1e6
     post_ms = f.post_kernel_avg_ns() / 1e6     # the step's post kernel (Murty-200 partitions when queued, weight sums, division)
     ms_per_step = dt / args.steps * 1e3
@@ -464,6 +463,7 @@ def main():
         dist.all_reduce(st, op=dist.ReduceOp.MAX)
         solo = args.steps / float(st.item())
         f.synchronize(); f.kernel_time_stats()
+    f.set_step_timing_stride(1)
 
     # per-phase breakdown (and the likelihood-sweep rate the north star asks for): the three stand-alone kernels, HIP events,
     # untimed pass after the region
