@@ -13,7 +13,7 @@ f = pkg.RBPHDFilter(n, gm_capacity=384)
 sc.load_scenario(f, scen)
 f.save_state()
 Z = scen["Z"]
-for _ in range(20):
+for _ in range(600):          # (a fresh process spends its first ~100 ms at low clocks: a 200-particle loop measured 260 us per call there, 131 afterwards)
     f.restore_state(); f.update(Z)
 S = 300
 t0 = time.perf_counter()
