@@ -400,7 +400,7 @@ def main():
         f.synchronize()
         return
 
-    for k in range(args.warmup):
+    for k in range(2):
         step(k)
     # shapes for the algorithmic byte counts (one instrumented step, untimed)
     if wl["reseed"]:
@@ -412,8 +412,18 @@ def main():
     nKept = int(f.gm_sizes().sum())
     if not wl["reseed"]:
         f.restore_state()
-        for k in range(args.warmup):
-            step(k)
+    # Untimed, right before the timed region (the instrumented pass above waits on the host and lets the GPU idle): a fresh
+    # process spends its first ~100 ms of GPU work at low clocks (tools/sync_update_bench.py: 260 us per call there, 131
+    # afterwards), so steps for 0.25 s first -- `pre_warmup_steps` in the JSON -- and then the W warm-up steps the caller asked for.
+    pre_warm = 0
+    t_pw = time.perf_counter()
+    while time.perf_counter() - t_pw < 0.25:
+        for k in range(8):
+            step(pre_warm + k)
+        pre_warm += 8
+        f.synchronize()
+    for k in range(args.warmup):
+        step(pre_warm + k)
     bytes_sweep, bytes_step = survey_bytes(n_local, nM, nAfter - nM, nKept, N_Z, BG, DZ)
     dbytes = dict(zip(kernels, design_bytes(n_local, nM, nAfter - nM, nKept, N_Z, BG).values()))
 
@@ -421,8 +431,8 @@ def main():
     f.kernel_time_stats()            # discard the warm-up statistics
     # The kernel durations behind `roofline` come from HIP events on the engine's stream inside the timed region.  Three event
     # records per step cost a C2a step 8 us of its 144 (each is a marker packet the queue drains before the next kernel
-    # starts), so a run long enough to leave 16+ samples carries them on every 8th step only; the statistics average over those.
-    timing_stride = 8 if args.steps >= 128 else 1
+    # starts), so they ride on every 8th step only (every (K // 4)-th for K < 32 steps); the statistics average over those.
+    timing_stride = min(8, max(1, args.steps // 4))
     f.set_step_timing_stride(timing_stride)
     if multi:
         dist.barrier()
@@ -531,6 +541,7 @@ def main():
                 "workload_key": wname,
                 "particles_total": n_local * world,
                 "gm_capacity": CAP,
+                "pre_warmup_steps": pre_warm,      # untimed clock-ramp steps (0.25 s) ahead of the W warm-up steps
                 "unit_definition": "one step = one update(Z) of one shard of %d particles; value sums the shard-steps of all ranks "
                                    "(global filter of %d particles: %.3f updates/s)" % (n_local, n_local * world, args.steps / dt),
                 "parallelism": f"particle-sharded: {world} GPU(s), one process per GPU, RCCL all-reduce of 2 doubles/step on the engine's stream",
