@@ -415,13 +415,20 @@ def main():
     # Untimed, right before the timed region (the instrumented pass above waits on the host and lets the GPU idle): a fresh
     # process spends its first ~100 ms of GPU work at low clocks (tools/sync_update_bench.py: 260 us per call there, 131
     # afterwards), so steps for 0.25 s first -- `pre_warmup_steps` in the JSON -- and then the W warm-up steps the caller asked for.
-    pre_warm = 0
+    # (the count comes from eight timed steps, agreed over the ranks: every rank must run the same number of collectives)
     t_pw = time.perf_counter()
-    while time.perf_counter() - t_pw < 0.25:
-        for k in range(8):
-            step(pre_warm + k)
-        pre_warm += 8
-        f.synchronize()
+    for k in range(8):
+        step(k)
+    f.synchronize()
+    t8 = time.perf_counter() - t_pw
+    if multi:
+        tt = torch.tensor([t8], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t8 = float(tt.item())
+    pre_warm = 8 + 8 * int(min(1024, max(0.0, 0.25 / max(t8 / 8, 1e-6)) // 8))
+    for k in range(8, pre_warm):
+        step(k)
+    f.synchronize()
     for k in range(args.warmup):
         step(pre_warm + k)
     bytes_sweep, bytes_step = survey_bytes(n_local, nM, nAfter - nM, nKept, N_Z, BG, DZ)
