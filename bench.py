@@ -289,7 +289,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None, help="default: c2a at --gpus 1, c3 (configs[2]'s shard) at --gpus N > 1")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None, help="default: c2a (configs[1]'s shape per GPU) at every --gpus N; c3 = configs[2]'s shard (--workload c3 --gpus 8 is configs[2])")
     ap.add_argument("--particles", type=int, default=None, help="particles per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 PMC child runs (roofline.traffic = null)")
@@ -331,7 +331,10 @@ def main():
     pkg = load_package()
     sc = pkg.scenarios
 
-    wname = args.workload or ("c2a" if not multi else "c3")
+    # The SAME per-GPU work at every N (weak scaling): configs[1]'s shape -- the configuration the metric is quoted on -- on each
+    # rank, so that value(N) / (N * value(1)) compares like with like.  (Until late in round 3 the N > 1 default was configs[2]'s
+    # shard, 2500 x 500 per rank: 1.9x the work of the N = 1 line per GPU.)  configs[2] itself: --workload c3 --gpus 8.
+    wname = args.workload or "c2a"
     wl = WORKLOADS[wname]
     n_local = args.particles or wl["n"]
     CAP = wl["cap"]
@@ -586,7 +589,6 @@ def main():
             out["config"]["ms_per_step_p90"] = round(float(np.percentile(d, 90)), 5)
         if solo is not None:
             out["config"]["same_workload_single_shard_steps_per_s"] = round(solo, 3)
-            out["config"]["weak_scaling_efficiency_vs_own_shard_alone"] = round((world * args.steps / dt) / (world * solo), 4)
         if not args.no_cpu_baseline and not multi:      # (rank 0 at N = 1 only)
             out["cpu_baseline"] = cpu_baseline(wname, n_local, args.particles)
     else:

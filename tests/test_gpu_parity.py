@@ -1440,6 +1440,7 @@ def test_bench_two_ranks_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 6 and d["warmup"] == 2
     assert d["config"]["particles_total"] == 512
+    assert d["config"]["workload_key"] == "c2a"       # the same per-GPU shape as the N = 1 line (weak scaling of configs[1])
     assert abs(d["value"] - 2 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-2 * d["value"]
     assert d["roofline"]["frac"] > 0
 

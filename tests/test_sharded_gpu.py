@@ -199,7 +199,7 @@ def test_configs2_whole_as_eight_shards_on_one_device(pkg):
 
 
 def test_bench_eight_ranks_share_the_gpu_end_to_end():
-    """bench.py --gpus 8 (configs[2]: eight ranks x 2500 particles x 500 landmarks, the driver's launch line) with the eight ranks sharing
+    """bench.py --workload c3 --gpus 8 (configs[2]: eight ranks x 2500 particles x 500 landmarks) with the eight ranks sharing
     this box's GPU over gloo (RFS_BENCH_SHARE_GPU=1): the timed region, the weak-scaling reference, and the forced global resampling
     with migration -- every rank's per-peer row counts (the all-to-all's split lists) come back in the JSON: some pairs exchange
     nothing, the totals balance."""
@@ -207,7 +207,7 @@ def test_bench_eight_ranks_share_the_gpu_end_to_end():
     import subprocess
     env = dict(os.environ, RFS_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "c3", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -234,7 +234,7 @@ def test_bench_rccl_calls_with_one_rank():
     env = dict(os.environ, RFS_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
     env.pop("RFS_BENCH_SHARE_GPU", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"]
+           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "c3", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
