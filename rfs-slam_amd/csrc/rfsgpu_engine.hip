@@ -972,7 +972,10 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
     // resident, three waves lose: 133 -> 180 us).  RFSGPU_STEP_WPP = 2 | 3 overrides.
     const size_t b2 = step_fused_lds_total(f->cap, ec, f->nZ, 2);
     const int perCU2 = (int)std::min<size_t>(8, b2 ? (size_t)(160 * 1024) / b2 : 8);
-    int wpp = ((long long)perCU2 * f->nCU >= f->N) ? 2 : 3;
+    // (three waves only where it is the LDS block that keeps two-wave workgroups below the 8 per CU the wave slots allow: at
+    //  capacity 384 -- 9 blocks of LDS per CU -- a launch of more than 2048 particles is better off with two waves per particle
+    //  in several rounds: 3000 particles 229 us against 389, 8000: 474 against 882)
+    int wpp = ((long long)perCU2 * f->nCU >= f->N || perCU2 >= 8) ? 2 : 3;
     if (f->stepWppOverride == 2 || f->stepWppOverride == 3) wpp = f->stepWppOverride;
     const size_t b = step_fused_lds_total(f->cap, ec, f->nZ, wpp);
     // phase priorities only when every workgroup is resident at once: 16 waves per CU at 128 VGPRs, LDS permitting
