@@ -181,14 +181,25 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
   // radius in both directions, so every pair that can pass lies in adjacent cells.
   const double x0 = (double)fxmin - 1e-3 * fabs((double)fxmin) - 1e-30, y0 = (double)fymin - 1e-3 * fabs((double)fymin) - 1e-30;
   const double spanx = (double)fxmax - x0, spany = (double)fymax - y0;
-  const double cellx = fmax((double)frad, spanx / MERGE_GX) * 1.001 + 1e-300, celly = fmax((double)frad, spany / MERGE_GY) * 1.001 + 1e-300;
+  // The 64 x 64 grid pays on sparse maps only (configs[2]'s shard: cells of two prefilter radii, fused step 254 -> 243 us).  Where
+  // a cell of extent / 64 would be thinner than ~1.5 radii it is clamped to the radius, the rows' slack (cell edge - radius) drops
+  // to zero and every row that merges falls back to the sequential scan (2000 x 400 Gaussians within 2.5 m: 319 -> 573 us): such a
+  // particle uses every other cell of the array, i.e. a 32 x 32 grid (gxe x gye cells in use, row stride MERGE_GX).
+  int gxe = MERGE_GX, gye = MERGE_GY;
+  if constexpr (GL == 6) {
+#ifndef MERGE_FINE_MIN
+#define MERGE_FINE_MIN 1.5
+#endif
+    if (!(spanx / MERGE_GX >= MERGE_FINE_MIN * (double)frad) || !(spany / MERGE_GY >= MERGE_FINE_MIN * (double)frad)) { gxe = MERGE_GX / 2; gye = MERGE_GY / 2; }
+  }
+  const double cellx = fmax((double)frad, spanx / gxe) * 1.001 + 1e-300, celly = fmax((double)frad, spany / gye) * 1.001 + 1e-300;
   const bool degenerate = !(cellx < 1.0e30) || !(celly < 1.0e30) || !(spanx == spanx) || !(spany == spany) || !(errAbs < 1.0e30f);  // inf / NaN -> a single cell
   const float x0f = (float)x0, y0f = (float)y0;
   const float invCx = degenerate ? 0.f : (float)(1.0 / cellx) * (1.f - 1e-6f), invCy = degenerate ? 0.f : (float)(1.0 / celly) * (1.f - 1e-6f);
   auto cell_of = [&](float x, float y, int &cx, int &cy) {
     int ix = (int)((x - x0f) * invCx), iy = (int)((y - y0f) * invCy);
-    cx = ix < 0 ? 0 : (ix >= MERGE_GX ? MERGE_GX - 1 : ix);
-    cy = iy < 0 ? 0 : (iy >= MERGE_GY ? MERGE_GY - 1 : iy);
+    cx = ix < 0 ? 0 : (ix >= gxe ? gxe - 1 : ix);
+    cy = iy < 0 ? 0 : (iy >= gye ? gye - 1 : iy);
     if (degenerate) { cx = 0; cy = 0; }
   };
   for (int m = tid, sidx = 0; m < N; m += NT, sidx++) {
@@ -267,7 +278,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     const float ax = sX[m], ay = sY[m], ar = sRad[m];
     int cx, cy;
     cell_of(ax, ay, cx, cy);
-    const int cxa = cx > 0 ? cx - 1 : 0, cxb = cx < MERGE_GX - 1 ? cx + 1 : MERGE_GX - 1;
+    const int cxa = cx > 0 ? cx - 1 : 0, cxb = cx < gxe - 1 ? cx + 1 : gxe - 1;
     unsigned long long buf0 = 0ull, buf1 = 0ull;  // up to 8 survivors, 16 bits each
     int nP = 0;
     float farE2 = 3.0e38f;   // nearest neighbour that fails the prefilter by a factor >= 2 in distance
@@ -276,7 +287,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     const unsigned qs1 = cell_at(cy * MERGE_GX + cxa), n1 = cell_at(cy * MERGE_GX + cxb + 1) - qs1;
     unsigned qs0 = 0, n0 = 0, qs2 = 0, n2 = 0;
     if (cy > 0) { qs0 = cell_at((cy - 1) * MERGE_GX + cxa); n0 = cell_at((cy - 1) * MERGE_GX + cxb + 1) - qs0; }
-    if (cy < MERGE_GY - 1) { qs2 = cell_at((cy + 1) * MERGE_GX + cxa); n2 = cell_at((cy + 1) * MERGE_GX + cxb + 1) - qs2; }
+    if (cy < gye - 1) { qs2 = cell_at((cy + 1) * MERGE_GX + cxa); n2 = cell_at((cy + 1) * MERGE_GX + cxb + 1) - qs2; }
     const unsigned n01 = n0 + n1, tot = n01 + n2;       // (tot >= 1: the entry itself)
 #ifdef RFS_PROFILE
     if (B.dbg && i == 7) {   // (this run's numbers: the host clears the words before the launch it reports)

@@ -11,6 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package
 pkg = load_package()
+if os.environ.get("RFS_LIB"):
+    pkg.engine.LIB = os.environ["RFS_LIB"]      # a tools/variant_bench.py --build variant
 sc = pkg.scenarios
 N, NM, NZ, CAP = [int(os.environ.get(k, d)) for k, d in (("SB_N", 2500), ("SB_NM", 500), ("SB_NZ", 30), ("SB_CAP", 640))]
 RMAX = float(os.environ.get("SB_RMAX", 5.0))
