@@ -470,6 +470,11 @@ int rfsgpu_restore_state(rfsgpu_filter *f);
 /* Duration in ns of the most recent launch of each hot-path kernel, from HIP events on the
  * engine's stream: [0]=phd_update_map [1]=phd_weight_multifeature [2]=gm_merge [3]=gm_prune. */
 int rfsgpu_last_kernel_ns(rfsgpu_filter *f, long long *ns4);
+/* [test] Which instantiation the last stream-ordered step (rfsgpu_update / _update_async / _step_async) launched: out4 = {waves per
+ * particle of the fused step kernel, phase priorities on (1 / 0), log2 of the merge grid's side (5 | 6), fused (1) or three
+ * kernels (0)} -- so that the full-size parity tests can say which kernel they checked (phd_step_fused_kernel<2, true, 5> is the
+ * one bench.py times at configs[1]). */
+int rfsgpu_last_step_variant(const rfsgpu_filter *f, int *out4);
 
 /* MatPerm::calc (src/MatrixPermanent.cpp:41-112), batched: `batch` row-major n x n matrices in A
  * (host), permanents to out (host).  n <= 24.  Standalone (no filter handle needed). */

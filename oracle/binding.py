@@ -83,7 +83,9 @@ def _capi():
 class OracleFilter:
     """Same interface as the product's filter class, backed by the CPU restatement."""
 
-    def __new__(cls, n_particles, stable_sort=True, lib=None, **kw):
+    def __new__(cls, n_particles, stable_sort=False, lib=None, **kw):
+        # stable_sort=False (default): sortByWeight is std::sort, exactly as the reference (include/GaussianMixture.hpp:523-534) --
+        # the mode every parity test uses; True: ties by index (what the device did until round 4; tools/tie_order_study.py)
         capi = _capi()
         lib = lib or load()
         obj = capi.CFilter(lib, "rfsor_", n_particles, **kw)

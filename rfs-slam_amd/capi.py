@@ -110,7 +110,7 @@ ABI_SYMBOLS = [
     "set_weights", "get_weights", "gm_size", "get_landmark", "import_gm", "export_gm", "gm_sizes", "predict_map",
     "update", "update_map", "importance_weighting", "merge", "prune", "get_unused", "landmarks_in_fov",
     "weight_sums", "weight_sums_async", "weight_sums_device_ptr", "normalize_weights", "resample_apply",
-    "get_timing", "reset_timing", "synchronize", "stream", "last_kernel_ns", "mat_perm",
+    "get_timing", "reset_timing", "synchronize", "stream", "last_kernel_ns", "last_step_variant", "mat_perm",
     "set_stream", "bind_weight_sums_buffer", "save_state", "restore_state", "import_aux",
     "set_model_victoriapark", "set_laser_scan", "export_birth_candidates", "import_birth_candidates",
     "update_async", "kernel_time_stats", "post_kernel_avg_ns", "set_step_timing_stride",

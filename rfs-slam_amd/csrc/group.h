@@ -240,7 +240,9 @@ int rfsgpu_group_predict_map(rfsgpu_group *g, int add_birth) {
     const rfsgpu_filter *f0 = g->shard[0];
     bool anyCopy = false;
     for (int p = 0; p < g->N; p++) anyCopy |= g->ppid[p] != p;
-    if (anyCopy && (f0->D != 2 || f0->cfg.birthGaussianMeasurementCountThreshold != 1u || f0->candUsed)) return group_predict_levels(g, add_birth);
+    bool candUsed = false;            // any shard that has held candidate lists (imported ones included) sends the whole group through the walk
+    for (size_t k = 0; k < g->shard.size(); k++) candUsed |= g->shard[k]->candUsed;
+    if (anyCopy && (f0->D != 2 || f0->cfg.birthGaussianMeasurementCountThreshold != 1u || candUsed)) return group_predict_levels(g, add_birth);
     if (anyCopy) {
       std::vector<unsigned long long> m((size_t)g->N), mn((size_t)g->N);
       for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_get_unused_masks(g->shard[k], m.data() + g->first[k]));
@@ -253,7 +255,10 @@ int rfsgpu_group_predict_map(rfsgpu_group *g, int add_birth) {
       if (any) for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_set_unused_masks(g->shard[k], mn.data() + g->first[k]));
     }
   }
-  for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_predict_map(g->shard[k], add_birth));
+  for (size_t k = 0; k < g->shard.size(); k++) {
+    g->shard[k]->externalAck = true;   // the group has applied the rule above (or no slot has a foreign parent)
+    GFWD(k, rfsgpu_predict_map(g->shard[k], add_birth));
+  }
   return RFSGPU_OK;
 }
 // (every shard is synchronised even when one reports an error: the others' streams and error words must not stay unharvested)

@@ -758,7 +758,11 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     plane(dl, cap, i, PL_SYY)[rank] = vyy;
   };
   // ranks among the survivors through the weighting phase's bucket sort (weighting.h): the grid's cursor array is the
-  // histogram (1024 buckets, inside either grid's cursor array), the pair list holds the bucket order, ties rank by list position (= ascending index)
+  // histogram (1024 buckets, inside either grid's cursor array), the pair list holds the bucket order, ties rank by list position (= ascending index).
+  // The order goes to sOrder (rank -> entry) first: survivors of equal weight are then put into the order std::sort leaves them in
+  // (stdsort_replay.h; GaussianMixture::prune sorts the WHOLE list, merged-away entries -- weight 0 -- included, :477-534), and only
+  // then is the compacted mixture written.
+  unsigned short *sOrder = sSlack;                                              // [nSurv] (the rows' slacks are dead)
   constexpr int NS = 8;
   bool ranked = false;
   if (nSurv <= NS * NT) {
@@ -769,7 +773,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
 #pragma unroll
       for (int k = 0; k < NS; k++) {
         const int q = tid + NT * k;
-        if (q < nSurv) put(rl[k], sSorted[q]);
+        if (q < nSurv) sOrder[rl[k]] = sSorted[q];
       }
     }
   }
@@ -783,9 +787,23 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
         const double wj = sW[j2];
         rank += (wj > wm || (wj == wm && j2 < m)) ? 1 : 0;
       }
-      put(rank, m);
+      sOrder[rank] = (unsigned short)m;
     }
   }
+  block_sync();
+  {
+    StdSortScratch ss;                              // the fp32 positions / radii of the merge are dead: 12 B per entry
+    ss.T = reinterpret_cast<unsigned short *>(sX);  // [N]          | Ll [N / 2 + 1]   (3 N + 2 <= 4 cap bytes)
+    ss.tStride = 1;
+    ss.Ll = ss.T + N;
+    ss.pos = reinterpret_cast<unsigned short *>(sY);  // [N]        | Rl [N / 2 + 1]
+    ss.Rl = ss.pos + N;
+    ss.eq = reinterpret_cast<unsigned long long *>(sRad);                       // [ceil(N / 64)] <= cap / 8 bytes
+    ss.stack = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(sRad) + (((size_t)(N + 63) >> 6) * 8));   // [26]: 104 B <= 4 cap - cap / 8
+    ss_correct_tie_order<WPP>([&](int e) { const double w = sW[e]; return w < 0.0 ? 0.0 : w; }, [&](int r) { return (int)sOrder[r]; },
+                              [&](int r, unsigned short e) { sOrder[r] = e; }, N, nSurv, ss, tid, block_sync);
+  }
+  for (int r = tid; r < nSurv; r += NT) put(r, sOrder[r]);
   if (tid == 0) B.count[i] = nSurv;
   DBG_TB(32, 4);
 #ifdef RFS_PROFILE
@@ -802,8 +820,14 @@ __global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(MERGE_
   gm_merge_particle<WPP, FUSE_PRUNE>(B, P, cur, dst, (int)blockIdx.x, (int)threadIdx.x, smem_raw);
 }
 
-// LDS per wave: keys[cap] doubles
+// LDS per wave: keys[cap] doubles + the order / std::sort-replay scratch (u16 each: order [cap], T [cap], pos [cap], two stopper
+// lists [cap / 2 + 1]; eq words, stack)
+__host__ __device__ inline size_t gm_prune_lds_bytes_per_wave(int cap) {
+  return (((size_t)cap * 8 + (size_t)cap * 2 * 3 + (size_t)(cap / 2 + 2) * 2 * 2 + (size_t)((cap + 63) / 64) * 8 + 128) + 15) & ~(size_t)15;
+}
 // NEG_IS_HOLE: the RB-PHD mixtures mark merged-away entries with w = -1; FastSLAM's log-odds weights are legitimately negative.
+// GaussianMixture::prune (include/GaussianMixture.hpp:477-534): std::sort of the whole list by weight, the sorted prefix with
+// w >= t stays.  Ranks by counting (ties by index), then equal weights in std::sort's order (stdsort_replay.h).
 template <int WPB, bool NEG_IS_HOLE = true>
 __global__ __launch_bounds__(WPB * 64) void gm_prune_kernel(Buffers B, Params P, int src, int dst) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -812,7 +836,9 @@ __global__ __launch_bounds__(WPB * 64) void gm_prune_kernel(Buffers B, Params P,
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
   if (i >= B.N) return;
   const int cap = B.cap;
-  double *keys = reinterpret_cast<double *>(smem_raw) + (size_t)wave * cap;
+  unsigned char *base = smem_raw + (size_t)wave * gm_prune_lds_bytes_per_wave(cap);
+  double *keys = reinterpret_cast<double *>(base);
+  unsigned short *sOrder = reinterpret_cast<unsigned short *>(keys + cap);
   const int N = B.count[i];
   const double *sl = B.slab[src];
   double *dl = B.slab[dst];
@@ -824,18 +850,35 @@ __global__ __launch_bounds__(WPB * 64) void gm_prune_kernel(Buffers B, Params P,
   for (int m = lane; m < N; m += 64) {
     const double wm = keys[m];
     const bool keep = (wm >= t) && (!NEG_IS_HOLE || wm >= 0.0);  // holes carry -1
-    int rank = 0;
     if (keep) {
+      int rank = 0;
       for (int j = 0; j < N; j++) {
         const double wj = keys[j];
         rank += (wj > wm || (wj == wm && j < m)) ? 1 : 0;  // everything ranked ahead of a survivor also survives
       }
-      for (int pl = 0; pl < B.npl; pl++)
-        (dl + ((size_t)i * B.npl + pl) * cap)[rank] = (sl + ((size_t)i * B.npl + pl) * cap)[m];
+      sOrder[rank] = (unsigned short)m;
       kept++;
     }
   }
   kept = wave_sum_i(kept);
+  wave_sync();
+  {
+    StdSortScratch ss;
+    ss.T = sOrder + cap;
+    ss.tStride = 1;
+    ss.pos = ss.T + cap;
+    ss.Ll = ss.pos + cap;
+    ss.Rl = ss.Ll + (cap / 2 + 2);
+    ss.eq = reinterpret_cast<unsigned long long *>(base + (size_t)cap * 8 + (size_t)cap * 2 * 3 + (size_t)(cap / 2 + 2) * 2 * 2);
+    ss.stack = reinterpret_cast<unsigned *>(ss.eq + (cap + 63) / 64);
+    ss_correct_tie_order<1>([&](int e) { const double w = keys[e]; return (NEG_IS_HOLE && w < 0.0) ? 0.0 : w; }, [&](int r) { return (int)sOrder[r]; },
+                            [&](int r, unsigned short e) { sOrder[r] = e; }, N, kept, ss, lane, [&]() { wave_sync(); });
+  }
+  for (int r = lane; r < kept; r += 64) {
+    const int m = sOrder[r];
+    for (int pl = 0; pl < B.npl; pl++)
+      (dl + ((size_t)i * B.npl + pl) * cap)[r] = (sl + ((size_t)i * B.npl + pl) * cap)[m];
+  }
   if (lane == 0) B.count[i] = kept;
 }
 

@@ -76,6 +76,7 @@ struct rfsgpu_filter {
   double *hSums = nullptr;  // pinned [2]
   rfsgpu_timing timing{};
   long long lastKernelNs[4] = {0, 0, 0, 0};
+  int lastStepVariant[4] = {0, 0, 0, 0};   // the last stream-ordered step: {waves per particle, phase priorities, merge grid log2, fused}
   bool phaseOpen = false;   // update_map ran, weighting/merge/prune may follow
   bool normPending = false; // a normalize_kernel event pair has not been accumulated yet
   // async steps: ring of per-phase event sets, harvested at the next sync
@@ -92,6 +93,7 @@ struct rfsgpu_filter {
   int inheritMode = RFSGPU_INHERIT_REFERENCE;
   std::vector<int> pid, ppid;         // Particle::id_ / idParent_ of the particle in each slot (ParticleFilter.hpp:446-479)
   bool resampleOccured = false;       // RBPHDFilter::resampleOccured_
+  bool externalAck = true;            // RFSGPU_INHERIT_EXTERNAL: the host has taken care of the inheritance rule since the last resampling (rfsgpu.h)
   bool fastSlamHandle = false;        // rfsgpu_fastslam_update has run: the filter class is rfs::FastSLAM, whose resampleWithMapCopy
                                       // copies the candidate lists right at resampling time (FastSLAM.hpp:747-753) -> eager copies
   int *dInhParent = nullptr, *dInhLevel = nullptr;   // [Ncap] each (allocated on first use)
@@ -343,7 +345,7 @@ void rfsgpu_destroy(rfsgpu_filter *f) {
   hipFree(B.unusedMask); hipFree(B.nInFov); hipFree(B.err); hipFree(B.Z); hipFree(f->ownSums); hipFree(f->dSrcSlot); if (f->dRowSlots) hipFree(f->dRowSlots); if (f->fsArena) hipFree(f->fsArena); if (f->mhArena) hipFree(f->mhArena); if (f->mhInts) hipFree(f->mhInts);
   if (f->dInhParent) hipFree(f->dInhParent);
   if (f->dInhLevel) hipFree(f->dInhLevel);
-  if (f->inhTmp.unused) { hipFree(f->inhTmp.unused); hipFree(f->inhTmp.count); hipFree(f->inhTmp.sup); hipFree(f->inhTmp.chk); hipFree(f->inhTmp.mean); hipFree(f->inhTmp.cov); }
+  hipFree(f->inhTmp.unused); hipFree(f->inhTmp.count); hipFree(f->inhTmp.sup); hipFree(f->inhTmp.chk); hipFree(f->inhTmp.mean); hipFree(f->inhTmp.cov);  // (hipFree(nullptr) is a no-op)
   hipFree(B.scan); hipFree(B.candMean); hipFree(B.candCov); hipFree(B.candSup); hipFree(B.candChk); hipFree(B.candCount);
   murty_free(f->Q, f->MS);
   if (f->hErr) hipHostFree(f->hErr);
@@ -786,7 +788,7 @@ static int launch_merge(rfsgpu_filter *f) { return launch_merge_t<false>(f); }
 static int launch_merge_prune(rfsgpu_filter *f) { return launch_merge_t<true>(f); }
 
 static int launch_prune(rfsgpu_filter *f) {
-  const size_t per = (size_t)f->cap * 8;
+  const size_t per = gm_prune_lds_bytes_per_wave(f->cap);
   const int src = f->cur, dst = f->cur ^ 1;
   int rc;
   if ((rc = set_lds(f, gm_prune_kernel<4>, 4 * per)) != RFSGPU_OK) return rc;
@@ -981,6 +983,7 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
     // phase priorities only when every workgroup is resident at once: 16 waves per CU at 128 VGPRs, LDS permitting
     const int perCU = (int)std::min<size_t>(16 / wpp, b ? (size_t)(160 * 1024) / b : 16);
     const int phasePrio = (long long)perCU * f->nCU >= f->N ? 1 : 0;
+    f->lastStepVariant[0] = wpp; f->lastStepVariant[1] = phasePrio; f->lastStepVariant[2] = 5; f->lastStepVariant[3] = 1;
     if (wpp == 2) {
       if ((rc = set_lds(f, (phd_step_fused_kernel<2, true>), b)) != RFSGPU_OK) return rc;
       if ((rc = set_lds(f, (phd_step_fused_kernel<2, false>), b)) != RFSGPU_OK) return rc;
@@ -994,6 +997,7 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
       const bool fine = f->mergeGridOverride ? f->mergeGridOverride == 6 : (perCU6 == perCU && perCU6 > 0);
       if (fine) {
         const int prio6 = (long long)perCU6 * f->nCU >= f->N ? 1 : 0;
+        f->lastStepVariant[1] = prio6; f->lastStepVariant[2] = 6;
         if ((rc = set_lds(f, (phd_step_fused_kernel<3, true, 6>), b6)) != RFSGPU_OK) return rc;
         if ((rc = set_lds(f, (phd_step_fused_kernel<3, false, 6>), b6)) != RFSGPU_OK) return rc;
         if (prio6) phd_step_fused_kernel<3, true, 6><<<f->N, 192, b6, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
@@ -1032,6 +1036,7 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
     if (timed) HIPCHK(hipEventRecord(e[0], f->stream));
     const int ec = eval_cap(f), useW = f->cfg.useClusterProcess ? 0 : 1;
     const size_t shared = vp_shared_lds_bytes(f->nZ, f->B.nScan), per = vp_step_lds_bytes_per_wave(f->cap, ec, f->nZ);
+    f->lastStepVariant[0] = 1; f->lastStepVariant[1] = 0; f->lastStepVariant[2] = 0; f->lastStepVariant[3] = 1;
     if (shared + 2 * per <= (size_t)64 * 1024) {
       const size_t b = shared + 2 * per;
       if ((rc = set_lds(f, vp_step_fused_kernel<2>, b)) != RFSGPU_OK) return rc;
@@ -1053,6 +1058,7 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
     f->timing.mapUpdate_cpu += now_ns() - t0;
     return RFSGPU_OK;
   }
+  f->lastStepVariant[0] = f->lastStepVariant[1] = f->lastStepVariant[2] = f->lastStepVariant[3] = 0;   // three kernels
   rc = stage_measurements(f, z, n_z);
   if (rc != RFSGPU_OK) return rc;
   HIPCHK(hipEventRecord(e[0], f->stream));
@@ -1163,15 +1169,15 @@ static int predict_launch(rfsgpu_filter *f, int add_birth) {
   }
   if (!any) { launch_predict_kernels(f, add_birth, all); return RFSGPU_OK; }
   if (!f->dInhLevel) HIPCHK(hipMalloc(&f->dInhLevel, (size_t)f->Ncap * sizeof(int)));
-  if (!f->dInhParent) {
-    HIPCHK(hipMalloc(&f->dInhParent, (size_t)f->Ncap * sizeof(int)));
+  {  // every buffer under its own guard: a failed allocation leaves the others usable and is retried by the next call
     const size_t nc = (size_t)f->Ncap * RFSGPU_MAX_CANDIDATES;
-    HIPCHK(hipMalloc(&f->inhTmp.unused, (size_t)f->Ncap * sizeof(unsigned long long)));
-    HIPCHK(hipMalloc(&f->inhTmp.count, (size_t)f->Ncap * sizeof(int)));
-    HIPCHK(hipMalloc(&f->inhTmp.sup, nc * sizeof(int)));
-    HIPCHK(hipMalloc(&f->inhTmp.chk, nc * sizeof(int)));
-    HIPCHK(hipMalloc(&f->inhTmp.mean, nc * 3 * sizeof(double)));
-    HIPCHK(hipMalloc(&f->inhTmp.cov, nc * 6 * sizeof(double)));
+    if (!f->dInhParent) HIPCHK(hipMalloc(&f->dInhParent, (size_t)f->Ncap * sizeof(int)));
+    if (!f->inhTmp.unused) HIPCHK(hipMalloc(&f->inhTmp.unused, (size_t)f->Ncap * sizeof(unsigned long long)));
+    if (!f->inhTmp.count) HIPCHK(hipMalloc(&f->inhTmp.count, (size_t)f->Ncap * sizeof(int)));
+    if (!f->inhTmp.sup) HIPCHK(hipMalloc(&f->inhTmp.sup, nc * sizeof(int)));
+    if (!f->inhTmp.chk) HIPCHK(hipMalloc(&f->inhTmp.chk, nc * sizeof(int)));
+    if (!f->inhTmp.mean) HIPCHK(hipMalloc(&f->inhTmp.mean, nc * 3 * sizeof(double)));
+    if (!f->inhTmp.cov) HIPCHK(hipMalloc(&f->inhTmp.cov, nc * 6 * sizeof(double)));
   }
   // (pageable host vectors: hipMemcpyAsync from them returns after the copy has been staged, so they may be reused at once)
   HIPCHK(hipMemcpyAsync(f->dInhParent, f->hInhParent.data(), (size_t)N * sizeof(int), hipMemcpyHostToDevice, f->stream));
@@ -1191,6 +1197,7 @@ static int predict_launch(rfsgpu_filter *f, int add_birth) {
 int rfsgpu_predict_map_level(rfsgpu_filter *f, int add_birth, const int *level_of_slot, int level, int do_static) {
   CHECK_HANDLE(f);
   if (!level_of_slot) return fail(f, RFSGPU_ERR_INVALID, "predict_map_level: null level array");
+  f->externalAck = true;
   hipSetDevice(f->device);
   if (!f->dInhLevel) HIPCHK(hipMalloc(&f->dInhLevel, (size_t)f->Ncap * sizeof(int)));
   f->hInhLevel.assign(level_of_slot, level_of_slot + f->N);
@@ -1207,6 +1214,10 @@ int rfsgpu_predict_map_level(rfsgpu_filter *f, int add_birth, const int *level_o
 
 int rfsgpu_predict_map(rfsgpu_filter *f, int add_birth) {
   CHECK_HANDLE(f);
+  if (add_birth && f->resampleOccured && f->inheritMode == RFSGPU_INHERIT_EXTERNAL && !f->externalAck)
+    return fail(f, RFSGPU_ERR_INVALID, "predict_map with births after a resampling in RFSGPU_INHERIT_EXTERNAL mode, but the host has not applied the "
+                "inheritance rule (rfsgpu_get/set_unused_masks, rfsgpu_predict_map_level, or rfsgpu_set_birth_inheritance(EXTERNAL) again to acknowledge): "
+                "go through the multi-GPU host's own predict (ShardedRBPHDFilter.predict_map / rfsgpu_group_predict_map)");
   long long t0 = now_ns();
   hipSetDevice(f->device);
   HIPCHK(hipEventRecord(f->ev[EV_P0], f->stream));
@@ -1222,6 +1233,10 @@ int rfsgpu_predict_map(rfsgpu_filter *f, int add_birth) {
 // RBPHDFilter::predict's map part without the error-word readback: stream-ordered, errors surface at the next synchronising call.
 int rfsgpu_predict_map_async(rfsgpu_filter *f, int add_birth) {
   CHECK_HANDLE(f);
+  if (add_birth && f->resampleOccured && f->inheritMode == RFSGPU_INHERIT_EXTERNAL && !f->externalAck)
+    return fail(f, RFSGPU_ERR_INVALID, "predict_map with births after a resampling in RFSGPU_INHERIT_EXTERNAL mode, but the host has not applied the "
+                "inheritance rule (rfsgpu_get/set_unused_masks, rfsgpu_predict_map_level, or rfsgpu_set_birth_inheritance(EXTERNAL) again to acknowledge): "
+                "go through the multi-GPU host's own predict (ShardedRBPHDFilter.predict_map / rfsgpu_group_predict_map)");
   long long t0 = now_ns();
   hipSetDevice(f->device);
   if (f->predPending && hipEventQuery(f->ev[EV_P1]) == hipSuccess) {   // the previous async predict has long finished: book it
@@ -1440,6 +1455,7 @@ int rfsgpu_resample_apply_n(rfsgpu_filter *f, const int *src_slot, int n_out) {
     else f->ppid[k] = f->pid[k];
   }
   f->resampleOccured = true;
+  f->externalAck = false;
   hipSetDevice(f->device);
   long long t0 = now_ns();
   HIPCHK(hipMemcpyAsync(f->dSrcSlot, src_slot, (size_t)f->N * sizeof(int), hipMemcpyHostToDevice, f->stream));
@@ -1458,6 +1474,7 @@ int rfsgpu_set_birth_inheritance(rfsgpu_filter *f, int mode) {
   CHECK_HANDLE(f);
   if (mode != RFSGPU_INHERIT_REFERENCE && mode != RFSGPU_INHERIT_EAGER && mode != RFSGPU_INHERIT_EXTERNAL) return fail(f, RFSGPU_ERR_INVALID, "set_birth_inheritance: unknown mode");
   f->inheritMode = mode;
+  f->externalAck = true;    // (EXTERNAL: the caller asserts that it owns the rule from here on, incl. for the coming predict)
   return RFSGPU_OK;
 }
 int rfsgpu_get_birth_inheritance(const rfsgpu_filter *f) { return f ? f->inheritMode : -1; }
@@ -1480,6 +1497,7 @@ int rfsgpu_get_unused_masks(rfsgpu_filter *f, unsigned long long *masks) {
   hipSetDevice(f->device);
   HIPCHK(hipMemcpyAsync(masks, f->B.unusedMask, (size_t)f->N * sizeof(unsigned long long), hipMemcpyDeviceToHost, f->stream));
   HIPCHK(hipStreamSynchronize(f->stream));
+  f->externalAck = true;
   return RFSGPU_OK;
 }
 int rfsgpu_set_unused_masks(rfsgpu_filter *f, const unsigned long long *masks) {
@@ -1488,6 +1506,7 @@ int rfsgpu_set_unused_masks(rfsgpu_filter *f, const unsigned long long *masks) {
   hipSetDevice(f->device);
   HIPCHK(hipMemcpyAsync(f->B.unusedMask, masks, (size_t)f->N * sizeof(unsigned long long), hipMemcpyHostToDevice, f->stream));
   HIPCHK(hipStreamSynchronize(f->stream));
+  f->externalAck = true;
   return RFSGPU_OK;
 }
 
@@ -1615,6 +1634,11 @@ int rfsgpu_restore_state(rfsgpu_filter *f) {
   f->nZ = f->snapNZ;
   return RFSGPU_OK;
 }
+int rfsgpu_last_step_variant(const rfsgpu_filter *f, int *out4) {
+  if (!f || !out4) return RFSGPU_ERR_INVALID;
+  for (int k = 0; k < 4; k++) out4[k] = f->lastStepVariant[k];
+  return RFSGPU_OK;
+}
 int rfsgpu_last_kernel_ns(rfsgpu_filter *f, long long *ns4) {
   CHECK_HANDLE(f);
   if (!ns4) return RFSGPU_ERR_INVALID;
@@ -1702,7 +1726,7 @@ static int fastslam_map_management(rfsgpu_filter *f, const FsParams &F, int n_z)
   if ((unsigned)n_z >= f->fs.pruningMeasurementsThreshold) {
     Params Pp = f->P;
     Pp.pruneT = f->fs.mapExistencePruneThreshold;
-    const size_t pb = (size_t)f->cap * 8;
+    const size_t pb = gm_prune_lds_bytes_per_wave(f->cap);
     if ((rc = set_lds(f, (gm_prune_kernel<4, false>), 4 * pb)) != RFSGPU_OK) return rc;
     gm_prune_kernel<4, false><<<(f->N + 3) / 4, 256, 4 * pb, f->stream>>>(f->B, Pp, f->cur, f->cur ^ 1);
     HIPCHK(hipGetLastError());

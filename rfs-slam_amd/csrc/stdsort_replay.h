@@ -1,0 +1,395 @@
+// stdsort_replay.h -- the order std::sort leaves EQUAL keys in, reproduced on the device.
+//
+// GaussianMixture::sortByWeight (reference include/GaussianMixture.hpp:523-534) is `std::sort(gList_.begin(), gList_.end(),
+// weightCompare)` with weightCompare(a, b) = a.weight > b.weight: an UNSTABLE sort, so Gaussians of exactly equal weight (every
+// birth Gaussian enters with birthGaussianWeight, RBPHDFilter.hpp:1000-1084; merged-away entries all carry weight 0; the
+// near-limit heuristic clamps weights to exactly 1, :692-703) come out in an order that is a property of the sort algorithm, and
+// that order is observable: it picks the evaluation points among tied weights (:747-761), it is the order the greedy merge walks
+// (GaussianMixture.hpp:394-416) and the order in which the next update appends its new Gaussians.  On the Victoria Park extract
+// the filter's weights differ by factors between the two orders (tools/tie_order_study.py), so "ties by index" is not the
+// reference's result.
+//
+// What is reproduced is libstdc++'s std::sort (bits/stl_algo.h: __sort -> __introsort_loop + __final_insertion_sort; unchanged
+// from GCC 4.9 to 13), the standard library of the reference's only supported toolchain (CMakeLists.txt: GNU flags):
+//   * __introsort_loop(first, last, depth = 2 floor(lg n)): while the range holds more than 16 elements: (depth exhausted: heap-
+//     sort the range and stop;) move the median of {first + 1, middle, last - 1} to `first`, Hoare-partition (first, last)
+//     around it (__unguarded_partition), recurse into the right part, continue with the left part;
+//   * __final_insertion_sort: an insertion sort of the whole array whose comparisons are strict, i.e. it is STABLE with respect to the
+//     arrangement the loop left.
+// Hence   std::sort(a) == stable_sort(arrangement after the partition phase),   and equal keys end up in the order of their
+// positions after the partition phase.  The device already has the stable order of the ORIGINAL arrangement (its rank sorts
+// break ties by index); what this header adds is the partition phase replayed on a u16 index array T (T[p] = entry at
+// position p; comparisons through the entries' keys) and a fix-up that reorders every run of tied ranks by position in T.
+//   * Only comparisons are replayed: no key is moved, no arithmetic happens, the result is exact by construction and is checked
+//     against the real std::sort on the host (tests/test_stdsort_replay.py, the serial form below compiled with g++) and against
+//     the oracle's std::sort on the device (every GPU parity test now runs the oracle in its reference mode).
+//   * A sub-range whose final ranks hold no two equal keys (that matter to the caller) is not followed further: elements never
+//     leave their sub-range, so its internal arrangement cannot influence the order of tied keys.  In a running filter the ties
+//     sit at the birth weight and at 0, so after one or two partitions most of the array is dropped.
+//   * A mixture of <= 16 entries, or without equal keys, needs nothing: std::sort is then the stable order.
+// One wavefront replays a partition step in parallel (ss_partition_wave): the stoppers of the two scans are enumerated with
+// ballots -- L[k] = k-th position from the left whose key is <= the pivot's, R[k] = k-th from the right whose key is >= it --
+// the scan swaps (L[k], R[k]) exactly while L[k] < R[k], K swaps in all, all disjoint, and returns
+// cut = min(L[K], R[K-1]) (L[0] when K = 0); see the derivation at ss_partition_lists, which the host test runs against the
+// two-pointer loop.
+#pragma once
+#if defined(__HIPCC__)
+#define SS_HD __host__ __device__
+#else
+#define SS_HD
+#endif
+
+#define SS_THRESHOLD 16   // libstdc++ _S_threshold
+
+SS_HD inline int ss_floor_lg(int n) { int k = 0; while (n > 1) { n >>= 1; k++; } return k; }   // std::__lg
+
+// ---- serial form (one thread): the reference for the host test, the device's fallback, and the depth-limit heap sort --------
+// get(p) -> entry at position p; put(p, e); gt(a, b) <=> key of entry a > key of entry b  (= weightCompare).
+
+// __adjust_heap + __push_heap (bits/stl_heap.h) on positions f + [0, len)
+template <class Get, class Put, class Gt>
+SS_HD inline void ss_adjust_heap(Get get, Put put, Gt gt, const int f, int hole, const int len, const unsigned short value) {
+  const int top = hole;
+  int child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (gt(get(f + child), get(f + child - 1))) child--;
+    put(f + hole, get(f + child));
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    put(f + hole, get(f + child - 1));
+    hole = child - 1;
+  }
+  int parent = (hole - 1) / 2;
+  while (hole > top && gt(get(f + parent), value)) {
+    put(f + hole, get(f + parent));
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  put(f + hole, value);
+}
+// __partial_sort(first, last, last): __heap_select with an empty tail (= __make_heap) + __sort_heap
+template <class Get, class Put, class Gt>
+SS_HD inline void ss_heap_sort(Get get, Put put, Gt gt, const int f, const int l) {
+  const int len = l - f;
+  if (len < 2) return;
+  for (int parent = (len - 2) / 2;; parent--) {
+    ss_adjust_heap(get, put, gt, f, parent, len, get(f + parent));
+    if (parent == 0) break;
+  }
+  for (int last = l; last - f > 1;) {
+    --last;
+    const unsigned short value = get(last);
+    put(last, get(f));
+    ss_adjust_heap(get, put, gt, f, 0, last - f, value);
+  }
+}
+// __move_median_to_first(first, first + 1, mid, last - 1): which of the three positions is swapped with `first`
+template <class Get, class Gt>
+SS_HD inline int ss_median_position(Get get, Gt gt, const int f, const int l) {
+  const int a = f + 1, b = f + (l - f) / 2, c = l - 1;
+  const unsigned short ea = get(a), eb = get(b), ec = get(c);
+  if (gt(ea, eb)) {
+    if (gt(eb, ec)) return b;
+    if (gt(ea, ec)) return c;
+    return a;
+  }
+  if (gt(ea, ec)) return a;
+  if (gt(eb, ec)) return c;
+  return b;
+}
+// __unguarded_partition_pivot, the two-pointer loop as written
+template <class Get, class Put, class Gt>
+SS_HD inline int ss_partition_serial(Get get, Put put, Gt gt, const int f, const int l) {
+  const int s = ss_median_position(get, gt, f, l);
+  { const unsigned short t = get(f); put(f, get(s)); put(s, t); }
+  const unsigned short pivot = get(f);
+  int first = f + 1, last = l;
+  while (true) {
+    while (gt(get(first), pivot)) ++first;
+    --last;
+    while (gt(pivot, get(last))) --last;
+    if (!(first < last)) return first;
+    { const unsigned short t = get(first); put(first, get(last)); put(last, t); }
+    ++first;
+  }
+}
+// The same partition step from the two stopper lists (the form the wavefront executes), serial, for the host test:
+//   L = positions p in (f, l), ascending, with !gt(T[p], pivot)   (where the left scan can stop),
+//   R = positions p in (f, l), descending, with !gt(pivot, T[p])  (where the right scan can stop).
+// Induction over the loop's trips: before trip k the array differs from the initial one only at L[0..k) and R[0..k), the left
+// pointer stands at L[k-1] + 1 and the right one at R[k-1].  The left scan stops at L[k] if L[k] < R[k-1] (untouched
+// positions in between hold no stopper before L[k]), else at R[k-1] (which now holds a left stopper); the right scan stops at
+// R[k] if R[k] > L[k-1], else at L[k-1].  A swap happens iff left < right, which in every case is L[k] < R[k]; L ascends and R
+// descends, so the swaps are k = 0 .. K-1 with K = #{k : L[k] < R[k]}, they touch pairwise distinct positions whose contents
+// are the initial ones, and the loop returns cut = L[K] if L[K] < R[K-1] (or K == 0) else R[K-1].  (L[0], R[0] exist: the two
+// non-median elements of the median-of-three are sentinels for the unguarded scans.)
+template <class Get, class Put, class Gt>
+SS_HD inline int ss_partition_lists(Get get, Put put, Gt gt, const int f, const int l, unsigned short *Ll, unsigned short *Rl) {
+  const int s = ss_median_position(get, gt, f, l);
+  { const unsigned short t = get(f); put(f, get(s)); put(s, t); }
+  const unsigned short pivot = get(f);
+  // (the lists are kept to their first LC = (l - f) / 2 + 1 entries, as on the device: K <= (l - f - 1) / 2 < LC)
+  const int LC = (l - f) / 2 + 1;
+  int nL = 0, nR = 0;
+  for (int p = f + 1; p < l && nL < LC; p++) if (!gt(get(p), pivot)) Ll[nL++] = (unsigned short)p;
+  for (int p = l - 1; p > f && nR < LC; p--) if (!gt(pivot, get(p))) Rl[nR++] = (unsigned short)p;
+  int K = 0;
+  while (K < nL && K < nR && Ll[K] < Rl[K]) {
+    const unsigned short t = get(Ll[K]); put(Ll[K], get(Rl[K])); put(Rl[K], t);
+    K++;
+  }
+  if (K == 0) return Ll[0];
+  return (K < nL && Ll[K] < Rl[K - 1]) ? Ll[K] : Rl[K - 1];
+}
+
+// Ranges waiting on the replay's stack: first (11 bits) | last (12 bits) << 11 | depth << 23  (n <= 2048)
+SS_HD inline unsigned ss_pack_range(int f, int l, int d) { return (unsigned)f | ((unsigned)l << 11) | ((unsigned)d << 23); }
+
+// __introsort_loop on T[0, N), ranges in any order (they are disjoint); relevant(f, l) == false drops a range (see the header).
+// stack: room for 2 floor(lg N) + 2 words.  USE_LISTS: partition through ss_partition_lists (host test of that form).
+template <bool USE_LISTS, class Get, class Put, class Gt, class Rel>
+SS_HD inline void ss_replay_serial(Get get, Put put, Gt gt, const int N, Rel relevant, unsigned *stack, unsigned short *Ll = nullptr,
+                                   unsigned short *Rl = nullptr) {
+  int sp = 0;
+  stack[sp++] = ss_pack_range(0, N, 2 * ss_floor_lg(N));
+  while (sp > 0) {
+    const unsigned w = stack[--sp];
+    const int f = (int)(w & 0x7ffu);
+    int l = (int)((w >> 11) & 0xfffu), d = (int)(w >> 23);
+    while (l - f > SS_THRESHOLD && relevant(f, l)) {
+      if (d == 0) { ss_heap_sort(get, put, gt, f, l); break; }
+      --d;
+      const int cut = USE_LISTS ? ss_partition_lists(get, put, gt, f, l, Ll, Rl) : ss_partition_serial(get, put, gt, f, l);
+      if (l - cut > SS_THRESHOLD) stack[sp++] = ss_pack_range(cut, l, d);
+      l = cut;
+    }
+  }
+}
+
+#if defined(__HIPCC__)
+// ---- wavefront form ------------------------------------------------------------------------------------------------------------
+// Scratch of one replay (all LDS, u16 unless noted).  T is addressed with a stride so that it can live in the unused upper
+// halves of an int[] permutation array (tStride 2) as well as in an array of its own (tStride 1).
+struct StdSortScratch {
+  unsigned short *T;     // [N * tStride] arrangement: entry at position p
+  int tStride;
+  unsigned short *pos;   // [N] position of entry m after the partition phase (written at the end of the replay)
+  unsigned short *Ll;    // [LC] left stoppers, ascending   (LC = N / 2 + 1; nullptr: no room -> lane 0 replays serially)
+  unsigned short *Rl;    // [LC] right stoppers, descending
+  unsigned long long *eq;  // [ceil(N / 64)] bit r of word r / 64: the keys of sorted ranks r - 1 and r are equal (and matter)
+  unsigned *stack;       // [>= 26]
+};
+__host__ __device__ inline int ss_list_cap(int N) { return N / 2 + 1; }
+
+// Lay the scratch out in a byte range [buf, buf + bytes) (8-byte aligned): eq words | stack | T (when ownT: an array of its own,
+// stride 1; otherwise the caller has set S.T / S.tStride) | pos | the two stopper lists if they still fit (else the replay runs
+// serially on lane 0).  Returns false when even the mandatory part does not fit.
+__device__ __forceinline__ bool ss_carve(StdSortScratch &S, unsigned char *buf, size_t bytes, const int N, const bool ownT) {
+  const size_t eqB = (size_t)((N + 63) >> 6) * 8, stackB = 112, arr = ((size_t)N * 2 + 7) & ~(size_t)7;
+  const size_t must = eqB + stackB + (ownT ? arr : 0) + arr;
+  if (must > bytes) return false;
+  unsigned char *p = buf;
+  S.eq = reinterpret_cast<unsigned long long *>(p); p += eqB;
+  S.stack = reinterpret_cast<unsigned *>(p); p += stackB;
+  if (ownT) { S.T = reinterpret_cast<unsigned short *>(p); S.tStride = 1; p += arr; }
+  S.pos = reinterpret_cast<unsigned short *>(p); p += arr;
+  const size_t listB = ((size_t)ss_list_cap(N) * 2 + 7) & ~(size_t)7;
+  if (must + 2 * listB <= bytes) {
+    S.Ll = reinterpret_cast<unsigned short *>(p); p += listB;
+    S.Rl = reinterpret_cast<unsigned short *>(p);
+  } else {
+    S.Ll = nullptr; S.Rl = nullptr;
+  }
+  return true;
+}
+
+// relevant(f, l): some rank in (f, l) carries an eq bit, i.e. two equal keys end up inside [f, l).  Uniform; all lanes call it.
+__device__ __forceinline__ bool ss_relevant(const unsigned long long *eq, const int f, const int l, const int lane) {
+  // ranks f + 1 .. l - 1
+  const int lo = f + 1, hi = l - 1;
+  unsigned long long m = 0ull;
+  const int w = lane;                       // word `lane` (<= 32 words: N <= 2048)
+  if (lo <= hi && w >= (lo >> 6) && w <= (hi >> 6)) {
+    m = eq[w];
+    if (w == (lo >> 6)) m &= ~0ull << (lo & 63);
+    if (w == (hi >> 6)) m &= ~0ull >> (63 - (hi & 63));
+  }
+  return __ballot(m != 0ull) != 0ull;
+}
+
+// One partition step (__unguarded_partition_pivot) on T[f, l) by the calling wavefront; returns the cut (uniform).
+// keyAt(e): key of entry e (LDS read); the comparisons are weightCompare's: gt(a, b) = keyAt(a) > keyAt(b).
+template <class KeyAt>
+__device__ __forceinline__ int ss_partition_wave(KeyAt keyAt, const StdSortScratch &S, const int f, const int l, const int lane) {
+  auto Tat = [&](int p) -> unsigned short & { return S.T[p * S.tStride]; };
+  const int LC = ss_list_cap(l - f);
+  {  // median of three to the front (uniform reads, lane 0 writes)
+    const int a = f + 1, b = f + (l - f) / 2, c = l - 1;
+    const unsigned short ea = Tat(a), eb = Tat(b), ec = Tat(c);
+    const double ka = keyAt(ea), kb = keyAt(eb), kc = keyAt(ec);
+    int s;
+    if (ka > kb) s = (kb > kc) ? b : ((ka > kc) ? c : a);
+    else s = (ka > kc) ? a : ((kb > kc) ? c : b);
+    const unsigned short ef = Tat(f), es = (s == a) ? ea : ((s == b) ? eb : ec);
+    wave_sync();
+    if (lane == 0) { Tat(f) = es; Tat(s) = ef; }
+    wave_sync();
+  }
+  const double kp = keyAt(Tat(f));
+  // stoppers from both ends at once: trip t looks at positions f + 1 + (64 t + lane) and l - 1 - (64 t + lane)
+  int nL = 0, nR = 0;
+  const int n1 = l - f - 1;                  // positions f + 1 .. l - 1
+  for (int t0 = 0; t0 < n1 && (nL < LC || nR < LC); t0 += 64) {
+    const int q = t0 + lane;
+    const bool in = q < n1;
+    const int pa = f + 1 + q, pd = l - 1 - q;
+    const double kx = in ? keyAt(Tat(pa)) : 0.0, ky = in ? keyAt(Tat(pd)) : 0.0;
+    const bool sl = in && !(kx > kp), sr = in && !(kp > ky);
+    const unsigned long long ml = __ballot(sl), mr = __ballot(sr);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int il = nL + __popcll(ml & below), ir = nR + __popcll(mr & below);
+    if (sl && il < LC) S.Ll[il] = (unsigned short)pa;
+    if (sr && ir < LC) S.Rl[ir] = (unsigned short)pd;
+    nL += __popcll(ml);
+    nR += __popcll(mr);
+  }
+  wave_sync();
+  nL = nL < LC ? nL : LC;
+  nR = nR < LC ? nR : LC;
+  // the swaps: k < K  <=>  L[k] < R[k]  (a prefix; beyond the lists' capacity L[k] > R[k] anyway: 2 k >= l - f - 2)
+  const int nMin = nL < nR ? nL : nR;
+  int K = 0;
+  for (int k0 = 0; k0 < nMin; k0 += 64) {
+    const int k = k0 + lane;
+    int pl = 0, pr = 0;
+    bool sw = false;
+    if (k < nMin) { pl = S.Ll[k]; pr = S.Rl[k]; sw = pl < pr; }
+    const unsigned long long ms = __ballot(sw);
+    if (sw) {
+      const unsigned short el = Tat(pl), er = Tat(pr);
+      Tat(pl) = er;
+      Tat(pr) = el;
+    }
+    K += __popcll(ms);
+    if (ms != ((k0 + 64 <= nMin) ? ~0ull : ((1ull << (nMin - k0)) - 1ull))) break;
+  }
+  wave_sync();
+  int cut;
+  if (K == 0) cut = S.Ll[0];
+  else {
+    const int rk = S.Rl[K - 1];
+    cut = (K < nL && (int)S.Ll[K] < rk) ? (int)S.Ll[K] : rk;
+  }
+  return cut;
+}
+
+// The whole partition phase on T[0, N) (identity on entry) by ONE wavefront, then pos[].  `S.eq` must be complete.
+template <class KeyAt>
+__device__ __forceinline__ void ss_replay_wave(KeyAt keyAt, const StdSortScratch &S, const int N, const int lane) {
+  auto Tat = [&](int p) -> unsigned short & { return S.T[p * S.tStride]; };
+  for (int p = lane; p < N; p += 64) Tat(p) = (unsigned short)p;
+  wave_sync();
+  auto get = [&](int p) -> unsigned short { return Tat(p); };
+  auto put = [&](int p, unsigned short e) { Tat(p) = e; };
+  auto gt = [&](unsigned short a, unsigned short b) -> bool { return keyAt(a) > keyAt(b); };
+  if (S.Ll == nullptr) {   // no room for the stopper lists: lane 0 alone, the two-pointer loop (relevance from the same bits)
+    if (lane == 0) {
+      auto rel = [&](int f, int l) -> bool {
+        for (int r = f + 1; r <= l - 1; r++) if ((S.eq[r >> 6] >> (r & 63)) & 1ull) return true;
+        return false;
+      };
+      ss_replay_serial<false>(get, put, gt, N, rel, S.stack);
+    }
+  } else {
+    int sp = 0;
+    unsigned top = ss_pack_range(0, N, 2 * ss_floor_lg(N));   // (the stack's top entry rides in a register)
+    bool have = true;
+    while (have) {
+      const int f = (int)(top & 0x7ffu);
+      int l = (int)((top >> 11) & 0xfffu), d = (int)(top >> 23);
+      have = false;
+      while (l - f > SS_THRESHOLD && ss_relevant(S.eq, f, l, lane)) {
+        if (d == 0) {
+          if (lane == 0) ss_heap_sort(get, put, gt, f, l);
+          wave_sync();
+          break;
+        }
+        --d;
+        const int cut = ss_partition_wave(keyAt, S, f, l, lane);
+        if (l - cut > SS_THRESHOLD) {
+          if (lane == 0) S.stack[sp] = ss_pack_range(cut, l, d);
+          sp++;
+        }
+        l = cut;
+      }
+      if (sp > 0) {
+        wave_sync();
+        --sp;
+        top = S.stack[sp];
+        have = true;
+      }
+    }
+  }
+  wave_sync();
+  for (int p = lane; p < N; p += 64) S.pos[Tat(p)] = (unsigned short)p;
+  wave_sync();
+}
+
+// eq bits of 64 sorted ranks [c0, c0 + 64) by the calling wavefront: rank r is flagged when r < R (ranks that matter), r > 0 and
+// key(rank r) == key(rank r - 1).  entryAt(r): entry at stable rank r.  Returns the word (uniform); the caller stores it.
+template <class KeyAt, class EntryAt>
+__device__ __forceinline__ unsigned long long ss_eq_word(KeyAt keyAt, EntryAt entryAt, const int c0, const int R, const int lane) {
+  const int r = c0 + lane;
+  bool e = false;
+  if (r > 0 && r < R) e = keyAt(entryAt(r)) == keyAt(entryAt(r - 1));
+  return __ballot(e);
+}
+
+// New rank of the entry at stable rank r: unchanged unless r lies in a run of equal keys, then run start + the number of run
+// members whose position after the partition phase is smaller.  Reads only (eq, pos, the stable order); the caller writes the
+// new order after every thread has computed its ranks.
+template <class EntryAt>
+__device__ __forceinline__ int ss_fixed_rank(const StdSortScratch &S, EntryAt entryAt, const int r, const int N) {
+  auto bit = [&](int q) -> bool { return q < N && ((S.eq[q >> 6] >> (q & 63)) & 1ull); };
+  if (!bit(r) && !bit(r + 1)) return r;
+  int r0 = r;
+  while (bit(r0)) r0--;                 // (bit 0 is never set)
+  int r1 = r + 1;
+  while (bit(r1)) r1++;
+  const unsigned short myPos = S.pos[entryAt(r)];
+  int ahead = 0;
+  for (int q = r0; q < r1; q++) ahead += (S.pos[entryAt(q)] < myPos) ? 1 : 0;
+  return r0 + ahead;
+}
+
+// The whole correction for one mixture, by all NT = WPP * 64 threads of the workgroup that owns it:
+//   keyAt(e)      key of entry e (the caller maps merged-away entries to the reference's weight 0);
+//   entryAt(r)    entry at rank r of the STABLE order (ties by index), r < R;  setEntry(r, e) installs the corrected order;
+//   N             entries std::sort sees (the whole gList_);  R <= N: the ranks whose order matters (prune: the survivors).
+// Returns false (nothing to do) for N <= 16 or when no two of the R leading keys are equal.  The caller's barrier separates the
+// steps; S.T is reused as the staging area of the new order once pos[] exists.
+template <int WPP, class KeyAt, class EntryAt, class SetEntry, class Sync>
+__device__ __forceinline__ bool ss_correct_tie_order(KeyAt keyAt, EntryAt entryAt, SetEntry setEntry, const int N, const int R, const StdSortScratch &S,
+                                                     const int tid, Sync block_sync) {
+  constexpr int NT = WPP * 64;
+  if (N <= SS_THRESHOLD || R < 2) return false;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int nWords = (N + 63) >> 6;
+  for (int c = wave; c < nWords; c += WPP) {
+    const unsigned long long w = ss_eq_word(keyAt, entryAt, 64 * c, R, lane);
+    if (lane == 0) S.eq[c] = w;
+  }
+  block_sync();
+  if (__ballot(lane < nWords && S.eq[lane < nWords ? lane : 0] != 0ull) == 0ull) return false;   // (uniform over the workgroup)
+  if (wave == 0) ss_replay_wave(keyAt, S, N, lane);
+  block_sync();
+  for (int r = tid; r < R; r += NT) S.T[ss_fixed_rank(S, entryAt, r, R) * S.tStride] = (unsigned short)entryAt(r);
+  block_sync();
+  for (int r = tid; r < R; r += NT) setEntry(r, S.T[r * S.tStride]);
+  block_sync();
+  return true;
+}
+#endif  // __HIPCC__

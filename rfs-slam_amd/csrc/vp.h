@@ -545,6 +545,20 @@ __device__ void vp_weight_particle(const Buffers &B, const Params &P, int src, i
     s.perm[rank] = m;
   }
   wave_sync();
+  {  // equal weights in the order std::sort leaves them (stdsort_replay.h): index array in the upper halves of s.perm's words, the
+     // rest of the scratch over the evaluation-point tables and the late part, which are written only after this
+    StdSortScratch ss;
+    ss.T = reinterpret_cast<unsigned short *>(s.perm) + 1;
+    ss.tStride = 2;
+    unsigned char *sbuf = reinterpret_cast<unsigned char *>(s.evX);
+    const size_t sbytes = (size_t)evalCap * 8 * 4 + (size_t)evalCap * 16 * 8 + vp_weight_lds_late_bytes(evalCap, nZ);
+    if (!ss_carve(ss, sbuf, sbytes, N, false)) {
+      if (N > SS_THRESHOLD && lane == 0) atomicOr(B.err, ERRBIT_CAPACITY);   // (gm_capacity beyond ~1900 with the 3-D model: refused loudly)
+    } else {
+      ss_correct_tie_order<1>([&](int e) { return s.keys[e]; }, [&](int r) { return (int)(unsigned short)s.perm[r]; },
+                              [&](int r, unsigned short e) { s.perm[r] = (int)e; }, N, N, ss, lane, [&]() { wave_sync(); });
+    }
+  }
   if (permOut) {
     for (int r = lane; r < N; r += 64) permOut[r] = (unsigned short)s.perm[r];
   } else {
@@ -705,7 +719,7 @@ __global__ __launch_bounds__(WPB * 64) void vp_weighting_kernel(Buffers B, Param
 // fp32 copy of position + prefilter radius for the candidate sweeps: 6.8 KB whatever the capacity).
 #define VP_MERGE_LANE_LDS_BYTES ((5 * 64 + 16 + 6 * 64) * 8 + 4 * 64 * 4 + 16)
 __host__ __device__ inline size_t vp_merge_lds_bytes_per_wave(int cap) {
-  size_t a = (size_t)cap * (5 * 8 + 2);
+  size_t a = (size_t)cap * (5 * 8 + 2 + 2);    // five fp64 arrays, the survivor list and the prune's order (u16 each)
   if (a < (size_t)VP_MERGE_LANE_LDS_BYTES) a = VP_MERGE_LANE_LDS_BYTES;
   return (a + 15) & ~(size_t)15;
 }
@@ -1038,17 +1052,33 @@ __device__ void vp_merge_particle(const Buffers &B, const Params &P, int cur, in
     nSurv += __popcll(km);
   }
   wave_sync();
+  // ranks among the survivors (ties by index) -> sOrder, equal weights into std::sort's order (stdsort_replay.h; the sort of
+  // GaussianMixture::prune runs over the whole list, merged-away entries -- weight 0 -- included), then the compaction
+  unsigned short *sOrder = sIdx + st;                       // [nSurv]   (room: see vp_merge_lds_bytes_per_wave)
   for (int q = lane; q < nSurv; q += 64) {
     const int m = sIdx[q];
     const double wm = sW[m];
-    Ent3 e;
-    load_ent3(slab, cap, i, at(m), e, false);   // the survivor's record first (independent loads in flight while the rank is counted)
     int rank = 0;
     for (int q2 = 0; q2 < nSurv; q2++) {
       const int j2 = sIdx[q2];
       const double wj = sW[j2];
       rank += ((wj > wm) | ((wj == wm) & (j2 < m))) ? 1 : 0;
     }
+    sOrder[rank] = (unsigned short)m;
+  }
+  wave_sync();
+  {
+    StdSortScratch ss;                                      // positions and bounds of the merge are dead: 4 x st doubles
+    if (ss_carve(ss, reinterpret_cast<unsigned char *>(sb), 4 * st * sizeof(double), N, true))
+      ss_correct_tie_order<1>([&](int e) { const double w = sW[e]; return w < 0.0 ? 0.0 : w; }, [&](int r) { return (int)sOrder[r]; },
+                              [&](int r, unsigned short e) { sOrder[r] = e; }, N, nSurv, ss, lane, [&]() { wave_sync(); });
+    else if (N > SS_THRESHOLD && lane == 0) atomicOr(B.err, ERRBIT_CAPACITY);
+  }
+  for (int rank = lane; rank < nSurv; rank += 64) {
+    const int m = sOrder[rank];
+    const double wm = sW[m];
+    Ent3 e;
+    load_ent3(slab, cap, i, at(m), e, false);
     plane3(dl, cap, i, P3_W)[rank] = wm;
     plane3(dl, cap, i, P3_WP)[rank] = 0.0;
     plane3(dl, cap, i, P3_MX)[rank] = e.x; plane3(dl, cap, i, P3_MY)[rank] = e.y; plane3(dl, cap, i, P3_MD)[rank] = e.d;

@@ -13,6 +13,7 @@
 // assignments, on wave 0; partitions with nR+nC > 8 go to the Murty work queue (murty.h).  (7) the particle weight.
 #pragma once
 #include "common.h"
+#include "stdsort_replay.h"
 
 // Partitions too large for the in-kernel enumeration (nR + nC > 8) are handed to murty.h through this queue.
 struct MurtyJob {
@@ -617,6 +618,21 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
   DBG_TB(16, 10);
   RFS_CUT(11);
   block_sync();
+  // ---- 1b. equal weights in the order std::sort leaves them (stdsort_replay.h): s.perm holds the stable order (ties by index); the
+  // partition phase of libstdc++'s introsort is replayed on an index array in the unused upper halves of s.perm's words, runs of
+  // tied ranks are reordered by position.  Nothing happens for mixtures of <= 16 entries or without equal weights.
+  {
+    StdSortScratch ss;
+    ss.T = reinterpret_cast<unsigned short *>(s.perm) + 1;
+    ss.tStride = 2;
+    ss.pos = reinterpret_cast<unsigned short *>(s.fkeys);                      // [N]        (the float keys are dead)
+    ss.Ll = ss.pos + N;                                                         // [N / 2 + 1]  3 N + 2 <= 4 cap64 bytes
+    ss.Rl = reinterpret_cast<unsigned short *>(s.compRows);                    // [N / 2 + 1] <= 2050 B of compRows | compCols | partLik (3072 B)
+    ss.eq = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(s.compRows) + 2056);   // [<= 32]
+    ss.stack = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(s.compRows) + 2056 + 256);     // [<= 26]
+    ss_correct_tie_order<WPP>([&](int e) { return s.keys[e]; }, [&](int r) { return (int)(unsigned short)s.perm[r]; },
+                              [&](int r, unsigned short e) { s.perm[r] = (int)e; }, N, N, ss, tid, block_sync);
+  }
   // sorted mixture -> other slab (or just the permutation, for the fused step's merge phase)
   if (permOut) {
     for (int r = tid; r < N; r += NT) permOut[r] = (unsigned short)s.perm[r];

@@ -66,6 +66,12 @@ class RBPHDFilter(capi.CFilter):
         self._call("last_kernel_ns", ns)
         return list(ns)
 
+    def last_step_variant(self):
+        """{waves per particle, phase priorities, merge grid log2, fused} of the last stream-ordered step."""
+        out = (C.c_int * 4)()
+        self._call("last_step_variant", out)
+        return tuple(out)
+
     def update_async(self, Z):
         """Stream-ordered update: no host sync; errors surface at synchronize()."""
         Z, n = self._z(Z)

@@ -43,7 +43,12 @@ class ShardedRBPHDFilter:
         assert inheritance in ("reference", "eager")
         self.inheritance = inheritance
         self.f = local
+        # the engine handle is switched to the mode this host needs and switched BACK by close(): a handle that outlives the
+        # wrapper must not stay in EXTERNAL mode (in which the engine refuses a birth predict after a resampling unless the host
+        # has dealt with the inheritance rule: every predict must go through self.predict_map, never through self.f.predict_map)
+        self._mode_before = local.get_birth_inheritance() if hasattr(local, "get_birth_inheritance") else None
         local.set_birth_inheritance(capi.INHERIT_EXTERNAL if inheritance == "reference" else capi.INHERIT_EAGER)
+        self.cand_lists_seen = False       # a candidate list has been moved / kept on SOME shard (all-reduced in predict_map)
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -127,20 +132,51 @@ class ShardedRBPHDFilter:
         candidate list exists and the walk has a closed form over the lists as they are before the predict: own list if
         idParent_ == slot, the parent slot's list if that is a HIGHER slot (not yet visited), nothing if it is a LOWER one
         (already consumed).  One all-gather of N 8-byte masks, only in those predicts."""
-        if add_birth and self.resampleOccured and self.inheritance == "reference" and np.any(self.ppid != np.arange(self.n_total)):
-            cfg = self.f.get_filter_config()
-            if cfg.birthGaussianMeasurementCountThreshold == 1 and self.f.dz == 2:
-                m_all = self._gather_masks()
-                lo = self.rank * self.n_local
-                g = np.arange(lo, lo + self.n_local)
-                p = self.ppid[g]
-                new = np.where(p == g, m_all[g], np.where(p > g, m_all[np.clip(p, 0, self.n_total - 1)], np.uint64(0))).astype(np.uint64)
-                if np.any(new != m_all[g]):
-                    self.f.set_unused_masks(new)
-            else:
-                self._predict_levels(add_birth)
-                return
+        if add_birth and self.resampleOccured and self.inheritance == "reference":
+            if np.any(self.ppid != np.arange(self.n_total)):
+                cfg = self.f.get_filter_config()
+                # ONE predicate for every rank (and the same one rfsgpu_group_predict_map uses): the closed form over the masks is
+                # only valid while no shard holds a candidate list -- imported lists on an immediate-birth configuration included
+                if cfg.birthGaussianMeasurementCountThreshold == 1 and self.f.dz == 2 and not self._any_shard_has_candidates():
+                    m_all = self._gather_masks()
+                    lo = self.rank * self.n_local
+                    g = np.arange(lo, lo + self.n_local)
+                    p = self.ppid[g]
+                    new = np.where(p == g, m_all[g], np.where(p > g, m_all[np.clip(p, 0, self.n_total - 1)], np.uint64(0))).astype(np.uint64)
+                    if np.any(new != m_all[g]):
+                        self.f.set_unused_masks(new)
+                else:
+                    self._predict_levels(add_birth)
+                    return
+            # acknowledge to the engine that the rule has been applied (or that no slot has a foreign parent) for this predict
+            self.f.set_birth_inheritance(capi.INHERIT_EXTERNAL)
         self.f.predict_map(add_birth)
+
+    def _any_shard_has_candidates(self):
+        """Does any shard hold birth candidates (count over its slots > 0)?  All-reduced so that every rank takes the same branch."""
+        has = 0
+        if hasattr(self.f, "has_birth_candidates"):
+            has = int(bool(self.f.has_birth_candidates()))
+        if self.world > 1:
+            t = torch.tensor([has], dtype=torch.int64)
+            if self.on_gpu and self.backend == "nccl":
+                with self._stream_ctx():
+                    td = t.to(self.device)
+                    dist.all_reduce(td, op=dist.ReduceOp.MAX, group=self.group)
+                    t = td.cpu()
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            has = int(t.item())
+        return bool(has)
+
+    def close(self):
+        """Give the engine handle back in the inheritance mode it had before this wrapper took it over."""
+        if self._mode_before is not None and self.f is not None:
+            try:
+                self.f.set_birth_inheritance(self._mode_before)
+            except Exception:   # noqa: BLE001  (handle already closed)
+                pass
+        self._mode_before = None
 
     def _predict_levels(self, add_birth):
         """Configurations that keep birth-candidate lists (Victoria Park; CountThreshold > 1): the walk in full, level by level over
@@ -339,6 +375,7 @@ def bench_resample_migration(pkg, f, rank, world, dev, stream=None, sums=None, r
             times.append(dt)
     t = torch.tensor([float(np.median(times)), float(sh.last_migration["rows_sent"]), float(sh.last_migration["bytes_sent"])],
                      dtype=torch.float64, device=dev)
+    sh.close()                                                  # the handle goes back in the mode it came in
     tmax = t.clone()
     # who sent how many rows to whom (row r = rank r's per-destination counts): the all-to-all's split lists, zeros included
     pair = torch.tensor(sh.last_migration.get("rows_to_rank", [0] * world), dtype=torch.float64, device=dev)

@@ -121,18 +121,18 @@ def check_candidates(out):
 
 
 def test_oracle_reference_inheritance_three_cases(ob, sc):
-    orc = ob.OracleFilter(5, stable_sort=True)
+    orc = ob.OracleFilter(5)
     assert orc.get_birth_inheritance() == 0
     check_immediate(script_immediate(orc, sc))
 
 
 def test_oracle_reference_inheritance_with_candidate_lists(ob, sc):
-    check_candidates(script_candidates(ob.OracleFilter(5, stable_sort=True), sc))
+    check_candidates(script_candidates(ob.OracleFilter(5), sc))
 
 
 def test_oracle_eager_mode_is_the_old_rule(ob, sc):
     """RFSGPU_INHERIT_EAGER (rounds 1-2): the child takes the parent's lists and FOV count at resampling time."""
-    orc = ob.OracleFilter(5, stable_sort=True)
+    orc = ob.OracleFilter(5)
     orc.set_birth_inheritance(1)
     _setup_immediate(orc, sc, 5, 6)
     orc.set_unused_masks(np.array([1, 6, 8, 49, 16], dtype=np.uint64))
@@ -147,7 +147,7 @@ def test_oracle_eager_mode_is_the_old_rule(ob, sc):
 
 def _pair(pkg, ob, n, cap=128, model=None):
     kw = {} if model is None else {"model": model}
-    return pkg.RBPHDFilter(n, gm_capacity=cap, **kw), ob.OracleFilter(n, stable_sort=True, **kw)
+    return pkg.RBPHDFilter(n, gm_capacity=cap, **kw), ob.OracleFilter(n, **kw)
 
 
 def _compare_all(sc, dev, orc, n, lists=True):

@@ -15,7 +15,7 @@ GM_RTOL, GM_ATOL = 1e-10, 1e-12
 
 def make_pair(pkg, ob, sc, scen, cap=512):
     dev = pkg.RBPHDFilter(scen["n"], device_id=0, gm_capacity=cap)
-    orc = ob.OracleFilter(scen["n"], stable_sort=True)
+    orc = ob.OracleFilter(scen["n"])
     for f in (dev, orc):
         sc.load_scenario(f, scen)
     return dev, orc
@@ -613,7 +613,7 @@ def test_tied_weights_rank_by_index(pkg, ob, sc, n_lm, cap):
     if n_lm > 128:
         scen["w"][:, 2::3] = np.array([0.9, 0.5, 0.31])[np.arange(n_lm // 3) % 3][None, :]      # a few values, tied all over
     dev = pkg.RBPHDFilter(scen["n"], gm_capacity=cap)
-    orc = ob.OracleFilter(scen["n"], stable_sort=True)
+    orc = ob.OracleFilter(scen["n"])
     for f in (dev, orc):
         sc.load_scenario(f, scen)
         f.update_map(scen["Z"])
@@ -639,7 +639,7 @@ def test_rank_sort_over_a_wide_range_of_weights(pkg, ob, sc, n_lm, cap, fused):
     w[:, k:2 * k] = 0.4 + 1e-13 * rng.integers(0, 50, (w.shape[0], k))       # inside one bucket, a few exact ties
     w[:, 2 * k:2 * k + 5] = 0.25                                            # exact ties
     dev = pkg.RBPHDFilter(scen["n"], gm_capacity=cap)
-    orc = ob.OracleFilter(scen["n"], stable_sort=True)
+    orc = ob.OracleFilter(scen["n"])
     for f in (dev, orc):
         sc.load_scenario(f, scen)
     if fused:
@@ -833,7 +833,7 @@ def test_fastslam_host_mirror_resamples_with_candidates(pkg, ob, sc):
     same host logic and the same uniform draws: weights, maps and the candidate lists that travel with resampled particles."""
     scen = sc.make_scenario(24, 40, 14, seed=81, rmax=8.0)
     dev = pkg.FastSLAM(scen["n"], gm_capacity=256)
-    orc = ob.OracleFilter(scen["n"], stable_sort=True)
+    orc = ob.OracleFilter(scen["n"])
     for f in (dev, orc):
         sc.load_scenario(f, scen)
         for i in range(scen["n"]):
@@ -907,7 +907,7 @@ def test_multi_hypothesis_fastslam(pkg, ob, sc, kw, hyp, diff):
     scen = sc.make_scenario(**kw)
     n0 = scen["n"]
     dev = pkg.RBPHDFilter(n0, gm_capacity=128, max_particles=n0 * hyp * 4)
-    orc = ob.OracleFilter(n0, stable_sort=True)
+    orc = ob.OracleFilter(n0)
     for f in (dev, orc):
         sc.load_scenario(f, scen)
         for i in range(n0):
@@ -958,7 +958,7 @@ def test_mh_fastslam_host_mirror(pkg, ob, sc):
     scen = sc.make_scenario(n_particles=8, n_landmarks=14, n_z=7, seed=15, rmax=5.0)
     n0 = scen["n"]
     dev = pkg.FastSLAM(n0, gm_capacity=128, max_hypotheses=3, n_particles_max=12)
-    orc = ob.OracleFilter(n0, stable_sort=True)
+    orc = ob.OracleFilter(n0)
     assert dev.max_particles >= 36
     for f in (dev, orc):
         sc.load_scenario(f, scen)
@@ -1029,7 +1029,7 @@ def test_fastslam_hypothesis_count_limit(pkg, sc):
 
 def make_vp_pair(pkg, ob, sc, scen, cap=192):
     dev = pkg.RBPHDFilter(scen["n"], device_id=0, gm_capacity=cap, model=pkg.capi.MODEL_VICTORIAPARK_3D)
-    orc = ob.OracleFilter(scen["n"], stable_sort=True, model=pkg.capi.MODEL_VICTORIAPARK_3D)
+    orc = ob.OracleFilter(scen["n"], model=pkg.capi.MODEL_VICTORIAPARK_3D)
     for f in (dev, orc):
         sc.load_scenario(f, scen)
     return dev, orc
@@ -1250,7 +1250,7 @@ def test_victoria_park_dataset_extract_device_vs_oracle(pkg, ob, sc, n):
     P = dict(sc.VP_PARAMS)
     runs = []
     for make in (lambda: pkg.RBPHDFilter(n, gm_capacity=192, model=pkg.capi.MODEL_VICTORIAPARK_3D),
-                 lambda: ob.OracleFilter(n, stable_sort=True, model=pkg.capi.MODEL_VICTORIAPARK_3D)):
+                 lambda: ob.OracleFilter(n, model=pkg.capi.MODEL_VICTORIAPARK_3D)):
         f = make()
         sc.apply_vp_params(f, P, np.full(361, 70.0))
         runs.append(pkg.vp_driver.VictoriaParkRun(f, data, P, seed=5).run(n_messages=900))
@@ -1274,7 +1274,7 @@ def test_c1_trajectory_device_vs_oracle(pkg, ob, sc, n, steps, seed):
     sd = pkg.sim2d_driver
     data = sd.generate(traj_seed=seed, kmax=steps)
     dev = pkg.RBPHDFilter(n, gm_capacity=256)
-    orc = ob.OracleFilter(n, stable_sort=True)
+    orc = ob.OracleFilter(n)
     seen = dict(updates=0, max_size=0, births=0)
 
     def check(k, run, fired):
@@ -1309,7 +1309,7 @@ def test_c1_full_run_device_and_oracle_agree_on_map_quality(pkg, ob, sc):
     for seed in (1, 4):
         data = sd.generate(traj_seed=seed)
         dev = pkg.RBPHDFilter(100, gm_capacity=256)
-        orc = ob.OracleFilter(100, stable_sort=True)
+        orc = ob.OracleFilter(100)
         run = sd.Sim2dRun([dev, orc], data, seed=seed).run()
         wd, wo = dev.get_weights(), orc.get_weights()
         np.testing.assert_allclose(wd, wo, rtol=1e-6)
@@ -1360,7 +1360,7 @@ def test_victoria_park_dataset_extract_fastslam(pkg, ob, sc):
     P = dict(sc.VP_PARAMS)
     runs = []
     for make in (lambda: pkg.RBPHDFilter(n, gm_capacity=192, model=pkg.capi.MODEL_VICTORIAPARK_3D),
-                 lambda: ob.OracleFilter(n, stable_sort=True, model=pkg.capi.MODEL_VICTORIAPARK_3D)):
+                 lambda: ob.OracleFilter(n, model=pkg.capi.MODEL_VICTORIAPARK_3D)):
         f = make()
         sc.apply_vp_params(f, P, np.full(361, 70.0))
         cfg = f.default_fastslam_config()
@@ -1384,7 +1384,7 @@ def test_victoria_park_dataset_extract_fastslam(pkg, ob, sc):
 
 # ---- BASELINE.json full-size configurations: size-independent properties + oracle parity on a particle subset -------------
 
-def _full_size_check(pkg, ob, sc, scen, cap, subset=24, check_murty=False):
+def _full_size_check(pkg, ob, sc, scen, cap, subset=24, check_murty=False, fused=None, fused_cap=None):
     n = scen["n"]
     dev = pkg.RBPHDFilter(n, gm_capacity=cap)
     sc.load_scenario(dev, scen)
@@ -1410,7 +1410,7 @@ def _full_size_check(pkg, ob, sc, scen, cap, subset=24, check_murty=False):
     sub.update(n=subset, poses=scen["poses"][idx], w=scen["w"][idx], mean=scen["mean"][idx], cov=scen["cov"][idx], particle_w=scen["particle_w"][idx])
     if np.ndim(scen["pose_cov"]) == 3:
         sub["pose_cov"] = scen["pose_cov"][idx]
-    orc = ob.OracleFilter(subset, stable_sort=True)
+    orc = ob.OracleFilter(subset)
     sc.load_scenario(orc, sub)
     orc.update(scen["Z"])
     if check_murty:
@@ -1419,6 +1419,24 @@ def _full_size_check(pkg, ob, sc, scen, cap, subset=24, check_murty=False):
     for k, i in enumerate(idx):
         sc.assert_gm_close(dev.export_gm(int(i)), orc.export_gm(k), GM_RTOL, GM_ATOL, ordered=True)
     dev.close()
+    # The same scenario through the launch bench.py TIMES: rfsgpu_step_async = ONE fused kernel + the post
+    # kernel (Murty partitions, weight sums, division), at the full particle count -- the instantiation is checked by name --
+    # against the same oracle subset: mixtures in order, particle weights after the global normalisation.
+    if fused is not None:
+        dev = pkg.RBPHDFilter(n, gm_capacity=fused_cap or cap)       # (bench.py's capacity for this workload)
+        sc.load_scenario(dev, scen)
+        dev.step_async(scen["Z"], normalize=True)
+        dev.synchronize()
+        assert dev.last_step_variant() == fused, dev.last_step_variant()
+        wf = dev.get_weights()
+        np.testing.assert_allclose(wf.sum(), 1.0, rtol=1e-12)
+        np.testing.assert_allclose(wf, wd / wd.sum(), rtol=1e-12, atol=0)          # fused step == the four stand-alone kernels
+        wo = orc.get_weights()
+        np.testing.assert_allclose(wf[idx] / wf[idx].sum(), wo / wo.sum(), rtol=1e-8)
+        assert np.array_equal(dev.gm_sizes(), sizes1)
+        for k, i in enumerate(idx):
+            sc.assert_gm_close(dev.export_gm(int(i)), orc.export_gm(k), GM_RTOL, GM_ATOL, ordered=True)
+        dev.close()
 
 
 def test_bench_two_ranks_on_one_gpu():
@@ -1447,12 +1465,12 @@ def test_bench_two_ranks_on_one_gpu():
 
 def test_full_size_c2(pkg, ob, sc):
     """configs[1]: 2000 particles x 200 GM landmarks x 30 measurements."""
-    _full_size_check(pkg, ob, sc, sc.make_scenario(2000, 200, 30, seed=12345), cap=384)
+    _full_size_check(pkg, ob, sc, sc.make_scenario(2000, 200, 30, seed=12345), cap=384, fused=(2, 1, 5, 1))   # phd_step_fused_kernel<2, true, 5>
 
 
 def test_full_size_c3_shard(pkg, ob, sc):
     """configs[2], one GPU's shard: 2500 particles x 500 GM landmarks x 30 measurements (range limit 5 m)."""
-    _full_size_check(pkg, ob, sc, sc.make_scenario(2500, 500, 30, seed=777, rmax=5.0), cap=704)
+    _full_size_check(pkg, ob, sc, sc.make_scenario(2500, 500, 30, seed=777, rmax=5.0), cap=704, fused=(3, 0, 6, 1), fused_cap=640)   # <3, false, 6>
 
 
 def test_full_size_c4_victoria_park(pkg, ob, sc):
@@ -1470,7 +1488,7 @@ def test_full_size_c4_victoria_park(pkg, ob, sc):
                particle_w=scen["particle_w"][idx])
     if np.ndim(scen["pose_cov"]) == 3:
         sub["pose_cov"] = scen["pose_cov"][idx]
-    orc = ob.OracleFilter(subset, stable_sort=True, model=pkg.capi.MODEL_VICTORIAPARK_3D)
+    orc = ob.OracleFilter(subset, model=pkg.capi.MODEL_VICTORIAPARK_3D)
     sc.load_scenario(orc, sub)
     rng = np.random.default_rng(9)
     for step in range(2):
@@ -1499,7 +1517,7 @@ def test_full_size_c4_victoria_park(pkg, ob, sc):
 def test_full_size_c5_murty_stress(pkg, ob, sc):
     """configs[4]: 1000 particles x 50 measurements, 40 evaluation points, 10-sigma weighting gate -> Murty-200 partitions."""
     scen = sc.make_scenario(1000, 200, 50, seed=555, n_clutter=10, n_eval=40, weighting_md=10.0, weights=(0.8, 1.0))
-    _full_size_check(pkg, ob, sc, scen, cap=448, subset=16, check_murty=True)
+    _full_size_check(pkg, ob, sc, scen, cap=448, subset=16, check_murty=True, fused=(2, 1, 5, 1))
 
 
 def test_murty_search_with_solver_waves_is_deterministic(pkg, sc):

@@ -177,7 +177,7 @@ def np_importance_weight(P, pose, pose_cov, w, wp, mu, Sg, Z, prev_weight):
 @pytest.mark.parametrize("seed", [4, 5, 6])
 def test_importance_weighting_vs_numpy(ob, sc, seed):
     scen = sc.make_scenario(3, 30, 9, seed=seed, per_particle_pose_cov=True, n_eval=6)
-    o = ob.OracleFilter(scen["n"], stable_sort=True)
+    o = ob.OracleFilter(scen["n"])
     sc.load_scenario(o, scen)
     o.update_map(scen["Z"])
     maps = [o.export_gm(i) for i in range(scen["n"])]
@@ -215,7 +215,7 @@ def np_merge(w, mu, Sg, t, f):
 @pytest.mark.parametrize("seed", [7, 8])
 def test_merge_and_prune_vs_numpy(ob, sc, seed):
     scen = sc.make_scenario(3, 40, 12, seed=seed)
-    o = ob.OracleFilter(scen["n"], stable_sort=True)
+    o = ob.OracleFilter(scen["n"])
     sc.load_scenario(o, scen)
     o.update_map(scen["Z"])
     o.importance_weighting()
@@ -342,7 +342,7 @@ def test_fastslam_update_against_numpy(ob, sc, seed, nm, nz, rmax):
     n = 6
     scen = sc.make_scenario(n, nm, nz, seed=seed, rmax=rmax)
     P = scen["params"]
-    orc = ob.OracleFilter(n, stable_sort=True)
+    orc = ob.OracleFilter(n)
     sc.load_scenario(orc, scen)
     lw0 = np.random.default_rng(seed).uniform(-1.0, 2.0, (n, nm))
     for i in range(n):

@@ -70,7 +70,7 @@ def _worker(rank, world, port, n_total, force_resample, q, big=False, cycles=0, 
     sc = pkg.scenarios
     ob.set_threads(1)
     scen = make_scen(sc, n_total, big)
-    local = ob.OracleFilter(n_total // world, stable_sort=True)
+    local = ob.OracleFilter(n_total // world)
     sc.load_scenario(local, shard_scen(scen, rank, world))
     if cand:
         candidate_config(local)
@@ -110,7 +110,7 @@ def run_world(n_total, force_resample, world=2, big=False, cycles=0, cand=False)
 def single_process(pkg, ob, n_total, force_resample, big=False):
     sc = pkg.scenarios
     scen = make_scen(sc, n_total, big)
-    f = ob.OracleFilter(n_total, stable_sort=True)
+    f = ob.OracleFilter(n_total)
     sc.load_scenario(f, scen)
     sh = pkg.sharded.ShardedRBPHDFilter(f)     # world 1: same host code path, no collectives
     sh.effNParticles_t = n_total + 1.0 if force_resample else 1e-9
@@ -161,7 +161,7 @@ def test_sharded_resampling_cycles_inherit_birth_state_as_the_reference(pkg, ob,
     n_total, cycles = 24, 4
     sc = pkg.scenarios
     scen = make_scen(sc, n_total)
-    ref = ob.OracleFilter(n_total, stable_sort=True)
+    ref = ob.OracleFilter(n_total)
     assert ref.get_birth_inheritance() == pkg.capi.INHERIT_REFERENCE
     sc.load_scenario(ref, scen)
     if cand:

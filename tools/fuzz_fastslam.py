@@ -51,7 +51,7 @@ for case in range(n_cases):
     diff = float(rng.choice([2.0, 5.0, 50.0]))
     model = pkg.capi.MODEL_VICTORIAPARK_3D if vp else pkg.capi.MODEL_RNGBRG_2D
     dev = pkg.RBPHDFilter(n0, gm_capacity=320, max_particles=n0 * hyp * 4, model=model)
-    orc = ob.OracleFilter(n0, stable_sort=True, model=model)
+    orc = ob.OracleFilter(n0, model=model)
     try:
         for f in (dev, orc):
             sc.load_scenario(f, scen)

@@ -37,7 +37,7 @@ def vp_case(case):
     if ONLY is not None and case not in ONLY:
         return
     dev = pkg.RBPHDFilter(n, gm_capacity=256, model=pkg.capi.MODEL_VICTORIAPARK_3D)
-    orc = ob.OracleFilter(n, stable_sort=True, model=pkg.capi.MODEL_VICTORIAPARK_3D)
+    orc = ob.OracleFilter(n, model=pkg.capi.MODEL_VICTORIAPARK_3D)
     try:
         for f in (dev, orc):
             sc.load_scenario(f, scen)
@@ -131,7 +131,7 @@ for case in range(n_cases):
     for fused in (1, 0):
         os.environ["RFSGPU_FUSED_STEP"] = str(fused)
         dev = pkg.RBPHDFilter(n, gm_capacity=cap)
-        orc = ob.OracleFilter(n, stable_sort=True)
+        orc = ob.OracleFilter(n)
         try:
             for f in (dev, orc):
                 sc.load_scenario(f, scen)
