@@ -33,13 +33,16 @@
  *   [async]    stream-ordered forms for host loops that pipeline (rfsgpu_*_async, rfsgpu_step_async, rfsgpu_set_stream, ...);
  *   [multi]    several GPUs: rfsgpu_group_* (one host thread), slab rows / device pointers (one process per GPU over RCCL);
  *   [state]    state injection and probes for tests and tools (import / export of mixtures, candidate lists, ids, masks);
- *   [bench]    snapshot / restore, kernel timing statistics, debug counters;
+ *   [bench]    snapshot / restore, kernel timing statistics, debug counters, test probes: declared only under
+ *              RFSGPU_ENABLE_BENCH_API (a maintainer reading this header for the binding never meets them);
  *   [fastslam] FastSLAM / MH-FastSLAM on the same handle, the optional device-side Ackerman propagation, rfsgpu_mat_perm.
  * A maintainer wiring the reference to the library reads the CORE entries and INTEGRATION.md; nothing optional is required
  * for correct results.
  */
 #ifndef RFSGPU_H
 #define RFSGPU_H
+
+#include <stddef.h>   /* size_t */
 
 #ifdef __cplusplus
 extern "C" {
@@ -204,10 +207,12 @@ int rfsgpu_set_model_victoriapark(rfsgpu_filter *f, const rfsgpu_vp_config *cfg)
 /* MeasurementModel_VictoriaPark::setLaserScan (src/MeasurementModel_VictoriaPark.cpp:267-281): the raw scan used by the
  * occlusion-based Pd and by the clutter intensity (expected clutter / field-of-view area); n <= RFSGPU_VP_MAX_SCAN. */
 int rfsgpu_set_laser_scan(rfsgpu_filter *f, const double *scan, int n);
+#ifdef RFSGPU_ENABLE_BENCH_API   /* [bench] / [test]: exported by the library, declared only for callers that ask (bench.py, the tests) */
 /* Probe for tests: MeasurementModel_VictoriaPark::probabilityOfDetection (src/MeasurementModel_VictoriaPark.cpp:153-199) of the
  * first max_n Gaussians of particle `slot` under the current pose and scan, as the kernels evaluate it: Pd and the
  * isCloseToSensingLimit flag. */
 int rfsgpu_vp_probe_pd(rfsgpu_filter *f, int slot, double *pd, int *close_to_limit, int max_n);
+#endif /* RFSGPU_ENABLE_BENCH_API */
 /* getLmkProcessModel()->setNoise(Q) (include/ProcessModel.hpp:195-208); Q is d_m x d_m. */
 int rfsgpu_set_lmk_process_noise(rfsgpu_filter *f, const double *Q);
 
@@ -302,6 +307,7 @@ int rfsgpu_propagate_ackerman_async(rfsgpu_filter *f, const double *u, const dou
  * call0 + 1, ...) in ONE launch; every particle takes the steps one after the other: the same poses, bit for bit. */
 int rfsgpu_propagate_ackerman_run_async(rfsgpu_filter *f, int n, const double *u, const double *var, const double *dt, const double *geom,
                                         unsigned long long seed, unsigned long long call0);
+#ifdef RFSGPU_ENABLE_BENCH_API   /* [bench] / [test]: exported by the library, declared only for callers that ask (bench.py, the tests) */
 /* [bench] Average duration (ns) of each hot-path kernel group over the async steps harvested since the last call / reset:
  * [0]=phd_update_map [1]=phd_weight_multifeature [2]=gm_merge(+prune); *n_steps = steps averaged.  Steps that ran as one
  * fused kernel report its duration in [0] and 0 in [1], [2] (their TimingInfo share is booked under mapUpdate). */
@@ -311,8 +317,10 @@ int rfsgpu_kernel_time_stats(rfsgpu_filter *f, double *avg_ns3, int *n_steps);
 double rfsgpu_post_kernel_avg_ns(const rfsgpu_filter *f);
 /* [bench] The HIP events behind the two calls above ride on every `every`-th fused stream-ordered step only (default 1: on each).  Three
  * event records per step cost a step of configs[1] 8 us of its 144 (each is a marker packet the queue drains before the next
- * kernel starts); bench.py samples every 8th step of its timed region.  Statistics average over the sampled steps. */
+ * kernel starts); bench.py samples every 8th step of its timed region.  Statistics average over the sampled steps; TimingInfo
+ * (rfsgpu_get_timing) books every sampled step `every` times, i.e. it stays an estimate of the whole run's device time. */
 int rfsgpu_set_step_timing_stride(rfsgpu_filter *f, int every);
+#endif /* RFSGPU_ENABLE_BENCH_API */
 /* The same four phases one at a time (used by the parity tests and by profiling):          */
 int rfsgpu_update_map(rfsgpu_filter *f, const double *z, int n_z);      /* updateMap       :543-725 */
 int rfsgpu_importance_weighting(rfsgpu_filter *f);                       /* importanceWeighting :728-997 */
@@ -461,6 +469,7 @@ int rfsgpu_set_stream(rfsgpu_filter *f, void *hip_stream);
 /* Let rfsgpu_weight_sums_async write {sum w, sum w^2} into a caller-owned device buffer (2 doubles),
  * e.g. a tensor the multi-GPU host all-reduces in place over RCCL.  NULL restores the internal one. */
 int rfsgpu_bind_weight_sums_buffer(rfsgpu_filter *f, void *dev_ptr);
+#ifdef RFSGPU_ENABLE_BENCH_API   /* [bench] / [test]: exported by the library, declared only for callers that ask (bench.py, the tests) */
 /* Device-side snapshot / restore of the MAP state of every particle (mixtures, sizes, particle weights, unused-measurement
  * lists, FOV counts): one snapshot slot per handle, allocated on first use.  A benchmarking / testing helper -- it is how a
  * timed step is re-seeded -- NOT a checkpoint: poses, the birth-candidate lists and the staged measurement set are not part of
@@ -475,6 +484,7 @@ int rfsgpu_last_kernel_ns(rfsgpu_filter *f, long long *ns4);
  * kernels (0)} -- so that the full-size parity tests can say which kernel they checked (phd_step_fused_kernel<2, true, 5> is the
  * one bench.py times at configs[1]). */
 int rfsgpu_last_step_variant(const rfsgpu_filter *f, int *out4);
+#endif /* RFSGPU_ENABLE_BENCH_API */
 
 /* MatPerm::calc (src/MatrixPermanent.cpp:41-112), batched: `batch` row-major n x n matrices in A
  * (host), permanents to out (host).  n <= 24.  Standalone (no filter handle needed). */

@@ -38,15 +38,16 @@ def build(force=False, verbose=False, extra_flags=()):
     return LIB
 
 
-# Test support, not product: the library with the quarter-wave Hungarian solver switched on (hungarian_quad.h; measured slower than
+# Test support, not product: the library with the quarter-wave Hungarian solver switched on (tests/support/variants/hungarian_quad.h; measured slower than
 # the shipped one-wave solvers, DESIGN 8 -- tests/test_gpu_parity.py checks that it returns the same bits).  Built next to the
 # other test artefacts (git-ignored, travels to the GPU box).
 QUAD_LIB = os.path.join(ROOT, "tests", "support", "_build", "librfsgpu_quad.so")
-QUAD_FLAGS = ["-DMURTY_QUAD=1", "-DMURTY_JOB_WAVES=3", "-DMURTY_WAVES_PER_EU=3", "-DMURTY_HEAP_LDS=32"]   # (a 32-entry LDS heap front: the search's heap spills into the arena in the test)
+QUAD_FLAGS = ["-I" + os.path.join(ROOT, "tests", "support", "variants"), "-DMURTY_QUAD=1", "-DMURTY_JOB_WAVES=3", "-DMURTY_WAVES_PER_EU=3", "-DMURTY_HEAP_LDS=32"]   # (a 32-entry LDS heap front: the search's heap spills into the arena in the test)
 
 
 def build_quad_variant(force=False, verbose=False):
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "rfsgpu.h")]
+    vdir = os.path.join(ROOT, "tests", "support", "variants")
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(vdir, f) for f in os.listdir(vdir)] + [os.path.join(ROOT, "include", "rfsgpu.h")]
     if not force and os.path.exists(QUAD_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(QUAD_LIB) for d in deps):
         return QUAD_LIB
     os.makedirs(os.path.dirname(QUAD_LIB), exist_ok=True)

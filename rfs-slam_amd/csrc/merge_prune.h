@@ -184,7 +184,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
   // The 64 x 64 grid pays on sparse maps only (configs[2]'s shard: cells of two prefilter radii, fused step 254 -> 243 us).  Where
   // a cell of extent / 64 would be thinner than ~1.5 radii it is clamped to the radius, the rows' slack (cell edge - radius) drops
   // to zero and every row that merges falls back to the sequential scan (2000 x 400 Gaussians within 2.5 m: 319 -> 573 us): such a
-  // particle uses every other cell of the array, i.e. a 32 x 32 grid (gxe x gye cells in use, row stride MERGE_GX).
+  // particle uses the first 32 x 32 cells of the array only (gxe x gye cells in use, row stride MERGE_GX).
   int gxe = MERGE_GX, gye = MERGE_GY;
   if constexpr (GL == 6) {
 #ifndef MERGE_FINE_MIN

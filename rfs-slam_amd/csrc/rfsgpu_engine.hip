@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 
+#define RFSGPU_ENABLE_BENCH_API 1   // the library defines (and exports) the [bench] / [test] entry points too
 #include "rfsgpu.h"
 #include "common.h"
 #include "update_map.h"
@@ -919,6 +920,8 @@ static void harvest_async(rfsgpu_filter *f) {
     long long ns[3] = {0, 0, 0};
     if (f->ringFused[k]) {  // one kernel for the whole step: booked under mapUpdate, reported as kernel 0
       accumulate(e[0], e[3], f->timing.mapUpdate_wall, &ns[0]);
+      // (only every timingStride-th fused step carries events: TimingInfo books the sampled step once for each step it stands for)
+      if (f->timingStride > 1) f->timing.mapUpdate_wall += ns[0] * (long long)(f->timingStride - 1);
       for (int q = 0; q < 3; q++) { f->statNs[q] += (double)ns[q]; f->lastKernelNs[q] = ns[q]; }
       {   // the post kernel (Murty jobs if any, queue reset, weight sums / division): event 1 is free on this path
         float ms = 0.f;

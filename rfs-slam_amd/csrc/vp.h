@@ -287,7 +287,7 @@ __host__ __device__ inline size_t vp_update_lds_bytes_per_wave(int cap) { return
 // RBPHDFilter::updateMap for the Victoria Park model (same phases as phd_update_map_kernel).
 // One wavefront takes particle i through the map update.  sZ / sScan: the measurement set and the laser scan, staged in LDS by
 // the caller (shared by the waves of a workgroup); wb: vp_update_lds_bytes_per_wave(cap) bytes of LDS of this wave.
-// pdCache (the fused step; may be null): receives, per landmark, the Pd-table index of its probabilityOfDetection (255: exactly 0
+// pdCache (the fused step; may be null): receives, per landmark, the Pd-table index of its probabilityOfDetection (254: not a table value, evaluate again; 255: exactly 0
 // by an early return) -- the weighting phase asks for the same number again when it picks evaluation points among landmarks
 // the update has not moved.  Returns the number of landmarks before the update.
 __device__ int vp_update_map_particle(const Buffers &B, const Params &P, int cur, int nZ, int i, int lane, const double *sZ, const double *sScan,
@@ -324,7 +324,7 @@ __device__ int vp_update_map_particle(const Buffers &B, const Params &P, int cur
     double pd = vp_pd_wave(P, sScan, B.nScan, px, py, pth, e, act, close, reinterpret_cast<unsigned char *>(sSeg + cap));
     if (!act) { pd = 0.0; close = false; }
     if (pdCache && act) {          // (the value is a table entry or the 0.0 of an early return: kept as an index, one byte)
-      int idx = 255;
+      int idx = (pd == 0.0) ? 255 : 254;   // 255: exactly 0; 254: a value that is no table entry (NaN entries, ...): NOT cached, re-evaluated later
       for (int k = 0; k < P.nPd; k++) idx = (P.PdTable[k] == pd) ? k : idx;
       pdCache[m] = (unsigned char)idx;
     }
@@ -593,8 +593,10 @@ __device__ void vp_weight_particle(const Buffers &B, const Params &P, int src, i
         load_ent3(sl, cap, i, m, e, false);
         if (pdCache && m < nCached) {       // a landmark the update left where it was: same pose, same mean, same covariance, same scan
           const int idx = pdCache[m];
-          pd = (idx == 255) ? 0.0 : P.PdTable[idx];
-          cached = true;
+          if (idx != 254) {
+            pd = (idx == 255) ? 0.0 : P.PdTable[idx];
+            cached = true;
+          }
         }
       }
       {

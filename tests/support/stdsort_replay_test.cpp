@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <string>
 #include <vector>
 #include "../../rfs-slam_amd/csrc/stdsort_replay.h"
 
@@ -99,6 +100,14 @@ static std::vector<int> killer(int n) {
 }
 
 int main(int argc, char **argv) {
+  if (argc > 3 && std::string(argv[1]) == "killer") {   // "killer n q": an adversarial weight sequence (values val / q), one per line, then
+    const int n = atoi(argv[2]), q = atoi(argv[3]);      // whether std::sort's depth limit is reached on it
+    const std::vector<int> val = killer(n);
+    std::vector<double> w(n);
+    for (int k = 0; k < n; k++) { w[k] = (double)(val[k] / q); printf("%d\n", val[k] / q); }
+    printf("depth_limit_reached %d\n", exhausts_depth(w) ? 1 : 0);
+    return 0;
+  }
   const int cases = argc > 1 ? atoi(argv[1]) : 20000;
   std::mt19937_64 rng(argc > 2 ? atoll(argv[2]) : 1);
   long done = 0;

@@ -1382,6 +1382,81 @@ def test_victoria_park_dataset_extract_fastslam(pkg, ob, sc):
         sc.assert_gm_close(dev.f.export_gm(i), orc.f.export_gm(i), 1e-7, 1e-9)
 
 
+def _killer_weights(tmp_path, n, q):
+    """An adversarial weight sequence for libstdc++'s std::sort (McIlroy's adversary run against std::sort itself, quantised by q so
+    that the heap-sorted ranges hold equal keys), from tests/support/stdsort_replay_test.cpp."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(str(tmp_path), "stdsort_replay_test")
+    if not os.path.exists(exe):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-o", exe, os.path.join(root, "tests", "support", "stdsort_replay_test.cpp")])
+    out = subprocess.run([exe, "killer", str(n), str(q)], capture_output=True, text=True, check=True).stdout.split()
+    return np.array(out[:n], dtype=np.float64), out[-1] == "1"
+
+
+@pytest.mark.parametrize("model", ["2d", "vp"])
+def test_equal_weights_come_out_in_std_sort_order(pkg, ob, sc, tmp_path, model):
+    """sortByWeight is the unstable std::sort (include/GaussianMixture.hpp:523-534); the device replays libstdc++'s partition phase to
+    put equal weights in the same order (csrc/stdsort_replay.h).  Mixtures built to stress that: one particle per pattern, all
+    landmarks outside the field of view (the update leaves their weights alone and appends nothing, so the sort sees exactly the
+    injected sequence): 16 and 17 entries (the insertion-sort threshold), one long run of equal weights, a handful of distinct
+    values, births at one weight among distinct ones, a sorted tied prefix, and adversarial sequences that drive std::sort into
+    its depth limit (heap-sort branch).  Compared IN ORDER with the oracle (real std::sort) after the weighting phase's sort,
+    after merge + prune, and through the fused step."""
+    vp = model == "vp"
+    nlm = 150 if vp else 300
+    rng = np.random.default_rng(77)
+    pats = []
+    pats.append(np.full(16, 0.5)); pats.append(np.full(17, 0.5))
+    pats.append(np.r_[np.full(17, 0.25), [0.9]])
+    pats.append(np.full(nlm, 0.01))
+    pats.append(rng.integers(1, 4, nlm) / 4.0)
+    pats.append(rng.integers(1, 40, nlm) / 40.0)
+    pats.append(np.where(rng.random(nlm) < 0.25, 0.01, rng.uniform(0.02, 1.0, nlm)))
+    pats.append(np.r_[1.0 - 1e-3 * (np.arange(nlm // 2) // 3), rng.uniform(0.02, 1.0, nlm - nlm // 2)])
+    n_heap = 0
+    for n_k, q in ((nlm, 2), (nlm, 3), (100, 1), (64, 2), (nlm, 5)):
+        w, hit = _killer_weights(tmp_path, n_k, q)
+        n_heap += hit
+        pats.append(0.02 + 0.9 * w / (w.max() + 1.0))
+    assert n_heap >= 2, "no adversarial sequence reaches std::sort's depth limit"
+    n = len(pats)
+    scen = (sc.make_vp_scenario(n, nlm, 6, seed=3, frac_in_fov=0.0) if vp else sc.make_scenario(n, nlm, 8, seed=3, frac_in_fov=0.0))
+    kw = dict(model=pkg.capi.MODEL_VICTORIAPARK_3D) if vp else {}
+    outs = []
+    for fused in (False, True):
+        dev = pkg.RBPHDFilter(n, gm_capacity=448, **kw)
+        orc = ob.OracleFilter(n, **kw)
+        for f in (dev, orc):
+            sc.load_scenario(f, scen, maps=False)
+            for i, w in enumerate(pats):
+                k = len(w)
+                f.import_gm(i, w, scen["mean"][i][:k], scen["cov"][i][:k])
+        if fused:
+            dev.update_async(scen["Z"]); dev.synchronize()
+            orc.update(scen["Z"])
+        else:
+            for f in (dev, orc):
+                f.update_map(scen["Z"])
+                f.importance_weighting()
+            assert np.array_equal(dev.gm_sizes(), orc.gm_sizes())
+            for i in range(n):
+                gd, go = dev.export_gm(i), orc.export_gm(i)
+                assert np.array_equal(gd[0], np.sort(pats[i])[::-1]), i         # the weights were left alone ...
+                assert np.array_equal(gd[2], go[2]) and np.array_equal(gd[0], go[0]), ("order after sortByWeight", i)   # ... and the order is std::sort's
+            for f in (dev, orc):
+                f.merge(); f.prune()
+        assert np.array_equal(dev.gm_sizes(), orc.gm_sizes())
+        for i in range(n):
+            sc.assert_gm_close(dev.export_gm(i), orc.export_gm(i), GM_RTOL, GM_ATOL, ordered=True)
+        outs.append([dev.export_gm(i) for i in range(n)])
+        dev.close()
+    for a, b in zip(*outs):
+        for k in (0, 2, 3):                                                  # (w, mean, cov; w_prev is scratch between updates)
+            assert np.array_equal(a[k], b[k])                                # fused step == phase kernels, bit for bit
+
+
 # ---- BASELINE.json full-size configurations: size-independent properties + oracle parity on a particle subset -------------
 
 def _full_size_check(pkg, ob, sc, scen, cap, subset=24, check_murty=False, fused=None, fused_cap=None):
