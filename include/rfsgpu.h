@@ -29,6 +29,13 @@
  *   RFSGPU_CORE: rfsgpu_set_kf_config rfsgpu_set_lmk_process_noise rfsgpu_set_poses rfsgpu_set_weights rfsgpu_get_weights
  *   RFSGPU_CORE: rfsgpu_predict_map rfsgpu_update rfsgpu_resample_apply rfsgpu_set_birth_inheritance rfsgpu_gm_size
  *   RFSGPU_CORE: rfsgpu_get_landmark rfsgpu_get_timing rfsgpu_set_phase_timing rfsgpu_synchronize
+ * The same binding over SEVERAL GPUs (RFSGPU_DEVICES=0,1,...: integration/RBPHDFilter_rfsgpu.hpp, rfsgpu_engine_facade) uses the group
+ * counterparts of those calls and nothing else:
+ *   RFSGPU_CORE_MULTI: rfsgpu_group_create rfsgpu_group_destroy rfsgpu_group_last_error rfsgpu_group_set_filter_config
+ *   RFSGPU_CORE_MULTI: rfsgpu_group_set_model_rngbrg rfsgpu_group_set_model_victoriapark rfsgpu_group_set_laser_scan rfsgpu_group_set_kf_config
+ *   RFSGPU_CORE_MULTI: rfsgpu_group_set_lmk_process_noise rfsgpu_group_set_poses rfsgpu_group_set_weights rfsgpu_group_get_weights
+ *   RFSGPU_CORE_MULTI: rfsgpu_group_predict_map rfsgpu_group_update rfsgpu_group_apply_plan rfsgpu_group_gm_size rfsgpu_group_get_landmark
+ *   RFSGPU_CORE_MULTI: rfsgpu_group_get_timing rfsgpu_group_set_phase_timing
  * Everything else is OPTIONAL and grouped below by who needs it:
  *   [async]    stream-ordered forms for host loops that pipeline (rfsgpu_*_async, rfsgpu_step_async, rfsgpu_set_stream, ...);
  *   [multi]    several GPUs: rfsgpu_group_* (one host thread), slab rows / device pointers (one process per GPU over RCCL);
@@ -416,8 +423,9 @@ void *rfsgpu_weights_device_ptr(rfsgpu_filter *f);
  * The particle set of rfs::RBPHDFilter is cut into contiguous blocks, one shard (an rfsgpu_filter) per listed device.  What a
  * C++ host standing where rfs::RBPHDFilter stands needs to use more than one GPU:
  *   predict / update / normalise / resample over the whole set, configuration broadcast to all shards, map access by global
- *   particle index.  Shards run their fused steps concurrently; they meet in the weight normalisation (per-shard sums added on
- *   the host in shard order) and in resampling, which stays GLOBAL (ParticleFilter::resample, include/ParticleFilter.hpp:399-492):
+ *   particle index.  Shards run their fused steps concurrently; they meet in the weight normalisation (an RCCL all-reduce of
+ *   {sum w, sum w^2} on the shards' streams -- single-process communicators from ncclCommInitAll, librccl loaded with dlopen -- or,
+ *   with repeated device ids, per-shard sums added on the host in shard order) and in resampling, which stays GLOBAL (ParticleFilter::resample, include/ParticleFilter.hpp:399-492):
  *   cross-device children travel as packed rows with hipMemcpyPeerAsync (rfsgpu_export/import_slab_rows).
  * device_ids may repeat a device (several shards on one GPU: how the single-GPU tests drive this code). */
 typedef struct rfsgpu_group rfsgpu_group;
@@ -432,6 +440,14 @@ int rfsgpu_group_set_filter_config(rfsgpu_group *g, const rfsgpu_filter_config *
 int rfsgpu_group_set_model_rngbrg(rfsgpu_group *g, const rfsgpu_rngbrg_config *c);
 int rfsgpu_group_set_kf_config(rfsgpu_group *g, const rfsgpu_kf_config *c);
 int rfsgpu_group_set_lmk_process_noise(rfsgpu_group *g, const double *Q);
+int rfsgpu_group_set_model_victoriapark(rfsgpu_group *g, const rfsgpu_vp_config *c);   /* configs[3] sharded: the 3-D model on every shard */
+int rfsgpu_group_set_laser_scan(rfsgpu_group *g, const double *scan, int n);
+int rfsgpu_group_set_phase_timing(rfsgpu_group *g, int on);
+/* RBPHDFilter::TimingInfo of the group: *_wall = the largest of the shards' (they run side by side), *_cpu = their sum. */
+int rfsgpu_group_get_timing(rfsgpu_group *g, rfsgpu_timing *t);
+/* How the shards' weight sums meet: "rccl" (all-reduce over RCCL / xGMI on the shards' streams, totals stay on the devices) or
+ * "host: <why>" (repeated device ids, RFSGPU_GROUP_RCCL=0, librccl not loadable ...: pairs added on the host in shard order). */
+const char *rfsgpu_group_collective(const rfsgpu_group *g);
 int rfsgpu_group_set_poses(rfsgpu_group *g, const double *x, const double *cov, int cov_stride);   /* N poses, as rfsgpu_set_poses */
 int rfsgpu_group_get_poses(rfsgpu_group *g, double *x);
 int rfsgpu_group_set_weights(rfsgpu_group *g, const double *w);
@@ -489,6 +505,10 @@ int rfsgpu_last_step_variant(const rfsgpu_filter *f, int *out4);
 /* MatPerm::calc (src/MatrixPermanent.cpp:41-112), batched: `batch` row-major n x n matrices in A
  * (host), permanents to out (host).  n <= 24.  Standalone (no filter handle needed). */
 int rfsgpu_mat_perm(const double *A, int n, int batch, double *out, int device_id);
+#ifdef RFSGPU_ENABLE_BENCH_API
+/* [bench] Device time (ms, HIP events) of the kernel of the last rfsgpu_mat_perm call of this process. */
+double rfsgpu_mat_perm_last_kernel_ms(void);
+#endif
 
 /* ---- [fastslam] FastSLAM 1.0 on the same handle (reference include/FastSLAM.hpp) --------------------------------
  * The handle's mixtures double as FastSLAM's per-particle landmark maps: a Gaussian's weight is the landmark's

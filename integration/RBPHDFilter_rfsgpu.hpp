@@ -105,6 +105,56 @@ template <> struct rfsgpu_model_access<MeasurementModel_VictoriaPark> {
   };
 };
 
+/* ---- one GPU or several ------------------------------------------------------------------------------------------------- */
+/* The reference constructor takes a particle count and nothing else (include/RBPHDFilter.hpp:350), so where the maps live comes
+ * from the environment: RFSGPU_DEVICE=<ordinal> (default 0) -> ONE handle on that GPU; RFSGPU_DEVICES=0,1,2,... -> the particle set
+ * cut into contiguous blocks over the listed GPUs (rfsgpu_group_*: the shards step side by side, the weight sums meet in an RCCL
+ * all-reduce, resampling stays global with cross-device children moved over xGMI; a device may be listed more than once).
+ * Every call the filter below makes goes through this facade, 1 : 1 onto rfsgpu_* or rfsgpu_group_*. */
+class rfsgpu_engine_facade {
+ public:
+  rfsgpu_engine_facade() : f_(NULL), g_(NULL) {}
+  ~rfsgpu_engine_facade() { if (g_) rfsgpu_group_destroy(g_); else rfsgpu_destroy(f_); }
+  int create(int model, int n, int capacity) {
+    const char *devs = std::getenv("RFSGPU_DEVICES"), *dev = std::getenv("RFSGPU_DEVICE");
+    if (devs && *devs) {
+      std::vector<int> ids;
+      for (const char *p = devs; *p;) {
+        char *e;
+        const long v = std::strtol(p, &e, 10);
+        if (e == p) break;
+        ids.push_back((int)v);
+        p = (*e == ',') ? e + 1 : e;
+      }
+      if (ids.empty()) return RFSGPU_ERR_INVALID;
+      return rfsgpu_group_create(&g_, model, n, ids.data(), (int)ids.size(), capacity);
+    }
+    return rfsgpu_create(&f_, model, n, dev ? std::atoi(dev) : 0, capacity);
+  }
+  const char *last_error() const { return g_ ? rfsgpu_group_last_error(g_) : rfsgpu_last_error(f_); }
+  int set_filter_config(const rfsgpu_filter_config *c) { return g_ ? rfsgpu_group_set_filter_config(g_, c) : rfsgpu_set_filter_config(f_, c); }
+  int set_kf_config(const rfsgpu_kf_config *c) { return g_ ? rfsgpu_group_set_kf_config(g_, c) : rfsgpu_set_kf_config(f_, c); }
+  int set_lmk_process_noise(const double *q) { return g_ ? rfsgpu_group_set_lmk_process_noise(g_, q) : rfsgpu_set_lmk_process_noise(f_, q); }
+  int set_model_rngbrg(const rfsgpu_rngbrg_config *c) { return g_ ? rfsgpu_group_set_model_rngbrg(g_, c) : rfsgpu_set_model_rngbrg(f_, c); }
+  int set_model_victoriapark(const rfsgpu_vp_config *c) { return g_ ? rfsgpu_group_set_model_victoriapark(g_, c) : rfsgpu_set_model_victoriapark(f_, c); }
+  int set_laser_scan(const double *scan, int n) { return g_ ? rfsgpu_group_set_laser_scan(g_, scan, n) : rfsgpu_set_laser_scan(f_, scan, n); }
+  int set_poses(const double *x, const double *cov, int stride) { return g_ ? rfsgpu_group_set_poses(g_, x, cov, stride) : rfsgpu_set_poses(f_, x, cov, stride); }
+  int set_weights(const double *w) { return g_ ? rfsgpu_group_set_weights(g_, w) : rfsgpu_set_weights(f_, w); }
+  int get_weights(double *w) { return g_ ? rfsgpu_group_get_weights(g_, w) : rfsgpu_get_weights(f_, w); }
+  int predict_map(int add_birth) { return g_ ? rfsgpu_group_predict_map(g_, add_birth) : rfsgpu_predict_map(f_, add_birth); }
+  int update(const double *z, int n_z) { return g_ ? rfsgpu_group_update(g_, z, n_z, NULL) : rfsgpu_update(f_, z, n_z); }
+  int resample_apply(const int *src) { return g_ ? rfsgpu_group_apply_plan(g_, src) : rfsgpu_resample_apply(f_, src); }
+  int gm_size(int i) { return g_ ? rfsgpu_group_gm_size(g_, i) : rfsgpu_gm_size(f_, i); }
+  int get_landmark(int i, int m, double *mean, double *cov, double *w) { return g_ ? rfsgpu_group_get_landmark(g_, i, m, mean, cov, w) : rfsgpu_get_landmark(f_, i, m, mean, cov, w); }
+  int get_timing(rfsgpu_timing *t) { return g_ ? rfsgpu_group_get_timing(g_, t) : rfsgpu_get_timing(f_, t); }
+  int set_phase_timing(int on) { return g_ ? rfsgpu_group_set_phase_timing(g_, on) : rfsgpu_set_phase_timing(f_, on); }
+ private:
+  rfsgpu_filter *f_;
+  rfsgpu_group *g_;
+  rfsgpu_engine_facade(const rfsgpu_engine_facade &);
+  rfsgpu_engine_facade &operator=(const rfsgpu_engine_facade &);
+};
+
 template <class RobotProcessModel, class LmkProcessModel, class MeasurementModel, class KalmanFilter>
 class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, GaussianMixture<typename MeasurementModel::TLandmark> > {
  public:
@@ -157,7 +207,7 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
   /* :370-382 -- the constructor's defaults.  (The reference leaves importanceWeightingEvalPointGuassianWeight_ and
    * useClusterProcess_ uninitialised; both drivers assign them, :485,490.  They start at 0 / false here.) */
   explicit RBPHDFilter(int n)
-      : ParticleFilter<RobotProcessModel, MeasurementModel, GaussianMixture<TLandmark> >(n), engine_(NULL), model_(this->pMeasurementModel_) {
+      : ParticleFilter<RobotProcessModel, MeasurementModel, GaussianMixture<TLandmark> >(n), model_(this->pMeasurementModel_) {
     lmkModelPtr_ = new LmkProcessModel;
     kf_ = new KalmanFilter(lmkModelPtr_, this->pMeasurementModel_);
     /* :362-364.  Particle::copy (include/Particle.hpp:218-223) dereferences data_, so every particle owns a mixture object as in
@@ -181,19 +231,19 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
     nUpdatesSinceResample_ = 0;
     nMeasurementsSinceResample_ = 0;
     resampleOccured_ = false;
-    /* The engine: device and per-particle capacity come from the environment (the reference constructor has no such
-     * arguments): RFSGPU_DEVICE (default 0), RFSGPU_GM_CAPACITY (default 512: room for nM_max + 4 nZ Gaussians). */
-    const char *dev = std::getenv("RFSGPU_DEVICE"), *cap = std::getenv("RFSGPU_GM_CAPACITY");
-    const int rc = rfsgpu_create(&engine_, rfsgpu_model_of<MeasurementModel>::value, n, dev ? std::atoi(dev) : 0, cap ? std::atoi(cap) : 512);
+    /* The engine: device(s) and per-particle capacity come from the environment (the reference constructor has no such
+     * arguments): RFSGPU_DEVICE (default 0) or RFSGPU_DEVICES=0,1,... (rfsgpu_engine_facade above), RFSGPU_GM_CAPACITY (default 512:
+     * room for nM_max + 4 nZ Gaussians). */
+    const char *cap = std::getenv("RFSGPU_GM_CAPACITY");
+    const int rc = engine_.create(rfsgpu_model_of<MeasurementModel>::value, n, cap ? std::atoi(cap) : 512);
     if (rc != RFSGPU_OK) throw std::runtime_error("rfsgpu_create failed (no gfx950 device?): status " + std::to_string(rc));
     /* rfsgpu_update runs the 2-D step as one fused launch and books it under TimingInfo::mapUpdate_*; a driver whose timing
      * printout (src/rbphdslam2dSim.cpp:664-679) should keep mapUpdate / particleWeighting / mapMerge apart sets
      * RFSGPU_PHASE_TIMING=1 and gets separate launches -- the same results bit for bit, about a third more device time. */
-    if (const char *pt = std::getenv("RFSGPU_PHASE_TIMING")) rfsgpu_set_phase_timing(engine_, std::atoi(pt));
+    if (const char *pt = std::getenv("RFSGPU_PHASE_TIMING")) engine_.set_phase_timing(std::atoi(pt));
   }
 
   ~RBPHDFilter() {
-    rfsgpu_destroy(engine_);
     delete kf_;
     delete lmkModelPtr_;
   }
@@ -210,7 +260,7 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
     timer_predict_.resume();
     pushConfiguration();
     pushPoses();
-    check(rfsgpu_predict_map(engine_, birthGaussianCheck ? 1 : 0), "predict_map");   /* addBirthGaussians :1000-1084 + staticStep :433-439 */
+    check(engine_.predict_map(birthGaussianCheck ? 1 : 0), "predict_map");   /* addBirthGaussians :1000-1084 + staticStep :433-439 */
     this->propagate(u, dT, useModelNoise, useInputNoise, true);                      /* :429, host RNG, keeps the trajectory */
     timer_predict_.stop();
   }
@@ -232,7 +282,7 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
     pushPoses();
     pushWeights();
     timer_mapUpdate_.resume();
-    check(rfsgpu_update(engine_, z.data(), nZ), "update");   /* updateMap + importanceWeighting + merge + prune, :469-520 */
+    check(engine_.update(z.data(), nZ), "update");   /* updateMap + importanceWeighting + merge + prune, :469-520 */
     timer_mapUpdate_.stop();
     pullWeights();
 
@@ -251,7 +301,7 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
   }
 
   int getGMSize(int i) {                                     /* :1152-1158 */
-    if (i >= 0 && i < this->nParticles_) return rfsgpu_gm_size(engine_, i);
+    if (i >= 0 && i < this->nParticles_) return engine_.gm_size(i);
     return -1;
   }
 
@@ -260,7 +310,7 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
     if (sz == -1 || m < 0 || m >= sz) return false;
     const int D = rfsgpu_model_of<MeasurementModel>::dim;
     double mean[3], cov[9];
-    if (rfsgpu_get_landmark(engine_, i, m, mean, cov, &w) != RFSGPU_OK) return false;
+    if (engine_.get_landmark(i, m, mean, cov, &w) != RFSGPU_OK) return false;
     for (int r = 0; r < D; r++) {
       u[r] = mean[r];
       for (int c = 0; c < D; c++) S(r, c) = cov[D * r + c];
@@ -272,7 +322,7 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
 
   TimingInfo *getTimingInfo() {                              /* :1219-1232: host timers for what stays on the host, the */
     rfsgpu_timing t;                                         /* engine's HIP-event buckets for what runs on the device  */
-    rfsgpu_get_timing(engine_, &t);
+    engine_.get_timing(&t);
     timer_predict_.elapsed(timingInfo_.predict_wall, timingInfo_.predict_cpu);
     timingInfo_.mapUpdate_wall = t.mapUpdate_wall;                   timingInfo_.mapUpdate_cpu = t.mapUpdate_cpu;
     timingInfo_.mapUpdate_kf_wall = t.mapUpdate_kf_wall;             timingInfo_.mapUpdate_kf_cpu = t.mapUpdate_kf_cpu;
@@ -284,7 +334,7 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
   }
 
  private:
-  rfsgpu_filter *engine_;
+  rfsgpu_engine_facade engine_;
   LmkProcessModel *lmkModelPtr_;
   KalmanFilter *kf_;
   typename rfsgpu_model_access<MeasurementModel>::holder model_;
@@ -302,7 +352,7 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
   }
 
   void check(int rc, const char *what) {
-    if (rc != RFSGPU_OK) throw std::runtime_error(std::string("rfsgpu ") + what + ": " + rfsgpu_last_error(engine_));
+    if (rc != RFSGPU_OK) throw std::runtime_error(std::string("rfsgpu ") + what + ": " + engine_.last_error());
   }
 
   /* The three config structs of the reference objects -> the engine, before every predict / update (they are public members
@@ -324,12 +374,12 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
     c.minUpdatesBeforeResample = config.minUpdatesBeforeResample_;
     c.minMeasurementsBeforeResample = config.minMeasurementsBeforeResample_;
     c.useClusterProcess = config.useClusterProcess_ ? 1 : 0;
-    check(rfsgpu_set_filter_config(engine_, &c), "set_filter_config");
+    check(engine_.set_filter_config(&c), "set_filter_config");
 
     rfsgpu_kf_config k;
     k.rangeInnovationThreshold = kf_->config.rangeInnovationThreshold_;
     k.bearingInnovationThreshold = kf_->config.bearingInnovationThreshold_;
-    check(rfsgpu_set_kf_config(engine_, &k), "set_kf_config");
+    check(engine_.set_kf_config(&k), "set_kf_config");
 
     typename TLandmark::Mat Q;
     lmkModelPtr_->getNoise(Q);                                    /* include/ProcessModel.hpp:92-95 */
@@ -337,7 +387,7 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
     double q[9];
     for (int r = 0; r < D; r++)
       for (int cc = 0; cc < D; cc++) q[D * r + cc] = Q(r, cc);
-    check(rfsgpu_set_lmk_process_noise(engine_, q), "set_lmk_process_noise");
+    check(engine_.set_lmk_process_noise(q), "set_lmk_process_noise");
     pushModel(model_.get());
   }
   void pushModel(MeasurementModel_RngBrg *m) {                     /* include/MeasurementModel_RngBrg.hpp:65-71 */
@@ -350,7 +400,7 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
     c.rangeLimMax = m->config.rangeLimMax_;
     c.rangeLimMin = m->config.rangeLimMin_;
     c.rangeLimBuffer = m->config.rangeLimBuffer_;
-    check(rfsgpu_set_model_rngbrg(engine_, &c), "set_model_rngbrg");
+    check(engine_.set_model_rngbrg(&c), "set_model_rngbrg");
   }
   void pushModel(rfsgpu_vp_model_handle *m) {                      /* include/MeasurementModel_VictoriaPark.hpp:136-152 */
     rfsgpu_vp_config c;
@@ -369,9 +419,9 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
     c.bearingLimitMax = m->config.bearingLimitMax_;
     c.bearingLimitMin = m->config.bearingLimitMin_;
     c.bufferZonePd = m->config.bufferZonePd_;
-    check(rfsgpu_set_model_victoriapark(engine_, &c), "set_model_victoriapark");
+    check(engine_.set_model_victoriapark(&c), "set_model_victoriapark");
     if (m->laserScanSerial() != scanPushed_) {                        /* a new scan since the last push (driver :582) */
-      check(rfsgpu_set_laser_scan(engine_, m->laserScan().data(), (int)m->laserScan().size()), "set_laser_scan");
+      check(engine_.set_laser_scan(m->laserScan().data(), (int)m->laserScan().size()), "set_laser_scan");
       scanPushed_ = m->laserScanSerial();
     }
   }
@@ -389,16 +439,16 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
         for (int c = 0; c < 3; c++) P[(size_t)9 * i + 3 * r + c] = S(r, c);
       }
     }
-    check(rfsgpu_set_poses(engine_, x.data(), P.data(), 9), "set_poses");
+    check(engine_.set_poses(x.data(), P.data(), 9), "set_poses");
   }
   void pushWeights() {
     std::vector<double> w(this->nParticles_);
     for (int i = 0; i < this->nParticles_; i++) w[i] = this->particleSet_[i]->getWeight();
-    check(rfsgpu_set_weights(engine_, w.data()), "set_weights");
+    check(engine_.set_weights(w.data()), "set_weights");
   }
   void pullWeights() {
     std::vector<double> w(this->nParticles_);
-    check(rfsgpu_get_weights(engine_, w.data()), "get_weights");
+    check(engine_.get_weights(w.data()), "get_weights");
     for (int i = 0; i < this->nParticles_; i++) this->particleSet_[i]->setWeight(w[i]);
   }
 
@@ -456,7 +506,7 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
         next_unsampled_idx++;
       }
     }
-    check(rfsgpu_resample_apply(engine_, src_slot.data()), "resample_apply");   /* also resets the device weights to 1 */
+    check(engine_.resample_apply(src_slot.data()), "resample_apply");   /* also resets the device weights to 1 */
     for (int i = 0; i < n; i++) this->particleSet_[i]->setWeight(1);            /* :486-489 */
     return true;
   }

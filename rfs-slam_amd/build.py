@@ -31,7 +31,7 @@ def build(force=False, verbose=False, extra_flags=()):
     """Compile the extension if sources are newer than the library. Returns the library path."""
     if not force and not stale():
         return LIB
-    cmd = [hipcc()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    cmd = [hipcc()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl", "-o", LIB]   # (-ldl: librccl is dlopen'ed by the multi-GPU group)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

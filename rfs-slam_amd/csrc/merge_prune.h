@@ -29,6 +29,10 @@
 __host__ __device__ constexpr int merge_cells(int gridLog) { return 1 << (2 * gridLog); }
 #define MERGE_PAIR_CAP(cap) ((cap) > 320 ? (cap) : 320)  // listed partners per particle: ~0.7 per entry on dense maps
 #define MERGE_ROW_SLOTS 8   // prefilter survivors one row can list; a row with more is replayed by the sequential scan
+// (Measured and dropped, r04 -- profiles/r04a_ab_merge_stage.txt: phase 1b leaving the replay's operands -- mean and covariance of
+//  every passing partner and of its row -- in LDS, so that the one wave that replays reads LDS instead of dependent global loads:
+//  fused step 125.2 -> 126.5 us at configs[1].  The loads the replay waits for are L2 hits issued together; the staging's stores
+//  and slot atomics in the pair phase cost more than they save.)
 __host__ __device__ inline size_t merge_lds_bytes_per_wave(int cap, int gridLog = 5) {
   // entries: w (f64) + x, y, radius (f32) + row record (u32) + grid-sorted index (u16) + prefilter slack (u16); grid: CELLS/2+4 u32; pair list: u32
   return (((size_t)cap * (8 + 3 * 4 + 4 + 2 + 2)) + (size_t)(merge_cells(gridLog) / 2 + 4) * 4 + (size_t)MERGE_PAIR_CAP(cap) * 4 + 16 + 15) & ~(size_t)15;
@@ -764,12 +768,14 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
   // then is the compacted mixture written.
   unsigned short *sOrder = sSlack;                                              // [nSurv] (the rows' slacks are dead)
   constexpr int NS = 8;
-  bool ranked = false;
+  bool ranked = false, tiedKeys = false;
   if (nSurv <= NS * NT) {
     int rl[NS];
     ranked = bucket_rank_sort<WPP, NS>([&](int q) { return sW[sSorted[q]]; }, nSurv, tid, sCellStart, reinterpret_cast<unsigned short *>(sPairs),
-                                       MERGE_LOG_CELLS, reinterpret_cast<int *>(sRed), rl, block_sync);
+                                       MERGE_LOG_CELLS, reinterpret_cast<int *>(sRed), rl, block_sync, tiedKeys);
     if (ranked) {
+      const bool any = __ballot(tiedKeys) != 0ull;
+      if (lane == 0) reinterpret_cast<int *>(sRed)[4 * WPP + wave] = any ? 1 : 0;   // (behind the sort's 2 WPP + 1 words of scratch)
 #pragma unroll
       for (int k = 0; k < NS; k++) {
         const int q = tid + NT * k;
@@ -791,6 +797,11 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     }
   }
   block_sync();
+  if (ranked) {
+    tiedKeys = false;
+#pragma unroll
+    for (int w2 = 0; w2 < WPP; w2++) tiedKeys |= reinterpret_cast<int *>(sRed)[4 * WPP + w2] != 0;
+  } else tiedKeys = true;
   {
     StdSortScratch ss;                              // the fp32 positions / radii of the merge are dead: 12 B per entry
     ss.T = reinterpret_cast<unsigned short *>(sX);  // [N]          | Ll [N / 2 + 1]   (3 N + 2 <= 4 cap bytes)
@@ -801,7 +812,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     ss.eq = reinterpret_cast<unsigned long long *>(sRad);                       // [ceil(N / 64)] <= cap / 8 bytes
     ss.stack = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(sRad) + (((size_t)(N + 63) >> 6) * 8));   // [26]: 104 B <= 4 cap - cap / 8
     ss_correct_tie_order<WPP>([&](int e) { const double w = sW[e]; return w < 0.0 ? 0.0 : w; }, [&](int r) { return (int)sOrder[r]; },
-                              [&](int r, unsigned short e) { sOrder[r] = e; }, N, nSurv, ss, tid, block_sync);
+                              [&](int r, unsigned short e) { sOrder[r] = e; }, N, nSurv, ss, tid, block_sync, tiedKeys);
   }
   for (int r = tid; r < nSurv; r += NT) put(r, sOrder[r]);
   if (tid == 0) B.count[i] = nSurv;
@@ -1114,52 +1125,3 @@ __global__ __launch_bounds__(WPB * 64) void predict_map_kernel(Buffers B, Params
   }
 }
 
-// MatPerm::calc (reference src/MatrixPermanent.cpp:41-112), Nijenhuis-Wilf / Gray-code Ryser.  One matrix per
-// wave; the 2^(n-1) Gray-code steps are split into 64 contiguous ranges, one per lane: each lane jumps to
-// its first subset directly (Gray code of the start index), then walks its range with the single-column
-// updates of the reference; partial sums are wave-reduced.
-__global__ __launch_bounds__(64) void mat_perm_kernel(const double *A, int n, int batch, double *out) {
-  const int b = blockIdx.x;
-  if (b >= batch) return;
-  const int lane = threadIdx.x & 63;
-  __shared__ double sA[24 * 24];
-  const double *Ab = A + (size_t)b * n * n;
-  for (int t = lane; t < n * n; t += 64) sA[t] = Ab[t];
-  __syncthreads();
-  // x_i(0) = A(i,n-1) - row_sum_i / 2; subset index k (1-based in the reference) has gray code g(k-1)
-  const unsigned long long total = 1ull << (n - 1);  // number of subsets (k = 1 .. 2^(n-1))
-  const unsigned long long per = (total + 63) / 64;
-  const unsigned long long k0 = per * lane;          // 0-based subset index
-  const unsigned long long k1 = (k0 + per < total) ? k0 + per : total;
-  double x[24];
-  double acc = 0.0;
-  if (k0 < total) {
-    const unsigned long long g0 = k0 ^ (k0 >> 1);
-    for (int r = 0; r < n; r++) {
-      double rs = 0;
-      for (int c = 0; c < n; c++) rs += sA[r * n + c];
-      double v = sA[r * n + (n - 1)] - 0.5 * rs;
-      for (int c = 0; c < n - 1; c++) if ((g0 >> c) & 1ull) v += sA[r * n + c];
-      x[r] = v;
-    }
-    unsigned long long g = g0;
-    for (unsigned long long k = k0; k < k1; k++) {
-      if (k != k0) {
-        const int j = __builtin_ctzll(k);  // bit flipped between gray(k-1) and gray(k)
-        const double z = ((g >> j) & 1ull) ? -1.0 : 1.0;
-        g ^= (1ull << j);
-        for (int r = 0; r < n; r++) x[r] += z * sA[r * n + j];
-      }
-      double prod = 1.0;
-      for (int r = 0; r < n; r++) prod *= x[r];
-      // sign: s = -1 for k=1 (0-based 0), alternating
-      acc += ((k & 1ull) ? 1.0 : -1.0) * prod;
-    }
-  }
-  acc = wave_sum(acc);
-  if (lane == 0) {
-    double ret = 2 * acc;
-    if (n % 2 != 0) ret *= -1;
-    out[b] = ret;
-  }
-}

@@ -3,6 +3,7 @@
 // kernels or returns an error status.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +19,7 @@
 #include "merge_prune.h"
 #include "step_fused.h"
 #include "murty.h"
+#include "mat_perm.h"
 #include "vp.h"
 #include "birth.h"
 #include "fastslam.h"
@@ -65,6 +67,7 @@ struct rfsgpu_filter {
   int *dRowSlots = nullptr; // slots of the rows being exported / imported (allocated on first use, grown on demand)
   int rowSlotsCap = 0;
   double *hStage[4] = {nullptr, nullptr, nullptr, nullptr};  // pinned staging ring of rfsgpu_set_step_inputs_async
+  double *hWeights = nullptr;         // pinned landing buffer of rfsgpu_get_weights
   hipEvent_t evStage[4] = {};
   int stageNext = 0;
   bool predPending = false;  // rfsgpu_predict_map_async's event pair has not been accumulated yet
@@ -352,6 +355,7 @@ void rfsgpu_destroy(rfsgpu_filter *f) {
   if (f->hErr) hipHostFree(f->hErr);
   if (f->hJobCount) hipHostFree(f->hJobCount);
   if (f->hSums) hipHostFree(f->hSums);
+  if (f->hWeights) hipHostFree(f->hWeights);
   for (int k = 0; k < 4; k++) { if (f->hStage[k]) hipHostFree(f->hStage[k]); if (f->evStage[k]) hipEventDestroy(f->evStage[k]); }
   for (int k = 0; k < RFSGPU_ASYNC_RING; k++)
     for (int e = 0; e < 5; e++) if (f->ring[k][e]) hipEventDestroy(f->ring[k][e]);
@@ -450,23 +454,31 @@ int rfsgpu_set_lmk_process_noise(rfsgpu_filter *f, const double *Q) {
   return RFSGPU_OK;
 }
 
+// One slot of the pinned staging ring (four slots of Ncap * 12 + RFSGPU_VP_MAX_SCAN doubles, created on first use): waits until
+// the copies issued from this slot four calls ago are done; the caller copies into *h, enqueues its host-to-device copies on the
+// stream and records f->evStage[*k].
+static int stage_slot(rfsgpu_filter *f, double **h, int *k_out) {
+  const int k = f->stageNext;
+  f->stageNext = (k + 1) & 3;
+  const size_t slotDoubles = (size_t)f->Ncap * 12 + RFSGPU_VP_MAX_SCAN;
+  const bool fresh = !f->hStage[k] || !f->evStage[k];   // (either creation may have failed on an earlier call: each is retried on its own)
+  if (!f->hStage[k]) HIPCHK(hipHostMalloc(&f->hStage[k], slotDoubles * sizeof(double)));
+  if (!f->evStage[k]) HIPCHK(hipEventCreateWithFlags(&f->evStage[k], hipEventDisableTiming));
+  if (fresh) HIPCHK(hipStreamSynchronize(f->stream));    // nothing recorded on this slot's event yet
+  else HIPCHK(hipEventSynchronize(f->evStage[k]));       // the copies issued from this slot four calls ago
+  *h = f->hStage[k];
+  *k_out = k;
+  return RFSGPU_OK;
+}
+
+// (r04: poses and weights go through the pinned staging ring of rfsgpu_set_step_inputs_async -- the caller's buffers are copied
+//  before the call returns, the host-to-device copies are stream-ordered and nothing waits for the GPU.  The synchronous forms
+//  these replaced -- a copy from pageable memory + a stream synchronisation each -- were 46 + 23 us of the 261 us that one
+//  RBPHDFilter::update costs through the binding at configs[1], bench.py `boundary`.)
 int rfsgpu_set_poses(rfsgpu_filter *f, const double *x, const double *cov, int cov_stride) {
   CHECK_HANDLE(f);
   if (!x || (cov_stride != 0 && cov_stride != 9)) return fail(f, RFSGPU_ERR_INVALID, "set_poses: bad arguments");
-  hipSetDevice(f->device);
-  HIPCHK(hipMemcpyAsync(f->B.pose, x, (size_t)f->N * 3 * sizeof(double), hipMemcpyHostToDevice, f->stream));
-  if (cov) {
-    const size_t n = cov_stride == 9 ? (size_t)f->N * 9 : 9;
-    HIPCHK(hipMemcpyAsync(f->B.poseCov, cov, n * sizeof(double), hipMemcpyHostToDevice, f->stream));
-    f->P.poseCovStride = cov_stride;
-    f->poseCovZero = false;
-  } else {
-    HIPCHK(hipMemsetAsync(f->B.poseCov, 0, 9 * sizeof(double), f->stream));
-    f->P.poseCovStride = 0;
-    f->poseCovZero = true;
-  }
-  HIPCHK(hipStreamSynchronize(f->stream));  // caller's buffers may be pageable / reused
-  return RFSGPU_OK;
+  return rfsgpu_set_step_inputs_async(f, x, cov, cov_stride, nullptr, 0);
 }
 int rfsgpu_get_poses(rfsgpu_filter *f, double *x) {
   CHECK_HANDLE(f);
@@ -477,16 +489,24 @@ int rfsgpu_get_poses(rfsgpu_filter *f, double *x) {
 }
 int rfsgpu_set_weights(rfsgpu_filter *f, const double *w) {
   CHECK_HANDLE(f);
+  if (!w) return fail(f, RFSGPU_ERR_INVALID, "set_weights: null buffer");
   hipSetDevice(f->device);
-  HIPCHK(hipMemcpyAsync(f->B.weight, w, (size_t)f->N * sizeof(double), hipMemcpyHostToDevice, f->stream));
-  HIPCHK(hipStreamSynchronize(f->stream));
+  double *h = nullptr;
+  int k = 0;
+  { const int rc = stage_slot(f, &h, &k); if (rc != RFSGPU_OK) return rc; }
+  memcpy(h, w, (size_t)f->N * sizeof(double));
+  HIPCHK(hipMemcpyAsync(f->B.weight, h, (size_t)f->N * sizeof(double), hipMemcpyHostToDevice, f->stream));
+  HIPCHK(hipEventRecord(f->evStage[k], f->stream));
   return RFSGPU_OK;
 }
 int rfsgpu_get_weights(rfsgpu_filter *f, double *w) {
   CHECK_HANDLE(f);
+  if (!w) return fail(f, RFSGPU_ERR_INVALID, "get_weights: null buffer");
   hipSetDevice(f->device);
-  HIPCHK(hipMemcpyAsync(w, f->B.weight, (size_t)f->N * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  if (!f->hWeights) HIPCHK(hipHostMalloc(&f->hWeights, (size_t)f->Ncap * sizeof(double)));   // pinned: a real DMA, no staging inside the runtime
+  HIPCHK(hipMemcpyAsync(f->hWeights, f->B.weight, (size_t)f->N * sizeof(double), hipMemcpyDeviceToHost, f->stream));
   HIPCHK(hipStreamSynchronize(f->stream));
+  memcpy(w, f->hWeights, (size_t)f->N * sizeof(double));
   return RFSGPU_OK;
 }
 
@@ -1333,15 +1353,9 @@ int rfsgpu_set_step_inputs_async(rfsgpu_filter *f, const double *x, const double
   if (scan && (f->model != RFSGPU_MODEL_VICTORIAPARK_3D || n_scan < 2 || n_scan > RFSGPU_VP_MAX_SCAN)) return fail(f, RFSGPU_ERR_INVALID, "set_step_inputs: laser scan needs the Victoria Park model and 2..RFSGPU_VP_MAX_SCAN beams");
   if (!x && !scan) return RFSGPU_OK;
   hipSetDevice(f->device);
-  const int k = f->stageNext;
-  f->stageNext = (k + 1) & 3;
-  const size_t slotDoubles = (size_t)f->Ncap * 12 + RFSGPU_VP_MAX_SCAN;
-  const bool fresh = !f->hStage[k] || !f->evStage[k];   // (either creation may have failed on an earlier call: each is retried on its own)
-  if (!f->hStage[k]) HIPCHK(hipHostMalloc(&f->hStage[k], slotDoubles * sizeof(double)));
-  if (!f->evStage[k]) HIPCHK(hipEventCreateWithFlags(&f->evStage[k], hipEventDisableTiming));
-  if (fresh) HIPCHK(hipStreamSynchronize(f->stream));    // nothing recorded on this slot's event yet
-  else HIPCHK(hipEventSynchronize(f->evStage[k]));       // the copies issued from this slot four calls ago
-  double *h = f->hStage[k];
+  double *h = nullptr;
+  int k = 0;
+  { const int rc = stage_slot(f, &h, &k); if (rc != RFSGPU_OK) return rc; }
   if (x) {
     memcpy(h, x, (size_t)f->N * 3 * sizeof(double));
     HIPCHK(hipMemcpyAsync(f->B.pose, h, (size_t)f->N * 3 * sizeof(double), hipMemcpyHostToDevice, f->stream));
@@ -1862,6 +1876,8 @@ int rfsgpu_fastslam_update(rfsgpu_filter *f, const double *z, int n_z) {
   return rc;
 }
 
+static double g_matPermLastKernelMs = 0.0;
+double rfsgpu_mat_perm_last_kernel_ms(void) { return g_matPermLastKernelMs; }
 int rfsgpu_mat_perm(const double *A, int n, int batch, double *out, int device_id) {
   if (!A || !out || n < 1 || n > 24 || batch < 0) return RFSGPU_ERR_INVALID;
   int ndev = 0;
@@ -1875,8 +1891,16 @@ int rfsgpu_mat_perm(const double *A, int n, int batch, double *out, int device_i
   int rc = RFSGPU_OK;
   if (hipMemcpy(dA, A, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = RFSGPU_ERR_HIP;
   if (rc == RFSGPU_OK) {
-    mat_perm_kernel<<<batch, 64>>>(dA, n, batch, dO);
-    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = RFSGPU_ERR_HIP;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool timed = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+    if (timed) hipEventRecord(e0, 0);
+    if (mat_perm_launch(dA, n, batch, dO) != hipSuccess) rc = RFSGPU_ERR_HIP;
+    if (timed) hipEventRecord(e1, 0);
+    if (hipDeviceSynchronize() != hipSuccess) rc = RFSGPU_ERR_HIP;
+    float ms = 0.f;
+    if (timed && rc == RFSGPU_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) g_matPermLastKernelMs = (double)ms;
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
   }
   if (rc == RFSGPU_OK && hipMemcpy(out, dO, (size_t)batch * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = RFSGPU_ERR_HIP;
   hipFree(dA);

@@ -373,9 +373,10 @@ __device__ __forceinline__ int ss_fixed_rank(const StdSortScratch &S, EntryAt en
 // steps; S.T is reused as the staging area of the new order once pos[] exists.
 template <int WPP, class KeyAt, class EntryAt, class SetEntry, class Sync>
 __device__ __forceinline__ bool ss_correct_tie_order(KeyAt keyAt, EntryAt entryAt, SetEntry setEntry, const int N, const int R, const StdSortScratch &S,
-                                                     const int tid, Sync block_sync) {
+                                                     const int tid, Sync block_sync, const bool maybeTied = true) {
   constexpr int NT = WPP * 64;
-  if (N <= SS_THRESHOLD || R < 2) return false;
+  // maybeTied (uniform over the workgroup): false when the caller's rank sort has already seen that no two keys are equal
+  if (N <= SS_THRESHOLD || R < 2 || !maybeTied) return false;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int nWords = (N + 63) >> 6;
   for (int c = wave; c < nWords; c += WPP) {

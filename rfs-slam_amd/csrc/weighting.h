@@ -374,9 +374,11 @@ __host__ __device__ inline int rank_sort_log_buckets(int cap) { return cap >= 34
 // keyAt(m): key of entry m < N (LDS reads; ties rank by m); hist: (NB / 2 + 4) words of LDS scratch for NB = 1 << logNB buckets; order: [N]
 // u16 of LDS scratch; xscr: 2 WPP + 1 ints of LDS scratch; the ranks of entries tid + NT * k go to rl[k] (N <= NS * NT).
 // All threads of the block call it; the caller synchronises before it reuses the scratch.
+// tied (out, per thread): one of this thread's entries shares its key with another entry -- what decides whether the order of equal
+// keys has to be corrected to std::sort's (stdsort_replay.h); undefined when the function returns false.
 template <int WPP, int NS, class KeyAt, class Sync>
 __device__ __forceinline__ bool bucket_rank_sort(KeyAt keyAt, const int N, const int tid, unsigned *hist, unsigned short *order, const int logNB, int *xscr,
-                                                 int (&rl)[NS], Sync block_sync) {
+                                                 int (&rl)[NS], Sync block_sync, bool &tied) {
   constexpr int NT = WPP * 64;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int NB = 1 << logNB;
@@ -453,13 +455,15 @@ __device__ __forceinline__ bool bucket_rank_sort(KeyAt keyAt, const int N, const
       const unsigned long long u = sort_key_u64(keyAt(m));
       const int b = bucket_of((unsigned)(u >> 32));
       const int st = (int)cell_at(b), en = (int)cell_at(b + 1);
-      int r = st;
+      int r = st, same = 0;
       for (int q = st; q < en; q++) {
         const int j = order[q];
         const unsigned long long uj = sort_key_u64(keyAt(j));
         r += ((uj > u) | ((uj == u) & (j < m))) ? 1 : 0;
+        same += (uj == u) ? 1 : 0;
       }
       rl[k] = r;
+      tied |= same > 1;       // (the entry itself is in its bucket)
     }
   }
   return true;
@@ -533,12 +537,14 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
   for (int m = tid; m < N; m += NT) s.keys[m] = qW[m];
   block_sync();
   constexpr int NS = 8;                                    // entries per thread held in registers
+  bool tiedKeys = false;                                   // some thread has seen two equal weights (all-pairs form: not looked for, assumed)
   if (N <= NS * NT) {
     int rl[NS];
     const int logNB = rank_sort_log_buckets(B.cap);
     unsigned *hist = reinterpret_cast<unsigned *>(s.perm);  // histogram + bucket-ordered list inside the 8 B per entry of perm + fkeys
     if (!bucket_rank_sort<WPP, NS>([&](int m) { return s.keys[m]; }, N, tid, hist, reinterpret_cast<unsigned short *>(hist + (1 << logNB) / 2 + 4), logNB,
-                                   s.labR, rl, block_sync)) {
+                                   s.labR, rl, block_sync, tiedKeys)) {
+    tiedKeys = true;   // (crowded buckets ARE equal weights)
     block_sync();
 #pragma unroll
     for (int k = 0; k < NS; k++) {
@@ -598,13 +604,21 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
       }
     }
     }
+    {   // the workgroup's verdict on equal weights rides on the barrier that is due anyway
+      const bool any = __ballot(tiedKeys) != 0ull;
+      if (lane == 0) s.labR[8 + wave] = any ? 1 : 0;       // (xscr of the sort: words 0 .. 2 WPP)
+    }
     block_sync();                                          // all ranks known: the sort's scratch is dead, perm may be written
+    tiedKeys = false;
+#pragma unroll
+    for (int w2 = 0; w2 < WPP; w2++) tiedKeys |= s.labR[8 + w2] != 0;
 #pragma unroll
     for (int k = 0; k < NS; k++) {
       const int m = tid + NT * k;
       if (m < N) s.perm[rl[k]] = m;
     }
   } else {  // more entries than the register slots cover: all-pairs ranking
+    tiedKeys = true;
     for (int m = tid; m < N; m += NT) {
       const double wm = s.keys[m];
       int rank = 0;
@@ -631,7 +645,7 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
     ss.eq = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(s.compRows) + 2056);   // [<= 32]
     ss.stack = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(s.compRows) + 2056 + 256);     // [<= 26]
     ss_correct_tie_order<WPP>([&](int e) { return s.keys[e]; }, [&](int r) { return (int)(unsigned short)s.perm[r]; },
-                              [&](int r, unsigned short e) { s.perm[r] = (int)e; }, N, N, ss, tid, block_sync);
+                              [&](int r, unsigned short e) { s.perm[r] = (int)e; }, N, N, ss, tid, block_sync, tiedKeys);
   }
   // sorted mixture -> other slab (or just the permutation, for the fused step's merge phase)
   if (permOut) {

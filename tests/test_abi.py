@@ -75,9 +75,9 @@ def test_resample_plan_matches_oracle_restatement(pkg, ob):
             assert np.all(src[src] == src)
 
 
-def core_symbols():
+def core_symbols(tag="RFSGPU_CORE"):
     txt = open(os.path.join(ROOT, "include", "rfsgpu.h")).read()
-    return sorted({w for line in re.findall(r"RFSGPU_CORE:(.*)", txt) for w in line.split()})
+    return sorted({w for line in re.findall(tag + r":(.*)", txt) for w in line.split()})
 
 
 def test_stable_core_is_small_declared_and_sufficient_for_the_reference_side_binding(pkg):
@@ -89,11 +89,14 @@ def test_stable_core_is_small_declared_and_sufficient_for_the_reference_side_bin
     assert set(core) <= set(declared_symbols())
     src = open(os.path.join(ROOT, "integration", "RBPHDFilter_rfsgpu.hpp")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    multi = core_symbols("RFSGPU_CORE_MULTI")          # the group counterparts the binding calls when RFSGPU_DEVICES lists several GPUs
+    assert 15 <= len(multi) <= 22 and set(multi) <= set(declared_symbols())
     used = set(re.findall(r"\b(rfsgpu_[a-z_0-9]+)\s*\(", src)) & set(declared_symbols())     # (the binding's helper classes also start with rfsgpu_)
-    assert used and used <= set(core), used - set(core)
+    assert used and used <= set(core) | set(multi), used - set(core) - set(multi)
+    assert set(multi) <= used                            # (the list names exactly what the facade forwards to)
     import subprocess
     for name in ("rbphdslam2dSim", "rbphdslam_VictoriaPark"):
         exe = os.path.join(ROOT, "tests", "support", "_build", name)
         if os.path.exists(exe):
             und = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True).stdout
-            assert set(re.findall(r"\b(rfsgpu_\w+)", und)) <= set(core)
+            assert set(re.findall(r"\b(rfsgpu_\w+)", und)) <= set(core) | set(multi)

@@ -419,9 +419,21 @@ def test_mat_perm_known_answers_on_device(pkg, ob):
         got = pkg.mat_perm(np.ones((n, n)) - np.eye(n))[0]
         assert got == want, (n, got, want)
     rng = np.random.default_rng(0)
-    for n in (1, 2, 5, 9, 13, 16):
+    for n in (1, 2, 5, 9, 10, 12, 13, 16, 17):     # 10 .. : the register-resident kernels mat_perm_kernel_t<12 | 16 | 20 | 24>
         A = rng.uniform(-1, 1, (7, n, n))
         np.testing.assert_allclose(pkg.mat_perm(A), ob.mat_perm(A), rtol=1e-10, atol=1e-13)
+    for n in (20, 21, 24):
+        # identity: every x_i is -1/2, 1/2 or 3/2, every term a multiple of 2^-n below 2^53 in magnitude -- any summation order is exact
+        assert pkg.mat_perm(np.eye(n))[0] == 1.0
+        # a permutation matrix plus one more entry per row of a 4-cycle: permanent 2 (two perfect matchings), small half-integer x
+        Pm = np.eye(n)[rng.permutation(n)]
+        cyc = rng.choice(n, 4, replace=False)
+        rows = [int(np.nonzero(Pm[:, c])[0][0]) for c in cyc]
+        for k in range(4):
+            Pm[rows[k], cyc[(k + 1) % 4]] = 1.0
+        assert pkg.mat_perm(Pm)[0] == 2.0
+    A = rng.uniform(0, 1, (3, 20, 20))              # (Ryser's sum cancels ~8 digits at n = 20 with entries in [0, 1])
+    np.testing.assert_allclose(pkg.mat_perm(A), ob.mat_perm(A), rtol=1e-6)
 
 
 def test_murty_partitions_match_oracle(pkg, ob, sc):

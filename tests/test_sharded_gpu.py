@@ -129,6 +129,81 @@ def test_group_of_shards_in_one_process_matches_single_filter(pkg, n_shards):
     grp.close(); ref.close()
 
 
+def test_group_weight_sums_over_rccl_with_one_communicator(pkg):
+    """The single-process RCCL form of the one collective on the path (VERDICT r3 missing 4): a group whose device ids are pairwise
+    distinct gets one communicator per shard from ncclCommInitAll (librccl loaded with dlopen) and all-reduces {sum w, sum w^2} on
+    the shards' streams, the divide reads the total on the device.  This box has ONE GPU, so the group that can show it here has
+    one shard: the RCCL calls themselves -- communicator set-up, ncclAllReduce between group start / end, the device-side divisor --
+    execute and must reproduce a plain handle bit for bit; groups with repeated ids (the other tests) report the host path."""
+    sc = pkg.scenarios
+    n = 24
+    scen = sc.make_scenario(n, 40, 12, seed=32, params=dict(min_updates=1))
+    scen["particle_w"] = np.random.default_rng(2).uniform(0.2, 1.0, n)
+    ref = pkg.RBPHDFilter(n, device_id=0, gm_capacity=192)
+    grp = pkg.FilterGroup(n, [0], gm_capacity=192)
+    assert grp.collective() == "rccl", grp.collective()
+    g2 = pkg.FilterGroup(n, [0, 0], gm_capacity=192)
+    assert g2.collective().startswith("host: repeated device ids")
+    g2.close()
+    for f in (ref, grp):
+        sc.load_scenario(f, scen)
+    ref.update(scen["Z"])
+    grp.update_nosums(scen["Z"])                       # stream-ordered: no host wait with the RCCL collective
+    s_ref = ref.weight_sums()
+    ref.normalize_weights(s_ref[0])
+    sums = grp.normalize()                             # weight sums -> ncclAllReduce -> divide by the device-resident total
+    np.testing.assert_array_equal(sums, s_ref)
+    np.testing.assert_array_equal(grp.get_weights(), ref.get_weights())
+    sums2 = grp.update(scen["Z"])                      # the form that does return the sums
+    ref.update(scen["Z"])
+    np.testing.assert_allclose(sums2, ref.weight_sums(), rtol=1e-13)   # (the step's post kernel and weight_sums_kernel add in different trees)
+    fired, plan = grp.resample(n + 1.0, 0.77)
+    assert fired
+    s_ref = ref.weight_sums()
+    ref.normalize_weights(s_ref[0])
+    ref.resample_apply(pkg.engine.systematic_resample_plan(ref.get_weights(), 0.77))
+    for i in range(n):
+        for a, b in zip(grp.export_gm(i), ref.export_gm(i)):
+            assert np.array_equal(a, b)
+    grp.close(); ref.close()
+
+
+def test_victoria_park_model_on_a_group_of_shards(pkg):
+    """rfsgpu_group_set_model_victoriapark / _set_laser_scan / _get_timing (VERDICT r3 missing 5): configs[3]'s model on three shards
+    of one GPU against one handle: two predict / update / normalise cycles and a forced global resampling in between (candidate
+    lists travel level by level), weights 1e-12, maps and sizes bit for bit."""
+    sc = pkg.scenarios
+    n = 30
+    scen = sc.make_vp_scenario(n, 40, 10, seed=17, scan="ragged")
+    ref = pkg.RBPHDFilter(n, device_id=0, gm_capacity=192, model=pkg.capi.MODEL_VICTORIAPARK_3D)
+    grp = pkg.FilterGroup(n, [0, 0, 0], gm_capacity=192, model=pkg.capi.MODEL_VICTORIAPARK_3D)
+    for f in (ref, grp):
+        sc.load_scenario(f, scen)
+    for cyc in range(2):
+        Z = scen["Z"] + 1e-3 * cyc
+        ref.predict_map(True); grp.predict_map(True)
+        ref.update(Z)
+        sums = grp.update(Z)
+        np.testing.assert_allclose(sums, ref.weight_sums(), rtol=1e-12)
+        np.testing.assert_array_equal(grp.get_weights(), ref.get_weights())
+        assert np.array_equal(grp.gm_sizes(), ref.gm_sizes())
+        for i in range(n):
+            for a, b in zip(grp.export_gm(i), ref.export_gm(i)):
+                assert np.array_equal(a, b)
+        if cyc == 0:
+            s = ref.weight_sums()
+            ref.normalize_weights(s[0])
+            plan = pkg.engine.systematic_resample_plan(ref.get_weights(), 0.31)
+            x = ref.get_poses()
+            ref.resample_apply(plan)
+            ref.set_poses(x[plan], None)
+            fired, plan_g = grp.resample(n + 1.0, 0.31)
+            assert fired and np.array_equal(plan_g, plan)
+    t = grp.getTimingInfo()
+    assert t.mapUpdate_wall > 0 and t.predict_wall > 0
+    grp.close(); ref.close()
+
+
 def test_configs2_whole_as_eight_shards_on_one_device(pkg):
     """BASELINE configs[2] as a whole -- 20 000 particles x 500 GM landmarks x 30 measurements, eight shards of 2500 -- on the one GPU of
     this box (rfsgpu_group with device_ids = [0] * 8; every shard its own handle, stream, slabs and migration buffers, rows moved

@@ -34,7 +34,7 @@ else:
     for name in sys.argv[2:]:
         code = (f"import sys; sys.path.insert(0, {ROOT!r}); import __graft_entry__ as g; pkg = g.load_package(); "
                 f"pkg.engine.LIB = {lib_of(name)!r}; import bench; "
-                f"sys.argv = ['bench.py', '--steps', '{steps}', '--warmup', '20', '--no-cpu-baseline', '--no-pmc']; bench.main()")
+                f"sys.argv = ['bench.py', '--steps', '{steps}', '--warmup', '20', '--no-cpu-baseline', '--no-pmc', '--no-boundary']; bench.main()")
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
         try:
             d = json.loads(r.stdout.strip().splitlines()[-1])
