@@ -32,7 +32,14 @@ __host__ __device__ constexpr int merge_cells(int gridLog) { return 1 << (2 * gr
 // (Measured and dropped, r04 -- profiles/r04a_ab_merge_stage.txt: phase 1b leaving the replay's operands -- mean and covariance of
 //  every passing partner and of its row -- in LDS, so that the one wave that replays reads LDS instead of dependent global loads:
 //  fused step 125.2 -> 126.5 us at configs[1].  The loads the replay waits for are L2 hits issued together; the staging's stores
-//  and slot atomics in the pair phase cost more than they save.)
+//  and slot atomics in the pair phase cost more than they save.
+//  Also measured and dropped, r04 -- profiles/r04c_ab_flat_candidate_scan.txt: the candidate scan FLATTENED over (entry, neighbour)
+//  items with every unordered pair visited once (own cell upwards, east cell, the three cells of the next row; items of all
+//  entries laid end to end and dealt out in equal runs; survivors appended to an unordered list and grouped into the rows'
+//  segments by a counting pass; bit-identical results, 200 fuzz cases clean): half the thread-per-entry form's vector
+//  instructions on the busier wave, but eight more workgroup barriers, LDS atomics per far neighbour and 3 KB more LDS: fused
+//  step 123.8-124.5 -> 125.0-125.2 us, stand-alone merge + prune 63.3 -> 62.2 us.  The phase is as long as its chain of dependent
+//  LDS round trips and barriers, not as its instruction count.)
 __host__ __device__ inline size_t merge_lds_bytes_per_wave(int cap, int gridLog = 5) {
   // entries: w (f64) + x, y, radius (f32) + row record (u32) + grid-sorted index (u16) + prefilter slack (u16); grid: CELLS/2+4 u32; pair list: u32
   return (((size_t)cap * (8 + 3 * 4 + 4 + 2 + 2)) + (size_t)(merge_cells(gridLog) / 2 + 4) * 4 + (size_t)MERGE_PAIR_CAP(cap) * 4 + 16 + 15) & ~(size_t)15;
@@ -277,8 +284,15 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
   //     and in the row record.
   const int pairCap = MERGE_PAIR_CAP(cap);
   const float slackOut = (float)(fmin(cellx, celly)) * (1.f - 4e-6f) - frad * (1.f + 4e-6f) - 3.f * errAbs;
-  for (int m = tid, sidx = 0; m < N; m += NT, sidx++) {
-    if ((hole >> sidx) & 1u) continue;
+#ifndef MERGE_SCAN_GRID_ORDER
+#define MERGE_SCAN_GRID_ORDER 1   // r04, profiles/r04d_ab_scan_grid_order.txt: fused step 124.0 -> 121.2-121.9 us at configs[1]
+#endif
+  const int nLive = MERGE_SCAN_GRID_ORDER ? (int)cell_at(MERGE_CELLS) : N;     // (entries in the grid = the live ones)
+  for (int t0 = tid, sidx = 0; t0 < nLive; t0 += NT, sidx++) {
+    // MERGE_SCAN_GRID_ORDER: the threads take the entries in GRID order, so that the lanes of a wave work on neighbouring cells --
+    // similar neighbour counts (the trips of four last as long as the busiest lane's), the same LDS words
+    const int m = MERGE_SCAN_GRID_ORDER ? (int)sSorted[t0] : t0;
+    if (!MERGE_SCAN_GRID_ORDER && ((hole >> sidx) & 1u)) continue;
     const float ax = sX[m], ay = sY[m], ar = sRad[m];
     int cx, cy;
     cell_of(ax, ay, cx, cy);
