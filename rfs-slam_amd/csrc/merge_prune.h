@@ -818,15 +818,27 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
   } else tiedKeys = true;
   {
     StdSortScratch ss;                              // the fp32 positions / radii of the merge are dead: 12 B per entry
-    ss.T = reinterpret_cast<unsigned short *>(sX);  // [N]          | Ll [N / 2 + 1]   (3 N + 2 <= 4 cap bytes)
-    ss.tStride = 1;
-    ss.Ll = ss.T + N;
-    ss.pos = reinterpret_cast<unsigned short *>(sY);  // [N]        | Rl [N / 2 + 1]
-    ss.Rl = ss.pos + N;
-    ss.eq = reinterpret_cast<unsigned long long *>(sRad);                       // [ceil(N / 64)] <= cap / 8 bytes
-    ss.stack = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(sRad) + (((size_t)(N + 63) >> 6) * 8));   // [26]: 104 B <= 4 cap - cap / 8
-    ss_correct_tie_order<WPP>([&](int e) { const double w = sW[e]; return w < 0.0 ? 0.0 : w; }, [&](int r) { return (int)sOrder[r]; },
-                              [&](int r, unsigned short e) { sOrder[r] = e; }, N, nSurv, ss, tid, block_sync, tiedKeys);
+    ss.T = reinterpret_cast<unsigned *>(sX);        // [N] words (group | entry)
+    ss.pos = reinterpret_cast<unsigned short *>(sY);  // [N]        | Ll [N / 2 + 1]   (3 N + 2 <= 4 cap bytes)
+    ss.posStride = 1;
+    ss.Ll = ss.pos + N;
+    ss.Rl = reinterpret_cast<unsigned short *>(sRad);                           // [N / 2 + 1] | eq | stack   (N + 2 + cap / 8 + 112 <= 4 cap bytes)
+    ss.eq = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(sRad) + ((((size_t)(N / 2 + 1) * 2) + 7) & ~(size_t)7));
+    ss.stack = reinterpret_cast<unsigned *>(ss.eq + ((N + 63) >> 6));
+    auto key0 = [&](int e) { const double w = sW[e]; return w < 0.0 ? 0.0 : w; };          // merged-away entries: weight 0 in the reference
+    auto is_rest = [&](int e) { const double w = sW[e]; return !((w >= t) && (w >= 0.0)); };  // not a survivor
+    // the entries below the survivors: group = nSurv + the number of such entries with a larger key (equal keys share a group)
+    auto rest_group = [&](unsigned *T) {
+      for (int e = tid; e < N; e += NT) {
+        if (!is_rest(e)) continue;
+        const double k = key0(e);
+        int g = nSurv;
+        for (int e2 = 0; e2 < N; e2++) g += (is_rest(e2) && key0(e2) > k) ? 1 : 0;
+        T[e] = ((unsigned)g << 16) | (unsigned)g;
+      }
+    };
+    ss_correct_tie_order<WPP>(key0, [&](int r) { return (int)sOrder[r]; }, [&](int r, unsigned short e) { sOrder[r] = e; }, rest_group, N, nSurv, ss, tid,
+                              block_sync, tiedKeys);
   }
   for (int r = tid; r < nSurv; r += NT) put(r, sOrder[r]);
   if (tid == 0) B.count[i] = nSurv;
@@ -848,7 +860,8 @@ __global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(MERGE_
 // LDS per wave: keys[cap] doubles + the order / std::sort-replay scratch (u16 each: order [cap], T [cap], pos [cap], two stopper
 // lists [cap / 2 + 1]; eq words, stack)
 __host__ __device__ inline size_t gm_prune_lds_bytes_per_wave(int cap) {
-  return (((size_t)cap * 8 + (size_t)cap * 2 * 3 + (size_t)(cap / 2 + 2) * 2 * 2 + (size_t)((cap + 63) / 64) * 8 + 128) + 15) & ~(size_t)15;
+  // keys f64 | order u16 | T u32 | pos u16 | two stopper lists u16 [cap / 2 + 2] | eq words | stack
+  return (((size_t)cap * 8 + (size_t)cap * 2 + (size_t)cap * 4 + (size_t)cap * 2 + (size_t)(cap / 2 + 2) * 2 * 2 + (size_t)((cap + 63) / 64) * 8 + 128) + 15) & ~(size_t)15;
 }
 // NEG_IS_HOLE: the RB-PHD mixtures mark merged-away entries with w = -1; FastSLAM's log-odds weights are legitimately negative.
 // GaussianMixture::prune (include/GaussianMixture.hpp:477-534): std::sort of the whole list by weight, the sorted prefix with
@@ -889,15 +902,26 @@ __global__ __launch_bounds__(WPB * 64) void gm_prune_kernel(Buffers B, Params P,
   wave_sync();
   {
     StdSortScratch ss;
-    ss.T = sOrder + cap;
-    ss.tStride = 1;
-    ss.pos = ss.T + cap;
+    ss.T = reinterpret_cast<unsigned *>(sOrder + cap);
+    ss.pos = reinterpret_cast<unsigned short *>(ss.T + cap);
+    ss.posStride = 1;
     ss.Ll = ss.pos + cap;
     ss.Rl = ss.Ll + (cap / 2 + 2);
-    ss.eq = reinterpret_cast<unsigned long long *>(base + (size_t)cap * 8 + (size_t)cap * 2 * 3 + (size_t)(cap / 2 + 2) * 2 * 2);
+    ss.eq = reinterpret_cast<unsigned long long *>(base + (size_t)cap * 16 + (size_t)(cap / 2 + 2) * 4);
     ss.stack = reinterpret_cast<unsigned *>(ss.eq + (cap + 63) / 64);
-    ss_correct_tie_order<1>([&](int e) { const double w = keys[e]; return (NEG_IS_HOLE && w < 0.0) ? 0.0 : w; }, [&](int r) { return (int)sOrder[r]; },
-                            [&](int r, unsigned short e) { sOrder[r] = e; }, N, kept, ss, lane, [&]() { wave_sync(); });
+    auto key0 = [&](int e) { const double w = keys[e]; return (NEG_IS_HOLE && w < 0.0) ? 0.0 : w; };
+    auto is_rest = [&](int e) { const double w = keys[e]; return !((w >= t) && (!NEG_IS_HOLE || w >= 0.0)); };
+    auto rest_group = [&](unsigned *T) {
+      for (int e = lane; e < N; e += 64) {
+        if (!is_rest(e)) continue;
+        const double k = key0(e);
+        int g = kept;
+        for (int e2 = 0; e2 < N; e2++) g += (is_rest(e2) && key0(e2) > k) ? 1 : 0;
+        T[e] = ((unsigned)g << 16) | (unsigned)g;
+      }
+    };
+    ss_correct_tie_order<1>(key0, [&](int r) { return (int)sOrder[r]; }, [&](int r, unsigned short e) { sOrder[r] = e; }, rest_group, N, kept, ss, lane,
+                            [&]() { wave_sync(); });
   }
   for (int r = lane; r < kept; r += 64) {
     const int m = sOrder[r];

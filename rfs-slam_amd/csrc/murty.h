@@ -270,6 +270,9 @@ __device__ __forceinline__ bool murty_root_wave(double *C, int n, MurtyArena &A,
 // child solved ahead of its parent's pop has none yet).  Out: pushed (a solution exists), its score and assignment.
 // MASK: `exclNode` = what child 0 of `par` must not take in its first row (the search's per-node set); a child c > 0 must not
 // take the parent's own choice for that row.
+// (Measured and dropped, r04 -- profiles/r04f_ab_murty_solver_as_call.txt: this body as a real call (__noinline__), so that the solver
+//  waves' path would get a register allocation of its own under the 64-VGPR cap: 360 B of stack per lane instead of 160 B of
+//  spills, configs[4] 5.18 -> 8.5 ms per update.)
 template <int LDSN, bool MASK = false>
 __device__ __forceinline__ void murty_solve_child(double *myTile, const double *C, const int n, const int realNC, MurtyArena &A, const int wave, const int par,
                                                   const int ppar, const int c, const int pn, const int aPar, const double termPar, bool &pushed,

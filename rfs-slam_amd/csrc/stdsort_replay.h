@@ -48,7 +48,7 @@ SS_HD inline int ss_floor_lg(int n) { int k = 0; while (n > 1) { n >>= 1; k++; }
 
 // __adjust_heap + __push_heap (bits/stl_heap.h) on positions f + [0, len)
 template <class Get, class Put, class Gt>
-SS_HD inline void ss_adjust_heap(Get get, Put put, Gt gt, const int f, int hole, const int len, const unsigned short value) {
+SS_HD inline void ss_adjust_heap(Get get, Put put, Gt gt, const int f, int hole, const int len, const decltype(get(0)) value) {
   const int top = hole;
   int child = hole;
   while (child < (len - 1) / 2) {
@@ -81,7 +81,7 @@ SS_HD inline void ss_heap_sort(Get get, Put put, Gt gt, const int f, const int l
   }
   for (int last = l; last - f > 1;) {
     --last;
-    const unsigned short value = get(last);
+    const auto value = get(last);
     put(last, get(f));
     ss_adjust_heap(get, put, gt, f, 0, last - f, value);
   }
@@ -90,7 +90,7 @@ SS_HD inline void ss_heap_sort(Get get, Put put, Gt gt, const int f, const int l
 template <class Get, class Gt>
 SS_HD inline int ss_median_position(Get get, Gt gt, const int f, const int l) {
   const int a = f + 1, b = f + (l - f) / 2, c = l - 1;
-  const unsigned short ea = get(a), eb = get(b), ec = get(c);
+  const auto ea = get(a), eb = get(b), ec = get(c);
   if (gt(ea, eb)) {
     if (gt(eb, ec)) return b;
     if (gt(ea, ec)) return c;
@@ -104,15 +104,15 @@ SS_HD inline int ss_median_position(Get get, Gt gt, const int f, const int l) {
 template <class Get, class Put, class Gt>
 SS_HD inline int ss_partition_serial(Get get, Put put, Gt gt, const int f, const int l) {
   const int s = ss_median_position(get, gt, f, l);
-  { const unsigned short t = get(f); put(f, get(s)); put(s, t); }
-  const unsigned short pivot = get(f);
+  { const auto t = get(f); put(f, get(s)); put(s, t); }
+  const auto pivot = get(f);
   int first = f + 1, last = l;
   while (true) {
     while (gt(get(first), pivot)) ++first;
     --last;
     while (gt(pivot, get(last))) --last;
     if (!(first < last)) return first;
-    { const unsigned short t = get(first); put(first, get(last)); put(last, t); }
+    { const auto t = get(first); put(first, get(last)); put(last, t); }
     ++first;
   }
 }
@@ -129,8 +129,8 @@ SS_HD inline int ss_partition_serial(Get get, Put put, Gt gt, const int f, const
 template <class Get, class Put, class Gt>
 SS_HD inline int ss_partition_lists(Get get, Put put, Gt gt, const int f, const int l, unsigned short *Ll, unsigned short *Rl) {
   const int s = ss_median_position(get, gt, f, l);
-  { const unsigned short t = get(f); put(f, get(s)); put(s, t); }
-  const unsigned short pivot = get(f);
+  { const auto t = get(f); put(f, get(s)); put(s, t); }
+  const auto pivot = get(f);
   // (the lists are kept to their first LC = (l - f) / 2 + 1 entries, as on the device: K <= (l - f - 1) / 2 < LC)
   const int LC = (l - f) / 2 + 1;
   int nL = 0, nR = 0;
@@ -138,7 +138,7 @@ SS_HD inline int ss_partition_lists(Get get, Put put, Gt gt, const int f, const 
   for (int p = l - 1; p > f && nR < LC; p--) if (!gt(pivot, get(p))) Rl[nR++] = (unsigned short)p;
   int K = 0;
   while (K < nL && K < nR && Ll[K] < Rl[K]) {
-    const unsigned short t = get(Ll[K]); put(Ll[K], get(Rl[K])); put(Rl[K], t);
+    const auto t = get(Ll[K]); put(Ll[K], get(Rl[K])); put(Rl[K], t);
     K++;
   }
   if (K == 0) return Ll[0];
@@ -171,12 +171,16 @@ SS_HD inline void ss_replay_serial(Get get, Put put, Gt gt, const int N, Rel rel
 
 #if defined(__HIPCC__)
 // ---- wavefront form ------------------------------------------------------------------------------------------------------------
-// Scratch of one replay (all LDS, u16 unless noted).  T is addressed with a stride so that it can live in the unused upper
-// halves of an int[] permutation array (tStride 2) as well as in an array of its own (tStride 1).
+// The replay works on 32-bit words  (group << 16) | rank : `rank` = the entry's stable rank, `group` = the stable rank of the first member of its run of
+// equal keys -- an order- and equality-preserving 16-bit image of the key (smaller group = larger weight) -- so that one LDS read
+// brings what a comparison needs:  gt(a, b)  <=>  group(a) < group(b).  (r04, first version: a u16 index array with the keys looked
+// up behind it -- two dependent LDS reads per comparison, the pivot re-read after the median swap, the cut read back from the lists:
+// 8 + 2 chunks LDS round trips per partition step, one wave, everything else waiting: +10.5 us per step at C2b, where every
+// mixture holds tied birth weights.  This form: 3 + chunks.)
 struct StdSortScratch {
-  unsigned short *T;     // [N * tStride] arrangement: entry at position p
-  int tStride;
-  unsigned short *pos;   // [N] position of entry m after the partition phase (written at the end of the replay)
+  unsigned *T;           // [N] arrangement: word at position p
+  unsigned short *pos;   // [N * posStride] position, after the partition phase, of the entry that the stable order ranks r-th (index: r)
+  int posStride;         // 1, or 2 when the array lives in the unused upper halves of an int[] permutation array
   unsigned short *Ll;    // [LC] left stoppers, ascending   (LC = N / 2 + 1; nullptr: no room -> lane 0 replays serially)
   unsigned short *Rl;    // [LC] right stoppers, descending
   unsigned long long *eq;  // [ceil(N / 64)] bit r of word r / 64: the keys of sorted ranks r - 1 and r are equal (and matter)
@@ -184,18 +188,18 @@ struct StdSortScratch {
 };
 __host__ __device__ inline int ss_list_cap(int N) { return N / 2 + 1; }
 
-// Lay the scratch out in a byte range [buf, buf + bytes) (8-byte aligned): eq words | stack | T (when ownT: an array of its own,
-// stride 1; otherwise the caller has set S.T / S.tStride) | pos | the two stopper lists if they still fit (else the replay runs
-// serially on lane 0).  Returns false when even the mandatory part does not fit.
-__device__ __forceinline__ bool ss_carve(StdSortScratch &S, unsigned char *buf, size_t bytes, const int N, const bool ownT) {
-  const size_t eqB = (size_t)((N + 63) >> 6) * 8, stackB = 112, arr = ((size_t)N * 2 + 7) & ~(size_t)7;
-  const size_t must = eqB + stackB + (ownT ? arr : 0) + arr;
+// Lay the scratch out in a byte range [buf, buf + bytes) (8-byte aligned): eq words | stack | T | pos (when ownPos; otherwise the
+// caller has set S.pos / S.posStride) | the two stopper lists if they still fit (else the replay runs serially on lane 0).
+// Returns false when even the mandatory part does not fit.
+__device__ __forceinline__ bool ss_carve(StdSortScratch &S, unsigned char *buf, size_t bytes, const int N, const bool ownPos) {
+  const size_t eqB = (size_t)((N + 63) >> 6) * 8, stackB = 112, tB = (size_t)N * 4 + ((N & 1) ? 4 : 0), posB = ((size_t)N * 2 + 7) & ~(size_t)7;
+  const size_t must = eqB + stackB + tB + (ownPos ? posB : 0);
   if (must > bytes) return false;
   unsigned char *p = buf;
   S.eq = reinterpret_cast<unsigned long long *>(p); p += eqB;
   S.stack = reinterpret_cast<unsigned *>(p); p += stackB;
-  if (ownT) { S.T = reinterpret_cast<unsigned short *>(p); S.tStride = 1; p += arr; }
-  S.pos = reinterpret_cast<unsigned short *>(p); p += arr;
+  S.T = reinterpret_cast<unsigned *>(p); p += tB;
+  if (ownPos) { S.pos = reinterpret_cast<unsigned short *>(p); S.posStride = 1; p += posB; }
   const size_t listB = ((size_t)ss_list_cap(N) * 2 + 7) & ~(size_t)7;
   if (must + 2 * listB <= bytes) {
     S.Ll = reinterpret_cast<unsigned short *>(p); p += listB;
@@ -206,95 +210,110 @@ __device__ __forceinline__ bool ss_carve(StdSortScratch &S, unsigned char *buf, 
   return true;
 }
 
-// relevant(f, l): some rank in (f, l) carries an eq bit, i.e. two equal keys end up inside [f, l).  Uniform; all lanes call it.
-__device__ __forceinline__ bool ss_relevant(const unsigned long long *eq, const int f, const int l, const int lane) {
-  // ranks f + 1 .. l - 1
-  const int lo = f + 1, hi = l - 1;
+// relevant(f, l): some rank in (f, l) carries an eq bit, i.e. two equal keys end up inside [f, l).  eqReg: lane w holds eq word w
+// (loaded once per replay: no LDS read here).  Uniform; all lanes call it.
+__device__ __forceinline__ bool ss_relevant(const unsigned long long eqReg, const int f, const int l, const int lane) {
+  const int lo = f + 1, hi = l - 1;          // ranks f + 1 .. l - 1
   unsigned long long m = 0ull;
-  const int w = lane;                       // word `lane` (<= 32 words: N <= 2048)
-  if (lo <= hi && w >= (lo >> 6) && w <= (hi >> 6)) {
-    m = eq[w];
-    if (w == (lo >> 6)) m &= ~0ull << (lo & 63);
-    if (w == (hi >> 6)) m &= ~0ull >> (63 - (hi & 63));
+  if (lo <= hi && lane >= (lo >> 6) && lane <= (hi >> 6)) {
+    m = eqReg;
+    if (lane == (lo >> 6)) m &= ~0ull << (lo & 63);
+    if (lane == (hi >> 6)) m &= ~0ull >> (63 - (hi & 63));
   }
   return __ballot(m != 0ull) != 0ull;
 }
 
 // One partition step (__unguarded_partition_pivot) on T[f, l) by the calling wavefront; returns the cut (uniform).
-// keyAt(e): key of entry e (LDS read); the comparisons are weightCompare's: gt(a, b) = keyAt(a) > keyAt(b).
-template <class KeyAt>
-__device__ __forceinline__ int ss_partition_wave(KeyAt keyAt, const StdSortScratch &S, const int f, const int l, const int lane) {
-  auto Tat = [&](int p) -> unsigned short & { return S.T[p * S.tStride]; };
+// Dependent LDS round trips: the median's four words; one per 64 positions from either end; the stopper lists; the swapped words.
+__device__ __forceinline__ int ss_partition_wave(const StdSortScratch &S, const int f, const int l, const int lane) {
+  unsigned *const T = S.T;
   const int LC = ss_list_cap(l - f);
-  {  // median of three to the front (uniform reads, lane 0 writes)
-    const int a = f + 1, b = f + (l - f) / 2, c = l - 1;
-    const unsigned short ea = Tat(a), eb = Tat(b), ec = Tat(c);
-    const double ka = keyAt(ea), kb = keyAt(eb), kc = keyAt(ec);
-    int s;
-    if (ka > kb) s = (kb > kc) ? b : ((ka > kc) ? c : a);
-    else s = (ka > kc) ? a : ((kb > kc) ? c : b);
-    const unsigned short ef = Tat(f), es = (s == a) ? ea : ((s == b) ? eb : ec);
-    wave_sync();
-    if (lane == 0) { Tat(f) = es; Tat(s) = ef; }
-    wave_sync();
-  }
-  const double kp = keyAt(Tat(f));
-  // stoppers from both ends at once: trip t looks at positions f + 1 + (64 t + lane) and l - 1 - (64 t + lane)
+  // median of three to the front: the four words in one trip; the swap is written by lane 0 and NOT waited for -- the scans
+  // below substitute the one word they could read stale (position s), and a barrier precedes the next reader of T
+  const int a = f + 1, b = f + (l - f) / 2, c = l - 1;
+  const unsigned wf = T[f], wa = T[a], wb = T[b], wc = T[c];
+  const unsigned ga = wa >> 16, gb = wb >> 16, gc = wc >> 16;      // gt(x, y) <=> group(x) < group(y)
+  int s;
+  if (ga < gb) s = (gb < gc) ? b : ((ga < gc) ? c : a);
+  else s = (ga < gc) ? a : ((gb < gc) ? c : b);
+  const unsigned wp = (s == a) ? wa : ((s == b) ? wb : wc);        // the pivot's word, now at position f
+  if (lane == 0) { T[f] = wp; T[s] = wf; }
+  const unsigned gp = wp >> 16;
+  // stoppers from both ends at once: trip t looks at positions f + 1 + (64 t + lane) and l - 1 - (64 t + lane).  Four trips'
+  // words are loaded together (eight independent LDS reads in flight, with the median's four above: one latency for a range of
+  // up to 256), then enumerated from registers.
   int nL = 0, nR = 0;
   const int n1 = l - f - 1;                  // positions f + 1 .. l - 1
-  for (int t0 = 0; t0 < n1 && (nL < LC || nR < LC); t0 += 64) {
-    const int q = t0 + lane;
-    const bool in = q < n1;
-    const int pa = f + 1 + q, pd = l - 1 - q;
-    const double kx = in ? keyAt(Tat(pa)) : 0.0, ky = in ? keyAt(Tat(pd)) : 0.0;
-    const bool sl = in && !(kx > kp), sr = in && !(kp > ky);
-    const unsigned long long ml = __ballot(sl), mr = __ballot(sr);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const int il = nL + __popcll(ml & below), ir = nR + __popcll(mr & below);
-    if (sl && il < LC) S.Ll[il] = (unsigned short)pa;
-    if (sr && ir < LC) S.Rl[ir] = (unsigned short)pd;
-    nL += __popcll(ml);
-    nR += __popcll(mr);
+  for (int t0 = 0; t0 < n1 && (nL < LC || nR < LC); t0 += 256) {
+    unsigned wx[4], wy[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int q = t0 + 64 * u + lane;
+      const bool in = q < n1;
+      wx[u] = in ? T[f + 1 + q] : 0u;
+      wy[u] = in ? T[l - 1 - q] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (t0 + 64 * u >= n1) break;          // (uniform)
+      const int q = t0 + 64 * u + lane;
+      const bool in = q < n1;
+      const int pa = f + 1 + q, pd = l - 1 - q;
+      const unsigned x = (pa == s) ? wf : wx[u], y = (pd == s) ? wf : wy[u];
+      const bool sl = in && !((x >> 16) < gp), sr = in && !(gp < (y >> 16));   // left stops at !gt(x, pivot), right at !gt(pivot, y)
+      const unsigned long long ml = __ballot(sl), mr = __ballot(sr);
+      const unsigned long long below = (1ull << lane) - 1ull;
+      const int il = nL + __popcll(ml & below), ir = nR + __popcll(mr & below);
+      if (sl && il < LC) S.Ll[il] = (unsigned short)pa;
+      if (sr && ir < LC) S.Rl[ir] = (unsigned short)pd;
+      nL += __popcll(ml);
+      nR += __popcll(mr);
+    }
   }
   wave_sync();
   nL = nL < LC ? nL : LC;
   nR = nR < LC ? nR : LC;
-  // the swaps: k < K  <=>  L[k] < R[k]  (a prefix; beyond the lists' capacity L[k] > R[k] anyway: 2 k >= l - f - 2)
+  // the swaps: k < K  <=>  L[k] < R[k]  (a prefix; beyond the lists' capacity L[k] > R[k] anyway: 2 k >= l - f - 2).  The cut comes
+  // out of the registers of the last trip: R[K - 1] sits on lane K - 1 - k0, L[K] on lane K - k0 (or in the list's next entry).
   const int nMin = nL < nR ? nL : nR;
-  int K = 0;
-  for (int k0 = 0; k0 < nMin; k0 += 64) {
+  int K = 0, cut = -1;
+  for (int k0 = 0; k0 < nMin || k0 == 0; k0 += 64) {
     const int k = k0 + lane;
-    int pl = 0, pr = 0;
-    bool sw = false;
-    if (k < nMin) { pl = S.Ll[k]; pr = S.Rl[k]; sw = pl < pr; }
+    int pl = 0x7fffffff, pr = -1;
+    if (k < nL) pl = S.Ll[k];
+    if (k < nR) pr = S.Rl[k];
+    const bool sw = (k < nMin) && pl < pr;
     const unsigned long long ms = __ballot(sw);
     if (sw) {
-      const unsigned short el = Tat(pl), er = Tat(pr);
-      Tat(pl) = er;
-      Tat(pr) = el;
+      const unsigned el = T[pl], er = T[pr];
+      T[pl] = er;
+      T[pr] = el;
     }
-    K += __popcll(ms);
-    if (ms != ((k0 + 64 <= nMin) ? ~0ull : ((1ull << (nMin - k0)) - 1ull))) break;
+    const int cnt = __popcll(ms);
+    K = k0 + cnt;
+    if (cnt < 64) {                          // the prefix ends inside this trip: lane cnt holds L[K] (if it exists), lane cnt - 1 holds R[K - 1]
+      const int lk = __builtin_amdgcn_readlane(pl, cnt);                       // 0x7fffffff: no such stopper
+      int rk1 = (cnt > 0) ? __builtin_amdgcn_readlane(pr, cnt - 1) : -1;
+      if (cnt == 0 && k0 > 0) rk1 = S.Rl[K - 1];                                // (the prefix ended exactly at the trip boundary)
+      cut = (K == 0) ? lk : ((lk < rk1) ? lk : rk1);
+      break;
+    }
+  }
+  if (cut < 0) {                             // every one of the nMin pairs swapped and nMin is a multiple of 64
+    const int rk1 = S.Rl[K - 1];
+    const int lk = (K < nL) ? (int)S.Ll[K] : 0x7fffffff;
+    cut = (lk < rk1) ? lk : rk1;
   }
   wave_sync();
-  int cut;
-  if (K == 0) cut = S.Ll[0];
-  else {
-    const int rk = S.Rl[K - 1];
-    cut = (K < nL && (int)S.Ll[K] < rk) ? (int)S.Ll[K] : rk;
-  }
   return cut;
 }
 
-// The whole partition phase on T[0, N) (identity on entry) by ONE wavefront, then pos[].  `S.eq` must be complete.
-template <class KeyAt>
-__device__ __forceinline__ void ss_replay_wave(KeyAt keyAt, const StdSortScratch &S, const int N, const int lane) {
-  auto Tat = [&](int p) -> unsigned short & { return S.T[p * S.tStride]; };
-  for (int p = lane; p < N; p += 64) Tat(p) = (unsigned short)p;
-  wave_sync();
-  auto get = [&](int p) -> unsigned short { return Tat(p); };
-  auto put = [&](int p, unsigned short e) { Tat(p) = e; };
-  auto gt = [&](unsigned short a, unsigned short b) -> bool { return keyAt(a) > keyAt(b); };
+// The whole partition phase on T[0, N) (already holding the words of the initial arrangement) by ONE wavefront, then pos[].
+__device__ __forceinline__ void ss_replay_wave(const StdSortScratch &S, const int N, const int lane) {
+  unsigned *const T = S.T;
+  auto get = [&](int p) -> unsigned { return T[p]; };
+  auto put = [&](int p, unsigned e) { T[p] = e; };
+  auto gt = [&](unsigned x, unsigned y) -> bool { return (x >> 16) < (y >> 16); };
   if (S.Ll == nullptr) {   // no room for the stopper lists: lane 0 alone, the two-pointer loop (relevance from the same bits)
     if (lane == 0) {
       auto rel = [&](int f, int l) -> bool {
@@ -304,6 +323,8 @@ __device__ __forceinline__ void ss_replay_wave(KeyAt keyAt, const StdSortScratch
       ss_replay_serial<false>(get, put, gt, N, rel, S.stack);
     }
   } else {
+    const int nWords = (N + 63) >> 6;
+    const unsigned long long eqReg = (lane < nWords) ? S.eq[lane] : 0ull;
     int sp = 0;
     unsigned top = ss_pack_range(0, N, 2 * ss_floor_lg(N));   // (the stack's top entry rides in a register)
     bool have = true;
@@ -311,15 +332,15 @@ __device__ __forceinline__ void ss_replay_wave(KeyAt keyAt, const StdSortScratch
       const int f = (int)(top & 0x7ffu);
       int l = (int)((top >> 11) & 0xfffu), d = (int)(top >> 23);
       have = false;
-      while (l - f > SS_THRESHOLD && ss_relevant(S.eq, f, l, lane)) {
+      while (l - f > SS_THRESHOLD && ss_relevant(eqReg, f, l, lane)) {
         if (d == 0) {
           if (lane == 0) ss_heap_sort(get, put, gt, f, l);
           wave_sync();
           break;
         }
         --d;
-        const int cut = ss_partition_wave(keyAt, S, f, l, lane);
-        if (l - cut > SS_THRESHOLD) {
+        const int cut = ss_partition_wave(S, f, l, lane);
+        if (l - cut > SS_THRESHOLD && ss_relevant(eqReg, cut, l, lane)) {
           if (lane == 0) S.stack[sp] = ss_pack_range(cut, l, d);
           sp++;
         }
@@ -334,34 +355,67 @@ __device__ __forceinline__ void ss_replay_wave(KeyAt keyAt, const StdSortScratch
     }
   }
   wave_sync();
-  for (int p = lane; p < N; p += 64) S.pos[Tat(p)] = (unsigned short)p;
+  for (int p = lane; p < N; p += 64) S.pos[(T[p] & 0xffffu) * S.posStride] = (unsigned short)p;   // by rank (the word's low half)
   wave_sync();
 }
 
 // eq bits of 64 sorted ranks [c0, c0 + 64) by the calling wavefront: rank r is flagged when r < R (ranks that matter), r > 0 and
-// key(rank r) == key(rank r - 1).  entryAt(r): entry at stable rank r.  Returns the word (uniform); the caller stores it.
+// key(rank r) == key(rank r - 1).  entryAt(r): entry at stable rank r.  In the same pass the ranks' words of the initial arrangement
+// are written (position = entry index): group = start of the rank's run, found from the ballot in registers; a rank whose run began
+// in an earlier chunk gets group 0xffff for now and is fixed once all eq words are known (ss_fix_groups).  Returns the word.
 template <class KeyAt, class EntryAt>
-__device__ __forceinline__ unsigned long long ss_eq_word(KeyAt keyAt, EntryAt entryAt, const int c0, const int R, const int lane) {
+__device__ __forceinline__ unsigned long long ss_eq_word_and_words(KeyAt keyAt, EntryAt entryAt, unsigned *T, const int c0, const int R, const int lane) {
   const int r = c0 + lane;
   bool e = false;
-  if (r > 0 && r < R) e = keyAt(entryAt(r)) == keyAt(entryAt(r - 1));
-  return __ballot(e);
+  int ent = 0;
+  if (r < R) {
+    ent = entryAt(r);
+    if (r > 0) e = keyAt(ent) == keyAt(entryAt(r - 1));
+  }
+  const unsigned long long w = __ballot(e);
+  if (r < R) {
+    const unsigned long long z = ~w & (~0ull >> (63 - lane));                  // run starts at positions <= lane
+    const unsigned g = z ? (unsigned)(c0 + 63 - __builtin_clzll(z)) : 0xffffu;
+    T[ent] = (g << 16) | (unsigned)r;
+  }
+  return w;
+}
+
+// start of the run of equal keys that rank r belongs to (r itself when its key differs from its predecessor's): the highest
+// clear eq bit at or below r -- one LDS read unless the run crosses a word boundary (a loop over the members would be one
+// dependent read per member)
+__device__ __forceinline__ int ss_run_start(const unsigned long long *eq, int r) {
+  int w = r >> 6;
+  unsigned long long z = ~eq[w] & (~0ull >> (63 - (r & 63)));     // clear bits at positions <= r
+  while (z == 0ull) { w--; z = ~eq[w]; }                           // (bit 0 of word 0 is never set: the loop ends)
+  return 64 * w + 63 - __builtin_clzll(z);
+}
+// one past the last rank of the run that rank r belongs to: the lowest clear eq bit above r (limit: R)
+__device__ __forceinline__ int ss_run_end(const unsigned long long *eq, int r, const int R) {
+  int q = r + 1;
+  while (q < R) {
+    const unsigned long long z = ~eq[q >> 6] & (~0ull << (q & 63));   // clear bits at positions >= q
+    if (z != 0ull) { q = 64 * (q >> 6) + __builtin_ctzll(z); break; }
+    q = 64 * ((q >> 6) + 1);
+  }
+  return q < R ? q : R;
 }
 
 // New rank of the entry at stable rank r: unchanged unless r lies in a run of equal keys, then run start + the number of run
-// members whose position after the partition phase is smaller.  Reads only (eq, pos, the stable order); the caller writes the
-// new order after every thread has computed its ranks.
-template <class EntryAt>
-__device__ __forceinline__ int ss_fixed_rank(const StdSortScratch &S, EntryAt entryAt, const int r, const int N) {
-  auto bit = [&](int q) -> bool { return q < N && ((S.eq[q >> 6] >> (q & 63)) & 1ull); };
-  if (!bit(r) && !bit(r + 1)) return r;
-  int r0 = r;
-  while (bit(r0)) r0--;                 // (bit 0 is never set)
-  int r1 = r + 1;
-  while (bit(r1)) r1++;
-  const unsigned short myPos = S.pos[entryAt(r)];
-  int ahead = 0;
-  for (int q = r0; q < r1; q++) ahead += (S.pos[entryAt(q)] < myPos) ? 1 : 0;
+// members whose position after the partition phase is smaller.  rp(q) = position of the entry at rank q (written by the replay
+// itself: the words carry the rank), four per trip.
+template <class RpAt>
+__device__ __forceinline__ int ss_fixed_rank(const unsigned long long *eq, RpAt rp, const int r, const int R) {
+  const bool mine = (eq[r >> 6] >> (r & 63)) & 1ull, next = (r + 1 < R) && ((eq[(r + 1) >> 6] >> ((r + 1) & 63)) & 1ull);
+  if (!mine && !next) return r;
+  const int r0 = ss_run_start(eq, r), r1 = ss_run_end(eq, r, R);
+  const unsigned short myPos = rp(r);
+  int ahead = 0, q = r0;
+  for (; q + 4 <= r1; q += 4) {
+    const unsigned short p0 = rp(q), p1 = rp(q + 1), p2 = rp(q + 2), p3 = rp(q + 3);
+    ahead += (p0 < myPos) + (p1 < myPos) + (p2 < myPos) + (p3 < myPos);
+  }
+  for (; q < r1; q++) ahead += (rp(q) < myPos) ? 1 : 0;
   return r0 + ahead;
 }
 
@@ -369,27 +423,55 @@ __device__ __forceinline__ int ss_fixed_rank(const StdSortScratch &S, EntryAt en
 //   keyAt(e)      key of entry e (the caller maps merged-away entries to the reference's weight 0);
 //   entryAt(r)    entry at rank r of the STABLE order (ties by index), r < R;  setEntry(r, e) installs the corrected order;
 //   N             entries std::sort sees (the whole gList_);  R <= N: the ranks whose order matters (prune: the survivors).
+// Entries that are NOT among the R leading ranks (prune: everything below the threshold, holes) need a word in T too: they all
+// compare below the survivors and their mutual order is irrelevant EXCEPT that equal keys must compare equal and unequal ones in
+// order -- their group is found by ranking them among themselves (keyRankOfRest: see the prune call sites; the weighting sort has
+// R == N and never needs it).  restGroup(T) writes T[e] = (g << 16) | g for every entry e outside the leading ranks, g = any value in
+// [R, N) that is monotone in the key (larger key -> smaller value, equal keys -> equal values).
 // Returns false (nothing to do) for N <= 16 or when no two of the R leading keys are equal.  The caller's barrier separates the
 // steps; S.T is reused as the staging area of the new order once pos[] exists.
-template <int WPP, class KeyAt, class EntryAt, class SetEntry, class Sync>
-__device__ __forceinline__ bool ss_correct_tie_order(KeyAt keyAt, EntryAt entryAt, SetEntry setEntry, const int N, const int R, const StdSortScratch &S,
-                                                     const int tid, Sync block_sync, const bool maybeTied = true) {
+struct SsNoHook { __device__ void operator()() const {} };
+// afterEq: called (by every calling thread) once the eq words are complete and at least one is non-zero, before the replay.
+template <int WPP, class KeyAt, class EntryAt, class SetEntry, class RestGroup, class Sync, class Hook = SsNoHook>
+__device__ __forceinline__ bool ss_correct_tie_order(KeyAt keyAt, EntryAt entryAt, SetEntry setEntry, RestGroup restGroup, const int N, const int R,
+                                                     const StdSortScratch &S, const int tid, Sync block_sync, const bool maybeTied = true,
+                                                     Hook afterEq = Hook()) {
   constexpr int NT = WPP * 64;
+#ifdef SS_TIE_ORDER_OFF   // (tuning aid: what the correction costs -- ties by index, NOT the reference's order)
+  return false;
+#endif
   // maybeTied (uniform over the workgroup): false when the caller's rank sort has already seen that no two keys are equal
   if (N <= SS_THRESHOLD || R < 2 || !maybeTied) return false;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int nWords = (N + 63) >> 6;
   for (int c = wave; c < nWords; c += WPP) {
-    const unsigned long long w = ss_eq_word(keyAt, entryAt, 64 * c, R, lane);
+    const unsigned long long w = ss_eq_word_and_words(keyAt, entryAt, S.T, 64 * c, R, lane);
     if (lane == 0) S.eq[c] = w;
   }
+  if (R < N) restGroup(S.T);                 // (prune: the words of the entries below the survivors)
   block_sync();
   if (__ballot(lane < nWords && S.eq[lane < nWords ? lane : 0] != 0ull) == 0ull) return false;   // (uniform over the workgroup)
-  if (wave == 0) ss_replay_wave(keyAt, S, N, lane);
+  afterEq();
+  if (wave == 0) {
+    // runs that cross a 64-rank boundary: their later members could not see the start in their own chunk
+    for (int c0 = 64; c0 < R; c0 += 64) {
+      const int r = c0 + lane;
+      const unsigned long long wq = S.eq[c0 >> 6];
+      if ((wq & 1ull) == 0ull) continue;                                        // (uniform: the chunk does not begin inside a run)
+      if (r < R && (~wq & (~0ull >> (63 - lane))) == 0ull) {                    // no run start at or below this lane: still in that run
+        const int ent = entryAt(r);
+        S.T[ent] = ((unsigned)ss_run_start(S.eq, r) << 16) | (unsigned)r;
+      }
+    }
+    wave_sync();
+    ss_replay_wave(S, N, lane);
+  }
   block_sync();
-  for (int r = tid; r < R; r += NT) S.T[ss_fixed_rank(S, entryAt, r, R) * S.tStride] = (unsigned short)entryAt(r);
+  unsigned short *stage = reinterpret_cast<unsigned short *>(S.T);     // (T is dead once the positions are known)
+  auto rpAt = [&](int q) -> unsigned short { return S.pos[q * S.posStride]; };
+  for (int r = tid; r < R; r += NT) stage[ss_fixed_rank(S.eq, rpAt, r, R)] = (unsigned short)entryAt(r);
   block_sync();
-  for (int r = tid; r < R; r += NT) setEntry(r, S.T[r * S.tStride]);
+  for (int r = tid; r < R; r += NT) setEntry(r, stage[r]);
   block_sync();
   return true;
 }

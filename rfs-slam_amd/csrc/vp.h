@@ -501,7 +501,7 @@ __device__ __forceinline__ void carve_vp_weight_lds(unsigned char *base, int cap
   s.labR = (int *)p; p += 64 * 4;
   s.labC = (int *)p; p += 64 * 4;
   s.perm = (int *)(base + (size_t)cap * 8 + (size_t)evalCap * 8 * 4 + (size_t)evalCap * 16 * 8 + vp_weight_lds_late_bytes(evalCap, nZ));
-  s.fkeys = nullptr; s.evIdx = nullptr; s.evZ = nullptr;    // (2-D kernel only)
+  s.fkeys = nullptr; s.evIdx = nullptr; s.evZ = nullptr; s.isum = nullptr;    // (2-D kernel only)
 }
 // One wavefront takes particle i through the weighting.  permOut == nullptr: the mixture sorted by weight is written to slab
 // `dst` (the stand-alone kernel; the merge kernel then works on that copy).  permOut != nullptr (the fused step): the sorted
@@ -545,18 +545,18 @@ __device__ void vp_weight_particle(const Buffers &B, const Params &P, int src, i
     s.perm[rank] = m;
   }
   wave_sync();
-  {  // equal weights in the order std::sort leaves them (stdsort_replay.h): index array in the upper halves of s.perm's words, the
+  {  // equal weights in the order std::sort leaves them (stdsort_replay.h): positions in the upper halves of s.perm's words, the
      // rest of the scratch over the evaluation-point tables and the late part, which are written only after this
     StdSortScratch ss;
-    ss.T = reinterpret_cast<unsigned short *>(s.perm) + 1;
-    ss.tStride = 2;
+    ss.pos = reinterpret_cast<unsigned short *>(s.perm) + 1;
+    ss.posStride = 2;
     unsigned char *sbuf = reinterpret_cast<unsigned char *>(s.evX);
     const size_t sbytes = (size_t)evalCap * 8 * 4 + (size_t)evalCap * 16 * 8 + vp_weight_lds_late_bytes(evalCap, nZ);
     if (!ss_carve(ss, sbuf, sbytes, N, false)) {
-      if (N > SS_THRESHOLD && lane == 0) atomicOr(B.err, ERRBIT_CAPACITY);   // (gm_capacity beyond ~1900 with the 3-D model: refused loudly)
+      if (N > SS_THRESHOLD && lane == 0) atomicOr(B.err, ERRBIT_CAPACITY);   // (gm_capacity beyond ~1000 with the 3-D model: refused loudly)
     } else {
       ss_correct_tie_order<1>([&](int e) { return s.keys[e]; }, [&](int r) { return (int)(unsigned short)s.perm[r]; },
-                              [&](int r, unsigned short e) { s.perm[r] = (int)e; }, N, N, ss, lane, [&]() { wave_sync(); });
+                              [&](int r, unsigned short e) { s.perm[r] = (int)e; }, [](unsigned *) {}, N, N, ss, lane, [&]() { wave_sync(); });
     }
   }
   if (permOut) {
@@ -1071,9 +1071,20 @@ __device__ void vp_merge_particle(const Buffers &B, const Params &P, int cur, in
   wave_sync();
   {
     StdSortScratch ss;                                      // positions and bounds of the merge are dead: 4 x st doubles
+    auto key0 = [&](int e) { const double w = sW[e]; return w < 0.0 ? 0.0 : w; };
+    auto is_rest = [&](int e) { const double w = sW[e]; return !((w >= t) && (w >= 0.0)); };
+    auto rest_group = [&](unsigned *T) {
+      for (int e = lane; e < N; e += 64) {
+        if (!is_rest(e)) continue;
+        const double k = key0(e);
+        int g = nSurv;
+        for (int e2 = 0; e2 < N; e2++) g += (is_rest(e2) && key0(e2) > k) ? 1 : 0;
+        T[e] = ((unsigned)g << 16) | (unsigned)g;
+      }
+    };
     if (ss_carve(ss, reinterpret_cast<unsigned char *>(sb), 4 * st * sizeof(double), N, true))
-      ss_correct_tie_order<1>([&](int e) { const double w = sW[e]; return w < 0.0 ? 0.0 : w; }, [&](int r) { return (int)sOrder[r]; },
-                              [&](int r, unsigned short e) { sOrder[r] = e; }, N, nSurv, ss, lane, [&]() { wave_sync(); });
+      ss_correct_tie_order<1>(key0, [&](int r) { return (int)sOrder[r]; }, [&](int r, unsigned short e) { sOrder[r] = e; }, rest_group, N, nSurv, ss, lane,
+                              [&]() { wave_sync(); });
     else if (N > SS_THRESHOLD && lane == 0) atomicOr(B.err, ERRBIT_CAPACITY);
   }
   for (int rank = lane; rank < nSurv; rank += 64) {

@@ -44,6 +44,7 @@ struct WeightLDS {
   int *labR, *labC;            // [64]
   unsigned long long *compRows, *compCols;  // [128]
   double *partLik;             // [128]
+  double *isum;                // [2 evalCap] intensity sums of the evaluation points (before / after), split mode
 };
 
 __host__ __device__ inline size_t weight_lds_bytes_per_wave(int cap, int evalCap, int nZ) {
@@ -58,6 +59,7 @@ __host__ __device__ inline size_t weight_lds_bytes_per_wave(int cap, int evalCap
   b += 64 * 4 * 2;                 // labR labC
   b += 128 * 8 * 2;                // compRows compCols
   b += 128 * 8;                    // partLik
+  b += (size_t)evalCap * 8 * 2;    // isum
   return (b + 15) & ~(size_t)15;
 }
 
@@ -73,6 +75,7 @@ __device__ __forceinline__ void carve_weight_lds(unsigned char *base, int cap, i
   s.compRows = (unsigned long long *)p; p += 128 * 8;
   s.compCols = (unsigned long long *)p; p += 128 * 8;
   s.partLik = (double *)p; p += 128 * 8;
+  s.isum = (double *)p; p += (size_t)evalCap * 8 * 2;
   s.perm = (int *)p; p += (size_t)((cap + 63) & ~63) * 4;
   s.fkeys = (float *)p; p += (size_t)((cap + 63) & ~63) * 4;
   s.evIdx = (int *)p; p += (size_t)evalCap * 4;
@@ -469,6 +472,9 @@ __device__ __forceinline__ bool bucket_rank_sort(KeyAt keyAt, const int N, const
   return true;
 }
 
+#ifndef WEIGHT_W0_SHARE_NUM
+#define WEIGHT_W0_SHARE_NUM 0   // split mode: wave 0 takes the intensity sums over the last NUM / 5 of the mixture's chunks after its own strand.
+#endif                          // Measured twice (r02k at C2a: weighting phase 36 -> 40 us; r04: fused step 121.4 -> 124.4 / 126.5 us with 1 / 2): off
 #ifndef WEIGHT_EVAL_GROUP
 #define WEIGHT_EVAL_GROUP 8  // evaluation points whose sums a wave keeps in registers per pass over the mixture
 #endif
@@ -633,35 +639,55 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
   RFS_CUT(11);
   block_sync();
   // ---- 1b. equal weights in the order std::sort leaves them (stdsort_replay.h): s.perm holds the stable order (ties by index); the
-  // partition phase of libstdc++'s introsort is replayed on an index array in the unused upper halves of s.perm's words, runs of
-  // tied ranks are reordered by position.  Nothing happens for mixtures of <= 16 entries or without equal weights.
+  // partition phase of libstdc++'s introsort is replayed on 32-bit words (group | rank) in the dead float-key array, the ranks'
+  // positions go to the unused upper halves of s.perm's words, runs of tied ranks are reordered by position.  Nothing happens for
+  // mixtures of <= 16 entries or without equal weights (the flag comes out of the rank sort).
+  StdSortScratch ss;
   {
-    StdSortScratch ss;
-    ss.T = reinterpret_cast<unsigned short *>(s.perm) + 1;
-    ss.tStride = 2;
-    ss.pos = reinterpret_cast<unsigned short *>(s.fkeys);                      // [N]        (the float keys are dead)
-    ss.Ll = ss.pos + N;                                                         // [N / 2 + 1]  3 N + 2 <= 4 cap64 bytes
-    ss.Rl = reinterpret_cast<unsigned short *>(s.compRows);                    // [N / 2 + 1] <= 2050 B of compRows | compCols | partLik (3072 B)
-    ss.eq = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(s.compRows) + 2056);   // [<= 32]
-    ss.stack = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(s.compRows) + 2056 + 256);     // [<= 26]
-    ss_correct_tie_order<WPP>([&](int e) { return s.keys[e]; }, [&](int r) { return (int)(unsigned short)s.perm[r]; },
-                              [&](int r, unsigned short e) { s.perm[r] = (int)e; }, N, N, ss, tid, block_sync, tiedKeys);
+    ss.T = reinterpret_cast<unsigned *>(s.fkeys);                              // [N] words   (4 N <= 4 cap64 bytes; the float keys are dead)
+    ss.pos = reinterpret_cast<unsigned short *>(s.perm) + 1;                   // upper half of s.perm[r]
+    ss.posStride = 2;
+    unsigned char *cbuf = reinterpret_cast<unsigned char *>(s.compRows);       // compRows | compCols | partLik: 3072 B, written only later
+    ss.eq = reinterpret_cast<unsigned long long *>(cbuf);                      // [<= 32]
+    ss.stack = reinterpret_cast<unsigned *>(cbuf + 256);                       // [<= 28]
+    const int LC = ss_list_cap(N);
+    if ((size_t)LC * 4 <= 3072 - 256 - 112) {                                  // N <= 1350: the stopper lists fit
+      ss.Ll = reinterpret_cast<unsigned short *>(cbuf + 256 + 112);
+      ss.Rl = ss.Ll + LC;
+    } else {
+      ss.Ll = nullptr; ss.Rl = nullptr;                                        // (lane 0 replays serially)
+    }
   }
-  // sorted mixture -> other slab (or just the permutation, for the fused step's merge phase)
-  if (permOut) {
-    for (int r = tid; r < N; r += NT) permOut[r] = (unsigned short)s.perm[r];
-  } else
-  for (int r = tid; r < N; r += NT) {
-    const int m = s.perm[r];
-    // all gathers first (independent loads in flight together), then the coalesced stores
-    const double v0 = s.keys[m], v1 = qWP[m], v2 = qMX[m], v3 = qMY[m], v4 = qSXX[m], v5 = qSXY[m], v6 = qSYY[m];
-    plane(dl, B.cap, i, PL_W)[r] = v0;
-    plane(dl, B.cap, i, PL_WP)[r] = v1;
-    plane(dl, B.cap, i, PL_MX)[r] = v2;
-    plane(dl, B.cap, i, PL_MY)[r] = v3;
-    plane(dl, B.cap, i, PL_SXX)[r] = v4;
-    plane(dl, B.cap, i, PL_SXY)[r] = v5;
-    plane(dl, B.cap, i, PL_SYY)[r] = v6;
+  auto keyOf = [&](int e) { return s.keys[e]; };
+  auto entryOf = [&](int r) { return (int)(unsigned short)s.perm[r]; };
+  auto setEntryOf = [&](int r, unsigned short e) { s.perm[r] = (int)e; };
+  // The correction is a chain of dependent LDS round trips that ONE wave walks (measured at C2b, where every mixture holds a run
+  // of tied birth weights: +10 us per step when the whole workgroup waits for it).  In the fused step it therefore runs on wave 0
+  // alone, BESIDE the other waves' intensity strand, which is the longer one by more than that: wave 0 first looks whether a tie
+  // can touch the evaluation points at all (an eq bit among the ranks whose weight reaches importanceWeightingEvalPointGuassianWeight);
+  // if not -- the ordinary case: ties sit at the birth weight -- it picks the evaluation points from the stable order, releases
+  // the other waves, and corrects the order afterwards; otherwise the correction comes first.  Same results either way.
+  constexpr bool SPLITTABLE = WPP > 1 && WEIGHT_W0_SHARE_NUM == 0;
+  const bool splitEarly = SPLITTABLE && (size_t)B.cap * 4 >= 128 * sizeof(double);
+  const bool overlap = splitEarly && permOut != nullptr && tiedKeys && N > SS_THRESHOLD;
+  if (!overlap) {
+    ss_correct_tie_order<WPP>(keyOf, entryOf, setEntryOf, [](unsigned *) {}, N, N, ss, tid, block_sync, tiedKeys);
+    // sorted mixture -> other slab (or just the permutation, for the fused step's merge phase)
+    if (permOut) {
+      for (int r = tid; r < N; r += NT) permOut[r] = (unsigned short)s.perm[r];
+    } else
+    for (int r = tid; r < N; r += NT) {
+      const int m = s.perm[r];
+      // all gathers first (independent loads in flight together), then the coalesced stores
+      const double v0 = s.keys[m], v1 = qWP[m], v2 = qMX[m], v3 = qMY[m], v4 = qSXX[m], v5 = qSXY[m], v6 = qSYY[m];
+      plane(dl, B.cap, i, PL_W)[r] = v0;
+      plane(dl, B.cap, i, PL_WP)[r] = v1;
+      plane(dl, B.cap, i, PL_MX)[r] = v2;
+      plane(dl, B.cap, i, PL_MY)[r] = v3;
+      plane(dl, B.cap, i, PL_SXX)[r] = v4;
+      plane(dl, B.cap, i, PL_SXY)[r] = v5;
+      plane(dl, B.cap, i, PL_SYY)[r] = v6;
+    }
   }
   DBG_TB(16, 8);
   RFS_CUT(12);
@@ -671,7 +697,7 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
   load_pose(B, P, i, pr);
 
   // ---- 2. evaluation points: first <= nEvalPoints sorted entries with w >= minW and Pd > 0 (:747-762) ----  (wave 0)
-  if (wave == 0) {
+  auto select_eval_points = [&]() {
     int nE = 0;
     bool evalOverflow = false;
     const int limit = nEvalPoints < RFSGPU_MAX_EVAL ? nEvalPoints : RFSGPU_MAX_EVAL;
@@ -681,7 +707,7 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
       bool below = true, cand = false;
       double mx = 0, my = 0, pd = 0;
       if (r < N) {
-        const int m = s.perm[r];
+        const int m = (int)(unsigned short)s.perm[r];          // (the upper halves may hold the correction's scratch)
         below = s.keys[m] < P.evalMinW;
         mx = qMX[m];
         my = qMY[m];
@@ -712,16 +738,41 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
     if (nE == limit && nEvalPoints > limit) evalOverflow = true;
     if (evalOverflow && lane == 0) atomicOr(B.err, ERRBIT_EVALPTS);
     if (lane == 0) sScrI[0] = nE;
-  }
+  };
   // ---- 3a. weight sums (:765-775) ----  (the last wave, alongside step 2)
-  if (wave == WPP - 1) {
+  auto weight_sums = [&]() {
     double sumPrev = 0.0, sumCur = 0.0;
     for (int m = lane; m < N; m += 64) { sumPrev += qWP[m]; sumCur += s.keys[m]; }
     sumPrev = wave_sum_dpp(sumPrev);
     sumCur = wave_sum_dpp(sumCur);
     if (lane == 0) { sScr[0] = sumPrev; sScr[1] = sumCur; }
+  };
+  if (!overlap) {
+    if (wave == 0) select_eval_points();
+    if (wave == WPP - 1) weight_sums();
+    block_sync();
+  } else if (wave == 0) {
+    // ranks whose weight reaches the evaluation points' threshold: the leading rCut ranks of the sorted order
+    int rCut = 0;
+    for (int m0 = 0; m0 < N; m0 += 64) rCut += __popcll(__ballot(m0 + lane < N && !(s.keys[(m0 + lane < N) ? m0 + lane : 0] < P.evalMinW)));
+    bool released = false;
+    auto wsync = [&]() { wave_sync(); };
+    auto after_eq = [&]() {             // (the eq words are complete here)
+      bool touch = false;
+      for (int c = 0; 64 * c < rCut; c++) {
+        unsigned long long w = ss.eq[c];
+        if (64 * c + 63 >= rCut) w &= (rCut - 64 * c >= 64) ? ~0ull : ((1ull << (rCut - 64 * c)) - 1ull);   // ranks < rCut
+        touch |= w != 0ull;
+      }
+      if (!touch) { select_eval_points(); block_sync(); released = true; }
+    };
+    ss_correct_tie_order<1>(keyOf, entryOf, setEntryOf, [](unsigned *) {}, N, N, ss, lane, wsync, true, after_eq);
+    if (!released) { select_eval_points(); block_sync(); }
+    for (int r = lane; r < N; r += 64) permOut[r] = (unsigned short)s.perm[r];
+  } else {
+    if (wave == WPP - 1) weight_sums();
+    block_sync();
   }
-  block_sync();
   const int nE = sScrI[0];
 
   DBG_TB(16, 2);
@@ -734,15 +785,17 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
   // rank-sort permutation's storage, free since step 2).
   constexpr int EG = WEIGHT_EVAL_GROUP;
   const bool split = WPP > 1 && (size_t)B.cap * 4 >= 128 * sizeof(double);  // (the sort's scratch, perm + fkeys = 8 B per entry, must hold 4 x 64 doubles)
-  double *sumB = reinterpret_cast<double *>(split ? (void *)s.perm : (void *)s.compRows), *sumA = sumB + 64;  // [64] each
-  double *sumB0 = sumA + 64, *sumA0 = sumB0 + 64;   // split mode: wave 0's partial sums over ITS share of the mixture
+  // where the sums go: the permutation's storage (4 x 64 doubles, free since step 2) -- except while the tie-order correction is still
+  // using it on wave 0 (the overlapped form above): then their own 2 evalCap doubles
+  // (only then: with the sums always in their own region the fused step at configs[1] was 0.8 us slower, r04 A/B)
+  const bool ownSums = split && WEIGHT_W0_SHARE_NUM == 0 && overlap;
+  const int sumStride = ownSums ? evalCap : 64;
+  double *sumB = ownSums ? s.isum : reinterpret_cast<double *>(split ? (void *)s.perm : (void *)s.compRows), *sumA = sumB + sumStride;
+  double *sumB0 = sumA + 64, *sumA0 = sumB0 + 64;   // (sharing knob only) wave 0's partial sums over ITS share of the mixture
   const int iw = split ? wave - 1 : wave, nIw = split ? WPP - 1 : WPP;  // this wave's share of the intensity groups
   // In split mode wave 0 can also take the intensity sums over the last WEIGHT_W0_SHARE_NUM / 5 of the mixture's 64-entry chunks once
   // it is through with its own strand; the two partial sums of an evaluation point are then added in a fixed order.
   const int nChunksI = (N + 63) >> 6;
-#ifndef WEIGHT_W0_SHARE_NUM
-#define WEIGHT_W0_SHARE_NUM 0   // measured at C2a (r02k): with a 2/5 share the weighting phase went from 36 to 40 us -- wave 0's strand is
-#endif                          // not the shorter one any more once the intensity pass has lost its second Gaussian prep; kept as a knob
   const int w0Chunks = (split && nChunksI >= 3) ? (WEIGHT_W0_SHARE_NUM * nChunksI) / 5 : 0;
   const int mSplit = (split && w0Chunks > 0) ? 64 * (nChunksI - w0Chunks) : N;   // waves >= 1: entries [0, mSplit); wave 0: [mSplit, N)
   // groups e0 = EG * first, step EG * stride; entries [mLo, mHi); results of evaluation point e to outB[e] / outA[e]
