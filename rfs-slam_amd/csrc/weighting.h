@@ -374,6 +374,9 @@ __host__ __device__ inline int rank_sort_log_buckets(int cap) { return cap >= 34
 #ifndef RANK_SORT_MAX_BUCKET
 #define RANK_SORT_MAX_BUCKET 32
 #endif
+// (Measured and dropped, r04 -- profiles/r04h_ab_rank_sort_bucket_order.txt: the last loop taking the entries in BUCKET order, as the
+//  merge's candidate scan takes them in grid order: fused step 121.7 -> 123.2 us at configs[1] -- the walks are short here, and the
+//  extra list read and the scattered write of the permutation cost more than the lanes' better agreement saves.)
 // keyAt(m): key of entry m < N (LDS reads; ties rank by m); hist: (NB / 2 + 4) words of LDS scratch for NB = 1 << logNB buckets; order: [N]
 // u16 of LDS scratch; xscr: 2 WPP + 1 ints of LDS scratch; the ranks of entries tid + NT * k go to rl[k] (N <= NS * NT).
 // All threads of the block call it; the caller synchronises before it reuses the scratch.
