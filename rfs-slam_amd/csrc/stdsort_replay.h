@@ -18,8 +18,10 @@
 //     arrangement the loop left.
 // Hence   std::sort(a) == stable_sort(arrangement after the partition phase),   and equal keys end up in the order of their
 // positions after the partition phase.  The device already has the stable order of the ORIGINAL arrangement (its rank sorts
-// break ties by index); what this header adds is the partition phase replayed on a u16 index array T (T[p] = entry at
-// position p; comparisons through the entries' keys) and a fix-up that reorders every run of tied ranks by position in T.
+// break ties by index); what this header adds is the partition phase replayed on an array T of 32-bit words, one per position
+// (word = (group << 16) | stable rank; group = the stable rank of the first member of the entry's run of equal keys, i.e. an
+// order- and equality-preserving 16-bit image of the key, so a comparison is one LDS read), and a fix-up that reorders every run
+// of tied ranks by position in T.
 //   * Only comparisons are replayed: no key is moved, no arithmetic happens, the result is exact by construction and is checked
 //     against the real std::sort on the host (tests/test_stdsort_replay.py, the serial form below compiled with g++) and against
 //     the oracle's std::sort on the device (every GPU parity test now runs the oracle in its reference mode).
@@ -31,7 +33,8 @@
 // ballots -- L[k] = k-th position from the left whose key is <= the pivot's, R[k] = k-th from the right whose key is >= it --
 // the scan swaps (L[k], R[k]) exactly while L[k] < R[k], K swaps in all, all disjoint, and returns
 // cut = min(L[K], R[K-1]) (L[0] when K = 0); see the derivation at ss_partition_lists, which the host test runs against the
-// two-pointer loop.
+// two-pointer loop.  What the correction costs is the chain of dependent LDS round trips that one wave walks (3 + one per 256
+// positions per partition step); in the fused 2-D step it runs on wave 0 beside the other waves' intensity strand (weighting.h).
 #pragma once
 #if defined(__HIPCC__)
 #define SS_HD __host__ __device__

@@ -18,7 +18,7 @@ run_pmc() {    # name, counter, command...
   rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/${name}_pmc_$ctr -o pmc -- "$@" > $OUT/${name}_pmc_$ctr.log 2>&1
 }
 python bench.py --workload c2a > $OUT/c2a_bench.log 2>&1
-python bench.py --workload c3 --no-cpu-baseline > $OUT/c3_bench.log 2>&1
+python bench.py --workload c3 > $OUT/c3_bench.log 2>&1
 python bench.py --workload c4 > $OUT/c4_bench.log 2>&1
 python bench.py --workload c5 --steps 30 --warmup 3 > $OUT/c5_bench.log 2>&1
 python bench.py --workload c2b --no-cpu-baseline --no-pmc > $OUT/c2b_bench.log 2>&1
