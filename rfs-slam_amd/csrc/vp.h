@@ -1143,7 +1143,17 @@ __global__ __launch_bounds__(WPB * 64) void vp_step_fused_kernel(Buffers B, Para
   unsigned char *wmem = smem_raw + vp_shared_lds_bytes(nZ, B.nScan) + (size_t)wave * per;
   unsigned char *sPdIdx = wmem + per - (((size_t)B.cap + 15) & ~(size_t)15);
   unsigned short *sPerm = reinterpret_cast<unsigned short *>(sPdIdx - (((size_t)B.cap * 2 + 15) & ~(size_t)15));
+#ifdef RFS_PROFILE
+  long long *fd = B.dbg ? B.dbg + 64 + 4 * (size_t)B.N + 4 * (size_t)i : nullptr;   // per particle: start | after update | after weighting | end (100 MHz ticks)
+  if (fd && lane == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 4), xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20);
+    fd[0] = (long long)((wall_clock64() & 0xfffffffffffull) | ((unsigned long long)(hw & 0xffffu) << 44) | ((unsigned long long)(xcc & 0xfu) << 60));
+  }
+#endif
   const int nBefore = vp_update_map_particle(B, P, cur, nZ, i, lane, sZ, sScan, wmem, sPdIdx);
+#ifdef RFS_PROFILE
+  if (fd && lane == 0) fd[1] = (long long)wall_clock64();
+#endif
   // (one wave: the slab rows it wrote are its own; order the global writes before the reads of the next phase)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   wave_sync();
@@ -1154,6 +1164,12 @@ __global__ __launch_bounds__(WPB * 64) void vp_step_fused_kernel(Buffers B, Para
     wave_sync();
     perm = sPerm;
   }
+#ifdef RFS_PROFILE
+  if (fd && lane == 0) fd[2] = (long long)wall_clock64();
+#endif
   vp_merge_particle<true>(B, P, cur, cur ^ 1, i, lane, wmem, perm);
+#ifdef RFS_PROFILE
+  if (fd && lane == 0) fd[3] = (long long)wall_clock64();
+#endif
 }
 

@@ -268,3 +268,33 @@ def test_device_resampling_cycles_match_oracle(pkg, ob, sc, mode):
             _compare_all(sc, dev, orc, n)
     assert max_level >= 2          # the level-ordered walk was exercised beyond "copy from a survivor"
     assert np.any(dev.get_particle_ids()[0] != np.arange(n))
+
+
+@pytest.mark.gpu
+def test_external_mode_refuses_an_unacknowledged_birth_predict(pkg, sc):
+    """in RFSGPU_INHERIT_EXTERNAL the HOST owns the reference's slot-ordered copy of the per-slot birth lists
+    (include/RBPHDFilter.hpp:1005-1011).  A birth predict right after a resampling that reaches the engine without the host having
+    touched the lists (rfsgpu_get / set_unused_masks, rfsgpu_predict_map_level, or the mode set again as an acknowledgement) would
+    silently skip the inheritance: it is refused; after the acknowledgement it runs; the Python multi-GPU wrapper gives the handle
+    back in the mode it found."""
+    n = 12
+    scen = sc.make_scenario(n, 30, 8, seed=5)
+    f = pkg.RBPHDFilter(n, gm_capacity=128)
+    sc.load_scenario(f, scen)
+    f.update(scen["Z"])
+    f.set_birth_inheritance(pkg.capi.INHERIT_EXTERNAL)
+    plan = np.arange(n, dtype=np.int32)
+    plan[3] = 7
+    f.resample_apply(plan)
+    with pytest.raises(pkg.capi.EngineError) as e:
+        f.predict_map(True)
+    assert "RFSGPU_INHERIT_EXTERNAL" in str(e.value)
+    f.predict_map(False)                                   # (no births: nothing to inherit, allowed)
+    f.get_unused_masks()                                   # the host has looked at the lists
+    f.predict_map(True)
+    f.set_birth_inheritance(pkg.capi.INHERIT_REFERENCE)
+    sh = pkg.sharded.ShardedRBPHDFilter(f)
+    assert f.get_birth_inheritance() == pkg.capi.INHERIT_EXTERNAL
+    sh.close()
+    assert f.get_birth_inheritance() == pkg.capi.INHERIT_REFERENCE
+    f.close()
