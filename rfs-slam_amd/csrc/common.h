@@ -214,6 +214,18 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) { return ~wave_max_u32(~v); }
+// max of a float over the wave with DPP moves, result in every lane (maxNum: a NaN loses against a number)
+__device__ __forceinline__ float wave_max_f32_dpp(float v) {
+#define RFS_DPP_F32(CTRL, MASK) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, MASK, 0xf, false))
+  v = __builtin_fmaxf(v, RFS_DPP_F32(0xb1, 0xf));
+  v = __builtin_fmaxf(v, RFS_DPP_F32(0x4e, 0xf));
+  v = __builtin_fmaxf(v, RFS_DPP_F32(0x114, 0xf));
+  v = __builtin_fmaxf(v, RFS_DPP_F32(0x118, 0xf));
+  v = __builtin_fmaxf(v, RFS_DPP_F32(0x142, 0xa));
+  v = __builtin_fmaxf(v, RFS_DPP_F32(0x143, 0xc));
+#undef RFS_DPP_F32
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 
 // exclusive prefix sum over the wave (small ints): Hillis-Steele inside each 16-lane row with row_shr DPP moves, then the row
 // totals across rows with row_bcast:15 / :31 -- six VALU instructions, no LDS permute and no lane-address registers (the

@@ -32,6 +32,10 @@ struct MurtyQueue {
 };
 #define MURTY_MAXN 64
 
+// Sparse intensity sums (phd_weight_particle, step 3b): per evaluation point a list of <= WEIGHT_SPARSE_SEG Gaussians (u16) + its own
+// term (f64) + four 32-bit words (x, y, threshold, count); 16 evaluation points in flight per workgroup (one wave x 16 or two waves x 8).
+#define WEIGHT_SPARSE_SEG 64
+#define WEIGHT_SPARSE_LDS_BYTES (16 * (WEIGHT_SPARSE_SEG * 2 + 8 + 4 * 4))
 struct WeightLDS {
   double *keys;                // [cap]
   int *perm;                   // [cap rounded up to 64] (doubles as the sorted-chunk buffer of the rank sort)
@@ -45,6 +49,7 @@ struct WeightLDS {
   unsigned long long *compRows, *compCols;  // [128]
   double *partLik;             // [128]
   double *isum;                // [2 evalCap] intensity sums of the evaluation points (before / after), split mode
+  unsigned char *sparse;       // [WEIGHT_SPARSE_LDS_BYTES] pair lists + fp32 evaluation points / thresholds of the sparse intensity sums
 };
 
 __host__ __device__ inline size_t weight_lds_bytes_per_wave(int cap, int evalCap, int nZ) {
@@ -60,6 +65,7 @@ __host__ __device__ inline size_t weight_lds_bytes_per_wave(int cap, int evalCap
   b += 128 * 8 * 2;                // compRows compCols
   b += 128 * 8;                    // partLik
   b += (size_t)evalCap * 8 * 2;    // isum
+  b += WEIGHT_SPARSE_LDS_BYTES;    // sparse
   return (b + 15) & ~(size_t)15;
 }
 
@@ -76,6 +82,7 @@ __device__ __forceinline__ void carve_weight_lds(unsigned char *base, int cap, i
   s.compCols = (unsigned long long *)p; p += 128 * 8;
   s.partLik = (double *)p; p += 128 * 8;
   s.isum = (double *)p; p += (size_t)evalCap * 8 * 2;
+  s.sparse = p; p += WEIGHT_SPARSE_LDS_BYTES;
   s.perm = (int *)p; p += (size_t)((cap + 63) & ~63) * 4;
   s.fkeys = (float *)p; p += (size_t)((cap + 63) & ~63) * 4;
   s.evIdx = (int *)p; p += (size_t)evalCap * 4;
@@ -478,6 +485,18 @@ __device__ __forceinline__ bool bucket_rank_sort(KeyAt keyAt, const int N, const
 #ifndef WEIGHT_W0_SHARE_NUM
 #define WEIGHT_W0_SHARE_NUM 0   // split mode: wave 0 takes the intensity sums over the last NUM / 5 of the mixture's chunks after its own strand.
 #endif                          // Measured twice (r02k at C2a: weighting phase 36 -> 40 us; r04: fused step 121.4 -> 124.4 / 126.5 us with 1 / 2): off
+#ifndef WEIGHT_SPARSE_INTENSITY
+#define WEIGHT_SPARSE_INTENSITY 1   // intensity sums over the pairs within reach only (phd_weight_particle, step 3b); 0: the dense loop
+#endif
+#ifndef WEIGHT_SPARSE_MIN_N
+#define WEIGHT_SPARSE_MIN_N 128     // mixtures up to two 64-entry chunks: the dense loop is as cheap
+#endif
+#ifndef WEIGHT_SPARSE_GROUP
+#define WEIGHT_SPARSE_GROUP 16      // evaluation points per sweep over the mixture (one or two waves per particle; 8 with three)
+#endif
+#define WEIGHT_SPARSE_BITS 66.0f    // a pair is listed when one of its terms can be within 2^-66 of its sum (fp32 estimate of the log2 term, +-0.5)
+#define WEIGHT_SPARSE_PRIOR_BITS 24.0f               // G: the sum before the update is taken to be >= 2^-G x the evaluation point's own term after it (checked)
+#define WEIGHT_SPARSE_PRIOR_SCALE 5.9604644775390625e-08   // 2^-G
 #ifndef WEIGHT_EVAL_GROUP
 #define WEIGHT_EVAL_GROUP 8  // evaluation points whose sums a wave keeps in registers per pass over the mixture
 #endif
@@ -709,8 +728,10 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
       const int r = c0 + lane;
       bool below = true, cand = false;
       double mx = 0, my = 0, pd = 0;
+      int mOf = 0;
       if (r < N) {
         const int m = (int)(unsigned short)s.perm[r];          // (the upper halves may hold the correction's scratch)
+        mOf = m;
         below = s.keys[m] < P.evalMinW;
         mx = qMX[m];
         my = qMY[m];
@@ -731,7 +752,7 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
         s.evY[e] = my;
         s.evPd[e] = pd;
         s.evLog1mPd[e] = log(1 - pd);
-        s.evIdx[e] = r;
+        s.evIdx[e] = r | (mOf << 16);    // sorted position | the Gaussian's index
       }
       int got = __popcll(candMask);
       if (got >= need) { got = need; done = true; }
@@ -840,10 +861,204 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
       }
     }
   };
+  // ---- the same sums over the pairs that can reach them (WEIGHT_SPARSE_INTENSITY) ----
+  // Of the nE x N (evaluation point, Gaussian) pairs only a few per cent contribute to a sum at all: a Gaussian ten of its own standard
+  // deviations away adds less than 2^-64 of the sum's largest term, i.e. nothing that survives the fp64 addition.  So the dense fp64 loop
+  // above (distance, exp, two multiply-adds for every pair) is replaced by
+  //   sweep   packed fp32 over all pairs: log2 of the pair's terms, v = c_m - md2 log2(e) / 2 with c_m = log2(weight / factor) after (w) and
+  //           before (w_prev) the update.  An evaluation point IS the mean of a Gaussian of the mixture, so its sum after the update is at
+  //           least that Gaussian's own term, ownA_e (md2 = 0); the sum before the update is ASSUMED to be at least 2^-G ownA_e (the parent
+  //           landmark of an updated copy sits inside the innovation gate of it: typically 2^-12) and the assumption is checked afterwards.  A
+  //           pair is LISTED when vA > log2(ownA_e) - BITS or vB + G > log2(ownA_e) - BITS (BITS = 64 + 2 for the fp32 rounding of v, bounded
+  //           below) -- ballot + mbcnt compaction into a per-evaluation-point list in LDS;
+  //   exact   the listed pairs in fp64 with the dense loop's own formulas (inv2, pdf_factor2, rfs_exp), one evaluation point per 16-lane
+  //           row, summed per lane in list order (Gaussian index ascending) and over the row by a fixed DPP tree;
+  //   check   the sum before the update over the listed pairs (a lower bound of the full sum) reaches 2^-G ownA_e -- otherwise, or when a
+  //           list overflows, that evaluation point is summed by the dense loop.
+  // What is dropped: terms below 2^-64 of their sum, at most N of them -- together below 2^-55 of the sum (N <= 512), half an ulp; the
+  // sums differ from the dense loop's by the order of the additions only.  A Gaussian whose fp32 image cannot be trusted (covariance not
+  // positive definite or correlated beyond 0.9995, non-finite or negative weights, a standard deviation so small against the coordinates
+  // that the fp32 difference could move v by half a bit) is listed for every evaluation point.  The result of an evaluation point does not
+  // depend on the group it is in or the wave that takes it (1, 2 or 3 waves per particle give the same bits).
+  constexpr int SG = (WPP >= 3) ? 8 : WEIGHT_SPARSE_GROUP;    // evaluation points in flight per wave
+  constexpr int SEG = WEIGHT_SPARSE_SEG;
+  auto intensity_dense_one = [&](const int e, double *outB, double *outA) {   // one evaluation point, lanes over the mixture
+    double aB = 0.0, aA = 0.0;
+    const double gx = s.evX[e], gy = s.evY[e];
+    for (int m = lane; m < N; m += 64) {
+      const double w = s.keys[m], wp = qWP[m], mx = qMX[m], my = qMY[m];
+      double i00, i01, i10, i11, det;
+      inv2(qSXX[m], qSXY[m], qSXY[m], qSYY[m], i00, i01, i10, i11, det);
+      const double rfac = 1.0 / pdf_factor2(det);
+      const double d0 = gx - mx, d1 = gy - my;
+      const double t0 = d0 * i00 + d1 * i01, t1 = d0 * i01 + d1 * i11;
+      const double md2 = t0 * d0 + t1 * d1;
+      double lik = (md2 > 1500.0) ? 0.0 : rfs_exp(-0.5 * md2) * rfac;
+      lik = (lik != lik) ? 0.0 : lik;
+      aB += wp * lik;
+      aA += w * lik;
+    }
+    aB = wave_sum_dpp(aB);
+    aA = wave_sum_dpp(aA);
+    if (lane == 0) { outB[e] = aB; outA[e] = aA; }
+  };
+  auto intensity_sparse = [&](const int first, const int stride, double *outB, double *outA, unsigned char *scr) {
+    unsigned short *list = reinterpret_cast<unsigned short *>(scr);                    // [SG][SEG]
+    double *ownAd = reinterpret_cast<double *>(scr + SG * SEG * 2);                     // [SG] 2^-G x the evaluation point's own term
+    float *gxf = reinterpret_cast<float *>(ownAd + SG), *gyf = gxf + SG;                 // evaluation points relative to the pose
+    float *nthA = gyf + SG;                                                            // BITS - log2(own term)
+    int *cntL = reinterpret_cast<int *>(nthA + SG);
+    const float ninf = -__builtin_huge_valf();
+    for (int e0 = SG * first; e0 < nE; e0 += SG * stride) {
+      const int nG = (nE - e0 < SG) ? nE - e0 : SG;
+      wave_sync();                                   // (the previous group's lists have been read)
+#ifdef RFS_PROFILE
+      if (B.dbg && i == 7 && lane == 0) B.dbg[9] = (long long)__builtin_readcyclecounter();
+#endif
+      float gs = 0.f;
+      if (lane < SG) {
+        const int e = e0 + ((lane < nG) ? lane : 0);
+        const float x = (float)(s.evX[e] - pr.x), y = (float)(s.evY[e] - pr.y);
+        gxf[lane] = x; gyf[lane] = y;
+        gs = __builtin_fmaxf(__builtin_fabsf(x), __builtin_fabsf(y));
+        const int me = (int)((unsigned)s.evIdx[e] >> 16);                        // the Gaussian the point is the mean of
+        const double sxx = qSXX[me], sxy = qSXY[me], syy = qSYY[me];
+        const double own = s.keys[me] / pdf_factor2(sxx * syy - sxy * sxy);
+        const bool ok = (own > 0.0) && (own < 1.0e300);                         // (a NaN / degenerate own term: list everything -> dense)
+        int ex;
+        const float mant = (float)__builtin_frexp(own, &ex);
+        nthA[lane] = ok ? WEIGHT_SPARSE_BITS - (__builtin_amdgcn_logf(mant) + (float)ex) : 3.0e38f;
+        ownAd[lane] = ok ? own * WEIGHT_SPARSE_PRIOR_SCALE : __builtin_huge_val();
+      }
+      const float gScale = 2.f * wave_max_f32(gs);   // (NaN coordinates: every pair of that point drops out, as its dense terms are 0)
+      wave_sync();
+      const f2_t *gx2 = reinterpret_cast<const f2_t *>(gxf), *gy2 = reinterpret_cast<const f2_t *>(gyf), *na2 = reinterpret_cast<const f2_t *>(nthA);
+      int cnt[SG];
+#pragma unroll
+      for (int t = 0; t < SG; t++) cnt[t] = 0;
+      bool anyB = false;
+      int zero = 0;
+      asm volatile("" : "+v"(zero));                  // one vector base per array, the pairs at immediate offsets
+      for (int m0 = 0; m0 < N; m0 += 64) {
+        // fp32 image of the lane's Gaussian: position relative to the pose, J = -log2(e)/2 Sigma^-1, c = log2(weight / factor)
+        const int m = m0 + lane;
+        const bool act = m < N;
+        const int mm = act ? m : 0;
+        const double w = s.keys[mm], wp = qWP[mm];
+        const float a = (float)qSXX[mm], b = (float)qSXY[mm], c = (float)qSYY[mm];
+        float fx = (float)(qMX[mm] - pr.x), fy = (float)(qMY[mm] - pr.y);
+        const float ac = a * c;
+        const float det = __builtin_fmaf(-b, b, ac);
+        const float rdet = __builtin_amdgcn_rcpf(det);
+        const float kr = -0.72134752044448170368f * rdet;
+        float j00 = c * kr, j01 = -b * kr, j11 = a * kr;
+        const float base = -2.65149612947231879804f - 0.5f * __builtin_amdgcn_logf(det);   // -log2(2 pi) - log2(det) / 2
+        int exA, exB;                                  // log2 of a double of any magnitude (weights far below fp32's range keep their order)
+        const float mantA = (float)__builtin_frexp(w, &exA), mantB = (float)__builtin_frexp(wp, &exB);
+        const float cA = __builtin_amdgcn_logf(mantA) + (float)exA + base;
+        const float cB = __builtin_amdgcn_logf(mantB) + (float)exB + base + WEIGHT_SPARSE_PRIOR_BITS;
+        float cS = __builtin_fmaxf(cA, cB);
+        // |dv| <= 2 |K| sqrt(md2 tr(Sigma^-1)) dd with dd <= 2^-24 S (S >= |g| + |m| per coordinate) and md2 <= 136 at the threshold:
+        // tr(Sigma^-1) S^2 < 6e10 keeps it below a quarter of a bit; det > 1e-3 a c bounds the cancellation in det (relative 2^-13: 0.01 bit)
+        const float S = gScale + __builtin_fabsf(fx) + __builtin_fabsf(fy);
+        const bool sane = (a > 0.f) & (c > 0.f) & (det > 1e-3f * ac) & ((a + c) * rdet * S * S < 6.0e10f) & (w >= 0.0) & (wp >= 0.0) & (S < 1.0e6f);
+        if (!sane) { j00 = 0.f; j01 = 0.f; j11 = 0.f; fx = 0.f; fy = 0.f; cS = 3.0e38f; }   // listed for every (finite) evaluation point
+        if (!act) cS = ninf;
+        anyB |= __ballot(act && !(wp == 0.0)) != 0ull;
+        const f2_t vfx = {fx, fx}, vfy = {fy, fy}, v00 = {j00, j00}, v01 = {j01, j01}, v11 = {j11, j11}, vc = {cS, cS};
+        bool sg[SG];
+#pragma unroll
+        for (int q = 0; q < SG / 2; q++) {
+          const f2_t d0 = gx2[q + zero] - vfx, d1 = gy2[q + zero] - vfy;    // (uniform addresses: LDS broadcast reads)
+          const f2_t t0 = d0 * v00 + d1 * v01, t1 = d0 * v01 + d1 * v11;
+          const f2_t h = t0 * d0 + t1 * d1;
+          const f2_t u = (h + vc) + na2[q + zero];
+          sg[2 * q] = u.x > 0.f;
+          sg[2 * q + 1] = u.y > 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < SG; t++) {
+          const unsigned long long mk = __ballot(sg[t]);
+          const int c0 = cnt[t], pc = __popcll(mk);
+          if (c0 + pc <= SEG) {                      // (wave-uniform)
+            const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+            if (sg[t]) list[t * SEG + c0 + pos] = (unsigned short)m;
+          }
+          cnt[t] = c0 + pc;
+        }
+      }
+      unsigned over = 0;                              // evaluation points whose list overflowed: dense
+#ifdef RFS_PROFILE
+      if (B.dbg && i == 7 && lane == 0) {
+        B.dbg[10] = (long long)__builtin_readcyclecounter();
+        long long tot = 0, trips = 0;
+        for (int t = 0; t < SG; t++) tot += cnt[t];
+        for (int q4 = 0; q4 < SG / 4; q4++) { int mx4 = 0; for (int r = 0; r < 4; r++) mx4 = cnt[4 * q4 + r] > mx4 ? cnt[4 * q4 + r] : mx4; trips += (mx4 + 15) / 16; }
+        B.dbg[12] = tot; B.dbg[13] = trips; B.dbg[15] = nE;
+      }
+#endif
+#pragma unroll
+      for (int t = 0; t < SG; t++) {
+        if (lane == t) cntL[t] = (cnt[t] > SEG) ? 0 : cnt[t];
+        if (cnt[t] > SEG && t < nG) over |= 1u << t;
+      }
+      wave_sync();
+      // ---- exact terms of the listed pairs: one evaluation point per 16-lane row ----
+#pragma unroll 1
+      for (int eq = 0; eq < SG / 4; eq++) {
+        if (4 * eq >= nG) break;
+        const int eL = eq * 4 + (lane >> 4);
+        const int c = cntL[eL];
+        const int cMax = (int)wave_max_u32((unsigned)c);
+        const int e = e0 + ((eL < nG) ? eL : 0);
+        const double gx = s.evX[e], gy = s.evY[e];
+        double aB = 0.0, aA = 0.0;
+        for (int j0 = 0; j0 < cMax; j0 += 16) {
+          const int slot = j0 + (lane & 15);
+          if (slot < c) {
+            const int m = (int)list[eL * SEG + slot];
+            const double w = s.keys[m], wp = qWP[m], mx = qMX[m], my = qMY[m];
+            double i00, i01, i10, i11, det;
+            inv2(qSXX[m], qSXY[m], qSXY[m], qSYY[m], i00, i01, i10, i11, det);
+            const double rfac = 1.0 / pdf_factor2(det);
+            const double d0 = gx - mx, d1 = gy - my;
+            const double t0 = d0 * i00 + d1 * i01, t1 = d0 * i01 + d1 * i11;
+            const double md2 = t0 * d0 + t1 * d1;
+            double lik = (md2 > 1500.0) ? 0.0 : rfs_exp(-0.5 * md2) * rfac;
+            lik = (lik != lik) ? 0.0 : lik;
+            aB += wp * lik;
+            aA += w * lik;
+          }
+        }
+        aB += dpp_f64<0xb1, 0xf>(aB); aA += dpp_f64<0xb1, 0xf>(aA);     // quad_perm [1,0,3,2]
+        aB += dpp_f64<0x4e, 0xf>(aB); aA += dpp_f64<0x4e, 0xf>(aA);     // quad_perm [2,3,0,1]
+        aB += dpp_f64<0x114, 0xf>(aB); aA += dpp_f64<0x114, 0xf>(aA);   // row_shr:4
+        aB += dpp_f64<0x118, 0xf>(aB); aA += dpp_f64<0x118, 0xf>(aA);   // row_shr:8 -> lane 15 of the row
+        const bool lead = (lane & 15) == 15 && eL < nG;
+        if (lead) { outB[e0 + eL] = aB; outA[e0 + eL] = aA; }
+        // the assumption behind the lists: the sum before the update reaches 2^-G of the point's own term (the listed part of it already does)
+        const unsigned long long bad = __ballot(lead && anyB && !(aB >= ownAd[eL]));
+#pragma unroll
+        for (int r = 0; r < 4; r++) over |= ((bad >> (16 * r + 15)) & 1ull) ? (1u << (eq * 4 + r)) : 0u;
+      }
+#ifdef RFS_PROFILE
+      if (B.dbg && i == 7 && lane == 0) { B.dbg[11] = (long long)__builtin_readcyclecounter(); B.dbg[14] = __popc(over); }
+#endif
+      while (over) {                                  // (wave-uniform)
+        const int t = __builtin_ctz(over);
+        over &= over - 1;
+        intensity_dense_one(e0 + t, outB, outA);
+      }
+    }
+  };
 #ifdef RFS_STOP_AT
   if ((RFS_STOP_AT == 14 || RFS_STOP_AT == 15) && split && wave > 0) __builtin_amdgcn_endpgm();   // wave 0's strand alone
 #endif
-  if (!split || wave > 0) intensity(0, mSplit, iw, nIw, sumB, sumA);
+  const bool sparseI = WEIGHT_SPARSE_INTENSITY && (split || WPP == 1) && w0Chunks == 0 && N > WEIGHT_SPARSE_MIN_N && N <= 65535;
+  if (!split || wave > 0) {
+    if (sparseI) intensity_sparse(iw, nIw, sumB, sumA, s.sparse + ((split && WPP >= 3) ? (size_t)(wave - 1) * (WEIGHT_SPARSE_LDS_BYTES / 2) : 0));
+    else intensity(0, mSplit, iw, nIw, sumB, sumA);
+  }
   if (!split) block_sync();
 
   DBG_TB(16, 3);
