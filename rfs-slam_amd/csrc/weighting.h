@@ -1013,22 +1013,33 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
         const int e = e0 + ((eL < nG) ? eL : 0);
         const double gx = s.evX[e], gy = s.evY[e];
         double aB = 0.0, aA = 0.0;
-        for (int j0 = 0; j0 < cMax; j0 += 16) {
-          const int slot = j0 + (lane & 15);
-          if (slot < c) {
-            const int m = (int)list[eL * SEG + slot];
-            const double w = s.keys[m], wp = qWP[m], mx = qMX[m], my = qMY[m];
-            double i00, i01, i10, i11, det;
-            inv2(qSXX[m], qSXY[m], qSXY[m], qSYY[m], i00, i01, i10, i11, det);
-            const double rfac = 1.0 / pdf_factor2(det);
-            const double d0 = gx - mx, d1 = gy - my;
-            const double t0 = d0 * i00 + d1 * i01, t1 = d0 * i01 + d1 * i11;
-            const double md2 = t0 * d0 + t1 * d1;
-            double lik = (md2 > 1500.0) ? 0.0 : rfs_exp(-0.5 * md2) * rfac;
-            lik = (lik != lik) ? 0.0 : lik;
-            aB += wp * lik;
-            aA += w * lik;
-          }
+        // one listed pair: the dense loop's term with 1 / sqrt(det) from v_rsq_f64 + two Newton steps standing in for its two divisions and
+        // square root (1 / det = r^2, 1 / factor = r / 2 pi: <= 3 ulp on the term, as far inside the 1e-9 weight tolerance as the dense loop's 1.5)
+        auto term = [&](const int slot, double &tB, double &tA) {
+          const bool v = slot < c;
+          int m = 0;
+          if (v) m = (int)list[eL * SEG + slot];
+          const double w = s.keys[m], wp = qWP[m], mx = qMX[m], my = qMY[m];
+          const double sxx = qSXX[m], sxy = qSXY[m], syy = qSYY[m];
+          const double det = sxx * syy - sxy * sxy;
+          double r = __builtin_amdgcn_rsq(det);
+          r = __builtin_fma(0.5 * r, __builtin_fma(-det * r, r, 1.0), r);
+          r = __builtin_fma(0.5 * r, __builtin_fma(-det * r, r, 1.0), r);
+          const double invdet = r * r, rfac = r * 0.15915494309189533577;
+          const double d0 = gx - mx, d1 = gy - my;
+          const double t0 = (d0 * syy - d1 * sxy) * invdet, t1 = (d1 * sxx - d0 * sxy) * invdet;   // Sigma^-1 d (inv2's entries x 1 / det)
+          const double md2 = t0 * d0 + t1 * d1;
+          double lik = (md2 > 1500.0) ? 0.0 : rfs_exp(-0.5 * md2) * rfac;
+          lik = (lik != lik) ? 0.0 : lik;
+          tB = v ? wp * lik : 0.0;
+          tA = v ? w * lik : 0.0;
+        };
+        for (int j0 = 0; j0 < cMax; j0 += 32) {       // two blocks of 16 per trip: two independent chains in flight
+          double b0, a0, b1, a1;
+          term(j0 + (lane & 15), b0, a0);
+          term(j0 + 16 + (lane & 15), b1, a1);
+          aB += b0; aA += a0;
+          aB += b1; aA += a1;
         }
         aB += dpp_f64<0xb1, 0xf>(aB); aA += dpp_f64<0xb1, 0xf>(aA);     // quad_perm [1,0,3,2]
         aB += dpp_f64<0x4e, 0xf>(aB); aA += dpp_f64<0x4e, 0xf>(aA);     // quad_perm [2,3,0,1]

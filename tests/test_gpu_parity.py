@@ -666,6 +666,62 @@ def test_rank_sort_over_a_wide_range_of_weights(pkg, ob, sc, n_lm, cap, fused):
     compare_maps(sc, dev, orc, scen["n"], ordered=True)
 
 
+def _intensity_scenario(sc, kind, seed):
+    """Mixtures of more than 128 Gaussians (the size from which the weighting phase sums its intensities over listed pairs,
+    weighting.h step 3b) built to take each branch of that path."""
+    rng = np.random.default_rng(seed)
+    if kind == "crowded":            # every Gaussian reaches every evaluation point: all lists overflow -> the dense loop per point
+        scen = sc.make_scenario(12, 300, 20, seed=seed, params=dict(min_weight=0.0))
+        scen["cov"] = scen["cov"] * 400.0          # sigma 0.4 ... 2 m on a 2.5 m map
+    elif kind == "half_crowded":     # lists of 30 ... 100 entries: some evaluation points overflow, some do not
+        scen = sc.make_scenario(12, 300, 20, seed=seed, params=dict(min_weight=0.0))
+        scen["cov"] = scen["cov"] * rng.uniform(1.0, 5.0, (12, 300, 1, 1))
+    elif kind == "untrusted":        # covariances whose fp32 image is refused: singular, indefinite, correlation 1 - 1e-7, sigma 1e-6, huge
+        scen = sc.make_scenario(12, 200, 24, seed=seed)
+        c = scen["cov"]
+        c[:, 3] = [[1e-3, 1e-3], [1e-3, 1e-3]]                      # det == 0
+        c[:, 17] = [[-1e-3, 0.0], [0.0, 2e-3]]                      # indefinite
+        c[:, 40, 0, 1] = c[:, 40, 1, 0] = np.sqrt(c[:, 40, 0, 0] * c[:, 40, 1, 1]) * (1 - 1e-7)
+        c[:, 77] = np.diag([1e-12, 1e-12])                          # sigma 1e-6 m
+        c[:, 101] = np.diag([1e6, 1e6])
+        c[:, 150] = np.diag([1e-9, 4e-3])
+    elif kind == "faint_parents":    # landmarks of weight 1e-8 under a clutter intensity of 1e-14: their updated copies get weight ~1 and become
+        scen = sc.make_scenario(12, 200, 24, seed=seed, params=dict(clutter=1e-14))   # evaluation points whose prior intensity is 2^-30 of their own term
+        scen["w"][:, ::2] = 1e-8
+    elif kind == "tiny_weights":     # weights far below fp32's range keep their order in the log2 estimate
+        scen = sc.make_scenario(12, 200, 24, seed=seed, params=dict(min_weight=0.0), n_eval=4)
+        scen["w"] *= 1e-50
+    else:
+        raise ValueError(kind)
+    return scen
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("kind", ["crowded", "half_crowded", "untrusted", "faint_parents", "tiny_weights"])
+def test_intensity_sums_over_listed_pairs(pkg, ob, sc, kind, fused):
+    """importanceWeighting's intensity sums (include/RBPHDFilter.hpp:776-800) on mixtures large enough for the sparse form: the
+    branches that leave the ordinary path -- list overflow, Gaussians listed for every point, the prior-intensity check failing --
+    give the oracle's weights like the ordinary one."""
+    scen = _intensity_scenario(sc, kind, 77)
+    dev = pkg.RBPHDFilter(scen["n"], gm_capacity=640)
+    orc = ob.OracleFilter(scen["n"])
+    for f in (dev, orc):
+        sc.load_scenario(f, scen)
+    if fused:
+        dev.update_async(scen["Z"])
+        dev.synchronize()
+        orc.update(scen["Z"])
+    else:
+        for f in (dev, orc):
+            f.update_map(scen["Z"])
+            f.importance_weighting()
+    wd, wo = dev.get_weights(), orc.get_weights()
+    assert np.array_equal(np.isfinite(wd), np.isfinite(wo))
+    ok = np.isfinite(wo)
+    np.testing.assert_allclose(wd[ok], wo[ok], rtol=1e-8, atol=0)
+    assert (wo[ok] > 0).any()
+
+
 def _clustered_mixtures(sc, n_particles, n_gauss, kind, seed):
     """Mixtures built to hit every path of the device merge: dense clusters (chains of merges, rows that share partners,
     rows absorbed by earlier rows), coincident means, crowded neighbourhoods (more partners than a row can list),
