@@ -87,6 +87,13 @@ __device__ __forceinline__ bool pair_gate(const Params &P, const LmKF &k, double
   if (P.kfBearing > 0 && fabs(w1) > P.kfBearing) return false;
   return true;
 }
+// Mahalanobis distance of the pair as pair_value forms it (same expression, same bits)
+__device__ __forceinline__ double pair_md2(const LmKF &k, double z0, double z1) {
+  const double e0 = z0 - k.zx0, e1 = z1 - k.zx1;  // UNWRAPPED difference
+  const double t0 = e0 * k.i00 + e1 * k.i10;
+  const double t1 = e0 * k.i01 + e1 * k.i11;
+  return t0 * e0 + t1 * e1;
+}
 // Likelihood part for a pair that passed the innovation gates: Pd*w*lik or 0 (KalmanFilter.hpp:317-326, RBPHDFilter.hpp:622-632).
 __device__ __forceinline__ double pair_value(const Params &P, const LmKF &k, double pdw, double z0, double z1) {
   const double e0 = z0 - k.zx0, e1 = z1 - k.zx1;  // UNWRAPPED difference
@@ -285,10 +292,20 @@ __device__ __forceinline__ void phd_update_map_particle(const Buffers &B, const 
 #pragma unroll
     for (int t = 0; t < UPDMAP_KEEP; t++) keepV[t] = 0.0;
     int cnt = 0;
+    // two loops, each as long as its busiest lane: the candidates of the fp32 sweep (a handful per landmark) through the exact
+    // innovation gates and the Mahalanobis gate -- distance only --, then the few that are left (seldom more than one per landmark)
+    // through the Gaussian: as one loop every trip paid for the exp and the division because SOME lane's candidate had passed
+    unsigned long long gated = 0;
     for (unsigned long long g = cand; g; g &= g - 1) {
       const int z = __builtin_ctzll(g);
       const double z0 = sZ[2 * z], z1 = sZ[2 * z + 1];
       if (!pair_gate(P, k, z0, z1)) continue;
+      if (pair_md2(k, z0, z1) > P.newGaussMd2) continue;
+      gated |= 1ull << z;
+    }
+    for (unsigned long long g = gated; g; g &= g - 1) {
+      const int z = __builtin_ctzll(g);
+      const double z0 = sZ[2 * z], z1 = sZ[2 * z + 1];
       const double v = pair_value(P, k, pdw, z0, z1);
       if (v != 0.0) {
         surv |= (1ull << z);
@@ -489,10 +506,20 @@ __device__ __forceinline__ void phd_update_map_block(const Buffers &B, const Par
 #pragma unroll
     for (int t = 0; t < UPDMAP_KEEP; t++) keepV[t] = 0.0;
     int cnt = 0;
+    // two loops, each as long as its busiest lane: the candidates of the fp32 sweep (a handful per landmark) through the exact
+    // innovation gates and the Mahalanobis gate -- distance only --, then the few that are left (seldom more than one per landmark)
+    // through the Gaussian: as one loop every trip paid for the exp and the division because SOME lane's candidate had passed
+    unsigned long long gated = 0;
     for (unsigned long long g = cand; g; g &= g - 1) {
       const int z = __builtin_ctzll(g);
       const double z0 = sZ[2 * z], z1 = sZ[2 * z + 1];
       if (!pair_gate(P, k, z0, z1)) continue;
+      if (pair_md2(k, z0, z1) > P.newGaussMd2) continue;
+      gated |= 1ull << z;
+    }
+    for (unsigned long long g = gated; g; g &= g - 1) {
+      const int z = __builtin_ctzll(g);
+      const double z0 = sZ[2 * z], z1 = sZ[2 * z + 1];
       const double v = pair_value(P, k, pdw, z0, z1);
       if (v != 0.0) {
         surv |= (1ull << z);

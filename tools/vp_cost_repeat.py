@@ -59,3 +59,15 @@ print("list scheduling of launch 1's durations on 3072 slots: slot order %.1f us
       % (makespan(d1), makespan(d1[np.argsort(-d0)]), makespan(d1[np.argsort(-d1)]), makespan(d1[np.argsort(d0)])))
 sizes = f.gm_sizes()
 print("corr(duration, mixture size after the step) %.3f" % np.corrcoef(d1, sizes)[0, 1])
+
+rng = np.random.default_rng(0)
+for nclass in (2, 3, 4, 8):
+    for qs in ([0.385], [0.3], [0.5]) if nclass == 2 else ([None],):
+        if nclass == 2:
+            edges = np.quantile(d0, qs)
+        else:
+            edges = np.quantile(d0, np.linspace(0, 1, nclass + 1)[1:-1])
+        cls = np.searchsorted(edges, d0)            # 0 = shortest class
+        key = -cls + 1e-3 * rng.random(N)           # longest class first, arrival order inside a class
+        order = np.argsort(key, kind="stable")
+        print("  %d classes by launch 0's durations (edges at %s us): launch 1 would take %.1f us" % (nclass, np.round(edges, 1).tolist(), makespan(d1[order])))
