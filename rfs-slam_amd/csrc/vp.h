@@ -341,9 +341,17 @@ __device__ int vp_update_map_particle(const Buffers &B, const Params &P, int cur
     RFS_CUT(102);
     unsigned long long surv = 0;
     if (fov) {
+      // gates and Mahalanobis distance for every measurement, the Gaussian only for the pairs inside the gate (one loop for both made
+      // every trip pay for the exp and the division as soon as ONE lane's pair had passed)
+      unsigned long long gated = 0;
       for (int z = 0; z < nZ; z++) {
         double nu0, nu1;
-        if (vp_gate(P, k, sZ[3 * z], sZ[3 * z + 1], nu0, nu1) && vp_value(P, k, pdw, sZ[3 * z], sZ[3 * z + 1], sZ[3 * z + 2]) != 0.0) surv |= 1ull << z;
+        if (vp_gate(P, k, sZ[3 * z], sZ[3 * z + 1], nu0, nu1) &&
+            !(md2_3(k.Si, sZ[3 * z] - k.zx0, sZ[3 * z + 1] - k.zx1, sZ[3 * z + 2] - k.zx2) > P.newGaussMd2)) gated |= 1ull << z;
+      }
+      for (unsigned long long g = gated; g; g &= g - 1) {
+        const int z = __builtin_ctzll(g);
+        if (vp_value(P, k, pdw, sZ[3 * z], sZ[3 * z + 1], sZ[3 * z + 2]) != 0.0) surv |= 1ull << z;
       }
     }
     if (p == 0) DBG_T(0, 3);

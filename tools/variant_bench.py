@@ -31,10 +31,11 @@ if sys.argv[1] == "--build":
         print(name, "rc", p.wait())
 else:
     steps = os.environ.get("VB_STEPS", "200")
+    wl = os.environ.get("VB_WORKLOAD", "c2a")
     for name in sys.argv[2:]:
         code = (f"import sys; sys.path.insert(0, {ROOT!r}); import __graft_entry__ as g; pkg = g.load_package(); "
                 f"pkg.engine.LIB = {lib_of(name)!r}; import bench; "
-                f"sys.argv = ['bench.py', '--steps', '{steps}', '--warmup', '20', '--no-cpu-baseline', '--no-pmc', '--no-boundary']; bench.main()")
+                f"sys.argv = ['bench.py', '--workload', '{wl}', '--steps', '{steps}', '--warmup', '20', '--no-cpu-baseline', '--no-pmc', '--no-boundary']; bench.main()")
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
         try:
             d = json.loads(r.stdout.strip().splitlines()[-1])
