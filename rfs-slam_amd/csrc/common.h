@@ -150,11 +150,6 @@ __device__ __forceinline__ int wave_sum_i(int v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
-  return v;
-}
 // ---- DPP wave reductions (gfx9 row_shr / row_bcast): ~10x cheaper than ds_bpermute-based shuffles ----------
 // Pattern of rocPRIM's warp_reduce_dpp: quad swaps, row_shr:4/8 inside each 16-lane row, then row_bcast:15 / :31
 // across rows; the full-wave result lands in lane 63 and is broadcast with v_readlane.
@@ -187,17 +182,6 @@ __device__ __forceinline__ int wave_sum_i_dpp(int v) {
   v += dpp_i32<0x143, 0xc>(v);
   return __builtin_amdgcn_readlane(v, 63);
 }
-// min / max of a float over the wave (exact in any order).  Uses shuffles of 32-bit values (one ds_bpermute each).
-__device__ __forceinline__ float wave_min_f32(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ float wave_max_f32(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
 
 // min / max of a u32 over the wave with DPP moves (lanes without a partner keep their own value)
 template <int CTRL, int ROW_MASK>
@@ -214,18 +198,44 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) { return ~wave_max_u32(~v); }
-// max of a float over the wave with DPP moves, result in every lane (maxNum: a NaN loses against a number)
-__device__ __forceinline__ float wave_max_f32_dpp(float v) {
-#define RFS_DPP_F32(CTRL, MASK) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, MASK, 0xf, false))
+// min / max of a float over the wave (exact in any order; minNum / maxNum: a NaN loses against a number), OR of a 64-bit mask:
+// DPP moves, result in every lane (r1-r3: six ds_bpermute shuffles each -- an LDS round trip per step)
+#define RFS_DPP_KEEP(x, CTRL, MASK) __builtin_amdgcn_update_dpp((x), (x), CTRL, MASK, 0xf, false)
+#define RFS_DPP_F32(CTRL, MASK) __builtin_bit_cast(float, RFS_DPP_KEEP(__builtin_bit_cast(int, v), CTRL, MASK))
+__device__ __forceinline__ float wave_max_f32(float v) {
   v = __builtin_fmaxf(v, RFS_DPP_F32(0xb1, 0xf));
   v = __builtin_fmaxf(v, RFS_DPP_F32(0x4e, 0xf));
   v = __builtin_fmaxf(v, RFS_DPP_F32(0x114, 0xf));
   v = __builtin_fmaxf(v, RFS_DPP_F32(0x118, 0xf));
   v = __builtin_fmaxf(v, RFS_DPP_F32(0x142, 0xa));
   v = __builtin_fmaxf(v, RFS_DPP_F32(0x143, 0xc));
-#undef RFS_DPP_F32
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+__device__ __forceinline__ float wave_min_f32(float v) {
+  v = __builtin_fminf(v, RFS_DPP_F32(0xb1, 0xf));
+  v = __builtin_fminf(v, RFS_DPP_F32(0x4e, 0xf));
+  v = __builtin_fminf(v, RFS_DPP_F32(0x114, 0xf));
+  v = __builtin_fminf(v, RFS_DPP_F32(0x118, 0xf));
+  v = __builtin_fminf(v, RFS_DPP_F32(0x142, 0xa));
+  v = __builtin_fminf(v, RFS_DPP_F32(0x143, 0xc));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_max_f32_dpp(float v) { return wave_max_f32(v); }
+#undef RFS_DPP_F32
+__device__ __forceinline__ unsigned wave_or_u32(unsigned u) {
+  int x = (int)u;
+  x |= RFS_DPP_KEEP(x, 0xb1, 0xf);
+  x |= RFS_DPP_KEEP(x, 0x4e, 0xf);
+  x |= RFS_DPP_KEEP(x, 0x114, 0xf);
+  x |= RFS_DPP_KEEP(x, 0x118, 0xf);
+  x |= RFS_DPP_KEEP(x, 0x142, 0xa);
+  x |= RFS_DPP_KEEP(x, 0x143, 0xc);
+  return (unsigned)__builtin_amdgcn_readlane(x, 63);
+}
+__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {
+  return ((unsigned long long)wave_or_u32((unsigned)(v >> 32)) << 32) | wave_or_u32((unsigned)v);
+}
+#undef RFS_DPP_KEEP
 
 // exclusive prefix sum over the wave (small ints): Hillis-Steele inside each 16-lane row with row_shr DPP moves, then the row
 // totals across rows with row_bcast:15 / :31 -- six VALU instructions, no LDS permute and no lane-address registers (the
