@@ -944,18 +944,36 @@ __device__ void vp_merge_particle(const Buffers &B, const Params &P, int cur, in
     // within eta = 2^-22 max|coordinate| of the true one, so |e| <= sqrt(B) implies |e_f| <= sqrt(B) + 2 eta; the radii are
     // rounded up, the product carries 2^-18 for its own roundings; NaN / inf (positions, bounds) compare as "keep".
     const float etaAll = wave_max_f32((float)(posMax * (1.0 + 0x1p-20))) * (2.0f * 0x1p-22f * (1.0f + 0x1p-20f));
-    auto sweep = [&](const int from, const bool want, const int jStart) -> unsigned long long {   // entries j > from (>= jStart: uniform) passing the prefilter
+    // Two entries per packed instruction (v_pk_*: the same fp32 operations with the same roundings as one by one), the verdicts shifted
+    // into two 32-bit words from the top entry down -- bit k of the pair of words <-> entry 2 (jStart / 2) + k --, `j > from`, `j < N`
+    // and the holes applied to the finished mask.  (r3: one entry per trip, the bit set through a 64-bit select: 16 instructions
+    // per entry against 9.)
+    typedef float vpf2_t __attribute__((ext_vector_type(2)));
+    auto sweep = [&](const int from, const bool want, const int jStart) -> unsigned long long {   // entries j > from (>= jStart: uniform, <= from + 1) passing the prefilter
       const float fax = (float)ax, fay = (float)ay, fad = (float)ad;
       const float ra = vp_radius_f32(ab);
       const float eta2 = fmaxf(etaAll, fmaxf(fmaxf(fabsf(fax), fabsf(fay)), fabsf(fad)) * (2.0f * 0x1p-22f * (1.0f + 0x1p-20f)));
-      unsigned long long m = 0ull;
-#pragma unroll 4
-      for (int j = jStart; j < N; j++) {
-        const float e0 = fX[j] - fax, e1 = fY[j] - fay, e2 = fD[j] - fad;
-        const float R = fmaxf(ra, fR[j]) + eta2;
-        const bool c = !(fmaf(e0, e0, fmaf(e1, e1, e2 * e2)) > (R * R) * (1.0f + 0x1p-18f));
-        m |= (c && j > from) ? (1ull << j) : 0ull;
-      }
+      const vpf2_t vx = {fax, fax}, vy = {fay, fay}, vd = {fad, fad}, ve = {eta2, eta2}, vk = {1.0f + 0x1p-18f, 1.0f + 0x1p-18f};
+      const vpf2_t *pX = reinterpret_cast<const vpf2_t *>(fX), *pY = reinterpret_cast<const vpf2_t *>(fY);
+      const vpf2_t *pD = reinterpret_cast<const vpf2_t *>(fD), *pR = reinterpret_cast<const vpf2_t *>(fR);
+      auto pair_bits = [&](const int q) -> unsigned {   // entries 2q (bit 0) and 2q + 1 (bit 1)
+        const vpf2_t e0 = pX[q] - vx, e1 = pY[q] - vy, e2 = pD[q] - vd;
+        vpf2_t R = pR[q];
+        R.x = fmaxf(ra, R.x); R.y = fmaxf(ra, R.y);
+        R = R + ve;
+        const vpf2_t d2 = __builtin_elementwise_fma(e0, e0, __builtin_elementwise_fma(e1, e1, e2 * e2));
+        const vpf2_t thr = (R * R) * vk;
+        return (!(d2.x > thr.x) ? 1u : 0u) | (!(d2.y > thr.y) ? 2u : 0u);
+      };
+      const int q0 = jStart >> 1, qEnd = (N + 1) >> 1, qMid = (q0 + 16 < qEnd) ? q0 + 16 : qEnd;
+      unsigned lo = 0u, hi = 0u;
+#pragma unroll 2
+      for (int q = qEnd - 1; q >= qMid; q--) hi = (hi << 2) | pair_bits(q);
+#pragma unroll 2
+      for (int q = qMid - 1; q >= q0; q--) lo = (lo << 2) | pair_bits(q);
+      unsigned long long m = (((unsigned long long)hi << 32) | lo) << (2 * q0);
+      m &= ~((2ull << (from & 63)) - 1ull);                                       // j > from
+      m &= (N >= 64) ? ~0ull : ((1ull << N) - 1ull);                              // j < N (the last pair may reach one past the mixture)
       return want ? (m & ~holes0) : 0ull;
     };
     unsigned long long cand = sweep(a, isRow, 1);
