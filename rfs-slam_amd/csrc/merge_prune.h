@@ -661,6 +661,14 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     }
 #endif
     const int firstDirty = cm ? __builtin_ctzll(cm) : 64;
+#ifndef MERGE_P2_BOOST
+#define MERGE_P2_BOOST 22       // rows left to validate one by one from which the workgroup's issue priority goes up (0: never)
+#define MERGE_P2_BOOST_PRIO 2
+#endif
+    // A launch ends with its slowest workgroups, and those are the particles whose replay validates many rows one by one (the replay's
+    // length explains 0.92 of the merge phase's spread, tools/tail_study.py; a particle is slow launch after launch).  The replay runs at
+    // the lowest issue priority (step_fused.h); a workgroup that finds itself with a long serial tail takes the map update's level back.
+    if (MERGE_P2_BOOST > 0 && firstDirty < 64 && __popcll(actm >> firstDirty) >= MERGE_P2_BOOST) __builtin_amdgcn_s_setprio(MERGE_P2_BOOST_PRIO);
     const bool commitNow = active && lane < firstDirty && ((alivem >> lane) & 1ull) && nAbs > 0;
     if (commitNow) {
       for (int k = 0; k < nAbs; k++) sRad[sSpec[lane * 8 + k]] = -1.f;
