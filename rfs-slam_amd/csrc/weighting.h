@@ -1054,6 +1054,7 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
       }
 #ifdef RFS_PROFILE
       if (B.dbg && i == 7 && lane == 0) { B.dbg[11] = (long long)__builtin_readcyclecounter(); B.dbg[14] = __popc(over); }
+      if (B.dbg && lane == 0 && over) atomicAdd((unsigned long long *)&B.dbg[8], (unsigned long long)__popc(over));   // all particles: dense fall-backs since the buffer was cleared
 #endif
       while (over) {                                  // (wave-uniform)
         const int t = __builtin_ctz(over);

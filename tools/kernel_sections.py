@@ -80,6 +80,7 @@ if lib.rfsgpu_debug_per_particle(f._h, pp) == 0:
     print("weight per particle: total cycles", q(a[:, 0]))
     print("weight per particle: components+partitions cycles", q(a[:, 1]))
     print("weight per particle: evaluation points", q(a[:, 2]))
+print("sparse intensity sums, all particles, the 3 launches of this run: %d evaluation points summed by the dense loop (list overflow or prior check)" % t[8])
 if t[15] > 0:
     print("sparse intensity sums (last group of the wave, particle 7): setup + sweep %d cycles, exact terms %d cycles; %d pairs listed for %d evaluation points, %d row trips, %d dense fall-backs"
           % (t[10] - t[9], t[11] - t[10], t[12], t[15], t[13], t[14]))
