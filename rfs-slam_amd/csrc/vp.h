@@ -268,6 +268,28 @@ __device__ __forceinline__ bool vp_gate(const Params &P, const LmKF3 &k, double 
   const bool g1 = !((P.kfBearing > 0) & (fabs(nu1) > P.kfBearing));
   return g0 & g1;
 }
+// Candidate mask of one landmark for the innovation gates of vp_gate: a sweep over the measurement set in fp32 with the thresholds widened by a
+// bound on the fp32 rounding of the operands, the difference and the 2-pi reduction (the 2-D kernel's gate_candidates, update_map.h, one
+// measurement at a time from the fp64 copy in LDS): it can only let extra pairs through; every candidate then goes through the exact gate.
+__device__ __forceinline__ unsigned long long vp_gate_candidates(const Params &P, const double zx0d, const double zx1d, const int nZ, const double *sZ,
+                                                                 const float zrMax, const float zbMax) {
+  const float zx0 = (float)zx0d, zx1 = (float)zx1d;
+  const float inf = __builtin_huge_valf();
+  float thrR = (P.kfRange > 0) ? (float)P.kfRange * (1.f + 1e-6f) + 2.5e-7f * (zrMax + fabsf(zx0)) + 1e-30f : inf;
+  float thrB = (P.kfBearing > 0) ? (float)P.kfBearing * (1.f + 1e-6f) + 1e-6f * (zbMax + 3.2f) + 1e-6f : inf;
+  if (!(zbMax < 50.f) || !(fabsf(zx1) < 50.f)) thrB = inf;       // far outside any sensible bearing range (or NaN): the exact test decides
+  if (!(zrMax < 1.0e30f)) thrR = inf;
+  unsigned long long m = 0ull;
+#pragma unroll 4
+  for (int z = 0; z < nZ; z++) {
+    const float e0 = (float)sZ[3 * z] - zx0;
+    float w = (float)sZ[3 * z + 1] - zx1;
+    w = w - __builtin_rintf(w * 0.15915494309189533577f) * 6.2831853071795864769f;
+    const bool c = ((int)!(fabsf(e0) > thrR) & (int)!(fabsf(w) > thrB)) != 0;    // !(x > t) form: a NaN is a candidate
+    m |= c ? (1ull << z) : 0ull;
+  }
+  return m;
+}
 __device__ __forceinline__ double vp_value(const Params &P, const LmKF3 &k, double pdw, double z0, double z1, double z2) {
   const double e0 = z0 - k.zx0, e1 = z1 - k.zx1, e2 = z2 - k.zx2;  // RAW difference (KalmanFilter.hpp:317-320)
   const double md2 = md2_3(k.Si, e0, e1, e2);
@@ -307,6 +329,8 @@ __device__ int vp_update_map_particle(const Buffers &B, const Params &P, int cur
   }
   double *slab = B.slab[cur];
   const double px = B.pose[3 * i], py = B.pose[3 * i + 1], pth = B.pose[3 * i + 2];
+  // largest |range| and |bearing| of the measurement set: the rounding bounds of the fp32 gate sweep (vp_gate_candidates)
+  const float zrMax = wave_max_f32((lane < nZ) ? fabsf((float)sZ[3 * lane]) : 0.f), zbMax = wave_max_f32((lane < nZ) ? fabsf((float)sZ[3 * lane + 1]) : 0.f);
   const int nPass = (nM + 63) >> 6;
   const int room = cap - nM;
   DBG_T(0, 0);
@@ -344,7 +368,8 @@ __device__ int vp_update_map_particle(const Buffers &B, const Params &P, int cur
       // gates and Mahalanobis distance for every measurement, the Gaussian only for the pairs inside the gate (one loop for both made
       // every trip pay for the exp and the division as soon as ONE lane's pair had passed)
       unsigned long long gated = 0;
-      for (int z = 0; z < nZ; z++) {
+      for (unsigned long long g = vp_gate_candidates(P, k.zx0, k.zx1, nZ, sZ, zrMax, zbMax); g; g &= g - 1) {
+        const int z = __builtin_ctzll(g);
         double nu0, nu1;
         if (vp_gate(P, k, sZ[3 * z], sZ[3 * z + 1], nu0, nu1) &&
             !(md2_3(k.Si, sZ[3 * z] - k.zx0, sZ[3 * z + 1] - k.zx1, sZ[3 * z + 2] - k.zx2) > P.newGaussMd2)) gated |= 1ull << z;
