@@ -2,8 +2,8 @@
 
 Tolerances: normalised particle weights rel 1e-9; GM components matched as multisets on
 (w, mu, Sigma) rel 1e-10 / abs 1e-12; integer outputs (mixture sizes, unused lists, FOV counts) exact.
-The oracle runs in (weight desc, index asc) sort mode == what the device implements (tie order is the one
-documented deviation from the reference's unstable std::sort)."""
+The oracle runs in its reference mode (oracle/binding.py: stable_sort=False): equal weights come out in the order
+libstdc++'s std::sort leaves them in, which the device reproduces (csrc/stdsort_replay.h, DESIGN 4)."""
 import numpy as np
 import pytest
 
@@ -614,11 +614,12 @@ def test_cpp_host_driver_logs_through_analysis2d_sim(pkg, tmp_path):
 
 
 @pytest.mark.parametrize("n_lm,cap", [(90, 256), (330, 512)])
-def test_tied_weights_rank_by_index(pkg, ob, sc, n_lm, cap):
-    """Equal prior weights (ordinary in real runs: all birth Gaussians share one weight): the sort is (weight desc, index
-    asc).  The device ranks 64-entry chunks and merges the chunk ranks, so ties inside a chunk (the wave redoes its chunk
-    with the index tie-break) and ties ACROSS chunks (">=" towards lower chunks, ">" towards higher ones) both matter:
-    330 landmarks with a handful of distinct weights tie across six chunks."""
+def test_tied_weights_come_out_in_reference_order_across_chunks(pkg, ob, sc, n_lm, cap):
+    """Equal prior weights (ordinary in real runs: all birth Gaussians share one weight): the reference's sort is
+    std::sort (include/GaussianMixture.hpp:523-534), and the oracle runs it.  The device ranks with ties by index (64-entry
+    chunks / buckets: ties inside a chunk and ties ACROSS chunks both matter -- 330 landmarks with a handful of distinct
+    weights tie across six chunks) and then replays std::sort's partition phase over the tied runs (stdsort_replay.h):
+    ORDERED comparison of maps and weights against the oracle."""
     scen = sc.make_scenario(16, n_lm, 14, seed=23)
     scen["w"][:, ::3] = 0.5                                  # many exact ties
     scen["w"][:, 1::3] = np.float64(np.float32(0.7)) + 1e-12 * np.arange(n_lm // 3)[None, :]   # distinct in fp64, equal in fp32
