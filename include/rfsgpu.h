@@ -397,8 +397,13 @@ int rfsgpu_resample_occured(const rfsgpu_filter *f);
  * + Q where they are created).  Between the calls the host moves lists with rfsgpu_get/set_unused_masks and
  * rfsgpu_export/import_birth_candidates (rfs-slam_amd/sharded.py, rfsgpu_group_predict_map). */
 int rfsgpu_predict_map_level(rfsgpu_filter *f, int add_birth, const int *level_of_slot, int level, int do_static);
-int rfsgpu_get_unused_masks(rfsgpu_filter *f, unsigned long long *masks);
+int rfsgpu_get_unused_masks(rfsgpu_filter *f, unsigned long long *masks);   /* a read: does NOT acknowledge the rule to an EXTERNAL-mode handle */
 int rfsgpu_set_unused_masks(rfsgpu_filter *f, const unsigned long long *masks);
+/* [multi] 1 if this handle has ever held birth-candidate lists (birthGaussians_, include/RBPHDFilter.hpp:1014-1083: a configuration
+ * that keeps them has run a birth predict, or lists were imported with rfsgpu_import_birth_candidates), else 0; -1 for a null
+ * handle.  The multi-GPU hosts take the closed form of the inheritance rule over the unused masks only while this is 0 on
+ * EVERY shard (rfsgpu_group_predict_map and rfs-slam_amd/sharded.py use this one predicate). */
+int rfsgpu_has_birth_candidates(const rfsgpu_filter *f);
 /* ParticleFilter::resample(n) with n < nParticles_ (:417-483; FastSLAM::resampleWithMapCopy): the first n_out slots
  * receive src_slot[0..n_out), the particle count becomes n_out.  A source below n_out must keep itself; sources at or
  * beyond n_out are dropped after the copy. */

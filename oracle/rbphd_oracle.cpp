@@ -902,6 +902,7 @@ struct FilterBase {
   int inherit_mode = RFSGPU_INHERIT_REFERENCE;
   std::vector<unsigned> pid, ppid; /* Particle::id_ / idParent_ of the particle in each slot */
   bool resample_occured = false;   /* RBPHDFilter::resampleOccured_ */
+  bool cand_used = false;          /* candidate lists have been imported (the stand-in of the engine's flag behind rfsgpu_has_birth_candidates) */
   bool fastslam_handle = false;    /* rfsor_fastslam_update has run: rfs::FastSLAM copies its candidate lists at resampling time (FastSLAM.hpp:747-753) */
   bool eager() const { return inherit_mode == RFSGPU_INHERIT_EAGER || fastslam_handle; }
   void ensure_ids() { while ((int)pid.size() < n) { pid.push_back((unsigned)pid.size()); ppid.push_back((unsigned)ppid.size()); } }
@@ -1837,13 +1838,17 @@ int rfsor_import_birth_candidates(void *f, int slot, int n, const double *mean, 
   FilterBase *F = F_(f);
   if (slot < 0 || slot >= F->n || n < 0) return RFSGPU_ERR_INVALID;
   F->import_candidates(slot, n, mean, cov, support, checks);
+  if (n > 0) F->cand_used = true;
   return RFSGPU_OK;
 }
+int rfsor_has_birth_candidates(const void *f) { return f ? (reinterpret_cast<const FilterBase *>(f)->cand_used ? 1 : 0) : -1; }
 
 int rfsor_predict_map(void *f, int add_birth) { return F_(f)->predict_map(add_birth); }
 int rfsor_predict_map_level(void *f, int add_birth, const int *level_of_slot, int level, int do_static) {
   if (!level_of_slot) return RFSGPU_ERR_INVALID;
-  return F_(f)->predict_map_level(add_birth, level_of_slot, level, do_static);
+  FilterBase *F = F_(f);
+  F->cand_used = F->cand_used || F->cfg.birthGaussianMeasurementCountThreshold != 1u;   /* (as the engine: lists exist from here on) */
+  return F->predict_map_level(add_birth, level_of_slot, level, do_static);
 }
 
 int rfsor_update_map(void *f, const double *z, int n_z) {

@@ -48,10 +48,12 @@ struct RcclApi {
 };
 static RcclApi g_rccl;
 static void *rccl_load(std::string &why) {
-  void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-  if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-  if (!h) { why = std::string("librccl not loadable: ") + (dlerror() ? dlerror() : "?"); return nullptr; }
+  // RFSGPU_RCCL_LIB names the library file instead of the three default names (an installation elsewhere; the test of this very fall-back)
+  const char *named = getenv("RFSGPU_RCCL_LIB");
+  void *h = (named && *named) ? dlopen(named, RTLD_NOW | RTLD_LOCAL) : dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h && !(named && *named)) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!h && !(named && *named)) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h) { const char *e = dlerror(); why = std::string("librccl not loadable: ") + (e ? e : "?"); return nullptr; }   // (dlerror() clears itself: one call)
   g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))dlsym(h, "ncclCommInitAll");
   g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
   g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
@@ -343,7 +345,7 @@ int rfsgpu_group_predict_map(rfsgpu_group *g, int add_birth) {
     bool anyCopy = false;
     for (int p = 0; p < g->N; p++) anyCopy |= g->ppid[p] != p;
     bool candUsed = false;            // any shard that has held candidate lists (imported ones included) sends the whole group through the walk
-    for (size_t k = 0; k < g->shard.size(); k++) candUsed |= g->shard[k]->candUsed;
+    for (size_t k = 0; k < g->shard.size(); k++) candUsed |= rfsgpu_has_birth_candidates(g->shard[k]) == 1;
     if (anyCopy && (f0->D != 2 || f0->cfg.birthGaussianMeasurementCountThreshold != 1u || candUsed)) return group_predict_levels(g, add_birth);
     if (anyCopy) {
       std::vector<unsigned long long> m((size_t)g->N), mn((size_t)g->N);

@@ -1514,9 +1514,9 @@ int rfsgpu_get_unused_masks(rfsgpu_filter *f, unsigned long long *masks) {
   hipSetDevice(f->device);
   HIPCHK(hipMemcpyAsync(masks, f->B.unusedMask, (size_t)f->N * sizeof(unsigned long long), hipMemcpyDeviceToHost, f->stream));
   HIPCHK(hipStreamSynchronize(f->stream));
-  f->externalAck = true;
-  return RFSGPU_OK;
+  return RFSGPU_OK;   // (a read acknowledges nothing: only set_unused_masks / predict_map_level / set_birth_inheritance do)
 }
+int rfsgpu_has_birth_candidates(const rfsgpu_filter *f) { return f ? (f->candUsed ? 1 : 0) : -1; }
 int rfsgpu_set_unused_masks(rfsgpu_filter *f, const unsigned long long *masks) {
   CHECK_HANDLE(f);
   if (!masks) return RFSGPU_ERR_INVALID;

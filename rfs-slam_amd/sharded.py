@@ -154,9 +154,7 @@ class ShardedRBPHDFilter:
 
     def _any_shard_has_candidates(self):
         """Does any shard hold birth candidates (count over its slots > 0)?  All-reduced so that every rank takes the same branch."""
-        has = 0
-        if hasattr(self.f, "has_birth_candidates"):
-            has = int(bool(self.f.has_birth_candidates()))
+        has = int(bool(self.f.has_birth_candidates()))   # (rfsgpu_has_birth_candidates: a missing symbol fails loudly)
         if self.world > 1:
             t = torch.tensor([has], dtype=torch.int64)
             if self.on_gpu and self.backend == "nccl":

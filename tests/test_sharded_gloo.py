@@ -59,6 +59,19 @@ def candidate_config(f):
     f.set_filter_config(cfg)
 
 
+def import_some_candidates(f, lo, n_local):
+    """Imported birth-candidate lists on an immediate-birth configuration (CountThreshold == 1 never builds any itself): global slot
+    g gets g % 3 candidates whose contents name the slot, so that a list that travels with the inheritance walk can be told apart."""
+    for i in range(n_local):
+        g = lo + i
+        k = g % 3
+        if k == 0:
+            continue
+        mean = np.array([[10.0 + g, -3.0 + 0.25 * j] for j in range(k)])
+        cov = np.array([[[0.01 * (j + 1), 0.0], [0.0, 0.02]] for j in range(k)])
+        f.import_birth_candidates(i, mean, cov, np.arange(1, k + 1, dtype=np.int32), np.full(k, g % 5, dtype=np.int32))
+
+
 def _worker(rank, world, port, n_total, force_resample, q, big=False, cycles=0, cand=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -72,7 +85,9 @@ def _worker(rank, world, port, n_total, force_resample, q, big=False, cycles=0, 
     scen = make_scen(sc, n_total, big)
     local = ob.OracleFilter(n_total // world)
     sc.load_scenario(local, shard_scen(scen, rank, world))
-    if cand:
+    if cand == "imported":
+        import_some_candidates(local, rank * (n_total // world), n_total // world)
+    elif cand:
         candidate_config(local)
     sh = pkg.sharded.ShardedRBPHDFilter(local)
     sh.effNParticles_t = n_total + 1.0 if force_resample else 1e-9     # always / never resample
@@ -150,22 +165,30 @@ def test_two_rank_update_matches_single_process(pkg, ob, force_resample):
         assert len(crossed) > 0
 
 
-@pytest.mark.parametrize("world,cand", [(2, False), (3, False), (2, True), (3, True)])
+@pytest.mark.parametrize("world,cand", [(2, False), (3, False), (2, True), (3, True), (2, "imported"), (3, "imported")])
 def test_sharded_resampling_cycles_inherit_birth_state_as_the_reference(pkg, ob, world, cand):
     """Forced global resamplings with predicts and updates in between, over 2 and 3 ranks: maps, unused lists, weights and particle
     ids equal those of ONE plain filter holding all particles in RFSGPU_INHERIT_REFERENCE mode (the engine's own, single-GPU
     implementation of include/RBPHDFilter.hpp:1005-1011) driven through the same decisions -- i.e. the sharded host's mask
     exchange over GLOBAL slots reproduces the reference's slot-ordered copy across shard boundaries.  cand: a configuration that
     keeps birth-candidate lists -- the sharded host then carries out the walk level by level (lists of parent slots on other
-    ranks travel as objects), and the candidate lists (means, covariances, supports, checks) must match too."""
+    ranks travel as objects), and the candidate lists (means, covariances, supports, checks) must match too.  cand == "imported":
+    candidate lists put into an IMMEDIATE-birth configuration from outside: rfsgpu_has_birth_candidates is then 1 on
+    the shards, every rank must leave the closed form over the masks for the full walk (the lists move with :1005-1011 although
+    CountThreshold == 1 never reads them), exactly as rfsgpu_group_predict_map does."""
     n_total, cycles = 24, 4
     sc = pkg.scenarios
     scen = make_scen(sc, n_total)
     ref = ob.OracleFilter(n_total)
     assert ref.get_birth_inheritance() == pkg.capi.INHERIT_REFERENCE
     sc.load_scenario(ref, scen)
-    if cand:
+    if cand == "imported":
+        import_some_candidates(ref, 0, n_total)
+        assert ref.has_birth_candidates()
+    elif cand:
         candidate_config(ref)
+    else:
+        assert not ref.has_birth_candidates()
 
     def step(Z, u01):
         ref.update(Z)
@@ -195,7 +218,7 @@ def test_sharded_resampling_cycles_inherit_birth_state_as_the_reference(pkg, ob,
         np.testing.assert_array_equal(cands[i][0], mr)
         np.testing.assert_array_equal(cands[i][1], cr)
         n_cand += len(sr)
-    assert (n_cand > 0) == cand
+    assert (n_cand > 0) == (cand is True)     # (imported lists on CountThreshold == 1 are promoted by the first birth predict: they end up in the MAPS)
     np.testing.assert_array_equal(np.concatenate([o["poses"] for o in out]), ref.get_poses())
     ids, par = ref.get_particle_ids()
     for o in out:

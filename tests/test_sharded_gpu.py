@@ -168,6 +168,31 @@ def test_group_weight_sums_over_rccl_with_one_communicator(pkg):
     grp.close(); ref.close()
 
 
+def test_group_without_a_loadable_librccl_falls_back_to_host_sums(pkg, monkeypatch):
+    """a machine without librccl must get the host path with its reason -- not a crash in the note's construction
+    (dlerror() clears itself: the second call returned NULL into a std::string).  RFSGPU_RCCL_LIB names a file that does not exist;
+    the one-shard group over distinct ids then reports "host: librccl not loadable: ..." and still reproduces a plain handle."""
+    monkeypatch.setenv("RFSGPU_RCCL_LIB", "/nonexistent/librccl_missing.so")
+    sc = pkg.scenarios
+    n = 24
+    scen = sc.make_scenario(n, 40, 12, seed=33, params=dict(min_updates=1))
+    scen["particle_w"] = np.random.default_rng(4).uniform(0.2, 1.0, n)
+    ref = pkg.RBPHDFilter(n, device_id=0, gm_capacity=192)
+    grp = pkg.FilterGroup(n, [0], gm_capacity=192)
+    note = grp.collective()
+    assert note.startswith("host: librccl not loadable: "), note
+    assert len(note) > len("host: librccl not loadable: ")          # the loader's own message is there
+    for f in (ref, grp):
+        sc.load_scenario(f, scen)
+    ref.update(scen["Z"])
+    sums = grp.update(scen["Z"])
+    np.testing.assert_allclose(sums, ref.weight_sums(), rtol=1e-13)
+    grp.normalize()
+    ref.normalize_weights(ref.weight_sums()[0])
+    np.testing.assert_allclose(grp.get_weights(), ref.get_weights(), rtol=1e-13)
+    grp.close(); ref.close()
+
+
 def test_victoria_park_model_on_a_group_of_shards(pkg):
     """rfsgpu_group_set_model_victoriapark / _set_laser_scan / _get_timing (VERDICT r3 missing 5): configs[3]'s model on three shards
     of one GPU against one handle: two predict / update / normalise cycles and a forced global resampling in between (candidate
