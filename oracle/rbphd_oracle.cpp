@@ -790,10 +790,30 @@ static double partitions_likelihood(CostMatrixGeneral &cm, const std::vector<dou
         partition_likelihood = 0;
         double pll = 0;
         murty.setRealAssignmentBlock(nRows, nCols);
+        /* study hook (tools/murty_early_stop_study.py; RFSOR_MURTY_STUDY=<file>): per partition, the first call after which no later
+         * term can change the running sum (exp(score) < 2^-56 of it: below half an ulp with a factor 4 to spare), the calls the
+         * reference makes, and whether the returned scores ever INCREASED (the early stop's premise is that they do not). */
+        static const char *study = getenv("RFSOR_MURTY_STUDY");
+        int kStop = -1, kTotal = 0;
+        double prev = 0, maxInc = 0;
         for (int k = 0; k < 200; k++) {
           int rank = murty.findNextBest(a, pll);
           if (rank == -1 || pll < BIG_NEG_NUM) break;
-          partition_likelihood += exp(pll);
+          const double term = exp(pll);
+          partition_likelihood += term;
+          if (study) {
+            if (k > 0 && pll - prev > maxInc) maxInc = pll - prev;
+            prev = pll;
+            kTotal = k + 1;
+            if (kStop < 0 && term < partition_likelihood * 0x1p-56) kStop = k + 1;
+          }
+        }
+        if (study) {
+#pragma omp critical(murty_study)
+          {
+            FILE *fp = fopen(study, "a");
+            if (fp) { fprintf(fp, "%u %u %u %d %d %.3e\n", nRows + nCols, nRows, nCols, kStop, kTotal, maxInc); fclose(fp); }
+          }
         }
       } else {
         partition_likelihood = 0;
