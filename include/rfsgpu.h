@@ -21,14 +21,14 @@
  *   - "slot" = particle index 0..n_particles-1.
  *   - the engine fails loudly: there is NO CPU fallback anywhere behind this ABI.
  *
- * STABLE CORE -- the 23 entry points a reference-side binding needs; integration/RBPHDFilter_rfsgpu.hpp (the class template that
+ * STABLE CORE -- the 24 entry points a reference-side binding needs (round 5: + rfsgpu_update_io, the update with its inputs and outputs in one call); integration/RBPHDFilter_rfsgpu.hpp (the class template that
  * stands where rfs::RBPHDFilter stands, compiled under the unmodified reference drivers) uses 19 of them and nothing else
  * (tests/test_abi.py checks the list against the linked drivers):
  *   RFSGPU_CORE: rfsgpu_abi_version rfsgpu_create rfsgpu_destroy rfsgpu_last_error rfsgpu_default_filter_config
  *   RFSGPU_CORE: rfsgpu_set_filter_config rfsgpu_set_model_rngbrg rfsgpu_set_model_victoriapark rfsgpu_set_laser_scan
  *   RFSGPU_CORE: rfsgpu_set_kf_config rfsgpu_set_lmk_process_noise rfsgpu_set_poses rfsgpu_set_weights rfsgpu_get_weights
  *   RFSGPU_CORE: rfsgpu_predict_map rfsgpu_update rfsgpu_resample_apply rfsgpu_set_birth_inheritance rfsgpu_gm_size
- *   RFSGPU_CORE: rfsgpu_get_landmark rfsgpu_get_timing rfsgpu_set_phase_timing rfsgpu_synchronize
+ *   RFSGPU_CORE: rfsgpu_get_landmark rfsgpu_get_timing rfsgpu_set_phase_timing rfsgpu_synchronize rfsgpu_update_io
  * The same binding over SEVERAL GPUs (RFSGPU_DEVICES=0,1,...: integration/RBPHDFilter_rfsgpu.hpp, rfsgpu_engine_facade) uses the group
  * counterparts of those calls and nothing else:
  *   RFSGPU_CORE_MULTI: rfsgpu_group_create rfsgpu_group_destroy rfsgpu_group_last_error rfsgpu_group_set_filter_config
@@ -265,6 +265,13 @@ int rfsgpu_predict_map(rfsgpu_filter *f, int add_birth);
  * (unless useClusterProcess), merge, prune.  z: n_z x d_z doubles.  n_z == 0 returns OK without
  * touching anything (:450-452).  Resampling / normalisation stay with the caller (below). */
 int rfsgpu_update(rfsgpu_filter *f, const double *z, int n_z);
+/* RBPHDFilter::update (:444-541) with everything it consumes and returns in ONE synchronous call: [optionally the predict that
+ * precedes it, see rfsgpu_cycle_async: `predict` = RFSGPU_CYCLE_NO_PREDICT | 0 | 1], poses `x` (+ covariance; NULL = unchanged),
+ * particle weights `w_in` (NULL = unchanged), the measurement set, and the updated (un-normalised) weights back in `w_out`
+ * (NULL = not wanted).  One wait for the device, one error check: what set_poses + set_weights + update + get_weights do in four
+ * calls and two waits.  The reference-side binding's update() is this call. */
+int rfsgpu_update_io(rfsgpu_filter *f, int predict, const double *x, const double *x_cov, int cov_stride, const double *w_in,
+                     const double *z, int n_z, double *w_out);
 /* rfsgpu_update runs the 2-D model's step as ONE fused launch by default and books its time under TimingInfo::mapUpdate.
  * on != 0: the phases run as separate launches instead (updateMap, importanceWeighting, merge + prune), so that the
  * mapUpdate / particleWeighting / mapMerge buckets of RBPHDFilter::TimingInfo (:152-167) are filled separately, as the
@@ -284,6 +291,17 @@ int rfsgpu_update_async(rfsgpu_filter *f, const double *z, int n_z);
  * GPU) the weights are divided by the sum right there, otherwise the caller all-reduces the pair across its shards and calls
  * rfsgpu_normalize_weights.  Two launches per step (fused step + post) instead of five. */
 int rfsgpu_step_async(rfsgpu_filter *f, const double *z, int n_z, int normalize);
+/* One submission per predict + update cycle (round 5).  RBPHDFilter::predict's map part (include/RBPHDFilter.hpp:415-442: birth
+ * Gaussians at the poses the previous update used, then StaticProcessModel::staticStep) -- `predict` = 1 with births, 0 without,
+ * RFSGPU_CYCLE_NO_PREDICT for none --, then the host's new poses `x` (+ covariance; NULL = unchanged) and particle weights `w_in`
+ * (NULL = unchanged), then RBPHDFilter::update's body (:444-523) with the post kernel's weight sums / division as in
+ * rfsgpu_step_async.  Stream-ordered, the caller's buffers are copied before the call returns.  Where the configuration allows it
+ * (2-D model, immediate births, no inheritance walk pending, n_z > 0) the predict runs at the head of the fused step kernel --
+ * one launch chain per cycle, no separate predict launch; otherwise the stand-alone kernels are enqueued in the same order.
+ * Same results either way as rfsgpu_predict_map + rfsgpu_set_poses + rfsgpu_set_weights + rfsgpu_step_async. */
+#define RFSGPU_CYCLE_NO_PREDICT (-1)
+int rfsgpu_cycle_async(rfsgpu_filter *f, int predict, const double *x, const double *x_cov, int cov_stride, const double *w_in,
+                       const double *z, int n_z, int normalize);
 /* The host side of an asynchronous filter loop (what the Victoria Park driver needs per lidar message: one call for the
  * inputs, one for the step, no host wait -- src/rbphdslam_VictoriaPark.cpp:555-583):
  *   rfsgpu_set_step_inputs_async  poses (+ covariance; x == NULL leaves them) and, Victoria Park model, the laser scan
@@ -329,6 +347,11 @@ double rfsgpu_post_kernel_avg_ns(const rfsgpu_filter *f);
 int rfsgpu_set_step_timing_stride(rfsgpu_filter *f, int every);
 #endif /* RFSGPU_ENABLE_BENCH_API */
 /* The same four phases one at a time (used by the parity tests and by profiling):          */
+/* [test] Murty-200 partition sums of n_jobs given extended tables (n_k x n_k row-major, back to back, n_k = nR[k] + nC[k] <= 64) by the
+ * step's own post kernel: sums_out[k] = the sum of exp(score) over the <= 200 best assignments Murty returns with
+ * setRealAssignmentBlock(nR, nC) (include/RBPHDFilter.hpp:942-959, src/MurtyAlgorithm.cpp:141-336).  The handle's weights are
+ * left as they were.  (tests/test_gpu_parity.py pins it to the reference's BruteForceLinearAssignment fixture.) */
+int rfsgpu_murty_partition_sums(rfsgpu_filter *f, const double *mats, const int *nR, const int *nC, int n_jobs, double *sums_out);
 int rfsgpu_update_map(rfsgpu_filter *f, const double *z, int n_z);      /* updateMap       :543-725 */
 int rfsgpu_importance_weighting(rfsgpu_filter *f);                       /* importanceWeighting :728-997 */
 int rfsgpu_merge(rfsgpu_filter *f);                                      /* GaussianMixture::merge  GaussianMixture.hpp:394-475 */

@@ -1109,13 +1109,14 @@ __global__ __launch_bounds__(256) void restore_state_kernel(Buffers B, int cur, 
 // measurements at the current (pre-propagation) pose -- immediate-birth branch of addBirthGaussians
 // (:1000-1084) with MeasurementModel_RngBrg::inverseMeasure (src/MeasurementModel_RngBrg.cpp:117-136) --
 // then StaticProcessModel::staticStep, Sigma += Q (include/ProcessModel.hpp:195-208).
-template <int WPB>
-__global__ __launch_bounds__(WPB * 64) void predict_map_kernel(Buffers B, Params P, int cur, int addBirth, int nZprev, BirthLevel LV) {
-  const int wave = threadIdx.x >> 6;
-  const int lane = threadIdx.x & 63;
-  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
-  if (i >= B.N) return;
-  addBirth = addBirth && LV.mine(i);
+// One particle's share of it, by NT threads (tid 0 ... NT-1; the births are lane work of the first wavefront, the static step is
+// spread over all threads).  birthPose: the poses the births happen at -- the ones the previous update used (the reference adds
+// the birth Gaussians before it propagates the particles, :424-431).  The stand-alone kernel below and the head of the fused
+// cycle (step_fused.h, round 5) both run THIS function: same expressions, same bits.
+template <int NT>
+__device__ __forceinline__ void predict_map_particle(const Buffers &B, const Params &P, const int cur, const int i, const int tid, bool addBirth,
+                                                     const int nZprev, const double *birthPose, const bool doStatic) {
+  const int lane = tid & 63;
   const int cap = B.cap;
   double *slab = B.slab[cur];
   double *pW = plane(slab, cap, i, PL_W), *pWP = plane(slab, cap, i, PL_WP), *pMX = plane(slab, cap, i, PL_MX),
@@ -1123,7 +1124,7 @@ __global__ __launch_bounds__(WPB * 64) void predict_map_kernel(Buffers B, Params
   double *pSXX = plane(slab, cap, i, PL_SXX), *pSXY = plane(slab, cap, i, PL_SXY), *pSYY = plane(slab, cap, i, PL_SYY);
   int n = B.count[i];
   const int nOld = n;  // staticStep below covers the pre-existing Gaussians; births get Q added where they are created
-  if (addBirth && nZprev > 0) {
+  if (addBirth && nZprev > 0 && tid < 64) {
     const unsigned long long um = B.unusedMask[i];
     const bool immediate = (P.birthCountThr == 1u) || ((unsigned)B.nInFov[i] <= P.birthCurThr);
     if (um != 0ull && !immediate) {
@@ -1136,7 +1137,7 @@ __global__ __launch_bounds__(WPB * 64) void predict_map_kernel(Buffers B, Params
       if (mine) {
         const int pos = n + rankFromTop;
         if (pos < cap) {
-          const double px = B.pose[3 * i], py = B.pose[3 * i + 1], pth = B.pose[3 * i + 2];
+          const double px = birthPose[3 * i], py = birthPose[3 * i + 1], pth = birthPose[3 * i + 2];
           const double zr = B.Z[2 * lane], zb = B.Z[2 * lane + 1];
           const double a = pth + zb;
           const double ca = cos(a), sa = sin(a);
@@ -1163,11 +1164,19 @@ __global__ __launch_bounds__(WPB * 64) void predict_map_kernel(Buffers B, Params
       if (lane == 0) { B.count[i] = n; B.unusedMask[i] = 0ull; }
     }
   }
-  if (!LV.doStatic) return;
-  for (int m = lane; m < nOld; m += 64) {
+  if (!doStatic) return;
+  for (int m = tid; m < nOld; m += NT) {
     pSXX[m] += P.Qlm[0];
     pSXY[m] += P.Qlm[1];
     pSYY[m] += P.Qlm[2];
   }
+}
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64) void predict_map_kernel(Buffers B, Params P, int cur, int addBirth, int nZprev, BirthLevel LV) {
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
+  if (i >= B.N) return;
+  predict_map_particle<64>(B, P, cur, i, lane, addBirth && LV.mine(i), nZprev, B.pose, LV.doStatic != 0);
 }
 

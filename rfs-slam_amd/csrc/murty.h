@@ -24,7 +24,7 @@
 // measured at configs[4] (1918 jobs of dimension 9-15), barrier form: 1 wave 26.8 ms, 2: 16.5, 3: 15.4, 4: 15.1; search wave + solvers
 // (murty_kbest_async) at the compiler's 92 VGPRs (5 waves per SIMD): 3: 8.9, 4: 6.3, 5: 7.8, 6: 8.9, 8: 8.4; capped at 64 VGPRs
 // (MURTY_WAVES_PER_EU 8: 100 B of scratch per lane, 1280 six-wave workgroups on the GPU at once): 4: 6.6, 5: 5.7, 6: 5.5, 7: 8.6, 8: 5.6
-#define MURTY_JOB_WAVES 6
+#define MURTY_JOB_WAVES 8   // (round 5, after the early end of the loop made the jobs 2.5x shorter: 6: 2.96 ms, 8: 2.50, 10: 3.1, 12: 5.3; with 16 table slots and three peeked heap positions 8: 2.25)
 #endif
 #define MURTY_CT_WAVES (MURTY_JOB_WAVES > 4 ? MURTY_JOB_WAVES : 4)   /* (the multi-hypothesis FastSLAM search uses up to four waves on the same arena) */
 
@@ -420,7 +420,7 @@ __device__ __forceinline__ void murty_kbest_block(double *C, int n, int partitio
 #define MURTY_QUAD 0           // 1: jobs of extended dimension <= 16 get solver waves of four 16-lane solvers each (hungarian_quad.h) -- bit-identical, measured slower, opt-in
 #endif
 #ifndef MURTY_SPEC_SLOTS
-#define MURTY_SPEC_SLOTS (MURTY_QUAD ? 16 : 8)
+#define MURTY_SPEC_SLOTS 16
 #endif
 #ifndef MURTY_SOLVER_SLEEP
 #define MURTY_SOLVER_SLEEP 4   // x 64 cycles between two looks at the mailbox (1 ... 64 measured at configs[4]: 6.37-6.44 ms, no trend)
@@ -429,7 +429,7 @@ __device__ __forceinline__ void murty_kbest_block(double *C, int n, int partitio
 #define MURTY_SEARCH_SLEEP 2
 #endif
 #ifndef MURTY_PEEK
-#define MURTY_PEEK (MURTY_QUAD ? 3 : 2)   // heap positions whose children are solved ahead of their pop when solvers are free
+#define MURTY_PEEK 5   // heap positions whose children are solved ahead of their pop when solvers are free (round 5, eight waves per job, 16 table slots: 2: 2.33 ms, 3: 2.25, 5: 2.16, 7: 2.49)
 #endif
 #define MURTY_VSOLVERS (MURTY_QUAD ? 4 * (MURTY_CT_WAVES - 1) : (MURTY_CT_WAVES - 1))   /* mailboxes 1..MURTY_VSOLVERS */
 struct MurtySpec {
@@ -439,7 +439,7 @@ struct MurtySpec {
   int doneSeq[MURTY_VSOLVERS + 1];       // solver v -> wave 0: tasks finished so far
   int taskNode[MURTY_VSOLVERS + 1], taskC[MURTY_VSOLVERS + 1], taskSlot[MURTY_VSOLVERS + 1];
   int quit;
-  int peekNode[4], peekPart[4];
+  int peekNode[8], peekPart[8];
   unsigned char pushed[MURTY_SPEC_SLOTS];
   unsigned char a[MURTY_SPEC_SLOTS][MURTY_N];
 };
@@ -550,12 +550,28 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
         const int parent = mheap_pop(H, hl);
         ctl[0] = parent; ctl[1] = A.nodeId[parent]; ctl[3] = hl;
         // the nodes a coming pop is most likely to take: the new top, then the better of its two children, then the other one
-        const int b1 = (hl > 0) ? (int)mheap_id(H, 0) : -1;
-        int b2 = (hl > 1) ? (int)mheap_id(H, 1) : -1, b3 = (hl > 2) ? (int)mheap_id(H, 2) : -1;
-        if (b3 >= 0 && mheap_sc(H, 2) > mheap_sc(H, 1)) { const int tmp = b2; b2 = b3; b3 = tmp; }
-        spec->peekNode[0] = b1; spec->peekPart[0] = (b1 >= 0) ? (int)A.nodeId[b1] : 0;
-        spec->peekNode[1] = b2; spec->peekPart[1] = (b2 >= 0) ? (int)A.nodeId[b2] : 0;
-        spec->peekNode[2] = b3; spec->peekPart[2] = (b3 >= 0) ? (int)A.nodeId[b3] : 0;
+        // (MURTY_PEEK > 3: the heap's first three levels, positions 0 ... 6, by score -- the exact top three and a good guess beyond)
+        if constexpr (MURTY_PEEK <= 3) {
+          const int b1 = (hl > 0) ? (int)mheap_id(H, 0) : -1;
+          int b2 = (hl > 1) ? (int)mheap_id(H, 1) : -1, b3 = (hl > 2) ? (int)mheap_id(H, 2) : -1;
+          if (b3 >= 0 && mheap_sc(H, 2) > mheap_sc(H, 1)) { const int tmp = b2; b2 = b3; b3 = tmp; }
+          spec->peekNode[0] = b1; spec->peekPart[0] = (b1 >= 0) ? (int)A.nodeId[b1] : 0;
+          spec->peekNode[1] = b2; spec->peekPart[1] = (b2 >= 0) ? (int)A.nodeId[b2] : 0;
+          spec->peekNode[2] = b3; spec->peekPart[2] = (b3 >= 0) ? (int)A.nodeId[b3] : 0;
+        } else {
+          static_assert(MURTY_HEAP_LDS >= 7 && MURTY_PEEK <= 7, "the peeked positions live in the LDS part of the heap");
+          int id[7];
+          double sc[7];
+#pragma unroll
+          for (int q = 0; q < 7; q++) { id[q] = (q < hl) ? (int)H.lid[q] : -1; sc[q] = (q < hl) ? H.lsc[q] : -1.7976931348623157e308; }
+#pragma unroll
+          for (int a = 1; a < 7; a++)          // insertion sort by score, descending (position 0 is the maximum already)
+#pragma unroll
+            for (int b = a; b > 1; b--)
+              if (sc[b] > sc[b - 1]) { const double ts = sc[b]; sc[b] = sc[b - 1]; sc[b - 1] = ts; const int ti = id[b]; id[b] = id[b - 1]; id[b - 1] = ti; }
+#pragma unroll
+          for (int q = 0; q < MURTY_PEEK; q++) { spec->peekNode[q] = id[q]; spec->peekPart[q] = (id[q] >= 0) ? (int)A.nodeId[id[q]] : 0; }
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (also: the nodes pushed so far are visible to the solvers before any task names them)
       __builtin_amdgcn_wave_barrier();

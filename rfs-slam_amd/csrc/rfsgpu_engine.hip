@@ -68,6 +68,7 @@ struct rfsgpu_filter {
   int rowSlotsCap = 0;
   double *hStage[4] = {nullptr, nullptr, nullptr, nullptr};  // pinned staging ring of rfsgpu_set_step_inputs_async
   double *hWeights = nullptr;         // pinned landing buffer of rfsgpu_get_weights
+  double *poseAlt = nullptr;          // [Ncap][3] second pose buffer: a fused predict + update cycle births at the old poses and updates at the new ones (rfsgpu_cycle_async)
   hipEvent_t evStage[4] = {};
   int stageNext = 0;
   bool predPending = false;  // rfsgpu_predict_map_async's event pair has not been accumulated yet
@@ -286,6 +287,7 @@ int rfsgpu_create_ex(rfsgpu_filter **out, int model, int n_particles, int device
   ok &= hipMalloc(&B.count, f->Ncap * sizeof(int)) == hipSuccess;
   ok &= hipMalloc(&B.pose, (size_t)f->Ncap * 3 * sizeof(double)) == hipSuccess;
   ok &= hipMalloc(&B.poseCov, (size_t)f->Ncap * 9 * sizeof(double)) == hipSuccess;
+  ok &= hipMalloc(&f->poseAlt, (size_t)f->Ncap * 3 * sizeof(double)) == hipSuccess;
   ok &= hipMalloc(&B.weight, f->Ncap * sizeof(double)) == hipSuccess;
   ok &= hipMalloc(&B.unusedMask, f->Ncap * sizeof(unsigned long long)) == hipSuccess;
   ok &= hipMalloc(&B.nInFov, f->Ncap * sizeof(int)) == hipSuccess;
@@ -345,7 +347,7 @@ void rfsgpu_destroy(rfsgpu_filter *f) {
   if (f->ownStream) hipStreamSynchronize(f->ownStream);
   Buffers &B = f->B;
   hipFree(f->snapSlab); hipFree(f->snapWeight); hipFree(f->snapCount); hipFree(f->snapFov); hipFree(f->snapUnused);
-  hipFree(B.slab[0]); hipFree(B.slab[1]); hipFree(B.count); hipFree(B.pose); hipFree(B.poseCov); hipFree(B.weight);
+  hipFree(B.slab[0]); hipFree(B.slab[1]); hipFree(B.count); hipFree(B.pose); hipFree(f->poseAlt); hipFree(B.poseCov); hipFree(B.weight);
   hipFree(B.unusedMask); hipFree(B.nInFov); hipFree(B.err); hipFree(B.Z); hipFree(f->ownSums); hipFree(f->dSrcSlot); if (f->dRowSlots) hipFree(f->dRowSlots); if (f->fsArena) hipFree(f->fsArena); if (f->mhArena) hipFree(f->mhArena); if (f->mhInts) hipFree(f->mhInts);
   if (f->dInhParent) hipFree(f->dInhParent);
   if (f->dInhLevel) hipFree(f->dInhLevel);
@@ -378,6 +380,34 @@ int rfsgpu_set_partition_mode(rfsgpu_filter *f, int mode) {
   if (mode != RFSGPU_PARTITION_MURTY200 && mode != RFSGPU_PARTITION_EXACT) return fail(f, RFSGPU_ERR_INVALID, "unknown partition mode");
   f->P.exactPartitions = mode == RFSGPU_PARTITION_EXACT ? 1 : 0;
   return RFSGPU_OK;
+}
+// [test] The Murty-200 partition sums of given extended tables by the step's own post kernel (murty_jobs_kernel): what
+// rfsMeasurementLikelihood's loop (include/RBPHDFilter.hpp:942-959) leaves in partition_likelihood for each table.  The tables
+// go into the handle's job queue exactly as the weighting phase writes them (n x n row-major, n = nR + nC, slot k), the kernel
+// runs once, the results come back; the particle weights are put back afterwards (the kernel multiplies the factors into them).
+int rfsgpu_murty_partition_sums(rfsgpu_filter *f, const double *mats, const int *nR, const int *nC, int n_jobs, double *sums_out) {
+  CHECK_HANDLE(f);
+  if (!mats || !nR || !nC || !sums_out || n_jobs < 1 || n_jobs > f->Q.maxJobs) return fail(f, RFSGPU_ERR_INVALID, "murty_partition_sums: bad arguments");
+  hipSetDevice(f->device);
+  HIPCHK(hipStreamSynchronize(f->stream));
+  std::vector<double> w((size_t)f->N);
+  HIPCHK(hipMemcpy(w.data(), f->B.weight, (size_t)f->N * sizeof(double), hipMemcpyDeviceToHost));
+  std::vector<MurtyJob> jobs((size_t)n_jobs);
+  size_t off = 0;
+  for (int k = 0; k < n_jobs; k++) {
+    const int n = nR[k] + nC[k];
+    if (nR[k] < 0 || nC[k] < 0 || n < 1 || n > MURTY_N) return fail(f, RFSGPU_ERR_INVALID, "murty_partition_sums: extended dimension out of range");
+    jobs[k].particle = k % f->N; jobs[k].nR = nR[k]; jobs[k].nC = nC[k]; jobs[k].slot = k / f->N;
+    HIPCHK(hipMemcpy(f->Q.mats + (size_t)k * MURTY_MAXN * MURTY_MAXN, mats + off, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice));
+    off += (size_t)n * n;
+  }
+  HIPCHK(hipMemcpy(f->Q.jobs, jobs.data(), (size_t)n_jobs * sizeof(MurtyJob), hipMemcpyHostToDevice));
+  const int cnt[2] = {n_jobs, 0};
+  HIPCHK(hipMemcpy(f->Q.count, cnt, sizeof(cnt), hipMemcpyHostToDevice));
+  if (murty_launch(f->Q, f->MS, f->B, f->stream, nullptr, 0, nullptr, 0, f->hJobCount) != 0) return fail(f, RFSGPU_ERR_HIP, "murty launch failed");
+  HIPCHK(hipMemcpyAsync(sums_out, f->Q.results, (size_t)n_jobs * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  HIPCHK(hipMemcpyAsync(f->B.weight, w.data(), (size_t)f->N * sizeof(double), hipMemcpyHostToDevice, f->stream));
+  return check_device_errors(f);
 }
 int rfsgpu_get_partition_mode(const rfsgpu_filter *f) { return f ? (f->P.exactPartitions ? RFSGPU_PARTITION_EXACT : RFSGPU_PARTITION_MURTY200) : -1; }
 int rfsgpu_get_filter_config(const rfsgpu_filter *f, rfsgpu_filter_config *c) {
@@ -460,7 +490,7 @@ int rfsgpu_set_lmk_process_noise(rfsgpu_filter *f, const double *Q) {
 static int stage_slot(rfsgpu_filter *f, double **h, int *k_out) {
   const int k = f->stageNext;
   f->stageNext = (k + 1) & 3;
-  const size_t slotDoubles = (size_t)f->Ncap * 12 + RFSGPU_VP_MAX_SCAN;
+  const size_t slotDoubles = (size_t)f->Ncap * 13 + RFSGPU_VP_MAX_SCAN;   // poses | pose covariances | weights | laser scan
   const bool fresh = !f->hStage[k] || !f->evStage[k];   // (either creation may have failed on an earlier call: each is retried on its own)
   if (!f->hStage[k]) HIPCHK(hipHostMalloc(&f->hStage[k], slotDoubles * sizeof(double)));
   if (!f->evStage[k]) HIPCHK(hipEventCreateWithFlags(&f->evStage[k], hipEventDisableTiming));
@@ -895,7 +925,7 @@ int rfsgpu_prune(rfsgpu_filter *f) {
 }
 
 // All four phases back to back on the stream, ONE host sync at the end (RBPHDFilter::update body :444-523).
-static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool with_sums, int normalize);
+static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool with_sums, int normalize, const StepPredict &sp = StepPredict{0, 0, nullptr});
 int rfsgpu_update(rfsgpu_filter *f, const double *z, int n_z) {
   CHECK_HANDLE(f);
   f->holes = false;
@@ -966,7 +996,7 @@ static void harvest_async(rfsgpu_filter *f) {
 
 // Shared body of the stream-ordered steps.  with_sums: the step's post kernel also leaves {sum w, sum w^2} in the bound sums
 // buffer (and divides the weights by the sum when normalize != 0).
-static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool with_sums, int normalize) {
+static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool with_sums, int normalize, const StepPredict &sp) {
   f->holes = false;
   if (n_z == 0) return RFSGPU_OK;  // :450-452
   long long t0 = now_ns();
@@ -1006,12 +1036,21 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
     // phase priorities only when every workgroup is resident at once: 16 waves per CU at 128 VGPRs, LDS permitting
     const int perCU = (int)std::min<size_t>(16 / wpp, b ? (size_t)(160 * 1024) / b : 16);
     const int phasePrio = (long long)perCU * f->nCU >= f->N ? 1 : 0;
-    f->lastStepVariant[0] = wpp; f->lastStepVariant[1] = phasePrio; f->lastStepVariant[2] = 5; f->lastStepVariant[3] = 1;
+    f->lastStepVariant[0] = wpp; f->lastStepVariant[1] = phasePrio; f->lastStepVariant[2] = 5; f->lastStepVariant[3] = sp.mode ? 2 : 1;   // ([3]: 1 = fused step, 2 = fused step with the predict at its head)
+    // (one instantiation per {waves per particle, phase priorities, merge grid} x {plain step, step with the predict at its head})
+#define STEP_LAUNCH(WPPV, PRIO, GLV, BYTES)                                                                                            \
+    do {                                                                                                                                \
+      if (sp.mode) {                                                                                                                    \
+        if ((rc = set_lds(f, (phd_step_fused_kernel<WPPV, PRIO, GLV, true>), BYTES)) != RFSGPU_OK) return rc;                           \
+        phd_step_fused_kernel<WPPV, PRIO, GLV, true><<<f->N, WPPV * 64, BYTES, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za, sp);  \
+      } else {                                                                                                                          \
+        if ((rc = set_lds(f, (phd_step_fused_kernel<WPPV, PRIO, GLV, false>), BYTES)) != RFSGPU_OK) return rc;                          \
+        phd_step_fused_kernel<WPPV, PRIO, GLV, false><<<f->N, WPPV * 64, BYTES, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za, sp); \
+      }                                                                                                                                 \
+    } while (0)
     if (wpp == 2) {
-      if ((rc = set_lds(f, (phd_step_fused_kernel<2, true>), b)) != RFSGPU_OK) return rc;
-      if ((rc = set_lds(f, (phd_step_fused_kernel<2, false>), b)) != RFSGPU_OK) return rc;
-      if (phasePrio) phd_step_fused_kernel<2, true><<<f->N, 128, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
-      else phd_step_fused_kernel<2, false><<<f->N, 128, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
+      if (phasePrio) STEP_LAUNCH(2, true, 5, b);
+      else STEP_LAUNCH(2, false, 5, b);
     } else {
       // the 64 x 64 merge grid where its 6 KB of extra cursors leave as many three-wave workgroups resident (merge_prune.h);
       // RFSGPU_MERGE_GRID = 5 | 6 overrides
@@ -1021,17 +1060,14 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
       if (fine) {
         const int prio6 = (long long)perCU6 * f->nCU >= f->N ? 1 : 0;
         f->lastStepVariant[1] = prio6; f->lastStepVariant[2] = 6;
-        if ((rc = set_lds(f, (phd_step_fused_kernel<3, true, 6>), b6)) != RFSGPU_OK) return rc;
-        if ((rc = set_lds(f, (phd_step_fused_kernel<3, false, 6>), b6)) != RFSGPU_OK) return rc;
-        if (prio6) phd_step_fused_kernel<3, true, 6><<<f->N, 192, b6, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
-        else phd_step_fused_kernel<3, false, 6><<<f->N, 192, b6, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
+        if (prio6) STEP_LAUNCH(3, true, 6, b6);
+        else STEP_LAUNCH(3, false, 6, b6);
       } else {
-        if ((rc = set_lds(f, (phd_step_fused_kernel<3, true>), b)) != RFSGPU_OK) return rc;
-        if ((rc = set_lds(f, (phd_step_fused_kernel<3, false>), b)) != RFSGPU_OK) return rc;
-        if (phasePrio) phd_step_fused_kernel<3, true><<<f->N, 192, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
-        else phd_step_fused_kernel<3, false><<<f->N, 192, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
+        if (phasePrio) STEP_LAUNCH(3, true, 5, b);
+        else STEP_LAUNCH(3, false, 5, b);
       }
     }
+#undef STEP_LAUNCH
     HIPCHK(hipGetLastError());
     if (timed) HIPCHK(hipEventRecord(e[3], f->stream));
     if (murty_launch(f->Q, f->MS, f->B, f->stream, with_sums ? f->dSums : nullptr, normalize, &za, 2 * n_z, f->hJobCount) != 0) return fail(f, RFSGPU_ERR_HIP, "post kernel launch failed");
@@ -1118,6 +1154,98 @@ int rfsgpu_step_async(rfsgpu_filter *f, const double *z, int n_z, int normalize)
     return normalize ? rfsgpu_normalize_weights(f, 0.0, f->dSums) : RFSGPU_OK;
   }
   return update_async_impl(f, z, n_z, true, normalize);
+}
+
+// ---- one submission per predict + update cycle (round 5) --------------------------------------------------------------------
+// RBPHDFilter::predict's map part (:415-442) + the host's new poses / weights + RBPHDFilter::update's body (:444-523) as ONE
+// stream-ordered chain.  Where the configuration allows it the predict runs at the head of the fused step kernel
+// (step_fused.h): 2-D model, immediate births (no candidate lists), no slot-ordered inheritance walk pending, fused steps on, a
+// non-empty measurement set; the births then read the OLD poses from the buffer the previous update used while the update reads
+// the new ones from the other buffer (the two swap roles).  Otherwise the same calls a host would make one by one are issued
+// here, in the reference's order: predict kernels, input copies, step.  Either way the results are those of
+// rfsgpu_predict_map + rfsgpu_set_poses + rfsgpu_set_weights + rfsgpu_step_async, bit for bit.
+static void ensure_ids(rfsgpu_filter *f);
+static int cycle_impl(rfsgpu_filter *f, int predict, const double *x, const double *cov, int cov_stride, const double *w_in, const double *z, int n_z,
+                      bool with_sums, int normalize) {
+  if (predict < -1 || predict > 1) return fail(f, RFSGPU_ERR_INVALID, "cycle: predict is RFSGPU_CYCLE_NO_PREDICT (-1), 0 (static step only) or 1 (births + static step)");
+  if (cov && cov_stride != 0 && cov_stride != 9) return fail(f, RFSGPU_ERR_INVALID, "cycle: cov_stride must be 0 or 9");
+  if (n_z < 0 || n_z > RFSGPU_MAX_Z || (n_z > 0 && !z)) return fail(f, RFSGPU_ERR_INVALID, "cycle: bad measurement set");
+  hipSetDevice(f->device);
+  bool fuse = predict >= 0 && n_z > 0 && f->D == 2 && f->fuseSteps && !f->phaseTiming && f->cfg.birthGaussianMeasurementCountThreshold == 1u && !f->fastSlamHandle;
+  if (fuse && predict == 1 && f->resampleOccured) {
+    if (f->inheritMode == RFSGPU_INHERIT_REFERENCE) {      // a slot with a foreign parent: the level-ordered walk, stand-alone kernels
+      ensure_ids(f);
+      for (int i = 0; i < f->N && fuse; i++) fuse = f->ppid[i] == i || f->ppid[i] < 0 || f->ppid[i] >= f->N;
+    } else if (f->inheritMode == RFSGPU_INHERIT_EXTERNAL && !f->externalAck) {
+      fuse = false;                                        // (rfsgpu_predict_map_async below refuses with the full message)
+    }
+  }
+  if (predict >= 0 && !fuse) { const int rc = rfsgpu_predict_map_async(f, predict); if (rc != RFSGPU_OK) return rc; }
+  StepPredict sp{0, 0, nullptr};
+  if (fuse) { sp.mode = predict ? 2 : 1; sp.nZprev = f->nZ; sp.birthPose = f->B.pose; }
+  if (x || w_in) {
+    double *h = nullptr;
+    int k = 0;
+    { const int rc = stage_slot(f, &h, &k); if (rc != RFSGPU_OK) return rc; }
+    if (x) {
+      double *dst = fuse ? f->poseAlt : f->B.pose;         // fused: the births still need the old poses
+      memcpy(h, x, (size_t)f->N * 3 * sizeof(double));
+      HIPCHK(hipMemcpyAsync(dst, h, (size_t)f->N * 3 * sizeof(double), hipMemcpyHostToDevice, f->stream));
+      if (fuse) { f->poseAlt = f->B.pose; f->B.pose = dst; }
+      double *hc = h + (size_t)f->Ncap * 3;
+      if (cov) {                                           // (the births do not read the pose covariance: in place)
+        const size_t n = cov_stride == 9 ? (size_t)f->N * 9 : 9;
+        memcpy(hc, cov, n * sizeof(double));
+        HIPCHK(hipMemcpyAsync(f->B.poseCov, hc, n * sizeof(double), hipMemcpyHostToDevice, f->stream));
+        f->P.poseCovStride = cov_stride;
+        f->poseCovZero = false;
+      } else {
+        if (!f->poseCovZero) {
+          memset(hc, 0, 9 * sizeof(double));
+          HIPCHK(hipMemcpyAsync(f->B.poseCov, hc, 9 * sizeof(double), hipMemcpyHostToDevice, f->stream));
+          f->poseCovZero = true;
+        }
+        f->P.poseCovStride = 0;
+      }
+    }
+    if (w_in) {
+      double *hw = h + (size_t)f->Ncap * 12;
+      memcpy(hw, w_in, (size_t)f->N * sizeof(double));
+      HIPCHK(hipMemcpyAsync(f->B.weight, hw, (size_t)f->N * sizeof(double), hipMemcpyHostToDevice, f->stream));
+    }
+    HIPCHK(hipEventRecord(f->evStage[k], f->stream));
+  }
+  if (n_z == 0) {       // no update (:450-452); the weights are still summed / normalised as the caller asked
+    if (!with_sums) return RFSGPU_OK;
+    const int rc = rfsgpu_weight_sums_async(f);
+    if (rc != RFSGPU_OK) return rc;
+    return normalize ? rfsgpu_normalize_weights(f, 0.0, f->dSums) : RFSGPU_OK;
+  }
+  return update_async_impl(f, z, n_z, with_sums, normalize, sp);
+}
+int rfsgpu_cycle_async(rfsgpu_filter *f, int predict, const double *x, const double *x_cov, int cov_stride, const double *w_in, const double *z, int n_z,
+                       int normalize) {
+  CHECK_HANDLE(f);
+  return cycle_impl(f, predict, x, x_cov, cov_stride, w_in, z, n_z, true, normalize);
+}
+// The synchronous form for a host that stands where RBPHDFilter::update stands (:444-541): everything the update consumes goes in,
+// the particle weights come back, ONE wait for the device and one error check -- in place of set_poses + set_weights + update +
+// get_weights (four calls, two waits: 199 us per update at configs[1] against 125 us stream-ordered, bench.py `boundary`).
+int rfsgpu_update_io(rfsgpu_filter *f, int predict, const double *x, const double *x_cov, int cov_stride, const double *w_in, const double *z, int n_z,
+                     double *w_out) {
+  CHECK_HANDLE(f);
+  long long t0 = now_ns();
+  int rc = cycle_impl(f, predict, x, x_cov, cov_stride, w_in, z, n_z, false, 0);
+  if (rc != RFSGPU_OK) return rc;
+  if (w_out) {
+    if (!f->hWeights) HIPCHK(hipHostMalloc(&f->hWeights, (size_t)f->Ncap * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(f->hWeights, f->B.weight, (size_t)f->N * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  }
+  rc = check_device_errors(f);      // the one wait (error word + weights land together)
+  harvest_async(f);
+  if (w_out) memcpy(w_out, f->hWeights, (size_t)f->N * sizeof(double));
+  f->timing.mapUpdate_cpu += now_ns() - t0;
+  return rc;
 }
 
 int rfsgpu_kernel_time_stats(rfsgpu_filter *f, double *avg_ns3, int *n_steps) {
@@ -1381,7 +1509,7 @@ int rfsgpu_set_step_inputs_async(rfsgpu_filter *f, const double *x, const double
     area += scan[0] * scan[n_scan - 1];
     area *= sin(acos(-1) / 360) / 2;
     f->vpClutter = f->vp.expectedClutterNumber / area;
-    double *hs = h + (size_t)f->Ncap * 12;
+    double *hs = h + (size_t)f->Ncap * 13;
     memcpy(hs, scan, (size_t)n_scan * sizeof(double));
     HIPCHK(hipMemcpyAsync(f->B.scan, hs, (size_t)n_scan * sizeof(double), hipMemcpyHostToDevice, f->stream));
     f->B.nScan = n_scan;

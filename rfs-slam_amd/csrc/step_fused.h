@@ -18,6 +18,12 @@
 #ifndef STEP_WPP
 #define STEP_WPP 2
 #endif
+// The predict folded into the head of a step (rfsgpu_cycle_async): 0 = none, 1 = static step only, 2 = births + static step.
+struct StepPredict {
+  int mode;
+  int nZprev;                // measurements of the previous update (B.Z holds them until this step's post kernel)
+  const double *birthPose;   // [N][3] the poses the previous update used
+};
 #ifndef STEP_WAVES_PER_EU
 #define STEP_WAVES_PER_EU 4  // <= 128 VGPRs: 8 workgroups of 2 waves per CU, i.e. all 2000 particles of C2 resident at once
 #endif
@@ -37,13 +43,27 @@ __host__ __device__ inline size_t step_fused_lds_total(int cap, int evalCap, int
 
 // useWeighting == 0: SC-PHD (useClusterProcess_): the particle weight comes out of the map update, the mixture is not
 // sorted, merge works on the slab the update wrote.
-template <int WPP, bool PHASE_PRIO, int GL = 5>
+// PRED: the instantiation with the predict at its head (a template parameter, not a run-time branch: the births' sin / cos bring
+// 60 B of scratch per lane into the kernel, and the plain step -- configs[1]'s headline -- lost 10 us to it when both shared one body;
+// the head as a real call with its own register allocation: C2b 0.112 -> 0.208 ms per cycle, profiles/r05a_*).
+template <int WPP, bool PHASE_PRIO, int GL = 5, bool PRED = false>
 __global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(STEP_WAVES_PER_EU)))
-void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, int useWeighting, MurtyQueue Q, ZArg zarg) {
+void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, int useWeighting, MurtyQueue Q, ZArg zarg, StepPredict SP) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int i = blockIdx.x;
+  // Round 5: the map part of the PREDICT that precedes this update (RBPHDFilter::predict, include/RBPHDFilter.hpp:415-442 -- birth
+  // Gaussians from the previous update's unused measurements at the poses that update used, then Sigma += Q on every Gaussian,
+  // include/ProcessModel.hpp:195-208) runs at the head of the step, by the workgroup that owns the particle: one launch chain per
+  // predict + update cycle, and the covariances the static step rewrites are still in L2 when the map update reads them.  The
+  // function is the stand-alone predict kernel's (merge_prune.h, predict_map_particle): same bits.  B.Z still holds the PREVIOUS
+  // measurement set here (this step's post kernel writes the new one).
+  if constexpr (PRED) {
+    predict_map_particle<WPP * 64>(B, P, cur, i, tid, SP.mode > 1, SP.nZprev, SP.birthPose, true);
+    __threadfence_block();
+    __syncthreads();
+  }
   // Issue priority falls from phase to phase (s_setprio 2/3 -> 1 -> 0): the SIMD arbiter otherwise always prefers its oldest waves, so the
   // last workgroups to arrive on a CU crawl through the map update while the first ones race ahead, and the launch lasts as
   // long as those stragglers.  With a workgroup that is a phase behind outranking the ones ahead, the eight workgroups of

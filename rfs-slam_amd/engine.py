@@ -82,6 +82,46 @@ class RBPHDFilter(capi.CFilter):
         Z, n = self._z(Z)
         self._call("step_async", self._ptr(Z), n, C.c_int(1 if normalize else 0))
 
+    def _opt(self, a, shape=None):
+        if a is None:
+            return None, C.c_void_p(None)
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if shape is not None:
+            assert a.shape == shape, (a.shape, shape)
+        return a, self._ptr(a)
+
+    def cycle_async(self, predict, Z, poses=None, pose_cov=None, weights=None, normalize=True):
+        """One submission per predict + update cycle (rfsgpu_cycle_async): predict = None (no predict part), False (static step
+        only) or True (births + static step); poses / pose_cov / weights = the host's new inputs or None (unchanged)."""
+        Z, n = self._z(Z)
+        x, px = self._opt(poses, (self.n, 3))
+        stride = 0
+        if pose_cov is not None:
+            pose_cov = np.ascontiguousarray(pose_cov, dtype=np.float64)
+            assert pose_cov.size in (9, 9 * self.n)
+            stride = 0 if pose_cov.size == 9 else 9
+        cv, pc = self._opt(pose_cov)
+        w, pw = self._opt(weights, (self.n,))
+        self._call("cycle_async", C.c_int(-1 if predict is None else (1 if predict else 0)), px, pc, C.c_int(stride), pw, self._ptr(Z), n,
+                   C.c_int(1 if normalize else 0))
+
+    def update_io(self, Z, predict=None, poses=None, pose_cov=None, weights=None, want_weights=True):
+        """RBPHDFilter::update with its inputs and outputs in one synchronous call (rfsgpu_update_io); returns the updated
+        (un-normalised) particle weights."""
+        Z, n = self._z(Z)
+        x, px = self._opt(poses, (self.n, 3))
+        stride = 0
+        if pose_cov is not None:
+            pose_cov = np.ascontiguousarray(pose_cov, dtype=np.float64)
+            assert pose_cov.size in (9, 9 * self.n)
+            stride = 0 if pose_cov.size == 9 else 9
+        cv, pc = self._opt(pose_cov)
+        w, pw = self._opt(weights, (self.n,))
+        out = np.empty(self.n, dtype=np.float64) if want_weights else None
+        self._call("update_io", C.c_int(-1 if predict is None else (1 if predict else 0)), px, pc, C.c_int(stride), pw, self._ptr(Z), n,
+                   self._ptr(out) if want_weights else C.c_void_p(None))
+        return out
+
     def kernel_time_stats(self):
         avg = (C.c_double * 3)()
         n = C.c_int()

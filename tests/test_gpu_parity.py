@@ -324,6 +324,95 @@ def test_multi_step_predict_update_cycle(pkg, ob, sc):
         compare_maps(sc, dev, orc, scen["n"])
 
 
+@pytest.mark.parametrize("n_lm,cap", [(25, 256), (150, 384)])
+def test_fused_predict_update_cycle_is_the_call_by_call_cycle(pkg, ob, sc, n_lm, cap):
+    """rfsgpu_cycle_async (round 5): the predict's map part (births at the poses the PREVIOUS update used,
+    Sigma += Q; include/RBPHDFilter.hpp:415-442) at the head of the fused step kernel, new poses and weights arriving with the
+    call.  Against (a) the same device doing predict_map / set_poses / set_weights / step_async call by call -- maps, unused
+    lists and weights BIT FOR BIT -- and (b) the oracle, through six cycles in which the poses move every cycle (the births of
+    cycle k must come out at the poses of update k-1, not at the new ones), a cycle without births, one without a predict,
+    and a resampling with foreign parents in between (the inheritance walk: the cycle falls back to the stand-alone kernels and
+    must still agree), followed by cycles that take the fused head again."""
+    scen = sc.make_scenario(16, n_lm, 12, seed=140 + n_lm)
+    fus, orc = make_pair(pkg, ob, sc, scen, cap=cap)
+    ref = pkg.RBPHDFilter(scen["n"], gm_capacity=cap)
+    sc.load_scenario(ref, scen)
+    rng = np.random.default_rng(7)
+    poses = scen["poses"].copy()
+    saw = set()
+    for f in (fus, ref, orc):                  # a first update, so that there are unused measurements to give birth from
+        f.update(scen["Z"])
+    for step in range(8):
+        Z = scen["Z"] + rng.normal(0, 2e-3, scen["Z"].shape)
+        Z[-2:, 0] = rng.uniform(1.0, 3.0, 2)                        # two measurements nobody explains -> births next cycle
+        poses = poses + rng.normal(0, 0.02, poses.shape)            # the host's propagate
+        w_in = rng.uniform(0.5, 1.0, scen["n"])
+        predict = None if step == 5 else (False if step == 2 else True)
+        fus.cycle_async(predict, Z, poses=poses, weights=w_in, normalize=False)
+        saw.add(fus.last_step_variant()[3])
+        for f in (ref, orc):
+            if predict is not None:
+                f.predict_map(bool(predict))
+            f.set_poses(poses)
+            f.set_weights(w_in)
+        ref.step_async(Z, False)
+        orc.update(Z)
+        fus.synchronize(); ref.synchronize()
+        np.testing.assert_array_equal(fus.get_weights(), ref.get_weights())
+        assert np.array_equal(fus.gm_sizes(), ref.gm_sizes())
+        for i in range(scen["n"]):
+            for a, b in zip(fus.export_gm(i), ref.export_gm(i)):
+                np.testing.assert_array_equal(a, b)
+            assert np.array_equal(fus.get_unused(i), ref.get_unused(i))
+        compare_weights(fus, orc)
+        compare_maps(sc, fus, orc, scen["n"])
+        if step == 3:                                                # a resampling whose plan has foreign parents
+            for f in (fus, ref, orc):
+                s = f.weight_sums()
+                f.normalize_weights(s[0])
+            fired, wn, src = ob.resample_decide(orc.get_weights(), scen["n"] + 1.0, 0.41)
+            assert fired and np.any(src != np.arange(scen["n"]))
+            for f in (fus, ref, orc):
+                f.resample_apply(src)
+            poses = poses[src]
+    assert saw == {1, 2}, saw          # both forms ran: the fused head (2) and the fall-back to the stand-alone predict (1)
+    ref.close()
+
+
+def test_update_io_is_set_poses_set_weights_update_get_weights(pkg, ob, sc):
+    """rfsgpu_update_io (VERDICT r4 item 3): RBPHDFilter::update with its inputs and outputs in one synchronous call == the four
+    calls the binding used to make, bit for bit, with and without the predict folded in; device errors come back from THIS call."""
+    scen = sc.make_scenario(12, 40, 12, seed=61)
+    a = pkg.RBPHDFilter(scen["n"], gm_capacity=192)
+    b = pkg.RBPHDFilter(scen["n"], gm_capacity=192)
+    for f in (a, b):
+        sc.load_scenario(f, scen)
+    rng = np.random.default_rng(3)
+    poses = scen["poses"].copy()
+    for step in range(4):
+        Z = scen["Z"] + rng.normal(0, 2e-3, scen["Z"].shape)
+        poses = poses + rng.normal(0, 0.01, poses.shape)
+        cov = np.tile(np.diag([1e-4, 1e-4, 1e-6]), (scen["n"], 1, 1)) * (1 + step)
+        w_in = rng.uniform(0.5, 1.0, scen["n"])
+        pred = None if step == 0 else True
+        w_a = a.update_io(Z, predict=pred, poses=poses, pose_cov=cov, weights=w_in)
+        if pred:
+            b.predict_map(True)
+        b.set_poses(poses, cov)
+        b.set_weights(w_in)
+        b.update(Z)
+        np.testing.assert_array_equal(w_a, b.get_weights())
+        for i in range(scen["n"]):
+            for x, y in zip(a.export_gm(i), b.export_gm(i)):
+                np.testing.assert_array_equal(x, y)
+    small = pkg.RBPHDFilter(4, gm_capacity=64)
+    sc.load_scenario(small, sc.make_scenario(4, 60, 30, seed=16))
+    with pytest.raises(pkg.capi.EngineError) as e:
+        small.update_io(sc.make_scenario(4, 60, 30, seed=16)["Z"])
+    assert e.value.status == pkg.capi.ERR_CAPACITY
+    a.close(); b.close(); small.close()
+
+
 def test_resample_apply(pkg, ob, sc):
     scen = sc.make_scenario(16, 20, 8, seed=15)
     dev, orc = make_pair(pkg, ob, sc, scen, cap=128)
@@ -458,6 +547,35 @@ def test_murty_partitions_of_every_size_class_match_oracle(pkg, ob, sc):
         f.importance_weighting()
     assert orc.murty_calls() > 40, "scenario does not reach the Murty path"
     compare_weights(dev, orc)
+
+
+def test_device_murty_sums_against_the_reference_bruteforce_fixture(pkg, ob):
+    """The device's job kernel pinned to the reference where the path uses Murty: the extended tables of
+    tests/golden/murty_extended_ranked.json (dimension 7 ... 9, built as include/RBPHDFilter.hpp:907-940 builds them, ranked and
+    de-duplicated by the reference's BruteForceLinearAssignment, tests/golden/make_combinatorics_fixtures.py) go through
+    murty_jobs_kernel as queued partitions; each partition sum must equal the sum of exp(score) over the fixture's <= 200 best
+    distinct assignments (:948-959) -- and the oracle's Murty the same."""
+    import json
+    import math
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "murty_extended_ranked.json")) as fh:
+        cases = json.load(fh)
+    dev = pkg.RBPHDFilter(8, gm_capacity=64)
+    w0 = dev.get_weights()
+    for rep in range(2):                                    # (second pass: the capped six-wave instance, after the filter has shown Murty work)
+        sums = dev.murty_partition_sums([np.array(c["C"]) for c in cases], [c["nR"] for c in cases], [c["nC"] for c in cases])
+        for c, got in zip(cases, sums):
+            want = 0.0
+            for sc_ in c["scores"]:
+                want += math.exp(sc_)
+            assert abs(got - want) <= 1e-12 * want, (c["nR"], c["nC"], got, want)
+            so, _ = ob.murty(np.array(c["C"]), c["nR"], c["nC"], kmax=200)
+            wo = 0.0
+            for sc_ in so[so >= -1000.0]:
+                wo += math.exp(sc_)
+            assert abs(got - wo) <= 1e-13 * wo
+    np.testing.assert_array_equal(dev.get_weights(), w0)     # the hook leaves the weights alone
+    dev.close()
 
 
 def test_cpp_host_driver_end_to_end(pkg):

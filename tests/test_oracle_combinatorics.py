@@ -111,6 +111,52 @@ def test_murty_plain_vs_golden_fixture(ob):
         assert np.allclose(got, want, rtol=0, atol=1e-9)
 
 
+def _extended_cases():
+    with open(os.path.join(GOLD, "murty_extended_ranked.json")) as fh:
+        return json.load(fh)
+
+
+def test_murty_with_the_real_assignment_block_vs_golden_fixture(ob):
+    """Murty where the path uses it: extended tables of dimension 7 ... 9 built the way rfsMeasurementLikelihood
+    builds them (include/RBPHDFilter.hpp:907-940), setRealAssignmentBlock(nR, nC) as at :942-947.  The fixture holds the ranking
+    by the reference's OWN BruteForceLinearAssignment over all n! assignments, de-duplicated as the reference's Murty example does
+    (src/examples/linearAssignment_MurtyAlgorithm.cpp:118-127).  The oracle's Murty must return exactly those scores, call by
+    call, and run dry where the distinct assignments do (no duplicate through the dummy block, none missing)."""
+    cases = _extended_cases()
+    assert len(cases) >= 20 and {c["nR"] + c["nC"] for c in cases} == {7, 8, 9}
+    for case in cases:
+        Cm = np.array(case["C"])
+        want = np.array(case["scores"])
+        got, assign = ob.murty(Cm, case["nR"], case["nC"], kmax=200)
+        got = got[got >= -1000.0]                       # (the caller's loop stops at the first score below BIG_NEG_NUM, :951-952)
+        assert got.size == min(case["n_distinct"], 200), (case["nR"], case["nC"], got.size, case["n_distinct"])
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
+        assert np.all(np.diff(got) <= 0)                # ranked: never increasing (the premise of the device's early end of the loop)
+
+
+def test_murty_with_the_real_assignment_block_vs_reference_bruteforce_live(ob):
+    """The same comparison against the reference class executed here (fresh tables, incl. dimension 9 with > 200 distinct assignments)."""
+    ref = ob.load_ref()
+    if ref is None:
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(77)
+    for nR, nC in ((4, 4), (5, 4), (4, 5), (3, 6)):
+        n = nR + nC
+        Cm = np.full((n, n), -1000.0)
+        L = np.log(rng.uniform(1e-6, 1.0, (nR, nC)))
+        L[rng.uniform(size=(nR, nC)) > 0.8] = -1000.0
+        Cm[:nR, :nC] = L
+        Cm[np.arange(nR), nC + np.arange(nR)] = np.log(1.0 - rng.uniform(0.5, 0.99, nR))
+        Cm[nR + np.arange(nC), np.arange(nC)] = np.log(rng.uniform(1e-3, 1e-1, nC))
+        Cm[nR:, nC:] = 0.0
+        s, _ = ob.ref_bruteforce(Cm, kmax=math.factorial(n))
+        keep = [s[i] for i in range(len(s)) if s[i] >= -1000.0 and (i == 0 or s[i] != s[i - 1])]
+        got, _ = ob.murty(Cm, nR, nC, kmax=200)
+        got = got[got >= -1000.0]
+        assert got.size == min(len(keep), 200)
+        np.testing.assert_allclose(got, keep[:got.size], rtol=1e-12, atol=0)
+
+
 def enumerate_partial(Lp, pd, clutter):
     """Independent brute force of sum over partial assignments (rows -> distinct cols or miss)."""
     r, c = Lp.shape
