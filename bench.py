@@ -342,42 +342,49 @@ def boundary_cost(pkg, sc, wl, n_local, CAP, scen, local_rank):
     P = scen["params"]
     cfg = g.get_filter_config()
 
-    def seq(with_update):
-        g.restore_state()
-        if not with_update:
-            g.synchronize()
-            return
+    def push_config():
         g.set_filter_config(cfg)                                           # pushConfiguration(): the public config members may change any time
         g.set_kf_config(P["kf_range"], P["kf_bearing"])
         g.set_lmk_process_noise(P["Q_lm"])
         g.set_model_rngbrg(P["R"], P["Pd"], P["clutter"], P["rmax"], P["rmin"], P["rbuf"])
-        g.set_poses(x, cov)                                                 # pushPoses(): mean + 3x3 covariance per particle
+
+    def seq(mode):
+        g.restore_state()
+        if mode == "restore_only":
+            g.synchronize()
+            return
+        push_config()
+        if mode == "io":        # round 5: integration/RBPHDFilter_rfsgpu.hpp::update -- poses + covariances + weights in, weights out, ONE call, one wait
+            g.update_io(Z, poses=x, pose_cov=cov, weights=w1)
+            return
+        g.set_poses(x, cov)                                                 # rounds 3-4: pushPoses(): mean + 3x3 covariance per particle
         g.set_weights(w1)                                                   # pushWeights()
         g.update(Z)                                                         # rfsgpu_update: synchronous
         g.get_weights()                                                     # pullWeights()
     for _ in range(300):
-        seq(True)
+        seq("io")
     t = {}
-    for name, flag in (("with", True), ("restore_only", False), ("with2", True)):
+    for name, mode in (("io", "io"), ("four_calls", "four"), ("restore_only", "restore_only"), ("io2", "io"), ("four_calls2", "four")):
         S = 300
         t0 = time.perf_counter()
         for _ in range(S):
-            seq(flag)
+            seq(mode)
         t[name] = (time.perf_counter() - t0) / S * 1e6
-    per = min(t["with"], t["with2"]) - t["restore_only"]
+    per = min(t["io"], t["io2"]) - t["restore_only"]
+    per4 = min(t["four_calls"], t["four_calls2"]) - t["restore_only"]
     # the parts, one at a time
     parts = {}
-    for name, fn in (("config_structs_and_model", lambda: (g.set_filter_config(cfg), g.set_kf_config(P["kf_range"], P["kf_bearing"]), g.set_lmk_process_noise(P["Q_lm"]),
-                                                          g.set_model_rngbrg(P["R"], P["Pd"], P["clutter"], P["rmax"], P["rmin"], P["rbuf"]))),
-                     ("set_poses", lambda: g.set_poses(x, cov)), ("set_weights", lambda: g.set_weights(w1)), ("get_weights", lambda: g.get_weights())):
+    for name, fn in (("config_structs_and_model", push_config),):
         t0 = time.perf_counter()
         for _ in range(300):
             fn()
         parts[name] = round((time.perf_counter() - t0) / 300 * 1e6, 2)
-    parts["rfsgpu_update_sync"] = round(per - sum(parts.values()), 2)
+    parts["rfsgpu_update_io"] = round(per - sum(parts.values()), 2)
     out["binding_sequence"] = dict(us_per_update=round(per, 2), parts_us=parts, particles=n_local,
-                                   note="ctypes calls through the C ABI in the order integration/RBPHDFilter_rfsgpu.hpp::update makes them; "
-                                        "the state re-seed between updates is measured alone and subtracted")
+                                   four_call_sequence_us_per_update=round(per4, 2),
+                                   note="ctypes calls through the C ABI in the order integration/RBPHDFilter_rfsgpu.hpp::update makes them (round 5: the "
+                                        "config structs + rfsgpu_update_io; four_call_sequence = set_poses + set_weights + update + get_weights, what rounds 3-4 "
+                                        "measured); the state re-seed between updates is measured alone and subtracted")
     g.close()
     # (b) the unmodified reference driver
     root = os.path.dirname(os.path.abspath(__file__))

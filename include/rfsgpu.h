@@ -35,7 +35,7 @@
  *   RFSGPU_CORE_MULTI: rfsgpu_group_set_model_rngbrg rfsgpu_group_set_model_victoriapark rfsgpu_group_set_laser_scan rfsgpu_group_set_kf_config
  *   RFSGPU_CORE_MULTI: rfsgpu_group_set_lmk_process_noise rfsgpu_group_set_poses rfsgpu_group_set_weights rfsgpu_group_get_weights
  *   RFSGPU_CORE_MULTI: rfsgpu_group_predict_map rfsgpu_group_update rfsgpu_group_apply_plan rfsgpu_group_gm_size rfsgpu_group_get_landmark
- *   RFSGPU_CORE_MULTI: rfsgpu_group_get_timing rfsgpu_group_set_phase_timing
+ *   RFSGPU_CORE_MULTI: rfsgpu_group_get_timing rfsgpu_group_set_phase_timing rfsgpu_group_update_io
  * Everything else is OPTIONAL and grouped below by who needs it:
  *   [async]    stream-ordered forms for host loops that pipeline (rfsgpu_*_async, rfsgpu_step_async, rfsgpu_set_stream, ...);
  *   [multi]    several GPUs: rfsgpu_group_* (one host thread), slab rows / device pointers (one process per GPU over RCCL);
@@ -340,10 +340,11 @@ int rfsgpu_kernel_time_stats(rfsgpu_filter *f, double *avg_ns3, int *n_steps);
 /* [bench] Average duration (ns) of the step's post kernel (Murty-200 partitions when any were queued, queue reset, weight sums /
  * division) over the fused steps the last rfsgpu_kernel_time_stats call covered. */
 double rfsgpu_post_kernel_avg_ns(const rfsgpu_filter *f);
-/* [bench] The HIP events behind the two calls above ride on every `every`-th fused stream-ordered step only (default 1: on each).  Three
- * event records per step cost a step of configs[1] 8 us of its 144 (each is a marker packet the queue drains before the next
- * kernel starts); bench.py samples every 8th step of its timed region.  Statistics average over the sampled steps; TimingInfo
- * (rfsgpu_get_timing) books every sampled step `every` times, i.e. it stays an estimate of the whole run's device time. */
+/* [bench] The HIP events behind the two calls above (and behind TimingInfo's device buckets) ride on every `every`-th fused step only
+ * (default 8 since round 5; a filter's first step always carries them).  Three event records per step cost a step of configs[1] 8 us
+ * of its 144 (each is a marker packet the queue drains before the next kernel starts).  Statistics average over the sampled steps;
+ * TimingInfo (rfsgpu_get_timing) books a sampled step once for itself and once for every un-sampled step since the previous
+ * sample, i.e. it stays an estimate of the whole run's device time.  `every` = 1 restores per-step events. */
 int rfsgpu_set_step_timing_stride(rfsgpu_filter *f, int every);
 #endif /* RFSGPU_ENABLE_BENCH_API */
 /* The same four phases one at a time (used by the parity tests and by profiling):          */
@@ -488,6 +489,10 @@ int rfsgpu_group_set_birth_inheritance(rfsgpu_group *g, int mode);          /* R
 int rfsgpu_group_get_particle_ids(rfsgpu_group *g, int *id, int *parent_id); /* Particle::getId / getParentId by global slot */
 /* RBPHDFilter::update body (:444-523) on every shard; weights stay un-normalised; sums_out (may be null) = {sum w, sum w^2}. */
 int rfsgpu_group_update(rfsgpu_group *g, const double *z, int n_z, double *sums_out);
+/* The group form of rfsgpu_update_io: global poses (+ covariances, NULL = unchanged) and weights (NULL = unchanged) in, the update on every
+ * shard (all chains enqueued before the first wait), the updated un-normalised weights of all particles out (NULL = not wanted);
+ * device-side errors of any shard are reported by this call. */
+int rfsgpu_group_update_io(rfsgpu_group *g, const double *x, const double *x_cov, int cov_stride, const double *w_in, const double *z, int n_z, double *w_out);
 int rfsgpu_group_normalize(rfsgpu_group *g, double *sums_out);               /* normalizeWeights over all N (:352-363) */
 /* ParticleFilter::resample (:399-492) with the caller's uniform draw (the reference's one drand48()); *fired tells whether the
  * N_eff test let it happen; plan_out (may be null, N ints): global source slot of every slot, for per-particle host data. */

@@ -143,6 +143,11 @@ class rfsgpu_engine_facade {
   int get_weights(double *w) { return g_ ? rfsgpu_group_get_weights(g_, w) : rfsgpu_get_weights(f_, w); }
   int predict_map(int add_birth) { return g_ ? rfsgpu_group_predict_map(g_, add_birth) : rfsgpu_predict_map(f_, add_birth); }
   int update(const double *z, int n_z) { return g_ ? rfsgpu_group_update(g_, z, n_z, NULL) : rfsgpu_update(f_, z, n_z); }
+  /* RBPHDFilter::update's device part with its inputs and outputs in ONE call and one wait (poses + covariances + weights in, weights out) */
+  int update_io(const double *x, const double *cov, int stride, const double *w_in, const double *z, int n_z, double *w_out) {
+    return g_ ? rfsgpu_group_update_io(g_, x, cov, stride, w_in, z, n_z, w_out)
+              : rfsgpu_update_io(f_, RFSGPU_CYCLE_NO_PREDICT, x, cov, stride, w_in, z, n_z, w_out);
+  }
   int resample_apply(const int *src) { return g_ ? rfsgpu_group_apply_plan(g_, src) : rfsgpu_resample_apply(f_, src); }
   int gm_size(int i) { return g_ ? rfsgpu_group_gm_size(g_, i) : rfsgpu_gm_size(f_, i); }
   int get_landmark(int i, int m, double *mean, double *cov, double *w) { return g_ ? rfsgpu_group_get_landmark(g_, i, m, mean, cov, w) : rfsgpu_get_landmark(f_, i, m, mean, cov, w); }
@@ -279,12 +284,16 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
       for (int d = 0; d < D; d++) z[(size_t)D * k + d] = v[d];
     }
     pushConfiguration();
-    pushPoses();
-    pushWeights();
+    /* poses (+ covariances) and weights in, updateMap + importanceWeighting + merge + prune (:469-520), weights out: one engine
+     * call, one wait for the device (round 5; until then set_poses + set_weights + update + get_weights, two waits) */
+    const int n = this->nParticles_;
+    std::vector<double> x((size_t)3 * n), P((size_t)9 * n), w((size_t)n);
+    gatherPoses(x, P);
+    for (int i = 0; i < n; i++) w[i] = this->particleSet_[i]->getWeight();
     timer_mapUpdate_.resume();
-    check(engine_.update(z.data(), nZ), "update");   /* updateMap + importanceWeighting + merge + prune, :469-520 */
+    check(engine_.update_io(x.data(), P.data(), 9, w.data(), z.data(), nZ, w.data()), "update");
     timer_mapUpdate_.stop();
-    pullWeights();
+    for (int i = 0; i < n; i++) this->particleSet_[i]->setWeight(w[i]);
 
     timer_particleResample_.resume();                       /* :524-539, unchanged */
     resampleOccured_ = false;
@@ -427,9 +436,8 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
   }
 
   /* pose mean + covariance of every particle (the covariance enters S in the 2-D model, src/MeasurementModel_RngBrg.cpp:102) */
-  void pushPoses() {
+  void gatherPoses(std::vector<double> &x, std::vector<double> &P) {
     const int n = this->nParticles_;
-    std::vector<double> x((size_t)3 * n), P((size_t)9 * n);
     for (int i = 0; i < n; i++) {
       typename TPose::Vec v;
       typename TPose::Mat S;
@@ -439,19 +447,12 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
         for (int c = 0; c < 3; c++) P[(size_t)9 * i + 3 * r + c] = S(r, c);
       }
     }
+  }
+  void pushPoses() {
+    std::vector<double> x((size_t)3 * this->nParticles_), P((size_t)9 * this->nParticles_);
+    gatherPoses(x, P);
     check(engine_.set_poses(x.data(), P.data(), 9), "set_poses");
   }
-  void pushWeights() {
-    std::vector<double> w(this->nParticles_);
-    for (int i = 0; i < this->nParticles_; i++) w[i] = this->particleSet_[i]->getWeight();
-    check(engine_.set_weights(w.data()), "set_weights");
-  }
-  void pullWeights() {
-    std::vector<double> w(this->nParticles_);
-    check(engine_.get_weights(w.data()), "get_weights");
-    for (int i = 0; i < this->nParticles_; i++) this->particleSet_[i]->setWeight(w[i]);
-  }
-
   /* ParticleFilter::resample() (include/ParticleFilter.hpp:399-492) with n = nParticles_, restated only because the maps are
    * not in Particle::data_: the decision, the draw and the slot assignment are the reference's, statement for statement;
    * `particleSet_[next] = particleSet_[idx]->copy()` (:473) copies the host part (pose, id, the empty mixture object) and sets

@@ -123,7 +123,7 @@ ABI_SYMBOLS = [
     "group_set_filter_config", "group_set_model_rngbrg", "group_set_kf_config", "group_set_lmk_process_noise", "group_set_poses",
     "group_get_poses", "group_set_weights", "group_get_weights", "group_predict_map", "group_update", "group_normalize",
     "group_resample", "group_apply_plan", "group_migration_stats", "group_gm_size", "group_get_landmark", "group_synchronize", "group_set_birth_inheritance", "group_get_particle_ids",
-    "group_set_model_victoriapark", "group_set_laser_scan", "group_set_phase_timing", "group_get_timing", "group_collective",
+    "group_update_io", "group_set_model_victoriapark", "group_set_laser_scan", "group_set_phase_timing", "group_get_timing", "group_collective",
 ]
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")

@@ -439,6 +439,27 @@ int rfsgpu_group_update(rfsgpu_group *g, const double *z, int n_z, double *sums_
   if (sums_out) { sums_out[0] = tot[0]; sums_out[1] = tot[1]; }
   return RFSGPU_OK;
 }
+// RBPHDFilter::update (:444-541) over the group with its inputs and outputs in one call (the group form of rfsgpu_update_io; what
+// integration/RBPHDFilter_rfsgpu.hpp's update() calls when RFSGPU_DEVICES lists several GPUs): global poses (+ covariances) and
+// weights in, every shard's chain enqueued before the first wait, the updated weights of all particles out.  The shards' device
+// error words are read by THIS call (rfsgpu_group_update(..., NULL) on the RCCL path left them for a later call).
+int rfsgpu_group_update_io(rfsgpu_group *g, const double *x, const double *x_cov, int cov_stride, const double *w_in, const double *z, int n_z, double *w_out) {
+  if (!g) return RFSGPU_ERR_INVALID;
+  if (x_cov && cov_stride != 0 && cov_stride != 9) return gfail(g, RFSGPU_ERR_INVALID, "group_update_io: cov_stride must be 0 or 9");
+  const int S = (int)g->shard.size();
+  for (int k = 0; k < S; k++) {
+    const size_t o = (size_t)g->first[k];
+    GFWD(k, update_io_begin(g->shard[k], RFSGPU_CYCLE_NO_PREDICT, x ? x + 3 * o : nullptr, x_cov ? x_cov + (cov_stride == 9 ? 9 * o : 0) : nullptr, cov_stride,
+                            w_in ? w_in + o : nullptr, z, n_z, w_out != nullptr));
+  }
+  if (n_z > 0) g->resampleOccured = false;       // RBPHDFilter.hpp:526
+  int first = RFSGPU_OK;
+  for (int k = 0; k < S; k++) {
+    const int rc = update_io_end(g->shard[k], w_out ? w_out + g->first[k] : nullptr);
+    if (rc != RFSGPU_OK && first == RFSGPU_OK) first = gfail(g, rc, std::string("shard ") + std::to_string(k) + ": " + rfsgpu_last_error(g->shard[k]));
+  }
+  return first;
+}
 // ParticleFilter::normalizeWeights over the whole particle set (:352-363).
 int rfsgpu_group_normalize(rfsgpu_group *g, double *sums_out) {
   if (!g) return RFSGPU_ERR_INVALID;

@@ -853,6 +853,27 @@ __device__ __forceinline__ void step_post_tail(double *weight, int N, double *su
     for (int j = 0; j < U; j++) { const int k = k0 + j * (int)blockDim.x; if (k < N) weight[k] = v[j] / d; }
   }
 }
+// Results of a step straight into a PINNED host buffer, by the post kernel's last workgroup (rfsgpu_update_io, round 5): the
+// particle weights, the device error word, then -- behind a system-scope release -- the sequence number the host spins on.  No
+// copy commands behind the step and no stream synchronisation: two blit kernels, their queue hand-overs and the wake-up of
+// hipStreamSynchronize were 20 us of an update through the boundary at configs[1].
+struct StepOut {
+  double *hostW;     // [N] (nullptr: nothing to deliver)
+  int *hostFlag;     // [0] error word, [1] sequence number
+  int seq;
+};
+__device__ __forceinline__ void step_post_out(const double *weight, int N, int *err, const StepOut &SO) {
+  if (!SO.hostW) return;
+  __threadfence();
+  __syncthreads();     // every thread's weight writes (Murty factors, division) before anybody reads them back
+  for (int k = threadIdx.x; k < N; k += blockDim.x) SO.hostW[k] = weight[k];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    SO.hostFlag[0] = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&SO.hostFlag[1], SO.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
 // Longest jobs first: a job's duration grows with its extended dimension (2.3 ms at 9, 10 ms at 15 at configs[4]), the jobs are
 // queued in whatever order the particles' weighting phases reach them, and more jobs than resident workgroups means a second
 // round -- in which a 10 ms job started after the first 2 ms ones have finished sets the launch's length.  One workgroup sorts the
@@ -894,13 +915,13 @@ __global__ __launch_bounds__(1024) void murty_order_kernel(MurtyQueue Q) {
 template <int W, int WAVES_PER_EU>
 __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(WAVES_PER_EU > 0 ? WAVES_PER_EU : 1, WAVES_PER_EU > 0 ? WAVES_PER_EU : 8)))
 void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err, double *weight, int N, double *sums,
-                                                                         int normalize, ZArg zarg, double *dZ, int nZdoubles, int *hostSeen, int ordered) {
+                                                                         int normalize, ZArg zarg, double *dZ, int nZdoubles, int *hostSeen, int ordered, StepOut SO) {
   // (a fused step carries the measurement set in its kernel arguments; the device copy the next predict reads is written here)
   if (blockIdx.x == 0 && dZ)
     for (int t = threadIdx.x; t < nZdoubles; t += blockDim.x) dZ[t] = zarg.v[t];
   const int nJobs = min(*Q.count, Q.maxJobs);
   if (nJobs == 0) {
-    if (blockIdx.x == 0) step_post_tail(weight, N, sums, normalize);
+    if (blockIdx.x == 0) { step_post_tail(weight, N, sums, normalize); step_post_out(weight, N, err, SO); }
     return;
   }
   __shared__ double sTile[W][MURTY_LDS_N * MURTY_LDS_N];
@@ -1032,6 +1053,7 @@ void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err, double *weight, 
   if (threadIdx.x == 0) printf("murty tail (last workgroup %d): factors into the weights %lld ticks of 10 ns, ends at tick %lld\n", (int)blockIdx.x, (long long)wall_clock64() - dbgTail0, (long long)wall_clock64());
 #endif
   step_post_tail(weight, N, sums, normalize);
+  step_post_out(weight, N, err, SO);
 }
 
 // Start of a step: measurement set -> device buffer (read by every kernel of the step and by the next predict), Murty
@@ -1070,7 +1092,7 @@ static inline void murty_free(MurtyQueue &Q, MurtyScratch &MS) {
 // instance (four waves, no register cap, no scratch set-up) on the same grid; a filter that has shown Murty work gets the capped
 // six-wave instance and the job ordering from the next step on.  Correct either way: jobs are strided over whatever grid there is.
 static inline int murty_launch(MurtyQueue &Q, MurtyScratch &MS, Buffers &B, hipStream_t stream, double *sums = nullptr, int normalize = 0,
-                               const ZArg *za = nullptr, int nZdoubles = 0, int *hostSeen = nullptr) {
+                               const ZArg *za = nullptr, int nZdoubles = 0, int *hostSeen = nullptr, const StepOut &SO = StepOut{nullptr, nullptr, 0}) {
   int blocks = std::min(MURTY_JOB_BLOCKS, Q.maxJobs);
   // (RFSGPU_MURTY_FIRST_BLOCKS: grid of the light instance, for A/B runs -- tools/murty_first_step.py)
   static const int firstBlocks = [] { const char *e = getenv("RFSGPU_MURTY_FIRST_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : MURTY_FIRST_BLOCKS; }();
@@ -1082,9 +1104,9 @@ static inline int murty_launch(MurtyQueue &Q, MurtyScratch &MS, Buffers &B, hipS
   if (ordered) murty_order_kernel<<<1, 1024, 0, stream>>>(Q);
   if (hostSeen && *hostSeen == 0)
     murty_jobs_kernel<MURTY_LIGHT_WAVES, 0><<<blocks, 64 * MURTY_LIGHT_WAVES, 0, stream>>>(Q, MS, B.err, B.weight, B.N, sums, normalize, za ? *za : none,
-                                                                                         za ? B.Z : nullptr, nZdoubles, hostSeen, ordered);
+                                                                                         za ? B.Z : nullptr, nZdoubles, hostSeen, ordered, SO);
   else
     murty_jobs_kernel<MURTY_JOB_WAVES, MURTY_WAVES_PER_EU><<<blocks, 64 * MURTY_JOB_WAVES, 0, stream>>>(Q, MS, B.err, B.weight, B.N, sums, normalize,
-                                                                                                      za ? *za : none, za ? B.Z : nullptr, nZdoubles, hostSeen, ordered);
+                                                                                                      za ? *za : none, za ? B.Z : nullptr, nZdoubles, hostSeen, ordered, SO);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }

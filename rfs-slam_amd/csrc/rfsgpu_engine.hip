@@ -68,6 +68,17 @@ struct rfsgpu_filter {
   int rowSlotsCap = 0;
   double *hStage[4] = {nullptr, nullptr, nullptr, nullptr};  // pinned staging ring of rfsgpu_set_step_inputs_async
   double *hWeights = nullptr;         // pinned landing buffer of rfsgpu_get_weights
+  double *hOutW = nullptr;            // pinned: where the post kernel leaves the weights of a synchronous rfsgpu_update_io ...
+  int *hOutFlag = nullptr;            // ... and {error word, sequence number} behind them (same allocation)
+  int outSeq = 0;                     // sequence number of the last delivery asked for
+  bool outArmed = false;              // the step in flight delivers through hOutW / hOutFlag (update_io_end spins instead of synchronising)
+
+  int stagePendingSlot = -1;          // a staging slot whose event must be recorded behind the step that reads it
+  bool ioTail = true;                 // RFSGPU_IO_TAIL=0: the post kernel always follows as its own launch (A/B)
+  bool ioPull = true;                 // RFSGPU_IO_PULL=0: inputs by copy commands, outputs by copies + a stream synchronisation (A/B, rounds 3-4 form)
+  double *ZAlt = nullptr;             // second measurement buffer (tail mode of the fused step: the step writes the set the NEXT predict reads while this launch's births still read the previous one)
+  int *dTicket = nullptr;             // finished-workgroup counter of the tail mode
+  bool tailMode = false;              // the step in flight ran in tail mode: RFSGPU_NEED_POST in the landing area means "launch the post kernel now"
   double *poseAlt = nullptr;          // [Ncap][3] second pose buffer: a fused predict + update cycle births at the old poses and updates at the new ones (rfsgpu_cycle_async)
   hipEvent_t evStage[4] = {};
   int stageNext = 0;
@@ -111,7 +122,10 @@ struct rfsgpu_filter {
   bool phaseTiming = false; // rfsgpu_set_phase_timing: rfsgpu_update runs its phases as separate launches (TimingInfo per phase)
   int stepWppOverride = 0;  // RFSGPU_STEP_WPP: waves per particle of the fused step kernel (2 or 3); 0 = chosen per launch
   unsigned stepSeq = 0;      // fused steps launched so far
-  int timingStride = 1;      // every timingStride-th of them carries the timing events (rfsgpu_set_step_timing_stride)
+  int timingStride = 8;      // every timingStride-th of them carries the timing events (rfsgpu_set_step_timing_stride; round 5: 8 by default --
+                             // three marker packets per step cost a configs[1] step 8 us; the FIRST step of a filter is always timed)
+  int untimedSince = 0;      // fused steps launched since the last one that carried events
+  int ringStands[RFSGPU_ASYNC_RING] = {};   // how many steps a timed ring entry stands for in TimingInfo (itself + the untimed ones before it)
   int mergeGridOverride = 0; // RFSGPU_MERGE_GRID: log2 of the merge grid's cells per side in the three-wave fused kernel (5 or 6); 0 = chosen per launch
   hipEvent_t evAfterWeightKernel = nullptr;   // where launch_weighting drops its mid-phase event (async steps only)
   int ringCount = 0;        // async steps recorded since the last harvest
@@ -262,6 +276,8 @@ int rfsgpu_create_ex(rfsgpu_filter **out, int model, int n_particles, int device
   rfsgpu_default_fastslam_config(&f->fs);
   f->fs.nParticlesMax = 3 * n_particles;
   { const char *e = getenv("RFSGPU_FUSED_STEP"); if (e && e[0] == '0') f->fuseSteps = false; }
+  { const char *e = getenv("RFSGPU_IO_PULL"); if (e && e[0] == '0') f->ioPull = false; }
+  { const char *e = getenv("RFSGPU_IO_TAIL"); if (e && e[0] == '0') f->ioTail = false; }
   { const char *e = getenv("RFSGPU_STEP_WPP"); if (e) f->stepWppOverride = atoi(e); }
   { const char *e = getenv("RFSGPU_BIRTH_INHERITANCE"); if (e && !strcmp(e, "eager")) f->inheritMode = RFSGPU_INHERIT_EAGER; }   // (initial mode; rfsgpu_set_birth_inheritance)
   { const char *e = getenv("RFSGPU_MERGE_GRID"); if (e) f->mergeGridOverride = atoi(e); }
@@ -293,6 +309,8 @@ int rfsgpu_create_ex(rfsgpu_filter **out, int model, int n_particles, int device
   ok &= hipMalloc(&B.nInFov, f->Ncap * sizeof(int)) == hipSuccess;
   ok &= hipMalloc(&B.err, sizeof(int)) == hipSuccess;
   ok &= hipMalloc(&B.Z, RFSGPU_MAX_Z * 3 * sizeof(double)) == hipSuccess;
+  ok &= hipMalloc(&f->ZAlt, RFSGPU_MAX_Z * 3 * sizeof(double)) == hipSuccess;
+  ok &= hipMalloc(&f->dTicket, sizeof(int)) == hipSuccess;
   ok &= hipMalloc(&B.scan, RFSGPU_VP_MAX_SCAN * sizeof(double)) == hipSuccess;
   ok &= hipMalloc(&B.candMean, (size_t)f->Ncap * RFSGPU_MAX_CANDIDATES * 3 * sizeof(double)) == hipSuccess;
   ok &= hipMalloc(&B.candCov, (size_t)f->Ncap * RFSGPU_MAX_CANDIDATES * 6 * sizeof(double)) == hipSuccess;
@@ -319,6 +337,8 @@ int rfsgpu_create_ex(rfsgpu_filter **out, int model, int n_particles, int device
   hipMemsetAsync(B.nInFov, 0, f->Ncap * sizeof(int), f->stream);
   hipMemsetAsync(B.err, 0, sizeof(int), f->stream);
   hipMemsetAsync(B.Z, 0, RFSGPU_MAX_Z * 3 * sizeof(double), f->stream);
+  hipMemsetAsync(f->ZAlt, 0, RFSGPU_MAX_Z * 3 * sizeof(double), f->stream);
+  hipMemsetAsync(f->dTicket, 0, sizeof(int), f->stream);
   hipMemsetAsync(B.scan, 0, RFSGPU_VP_MAX_SCAN * sizeof(double), f->stream);
   hipMemsetAsync(B.candCount, 0, (size_t)f->Ncap * sizeof(int), f->stream);
   B.nScan = 0;
@@ -348,7 +368,7 @@ void rfsgpu_destroy(rfsgpu_filter *f) {
   Buffers &B = f->B;
   hipFree(f->snapSlab); hipFree(f->snapWeight); hipFree(f->snapCount); hipFree(f->snapFov); hipFree(f->snapUnused);
   hipFree(B.slab[0]); hipFree(B.slab[1]); hipFree(B.count); hipFree(B.pose); hipFree(f->poseAlt); hipFree(B.poseCov); hipFree(B.weight);
-  hipFree(B.unusedMask); hipFree(B.nInFov); hipFree(B.err); hipFree(B.Z); hipFree(f->ownSums); hipFree(f->dSrcSlot); if (f->dRowSlots) hipFree(f->dRowSlots); if (f->fsArena) hipFree(f->fsArena); if (f->mhArena) hipFree(f->mhArena); if (f->mhInts) hipFree(f->mhInts);
+  hipFree(B.unusedMask); hipFree(B.nInFov); hipFree(B.err); hipFree(B.Z); hipFree(f->ZAlt); hipFree(f->dTicket); hipFree(f->ownSums); hipFree(f->dSrcSlot); if (f->dRowSlots) hipFree(f->dRowSlots); if (f->fsArena) hipFree(f->fsArena); if (f->mhArena) hipFree(f->mhArena); if (f->mhInts) hipFree(f->mhInts);
   if (f->dInhParent) hipFree(f->dInhParent);
   if (f->dInhLevel) hipFree(f->dInhLevel);
   hipFree(f->inhTmp.unused); hipFree(f->inhTmp.count); hipFree(f->inhTmp.sup); hipFree(f->inhTmp.chk); hipFree(f->inhTmp.mean); hipFree(f->inhTmp.cov);  // (hipFree(nullptr) is a no-op)
@@ -358,6 +378,7 @@ void rfsgpu_destroy(rfsgpu_filter *f) {
   if (f->hJobCount) hipHostFree(f->hJobCount);
   if (f->hSums) hipHostFree(f->hSums);
   if (f->hWeights) hipHostFree(f->hWeights);
+  if (f->hOutW) hipHostFree(f->hOutW);
   for (int k = 0; k < 4; k++) { if (f->hStage[k]) hipHostFree(f->hStage[k]); if (f->evStage[k]) hipEventDestroy(f->evStage[k]); }
   for (int k = 0; k < RFSGPU_ASYNC_RING; k++)
     for (int e = 0; e < 5; e++) if (f->ring[k][e]) hipEventDestroy(f->ring[k][e]);
@@ -925,7 +946,9 @@ int rfsgpu_prune(rfsgpu_filter *f) {
 }
 
 // All four phases back to back on the stream, ONE host sync at the end (RBPHDFilter::update body :444-523).
-static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool with_sums, int normalize, const StepPredict &sp = StepPredict{0, 0, nullptr});
+static const StepOut NO_OUT{nullptr, nullptr, 0};
+static const StepPredict NO_HEAD{0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, StepOut{nullptr, nullptr, 0}};
+static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool with_sums, int normalize, const StepPredict &sp = NO_HEAD, const StepOut &so = NO_OUT);
 int rfsgpu_update(rfsgpu_filter *f, const double *z, int n_z) {
   CHECK_HANDLE(f);
   f->holes = false;
@@ -971,7 +994,7 @@ static void harvest_async(rfsgpu_filter *f) {
     if (f->ringFused[k]) {  // one kernel for the whole step: booked under mapUpdate, reported as kernel 0
       accumulate(e[0], e[3], f->timing.mapUpdate_wall, &ns[0]);
       // (only every timingStride-th fused step carries events: TimingInfo books the sampled step once for each step it stands for)
-      if (f->timingStride > 1) f->timing.mapUpdate_wall += ns[0] * (long long)(f->timingStride - 1);
+      if (f->ringStands[k] > 1) f->timing.mapUpdate_wall += ns[0] * (long long)(f->ringStands[k] - 1);
       for (int q = 0; q < 3; q++) { f->statNs[q] += (double)ns[q]; f->lastKernelNs[q] = ns[q]; }
       {   // the post kernel (Murty jobs if any, queue reset, weight sums / division): event 1 is free on this path
         float ms = 0.f;
@@ -996,7 +1019,7 @@ static void harvest_async(rfsgpu_filter *f) {
 
 // Shared body of the stream-ordered steps.  with_sums: the step's post kernel also leaves {sum w, sum w^2} in the bound sums
 // buffer (and divides the weights by the sum when normalize != 0).
-static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool with_sums, int normalize, const StepPredict &sp) {
+static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool with_sums, int normalize, const StepPredict &sp, const StepOut &so) {
   f->holes = false;
   if (n_z == 0) return RFSGPU_OK;  // :450-452
   long long t0 = now_ns();
@@ -1019,6 +1042,7 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
     f->nZ = n_z;
     if (n_z > 0) f->resampleOccured = false;
     const bool timed = (f->stepSeq++ % (unsigned)f->timingStride) == 0;   // (rfsgpu_set_step_timing_stride)
+    if (timed) { f->ringStands[f->ringCount] = f->untimedSince + 1; f->untimedSince = 0; } else f->untimedSince++;
     if (timed) HIPCHK(hipEventRecord(e[0], f->stream));
     const int ec = eval_cap(f), useW = f->cfg.useClusterProcess ? 0 : 1;
     // Waves per particle: two, unless the two-wave grid cannot be resident at once (large mixtures: the LDS block limits the
@@ -1036,11 +1060,11 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
     // phase priorities only when every workgroup is resident at once: 16 waves per CU at 128 VGPRs, LDS permitting
     const int perCU = (int)std::min<size_t>(16 / wpp, b ? (size_t)(160 * 1024) / b : 16);
     const int phasePrio = (long long)perCU * f->nCU >= f->N ? 1 : 0;
-    f->lastStepVariant[0] = wpp; f->lastStepVariant[1] = phasePrio; f->lastStepVariant[2] = 5; f->lastStepVariant[3] = sp.mode ? 2 : 1;   // ([3]: 1 = fused step, 2 = fused step with the predict at its head)
+    f->lastStepVariant[0] = wpp; f->lastStepVariant[1] = phasePrio; f->lastStepVariant[2] = 5; f->lastStepVariant[3] = sp.mode ? 2 : ((sp.inX || sp.inCov || sp.inW) ? 3 : 1);   // ([3]: 1 = fused step, 2 = with the predict at its head, 3 = with the input pull only)
     // (one instantiation per {waves per particle, phase priorities, merge grid} x {plain step, step with the predict at its head})
 #define STEP_LAUNCH(WPPV, PRIO, GLV, BYTES)                                                                                            \
     do {                                                                                                                                \
-      if (sp.mode) {                                                                                                                    \
+      if (sp.mode || sp.inX || sp.inCov || sp.inW || sp.ticket) {                                                                       \
         if ((rc = set_lds(f, (phd_step_fused_kernel<WPPV, PRIO, GLV, true>), BYTES)) != RFSGPU_OK) return rc;                           \
         phd_step_fused_kernel<WPPV, PRIO, GLV, true><<<f->N, WPPV * 64, BYTES, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za, sp);  \
       } else {                                                                                                                          \
@@ -1070,7 +1094,9 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
 #undef STEP_LAUNCH
     HIPCHK(hipGetLastError());
     if (timed) HIPCHK(hipEventRecord(e[3], f->stream));
-    if (murty_launch(f->Q, f->MS, f->B, f->stream, with_sums ? f->dSums : nullptr, normalize, &za, 2 * n_z, f->hJobCount) != 0) return fail(f, RFSGPU_ERR_HIP, "post kernel launch failed");
+    if (sp.ticket) {      // tail mode: the last workgroup of the step kernel has done the post work; the measurement set went to the other buffer
+      double *t = f->B.Z; f->B.Z = f->ZAlt; f->ZAlt = t;
+    } else if (murty_launch(f->Q, f->MS, f->B, f->stream, with_sums ? f->dSums : nullptr, normalize, &za, 2 * n_z, f->hJobCount, so) != 0) return fail(f, RFSGPU_ERR_HIP, "post kernel launch failed");
     if (timed) HIPCHK(hipEventRecord(e[1], f->stream));
     f->cur ^= 1;  // the map update works in place, the weighting phase leaves only a permutation in LDS, merge + prune write the other slab
     if (timed) {
@@ -1092,6 +1118,7 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
     f->nZ = n_z;
     if (n_z > 0) f->resampleOccured = false;
     const bool timed = (f->stepSeq++ % (unsigned)f->timingStride) == 0;
+    if (timed) { f->ringStands[f->ringCount] = f->untimedSince + 1; f->untimedSince = 0; } else f->untimedSince++;
     if (timed) HIPCHK(hipEventRecord(e[0], f->stream));
     const int ec = eval_cap(f), useW = f->cfg.useClusterProcess ? 0 : 1;
     const size_t shared = vp_shared_lds_bytes(f->nZ, f->B.nScan), per = vp_step_lds_bytes_per_wave(f->cap, ec, f->nZ);
@@ -1165,13 +1192,26 @@ int rfsgpu_step_async(rfsgpu_filter *f, const double *z, int n_z, int normalize)
 // here, in the reference's order: predict kernels, input copies, step.  Either way the results are those of
 // rfsgpu_predict_map + rfsgpu_set_poses + rfsgpu_set_weights + rfsgpu_step_async, bit for bit.
 static void ensure_ids(rfsgpu_filter *f);
+// RFSGPU_IO_PROFILE=1: host-side shares of rfsgpu_update_io, printed when the process ends (tuning aid: tools/boundary_trace.py)
+struct IoProfile {
+  bool on = getenv("RFSGPU_IO_PROFILE") != nullptr;
+  long long n = 0, stage = 0, launch = 0, wait = 0, copyOut = 0;
+  ~IoProfile() {
+    if (on && n) fprintf(stderr, "rfsgpu_update_io x %lld: inputs into the pinned slot %.2f us, launches %.2f us, wait for the delivery %.2f us, weights out %.2f us\n", n,
+                         stage / 1e3 / n, launch / 1e3 / n, wait / 1e3 / n, copyOut / 1e3 / n);
+  }
+};
+static IoProfile g_ioProf;
 static int cycle_impl(rfsgpu_filter *f, int predict, const double *x, const double *cov, int cov_stride, const double *w_in, const double *z, int n_z,
-                      bool with_sums, int normalize) {
+                      bool with_sums, int normalize, bool deliver = false) {
   if (predict < -1 || predict > 1) return fail(f, RFSGPU_ERR_INVALID, "cycle: predict is RFSGPU_CYCLE_NO_PREDICT (-1), 0 (static step only) or 1 (births + static step)");
   if (cov && cov_stride != 0 && cov_stride != 9) return fail(f, RFSGPU_ERR_INVALID, "cycle: cov_stride must be 0 or 9");
   if (n_z < 0 || n_z > RFSGPU_MAX_Z || (n_z > 0 && !z)) return fail(f, RFSGPU_ERR_INVALID, "cycle: bad measurement set");
   hipSetDevice(f->device);
-  bool fuse = predict >= 0 && n_z > 0 && f->D == 2 && f->fuseSteps && !f->phaseTiming && f->cfg.birthGaussianMeasurementCountThreshold == 1u && !f->fastSlamHandle;
+  f->outArmed = false;
+  // is this step the 2-D fused kernel (whose head can take the predict and pull the inputs)?
+  const bool head = n_z > 0 && f->D == 2 && f->fuseSteps && !f->phaseTiming;
+  bool fuse = head && predict >= 0 && f->cfg.birthGaussianMeasurementCountThreshold == 1u && !f->fastSlamHandle;
   if (fuse && predict == 1 && f->resampleOccured) {
     if (f->inheritMode == RFSGPU_INHERIT_REFERENCE) {      // a slot with a foreign parent: the level-ordered walk, stand-alone kernels
       ensure_ids(f);
@@ -1181,22 +1221,29 @@ static int cycle_impl(rfsgpu_filter *f, int predict, const double *x, const doub
     }
   }
   if (predict >= 0 && !fuse) { const int rc = rfsgpu_predict_map_async(f, predict); if (rc != RFSGPU_OK) return rc; }
-  StepPredict sp{0, 0, nullptr};
+  StepPredict sp = NO_HEAD;
   if (fuse) { sp.mode = predict ? 2 : 1; sp.nZprev = f->nZ; sp.birthPose = f->B.pose; }
+  const long long tp0 = g_ioProf.on ? now_ns() : 0;
+  const bool pull = head && f->ioPull;                    // the step kernel reads the pinned slot itself (step_fused.h, StepPredict)
   if (x || w_in) {
     double *h = nullptr;
     int k = 0;
     { const int rc = stage_slot(f, &h, &k); if (rc != RFSGPU_OK) return rc; }
     if (x) {
-      double *dst = fuse ? f->poseAlt : f->B.pose;         // fused: the births still need the old poses
       memcpy(h, x, (size_t)f->N * 3 * sizeof(double));
-      HIPCHK(hipMemcpyAsync(dst, h, (size_t)f->N * 3 * sizeof(double), hipMemcpyHostToDevice, f->stream));
-      if (fuse) { f->poseAlt = f->B.pose; f->B.pose = dst; }
+      if (pull) {
+        sp.inX = h;                                        // (births first, then the workgroup overwrites its particle's pose: one buffer)
+      } else {
+        double *dst = fuse ? f->poseAlt : f->B.pose;       // fused predict + copy commands: the births still need the old poses
+        HIPCHK(hipMemcpyAsync(dst, h, (size_t)f->N * 3 * sizeof(double), hipMemcpyHostToDevice, f->stream));
+        if (fuse) { f->poseAlt = f->B.pose; f->B.pose = dst; }
+      }
       double *hc = h + (size_t)f->Ncap * 3;
-      if (cov) {                                           // (the births do not read the pose covariance: in place)
+      if (cov) {                                           // (the births do not read the pose covariance)
         const size_t n = cov_stride == 9 ? (size_t)f->N * 9 : 9;
         memcpy(hc, cov, n * sizeof(double));
-        HIPCHK(hipMemcpyAsync(f->B.poseCov, hc, n * sizeof(double), hipMemcpyHostToDevice, f->stream));
+        if (pull && cov_stride == 9) sp.inCov = hc;
+        else HIPCHK(hipMemcpyAsync(f->B.poseCov, hc, n * sizeof(double), hipMemcpyHostToDevice, f->stream));
         f->P.poseCovStride = cov_stride;
         f->poseCovZero = false;
       } else {
@@ -1211,9 +1258,11 @@ static int cycle_impl(rfsgpu_filter *f, int predict, const double *x, const doub
     if (w_in) {
       double *hw = h + (size_t)f->Ncap * 12;
       memcpy(hw, w_in, (size_t)f->N * sizeof(double));
-      HIPCHK(hipMemcpyAsync(f->B.weight, hw, (size_t)f->N * sizeof(double), hipMemcpyHostToDevice, f->stream));
+      if (pull) sp.inW = hw;
+      else HIPCHK(hipMemcpyAsync(f->B.weight, hw, (size_t)f->N * sizeof(double), hipMemcpyHostToDevice, f->stream));
     }
-    HIPCHK(hipEventRecord(f->evStage[k], f->stream));
+    if (!pull) HIPCHK(hipEventRecord(f->evStage[k], f->stream));
+    else f->stagePendingSlot = k;
   }
   if (n_z == 0) {       // no update (:450-452); the weights are still summed / normalised as the caller asked
     if (!with_sums) return RFSGPU_OK;
@@ -1221,7 +1270,28 @@ static int cycle_impl(rfsgpu_filter *f, int predict, const double *x, const doub
     if (rc != RFSGPU_OK) return rc;
     return normalize ? rfsgpu_normalize_weights(f, 0.0, f->dSums) : RFSGPU_OK;
   }
-  return update_async_impl(f, z, n_z, with_sums, normalize, sp);
+  StepOut so = NO_OUT;
+  if (deliver && pull) {
+    if (!f->hOutW) {
+      HIPCHK(hipHostMalloc(&f->hOutW, (size_t)f->Ncap * sizeof(double) + 2 * sizeof(int)));
+      f->hOutFlag = reinterpret_cast<int *>(f->hOutW + f->Ncap);
+      f->hOutFlag[0] = 0; f->hOutFlag[1] = 0;
+    }
+    so.hostW = f->hOutW; so.hostFlag = f->hOutFlag; so.seq = ++f->outSeq;
+    f->outArmed = true;
+    // a filter that has never queued a Murty partition: the step's last workgroup does the post work itself (tail mode) -- no
+    // second launch; should this very step queue partitions, update_io_end launches the post kernel when it sees the mark
+    f->tailMode = f->ioTail && f->hJobCount && *f->hJobCount == 0 && !with_sums;
+    if (f->tailMode) { sp.ticket = f->dTicket; sp.zNext = f->ZAlt; sp.out = so; }
+  }
+  const long long tp1 = g_ioProf.on ? now_ns() : 0;
+  const int rc = update_async_impl(f, z, n_z, with_sums, normalize, sp, so);
+  if (g_ioProf.on) { const long long tp2 = now_ns(); g_ioProf.stage += tp1 - tp0; g_ioProf.launch += tp2 - tp1; }
+  if (f->stagePendingSlot >= 0) {            // the pinned slot is read by the kernels just enqueued: its event goes behind them
+    if (rc == RFSGPU_OK) HIPCHK(hipEventRecord(f->evStage[f->stagePendingSlot], f->stream));
+    f->stagePendingSlot = -1;
+  }
+  return rc;
 }
 int rfsgpu_cycle_async(rfsgpu_filter *f, int predict, const double *x, const double *x_cov, int cov_stride, const double *w_in, const double *z, int n_z,
                        int normalize) {
@@ -1231,19 +1301,67 @@ int rfsgpu_cycle_async(rfsgpu_filter *f, int predict, const double *x, const dou
 // The synchronous form for a host that stands where RBPHDFilter::update stands (:444-541): everything the update consumes goes in,
 // the particle weights come back, ONE wait for the device and one error check -- in place of set_poses + set_weights + update +
 // get_weights (four calls, two waits: 199 us per update at configs[1] against 125 us stream-ordered, bench.py `boundary`).
+// (two halves, so that a group of shards can have every shard's chain in flight before it waits for the first: csrc/group.h)
+static int update_io_begin(rfsgpu_filter *f, int predict, const double *x, const double *x_cov, int cov_stride, const double *w_in, const double *z, int n_z,
+                           bool want_weights) {
+  const int rc = cycle_impl(f, predict, x, x_cov, cov_stride, w_in, z, n_z, false, 0, true);
+  if (rc != RFSGPU_OK) return rc;
+  if (want_weights && !f->outArmed) {      // (3-D model, phase timing, an empty measurement set, RFSGPU_IO_PULL=0: copy commands)
+    if (!f->hWeights) HIPCHK(hipHostMalloc(&f->hWeights, (size_t)f->Ncap * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(f->hWeights, f->B.weight, (size_t)f->N * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  }
+  return RFSGPU_OK;
+}
+static int update_io_end(rfsgpu_filter *f, double *w_out) {
+  hipSetDevice(f->device);
+  if (f->outArmed) {
+    // the post kernel's last workgroup writes weights, error word and -- behind a system-scope release -- the sequence number
+    // into pinned memory: spin on it (bounded: after ~2 s the stream is asked instead, which also surfaces a launch failure)
+    f->outArmed = false;
+    const long long t0 = now_ns();
+    bool seen = false;
+    for (unsigned spin = 0;; spin++) {
+      if (__atomic_load_n(&f->hOutFlag[1], __ATOMIC_ACQUIRE) == f->outSeq) { seen = true; break; }
+      if ((spin & 1023u) == 1023u && now_ns() - t0 > 2000000000LL) break;
+      __builtin_ia32_pause();
+    }
+    if (seen && f->tailMode && f->hOutFlag[0] == RFSGPU_NEED_POST) {
+      // the step queued Murty partitions (the first time for this filter): its post kernel now, delivering through the same landing area
+      StepOut so{f->hOutW, f->hOutFlag, ++f->outSeq};
+      f->tailMode = false;
+      if (murty_launch(f->Q, f->MS, f->B, f->stream, nullptr, 0, nullptr, 0, f->hJobCount, so) != 0) return fail(f, RFSGPU_ERR_HIP, "post kernel launch failed");
+      seen = false;
+      for (unsigned spin = 0;; spin++) {
+        if (__atomic_load_n(&f->hOutFlag[1], __ATOMIC_ACQUIRE) == f->outSeq) { seen = true; break; }
+        if ((spin & 1023u) == 1023u && now_ns() - t0 > 4000000000LL) break;
+        __builtin_ia32_pause();
+      }
+    }
+    f->tailMode = false;
+    if (seen && f->hOutFlag[0] == 0) {
+      const long long t1 = g_ioProf.on ? now_ns() : 0;
+      if (w_out) memcpy(w_out, f->hOutW, (size_t)f->N * sizeof(double));
+      if (g_ioProf.on) { g_ioProf.n++; g_ioProf.wait += t1 - t0; g_ioProf.copyOut += now_ns() - t1; }
+      return RFSGPU_OK;
+    }
+    const int rc = check_device_errors(f);     // an error bit (or no answer): synchronise, read and clear the word, build the message
+    harvest_async(f);
+    if (w_out) memcpy(w_out, f->hOutW, (size_t)f->N * sizeof(double));
+    if (rc == RFSGPU_OK && !seen) return fail(f, RFSGPU_ERR_HIP, "update_io: the post kernel never delivered its results");
+    return rc;
+  }
+  const int rc = check_device_errors(f);      // the one wait (error word + weights land together)
+  harvest_async(f);
+  if (w_out && f->hWeights) memcpy(w_out, f->hWeights, (size_t)f->N * sizeof(double));
+  return rc;
+}
 int rfsgpu_update_io(rfsgpu_filter *f, int predict, const double *x, const double *x_cov, int cov_stride, const double *w_in, const double *z, int n_z,
                      double *w_out) {
   CHECK_HANDLE(f);
   long long t0 = now_ns();
-  int rc = cycle_impl(f, predict, x, x_cov, cov_stride, w_in, z, n_z, false, 0);
+  int rc = update_io_begin(f, predict, x, x_cov, cov_stride, w_in, z, n_z, w_out != nullptr);
   if (rc != RFSGPU_OK) return rc;
-  if (w_out) {
-    if (!f->hWeights) HIPCHK(hipHostMalloc(&f->hWeights, (size_t)f->Ncap * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(f->hWeights, f->B.weight, (size_t)f->N * sizeof(double), hipMemcpyDeviceToHost, f->stream));
-  }
-  rc = check_device_errors(f);      // the one wait (error word + weights land together)
-  harvest_async(f);
-  if (w_out) memcpy(w_out, f->hWeights, (size_t)f->N * sizeof(double));
+  rc = update_io_end(f, w_out);
   f->timing.mapUpdate_cpu += now_ns() - t0;
   return rc;
 }
@@ -1367,7 +1485,7 @@ int rfsgpu_predict_map(rfsgpu_filter *f, int add_birth) {
   CHECK_HANDLE(f);
   if (add_birth && f->resampleOccured && f->inheritMode == RFSGPU_INHERIT_EXTERNAL && !f->externalAck)
     return fail(f, RFSGPU_ERR_INVALID, "predict_map with births after a resampling in RFSGPU_INHERIT_EXTERNAL mode, but the host has not applied the "
-                "inheritance rule (rfsgpu_get/set_unused_masks, rfsgpu_predict_map_level, or rfsgpu_set_birth_inheritance(EXTERNAL) again to acknowledge): "
+                "inheritance rule (rfsgpu_set_unused_masks, rfsgpu_predict_map_level, or rfsgpu_set_birth_inheritance(EXTERNAL) again to acknowledge): "
                 "go through the multi-GPU host's own predict (ShardedRBPHDFilter.predict_map / rfsgpu_group_predict_map)");
   long long t0 = now_ns();
   hipSetDevice(f->device);
@@ -1386,7 +1504,7 @@ int rfsgpu_predict_map_async(rfsgpu_filter *f, int add_birth) {
   CHECK_HANDLE(f);
   if (add_birth && f->resampleOccured && f->inheritMode == RFSGPU_INHERIT_EXTERNAL && !f->externalAck)
     return fail(f, RFSGPU_ERR_INVALID, "predict_map with births after a resampling in RFSGPU_INHERIT_EXTERNAL mode, but the host has not applied the "
-                "inheritance rule (rfsgpu_get/set_unused_masks, rfsgpu_predict_map_level, or rfsgpu_set_birth_inheritance(EXTERNAL) again to acknowledge): "
+                "inheritance rule (rfsgpu_set_unused_masks, rfsgpu_predict_map_level, or rfsgpu_set_birth_inheritance(EXTERNAL) again to acknowledge): "
                 "go through the multi-GPU host's own predict (ShardedRBPHDFilter.predict_map / rfsgpu_group_predict_map)");
   long long t0 = now_ns();
   hipSetDevice(f->device);
@@ -1698,9 +1816,10 @@ void *rfsgpu_weights_device_ptr(rfsgpu_filter *f) { return f ? (void *)f->B.weig
 int rfsgpu_get_timing(rfsgpu_filter *f, rfsgpu_timing *t) {
   CHECK_HANDLE(f);
   if (!t) return RFSGPU_ERR_INVALID;
-  if (f->normPending || f->predPending) {
+  if (f->normPending || f->predPending || f->ringCount > 0) {   // (steps whose results were delivered through pinned memory have not been harvested yet)
     hipSetDevice(f->device);
     HIPCHK(hipStreamSynchronize(f->stream));
+    harvest_async(f);
     if (f->normPending) accumulate(f->ev[EV_R0], f->ev[EV_R1], f->timing.particleResample_wall, nullptr);
     if (f->predPending) accumulate(f->ev[EV_P0], f->ev[EV_P1], f->timing.predict_wall, nullptr);
     f->normPending = f->predPending = false;

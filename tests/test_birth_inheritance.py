@@ -274,9 +274,10 @@ def test_device_resampling_cycles_match_oracle(pkg, ob, sc, mode):
 def test_external_mode_refuses_an_unacknowledged_birth_predict(pkg, sc):
     """in RFSGPU_INHERIT_EXTERNAL the HOST owns the reference's slot-ordered copy of the per-slot birth lists
     (include/RBPHDFilter.hpp:1005-1011).  A birth predict right after a resampling that reaches the engine without the host having
-    touched the lists (rfsgpu_get / set_unused_masks, rfsgpu_predict_map_level, or the mode set again as an acknowledgement) would
+    applied the rule (rfsgpu_set_unused_masks, rfsgpu_predict_map_level, or the mode set again as an acknowledgement) would
     silently skip the inheritance: it is refused; after the acknowledgement it runs; the Python multi-GPU wrapper gives the handle
-    back in the mode it found."""
+    back in the mode it found.  ADVICE r4: READING the masks acknowledges nothing -- a host that only inspects them must not
+    silence the guard."""
     n = 12
     scen = sc.make_scenario(n, 30, 8, seed=5)
     f = pkg.RBPHDFilter(n, gm_capacity=128)
@@ -290,7 +291,12 @@ def test_external_mode_refuses_an_unacknowledged_birth_predict(pkg, sc):
         f.predict_map(True)
     assert "RFSGPU_INHERIT_EXTERNAL" in str(e.value)
     f.predict_map(False)                                   # (no births: nothing to inherit, allowed)
-    f.get_unused_masks()                                   # the host has looked at the lists
+    m = f.get_unused_masks()                               # the host has only LOOKED at the lists: still refused
+    with pytest.raises(pkg.capi.EngineError):
+        f.predict_map(True)
+    with pytest.raises(pkg.capi.EngineError):              # (the one-submission cycle goes through the same guard)
+        f.cycle_async(True, scen["Z"])
+    f.set_unused_masks(m)                                  # ... and has written them back: the rule is the host's, acknowledged
     f.predict_map(True)
     f.set_birth_inheritance(pkg.capi.INHERIT_REFERENCE)
     sh = pkg.sharded.ShardedRBPHDFilter(f)

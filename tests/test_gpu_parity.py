@@ -375,7 +375,7 @@ def test_fused_predict_update_cycle_is_the_call_by_call_cycle(pkg, ob, sc, n_lm,
             for f in (fus, ref, orc):
                 f.resample_apply(src)
             poses = poses[src]
-    assert saw == {1, 2}, saw          # both forms ran: the fused head (2) and the fall-back to the stand-alone predict (1)
+    assert saw == {2, 3}, saw          # both forms ran: the predict at the head (2) and the fall-back to the stand-alone predict kernel (3: the head only pulls the inputs)
     ref.close()
 
 
@@ -405,6 +405,20 @@ def test_update_io_is_set_poses_set_weights_update_get_weights(pkg, ob, sc):
         for i in range(scen["n"]):
             for x, y in zip(a.export_gm(i), b.export_gm(i)):
                 np.testing.assert_array_equal(x, y)
+    # a filter whose FIRST update queues Murty partitions: the step ran in tail mode (no post kernel enqueued), its last workgroup
+    # leaves the RFSGPU_NEED_POST mark, the waiting call launches the post kernel after all -- same weights as rfsgpu_update's
+    mscen = sc.make_scenario(16, 200, 50, seed=555, n_clutter=10, n_eval=40, weighting_md=10.0, weights=(0.8, 1.0))
+    m1 = pkg.RBPHDFilter(16, gm_capacity=448)
+    m2 = pkg.RBPHDFilter(16, gm_capacity=448)
+    for f in (m1, m2):
+        sc.load_scenario(f, mscen)
+    for rep in range(3):                       # (the second and third go the two-launch way: the filter has shown Murty work)
+        w1 = m1.update_io(mscen["Z"], weights=np.ones(16))
+        m2.set_weights(np.ones(16))
+        m2.update(mscen["Z"])
+        np.testing.assert_array_equal(w1, m2.get_weights())
+        assert np.ptp(w1) > 0
+    m1.close(); m2.close()
     small = pkg.RBPHDFilter(4, gm_capacity=64)
     sc.load_scenario(small, sc.make_scenario(4, 60, 30, seed=16))
     with pytest.raises(pkg.capi.EngineError) as e:

@@ -45,7 +45,7 @@ def test_unmodified_reference_driver_compiles_and_links_against_the_binding(lib,
     assert "librfsgpu.so" in needed
     undefined = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True).stdout
     used = set(re.findall(r"\b(rfsgpu_\w+)", undefined))
-    assert {"rfsgpu_create", "rfsgpu_update", "rfsgpu_predict_map", "rfsgpu_resample_apply", "rfsgpu_get_landmark"} <= used
+    assert {"rfsgpu_create", "rfsgpu_update_io", "rfsgpu_predict_map", "rfsgpu_resample_apply", "rfsgpu_get_landmark"} <= used      # (round 5: update() is ONE engine call, rfsgpu_update_io)
     exported = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True).stdout
     assert used <= set(re.findall(r"\b(rfsgpu_\w+)", exported))
     help_ = subprocess.run([exe, "-h"], capture_output=True, text=True, timeout=60)
