@@ -74,11 +74,7 @@ struct rfsgpu_filter {
   bool outArmed = false;              // the step in flight delivers through hOutW / hOutFlag (update_io_end spins instead of synchronising)
 
   int stagePendingSlot = -1;          // a staging slot whose event must be recorded behind the step that reads it
-  bool ioTail = true;                 // RFSGPU_IO_TAIL=0: the post kernel always follows as its own launch (A/B)
   bool ioPull = true;                 // RFSGPU_IO_PULL=0: inputs by copy commands, outputs by copies + a stream synchronisation (A/B, rounds 3-4 form)
-  double *ZAlt = nullptr;             // second measurement buffer (tail mode of the fused step: the step writes the set the NEXT predict reads while this launch's births still read the previous one)
-  int *dTicket = nullptr;             // finished-workgroup counter of the tail mode
-  bool tailMode = false;              // the step in flight ran in tail mode: RFSGPU_NEED_POST in the landing area means "launch the post kernel now"
   double *poseAlt = nullptr;          // [Ncap][3] second pose buffer: a fused predict + update cycle births at the old poses and updates at the new ones (rfsgpu_cycle_async)
   hipEvent_t evStage[4] = {};
   int stageNext = 0;
@@ -277,7 +273,6 @@ int rfsgpu_create_ex(rfsgpu_filter **out, int model, int n_particles, int device
   f->fs.nParticlesMax = 3 * n_particles;
   { const char *e = getenv("RFSGPU_FUSED_STEP"); if (e && e[0] == '0') f->fuseSteps = false; }
   { const char *e = getenv("RFSGPU_IO_PULL"); if (e && e[0] == '0') f->ioPull = false; }
-  { const char *e = getenv("RFSGPU_IO_TAIL"); if (e && e[0] == '0') f->ioTail = false; }
   { const char *e = getenv("RFSGPU_STEP_WPP"); if (e) f->stepWppOverride = atoi(e); }
   { const char *e = getenv("RFSGPU_BIRTH_INHERITANCE"); if (e && !strcmp(e, "eager")) f->inheritMode = RFSGPU_INHERIT_EAGER; }   // (initial mode; rfsgpu_set_birth_inheritance)
   { const char *e = getenv("RFSGPU_MERGE_GRID"); if (e) f->mergeGridOverride = atoi(e); }
@@ -309,8 +304,6 @@ int rfsgpu_create_ex(rfsgpu_filter **out, int model, int n_particles, int device
   ok &= hipMalloc(&B.nInFov, f->Ncap * sizeof(int)) == hipSuccess;
   ok &= hipMalloc(&B.err, sizeof(int)) == hipSuccess;
   ok &= hipMalloc(&B.Z, RFSGPU_MAX_Z * 3 * sizeof(double)) == hipSuccess;
-  ok &= hipMalloc(&f->ZAlt, RFSGPU_MAX_Z * 3 * sizeof(double)) == hipSuccess;
-  ok &= hipMalloc(&f->dTicket, sizeof(int)) == hipSuccess;
   ok &= hipMalloc(&B.scan, RFSGPU_VP_MAX_SCAN * sizeof(double)) == hipSuccess;
   ok &= hipMalloc(&B.candMean, (size_t)f->Ncap * RFSGPU_MAX_CANDIDATES * 3 * sizeof(double)) == hipSuccess;
   ok &= hipMalloc(&B.candCov, (size_t)f->Ncap * RFSGPU_MAX_CANDIDATES * 6 * sizeof(double)) == hipSuccess;
@@ -337,8 +330,6 @@ int rfsgpu_create_ex(rfsgpu_filter **out, int model, int n_particles, int device
   hipMemsetAsync(B.nInFov, 0, f->Ncap * sizeof(int), f->stream);
   hipMemsetAsync(B.err, 0, sizeof(int), f->stream);
   hipMemsetAsync(B.Z, 0, RFSGPU_MAX_Z * 3 * sizeof(double), f->stream);
-  hipMemsetAsync(f->ZAlt, 0, RFSGPU_MAX_Z * 3 * sizeof(double), f->stream);
-  hipMemsetAsync(f->dTicket, 0, sizeof(int), f->stream);
   hipMemsetAsync(B.scan, 0, RFSGPU_VP_MAX_SCAN * sizeof(double), f->stream);
   hipMemsetAsync(B.candCount, 0, (size_t)f->Ncap * sizeof(int), f->stream);
   B.nScan = 0;
@@ -368,7 +359,7 @@ void rfsgpu_destroy(rfsgpu_filter *f) {
   Buffers &B = f->B;
   hipFree(f->snapSlab); hipFree(f->snapWeight); hipFree(f->snapCount); hipFree(f->snapFov); hipFree(f->snapUnused);
   hipFree(B.slab[0]); hipFree(B.slab[1]); hipFree(B.count); hipFree(B.pose); hipFree(f->poseAlt); hipFree(B.poseCov); hipFree(B.weight);
-  hipFree(B.unusedMask); hipFree(B.nInFov); hipFree(B.err); hipFree(B.Z); hipFree(f->ZAlt); hipFree(f->dTicket); hipFree(f->ownSums); hipFree(f->dSrcSlot); if (f->dRowSlots) hipFree(f->dRowSlots); if (f->fsArena) hipFree(f->fsArena); if (f->mhArena) hipFree(f->mhArena); if (f->mhInts) hipFree(f->mhInts);
+  hipFree(B.unusedMask); hipFree(B.nInFov); hipFree(B.err); hipFree(B.Z); hipFree(f->ownSums); hipFree(f->dSrcSlot); if (f->dRowSlots) hipFree(f->dRowSlots); if (f->fsArena) hipFree(f->fsArena); if (f->mhArena) hipFree(f->mhArena); if (f->mhInts) hipFree(f->mhInts);
   if (f->dInhParent) hipFree(f->dInhParent);
   if (f->dInhLevel) hipFree(f->dInhLevel);
   hipFree(f->inhTmp.unused); hipFree(f->inhTmp.count); hipFree(f->inhTmp.sup); hipFree(f->inhTmp.chk); hipFree(f->inhTmp.mean); hipFree(f->inhTmp.cov);  // (hipFree(nullptr) is a no-op)
@@ -511,7 +502,7 @@ int rfsgpu_set_lmk_process_noise(rfsgpu_filter *f, const double *Q) {
 static int stage_slot(rfsgpu_filter *f, double **h, int *k_out) {
   const int k = f->stageNext;
   f->stageNext = (k + 1) & 3;
-  const size_t slotDoubles = (size_t)f->Ncap * 13 + RFSGPU_VP_MAX_SCAN;   // poses | pose covariances | weights | laser scan
+  const size_t slotDoubles = (size_t)f->Ncap * 22 + RFSGPU_VP_MAX_SCAN;   // poses | pose covariances | weights (or the 13-per-particle packed form) | covariances of the packed form's copy path | laser scan
   const bool fresh = !f->hStage[k] || !f->evStage[k];   // (either creation may have failed on an earlier call: each is retried on its own)
   if (!f->hStage[k]) HIPCHK(hipHostMalloc(&f->hStage[k], slotDoubles * sizeof(double)));
   if (!f->evStage[k]) HIPCHK(hipEventCreateWithFlags(&f->evStage[k], hipEventDisableTiming));
@@ -947,7 +938,7 @@ int rfsgpu_prune(rfsgpu_filter *f) {
 
 // All four phases back to back on the stream, ONE host sync at the end (RBPHDFilter::update body :444-523).
 static const StepOut NO_OUT{nullptr, nullptr, 0};
-static const StepPredict NO_HEAD{0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, StepOut{nullptr, nullptr, 0}};
+static const StepPredict NO_HEAD{0, 0, nullptr, nullptr, 0};
 static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool with_sums, int normalize, const StepPredict &sp = NO_HEAD, const StepOut &so = NO_OUT);
 int rfsgpu_update(rfsgpu_filter *f, const double *z, int n_z) {
   CHECK_HANDLE(f);
@@ -1060,11 +1051,11 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
     // phase priorities only when every workgroup is resident at once: 16 waves per CU at 128 VGPRs, LDS permitting
     const int perCU = (int)std::min<size_t>(16 / wpp, b ? (size_t)(160 * 1024) / b : 16);
     const int phasePrio = (long long)perCU * f->nCU >= f->N ? 1 : 0;
-    f->lastStepVariant[0] = wpp; f->lastStepVariant[1] = phasePrio; f->lastStepVariant[2] = 5; f->lastStepVariant[3] = sp.mode ? 2 : ((sp.inX || sp.inCov || sp.inW) ? 3 : 1);   // ([3]: 1 = fused step, 2 = with the predict at its head, 3 = with the input pull only)
+    f->lastStepVariant[0] = wpp; f->lastStepVariant[1] = phasePrio; f->lastStepVariant[2] = 5; f->lastStepVariant[3] = sp.mode ? 2 : (sp.inMask ? 3 : 1);   // ([3]: 1 = fused step, 2 = with the predict at its head, 3 = with the input pull only)
     // (one instantiation per {waves per particle, phase priorities, merge grid} x {plain step, step with the predict at its head})
 #define STEP_LAUNCH(WPPV, PRIO, GLV, BYTES)                                                                                            \
     do {                                                                                                                                \
-      if (sp.mode || sp.inX || sp.inCov || sp.inW || sp.ticket) {                                                                       \
+      if (sp.mode || sp.inMask) {                                                                                                        \
         if ((rc = set_lds(f, (phd_step_fused_kernel<WPPV, PRIO, GLV, true>), BYTES)) != RFSGPU_OK) return rc;                           \
         phd_step_fused_kernel<WPPV, PRIO, GLV, true><<<f->N, WPPV * 64, BYTES, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za, sp);  \
       } else {                                                                                                                          \
@@ -1094,9 +1085,7 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
 #undef STEP_LAUNCH
     HIPCHK(hipGetLastError());
     if (timed) HIPCHK(hipEventRecord(e[3], f->stream));
-    if (sp.ticket) {      // tail mode: the last workgroup of the step kernel has done the post work; the measurement set went to the other buffer
-      double *t = f->B.Z; f->B.Z = f->ZAlt; f->ZAlt = t;
-    } else if (murty_launch(f->Q, f->MS, f->B, f->stream, with_sums ? f->dSums : nullptr, normalize, &za, 2 * n_z, f->hJobCount, so) != 0) return fail(f, RFSGPU_ERR_HIP, "post kernel launch failed");
+    if (murty_launch(f->Q, f->MS, f->B, f->stream, with_sums ? f->dSums : nullptr, normalize, &za, 2 * n_z, f->hJobCount, so) != 0) return fail(f, RFSGPU_ERR_HIP, "post kernel launch failed");
     if (timed) HIPCHK(hipEventRecord(e[1], f->stream));
     f->cur ^= 1;  // the map update works in place, the weighting phase leaves only a permutation in LDS, merge + prune write the other slab
     if (timed) {
@@ -1229,21 +1218,32 @@ static int cycle_impl(rfsgpu_filter *f, int predict, const double *x, const doub
     double *h = nullptr;
     int k = 0;
     { const int rc = stage_slot(f, &h, &k); if (rc != RFSGPU_OK) return rc; }
+    const bool pullCov = pull && x && cov && cov_stride == 9;
+    if (pull) {
+      // 13 doubles per particle side by side: the workgroup that owns a particle reads them in one go (step_fused.h, StepPredict)
+      sp.inPacked = h;
+      sp.inMask = (x ? 1 : 0) | (pullCov ? 2 : 0) | (w_in ? 4 : 0);
+      for (int i = 0; i < f->N; i++) {
+        double *d = h + (size_t)13 * i;
+        if (x) { d[0] = x[3 * i]; d[1] = x[3 * i + 1]; d[2] = x[3 * i + 2]; }
+        if (pullCov) memcpy(d + 3, cov + (size_t)9 * i, 9 * sizeof(double));
+        if (w_in) d[12] = w_in[i];
+      }
+    }
     if (x) {
-      memcpy(h, x, (size_t)f->N * 3 * sizeof(double));
-      if (pull) {
-        sp.inX = h;                                        // (births first, then the workgroup overwrites its particle's pose: one buffer)
-      } else {
+      if (!pull) {
+        memcpy(h, x, (size_t)f->N * 3 * sizeof(double));
         double *dst = fuse ? f->poseAlt : f->B.pose;       // fused predict + copy commands: the births still need the old poses
         HIPCHK(hipMemcpyAsync(dst, h, (size_t)f->N * 3 * sizeof(double), hipMemcpyHostToDevice, f->stream));
         if (fuse) { f->poseAlt = f->B.pose; f->B.pose = dst; }
       }
-      double *hc = h + (size_t)f->Ncap * 3;
+      double *hc = h + (size_t)f->Ncap * 13;               // (behind the packed block: the small / copy-command forms of the covariance)
       if (cov) {                                           // (the births do not read the pose covariance)
-        const size_t n = cov_stride == 9 ? (size_t)f->N * 9 : 9;
-        memcpy(hc, cov, n * sizeof(double));
-        if (pull && cov_stride == 9) sp.inCov = hc;
-        else HIPCHK(hipMemcpyAsync(f->B.poseCov, hc, n * sizeof(double), hipMemcpyHostToDevice, f->stream));
+        if (!pullCov) {
+          const size_t n = cov_stride == 9 ? (size_t)f->N * 9 : 9;
+          memcpy(hc, cov, n * sizeof(double));
+          HIPCHK(hipMemcpyAsync(f->B.poseCov, hc, n * sizeof(double), hipMemcpyHostToDevice, f->stream));
+        }
         f->P.poseCovStride = cov_stride;
         f->poseCovZero = false;
       } else {
@@ -1255,11 +1255,10 @@ static int cycle_impl(rfsgpu_filter *f, int predict, const double *x, const doub
         f->P.poseCovStride = 0;
       }
     }
-    if (w_in) {
+    if (w_in && !pull) {
       double *hw = h + (size_t)f->Ncap * 12;
       memcpy(hw, w_in, (size_t)f->N * sizeof(double));
-      if (pull) sp.inW = hw;
-      else HIPCHK(hipMemcpyAsync(f->B.weight, hw, (size_t)f->N * sizeof(double), hipMemcpyHostToDevice, f->stream));
+      HIPCHK(hipMemcpyAsync(f->B.weight, hw, (size_t)f->N * sizeof(double), hipMemcpyHostToDevice, f->stream));
     }
     if (!pull) HIPCHK(hipEventRecord(f->evStage[k], f->stream));
     else f->stagePendingSlot = k;
@@ -1279,10 +1278,6 @@ static int cycle_impl(rfsgpu_filter *f, int predict, const double *x, const doub
     }
     so.hostW = f->hOutW; so.hostFlag = f->hOutFlag; so.seq = ++f->outSeq;
     f->outArmed = true;
-    // a filter that has never queued a Murty partition: the step's last workgroup does the post work itself (tail mode) -- no
-    // second launch; should this very step queue partitions, update_io_end launches the post kernel when it sees the mark
-    f->tailMode = f->ioTail && f->hJobCount && *f->hJobCount == 0 && !with_sums;
-    if (f->tailMode) { sp.ticket = f->dTicket; sp.zNext = f->ZAlt; sp.out = so; }
   }
   const long long tp1 = g_ioProf.on ? now_ns() : 0;
   const int rc = update_async_impl(f, z, n_z, with_sums, normalize, sp, so);
@@ -1325,19 +1320,6 @@ static int update_io_end(rfsgpu_filter *f, double *w_out) {
       if ((spin & 1023u) == 1023u && now_ns() - t0 > 2000000000LL) break;
       __builtin_ia32_pause();
     }
-    if (seen && f->tailMode && f->hOutFlag[0] == RFSGPU_NEED_POST) {
-      // the step queued Murty partitions (the first time for this filter): its post kernel now, delivering through the same landing area
-      StepOut so{f->hOutW, f->hOutFlag, ++f->outSeq};
-      f->tailMode = false;
-      if (murty_launch(f->Q, f->MS, f->B, f->stream, nullptr, 0, nullptr, 0, f->hJobCount, so) != 0) return fail(f, RFSGPU_ERR_HIP, "post kernel launch failed");
-      seen = false;
-      for (unsigned spin = 0;; spin++) {
-        if (__atomic_load_n(&f->hOutFlag[1], __ATOMIC_ACQUIRE) == f->outSeq) { seen = true; break; }
-        if ((spin & 1023u) == 1023u && now_ns() - t0 > 4000000000LL) break;
-        __builtin_ia32_pause();
-      }
-    }
-    f->tailMode = false;
     if (seen && f->hOutFlag[0] == 0) {
       const long long t1 = g_ioProf.on ? now_ns() : 0;
       if (w_out) memcpy(w_out, f->hOutW, (size_t)f->N * sizeof(double));
@@ -1627,7 +1609,7 @@ int rfsgpu_set_step_inputs_async(rfsgpu_filter *f, const double *x, const double
     area += scan[0] * scan[n_scan - 1];
     area *= sin(acos(-1) / 360) / 2;
     f->vpClutter = f->vp.expectedClutterNumber / area;
-    double *hs = h + (size_t)f->Ncap * 13;
+    double *hs = h + (size_t)f->Ncap * 22;
     memcpy(hs, scan, (size_t)n_scan * sizeof(double));
     HIPCHK(hipMemcpyAsync(f->B.scan, hs, (size_t)n_scan * sizeof(double), hipMemcpyHostToDevice, f->stream));
     f->B.nScan = n_scan;

@@ -14,32 +14,29 @@
 #include "update_map.h"
 #include "weighting.h"
 #include "merge_prune.h"
-#include "murty.h"
 
 #ifndef STEP_WPP
 #define STEP_WPP 2
 #endif
 // What the head of a step does before the map update (rfsgpu_cycle_async / rfsgpu_update_io, round 5).
 // mode: the predict folded in -- 0 = none, 1 = static step only, 2 = births + static step.
-// inX / inCov / inW: the host's new poses [N][3], pose covariances [N][9] and particle weights [N] in a PINNED host buffer the
-// kernel reads over PCIe itself (each workgroup pulls its particle's 13 doubles and leaves them in the device arrays for every
-// later kernel) -- no copy commands in front of the step: three SDMA / blit copies and their queue hand-overs were 40 us of a
-// 180 us update through the boundary at configs[1] (tools/boundary_trace.py).  NULL = that array is unchanged.
-// tail: the step's POST work by the last workgroup to finish (a ticket) instead of a second launch -- only for the synchronous
-// rfsgpu_update_io of a filter that has not shown Murty work: the measurement set goes to `zNext` (the buffer the next predict
-// reads; the host swaps the two), and the last workgroup delivers weights + error word + sequence number to the pinned landing
-// area (murty.h, step_post_out) -- or, if this very step queued Murty partitions, the RFSGPU_NEED_POST mark, on which the waiting
-// host launches the post kernel after all.  One launch and one queue hand-over less per update (12 us at configs[1]).
+// inPacked: the host's new inputs in a PINNED host buffer the kernel reads over PCIe itself, 13 doubles per particle side by side
+// (pose 3 | pose covariance 9 | weight 1: ONE contiguous 104-byte read per workgroup; three separate arrays were three small PCIe
+// reads per workgroup and made the kernel 25 us longer), which the workgroup leaves in the device arrays for every later kernel --
+// no copy commands in front of the step: three SDMA / blit copies and their queue hand-overs were 40 us of a 180 us update through
+// the boundary at configs[1] (tools/boundary_trace.py).  inMask: bit 0 poses, bit 1 covariances, bit 2 weights present.
 struct StepPredict {
   int mode;
   int nZprev;                // measurements of the previous update (B.Z holds them until this step's post kernel)
   const double *birthPose;   // [N][3] the poses the previous update used
-  const double *inX, *inCov, *inW;
-  int *ticket;               // tail mode: finished-workgroup counter (nullptr: the post kernel follows as a launch of its own)
-  double *zNext;
-  StepOut out;
+  const double *inPacked;
+  int inMask;
 };
-#define RFSGPU_NEED_POST 0x40000000   /* error-word mark: the step queued Murty partitions, its post kernel has not run */
+// (Measured and dropped, round 5 -- profiles/r05b_*: the step's POST work by the last workgroup of this kernel to finish (a ticket,
+//  weights re-stored write-through, results to the pinned landing area) instead of the post kernel's launch, for filters without
+//  Murty work: the launch, the queue hand-over and the post kernel it saves cost what the ticket and the delivery cost here --
+//  136.7 + 4.2 us against 134.5 + 7.9 us per update through the boundary.  On the way: a device-scope fence per finishing workgroup
+//  writes back the XCD's whole L2 each time, 112 -> 215 us; one agent-scope load per weight in the last workgroup, +30 us.)
 #ifndef STEP_WAVES_PER_EU
 #define STEP_WAVES_PER_EU 4  // <= 128 VGPRs: 8 workgroups of 2 waves per CU, i.e. all 2000 particles of C2 resident at once
 #endif
@@ -78,9 +75,12 @@ void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, in
   if constexpr (PRED) {
     if (SP.mode) predict_map_particle<WPP * 64>(B, P, cur, i, tid, SP.mode > 1, SP.nZprev, SP.birthPose, true);
     // the host's inputs for THIS update, after the births have read the old pose (same wave, program order)
-    if (tid < 3 && SP.inX) B.pose[3 * i + tid] = SP.inX[3 * i + tid];
-    if (tid >= 64 && tid < 73 && SP.inCov) B.poseCov[9 * i + (tid - 64)] = SP.inCov[9 * i + (tid - 64)];
-    if (tid == 16 && SP.inW) B.weight[i] = SP.inW[i];
+    if (SP.inMask && tid < 13) {
+      const double v = SP.inPacked[13 * i + tid];
+      if (tid < 3) { if (SP.inMask & 1) B.pose[3 * i + tid] = v; }
+      else if (tid < 12) { if (SP.inMask & 2) B.poseCov[9 * i + (tid - 3)] = v; }
+      else if (SP.inMask & 4) B.weight[i] = v;
+    }
     __threadfence_block();
     __syncthreads();
     __builtin_amdgcn_s_dcache_inv();   // count / pose / covariance are read through the scalar cache below: drop what the head's own loads left there
@@ -97,10 +97,6 @@ void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, in
   // device buffer that later kernels read (the next predict's births).  (Writing it from here cost 112 B/lane of scratch.)
   stage_measurements_lds(smem_raw, [&](int t) { return zarg.v[t]; }, nZ, tid, WPP * 64);
   __syncthreads();
-  if constexpr (PRED) {
-    if (SP.ticket && i == 0)   // tail mode: the measurement set for the next predict's births, from the LDS copy (the post kernel's job otherwise)
-      for (int t = tid; t < 2 * nZ; t += WPP * 64) SP.zNext[t] = reinterpret_cast<const double *>(smem_raw)[t];
-  }
 #ifdef RFS_PROFILE
   long long *fd = B.dbg ? B.dbg + 64 + 4 * (size_t)B.N + 4 * (size_t)i : nullptr;
   if (fd && tid == 0) {  // start tick | (XCC_ID << 60) | (HW_ID[15:0] << 44)
@@ -149,49 +145,4 @@ void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, in
 #ifdef RFS_PROFILE
   if (fd && tid == 0) fd[3] = (long long)wall_clock64();
 #endif
-  if constexpr (PRED) {
-    if (SP.ticket) {
-      // No device-wide fence here: on this part an agent-scope release writes back the XCD's whole L2 (buffer_wbl2) -- 2000 of
-      // those, one per finishing workgroup, doubled the kernel (112 -> 215 us, measured).  What the last workgroup needs from the
-      // others is 8 bytes each: every workgroup re-stores its particle's weight with an agent-scope (write-through, sc1) store,
-      // waits for it, takes its ticket; the last one invalidates (agent-scope acquire: buffer_inv, cheap) and reads the weights back.  Error bits and the Murty
-      // job count are device-scope atomics already.  (The flag lives in the dynamic LDS block, which every thread has left by
-      // the first barrier: a static word would push the workgroup's LDS over 20 KB at configs[1], seven workgroups per CU.)
-      volatile int *sLast = reinterpret_cast<volatile int *>(smem_raw);
-      __threadfence_block();
-      __syncthreads();
-      if (tid == 0) {
-        const unsigned long long w = reinterpret_cast<const unsigned long long *>(B.weight)[i];
-        __hip_atomic_store(reinterpret_cast<unsigned long long *>(B.weight) + i, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (s_waitcnt vmcnt(0): the write-through store is acknowledged before the ticket)
-        *sLast = (__hip_atomic_fetch_add(SP.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) ? 1 : 0;
-      }
-      __syncthreads();
-      if (*sLast) {
-        if (tid == 0) __hip_atomic_store(SP.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int nJobs = __hip_atomic_load(Q.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (nJobs == 0) {
-          // (an agent-scope ACQUIRE only invalidates -- buffer_inv, no write-back -- and lets the weights be read by plain, pipelined
-          //  loads; one agent-scope load per weight, 16 dependent memory round trips per thread, cost 30 us)
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          for (int k = tid; k < B.N; k += WPP * 64) SP.out.hostW[k] = B.weight[k];
-          // The landing area is fine-grained (coherent) host memory: the GPU maps it uncached, stores go straight out over PCIe
-          // and stay in order there (posted writes).  A system-scope release would add a write-back of this XCD's whole L2 --
-          // megabytes of slab data the kernel has just written (+30 us, measured) -- which these stores do not need: each thread
-          // waits for its own stores to be acknowledged (vmcnt(0)), the barrier collects the threads, then the flag goes out.
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          __syncthreads();
-          if (tid == 0) {
-            SP.out.hostFlag[0] = __hip_atomic_load(B.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __hip_atomic_store(&SP.out.hostFlag[1], SP.out.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          }
-        } else if (tid == 0) {             // Murty partitions were queued after all: the host launches the post kernel
-          SP.out.hostFlag[0] = RFSGPU_NEED_POST;
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          __hip_atomic_store(&SP.out.hostFlag[1], SP.out.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-      }
-    }
-  }
 }

@@ -405,14 +405,14 @@ def test_update_io_is_set_poses_set_weights_update_get_weights(pkg, ob, sc):
         for i in range(scen["n"]):
             for x, y in zip(a.export_gm(i), b.export_gm(i)):
                 np.testing.assert_array_equal(x, y)
-    # a filter whose FIRST update queues Murty partitions: the step ran in tail mode (no post kernel enqueued), its last workgroup
-    # leaves the RFSGPU_NEED_POST mark, the waiting call launches the post kernel after all -- same weights as rfsgpu_update's
+    # a filter whose updates queue Murty partitions (first the light post-kernel instance, then the eight-wave one): the weights the
+    # post kernel delivers to the pinned landing area carry the Murty factors -- same weights as rfsgpu_update's
     mscen = sc.make_scenario(16, 200, 50, seed=555, n_clutter=10, n_eval=40, weighting_md=10.0, weights=(0.8, 1.0))
     m1 = pkg.RBPHDFilter(16, gm_capacity=448)
     m2 = pkg.RBPHDFilter(16, gm_capacity=448)
     for f in (m1, m2):
         sc.load_scenario(f, mscen)
-    for rep in range(3):                       # (the second and third go the two-launch way: the filter has shown Murty work)
+    for rep in range(3):
         w1 = m1.update_io(mscen["Z"], weights=np.ones(16))
         m2.set_weights(np.ones(16))
         m2.update(mscen["Z"])
