@@ -504,12 +504,43 @@ def main():
     Z = scen["Z"]
     sums_ptr = sums.data_ptr()
 
+    # N > 1: the one collective of the path -- the all-reduce of {sum w, sum w^2}, 2 doubles over xGMI -- runs on a side stream BESIDE the
+    # next step's kernel: the post kernel of step k + 1 divides the weights by step k's total (rfsgpu_step_async_deferred) instead
+    # of a divide kernel behind the collective at the end of step k (round 4: 21 us per step with one rank).  RFS_BENCH_INLINE_COLLECTIVE=1
+    # restores the round-4 order (A/B).
+    deferred = multi and os.environ.get("RFS_BENCH_INLINE_COLLECTIVE") != "1"
+    if deferred:
+        side = torch.cuda.Stream()
+        tot = torch.ones(2, dtype=torch.float64, device=dev)
+        ev_post, ev_tot = torch.cuda.Event(), torch.cuda.Event()
+        ev_post.record(stream); ev_tot.record(side)          # (creates the handles)
+        pend = {"have": False}
+
+        def collective_step(Zk):
+            f.step_async_deferred(Zk, tot.data_ptr() if pend["have"] else None, ev_tot.cuda_event if pend["have"] else None)
+            ev_post.record(stream)
+            with torch.cuda.stream(side):
+                side.wait_event(ev_post)
+                tot.copy_(sums)
+                dist.all_reduce(tot)
+                ev_tot.record(side)
+            pend["have"] = True
+
+        def collective_flush():          # what a host does when it needs the normalised weights / N_eff (the resample test)
+            if pend["have"]:
+                stream.wait_event(ev_tot)
+                f.normalize_weights(0.0, tot.data_ptr(), 1)
+                pend["have"] = False
+
     if wl["reseed"]:
         def step(k):
             f.restore_state()
             # stream-ordered: the host never waits inside a step; device errors surface at the final sync.  Two launches: the
             # fused step kernel (measurement set in its arguments) and the post kernel (Murty partitions if any, weight sums,
             # and -- one GPU -- the division).
+            if deferred:
+                collective_step(Z)
+                return
             f.step_async(Z, not multi)
             if multi:                 # the only collective on the path: 2 doubles over xGMI
                 with torch.cuda.stream(stream):
@@ -597,6 +628,8 @@ def main():
         step(k)
         if not wl["reseed"]:         # (C2b's predict_map syncs anyway: per-step wall times for the median)
             per_step.append(time.perf_counter())
+    if deferred:
+        collective_flush()           # the last step's total: wait for its collective, divide (inside the timed region)
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
@@ -708,7 +741,9 @@ def main():
                 "pre_warmup_steps": pre_warm,      # untimed clock-ramp steps (0.25 s) ahead of the W warm-up steps
                 "unit_definition": "one step = one update(Z) of one shard of %d particles; value sums the shard-steps of all ranks "
                                    "(global filter of %d particles: %.3f updates/s)" % (n_local, n_local * world, args.steps / dt),
-                "parallelism": f"particle-sharded: {world} GPU(s), one process per GPU, RCCL all-reduce of 2 doubles/step on the engine's stream",
+                "parallelism": f"particle-sharded: {world} GPU(s), one process per GPU, RCCL all-reduce of 2 doubles/step" +
+                               (" on a side stream beside the next step's kernel; the weights are divided by the previous step's total inside the post kernel "
+                                "(rfsgpu_step_async_deferred), the last total is applied before the timed region ends" if deferred else " on the engine's stream"),
                 "gm_before": nM // n_local, "gm_after_update": nAfter // n_local, "gm_after_prune": nKept // n_local,
                 "kernels": {(fused_name if fused else "three_kernels"): dict(ms=round(float(kern_ms[0]) if fused else float(kern_ms.sum()), 5),
                                                                                survey_bytes_step=int(bytes_step), design_bytes=design_total),

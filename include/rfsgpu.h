@@ -299,6 +299,14 @@ int rfsgpu_step_async(rfsgpu_filter *f, const double *z, int n_z, int normalize)
  * (2-D model, immediate births, no inheritance walk pending, n_z > 0) the predict runs at the head of the fused step kernel --
  * one launch chain per cycle, no separate predict launch; otherwise the stand-alone kernels are enqueued in the same order.
  * Same results either way as rfsgpu_predict_map + rfsgpu_set_poses + rfsgpu_set_weights + rfsgpu_step_async. */
+/* [multi] rfsgpu_step_async(normalize = 0) for hosts that shard the particles over several GPUs, with the weight normalisation
+ * trailing by one step: the post kernel divides the weights by *prev_total_dev ({sum w, sum w^2} of the PREVIOUS step over all
+ * shards, device memory, NULL = none) before it takes this step's sums into the bound sums buffer, and the stream waits for
+ * `wait_event` (a hipEvent_t recorded on another stream behind the collective that wrote that total; NULL = none) only between
+ * the step kernel and the post kernel.  The one collective of the path then runs beside the next step kernel, not in front of
+ * it.  (w L) / T instead of (w / T) L: an ulp apart from the call-by-call order.  A host that needs the normalised weights or
+ * N_eff (the resample test, include/ParticleFilter.hpp:405-415) finishes with rfsgpu_normalize_weights(f, 0, total_dev). */
+int rfsgpu_step_async_deferred(rfsgpu_filter *f, const double *z, int n_z, const void *prev_total_dev, void *wait_event);
 #define RFSGPU_CYCLE_NO_PREDICT (-1)
 int rfsgpu_cycle_async(rfsgpu_filter *f, int predict, const double *x, const double *x_cov, int cov_stride, const double *w_in,
                        const double *z, int n_z, int normalize);
@@ -489,6 +497,11 @@ int rfsgpu_group_set_birth_inheritance(rfsgpu_group *g, int mode);          /* R
 int rfsgpu_group_get_particle_ids(rfsgpu_group *g, int *id, int *parent_id); /* Particle::getId / getParentId by global slot */
 /* RBPHDFilter::update body (:444-523) on every shard; weights stay un-normalised; sums_out (may be null) = {sum w, sum w^2}. */
 int rfsgpu_group_update(rfsgpu_group *g, const double *z, int n_z, double *sums_out);
+/* rfsgpu_group_update whose weight normalisation trails by one step (RCCL path: the all-reduce of {sum w, sum w^2} on a side stream
+ * per shard beside the next step's kernel; each shard's post kernel divides by the previous call's total, rfsgpu_step_async_deferred).
+ * Nothing waits for the GPUs; the next rfsgpu_group_* call that reads or replaces the weights applies the pending total first.
+ * For steps after which the host does not need N_eff (the resample test is not due). */
+int rfsgpu_group_update_deferred(rfsgpu_group *g, const double *z, int n_z);
 /* The group form of rfsgpu_update_io: global poses (+ covariances, NULL = unchanged) and weights (NULL = unchanged) in, the update on every
  * shard (all chains enqueued before the first wait), the updated un-normalised weights of all particles out (NULL = not wanted);
  * device-side errors of any shard are reported by this call. */

@@ -118,12 +118,12 @@ ABI_SYMBOLS = [
     "normalize_weights_parts", "create_ex", "n_particles", "max_particles", "resample_apply_n",
     "fastslam_set_resample_occured", "particle_parents", "vp_probe_pd",
     "slab_row_bytes", "export_slab_rows", "import_slab_rows", "weights_device_ptr", "step_async", "set_step_inputs_async", "predict_map_async", "set_phase_timing", "static_steps_async", "propagate_ackerman_async", "propagate_ackerman_run_async", "set_partition_mode", "get_partition_mode",
-    "set_birth_inheritance", "get_birth_inheritance", "get_particle_ids", "set_particle_ids", "resample_occured", "get_unused_masks", "set_unused_masks", "has_birth_candidates", "predict_map_level", "murty_partition_sums", "cycle_async", "update_io",
+    "set_birth_inheritance", "get_birth_inheritance", "get_particle_ids", "set_particle_ids", "resample_occured", "get_unused_masks", "set_unused_masks", "has_birth_candidates", "predict_map_level", "murty_partition_sums", "cycle_async", "update_io", "step_async_deferred",
     "group_create", "group_destroy", "group_last_error", "group_n_shards", "group_n_particles", "group_shard", "group_locate",
     "group_set_filter_config", "group_set_model_rngbrg", "group_set_kf_config", "group_set_lmk_process_noise", "group_set_poses",
     "group_get_poses", "group_set_weights", "group_get_weights", "group_predict_map", "group_update", "group_normalize",
     "group_resample", "group_apply_plan", "group_migration_stats", "group_gm_size", "group_get_landmark", "group_synchronize", "group_set_birth_inheritance", "group_get_particle_ids",
-    "group_update_io", "group_set_model_victoriapark", "group_set_laser_scan", "group_set_phase_timing", "group_get_timing", "group_collective",
+    "group_update_io", "group_update_deferred", "group_set_model_victoriapark", "group_set_laser_scan", "group_set_phase_timing", "group_get_timing", "group_collective",
 ]
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -772,6 +772,11 @@ class Group:
 
     def get_filter_config(self):
         return self.shards[0].get_filter_config()
+
+    def update_deferred(self, Z):
+        """rfsgpu_group_update_deferred: the normalisation trails by one step, the collective runs beside the next step's kernel."""
+        Z = _f64(Z).reshape(-1, self.dz)
+        self._call("update_deferred", Z.ctypes.data_as(C.c_void_p), C.c_int(Z.shape[0]))
 
     def update_nosums(self, Z):
         """rfsgpu_group_update without the host copy of the sums: with the RCCL collective nothing waits for the GPUs."""

@@ -32,6 +32,10 @@ struct rfsgpu_group {
   std::vector<void *> comm;            // ncclComm_t per shard (empty: host path)
   std::vector<double *> dTot;          // per shard, on its device: the all-reduced {sum w, sum w^2}
   std::string rcclNote;                // why the host path is in use, if it is
+  // trailing normalisation (rfsgpu_group_update_deferred): the all-reduce of step k on a side stream per shard, beside step k + 1's kernel
+  std::vector<hipStream_t> side;
+  std::vector<hipEvent_t> evPost, evTot;
+  bool pendingTotal = false;           // dTot holds a total the weights have not been divided by yet
   std::string err;
 };
 
@@ -161,6 +165,14 @@ int rfsgpu_group_create(rfsgpu_group **out, int model, int n_particles, const in
           }
         }
       }
+      if (!g->comm.empty()) {           // side streams + events of the trailing normalisation
+        g->side.assign(n_dev, nullptr); g->evPost.assign(n_dev, nullptr); g->evTot.assign(n_dev, nullptr);
+        for (int k = 0; k < n_dev; k++) {
+          hipSetDevice(device_ids[k]);
+          if (hipStreamCreateWithFlags(&g->side[k], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&g->evPost[k], hipEventDisableTiming) != hipSuccess ||
+              hipEventCreateWithFlags(&g->evTot[k], hipEventDisableTiming) != hipSuccess) { g->side.clear(); break; }
+        }
+      }
       (void)hipGetLastError();
     }
   }
@@ -175,6 +187,9 @@ void rfsgpu_group_destroy(rfsgpu_group *g) {
     if (k < g->recvBuf.size() && g->recvBuf[k]) hipFree(g->recvBuf[k]);
     if (k < g->evExport.size() && g->evExport[k]) hipEventDestroy(g->evExport[k]);
     if (k < g->dTot.size() && g->dTot[k]) hipFree(g->dTot[k]);
+    if (k < g->side.size() && g->side[k]) hipStreamDestroy(g->side[k]);
+    if (k < g->evPost.size() && g->evPost[k]) hipEventDestroy(g->evPost[k]);
+    if (k < g->evTot.size() && g->evTot[k]) hipEventDestroy(g->evTot[k]);
     rfsgpu_destroy(g->shard[k]);
   }
   for (void *c : g->comm) if (c) g_rccl.CommDestroy(c);
@@ -262,13 +277,29 @@ int rfsgpu_group_get_poses(rfsgpu_group *g, double *x) {
   for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_get_poses(g->shard[k], x + 3 * (size_t)g->first[k]));
   return RFSGPU_OK;
 }
+// A total left pending by rfsgpu_group_update_deferred: every shard's stream waits for its collective, then divides (device-side
+// divisor).  Called by whatever reads or replaces the weights.
+static int group_flush(rfsgpu_group *g) {
+  if (!g->pendingTotal) return RFSGPU_OK;
+  g->pendingTotal = false;
+  for (size_t k = 0; k < g->shard.size(); k++) {
+    rfsgpu_filter *f = g->shard[k];
+    hipSetDevice(f->device);
+    GCHK(hipStreamWaitEvent(f->stream, g->evTot[k], 0));
+    GFWD(k, rfsgpu_normalize_weights(f, 0.0, g->dTot[k]));
+  }
+  return RFSGPU_OK;
+}
+#define GFLUSH(g) do { const int rcf_ = group_flush(g); if (rcf_ != RFSGPU_OK) return rcf_; } while (0)
 int rfsgpu_group_set_weights(rfsgpu_group *g, const double *w) {
   if (!g || !w) return RFSGPU_ERR_INVALID;
+  GFLUSH(g);
   for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_set_weights(g->shard[k], w + g->first[k]));
   return RFSGPU_OK;
 }
 int rfsgpu_group_get_weights(rfsgpu_group *g, double *w) {
   if (!g || !w) return RFSGPU_ERR_INVALID;
+  GFLUSH(g);
   for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_get_weights(g->shard[k], w + g->first[k]));
   return RFSGPU_OK;
 }
@@ -368,6 +399,7 @@ int rfsgpu_group_predict_map(rfsgpu_group *g, int add_birth) {
 // (every shard is synchronised even when one reports an error: the others' streams and error words must not stay unharvested)
 int rfsgpu_group_synchronize(rfsgpu_group *g) {
   if (!g) return RFSGPU_ERR_INVALID;
+  GFLUSH(g);
   int first = RFSGPU_OK;
   for (size_t k = 0; k < g->shard.size(); k++) {
     const int rc = rfsgpu_synchronize(g->shard[k]);
@@ -426,6 +458,7 @@ static int group_allreduce(rfsgpu_group *g, bool launch_sums, double *tot) {
 // nullptr: nothing waits for the GPUs (device-side errors surface at the next synchronising call).
 int rfsgpu_group_update(rfsgpu_group *g, const double *z, int n_z, double *sums_out) {
   if (!g) return RFSGPU_ERR_INVALID;
+  GFLUSH(g);
   for (size_t k = 0; k < g->shard.size(); k++) GFWD(k, rfsgpu_step_async(g->shard[k], z, n_z, 0));
   if (n_z > 0) g->resampleOccured = false;       // RBPHDFilter.hpp:526
   if (n_z == 0) { if (sums_out) { sums_out[0] = sums_out[1] = 0.0; } return RFSGPU_OK; }   // (:451-452: nothing ran, no sums were written)
@@ -439,12 +472,49 @@ int rfsgpu_group_update(rfsgpu_group *g, const double *z, int n_z, double *sums_
   if (sums_out) { sums_out[0] = tot[0]; sums_out[1] = tot[1]; }
   return RFSGPU_OK;
 }
+// rfsgpu_group_update with the weight normalisation trailing by one step (round 5): every shard's post kernel divides
+// its weights by the all-reduced total of the PREVIOUS call (rfsgpu_step_async_deferred) and leaves this step's pair; the pairs
+// are all-reduced on a side stream per shard, beside the next step's kernel.  Nothing waits for the GPUs.  The next call that
+// reads or replaces the weights (normalize, get / set_weights, resample, apply_plan, update, update_io, synchronize) applies the
+// pending total first.  Host path (repeated device ids, no librccl): rfsgpu_group_update + rfsgpu_group_normalize, as before.
+int rfsgpu_group_update_deferred(rfsgpu_group *g, const double *z, int n_z) {
+  if (!g) return RFSGPU_ERR_INVALID;
+  if (g->comm.empty() || g->side.empty()) {
+    const int rc = rfsgpu_group_update(g, z, n_z, nullptr);
+    return rc != RFSGPU_OK ? rc : rfsgpu_group_normalize(g, nullptr);
+  }
+  const int S = (int)g->shard.size();
+  for (int k = 0; k < S; k++) {
+    rfsgpu_filter *f = g->shard[k];
+    GFWD(k, rfsgpu_step_async_deferred(f, z, n_z, g->pendingTotal ? g->dTot[k] : nullptr, g->pendingTotal ? (void *)g->evTot[k] : nullptr));
+    hipSetDevice(f->device);
+    GCHK(hipEventRecord(g->evPost[k], f->stream));
+    GCHK(hipStreamWaitEvent(g->side[k], g->evPost[k], 0));
+  }
+  if (n_z > 0) g->resampleOccured = false;       // RBPHDFilter.hpp:526
+  int rc = g_rccl.GroupStart();
+  for (int k = 0; k < S && rc == 0; k++) {
+    rfsgpu_filter *f = g->shard[k];
+    hipSetDevice(f->device);
+    rc = g_rccl.AllReduce(f->dSums, g->dTot[k], 2, /*ncclDouble*/ 8, /*ncclSum*/ 0, g->comm[k], g->side[k]);
+  }
+  const int rce = g_rccl.GroupEnd();
+  if (rc == 0) rc = rce;
+  if (rc != 0) return gfail(g, RFSGPU_ERR_HIP, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
+  for (int k = 0; k < S; k++) {
+    hipSetDevice(g->shard[k]->device);
+    GCHK(hipEventRecord(g->evTot[k], g->side[k]));
+  }
+  g->pendingTotal = true;
+  return RFSGPU_OK;
+}
 // RBPHDFilter::update (:444-541) over the group with its inputs and outputs in one call (the group form of rfsgpu_update_io; what
 // integration/RBPHDFilter_rfsgpu.hpp's update() calls when RFSGPU_DEVICES lists several GPUs): global poses (+ covariances) and
 // weights in, every shard's chain enqueued before the first wait, the updated weights of all particles out.  The shards' device
 // error words are read by THIS call (rfsgpu_group_update(..., NULL) on the RCCL path left them for a later call).
 int rfsgpu_group_update_io(rfsgpu_group *g, const double *x, const double *x_cov, int cov_stride, const double *w_in, const double *z, int n_z, double *w_out) {
   if (!g) return RFSGPU_ERR_INVALID;
+  GFLUSH(g);
   if (x_cov && cov_stride != 0 && cov_stride != 9) return gfail(g, RFSGPU_ERR_INVALID, "group_update_io: cov_stride must be 0 or 9");
   const int S = (int)g->shard.size();
   for (int k = 0; k < S; k++) {
@@ -463,6 +533,7 @@ int rfsgpu_group_update_io(rfsgpu_group *g, const double *x, const double *x_cov
 // ParticleFilter::normalizeWeights over the whole particle set (:352-363).
 int rfsgpu_group_normalize(rfsgpu_group *g, double *sums_out) {
   if (!g) return RFSGPU_ERR_INVALID;
+  GFLUSH(g);
   if (!g->comm.empty()) {
     const int rc = group_allreduce(g, true, sums_out);
     if (rc != RFSGPU_OK) return rc;
@@ -489,6 +560,7 @@ static int grow(rfsgpu_group *g, unsigned char *&buf, size_t &cap, size_t need) 
 // Carry out a global plan (src[global slot] = global source slot; a source keeps itself).
 int rfsgpu_group_apply_plan(rfsgpu_group *g, const int *src) {
   if (!g || !src) return RFSGPU_ERR_INVALID;
+  GFLUSH(g);
   const int S = (int)g->shard.size();
   auto shard_of = [&](int p) { int k = 0; while (p >= g->first[k + 1]) k++; return k; };
   for (int p = 0; p < g->N; p++)
@@ -560,6 +632,7 @@ int rfsgpu_group_apply_plan(rfsgpu_group *g, const int *src) {
 // plan_out (may be null, N ints) receives the global plan when *fired.
 int rfsgpu_group_resample(rfsgpu_group *g, double eff_n_threshold, double u01, int *fired, int *plan_out) {
   if (!g || !fired) return RFSGPU_ERR_INVALID;
+  GFLUSH(g);
   *fired = 0;
   double tot[2];
   int rc = rfsgpu_group_normalize(g, tot);

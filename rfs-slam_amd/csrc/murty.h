@@ -818,8 +818,13 @@ __device__ __forceinline__ double murty_partition_sum_block(double *C, int n, in
 // clears the queue for the next step and, when `sums` is given, leaves {sum w, sum w^2} of the shard there
 // (ParticleFilter::normalizeWeights / N_eff, include/ParticleFilter.hpp:352-363, 405-415) and -- `normalize` != 0, a filter
 // that lives on one GPU -- divides the weights by the sum right away.  One launch instead of three (Murty, sums, divide).
-__device__ __forceinline__ void step_post_tail(double *weight, int N, double *sums, int normalize) {
+// preDiv (round 5, multi-GPU hosts): the all-reduced weight total of the PREVIOUS step, which has travelled over xGMI while this
+// step's kernel ran -- the weights are divided by it HERE, before this step's sums are taken, instead of by a kernel of its own
+// behind the collective at the end of the previous step: (w L) / T in place of (w / T) L, an ulp apart, and the collective is
+// off the step's critical path.
+__device__ __forceinline__ void step_post_tail(double *weight, int N, double *sums, int normalize, const double *preDiv = nullptr) {
   if (!sums) return;
+  const double pd = preDiv ? preDiv[0] : 1.0;
   __shared__ double sA[16], sB[16];   // (one entry per wave of the block, whatever it was launched with)
   __shared__ double sDiv;
   // (eight loads in flight per thread: one block sums the whole shard, and taken one at a time the ~16 dependent L2 round trips
@@ -830,6 +835,10 @@ __device__ __forceinline__ void step_post_tail(double *weight, int N, double *su
     double v[U];
 #pragma unroll
     for (int j = 0; j < U; j++) { const int k = k0 + j * (int)blockDim.x; v[j] = (k < N) ? weight[k] : 0.0; }
+    if (preDiv) {
+#pragma unroll
+      for (int j = 0; j < U; j++) { const int k = k0 + j * (int)blockDim.x; v[j] = v[j] / pd; if (k < N) weight[k] = v[j]; }
+    }
 #pragma unroll
     for (int j = 0; j < U; j++) { a += v[j]; b += v[j] * v[j]; }
   }
@@ -861,6 +870,7 @@ struct StepOut {
   double *hostW;     // [N] (nullptr: nothing to deliver)
   int *hostFlag;     // [0] error word, [1] sequence number
   int seq;
+  const double *preDiv;   // device: {sum w, sum w^2} of the previous step over all shards, or nullptr (step_post_tail)
 };
 __device__ __forceinline__ void step_post_out(const double *weight, int N, int *err, const StepOut &SO) {
   if (!SO.hostW) return;
@@ -921,7 +931,7 @@ void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err, double *weight, 
     for (int t = threadIdx.x; t < nZdoubles; t += blockDim.x) dZ[t] = zarg.v[t];
   const int nJobs = min(*Q.count, Q.maxJobs);
   if (nJobs == 0) {
-    if (blockIdx.x == 0) { step_post_tail(weight, N, sums, normalize); step_post_out(weight, N, err, SO); }
+    if (blockIdx.x == 0) { step_post_tail(weight, N, sums, normalize, SO.preDiv); step_post_out(weight, N, err, SO); }
     return;
   }
   __shared__ double sTile[W][MURTY_LDS_N * MURTY_LDS_N];
@@ -1052,7 +1062,7 @@ void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err, double *weight, 
 #ifdef RFS_PROFILE
   if (threadIdx.x == 0) printf("murty tail (last workgroup %d): factors into the weights %lld ticks of 10 ns, ends at tick %lld\n", (int)blockIdx.x, (long long)wall_clock64() - dbgTail0, (long long)wall_clock64());
 #endif
-  step_post_tail(weight, N, sums, normalize);
+  step_post_tail(weight, N, sums, normalize, SO.preDiv);
   step_post_out(weight, N, err, SO);
 }
 
@@ -1092,7 +1102,7 @@ static inline void murty_free(MurtyQueue &Q, MurtyScratch &MS) {
 // instance (four waves, no register cap, no scratch set-up) on the same grid; a filter that has shown Murty work gets the capped
 // six-wave instance and the job ordering from the next step on.  Correct either way: jobs are strided over whatever grid there is.
 static inline int murty_launch(MurtyQueue &Q, MurtyScratch &MS, Buffers &B, hipStream_t stream, double *sums = nullptr, int normalize = 0,
-                               const ZArg *za = nullptr, int nZdoubles = 0, int *hostSeen = nullptr, const StepOut &SO = StepOut{nullptr, nullptr, 0}) {
+                               const ZArg *za = nullptr, int nZdoubles = 0, int *hostSeen = nullptr, const StepOut &SO = StepOut{nullptr, nullptr, 0, nullptr}) {
   int blocks = std::min(MURTY_JOB_BLOCKS, Q.maxJobs);
   // (RFSGPU_MURTY_FIRST_BLOCKS: grid of the light instance, for A/B runs -- tools/murty_first_step.py)
   static const int firstBlocks = [] { const char *e = getenv("RFSGPU_MURTY_FIRST_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : MURTY_FIRST_BLOCKS; }();

@@ -937,9 +937,10 @@ int rfsgpu_prune(rfsgpu_filter *f) {
 }
 
 // All four phases back to back on the stream, ONE host sync at the end (RBPHDFilter::update body :444-523).
-static const StepOut NO_OUT{nullptr, nullptr, 0};
+static const StepOut NO_OUT{nullptr, nullptr, 0, nullptr};
 static const StepPredict NO_HEAD{0, 0, nullptr, nullptr, 0};
-static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool with_sums, int normalize, const StepPredict &sp = NO_HEAD, const StepOut &so = NO_OUT);
+static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool with_sums, int normalize, const StepPredict &sp = NO_HEAD, const StepOut &so = NO_OUT,
+                             hipEvent_t waitBeforePost = nullptr);
 int rfsgpu_update(rfsgpu_filter *f, const double *z, int n_z) {
   CHECK_HANDLE(f);
   f->holes = false;
@@ -1010,7 +1011,8 @@ static void harvest_async(rfsgpu_filter *f) {
 
 // Shared body of the stream-ordered steps.  with_sums: the step's post kernel also leaves {sum w, sum w^2} in the bound sums
 // buffer (and divides the weights by the sum when normalize != 0).
-static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool with_sums, int normalize, const StepPredict &sp, const StepOut &so) {
+static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool with_sums, int normalize, const StepPredict &sp, const StepOut &so,
+                             hipEvent_t waitBeforePost) {
   f->holes = false;
   if (n_z == 0) return RFSGPU_OK;  // :450-452
   long long t0 = now_ns();
@@ -1085,6 +1087,7 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
 #undef STEP_LAUNCH
     HIPCHK(hipGetLastError());
     if (timed) HIPCHK(hipEventRecord(e[3], f->stream));
+    if (waitBeforePost) HIPCHK(hipStreamWaitEvent(f->stream, waitBeforePost, 0));   // (the collective that produced so.preDiv, on another stream)
     if (murty_launch(f->Q, f->MS, f->B, f->stream, with_sums ? f->dSums : nullptr, normalize, &za, 2 * n_z, f->hJobCount, so) != 0) return fail(f, RFSGPU_ERR_HIP, "post kernel launch failed");
     if (timed) HIPCHK(hipEventRecord(e[1], f->stream));
     f->cur ^= 1;  // the map update works in place, the weighting phase leaves only a permutation in LDS, merge + prune write the other slab
@@ -1123,7 +1126,8 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
     }
     HIPCHK(hipGetLastError());
     if (timed) HIPCHK(hipEventRecord(e[3], f->stream));
-    if (murty_launch(f->Q, f->MS, f->B, f->stream, with_sums ? f->dSums : nullptr, normalize, &za, 3 * n_z, f->hJobCount) != 0) return fail(f, RFSGPU_ERR_HIP, "post kernel launch failed");
+    if (waitBeforePost) HIPCHK(hipStreamWaitEvent(f->stream, waitBeforePost, 0));
+    if (murty_launch(f->Q, f->MS, f->B, f->stream, with_sums ? f->dSums : nullptr, normalize, &za, 3 * n_z, f->hJobCount, so) != 0) return fail(f, RFSGPU_ERR_HIP, "post kernel launch failed");
     if (timed) HIPCHK(hipEventRecord(e[1], f->stream));
     f->cur ^= 1;
     if (timed) {
@@ -1170,6 +1174,25 @@ int rfsgpu_step_async(rfsgpu_filter *f, const double *z, int n_z, int normalize)
     return normalize ? rfsgpu_normalize_weights(f, 0.0, f->dSums) : RFSGPU_OK;
   }
   return update_async_impl(f, z, n_z, true, normalize);
+}
+
+// The step of a multi-GPU host whose weight normalisation trails by one step (round 5).  As rfsgpu_step_async
+// with normalize = 0 -- this shard's {sum w, sum w^2} go to the bound sums buffer -- except that the post kernel first divides
+// the weights by *prev_total_dev, the all-reduced total of the PREVIOUS step (NULL: no division), and waits for `wait_event` (a
+// hipEvent_t recorded on ANOTHER stream behind the collective that produced that total; NULL: none) only between the step kernel
+// and the post kernel: the collective of step k runs beside the step kernel of step k + 1 instead of in front of it.
+int rfsgpu_step_async_deferred(rfsgpu_filter *f, const double *z, int n_z, const void *prev_total_dev, void *wait_event) {
+  CHECK_HANDLE(f);
+  hipSetDevice(f->device);
+  if (n_z == 0 || !f->fuseSteps || f->phaseTiming) {        // no fused step: the same arithmetic with the stand-alone kernels, in stream order
+    if (wait_event) HIPCHK(hipStreamWaitEvent(f->stream, (hipEvent_t)wait_event, 0));
+    if (n_z > 0) { const int rc = update_async_impl(f, z, n_z, false, 0); if (rc != RFSGPU_OK) return rc; }
+    if (prev_total_dev) { const int rc = rfsgpu_normalize_weights(f, 0.0, prev_total_dev); if (rc != RFSGPU_OK) return rc; }
+    return rfsgpu_weight_sums_async(f);
+  }
+  StepOut so = NO_OUT;
+  so.preDiv = reinterpret_cast<const double *>(prev_total_dev);
+  return update_async_impl(f, z, n_z, true, 0, NO_HEAD, so, (hipEvent_t)wait_event);
 }
 
 // ---- one submission per predict + update cycle (round 5) --------------------------------------------------------------------

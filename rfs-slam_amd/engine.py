@@ -82,6 +82,12 @@ class RBPHDFilter(capi.CFilter):
         Z, n = self._z(Z)
         self._call("step_async", self._ptr(Z), n, C.c_int(1 if normalize else 0))
 
+    def step_async_deferred(self, Z, prev_total_ptr=None, wait_event=None):
+        """rfsgpu_step_async_deferred: the step of a sharded host whose normalisation trails by one step (the post kernel divides by
+        the previous step's all-reduced total, device pointer, and waits for `wait_event` -- a hipEvent_t handle -- just before it)."""
+        Z, n = self._z(Z)
+        self._call("step_async_deferred", self._ptr(Z), n, C.c_void_p(prev_total_ptr), C.c_void_p(wait_event))
+
     def _opt(self, a, shape=None):
         if a is None:
             return None, C.c_void_p(None)

@@ -48,6 +48,7 @@ class ShardedRBPHDFilter:
         # has dealt with the inheritance rule: every predict must go through self.predict_map, never through self.f.predict_map)
         self._mode_before = local.get_birth_inheritance() if hasattr(local, "get_birth_inheritance") else None
         local.set_birth_inheritance(capi.INHERIT_EXTERNAL if inheritance == "reference" else capi.INHERIT_EAGER)
+        self.defer_normalisation = True    # update(): steps whose resample test is not due let the normalisation trail (update_deferred)
         self.cand_lists_seen = False       # a candidate list has been moved / kept on SOME shard (all-reduced in predict_map)
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -75,6 +76,12 @@ class ShardedRBPHDFilter:
             # device tensor that the all-reduce updates in place and normalize_kernel reads: no host round trip per step
             self.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
             self.f.set_stream(self.stream.cuda_stream)
+            # the trailing normalisation (update_deferred): the collective of step k on a side stream beside step k + 1's kernel
+            self._side = torch.cuda.Stream(device=self.device)
+            self._tot = torch.ones(2, dtype=torch.float64, device=self.device)
+            self._ev_post, self._ev_tot = torch.cuda.Event(), torch.cuda.Event()
+            self._ev_post.record(self.stream); self._ev_tot.record(self._side)
+            self._pending = False
             self.sums = sums if sums is not None else torch.zeros(2, dtype=torch.float64, device=self.device)
             self.f.bind_weight_sums_buffer(self.sums.data_ptr())
             try:
@@ -90,6 +97,7 @@ class ShardedRBPHDFilter:
         """normalizeWeights over ALL shards.  Device engine: weight sums -> all-reduce in place -> on-device divide, all on
         the engine's stream; the two totals come back to the host only when the caller needs N_eff (16 bytes)."""
         if self.on_gpu:
+            self.flush_deferred()
             self.f.weight_sums_async()
             if self.world > 1:
                 with self._stream_ctx():
@@ -107,8 +115,35 @@ class ShardedRBPHDFilter:
         self.f.normalize_weights(float(tot[0]))
         return tot
 
+    # -- trailing normalisation (round 5) -----------------------------------------------------------------
+    def update_deferred(self, Z):
+        """RBPHDFilter::update's device part for a step after which the host does NOT need the normalised weights or N_eff (the
+        resample test is not due: minUpdatesBeforeResample / minMeasurementsBeforeResample, include/RBPHDFilter.hpp:527-531): the
+        all-reduce of this step's {sum w, sum w^2} goes on a side stream and the division by its result is done by the NEXT step's
+        post kernel (rfsgpu_step_async_deferred) -- the collective leaves the step's critical path.  Any call that needs the
+        weights (normalize, resample, gather_weights) first applies the pending total (flush_deferred).  Device engine only."""
+        assert self.on_gpu, "the trailing normalisation is a device-path feature (the CPU stand-in normalises in place)"
+        Z = np.asarray(Z, dtype=np.float64).reshape(-1, self.f.dz)
+        self.f.step_async_deferred(Z, self._tot.data_ptr() if self._pending else None, self._ev_tot.cuda_event if self._pending else None)
+        self._ev_post.record(self.stream)
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(self._ev_post)
+            self._tot.copy_(self.sums)
+            if self.world > 1:
+                dist.all_reduce(self._tot, group=self.group)
+            self._ev_tot.record(self._side)
+        self._pending = True
+
+    def flush_deferred(self):
+        """Apply the total a deferred step left pending: wait for its collective (stream-ordered), divide on the device."""
+        if self.on_gpu and self._pending:
+            self.stream.wait_event(self._ev_tot)
+            self.f.normalize_weights(0.0, self._tot.data_ptr())
+            self._pending = False
+
     def gather_weights(self):
         """All N weights on every rank (host array, for the systematic-resampling plan): all-gather of device tensors."""
+        self.flush_deferred()
         if self.on_gpu and self._w_view is not None:
             with self._stream_ctx():
                 if self.world == 1:
@@ -169,6 +204,11 @@ class ShardedRBPHDFilter:
 
     def close(self):
         """Give the engine handle back in the inheritance mode it had before this wrapper took it over."""
+        if self.f is not None:
+            try:
+                self.flush_deferred()
+            except Exception:   # noqa: BLE001  (handle already closed)
+                pass
         if self._mode_before is not None and self.f is not None:
             try:
                 self.f.set_birth_inheritance(self._mode_before)
@@ -234,14 +274,21 @@ class ShardedRBPHDFilter:
         if Z.shape[0] == 0:
             return False
         self.nMeasurementsSinceResample += Z.shape[0]
+        cfg = self.f.get_filter_config()
+        due = (self.nUpdatesSinceResample >= cfg.minUpdatesBeforeResample and
+               self.nMeasurementsSinceResample >= cfg.minMeasurementsBeforeResample)
+        if self.on_gpu and not due and self.defer_normalisation:
+            # the resample test is not due: nobody reads N_eff after this step, the normalisation may trail (update_deferred)
+            self.update_deferred(Z)
+            self.resampleOccured = False
+            return False
         if self.on_gpu:
+            self.flush_deferred()         # (a trailing total of the previous step divides the weights before this step multiplies them)
             self.f.update_async(Z)        # stream-ordered; device errors surface at the next synchronize()
         else:
             self.f.update(Z)
-        cfg = self.f.get_filter_config()
         self.resampleOccured = False
-        if (self.nUpdatesSinceResample >= cfg.minUpdatesBeforeResample and
-                self.nMeasurementsSinceResample >= cfg.minMeasurementsBeforeResample):
+        if due:
             self.resampleOccured = self.resample(u01)
         if self.resampleOccured:
             self.nUpdatesSinceResample = 0
