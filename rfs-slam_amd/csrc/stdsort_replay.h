@@ -191,6 +191,8 @@ struct StdSortScratch {
 };
 __host__ __device__ inline int ss_list_cap(int N) { return N / 2 + 1; }
 
+// the part ss_carve cannot do without (a caller that provides the position array itself): eq words, stack, T
+__host__ __device__ inline size_t ss_must_bytes(int N) { return (size_t)((N + 63) >> 6) * 8 + 112 + (size_t)N * 4 + 4; }
 // Lay the scratch out in a byte range [buf, buf + bytes) (8-byte aligned): eq words | stack | T | pos (when ownPos; otherwise the
 // caller has set S.pos / S.posStride) | the two stopper lists if they still fit (else the replay runs serially on lane 0).
 // Returns false when even the mandatory part does not fit.

@@ -514,9 +514,16 @@ __host__ __device__ inline size_t vp_weight_lds_late_bytes(int evalCap, int nZ) 
   if (late < (size_t)VP_PD_SCRATCH_BYTES) late = VP_PD_SCRATCH_BYTES;
   return late;
 }
+// The evaluation-point tables + the late part double as the scratch of the tie-order replay (stdsort_replay.h) right after the rank
+// sort; with few evaluation points and a large gm_capacity they would be smaller than what the replay cannot do without -- the
+// range is then padded up to that (such a configuration used to be accepted at create and to fail with a capacity
+// error in the middle of a run).
+__host__ __device__ inline size_t vp_weight_scratch_bytes(int cap, int evalCap, int nZ) {
+  const size_t a = (size_t)evalCap * 8 * 4 + (size_t)evalCap * 16 * 8 + vp_weight_lds_late_bytes(evalCap, nZ), b = (ss_must_bytes(cap) + 7) & ~(size_t)7;
+  return a > b ? a : b;
+}
 __host__ __device__ inline size_t vp_weight_lds_bytes_per_wave(int cap, int evalCap, int nZ) {
-  const size_t early = (size_t)cap * 8 + (size_t)((cap + 63) & ~63) * 4 + (size_t)evalCap * 8 * 4 + (size_t)evalCap * 16 * 8;
-  return (early + vp_weight_lds_late_bytes(evalCap, nZ) + 15) & ~(size_t)15;
+  return ((size_t)cap * 8 + (size_t)((cap + 63) & ~63) * 4 + vp_weight_scratch_bytes(cap, evalCap, nZ) + 15) & ~(size_t)15;
 }
 __device__ __forceinline__ void carve_vp_weight_lds(unsigned char *base, int cap, int evalCap, int nZ, WeightLDS &s, double *&evD, unsigned char *&pdScratch) {
   unsigned char *p = base;
@@ -533,7 +540,7 @@ __device__ __forceinline__ void carve_vp_weight_lds(unsigned char *base, int cap
   s.partLik = (double *)p; p += 128 * 8;
   s.labR = (int *)p; p += 64 * 4;
   s.labC = (int *)p; p += 64 * 4;
-  s.perm = (int *)(base + (size_t)cap * 8 + (size_t)evalCap * 8 * 4 + (size_t)evalCap * 16 * 8 + vp_weight_lds_late_bytes(evalCap, nZ));
+  s.perm = (int *)(base + (size_t)cap * 8 + vp_weight_scratch_bytes(cap, evalCap, nZ));
   s.fkeys = nullptr; s.evIdx = nullptr; s.evZ = nullptr; s.isum = nullptr;    // (2-D kernel only)
 }
 // One wavefront takes particle i through the weighting.  permOut == nullptr: the mixture sorted by weight is written to slab
@@ -584,9 +591,9 @@ __device__ void vp_weight_particle(const Buffers &B, const Params &P, int src, i
     ss.pos = reinterpret_cast<unsigned short *>(s.perm) + 1;
     ss.posStride = 2;
     unsigned char *sbuf = reinterpret_cast<unsigned char *>(s.evX);
-    const size_t sbytes = (size_t)evalCap * 8 * 4 + (size_t)evalCap * 16 * 8 + vp_weight_lds_late_bytes(evalCap, nZ);
+    const size_t sbytes = vp_weight_scratch_bytes(cap, evalCap, nZ);
     if (!ss_carve(ss, sbuf, sbytes, N, false)) {
-      if (N > SS_THRESHOLD && lane == 0) atomicOr(B.err, ERRBIT_CAPACITY);   // (gm_capacity beyond ~1000 with the 3-D model: refused loudly)
+      if (N > SS_THRESHOLD && lane == 0) atomicOr(B.err, ERRBIT_CAPACITY);   // (cannot happen: the range is sized for N <= gm_capacity, vp_weight_scratch_bytes)
     } else {
       ss_correct_tie_order<1>([&](int e) { return s.keys[e]; }, [&](int r) { return (int)(unsigned short)s.perm[r]; },
                               [&](int r, unsigned short e) { s.perm[r] = (int)e; }, [](unsigned *) {}, N, N, ss, lane, [&]() { wave_sync(); });
@@ -1136,7 +1143,7 @@ __device__ void vp_merge_particle(const Buffers &B, const Params &P, int cur, in
     if (ss_carve(ss, reinterpret_cast<unsigned char *>(sb), 4 * st * sizeof(double), N, true))
       ss_correct_tie_order<1>(key0, [&](int r) { return (int)sOrder[r]; }, [&](int r, unsigned short e) { sOrder[r] = e; }, rest_group, N, nSurv, ss, lane,
                               [&]() { wave_sync(); });
-    else if (N > SS_THRESHOLD && lane == 0) atomicOr(B.err, ERRBIT_CAPACITY);
+    else if (N > SS_THRESHOLD && lane == 0) atomicOr(B.err, ERRBIT_CAPACITY);   // (cannot happen: 32 st bytes against ~6.2 N + 124 with N <= st)
   }
   for (int rank = lane; rank < nSurv; rank += 64) {
     const int m = sOrder[rank];
