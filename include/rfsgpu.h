@@ -22,7 +22,7 @@
  *   - the engine fails loudly: there is NO CPU fallback anywhere behind this ABI.
  *
  * STABLE CORE -- the 24 entry points a reference-side binding needs (round 5: + rfsgpu_update_io, the update with its inputs and outputs in one call); integration/RBPHDFilter_rfsgpu.hpp (the class template that
- * stands where rfs::RBPHDFilter stands, compiled under the unmodified reference drivers) uses 19 of them and nothing else
+ * stands where rfs::RBPHDFilter stands, compiled under the unmodified reference drivers) uses 20 of them and nothing else
  * (tests/test_abi.py checks the list against the linked drivers):
  *   RFSGPU_CORE: rfsgpu_abi_version rfsgpu_create rfsgpu_destroy rfsgpu_last_error rfsgpu_default_filter_config
  *   RFSGPU_CORE: rfsgpu_set_filter_config rfsgpu_set_model_rngbrg rfsgpu_set_model_victoriapark rfsgpu_set_laser_scan

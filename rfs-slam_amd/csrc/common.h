@@ -45,6 +45,7 @@ struct Params {
   double birthSupportD2;   // birthGaussianMeasurementSupportDist^2
   int poseCovStride;       // 0 shared, 9 per particle
   int exactPartitions;     // rfsgpu_set_partition_mode: partitions with nR + nC > 8 by the exact subset recurrence instead of Murty-200
+  int denseIntensity;      // RFSGPU_DENSE_INTENSITY=1: the intensity sums over EVERY (evaluation point, Gaussian) pair, the reference's term list (deviation 9 off)
   // MeasurementModel_VictoriaPark (model 1); R[] above then holds its 2x2 range-bearing block
   double R9[9];
   double Slb;

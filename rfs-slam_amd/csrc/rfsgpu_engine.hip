@@ -74,6 +74,7 @@ struct rfsgpu_filter {
   bool outArmed = false;              // the step in flight delivers through hOutW / hOutFlag (update_io_end spins instead of synchronising)
 
   int stagePendingSlot = -1;          // a staging slot whose event must be recorded behind the step that reads it
+  bool denseIntensity = false;        // RFSGPU_DENSE_INTENSITY=1 at create: deviation 9 off (the dense loop for every mixture size), for runs against a future pinned fixture
   bool ioPull = true;                 // RFSGPU_IO_PULL=0: inputs by copy commands, outputs by copies + a stream synchronisation (A/B, rounds 3-4 form)
   double *poseAlt = nullptr;          // [Ncap][3] second pose buffer: a fused predict + update cycle births at the old poses and updates at the new ones (rfsgpu_cycle_async)
   hipEvent_t evStage[4] = {};
@@ -153,6 +154,7 @@ static int fail(rfsgpu_filter *f, int code, const char *msg) {
 
 static void rebuild_params(rfsgpu_filter *f) {
   Params &P = f->P;
+  P.denseIntensity = f->denseIntensity ? 1 : 0;
   for (int k = 0; k < 4; k++) P.R[k] = f->rb.R[k];
   P.Pd = f->rb.probabilityOfDetection;
   P.clutter = f->rb.uniformClutterIntensity;
@@ -273,6 +275,7 @@ int rfsgpu_create_ex(rfsgpu_filter **out, int model, int n_particles, int device
   f->fs.nParticlesMax = 3 * n_particles;
   { const char *e = getenv("RFSGPU_FUSED_STEP"); if (e && e[0] == '0') f->fuseSteps = false; }
   { const char *e = getenv("RFSGPU_IO_PULL"); if (e && e[0] == '0') f->ioPull = false; }
+  { const char *e = getenv("RFSGPU_DENSE_INTENSITY"); if (e && e[0] == '1') f->denseIntensity = true; }
   { const char *e = getenv("RFSGPU_STEP_WPP"); if (e) f->stepWppOverride = atoi(e); }
   { const char *e = getenv("RFSGPU_BIRTH_INHERITANCE"); if (e && !strcmp(e, "eager")) f->inheritMode = RFSGPU_INHERIT_EAGER; }   // (initial mode; rfsgpu_set_birth_inheritance)
   { const char *e = getenv("RFSGPU_MERGE_GRID"); if (e) f->mergeGridOverride = atoi(e); }

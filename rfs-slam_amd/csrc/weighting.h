@@ -1066,7 +1066,7 @@ __device__ __forceinline__ void phd_weight_particle(const Buffers &B, const Para
 #ifdef RFS_STOP_AT
   if ((RFS_STOP_AT == 14 || RFS_STOP_AT == 15) && split && wave > 0) __builtin_amdgcn_endpgm();   // wave 0's strand alone
 #endif
-  const bool sparseI = WEIGHT_SPARSE_INTENSITY && (split || WPP == 1) && w0Chunks == 0 && N > WEIGHT_SPARSE_MIN_N && N <= 65535;
+  const bool sparseI = WEIGHT_SPARSE_INTENSITY && (split || WPP == 1) && w0Chunks == 0 && N > WEIGHT_SPARSE_MIN_N && N <= 65535 && !P.denseIntensity;
   if (!split || wave > 0) {
     if (sparseI) intensity_sparse(iw, nIw, sumB, sumA, s.sparse + ((split && WPP >= 3) ? (size_t)(wave - 1) * (WEIGHT_SPARSE_LDS_BYTES / 2) : 0));
     else intensity(0, mSplit, iw, nIw, sumB, sumA);

@@ -592,6 +592,26 @@ def test_device_murty_sums_against_the_reference_bruteforce_fixture(pkg, ob):
     dev.close()
 
 
+def test_dense_intensity_switch_matches_the_sparse_sums(pkg, ob, sc, monkeypatch):
+    """RFSGPU_DENSE_INTENSITY=1: a handle created under it adds every (evaluation point, Gaussian) term,
+    as the reference does (include/RBPHDFilter.hpp:776-800) -- deviation 9 (terms below 2^-64 of their sum left out, mixtures of more
+    than 128 Gaussians) switched off, so that a future reference-pinned fixture can be run both ways.  Both forms against the oracle,
+    and against each other to an ulp of the weight."""
+    scen = sc.make_scenario(24, 300, 30, seed=91)
+    out = []
+    for dense in (False, True):
+        if dense:
+            monkeypatch.setenv("RFSGPU_DENSE_INTENSITY", "1")
+        dev, orc = make_pair(pkg, ob, sc, scen, cap=640)
+        for f in (dev, orc):
+            f.update(scen["Z"])
+        compare_weights(dev, orc)
+        compare_maps(sc, dev, orc, scen["n"])
+        out.append(dev.get_weights())
+        dev.close()
+    np.testing.assert_allclose(out[0], out[1], rtol=1e-13)
+
+
 def test_cpp_host_driver_end_to_end(pkg):
     """The C++ host mirror (rfs-slam_amd/host/rbphd_filter.hpp) driving the device path through the C ABI on the
     shipped C1 configuration (cfg values of the reference's rbphdslam2dSim.xml): the map must converge."""
