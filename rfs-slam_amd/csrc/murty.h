@@ -783,10 +783,17 @@ __device__ __forceinline__ double murty_partition_sum_block(double *C, int n, in
     earlyStop = __ballot(bad) == 0ull && mn >= -1000.0 && mx <= 1000.0;
   }
 #endif
-  auto onRoot = [&](double s) { if (s < BIG_NEG) return true; *sSum = exp(s); return false; };
+  // (rfs_exp, common.h: relative error <= 1e-14, coefficients as scalar operands.  The library exp's eleven fp64 coefficients were
+  //  materialised in vector registers ahead of the search loop and -- under the 64-VGPR cap -- spilled: 72 of the kernel's 140 bytes
+  //  of scratch per lane, i.e. half of the 154 MB the launch wrote at configs[4]; MURTY_LIB_EXP=1 restores it.)
+#ifndef MURTY_LIB_EXP
+#define MURTY_LIB_EXP 0
+#endif
+  auto term_of = [](double s) { return MURTY_LIB_EXP ? exp(s) : rfs_exp(s); };
+  auto onRoot = [&](double s) { if (s < BIG_NEG) return true; *sSum = term_of(s); return false; };
   auto onTop = [&](double st, int) {
     if (st < BIG_NEG) return true;
-    const double t = exp(st), sum = *sSum + t;
+    const double t = term_of(st), sum = *sSum + t;
     *sSum = sum;
     return earlyStop && t < sum * 0x1p-56;
   };
@@ -910,7 +917,7 @@ __global__ __launch_bounds__(1024) void murty_order_kernel(MurtyQueue Q) {
 #define MURTY_WAVES_PER_EU 8   // <= 64 VGPRs: five six-wave workgroups per CU instead of three (see MURTY_JOB_WAVES)
 #endif
 #ifndef MURTY_LIGHT_WAVES
-#define MURTY_LIGHT_WAVES 4
+#define MURTY_LIGHT_WAVES (MURTY_JOB_WAVES >= 8 ? 8 : 4)   // (round 5: eight -- the first update that queues partitions 5.8 -> 4.4 ms at configs[4], the empty-queue step of configs[1] unchanged at 121.4-122.3 us)
 #endif
 #ifndef MURTY_FIRST_BLOCKS
 #define MURTY_FIRST_BLOCKS 2048   // workgroups of the light instance (a filter that has not shown Murty work yet): the full grid --
@@ -919,7 +926,7 @@ __global__ __launch_bounds__(1024) void murty_order_kernel(MurtyQueue Q) {
 // workgroups, 25.5 on 256, 15.8 on 512, 10.7 on 1024 and 9.2 on 2048 (steady state, the capped six-wave instance: 5.1-5.3)
 #endif
 // Two instances.  <MURTY_JOB_WAVES, MURTY_WAVES_PER_EU>: the one for filters that have shown Murty work.  <MURTY_LIGHT_WAVES, 0>
-// (four waves, the compiler's own register count, no scratch): what a filter WITHOUT Murty work launches as its post kernel
+// (the compiler's own register count, no scratch): what a filter WITHOUT Murty work launches as its post kernel
 // step after step -- the capped instance needs scratch memory set up for every wave it dispatches and costs 0.2 us more per
 // step for nothing.  Both do the same thing with whatever the queue holds.
 template <int W, int WAVES_PER_EU>

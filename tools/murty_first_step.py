@@ -11,6 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package
 pkg = load_package()
+if os.environ.get("RFS_LIB"):
+    pkg.engine.LIB = os.environ["RFS_LIB"]      # a tools/variant_bench.py --build variant
 sc = pkg.scenarios
 # clocks up: a C2a filter stepping for a while; its steady step time is the empty-queue cost figure
 s2 = sc.make_scenario(2000, 200, 30, seed=12345)
