@@ -11,7 +11,11 @@ SOURCES = ["rfsgpu_engine.hip"]
 # Two code objects for the one target, picked by the runtime from the device's XNACK mode: without XNACK replay to allow for, the compiler may
 # reuse a load's address registers early and drops the padding around memory clauses (+0.6 % on the fused step, profiles/r04p_*); a device run
 # with XNACK on still finds its image.  -parallel-jobs: both in the time of one.
-FLAGS = ["--offload-arch=gfx950:xnack-", "--offload-arch=gfx950:xnack+", "-parallel-jobs=2", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc" if False else "-Wall", "-Wno-unused-result", "-Wno-unused-value",
+# -disable-machine-licm (round 5): the backend's loop-invariant code motion hoists constant pairs (libm coefficients) and per-lane addresses out
+# of the long search / phase loops and then spills them under the kernels' register caps -- without it murty_jobs_kernel<8,8> needs no scratch at
+# all (60 B per lane with it, 74 MB of spill traffic per launch at configs[4]), the step kernel with the predict at its head 120 VGPRs and no
+# scratch (128 + 60 B: C2b 0.1121 -> 0.1058 ms per cycle), the Victoria Park step 132 VGPRs (152); configs[1], [2] and [3] are unchanged to 1 %.
+FLAGS = ["--offload-arch=gfx950:xnack-", "--offload-arch=gfx950:xnack+", "-parallel-jobs=2", "-O3", "-mllvm", "-disable-machine-licm", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc" if False else "-Wall", "-Wno-unused-result", "-Wno-unused-value",
          "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
