@@ -1185,8 +1185,15 @@ __host__ __device__ inline size_t vp_step_lds_bytes_per_wave(int cap, int evalCa
   if (c > a) a = c;
   return ((a + 15) & ~(size_t)15) + (((size_t)cap * 2 + 15) & ~(size_t)15) + (((size_t)cap + 15) & ~(size_t)15);   // + the permutation + the Pd cache
 }
+#ifndef VP_STEP_WAVES_PER_EU
+#define VP_STEP_WAVES_PER_EU 0   // 0: the compiler's own register count (132 VGPRs with -disable-machine-licm: three waves per SIMD)
+#endif
 template <int WPB>
-__global__ __launch_bounds__(WPB * 64) void vp_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, int useWeighting, MurtyQueue Q, ZArg zarg) {
+__global__ __launch_bounds__(WPB * 64)
+#if VP_STEP_WAVES_PER_EU > 0
+__attribute__((amdgpu_waves_per_eu(VP_STEP_WAVES_PER_EU)))
+#endif
+void vp_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, int useWeighting, MurtyQueue Q, ZArg zarg) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double *sZ = reinterpret_cast<double *>(smem_raw);
   double *sScan = sZ + 3 * nZ;
