@@ -1389,6 +1389,41 @@ def test_vp_fused_step_is_bit_identical_to_the_three_kernel_path(pkg, sc, kw):
     assert t.mapUpdate_wall > 0 and t.particleWeighting_wall == 0      # the fused path books the whole step under mapUpdate
 
 
+def test_cycle_and_update_io_fall_back_for_the_victoria_park_model(pkg, sc):
+    """rfsgpu_cycle_async / rfsgpu_update_io on a handle whose step kernel has no head (the 3-D model: candidate lists, its own fused
+    kernel): the predict kernels, the input copies and the step are enqueued in the reference's order -- the same bits as
+    predict_map + set_poses + set_weights + update / get_weights call by call (the unmodified Victoria Park driver's update() goes
+    through this path)."""
+    scen = sc.make_vp_scenario(n_particles=24, n_landmarks=30, n_z=10, seed=77, scan="ragged")
+    a = pkg.RBPHDFilter(scen["n"], gm_capacity=256, model=pkg.capi.MODEL_VICTORIAPARK_3D)
+    b = pkg.RBPHDFilter(scen["n"], gm_capacity=256, model=pkg.capi.MODEL_VICTORIAPARK_3D)
+    for f in (a, b):
+        sc.load_scenario(f, scen)
+    rng = np.random.default_rng(9)
+    poses = scen["poses"].copy()
+    for step in range(4):
+        Z = scen["Z"] + rng.normal(0, 1, scen["Z"].shape) * np.array([0.05, 0.002, 0.01])
+        poses = poses + rng.normal(0, 0.01, poses.shape)
+        w_in = rng.uniform(0.5, 1.0, scen["n"])
+        if step % 2 == 0:
+            a.cycle_async(True, Z, poses=poses, weights=w_in, normalize=False)
+            a.synchronize()
+            w_a = a.get_weights()
+        else:
+            w_a = a.update_io(Z, predict=True, poses=poses, weights=w_in)
+        b.predict_map(True)
+        b.set_poses(poses)
+        b.set_weights(w_in)
+        b.update(Z)
+        np.testing.assert_array_equal(w_a, b.get_weights())
+        assert np.array_equal(a.gm_sizes(), b.gm_sizes()) and a.gm_sizes().max() > 5
+        for i in range(scen["n"]):
+            for x, y in zip(a.export_gm(i), b.export_gm(i)):
+                np.testing.assert_array_equal(x, y)
+            assert list(a.get_unused(i)) == list(b.get_unused(i))
+    a.close(); b.close()
+
+
 def test_2d_birth_candidate_list_mode(pkg, ob, sc):
     """The candidate-list branch of addBirthGaussians with the 2-D model (birthGaussianMeasurementCountThreshold > 1)."""
     scen = sc.make_scenario(12, 6, 8, seed=45)
