@@ -1325,7 +1325,19 @@ int rfsgpu_cycle_async(rfsgpu_filter *f, int predict, const double *x, const dou
 // (two halves, so that a group of shards can have every shard's chain in flight before it waits for the first: csrc/group.h)
 static int update_io_begin(rfsgpu_filter *f, int predict, const double *x, const double *x_cov, int cov_stride, const double *w_in, const double *z, int n_z,
                            bool want_weights) {
-  const int rc = cycle_impl(f, predict, x, x_cov, cov_stride, w_in, z, n_z, false, 0, true);
+  int rc;
+  if (f->phaseTiming) {
+    // rfsgpu_set_phase_timing (the binding's RFSGPU_PHASE_TIMING=1): the caller wants TimingInfo's per-phase buckets, i.e. the phases as
+    // separate launches with their own event pairs -- the call-by-call sequence, synchronous rfsgpu_update included
+    f->outArmed = false;
+    if (predict < -1 || predict > 1) return fail(f, RFSGPU_ERR_INVALID, "update_io: predict is RFSGPU_CYCLE_NO_PREDICT (-1), 0 or 1");
+    if (predict >= 0 && (rc = rfsgpu_predict_map(f, predict)) != RFSGPU_OK) return rc;
+    if (x && (rc = rfsgpu_set_poses(f, x, x_cov, x_cov ? cov_stride : 0)) != RFSGPU_OK) return rc;
+    if (w_in && (rc = rfsgpu_set_weights(f, w_in)) != RFSGPU_OK) return rc;
+    rc = rfsgpu_update(f, z, n_z);
+  } else {
+    rc = cycle_impl(f, predict, x, x_cov, cov_stride, w_in, z, n_z, false, 0, true);
+  }
   if (rc != RFSGPU_OK) return rc;
   if (want_weights && !f->outArmed) {      // (3-D model, phase timing, an empty measurement set, RFSGPU_IO_PULL=0: copy commands)
     if (!f->hWeights) HIPCHK(hipHostMalloc(&f->hWeights, (size_t)f->Ncap * sizeof(double)));

@@ -419,6 +419,18 @@ def test_update_io_is_set_poses_set_weights_update_get_weights(pkg, ob, sc):
         np.testing.assert_array_equal(w1, m2.get_weights())
         assert np.ptp(w1) > 0
     m1.close(); m2.close()
+    # rfsgpu_set_phase_timing (the binding's RFSGPU_PHASE_TIMING=1) is honoured by the one-call form too: separate launches, per-phase buckets
+    p1 = pkg.RBPHDFilter(scen["n"], gm_capacity=192)
+    sc.load_scenario(p1, scen)
+    p1.set_phase_timing(True)
+    p1.reset_timing()
+    w_p = p1.update_io(scen["Z"], poses=scen["poses"], weights=np.ones(scen["n"]))
+    t = p1.getTimingInfo()
+    assert t.mapUpdate_wall > 0 and t.particleWeighting_wall > 0 and t.mapMerge_wall > 0
+    p2 = pkg.RBPHDFilter(scen["n"], gm_capacity=192)
+    sc.load_scenario(p2, scen)
+    np.testing.assert_array_equal(w_p, p2.update_io(scen["Z"], poses=scen["poses"], weights=np.ones(scen["n"])))
+    p1.close(); p2.close()
     small = pkg.RBPHDFilter(4, gm_capacity=64)
     sc.load_scenario(small, sc.make_scenario(4, 60, 30, seed=16))
     with pytest.raises(pkg.capi.EngineError) as e:
