@@ -516,13 +516,23 @@ def main():
         ev_post.record(stream); ev_tot.record(side)          # (creates the handles)
         pend = {"have": False}
 
+        use_events = os.environ.get("RFS_BENCH_COLLECTIVE") == "events"    # (A/B: hand-over by stream events instead of device sequence numbers)
+
         def collective_step(Zk):
-            f.step_async_deferred(Zk, tot.data_ptr() if pend["have"] else None, ev_tot.cuda_event if pend["have"] else None)
-            ev_post.record(stream)
+            if use_events:
+                f.step_async_deferred(Zk, tot.data_ptr() if pend["have"] else None, ev_tot.cuda_event if pend["have"] else None)
+                ev_post.record(stream)
+            else:      # no event on the step's stream: the post kernel and the side stream's gate kernel meet through two device words
+                f.step_async_trailing(Zk, tot.data_ptr(), pend["have"])
             with torch.cuda.stream(side):
-                side.wait_event(ev_post)
+                if use_events:
+                    side.wait_event(ev_post)
+                else:
+                    f.collective_gate(side.cuda_stream)
                 tot.copy_(sums)
                 dist.all_reduce(tot)
+                if not use_events:
+                    f.collective_publish(side.cuda_stream)
                 ev_tot.record(side)
             pend["have"] = True
 

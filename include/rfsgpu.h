@@ -307,6 +307,15 @@ int rfsgpu_step_async(rfsgpu_filter *f, const double *z, int n_z, int normalize)
  * it.  (w L) / T instead of (w / T) L: an ulp apart from the call-by-call order.  A host that needs the normalised weights or
  * N_eff (the resample test, include/ParticleFilter.hpp:405-415) finishes with rfsgpu_normalize_weights(f, 0, total_dev). */
 int rfsgpu_step_async_deferred(rfsgpu_filter *f, const double *z, int n_z, const void *prev_total_dev, void *wait_event);
+/* [multi] The same hand-over without stream events (an event record and an event wait are a marker and a barrier packet on the step's
+ * stream).  Per step: rfsgpu_step_async_trailing(h, z, n, total_dev, have_prev) on the engine's stream, then ON THE SIDE STREAM
+ * rfsgpu_collective_gate(h, side) -> the collective of the shards' sums (the bound sums buffer) into total_dev ->
+ * rfsgpu_collective_publish(h, side).  The gate kernel waits on the device for this step's sums, the next step's post kernel waits on
+ * the device for the published total (bounded spins; a protocol that is never completed raises RFSGPU_ERR_UNSUPPORTED at the next
+ * synchronising call instead of hanging).  have_prev = 0 for the first step of a run or after the pending total has been applied. */
+int rfsgpu_step_async_trailing(rfsgpu_filter *f, const double *z, int n_z, const void *total_dev, int have_prev);
+int rfsgpu_collective_gate(rfsgpu_filter *f, void *hip_stream);
+int rfsgpu_collective_publish(rfsgpu_filter *f, void *hip_stream);
 #define RFSGPU_CYCLE_NO_PREDICT (-1)
 int rfsgpu_cycle_async(rfsgpu_filter *f, int predict, const double *x, const double *x_cov, int cov_stride, const double *w_in,
                        const double *z, int n_z, int normalize);

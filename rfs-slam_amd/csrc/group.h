@@ -484,12 +484,20 @@ int rfsgpu_group_update_deferred(rfsgpu_group *g, const double *z, int n_z) {
     return rc != RFSGPU_OK ? rc : rfsgpu_group_normalize(g, nullptr);
   }
   const int S = (int)g->shard.size();
+  // hand-over between a shard's stream and its side stream: device sequence numbers (rfsgpu_step_async_trailing: nothing but the two
+  // kernels on the step's stream), or -- RFSGPU_GROUP_EVENTS=1, the first form of the round, kept for A/B -- an event record and an event wait
+  static const bool useEvents = [] { const char *e = getenv("RFSGPU_GROUP_EVENTS"); return e && e[0] == '1'; }();
   for (int k = 0; k < S; k++) {
     rfsgpu_filter *f = g->shard[k];
-    GFWD(k, rfsgpu_step_async_deferred(f, z, n_z, g->pendingTotal ? g->dTot[k] : nullptr, g->pendingTotal ? (void *)g->evTot[k] : nullptr));
-    hipSetDevice(f->device);
-    GCHK(hipEventRecord(g->evPost[k], f->stream));
-    GCHK(hipStreamWaitEvent(g->side[k], g->evPost[k], 0));
+    if (useEvents) {
+      GFWD(k, rfsgpu_step_async_deferred(f, z, n_z, g->pendingTotal ? g->dTot[k] : nullptr, g->pendingTotal ? (void *)g->evTot[k] : nullptr));
+      hipSetDevice(f->device);
+      GCHK(hipEventRecord(g->evPost[k], f->stream));
+      GCHK(hipStreamWaitEvent(g->side[k], g->evPost[k], 0));
+    } else {
+      GFWD(k, rfsgpu_step_async_trailing(f, z, n_z, g->dTot[k], g->pendingTotal ? 1 : 0));
+      GFWD(k, rfsgpu_collective_gate(f, g->side[k]));
+    }
   }
   if (n_z > 0) g->resampleOccured = false;       // RBPHDFilter.hpp:526
   int rc = g_rccl.GroupStart();
@@ -503,7 +511,8 @@ int rfsgpu_group_update_deferred(rfsgpu_group *g, const double *z, int n_z) {
   if (rc != 0) return gfail(g, RFSGPU_ERR_HIP, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
   for (int k = 0; k < S; k++) {
     hipSetDevice(g->shard[k]->device);
-    GCHK(hipEventRecord(g->evTot[k], g->side[k]));
+    if (!useEvents) GFWD(k, rfsgpu_collective_publish(g->shard[k], g->side[k]));
+    GCHK(hipEventRecord(g->evTot[k], g->side[k]));      // (waited for only when the pending total is applied: group_flush)
   }
   g->pendingTotal = true;
   return RFSGPU_OK;

@@ -829,9 +829,19 @@ __device__ __forceinline__ double murty_partition_sum_block(double *C, int n, in
 // step's kernel ran -- the weights are divided by it HERE, before this step's sums are taken, instead of by a kernel of its own
 // behind the collective at the end of the previous step: (w L) / T in place of (w / T) L, an ulp apart, and the collective is
 // off the step's critical path.
-__device__ __forceinline__ void step_post_tail(double *weight, int N, double *sums, int normalize, const double *preDiv = nullptr) {
+__device__ __forceinline__ bool coll_wait(const int *word, int need);   // (below, with StepOut)
+__device__ __forceinline__ void step_post_tail(double *weight, int N, double *sums, int normalize, const double *preDiv = nullptr, int *collSeq = nullptr,
+                                               int collNeed = 0, int collPost = 0, int *err = nullptr) {
   if (!sums) return;
-  const double pd = preDiv ? preDiv[0] : 1.0;
+  __shared__ double sPd;
+  if (collSeq) {      // event-free hand-over: wait for the previous collective's sequence number, then read its total coherently
+    if (threadIdx.x == 0) {
+      if (collNeed > 0 && !coll_wait(collSeq + 1, collNeed) && err) atomicOr(err, ERRBIT_MURTY);
+      sPd = preDiv ? __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(preDiv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 1.0;
+    }
+    __syncthreads();
+  }
+  const double pd = collSeq ? sPd : (preDiv ? preDiv[0] : 1.0);
   __shared__ double sA[16], sB[16];   // (one entry per wave of the block, whatever it was launched with)
   __shared__ double sDiv;
   // (eight loads in flight per thread: one block sums the whole shard, and taken one at a time the ~16 dependent L2 round trips
@@ -857,6 +867,7 @@ __device__ __forceinline__ void step_post_tail(double *weight, int N, double *su
     for (int k = 0; k < (int)(blockDim.x >> 6); k++) { x += sA[k]; y += sB[k]; }
     sums[0] = x; sums[1] = y;
     sDiv = x;
+    if (collSeq) __hip_atomic_store(collSeq, collPost, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // the sums are out: the side stream's gate may pass
   }
   if (!normalize) return;
   __syncthreads();
@@ -878,7 +889,23 @@ struct StepOut {
   int *hostFlag;     // [0] error word, [1] sequence number
   int seq;
   const double *preDiv;   // device: {sum w, sum w^2} of the previous step over all shards, or nullptr (step_post_tail)
+  // The same hand-over WITHOUT stream events (rfsgpu_step_async_trailing): collSeq[1] is raised to k by a one-thread kernel behind the
+  // collective of step k on its side stream; the post kernel of step k + 1 waits for it HERE (it has been there for ~100 us), and raises
+  // collSeq[0] to its own number once its sums are written, on which the side stream's gate kernel waits.  An event record and an event
+  // wait are a marker and a barrier packet on the step's stream, ~4 us each at configs[1].
+  int *collSeq;
+  int collNeed, collPost;
 };
+// (bounded: a host that never runs the collective must not hang the device -- the post kernel gives up after ~0.5 s and raises the Murty / protocol bit)
+__device__ __forceinline__ bool coll_wait(const int *word, int need) {
+  for (unsigned spin = 0; spin < (1u << 22); spin++) {
+    if (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
+    __builtin_amdgcn_s_sleep(32);
+  }
+  return false;
+}
+__global__ void coll_gate_kernel(const int *collSeq, int need, int *err) { if (threadIdx.x == 0 && !coll_wait(collSeq, need)) atomicOr(err, ERRBIT_MURTY); }
+__global__ void coll_publish_kernel(int *word, int seq) { if (threadIdx.x == 0) __hip_atomic_store(word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void step_post_out(const double *weight, int N, int *err, const StepOut &SO) {
   if (!SO.hostW) return;
   __threadfence();
@@ -938,7 +965,7 @@ void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err, double *weight, 
     for (int t = threadIdx.x; t < nZdoubles; t += blockDim.x) dZ[t] = zarg.v[t];
   const int nJobs = min(*Q.count, Q.maxJobs);
   if (nJobs == 0) {
-    if (blockIdx.x == 0) { step_post_tail(weight, N, sums, normalize, SO.preDiv); step_post_out(weight, N, err, SO); }
+    if (blockIdx.x == 0) { step_post_tail(weight, N, sums, normalize, SO.preDiv, SO.collSeq, SO.collNeed, SO.collPost, err); step_post_out(weight, N, err, SO); }
     return;
   }
   __shared__ double sTile[W][MURTY_LDS_N * MURTY_LDS_N];
@@ -1069,7 +1096,7 @@ void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err, double *weight, 
 #ifdef RFS_PROFILE
   if (threadIdx.x == 0) printf("murty tail (last workgroup %d): factors into the weights %lld ticks of 10 ns, ends at tick %lld\n", (int)blockIdx.x, (long long)wall_clock64() - dbgTail0, (long long)wall_clock64());
 #endif
-  step_post_tail(weight, N, sums, normalize, SO.preDiv);
+  step_post_tail(weight, N, sums, normalize, SO.preDiv, SO.collSeq, SO.collNeed, SO.collPost, err);
   step_post_out(weight, N, err, SO);
 }
 
@@ -1109,7 +1136,7 @@ static inline void murty_free(MurtyQueue &Q, MurtyScratch &MS) {
 // instance (four waves, no register cap, no scratch set-up) on the same grid; a filter that has shown Murty work gets the capped
 // six-wave instance and the job ordering from the next step on.  Correct either way: jobs are strided over whatever grid there is.
 static inline int murty_launch(MurtyQueue &Q, MurtyScratch &MS, Buffers &B, hipStream_t stream, double *sums = nullptr, int normalize = 0,
-                               const ZArg *za = nullptr, int nZdoubles = 0, int *hostSeen = nullptr, const StepOut &SO = StepOut{nullptr, nullptr, 0, nullptr}) {
+                               const ZArg *za = nullptr, int nZdoubles = 0, int *hostSeen = nullptr, const StepOut &SO = StepOut{nullptr, nullptr, 0, nullptr, nullptr, 0, 0}) {
   int blocks = std::min(MURTY_JOB_BLOCKS, Q.maxJobs);
   // (RFSGPU_MURTY_FIRST_BLOCKS: grid of the light instance, for A/B runs -- tools/murty_first_step.py)
   static const int firstBlocks = [] { const char *e = getenv("RFSGPU_MURTY_FIRST_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : MURTY_FIRST_BLOCKS; }();

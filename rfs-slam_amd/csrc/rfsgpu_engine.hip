@@ -76,6 +76,8 @@ struct rfsgpu_filter {
   int stagePendingSlot = -1;          // a staging slot whose event must be recorded behind the step that reads it
   bool denseIntensity = false;        // RFSGPU_DENSE_INTENSITY=1 at create: deviation 9 off (the dense loop for every mixture size), for runs against a future pinned fixture
   bool ioPull = true;                 // RFSGPU_IO_PULL=0: inputs by copy commands, outputs by copies + a stream synchronisation (A/B, rounds 3-4 form)
+  int *dCollSeq = nullptr;            // [2] device: {number of the last step whose sums are out, number of the last step whose collective is done} (rfsgpu_step_async_trailing)
+  int collStep = 0;                   // steps issued in the event-free trailing form
   double *poseAlt = nullptr;          // [Ncap][3] second pose buffer: a fused predict + update cycle births at the old poses and updates at the new ones (rfsgpu_cycle_async)
   hipEvent_t evStage[4] = {};
   int stageNext = 0;
@@ -302,6 +304,8 @@ int rfsgpu_create_ex(rfsgpu_filter **out, int model, int n_particles, int device
   ok &= hipMalloc(&B.pose, (size_t)f->Ncap * 3 * sizeof(double)) == hipSuccess;
   ok &= hipMalloc(&B.poseCov, (size_t)f->Ncap * 9 * sizeof(double)) == hipSuccess;
   ok &= hipMalloc(&f->poseAlt, (size_t)f->Ncap * 3 * sizeof(double)) == hipSuccess;
+  ok &= hipMalloc(&f->dCollSeq, 2 * sizeof(int)) == hipSuccess;
+  if (ok) ok &= hipMemset(f->dCollSeq, 0, 2 * sizeof(int)) == hipSuccess;
   ok &= hipMalloc(&B.weight, f->Ncap * sizeof(double)) == hipSuccess;
   ok &= hipMalloc(&B.unusedMask, f->Ncap * sizeof(unsigned long long)) == hipSuccess;
   ok &= hipMalloc(&B.nInFov, f->Ncap * sizeof(int)) == hipSuccess;
@@ -361,7 +365,7 @@ void rfsgpu_destroy(rfsgpu_filter *f) {
   if (f->ownStream) hipStreamSynchronize(f->ownStream);
   Buffers &B = f->B;
   hipFree(f->snapSlab); hipFree(f->snapWeight); hipFree(f->snapCount); hipFree(f->snapFov); hipFree(f->snapUnused);
-  hipFree(B.slab[0]); hipFree(B.slab[1]); hipFree(B.count); hipFree(B.pose); hipFree(f->poseAlt); hipFree(B.poseCov); hipFree(B.weight);
+  hipFree(B.slab[0]); hipFree(B.slab[1]); hipFree(B.count); hipFree(B.pose); hipFree(f->poseAlt); hipFree(f->dCollSeq); hipFree(B.poseCov); hipFree(B.weight);
   hipFree(B.unusedMask); hipFree(B.nInFov); hipFree(B.err); hipFree(B.Z); hipFree(f->ownSums); hipFree(f->dSrcSlot); if (f->dRowSlots) hipFree(f->dRowSlots); if (f->fsArena) hipFree(f->fsArena); if (f->mhArena) hipFree(f->mhArena); if (f->mhInts) hipFree(f->mhInts);
   if (f->dInhParent) hipFree(f->dInhParent);
   if (f->dInhLevel) hipFree(f->dInhLevel);
@@ -940,7 +944,7 @@ int rfsgpu_prune(rfsgpu_filter *f) {
 }
 
 // All four phases back to back on the stream, ONE host sync at the end (RBPHDFilter::update body :444-523).
-static const StepOut NO_OUT{nullptr, nullptr, 0, nullptr};
+static const StepOut NO_OUT{nullptr, nullptr, 0, nullptr, nullptr, 0, 0};
 static const StepPredict NO_HEAD{0, 0, nullptr, nullptr, 0};
 static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool with_sums, int normalize, const StepPredict &sp = NO_HEAD, const StepOut &so = NO_OUT,
                              hipEvent_t waitBeforePost = nullptr);
@@ -1196,6 +1200,47 @@ int rfsgpu_step_async_deferred(rfsgpu_filter *f, const double *z, int n_z, const
   StepOut so = NO_OUT;
   so.preDiv = reinterpret_cast<const double *>(prev_total_dev);
   return update_async_impl(f, z, n_z, true, 0, NO_HEAD, so, (hipEvent_t)wait_event);
+}
+
+// The same without stream events.  The caller pairs every call with rfsgpu_collective_gate(side stream) -> its collective over the
+// shards' sums into total_dev -> rfsgpu_collective_publish(side stream): the gate kernel waits on the device for this step's post
+// kernel to have written the sums, the publish kernel raises the number the NEXT step's post kernel waits for (on the device, just
+// before it divides by total_dev).  have_prev == 0: the first step of a run (or the first after a flush): nothing to divide by.
+int rfsgpu_step_async_trailing(rfsgpu_filter *f, const double *z, int n_z, const void *total_dev, int have_prev) {
+  CHECK_HANDLE(f);
+  hipSetDevice(f->device);
+  if (!total_dev) return fail(f, RFSGPU_ERR_INVALID, "step_async_trailing: null total buffer");
+  const int k = ++f->collStep;
+  if (n_z == 0 || !f->fuseSteps || f->phaseTiming || f->D != 2) {   // no 2-D fused step: stand-alone kernels in stream order, the hand-over by the same two small kernels
+    if (have_prev) coll_gate_kernel<<<1, 64, 0, f->stream>>>(f->dCollSeq + 1, k - 1, f->B.err);
+    if (n_z > 0) { const int rc = update_async_impl(f, z, n_z, false, 0); if (rc != RFSGPU_OK) return rc; }
+    if (have_prev) { const int rc = rfsgpu_normalize_weights(f, 0.0, total_dev); if (rc != RFSGPU_OK) return rc; }
+    const int rc = rfsgpu_weight_sums_async(f);
+    coll_publish_kernel<<<1, 1, 0, f->stream>>>(f->dCollSeq, k);         // word [0]: "the sums of step k are out"
+    HIPCHK(hipGetLastError());
+    return rc;
+  }
+  StepOut so = NO_OUT;
+  so.preDiv = have_prev ? reinterpret_cast<const double *>(total_dev) : nullptr;
+  so.collSeq = f->dCollSeq; so.collNeed = have_prev ? k - 1 : 0; so.collPost = k;
+  return update_async_impl(f, z, n_z, true, 0, NO_HEAD, so, nullptr);
+}
+// [multi] on `hip_stream` (the side stream of the collective): wait, on the device, until the post kernel of the last
+// rfsgpu_step_async_trailing call has written this shard's sums.
+int rfsgpu_collective_gate(rfsgpu_filter *f, void *hip_stream) {
+  CHECK_HANDLE(f);
+  hipSetDevice(f->device);
+  coll_gate_kernel<<<1, 64, 0, (hipStream_t)hip_stream>>>(f->dCollSeq, f->collStep, f->B.err);
+  HIPCHK(hipGetLastError());
+  return RFSGPU_OK;
+}
+// [multi] on the same stream, behind the collective: the total of the last step is in place.
+int rfsgpu_collective_publish(rfsgpu_filter *f, void *hip_stream) {
+  CHECK_HANDLE(f);
+  hipSetDevice(f->device);
+  coll_publish_kernel<<<1, 1, 0, (hipStream_t)hip_stream>>>(f->dCollSeq + 1, f->collStep);   // word [1]: "the total of step k is in place"
+  HIPCHK(hipGetLastError());
+  return RFSGPU_OK;
 }
 
 // ---- one submission per predict + update cycle (round 5) --------------------------------------------------------------------

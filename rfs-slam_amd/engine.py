@@ -88,6 +88,17 @@ class RBPHDFilter(capi.CFilter):
         Z, n = self._z(Z)
         self._call("step_async_deferred", self._ptr(Z), n, C.c_void_p(prev_total_ptr), C.c_void_p(wait_event))
 
+    def step_async_trailing(self, Z, total_ptr, have_prev):
+        """rfsgpu_step_async_trailing: the deferred step without stream events (pair with collective_gate / collective_publish on the side stream)."""
+        Z, n = self._z(Z)
+        self._call("step_async_trailing", self._ptr(Z), n, C.c_void_p(total_ptr), C.c_int(1 if have_prev else 0))
+
+    def collective_gate(self, hip_stream):
+        self._call("collective_gate", C.c_void_p(hip_stream))
+
+    def collective_publish(self, hip_stream):
+        self._call("collective_publish", C.c_void_p(hip_stream))
+
     def _opt(self, a, shape=None):
         if a is None:
             return None, C.c_void_p(None)

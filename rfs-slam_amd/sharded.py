@@ -124,13 +124,15 @@ class ShardedRBPHDFilter:
         weights (normalize, resample, gather_weights) first applies the pending total (flush_deferred).  Device engine only."""
         assert self.on_gpu, "the trailing normalisation is a device-path feature (the CPU stand-in normalises in place)"
         Z = np.asarray(Z, dtype=np.float64).reshape(-1, self.f.dz)
-        self.f.step_async_deferred(Z, self._tot.data_ptr() if self._pending else None, self._ev_tot.cuda_event if self._pending else None)
-        self._ev_post.record(self.stream)
+        # (no event on the step's stream: this step's post kernel and the side stream's gate kernel meet through two device words,
+        #  rfsgpu_step_async_trailing; the event behind the collective is only waited for when the pending total is applied)
+        self.f.step_async_trailing(Z, self._tot.data_ptr(), self._pending)
         with torch.cuda.stream(self._side):
-            self._side.wait_event(self._ev_post)
+            self.f.collective_gate(self._side.cuda_stream)
             self._tot.copy_(self.sums)
             if self.world > 1:
                 dist.all_reduce(self._tot, group=self.group)
+            self.f.collective_publish(self._side.cuda_stream)
             self._ev_tot.record(self._side)
         self._pending = True
 
