@@ -1055,6 +1055,14 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
     //  capacity 384 -- 9 blocks of LDS per CU -- a launch of more than 2048 particles is better off with two waves per particle
     //  in several rounds: 3000 particles 229 us against 389, 8000: 474 against 882)
     int wpp = ((long long)perCU2 * f->nCU >= f->N || perCU2 >= 8) ? 2 : 3;
+    {  // (round 5) a launch small enough for every THREE-wave workgroup to be resident at once takes three waves per particle: a
+       // particle's own chain is what such a launch lasts, and the third wave shortens it -- fused step at configs[1]'s shape with
+       // 1000 / 500 / 250 particles 103.6 / 95.4 / 102.4 -> 99.3 / 86.1 / 94.6 us; at 2000 particles (1280 three-wave workgroups
+       // resident) two waves stay: 112 against 180 us
+      const size_t b3 = step_fused_lds_total(f->cap, ec, f->nZ, 3);
+      const int perCU3 = (int)std::min<size_t>(16 / 3, b3 ? (size_t)(160 * 1024) / b3 : 16 / 3);
+      if ((long long)perCU3 * f->nCU >= f->N) wpp = 3;
+    }
     if (f->stepWppOverride == 2 || f->stepWppOverride == 3) wpp = f->stepWppOverride;
     const size_t b = step_fused_lds_total(f->cap, ec, f->nZ, wpp);
     // phase priorities only when every workgroup is resident at once: 16 waves per CU at 128 VGPRs, LDS permitting

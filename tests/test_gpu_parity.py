@@ -252,10 +252,12 @@ def test_exact_partition_mode(pkg, ob, sc):
 
 @pytest.mark.parametrize("kw", [SCENARIOS[1], SCENARIOS[2], SCENARIOS[3], dict(n_particles=12, n_landmarks=500, n_z=30, seed=9, rmax=5.0),
                                 dict(n_particles=9, n_landmarks=40, n_z=7, seed=8, use_cluster=1)])
-def test_fused_step_with_three_waves_per_particle(pkg, ob, sc, kw, monkeypatch):
-    """The fused step kernel's three-wave form (what the engine picks when the two-wave grid cannot be resident at once, e.g. the
-    configs[2] shard; forced here with RFSGPU_STEP_WPP=3): bit-identical to the synchronous three-kernel path over two steps."""
-    monkeypatch.setenv("RFSGPU_STEP_WPP", "3")
+@pytest.mark.parametrize("wpp", [2, 3])
+def test_fused_step_with_two_and_three_waves_per_particle(pkg, ob, sc, kw, wpp, monkeypatch):
+    """The fused step kernel's two forms, forced with RFSGPU_STEP_WPP (the engine picks three waves per particle when the two-wave grid
+    cannot be resident at once -- the configs[2] shard -- and, since round 5, when the launch is small enough for every three-wave
+    workgroup to be resident; two waves otherwise, e.g. configs[1]): bit-identical to the synchronous three-kernel path over two steps."""
+    monkeypatch.setenv("RFSGPU_STEP_WPP", str(wpp))
     scen = sc.make_scenario(**kw)
     cap = 704 if kw["n_landmarks"] >= 500 else 512
     dev, orc = make_pair(pkg, ob, sc, scen, cap=cap)
@@ -804,10 +806,12 @@ def test_tied_weights_come_out_in_reference_order_across_chunks(pkg, ob, sc, n_l
 
 
 @pytest.mark.parametrize("n_lm,cap,fused", [(30, 64, False), (70, 128, True), (120, 192, False), (200, 384, True), (200, 384, False), (420, 640, True)])
-def test_rank_sort_over_a_wide_range_of_weights(pkg, ob, sc, n_lm, cap, fused):
+@pytest.mark.parametrize("wpp", [2, 3])
+def test_rank_sort_over_a_wide_range_of_weights(pkg, ob, sc, n_lm, cap, fused, wpp, monkeypatch):
     """The weighting phase ranks the mixture through a histogram over the upper words of the keys (weighting.h,
     bucket_rank_sort): weights spread over 200 decades (the bucket width adapts), clusters closer than a bucket, a few exact
     ties, and every bucket-count tier of the LDS budget (cap 64 ... 640).  Order and weights against the oracle."""
+    monkeypatch.setenv("RFSGPU_STEP_WPP", str(wpp))      # (both forms of the fused step kernel: the engine would pick three waves for a launch this small)
     scen = sc.make_scenario(10, n_lm, 12, seed=n_lm + cap)
     rng = np.random.default_rng(cap)
     w = scen["w"]
@@ -863,10 +867,12 @@ def _intensity_scenario(sc, kind, seed):
 
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("kind", ["crowded", "half_crowded", "untrusted", "faint_parents", "tiny_weights"])
-def test_intensity_sums_over_listed_pairs(pkg, ob, sc, kind, fused):
+@pytest.mark.parametrize("wpp", [2, 3])
+def test_intensity_sums_over_listed_pairs(pkg, ob, sc, kind, fused, wpp, monkeypatch):
     """importanceWeighting's intensity sums (include/RBPHDFilter.hpp:776-800) on mixtures large enough for the sparse form: the
     branches that leave the ordinary path -- list overflow, Gaussians listed for every point, the prior-intensity check failing --
     give the oracle's weights like the ordinary one."""
+    monkeypatch.setenv("RFSGPU_STEP_WPP", str(wpp))      # (both forms of the fused step kernel: the engine would pick three waves for a launch this small)
     scen = _intensity_scenario(sc, kind, 77)
     dev = pkg.RBPHDFilter(scen["n"], gm_capacity=640)
     orc = ob.OracleFilter(scen["n"])
@@ -975,8 +981,10 @@ def test_merge_with_degenerate_covariances(pkg, ob, sc):
 
 
 @pytest.mark.parametrize("kind,M", [("clusters", 150), ("crowded", 100), ("chain", 120)])
-def test_fused_merge_prune_stress_through_update(pkg, ob, sc, kind, M):
+@pytest.mark.parametrize("wpp", [2, 3])
+def test_fused_merge_prune_stress_through_update(pkg, ob, sc, kind, M, wpp, monkeypatch):
     """Same adversarial maps through rfsgpu_update (fused merge+prune kernel) and update_async."""
+    monkeypatch.setenv("RFSGPU_STEP_WPP", str(wpp))      # (both forms of the fused step kernel: the engine would pick three waves for a launch this small)
     scen = _clustered_mixtures(sc, 10, M, kind, seed=900 + M)
     dev, orc = make_pair(pkg, ob, sc, scen, cap=512)
     for f in (dev, orc):
@@ -1860,7 +1868,7 @@ def test_full_size_c4_victoria_park(pkg, ob, sc):
 def test_full_size_c5_murty_stress(pkg, ob, sc):
     """configs[4]: 1000 particles x 50 measurements, 40 evaluation points, 10-sigma weighting gate -> Murty-200 partitions."""
     scen = sc.make_scenario(1000, 200, 50, seed=555, n_clutter=10, n_eval=40, weighting_md=10.0, weights=(0.8, 1.0))
-    _full_size_check(pkg, ob, sc, scen, cap=448, subset=16, check_murty=True, fused=(2, 1, 5, 1))
+    _full_size_check(pkg, ob, sc, scen, cap=448, subset=16, check_murty=True, fused=(3, 1, 6, 1))   # (1000 particles: every three-wave workgroup resident)
 
 
 def test_murty_search_with_solver_waves_is_deterministic(pkg, sc):

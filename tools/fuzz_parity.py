@@ -130,6 +130,8 @@ for case in range(n_cases):
         continue
     for fused in (1, 0):
         os.environ["RFSGPU_FUSED_STEP"] = str(fused)
+        # both forms of the fused step kernel take their share of the cases (the engine itself would pick three waves per particle for launches this small)
+        os.environ["RFSGPU_STEP_WPP"] = "2" if case % 2 == 0 else "3"
         dev = pkg.RBPHDFilter(n, gm_capacity=cap)
         orc = ob.OracleFilter(n)
         try:
