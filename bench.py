@@ -786,9 +786,9 @@ def main():
                          "likelihood_sweep_GBps": sweep["achieved_GBps"] if sweep else None,
                          "bound_note": ("the dominant kernel of this workload is the Murty-200 assignment search (serial per partition, fp64 dependency "
                                         "chains: latency-bound, not a streaming kernel); the HBM figure is reported for the record, the quantity to "
-                                        "watch is its duration.  Its PMC traffic is mostly register spills: the kernel runs capped at 64 VGPRs (about 100 B of scratch "
-                                        "per lane) so that 1280 six-wave jobs are resident at once -- job residency, not HBM, is what shortens the launch "
-                                        "(DESIGN.md section 8)") if murty_dominant else None},
+                                        "watch is its duration.  Round 5: the ranked enumeration ends once no later term can change the sum (the same sum "
+                                        "bit for bit), eight waves per job under a 64-VGPR cap (1024 jobs resident at once) and -- built with "
+                                        "-disable-machine-licm -- no register spills: its PMC traffic is the node pool and the results (DESIGN.md section 8)") if murty_dominant else None},
         }
         if per_step:
             d = np.diff(np.array([t0] + per_step)) * 1e3

@@ -941,7 +941,7 @@ __global__ __launch_bounds__(1024) void murty_order_kernel(MurtyQueue Q) {
   }
 }
 #ifndef MURTY_WAVES_PER_EU
-#define MURTY_WAVES_PER_EU 8   // <= 64 VGPRs: five six-wave workgroups per CU instead of three (see MURTY_JOB_WAVES)
+#define MURTY_WAVES_PER_EU 8   // <= 64 VGPRs: four eight-wave workgroups per CU (round 3: five six-wave ones instead of three; see MURTY_JOB_WAVES).  No scratch since the build runs with -disable-machine-licm
 #endif
 #ifndef MURTY_LIGHT_WAVES
 #define MURTY_LIGHT_WAVES (MURTY_JOB_WAVES >= 8 ? 8 : 4)   // (round 5: eight -- the first update that queues partitions 5.8 -> 4.4 ms at configs[4], the empty-queue step of configs[1] unchanged at 121.4-122.3 us)
@@ -1134,7 +1134,7 @@ static inline void murty_free(MurtyQueue &Q, MurtyScratch &MS) {
 // The job count lives on the device: one launch, which is empty when no partition exceeded 8.
 // `hostSeen` (pinned, device-visible): set by the kernel once any step has queued Murty jobs.  Until then the launch is the light
 // instance (four waves, no register cap, no scratch set-up) on the same grid; a filter that has shown Murty work gets the capped
-// six-wave instance and the job ordering from the next step on.  Correct either way: jobs are strided over whatever grid there is.
+// eight-wave instance and the job ordering from the next step on.  Correct either way: jobs are strided over whatever grid there is.
 static inline int murty_launch(MurtyQueue &Q, MurtyScratch &MS, Buffers &B, hipStream_t stream, double *sums = nullptr, int normalize = 0,
                                const ZArg *za = nullptr, int nZdoubles = 0, int *hostSeen = nullptr, const StepOut &SO = StepOut{nullptr, nullptr, 0, nullptr, nullptr, 0, 0}) {
   int blocks = std::min(MURTY_JOB_BLOCKS, Q.maxJobs);
