@@ -1003,6 +1003,16 @@ void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err, double *weight, 
 #ifdef RFS_PROFILE
     const long long dbgJob0 = (long long)wall_clock64();
 #endif
+#if defined(MURTY_ONLY_MIN) || defined(MURTY_ONLY_MAX)   // tuning aid: time one class of jobs alone (the others count as 1.0: WRONG weights)
+#ifndef MURTY_ONLY_MIN
+#define MURTY_ONLY_MIN 0
+#endif
+#ifndef MURTY_ONLY_MAX
+#define MURTY_ONLY_MAX 64
+#endif
+    if (n < MURTY_ONLY_MIN || n > MURTY_ONLY_MAX) {
+    } else
+#endif
     if (n <= 0 || (unsigned)J.particle >= (unsigned)N) {
       // a queue slot its producer reserved but could not fill (partition beyond MURTY_MAXN: the error bit is already set): skipped
     } else if (n > MURTY_N || (int)blockIdx.x >= MS.nArenas) {
