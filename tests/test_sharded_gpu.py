@@ -248,6 +248,80 @@ def test_trailing_normalisation_equals_the_step_by_step_order(pkg):
     sh.close(); f.close(); ref.close()
 
 
+def _worker_trailing(rank, world, port, n_total, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from test_sharded_gloo import shard_scen
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    sc = pkg.scenarios
+    scen = sc.make_scenario(n_total, 60, 12, seed=52, params=dict(min_updates=1))
+    scen["particle_w"] = np.random.default_rng(5).uniform(0.2, 1.0, n_total)
+    local = pkg.RBPHDFilter(n_total // world, device_id=0, gm_capacity=256)
+    sc.load_scenario(local, shard_scen(scen, rank, world))
+    cfg = local.get_filter_config()
+    cfg.minUpdatesBeforeResample = 4                     # the resample test is due on every fourth update only: the others let the normalisation trail
+    local.set_filter_config(cfg)
+    sh = pkg.sharded.ShardedRBPHDFilter(local)
+    sh.effNParticles_t = 1e-9
+    rng = np.random.default_rng(8)
+    deferred = 0
+    for k in range(5):
+        Z = scen["Z"] + rng.normal(0, 2e-3, scen["Z"].shape)
+        sh.predict_map(True)
+        sh.update(Z)
+        deferred += int(sh._pending)
+    sh.flush_deferred()
+    local.synchronize()
+    q.put(dict(rank=rank, deferred=deferred, w=local.get_weights(), maps=[local.export_gm(i) for i in range(local.n)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trailing_normalisation_over_two_ranks(pkg):
+    """The trailing normalisation with a REAL collective between two processes (gloo; both ranks share this box's GPU): every rank's
+    post kernel divides by the all-reduced total of the previous step (rfsgpu_step_async_trailing, the gate / publish kernels on the
+    side stream around the all-reduce), three updates of every four.  Against one filter holding all particles that normalises step
+    by step: weights 1e-12 (they sum to 1 over BOTH shards), maps bit for bit."""
+    import torch.multiprocessing as mp
+    from test_sharded_gloo import free_port
+    n_total, world = 32, 2
+    sc = pkg.scenarios
+    scen = sc.make_scenario(n_total, 60, 12, seed=52, params=dict(min_updates=1))
+    scen["particle_w"] = np.random.default_rng(5).uniform(0.2, 1.0, n_total)
+    ref = pkg.RBPHDFilter(n_total, device_id=0, gm_capacity=256)
+    sc.load_scenario(ref, scen)
+    rng = np.random.default_rng(8)
+    for k in range(5):
+        Z = scen["Z"] + rng.normal(0, 2e-3, scen["Z"].shape)
+        ref.predict_map(True)
+        ref.update(Z)
+        ref.normalize_weights(ref.weight_sums()[0])
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = free_port()
+    procs = [ctx.Process(target=_worker_trailing, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get() for _ in range(world)], key=lambda d: d["rank"])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(o["deferred"] >= 3 for o in out)
+    w = np.concatenate([o["w"] for o in out])
+    np.testing.assert_allclose(w, ref.get_weights(), rtol=1e-12)
+    assert abs(w.sum() - 1.0) < 1e-12
+    maps = [m for o in out for m in o["maps"]]
+    for i in range(n_total):
+        for a, b in zip(maps[i], ref.export_gm(i)):
+            assert np.array_equal(a, b)
+    ref.close()
+
+
 def test_victoria_park_model_on_a_group_of_shards(pkg):
     """rfsgpu_group_set_model_victoriapark / _set_laser_scan / _get_timing (VERDICT r3 missing 5): configs[3]'s model on three shards
     of one GPU against one handle: two predict / update / normalise cycles and a forced global resampling in between (candidate
