@@ -2,6 +2,7 @@
 import os
 import shutil
 import subprocess
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
@@ -38,11 +39,26 @@ def build(force=False, verbose=False, extra_flags=()):
     """Compile the extension if sources are newer than the library. Returns the library path."""
     if not force and not stale():
         return LIB
-    cmd = [hipcc()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl", "-o", LIB]   # (-ldl: librccl is dlopen'ed by the multi-GPU group)
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return LIB
+    return compile_library(list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"], LIB, verbose)   # (-ldl: librccl is dlopen'ed by the multi-GPU group)
+
+
+def compile_library(args, lib, verbose=False):
+    """hipcc FLAGS args -o lib, with the device code taken THROUGH its assembly text (-save-temps, in a scratch directory that is removed
+    afterwards).  Same instructions as the integrated path (checked: the disassembly of the two code objects is identical), but an
+    instruction the target does not have stops the build instead of being encoded as something else: with `-mllvm -disable-machine-cse`
+    this backend emits `s_mov_b64 s[a:b], <64-bit literal>`, which gfx950 lacks -- the integrated assembler cuts the literal to its low
+    32 bits without a word (1024.0 became 0 and exp() of every negative argument 0: DESIGN 8, round 5), its text parser refuses the line."""
+    tmp = tempfile.mkdtemp(prefix="rfsgpu_build_")
+    try:
+        out = os.path.join(tmp, os.path.basename(lib))
+        cmd = [hipcc()] + FLAGS + ["-save-temps=obj"] + args + ["-o", out]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        shutil.move(out, lib)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return lib
 
 
 # Test support, not product: the library with the quarter-wave Hungarian solver switched on (tests/support/variants/hungarian_quad.h; measured slower than
@@ -58,11 +74,7 @@ def build_quad_variant(force=False, verbose=False):
     if not force and os.path.exists(QUAD_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(QUAD_LIB) for d in deps):
         return QUAD_LIB
     os.makedirs(os.path.dirname(QUAD_LIB), exist_ok=True)
-    cmd = [hipcc()] + FLAGS + QUAD_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", QUAD_LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return QUAD_LIB
+    return compile_library(QUAD_FLAGS + [os.path.join(CSRC, s) for s in SOURCES], QUAD_LIB, verbose)
 
 
 SIM = os.path.join(HERE, "host", "rbphdslam2d_sim")

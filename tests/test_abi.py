@@ -100,3 +100,26 @@ def test_stable_core_is_small_declared_and_sufficient_for_the_reference_side_bin
         if os.path.exists(exe):
             und = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True).stdout
             assert set(re.findall(r"\b(rfsgpu_\w+)", und)) <= set(core) | set(multi)
+
+
+def test_library_build_goes_through_the_assembler_text(pkg, tmp_path):
+    """build.compile_library takes the device code through its assembly text (-save-temps): the target's text parser refuses
+    `s_mov_b64 s[a:b], <64-bit literal>` -- an operand gfx950 does not have, which this backend emits under -disable-machine-cse
+    and whose literal the integrated path cuts to 32 bits in silence (exp() of a negative argument was 0).
+    The premise (the assembler refuses the line; it takes the two-instruction form) and the build path's flag."""
+    import inspect
+    import shutil
+    import subprocess
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    if not os.path.exists(clang):
+        pytest.skip("no ROCm LLVM here")
+    assert "-save-temps" in inspect.getsource(pkg.build_mod.compile_library)
+    bad = tmp_path / "bad.s"
+    bad.write_text('\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"\n\t.text\n\ts_mov_b64 s[0:1], 0x4090000000000000\n')
+    r = subprocess.run([clang, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", str(bad), "-o", str(tmp_path / "bad.o")],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "invalid operand" in r.stderr
+    good = tmp_path / "good.s"
+    good.write_text('\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"\n\t.text\n\ts_mov_b32 s0, 0\n\ts_mov_b32 s1, 0x40900000\n')
+    subprocess.check_call([clang, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", str(good), "-o", str(tmp_path / "good.o")])
+    shutil.rmtree(tmp_path, ignore_errors=True)

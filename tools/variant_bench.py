@@ -22,13 +22,20 @@ if sys.argv[1] == "--build":
     import __graft_entry__ as g
     bm = g.load_package().build_mod
     os.makedirs(OUT, exist_ok=True)
-    procs = []
-    for spec in sys.argv[2:]:
+    # through the assembly text like the product build (build.compile_library): a flag under which the backend emits an instruction the
+    # target lacks fails here instead of giving a library that computes something else (the -disable-machine-cse episode)
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(spec):
         name, flags = spec.split("=", 1)
-        cmd = [bm.hipcc()] + bm.FLAGS + flags.split() + [os.path.join(bm.CSRC, "rfsgpu_engine.hip"), "-o", lib_of(name)]
-        procs.append((name, subprocess.Popen(cmd, stderr=subprocess.DEVNULL)))
-    for name, p in procs:
-        print(name, "rc", p.wait())
+        try:
+            bm.compile_library(flags.split() + [os.path.join(bm.CSRC, "rfsgpu_engine.hip"), "-ldl"], lib_of(name))
+            return name, 0
+        except subprocess.CalledProcessError as e:
+            return name, e.returncode
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for name, rc in ex.map(one, sys.argv[2:]):
+            print(name, "rc", rc)
 else:
     steps = os.environ.get("VB_STEPS", "200")
     wl = os.environ.get("VB_WORKLOAD", "c2a")
