@@ -475,6 +475,24 @@ def test_bench_rccl_calls_with_one_rank():
     assert m["rows_migrated_total"] == 0 and np.array(m["rows_from_rank_to_rank"]).shape == (1, 1)
 
 
+def test_bench_falls_back_to_stream_events_when_the_sequence_number_hand_over_times_out():
+    """bench.py's N > 1 path hands the total from the collective's stream to the step's through two device words; the waits are
+    bounded (a stalled side stream must not hang the device), and a time-out in the untimed first steps makes the run go on with
+    stream events instead of failing.  Forced here by never publishing the word (RFS_BENCH_DROP_PUBLISH=1), one rank."""
+    import json
+    import subprocess
+    env = dict(os.environ, RFS_BENCH_FORCE_DIST="1", RFS_BENCH_DROP_PUBLISH="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    env.pop("RFS_BENCH_SHARE_GPU", None)
+    env.pop("RFS_BENCH_COLLECTIVE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29549", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "2", "--no-cpu-baseline", "--no-pmc", "--no-boundary"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "continuing with stream events" in r.stderr
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["value"] > 0 and "fell back from the sequence-number form" in d["config"]["parallelism"]
+
+
 @pytest.mark.parametrize("n_shards", [3, 8])
 def test_group_with_birth_candidate_lists_inherits_as_a_single_filter(pkg, n_shards):
     """A configuration that keeps birth-candidate lists (CountThreshold 3) over several shards: after forced global resamplings the
