@@ -545,9 +545,52 @@ def main():
                 f.normalize_weights(0.0, tot.data_ptr(), 1)
                 pend["have"] = False
 
+    # Re-seeding.  Every step of a `reseed` workload runs on the SAME saved state.  Until round 5 that state was copied back inside the
+    # step (rfsgpu_restore_state: 45 MB and 8.8 us of a 124 us step at configs[1] -- benchmark scaffolding, not the path).  Now the inputs of
+    # the W warm-up and K timed steps are resident in HBM before the timed region starts: a ring of W + K pre-seeded copies of the state
+    # (rfsgpu_state_ring_create), and a step takes the next one by a pointer swap on the host.  RFS_BENCH_RESEED_IN_LOOP=1 (or a ring
+    # that would not fit in half of the free memory) keeps the copy in the loop.
+    # The untimed steps ahead of it (clock ramp, 0.25 s) go round the same ring and fill it again whenever it has been used up -- so that they
+    # too read a state that has left the caches (220 slots x 43 MB), and the kernel average a profiler takes over the whole process is the
+    # timed region's.
+    ring = {"on": False, "slots": 0, "left": 0}
+
+    def reseed():
+        if ring["on"]:
+            if ring["left"] == 0:
+                f.state_ring_seed()
+                ring["left"] = ring["slots"]
+            f.state_ring_next()
+            ring["left"] -= 1
+        else:
+            f.restore_state()
+
+    def ring_start(n_slots):
+        if not wl["reseed"] or os.environ.get("RFS_BENCH_RESEED_IN_LOOP") == "1":
+            return
+        slot_bytes = n_local * (11 if vp else 7) * CAP * 8 + n_local * 28
+        free_b, _ = torch.cuda.mem_get_info()
+        if n_slots * slot_bytes > free_b // 2:
+            return
+        f.synchronize()
+        f.state_ring_create(n_slots)
+        ring["on"], ring["slots"], ring["left"] = True, n_slots, n_slots
+
+    def ring_refill():                    # every slot fresh: the next `slots` steps find their inputs resident
+        if ring["on"]:
+            f.synchronize()
+            f.state_ring_seed()
+            ring["left"] = ring["slots"]
+
+    def ring_stop():
+        if ring["on"]:
+            f.synchronize()
+            f.state_ring_create(0)
+            ring["on"] = False
+
     if wl["reseed"]:
         def step(k):
-            f.restore_state()
+            reseed()
             # stream-ordered: the host never waits inside a step; device errors surface at the final sync.  Two launches: the
             # fused step kernel (measurement set in its arguments) and the post kernel (Murty partitions if any, weight sums,
             # and -- one GPU -- the division).
@@ -583,6 +626,7 @@ def main():
                 f.normalize_weights(0.0, sums_ptr, 1)
 
     if args.pmc_child:                    # the short run the parent profiles with rocprofv3 --pmc (no output, no baselines)
+        ring_start(13)
         for k in range(3):
             step(k)
         f.synchronize()                   # (a filter that queues Murty partitions switches to its full post-kernel instance once the host has seen the flag)
@@ -591,6 +635,7 @@ def main():
         f.synchronize()
         return
 
+    ring_start(max(args.warmup + args.steps, 16))
     try:
         for k in range(3):
             step(k)
@@ -639,6 +684,7 @@ def main():
     for k in range(8, pre_warm):
         step(k)
     f.synchronize()
+    ring_refill()                         # the W + K steps from here on find their inputs resident (see `reseed` above)
     for k in range(args.warmup):
         step(pre_warm + k)
     bytes_sweep, bytes_step = survey_bytes(n_local, nM, nAfter - nM, nKept, N_Z, BG, DZ)
@@ -683,16 +729,19 @@ def main():
     # weak-scaling reference on the SAME workload: this rank's shard alone, without the collective (N > 1 only)
     solo = None
     if multi and wl["reseed"]:
+        ring_refill()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for k in range(args.steps):
-            f.restore_state(); f.step_async(Z, True)
+            reseed(); f.step_async(Z, True)
         torch.cuda.synchronize()
         st = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
         dist.all_reduce(st, op=dist.ReduceOp.MAX)
         solo = args.steps / float(st.item())
         f.synchronize(); f.kernel_time_stats()
     f.set_step_timing_stride(1)
+    ring_slots = ring["slots"] if ring["on"] else 0
+    ring_stop()
 
     # per-phase breakdown (and the likelihood-sweep rate the north star asks for): the three stand-alone kernels, HIP events,
     # untimed pass after the region
@@ -771,6 +820,9 @@ def main():
                 "particles_total": n_local * world,
                 "gm_capacity": CAP,
                 "pre_warmup_steps": pre_warm,      # untimed clock-ramp steps (0.25 s) ahead of the W warm-up steps
+                "state_reseed": (("ring: the input state of each of the W + K steps is a pre-seeded copy resident in HBM before the timed region "
+                                  "(%d slots, rfsgpu_state_ring_*); a step takes it by a pointer swap" % ring_slots) if ring_slots
+                                 else ("in the loop: rfsgpu_restore_state copies the saved state back inside every step" if wl["reseed"] else "none (steady state)")),
                 "unit_definition": "one step = one update(Z) of one shard of %d particles; value sums the shard-steps of all ranks "
                                    "(global filter of %d particles: %.3f updates/s)" % (n_local, n_local * world, args.steps / dt),
                 "parallelism": f"particle-sharded: {world} GPU(s), one process per GPU, RCCL all-reduce of 2 doubles/step" +

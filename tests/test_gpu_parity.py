@@ -326,6 +326,64 @@ def test_multi_step_predict_update_cycle(pkg, ob, sc):
         compare_maps(sc, dev, orc, scen["n"])
 
 
+@pytest.mark.parametrize("model", ["2d", "vp"])
+def test_state_ring_steps_equal_restore_and_step(pkg, ob, sc, model):
+    """bench.py's re-seeding (round 5): a ring of pre-seeded copies of the saved state, taken one per step by a pointer swap
+    (rfsgpu_state_ring_create / _next / _seed), instead of rfsgpu_restore_state inside the timed step.  Every ring step must be the
+    restore + step it replaces -- weights, sizes, maps, unused lists bit for bit -- and agree with the oracle; a consumed ring refuses
+    the next swap, a re-seeded one serves again; the handle works on after the ring is freed."""
+    vp = model == "vp"
+    kw = dict(model=pkg.capi.MODEL_VICTORIAPARK_3D) if vp else {}
+    scen = sc.make_vp_scenario(12, 30, 9, seed=77, scan="ragged") if vp else sc.make_scenario(12, 60, 14, seed=77)
+    dev = pkg.RBPHDFilter(scen["n"], gm_capacity=256, **kw)
+    orc = ob.OracleFilter(scen["n"], **kw)
+    for f in (dev, orc):
+        sc.load_scenario(f, scen)
+    dev.save_state()
+
+    def snapshot():
+        dev.synchronize()
+        return (dev.get_weights().copy(), dev.gm_sizes().copy(), [tuple(a.copy() for a in dev.export_gm(i)) for i in range(scen["n"])],
+                [np.array(dev.get_unused(i)) for i in range(scen["n"])])
+
+    def same(a, b):
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+        for ga, gb in zip(a[2], b[2]):
+            for x, y in zip(ga, gb):
+                np.testing.assert_array_equal(x, y)
+        for ua, ub in zip(a[3], b[3]):
+            np.testing.assert_array_equal(ua, ub)
+
+    dev.restore_state()
+    dev.step_async(scen["Z"], False)
+    want = snapshot()
+    orc.update(scen["Z"])
+    compare_weights(dev, orc)
+    compare_maps(sc, dev, orc, scen["n"])
+    dev.state_ring_create(3)
+    for _ in range(3):
+        dev.state_ring_next()
+        dev.step_async(scen["Z"], False)
+        same(snapshot(), want)
+    with pytest.raises(Exception, match="consumed"):
+        dev.state_ring_next()
+    dev.state_ring_seed()
+    for _ in range(2):
+        dev.state_ring_next()
+        dev.step_async(scen["Z"], False)
+        same(snapshot(), want)
+    dev.restore_state()                       # the two ways of re-seeding mix
+    dev.step_async(scen["Z"], False)
+    same(snapshot(), want)
+    dev.state_ring_create(0)
+    with pytest.raises(Exception, match="no ring"):
+        dev.state_ring_next()
+    dev.restore_state()
+    dev.step_async(scen["Z"], False)
+    same(snapshot(), want)
+
+
 @pytest.mark.parametrize("n_lm,cap", [(25, 256), (150, 384)])
 def test_fused_predict_update_cycle_is_the_call_by_call_cycle(pkg, ob, sc, n_lm, cap):
     """rfsgpu_cycle_async (round 5): the predict's map part (births at the poses the PREVIOUS update used,
