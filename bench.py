@@ -47,23 +47,23 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     "c2a": dict(n=2000, nm=200, nz=30, cap=384, rmax=None, frac=1.0, reseed=True,
                 label="C2a (BASELINE configs[1]): {n} particles/GPU x 200 GM landmarks x 30 measurements/step, all landmarks in FOV, "
-                      "2D RngBrg model, multi-feature weighting (nEvalPt 15), state re-seeded from a device snapshot every step"),
+                      "2D RngBrg model, multi-feature weighting (nEvalPt 15), every step on the same saved state (config.state_reseed)"),
     "c3": dict(n=2500, nm=500, nz=30, cap=640, rmax=5.0, frac=1.0, reseed=True,
                label="C3 shard (BASELINE configs[2]: 20000 particles x 500 GM landmarks over 8 GPUs): {n} particles/GPU x 500 GM landmarks x "
-                     "30 measurements/step, range limit 5 m, 2D RngBrg model, multi-feature weighting (nEvalPt 15), state re-seeded from a "
-                     "device snapshot every step"),
+                     "30 measurements/step, range limit 5 m, 2D RngBrg model, multi-feature weighting (nEvalPt 15), every step on the "
+                     "same saved state (config.state_reseed)"),
     "c2b": dict(n=2000, nm=200, nz=30, cap=384, rmax=None, frac=0.15, reseed=False,
                 label="C2b steady state: {n} particles/GPU x 200 GM landmarks (30 inside the FOV) x 30 measurements/step, NOT re-seeded: "
                       "predict (births) + update + normalise per step, fresh measurement noise and clutter every step"),
     "c4": dict(n=5000, nm=40, nz=12, cap=192, model="vp", reseed=True, cpu_sample=1024,
                label="C4 (BASELINE configs[3]): Victoria Park model (Ackerman2D poses, MeasurementModel_VictoriaPark: 3-D landmarks x, y, trunk "
                      "diameter; scan-based Pd), {n} particles x 40 landmarks x 12 measurements/update, multi-feature weighting (nEvalPt 15), "
-                     "synthetic ragged 361-beam scan (the dataset's LASER.txt is not in the reference tree), state re-seeded every step"),
+                     "synthetic ragged 361-beam scan (the dataset's LASER.txt is not in the reference tree), every step on the same saved state (config.state_reseed)"),
     "c5": dict(n=1000, nm=200, nz=50, cap=448, rmax=None, frac=1.0, reseed=True, cpu_sample=64,
                scen_kw=dict(n_clutter=10, n_eval=40, weighting_md=10.0, weights=(0.8, 1.0)), seed=555,
                label="C5 (BASELINE configs[4]): SC-PHD / multi-feature weighting stress, {n} particles x 200 GM landmarks x 50 measurements/step "
                      "(40 detections + 10 clutter), 40 evaluation points, 10-sigma weighting gate -> partitions of extended dimension 9-15 -> "
-                     "Murty-200 (bug-compatible with the reference's truncation), fp64, state re-seeded every step"),
+                     "Murty-200 (bug-compatible with the reference's truncation), fp64, every step on the same saved state (config.state_reseed)"),
 }
 
 
