@@ -551,7 +551,8 @@ int rfsgpu_restore_state(rfsgpu_filter *f);
  * region instead of being copied inside it (restore_state is a 45 MB copy per step at configs[1]).  _create allocates and fills the
  * slots from the snapshot (rfsgpu_save_state first; 0 frees the ring); _next makes the next slot the handle's current state by
  * swapping device pointers -- host work only, nothing is launched; a slot is consumed by the step that runs on it, _next past the
- * last slot is an error, _seed fills all slots again.  Results are those of rfsgpu_restore_state + the same step
+ * last slot is an error, _seed fills all slots again.  A swap moves the handle's weight array: a pointer obtained from
+ * rfsgpu_weights_device_ptr before it is stale afterwards.  Results are those of rfsgpu_restore_state + the same step
  * (tests/test_gpu_parity.py::test_state_ring_steps_equal_restore_and_step). */
 int rfsgpu_state_ring_create(rfsgpu_filter *f, int n_slots);
 int rfsgpu_state_ring_seed(rfsgpu_filter *f);
