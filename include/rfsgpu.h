@@ -527,7 +527,13 @@ int rfsgpu_group_synchronize(rfsgpu_group *g);
 
 /* ---- [core] timing, [bench] / misc ---------------------------------------------------------------------------- */
 
-int rfsgpu_get_timing(rfsgpu_filter *f, rfsgpu_timing *t);              /* getTimingInfo :1219-1232 */
+/* getTimingInfo (:1219-1232).  The device buckets (mapUpdate_wall, ...) come from HIP events, and on the fused one-launch step those
+ * events ride on every 8th step only (three marker packets per step cost a configs[1] step 8 us): a SAMPLED step is booked once for
+ * itself and once for every un-sampled step since the previous sample, and un-sampled steps behind the last sample are booked at
+ * that sample's duration at the next synchronising call -- so the bucket covers every step, as an estimate, not a per-step
+ * measurement like the reference's timer_mapUpdate_.  rfsgpu_set_step_timing_stride(f, 1) (bench API) or rfsgpu_set_phase_timing
+ * (per-phase launches with their own event pairs) give measured per-step values. */
+int rfsgpu_get_timing(rfsgpu_filter *f, rfsgpu_timing *t);
 int rfsgpu_reset_timing(rfsgpu_filter *f);
 /* Block until all queued device work of this handle is complete; reports a pending device-side error of async steps. */
 int rfsgpu_synchronize(rfsgpu_filter *f);

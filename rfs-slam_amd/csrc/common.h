@@ -20,7 +20,7 @@
 
 enum Plane { PL_W = 0, PL_WP = 1, PL_MX = 2, PL_MY = 3, PL_SXX = 4, PL_SXY = 5, PL_SYY = 6, PL_COUNT = 7 };
 
-enum ErrBits { ERRBIT_CAPACITY = 1, ERRBIT_MURTY = 2, ERRBIT_EVALPTS = 4, ERRBIT_BIRTHLIST = 8 };
+enum ErrBits { ERRBIT_CAPACITY = 1, ERRBIT_MURTY = 2, ERRBIT_EVALPTS = 4, ERRBIT_BIRTHLIST = 8, ERRBIT_COLLECTIVE = 16 };
 
 // Everything a kernel needs besides the buffers; passed by value (lives in SGPRs / kernarg segment).
 struct Params {

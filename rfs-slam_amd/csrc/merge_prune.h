@@ -1124,6 +1124,11 @@ __device__ __forceinline__ void predict_map_particle(const Buffers &B, const Par
   double *pSXX = plane(slab, cap, i, PL_SXX), *pSXY = plane(slab, cap, i, PL_SXY), *pSYY = plane(slab, cap, i, PL_SYY);
   int n = B.count[i];
   const int nOld = n;  // staticStep below covers the pre-existing Gaussians; births get Q added where they are created
+  // Several waves per particle (the fused cycle's head): EVERY wave must hold the pre-birth count before the first wave publishes
+  // count + births below -- a wave that arrived late would otherwise take the new count for nOld, add Q to the newborn Gaussians a
+  // second time and race with the first wave's stores to them.  The barrier waits for outstanding loads (vmcnt / lgkmcnt 0) first.
+  // The call is block-uniform in the fused kernel; the one-wave stand-alone kernel needs nothing.
+  if constexpr (NT > 64) __syncthreads();
   if (addBirth && nZprev > 0 && tid < 64) {
     const unsigned long long um = B.unusedMask[i];
     const bool immediate = (P.birthCountThr == 1u) || ((unsigned)B.nInFov[i] <= P.birthCurThr);

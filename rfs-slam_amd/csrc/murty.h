@@ -836,7 +836,7 @@ __device__ __forceinline__ void step_post_tail(double *weight, int N, double *su
   __shared__ double sPd;
   if (collSeq) {      // event-free hand-over: wait for the previous collective's sequence number, then read its total coherently
     if (threadIdx.x == 0) {
-      if (collNeed > 0 && !coll_wait(collSeq + 1, collNeed) && err) atomicOr(err, ERRBIT_MURTY);
+      if (collNeed > 0 && !coll_wait(collSeq + 1, collNeed) && err) atomicOr(err, ERRBIT_COLLECTIVE);
       sPd = preDiv ? __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(preDiv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 1.0;
     }
     __syncthreads();
@@ -896,15 +896,18 @@ struct StepOut {
   int *collSeq;
   int collNeed, collPost;
 };
-// (bounded: a host that never runs the collective must not hang the device -- the post kernel gives up after ~0.5 s and raises the Murty / protocol bit)
+// (bounded: a host that never runs the collective must not hang the device -- the waiter gives up after 0.5 s of the constant 100 MHz
+//  clock and raises the collective-protocol bit, its own error bit and message, not Murty's)
+#define COLL_WAIT_TICKS 50000000ll
 __device__ __forceinline__ bool coll_wait(const int *word, int need) {
-  for (unsigned spin = 0; spin < (1u << 22); spin++) {
+  const long long t0 = (long long)wall_clock64();
+  for (;;) {
     if (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
+    if ((long long)wall_clock64() - t0 > COLL_WAIT_TICKS) return false;
     __builtin_amdgcn_s_sleep(32);
   }
-  return false;
 }
-__global__ void coll_gate_kernel(const int *collSeq, int need, int *err) { if (threadIdx.x == 0 && !coll_wait(collSeq, need)) atomicOr(err, ERRBIT_MURTY); }
+__global__ void coll_gate_kernel(const int *collSeq, int need, int *err) { if (threadIdx.x == 0 && !coll_wait(collSeq, need)) atomicOr(err, ERRBIT_COLLECTIVE); }
 __global__ void coll_publish_kernel(int *word, int seq) { if (threadIdx.x == 0) __hip_atomic_store(word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void step_post_out(const double *weight, int N, int *err, const StepOut &SO) {
   if (!SO.hostW) return;

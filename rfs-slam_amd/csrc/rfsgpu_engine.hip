@@ -127,7 +127,8 @@ struct rfsgpu_filter {
   unsigned stepSeq = 0;      // fused steps launched so far
   int timingStride = 8;      // every timingStride-th of them carries the timing events (rfsgpu_set_step_timing_stride; round 5: 8 by default --
                              // three marker packets per step cost a configs[1] step 8 us; the FIRST step of a filter is always timed)
-  int untimedSince = 0;      // fused steps launched since the last one that carried events
+  int untimedSince = 0;      // fused steps launched since the last one that carried events (and not yet booked into TimingInfo)
+  long long lastFusedNs = 0; // duration of the last sampled fused step (what an un-sampled step is booked at)
   int ringStands[RFSGPU_ASYNC_RING] = {};   // how many steps a timed ring entry stands for in TimingInfo (itself + the untimed ones before it)
   int mergeGridOverride = 0; // RFSGPU_MERGE_GRID: log2 of the merge grid's cells per side in the three-wave fused kernel (5 or 6); 0 = chosen per launch
   hipEvent_t evAfterWeightKernel = nullptr;   // where launch_weighting drops its mid-phase event (async steps only)
@@ -225,6 +226,7 @@ static int check_device_errors(rfsgpu_filter *f) {
   add(ERRBIT_MURTY, RFSGPU_ERR_UNSUPPORTED, "Murty job queue overflow, a partition larger than MURTY_MAXN, or a FastSLAM association component beyond the in-kernel solver");
   add(ERRBIT_EVALPTS, RFSGPU_ERR_UNSUPPORTED, "more than RFSGPU_MAX_EVAL evaluation points requested");
   add(ERRBIT_BIRTHLIST, RFSGPU_ERR_UNSUPPORTED, "a particle's birth-candidate / landmark-candidate list outgrew RFSGPU_MAX_CANDIDATES");
+  add(ERRBIT_COLLECTIVE, RFSGPU_ERR_UNSUPPORTED, "collective hand-over timed out: the sequence number of the weight all-reduce was not published within 0.5 s (rfsgpu_step_async_trailing / rfsgpu_collective_gate / _publish)");
   if (code != RFSGPU_OK) { f->err = msg; return code; }
   return fail(f, RFSGPU_ERR_HIP, "unknown device error flag");
 }
@@ -988,6 +990,15 @@ int rfsgpu_update(rfsgpu_filter *f, const double *z, int n_z) {
   return rc;
 }
 
+// Does the fused step being launched carry the timing events?  Every timingStride-th one does (the first of a filter always); a
+// timed ring entry stands for itself + the untimed steps launched since the previous booking (2-D and Victoria Park steps alike).
+static bool step_carries_events(rfsgpu_filter *f) {
+  const bool timed = (f->stepSeq++ % (unsigned)f->timingStride) == 0;
+  if (timed) { f->ringStands[f->ringCount] = f->untimedSince + 1; f->untimedSince = 0; }
+  else f->untimedSince++;
+  return timed;
+}
+
 // Fold the event pairs of the async steps recorded since the last harvest into TimingInfo / the kernel statistics.
 // Caller has synchronised the stream.
 static void harvest_async(rfsgpu_filter *f) {
@@ -1000,6 +1011,7 @@ static void harvest_async(rfsgpu_filter *f) {
       // (only every timingStride-th fused step carries events: TimingInfo books the sampled step once for each step it stands for)
       if (f->ringStands[k] > 1) f->timing.mapUpdate_wall += ns[0] * (long long)(f->ringStands[k] - 1);
       for (int q = 0; q < 3; q++) { f->statNs[q] += (double)ns[q]; f->lastKernelNs[q] = ns[q]; }
+      f->lastFusedNs = ns[0];
       {   // the post kernel (Murty jobs if any, queue reset, weight sums / division): event 1 is free on this path
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e[3], e[1]) == hipSuccess) f->statPostNs += (double)ms * 1.0e6;
@@ -1016,6 +1028,12 @@ static void harvest_async(rfsgpu_filter *f) {
     accumulate(e[2], e[3], f->timing.mapMerge_wall, &ns[2]);
     for (int q = 0; q < 3; q++) { f->statNs[q] += (double)ns[q]; f->lastKernelNs[q] = ns[q]; }
     f->statSteps++;
+  }
+  // un-sampled steps launched since the last sampled one: booked now at the last sample's duration (the stream is drained, they have
+  // run), so that TimingInfo covers every step at every harvest instead of trailing by up to timingStride - 1 steps
+  if (f->untimedSince > 0 && f->lastFusedNs > 0) {
+    f->timing.mapUpdate_wall += f->lastFusedNs * (long long)f->untimedSince;
+    f->untimedSince = 0;
   }
   f->timing.mapUpdate_kf_wall = f->timing.mapUpdate_wall;
   f->ringCount = 0;
@@ -1046,8 +1064,7 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
     memcpy(za.v, z, (size_t)n_z * 2 * sizeof(double));
     f->nZ = n_z;
     if (n_z > 0) f->resampleOccured = false;
-    const bool timed = (f->stepSeq++ % (unsigned)f->timingStride) == 0;   // (rfsgpu_set_step_timing_stride)
-    if (timed) { f->ringStands[f->ringCount] = f->untimedSince + 1; f->untimedSince = 0; } else f->untimedSince++;
+    const bool timed = step_carries_events(f);   // (rfsgpu_set_step_timing_stride)
     if (timed) HIPCHK(hipEventRecord(e[0], f->stream));
     const int ec = eval_cap(f), useW = f->cfg.useClusterProcess ? 0 : 1;
     // Waves per particle: two, unless the two-wave grid cannot be resident at once (large mixtures: the LDS block limits the
@@ -1129,8 +1146,7 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
     memcpy(za.v, z, (size_t)n_z * 3 * sizeof(double));
     f->nZ = n_z;
     if (n_z > 0) f->resampleOccured = false;
-    const bool timed = (f->stepSeq++ % (unsigned)f->timingStride) == 0;
-    if (timed) { f->ringStands[f->ringCount] = f->untimedSince + 1; f->untimedSince = 0; } else f->untimedSince++;
+    const bool timed = step_carries_events(f);
     if (timed) HIPCHK(hipEventRecord(e[0], f->stream));
     const int ec = eval_cap(f), useW = f->cfg.useClusterProcess ? 0 : 1;
     const size_t shared = vp_shared_lds_bytes(f->nZ, f->B.nScan), per = vp_step_lds_bytes_per_wave(f->cap, ec, f->nZ);
@@ -1424,6 +1440,8 @@ static int update_io_end(rfsgpu_filter *f, double *w_out) {
     }
     const int rc = check_device_errors(f);     // an error bit (or no answer): synchronise, read and clear the word, build the message
     harvest_async(f);
+    // the stream is drained now: a step that merely outlasted the spin (large N, Murty-heavy, a profiler attached) HAS delivered
+    if (!seen) seen = __atomic_load_n(&f->hOutFlag[1], __ATOMIC_ACQUIRE) == f->outSeq;
     if (w_out) memcpy(w_out, f->hOutW, (size_t)f->N * sizeof(double));
     if (rc == RFSGPU_OK && !seen) return fail(f, RFSGPU_ERR_HIP, "update_io: the post kernel never delivered its results");
     return rc;
