@@ -316,6 +316,13 @@ int rfsgpu_step_async_deferred(rfsgpu_filter *f, const double *z, int n_z, const
 int rfsgpu_step_async_trailing(rfsgpu_filter *f, const double *z, int n_z, const void *total_dev, int have_prev);
 int rfsgpu_collective_gate(rfsgpu_filter *f, void *hip_stream);
 int rfsgpu_collective_publish(rfsgpu_filter *f, void *hip_stream);
+/* [multi] Whether the engine's stream and `hip_stream` make progress side by side on this runtime -- what the sequence-number form
+ * above needs (its post kernel waits for a word a LATER submission on the other stream publishes; two streams mapped onto one
+ * hardware queue serialise, and the wait can only run out: RFSGPU_ERR_UNSUPPORTED, "collective hand-over timed out").  Plays the
+ * hand-over once with nothing at stake (bounded 0.2 s, synchronises both streams); *side_by_side = 1 | 0.  Probe once per stream
+ * pair; on 0 use rfsgpu_step_async_deferred (stream events: two packets on the step's stream, ~+9 us per step) -- which is why both
+ * forms stay.  rfsgpu_group_update_deferred and the Python hosts do exactly that. */
+int rfsgpu_collective_probe(rfsgpu_filter *f, void *hip_stream, int *side_by_side);
 #define RFSGPU_CYCLE_NO_PREDICT (-1)
 int rfsgpu_cycle_async(rfsgpu_filter *f, int predict, const double *x, const double *x_cov, int cov_stride, const double *w_in,
                        const double *z, int n_z, int normalize);

@@ -30,7 +30,10 @@
 #ifndef RBPHDFILTER_HPP   /* the reference's own include guard: this file stands in for that header */
 #define RBPHDFILTER_HPP
 
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <ctime>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -144,10 +147,11 @@ class rfsgpu_engine_facade {
   int predict_map(int add_birth) { return g_ ? rfsgpu_group_predict_map(g_, add_birth) : rfsgpu_predict_map(f_, add_birth); }
   int update(const double *z, int n_z) { return g_ ? rfsgpu_group_update(g_, z, n_z, NULL) : rfsgpu_update(f_, z, n_z); }
   /* RBPHDFilter::update's device part with its inputs and outputs in ONE call and one wait (poses + covariances + weights in, weights out) */
-  int update_io(const double *x, const double *cov, int stride, const double *w_in, const double *z, int n_z, double *w_out) {
-    return g_ ? rfsgpu_group_update_io(g_, x, cov, stride, w_in, z, n_z, w_out)
-              : rfsgpu_update_io(f_, RFSGPU_CYCLE_NO_PREDICT, x, cov, stride, w_in, z, n_z, w_out);
+  int update_io(int predict, const double *x, const double *cov, int stride, const double *w_in, const double *z, int n_z, double *w_out) {
+    return g_ ? rfsgpu_group_update_io(g_, x, cov, stride, w_in, z, n_z, w_out)     /* (a group never has a predict pending: single() below) */
+              : rfsgpu_update_io(f_, predict, x, cov, stride, w_in, z, n_z, w_out);
   }
+  bool single() const { return g_ == NULL; }      /* one handle: rfsgpu_update_io can take the pending predict's map part with it */
   int resample_apply(const int *src) { return g_ ? rfsgpu_group_apply_plan(g_, src) : rfsgpu_resample_apply(f_, src); }
   int gm_size(int i) { return g_ ? rfsgpu_group_gm_size(g_, i) : rfsgpu_gm_size(f_, i); }
   int get_landmark(int i, int m, double *mean, double *cov, double *w) { return g_ ? rfsgpu_group_get_landmark(g_, i, m, mean, cov, w) : rfsgpu_get_landmark(f_, i, m, mean, cov, w); }
@@ -249,6 +253,10 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
   }
 
   ~RBPHDFilter() {
+    if (prof_ && profN_ > 0)
+      std::fprintf(stderr, "rfsgpu binding predict() breakdown over %lld calls, us per call: flush + configuration %.2f | map part (lazy: pose check + record; eager: "
+                           "pose push + predict launch + wait) %.2f | ParticleFilter::propagate (reference host code) %.2f | lazy=%d\n",
+                   profN_, 1e-3 * profNs_[0] / profN_, 1e-3 * profNs_[1] / profN_, 1e-3 * profNs_[2] / profN_, lazyPredict_ ? 1 : 0);
     delete kf_;
     delete lmkModelPtr_;
   }
@@ -260,13 +268,30 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
    * pass through the handle above (the 2-D tuple gets the model pointer itself, as in the reference) */
   typename rfsgpu_model_access<MeasurementModel>::pointer getMeasurementModel() { return model_.get(); }
 
-  /* :415-442.  Births use the pose BEFORE propagation (:423-426), so the poses go to the device first. */
+  /* :415-442.  Births use the pose BEFORE propagation (:423-426).
+   * Round 6: the map part of the predict (addBirthGaussians :1000-1084 + staticStep :433-439) is LAZY where that changes nothing: when
+   * the device still holds exactly the poses the particles have now -- the previous update() pushed them and nothing has moved them
+   * since, checked against a host copy -- the births can happen at those device poses at any later time, so predict() only records
+   * (birthGaussianCheck) and the next update() hands it to rfsgpu_update_io, whose step kernel runs the births + static step at its
+   * head: no pose push, no predict launch, no wait for it (the same Gaussians bit for bit,
+   * test_fused_predict_update_cycle_is_the_call_by_call_cycle).  Anything that reads the maps in between (getGMSize, getLandmark), a
+   * second predict() before the update, a configuration change between predict() and update(), the Victoria Park model and a filter
+   * over several GPUs take the eager path -- the call-by-call sequence of rounds 3-5.  RFSGPU_LAZY_PREDICT=0 turns the lazy path off. */
   void predict(TInput u, TimeStamp const &dT, bool useModelNoise = true, bool useInputNoise = false, bool birthGaussianCheck = true) {
     timer_predict_.resume();
+    const long long t0 = prof_now();
+    flushPredict();                                          /* (a predict still pending from a step without an update) */
     pushConfiguration();
-    pushPoses();
-    check(engine_.predict_map(birthGaussianCheck ? 1 : 0), "predict_map");   /* addBirthGaussians :1000-1084 + staticStep :433-439 */
+    const long long t1 = prof_now();
+    if (lazyPredict_ && rfsgpu_model_of<MeasurementModel>::dim == 2 && engine_.single() && devicePosesAreCurrent()) {
+      predictPending_ = birthGaussianCheck ? 1 : 0;
+    } else {
+      pushPoses();
+      check(engine_.predict_map(birthGaussianCheck ? 1 : 0), "predict_map");
+    }
+    const long long t2 = prof_now();
     this->propagate(u, dT, useModelNoise, useInputNoise, true);                      /* :429, host RNG, keeps the trajectory */
+    if (prof_) { const long long t3 = prof_now(); profNs_[0] += t1 - t0; profNs_[1] += t2 - t1; profNs_[2] += t3 - t2; profN_++; }
     timer_predict_.stop();
   }
 
@@ -283,17 +308,21 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
       typename TMeasurement::Vec v = this->measurements_[k].get();
       for (int d = 0; d < D; d++) z[(size_t)D * k + d] = v[d];
     }
-    pushConfiguration();
-    /* poses (+ covariances) and weights in, updateMap + importanceWeighting + merge + prune (:469-520), weights out: one engine
-     * call, one wait for the device (round 5; until then set_poses + set_weights + update + get_weights, two waits) */
+    pushConfiguration();                                   /* (flushes a pending predict first if the configuration has changed under it) */
+    /* poses (+ covariances) and weights in, [the pending predict's births + static step,] updateMap + importanceWeighting + merge +
+     * prune (:469-520), weights out: one engine call, one wait for the device */
     const int n = this->nParticles_;
-    std::vector<double> x((size_t)3 * n), P((size_t)9 * n), w((size_t)n);
-    gatherPoses(x, P);
-    for (int i = 0; i < n; i++) w[i] = this->particleSet_[i]->getWeight();
+    xHost_.resize((size_t)3 * n); PHost_.resize((size_t)9 * n); wHost_.resize((size_t)n);
+    gatherPoses(xHost_, PHost_);
+    for (int i = 0; i < n; i++) wHost_[i] = this->particleSet_[i]->getWeight();
     timer_mapUpdate_.resume();
-    check(engine_.update_io(x.data(), P.data(), 9, w.data(), z.data(), nZ, w.data()), "update");
+    const int pred = predictPending_ >= 0 ? predictPending_ : RFSGPU_CYCLE_NO_PREDICT;
+    predictPending_ = -1;
+    xOnDeviceValid_ = false;
+    check(engine_.update_io(pred, xHost_.data(), PHost_.data(), 9, wHost_.data(), z.data(), nZ, wHost_.data()), "update");
+    xOnDeviceValid_ = true;                                 /* xHost_ is what the device holds now (a resampling copies both sides alike) */
     timer_mapUpdate_.stop();
-    for (int i = 0; i < n; i++) this->particleSet_[i]->setWeight(w[i]);
+    for (int i = 0; i < n; i++) this->particleSet_[i]->setWeight(wHost_[i]);
 
     timer_particleResample_.resume();                       /* :524-539, unchanged */
     resampleOccured_ = false;
@@ -310,6 +339,7 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
   }
 
   int getGMSize(int i) {                                     /* :1152-1158 */
+    flushPredict();                                          /* (the maps are read: a recorded predict happens now) */
     if (i >= 0 && i < this->nParticles_) return engine_.gm_size(i);
     return -1;
   }
@@ -327,7 +357,7 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
     return true;
   }
 
-  void setParticlePose(int i, TPose &p) { *(this->particleSet_[i]) = p; }   /* :1180-1186 */
+  void setParticlePose(int i, TPose &p) { *(this->particleSet_[i]) = p; }   /* :1180-1186 (seen by devicePosesAreCurrent() at the next predict) */
 
   TimingInfo *getTimingInfo() {                              /* :1219-1232: host timers for what stays on the host, the */
     rfsgpu_timing t;                                         /* engine's HIP-event buckets for what runs on the device  */
@@ -351,6 +381,44 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
   int nUpdatesSinceResample_, nMeasurementsSinceResample_;
   bool resampleOccured_;
   Timer timer_predict_, timer_mapUpdate_, timer_particleResample_;
+  /* lazy predict (round 6) */
+  int predictPending_ = -1;                                 /* -1 none | 0 static step only | 1 births + static step: recorded, not yet run */
+  bool lazyPredict_ = !(std::getenv("RFSGPU_LAZY_PREDICT") && std::atoi(std::getenv("RFSGPU_LAZY_PREDICT")) == 0);
+  bool xOnDeviceValid_ = false;                             /* xHost_ holds the pose means the last update() pushed */
+  std::vector<double> xHost_, PHost_, wHost_;
+  std::vector<int> srcSlot_;
+  struct PushedConfig { rfsgpu_filter_config c; rfsgpu_kf_config k; double q[9]; rfsgpu_rngbrg_config m; bool valid; } pushed_ = {};
+  /* RFSGPU_BINDING_PROFILE=1: where predict()'s host time goes, printed by the destructor (profiles/r06*_binding_predict_breakdown.txt) */
+  bool prof_ = std::getenv("RFSGPU_BINDING_PROFILE") && std::atoi(std::getenv("RFSGPU_BINDING_PROFILE")) != 0;
+  long long profNs_[3] = {0, 0, 0}, profN_ = 0;
+  long long prof_now() const {
+    if (!prof_) return 0;
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (long long)ts.tv_sec * 1000000000LL + ts.tv_nsec;
+  }
+
+  /* A recorded predict happens NOW, at the poses the device holds (the pre-propagation ones: nothing has pushed poses since). */
+  void flushPredict() {
+    if (predictPending_ < 0) return;
+    const int p = predictPending_;
+    predictPending_ = -1;
+    check(engine_.predict_map(p), "predict_map");
+  }
+  /* Are the device's poses the particles' poses?  True when the last update() pushed them (xHost_) and every particle's mean still
+   * equals that copy -- a resampling permutes both sides alike (resampleWithDeviceMaps keeps xHost_ in step), setParticlePose and
+   * writes through getParticleSet() show up as a difference.  Only the means matter: inverseMeasure (births) reads no covariance. */
+  bool devicePosesAreCurrent() {
+    if (!xOnDeviceValid_) return false;
+    const int n = this->nParticles_;
+    if (xHost_.size() != (size_t)3 * n) return false;
+    for (int i = 0; i < n; i++) {
+      typename TPose::Vec v;
+      this->particleSet_[i]->get(v);
+      if (v[0] != xHost_[(size_t)3 * i] || v[1] != xHost_[(size_t)3 * i + 1] || v[2] != xHost_[(size_t)3 * i + 2]) return false;
+    }
+    return true;
+  }
 
   /* include/ParticleFilter.hpp:140 (pure virtual) / include/RBPHDFilter.hpp:306 (private there too).  The reference calls it
    * from inside update() only (:490); here the weighting of ALL particles is a phase of the device step that update() launches,
@@ -368,6 +436,7 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
    * the driver may change at any time; src/rbphdslam_VictoriaPark.cpp:510,538 changes the landmark noise every step). */
   void pushConfiguration() {
     rfsgpu_filter_config c;
+    std::memset(&c, 0, sizeof(c));                          /* (padding bytes: the structs are compared below) */
     c.birthGaussianWeight = config.birthGaussianWeight_;
     c.birthGaussianMeasurementCountThreshold = config.birthGaussianMeasurementCountThreshold_;
     c.birthGaussianMeasurementCheckThreshold = config.birthGaussianMeasurementCheckThreshold_;
@@ -383,24 +452,36 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
     c.minUpdatesBeforeResample = config.minUpdatesBeforeResample_;
     c.minMeasurementsBeforeResample = config.minMeasurementsBeforeResample_;
     c.useClusterProcess = config.useClusterProcess_ ? 1 : 0;
-    check(engine_.set_filter_config(&c), "set_filter_config");
 
     rfsgpu_kf_config k;
+    std::memset(&k, 0, sizeof(k));
     k.rangeInnovationThreshold = kf_->config.rangeInnovationThreshold_;
     k.bearingInnovationThreshold = kf_->config.bearingInnovationThreshold_;
-    check(engine_.set_kf_config(&k), "set_kf_config");
 
     typename TLandmark::Mat Q;
     lmkModelPtr_->getNoise(Q);                                    /* include/ProcessModel.hpp:92-95 */
     const int D = rfsgpu_model_of<MeasurementModel>::dim;
-    double q[9];
+    double q[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int r = 0; r < D; r++)
       for (int cc = 0; cc < D; cc++) q[D * r + cc] = Q(r, cc);
-    check(engine_.set_lmk_process_noise(q), "set_lmk_process_noise");
+
+    /* A recorded predict must run under the configuration predict() saw (birth weight, R, Q, ...): if the driver has changed
+     * anything since, it happens now, before the new values go to the engine. */
+    const bool same = pushed_.valid && std::memcmp(&pushed_.c, &c, sizeof(c)) == 0 && std::memcmp(&pushed_.k, &k, sizeof(k)) == 0 &&
+                      std::memcmp(pushed_.q, q, sizeof(q)) == 0;
+    if (!same) {
+      flushPredict();
+      check(engine_.set_filter_config(&c), "set_filter_config");
+      check(engine_.set_kf_config(&k), "set_kf_config");
+      check(engine_.set_lmk_process_noise(q), "set_lmk_process_noise");
+      pushed_.c = c; pushed_.k = k; std::memcpy(pushed_.q, q, sizeof(q));
+    }
     pushModel(model_.get());
+    pushed_.valid = true;
   }
   void pushModel(MeasurementModel_RngBrg *m) {                     /* include/MeasurementModel_RngBrg.hpp:65-71 */
     rfsgpu_rngbrg_config c;
+    std::memset(&c, 0, sizeof(c));
     MeasurementModel_RngBrg::TMeasurement::Mat R;
     m->getNoise(R);
     c.R[0] = R(0, 0); c.R[1] = R(0, 1); c.R[2] = R(1, 0); c.R[3] = R(1, 1);
@@ -409,7 +490,10 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
     c.rangeLimMax = m->config.rangeLimMax_;
     c.rangeLimMin = m->config.rangeLimMin_;
     c.rangeLimBuffer = m->config.rangeLimBuffer_;
+    if (pushed_.valid && std::memcmp(&pushed_.m, &c, sizeof(c)) == 0) return;    /* unchanged since the last push */
+    flushPredict();                                                   /* (R enters the birth covariance) */
     check(engine_.set_model_rngbrg(&c), "set_model_rngbrg");
+    pushed_.m = c;
   }
   void pushModel(rfsgpu_vp_model_handle *m) {                      /* include/MeasurementModel_VictoriaPark.hpp:136-152 */
     rfsgpu_vp_config c;
@@ -508,6 +592,10 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
       }
     }
     check(engine_.resample_apply(src_slot.data()), "resample_apply");   /* also resets the device weights to 1 */
+    if (xOnDeviceValid_ && xHost_.size() == (size_t)3 * n)                /* the device's pose array travelled with the particles: so does its host copy */
+      for (int i = 0; i < n; i++)
+        if (src_slot[i] != i)
+          for (int r = 0; r < 3; r++) xHost_[(size_t)3 * i + r] = xHost_[(size_t)3 * src_slot[i] + r];
     for (int i = 0; i < n; i++) this->particleSet_[i]->setWeight(1);            /* :486-489 */
     return true;
   }

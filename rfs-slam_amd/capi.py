@@ -118,7 +118,7 @@ ABI_SYMBOLS = [
     "normalize_weights_parts", "create_ex", "n_particles", "max_particles", "resample_apply_n",
     "fastslam_set_resample_occured", "particle_parents", "vp_probe_pd",
     "slab_row_bytes", "export_slab_rows", "import_slab_rows", "weights_device_ptr", "step_async", "set_step_inputs_async", "predict_map_async", "set_phase_timing", "static_steps_async", "propagate_ackerman_async", "propagate_ackerman_run_async", "set_partition_mode", "get_partition_mode",
-    "set_birth_inheritance", "get_birth_inheritance", "get_particle_ids", "set_particle_ids", "resample_occured", "get_unused_masks", "set_unused_masks", "has_birth_candidates", "predict_map_level", "murty_partition_sums", "cycle_async", "update_io", "step_async_deferred", "step_async_trailing", "collective_gate", "collective_publish",
+    "set_birth_inheritance", "get_birth_inheritance", "get_particle_ids", "set_particle_ids", "resample_occured", "get_unused_masks", "set_unused_masks", "has_birth_candidates", "predict_map_level", "murty_partition_sums", "cycle_async", "update_io", "step_async_deferred", "step_async_trailing", "collective_gate", "collective_publish", "collective_probe",
     "group_create", "group_destroy", "group_last_error", "group_n_shards", "group_n_particles", "group_shard", "group_locate",
     "group_set_filter_config", "group_set_model_rngbrg", "group_set_kf_config", "group_set_lmk_process_noise", "group_set_poses",
     "group_get_poses", "group_set_weights", "group_get_weights", "group_predict_map", "group_update", "group_normalize",

@@ -34,6 +34,7 @@ struct rfsgpu_group {
   std::string rcclNote;                // why the host path is in use, if it is
   // trailing normalisation (rfsgpu_group_update_deferred): the all-reduce of step k on a side stream per shard, beside step k + 1's kernel
   std::vector<hipStream_t> side;
+  int handover = 0;            // 0 not probed yet | 1 device sequence numbers | 2 stream events (rfsgpu_group_update_deferred)
   std::vector<hipEvent_t> evPost, evTot;
   bool pendingTotal = false;           // dTot holds a total the weights have not been divided by yet
   std::string err;
@@ -200,6 +201,8 @@ const char *rfsgpu_group_collective(const rfsgpu_group *g) {
   static thread_local std::string s;
   if (!g) return "null group";
   s = g->comm.empty() ? ("host: " + g->rcclNote) : std::string("rccl");
+  // (once rfsgpu_group_update_deferred has probed the shards' stream pairs: which hand-over the trailing normalisation uses)
+  if (!g->comm.empty() && g->handover) s += g->handover == 1 ? "; hand-over: sequence numbers" : "; hand-over: stream events";
   return s.c_str();
 }
 const char *rfsgpu_group_last_error(const rfsgpu_group *g) { return g ? g->err.c_str() : "null group"; }
@@ -485,8 +488,20 @@ int rfsgpu_group_update_deferred(rfsgpu_group *g, const double *z, int n_z) {
   }
   const int S = (int)g->shard.size();
   // hand-over between a shard's stream and its side stream: device sequence numbers (rfsgpu_step_async_trailing: nothing but the two
-  // kernels on the step's stream), or -- RFSGPU_GROUP_EVENTS=1, the first form of the round, kept for A/B -- an event record and an event wait
-  static const bool useEvents = [] { const char *e = getenv("RFSGPU_GROUP_EVENTS"); return e && e[0] == '1'; }();
+  // kernels on the step's stream) where the two streams of EVERY shard make progress side by side -- probed once, at the first
+  // deferred step (rfsgpu_collective_probe) --, otherwise an event record and an event wait per step (rfsgpu_step_async_deferred, the
+  // fall-back: +9 us per step with one rank).  RFSGPU_GROUP_EVENTS=1 forces the event form (A/B).
+  if (g->handover == 0) {
+    const char *e = getenv("RFSGPU_GROUP_EVENTS");
+    bool ev = e && e[0] == '1';
+    for (int k = 0; k < S && !ev; k++) {
+      int ok = 0;
+      GFWD(k, rfsgpu_collective_probe(g->shard[k], g->side[k], &ok));
+      if (!ok) ev = true;
+    }
+    g->handover = ev ? 2 : 1;
+  }
+  const bool useEvents = g->handover == 2;
   for (int k = 0; k < S; k++) {
     rfsgpu_filter *f = g->shard[k];
     if (useEvents) {

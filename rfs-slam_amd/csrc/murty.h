@@ -908,6 +908,24 @@ __device__ __forceinline__ bool coll_wait(const int *word, int need) {
   }
 }
 __global__ void coll_gate_kernel(const int *collSeq, int need, int *err) { if (threadIdx.x == 0 && !coll_wait(collSeq, need)) atomicOr(err, ERRBIT_COLLECTIVE); }
+// rfsgpu_collective_probe: the hand-over played once with nothing at stake -- *verdict = need if the word arrived within `ticks`
+#define COLL_PROBE_TICKS 20000000ll    // 0.2 s
+__global__ void coll_probe_kernel(const int *word, int need, int *verdict, long long ticks) {
+  if (threadIdx.x != 0) return;
+  const long long t0 = (long long)wall_clock64();
+  int seen = 0;
+  for (;;) {
+    if (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= need) { seen = need; break; }
+    if ((long long)wall_clock64() - t0 > ticks) break;
+    __builtin_amdgcn_s_sleep(32);
+  }
+  *verdict = seen;
+}
+__global__ void coll_spin_kernel(long long ticks) {     // (test hook: holds a stream back)
+  if (threadIdx.x != 0) return;
+  const long long t0 = (long long)wall_clock64();
+  while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
 __global__ void coll_publish_kernel(int *word, int seq) { if (threadIdx.x == 0) __hip_atomic_store(word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void step_post_out(const double *weight, int N, int *err, const StepOut &SO) {
   if (!SO.hostW) return;

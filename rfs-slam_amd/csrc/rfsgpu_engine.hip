@@ -80,7 +80,8 @@ struct rfsgpu_filter {
   int stagePendingSlot = -1;          // a staging slot whose event must be recorded behind the step that reads it
   bool denseIntensity = false;        // RFSGPU_DENSE_INTENSITY=1 at create: deviation 9 off (the dense loop for every mixture size), for runs against a future pinned fixture
   bool ioPull = true;                 // RFSGPU_IO_PULL=0: inputs by copy commands, outputs by copies + a stream synchronisation (A/B, rounds 3-4 form)
-  int *dCollSeq = nullptr;            // [2] device: {number of the last step whose sums are out, number of the last step whose collective is done} (rfsgpu_step_async_trailing)
+  int collProbeSeq = 0;               // probes made so far (rfsgpu_collective_probe)
+  int *dCollSeq = nullptr;            // [2 + 2] device: {number of the last step whose sums are out, number of the last step whose collective is done} (rfsgpu_step_async_trailing)
   int collStep = 0;                   // steps issued in the event-free trailing form
   double *poseAlt = nullptr;          // [Ncap][3] second pose buffer: a fused predict + update cycle births at the old poses and updates at the new ones (rfsgpu_cycle_async)
   hipEvent_t evStage[4] = {};
@@ -310,8 +311,8 @@ int rfsgpu_create_ex(rfsgpu_filter **out, int model, int n_particles, int device
   ok &= hipMalloc(&B.pose, (size_t)f->Ncap * 3 * sizeof(double)) == hipSuccess;
   ok &= hipMalloc(&B.poseCov, (size_t)f->Ncap * 9 * sizeof(double)) == hipSuccess;
   ok &= hipMalloc(&f->poseAlt, (size_t)f->Ncap * 3 * sizeof(double)) == hipSuccess;
-  ok &= hipMalloc(&f->dCollSeq, 2 * sizeof(int)) == hipSuccess;
-  if (ok) ok &= hipMemset(f->dCollSeq, 0, 2 * sizeof(int)) == hipSuccess;
+  ok &= hipMalloc(&f->dCollSeq, 4 * sizeof(int)) == hipSuccess;      // + [2] probe word, [3] probe verdict (rfsgpu_collective_probe)
+  if (ok) ok &= hipMemset(f->dCollSeq, 0, 4 * sizeof(int)) == hipSuccess;
   ok &= hipMalloc(&B.weight, f->Ncap * sizeof(double)) == hipSuccess;
   ok &= hipMalloc(&B.unusedMask, f->Ncap * sizeof(unsigned long long)) == hipSuccess;
   ok &= hipMalloc(&B.nInFov, f->Ncap * sizeof(int)) == hipSuccess;
@@ -1269,6 +1270,35 @@ int rfsgpu_collective_publish(rfsgpu_filter *f, void *hip_stream) {
   hipSetDevice(f->device);
   coll_publish_kernel<<<1, 1, 0, (hipStream_t)hip_stream>>>(f->dCollSeq + 1, f->collStep);   // word [1]: "the total of step k is in place"
   HIPCHK(hipGetLastError());
+  return RFSGPU_OK;
+}
+// [multi] Do the engine's stream and `hip_stream` make progress SIDE BY SIDE?  The sequence-number hand-over above needs it: a post
+// kernel on the engine's stream waits, on the device, for a word that a kernel on the side stream publishes LATER in submission
+// order.  Two streams that a runtime maps onto one hardware queue (GPU_MAX_HW_QUEUES streams share four by default) serialise instead,
+// and the wait can only run out.  The probe plays the hand-over once with nothing at stake: a one-thread waiter on the engine's
+// stream (bounded: 0.2 s), then the publish on the side stream; *side_by_side = 1 if the waiter saw the word.  Hosts probe once
+// per (stream, side stream) pair and use the stream-event form (rfsgpu_step_async_deferred) when the answer is 0
+// (ShardedRBPHDFilter, rfsgpu_group_update_deferred, bench.py).  RFSGPU_COLL_PROBE_DELAY_MS (test hook): the publish is held back by
+// a spinning kernel for that long -- past the bound the probe must answer 0 and the hosts must take the event form.
+int rfsgpu_collective_probe(rfsgpu_filter *f, void *hip_stream, int *side_by_side) {
+  CHECK_HANDLE(f);
+  if (!side_by_side) return fail(f, RFSGPU_ERR_INVALID, "collective_probe: null result pointer");
+  hipSetDevice(f->device);
+  const int k = ++f->collProbeSeq;
+  hipStream_t side = (hipStream_t)hip_stream;
+  coll_probe_kernel<<<1, 64, 0, f->stream>>>(f->dCollSeq + 2, k, f->dCollSeq + 3, COLL_PROBE_TICKS);
+  HIPCHK(hipGetLastError());
+  if (const char *d = getenv("RFSGPU_COLL_PROBE_DELAY_MS")) {
+    const long long ms = atoll(d);
+    if (ms > 0) coll_spin_kernel<<<1, 64, 0, side>>>(ms * 100000ll);      // (100 MHz constant clock)
+  }
+  coll_publish_kernel<<<1, 1, 0, side>>>(f->dCollSeq + 2, k);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(f->stream));
+  HIPCHK(hipStreamSynchronize(side));
+  int verdict = 0;
+  HIPCHK(hipMemcpy(&verdict, f->dCollSeq + 3, sizeof(int), hipMemcpyDeviceToHost));
+  *side_by_side = verdict == k ? 1 : 0;
   return RFSGPU_OK;
 }
 

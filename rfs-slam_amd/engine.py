@@ -99,6 +99,13 @@ class RBPHDFilter(capi.CFilter):
     def collective_publish(self, hip_stream):
         self._call("collective_publish", C.c_void_p(hip_stream))
 
+    def collective_probe(self, hip_stream):
+        """rfsgpu_collective_probe: do the engine's stream and `hip_stream` make progress side by side (what the sequence-number
+        hand-over needs)?  Synchronises both streams."""
+        ok = C.c_int(0)
+        self._call("collective_probe", C.c_void_p(hip_stream), C.byref(ok))
+        return bool(ok.value)
+
     def _opt(self, a, shape=None):
         if a is None:
             return None, C.c_void_p(None)

@@ -17,6 +17,8 @@ and device rows (two ranks sharing one GPU in the tests) the rows are staged thr
 device-to-device transport (point-to-point send/recv there); over RCCL ("nccl") nothing is staged.
 """
 import numpy as np
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -39,7 +41,7 @@ class ShardedRBPHDFilter:
     that keep candidate lists by the walk itself, level by level (predict_map / _predict_levels below).  "eager" = a child takes
     its parent's lists and FOV count at resampling time (rounds 1-2; not the reference's results)."""
 
-    def __init__(self, local, group=None, device=None, stream=None, sums=None, inheritance="reference"):
+    def __init__(self, local, group=None, device=None, stream=None, sums=None, inheritance="reference", defer_normalisation=False):
         assert inheritance in ("reference", "eager")
         self.inheritance = inheritance
         self.f = local
@@ -48,7 +50,14 @@ class ShardedRBPHDFilter:
         # has dealt with the inheritance rule: every predict must go through self.predict_map, never through self.f.predict_map)
         self._mode_before = local.get_birth_inheritance() if hasattr(local, "get_birth_inheritance") else None
         local.set_birth_inheritance(capi.INHERIT_EXTERNAL if inheritance == "reference" else capi.INHERIT_EAGER)
-        self.defer_normalisation = True    # update(): steps whose resample test is not due let the normalisation trail (update_deferred)
+        # update(): steps whose resample test is not due may let the normalisation trail by one step (update_deferred: the collective leaves
+        # the step's critical path).  OPT-IN: the trailing form multiplies before it divides -- (w L) / T against the
+        # reference's (w / T) L, include/RBPHDFilter.hpp:537-539 -- an ulp apart, so the default keeps the sharded path bit-identical
+        # to the one-handle path; hosts that want the collective off the critical path (bench.py --gpus N) pass defer_normalisation=True.
+        self.defer_normalisation = bool(defer_normalisation)
+        self.deferred_check_every = 16     # deferred steps between two looks at the device error word (nothing else waits for the GPU on that path)
+        self._deferred_since_check = 0
+        self._handover = None              # "sequence_numbers" | "events": decided by a probe at the first deferred step (all ranks agree)
         self.cand_lists_seen = False       # a candidate list has been moved / kept on SOME shard (all-reduced in predict_map)
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -124,17 +133,64 @@ class ShardedRBPHDFilter:
         weights (normalize, resample, gather_weights) first applies the pending total (flush_deferred).  Device engine only."""
         assert self.on_gpu, "the trailing normalisation is a device-path feature (the CPU stand-in normalises in place)"
         Z = np.asarray(Z, dtype=np.float64).reshape(-1, self.f.dz)
-        # (no event on the step's stream: this step's post kernel and the side stream's gate kernel meet through two device words,
-        #  rfsgpu_step_async_trailing; the event behind the collective is only waited for when the pending total is applied)
-        self.f.step_async_trailing(Z, self._tot.data_ptr(), self._pending)
+        if self._handover is None:
+            self._choose_handover()
+        if self._handover == "sequence_numbers":
+            # (no event on the step's stream: this step's post kernel and the side stream's gate kernel meet through two device words,
+            #  rfsgpu_step_async_trailing; the event behind the collective is only waited for when the pending total is applied)
+            self.f.step_async_trailing(Z, self._tot.data_ptr(), self._pending)
+        else:
+            # the fall-back where the two streams do not run side by side: an event record behind the post kernel, an event wait in
+            # front of the next one (two packets on the step's stream, ~+9 us per step with one rank)
+            self.f.step_async_deferred(Z, self._tot.data_ptr() if self._pending else None, self._ev_tot.cuda_event if self._pending else None)
+            self._ev_post.record(self.stream)
         with torch.cuda.stream(self._side):
-            self.f.collective_gate(self._side.cuda_stream)
+            if self._handover == "sequence_numbers":
+                self.f.collective_gate(self._side.cuda_stream)
+            else:
+                self._side.wait_event(self._ev_post)
             self._tot.copy_(self.sums)
             if self.world > 1:
                 dist.all_reduce(self._tot, group=self.group)
-            self.f.collective_publish(self._side.cuda_stream)
+            if self._handover == "sequence_numbers":
+                self.f.collective_publish(self._side.cuda_stream)
             self._ev_tot.record(self._side)
         self._pending = True
+        # nothing on this path waits for the GPU: look at the device error word (capacity, Murty, the hand-over's time-out) every so often
+        self._deferred_since_check += 1
+        if self._deferred_since_check >= self.deferred_check_every:
+            self._deferred_since_check = 0
+            self.f.synchronize()
+
+    def _choose_handover(self):
+        """Sequence numbers need the step's stream and the collective's stream to make progress side by side (the post kernel waits, on
+        the device, for a word a LATER submission on the side stream publishes): rfsgpu_collective_probe plays that hand-over once with
+        nothing at stake.  Every rank probes its own stream pair; the ranks must issue the same collectives, so the verdict is the
+        minimum over the ranks.  RFSGPU_SHARDED_HANDOVER=events | sequence_numbers overrides the probe."""
+        forced = os.environ.get("RFSGPU_SHARDED_HANDOVER")
+        if forced in ("events", "sequence_numbers"):
+            self._handover, self.handover_probe = forced, "forced by RFSGPU_SHARDED_HANDOVER"
+            return
+        self.stream.synchronize()
+        ok = 1 if self.f.collective_probe(self._side.cuda_stream) else 0
+        if self.world > 1:
+            t = torch.tensor([ok], dtype=torch.int64)
+            if self.backend == "nccl":
+                with self._stream_ctx():
+                    td = t.to(self.device)
+                    dist.all_reduce(td, op=dist.ReduceOp.MIN, group=self.group)
+                    t = td.cpu()
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+            ok = int(t.item())
+        self._handover = "sequence_numbers" if ok else "events"
+        self.handover_probe = "side by side" if ok else "serialised (or a rank's probe timed out): stream events"
+
+    def get_weights(self):
+        """This shard's particle weights, NORMALISED: a total left pending by a deferred step is applied first (reading the engine
+        handle directly, self.f.get_weights(), would return them undivided in the meantime)."""
+        self.flush_deferred()
+        return self.f.get_weights()
 
     def flush_deferred(self):
         """Apply the total a deferred step left pending: wait for its collective (stream-ordered), divide on the device."""

@@ -143,6 +143,32 @@ def test_unmodified_rbphdslam2dsim_over_a_group_of_shards_writes_the_same_map(tm
 
 
 @pytest.mark.gpu
+def test_lazy_predict_writes_the_files_of_the_eager_binding(tmp_path):
+    """VERDICT r5 item 2: `rfs::RBPHDFilter::predict` (include/RBPHDFilter.hpp:415-442) records its map part and the next update()
+    runs it at the head of the step kernel (rfsgpu_update_io(predict = 0 | 1)) -- unless something reads the maps in between.  The
+    unmodified 2-D driver, 600 steps (the first 100 with setParticlePose between predict and update, src/rbphdslam2dSim.cpp:590-593;
+    getGMSize / getLandmark after every update; resampling on): every log file must be the one the eager binding
+    (RFSGPU_LAZY_PREDICT=0: pose push + predict launch + wait inside predict(), rounds 3-5) writes, byte for byte; and the lazy run
+    must really have been lazy (the binding's own breakdown, RFSGPU_BINDING_PROFILE=1)."""
+    exe = _prebuilt("rbphdslam2dSim")
+    outs, errs = [], []
+    for tag, env in (("lazy", {"RFSGPU_BINDING_PROFILE": "1"}), ("eager", {"RFSGPU_LAZY_PREDICT": "0", "RFSGPU_BINDING_PROFILE": "1"})):
+        d = tmp_path / tag
+        d.mkdir()
+        cfg = _cfg_2d(d, timesteps=600)
+        p = subprocess.run([exe, "-c", cfg, "-t", "1", "-s", "1"], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr[-3000:] + p.stdout[-1000:]
+        outs.append({f: open(os.path.join(str(d), "log", f), "rb").read() for f in ("landmarkEst.dat", "particlePose.dat")})
+        errs.append(p.stderr)
+    assert len(outs[0]["landmarkEst.dat"]) > 1000
+    for f in outs[0]:
+        assert outs[0][f] == outs[1][f], f
+    assert "lazy=1" in errs[0] and "lazy=0" in errs[1], errs
+    part = [float(re.search(r"map part[^|]*\) ([0-9.]+) \|", e).group(1)) for e in errs]
+    assert part[0] < part[1], part         # recording + a pose compare against a pose push + a launch + a wait
+
+
+@pytest.mark.gpu
 def test_unmodified_rbphdslam_victoriapark_runs_on_the_device(tmp_path):
     """src/rbphdslam_VictoriaPark.cpp, unmodified (3-D model, Ackerman motion, artificial clutter, `setNoise(R, Slb)` and
     `setLaserScan` through the handle), on the first 900 messages of the dataset.  The dataset's raw laser file is not part

@@ -231,7 +231,7 @@ def test_trailing_normalisation_equals_the_step_by_step_order(pkg):
     cfg = f.get_filter_config()
     cfg.minUpdatesBeforeResample = 4
     f.set_filter_config(cfg)
-    sh = pkg.sharded.ShardedRBPHDFilter(f)
+    sh = pkg.sharded.ShardedRBPHDFilter(f, defer_normalisation=True)      # (opt-in since round 6: the default is the step-by-step order)
     sh.effNParticles_t = 1e-9                       # (never resample: the comparison is about the normalisation)
     deferred_steps = 0
     for Z in Zs:
@@ -246,6 +246,88 @@ def test_trailing_normalisation_equals_the_step_by_step_order(pkg):
             assert np.array_equal(a, b)
         assert np.array_equal(f.get_unused(i), ref.get_unused(i))
     sh.close(); f.close(); ref.close()
+
+
+def test_trailing_normalisation_falls_back_to_events_when_the_side_stream_is_late(pkg, monkeypatch):
+    """the sequence-number hand-over needs the step's stream and the collective's stream to make progress
+    side by side.  Both hosts probe that once (rfsgpu_collective_probe) before their first deferred step; here the probe's publish is
+    held back on the side stream past the probe's bounded wait (RFSGPU_COLL_PROBE_DELAY_MS, a spinning kernel), which is what two
+    streams serialised onto one hardware queue look like from the device.  ShardedRBPHDFilter and rfsgpu_group_update_deferred must
+    then take the stream-event form BY THEMSELVES and the steps must still be right: weights 1e-12 against a filter that normalises
+    step by step, maps bit for bit -- and without the delay both must use the sequence numbers.  A default-constructed
+    ShardedRBPHDFilter does not defer at all: the reference's order of operations."""
+    sc = pkg.scenarios
+    n = 32
+    scen = sc.make_scenario(n, 60, 12, seed=53, params=dict(min_updates=1))
+    scen["particle_w"] = np.random.default_rng(6).uniform(0.2, 1.0, n)
+    rng = np.random.default_rng(9)
+    Zs = [scen["Z"] + rng.normal(0, 2e-3, scen["Z"].shape) for _ in range(5)]
+    ref = pkg.RBPHDFilter(n, device_id=0, gm_capacity=256)
+    sc.load_scenario(ref, scen)
+    for Z in Zs:
+        ref.predict_map(True)
+        ref.update(Z)
+        ref.normalize_weights(ref.weight_sums()[0])
+    w_ref = ref.get_weights()
+
+    def run_sharded(defer):
+        f = pkg.RBPHDFilter(n, device_id=0, gm_capacity=256)
+        sc.load_scenario(f, scen)
+        cfg = f.get_filter_config()
+        cfg.minUpdatesBeforeResample = 4
+        f.set_filter_config(cfg)
+        sh = pkg.sharded.ShardedRBPHDFilter(f, defer_normalisation=defer)
+        sh.effNParticles_t = 1e-9
+        deferred = 0
+        for Z in Zs:
+            sh.predict_map(True)
+            sh.update(Z)
+            deferred += int(sh._pending)
+        w = sh.get_weights()                      # (applies a pending total)
+        maps = [f.export_gm(i) for i in range(n)]
+        mode = sh._handover
+        sh.close(); f.close()
+        return w, maps, deferred, mode
+
+    def run_group():
+        grp = pkg.FilterGroup(n, [0], gm_capacity=256)
+        sc.load_scenario(grp, scen)
+        for Z in Zs:
+            grp.predict_map(True)
+            grp.update_deferred(Z)
+        w = grp.get_weights()
+        maps = [grp.export_gm(i) for i in range(n)]
+        mode = grp.collective()
+        grp.close()
+        return w, maps, mode
+
+    def check(w, maps, rtol):
+        np.testing.assert_allclose(w, w_ref, rtol=rtol)
+        for i in range(n):
+            for a, b in zip(maps[i], ref.export_gm(i)):
+                assert np.array_equal(a, b)
+
+    # the ordinary case on this box: side by side -> sequence numbers
+    w, maps, deferred, mode = run_sharded(True)
+    assert deferred >= 3 and mode == "sequence_numbers", (deferred, mode)
+    check(w, maps, 1e-12)
+    w, maps, mode = run_group()
+    assert mode == "rccl; hand-over: sequence numbers", mode
+    check(w, maps, 1e-12)
+    # the side stream held back past the bounded wait: both hosts fall back to stream events, by themselves
+    monkeypatch.setenv("RFSGPU_COLL_PROBE_DELAY_MS", "350")
+    w, maps, deferred, mode = run_sharded(True)
+    assert deferred >= 3 and mode == "events", (deferred, mode)
+    check(w, maps, 1e-12)
+    w, maps, mode = run_group()
+    assert mode == "rccl; hand-over: stream events", mode
+    check(w, maps, 1e-12)
+    monkeypatch.delenv("RFSGPU_COLL_PROBE_DELAY_MS")
+    # the default: no deferral, the reference's order of operations -> the plain handle's bits
+    w, maps, deferred, mode = run_sharded(False)
+    assert deferred == 0 and mode is None
+    check(w, maps, 1e-13)                         # (w / T) L, the reference's order: the plain handle's weights to rounding of the sum
+    ref.close()
 
 
 def _worker_trailing(rank, world, port, n_total, q):
@@ -266,7 +348,7 @@ def _worker_trailing(rank, world, port, n_total, q):
     cfg = local.get_filter_config()
     cfg.minUpdatesBeforeResample = 4                     # the resample test is due on every fourth update only: the others let the normalisation trail
     local.set_filter_config(cfg)
-    sh = pkg.sharded.ShardedRBPHDFilter(local)
+    sh = pkg.sharded.ShardedRBPHDFilter(local, defer_normalisation=True)
     sh.effNParticles_t = 1e-9
     rng = np.random.default_rng(8)
     deferred = 0

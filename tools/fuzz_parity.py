@@ -23,6 +23,25 @@ n_vp = 0
 rng_aux = np.random.default_rng(12345)   # draws that must not disturb the case generator's stream
 
 
+n_degenerate = 0   # weight comparisons whose particle weights sum to 0 / inf / NaN: made on the raw weights, never through a NaN / NaN division
+
+
+def assert_weights_match(wd, wo, rtol):
+    """Normalised weights to rtol -- unless a sum is not a positive finite number (every weight 0, an overflow, a NaN): then the
+    RAW weights are compared, device and oracle must agree entry by entry on which weights are not finite, and the case is counted
+    (the quotient of weights and their sum compared NaN with NaN and passed)."""
+    global n_degenerate
+    sd, so = float(np.sum(wd)), float(np.sum(wo))
+    if np.isfinite(sd) and np.isfinite(so) and sd > 0.0 and so > 0.0:
+        np.testing.assert_allclose(wd / sd, wo / so, rtol=rtol, atol=1e-300)
+        return
+    n_degenerate += 1
+    fd, fo = np.isfinite(wd), np.isfinite(wo)
+    assert np.array_equal(fd, fo), "device and oracle disagree on which weights are finite"
+    assert np.array_equal(np.isnan(wd), np.isnan(wo)) and np.array_equal(np.isposinf(wd), np.isposinf(wo)), "non-finite weights of different kinds"
+    np.testing.assert_allclose(wd[fd], wo[fo], rtol=rtol, atol=1e-300)
+
+
 def vp_case(case):
     """Victoria Park model: 3-D landmarks, scan-based Pd with uncertain / thin landmarks (many shifted copies), birth candidates."""
     global bad, n_vp
@@ -73,7 +92,7 @@ def vp_case(case):
                     f.predict_map(True)
                     f.update(Z)
             wd, wo = dev.get_weights(), orc.get_weights()
-            np.testing.assert_allclose(wd / wd.sum(), wo / wo.sum(), rtol=1e-9, atol=1e-300)
+            assert_weights_match(wd, wo, 1e-9)
             assert np.array_equal(dev.gm_sizes(), orc.gm_sizes())
             for i in range(n):
                 sc.assert_gm_close(dev.export_gm(i), orc.export_gm(i), 1e-10, 1e-12)
@@ -149,7 +168,7 @@ for case in range(n_cases):
                 dev.update_async(Z); dev.synchronize()
                 orc.update(Z)
                 wd, wo = dev.get_weights(), orc.get_weights()
-                np.testing.assert_allclose(wd / wd.sum(), wo / wo.sum(), rtol=1e-6 if indefinite else (1e-9 if "weighting_md" not in kw else 1e-8), atol=1e-300)
+                assert_weights_match(wd, wo, 1e-6 if indefinite else (1e-9 if "weighting_md" not in kw else 1e-8))
                 assert np.array_equal(dev.gm_sizes(), orc.gm_sizes())
                 for i in range(n):
                     sc.assert_gm_close(dev.export_gm(i), orc.export_gm(i), 1e-7 if indefinite else 1e-10, 1e-9 if indefinite else 1e-12, ordered=True)
@@ -187,7 +206,7 @@ for case in range(n_cases):
                 dev.update_async(Z2); dev.synchronize()
                 orc.update(Z2)
                 wd, wo = dev.get_weights(), orc.get_weights()
-                np.testing.assert_allclose(wd / wd.sum(), wo / wo.sum(), rtol=1e-6 if indefinite else (1e-9 if "weighting_md" not in kw else 1e-8), atol=1e-300)
+                assert_weights_match(wd, wo, 1e-6 if indefinite else (1e-9 if "weighting_md" not in kw else 1e-8))
                 assert np.array_equal(dev.gm_sizes(), orc.gm_sizes())
                 for i in range(n):
                     sc.assert_gm_close(dev.export_gm(i), orc.export_gm(i), tol[0], tol[1], ordered=True)
@@ -213,5 +232,6 @@ for case in range(n_cases):
         dev.close()
     if fused == 0 and "weighting_md" in kw:
         murty += orc.murty_calls()
-print("fuzz: %d cases (2-D ones on both paths; %d Victoria Park ones), %d failures (Murty problems solved along the way: %d)" % (n_cases, n_vp, bad, murty))
+print("fuzz: %d cases (2-D ones on both paths; %d Victoria Park ones), %d failures (Murty problems solved along the way: %d); "
+      "%d weight comparisons had a zero / non-finite sum and were made on the raw weights" % (n_cases, n_vp, bad, murty, n_degenerate))
 sys.exit(1 if bad else 0)
