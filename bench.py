@@ -956,8 +956,10 @@ def main():
                          "bound_note": ("the dominant kernel of this workload is the Murty-200 assignment search (serial per partition, fp64 dependency "
                                         "chains: latency-bound, not a streaming kernel); the HBM figure is reported for the record, the quantity to "
                                         "watch is its duration.  Round 5: the ranked enumeration ends once no later term can change the sum (the same sum "
-                                        "bit for bit), eight waves per job under a 64-VGPR cap (1024 jobs resident at once) and -- built with "
-                                        "-disable-machine-licm -- no register spills: its PMC traffic is the node pool and the results (DESIGN.md section 8)") if murty_dominant else None},
+                                        "bit for bit).  Round 6: a child of an expansion is solved by ONE augmentation from its parent's dual variables instead of "
+                                        "a solve from scratch (hungarian_warm_wave; the k best scores are what the path sums), five waves per job, two peeked heap "
+                                        "positions; the search wave's own bookkeeping is what a pop costs now.  Its PMC traffic is the node pool (with a node's row "
+                                        "duals since round 6) and the results (DESIGN.md section 8)") if murty_dominant else None},
         }
         # what the run was, as FIELDS (so that a SCALE record can show that RCCL saw N distinct devices)
         out["config"]["distributed"] = dict(

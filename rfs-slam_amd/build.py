@@ -61,20 +61,20 @@ def compile_library(args, lib, verbose=False):
     return lib
 
 
-# Test support, not product: the library with the quarter-wave Hungarian solver switched on (tests/support/variants/hungarian_quad.h; measured slower than
-# the shipped one-wave solvers, DESIGN 8 -- tests/test_gpu_parity.py checks that it returns the same bits).  Built next to the
-# other test artefacts (git-ignored, travels to the GPU box).
-QUAD_LIB = os.path.join(ROOT, "tests", "support", "_build", "librfsgpu_quad.so")
-QUAD_FLAGS = ["-I" + os.path.join(ROOT, "tests", "support", "variants"), "-DMURTY_QUAD=1", "-DMURTY_JOB_WAVES=3", "-DMURTY_WAVES_PER_EU=3", "-DMURTY_HEAP_LDS=32"]   # (a 32-entry LDS heap front: the search's heap spills into the arena in the test)
+# Test support, not product: the library with every Murty child solved FROM SCRATCH by the reference-faithful solver (-DMURTY_WARM=0: what
+# rounds 1-5 shipped).  tests/test_gpu_parity.py holds the shipped library -- children started from their parent's dual variables, round 6
+# -- against it (partition sums to 1e-12) and it against the oracle.  Built next to the other test artefacts (git-ignored, travels to the
+# GPU box).
+COLD_LIB = os.path.join(ROOT, "tests", "support", "_build", "librfsgpu_coldmurty.so")
+COLD_FLAGS = ["-DMURTY_WARM=0"]
 
 
-def build_quad_variant(force=False, verbose=False):
-    vdir = os.path.join(ROOT, "tests", "support", "variants")
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(vdir, f) for f in os.listdir(vdir)] + [os.path.join(ROOT, "include", "rfsgpu.h")]
-    if not force and os.path.exists(QUAD_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(QUAD_LIB) for d in deps):
-        return QUAD_LIB
-    os.makedirs(os.path.dirname(QUAD_LIB), exist_ok=True)
-    return compile_library(QUAD_FLAGS + [os.path.join(CSRC, s) for s in SOURCES], QUAD_LIB, verbose)
+def build_cold_murty_variant(force=False, verbose=False):
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "rfsgpu.h")]
+    if not force and os.path.exists(COLD_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(COLD_LIB) for d in deps):
+        return COLD_LIB
+    os.makedirs(os.path.dirname(COLD_LIB), exist_ok=True)
+    return compile_library(COLD_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"], COLD_LIB, verbose)
 
 
 SIM = os.path.join(HERE, "host", "rbphdslam2d_sim")

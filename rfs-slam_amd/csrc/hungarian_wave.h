@@ -59,8 +59,12 @@ __device__ __forceinline__ double wave_ordered_sum(double v, int n) {
 // job's table itself): offset and greedy start run ROW-parallel -- lane x walks row x for its minimum, then for its offset-free
 // maximum and the LAST column holding it (what the reference's `>=` scan keeps) -- instead of one wave-wide max-reduction per
 // row, and the end of the solve neither re-adds the offset nor sums the cost.  Same lx, xy, yx out of the start; *cost = 0.
+// lxRaw (may be null): on success lane x < n receives the row's dual variable for the table AS GIVEN (lx + offset: with the column
+// duals the solve ends with, lx + ly >= C - offset and equality on the assignment) -- what hungarian_warm_wave below starts a
+// child's solve from.
 template <bool SCRATCH = false>
-__device__ __forceinline__ bool hungarian_wave(double *C, int ld, int n, int &xyOut, double *cost, unsigned char *queue, long long *prof = nullptr) {
+__device__ __forceinline__ bool hungarian_wave(double *C, int ld, int n, int &xyOut, double *cost, unsigned char *queue, long long *prof = nullptr,
+                                               double *lxRaw = nullptr) {
   const int lane = threadIdx.x & 63;
   const bool in = lane < n;
   double *Ccol = C + lane;           // column `lane`
@@ -149,6 +153,7 @@ __device__ __forceinline__ bool hungarian_wave(double *C, int ld, int n, int &xy
       S = false; T = false; NS = false;
       const unsigned long long fr = __ballot(in && xy == -1);
       if (fr == 0) {
+        if (lxRaw) *lxRaw = lx + offset;
         if constexpr (SCRATCH) {
           *cost = 0;
           xyOut = xy;
@@ -265,6 +270,67 @@ __device__ __forceinline__ bool hungarian_wave(double *C, int ld, int n, int &xy
         if (d < slack) slack = d;
       }
       pickFreeVertex = false;
+    }
+  }
+  return false;
+}
+
+// ---- one augmentation from the parent's dual variables (round 6) -------------------------------------------------------------
+// A child of a Murty expansion is its parent's sub-problem with rows dropped (they stay with the parent's columns) and a few cells
+// of its FIRST row forbidden (the parent's own choice there, plus what the chain of ancestors created at the same row forbids).
+// The parent's optimal assignment restricted to the child's rows is therefore a matching that misses exactly row 0, and the
+// parent's dual variables, restricted likewise, are still feasible for the child (lowering cells keeps lx + ly >= C): ONE shortest
+// augmenting path from row 0 -- the Hungarian method's last phase -- ends at the child's optimum.  A solve from scratch runs ~25
+// dependent trips of ~200 instructions at dimension 15; this one runs as many trips as the path has rows (one to a
+// handful) of ~60.
+// What it returns is AN optimal assignment of the child's table.  Where several are optimal to within the arithmetic (rounding of
+// the duals: a few 1e-16 of the cell magnitude per update) it need not be the one the reference's solver would pick; the k-best
+// SCORES, which is all rfsMeasurementLikelihood sums (include/RBPHDFilter.hpp:948-959), do not depend on that choice, the ranked
+// ASSIGNMENTS of the FastSLAM path would -- so only the RB-PHD partition sums use it (murty.h, WARM), everything else keeps
+// hungarian_wave.
+// Reduced indices throughout: row r / column y of the child's table Ct (leading dimension ld, n <= 64 rows and columns), lane r
+// holds row r's state, lane y column y's.  In: lxIn (row duals; row 0's is the parent's dual of that row), xyIn (column of row r in
+// the parent's matching, -1 for row 0), lyIn / yxIn (column duals -- C[parent's row][y] - lx of that row, computed by the caller
+// from the UNCONSTRAINED table -- and the matched row, -1 for the one free column).  Out: xyOut, lxOut.  False if no augmenting path
+// is found within n trips (NaN cells): the caller falls back to hungarian_wave.  Ct is only read.
+__device__ __forceinline__ bool hungarian_warm_wave(const double *Ct, int ld, int n, double lxIn, int xyIn, double lyIn, int yxIn, int &xyOut, double &lxOut) {
+  const int lane = threadIdx.x & 63;
+  const bool in = lane < n;
+  const double INF = 1.7976931348623157e308;
+  double lx = lxIn, ly = lyIn;
+  int xy = xyIn, yx = yxIn;
+  bool S = (lane == 0), T = false;
+  int from = 0;                                    // row through which column `lane` got its present slack
+  double slack = in ? (readlane_f64(lx, 0) + ly - Ct[lane]) : INF;
+  for (int trip = 0; trip < n; trip++) {
+    const double d = wave_min_f64((in && !T) ? slack : INF);
+    const unsigned long long at = __ballot(in && !T && slack == d);
+    if (at == 0ull) return false;                  // (NaN slacks)
+    const int y = __builtin_ctzll(at);
+    // dual update: rows of the tree down, its columns up, the others' slacks down -- slack[y] becomes 0
+    if (S) lx -= d;
+    if (T) ly += d; else slack -= d;
+    const int x = __builtin_amdgcn_readlane(yx, y);
+    if (x < 0) {                                   // a free column: flip the path y <- from[y] <- (its old column) <- ...
+      int yy = y;
+      for (int g = 0; g <= n; g++) {
+        const int xx = __builtin_amdgcn_readlane(from, yy);
+        const int yPrev = __builtin_amdgcn_readlane(xy, xx);
+        if (lane == xx) xy = yy;
+        if (lane == yy) yx = xx;
+        if (xx == 0) break;
+        yy = yPrev;
+      }
+      xyOut = xy;
+      lxOut = lx;
+      return true;
+    }
+    if (lane == y) T = true;
+    if (lane == x) S = true;
+    const double lxx = readlane_f64(lx, x);
+    if (in && !T) {
+      const double s2 = lxx + ly - Ct[x * ld + lane];
+      if (s2 < slack) { slack = s2; from = x; }
     }
   }
   return false;

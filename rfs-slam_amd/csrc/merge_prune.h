@@ -29,6 +29,9 @@
 __host__ __device__ constexpr int merge_cells(int gridLog) { return 1 << (2 * gridLog); }
 #define MERGE_PAIR_CAP(cap) ((cap) > 320 ? (cap) : 320)  // listed partners per particle: ~0.7 per entry on dense maps
 #define MERGE_ROW_SLOTS 8   // prefilter survivors one row can list; a row with more is replayed by the sequential scan
+#ifndef MERGE_SCAN_SHIFTED_RADIUS
+#define MERGE_SCAN_SHIFTED_RADIUS 1   // r06: the scan's rounding allowance is folded into the LDS radius once per entry (see the grid scatter)
+#endif
 // (Measured and dropped, r04 -- profiles/r04a_ab_merge_stage.txt: phase 1b leaving the replay's operands -- mean and covariance of
 //  every passing partner and of its row -- in LDS, so that the one wave that replays reads LDS instead of dependent global loads:
 //  fused step 125.2 -> 126.5 us at configs[1].  The loads the replay waits for are L2 hits issued together; the staging's stores
@@ -268,6 +271,17 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     const int e = cy * MERGE_GX + cx + 1;
     const unsigned pos = (atomicAdd(&sCellStart[e >> 1], 1u << (16 * (e & 1))) >> (16 * (e & 1))) & 0xffffu;
     sSorted[pos] = (unsigned short)m;
+#if MERGE_SCAN_SHIFTED_RADIUS
+    // Round 6: from here on sRad holds the prefilter radius WITH the fp32 rounding bound of a coordinate difference added
+    // (r + 1.5 errAbs): the candidate scan's per-neighbour threshold is then max(r_a', r_j')^2 (1 + 1e-5) -- the value it used to
+    // form from the two radii per neighbour (the shift is monotone, so the maximum commutes with it: the same fp32 number), three
+    // vector instructions instead of six.  Every later reader wants an upper bound of the radius (the sequential scan's bound) or
+    // takes the shift back out (the walk's rPass); the sign stays the liveness flag.
+    {
+      const float r2 = sRad[m] + 1.5f * errAbs;
+      sRad[m] = (r2 == 1.0f) ? 1.0000001f : r2;   // (-1.f stays the mark of an entry that arrived absorbed, see the stage)
+    }
+#endif
   }
   if (tid == 0) *sPairCount = 0u;
   block_sync();
@@ -288,17 +302,21 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
 #ifndef MERGE_SCAN_GRID_ORDER
 #define MERGE_SCAN_GRID_ORDER 1   // r04, profiles/r04d_ab_scan_grid_order.txt: fused step 124.0 -> 121.2-121.9 us at configs[1]
 #endif
+#ifndef MERGE_SCAN_PACK_ALIGNBIT
+#define MERGE_SCAN_PACK_ALIGNBIT 1   // r06: a row's survivors in a four-register shift chain (v_alignbit) instead of variable 64-bit shifts + selects
+#endif
   const int nLive = MERGE_SCAN_GRID_ORDER ? (int)cell_at(MERGE_CELLS) : N;     // (entries in the grid = the live ones)
   for (int t0 = tid, sidx = 0; t0 < nLive; t0 += NT, sidx++) {
     // MERGE_SCAN_GRID_ORDER: the threads take the entries in GRID order, so that the lanes of a wave work on neighbouring cells --
     // similar neighbour counts (the trips of four last as long as the busiest lane's), the same LDS words
     const int m = MERGE_SCAN_GRID_ORDER ? (int)sSorted[t0] : t0;
     if (!MERGE_SCAN_GRID_ORDER && ((hole >> sidx) & 1u)) continue;
-    const float ax = sX[m], ay = sY[m], ar = sRad[m];
+    const float ax = sX[m], ay = sY[m], ar = sRad[m];   // (MERGE_SCAN_SHIFTED_RADIUS: ar, jr carry + 1.5 errAbs already)
     int cx, cy;
     cell_of(ax, ay, cx, cy);
     const int cxa = cx > 0 ? cx - 1 : 0, cxb = cx < gxe - 1 ? cx + 1 : gxe - 1;
     unsigned long long buf0 = 0ull, buf1 = 0ull;  // up to 8 survivors, 16 bits each
+    unsigned sb0 = 0u, sb1 = 0u, sb2 = 0u, sb3 = 0u;   // MERGE_SCAN_PACK_ALIGNBIT: the same eight fields as a shift chain, newest in sb0's low half
     int nP = 0;
     float farE2 = 3.0e38f;   // nearest neighbour that fails the prefilter by a factor >= 2 in distance
     // the three cell rows are three contiguous ranges of the sorted list; they are walked as ONE sequence (same order as
@@ -330,7 +348,12 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
         for (int k = 0; k < 4; k++) {
           const float e0 = jx[k] - ax, e1 = jy[k] - ay;
           const float e2 = e0 * e0 + e1 * e1;
+#if MERGE_SCAN_SHIFTED_RADIUS
+          float thr;                                                 // max(ar, jr) of two radii that are numbers (or +inf): the raw instruction, no canonicalising pre-pass
+          asm("v_max_f32 %0, %1, %2" : "=v"(thr) : "v"(ar), "v"(jr[k]));
+#else
           const float thr = fmaxf(ar, jr[k]) + 1.5f * errAbs;       // exact |e| <= exact radius  =>  fp32 |e| <= thr (+ ulps)
+#endif
           const float T = thr * thr * (1.f + 1e-5f);
           // higher index only (the entry plays `a`); NaN distances fall through to the exact test like the reference
           const bool cand = (q + k < tot) & (jj[k] > (unsigned)m);
@@ -341,8 +364,17 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
           const bool farFail = cand & !c & !reserve;
           farE2 = farFail ? fminf(farE2, e2) : farE2;  // exact distance - exact radius >= sqrt(e2) / 2 for these
           if (c | reserve) {
+#if MERGE_SCAN_PACK_ALIGNBIT
+            // (the order of a row's segment is free: every reader takes the lowest index first; fields pushed out of the top belong
+            //  to a row with more than eight survivors, which is not listed at all)
+            sb3 = __builtin_amdgcn_alignbit(sb3, sb2, 16);
+            sb2 = __builtin_amdgcn_alignbit(sb2, sb1, 16);
+            sb1 = __builtin_amdgcn_alignbit(sb1, sb0, 16);
+            sb0 = (sb0 << 16) | (jj[k] | (reserve ? 0x4000u : 0u));
+#else
             const unsigned long long v = (unsigned long long)(jj[k] | (reserve ? 0x4000u : 0u)) << (16 * (nP & 3));
             if (nP < 4) buf0 |= v; else if (nP < 8) buf1 |= v;
+#endif
             nP++;
           }
         }
@@ -357,10 +389,18 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
         listed = base + (unsigned)nP <= (unsigned)pairCap;
       }
       if (listed) {
+#if MERGE_SCAN_PACK_ALIGNBIT
+        const unsigned hi = (unsigned)m << 16;
+        const unsigned fl[MERGE_ROW_SLOTS] = {sb0 & 0xffffu, sb0 >> 16, sb1 & 0xffffu, sb1 >> 16, sb2 & 0xffffu, sb2 >> 16, sb3 & 0xffffu, sb3 >> 16};
+#pragma unroll
+        for (int k = 0; k < MERGE_ROW_SLOTS; k++)
+          if (k < nP) sPairs[base + k] = hi | fl[k];                                              // index | reserve flag
+#else
         for (int k = 0; k < nP; k++) {
           const unsigned j = (unsigned)(((k < 4 ? buf0 : buf1) >> (16 * (k & 3))) & 0xffffull);  // index | reserve flag
           sPairs[base + k] = ((unsigned)m << 16) | j;
         }
+#endif
         rec |= ((unsigned)nP << 20) | base;
       } else {
         rec |= MERGE_REC_ISROW | (15u << 20);  // too crowded to list: the sequential scan handles this row
@@ -487,7 +527,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
         pj = phys(j);
         jx = pMX[pj]; jy = pMY[pj]; jw = sW[j];
         const float r = sRad[j];
-        jb = (r < 0.f) ? -1.0 : (double)r * (double)r * (1.0 + 1e-5);   // >= the entry's exact bound
+        jb = (r < 0.f) ? -1.0 : (double)r * (double)r * (1.0 + 1e-5);   // >= the entry's exact bound (a shifted radius is only larger)
       }
       bool live = !(jb < 0.0);
       while (true) {
@@ -532,9 +572,14 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
   };
 
 #ifndef MERGE_COMPONENT_REPLAY
-#define MERGE_COMPONENT_REPLAY 1
+#define MERGE_COMPONENT_REPLAY 0   // measured and dropped, round 6 (profiles/r06b_ab_component_replay.txt): exact, and 19 % slower -- see below
 #endif
-  // ---- Round 6: replay by CONNECTED COMPONENTS of the listed-pair graph, one component per lane, no speculation ----
+  // ---- Round 6, MEASURED AND DROPPED (opt-in: -DMERGE_COMPONENT_REPLAY=1; profiles/r06b_*): replay by CONNECTED COMPONENTS of the
+  // listed-pair graph, one component per lane, no speculation.  Exact (the full GPU suite and 1500 fuzz cases pass with it), but the
+  // fused step at configs[1] takes 137.3 us with it against 115.0: the components are small (12-25 per particle, the largest 4-7 rows,
+  // tools/merge_components_study.py) but the label propagation needs ~4 trips over the pair list (7.8 k cycles) and the busiest lane
+  // walks 3 rows one after the other (28 k cycles) where the speculative pass below walks all rows at once (15 k) and validates in
+  // 11 k -- the kernel's time follows the wave-instructions it issues, and this form issues more of them. ----
   // What one row's replay depends on beside its own initial state: whether the row itself and its listed partners are still alive,
   // i.e. what EARLIER rows absorbed.  Rows interact only through a listed pair (a row absorbs another row, or two rows list the same
   // partner) -- so the rows of different connected components of the graph {(row, listed partner) : row has a passing partner}
@@ -568,9 +613,13 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
           if (la != lj) { const unsigned mn = min(la, lj); atomicMin(&sLab[ea], mn); atomicMin(&sLab[ej], mn); ch = true; }
         }
         wave_sync();
+#ifdef RFS_PROFILE
+        if (B.dbg && i == 7 && lane == 0) B.dbg[46] = iter + 1;
+#endif
         if (__ballot(ch) == 0ull) { usable = true; break; }
       }
     }
+    DBG_TB(32, 12);
     if (usable) {
       double *bk = B.slab[dst];    // backup of the rows that merge (their initial w, mean, covariance), at their own slab positions
       bool ovfAny = false, merged = false;
@@ -586,7 +635,13 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
           if (lane == k) mine = mk;
           todo &= ~mk;
         }
+#ifdef RFS_PROFILE
+        int dbgTrips = 0;
+#endif
         while (mine) {
+#ifdef RFS_PROFILE
+          dbgTrips++;
+#endif
           // next row of the component that is still alive
           int a = -1;
           while (mine) {
@@ -612,7 +667,8 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
           double ax = pMX[pa], ay = pMY[pa], aw = sW[a];
           double axx = pSXX[pa], axy = pSXY[pa], ayy = pSYY[pa];
           const float slack = __uint_as_float((unsigned)sSlack[a] << 16);
-          const float rPass = sRad[a] * (1.f - 1e-5f);     // <= the row's exact initial radius
+          const float rPass = MERGE_SCAN_SHIFTED_RADIUS ? ((sRad[a] - 1.5f * errAbs) - 1.2e-7f * sRad[a]) * (1.f - 1e-5f)   // (the shift taken back out, less the two roundings it cost)
+                                                       : sRad[a] * (1.f - 1e-5f);     // <= the row's exact initial radius
           float shift = 0.f;
           bool changed = false, ovf = false;
           double a00 = 0, a01 = 0, a11 = 0;
@@ -682,8 +738,12 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
           if (ovf) { ovfAny = true; break; }
         }
         wave_sync();     // a component that continues in the next chunk of rows may change lanes
+#ifdef RFS_PROFILE
+        if (B.dbg && i == 7) { const int mt = (int)wave_max_u32((unsigned)dbgTrips); if (lane == 0) B.dbg[47] = mt; }
+#endif
         if (__ballot(ovfAny) != 0ull) break;
       }
+      DBG_TB(32, 13);
       if (__ballot(ovfAny) == 0ull) {
         compDone = true;
         anyMerge = __ballot(merged) != 0ull;
@@ -745,7 +805,8 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
         ax = pMX[pa]; ay = pMY[pa]; aw = sW[a];
         axx = pSXX[pa]; axy = pSXY[pa]; ayy = pSYY[pa];
         const float slack = __uint_as_float((unsigned)sSlack[a] << 16);
-        const float rPass = sRad[a] * (1.f - 1e-5f);     // <= the row's exact initial radius
+        const float rPass = MERGE_SCAN_SHIFTED_RADIUS ? ((sRad[a] - 1.5f * errAbs) - 1.2e-7f * sRad[a]) * (1.f - 1e-5f)   // (the shift taken back out, less the two roundings it cost)
+                                                       : sRad[a] * (1.f - 1e-5f);     // <= the row's exact initial radius
         float shift = 0.f;
         bool changed = false;
         double a00 = 0, a01 = 0, a11 = 0;

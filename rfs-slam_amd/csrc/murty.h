@@ -20,14 +20,24 @@
 #define MURTY_N 64             /* max extended dimension nR + nC handled on the device */
 #define MURTY_KBEST 200
 #define MURTY_MAX_NODES 6401   /* 1 root + <= 200 expansions x <= 32 children */
+#define MURTY_WARM_N 16        /* jobs up to this extended dimension (the small form) keep their nodes' dual variables */
+#ifndef MURTY_WARM
+#define MURTY_WARM 1           /* children of the RB-PHD partition sums start from their parent's duals: one augmentation instead of a solve (hungarian_wave.h) */
+#endif
 #ifndef MURTY_JOB_WAVES
 // measured at configs[4] (1918 jobs of dimension 9-15), barrier form: 1 wave 26.8 ms, 2: 16.5, 3: 15.4, 4: 15.1; search wave + solvers
 // (murty_kbest_async) at the compiler's 92 VGPRs (5 waves per SIMD): 3: 8.9, 4: 6.3, 5: 7.8, 6: 8.9, 8: 8.4; capped at 64 VGPRs
 // (MURTY_WAVES_PER_EU 8: 100 B of scratch per lane, 1280 six-wave workgroups on the GPU at once): 4: 6.6, 5: 5.7, 6: 5.5, 7: 8.6, 8: 5.6
-#define MURTY_JOB_WAVES 8   // (round 5, after the early end of the loop made the jobs 2.5x shorter: 6: 2.96 ms, 8: 2.50, 10: 3.1, 12: 5.3; with 16 table slots and three peeked heap positions 8: 2.25)
+#define MURTY_JOB_WAVES 5   // round 6, children solved by ONE augmentation from their parent's duals (MURTY_WARM): the search wave's own bookkeeping is what a pop
+                            // costs now, and solver waves that mostly poll their mailboxes only take issue slots from it -- configs[4], kernel ms (profiles/r06d_*):
+                            // 8 waves 1.80 (2.10 with the solves from scratch), 6: 1.73, 5: 1.61, 4: 1.52; with two peeked heap positions instead of five 4: 1.43,
+                            // 5: 1.35, 6: 1.39.  (round 5, solves from scratch: 6: 2.96 ms, 8: 2.50, 10: 3.1, 12: 5.3; 16 table slots + peeks: 8: 2.16)
 #endif
 #define MURTY_CT_WAVES (MURTY_JOB_WAVES > 4 ? MURTY_JOB_WAVES : 4)   /* (the multi-hypothesis FastSLAM search uses up to four waves on the same arena) */
 
+#if defined(MURTY_WARM_CHECK)
+__device__ unsigned long long g_murtyWarmChecks = 0ull, g_murtyWarmBad = 0ull;
+#endif
 struct MurtyScratch {
   unsigned char *arena;   // [nArenas][jobBytes]: scratch that is live only while a workgroup works on a job -> one per WORKGROUP
   size_t jobBytes;
@@ -45,7 +55,8 @@ struct MurtyArena {
   unsigned char *nodeId;   // [MAX_NODES]
   unsigned char *nodeA;    // [MAX_NODES][N]
   short *heap;             // [MAX_NODES]
-  unsigned short *nodeExcl;   // [MAX_NODES] (quad search, n <= 16): the columns child 0 of the node must not take in its first row
+  unsigned short *nodeExcl;   // [MAX_NODES] (small form, n <= 16): the columns child 0 of the node must not take in its first row
+  double *nodeLx;             // [MAX_NODES][MURTY_WARM_N] (small form, round 6): the node's row duals for the job's table -- where its children's solves start (hungarian_warm_wave)
 };
 
 __host__ __device__ inline size_t murty_job_bytes() {
@@ -60,6 +71,7 @@ __host__ __device__ inline size_t murty_job_bytes() {
   b += (size_t)MURTY_MAX_NODES * MURTY_N;  // assignments
   b += (size_t)MURTY_MAX_NODES * 2;        // heap
   b += (size_t)MURTY_MAX_NODES * 2 + 2;    // nodeExcl
+  b += (size_t)MURTY_MAX_NODES * MURTY_WARM_N * 8 + 8;   // nodeLx
   return (b + 63) & ~(size_t)63;
 }
 
@@ -84,6 +96,7 @@ __device__ inline void murty_carve(unsigned char *base, MurtyArena &A) {
   A.nodeId = p; p += MURTY_MAX_NODES;
   A.nodeA = p; p += (size_t)MURTY_MAX_NODES * MURTY_N;
   A.nodeExcl = (unsigned short *)(((size_t)p + 1) & ~(size_t)1);
+  A.nodeLx = (double *)(((size_t)(A.nodeExcl + MURTY_MAX_NODES) + 7) & ~(size_t)7);
 }
 
 // std::priority_queue<MurtyNode*, vector, MurtyNodeCompare> == libstdc++ push_heap / pop_heap on scores.
@@ -206,10 +219,12 @@ __device__ __forceinline__ void murty_publish() {  // stores of one lane -> load
 // has curPart == nn), so they are a set of job columns: `excl`.  Lane dj of the walk = the lane whose free column is the
 // excluded one (an excluded column is never one of the child's fixed columns: it is an ancestor's choice for row nn, and the
 // ancestor shares the child's rows 0..nn-1).
-template <int LDT, bool MASK = false>
+// WARM (round 6; the RB-PHD partition sums of the small form): aPar / lxPar = the parent's assignment and row duals, job row r on lane
+// r.  The child's solve is ONE augmentation from them (hungarian_warm_wave); lxNew (reduced row r on lane r) = the child's own duals.
+template <int LDT, bool MASK = false, bool WARM = false>
 __device__ __forceinline__ bool murty_child_wave(double *Ct, const double *C, int n, int nn, int nFree, int pn, int parent, int colRemap,
                                                  unsigned long long freeCols, int realNC, MurtyArena &A, int &aTmp, unsigned char *queue,
-                                                 long long *prof, const unsigned excl = 0u) {
+                                                 long long *prof, const unsigned excl = 0u, const int aPar = 0, const double lxPar = 0.0, double *lxNew = nullptr) {
   const double bigNumber = 10000.0;
   const int lane = threadIdx.x & 63;
   if (lane < nFree) {
@@ -239,7 +254,52 @@ __device__ __forceinline__ bool murty_child_wave(double *Ct, const double *C, in
 #ifdef RFS_PROFILE
   const long long tH = (long long)__builtin_readcyclecounter();
 #endif
-  const bool okH = hungarian_wave<true>(Ct, LDT, nFree, aTmp, &s, queue, prof);
+  if constexpr (WARM) {
+    // the parent's matching and duals in the child's reduced indices
+    const bool inr = lane < nFree;
+    const int jr = inr ? nn + lane : 0;                                  // job row of reduced row `lane`
+    const double lxr = __shfl(lxPar, jr, 64);
+    const int jcOfRow = __shfl(aPar, jr, 64);                            // the parent's column of that row (a free column: the row is not fixed)
+    const int xyIn = (inr && lane > 0) ? __popcll(freeCols & ((1ull << jcOfRow) - 1ull)) : -1;
+    // column side: the row the parent gave the job column to (the inverse of aPar, by a forward permute), its dual from tightness
+    const int invA = __builtin_amdgcn_ds_permute(((lane < n) ? aPar : lane) << 2, lane);   // lane c: the row r with aPar[r] == c
+    const int rowOfCol = __shfl(invA, inr ? colRemap : 0, 64);
+    const double lxOfCol = __shfl(lxPar, rowOfCol, 64);
+    const double lyIn = inr ? C[rowOfCol * n + colRemap] - lxOfCol : 0.0;  // (the UNCONSTRAINED cell: the parent's edge was tight)
+    const int yxIn = (inr && rowOfCol > nn) ? rowOfCol - nn : -1;        // the column row nn held is the free one
+    int aW = 0;
+    double lxW = 0.0;
+    bool okW = hungarian_warm_wave(Ct, LDT, nFree, lxr, xyIn, lyIn, yxIn, aW, lxW);
+#if defined(MURTY_WARM_CHECK)
+    {   // test builds (tools/murty_warm_check.py): the augmentation's assignment must be worth what the solve from scratch finds
+      int aC = 0;
+      double dummy = 0;
+      const bool okC = hungarian_wave<true>(Ct, LDT, nFree, aC, &dummy, queue, nullptr);
+      // (that solver has taken its offset out of the tile -- every cell moved by the same amount: both assignments are priced on the tile as it is now)
+      const double tw = (okW && inr) ? Ct[lane * LDT + aW] : 0.0, tc = (okC && inr) ? Ct[lane * LDT + aC] : 0.0;
+      double cw = 0, cc = 0;
+      for (int r = 0; r < nFree; r++) { cw += readlane_f64(tw, r); cc += readlane_f64(tc, r); }
+      if (lane == 0) {
+        atomicAdd(&g_murtyWarmChecks, 1ull);
+        if (okW != okC || fabs(cw - cc) > 1e-9 * (1.0 + fabs(cc))) {
+          if (atomicAdd(&g_murtyWarmBad, 1ull) < 8ull) printf("MURTY WARM MISMATCH n %d nn %d nFree %d: warm %d %.17g, from scratch %d %.17g\n", n, nn, nFree, (int)okW, cw, (int)okC, cc);
+        }
+      }
+    }
+#endif
+    if (okW) {
+      aTmp = aW;
+      if (lxNew) *lxNew = lxW;
+#ifdef RFS_PROFILE
+      if (prof) { prof[1] += (long long)__builtin_readcyclecounter() - tH; prof[2]++; }
+#endif
+      return true;
+    }
+    // (no path within nFree trips -- NaN cells: the solve from scratch decides, as before)
+  }
+  double lxCold = 0.0;
+  const bool okH = hungarian_wave<true>(Ct, LDT, nFree, aTmp, &s, queue, prof, WARM ? &lxCold : nullptr);
+  if (WARM && lxNew) *lxNew = lxCold;
 #ifdef RFS_PROFILE
   if (prof) { prof[1] += (long long)__builtin_readcyclecounter() - tH; prof[2]++; }
 #endif
@@ -247,9 +307,9 @@ __device__ __forceinline__ bool murty_child_wave(double *Ct, const double *C, in
 }
 
 // root: the solver on the full table (:147-158); node 0.  False when there is no assignment.
-__device__ __forceinline__ bool murty_root_wave(double *C, int n, MurtyArena &A, int &a0, double &s, unsigned char *queue) {
+__device__ __forceinline__ bool murty_root_wave(double *C, int n, MurtyArena &A, int &a0, double &s, unsigned char *queue, double *lxRaw = nullptr) {
   const int lane = threadIdx.x & 63;
-  if (!hungarian_wave(C, n, n, a0, &s, queue)) return false;
+  if (!hungarian_wave(C, n, n, a0, &s, queue, nullptr, lxRaw)) return false;
   if (lane < n) A.nodeA[lane] = (unsigned char)a0;
   if (lane == 0) {
     A.nodeId[0] = 0;
@@ -273,10 +333,12 @@ __device__ __forceinline__ bool murty_root_wave(double *C, int n, MurtyArena &A,
 // (Measured and dropped, r04 -- profiles/r04f_ab_murty_solver_as_call.txt: this body as a real call (__noinline__), so that the solver
 //  waves' path would get a register allocation of its own under the 64-VGPR cap: 360 B of stack per lane instead of 160 B of
 //  spills, configs[4] 5.18 -> 8.5 ms per update.)
-template <int LDSN, bool MASK = false>
+// WARM: lxPar = the parent's row duals (job row r on lane r); lxNew (may be null) receives the child's, in the same indexing.
+template <int LDSN, bool MASK = false, bool WARM = false>
 __device__ __forceinline__ void murty_solve_child(double *myTile, const double *C, const int n, const int realNC, MurtyArena &A, const int wave, const int par,
                                                   const int ppar, const int c, const int pn, const int aPar, const double termPar, bool &pushed,
-                                                  double &sAcc, int &aNew, long long *prof, const unsigned exclNode = 0u) {
+                                                  double &sAcc, int &aNew, long long *prof, const unsigned exclNode = 0u, const double lxPar = 0.0,
+                                                  double *lxNew = nullptr) {
   const int lane = threadIdx.x & 63;
   const int nn = ppar + c;
   double fixedScore = 0;
@@ -291,9 +353,16 @@ __device__ __forceinline__ void murty_solve_child(double *myTile, const double *
   int aTmp = 0;
   unsigned excl = 0u;
   if constexpr (MASK) excl = (c == 0) ? exclNode : (1u << __builtin_amdgcn_readlane(aPar, nn));
+  double lxRed = 0.0;     // the child's row duals, reduced row r on lane r
   const bool okH = (nFree <= LDSN)
-                       ? murty_child_wave<LDSN, MASK>(myTile, C, n, nn, nFree, pn, par, colRemap, freeCols, realNC, A, aTmp, nullptr, prof, excl)
-                       : murty_child_wave<MURTY_N, MASK>(A.Ct + (size_t)wave * MURTY_N * MURTY_N, C, n, nn, nFree, pn, par, colRemap, freeCols, realNC, A, aTmp, nullptr, prof, excl);
+                       ? murty_child_wave<LDSN, MASK, WARM>(myTile, C, n, nn, nFree, pn, par, colRemap, freeCols, realNC, A, aTmp, nullptr, prof, excl, aPar, lxPar, &lxRed)
+                       : murty_child_wave<MURTY_N, MASK, WARM>(A.Ct + (size_t)wave * MURTY_N * MURTY_N, C, n, nn, nFree, pn, par, colRemap, freeCols, realNC, A, aTmp, nullptr, prof, excl, aPar, lxPar, &lxRed);
+  if constexpr (WARM) {
+    if (lxNew) {   // back to job rows: rows nn .. n-1 are the child's, the fixed rows keep the parent's values (nothing reads them again)
+      const double sh = __shfl(lxRed, (lane >= nn) ? lane - nn : 0, 64);
+      *lxNew = (lane >= nn && lane < n) ? sh : lxPar;
+    }
+  }
   if (okH) {
     const int ja = __shfl((lane < nFree) ? colRemap : 0, (lane < nFree) ? aTmp : 0, 64);
     const double term = (lane < nFree) ? C[(nn + lane) * n + ja] : 0.0;
@@ -416,9 +485,7 @@ __device__ __forceinline__ void murty_kbest_block(double *C, int n, int partitio
 // pushes and pops are exactly the serial ones: the table only replaces a solve by its own result.  No workgroup barrier inside
 // the search -- flags in LDS (release / acquire at workgroup scope); wave 0 never waits for anything but a solve in flight, the
 // solvers for nothing but a task or the end, so there is no cycle to wait in.
-#ifndef MURTY_QUAD
-#define MURTY_QUAD 0           // 1: jobs of extended dimension <= 16 get solver waves of four 16-lane solvers each (hungarian_quad.h) -- bit-identical, measured slower, opt-in
-#endif
+
 #ifndef MURTY_SPEC_SLOTS
 #define MURTY_SPEC_SLOTS 16
 #endif
@@ -429,9 +496,9 @@ __device__ __forceinline__ void murty_kbest_block(double *C, int n, int partitio
 #define MURTY_SEARCH_SLEEP 2
 #endif
 #ifndef MURTY_PEEK
-#define MURTY_PEEK 5   // heap positions whose children are solved ahead of their pop when solvers are free (round 5, eight waves per job, 16 table slots: 2: 2.33 ms, 3: 2.25, 5: 2.16, 7: 2.49)
+#define MURTY_PEEK 2   // heap positions whose children are solved ahead of their pop when solvers are free (round 6, five waves per job, warm solves: 1: 1.50 ms (4 waves), 2: 1.35, 3: 1.38; round 5, eight waves, solves from scratch: 2: 2.33 ms, 3: 2.25, 5: 2.16, 7: 2.49)
 #endif
-#define MURTY_VSOLVERS (MURTY_QUAD ? 4 * (MURTY_CT_WAVES - 1) : (MURTY_CT_WAVES - 1))   /* mailboxes 1..MURTY_VSOLVERS */
+#define MURTY_VSOLVERS (MURTY_CT_WAVES - 1)   /* mailboxes 1..MURTY_VSOLVERS */
 struct MurtySpec {
   double score[MURTY_SPEC_SLOTS];
   int ready[MURTY_SPEC_SLOTS];           // slot payload complete (solver: 1; wave 0 clears it when it hands the slot out)
@@ -442,34 +509,30 @@ struct MurtySpec {
   int peekNode[8], peekPart[8];
   unsigned char pushed[MURTY_SPEC_SLOTS];
   unsigned char a[MURTY_SPEC_SLOTS][MURTY_N];
+  double lx[MURTY_SPEC_SLOTS][MURTY_WARM_N];   // (small form, MURTY_WARM) the solved child's row duals, until its node has a number
 };
 __device__ __forceinline__ int murty_flag_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void murty_flag_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-// ---- quarter-wave solver variant (-DMURTY_QUAD=1): test support, lives in tests/support/variants/ -- not in the shipped library ----
-#if MURTY_QUAD
-#include "murty_quad_solver.h"
-#else
 #define HQ_N 16                 // the small form's LDS table (murty_kbest_async<..., SMALL>) keeps this leading dimension
-struct HQScratch;               // (only pointers to it -- always null -- exist in the shipped build)
-__device__ void murty_quad_solver_wave(const double *C, const int n, const int realNC, MurtyArena &A, const int wave, MurtySpec *spec,
-                                       HQScratch *quadScratch, double *sC);   // never instantiated: `if constexpr (QUAD)` below is false
-#endif
 
-// QUAD: the job's extended dimension is <= 16 and the solver waves run murty_quad_solver_wave (NS = 4 (W - 1) mailboxes);
-// otherwise one mailbox per solver wave (hungarian_wave, any dimension up to MURTY_N).  The search is the same either way.
+// One mailbox per solver wave.  (A quarter-wave solver variant -- four 16-lane Hungarian solvers per wave, rounds 2-5, test support --
+// was bit-identical and slower; it is gone with round 6, when the children's solves became single augmentations.)
 // SMALL (extended dimension <= 16): the job's table is read from a copy in LDS (`sC`, taken after the root's solve, which
 // rewrites the table in place) and the children's negative constraints come from the per-node sets (`nodeExcl`) instead of the
 // walk over the partition chain -- a child's set-up then waits for ONE round of global loads (the node's row, its partition
 // index, its set) instead of three to five dependent ones.
-template <int W, int LDSN, bool QUAD, bool SMALL, class FRoot, class FTop>
+template <int W, int LDSN, bool SMALL, class FRoot, class FTop>
 __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitionMax, int realNC, int maxNodes, int maxK, MurtyArena &A, bool &ok,
                                                   double *myTile, int *ctl, double *sScore, unsigned char *sPushed, const int wave, MurtySpec *spec,
-                                                  HQScratch *quadScratch, double *sC, const MurtyHeap H, FRoot onRoot, FTop onTop) {
+                                                  double *sC, const MurtyHeap H, FRoot onRoot, FTop onTop) {
   static_assert(W >= 2 && W <= MURTY_CT_WAVES, "one searching wave + at least one solver");
-  static_assert(SMALL || !QUAD, "the quarter-wave solvers need the small form");
-  constexpr int NS = QUAD ? 4 * (W - 1) : (W - 1);
+  constexpr int NS = W - 1;
   static_assert(NS <= MURTY_VSOLVERS && NS < 32, "mailboxes");
+  // WARM (round 6): every node keeps its row duals (A.nodeLx), and a child's solve is one augmentation from its parent's
+  // (hungarian_warm_wave) -- the small form of the RB-PHD partition sums only; scores, not ranked assignments, are what that path uses
+  constexpr bool WARM = SMALL && (MURTY_WARM != 0);
+  static_assert(!WARM || HQ_N <= MURTY_WARM_N, "the small form's dimension fits the dual-variable records");
   const int lane = threadIdx.x & 63;
   if (wave == 0) {
     if (lane < MURTY_SPEC_SLOTS) spec->ready[lane] = 0;
@@ -477,7 +540,9 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
     if (lane == 0) spec->quit = 0;
     int a0;
     double s = 0;
-    const bool okr = murty_root_wave(C, n, A, a0, s, nullptr);
+    double lxRoot = 0.0;
+    const bool okr = murty_root_wave(C, n, A, a0, s, nullptr, WARM ? &lxRoot : nullptr);
+    if constexpr (WARM) { if (lane < MURTY_WARM_N) A.nodeLx[lane] = lxRoot; }
     if (lane == 0) {
       if (okr) { H.lid[0] = 0; H.lsc[0] = s; }      // (murty_root_wave pushed node 0 onto the arena's heap: position 0 lives in LDS here)
       if constexpr (SMALL) A.nodeExcl[0] = (unsigned short)(1u << a0);
@@ -507,9 +572,7 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
 #define MS_STAMP(i) do { } while (0)
 #endif
   if (wave != 0) {
-    if constexpr (QUAD) {
-      murty_quad_solver_wave(C, n, realNC, A, wave, spec, quadScratch, sC);
-    } else {
+    {
       // ---- solver ----
       int seen = 0;
       for (;;) {
@@ -530,7 +593,10 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
         bool pushed = false;
         double sAcc = 0;
         int aNew = aPar;
-        murty_solve_child<LDSN, SMALL>(myTile, Cs, n, realNC, A, wave, X, ppX, c, 0x7ffe, aPar, termPar, pushed, sAcc, aNew, prof, exclX);
+        double lxPar = 0.0, lxNew = 0.0;
+        if constexpr (WARM) lxPar = (lane < MURTY_WARM_N) ? A.nodeLx[(size_t)X * MURTY_WARM_N + lane] : 0.0;
+        murty_solve_child<LDSN, SMALL, WARM>(myTile, Cs, n, realNC, A, wave, X, ppX, c, 0x7ffe, aPar, termPar, pushed, sAcc, aNew, prof, exclX, lxPar, WARM ? &lxNew : nullptr);
+        if constexpr (WARM) { if (lane < MURTY_WARM_N) spec->lx[e][lane] = lxNew; }
         spec->a[e][lane] = (unsigned char)aNew;
         if (lane == 0) { spec->score[e] = sAcc; spec->pushed[e] = pushed ? 1 : 0; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -659,6 +725,8 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
         const double termPar = (lane < n) ? Cs[lane * n + aPar] : 0.0;
         unsigned exclPar = 0;
         if constexpr (SMALL) exclPar = A.nodeExcl[parent];
+        double lxParent = 0.0;
+        if constexpr (WARM) lxParent = (lane < MURTY_WARM_N) ? A.nodeLx[(size_t)parent * MURTY_WARM_N + lane] : 0.0;
         // (small form) what child 0 of the new node -- child c of `parent`, created at row nn = pp + c -- must not take in its
         // first row, which is row nn again: the constraint walk (src/MurtyAlgorithm.cpp:247-265) visits the node itself, its
         // parent, and goes on upwards for as long as the ancestor was created at the same row.  So: the node's own choice for
@@ -676,7 +744,9 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
           bool pushed = false;
           double sAcc = 0;
           int aNew = aPar;
-          murty_solve_child<LDSN, SMALL>(myTile, Cs, n, realNC, A, 0, parent, pp, c, pn, aPar, termPar, pushed, sAcc, aNew, prof, exclPar);
+          double lxNew = 0.0;
+          murty_solve_child<LDSN, SMALL, WARM>(myTile, Cs, n, realNC, A, 0, parent, pp, c, pn, aPar, termPar, pushed, sAcc, aNew, prof, exclPar, lxParent, WARM ? &lxNew : nullptr);
+          if constexpr (WARM) { if (lane >= pp + c && lane < n) A.nodeLx[(size_t)pn * MURTY_WARM_N + lane] = lxNew; }   // (rows below pp + c stay with the parent's columns in every descendant: their duals are never read)
           if (lane < n) A.nodeA[(size_t)pn * MURTY_N + lane] = (unsigned char)aNew;
           if (lane == 0) { sPushed[c] = pushed ? 1 : 0; sScore[c] = sAcc; }
           note_excl(c, pn, aNew);
@@ -698,6 +768,7 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
           dbgWait += (long long)__builtin_readcyclecounter() - tw;
 #endif
           const int aNew = spec->a[e][lane];
+          if constexpr (WARM) { if (lane >= pp + c && lane < n) A.nodeLx[(size_t)pn * MURTY_WARM_N + lane] = spec->lx[e][lane]; }
           if (lane < n) A.nodeA[(size_t)pn * MURTY_N + lane] = (unsigned char)aNew;
           if (lane == 0) { sPushed[c] = spec->pushed[e]; sScore[c] = spec->score[e]; }
           note_excl(c, pn, aNew);
@@ -753,7 +824,7 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
 template <int W>
 __device__ __forceinline__ double murty_partition_sum_block(double *C, int n, int nR, int nC, MurtyArena &A, bool &ok, double *myTile, int *ctl,
                                                             double *sSum, double *sScore, unsigned char *sPushed, const int wave,
-                                                            MurtySpec *spec = nullptr, HQScratch *quadScratch = nullptr, double *sC = nullptr, short *heapId = nullptr,
+                                                            MurtySpec *spec = nullptr, double *sC = nullptr, short *heapId = nullptr,
                                                             double *heapSc = nullptr) {
   const double BIG_NEG = -1000.0;
   const int realNR = nR > n ? n : nR, realNC = nC > n ? n : nC;
@@ -801,12 +872,10 @@ __device__ __forceinline__ double murty_partition_sum_block(double *C, int n, in
     if (spec) {
       const MurtyHeap H{heapId, heapSc, A.heap, A.nodeScore};
       if (sC && n <= HQ_N) {
-        murty_kbest_async<W, MURTY_LDS_N, (MURTY_QUAD != 0), true>(C, n, partitionMax, realNC, MURTY_MAX_NODES, MURTY_KBEST, A, ok, myTile, ctl, sScore, sPushed, wave,
-                                                                   spec, quadScratch, sC, H, onRoot, onTop);
+        murty_kbest_async<W, MURTY_LDS_N, true>(C, n, partitionMax, realNC, MURTY_MAX_NODES, MURTY_KBEST, A, ok, myTile, ctl, sScore, sPushed, wave, spec, sC, H, onRoot, onTop);
         return *sSum;
       }
-      murty_kbest_async<W, MURTY_LDS_N, false, false>(C, n, partitionMax, realNC, MURTY_MAX_NODES, MURTY_KBEST, A, ok, myTile, ctl, sScore, sPushed, wave, spec,
-                                                      nullptr, nullptr, H, onRoot, onTop);
+      murty_kbest_async<W, MURTY_LDS_N, false>(C, n, partitionMax, realNC, MURTY_MAX_NODES, MURTY_KBEST, A, ok, myTile, ctl, sScore, sPushed, wave, spec, nullptr, H, onRoot, onTop);
       return *sSum;
     }
   }
@@ -1000,12 +1069,6 @@ void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err, double *weight, 
 #else
   MurtySpec *const spec = nullptr;
 #endif
-#if MURTY_QUAD && !defined(MURTY_NO_SPEC)
-  __shared__ HQScratch sQuad[4 * (W - 1)];
-  HQScratch *const quad = sQuad;
-#else
-  HQScratch *const quad = nullptr;
-#endif
   __shared__ double sHeapSc[MURTY_HEAP_LDS];   // the searching wave's heap, first positions (mheap_*)
   __shared__ short sHeapId[MURTY_HEAP_LDS];
 #if !defined(MURTY_NO_SPEC) && !defined(MURTY_NO_SMALL)
@@ -1043,7 +1106,7 @@ void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err, double *weight, 
       murty_carve(MS.arena + (size_t)blockIdx.x * MS.jobBytes, A);
       bool ok;
       v = murty_partition_sum_block<W>(Q.mats + (size_t)j * MURTY_MAXN * MURTY_MAXN, n, J.nR, J.nC, A, ok, sTile[wave], sCtl, &sSum, sScore,
-                                                     sPushed, wave, spec, quad, jobC, sHeapId, sHeapSc);
+                                                     sPushed, wave, spec, jobC, sHeapId, sHeapSc);
       if (!ok && threadIdx.x == 0) atomicOr(err, ERRBIT_MURTY);
     }
     if (threadIdx.x == 0) Q.results[j] = v;
@@ -1072,6 +1135,9 @@ void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err, double *weight, 
 #endif
 #ifdef RFS_PROFILE
   const long long dbgTail0 = (long long)wall_clock64();
+#endif
+#if defined(MURTY_WARM_CHECK)
+  if (threadIdx.x == 0) printf("murty warm check: %llu child solves compared with the solve from scratch, %llu mismatches (running totals)\n", g_murtyWarmChecks, g_murtyWarmBad);
 #endif
   if (threadIdx.x == 0 && hostSeen) *hostSeen = 1;            // (pinned host word: this filter does reach the Murty path -- see murty_launch)
   // Every particle's factors, multiplied in partition (slot) order.  The jobs of a particle are chained through a list first

@@ -254,7 +254,7 @@ def test_trailing_normalisation_falls_back_to_events_when_the_side_stream_is_lat
     held back on the side stream past the probe's bounded wait (RFSGPU_COLL_PROBE_DELAY_MS, a spinning kernel), which is what two
     streams serialised onto one hardware queue look like from the device.  ShardedRBPHDFilter and rfsgpu_group_update_deferred must
     then take the stream-event form BY THEMSELVES and the steps must still be right: weights 1e-12 against a filter that normalises
-    step by step, maps bit for bit -- and without the delay both must use the sequence numbers.  A default-constructed
+    step by step, maps bit for bit -- and without the delay both must be right in whichever form their probe picks.  A default-constructed
     ShardedRBPHDFilter does not defer at all: the reference's order of operations."""
     sc = pkg.scenarios
     n = 32
@@ -307,12 +307,14 @@ def test_trailing_normalisation_falls_back_to_events_when_the_side_stream_is_lat
             for a, b in zip(maps[i], ref.export_gm(i)):
                 assert np.array_equal(a, b)
 
-    # the ordinary case on this box: side by side -> sequence numbers
+    # no delay: whatever the probe finds for THIS stream pair is right -- sequence numbers where the two streams run side by side,
+    # stream events where the runtime has mapped them onto one hardware queue (HIP deals its streams out over four queues by default;
+    # seen on the GPU box in round 6: the same test took either form depending on how many streams the process had created before)
     w, maps, deferred, mode = run_sharded(True)
-    assert deferred >= 3 and mode == "sequence_numbers", (deferred, mode)
+    assert deferred >= 3 and mode in ("sequence_numbers", "events"), (deferred, mode)
     check(w, maps, 1e-12)
     w, maps, mode = run_group()
-    assert mode == "rccl; hand-over: sequence numbers", mode
+    assert mode in ("rccl; hand-over: sequence numbers", "rccl; hand-over: stream events"), mode
     check(w, maps, 1e-12)
     # the side stream held back past the bounded wait: both hosts fall back to stream events, by themselves
     monkeypatch.setenv("RFSGPU_COLL_PROBE_DELAY_MS", "350")
