@@ -712,6 +712,13 @@ def main():
         for k in range(3, 13):
             step(k)
         f.synchronize()
+        if wl["reseed"]:                  # + the stand-alone likelihood sweep (phase-by-phase update), so that the SQ pass can give it its own issue-slot share
+            ring_stop()
+            f.set_phase_timing(True)
+            for _ in range(6):
+                f.restore_state()
+                f.update(Z)
+            f.set_phase_timing(False)
         return
 
     ring_start(max(args.warmup + args.steps, 16))

@@ -315,8 +315,8 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     int cx, cy;
     cell_of(ax, ay, cx, cy);
     const int cxa = cx > 0 ? cx - 1 : 0, cxb = cx < gxe - 1 ? cx + 1 : gxe - 1;
-    unsigned long long buf0 = 0ull, buf1 = 0ull;  // up to 8 survivors, 16 bits each
-    unsigned sb0 = 0u, sb1 = 0u, sb2 = 0u, sb3 = 0u;   // MERGE_SCAN_PACK_ALIGNBIT: the same eight fields as a shift chain, newest in sb0's low half
+    [[maybe_unused]] unsigned long long buf0 = 0ull, buf1 = 0ull;  // up to 8 survivors, 16 bits each
+    [[maybe_unused]] unsigned sb0 = 0u, sb1 = 0u, sb2 = 0u, sb3 = 0u;   // MERGE_SCAN_PACK_ALIGNBIT: the same eight fields as a shift chain, newest in sb0's low half
     int nP = 0;
     float farE2 = 3.0e38f;   // nearest neighbour that fails the prefilter by a factor >= 2 in distance
     // the three cell rows are three contiguous ranges of the sorted list; they are walked as ONE sequence (same order as

@@ -31,7 +31,7 @@
 #define MURTY_JOB_WAVES 5   // round 6, children solved by ONE augmentation from their parent's duals (MURTY_WARM): the search wave's own bookkeeping is what a pop
                             // costs now, and solver waves that mostly poll their mailboxes only take issue slots from it -- configs[4], kernel ms (profiles/r06d_*):
                             // 8 waves 1.80 (2.10 with the solves from scratch), 6: 1.73, 5: 1.61, 4: 1.52; with two peeked heap positions instead of five 4: 1.43,
-                            // 5: 1.35, 6: 1.39.  (round 5, solves from scratch: 6: 2.96 ms, 8: 2.50, 10: 3.1, 12: 5.3; 16 table slots + peeks: 8: 2.16)
+                            // 5: 1.35, 6: 1.39; then with the open nodes in an unsorted array scanned by the wave (MURTY_ARGQ) 5: 1.07, 4: 1.20, 6: 1.16, 3: 1.51.  (round 5, solves from scratch: 6: 2.96 ms, 8: 2.50, 10: 3.1, 12: 5.3; 16 table slots + peeks: 8: 2.16)
 #endif
 #define MURTY_CT_WAVES (MURTY_JOB_WAVES > 4 ? MURTY_JOB_WAVES : 4)   /* (the multi-hypothesis FastSLAM search uses up to four waves on the same arena) */
 
@@ -192,6 +192,48 @@ __device__ inline short mheap_pop(const MurtyHeap &H, int &len) {
   }
   mheap_set(H, hole, value, vs);
   return top;
+}
+
+// ---- the same store as an UNSORTED array scanned by the whole wave (round 6, the RB-PHD partition sums of the small form) ----
+// With the children's solves down to one augmentation (MURTY_WARM) a pop's cost was lane 0's walk through the binary heap: pop_heap's
+// sift-down and push_heap's sift-up are chains of dependent LDS reads that one lane runs while 63 idle (3.6 k + 2.9 k cycles of a
+// 14 k-cycle pop on an idle GPU, five to ten times that when every SIMD holds six such waves; profiles/r06i_*).  Here the entries
+// lie in the same arrays in arrival order, a push appends, a pop removes by moving the last entry into the hole, and the best three
+// come out of ONE pass in which every lane looks at len / 64 entries and the wave reduces (DPP maxima, no memory in the chain).
+// Which of several entries with EXACTLY equal scores comes out first differs from std::priority_queue's order: the partition sum
+// adds equal terms then, in a different order -- the same sum (the ranked ASSIGNMENTS would differ: FastSLAM keeps the heap).
+struct MqTop { int id[3]; int pos0; double sc0; };
+__device__ __forceinline__ void mq_push(const MurtyHeap &H, int &len, int id, double sc) {   // lane 0's stores; len is uniform
+  if ((threadIdx.x & 63) == 0) mheap_set(H, len, (short)id, sc);
+  len++;
+}
+__device__ __forceinline__ void mq_remove(const MurtyHeap &H, int &len, int pos) {          // lane 0's stores
+  len--;
+  if ((threadIdx.x & 63) == 0 && pos != len) mheap_set(H, pos, mheap_id(H, len), mheap_sc(H, len));
+}
+// the three best entries (ids; -1 where there are fewer), the best one's position and score; all lanes call
+__device__ __forceinline__ void mq_top3(const MurtyHeap &H, int len, MqTop &T) {
+  const int lane = threadIdx.x & 63;
+  const double NONE = -1.7976931348623157e308;
+  double b0 = NONE, b1 = NONE, b2 = NONE;     // this lane's three best, descending (ties: the earlier position first)
+  int i0 = -1, i1 = -1, i2 = -1, p0 = -1;
+  for (int pos = lane; pos < len; pos += 64) {
+    const double sc = mheap_sc(H, pos);
+    const int id = mheap_id(H, pos);
+    if (sc > b0) { b2 = b1; i2 = i1; b1 = b0; i1 = i0; b0 = sc; i0 = id; p0 = pos; }
+    else if (sc > b1) { b2 = b1; i2 = i1; b1 = sc; i1 = id; }
+    else if (sc > b2) { b2 = sc; i2 = id; }
+  }
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const double m = wave_max_f64(i0 >= 0 ? b0 : NONE);
+    const unsigned long long own = __ballot(i0 >= 0 && b0 == m);
+    if (own == 0ull) { T.id[r] = -1; if (r == 0) { T.pos0 = -1; T.sc0 = NONE; } continue; }
+    const int l = __builtin_ctzll(own);
+    T.id[r] = __builtin_amdgcn_readlane(i0, l);
+    if (r == 0) { T.pos0 = __builtin_amdgcn_readlane(p0, l); T.sc0 = m; }
+    if (lane == l) { b0 = b1; i0 = i1; b1 = b2; i1 = i2; b2 = NONE; i2 = -1; }
+  }
 }
 
 // ---- one WAVEFRONT per Murty problem (hungarian_wave.h as the inner solver) --------------------------------------------
@@ -532,6 +574,13 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
   // WARM (round 6): every node keeps its row duals (A.nodeLx), and a child's solve is one augmentation from its parent's
   // (hungarian_warm_wave) -- the small form of the RB-PHD partition sums only; scores, not ranked assignments, are what that path uses
   constexpr bool WARM = SMALL && (MURTY_WARM != 0);
+  // ARGQ: the open nodes as an unsorted array scanned by the wave (mq_*) instead of lane 0's binary heap -- with WARM only (scores, not
+  // ranked assignments; -DMURTY_ARGQ=0 keeps the heap for A/B)
+#ifndef MURTY_ARGQ
+#define MURTY_ARGQ 1
+#endif
+  constexpr bool ARGQ = WARM && (MURTY_ARGQ != 0);
+  static_assert(!ARGQ || MURTY_PEEK <= 2, "mq_top3 yields the popped node and two peeks");
   static_assert(!WARM || HQ_N <= MURTY_WARM_N, "the small form's dimension fits the dual-variable records");
   const int lane = threadIdx.x & 63;
   if (wave == 0) {
@@ -564,7 +613,7 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
   int dbgHit = 0, dbgPosted = 0, dbgDirect = 0, dbgSpec = 0, dbgPops = 0;
   long long dbgWait = 0;
   const long long dbgT0 = (long long)__builtin_readcyclecounter();
-  long long sec[6] = {0, 0, 0, 0, 0, 0}, secT = dbgT0;   // search sections: pop + peeks, table look-up + posts, own solves, results from the table, push + stop rule
+  long long sec[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, secT = dbgT0;   // search sections: pop + peeks, table look-up + posts, own solves, results from the table, push + stop rule
 #define MS_STAMP(i) do { const long long tn = (long long)__builtin_readcyclecounter(); sec[i] += tn - secT; secT = tn; } while (0)
   long long *const prof = hp;
 #else
@@ -610,7 +659,20 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
     int tNode = -1, tC = 0;   // lane e < MURTY_SPEC_SLOTS: the key of table slot e (node < 0: free)
     int fifo = 0;             // next slot to recycle when none is free
     int postedL = 0;          // lane v in 1..NS: tasks posted to mailbox v so far
+    MqTop top;                // (ARGQ) the best three open nodes, found after the last push
+    int qLen = __builtin_amdgcn_readfirstlane(ctl[3]);
+    if constexpr (ARGQ) mq_top3(H, qLen, top);
     for (int k = 1; k < maxK && __builtin_amdgcn_readfirstlane(ctl[4]) == 0; k++) {
+      if constexpr (ARGQ) {
+        const int parent = top.id[0];
+        mq_remove(H, qLen, top.pos0);
+        if (lane == 0) {
+          ctl[0] = parent; ctl[1] = A.nodeId[parent]; ctl[3] = qLen;
+          const int b1 = top.id[1], b2 = top.id[2];     // what is left, best first: the nodes a coming pop is most likely to take
+          spec->peekNode[0] = b1; spec->peekPart[0] = (b1 >= 0) ? (int)A.nodeId[b1] : 0;
+          if (MURTY_PEEK > 1) { spec->peekNode[1] = b2; spec->peekPart[1] = (b2 >= 0) ? (int)A.nodeId[b2] : 0; }
+        }
+      } else
       if (lane == 0) {
         int hl = ctl[3];
         const int parent = mheap_pop(H, hl);
@@ -639,6 +701,7 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
           for (int q = 0; q < MURTY_PEEK; q++) { spec->peekNode[q] = id[q]; spec->peekPart[q] = (id[q] >= 0) ? (int)A.nodeId[id[q]] : 0; }
         }
       }
+      MS_STAMP(5);    // (profile builds: lane 0's pop + peeks alone; section 0 below is then the fence and the control words)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (also: the nodes pushed so far are visible to the solvers before any task names them)
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -702,6 +765,7 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
             direct |= 1ull << c;
           }
         }
+        MS_STAMP(6);    // (look-up + this node's posts; section 1 below: the posts ahead of coming pops)
         // solvers still free: children of the nodes next in the heap
         for (int cand = 0; cand < MURTY_PEEK && freeW; cand++) {
           const int X = __builtin_amdgcn_readfirstlane(spec->peekNode[cand]);
@@ -737,6 +801,7 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
             if (lane == 0) A.nodeExcl[pn] = (unsigned short)ex;
           }
         };
+        MS_STAMP(7);    // (the parent's record loaded; section 2 below: node records written + wave 0's own solves)
         for (int c = 0; c < cnt; c++) {
           const int nn = pp + c, pn = nNodes + c;
           if (lane == 0) { A.nodeId[pn] = (unsigned char)nn; A.nodeParent[pn] = (short)parent; }
@@ -779,6 +844,33 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      MS_STAMP(8);      // (the fence ahead of the push)
+      if constexpr (ARGQ) {
+        int stop = 0;
+        if (poolFull) {
+          if (lane == 0) ctl[5] = 0;
+          stop = 1;
+        } else {
+          for (int c = 0; c < cnt; c++)
+            if (sPushed[c]) {      // (uniform: one LDS byte)
+              const double sc = sScore[c];
+              if (lane == 0 && qLen >= MURTY_HEAP_LDS) A.nodeScore[nNodes + c] = sc;   // (an entry beyond the LDS positions keeps its score in the arena; the others never read it)
+              mq_push(H, qLen, nNodes + c, sc);
+            }
+          if (lane == 0) { ctl[2] = nNodes + (cnt > 0 ? cnt : 0); ctl[3] = qLen; }
+          if (qLen == 0) stop = 1;  // rank == -1
+          else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // lane 0's appends -> the scan's reads
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            mq_top3(H, qLen, top);
+            int st = 0;
+            if (lane == 0) st = onTop(top.sc0, top.id[0]) ? 1 : 0;
+            stop = __builtin_amdgcn_readfirstlane(st);
+          }
+        }
+        if (lane == 0) ctl[4] = stop;
+      } else
       if (lane == 0) {
         int stop = 0;
         if (poolFull) {
@@ -801,6 +893,7 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
         }
         ctl[4] = stop;
       }
+      MS_STAMP(9);      // (lane 0's pushes + stop rule; section 4 below: the fence behind them)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -812,7 +905,8 @@ __device__ __forceinline__ void murty_kbest_async(double *C, int n, int partitio
       printf("murty block %d: n %d pops %d nodes %d; children from the table %d, posted at the pop %d, solved by wave 0 %d, ahead of a pop %d; wave 0 waited %lld of %lld cycles; its own solves: %lld, cycles in the solver %lld (main loop %lld), trips %lld, BFS dequeues %lld, label updates %lld, sum of dimensions %lld\n",
              (int)blockIdx.x, n, dbgPops, ctl[2], dbgHit, dbgPosted, dbgDirect, dbgSpec, dbgWait, (long long)__builtin_readcyclecounter() - dbgT0, hp[2], hp[1], hp[8], hp[4], hp[5], hp[6], hp[7]);
     if (lane == 0 && (blockIdx.x & 255) == 7)
-      printf("murty sections block %d n %d: pop+peeks %lld, look-up+posts %lld, own solves %lld, table results %lld, push+stop %lld cycles\n", (int)blockIdx.x, n, sec[0], sec[1], sec[2], sec[3], sec[4]);
+      printf("murty sections block %d n %d pops %d: pop+peeks (lane 0) %lld | fence+control %lld | look-up + own posts %lld | posts ahead %lld | parent record %lld | records + own solves %lld | table results %lld | fence %lld | pushes+stop (lane 0) %lld | fence %lld cycles\n",
+             (int)blockIdx.x, n, dbgPops, sec[5], sec[0], sec[6], sec[1], sec[7], sec[2], sec[3], sec[8], sec[9], sec[4]);
 #endif
   }
   __threadfence_block();

@@ -5,7 +5,7 @@ TAG=${1:-x}
 OUT=gpurun_out/ic_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-ARGS="--steps 20 --warmup 3 --no-cpu-baseline"
+ARGS="--steps 20 --warmup 3 --no-cpu-baseline --no-pmc --no-boundary"
 k=0
 for set in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" "SQ_IFETCH SQ_IFETCH_LEVEL SQC_TC_INST_REQ SQC_ICACHE_BUSY_CYCLES" "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQ_WAVE_CYCLES"; do
   k=$((k+1))
