@@ -77,6 +77,19 @@ def build_cold_murty_variant(force=False, verbose=False):
     return compile_library(COLD_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"], COLD_LIB, verbose)
 
 
+# ... and the shipped search with only 16 of the open-node array's positions in LDS (-DMURTY_HEAP_LDS=16; 512 in the product): the
+# positions beyond live in the job's arena, a path configs[4]'s jobs never reach with 512 -- same weights bit for bit.
+SMALLQ_LIB = os.path.join(ROOT, "tests", "support", "_build", "librfsgpu_smallqueue.so")
+
+
+def build_small_queue_variant(force=False, verbose=False):
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "rfsgpu.h")]
+    if not force and os.path.exists(SMALLQ_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(SMALLQ_LIB) for d in deps):
+        return SMALLQ_LIB
+    os.makedirs(os.path.dirname(SMALLQ_LIB), exist_ok=True)
+    return compile_library(["-DMURTY_HEAP_LDS=16"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"], SMALLQ_LIB, verbose)
+
+
 SIM = os.path.join(HERE, "host", "rbphdslam2d_sim")
 SIM_FASTSLAM = os.path.join(HERE, "host", "fastslam2d_sim")
 SIM_VP = os.path.join(HERE, "host", "rbphdslam_vp")

@@ -1972,6 +1972,13 @@ def test_warm_started_murty_children_give_the_sums_of_the_solver_from_scratch(pk
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "cold ok" in p.stdout, p.stderr[-3000:]
     w_cold = np.load(out)
+    # the same search with only 16 positions of the open-node array in LDS (the rest in the job's arena: the overflow path): same bits
+    w_smallq = None
+    smallq = pkg.build_mod.SMALLQ_LIB
+    if os.path.exists(smallq):
+        p = subprocess.run([sys.executable, "-c", code.replace(cold, smallq)], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and "cold ok" in p.stdout, p.stderr[-3000:]
+        w_smallq = np.load(out)
     scen = sc.make_scenario(96, 200, 50, **kw)
     dev, orc = make_pair(pkg, ob, sc, scen, cap=448)
     for f in (dev, orc):
@@ -1979,6 +1986,8 @@ def test_warm_started_murty_children_give_the_sums_of_the_solver_from_scratch(pk
         f.importance_weighting()
     assert orc.murty_calls() > 50, "scenario does not reach the Murty path"
     np.testing.assert_allclose(dev.get_weights(), w_cold, rtol=1e-12, atol=0.0)
+    if w_smallq is not None:
+        assert np.array_equal(dev.get_weights(), w_smallq)
     np.testing.assert_allclose(w_cold / w_cold.sum(), orc.get_weights() / orc.get_weights().sum(), rtol=1e-9, atol=1e-300)
     compare_weights(dev, orc)
 
