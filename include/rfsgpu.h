@@ -409,7 +409,10 @@ int rfsgpu_normalize_weights_parts(rfsgpu_filter *f, double sum, const void *sum
  * SOURCE's id; idParent_ = the source's id; a survivor's idParent_ = its own id, which differs from its slot once it has been
  * a copy itself) and remembers that a resampling occurred (RBPHDFilter::resampleOccured_, cleared by the next update with
  * measurements, include/RBPHDFilter.hpp:526).  What happens to the three per-SLOT arrays of RBPHDFilter -- unused_measurements_,
- * birthGaussians_, nLandmarksInFOV_ -- is selected by rfsgpu_set_birth_inheritance (below). */
+ * birthGaussians_, nLandmarksInFOV_ -- is selected by rfsgpu_set_birth_inheritance (below).
+ * Stream-ordered since round 6: src_slot is copied before the call returns, the device copy is enqueued behind whatever is on the handle's
+ * stream and nothing waits for it (every reader of maps / weights does, on that stream); TimingInfo's particleResample buckets hold the
+ * host time of the call. */
 int rfsgpu_resample_apply(rfsgpu_filter *f, const int *src_slot);
 /* Birth-state inheritance after a resampling (include/RBPHDFilter.hpp:1005-1011).
  *   RFSGPU_INHERIT_REFERENCE (default)  the reference, statement for statement: nothing but pose + mixture moves at resampling

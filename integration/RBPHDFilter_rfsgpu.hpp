@@ -257,6 +257,9 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
       std::fprintf(stderr, "rfsgpu binding predict() breakdown over %lld calls, us per call: flush + configuration %.2f | map part (lazy: pose check + record; eager: "
                            "pose push + predict launch + wait) %.2f | ParticleFilter::propagate (reference host code) %.2f | lazy=%d\n",
                    profN_, 1e-3 * profNs_[0] / profN_, 1e-3 * profNs_[1] / profN_, 1e-3 * profNs_[2] / profN_, lazyPredict_ ? 1 : 0);
+    if (prof_ && profTailN_ > 0)
+      std::fprintf(stderr, "rfsgpu binding resample tail of update(): %lld updates, %.2f us per update in all; rfsgpu_resample_apply fired %lld times, %.2f us per call\n",
+                   profTailN_, 1e-3 * profTailNs_ / profTailN_, profResN_, profResN_ ? 1e-3 * profResNs_ / profResN_ : 0.0);
     delete kf_;
     delete lmkModelPtr_;
   }
@@ -325,6 +328,7 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
     for (int i = 0; i < n; i++) this->particleSet_[i]->setWeight(wHost_[i]);
 
     timer_particleResample_.resume();                       /* :524-539, unchanged */
+    const long long tt0 = prof_now();
     resampleOccured_ = false;
     if (nUpdatesSinceResample_ >= config.minUpdatesBeforeResample_ && nMeasurementsSinceResample_ >= config.minMeasurementsBeforeResample_) {
       resampleOccured_ = resampleWithDeviceMaps();
@@ -335,6 +339,7 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
     } else {
       this->normalizeWeights();
     }
+    if (prof_) { profTailNs_ += prof_now() - tt0; profTailN_++; }
     timer_particleResample_.stop();
   }
 
@@ -390,7 +395,7 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
   struct PushedConfig { rfsgpu_filter_config c; rfsgpu_kf_config k; double q[9]; rfsgpu_rngbrg_config m; bool valid; } pushed_ = {};
   /* RFSGPU_BINDING_PROFILE=1: where predict()'s host time goes, printed by the destructor (profiles/r06*_binding_predict_breakdown.txt) */
   bool prof_ = std::getenv("RFSGPU_BINDING_PROFILE") && std::atoi(std::getenv("RFSGPU_BINDING_PROFILE")) != 0;
-  long long profNs_[3] = {0, 0, 0}, profN_ = 0;
+  long long profNs_[3] = {0, 0, 0}, profN_ = 0, profResNs_ = 0, profResN_ = 0, profTailNs_ = 0, profTailN_ = 0;
   long long prof_now() const {
     if (!prof_) return 0;
     struct timespec ts;
@@ -591,7 +596,9 @@ class RBPHDFilter : public ParticleFilter<RobotProcessModel, MeasurementModel, G
         next_unsampled_idx++;
       }
     }
+    const long long tr0 = prof_now();
     check(engine_.resample_apply(src_slot.data()), "resample_apply");   /* also resets the device weights to 1 */
+    if (prof_) { profResNs_ += prof_now() - tr0; profResN_++; }
     if (xOnDeviceValid_ && xHost_.size() == (size_t)3 * n)                /* the device's pose array travelled with the particles: so does its host copy */
       for (int i = 0; i < n; i++)
         if (src_slot[i] != i)

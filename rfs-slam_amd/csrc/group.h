@@ -637,7 +637,7 @@ int rfsgpu_group_apply_plan(rfsgpu_group *g, const int *src) {
           GCHK(hipMemcpyPeerAsync(g->recvBuf[kd] + recvOff[kd][ks] * R, f->device, g->sendBuf[ks] + sendOff[ks][kd] * R, fs->device, n * R, f->stream));
       }
     }
-    GFWD(kd, rfsgpu_resample_apply(f, localSrc[kd].data()));   // also resets every weight to 1 (:486-489); syncs the shard's stream
+    GFWD(kd, rfsgpu_resample_apply(f, localSrc[kd].data()));   // also resets every weight to 1 (:486-489); stream-ordered (round 6)
     if (!slots.empty()) GFWD(kd, rfsgpu_import_slab_rows(f, slots.data(), (int)slots.size(), g->recvBuf[kd]));
   }
   for (int k = 0; k < S; k++) GFWD(k, rfsgpu_synchronize(g->shard[k]));   // (send buffers are reused by the next resampling)
