@@ -6,11 +6,12 @@ include/RBPHDFilter.hpp:444-523) over one batch of synthetic input + the weight 
 reduction, RCCL all-reduce across ranks when N>1, divide).  Workloads:
 
   c2a  BASELINE configs[1]: 2000 particles x 200 GM landmarks x 30 measurements, all landmarks in the field of view
-       (worst case: 6000 landmark-measurement pairs per particle).  DEFAULT at --gpus 1.  The state collapses after one update
-       (Pd = 0.99), so every step starts from a device-resident snapshot (rfsgpu_restore_state, inside the timed region).
+       (worst case: 6000 landmark-measurement pairs per particle).  DEFAULT at every --gpus N (the same per-GPU work: weak scaling).
+       The state collapses after one update (Pd = 0.99), so every step starts from a fresh copy of the saved state; the copies of all
+       W + K steps are resident in HBM before the timed region (rfsgpu_state_ring_*, a pointer swap per step).
   c3   BASELINE configs[2]'s shard: 2500 particles x 500 GM landmarks x 30 measurements per GPU, range limit 5 m
-       (20 000 particles over 8 GPUs).  DEFAULT at --gpus N > 1.  Same re-seeding.  One global resampling step with
-       cross-shard mixture migration is timed separately after the region (`resample_migration`).
+       (--workload c3 --gpus 8 is configs[2]: 20 000 particles over 8 GPUs).  Same re-seeding.  With N > 1 one global resampling step
+       with cross-shard mixture migration is timed separately after the region (`resample_migration`).
   c2b  the C2 map with ~30 landmarks inside the field of view, NOT re-seeded: predict (births) + update + normalise per step,
        a fresh noisy measurement set every step; median over the steps is reported beside the mean.
   c4   BASELINE configs[3]: Victoria Park model (3-D landmarks, scan-based Pd), 5000 particles x 40 landmarks x 12 measurements
@@ -26,7 +27,10 @@ reduction, RCCL all-reduce across ranks when N>1, divide).  Workloads (SURVEY 8(
 Particles shard across ranks with no data-path collective except the 2-double all-reduce (weak scaling).  Rank 0 prints
 ONE JSON line.  roofline.achieved = SURVEY 8(d)'s bytes_step / the fused step kernel's average HIP-event duration inside the
 timed region; roofline.traffic = HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of this same
-workload, collected live by two short child runs (N = 1, rank 0; --no-pmc skips them).
+workload, collected live by two short child runs (N = 1, rank 0; --no-pmc skips them); roofline.valu_issue_frac (what binds) from a
+third, SQ-counter pass; roofline.flop_frac = SURVEY 8(d)'s algorithmic fp64 flops / kernel time / 78.6 TFLOP/s.  cpu_baseline = the
+oracle's restatement timed on the host cores (two labelled figures), boundary = what an update costs through the reference-side
+binding and under the unmodified reference driver, config.distributed = world size / backend / PCI bus ids / the collective's form.
 """
 import os
 import argparse
