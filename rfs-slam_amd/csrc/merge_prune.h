@@ -161,8 +161,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     sX[m] = fx; sY[m] = fy; sW[m] = w;
     sRec[m] = MERGE_REC_NOCLAIM;
     if (w < 0) { hole |= 1u << sidx; sRad[m] = -1.f; continue; }  // already absorbed (merge called twice); radius < 0 marks a hole
-    float rad = merge_radius_f32(bnd);
-    rad = (rad == 1.0f) ? 1.0000001f : rad;   // (-1.f is the mark of an entry that arrived absorbed; the component replay marks ITS holes by the radius' sign)
+    const float rad = merge_radius_f32(bnd);
     sRad[m] = rad;
     fxmin = fminf(fxmin, fx); fxmax = fmaxf(fxmax, fx);
     fymin = fminf(fymin, fy); fymax = fmaxf(fymax, fy);
@@ -277,10 +276,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     // form from the two radii per neighbour (the shift is monotone, so the maximum commutes with it: the same fp32 number), three
     // vector instructions instead of six.  Every later reader wants an upper bound of the radius (the sequential scan's bound) or
     // takes the shift back out (the walk's rPass); the sign stays the liveness flag.
-    {
-      const float r2 = sRad[m] + 1.5f * errAbs;
-      sRad[m] = (r2 == 1.0f) ? 1.0000001f : r2;   // (-1.f stays the mark of an entry that arrived absorbed, see the stage)
-    }
+    sRad[m] = sRad[m] + 1.5f * errAbs;
 #endif
   }
   if (tid == 0) *sPairCount = 0u;
@@ -571,210 +567,13 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     wave_sync();
   };
 
-#ifndef MERGE_COMPONENT_REPLAY
-#define MERGE_COMPONENT_REPLAY 0   // measured and dropped, round 6 (profiles/r06b_ab_component_replay.txt): exact, and 19 % slower -- see below
-#endif
-  // ---- Round 6, MEASURED AND DROPPED (opt-in: -DMERGE_COMPONENT_REPLAY=1; profiles/r06b_*): replay by CONNECTED COMPONENTS of the
-  // listed-pair graph, one component per lane, no speculation.  Exact (the full GPU suite and 1500 fuzz cases pass with it), but the
-  // fused step at configs[1] takes 137.3 us with it against 115.0: the components are small (12-25 per particle, the largest 4-7 rows,
-  // tools/merge_components_study.py) but the label propagation needs ~4 trips over the pair list (7.8 k cycles) and the busiest lane
-  // walks 3 rows one after the other (28 k cycles) where the speculative pass below walks all rows at once (15 k) and validates in
-  // 11 k -- the kernel's time follows the wave-instructions it issues, and this form issues more of them. ----
-  // What one row's replay depends on beside its own initial state: whether the row itself and its listed partners are still alive,
-  // i.e. what EARLIER rows absorbed.  Rows interact only through a listed pair (a row absorbs another row, or two rows list the same
-  // partner) -- so the rows of different connected components of the graph {(row, listed partner) : row has a passing partner}
-  // commute, and inside a component the reference's ascending order is kept by giving the whole component to ONE lane, which walks
-  // its rows one after the other against the liveness it has itself produced: exactly the greedy scan, without claims, validation
-  // or re-walks (the speculative form below paid ~11 k cycles of row-by-row validation per particle at configs[1], more on the
-  // particles that end a launch: 8 conflicts among 28 rows is typical).  The results are final as they are computed, so holes are
-  // marked at once (the radius' sign) and a merged row is written in place when its walk ends.
-  // The one thing that breaks the independence is a row that leaves its list (outgrows its slack, or could not be listed at all):
-  // its scan may then meet entries of other components.  Rare (0.01 rows per particle at configs[1]).  Such a particle is put back
-  // into its initial state -- the radius' sign, the merged rows' initial values from a backup in the OTHER slab (dead until the
-  // prune writes it) -- and goes through the speculative replay below, which handles those rows with the reference's full scan.
-  bool compDone = false;
-  if (MERGE_COMPONENT_REPLAY && nRowsTotal > 0) {
-    bool unl = false;
-    for (int r = lane; r < nRowsTotal; r += 64) unl |= ((sRec[sRows[r]] >> 20) & 15u) == 15u;
-    bool usable = __ballot(unl) == 0ull;
-    unsigned *sLab = reinterpret_cast<unsigned *>(sX);      // [N] component label = lowest entry of the component (the scan's fp32 positions are dead)
-    if (usable) {
-      for (int m = lane; m < N; m += 64) sLab[m] = (unsigned)m;
-      wave_sync();
-      const int nPairs = (int)min(*sPairCount, (unsigned)pairCap);
-      usable = false;
-      for (int iter = 0; iter < 48; iter++) {     // label propagation (min over every edge); stars settle in one trip, chains in their length
-        bool ch = false;
-        for (int p0 = lane; p0 < nPairs; p0 += 64) {
-          const unsigned pr2 = sPairs[p0];
-          const unsigned ea = pr2 >> 16, ej = pr2 & 0x3fffu;
-          if (pr2 == 0xffffffffu || !(sRec[ea] & MERGE_REC_ISROW)) continue;
-          const unsigned la = sLab[ea], lj = sLab[ej];
-          if (la != lj) { const unsigned mn = min(la, lj); atomicMin(&sLab[ea], mn); atomicMin(&sLab[ej], mn); ch = true; }
-        }
-        wave_sync();
-#ifdef RFS_PROFILE
-        if (B.dbg && i == 7 && lane == 0) B.dbg[46] = iter + 1;
-#endif
-        if (__ballot(ch) == 0ull) { usable = true; break; }
-      }
-    }
-    DBG_TB(32, 12);
-    if (usable) {
-      double *bk = B.slab[dst];    // backup of the rows that merge (their initial w, mean, covariance), at their own slab positions
-      bool ovfAny = false, merged = false;
-      for (int r0 = 0; r0 < nRowsTotal; r0 += 64) {
-        const int cnt = (nRowsTotal - r0 < 64) ? nRowsTotal - r0 : 64;
-        const unsigned myLab = (lane < cnt) ? sLab[sRows[r0 + lane]] : 0xffffffffu;
-        // the chunk's rows grouped by component: the lowest row of each takes the component's rows (a bit per lane of the chunk)
-        unsigned long long todo = (cnt == 64) ? ~0ull : ((1ull << cnt) - 1ull), mine = 0ull;
-        while (todo) {
-          const int k = __builtin_ctzll(todo);
-          const unsigned L = (unsigned)__builtin_amdgcn_readlane((int)myLab, k);
-          const unsigned long long mk = __ballot(myLab == L) & todo;
-          if (lane == k) mine = mk;
-          todo &= ~mk;
-        }
-#ifdef RFS_PROFILE
-        int dbgTrips = 0;
-#endif
-        while (mine) {
-#ifdef RFS_PROFILE
-          dbgTrips++;
-#endif
-          // next row of the component that is still alive
-          int a = -1;
-          while (mine) {
-            const int r = __builtin_ctzll(mine);
-            mine &= mine - 1ull;
-            const int c = (int)sRows[r0 + r];
-            if (!(sRad[c] < 0.f)) { a = c; break; }
-          }
-          if (a < 0) break;
-#ifdef RFS_PROFILE
-          dbgRows++;
-#endif
-          const int pa = phys(a);
-          const unsigned rec = sRec[a];
-          const int n = (int)((rec >> 20) & 15u);
-          const unsigned base = rec & 0xfffffu;
-          unsigned it[MERGE_ROW_SLOTS];
-#pragma unroll
-          for (int k = 0; k < MERGE_ROW_SLOTS; k++) it[k] = (k < n) ? (sPairs[base + k] & 0xffffu) : 0xffffffffu;
-#pragma unroll
-          for (int k = 0; k < MERGE_ROW_SLOTS; k++)
-            if (k < n && sRad[it[k] & 0x3fffu] < 0.f) it[k] = 0xffffffffu;
-          double ax = pMX[pa], ay = pMY[pa], aw = sW[a];
-          double axx = pSXX[pa], axy = pSXY[pa], ayy = pSYY[pa];
-          const float slack = __uint_as_float((unsigned)sSlack[a] << 16);
-          const float rPass = MERGE_SCAN_SHIFTED_RADIUS ? ((sRad[a] - 1.5f * errAbs) - 1.2e-7f * sRad[a]) * (1.f - 1e-5f)   // (the shift taken back out, less the two roundings it cost)
-                                                       : sRad[a] * (1.f - 1e-5f);     // <= the row's exact initial radius
-          float shift = 0.f;
-          bool changed = false, ovf = false;
-          double a00 = 0, a01 = 0, a11 = 0;
-          unsigned cur = (unsigned)a;
-          for (int step = 0; step < MERGE_ROW_SLOTS; step++) {
-            unsigned best = 0xffffffffu;   // lowest listed partner above `cur`
-#pragma unroll
-            for (int k = 0; k < MERGE_ROW_SLOTS; k++) {
-              const unsigned j = it[k] & 0x3fffu;
-              const bool c = (it[k] != 0xffffffffu) & (j > cur) & (j < (best & 0x3fffu) || best == 0xffffffffu);
-              best = c ? it[k] : best;
-            }
-            if (best == 0xffffffffu) break;
-            const unsigned j = best & 0x3fffu;
-            cur = j;
-            bool pass = (best & 0x8000u) != 0u;  // verdict of phase 1b: valid while the row is in its initial state
-            if (!changed && !pass) continue;
-            const int pj = phys((int)j);
-            const double jw = sW[j], jx = pMX[pj], jy = pMY[pj];
-            const double jxx = pSXX[pj], jxy = pSXY[pj], jyy = pSYY[pj];
-            if (changed) {
-              const double e0 = jx - ax, e1 = jy - ay;
-              const double u0 = e0 * a00 + e1 * a01, u1 = e0 * a01 + e1 * a11;
-              bool far = (u0 * e0 + u1 * e1) > t2;
-              if (far) {
-                double j00, j01, j10, j11, jdet;
-                inv2(jxx, jxy, jxy, jyy, j00, j01, j10, j11, jdet);
-                const double g0 = -e0, g1 = -e1;
-                const double v0 = g0 * j00 + g1 * j01, v1 = g0 * j01 + g1 * j11;
-                far = (v0 * g0 + v1 * g1) > t2;
-              }
-              pass = !far && ((aw + jw) != 0.0);
-              if (!pass) continue;
-            } else {   // the row's first merge: its initial state goes to the backup first
-              plane(bk, cap, i, PL_W)[pa] = aw; plane(bk, cap, i, PL_MX)[pa] = ax; plane(bk, cap, i, PL_MY)[pa] = ay;
-              plane(bk, cap, i, PL_SXX)[pa] = axx; plane(bk, cap, i, PL_SXY)[pa] = axy; plane(bk, cap, i, PL_SYY)[pa] = ayy;
-            }
-            sRad[j] = -sRad[j];     // absorbed (final: nobody outside this lane's component ever looks at j)
-#ifdef RFS_PROFILE
-            dbgMerges++;
-#endif
-            const double w1 = aw, w2 = jw;
-            const double wm = w1 + w2;
-            const double xm = (ax * w1 + jx * w2) / wm, ym = (ay * w1 + jy * w2) / wm;
-            const double d10 = xm - ax, d11 = ym - ay, d20 = xm - jx, d21 = ym - jy;
-            const double nxx = (w1 * (axx + (f * d10) * d10) + w2 * (jxx + (f * d20) * d20)) / wm;
-            const double nxy = (w1 * (axy + (f * d10) * d11) + w2 * (jxy + (f * d20) * d21)) / wm;
-            const double nyy = (w1 * (ayy + (f * d11) * d11) + w2 * (jyy + (f * d21) * d21)) / wm;
-            ax = xm; ay = ym; axx = nxx; axy = nxy; ayy = nyy; aw = wm;
-            changed = true;
-            // Could an entry outside the list pass now?  Not while the row has moved / grown by less than its slack.
-            const double ab = merge_bound(t2, axx, axy, ayy);
-            shift += __builtin_amdgcn_sqrtf((float)(d10 * d10 + d11 * d11)) * (1.f + 4e-6f) + 1e-30f;
-            const float grow = __builtin_amdgcn_sqrtf((float)ab) * (1.f + 4e-6f) - rPass;
-            if (!(slack > shift + fmaxf(grow, 0.f))) { ovf = true; break; }
-            double a10, adet;
-            inv2(axx, axy, axy, ayy, a00, a01, a10, a11, adet);
-          }
-          if (changed) {   // (also on ovf: the mark tells the restore below which rows have a backup)
-            merged = true;
-            sRec[a] = rec & 0x01ffffffu;     // claim field 0: this row has merged
-            if (!ovf) {
-              sW[a] = aw;
-              pW[pa] = aw; pMX[pa] = ax; pMY[pa] = ay; pSXX[pa] = axx; pSXY[pa] = axy; pSYY[pa] = ayy;
-            }
-          }
-          if (ovf) { ovfAny = true; break; }
-        }
-        wave_sync();     // a component that continues in the next chunk of rows may change lanes
-#ifdef RFS_PROFILE
-        if (B.dbg && i == 7) { const int mt = (int)wave_max_u32((unsigned)dbgTrips); if (lane == 0) B.dbg[47] = mt; }
-#endif
-        if (__ballot(ovfAny) != 0ull) break;
-      }
-      DBG_TB(32, 13);
-      if (__ballot(ovfAny) == 0ull) {
-        compDone = true;
-        anyMerge = __ballot(merged) != 0ull;
-      } else {
-        // back to the initial state: holes of this pass come alive again, rows that merged take their initial values back
-#ifdef RFS_PROFILE
-        dbgFallbacks += 1000;
-#endif
-        wave_sync();
-        for (int m = lane; m < N; m += 64) {
-          const float r = sRad[m];
-          if (r < 0.f && r != -1.f) sRad[m] = -r;
-          const unsigned rec = sRec[m];
-          if ((rec >> 25) == 0u) {
-            const int pm = phys(m);
-            const double w0 = plane(bk, cap, i, PL_W)[pm];
-            // (a row whose first merge already failed the slack test was never written: putting its own values back is harmless)
-            sW[m] = w0;
-            pW[pm] = w0; pMX[pm] = plane(bk, cap, i, PL_MX)[pm]; pMY[pm] = plane(bk, cap, i, PL_MY)[pm];
-            pSXX[pm] = plane(bk, cap, i, PL_SXX)[pm]; pSXY[pm] = plane(bk, cap, i, PL_SXY)[pm]; pSYY[pm] = plane(bk, cap, i, PL_SYY)[pm];
-            sRec[m] = rec | MERGE_REC_NOCLAIM;
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the restored values are read back through global loads by other lanes below
-        wave_sync();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      }
-    }
-  }
-
-  for (int r0 = 0; !compDone && r0 < nRowsTotal; r0 += 64) {
+  // (Measured and dropped, round 6 -- profiles/r06b_ab_component_replay.txt, r06b_component_replay.patch: the replay by CONNECTED
+  //  COMPONENTS of the listed-pair graph, one component per lane walking its rows in the reference's order, no claims / validation /
+  //  re-walks.  Exact -- the full GPU suite and 1500 fuzz cases pass with it -- and 19 % slower: fused step 137.3 against 115.0 us at
+  //  configs[1].  The components are small (12-25 per particle, the largest 4-7 rows, tools/merge_components_study.py) but the label
+  //  propagation takes ~4 trips over the pair list (7.8 k cycles) and the busiest lane walks 3 rows one after the other (28 k) where the
+  //  speculative pass below walks all rows at once (15 k) and validates in 11 k.)
+  for (int r0 = 0; r0 < nRowsTotal; r0 += 64) {
     const int cnt = (nRowsTotal - r0 < 64) ? nRowsTotal - r0 : 64;
     // ---- speculative replay, one row per lane ----
     const int a = (lane < cnt) ? (int)sRows[r0 + lane] : 0;

@@ -52,7 +52,6 @@ print("update_map pass0: precompute %d, gates %d, maha+lik %d, scan+write %d, fo
 print("weight: key load + chunk sort %d, merge ranks + scatter %d, fallback check + sorted write-out %d" % (t[16+9]-t[16], t[16+10]-t[16+9], t[16+8]-t[16+10]))
 print("weight partitions: masks+components %d, log table %d, component masks/zero merge %d, enumeration %d; partitions %d" % (t[28]-t[27], t[29]-t[28], t[29]-t[29], t[30]-t[29], t[31]))
 print("merge phase2: rows %d, speculative %d, validate %d, tail %d" % (t[41]-t[34], t[42]-t[41], t[43]-t[42], t[35]-t[43]))
-print("merge phase2 by components (round 6): rows list %d, labels %d (%d propagation trips), component walks %d (%d walk trips of the busiest lane), tail %d" % (t[41]-t[34], t[44]-t[41], t[46], t[45]-t[44], t[47], t[35]-t[45]))
 print("merge fallbacks: unlistable %d, slack %d, >8 merges %d, claim conflicts %d of %d active rows" % (t[52], t[53], t[54], t[55], t[56]))
 print("merge: grid build %d, candidate scan %d; phase2 rows %d merges %d chunks %d N %d" % (t[40]-t[33], t[34]-t[40], t[48], t[49], t[50], t[51]))
 print("merge candidate scan (particle 7, 3 runs): neighbours examined per run %d; trips of four per chunk-wave iteration (max over the runs) %s" % (t[58] // 3, [int(t[k]) for k in (57, 59, 60, 61, 62, 63)]))

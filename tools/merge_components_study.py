@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Tuning aid (CPU, oracle): connected components of the merge's listed-pair graph at configs[1] -- rows per component, with all listed
 partners as edges and with the initially passing ones only (round 6: the component-parallel replay, measured and dropped)."""
-import sys, numpy as np
-sys.path.insert(0,'/root/repo')
+import os, sys, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_package
 pkg=load_package(); sc=pkg.scenarios
 from oracle import binding as ob
