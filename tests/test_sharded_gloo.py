@@ -128,6 +128,7 @@ def single_process(pkg, ob, n_total, force_resample, big=False):
     f = ob.OracleFilter(n_total)
     sc.load_scenario(f, scen)
     sh = pkg.sharded.ShardedRBPHDFilter(f)     # world 1: same host code path, no collectives
+    assert sh.defer_normalisation is False and sh._handover is None   # (round 6: the trailing normalisation is opt-in; the default keeps the reference's order)
     sh.effNParticles_t = n_total + 1.0 if force_resample else 1e-9
     fired = sh.resample(u01=0.4321) if big else sh.update(scen["Z"], u01=0.4321)
     return f, fired
