@@ -1102,6 +1102,98 @@ __device__ __forceinline__ void step_post_out(const double *weight, int N, int *
     __hip_atomic_store(&SO.hostFlag[1], SO.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+// Launch order of the NEXT step's particles from THIS step's measured durations (round 6; the Victoria Park step: one wavefront per
+// particle, 5000 particles on ~3000 resident wave slots, i.e. two rounds whose second ends with whatever started last -- a third of the
+// launch was tail).  With the particles that took longest first, the tail is made of short ones: 190.6 -> 163.7 us at configs[3] with the
+// durations of the previous launch, 164.3 with eight classes of them (tools/vp_order_study.py; shortest first: 196.4).  A particle's cost
+// repeats from step to step (r = 0.85 in a running filter, tools/vp_cost_repeat.py).  The step's post kernel sorts the particles into
+// STEP_ORDER_CLASSES equal-width classes of duration, longest first, ONE CLASS PER WORKGROUP (blocks 1 .. STEP_ORDER_CLASSES, beside
+// block 0's weight sums), in ONE pass over the durations: a thread reads its share, counts the particles of the classes ahead of its
+// own block's and keeps a bit per particle of its own class; wave sums, one barrier, and the class is written where it starts --
+// members in (wavefront, bit, lane) order, so the order array is a function of the durations alone.  No workgroup waits for another and
+// nothing is zeroed between steps.  The class limits are the extrema of the PREVIOUS step's durations (`ext`, two pairs used in turn:
+// the first class block writes the pair the next launch reads; all zero at the start = one class = the identity order): with this
+// step's own extrema every block would have to read the durations twice.  What this costs on the post kernel's critical path at
+// n = 5000 (profiles/r06t): the whole sort in block 1 with an LDS atomic per particle 6.8 us; a class per block with the extrema first
+// and an atomic per ballot 10.6 us (2 fetch rounds x 3 passes); this form: see there.
+#ifndef STEP_ORDER_CLASSES
+#define STEP_ORDER_CLASSES 32
+#endif
+#define STEP_ORDER_QUADS 8         // 16-byte loads a thread has in flight at a time (a round: 32 durations)
+#define STEP_ORDER_MAX_ROUNDS 2    // (a bit per particle in one 64-bit word: n <= 64 x blockDim, else the order is left as it is)
+#ifndef STEP_ORDER_STOP
+#define STEP_ORDER_STOP 9          // (tuning hook: 0 nothing | 1 the pass, no barrier | 2 all but the order's stores)
+#endif
+struct StepOrderArg {
+  const float *cost;   // [n] ticks per particle, written by the step kernel (nullptr: no ordering)
+  int *order;          // [n] launch slot -> particle, read by the next step kernel
+  int n;
+  float *ext;          // [4] {lo, hi} x 2: extrema of the durations, read at [2 parity], written at [2 (1 - parity)]
+  int parity;
+};
+__device__ __forceinline__ void step_cost_order_class(const StepOrderArg &O, const int c) {
+  __shared__ unsigned sLo, sHi;
+  __shared__ int sBase, sMine[16];
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+  constexpr int PER_ROUND = 4 * STEP_ORDER_QUADS;
+  const int rounds = (O.n + nt * PER_ROUND - 1) / (nt * PER_ROUND);
+  if (rounds > STEP_ORDER_MAX_ROUNDS || STEP_ORDER_STOP == 0) return;    // (block-uniform; the order array keeps the permutation it holds)
+  if (tid == 0) { sLo = 0xffffffffu; sHi = 0u; sBase = 0; }
+  __syncthreads();
+  const float fLo = O.ext[2 * O.parity], fHi = O.ext[2 * O.parity + 1];
+  const float scale = (fHi > fLo) ? (float)STEP_ORDER_CLASSES / (fHi - fLo) : 0.f;
+  unsigned lo = 0xffffffffu, hi = 0u;            // durations are positive floats: their bit patterns order like the values
+  unsigned long long mine = 0ull;                // bit 32 r + 4 j + e: particle 4 ((r QUADS + j) nt + tid) + e
+  int ahead = 0;
+  const float4 *const cost4 = (const float4 *)O.cost;       // (the array is 16-byte aligned and four floats longer than its capacity)
+  for (int r = 0; r < rounds; r++) {
+    float4 v[STEP_ORDER_QUADS];
+#pragma unroll
+    for (int j = 0; j < STEP_ORDER_QUADS; j++) {
+      const int k4 = (r * STEP_ORDER_QUADS + j) * nt + tid;
+      v[j] = 4 * k4 < O.n ? cost4[k4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < STEP_ORDER_QUADS; j++) {
+      const int k = 4 * ((r * STEP_ORDER_QUADS + j) * nt + tid);
+      const float ve[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        if (k + e >= O.n) continue;
+        const float x = fmaxf(ve[e], 0.f);
+        int q = (int)((fHi - x) * scale);        // class 0 = the longest
+        q = q < 0 ? 0 : (q >= STEP_ORDER_CLASSES ? STEP_ORDER_CLASSES - 1 : q);
+        ahead += q < c ? 1 : 0;
+        if (q == c) mine |= 1ull << (r * PER_ROUND + 4 * j + e);
+        const unsigned b = __float_as_uint(x);
+        lo = min(lo, b); hi = max(hi, b);
+      }
+    }
+  }
+  if (STEP_ORDER_STOP == 1) { if (ahead + (int)mine + (int)lo + (int)hi == -12345) O.order[0] = 0; return; }
+  const int aheadW = wave_sum_i(ahead), mineW = wave_sum_i(__popcll(mine));
+  if (lane == 0) { if (aheadW) atomicAdd(&sBase, aheadW); sMine[wave] = mineW; }
+  if (c == 0) {                                  // (block-uniform) the limits the next launch's classes use
+    lo = wave_min_u32(lo); hi = wave_max_u32(hi);
+    if (lane == 0) { atomicMin(&sLo, lo); atomicMax(&sHi, hi); }
+  }
+  __syncthreads();
+  if (c == 0 && tid == 0 && sLo <= sHi) { O.ext[2 * (1 - O.parity)] = __uint_as_float(sLo); O.ext[2 * (1 - O.parity) + 1] = __uint_as_float(sHi); }
+  int total = 0, before = 0;
+  for (int w = 0; w < nw; w++) { const int m = sMine[w]; total += m; before += w < wave ? m : 0; }
+  if (total == 0) return;
+  int at = sBase + before;                       // a wavefront's members behind those of the wavefronts before it
+  const int nbits = rounds * PER_ROUND;
+  if (STEP_ORDER_STOP == 2) return;
+  for (int b = 0; b < nbits; b++) {
+    const bool is = (mine >> b) & 1ull;
+    const unsigned long long m = __ballot(is);
+    if (m == 0ull) continue;                     // (wave-uniform)
+    if (is) O.order[at + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = 4 * ((b >> 2) * nt + tid) + (b & 3);
+    at += __popcll(m);
+  }
+}
+
 // Longest jobs first: a job's duration grows with its extended dimension (2.3 ms at 9, 10 ms at 15 at configs[4]), the jobs are
 // queued in whatever order the particles' weighting phases reach them, and more jobs than resident workgroups means a second
 // round -- in which a 10 ms job started after the first 2 ms ones have finished sets the launch's length.  One workgroup sorts the
@@ -1143,10 +1235,13 @@ __global__ __launch_bounds__(1024) void murty_order_kernel(MurtyQueue Q) {
 template <int W, int WAVES_PER_EU>
 __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(WAVES_PER_EU > 0 ? WAVES_PER_EU : 1, WAVES_PER_EU > 0 ? WAVES_PER_EU : 8)))
 void murty_jobs_kernel(MurtyQueue Q, MurtyScratch MS, int *err, double *weight, int N, double *sums,
-                                                                         int normalize, ZArg zarg, double *dZ, int nZdoubles, int *hostSeen, int ordered, StepOut SO) {
+                                                                         int normalize, ZArg zarg, double *dZ, int nZdoubles, int *hostSeen, int ordered, StepOut SO,
+                                                                         StepOrderArg SOrd) {
   // (a fused step carries the measurement set in its kernel arguments; the device copy the next predict reads is written here)
   if (blockIdx.x == 0 && dZ)
     for (int t = threadIdx.x; t < nZdoubles; t += blockDim.x) dZ[t] = zarg.v[t];
+  if (SOrd.cost && blockIdx.x >= 1 && blockIdx.x <= STEP_ORDER_CLASSES)     // (every launch has >= 64 workgroups; block-uniform)
+    step_cost_order_class(SOrd, (int)blockIdx.x - 1);
   const int nJobs = min(*Q.count, Q.maxJobs);
   if (nJobs == 0) {
     if (blockIdx.x == 0) { step_post_tail(weight, N, sums, normalize, SO.preDiv, SO.collSeq, SO.collNeed, SO.collPost, err); step_post_out(weight, N, err, SO); }
@@ -1327,7 +1422,8 @@ static inline void murty_free(MurtyQueue &Q, MurtyScratch &MS) {
 // instance (four waves, no register cap, no scratch set-up) on the same grid; a filter that has shown Murty work gets the capped
 // eight-wave instance and the job ordering from the next step on.  Correct either way: jobs are strided over whatever grid there is.
 static inline int murty_launch(MurtyQueue &Q, MurtyScratch &MS, Buffers &B, hipStream_t stream, double *sums = nullptr, int normalize = 0,
-                               const ZArg *za = nullptr, int nZdoubles = 0, int *hostSeen = nullptr, const StepOut &SO = StepOut{nullptr, nullptr, 0, nullptr, nullptr, 0, 0}) {
+                               const ZArg *za = nullptr, int nZdoubles = 0, int *hostSeen = nullptr, const StepOut &SO = StepOut{nullptr, nullptr, 0, nullptr, nullptr, 0, 0},
+                               const StepOrderArg &SOrd = StepOrderArg{nullptr, nullptr, 0, nullptr, 0}) {
   int blocks = std::min(MURTY_JOB_BLOCKS, Q.maxJobs);
   // (RFSGPU_MURTY_FIRST_BLOCKS: grid of the light instance, for A/B runs -- tools/murty_first_step.py)
   static const int firstBlocks = [] { const char *e = getenv("RFSGPU_MURTY_FIRST_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : MURTY_FIRST_BLOCKS; }();
@@ -1336,12 +1432,14 @@ static inline int murty_launch(MurtyQueue &Q, MurtyScratch &MS, Buffers &B, hipS
   // (a filter that has shown Murty work -- or a caller without the pinned flag -- gets its jobs ordered, longest first; ~5 us,
   //  and only then)
   const int ordered = (Q.order && (!hostSeen || *hostSeen != 0)) ? 1 : 0;
+  // (the step-order classes take one workgroup each after block 0; a grid without them leaves the order it has -- a permutation already)
+  const StepOrderArg sord = blocks > STEP_ORDER_CLASSES ? SOrd : StepOrderArg{nullptr, nullptr, 0, nullptr, 0};
   if (ordered) murty_order_kernel<<<1, 1024, 0, stream>>>(Q);
   if (hostSeen && *hostSeen == 0)
     murty_jobs_kernel<MURTY_LIGHT_WAVES, 0><<<blocks, 64 * MURTY_LIGHT_WAVES, 0, stream>>>(Q, MS, B.err, B.weight, B.N, sums, normalize, za ? *za : none,
-                                                                                         za ? B.Z : nullptr, nZdoubles, hostSeen, ordered, SO);
+                                                                                         za ? B.Z : nullptr, nZdoubles, hostSeen, ordered, SO, sord);
   else
     murty_jobs_kernel<MURTY_JOB_WAVES, MURTY_WAVES_PER_EU><<<blocks, 64 * MURTY_JOB_WAVES, 0, stream>>>(Q, MS, B.err, B.weight, B.N, sums, normalize,
-                                                                                                      za ? *za : none, za ? B.Z : nullptr, nZdoubles, hostSeen, ordered, SO);
+                                                                                                      za ? *za : none, za ? B.Z : nullptr, nZdoubles, hostSeen, ordered, SO, sord);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }

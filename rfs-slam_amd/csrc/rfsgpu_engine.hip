@@ -80,6 +80,11 @@ struct rfsgpu_filter {
   int stagePendingSlot = -1;          // a staging slot whose event must be recorded behind the step that reads it
   bool denseIntensity = false;        // RFSGPU_DENSE_INTENSITY=1 at create: deviation 9 off (the dense loop for every mixture size), for runs against a future pinned fixture
   bool ioPull = true;                 // RFSGPU_IO_PULL=0: inputs by copy commands, outputs by copies + a stream synchronisation (A/B, rounds 3-4 form)
+  int vpParity = 0;                   // which pair of duration extrema (vpCost[Ncap ..]) the next post kernel reads
+  float *vpCost = nullptr;            // [Ncap + 4] Victoria Park fused step: last measured duration per particle (100 MHz ticks)
+  int *vpOrder = nullptr;             // [Ncap] launch slot -> particle (identity until the first post kernel has sorted the costs)
+  int vpOrderN = -1;                  // particle count the order array is valid for
+  int vpOrderMode = 2;                // 0 slot == particle | 1 a host-given order, frozen | 2 re-sorted by every step's post kernel (default; RFSGPU_VP_COST_ORDER=0: 0)
   int collProbeSeq = 0;               // probes made so far (rfsgpu_collective_probe)
   int *dCollSeq = nullptr;            // [2 + 2] device: {number of the last step whose sums are out, number of the last step whose collective is done} (rfsgpu_step_async_trailing)
   int collStep = 0;                   // steps issued in the event-free trailing form
@@ -373,7 +378,7 @@ void rfsgpu_destroy(rfsgpu_filter *f) {
   Buffers &B = f->B;
   hipFree(f->snapSlab); hipFree(f->snapWeight); hipFree(f->snapCount); hipFree(f->snapFov); hipFree(f->snapUnused);
   for (auto &r : f->stateRing) { hipFree(r.slab); hipFree(r.weight); hipFree(r.count); hipFree(r.fov); hipFree(r.unused); }
-  hipFree(B.slab[0]); hipFree(B.slab[1]); hipFree(B.count); hipFree(B.pose); hipFree(f->poseAlt); hipFree(f->dCollSeq); hipFree(B.poseCov); hipFree(B.weight);
+  hipFree(B.slab[0]); hipFree(B.slab[1]); hipFree(B.count); hipFree(B.pose); hipFree(f->poseAlt); hipFree(f->dCollSeq); if (f->vpCost) hipFree(f->vpCost); if (f->vpOrder) hipFree(f->vpOrder); hipFree(B.poseCov); hipFree(B.weight);
   hipFree(B.unusedMask); hipFree(B.nInFov); hipFree(B.err); hipFree(B.Z); hipFree(f->ownSums); hipFree(f->dSrcSlot); if (f->dRowSlots) hipFree(f->dRowSlots); if (f->fsArena) hipFree(f->fsArena); if (f->mhArena) hipFree(f->mhArena); if (f->mhInts) hipFree(f->mhInts);
   if (f->dInhParent) hipFree(f->dInhParent);
   if (f->dInhLevel) hipFree(f->dInhLevel);
@@ -954,6 +959,7 @@ int rfsgpu_prune(rfsgpu_filter *f) {
 // All four phases back to back on the stream, ONE host sync at the end (RBPHDFilter::update body :444-523).
 static const StepOut NO_OUT{nullptr, nullptr, 0, nullptr, nullptr, 0, 0};
 static const StepPredict NO_HEAD{0, 0, nullptr, nullptr, 0};
+static int vp_order_buffers(rfsgpu_filter *f);
 static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool with_sums, int normalize, const StepPredict &sp = NO_HEAD, const StepOut &so = NO_OUT,
                              hipEvent_t waitBeforePost = nullptr);
 int rfsgpu_update(rfsgpu_filter *f, const double *z, int n_z) {
@@ -1152,19 +1158,25 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
     const int ec = eval_cap(f), useW = f->cfg.useClusterProcess ? 0 : 1;
     const size_t shared = vp_shared_lds_bytes(f->nZ, f->B.nScan), per = vp_step_lds_bytes_per_wave(f->cap, ec, f->nZ);
     f->lastStepVariant[0] = 1; f->lastStepVariant[1] = 0; f->lastStepVariant[2] = 0; f->lastStepVariant[3] = 1;
+    // cost-ordered launch (round 6, murty.h step_cost_order_class): this step's particles in the order the previous step's post kernel
+    // left -- longest first --, this step's durations captured for the next one
+    if ((rc = vp_order_buffers(f)) != RFSGPU_OK) return rc;
+    const int *vpOrd = f->vpOrderMode ? f->vpOrder : nullptr;
+    const StepOrderArg sord{f->vpOrderMode == 2 ? f->vpCost : nullptr, f->vpOrder, f->N, f->vpCost + f->Ncap, f->vpParity};
+    if (f->vpOrderMode == 2) f->vpParity ^= 1;
     if (shared + 2 * per <= (size_t)64 * 1024) {
       const size_t b = shared + 2 * per;
       if ((rc = set_lds(f, vp_step_fused_kernel<2>, b)) != RFSGPU_OK) return rc;
-      vp_step_fused_kernel<2><<<(f->N + 1) / 2, 128, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
+      vp_step_fused_kernel<2><<<(f->N + 1) / 2, 128, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za, f->vpCost, vpOrd);
     } else {
       const size_t b = shared + per;
       if ((rc = set_lds(f, vp_step_fused_kernel<1>, b)) != RFSGPU_OK) return rc;
-      vp_step_fused_kernel<1><<<f->N, 64, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za);
+      vp_step_fused_kernel<1><<<f->N, 64, b, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za, f->vpCost, vpOrd);
     }
     HIPCHK(hipGetLastError());
     if (timed) HIPCHK(hipEventRecord(e[3], f->stream));
     if (waitBeforePost) HIPCHK(hipStreamWaitEvent(f->stream, waitBeforePost, 0));
-    if (murty_launch(f->Q, f->MS, f->B, f->stream, with_sums ? f->dSums : nullptr, normalize, &za, 3 * n_z, f->hJobCount, so) != 0) return fail(f, RFSGPU_ERR_HIP, "post kernel launch failed");
+    if (murty_launch(f->Q, f->MS, f->B, f->stream, with_sums ? f->dSums : nullptr, normalize, &za, 3 * n_z, f->hJobCount, so, sord) != 0) return fail(f, RFSGPU_ERR_HIP, "post kernel launch failed");
     if (timed) HIPCHK(hipEventRecord(e[1], f->stream));
     f->cur ^= 1;
     if (timed) {
@@ -1299,6 +1311,40 @@ int rfsgpu_collective_probe(rfsgpu_filter *f, void *hip_stream, int *side_by_sid
   int verdict = 0;
   HIPCHK(hipMemcpy(&verdict, f->dCollSeq + 3, sizeof(int), hipMemcpyDeviceToHost));
   *side_by_side = verdict == k ? 1 : 0;
+  return RFSGPU_OK;
+}
+
+// Buffers of the Victoria Park step's cost-ordered launch, created with the first fused step: durations (zero) and the identity order.
+__global__ void iota_kernel(int *p, int n) { const int k = blockIdx.x * blockDim.x + threadIdx.x; if (k < n) p[k] = k; }
+static int vp_order_buffers(rfsgpu_filter *f) {
+  if (f->vpCost && f->vpOrder && f->vpOrderN == f->N) return RFSGPU_OK;
+  static const bool off = [] { const char *e = getenv("RFSGPU_VP_COST_ORDER"); return e && atoi(e) == 0; }();
+  if (off) f->vpOrderMode = 0;
+  if (!f->vpCost) { HIPCHK(hipMalloc(&f->vpCost, (size_t)(f->Ncap + 4) * sizeof(float))); HIPCHK(hipMemsetAsync(f->vpCost, 0, (size_t)(f->Ncap + 4) * sizeof(float), f->stream)); }
+  if (!f->vpOrder) HIPCHK(hipMalloc(&f->vpOrder, (size_t)f->Ncap * sizeof(int)));
+  iota_kernel<<<(f->Ncap + 255) / 256, 256, 0, f->stream>>>(f->vpOrder, f->Ncap);      // (first use, or the particle count has changed: every slot its own particle)
+  HIPCHK(hipGetLastError());
+  f->vpOrderN = f->N;
+  return RFSGPU_OK;
+}
+// [bench] / [test] The Victoria Park step's launch order.  mode 0: slot == particle; 1: order_in (slot -> particle, a permutation of 0..N-1),
+// frozen; 2: re-sorted by every step's post kernel from that step's durations, longest first (the default).  cost_out (N floats, may be
+// null): the last step's duration per particle, 100 MHz ticks.
+int rfsgpu_vp_launch_order(rfsgpu_filter *f, int mode, const int *order_in, float *cost_out) {
+  CHECK_HANDLE(f);
+  if (f->D != 3) return fail(f, RFSGPU_ERR_INVALID, "vp_launch_order: Victoria Park model only");
+  if (mode < 0 || mode > 2 || (mode == 1 && !order_in)) return fail(f, RFSGPU_ERR_INVALID, "vp_launch_order: mode 0, 1 (with an order) or 2");
+  hipSetDevice(f->device);
+  int rc = vp_order_buffers(f);
+  if (rc != RFSGPU_OK) return rc;
+  HIPCHK(hipStreamSynchronize(f->stream));
+  if (cost_out) HIPCHK(hipMemcpy(cost_out, f->vpCost, (size_t)f->N * sizeof(float), hipMemcpyDeviceToHost));
+  if (mode == 1) {
+    std::vector<char> seen((size_t)f->N, 0);
+    for (int k = 0; k < f->N; k++) { const int p = order_in[k]; if (p < 0 || p >= f->N || seen[p]) return fail(f, RFSGPU_ERR_INVALID, "vp_launch_order: not a permutation"); seen[p] = 1; }
+    HIPCHK(hipMemcpy(f->vpOrder, order_in, (size_t)f->N * sizeof(int), hipMemcpyHostToDevice));
+  }
+  f->vpOrderMode = mode;
   return RFSGPU_OK;
 }
 

@@ -1193,7 +1193,7 @@ __global__ __launch_bounds__(WPB * 64)
 #if VP_STEP_WAVES_PER_EU > 0
 __attribute__((amdgpu_waves_per_eu(VP_STEP_WAVES_PER_EU)))
 #endif
-void vp_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, int useWeighting, MurtyQueue Q, ZArg zarg) {
+void vp_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, int useWeighting, MurtyQueue Q, ZArg zarg, float *stepCost, const int *stepOrder) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double *sZ = reinterpret_cast<double *>(smem_raw);
   double *sScan = sZ + 3 * nZ;
@@ -1202,8 +1202,13 @@ void vp_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, int
   for (int t = threadIdx.x; t < 3 * nZ; t += WPB * 64) sZ[t] = zarg.v[t];     // the measurement set rides in the kernel arguments
   for (int t = threadIdx.x; t < B.nScan; t += WPB * 64) sScan[t] = B.scan[t];
   __syncthreads();
-  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
-  if (i >= B.N) return;
+  // stepOrder (may be null): launch slot -> particle.  A launch of 5000 one-wave particles on ~3000 wave slots ends with the waves that
+  // started last; with the particles that took longest in the PREVIOUS step first, the tail is made of short ones (round 6; stepCost
+  // receives this step's duration per particle, 100 MHz ticks).  Which particle a slot works on changes nothing in any result.
+  const int slot = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave);
+  if (slot >= B.N) return;
+  const int i = stepOrder ? __builtin_amdgcn_readfirstlane(stepOrder[slot]) : slot;
+  const long long tStart = stepCost ? (long long)wall_clock64() : 0ll;
   const size_t per = vp_step_lds_bytes_per_wave(B.cap, evalCap, nZ);
   unsigned char *wmem = smem_raw + vp_shared_lds_bytes(nZ, B.nScan) + (size_t)wave * per;
   unsigned char *sPdIdx = wmem + per - (((size_t)B.cap + 15) & ~(size_t)15);
@@ -1233,6 +1238,7 @@ void vp_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, int
   if (fd && lane == 0) fd[2] = (long long)wall_clock64();
 #endif
   vp_merge_particle<true>(B, P, cur, cur ^ 1, i, lane, wmem, perm);
+  if (stepCost && lane == 0) stepCost[i] = (float)((long long)wall_clock64() - tStart);
 #ifdef RFS_PROFILE
   if (fd && lane == 0) fd[3] = (long long)wall_clock64();
 #endif

@@ -1429,6 +1429,49 @@ def test_vp_fused_update_and_birth_candidates_multi_step(pkg, ob, sc):
     assert promoted > 0, "scenario never produced a birth candidate"
 
 
+@pytest.mark.parametrize("n_particles,n_landmarks,n_z,stride", [(150, 45, 12, 1), (4700, 24, 8, 97), (9000, 10, 4, 499), (20000, 6, 3, 1999)])
+def test_vp_step_results_do_not_depend_on_the_launch_order(pkg, sc, n_particles, n_landmarks, n_z, stride):
+    """Round 6: the Victoria Park step launches its particles in the order the previous step's post kernel sorted them into (longest
+    first, one class of durations per workgroup, csrc/murty.h step_cost_order_class; 190 -> 166 us at configs[3]).  (4700 particles:
+    one fetch round of the 256-thread post kernel with every class populated; 9000: two rounds; 20000: more than the sort's 64
+    particles per thread, the order stays what it was.)  Which wave slot works on which particle must change no
+    result: the same predict / update steps with slot == particle (mode 0), with the automatic order (mode 2, the default) and with a
+    reversed and a random frozen order (mode 1) give the same bits -- weights, maps, unused lists, FOV counts; the measured durations
+    come back per particle; a list that is not a permutation is refused."""
+    scen = sc.make_vp_scenario(n_particles=n_particles, n_landmarks=n_landmarks, n_z=n_z, seed=94)
+    n = scen["n"]
+    rng = np.random.default_rng(3)
+    orders = [("off", 0, None), ("auto", 2, None), ("reversed", 1, np.arange(n - 1, -1, -1)), ("random", 1, rng.permutation(n))]
+    fs = []
+    for name, mode, order in orders:
+        f = pkg.RBPHDFilter(n, gm_capacity=256, model=pkg.capi.MODEL_VICTORIAPARK_3D)
+        sc.load_scenario(f, scen)
+        f.vp_launch_order(order=order, mode=mode, want_costs=False)
+        fs.append(f)
+    zr = np.random.default_rng(8)
+    for step in range(4):
+        Z = scen["Z"] + zr.normal(0, 1, scen["Z"].shape) * np.array([0.05, 0.002, 0.01])
+        for f in fs:
+            f.predict_map(True)
+            f.update(Z)
+        a = fs[0]
+        for (name, _, _), b in zip(orders[1:], fs[1:]):
+            assert np.array_equal(a.get_weights(), b.get_weights()), (name, step)
+            assert np.array_equal(a.gm_sizes(), b.gm_sizes()), (name, step)
+            for i in range(0, n, stride):
+                for x, y in zip(a.export_gm(i), b.export_gm(i)):
+                    assert np.array_equal(x, y), (name, step, i)
+                assert list(a.get_unused(i)) == list(b.get_unused(i)) and a.landmarks_in_fov(i) == b.landmarks_in_fov(i)
+        for f in fs:
+            s_ = f.weight_sums(); f.normalize_weights(s_[0])
+    cost = fs[1].vp_launch_order(mode=2)
+    assert cost.shape == (n,) and np.all(cost > 0) and np.all(np.isfinite(cost))
+    with pytest.raises(RuntimeError):
+        fs[1].vp_launch_order(order=np.zeros(n, dtype=np.int32))
+    for f in fs:
+        f.close()
+
+
 @pytest.mark.parametrize("kw", [dict(n_particles=40, n_landmarks=45, n_z=12, seed=91), dict(n_particles=33, n_landmarks=130, n_z=18, seed=92),
                                 dict(n_particles=12, n_landmarks=20, n_z=7, seed=93, use_cluster=1)])
 def test_vp_fused_step_is_bit_identical_to_the_three_kernel_path(pkg, sc, kw):
