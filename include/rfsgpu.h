@@ -370,11 +370,14 @@ double rfsgpu_post_kernel_avg_ns(const rfsgpu_filter *f);
  * TimingInfo (rfsgpu_get_timing) books a sampled step once for itself and once for every un-sampled step since the previous
  * sample, i.e. it stays an estimate of the whole run's device time.  `every` = 1 restores per-step events. */
 int rfsgpu_set_step_timing_stride(rfsgpu_filter *f, int every);
-/* [bench] Victoria Park step (one wavefront per particle, more particles than resident wave slots): cost_out (N floats, may be NULL)
- * receives every particle's duration in the last step (100 MHz ticks; 0 before the first step after this call switched the capture
- * on); mode 1 + order_in (a permutation of 0..N-1: launch slot -> particle) makes the following steps launch their particles in that
- * order, mode 0 goes back to slot == particle.  Results do not depend on the order. */
-int rfsgpu_vp_launch_order(rfsgpu_filter *f, int mode, const int *order_in, float *cost_out);
+/* [bench] Launch order of the fused step's particles, for launches with more workgroups than the GPU holds at once (the Victoria Park
+ * step: one wavefront per particle; the 2-D step when its instantiation runs without phase priorities): such a launch lasts as long as
+ * whatever started last, so the step kernel records every particle's duration and the post kernel sorts them for the next step, longest
+ * first (mode 2, the default; RFSGPU_VP_COST_ORDER=0 in the environment: mode 0).  cost_out (N floats, may be NULL) receives every
+ * particle's duration in the last step (100 MHz ticks; 0 where the launch did not capture them); mode 1 + order_in (a permutation of
+ * 0..N-1: launch slot -> particle) freezes that order for the following steps, mode 0 goes back to slot == particle.  Results do not
+ * depend on the order. */
+int rfsgpu_step_launch_order(rfsgpu_filter *f, int mode, const int *order_in, float *cost_out);
 #endif /* RFSGPU_ENABLE_BENCH_API */
 /* The same four phases one at a time (used by the parity tests and by profiling):          */
 /* [test] Murty-200 partition sums of n_jobs given extended tables (n_k x n_k row-major, back to back, n_k = nR[k] + nC[k] <= 64) by the

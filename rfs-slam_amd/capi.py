@@ -113,7 +113,7 @@ ABI_SYMBOLS = [
     "get_timing", "reset_timing", "synchronize", "stream", "last_kernel_ns", "last_step_variant", "mat_perm", "mat_perm_last_kernel_ms",
     "set_stream", "bind_weight_sums_buffer", "save_state", "restore_state", "state_ring_create", "state_ring_seed", "state_ring_next", "import_aux",
     "set_model_victoriapark", "set_laser_scan", "export_birth_candidates", "import_birth_candidates",
-    "update_async", "kernel_time_stats", "post_kernel_avg_ns", "set_step_timing_stride", "vp_launch_order",
+    "update_async", "kernel_time_stats", "post_kernel_avg_ns", "set_step_timing_stride", "step_launch_order",
     "default_fastslam_config", "set_fastslam_config", "get_fastslam_config", "fastslam_update",
     "normalize_weights_parts", "create_ex", "n_particles", "max_particles", "resample_apply_n",
     "fastslam_set_resample_occured", "particle_parents", "vp_probe_pd",

@@ -51,6 +51,9 @@ __host__ __device__ inline size_t merge_lds_bytes_per_wave(int cap, int gridLog 
 // passes the exact test against the initial states | [23:20] number of listed survivors (15 = not listable) |
 // [19:0] offset of the row's contiguous segment in the pair list.
 #define MERGE_REC_NOCLAIM 0xfe000000u
+#ifndef MERGE_VALIDATE_ROUNDS
+#define MERGE_VALIDATE_ROUNDS 1   // phase 2 validates in sub-rounds (0: rows after the first conflict one by one, the form of rounds 2-5)
+#endif
 #define MERGE_REC_ISROW 0x01000000u
 // + cross-wave reduction scratch ([waves][8] floats) when a workgroup of several waves works on one particle
 __host__ __device__ inline size_t merge_lds_bytes_per_block(int cap, int wavesPerParticle, int gridLog = 5) {
@@ -145,7 +148,8 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
 #ifdef RFS_PROFILE
   const long long dbgT0 = (long long)__builtin_readcyclecounter();
   long long dbgT2 = 0, dbgT3 = 0;
-  int dbgFallbacks = 0, dbgSlackN = 0, dbgUnlistN = 0;
+  int dbgFallbacks = 0, dbgSlackN = 0, dbgUnlistN = 0, dbgSerial = 0, dbgRewalks = 0;
+  long long dbgRewalkCycles = 0;
   unsigned dbgPairs = 0;
   if (B.dbg && tid == 0) B.dbg[64 + 4 * (size_t)i + 3] = 0;
   __syncthreads();
@@ -665,6 +669,98 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     };
     if (active) walk();
     wave_sync();
+#ifndef MERGE_P2_BOOST
+#define MERGE_P2_BOOST 22       // rows left to validate one by one from which the workgroup's issue priority goes up (0: never)
+#define MERGE_P2_BOOST_PRIO 2
+#endif
+#if MERGE_VALIDATE_ROUNDS
+    // Validation in sub-rounds (round 6).  `pending`: the rows of this round that are not final yet.  Per sub-round: the pending lanes
+    // claim what they absorbed (the lane in the top bits of the entry's record, lowest lane wins); `conflict`: the lane lost a claim
+    // (or could not finish its row).  A row is absorbed exactly when the (lowest) lane claiming it is itself alive: alive(l) =
+    // !claimed(a_l) || !alive(claimer(a_l)), claimer < l -- resolved by iterating to the fixed point (chain depth, usually 1-2 trips).
+    // Before the first lane that is alive AND in conflict this is exact: an alive lane without conflict holds the lowest claim on
+    // everything it absorbed, and any other claimer of those entries would be alive-and-in-conflict itself or dead.  Those rows commit
+    // together.  Then, instead of validating the rest one by one (rounds 2-5: p50 11 rows and 3 one-lane re-walks of ~2.5 k cycles
+    // each per particle, the slowest particles 26 and 11 -- and a launch ends with those), the rest goes through the same procedure
+    // again: rows absorbed by now drop out, EVERY row that absorbed an entry that has gone since walks again -- all of them at once,
+    // against the present liveness --, the claims are cleared and made again by the pending lanes only.  A walk depends on the liveness
+    // only through the entries it absorbed (an entry it met and left is as good as a hole), so a row none of whose entries has gone has
+    // the walk it would have now; the lowest pending lane, re-walked with every earlier row final, wins all its claims: each sub-round
+    // settles at least that row, and as many more as have no real overlap (chain depth instead of row count).  A row that cannot be
+    // finished from its list is replayed by the whole wave (the reference's scan) when it is the lowest pending one.
+    bool pendLane = active;
+    unsigned long long commit = 0ull;
+    const unsigned long long actm = __ballot(active);
+    while (true) {
+      if (pendLane)
+        for (int k = 0; k < nAbs; k++) {
+          const unsigned e = sSpec[lane * 8 + k];
+          atomicMin(&sRec[e], ((unsigned)lane << 25) | (sRec[e] & 0x01ffffffu));
+        }
+      wave_sync();
+      DBG_TB(32, 10);
+      bool conflict = ovf;
+      bool claimedRow = false;
+      unsigned claimer = 0;
+      if (pendLane) {
+        claimer = sRec[a] >> 25;
+        claimedRow = claimer != 0x7fu;
+        claimer &= 63u;
+        for (int k = 0; k < nAbs; k++) conflict |= (sRec[sSpec[lane * 8 + k]] >> 25) != (unsigned)lane;
+      }
+      const unsigned long long pendm = __ballot(pendLane);
+      unsigned long long alivem = __ballot(pendLane & !claimedRow);
+      for (int it = 0; it < 64; it++) {
+        const unsigned long long nm = __ballot(pendLane & (!claimedRow | !((alivem >> claimer) & 1ull)));
+        if (nm == alivem) break;
+        alivem = nm;
+      }
+      const unsigned long long cm = __ballot(conflict & pendLane) & alivem;
+#ifdef RFS_PROFILE
+      dbgSlackN += __popcll(__ballot(pendLane && (dbgWhy & 2) != 0));
+      dbgUnlistN += __popcll(__ballot(pendLane && (dbgWhy & 1) != 0));
+      if (B.dbg && i == 7 && pendm == actm) {
+        const int w1 = __popcll(__ballot(dbgWhy & 1)), w2 = __popcll(__ballot(dbgWhy & 2)), w4 = __popcll(__ballot(dbgWhy & 4)), wc = __popcll(__ballot(conflict & active & !ovf));
+        if (lane == 0) { B.dbg[52] = w1; B.dbg[53] = w2; B.dbg[54] = w4; B.dbg[55] = wc; B.dbg[56] = __popcll(actm); }
+      }
+      dbgSerial++;
+#endif
+      const int firstDirty = cm ? __builtin_ctzll(cm) : 64;
+      // (a workgroup that finds itself with a long tail takes the map update's issue priority back, see MERGE_P2_BOOST)
+      if (MERGE_P2_BOOST > 0 && firstDirty < 64 && __popcll(pendm >> firstDirty) >= MERGE_P2_BOOST) __builtin_amdgcn_s_setprio(MERGE_P2_BOOST_PRIO);
+      const bool commitNow = pendLane && lane < firstDirty && ((alivem >> lane) & 1ull) && nAbs > 0;
+      if (commitNow) {
+        for (int k = 0; k < nAbs; k++) sRad[sSpec[lane * 8 + k]] = -1.f;
+      }
+      commit |= __ballot(commitNow);
+#ifdef RFS_PROFILE
+      dbgRows += __popcll(alivem & ((firstDirty < 64) ? ((1ull << firstDirty) - 1ull) : ~0ull));
+#endif
+      if (firstDirty >= 64) break;                 // every pending row was clean: the round is done
+      wave_sync();
+      // lane firstDirty is alive and every row before it is final
+      pendLane = pendLane && lane >= firstDirty;
+      if ((__ballot(ovf) >> firstDirty) & 1ull) {
+        seq_replay(__builtin_amdgcn_readlane(a, firstDirty));   // the row could not be finished from its list: the reference's scan, exactly
+        if (lane == firstDirty) pendLane = false;
+      }
+      if (pendLane && sRad[a] < 0.f) pendLane = false;   // absorbed by a row that is final: the row no longer exists
+      bool stale = false;
+      if (pendLane)
+        for (int k = 0; k < nAbs; k++) stale |= sRad[sSpec[lane * 8 + k]] < 0.f;
+#ifdef RFS_PROFILE
+      const long long rw0 = (long long)__builtin_readcyclecounter();
+      dbgRewalks += __popcll(__ballot(stale));
+#endif
+      if (stale) walk();                            // every earlier row's holes are visible; rows that overlap a PENDING row come round again
+#ifdef RFS_PROFILE
+      dbgRewalkCycles += (long long)__builtin_readcyclecounter() - rw0;
+#endif
+      if (__ballot(pendLane) == 0ull) break;
+      for (int m = lane; m < N; m += 64) sRec[m] |= MERGE_REC_NOCLAIM;   // claims are per sub-round
+      wave_sync();
+    }
+#else
     // claims: the lane in the top bits of the record of every entry a lane absorbed (lowest lane wins)
     for (int k = 0; k < nAbs; k++) {
       const unsigned e = sSpec[lane * 8 + k];
@@ -705,10 +801,6 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
     }
 #endif
     const int firstDirty = cm ? __builtin_ctzll(cm) : 64;
-#ifndef MERGE_P2_BOOST
-#define MERGE_P2_BOOST 22       // rows left to validate one by one from which the workgroup's issue priority goes up (0: never)
-#define MERGE_P2_BOOST_PRIO 2
-#endif
     // A launch ends with its slowest workgroups, and those are the particles whose replay validates many rows one by one (the replay's
     // length explains 0.92 of the merge phase's spread, tools/tail_study.py; a particle is slow launch after launch).  The replay runs at
     // the lowest issue priority (step_fused.h); a workgroup that finds itself with a long serial tail takes the map update's level back.
@@ -728,6 +820,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
       if (sRad[al] < 0.f) continue;  // absorbed by an earlier row of this round: the row no longer exists
 #ifdef RFS_PROFILE
       dbgRows++;
+      dbgSerial++;
 #endif
       const int nl = __builtin_amdgcn_readlane(nAbs, l);
       const bool ovl = (__ballot(ovf) >> l) & 1ull;
@@ -739,8 +832,15 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
       } else if (__ballot(taken) != 0ull) {
         // An entry this row absorbed is gone.  Every earlier row is final now, so the row's own walk, redone by its
         // lane against the present liveness, is final too (unless it outgrows its list: then the full scan).
+#ifdef RFS_PROFILE
+        const long long rw0 = (long long)__builtin_readcyclecounter();
+#endif
         if (lane == l) walk();
         wave_sync();
+#ifdef RFS_PROFILE
+        dbgRewalks++;
+        dbgRewalkCycles += (long long)__builtin_readcyclecounter() - rw0;
+#endif
         if ((__ballot(ovf) >> l) & 1ull) {
           seq_replay(al);
         } else {
@@ -755,6 +855,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
         wave_sync();
       }
     }
+#endif
     if ((commit >> lane) & 1ull) {  // committed rows publish their merged state
       anyMerge = true;
       sW[a] = aw;
@@ -898,7 +999,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
 #ifdef RFS_PROFILE
   if (B.dbg && tid == 0) {
     long long *d = B.dbg + 64 + 4 * (size_t)i;
-    d[0] = (long long)__builtin_readcyclecounter() - dbgT0; d[1] = dbgT3 - dbgT2; d[2] = dbgFallbacks | (dbgSlackN << 8) | (dbgUnlistN << 16); atomicAdd((unsigned long long *)&d[3], (unsigned long long)N | ((unsigned long long)min(dbgPairs, 65535u) << 16));
+    d[0] = (long long)__builtin_readcyclecounter() - dbgT0; d[1] = dbgT3 - dbgT2; d[2] = (long long)(dbgFallbacks | (dbgSlackN << 8) | (dbgUnlistN << 16)) | ((long long)min(dbgSerial, 255) << 24) | ((long long)min(dbgRewalks, 255) << 32) | (min(dbgRewalkCycles, 0xfffffll) << 40); atomicAdd((unsigned long long *)&d[3], (unsigned long long)N | ((unsigned long long)min(dbgPairs, 65535u) << 16));
   }
 #endif
 }

@@ -1099,15 +1099,20 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
     const int phasePrio = (long long)perCU * f->nCU >= f->N ? 1 : 0;
     f->lastStepVariant[0] = wpp; f->lastStepVariant[1] = phasePrio; f->lastStepVariant[2] = 5; f->lastStepVariant[3] = sp.mode ? 2 : (sp.inMask ? 3 : 1);   // ([3]: 1 = fused step, 2 = with the predict at its head, 3 = with the input pull only)
     // (one instantiation per {waves per particle, phase priorities, merge grid} x {plain step, step with the predict at its head})
+    // cost-ordered launch for the instantiations without phase priorities (several rounds of workgroups; step_fused.h StepLaunchOrder)
+    if ((rc = vp_order_buffers(f)) != RFSGPU_OK) return rc;
+    const StepLaunchOrder sloOn{f->vpOrderMode ? f->vpCost : nullptr, f->vpOrderMode ? f->vpOrder : nullptr}, sloOff{nullptr, nullptr};
+    bool orderedLaunch = false;
 #define STEP_LAUNCH(WPPV, PRIO, GLV, BYTES)                                                                                            \
     do {                                                                                                                                \
       if (sp.mode || sp.inMask) {                                                                                                        \
         if ((rc = set_lds(f, (phd_step_fused_kernel<WPPV, PRIO, GLV, true>), BYTES)) != RFSGPU_OK) return rc;                           \
-        phd_step_fused_kernel<WPPV, PRIO, GLV, true><<<f->N, WPPV * 64, BYTES, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za, sp);  \
+        phd_step_fused_kernel<WPPV, PRIO, GLV, true><<<f->N, WPPV * 64, BYTES, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za, sp, PRIO ? sloOff : sloOn);  \
       } else {                                                                                                                          \
         if ((rc = set_lds(f, (phd_step_fused_kernel<WPPV, PRIO, GLV, false>), BYTES)) != RFSGPU_OK) return rc;                          \
-        phd_step_fused_kernel<WPPV, PRIO, GLV, false><<<f->N, WPPV * 64, BYTES, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za, sp); \
+        phd_step_fused_kernel<WPPV, PRIO, GLV, false><<<f->N, WPPV * 64, BYTES, f->stream>>>(f->B, f->P, f->cur, f->nZ, ec, useW, f->Q, za, sp, PRIO ? sloOff : sloOn); \
       }                                                                                                                                 \
+      orderedLaunch = !(PRIO);                                                                                                          \
     } while (0)
     if (wpp == 2) {
       if (phasePrio) STEP_LAUNCH(2, true, 5, b);
@@ -1132,7 +1137,10 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
     HIPCHK(hipGetLastError());
     if (timed) HIPCHK(hipEventRecord(e[3], f->stream));
     if (waitBeforePost) HIPCHK(hipStreamWaitEvent(f->stream, waitBeforePost, 0));   // (the collective that produced so.preDiv, on another stream)
-    if (murty_launch(f->Q, f->MS, f->B, f->stream, with_sums ? f->dSums : nullptr, normalize, &za, 2 * n_z, f->hJobCount, so) != 0) return fail(f, RFSGPU_ERR_HIP, "post kernel launch failed");
+    const bool sortCosts = orderedLaunch && f->vpOrderMode == 2;
+    const StepOrderArg sord{sortCosts ? f->vpCost : nullptr, f->vpOrder, f->N, f->vpCost + f->Ncap, f->vpParity};
+    if (sortCosts) f->vpParity ^= 1;
+    if (murty_launch(f->Q, f->MS, f->B, f->stream, with_sums ? f->dSums : nullptr, normalize, &za, 2 * n_z, f->hJobCount, so, sord) != 0) return fail(f, RFSGPU_ERR_HIP, "post kernel launch failed");
     if (timed) HIPCHK(hipEventRecord(e[1], f->stream));
     f->cur ^= 1;  // the map update works in place, the weighting phase leaves only a permutation in LDS, merge + prune write the other slab
     if (timed) {
@@ -1314,7 +1322,7 @@ int rfsgpu_collective_probe(rfsgpu_filter *f, void *hip_stream, int *side_by_sid
   return RFSGPU_OK;
 }
 
-// Buffers of the Victoria Park step's cost-ordered launch, created with the first fused step: durations (zero) and the identity order.
+// Buffers of the fused step's cost-ordered launch (Victoria Park step; 2-D step when its workgroups are not all resident), created with the first fused step: durations (zero) and the identity order.
 __global__ void iota_kernel(int *p, int n) { const int k = blockIdx.x * blockDim.x + threadIdx.x; if (k < n) p[k] = k; }
 static int vp_order_buffers(rfsgpu_filter *f) {
   if (f->vpCost && f->vpOrder && f->vpOrderN == f->N) return RFSGPU_OK;
@@ -1330,10 +1338,9 @@ static int vp_order_buffers(rfsgpu_filter *f) {
 // [bench] / [test] The Victoria Park step's launch order.  mode 0: slot == particle; 1: order_in (slot -> particle, a permutation of 0..N-1),
 // frozen; 2: re-sorted by every step's post kernel from that step's durations, longest first (the default).  cost_out (N floats, may be
 // null): the last step's duration per particle, 100 MHz ticks.
-int rfsgpu_vp_launch_order(rfsgpu_filter *f, int mode, const int *order_in, float *cost_out) {
+int rfsgpu_step_launch_order(rfsgpu_filter *f, int mode, const int *order_in, float *cost_out) {
   CHECK_HANDLE(f);
-  if (f->D != 3) return fail(f, RFSGPU_ERR_INVALID, "vp_launch_order: Victoria Park model only");
-  if (mode < 0 || mode > 2 || (mode == 1 && !order_in)) return fail(f, RFSGPU_ERR_INVALID, "vp_launch_order: mode 0, 1 (with an order) or 2");
+  if (mode < 0 || mode > 2 || (mode == 1 && !order_in)) return fail(f, RFSGPU_ERR_INVALID, "step_launch_order: mode 0, 1 (with an order) or 2");
   hipSetDevice(f->device);
   int rc = vp_order_buffers(f);
   if (rc != RFSGPU_OK) return rc;
@@ -1341,7 +1348,7 @@ int rfsgpu_vp_launch_order(rfsgpu_filter *f, int mode, const int *order_in, floa
   if (cost_out) HIPCHK(hipMemcpy(cost_out, f->vpCost, (size_t)f->N * sizeof(float), hipMemcpyDeviceToHost));
   if (mode == 1) {
     std::vector<char> seen((size_t)f->N, 0);
-    for (int k = 0; k < f->N; k++) { const int p = order_in[k]; if (p < 0 || p >= f->N || seen[p]) return fail(f, RFSGPU_ERR_INVALID, "vp_launch_order: not a permutation"); seen[p] = 1; }
+    for (int k = 0; k < f->N; k++) { const int p = order_in[k]; if (p < 0 || p >= f->N || seen[p]) return fail(f, RFSGPU_ERR_INVALID, "step_launch_order: not a permutation"); seen[p] = 1; }
     HIPCHK(hipMemcpy(f->vpOrder, order_in, (size_t)f->N * sizeof(int), hipMemcpyHostToDevice));
   }
   f->vpOrderMode = mode;

@@ -32,6 +32,13 @@ struct StepPredict {
   const double *inPacked;
   int inMask;
 };
+// Cost-ordered launch (round 6; murty.h step_cost_order_class): only the instantiations WITHOUT phase priorities use it -- those are the
+// launches whose workgroups are not all resident at once, where the last round's length is that of whatever started last.  The
+// all-resident instantiations (configs[1]'s headline among them) ignore the argument: same code as without it.
+struct StepLaunchOrder {
+  float *cost;        // [N] this step's duration per particle (100 MHz ticks), or nullptr
+  const int *order;   // [N] launch slot -> particle, or nullptr: slot == particle
+};
 // (Measured and dropped, round 5 -- profiles/r05b_*: the step's POST work by the last workgroup of this kernel to finish (a ticket,
 //  weights re-stored write-through, results to the pinned landing area) instead of the post kernel's launch, for filters without
 //  Murty work: the launch, the queue hand-over and the post kernel it saves cost what the ticket and the delivery cost here --
@@ -61,11 +68,17 @@ __host__ __device__ inline size_t step_fused_lds_total(int cap, int evalCap, int
 // the head as a real call with its own register allocation: C2b 0.112 -> 0.208 ms per cycle, profiles/r05a_*).
 template <int WPP, bool PHASE_PRIO, int GL = 5, bool PRED = false>
 __global__ __launch_bounds__(WPP * 64) __attribute__((amdgpu_waves_per_eu(STEP_WAVES_PER_EU)))
-void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, int useWeighting, MurtyQueue Q, ZArg zarg, StepPredict SP) {
+void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, int useWeighting, MurtyQueue Q, ZArg zarg, StepPredict SP,
+                           StepLaunchOrder SLO) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int i = blockIdx.x;
+  int i = blockIdx.x;
+  unsigned long long tStart = 0ull;
+  if constexpr (!PHASE_PRIO) {
+    if (SLO.order) i = SLO.order[blockIdx.x];      // (workgroup-uniform: a scalar load)
+    if (SLO.cost) tStart = wall_clock64();
+  }
   // Round 5: the map part of the PREDICT that precedes this update (RBPHDFilter::predict, include/RBPHDFilter.hpp:415-442 -- birth
   // Gaussians from the previous update's unused measurements at the poses that update used, then Sigma += Q on every Gaussian,
   // include/ProcessModel.hpp:195-208) runs at the head of the step, by the workgroup that owns the particle: one launch chain per
@@ -145,4 +158,7 @@ void phd_step_fused_kernel(Buffers B, Params P, int cur, int nZ, int evalCap, in
 #ifdef RFS_PROFILE
   if (fd && tid == 0) fd[3] = (long long)wall_clock64();
 #endif
+  if constexpr (!PHASE_PRIO) {
+    if (SLO.cost && threadIdx.x == 0) SLO.cost[i] = (float)(wall_clock64() - tStart);
+  }
 }

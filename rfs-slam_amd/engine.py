@@ -158,13 +158,13 @@ class RBPHDFilter(capi.CFilter):
         fn.restype = C.c_double
         return float(fn(self._h))
 
-    def vp_launch_order(self, order=None, mode=None, want_costs=True):
-        """rfsgpu_vp_launch_order: the last Victoria Park step's per-particle durations (ticks) out; launch order in: `order` (slot ->
+    def step_launch_order(self, order=None, mode=None, want_costs=True):
+        """rfsgpu_step_launch_order: the last Victoria Park step's per-particle durations (ticks) out; launch order in: `order` (slot ->
         particle, frozen: mode 1), or mode 0 (slot == particle) / mode 2 (re-sorted by every step's post kernel, the default)."""
         cost = np.zeros(self.n, dtype=np.float32) if want_costs else None
         o = None if order is None else np.ascontiguousarray(order, dtype=np.int32)
         m = 1 if order is not None else (2 if mode is None else int(mode))
-        self._call("vp_launch_order", C.c_int(m), None if o is None else o.ctypes.data_as(C.c_void_p),
+        self._call("step_launch_order", C.c_int(m), None if o is None else o.ctypes.data_as(C.c_void_p),
                    None if cost is None else cost.ctypes.data_as(C.c_void_p))
         return cost
 

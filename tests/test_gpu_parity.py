@@ -1446,7 +1446,7 @@ def test_vp_step_results_do_not_depend_on_the_launch_order(pkg, sc, n_particles,
     for name, mode, order in orders:
         f = pkg.RBPHDFilter(n, gm_capacity=256, model=pkg.capi.MODEL_VICTORIAPARK_3D)
         sc.load_scenario(f, scen)
-        f.vp_launch_order(order=order, mode=mode, want_costs=False)
+        f.step_launch_order(order=order, mode=mode, want_costs=False)
         fs.append(f)
     zr = np.random.default_rng(8)
     for step in range(4):
@@ -1464,12 +1464,56 @@ def test_vp_step_results_do_not_depend_on_the_launch_order(pkg, sc, n_particles,
                 assert list(a.get_unused(i)) == list(b.get_unused(i)) and a.landmarks_in_fov(i) == b.landmarks_in_fov(i)
         for f in fs:
             s_ = f.weight_sums(); f.normalize_weights(s_[0])
-    cost = fs[1].vp_launch_order(mode=2)
+    cost = fs[1].step_launch_order(mode=2)
     assert cost.shape == (n,) and np.all(cost > 0) and np.all(np.isfinite(cost))
     with pytest.raises(RuntimeError):
-        fs[1].vp_launch_order(order=np.zeros(n, dtype=np.int32))
+        fs[1].step_launch_order(order=np.zeros(n, dtype=np.int32))
     for f in fs:
         f.close()
+
+
+def test_2d_step_results_do_not_depend_on_the_launch_order(pkg, sc):
+    """The 2-D fused step takes the cost-ordered launch where its workgroups are not all resident at once (the instantiations without
+    phase priorities, csrc/step_fused.h StepLaunchOrder): 3000 particles at capacity 384 are such a launch (2048 two-wave workgroups
+    resident).  Same bits with slot == particle, the automatic order and a random frozen one, over predict / update steps; the
+    all-resident launch (300 particles) ignores the order and reports no durations."""
+    scen = sc.make_scenario(3000, 60, 10, seed=314)
+    n = 3000
+    rng = np.random.default_rng(5)
+    orders = [("off", 0, None), ("auto", 2, None), ("random", 1, rng.permutation(n))]
+    fs = []
+    for name, mode, order in orders:
+        f = pkg.RBPHDFilter(n, gm_capacity=384)
+        sc.load_scenario(f, scen)
+        f.step_launch_order(order=order, mode=mode, want_costs=False)
+        fs.append(f)
+    zr = np.random.default_rng(9)
+    for step in range(4):
+        Z = scen["Z"] + zr.normal(0, 1, scen["Z"].shape) * np.array([0.05, 0.002])
+        for f in fs:
+            f.predict_map(True)
+            f.update(Z)
+        assert fs[0].last_step_variant()[1] == 0, "this launch was meant to run without phase priorities"
+        a = fs[0]
+        for (name, _, _), b in zip(orders[1:], fs[1:]):
+            assert np.array_equal(a.get_weights(), b.get_weights()), (name, step)
+            assert np.array_equal(a.gm_sizes(), b.gm_sizes()), (name, step)
+            for i in range(0, n, 61):
+                for x, y in zip(a.export_gm(i), b.export_gm(i)):
+                    assert np.array_equal(x, y), (name, step, i)
+                assert list(a.get_unused(i)) == list(b.get_unused(i))
+        for f in fs:
+            s_ = f.weight_sums(); f.normalize_weights(s_[0])
+    cost = fs[1].step_launch_order(mode=2)
+    assert np.all(cost > 0) and np.all(np.isfinite(cost))
+    for f in fs:
+        f.close()
+    small = sc.make_scenario(300, 60, 10, seed=315)
+    f = pkg.RBPHDFilter(300, gm_capacity=384)
+    sc.load_scenario(f, small)
+    f.update(small["Z"])
+    assert f.last_step_variant()[1] == 1 and not np.any(f.step_launch_order(mode=2))
+    f.close()
 
 
 @pytest.mark.parametrize("kw", [dict(n_particles=40, n_landmarks=45, n_z=12, seed=91), dict(n_particles=33, n_landmarks=130, n_z=18, seed=92),

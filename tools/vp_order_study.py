@@ -32,17 +32,17 @@ def timed(steps=60):
     return ka[0] / 1e3
 
 
-f.vp_launch_order(mode=0)           # slot == particle
+f.step_launch_order(mode=0)           # slot == particle
 base = timed()
-cost = f.vp_launch_order(mode=0)
+cost = f.step_launch_order(mode=0)
 print("identity order: fused kernel %.1f us; per-particle ticks p50 %.0f p90 %.0f max %.0f" % (base, np.percentile(cost, 50), np.percentile(cost, 90), cost.max()))
 for name, order in (("longest first", np.argsort(-cost, kind="stable")), ("shortest first", np.argsort(cost, kind="stable")),
                     ("8 classes, longest first", np.argsort(-np.digitize(cost, np.quantile(cost, np.linspace(0, 1, 9)[1:-1])), kind="stable"))):
-    f.vp_launch_order(order.astype(np.int32))
+    f.step_launch_order(order.astype(np.int32))
     t = timed()
-    c2 = f.vp_launch_order(order.astype(np.int32))
+    c2 = f.step_launch_order(order.astype(np.int32))
     print("%-26s fused kernel %.1f us (%+.1f %%); correlation of the durations with the identity run's %.3f" % (name, t, 100 * (t / base - 1), np.corrcoef(cost, c2)[0, 1]))
-f.vp_launch_order(mode=0, want_costs=False)
+f.step_launch_order(mode=0, want_costs=False)
 print("identity again: %.1f us" % timed())
-f.vp_launch_order(mode=2, want_costs=False)
+f.step_launch_order(mode=2, want_costs=False)
 print("automatic (every post kernel sorts its step's durations into %d classes): %.1f us" % (32, timed()))
