@@ -51,6 +51,9 @@ __host__ __device__ inline size_t merge_lds_bytes_per_wave(int cap, int gridLog 
 // passes the exact test against the initial states | [23:20] number of listed survivors (15 = not listable) |
 // [19:0] offset of the row's contiguous segment in the pair list.
 #define MERGE_REC_NOCLAIM 0xfe000000u
+#ifndef MERGE_WALK_PREFETCH
+#define MERGE_WALK_PREFETCH 1     // the replay's walk requests the next partner's operands before it merges the present one
+#endif
 #ifndef MERGE_VALIDATE_ROUNDS
 #define MERGE_VALIDATE_ROUNDS 1   // phase 2 validates in sub-rounds (0: rows after the first conflict one by one, the form of rounds 2-5)
 #endif
@@ -613,6 +616,41 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
         float shift = 0.f;
         bool changed = false;
         double a00 = 0, a01 = 0, a11 = 0;
+#if MERGE_WALK_PREFETCH
+        // The partner this step works on was picked -- and its operands requested -- during the step before: while the row is in its
+        // initial state the lowest listed partner that PASSED in phase 1b (the others change nothing), from its first merge on the
+        // lowest listed one above the last.  A step that is worked on at all leaves the row changed or finds it so, hence the partner
+        // after it is always "the lowest listed above it": its loads (L2 hits, ~700 cycles with the SIMDs as empty as this phase leaves
+        // them) are in flight during the five divisions of the merge instead of after them.
+        auto pick = [&](const unsigned above, const bool passOnly) -> unsigned {
+          unsigned best = 0xffffffffu;
+#pragma unroll
+          for (int k = 0; k < MERGE_ROW_SLOTS; k++) {
+            const unsigned j = it[k] & 0x3fffu;
+            const bool c = (it[k] != 0xffffffffu) & (j > above) & (!passOnly | ((it[k] & 0x8000u) != 0u)) & (j < (best & 0x3fffu) || best == 0xffffffffu);
+            best = c ? it[k] : best;
+          }
+          return best;
+        };
+        unsigned nb = pick((unsigned)a, true);
+        double njw = 0, njx = 0, njy = 0, njxx = 1, njxy = 0, njyy = 1;
+        auto fetch = [&]() {
+          if (nb != 0xffffffffu) {
+            const unsigned j = nb & 0x3fffu;
+            const int pj = phys((int)j);
+            njw = sW[j]; njx = pMX[pj]; njy = pMY[pj];
+            njxx = pSXX[pj]; njxy = pSXY[pj]; njyy = pSYY[pj];
+          }
+        };
+        fetch();
+        for (int step = 0; step < MERGE_ROW_SLOTS; step++) {
+          if (nb == 0xffffffffu) break;
+          const unsigned j = nb & 0x3fffu;
+          const double jw = njw, jx = njx, jy = njy, jxx = njxx, jxy = njxy, jyy = njyy;
+          nb = pick(j, false);
+          fetch();
+          bool pass = true;                    // (initial state: picked because it passed)
+#else
         unsigned cur = (unsigned)a;
         for (int step = 0; step < MERGE_ROW_SLOTS; step++) {
           // lowest listed partner above `cur`
@@ -631,6 +669,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
           const int pj = phys((int)j);
           const double jw = sW[j], jx = pMX[pj], jy = pMY[pj];
           const double jxx = pSXX[pj], jxy = pSXY[pj], jyy = pSYY[pj];
+#endif
           if (changed) {
             const double e0 = jx - ax, e1 = jy - ay;
             const double u0 = e0 * a00 + e1 * a01, u1 = e0 * a01 + e1 * a11;
