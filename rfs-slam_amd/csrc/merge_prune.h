@@ -152,7 +152,8 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
   const long long dbgT0 = (long long)__builtin_readcyclecounter();
   long long dbgT2 = 0, dbgT3 = 0;
   int dbgFallbacks = 0, dbgSlackN = 0, dbgUnlistN = 0, dbgSerial = 0, dbgRewalks = 0;
-  long long dbgRewalkCycles = 0;
+  long long dbgRewalkCycles = 0, dbgWalk1 = 0;
+  int dbgRoundsN = 0;
   unsigned dbgPairs = 0;
   if (B.dbg && tid == 0) B.dbg[64 + 4 * (size_t)i + 3] = 0;
   __syncthreads();
@@ -706,8 +707,15 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
         }
       }
     };
+#ifdef RFS_PROFILE
+    const long long wk0 = (long long)__builtin_readcyclecounter();
+#endif
     if (active) walk();
     wave_sync();
+#ifdef RFS_PROFILE
+    dbgWalk1 += (long long)__builtin_readcyclecounter() - wk0;
+    dbgRoundsN++;
+#endif
 #ifndef MERGE_P2_BOOST
 #define MERGE_P2_BOOST 22       // rows left to validate one by one from which the workgroup's issue priority goes up (0: never)
 #define MERGE_P2_BOOST_PRIO 2
@@ -1038,7 +1046,7 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
 #ifdef RFS_PROFILE
   if (B.dbg && tid == 0) {
     long long *d = B.dbg + 64 + 4 * (size_t)i;
-    d[0] = (long long)__builtin_readcyclecounter() - dbgT0; d[1] = dbgT3 - dbgT2; d[2] = (long long)(dbgFallbacks | (dbgSlackN << 8) | (dbgUnlistN << 16)) | ((long long)min(dbgSerial, 255) << 24) | ((long long)min(dbgRewalks, 255) << 32) | (min(dbgRewalkCycles, 0xfffffll) << 40); atomicAdd((unsigned long long *)&d[3], (unsigned long long)N | ((unsigned long long)min(dbgPairs, 65535u) << 16));
+    d[0] = (long long)__builtin_readcyclecounter() - dbgT0; d[1] = ((dbgT3 - dbgT2) & 0xffffffll) | ((dbgWalk1 & 0xffffffll) << 24) | ((long long)dbgRoundsN << 48); d[2] = (long long)(dbgFallbacks | (dbgSlackN << 8) | (dbgUnlistN << 16)) | ((long long)min(dbgSerial, 255) << 24) | ((long long)min(dbgRewalks, 255) << 32) | (min(dbgRewalkCycles, 0xfffffll) << 40); atomicAdd((unsigned long long *)&d[3], (unsigned long long)N | ((unsigned long long)min(dbgPairs, 65535u) << 16));
   }
 #endif
 }

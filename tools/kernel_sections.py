@@ -61,11 +61,13 @@ import numpy as np
 pp = (C.c_longlong * (4 * n))()
 if lib.rfsgpu_debug_per_particle(f._h, pp) == 0:
     a = np.frombuffer(pp, dtype=np.int64).reshape(n, 4)
-    tot, p2, fb, nn = a[:, 0], a[:, 1], a[:, 2] & 255, a[:, 3]
+    tot, p2, fb, nn = a[:, 0], a[:, 1] & 0xffffff, a[:, 2] & 255, a[:, 3]
+    walk1, rounds = (a[:, 1] >> 24) & 0xffffff, a[:, 1] >> 48
     print("merge per particle: slack-type rows mean %.2f max %d; unlistable rows mean %.2f max %d" % (((a[:, 2] >> 8) & 255).mean(), ((a[:, 2] >> 8) & 255).max(), ((a[:, 2] >> 16) & 255).mean(), ((a[:, 2] >> 16) & 255).max()))
     q = lambda v: "min %d p50 %d p90 %d p99 %d max %d" % (v.min(), np.percentile(v, 50), np.percentile(v, 90), np.percentile(v, 99), v.max())
     print("merge per particle: total cycles", q(tot))
     print("merge per particle: phase-2 cycles", q(p2))
+    print("merge per particle: rounds of 64 rows", q(rounds), "; cycles in the rounds' first walks", q(walk1))
     print("merge per particle: sequential fallbacks", q(fb), "mean %.2f" % fb.mean())
     print("merge per particle: rows validated one by one", q((a[:, 2] >> 24) & 255), "; re-walked", q((a[:, 2] >> 32) & 255), "; cycles in re-walks", q((a[:, 2] >> 40) & 0xfffff))
     print("merge per particle: N", q(nn & 0xffff))
