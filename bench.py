@@ -784,8 +784,9 @@ def main():
     f.kernel_time_stats()            # discard the warm-up statistics
     # The kernel durations behind `roofline` come from HIP events on the engine's stream inside the timed region.  Three event
     # records per step cost a C2a step 8 us of its 144 (each is a marker packet the queue drains before the next kernel
-    # starts), so they ride on every 8th step only (every (K // 4)-th for K < 32 steps); the statistics average over those.
-    timing_stride = min(8, max(1, args.steps // 4))
+    # starts), so they ride on a few steps only -- four of K < 64 steps, six of a longer run (every 8th until round 6: 1 us per step of
+    # the default run); the statistics average over those, and the kernel's spread from launch to launch is ~1 %.
+    timing_stride = max(1, -(-args.steps // (4 if args.steps < 64 else 6)))
     f.set_step_timing_stride(timing_stride)
     if multi:
         dist.barrier()

@@ -58,6 +58,8 @@ else:
     env = dict(os.environ, TMPDIR="/tmp")
     rows = []
     for k, label in CUTS:
+        if not os.path.exists(lib_of(k)):      # (a subset of the cut libraries was built)
+            continue
         d = f"/tmp/cutprof/{k}"
         agg = {}
         for n, ctrs in enumerate((["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES"], ["SQ_ACTIVE_INST_VALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_BUSY_CYCLES"])):
