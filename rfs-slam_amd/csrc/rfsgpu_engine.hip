@@ -1096,7 +1096,9 @@ static int update_async_impl(rfsgpu_filter *f, const double *z, int n_z, bool wi
     const size_t b = step_fused_lds_total(f->cap, ec, f->nZ, wpp);
     // phase priorities only when every workgroup is resident at once: 16 waves per CU at 128 VGPRs, LDS permitting
     const int perCU = (int)std::min<size_t>(16 / wpp, b ? (size_t)(160 * 1024) / b : 16);
-    const int phasePrio = (long long)perCU * f->nCU >= f->N ? 1 : 0;
+    // (RFSGPU_STEP_PHASE_PRIO = 0 | 1: tuning override of the choice below)
+    static const int prioOverride = [] { const char *e = getenv("RFSGPU_STEP_PHASE_PRIO"); return e ? atoi(e) : -1; }();
+    const int phasePrio = prioOverride >= 0 ? (prioOverride ? 1 : 0) : ((long long)perCU * f->nCU >= f->N ? 1 : 0);
     f->lastStepVariant[0] = wpp; f->lastStepVariant[1] = phasePrio; f->lastStepVariant[2] = 5; f->lastStepVariant[3] = sp.mode ? 2 : (sp.inMask ? 3 : 1);   // ([3]: 1 = fused step, 2 = with the predict at its head, 3 = with the input pull only)
     // (one instantiation per {waves per particle, phase priorities, merge grid} x {plain step, step with the predict at its head})
     // cost-ordered launch for the instantiations without phase priorities (several rounds of workgroups; step_fused.h StepLaunchOrder)
