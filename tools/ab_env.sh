@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/_ab_env.sh VAR "v1 v2 ..." [bench args]   -- bench.py under VAR=v for every v, one line each
+# usage: tools/ab_env.sh VAR "v1 v2 ..." [bench args]   -- bench.py under VAR=v for every v, one line each
 VAR=$1; VALS=$2; shift 2
 for v in $VALS; do
   env $VAR=$v python bench.py --no-cpu-baseline --no-boundary --no-pmc "$@" 2>/dev/null | python -c "
