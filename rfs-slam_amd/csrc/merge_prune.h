@@ -473,9 +473,10 @@ __device__ __forceinline__ void gm_merge_particle(const Buffers &B, const Params
   // would; before the row's first merge the verdicts of phase 1b are reused.  A row only reads entries with a higher
   // index, and an entry's mean/covariance change only while it is the outer row, so the sole cross-row hazard is an
   // entry absorbed by an EARLIER row of the same round.  Rows are therefore validated in ascending order: a row that
-  // was itself absorbed is dropped; a row that absorbed an entry already taken is replayed again, sequentially by the
-  // whole wave (the reference's own scan), with the committed holes visible; everything else commits as computed.
-  // A row that outgrows its slack (unlisted entries might start passing) also goes to the sequential scan.
+  // was itself absorbed is dropped; a row that absorbed an entry already taken walks again with the committed holes
+  // visible (round 6: all such rows at once, in sub-rounds -- see MERGE_VALIDATE_ROUNDS below; rounds 2-5: one by one);
+  // everything else commits as computed.  A row that outgrows its slack (unlisted entries might start passing) or its
+  // list goes to the sequential scan by the whole wave (the reference's own scan).
   bool anyMerge = false;
 #ifdef RFS_PROFILE
   int dbgRows = 0, dbgMerges = 0, dbgChunks = 0;

@@ -69,7 +69,7 @@ if lib.rfsgpu_debug_per_particle(f._h, pp) == 0:
     print("merge per particle: phase-2 cycles", q(p2))
     print("merge per particle: rounds of 64 rows", q(rounds), "; cycles in the rounds' first walks", q(walk1))
     print("merge per particle: sequential fallbacks", q(fb), "mean %.2f" % fb.mean())
-    print("merge per particle: rows validated one by one", q((a[:, 2] >> 24) & 255), "; re-walked", q((a[:, 2] >> 32) & 255), "; cycles in re-walks", q((a[:, 2] >> 40) & 0xfffff))
+    print("merge per particle: validation sub-rounds (-DMERGE_VALIDATE_ROUNDS=0: rows validated one by one)", q((a[:, 2] >> 24) & 255), "; re-walked", q((a[:, 2] >> 32) & 255), "; cycles in re-walks", q((a[:, 2] >> 40) & 0xfffff))
     print("merge per particle: N", q(nn & 0xffff))
     print("merge per particle: listed pairs", q((nn >> 16) & 0xffff))
     print("merge per particle: near-failing neighbours", q(nn >> 32))
