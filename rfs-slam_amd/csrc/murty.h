@@ -1121,9 +1121,6 @@ __device__ __forceinline__ void step_post_out(const double *weight, int N, int *
 #endif
 #define STEP_ORDER_QUADS 8         // 16-byte loads a thread has in flight at a time (a round: 32 durations)
 #define STEP_ORDER_MAX_ROUNDS 2    // (a bit per particle in one 64-bit word: n <= 64 x blockDim, else the order is left as it is)
-#ifndef STEP_ORDER_STOP
-#define STEP_ORDER_STOP 9          // (tuning hook: 0 nothing | 1 the pass, no barrier | 2 all but the order's stores)
-#endif
 struct StepOrderArg {
   const float *cost;   // [n] ticks per particle, written by the step kernel (nullptr: no ordering)
   int *order;          // [n] launch slot -> particle, read by the next step kernel
@@ -1137,7 +1134,7 @@ __device__ __forceinline__ void step_cost_order_class(const StepOrderArg &O, con
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
   constexpr int PER_ROUND = 4 * STEP_ORDER_QUADS;
   const int rounds = (O.n + nt * PER_ROUND - 1) / (nt * PER_ROUND);
-  if (rounds > STEP_ORDER_MAX_ROUNDS || STEP_ORDER_STOP == 0) return;    // (block-uniform; the order array keeps the permutation it holds)
+  if (rounds > STEP_ORDER_MAX_ROUNDS) return;    // (block-uniform; the order array keeps the permutation it holds)
   if (tid == 0) { sLo = 0xffffffffu; sHi = 0u; sBase = 0; }
   __syncthreads();
   const float fLo = O.ext[2 * O.parity], fHi = O.ext[2 * O.parity + 1];
@@ -1170,7 +1167,6 @@ __device__ __forceinline__ void step_cost_order_class(const StepOrderArg &O, con
       }
     }
   }
-  if (STEP_ORDER_STOP == 1) { if (ahead + (int)mine + (int)lo + (int)hi == -12345) O.order[0] = 0; return; }
   const int aheadW = wave_sum_i(ahead), mineW = wave_sum_i(__popcll(mine));
   if (lane == 0) { if (aheadW) atomicAdd(&sBase, aheadW); sMine[wave] = mineW; }
   if (c == 0) {                                  // (block-uniform) the limits the next launch's classes use
@@ -1184,7 +1180,6 @@ __device__ __forceinline__ void step_cost_order_class(const StepOrderArg &O, con
   if (total == 0) return;
   int at = sBase + before;                       // a wavefront's members behind those of the wavefronts before it
   const int nbits = rounds * PER_ROUND;
-  if (STEP_ORDER_STOP == 2) return;
   for (int b = 0; b < nbits; b++) {
     const bool is = (mine >> b) & 1ull;
     const unsigned long long m = __ballot(is);
