@@ -775,18 +775,22 @@ def main():
         step(k)
     f.synchronize()
     ring_refill()                         # the W + K steps from here on find their inputs resident (see `reseed` above)
-    for k in range(args.warmup):
-        step(pre_warm + k)
+    # (host-side bookkeeping BEFORE the warm-up steps: nothing but a synchronisation and three cheap calls may sit between the warm-up and
+    #  the timed region -- a GPU left idle for a millisecond starts the timed region at lower clocks, which a 20-step run shows)
     bytes_sweep, bytes_step = survey_bytes(n_local, nM, nAfter - nM, nKept, N_Z, BG, DZ)
     dbytes = dict(zip(kernels, design_bytes(n_local, nM, nAfter - nM, nKept, N_Z, BG).values()))
+    for k in range(args.warmup):
+        step(pre_warm + k)
 
     f.synchronize()
     f.kernel_time_stats()            # discard the warm-up statistics
     # The kernel durations behind `roofline` come from HIP events on the engine's stream inside the timed region.  Three event
     # records per step cost a C2a step 8 us of its 144 (each is a marker packet the queue drains before the next kernel
-    # starts), so they ride on a few steps only -- four of K < 64 steps, six of a longer run (every 8th until round 6: 1 us per step of
-    # the default run); the statistics average over those, and the kernel's spread from launch to launch is ~1 %.
-    timing_stride = max(1, -(-args.steps // (4 if args.steps < 64 else 6)))
+    # starts), so they ride on a few steps only -- two of K < 64 steps, six of a longer run (every 8th until round 6: 1 us per step of
+    # the default run, 1.6 of a 20-step one -- tools/fixed_cost_probe.py: a timed region's own fixed cost is ~10 us, the rest of the
+    # difference between a 20-step and a 200-step figure was these records); the statistics average over those, and the kernel's
+    # spread from launch to launch is ~1 %.
+    timing_stride = max(1, -(-args.steps // (2 if args.steps < 64 else 6)))
     f.set_step_timing_stride(timing_stride)
     if multi:
         dist.barrier()
