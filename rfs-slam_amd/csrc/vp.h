@@ -123,7 +123,10 @@ __device__ double vp_pd2(const Params &P, const double *scan, int nScan, double 
 // looping over its own copies leaves the wave waiting for its worst landmark.  Here the (landmark, copy) evaluations of all
 // lanes are laid end to end and dealt out to the lanes; minimum and maximum (exact in any order: the values come from the
 // Pd table) are folded with LDS atomics on the bit patterns (the values are >= 0).  `ws`: VP_PD_SCRATCH_BYTES of LDS per wave.
-#define VP_PD_SCRATCH_BYTES (64 * (5 * 8 + 2 * 8) + 65 * 4 + 4 + 64 * 4)
+#ifndef VP_PD_OWN_MAX
+#define VP_PD_OWN_MAX 512      // pool items whose landmark is looked up in a byte table (0: every item by binary search over the block starts)
+#endif
+#define VP_PD_SCRATCH_BYTES (64 * (5 * 8 + 2 * 8) + 65 * 4 + 4 + 64 * 4 + VP_PD_OWN_MAX)
 __device__ double vp_pd_wave(const Params &P, const double *scan, int nScan, double px, double py, double pth, const Ent3 &e, bool act, bool &close,
                              unsigned char *ws) {
   const int lane = threadIdx.x & 63;
@@ -166,11 +169,19 @@ __device__ double vp_pd_wave(const Params &P, const double *scan, int nScan, dou
   const int total = __builtin_amdgcn_readlane(off + cnt, 63);
   pre[lane] = off;
   if (lane == 63) pre[64] = total;
+  // (round 6) the owner of the first VP_PD_OWN_MAX items from a byte table the landmarks fill: the binary search below is six
+  // DEPENDENT LDS reads per item
+  [[maybe_unused]] unsigned char *own = reinterpret_cast<unsigned char *>(lcl + 64);
+  if (VP_PD_OWN_MAX > 0)
+    for (int k = 0; k < cnt && off + k < VP_PD_OWN_MAX; k++) own[off + k] = (unsigned char)lane;
   wave_sync();
   for (int t = lane; t < total; t += 64) {
     int l = 0;                                             // owner: the last landmark whose block starts at or before t
+    if (VP_PD_OWN_MAX > 0 && t < VP_PD_OWN_MAX) l = own[t];
+    else {
 #pragma unroll
-    for (int st = 32; st >= 1; st >>= 1) l += (pre[l + st] <= t) ? st : 0;
+      for (int st = 32; st >= 1; st >>= 1) l += (pre[l + st] <= t) ? st : 0;
+    }
     const int j = t - pre[l];
     const bool self = (t + 1 == pre[l + 1]);               // the last item of a landmark's block: the landmark where it is
     const int i = (j >> 1) + 1;
